@@ -1,0 +1,165 @@
+/*
+ * scrubby_hip.h — C ABI of libscrubby_hip.so, the MI355X (gfx950) host-depletion backend.
+ *
+ * This is the drop-in boundary for the one hot path of esteinig/scrubby that this
+ * library replaces: the in-process `mm2` aligner path
+ *     Cleaner::run_minimap2_rs        /root/reference/src/cleaner.rs:443-575
+ * whose arithmetic the reference reaches through the `minimap2` crate (FFI into
+ * lh3/minimap2).  Every entry point below cites the reference interface it stands in
+ * for; INTEGRATION.md shows the Rust `extern "C"` block a Scrubby maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns an sh_status (0 = OK) and
+ *     never throws or aborts across the boundary; sh_last_error() gives the message
+ *     (thread-local), mirroring the `&'static str` errors minimap2-rs hands to
+ *     ScrubbyError::Minimap2RustAlignerBuilderFailed / Minimap2RustAlignmentFailed
+ *     (/root/reference/src/error.rs:147-152).
+ *   - the caller owns every input/output buffer; the library owns sh_index / sh_ctx.
+ *   - "_device" variants take HIP device pointers (inputs already resident in HBM) and
+ *     a hipStream_t passed as void*; the others take host pointers and stage through
+ *     HBM internally.
+ *   - a read batch is the reference's Vec<(id, Vec<u8>)> (cleaner.rs:547-549) flattened:
+ *     `bases` = concatenated ASCII sequence bytes, `offsets[n_reads+1]` = start of each
+ *     read in `bases`.  Paired-end input is simply two records per pair: the reference
+ *     maps each mate independently as single-end (cleaner.rs:499-501,527-529).
+ */
+#ifndef SCRUBBY_HIP_H
+#define SCRUBBY_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SH_VERSION 100   /* 0.1.0 */
+
+typedef int32_t sh_status;
+enum {
+    SH_OK = 0,
+    SH_ERR_BAD_ARG = 1,        /* null pointer, unsupported k/w, ... */
+    SH_ERR_PRESET_UNKNOWN = 2,
+    SH_ERR_PRESET_UNSUPPORTED = 3, /* Preset::Lr -> ScrubbyError::Minimap2PresetNotSupported (cleaner.rs:469) */
+    SH_ERR_NO_DEVICE = 4,
+    SH_ERR_OOM = 5,
+    SH_ERR_HIP = 6,
+    SH_ERR_IO = 7,
+    SH_ERR_EMPTY_READ = 8,     /* minimap2-rs: Err("Sequence is empty") -> Minimap2RustAlignmentFailed; aborts the run (cleaner.rs:552,566) */
+    SH_ERR_INDEX = 9           /* index build failed -> Minimap2RustAlignerBuilderFailed (cleaner.rs:480-482) */
+};
+
+/* Mapping options = the subset of minimap2's mm_idxopt_t/mm_mapopt_t that decides
+ * `mappings.len() > 0`; filled by sh_preset() the way Aligner::builder().sr() / .map_ont()
+ * ... fill them (cleaner.rs:455-470).  Layout is shared with the device code. */
+typedef struct sh_opts {
+    int32_t k, w;
+    int32_t is_sr;
+    int32_t mid_occ;          /* <= 0: derived from the index (mm_mapopt_update) */
+    int32_t max_occ;
+    int32_t max_max_occ;
+    int32_t occ_dist;
+    int32_t min_mid_occ, max_mid_occ;
+    float   mid_occ_frac;
+    float   q_occ_frac;
+    int32_t min_cnt, min_chain_score;
+    int32_t max_gap, max_gap_ref, max_frag_len, bw;
+    int32_t max_chain_skip, max_chain_iter;
+    float   chain_gap_scale, chain_skip_scale;
+} sh_opts;
+
+/* Per-read decision trace (optional output; used by the parity tests). */
+typedef struct sh_trace {
+    int32_t n_mini, n_seed, n_anchor, rep_len, rechained, n_chain, best_score, flag;
+} sh_trace;
+
+typedef struct sh_index_info {
+    int32_t  k, w;
+    int32_t  mid_occ;          /* resolved value (sr: 1000; map-ont: from index) */
+    uint32_t n_contigs;
+    uint64_t n_bases;
+    uint64_t n_minimizers;     /* stored (hash,pos) pairs */
+    uint64_t n_keys;           /* distinct minimizer hashes */
+    uint64_t n_slots;          /* 16-B table slots */
+    uint64_t n_positions;      /* entries of the multi-occurrence position array */
+    uint64_t hbm_bytes;        /* table + positions resident in HBM */
+    double   build_ms;
+} sh_index_info;
+
+typedef struct sh_stats {
+    uint64_t n_reads;
+    uint64_t n_host;           /* flags == 1 */
+    uint64_t n_no_seed;        /* decided by the sketch/probe kernel alone */
+    uint64_t n_chain_small;    /* reads chained in LDS (lane per read) */
+    uint64_t n_chain_large;    /* reads chained in the HBM arena */
+    uint64_t n_minimizers;     /* sum of sketch sizes = table probes issued */
+    uint64_t n_bases;
+    double   ms_sketch_probe;  /* HIP-event time of each stage, summed over chunks */
+    double   ms_chain_small;
+    double   ms_chain_large;
+    double   ms_total;         /* first kernel start -> last kernel end */
+} sh_stats;
+
+typedef struct sh_index sh_index;
+typedef struct sh_ctx sh_ctx;
+
+/* ---- library ------------------------------------------------------------------------ */
+int32_t     sh_version(void);
+int32_t     sh_device_count(void);
+const char *sh_last_error(void);
+
+/* Aligner::builder().<preset>()  (cleaner.rs:453-470); name = Preset's Display form
+ * ("sr", "map-ont", "lr:hq", ...; /root/reference/src/scrubby.rs:137-155). */
+sh_status sh_preset(const char *name, sh_opts *out);
+
+/* ---- index:  .with_index_threads(t).with_index(path, None)  (cleaner.rs:472-482) ----- */
+/* Build from host sequences (already parsed FASTA records). */
+sh_status sh_index_build(const uint8_t *const *seqs, const uint64_t *lens, uint32_t n_seq,
+                         const sh_opts *opts, int32_t device, sh_index **out);
+/* Build from a reference already resident in HBM: `d_bases` = concatenated ASCII contigs,
+ * `contig_starts[n_contigs+1]` (host array) = start of each contig in d_bases. */
+sh_status sh_index_build_device(const uint8_t *d_bases, const uint64_t *contig_starts, uint32_t n_contigs,
+                                const sh_opts *opts, int32_t device, void *stream, sh_index **out);
+/* Build from a FASTA file (plain or gzip); the reference rebuilds the index from FASTA on
+ * every run (cleaner.rs:475-479). */
+sh_status sh_index_build_fasta(const char *path, const sh_opts *opts, int32_t device, sh_index **out);
+/* Binary cache of a built index (the reference passes output=None). */
+sh_status sh_index_save(const sh_index *idx, const char *path);
+sh_status sh_index_load(const char *path, int32_t device, sh_index **out);
+sh_status sh_index_info_get(const sh_index *idx, sh_index_info *out);
+/* Copy table and position array to host (tests, CPU baseline).  Either pointer may be NULL. */
+sh_status sh_index_export(const sh_index *idx, uint64_t *slots /* 2*n_slots */, uint64_t *positions);
+sh_status sh_index_free(sh_index *idx);
+
+/* ---- classification:  aligner.map(&seq,false,false,None,None) -> len()>0  (cleaner.rs:550-558) --- */
+/* A context owns the stream-ordered scratch (seed records, work lists, chain arena) for
+ * batches of up to max_reads reads / max_bases bases; it plays the role of minimap2's
+ * thread-local mm_tbuf_t.  One context per host thread; contexts share the immutable index. */
+sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uint64_t max_reads, uint64_t max_bases,
+                        uint32_t max_read_len, sh_ctx **out);
+sh_status sh_ctx_destroy(sh_ctx *ctx);
+
+/* Inputs and outputs in HBM.  d_flags[r] = 1 host (>=1 mapping), 0 retained, 2 empty read.
+ * d_trace may be NULL.  Asynchronous on `stream`; stats (nullable) forces a stream sync. */
+sh_status sh_classify_device(sh_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                             uint64_t n_bases, uint8_t *d_flags, sh_trace *d_trace, void *stream, sh_stats *stats);
+
+/* Host buffers in, host flags out; chunks internally, overlapping copies with kernels.
+ * Returns SH_ERR_EMPTY_READ (after filling flags) if any read is empty, as the reference's
+ * per-read Err aborts the run. */
+sh_status sh_classify_batch(const sh_index *idx, const sh_opts *opts, const uint8_t *bases, const uint64_t *offsets,
+                            uint64_t n_reads, uint8_t *out_flags, sh_trace *out_trace, sh_stats *stats);
+
+/* ---- synthetic workload (bench/test utility) ---------------------------- */
+/* params structs are syn_ref_params / syn_read_params of csrc/sh_synth_core.h, passed opaquely */
+sh_status sh_synth_ref_device(const void *ref_params, uint64_t g0, uint64_t n, uint8_t *d_out, void *stream);
+sh_status sh_synth_reads_device(const void *ref_params, const void *read_params, uint64_t r0, uint64_t n_records,
+                                uint8_t *d_out, uint64_t *d_offsets /* n_records+1, may be NULL */, void *stream);
+
+/* ---- micro-benchmarks for the roofline (bench.py) ---------------------------------------- */
+/* random 16-B slot gathers over the index table; returns achieved GB/s of useful bytes */
+sh_status sh_bench_gather(const sh_index *idx, uint64_t n_probes, int32_t iters, double *out_gbs_useful, double *out_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,310 @@
+// sh_api.hip — library-level entry points of the C ABI (include/scrubby_hip.h): errors, presets,
+// host-buffer classification, index cache, synthetic workload, gather micro-benchmark.
+#include "sh_common.h"
+#include "sh_synth_core.h"
+#include <cstdarg>
+#include <algorithm>
+#include <chrono>
+
+// ---- errors ----------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void sh_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *sh_last_error(void) { return g_err; }
+extern "C" int32_t sh_version(void) { return SH_VERSION; }
+extern "C" int32_t sh_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---- presets: Aligner::builder().sr() / .map_ont() / ...  (/root/reference/src/cleaner.rs:455-470) ------
+// values: SURVEY.md App. A.1 (minimap2 mm_set_opt)
+static void opts_default(sh_opts *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->k = 15; o->w = 10; o->is_sr = 0; o->mid_occ = 0; o->max_occ = 0;
+    o->max_max_occ = 4095; o->occ_dist = 500; o->min_mid_occ = 10; o->max_mid_occ = 1000000;
+    o->mid_occ_frac = 2e-4f; o->q_occ_frac = 0.01f;
+    o->min_cnt = 3; o->min_chain_score = 40;
+    o->max_gap = 5000; o->max_gap_ref = -1; o->max_frag_len = 0; o->bw = 500;
+    o->max_chain_skip = 25; o->max_chain_iter = 5000;
+    o->chain_gap_scale = 0.8f; o->chain_skip_scale = 0.0f;
+}
+
+extern "C" sh_status sh_preset(const char *name, sh_opts *o)
+{
+    SH_CHECK(name && o, SH_ERR_BAD_ARG, "sh_preset: null argument");
+    opts_default(o);
+    std::string n(name);
+    if (n == "sr") {
+        o->k = 21; o->w = 11; o->is_sr = 1; o->max_frag_len = 800; o->max_gap = 100; o->bw = 100;
+        o->min_cnt = 2; o->min_chain_score = 25; o->mid_occ = 1000; o->max_occ = 5000;
+        return SH_OK;
+    }
+    if (n == "map-ont") { o->k = 15; o->w = 10; return SH_OK; }
+    if (n == "lr:hq") { o->k = 19; o->w = 19; o->max_gap = 10000; o->min_mid_occ = 50; o->max_mid_occ = 500; return SH_OK; }
+    if (n == "lr") {   // ScrubbyError::Minimap2PresetNotSupported(Preset::Lr), cleaner.rs:469
+        sh_set_error("Minimap2 preset not supported: lr");
+        return SH_ERR_PRESET_UNSUPPORTED;
+    }
+    static const char *later[] = {"asm", "asm5", "asm10", "asm20", "ava-ont", "ava-pb", "map-hifi", "map-pb", "splice", "splice:hq"};
+    for (const char *l : later)
+        if (n == l) { sh_set_error("preset %s: chaining variant (RMQ / splice / all-vs-all) not implemented on the HIP path yet", name); return SH_ERR_PRESET_UNSUPPORTED; }
+    sh_set_error("unknown preset: %s", name);
+    return SH_ERR_PRESET_UNKNOWN;
+}
+
+// ---- host-buffer classification ----------------------------------------------------------------
+extern "C" sh_status sh_classify_batch(const sh_index *idx, const sh_opts *opts, const uint8_t *bases, const uint64_t *offsets,
+                                       uint64_t n_reads, uint8_t *out_flags, sh_trace *out_trace, sh_stats *stats)
+{
+    SH_CHECK(idx && opts && offsets && out_flags, SH_ERR_BAD_ARG, "sh_classify_batch: null argument");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (n_reads == 0) return SH_OK;
+    SH_HIP(hipSetDevice(idx->device));
+    const uint64_t CH = 1ull << 22;       // reads per chunk
+    const uint64_t n_bases = offsets[n_reads] - offsets[0];
+    uint32_t max_len = 0;
+    for (uint64_t r = 0; r < n_reads; ++r) max_len = std::max<uint32_t>(max_len, (uint32_t)std::min<uint64_t>(offsets[r + 1] - offsets[r], UINT32_MAX));
+    sh_ctx *ctx = nullptr;
+    sh_status st = sh_ctx_create(idx, opts, std::min(CH, n_reads), n_bases, max_len, &ctx);
+    if (st != SH_OK) return st;
+    uint8_t *d_bases = nullptr, *d_flags = nullptr; uint64_t *d_off = nullptr; sh_trace *d_tr = nullptr;
+    hipStream_t s = nullptr;
+    auto cleanup = [&]() {
+        if (d_bases) hipFree(d_bases);
+        if (d_flags) hipFree(d_flags);
+        if (d_off) hipFree(d_off);
+        if (d_tr) hipFree(d_tr);
+        if (s) hipStreamDestroy(s);
+        sh_ctx_destroy(ctx);
+    };
+#define CB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { sh_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); cleanup(); return e_ == hipErrorOutOfMemory ? SH_ERR_OOM : SH_ERR_HIP; } } while (0)
+    CB_HIP(hipStreamCreate(&s));
+    CB_HIP(hipMalloc(&d_bases, n_bases + 32));
+    CB_HIP(hipMalloc(&d_off, (n_reads + 1) * 8));
+    CB_HIP(hipMalloc(&d_flags, n_reads));
+    if (out_trace) CB_HIP(hipMalloc(&d_tr, n_reads * sizeof(sh_trace)));
+    // offsets are rebased so that d_bases[0] is the first base of the batch
+    std::vector<uint64_t> off0;
+    const uint64_t *offp = offsets;
+    if (offsets[0] != 0) {
+        off0.resize(n_reads + 1);
+        for (uint64_t r = 0; r <= n_reads; ++r) off0[r] = offsets[r] - offsets[0];
+        offp = off0.data();
+    }
+    CB_HIP(hipMemcpyAsync(d_bases, bases + offsets[0], n_bases, hipMemcpyHostToDevice, s));
+    CB_HIP(hipMemcpyAsync(d_off, offp, (n_reads + 1) * 8, hipMemcpyHostToDevice, s));
+    st = sh_classify_device(ctx, d_bases, d_off, n_reads, n_bases, d_flags, d_tr, s, stats);
+    if (st != SH_OK) { cleanup(); return st; }
+    CB_HIP(hipMemcpyAsync(out_flags, d_flags, n_reads, hipMemcpyDeviceToHost, s));
+    if (out_trace) CB_HIP(hipMemcpyAsync(out_trace, d_tr, n_reads * sizeof(sh_trace), hipMemcpyDeviceToHost, s));
+    CB_HIP(hipStreamSynchronize(s));
+    cleanup();
+#undef CB_HIP
+    for (uint64_t r = 0; r < n_reads; ++r)
+        if (out_flags[r] == 2) {   // minimap2-rs: Err("Sequence is empty") aborts the run (cleaner.rs:552,566)
+            sh_set_error("Sequence is empty (read %llu)", (unsigned long long)r);
+            return SH_ERR_EMPTY_READ;
+        }
+    return SH_OK;
+}
+
+// ---- index cache -----------------------------------------------------------------
+struct CacheHeader {
+    char magic[8];                 // "SHIDX001"
+    int32_t k, w, mid_occ; uint32_t n_contigs, lg_slots, pad;
+    uint64_t n_bases, n_minimizers, n_keys, n_slots, n_positions;
+};
+
+extern "C" sh_status sh_index_save(const sh_index *idx, const char *path)
+{
+    SH_CHECK(idx && path, SH_ERR_BAD_ARG, "sh_index_save: null argument");
+    FILE *f = fopen(path, "wb");
+    SH_CHECK(f, SH_ERR_IO, "cannot open %s for writing", path);
+    CacheHeader h{};
+    memcpy(h.magic, "SHIDX001", 8);
+    h.k = idx->k; h.w = idx->w; h.mid_occ = idx->mid_occ; h.n_contigs = idx->n_contigs; h.lg_slots = idx->lg_slots;
+    h.n_bases = idx->n_bases; h.n_minimizers = idx->n_minimizers; h.n_keys = idx->n_keys; h.n_slots = idx->n_slots; h.n_positions = idx->n_positions;
+    std::vector<uint64_t> slots(idx->n_slots * 2), pos(idx->n_positions);
+    sh_status st = sh_index_export(idx, slots.data(), pos.data());
+    if (st != SH_OK) { fclose(f); return st; }
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(idx->contig_len.data(), 8, idx->n_contigs, f) == idx->n_contigs &&
+              fwrite(slots.data(), 16, idx->n_slots, f) == idx->n_slots && fwrite(pos.data(), 8, idx->n_positions, f) == idx->n_positions;
+    fclose(f);
+    SH_CHECK(ok, SH_ERR_IO, "short write to %s", path);
+    return SH_OK;
+}
+
+extern "C" sh_status sh_index_load(const char *path, int32_t device, sh_index **out)
+{
+    SH_CHECK(path && out, SH_ERR_BAD_ARG, "sh_index_load: null argument");
+    FILE *f = fopen(path, "rb");
+    SH_CHECK(f, SH_ERR_IO, "cannot open %s", path);
+    CacheHeader h{};
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SHIDX001", 8) != 0) { fclose(f); sh_set_error("%s is not a scrubby-hip index", path); return SH_ERR_IO; }
+    sh_index *idx = new sh_index();
+    idx->device = device; idx->k = h.k; idx->w = h.w; idx->mid_occ = h.mid_occ; idx->n_contigs = h.n_contigs; idx->lg_slots = h.lg_slots;
+    idx->n_bases = h.n_bases; idx->n_minimizers = h.n_minimizers; idx->n_keys = h.n_keys; idx->n_slots = h.n_slots; idx->n_positions = h.n_positions;
+    idx->contig_len.resize(h.n_contigs);
+    std::vector<uint64_t> slots(h.n_slots * 2), pos(h.n_positions);
+    bool ok = fread(idx->contig_len.data(), 8, h.n_contigs, f) == h.n_contigs && fread(slots.data(), 16, h.n_slots, f) == h.n_slots &&
+              fread(pos.data(), 8, h.n_positions, f) == h.n_positions;
+    fclose(f);
+    if (!ok) { delete idx; sh_set_error("short read from %s", path); return SH_ERR_IO; }
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc(&idx->d_slots, h.n_slots * 16);
+    if (e == hipSuccess) e = hipMalloc(&idx->d_positions, (h.n_positions + 2) * 8);
+    if (e == hipSuccess) e = hipMemcpy(idx->d_slots, slots.data(), h.n_slots * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess && h.n_positions) e = hipMemcpy(idx->d_positions, pos.data(), h.n_positions * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { sh_set_error("sh_index_load: %s", hipGetErrorString(e)); sh_index_free(idx); return e == hipErrorOutOfMemory ? SH_ERR_OOM : SH_ERR_HIP; }
+    *out = idx;
+    return SH_OK;
+}
+
+// ---- FASTA -> index -----------------------------------------------------------------------------------
+extern "C" sh_status sh_index_build_fasta(const char *path, const sh_opts *opts, int32_t device, sh_index **out)
+{
+    SH_CHECK(path && opts && out, SH_ERR_BAD_ARG, "sh_index_build_fasta: null argument");
+    // plain or gzip, sniffed by magic bytes like needletail does; gzip through zcat
+    FILE *f = fopen(path, "rb");
+    SH_CHECK(f, SH_ERR_IO, "cannot open %s", path);
+    unsigned char mg[2] = {0, 0};
+    size_t got = fread(mg, 1, 2, f);
+    bool gz = got == 2 && mg[0] == 0x1f && mg[1] == 0x8b;
+    if (gz) {
+        fclose(f);
+        std::string cmd = "gzip -dc '" + std::string(path) + "'";
+        f = popen(cmd.c_str(), "r");
+        SH_CHECK(f, SH_ERR_IO, "cannot run gzip on %s", path);
+    } else rewind(f);
+    std::vector<std::vector<uint8_t>> seqs;
+    std::vector<char> line(1 << 16);
+    bool fastq = false; int fq_state = 0;
+    while (fgets(line.data(), (int)line.size(), f)) {
+        size_t n = strlen(line.data());
+        while (n && (line[n - 1] == '\n' || line[n - 1] == '\r')) --n;
+        if (seqs.empty() && n && line[0] == '@') fastq = true;
+        if (!fastq) {
+            if (n && line[0] == '>') { seqs.emplace_back(); continue; }
+            if (seqs.empty()) continue;
+            seqs.back().insert(seqs.back().end(), line.data(), line.data() + n);
+        } else {
+            if (fq_state == 0) { seqs.emplace_back(); fq_state = 1; }
+            else if (fq_state == 1) { seqs.back().insert(seqs.back().end(), line.data(), line.data() + n); fq_state = 2; }
+            else if (fq_state == 2) fq_state = 3;
+            else fq_state = 0;
+        }
+    }
+    if (gz) pclose(f); else fclose(f);
+    SH_CHECK(!seqs.empty(), SH_ERR_INDEX, "no sequences in %s", path);
+    std::vector<const uint8_t *> ptr; std::vector<uint64_t> len;
+    for (auto &s : seqs) { ptr.push_back(s.data()); len.push_back(s.size()); }
+    return sh_index_build(ptr.data(), len.data(), (uint32_t)seqs.size(), opts, device, out);
+}
+
+// ---- synthetic workload --------------------------------------------------------------------------------
+__global__ void k_synth_ref(syn_ref_params P, uint64_t g0, uint64_t n, uint8_t *out)
+{
+    uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    uint32_t w = 0;
+    for (int b = 0; b < 4; ++b) {
+        uint8_t ch = i + b < n ? (uint8_t)"ACGT"[syn_ref_base(&P, g0 + i + b)] : 0;
+        w |= (uint32_t)ch << (8 * b);
+    }
+    if (i + 4 <= n && ((uintptr_t)(out + i) & 3) == 0) *(uint32_t *)(out + i) = w;
+    else for (int b = 0; b < 4 && i + b < n; ++b) out[i + b] = (uint8_t)(w >> (8 * b));
+}
+
+__global__ void k_synth_reads(syn_ref_params P, syn_read_params R, uint64_t r0, uint64_t n_rec, uint8_t *out, uint64_t *offsets)
+{
+    // one thread per 4 bases of a record
+    const uint32_t q4 = (R.read_len + 3) / 4;
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t rec = t / q4;
+    uint32_t j = (uint32_t)(t % q4) * 4;
+    if (rec >= n_rec) return;
+    uint64_t r = r0 + rec;
+    syn_pair pl = syn_place_pair(&P, &R, r >> 1);
+    for (uint32_t b = 0; b < 4 && j + b < R.read_len; ++b)
+        out[rec * R.read_len + j + b] = syn_read_base(&P, &R, &pl, r >> 1, (uint32_t)(r & 1), j + b);
+    if (offsets && j == 0) {
+        offsets[rec] = rec * R.read_len;
+        if (rec + 1 == n_rec) offsets[n_rec] = n_rec * R.read_len;
+    }
+}
+
+extern "C" sh_status sh_synth_ref_device(const void *ref_params, uint64_t g0, uint64_t n, uint8_t *d_out, void *stream)
+{
+    SH_CHECK(ref_params && d_out, SH_ERR_BAD_ARG, "sh_synth_ref_device: null argument");
+    syn_ref_params P = *(const syn_ref_params *)ref_params;
+    if (n == 0) return SH_OK;
+    uint64_t nt = (n + 3) / 4;
+    hipLaunchKernelGGL(k_synth_ref, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, g0, n, d_out);
+    SH_HIP(hipGetLastError());
+    return SH_OK;
+}
+
+extern "C" sh_status sh_synth_reads_device(const void *ref_params, const void *read_params, uint64_t r0, uint64_t n_records,
+                                           uint8_t *d_out, uint64_t *d_offsets, void *stream)
+{
+    SH_CHECK(ref_params && read_params && d_out, SH_ERR_BAD_ARG, "sh_synth_reads_device: null argument");
+    syn_ref_params P = *(const syn_ref_params *)ref_params;
+    syn_read_params R = *(const syn_read_params *)read_params;
+    if (n_records == 0) return SH_OK;
+    uint64_t nt = n_records * ((R.read_len + 3) / 4);
+    SH_CHECK((nt + 255) / 256 < (1ull << 31), SH_ERR_BAD_ARG, "too many records for one launch");
+    hipLaunchKernelGGL(k_synth_reads, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, R, r0, n_records, d_out, d_offsets);
+    SH_HIP(hipGetLastError());
+    return SH_OK;
+}
+
+// ---- gather micro-benchmark: the practical ceiling for 16-B random probes into this table ----------------
+__global__ void k_gather(const uint4 *slots, uint32_t lg, uint64_t n, uint64_t seed, unsigned long long *sink)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (; i < n; i += stride * 4) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint64_t j = i + u * stride;
+            uint64_t h = syn_mix(seed ^ j) >> (64 - lg);
+            v[u] = j < n ? slots[h] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    if (acc == 0x12345678u) atomicAdd(sink, 1ull);
+}
+
+extern "C" sh_status sh_bench_gather(const sh_index *idx, uint64_t n_probes, int32_t iters, double *out_gbs_useful, double *out_ms)
+{
+    SH_CHECK(idx && out_gbs_useful && out_ms && iters > 0, SH_ERR_BAD_ARG, "sh_bench_gather: bad argument");
+    SH_HIP(hipSetDevice(idx->device));
+    unsigned long long *sink = nullptr;
+    SH_HIP(hipMalloc(&sink, 8));
+    hipEvent_t e0, e1;
+    SH_HIP(hipEventCreate(&e0)); SH_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_gather, dim3(256 * 16), dim3(256), 0, nullptr, (const uint4 *)idx->d_slots, idx->lg_slots, n_probes, 1ull, sink);
+    SH_HIP(hipEventRecord(e0, nullptr));
+    for (int it = 0; it < iters; ++it)
+        hipLaunchKernelGGL(k_gather, dim3(256 * 16), dim3(256), 0, nullptr, (const uint4 *)idx->d_slots, idx->lg_slots, n_probes, 2ull + it, sink);
+    SH_HIP(hipEventRecord(e1, nullptr));
+    SH_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    SH_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *out_ms = ms / iters;
+    *out_gbs_useful = 16.0 * (double)n_probes / (*out_ms * 1e-3) / 1e9;
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(sink);
+    return SH_OK;
+}

@@ -1,0 +1,374 @@
+// sh_chain.h — seed filtering, anchor generation, chaining DP and backtrack (device code).
+//
+// Restates what happens between minimap2's sketch and its `n_regs0 > 0` for one
+// single-segment query, i.e. the part of
+//     aligner.map(&sequence, false, false, None, None)      /root/reference/src/cleaner.rs:552
+// that decides `mappings.len() > 0` (:553) before base-level alignment.  Statement order
+// follows the CPU oracle (oracle/mm_oracle.c) one to one so that every intermediate
+// (n_anchor, rep_len, n_chain, best_score) is bit-identical; the f32 pair-score path needs
+// -ffp-contract=off on both sides.
+//
+// One lane owns one read.  The code is generic over a Store (where the anchor / DP arrays
+// live): SmallStore = LDS, 11 B per anchor, lane-interleaved; LargeStore = per-read slices
+// of an HBM arena.
+#pragma once
+#include "sh_common.h"
+
+struct ChainParams {
+    int32_t k, is_sr;
+    int32_t mid_occ, max_occ, max_max_occ, occ_dist;
+    int32_t min_cnt, min_sc;
+    int32_t max_gap, max_gap_ref, max_frag_len, bw;
+    int32_t max_skip, max_iter;
+    float pen_gap, pen_skip;
+};
+
+// ---- seeds: one 16-B record per query minimizer found in the index ---------------------------
+//   .x,.y = w1 of the slot (position word, or off<<28|n)   .z = n | flt<<31   .w = qpos<<1|strand
+struct SeedView {
+    uint4 *base;
+    uint32_t stride;   // in records
+    uint32_t n;
+    __device__ inline uint4 get(uint32_t i) const { return base[(size_t)i * stride]; }
+    __device__ inline uint32_t occ(uint32_t i) const { return base[(size_t)i * stride].z & 0x7fffffffu; }
+    __device__ inline uint32_t qposz(uint32_t i) const { return base[(size_t)i * stride].w; }
+    __device__ inline void set_flt(uint32_t i, uint32_t occ_, uint32_t flt) { base[(size_t)i * stride].z = occ_ | flt << 31; }
+};
+
+// mm_seed_select + the plain occurrence cut + the rep_len / anchor count loop of
+// mm_collect_matches.  Sets the flt bit of every record.
+__device__ inline void seed_filter(SeedView sv, int32_t qlen, int32_t max_occ, const ChainParams &P,
+                                   int64_t &n_a_out, int32_t &rep_len_out)
+{
+    const int32_t n = (int32_t)sv.n;
+    const bool use_select = P.occ_dist > 0 && P.max_max_occ > max_occ;
+    if (!use_select) {
+        for (int32_t i = 0; i < n; ++i) { uint32_t o = sv.occ(i); sv.set_flt(i, o, o > (uint32_t)max_occ); }
+    } else {
+        int32_t m = 0;
+        for (int32_t i = 0; i < n; ++i) { uint32_t o = sv.occ(i); sv.set_flt(i, o, 0); m += o > (uint32_t)max_occ; }
+        if (n >= 2 && m > 0) {
+            int32_t last0 = -1;
+            for (int32_t i = 0; i <= n; ++i) {
+                bool low = (i == n) || sv.occ(i) <= (uint32_t)max_occ;
+                if (!low) continue;
+                if (i - last0 > 1) {
+                    int32_t ps = last0 < 0 ? 0 : (int32_t)(sv.qposz(last0) >> 1);
+                    int32_t pe = i == n ? qlen : (int32_t)(sv.qposz(i) >> 1);
+                    int32_t st = last0 + 1, en = i;
+                    int32_t mho = (int32_t)((double)(pe - ps) / (double)P.occ_dist + .499);
+                    if (mho > 128) mho = 128;
+                    for (int32_t j = st; j < en; ++j) {
+                        uint32_t oj = sv.occ(j);
+                        uint32_t flt = 1;
+                        if (mho > 0) {      // keep the mho smallest by (occ, index)
+                            int32_t rank = 0;
+                            for (int32_t t = st; t < en; ++t) {
+                                uint32_t ot = sv.occ(t);
+                                rank += (ot < oj) || (ot == oj && t < j);
+                            }
+                            if (rank < mho) flt = 0;
+                        }
+                        if (oj > (uint32_t)P.max_max_occ) flt = 1;
+                        sv.set_flt(j, oj, flt);
+                    }
+                }
+                last0 = i;
+            }
+        }
+    }
+    int64_t n_a = 0;
+    int32_t rep_st = 0, rep_en = 0, rep_len = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        uint4 s = sv.get(i);
+        if (s.z >> 31) {
+            int32_t en = (int32_t)(s.w >> 1) + 1, st = en - P.k;
+            if (st > rep_en) { rep_len += rep_en - rep_st; rep_st = st; rep_en = en; }
+            else rep_en = en;
+        } else n_a += s.z;
+    }
+    rep_len += rep_en - rep_st;
+    n_a_out = n_a; rep_len_out = rep_len;
+}
+
+// anchor (x, qpos') of occurrence r of a seed at qposz
+__device__ inline void make_anchor(uint64_t r, uint32_t qposz, int32_t qlen, int32_t k, uint64_t &x, uint32_t &q)
+{
+    uint32_t rpos = (uint32_t)r >> 1;
+    if ((r & 1) == (qposz & 1)) {
+        x = (r & 0xffffffff00000000ULL) | rpos;
+        q = qposz >> 1;
+    } else {
+        x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | rpos;
+        q = (uint32_t)(qlen - ((int32_t)(qposz >> 1) + 1 - k) - 1);
+    }
+}
+
+// ---- pair score (mg_lchain_dp's comput_sc, single segment, not cDNA) ---------------------------
+__device__ inline float sh_mg_log2(float x)
+{
+    uint32_t zi = __float_as_uint(x);
+    float log_2 = (float)((int32_t)((zi >> 23) & 255) - 128);
+    zi &= ~(255u << 23);
+    zi += 127u << 23;
+    float zf = __uint_as_float(zi);
+    log_2 += (-0.34484843f * zf + 2.02466578f) * zf - 0.67487759f;
+    return log_2;
+}
+
+#define SH_SC_NONE INT32_MIN
+__device__ inline int32_t comput_sc(uint32_t lo_i, uint32_t q_i, uint32_t lo_j, uint32_t q_j, int32_t max_dist_x,
+                                    int32_t max_dist_y, const ChainParams &P)
+{
+    int32_t dq = (int32_t)q_i - (int32_t)q_j, dr, dd, dg, sc;
+    if (dq <= 0 || dq > max_dist_x) return SH_SC_NONE;
+    dr = (int32_t)(lo_i - lo_j);
+    if (dr == 0 || dq > max_dist_y) return SH_SC_NONE;
+    dd = dr > dq ? dr - dq : dq - dr;
+    if (dd > P.bw) return SH_SC_NONE;
+    dg = dr < dq ? dr : dq;
+    sc = P.k < dg ? P.k : dg;
+    if (dd || dg > P.k) {
+        float lin_pen = P.pen_gap * (float)dd + P.pen_skip * (float)dg;
+        float log_pen = dd >= 1 ? sh_mg_log2((float)(dd + 1)) : 0.0f;
+        sc -= (int32_t)(lin_pen + .5f * log_pen);
+    }
+    return sc;
+}
+
+// ---- stores -----------------------------------------------------------------------------------
+// LDS, lane-interleaved [i][64]; 11 B per anchor.  `aux` holds x>>32 while sorting, then
+// {f:16, p:8, t:8}; group ids (rank of x>>32 among the read's anchors) replace x>>32.
+template <int CAP>
+struct SmallStore {
+    uint32_t *lo; uint32_t *aux; uint16_t *qv; uint8_t *gv;     // already offset by lane
+    static constexpr int S = 64;
+    __device__ inline void set_raw(int i, uint64_t x, uint32_t q) { lo[i * S] = (uint32_t)x; aux[i * S] = (uint32_t)(x >> 32); qv[i * S] = (uint16_t)q; }
+    __device__ inline uint64_t raw_x(int i) const { return (uint64_t)aux[i * S] << 32 | lo[i * S]; }
+    __device__ inline void sort_finalize(int n)
+    {   // stable insertion sort by x (radix_sort_128x is an insertion sort below 64 elements)
+        for (int i = 1; i < n; ++i) {
+            uint64_t x = raw_x(i);
+            if (x >= raw_x(i - 1)) continue;
+            uint32_t q = qv[i * S];
+            int j = i;
+            for (; j > 0 && x < raw_x(j - 1); --j) { lo[j * S] = lo[(j - 1) * S]; aux[j * S] = aux[(j - 1) * S]; qv[j * S] = qv[(j - 1) * S]; }
+            set_raw(j, x, q);
+        }
+        uint32_t prev = n > 0 ? aux[0] : 0;
+        uint8_t g = 0;
+        for (int i = 0; i < n; ++i) { uint32_t h = aux[i * S]; g += h != prev; prev = h; gv[i * S] = g; }
+    }
+    __device__ inline uint32_t grp(int i) const { return gv[i * S]; }
+    __device__ inline uint32_t rlo(int i) const { return lo[i * S]; }
+    __device__ inline uint32_t qp(int i) const { return qv[i * S]; }
+    __device__ inline int32_t F(int i) const { return (int32_t)(aux[i * S] & 0xffffu); }
+    __device__ inline int32_t Pm(int i) const { uint32_t v = (aux[i * S] >> 16) & 0xffu; return v == 0xffu ? -1 : (int32_t)v; }
+    __device__ inline int32_t T(int i) const { return (int32_t)(aux[i * S] >> 24); }
+    __device__ inline void setFP(int i, int32_t f, int32_t p) { aux[i * S] = (aux[i * S] & 0xff000000u) | ((uint32_t)(p & 0xff) << 16) | ((uint32_t)f & 0xffffu); }
+    __device__ inline void setT(int i, int32_t t) { aux[i * S] = (aux[i * S] & 0x00ffffffu) | (uint32_t)t << 24; }
+    __device__ inline void clearT(int n) { for (int i = 0; i < n; ++i) aux[i * S] &= 0x00ffffffu; }
+    __device__ inline void clearAux(int n) { for (int i = 0; i < n; ++i) aux[i * S] = 0; }
+};
+
+// HBM arena slices of one read
+struct LargeStore {
+    uint64_t *x, *x2, *z; uint32_t *q, *q2; int32_t *f, *p, *t;
+    static __host__ __device__ inline size_t bytes_for(int64_t n) { return (size_t)(n + 2) * (8 + 8 + 8 + 4 + 4 + 4 + 4 + 4); }
+    __device__ inline void carve(uint8_t *m, int64_t n)
+    {
+        size_t n2 = (size_t)(n + 2);
+        x = (uint64_t *)m; x2 = x + n2; z = x2 + n2; q = (uint32_t *)(z + n2); q2 = q + n2;
+        f = (int32_t *)(q2 + n2); p = f + n2; t = p + n2;
+    }
+    __device__ inline void set_raw(int64_t i, uint64_t xv, uint32_t qv_) { x[i] = xv; q[i] = qv_; }
+    __device__ inline void sort_finalize(int64_t n)
+    {   // stable bottom-up merge sort by x, ping-pong between (x,q) and (x2,q2)
+        bool sorted = true;
+        for (int64_t i = 1; i < n; ++i) if (x[i] < x[i - 1]) { sorted = false; break; }
+        if (sorted) return;
+        uint64_t *sx = x, *dx = x2; uint32_t *sq = q, *dq = q2;
+        for (int64_t width = 1; width < n; width <<= 1) {
+            for (int64_t i = 0; i < n; i += 2 * width) {
+                int64_t m = i + width < n ? i + width : n, r = i + 2 * width < n ? i + 2 * width : n;
+                int64_t a = i, b = m, o = i;
+                while (a < m && b < r) { if (sx[b] < sx[a]) { dx[o] = sx[b]; dq[o] = sq[b]; ++b; } else { dx[o] = sx[a]; dq[o] = sq[a]; ++a; } ++o; }
+                while (a < m) { dx[o] = sx[a]; dq[o] = sq[a]; ++a; ++o; }
+                while (b < r) { dx[o] = sx[b]; dq[o] = sq[b]; ++b; ++o; }
+            }
+            uint64_t *tx = sx; sx = dx; dx = tx; uint32_t *tq = sq; sq = dq; dq = tq;
+        }
+        if (sx != x) { uint64_t *tx = x; x = x2; x2 = tx; uint32_t *tq = q; q = q2; q2 = tq; }
+    }
+    __device__ inline uint32_t grp(int64_t i) const { return (uint32_t)(x[i] >> 32); }
+    __device__ inline uint32_t rlo(int64_t i) const { return (uint32_t)x[i]; }
+    __device__ inline uint32_t qp(int64_t i) const { return q[i]; }
+    __device__ inline int32_t F(int64_t i) const { return f[i]; }
+    __device__ inline int32_t Pm(int64_t i) const { return p[i]; }
+    __device__ inline int32_t T(int64_t i) const { return t[i]; }
+    __device__ inline void setFP(int64_t i, int32_t fv, int32_t pv) { f[i] = fv; p[i] = pv; }
+    __device__ inline void setT(int64_t i, int32_t tv) { t[i] = tv; }
+    __device__ inline void clearT(int64_t n) { for (int64_t i = 0; i < n; ++i) t[i] = 0; }
+    __device__ inline void clearAux(int64_t n) { clearT(n); }
+};
+
+// expand the unfiltered seeds into anchors (seed order, then occurrence order), sort by x
+template <class Store>
+__device__ inline void gen_anchors(Store &S, SeedView sv, const uint64_t *__restrict__ positions, int32_t qlen, int32_t k)
+{
+    int64_t na = 0;
+    for (uint32_t i = 0; i < sv.n; ++i) {
+        uint4 s = sv.get(i);
+        if (s.z >> 31) continue;
+        uint32_t occ = s.z;
+        uint64_t w1 = (uint64_t)s.y << 32 | s.x;
+        if (occ == 1) {
+            uint64_t x; uint32_t q;
+            make_anchor(w1, s.w, qlen, k, x, q);
+            S.set_raw(na++, x, q);
+        } else {
+            const uint64_t *cr = positions + (w1 >> SH_SLOT_NBITS);
+            for (uint32_t t = 0; t < occ; ++t) {
+                uint64_t x; uint32_t q;
+                make_anchor(cr[t], s.w, qlen, k, x, q);
+                S.set_raw(na++, x, q);
+            }
+        }
+    }
+    S.sort_finalize(na);
+}
+
+// mg_lchain_dp: fills f/p; t is scratch
+template <class Store, class Idx>
+__device__ inline void chain_dp(Store &S, Idx n, int32_t qlen, const ChainParams &P)
+{
+    int32_t max_dist_y = P.is_sr ? (qlen > P.max_gap ? qlen : P.max_gap) : P.max_gap;
+    int32_t max_dist_x;
+    if (P.max_gap_ref > 0) max_dist_x = P.max_gap_ref;
+    else if (P.max_frag_len > 0) { max_dist_x = P.max_frag_len - qlen; if (max_dist_x < P.max_gap) max_dist_x = P.max_gap; }
+    else max_dist_x = P.max_gap;
+    if (max_dist_x < P.bw) max_dist_x = P.bw;
+    if (max_dist_y < P.bw) max_dist_y = P.bw;
+
+    S.clearAux(n);
+    Idx st = 0, max_ii = -1;
+    for (Idx i = 0; i < n; ++i) {
+        Idx max_j = -1, j;
+        const uint32_t gi = S.grp(i), li = S.rlo(i), qi = S.qp(i);
+        int32_t max_f = P.k, n_skip = 0;
+        while (st < i && (gi != S.grp(st) || (uint64_t)li > (uint64_t)S.rlo(st) + (uint64_t)max_dist_x)) ++st;
+        if (i - st > (Idx)P.max_iter) st = i - (Idx)P.max_iter;
+        for (j = i - 1; j >= st; --j) {
+            int32_t sc = comput_sc(li, qi, S.rlo(j), S.qp(j), max_dist_x, max_dist_y, P);
+            if (sc == SH_SC_NONE) continue;
+            sc += S.F(j);
+            if (sc > max_f) {
+                max_f = sc; max_j = j;
+                if (n_skip > 0) --n_skip;
+            } else if (S.T(j) == (int32_t)i) {
+                if (++n_skip > P.max_skip) break;
+            }
+            int32_t pj = S.Pm(j);
+            if (pj >= 0) S.setT(pj, (int32_t)i);
+        }
+        Idx end_j = j;
+        bool far = true;
+        if (max_ii >= 0) far = (gi != S.grp(max_ii)) || ((uint64_t)(li - S.rlo(max_ii)) > (uint64_t)max_dist_x);
+        if (max_ii < 0 || far) {
+            int32_t mx = INT32_MIN;
+            max_ii = -1;
+            for (j = i - 1; j >= st; --j) { int32_t fj = S.F(j); if (mx < fj) { mx = fj; max_ii = j; } }
+        }
+        if (max_ii >= 0 && max_ii < end_j) {
+            int32_t tmp = comput_sc(li, qi, S.rlo(max_ii), S.qp(max_ii), max_dist_x, max_dist_y, P);
+            if (tmp != SH_SC_NONE && max_f < tmp + S.F(max_ii)) { max_f = tmp + S.F(max_ii); max_j = max_ii; }
+        }
+        S.setFP(i, max_f, (int32_t)max_j);
+        bool near = false;
+        if (max_ii >= 0) near = (gi == S.grp(max_ii)) && ((uint64_t)(li - S.rlo(max_ii)) <= (uint64_t)max_dist_x);
+        if (max_ii < 0 || (near && S.F(max_ii) < max_f)) max_ii = i;
+    }
+}
+
+// mg_chain_bk_end
+template <class Store, class Idx>
+__device__ inline Idx chain_bk_end(Store &S, int32_t max_drop, int32_t zf, Idx zi)
+{
+    Idx i = zi, end_i = -1, max_i = i;
+    int32_t max_s = 0;
+    if (i < 0 || S.T(i) != 0) return i;
+    do {
+        S.setT(i, 2);
+        end_i = i = (Idx)S.Pm(i);
+        int32_t s = i < 0 ? zf : zf - S.F(i);
+        if (s > max_s) { max_s = s; max_i = i; }
+        else if (max_s - s > max_drop) break;
+    } while (i >= 0 && S.T(i) == 0);
+    for (i = zi; i >= 0 && i != end_i; i = (Idx)S.Pm(i)) S.setT(i, 0);
+    return max_i;
+}
+
+// one candidate of mg_chain_backtrack's first loop
+template <class Store, class Idx>
+__device__ inline void backtrack_visit(Store &S, const ChainParams &P, int32_t zf, Idx zi, int64_t &n_v, int32_t &n_u, int32_t &best)
+{
+    if (S.T(zi) != 0) return;
+    int64_t n_v0 = n_v;
+    Idx end_i = chain_bk_end<Store, Idx>(S, P.bw, zf, zi), i;
+    for (i = zi; i != end_i; i = (Idx)S.Pm(i)) { ++n_v; S.setT(i, 1); }
+    int32_t sc = i < 0 ? zf : zf - S.F(i);
+    if (sc >= P.min_sc && n_v > n_v0 && n_v - n_v0 >= P.min_cnt) { ++n_u; if (sc > best) best = sc; }
+    else n_v = n_v0;
+}
+
+// candidates (f >= min_sc) in descending (f, index) order; small n: O(n^2) selection, no extra memory
+template <class Store>
+__device__ inline void backtrack_small(Store &S, int n, const ChainParams &P, int32_t &n_u, int32_t &best)
+{
+    n_u = 0; best = 0;
+    S.clearT(n);
+    int64_t n_v = 0;
+    int64_t bound = INT64_MAX;
+    for (;;) {
+        int64_t cur = -1;
+        for (int i = 0; i < n; ++i) {
+            int32_t f = S.F(i);
+            if (f < P.min_sc) continue;
+            int64_t key = (int64_t)f << 32 | (uint32_t)i;
+            if (key < bound && key > cur) cur = key;
+        }
+        if (cur < 0) break;
+        bound = cur;
+        backtrack_visit<Store, int>(S, P, (int32_t)(cur >> 32), (int)(cur & 0xffffffff), n_v, n_u, best);
+    }
+}
+
+// large n: heap sort of (f<<32|index) in the arena, then the same visit order
+__device__ inline void backtrack_large(LargeStore &S, int64_t n, const ChainParams &P, int32_t &n_u, int32_t &best)
+{
+    n_u = 0; best = 0;
+    uint64_t *z = S.z;
+    int64_t nz = 0;
+    for (int64_t i = 0; i < n; ++i) if (S.f[i] >= P.min_sc) z[nz++] = (uint64_t)(uint32_t)S.f[i] << 32 | (uint32_t)i;
+    if (nz == 0) return;
+    S.clearT(n);
+    // max-heap; pop order = descending (f, index)
+    auto down = [&](int64_t i, int64_t m) {
+        uint64_t tmp = z[i];
+        int64_t k = i;
+        while ((k = (k << 1) + 1) < m) {
+            if (k != m - 1 && z[k] < z[k + 1]) ++k;
+            if (z[k] < tmp) break;
+            z[i] = z[k]; i = k;
+        }
+        z[i] = tmp;
+    };
+    for (int64_t i = (nz >> 1) - 1; i >= 0; --i) down(i, nz);
+    int64_t n_v = 0;
+    for (int64_t m = nz; m > 0; --m) {
+        uint64_t top = z[0];
+        z[0] = z[m - 1];
+        if (m - 1 > 0) down(0, m - 1);
+        backtrack_visit<LargeStore, int64_t>(S, P, (int32_t)(top >> 32), (int64_t)(top & 0xffffffff), n_v, n_u, best);
+    }
+}

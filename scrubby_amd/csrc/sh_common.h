@@ -1,0 +1,81 @@
+// sh_common.h — internal declarations shared by the translation units of libscrubby_hip.so.
+#pragma once
+#include <cstring>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include "../../include/scrubby_hip.h"
+
+// ---- HBM index layout ---------------------------------------------------------
+// slot = 16 B {w0, w1}; w0 = ~0 (empty) | key (2k bits <= 56) | multi << 63
+//                       w1 = position word rid<<32|pos<<1|strand  (singleton)
+//                            off << 28 | n                        (multi: n entries at positions[off])
+#define SH_SLOT_EMPTY 0xFFFFFFFFFFFFFFFFULL
+#define SH_SLOT_MULTI (1ULL << 63)
+#define SH_SLOT_KEYMASK ((1ULL << 56) - 1)
+#define SH_SLOT_NBITS 28
+#define SH_SLOT_NMASK ((1ULL << SH_SLOT_NBITS) - 1)
+
+struct sh_index {
+    int32_t device = 0;
+    int32_t k = 0, w = 0;
+    int32_t mid_occ = 0;          // resolved
+    uint32_t n_contigs = 0;
+    uint64_t n_bases = 0;
+    uint64_t n_minimizers = 0, n_keys = 0, n_slots = 0, n_positions = 0;
+    uint32_t lg_slots = 0;
+    uint64_t *d_slots = nullptr;      // 2 * n_slots
+    uint64_t *d_positions = nullptr;  // n_positions (+1)
+    std::vector<uint64_t> contig_len;
+    double build_ms = 0;
+};
+
+// ---- errors ----------------------------------------------------------------------------------
+void sh_set_error(const char *fmt, ...);
+#define SH_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            sh_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return e_ == hipErrorOutOfMemory ? SH_ERR_OOM : SH_ERR_HIP;                      \
+        }                                                                                    \
+    } while (0)
+#define SH_CHECK(cond, code, ...)         \
+    do {                                  \
+        if (!(cond)) {                    \
+            sh_set_error(__VA_ARGS__);    \
+            return (code);                \
+        }                                 \
+    } while (0)
+
+// ---- device helpers --------------------------------------------------------------------------
+__host__ __device__ static inline uint64_t sh_hash64(uint64_t key, uint64_t mask)
+{   // minimap2's invertible integer mix on 2k bits
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & mask;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & mask;
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+
+__host__ __device__ static inline uint64_t sh_slot_home(uint64_t key, uint32_t lg)
+{
+    return (key * 0x9E3779B97F4A7C15ULL) >> (64 - lg);
+}
+
+// ASCII -> 0..3 (A,C,G,T/U, either case), 4 otherwise
+__host__ __device__ static inline uint32_t sh_nt4(uint32_t c)
+{
+    uint32_t u = c & 0xDFu;
+    bool ok = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T') | (u == 'U');
+    return ok ? ((c >> 1) ^ (c >> 2)) & 3u : 4u;
+}
+
+// internal entry points implemented across translation units
+sh_status shi_index_build_device(const uint8_t *d_bases, const uint64_t *contig_starts, uint32_t n_contigs,
+                                 const sh_opts *opts, int32_t device, hipStream_t stream, sh_index **out);

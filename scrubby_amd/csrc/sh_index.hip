@@ -1,0 +1,350 @@
+// sh_index.hip — minimizer index construction on gfx950 and its HBM layout.
+//
+// Replaces  Aligner::builder().<preset>().with_cigar().with_index_threads(t).with_index(path, None)
+//           /root/reference/src/cleaner.rs:472-482   (minimap2's mm_idx_gen behind the crate)
+// The logical content is minimap2's: minimizer hash -> ascending list of
+// (rid<<32 | pos<<1 | strand).  The physical layout is ours: one open-addressing table of 16-B slots
+// (singletons inline, so the common probe is ONE 16-B gather) plus one position array for repeated
+// minimizers; both stay resident in HBM (CHM13v2: ~8 GiB table + positions, of 288 GB).
+//
+// Build pipeline, all on the device:
+//   1 k_ref_sketch<count>   one lane per 1024-bp segment (+ w+k warm-up), window in VGPRs
+//   2 exclusive scan -> k_ref_sketch<emit> writes (hash, position) pairs in reference order
+//   3 rocPRIM radix sort by hash (stable: positions stay ascending per hash)
+//   4 run-length encode -> distinct hashes + counts; select -> position array of repeated hashes
+//   5 k_table_fill          atomicCAS insertion, linear probing
+// rocPRIM supplies the generic sort / scan / RLE / select primitives (the index build is not the
+// timed hot path); sketching and the table are hand-written.
+#include "sh_common.h"
+#include "sh_sketch.h"
+#include <rocprim/rocprim.hpp>
+#include <chrono>
+
+#define SEG_LEN 1024u
+
+struct RefArgs {
+    const uint8_t *bases;
+    const uint64_t *contig_start;   // device, n_contigs+1
+    const uint64_t *seg_first;      // device, n_contigs+1: first segment id of each contig
+    uint32_t n_contigs; uint64_t n_segs; int32_t k;
+    uint32_t *counts;               // per segment (count pass)
+    const uint64_t *seg_off;        // per segment (emit pass)
+    uint64_t *keys, *vals;
+};
+
+template <int W, bool EMIT>
+__global__ __launch_bounds__(256) void k_ref_sketch(RefArgs a)
+{
+    const uint64_t seg = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (seg >= a.n_segs) return;
+    uint32_t lo = 0, hi = a.n_contigs;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (a.seg_first[mid] <= seg) lo = mid; else hi = mid; }
+    const uint32_t rid = lo;
+    const uint64_t cs = a.contig_start[rid], clen = a.contig_start[rid + 1] - cs;
+    const uint64_t start = (seg - a.seg_first[rid]) * SEG_LEN;
+    const uint64_t end = start + SEG_LEN < clen ? start + SEG_LEN : clen;
+    const uint64_t warm = (uint64_t)(W + a.k);
+    const uint64_t from = start > warm ? start - warm : 0;
+    const uint8_t *seq = a.bases + cs;
+
+    SketchState<W> st;
+    st.init(a.k);
+    uint64_t n = 0, cur = 0;
+    const uint64_t o0 = EMIT ? a.seg_off[seg] : 0;
+    auto emit = [&](uint64_t x, uint32_t y) {
+        if (cur < start) return;            // pushes made during warm-up belong to the previous segment
+        if (EMIT) { a.keys[o0 + n] = x >> 8; a.vals[o0 + n] = (uint64_t)rid << 32 | y; }
+        ++n;
+    };
+    for (uint64_t i0 = from; i0 < end; i0 += W) {
+        auto one = [&](auto Pc) {
+            constexpr int P = decltype(Pc)::value;
+            const uint64_t i = i0 + P;
+            if (i < end) { cur = i; st.template step<P>(sh_nt4(seq[i]), (uint32_t)i, emit); }
+        };
+        [&]<int... Ps>(std::integer_sequence<int, Ps...>) { (one(std::integral_constant<int, Ps>{}), ...); }
+        (std::make_integer_sequence<int, W>{});
+    }
+    if (end == clen) { cur = end; st.finish(emit); }
+    if (!EMIT) a.counts[seg] = (uint32_t)n;
+}
+
+__global__ void k_multi_flags(const uint64_t *keys, uint64_t n, uint8_t *flags)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t k = keys[i];
+    bool m = (i > 0 && keys[i - 1] == k) || (i + 1 < n && keys[i + 1] == k);
+    flags[i] = m;
+}
+
+__global__ void k_multi_counts(const uint32_t *counts, uint64_t n, uint64_t *mc)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) mc[i] = counts[i] > 1 ? counts[i] : 0;
+}
+
+__global__ void k_table_fill(const uint64_t *ukeys, const uint32_t *counts, const uint64_t *start, const uint64_t *moff,
+                             const uint64_t *vals, uint64_t n_unique, unsigned long long *slots, uint32_t lg, int *err)
+{
+    uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_unique) return;
+    const uint64_t key = ukeys[u];
+    const uint32_t c = counts[u];
+    unsigned long long w0, w1;
+    if (c == 1) { w0 = key; w1 = vals[start[u]]; }
+    else {
+        if (c > SH_SLOT_NMASK) { *err = 1; return; }
+        w0 = key | SH_SLOT_MULTI; w1 = (unsigned long long)moff[u] << SH_SLOT_NBITS | c;
+    }
+    const uint64_t mask = (1ULL << lg) - 1;
+    uint64_t h = sh_slot_home(key, lg);
+    for (;;) {
+        unsigned long long old = atomicCAS(&slots[2 * h], (unsigned long long)SH_SLOT_EMPTY, w0);
+        if (old == SH_SLOT_EMPTY) { slots[2 * h + 1] = w1; return; }
+        h = (h + 1) & mask;
+    }
+}
+
+template <int W>
+static void launch_ref_sketch(bool emit, const RefArgs &a, hipStream_t s)
+{
+    dim3 g((uint32_t)((a.n_segs + 255) / 256)), b(256);
+    if (emit) hipLaunchKernelGGL((k_ref_sketch<W, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_ref_sketch<W, false>), g, b, 0, s, a);
+}
+
+static sh_status dispatch_ref_sketch(int w, bool emit, const RefArgs &a, hipStream_t s)
+{
+    switch (w) {
+    case 5: launch_ref_sketch<5>(emit, a, s); break;
+    case 10: launch_ref_sketch<10>(emit, a, s); break;
+    case 11: launch_ref_sketch<11>(emit, a, s); break;
+    case 19: launch_ref_sketch<19>(emit, a, s); break;
+    default: sh_set_error("unsupported minimizer window w=%d (supported: 5, 10, 11, 19)", w); return SH_ERR_BAD_ARG;
+    }
+    return SH_OK;
+}
+
+struct DevBuf {   // frees on scope exit
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    template <class T> T *as() { return (T *)p; }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+
+sh_status shi_index_build_device(const uint8_t *d_bases, const uint64_t *contig_starts, uint32_t n_contigs,
+                                 const sh_opts *opts, int32_t device, hipStream_t s, sh_index **out)
+{
+    SH_CHECK(d_bases && contig_starts && opts && out && n_contigs > 0, SH_ERR_BAD_ARG, "sh_index_build: null/empty argument");
+    SH_CHECK(opts->k > 0 && opts->k <= 28 && (opts->k & 1), SH_ERR_BAD_ARG,
+             "k=%d unsupported: k must be odd and <= 28 (every minimap2 preset is; odd k has no strand-ambiguous k-mers)", opts->k);
+    SH_CHECK(opts->w > 0 && opts->w < 256, SH_ERR_BAD_ARG, "w=%d out of range", opts->w);
+    SH_HIP(hipSetDevice(device));
+    auto t0 = std::chrono::steady_clock::now();
+
+    std::vector<uint64_t> seg_first(n_contigs + 1, 0);
+    for (uint32_t i = 0; i < n_contigs; ++i) {
+        uint64_t len = contig_starts[i + 1] - contig_starts[i];
+        SH_CHECK(len < (1ULL << 31) - 1, SH_ERR_BAD_ARG, "contig %u has %llu bases; limit is 2^31-2", i, (unsigned long long)len);
+        seg_first[i + 1] = seg_first[i] + (len + SEG_LEN - 1) / SEG_LEN;
+    }
+    const uint64_t n_segs = seg_first[n_contigs];
+    const uint64_t n_bases = contig_starts[n_contigs] - contig_starts[0];
+
+    DevBuf b_cs, b_sf, b_cnt, b_off, b_tmp;
+    SH_HIP(b_cs.alloc((n_contigs + 1) * 8)); SH_HIP(b_sf.alloc((n_contigs + 1) * 8));
+    SH_HIP(b_cnt.alloc((n_segs + 1) * 4)); SH_HIP(b_off.alloc((n_segs + 1) * 8));
+    SH_HIP(hipMemcpyAsync(b_cs.p, contig_starts, (n_contigs + 1) * 8, hipMemcpyHostToDevice, s));
+    SH_HIP(hipMemcpyAsync(b_sf.p, seg_first.data(), (n_contigs + 1) * 8, hipMemcpyHostToDevice, s));
+    SH_HIP(hipMemsetAsync(b_cnt.p, 0, (n_segs + 1) * 4, s));
+
+    RefArgs ra{};
+    ra.bases = d_bases; ra.contig_start = b_cs.as<uint64_t>(); ra.seg_first = b_sf.as<uint64_t>();
+    ra.n_contigs = n_contigs; ra.n_segs = n_segs; ra.k = opts->k;
+    ra.counts = b_cnt.as<uint32_t>();
+    sh_status st = dispatch_ref_sketch(opts->w, false, ra, s);
+    if (st != SH_OK) return st;
+
+    // exclusive scan over n_segs+1 entries: last element = total
+    size_t tmp_bytes = 0;
+    SH_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, b_cnt.as<uint32_t>(), b_off.as<uint64_t>(), (uint64_t)0, n_segs + 1, rocprim::plus<uint64_t>(), s));
+    SH_HIP(b_tmp.alloc(tmp_bytes));
+    SH_HIP(rocprim::exclusive_scan(b_tmp.p, tmp_bytes, b_cnt.as<uint32_t>(), b_off.as<uint64_t>(), (uint64_t)0, n_segs + 1, rocprim::plus<uint64_t>(), s));
+    uint64_t n_mini = 0;
+    SH_HIP(hipMemcpyAsync(&n_mini, b_off.as<uint64_t>() + n_segs, 8, hipMemcpyDeviceToHost, s));
+    SH_HIP(hipStreamSynchronize(s));
+
+    DevBuf b_k1, b_v1, b_k2, b_v2;
+    SH_HIP(b_k1.alloc(n_mini * 8)); SH_HIP(b_v1.alloc(n_mini * 8)); SH_HIP(b_k2.alloc(n_mini * 8)); SH_HIP(b_v2.alloc(n_mini * 8));
+    ra.seg_off = b_off.as<uint64_t>(); ra.keys = b_k1.as<uint64_t>(); ra.vals = b_v1.as<uint64_t>();
+    st = dispatch_ref_sketch(opts->w, true, ra, s);
+    if (st != SH_OK) return st;
+
+    uint64_t *keys = b_k2.as<uint64_t>(), *vals = b_v2.as<uint64_t>();
+    if (n_mini > 0) {
+        DevBuf b_st;
+        size_t sb = 0;
+        SH_HIP(rocprim::radix_sort_pairs(nullptr, sb, b_k1.as<uint64_t>(), keys, b_v1.as<uint64_t>(), vals, n_mini, 0, 2 * opts->k, s));
+        SH_HIP(b_st.alloc(sb));
+        SH_HIP(rocprim::radix_sort_pairs(b_st.p, sb, b_k1.as<uint64_t>(), keys, b_v1.as<uint64_t>(), vals, n_mini, 0, 2 * opts->k, s));
+        SH_HIP(hipStreamSynchronize(s));
+    }
+    // k1/v1 are free for reuse from here: ukeys in k1, start/moff in v1 + extra
+    hipFree(b_k1.p); b_k1.p = nullptr; hipFree(b_v1.p); b_v1.p = nullptr;
+
+    DevBuf b_uk, b_uc, b_nr, b_start, b_mc, b_moff, b_flags, b_npos;
+    SH_HIP(b_uk.alloc(n_mini * 8)); SH_HIP(b_uc.alloc(n_mini * 4 + 4)); SH_HIP(b_nr.alloc(16)); SH_HIP(b_npos.alloc(16));
+    uint64_t n_unique = 0, n_pos = 0;
+    sh_index *idx = new sh_index();
+    idx->device = device; idx->k = opts->k; idx->w = opts->w; idx->n_contigs = n_contigs; idx->n_bases = n_bases;
+    idx->n_minimizers = n_mini;
+    for (uint32_t i = 0; i < n_contigs; ++i) idx->contig_len.push_back(contig_starts[i + 1] - contig_starts[i]);
+    auto bail = [&](sh_status code) { sh_index_free(idx); return code; };
+#define IDX_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { sh_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return bail(e_ == hipErrorOutOfMemory ? SH_ERR_OOM : SH_ERR_HIP); } } while (0)
+
+    if (n_mini > 0) {
+        DevBuf b_t2;
+        size_t sb = 0;
+        IDX_HIP(rocprim::run_length_encode(nullptr, sb, keys, n_mini, b_uk.as<uint64_t>(), b_uc.as<uint32_t>(), b_nr.as<uint64_t>(), s));
+        IDX_HIP(b_t2.alloc(sb));
+        IDX_HIP(rocprim::run_length_encode(b_t2.p, sb, keys, n_mini, b_uk.as<uint64_t>(), b_uc.as<uint32_t>(), b_nr.as<uint64_t>(), s));
+        IDX_HIP(hipMemcpyAsync(&n_unique, b_nr.p, 8, hipMemcpyDeviceToHost, s));
+        IDX_HIP(hipStreamSynchronize(s));
+    }
+    uint32_t lg = 4;
+    while ((1ULL << lg) < 2 * n_unique + 1) ++lg;
+    idx->n_keys = n_unique; idx->lg_slots = lg; idx->n_slots = 1ULL << lg;
+    IDX_HIP(hipMalloc(&idx->d_slots, idx->n_slots * 16));
+    IDX_HIP(hipMemsetAsync(idx->d_slots, 0xff, idx->n_slots * 16, s));
+
+    if (n_unique > 0) {
+        const uint32_t gU = (uint32_t)((n_unique + 255) / 256), gM = (uint32_t)((n_mini + 255) / 256);
+        IDX_HIP(b_start.alloc(n_unique * 8)); IDX_HIP(b_mc.alloc(n_unique * 8)); IDX_HIP(b_moff.alloc(n_unique * 8));
+        IDX_HIP(b_flags.alloc(n_mini));
+        hipLaunchKernelGGL(k_multi_counts, dim3(gU), dim3(256), 0, s, b_uc.as<uint32_t>(), n_unique, b_mc.as<uint64_t>());
+        hipLaunchKernelGGL(k_multi_flags, dim3(gM), dim3(256), 0, s, keys, n_mini, b_flags.as<uint8_t>());
+        {
+            DevBuf t;
+            size_t sb = 0;
+            IDX_HIP(rocprim::exclusive_scan(nullptr, sb, b_uc.as<uint32_t>(), b_start.as<uint64_t>(), (uint64_t)0, n_unique, rocprim::plus<uint64_t>(), s));
+            IDX_HIP(t.alloc(sb));
+            IDX_HIP(rocprim::exclusive_scan(t.p, sb, b_uc.as<uint32_t>(), b_start.as<uint64_t>(), (uint64_t)0, n_unique, rocprim::plus<uint64_t>(), s));
+            IDX_HIP(hipStreamSynchronize(s));
+        }
+        {
+            DevBuf t;
+            size_t sb = 0;
+            IDX_HIP(rocprim::exclusive_scan(nullptr, sb, b_mc.as<uint64_t>(), b_moff.as<uint64_t>(), (uint64_t)0, n_unique, rocprim::plus<uint64_t>(), s));
+            IDX_HIP(t.alloc(sb));
+            IDX_HIP(rocprim::exclusive_scan(t.p, sb, b_mc.as<uint64_t>(), b_moff.as<uint64_t>(), (uint64_t)0, n_unique, rocprim::plus<uint64_t>(), s));
+            IDX_HIP(hipStreamSynchronize(s));
+        }
+        // positions of repeated minimizers, in sorted (hash, position) order
+        IDX_HIP(hipMalloc(&idx->d_positions, (n_mini + 2) * 8));     // upper bound; shrunk below
+        {
+            DevBuf t;
+            size_t sb = 0;
+            IDX_HIP(rocprim::select(nullptr, sb, vals, b_flags.as<uint8_t>(), idx->d_positions, b_npos.as<uint64_t>(), n_mini, s));
+            IDX_HIP(t.alloc(sb));
+            IDX_HIP(rocprim::select(t.p, sb, vals, b_flags.as<uint8_t>(), idx->d_positions, b_npos.as<uint64_t>(), n_mini, s));
+            IDX_HIP(hipMemcpyAsync(&n_pos, b_npos.p, 8, hipMemcpyDeviceToHost, s));
+            IDX_HIP(hipStreamSynchronize(s));
+        }
+        idx->n_positions = n_pos;
+        if (n_pos + 2 < n_mini / 2) {      // most minimizers are singletons: give the slack back
+            uint64_t *small = nullptr;
+            IDX_HIP(hipMalloc(&small, (n_pos + 2) * 8));
+            IDX_HIP(hipMemcpyAsync(small, idx->d_positions, n_pos * 8, hipMemcpyDeviceToDevice, s));
+            IDX_HIP(hipStreamSynchronize(s));
+            hipFree(idx->d_positions);
+            idx->d_positions = small;
+        }
+        DevBuf b_err;
+        IDX_HIP(b_err.alloc(4));
+        IDX_HIP(hipMemsetAsync(b_err.p, 0, 4, s));
+        hipLaunchKernelGGL(k_table_fill, dim3(gU), dim3(256), 0, s, b_uk.as<uint64_t>(), b_uc.as<uint32_t>(), b_start.as<uint64_t>(),
+                           b_moff.as<uint64_t>(), vals, n_unique, (unsigned long long *)idx->d_slots, lg, b_err.as<int>());
+        int err = 0;
+        IDX_HIP(hipMemcpyAsync(&err, b_err.p, 4, hipMemcpyDeviceToHost, s));
+        IDX_HIP(hipStreamSynchronize(s));
+        if (err) { sh_set_error("a minimizer occurs more than 2^28 times"); return bail(SH_ERR_INDEX); }
+    } else {
+        IDX_HIP(hipMalloc(&idx->d_positions, 16));
+    }
+
+    // mm_mapopt_update: mid_occ from the occurrence distribution unless the preset fixes it
+    idx->mid_occ = opts->mid_occ;
+    if (opts->mid_occ <= 0) {
+        int32_t mo = INT32_MAX;
+        if (opts->mid_occ_frac > 0.f && n_unique > 0) {
+            DevBuf b_sorted, t;
+            size_t sb = 0;
+            IDX_HIP(b_sorted.alloc(n_unique * 4));
+            IDX_HIP(rocprim::radix_sort_keys(nullptr, sb, b_uc.as<uint32_t>(), b_sorted.as<uint32_t>(), n_unique, 0, 32, s));
+            IDX_HIP(t.alloc(sb));
+            IDX_HIP(rocprim::radix_sort_keys(t.p, sb, b_uc.as<uint32_t>(), b_sorted.as<uint32_t>(), n_unique, 0, 32, s));
+            uint32_t kth = (uint32_t)((1. - opts->mid_occ_frac) * n_unique), v = 0;
+            IDX_HIP(hipMemcpyAsync(&v, b_sorted.as<uint32_t>() + kth, 4, hipMemcpyDeviceToHost, s));
+            IDX_HIP(hipStreamSynchronize(s));
+            mo = (int32_t)(v + 1);
+        }
+        if (mo < opts->min_mid_occ) mo = opts->min_mid_occ;
+        if (opts->max_mid_occ > opts->min_mid_occ && mo > opts->max_mid_occ) mo = opts->max_mid_occ;
+        idx->mid_occ = mo;
+    }
+    IDX_HIP(hipStreamSynchronize(s));
+    IDX_HIP(hipGetLastError());
+    idx->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *out = idx;
+    return SH_OK;
+#undef IDX_HIP
+}
+
+extern "C" sh_status sh_index_build_device(const uint8_t *d_bases, const uint64_t *contig_starts, uint32_t n_contigs,
+                                           const sh_opts *opts, int32_t device, void *stream, sh_index **out)
+{
+    return shi_index_build_device(d_bases, contig_starts, n_contigs, opts, device, (hipStream_t)stream, out);
+}
+
+extern "C" sh_status sh_index_build(const uint8_t *const *seqs, const uint64_t *lens, uint32_t n_seq,
+                                    const sh_opts *opts, int32_t device, sh_index **out)
+{
+    SH_CHECK(seqs && lens && opts && out && n_seq > 0, SH_ERR_BAD_ARG, "sh_index_build: null/empty argument");
+    SH_HIP(hipSetDevice(device));
+    std::vector<uint64_t> cs(n_seq + 1, 0);
+    for (uint32_t i = 0; i < n_seq; ++i) cs[i + 1] = cs[i] + lens[i];
+    DevBuf d;
+    SH_HIP(d.alloc(cs[n_seq] + 16));
+    for (uint32_t i = 0; i < n_seq; ++i)
+        if (lens[i]) SH_HIP(hipMemcpy(d.as<uint8_t>() + cs[i], seqs[i], lens[i], hipMemcpyHostToDevice));
+    return shi_index_build_device(d.as<uint8_t>(), cs.data(), n_seq, opts, device, nullptr, out);
+}
+
+extern "C" sh_status sh_index_info_get(const sh_index *idx, sh_index_info *o)
+{
+    SH_CHECK(idx && o, SH_ERR_BAD_ARG, "sh_index_info_get: null argument");
+    o->k = idx->k; o->w = idx->w; o->mid_occ = idx->mid_occ; o->n_contigs = idx->n_contigs; o->n_bases = idx->n_bases;
+    o->n_minimizers = idx->n_minimizers; o->n_keys = idx->n_keys; o->n_slots = idx->n_slots; o->n_positions = idx->n_positions;
+    o->hbm_bytes = idx->n_slots * 16 + idx->n_positions * 8; o->build_ms = idx->build_ms;
+    return SH_OK;
+}
+
+extern "C" sh_status sh_index_export(const sh_index *idx, uint64_t *slots, uint64_t *positions)
+{
+    SH_CHECK(idx, SH_ERR_BAD_ARG, "sh_index_export: null index");
+    SH_HIP(hipSetDevice(idx->device));
+    if (slots) SH_HIP(hipMemcpy(slots, idx->d_slots, idx->n_slots * 16, hipMemcpyDeviceToHost));
+    if (positions && idx->n_positions) SH_HIP(hipMemcpy(positions, idx->d_positions, idx->n_positions * 8, hipMemcpyDeviceToHost));
+    return SH_OK;
+}
+
+extern "C" sh_status sh_index_free(sh_index *idx)
+{
+    if (!idx) return SH_OK;
+    hipSetDevice(idx->device);
+    if (idx->d_slots) hipFree(idx->d_slots);
+    if (idx->d_positions) hipFree(idx->d_positions);
+    delete idx;
+    return SH_OK;
+}

@@ -1,0 +1,303 @@
+"""ctypes binding of libscrubby_hip.so (include/scrubby_hip.h).
+
+The library is the product; this module only loads it and marshals arguments.  There is no
+CPU fallback: if the shared object is missing or no MI355X is visible, calls raise.
+torch is used for device memory and streams only (tensor.data_ptr(), current stream).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscrubby_hip.so")
+SYN_MAX_CONTIGS = 64
+
+SH_OK = 0
+STATUS_NAMES = {
+    0: "SH_OK", 1: "SH_ERR_BAD_ARG", 2: "SH_ERR_PRESET_UNKNOWN", 3: "SH_ERR_PRESET_UNSUPPORTED",
+    4: "SH_ERR_NO_DEVICE", 5: "SH_ERR_OOM", 6: "SH_ERR_HIP", 7: "SH_ERR_IO", 8: "SH_ERR_EMPTY_READ",
+    9: "SH_ERR_INDEX",
+}
+SH_ERR_PRESET_UNKNOWN, SH_ERR_PRESET_UNSUPPORTED, SH_ERR_EMPTY_READ = 2, 3, 8
+
+
+class ScrubbyHipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+        self.message = message
+
+
+class Opts(C.Structure):
+    _fields_ = [
+        ("k", C.c_int32), ("w", C.c_int32), ("is_sr", C.c_int32), ("mid_occ", C.c_int32),
+        ("max_occ", C.c_int32), ("max_max_occ", C.c_int32), ("occ_dist", C.c_int32),
+        ("min_mid_occ", C.c_int32), ("max_mid_occ", C.c_int32), ("mid_occ_frac", C.c_float),
+        ("q_occ_frac", C.c_float), ("min_cnt", C.c_int32), ("min_chain_score", C.c_int32),
+        ("max_gap", C.c_int32), ("max_gap_ref", C.c_int32), ("max_frag_len", C.c_int32),
+        ("bw", C.c_int32), ("max_chain_skip", C.c_int32), ("max_chain_iter", C.c_int32),
+        ("chain_gap_scale", C.c_float), ("chain_skip_scale", C.c_float),
+    ]
+
+
+TRACE_FIELDS = ("n_mini", "n_seed", "n_anchor", "rep_len", "rechained", "n_chain", "best_score", "flag")
+TRACE_DTYPE = np.dtype([(n, "<i4") for n in TRACE_FIELDS])
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [
+        ("k", C.c_int32), ("w", C.c_int32), ("mid_occ", C.c_int32), ("n_contigs", C.c_uint32),
+        ("n_bases", C.c_uint64), ("n_minimizers", C.c_uint64), ("n_keys", C.c_uint64),
+        ("n_slots", C.c_uint64), ("n_positions", C.c_uint64), ("hbm_bytes", C.c_uint64),
+        ("build_ms", C.c_double),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_reads", C.c_uint64), ("n_host", C.c_uint64), ("n_no_seed", C.c_uint64),
+        ("n_chain_small", C.c_uint64), ("n_chain_large", C.c_uint64), ("n_minimizers", C.c_uint64),
+        ("n_bases", C.c_uint64), ("ms_sketch_probe", C.c_double), ("ms_chain_small", C.c_double),
+        ("ms_chain_large", C.c_double), ("ms_total", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class RefParams(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64), ("genome_len", C.c_uint64), ("n_contigs", C.c_uint32),
+        ("sb_shift", C.c_uint32), ("rb_shift", C.c_uint32), ("sat_pct", C.c_uint32),
+        ("rep_pct", C.c_uint32), ("n_sat_fam", C.c_uint32), ("n_rep_fam", C.c_uint32),
+        ("pad", C.c_uint32), ("contig_start", C.c_uint64 * (SYN_MAX_CONTIGS + 1)),
+    ]
+
+
+class ReadParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("read_len", C.c_uint32), ("host_pct", C.c_uint32),
+                ("sub_per_10k", C.c_uint32), ("n_read_pct", C.c_uint32)]
+
+
+EXPORTS = [
+    "sh_version", "sh_device_count", "sh_last_error", "sh_preset",
+    "sh_index_build", "sh_index_build_device", "sh_index_build_fasta", "sh_index_save", "sh_index_load",
+    "sh_index_info_get", "sh_index_export", "sh_index_free",
+    "sh_ctx_create", "sh_ctx_destroy", "sh_classify_device", "sh_classify_batch",
+    "sh_synth_ref_device", "sh_synth_reads_device", "sh_bench_gather",
+]
+
+_LIB = None
+
+
+def load():
+    """Load libscrubby_hip.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ScrubbyHipError(4, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32, u32 = C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32
+    L.sh_version.restype = i32
+    L.sh_device_count.restype = i32
+    L.sh_last_error.restype = C.c_char_p
+    L.sh_preset.argtypes = [C.c_char_p, C.POINTER(Opts)]
+    L.sh_index_build.argtypes = [C.POINTER(vp), C.POINTER(u64), u32, C.POINTER(Opts), i32, C.POINTER(vp)]
+    L.sh_index_build_device.argtypes = [vp, C.POINTER(u64), u32, C.POINTER(Opts), i32, vp, C.POINTER(vp)]
+    L.sh_index_build_fasta.argtypes = [C.c_char_p, C.POINTER(Opts), i32, C.POINTER(vp)]
+    L.sh_index_save.argtypes = [vp, C.c_char_p]
+    L.sh_index_load.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+    L.sh_index_info_get.argtypes = [vp, C.POINTER(IndexInfo)]
+    L.sh_index_export.argtypes = [vp, vp, vp]
+    L.sh_index_free.argtypes = [vp]
+    L.sh_ctx_create.argtypes = [vp, C.POINTER(Opts), u64, u64, u32, C.POINTER(vp)]
+    L.sh_ctx_destroy.argtypes = [vp]
+    L.sh_classify_device.argtypes = [vp, vp, vp, u64, u64, vp, vp, vp, C.POINTER(Stats)]
+    L.sh_classify_batch.argtypes = [vp, C.POINTER(Opts), vp, vp, u64, vp, vp, C.POINTER(Stats)]
+    L.sh_synth_ref_device.argtypes = [C.POINTER(RefParams), u64, u64, vp, vp]
+    L.sh_synth_reads_device.argtypes = [C.POINTER(RefParams), C.POINTER(ReadParams), u64, u64, vp, vp, vp]
+    L.sh_bench_gather.argtypes = [vp, u64, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    for name in EXPORTS:
+        if name not in ("sh_version", "sh_device_count", "sh_last_error"):
+            getattr(L, name).restype = i32
+    _LIB = L
+    return L
+
+
+def check(status):
+    if status != SH_OK:
+        raise ScrubbyHipError(status, load().sh_last_error().decode(errors="replace"))
+
+
+def preset(name):
+    o = Opts()
+    check(load().sh_preset(name.encode(), C.byref(o)))
+    return o
+
+
+def require_gpu():
+    L = load()
+    if L.sh_device_count() < 1:
+        raise ScrubbyHipError(4, "no HIP device visible; libscrubby_hip has no CPU path")
+    return L
+
+
+def _stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Index:
+    """Owns an sh_index (table + positions resident in HBM)."""
+
+    def __init__(self, handle, opts):
+        self.h = handle
+        self.opts = opts
+
+    @classmethod
+    def build(cls, seqs, opts, device=0):
+        L = require_gpu()
+        arrs = [np.frombuffer(bytes(s), dtype=np.uint8) if not isinstance(s, np.ndarray) else np.ascontiguousarray(s, dtype=np.uint8)
+                for s in seqs]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        lens = (C.c_uint64 * len(arrs))(*[len(a) for a in arrs])
+        h = C.c_void_p()
+        check(L.sh_index_build(ptrs, lens, len(arrs), C.byref(opts), device, C.byref(h)))
+        return cls(h, opts)
+
+    @classmethod
+    def build_device(cls, d_bases, contig_starts, opts, device=0):
+        """d_bases: torch uint8 CUDA tensor of concatenated contigs."""
+        L = require_gpu()
+        cs = (C.c_uint64 * len(contig_starts))(*[int(x) for x in contig_starts])
+        h = C.c_void_p()
+        check(L.sh_index_build_device(C.c_void_p(d_bases.data_ptr()), cs, len(contig_starts) - 1, C.byref(opts), device,
+                                      _stream_ptr(), C.byref(h)))
+        return cls(h, opts)
+
+    @classmethod
+    def build_fasta(cls, path, opts, device=0):
+        L = require_gpu()
+        h = C.c_void_p()
+        check(L.sh_index_build_fasta(os.fsencode(path), C.byref(opts), device, C.byref(h)))
+        return cls(h, opts)
+
+    @classmethod
+    def load(cls, path, opts, device=0):
+        L = require_gpu()
+        h = C.c_void_p()
+        check(L.sh_index_load(os.fsencode(path), device, C.byref(h)))
+        return cls(h, opts)
+
+    def save(self, path):
+        check(load().sh_index_save(self.h, os.fsencode(path)))
+
+    def info(self):
+        i = IndexInfo()
+        check(load().sh_index_info_get(self.h, C.byref(i)))
+        return {n: getattr(i, n) for n, _ in IndexInfo._fields_}
+
+    def export(self):
+        """(slots uint64[2*n_slots], positions uint64[n_positions]) copied to host."""
+        inf = self.info()
+        slots = np.zeros(2 * inf["n_slots"], dtype=np.uint64)
+        pos = np.zeros(max(inf["n_positions"], 1), dtype=np.uint64)
+        check(load().sh_index_export(self.h, slots.ctypes.data, pos.ctypes.data))
+        return slots, pos[: inf["n_positions"]]
+
+    def classify(self, bases, offsets, want_trace=False):
+        """Host buffers in, host flags (and trace) out: sh_classify_batch."""
+        L = require_gpu()
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        flags = np.zeros(max(n, 1), dtype=np.uint8)
+        tr = np.zeros(max(n, 1), dtype=TRACE_DTYPE) if want_trace else None
+        st = Stats()
+        rc = L.sh_classify_batch(self.h, C.byref(self.opts), bases.ctypes.data, offsets.ctypes.data, n, flags.ctypes.data,
+                                 tr.ctypes.data if want_trace else None, C.byref(st))
+        if rc not in (SH_OK, SH_ERR_EMPTY_READ):
+            check(rc)
+        return flags[:n], (tr[:n] if want_trace else None), st.as_dict(), rc
+
+    def gather_bench(self, n_probes=1 << 28, iters=3):
+        gbs, ms = C.c_double(), C.c_double()
+        check(load().sh_bench_gather(self.h, n_probes, iters, C.byref(gbs), C.byref(ms)))
+        return gbs.value, ms.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().sh_index_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """Owns an sh_ctx: stream-ordered scratch for device-resident batches."""
+
+    def __init__(self, index, max_reads, max_bases, max_read_len):
+        L = require_gpu()
+        self.index = index
+        h = C.c_void_p()
+        check(L.sh_ctx_create(index.h, C.byref(index.opts), max_reads, max_bases, max_read_len, C.byref(h)))
+        self.h = h
+
+    def classify(self, d_bases, d_offsets, d_flags, d_trace=None, want_stats=True):
+        """All arguments are torch CUDA tensors (uint8 / int64-as-uint64 / uint8 / int32[n,8])."""
+        n = d_offsets.numel() - 1
+        st = Stats()
+        check(load().sh_classify_device(self.h, C.c_void_p(d_bases.data_ptr()), C.c_void_p(d_offsets.data_ptr()), n,
+                                        d_bases.numel(), C.c_void_p(d_flags.data_ptr()),
+                                        C.c_void_p(d_trace.data_ptr()) if d_trace is not None else None,
+                                        _stream_ptr(), C.byref(st) if want_stats else None))
+        return st.as_dict() if want_stats else None
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().sh_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ref_params(seed, contig_lens, sb_shift=17, rb_shift=11, sat_pct=6, rep_pct=45, n_sat_fam=64, n_rep_fam=1000):
+    p = RefParams()
+    p.seed = seed
+    p.n_contigs = len(contig_lens)
+    assert p.n_contigs <= SYN_MAX_CONTIGS
+    acc = 0
+    for i, ln in enumerate(contig_lens):
+        p.contig_start[i] = acc
+        acc += ln
+    p.contig_start[len(contig_lens)] = acc
+    p.genome_len = acc
+    p.sb_shift, p.rb_shift, p.sat_pct, p.rep_pct = sb_shift, rb_shift, sat_pct, rep_pct
+    p.n_sat_fam, p.n_rep_fam = n_sat_fam, n_rep_fam
+    return p
+
+
+def read_params(seed, read_len=150, host_pct=50, sub_per_10k=50, n_read_pct=1):
+    r = ReadParams()
+    r.seed, r.read_len, r.host_pct, r.sub_per_10k, r.n_read_pct = seed, read_len, host_pct, sub_per_10k, n_read_pct
+    return r
+
+
+def synth_ref_device(P, g0, n, out):
+    """Fill torch uint8 CUDA tensor `out` (>= n bytes) with reference bases [g0, g0+n)."""
+    check(require_gpu().sh_synth_ref_device(C.byref(P), g0, n, C.c_void_p(out.data_ptr()), _stream_ptr()))
+
+
+def synth_reads_device(P, R, r0, n_records, out, offsets=None):
+    check(require_gpu().sh_synth_reads_device(C.byref(P), C.byref(R), r0, n_records, C.c_void_p(out.data_ptr()),
+                                             C.c_void_p(offsets.data_ptr()) if offsets is not None else None, _stream_ptr()))
