@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py — reads/s depleted on the BASELINE.json workload, one process per GPU.
+
+Workload (BASELINE.json configs[1]): 10 M synthetic 2x150 bp pairs
+(20 M records, 50 % host) classified against a CHM13v2-sized (3 117 292 070 bp, 25 contigs)
+synthetic reference with the `sr` preset.  No network on the GPU box, so the reference and the
+reads are generated on the device from fixed seeds (scrubby_amd/csrc/sh_synth_core.h).
+
+A "step" = one pass of the hot path (sketch+probe -> chain -> flags) over this rank's batch of
+records, inputs already resident in HBM.  With N > 1 every rank holds its own shard of the
+global record space (weak scaling: 20 M records per GPU) and a replica of the index; the only
+exchange is the final union of the depleted-record bitmap (all_gather over RCCL), done inside
+the timed region.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel (k_sketch_probe): algorithmic bytes / HIP-event kernel time vs 8 TB/s
+  cpu_baseline  the CPU oracle (oracle/, "port": restated minimap2 decision path, NOT minimap2-rs)
+                on the host cores, on a bounded sample of the same records and the same index
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from scrubby_amd import lib as S  # noqa: E402
+
+# CHM13v2 sequence lengths (chr1..22, X, Y, M of T2T-CHM13v2.0), total 3 117 292 070 bp
+CHM13_CONTIGS = [248387328, 242696752, 201105948, 193574945, 182045439, 172126628, 160567428, 146259331,
+                 150617247, 134758134, 135127769, 133324548, 113566686, 101161492, 99753195, 96330374,
+                 84276897, 80542538, 61707364, 66210255, 45090682, 51324926, 154259566, 62460029, 16569]
+REF_SEED, READ_SEED = 0x5C2B0010, 0x5C2B0011
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--records", type=int, default=20_000_000, help="records per GPU (2 per pair)")
+    ap.add_argument("--chunk", type=int, default=1 << 22, help="records per kernel launch")
+    ap.add_argument("--small", action="store_true", help="5 Mb reference / 200k records (plumbing check)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--gather-bench", action="store_true", help="also time raw 16-B random gathers over the table")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    S.require_gpu()
+
+    contigs = [1_000_000] * 5 if a.small else CHM13_CONTIGS
+    n_rec = 200_000 if a.small else a.records
+    P = S.ref_params(REF_SEED, contigs)
+    R = S.read_params(READ_SEED)
+    G = P.genome_len
+    opts = S.preset("sr")
+
+    # ---- setup (untimed): reference -> index -> reads, all in HBM -------------------------------------
+    t0 = time.time()
+    d_ref = torch.empty(G + 64, dtype=torch.uint8, device=dev)
+    S.synth_ref_device(P, 0, G, d_ref)
+    torch.cuda.synchronize()
+    t_ref = time.time() - t0
+    t0 = time.time()
+    index = S.Index.build_device(d_ref, [P.contig_start[i] for i in range(len(contigs) + 1)], opts, device=local)
+    torch.cuda.synchronize()
+    t_idx = time.time() - t0
+    info = index.info()
+    del d_ref
+    torch.cuda.empty_cache()
+
+    L = R.read_len
+    d_reads = torch.empty(n_rec * L + 64, dtype=torch.uint8, device=dev)
+    d_off = torch.empty(n_rec + 1, dtype=torch.int64, device=dev)
+    S.synth_reads_device(P, R, rank * n_rec, n_rec, d_reads, d_off)     # this rank's shard of the record space
+    d_flags = torch.zeros(n_rec, dtype=torch.uint8, device=dev)
+    ctx = S.Context(index, min(a.chunk, n_rec), n_rec * L, L)
+    torch.cuda.synchronize()
+
+    n_bits = (n_rec + 7) // 8
+    weights = (2 ** torch.arange(8, device=dev, dtype=torch.int32)).to(torch.uint8)
+    gathered = torch.empty(world * n_bits, dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def step():
+        st = ctx.classify(d_reads[: n_rec * L], d_off, d_flags, None, want_stats=True)
+        if world > 1:   # depleted-record bitmap union: disjoint slices, one all_gather
+            pad = torch.zeros(n_bits * 8, dtype=torch.uint8, device=dev)
+            pad[:n_rec] = (d_flags == 1)
+            bits = (pad.view(-1, 8) * weights).sum(dim=1).to(torch.uint8)
+            dist.all_gather_into_tensor(gathered, bits)
+        return st
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(a.steps):
+        stats.append(step())
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    n_host = int((d_flags == 1).sum().item())
+    ms_step = dt / a.steps * 1e3
+    value = world * n_rec * a.steps / dt
+
+    # ---- roofline of the dominant kernel (HIP events on the launch stream, inside the library) -------
+    k1_ms = float(np.mean([s["ms_sketch_probe"] for s in stats]))      # per step = sum over its launches
+    k2_ms = float(np.mean([s["ms_chain_small"] for s in stats]))
+    k3_ms = float(np.mean([s["ms_chain_large"] for s in stats]))
+    n_launch = (n_rec + ctx_chunk(a, n_rec) - 1) // ctx_chunk(a, n_rec)
+    s0 = stats[-1]
+    # algorithmic bytes of k_sketch_probe per step: L + 8 (offset) + 16 per probe + 1 (flag)
+    alg_bytes = s0["n_bases"] + 9 * s0["n_reads"] + 16 * s0["n_minimizers"]
+    achieved = alg_bytes / n_launch / (k1_ms / n_launch * 1e-3) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": "k_sketch_probe", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "launches_per_step": n_launch, "avg_launch_ms": round(k1_ms / n_launch, 4),
+        "alg_bytes_per_launch": int(alg_bytes / n_launch),
+        "stage_ms_per_step": {"k_sketch_probe": round(k1_ms, 3), "k_chain_small": round(k2_ms, 3), "k_chain_large": round(k3_ms, 3)},
+    }
+    traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+    if os.path.exists(traffic_file) and not a.small:
+        try:
+            tj = json.load(open(traffic_file))
+            if tj.get("records_per_launch") == ctx_chunk(a, n_rec):
+                roofline["traffic"] = tj["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+
+    gather = None
+    if a.gather_bench and rank == 0:
+        gbs, gms = index.gather_bench(1 << 28, 3)
+        gather = {"useful_GBs_16B_probes": round(gbs, 1), "ms": round(gms, 3), "probes": 1 << 28}
+
+    # ---- CPU baseline: the oracle on the host cores, same index, bounded sample -------------------------
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu:
+        cpu = cpu_baseline(index, info, d_reads, n_rec, L, a.cpu_seconds, d_flags)
+
+    if rank == 0:
+        out = {
+            "metric": "reads/s depleted (2x150bp PE vs CHM13v2-sized reference), records classified per second",
+            "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64/i32 (f32 in the chain gap penalty)", "data": "synthetic",
+            "config": {
+                "workload": ("cfg1-small: 200k records vs 5 Mb" if a.small else
+                             "configs[1]: 10M synthetic 2x150bp PE (20M records) vs CHM13v2-sized synthetic reference, sr preset, k-mer/minimizer classifier path"),
+                "records_per_gpu": n_rec, "read_len": L, "host_pct": R.host_pct, "reference_bp": int(G),
+                "preset": "sr", "k": info["k"], "w": info["w"], "records_per_launch": ctx_chunk(a, n_rec),
+                "parallelism": f"read-sharded x{world}, index replicated", "ref_seed": hex(REF_SEED), "read_seed": hex(READ_SEED),
+            },
+            "result": {"reads_removed_rank0": n_host, "n_no_seed": s0["n_no_seed"], "n_chain_small": s0["n_chain_small"],
+                       "n_chain_large": s0["n_chain_large"], "probes": s0["n_minimizers"]},
+            "index": {"n_keys": info["n_keys"], "n_minimizers": info["n_minimizers"], "n_slots": info["n_slots"],
+                      "n_positions": info["n_positions"], "hbm_GB": round(info["hbm_bytes"] / 1e9, 2),
+                      "build_s": round(t_idx, 2), "ref_synth_s": round(t_ref, 2)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if gather:
+            out["gather_ceiling"] = gather
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def ctx_chunk(a, n_rec):
+    return min(a.chunk, n_rec)
+
+
+def cpu_baseline(index, info, d_reads, n_rec, L, seconds, d_flags):
+    """Oracle (port of the decision path) on all host cores over a bounded sample; also a parity spot check."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        avail_gb = int(open("/proc/meminfo").read().split("MemAvailable:")[1].split()[0]) / 1e6
+    except Exception:
+        avail_gb = 0.0
+    need_gb = (info["n_slots"] * 16 + info["n_positions"] * 8) / 1e9 * 1.1 + 2
+    if avail_gb and avail_gb < need_gb:
+        return {"value": None, "unit": "reads/s", "cores": cores, "kind": "port",
+                "sample": f"skipped: host has {avail_gb:.0f} GB free, index copy needs {need_gb:.0f} GB"}
+    slots, pos = index.export()
+    oidx = O.Index.wrap(slots, pos, info["w"], info["k"])
+    oo = O.preset("sr")
+    batch = 50_000
+    done, t_used, mism = 0, 0.0, 0
+    while t_used < seconds and done + batch <= n_rec:
+        reads = d_reads[done * L:(done + batch) * L].cpu().numpy()
+        off = np.arange(batch + 1, dtype=np.uint64) * L
+        t0 = time.perf_counter()
+        fl, _ = oidx.classify(oo, reads, off, threads=cores, want_trace=False)
+        t_used += time.perf_counter() - t0
+        mism += int((fl != d_flags[done:done + batch].cpu().numpy()).sum())
+        done += batch
+    return {"value": round(done / t_used, 1), "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": f"first {done} records of the same batch, same index (copied from HBM), {cores} threads, {t_used:.1f} s; "
+                      f"restatement baseline - not minimap2-rs; flags differing from the GPU on the sample: {mism}"}
+
+
+if __name__ == "__main__":
+    main()

@@ -353,13 +353,15 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
         const uint32_t wi = base + lane;
         bool host = false;
         if (wi < n_work) {
-            const uint32_t r = a.work[wi];
+            const uint32_t entry = a.work[wi];
+            const uint32_t r = entry & 0x7fffffffu;
+            const uint32_t mode = a.mode == 2 ? entry >> 31 : a.mode;     // mode 2: per-entry (deferred reads keep theirs)
             const uint64_t o_beg = a.offsets[r];
             const int32_t qlen = (int32_t)(a.offsets[r + 1] - o_beg);
             int32_t n_mini, n_seed;
             SeedView sv;
             bool defer = false;
-            if (a.mode == 0) {
+            if (mode == 0) {
                 const uint32_t info = a.k1info[r];
                 n_mini = (int32_t)(info & 0xffffu); n_seed = (int32_t)(info >> 16);
                 sv.base = a.records + (size_t)(r >> 6) * a.seed_cap * 64 + (r & 63);
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
             }
             if (defer) {
                 uint32_t li = atomicAdd(&a.ctr->n_defer, 1u);
-                a.work_defer[li] = r;
+                a.work_defer[li] = r | mode << 31;
             }
         }
         uint64_t mh = __ballot(host);
@@ -493,8 +495,8 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         if ((e = hipMalloc(&c->d_work_large[b], max_reads * 4)) != hipSuccess) return fail(e, "work_large");
     if ((e = hipMalloc(&c->d_ctr, sizeof(Counters))) != hipSuccess) return fail(e, "counters");
     if ((e = hipHostMalloc(&c->h_ctr, sizeof(Counters))) != hipSuccess) return fail(e, "pinned counters");
-    // arena: anchors of repeat reads; 64 B per read of the batch, at least 256 MiB
-    c->arena_bytes = std::max<uint64_t>(256ull << 20, max_reads * 256ull);
+    // arena: anchors of repeat reads; 2 KiB per read of the batch, at least 256 MiB (288 GB of HBM to size against)
+    c->arena_bytes = std::max<uint64_t>(256ull << 20, max_reads * 2048ull);
     if (const char *env = getenv("SCRUBBY_HIP_ARENA_MB")) c->arena_bytes = (uint64_t)atoll(env) << 20;
     if ((e = hipMalloc(&c->d_arena, c->arena_bytes)) != hipSuccess) return fail(e, "arena");
     for (auto &ev : c->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "event");
@@ -582,17 +584,16 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     int rounds = 0;
     while (n_defer > 0) {
         SH_CHECK(++rounds < 64, SH_ERR_OOM, "chain arena (%llu MiB) too small for a single read; set SCRUBBY_HIP_ARENA_MB", (unsigned long long)(c->arena_bytes >> 20));
-        // A deferred read may have come from the tile-record lists or from the re-sketch list; re-sketch handles both.
         std::swap(c->d_work_defer, c->d_work_defer2);
         Counters z = *c->h_ctr;
         z.n_defer = 0; z.arena_cursor = 0; z.n_resketch = n_defer;
         SH_HIP(hipMemcpyAsync(c->d_ctr, &z, sizeof(Counters), hipMemcpyHostToDevice, s));
-        b.work = c->d_work_defer2; b.work_count = &c->d_ctr->n_resketch; b.mode = 1; b.work_defer = c->d_work_defer;
+        b.work = c->d_work_defer2; b.work_count = &c->d_ctr->n_resketch; b.mode = 2; b.work_defer = c->d_work_defer;
         hipLaunchKernelGGL(k_chain_large, dim3(grid), dim3(64), 0, s, b);
         SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
         SH_HIP(hipStreamSynchronize(s));
         uint32_t nd = c->h_ctr->n_defer;
-        SH_CHECK(nd < n_defer || rounds < 2, SH_ERR_OOM, "chain arena (%llu MiB) too small; set SCRUBBY_HIP_ARENA_MB", (unsigned long long)(c->arena_bytes >> 20));
+        SH_CHECK(nd < n_defer, SH_ERR_OOM, "chain arena (%llu MiB) too small; set SCRUBBY_HIP_ARENA_MB", (unsigned long long)(c->arena_bytes >> 20));
         n_defer = nd;
         (void)n_resk_left;
     }

@@ -1,0 +1,188 @@
+"""GPU parity: libscrubby_hip (through its C ABI) vs the CPU oracle, bit-exact.
+
+Every comparison is on integers: reference bytes, index content, per-read decision trace
+(n_mini, n_seed, n_anchor, rep_len, rechained, n_chain, best_score) and the flag.
+"""
+import numpy as np
+import pytest
+
+from tests import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    from scrubby_amd import lib
+    lib.require_gpu()
+    return lib
+
+
+@pytest.fixture(scope="module")
+def cfg1(oracle):
+    return W.cfg1(oracle, 20000)
+
+
+@pytest.fixture(scope="module")
+def gpu_index(S, cfg1):
+    P, R, ref, seqs, reads, off = cfg1
+    return S.Index.build([bytes(s) for s in seqs], S.preset("sr"))
+
+
+@pytest.fixture(scope="module")
+def cpu_index(oracle, cfg1):
+    P, R, ref, seqs, reads, off = cfg1
+    return oracle.Index.build(seqs, 11, 21)
+
+
+def assert_trace_equal(S, gf, gt, of, ot):
+    assert np.array_equal(gf, of), f"{int((gf != of).sum())} flags differ"
+    for name in S.TRACE_FIELDS:
+        bad = np.where(gt[name] != ot[name])[0]
+        assert len(bad) == 0, f"trace.{name}: {len(bad)} differ, first read {bad[0]}: gpu={gt[name][bad[0]]} cpu={ot[name][bad[0]]}"
+
+
+def test_presets_match_oracle(S, oracle):
+    for name in ("sr", "map-ont", "lr:hq"):
+        g, o = S.preset(name), oracle.preset(name)
+        for f, _ in S.Opts._fields_:
+            assert getattr(g, f) == getattr(o, f), (name, f)
+
+
+def test_synth_device_matches_cpu(S, oracle, cfg1):
+    import torch
+    P, R, ref, seqs, reads, off = cfg1
+    Pg, Rg = S.ref_params(W.CFG1_REF_SEED, W.CFG1_CONTIGS), S.read_params(W.CFG1_READ_SEED)
+    d = torch.empty(P.genome_len + 64, dtype=torch.uint8, device="cuda")
+    S.synth_ref_device(Pg, 0, P.genome_len, d)
+    assert np.array_equal(d[:P.genome_len].cpu().numpy(), ref)
+    n = len(off) - 1
+    dr = torch.empty(n * 150 + 64, dtype=torch.uint8, device="cuda")
+    do = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    S.synth_reads_device(Pg, Rg, 0, n, dr, do)
+    assert np.array_equal(dr[:n * 150].cpu().numpy(), reads)
+    assert np.array_equal(do.cpu().numpy().astype(np.uint64), off)
+
+
+def test_index_content_identical(S, oracle, gpu_index, cpu_index):
+    slots, pos = gpu_index.export()
+    wrapped = oracle.Index.wrap(slots, pos, 11, 21)
+    k1, c1, p1 = wrapped.dump()
+    k2, c2, p2 = cpu_index.dump()
+    assert np.array_equal(k1, k2) and np.array_equal(c1, c2) and np.array_equal(p1, p2)
+    info = gpu_index.info()
+    assert info["n_keys"] == len(k2) and info["n_minimizers"] == int(c2.sum())
+
+
+def test_index_device_build_equals_host_build(S, oracle, cfg1, gpu_index):
+    import torch
+    P, R, ref, seqs, reads, off = cfg1
+    d = torch.from_numpy(np.concatenate([ref, np.zeros(64, np.uint8)])).cuda()
+    idx2 = S.Index.build_device(d, [P.contig_start[i] for i in range(len(W.CFG1_CONTIGS) + 1)], S.preset("sr"))
+    a = oracle.Index.wrap(*gpu_index.export(), 11, 21).dump()
+    b = oracle.Index.wrap(*idx2.export(), 11, 21).dump()
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_classify_cfg1_trace_parity(S, oracle, cfg1, gpu_index, cpu_index):
+    P, R, ref, seqs, reads, off = cfg1
+    gf, gt, st, rc = gpu_index.classify(reads, off, want_trace=True)
+    of, ot = cpu_index.classify(oracle.preset("sr"), reads, off, threads=8)
+    assert rc == 0
+    assert_trace_equal(S, gf, gt, of, ot)
+    truth = oracle.synth_truth(P, R, 0, len(gf))
+    assert int(gf.sum()) == int(truth.sum()) == st["n_host"]      # reads_removed count
+    assert st["n_chain_large"] > 0 and st["n_chain_small"] > 0 and st["n_no_seed"] > 0   # every kernel exercised
+
+
+def test_classify_flag_only_equals_trace_mode(S, oracle, cfg1, gpu_index):
+    P, R, ref, seqs, reads, off = cfg1
+    f1, _, _, _ = gpu_index.classify(reads, off, want_trace=False)
+    f2, _, _, _ = gpu_index.classify(reads, off, want_trace=True)
+    assert np.array_equal(f1, f2)
+
+
+def test_edge_cases(S, oracle, cfg1, gpu_index, cpu_index):
+    P, R, ref, seqs, reads, off = cfg1
+    recs, bases, offs = W.edge_reads(ref)
+    gf, gt, st, rc = gpu_index.classify(bases, offs, want_trace=True)
+    of, ot = cpu_index.classify(oracle.preset("sr"), bases, offs, threads=1)
+    assert_trace_equal(S, gf, gt, of, ot)
+    assert gf[0] == 2 and rc == S.SH_ERR_EMPTY_READ        # reference: Err("Sequence is empty") aborts the run
+    assert gf[6] == 1                                       # lower-case host read maps
+
+
+def test_misaligned_and_offset_batches(S, oracle, cfg1, gpu_index, cpu_index):
+    """offsets[0] != 0 and a base pointer that is not 16-B aligned."""
+    P, R, ref, seqs, reads, off = cfg1
+    n = 1000
+    pad = np.concatenate([np.frombuffer(b"GATTACA", dtype=np.uint8), reads[: n * 150]])
+    off2 = off[: n + 1] + np.uint64(7)
+    gf, gt, st, rc = gpu_index.classify(pad, off2, want_trace=True)
+    of, ot = cpu_index.classify(oracle.preset("sr"), reads[: n * 150], off[: n + 1], threads=2)
+    assert_trace_equal(S, gf, gt, of, ot)
+
+
+def test_device_context_repeatable_and_chunked(S, oracle, cfg1, gpu_index, cpu_index):
+    import torch
+    P, R, ref, seqs, reads, off = cfg1
+    n = len(off) - 1
+    d_reads = torch.from_numpy(np.concatenate([reads, np.zeros(64, np.uint8)])).cuda()
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    of, ot = cpu_index.classify(oracle.preset("sr"), reads, off, threads=8)
+    for chunk in (n, 4096 + 64):                     # one launch, and several launches with a ragged tail
+        ctx = S.Context(gpu_index, chunk, n * 150, 150)
+        fl = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        tr = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+        for _ in range(2):
+            ctx.classify(d_reads[: n * 150], d_off, fl, tr)
+        gt = tr.cpu().numpy().view(S.TRACE_DTYPE).reshape(-1)
+        assert_trace_equal(S, fl.cpu().numpy(), gt, of, ot)
+        ctx.close()
+
+
+def test_small_arena_defers_and_still_matches(S, oracle, cfg1, gpu_index, cpu_index, monkeypatch):
+    """A chain arena too small for the batch forces the deferral loop; results must not change."""
+    P, R, ref, seqs, reads, off = cfg1
+    monkeypatch.setenv("SCRUBBY_HIP_ARENA_MB", "8")
+    gf, gt, st, rc = gpu_index.classify(reads, off, want_trace=True)
+    of, ot = cpu_index.classify(oracle.preset("sr"), reads, off, threads=8)
+    assert_trace_equal(S, gf, gt, of, ot)
+
+
+def test_map_ont_preset_short_reads(S, oracle, cfg1):
+    """k=15,w=10, mid_occ derived from the index (mm_mapopt_update)."""
+    P, R, ref, seqs, reads, off = cfg1
+    go = S.preset("map-ont")
+    gidx = S.Index.build([bytes(s) for s in seqs], go)
+    cidx = oracle.Index.build(seqs, 10, 15)
+    oo = cidx.update_opts(oracle.preset("map-ont"))
+    assert gidx.info()["mid_occ"] == oo.mid_occ
+    n = 4000
+    gf, gt, st, rc = gidx.classify(reads[: n * 150], off[: n + 1], want_trace=True)
+    of, ot = cidx.classify(oo, reads[: n * 150], off[: n + 1], threads=8)
+    assert_trace_equal(S, gf, gt, of, ot)
+
+
+def test_idempotent_and_order_independent(S, cfg1, gpu_index):
+    """Size-independent properties: same batch twice -> same flags; permuting records permutes flags."""
+    P, R, ref, seqs, reads, off = cfg1
+    n = 5000
+    f1, _, _, _ = gpu_index.classify(reads[: n * 150], off[: n + 1])
+    f2, _, _, _ = gpu_index.classify(reads[: n * 150], off[: n + 1])
+    assert np.array_equal(f1, f2)
+    perm = np.random.default_rng(3).permutation(n)
+    shuf = reads[: n * 150].reshape(n, 150)[perm].reshape(-1)
+    f3, _, _, _ = gpu_index.classify(shuf, off[: n + 1])
+    assert np.array_equal(f3, f1[perm])
+
+
+def test_index_save_load_roundtrip(S, cfg1, gpu_index, tmp_path):
+    P, R, ref, seqs, reads, off = cfg1
+    path = str(tmp_path / "mini.shidx")
+    gpu_index.save(path)
+    idx2 = S.Index.load(path, S.preset("sr"))
+    n = 2000
+    f1, t1, _, _ = gpu_index.classify(reads[: n * 150], off[: n + 1], want_trace=True)
+    f2, t2, _, _ = idx2.classify(reads[: n * 150], off[: n + 1], want_trace=True)
+    assert np.array_equal(f1, f2) and np.array_equal(t1, t2)
