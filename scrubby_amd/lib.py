@@ -98,6 +98,9 @@ def load():
         return _LIB
     if not os.path.exists(LIB_PATH):
         raise ScrubbyHipError(4, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    # torch ships its own libamdhip64; load it first so that this process has ONE HIP runtime
+    # (device memory and streams come from torch, kernels from this library)
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, u64, i32, u32 = C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32
     L.sh_version.restype = i32
