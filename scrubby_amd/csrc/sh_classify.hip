@@ -16,9 +16,20 @@
 //        Reads without a single hit are final here (flag 0): no anchor => no mapping.
 //   K2 k_chain_small    one lane per read with >=1 seed: occurrence filter, anchors, chaining DP and
 //        backtrack entirely in LDS (11 B per anchor, lane-interleaved), up to CAP anchors.
-//   K3 k_chain_large    the same code over per-read slices of an HBM arena for reads with more
-//        anchors (repeats) — binned by anchor count so that the lanes of a wave carry similar work —
-//        and for the rare reads K1 could not finish (seed/list overflow), which it re-sketches.
+//   K3 the repeat path, for reads with more anchors (29 % of the host reads of the CHM13-sized
+//        workload, carrying 90 % of all anchors).  Sorted anchors split into CLUSTERS at every gap
+//        > max_dist_x (or strand / contig change); the chaining DP window, its max_ii shortcut and
+//        the backtrack never cross such a gap, so clusters are independent DP problems and the
+//        per-read result is (sum of chains, max score) over its clusters:
+//          k_expand       one wave per read: lane-per-seed occurrence filter (mm_seed_select by ballots),
+//                         anchors written coalesced to the HBM arena, <= 64 anchors sorted in registers
+//          k_sort         one wave per longer read: 64-anchor tiles ranked in registers, then merge-path
+//                         rounds between two arena buffers; cluster boundaries by ballot
+//          k_dp_small     one lane per cluster of <= 32 anchors, DP + backtrack in LDS (the K2 code)
+//          k_dp_big       larger clusters over arena slices
+//          k_finalize     per read: flag / trace, or hand the read to the second (max_occ) pass
+//   k_chain_large   legacy lane-per-read path over arena slices, kept for the rare reads K1 could not
+//        finish (seed/list overflow), which it re-sketches.
 //
 // Results are bit-identical to oracle/mm_oracle.c (tests/test_parity_gpu.py).
 #include "sh_common.h"
@@ -29,11 +40,12 @@
 #define K1_LIST_CAP 32          // queued minimizers per lane between two probe phases
 #define K1_FLUSH_AT 16
 #define K2_CAP 32               // anchors per read chained in LDS
-#define N_BUCKETS 6             // (32,128] (128,512] (512,2048] (2048,8192] (8192,32768] >32768
+#define DP_SMALL_CAP 32         // anchors per cluster chained in LDS
 
 struct Counters {
-    uint32_t n_small, n_resketch, n_large[N_BUCKETS], n_defer, n_noseed, n_host, n_done_small, n_done_large, pad;
-    unsigned long long arena_cursor, sum_mini;
+    uint32_t n_small, n_resketch, n_big[2], n_big_defer[2], n_defer, n_noseed, n_host;
+    uint32_t n_sort, n_clus_small, n_clus_big, n_big_total, n_clusters_total, pad;
+    unsigned long long arena_cursor, sum_mini, anchor_cursor, sum_anchors;
 };
 
 __device__ inline uint32_t lane_id() { return threadIdx.x & 63; }
@@ -253,9 +265,21 @@ __global__ void k_route_all(uint64_t n_reads, uint32_t *work_resketch, Counters 
     if (r == 0) ctr->n_resketch = (uint32_t)n_reads;
 }
 
+
 // ------------------------------------------------------------------------------------------------
 // K2 / K3
 // ------------------------------------------------------------------------------------------------
+struct BigMeta { uint32_t r, n_a; int32_t rep_len; uint32_t state; };   // state: 0 expanded, 1 deferred
+struct SortItem { uint32_t w, n, qlen, pad; unsigned long long off; };
+struct ClusterDesc { unsigned long long off; uint32_t len, w; uint32_t qlen, pad; };
+
+struct BigBufs {        // the repeat path's slice of the arena (all arrays indexed by anchor slot)
+    uint64_t *ax, *bx, *az; uint32_t *aq, *bq; int32_t *af, *ap, *at;
+    unsigned long long anchor_cap;
+    BigMeta *meta; int32_t *acc_nu, *acc_best;
+    SortItem *sort_items; ClusterDesc *clus_small, *clus_big;
+};
+
 struct K2Args {
     const uint64_t *offsets; const uint8_t *bases; uint64_t n_reads;
     const uint4 *slots; uint32_t lg_slots; int32_t w;
@@ -263,19 +287,12 @@ struct K2Args {
     uint4 *records; uint32_t seed_cap;
     const uint32_t *k1info; uint8_t *flags; sh_trace *trace;
     const uint32_t *work; const uint32_t *work_count;        // input list
-    uint32_t *work_large[N_BUCKETS]; uint32_t *work_defer;   // outputs
+    uint32_t *work_big; uint32_t *work_defer;                // outputs
     Counters *ctr;
     uint8_t *arena; unsigned long long arena_bytes;
     ChainParams P;
-    uint32_t mode;       // K3: 0 = seeds from tile records, 1 = re-sketch
+    uint32_t mode;       // k_chain_large: 0 = seeds from tile records, 1 = re-sketch, 2 = per entry
 };
-
-__device__ inline int bucket_of(int64_t n_a)
-{
-    int lg = 63 - __clzll((unsigned long long)(n_a - 1));   // n_a > 32  =>  lg >= 5
-    int b = (lg - 5) >> 1;
-    return b < N_BUCKETS - 1 ? b : N_BUCKETS - 1;
-}
 
 __device__ inline void finish_read(const K2Args &a, uint32_t r, int32_t n_mini, int32_t n_seed, int64_t n_a, int32_t rep_len,
                                    int32_t rechained, int32_t n_u, int32_t best)
@@ -300,9 +317,10 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
     for (uint32_t base = blockIdx.x * 64; base < n_work; base += gridDim.x * 64) {
         const uint32_t wi = base + lane;
         const bool valid = wi < n_work;
-        bool host = false;
+        bool host = false, routed = false;
+        uint32_t r = 0;
         if (valid) {
-            const uint32_t r = a.work[wi];
+            r = a.work[wi];
             const uint32_t info = a.k1info[r];
             const int32_t n_mini = (int32_t)(info & 0xffffu), n_seed = (int32_t)(info >> 16);
             const int32_t qlen = (int32_t)(a.offsets[r + 1] - a.offsets[r]);
@@ -311,7 +329,6 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
             sv.stride = 64; sv.n = (uint32_t)n_seed;
             int32_t max_occ = a.P.mid_occ, rechained = 0, n_u = 0, best = 0, rep_len = 0;
             int64_t n_a = 0;
-            bool routed = false;
             for (;;) {
                 seed_filter(sv, qlen, max_occ, a.P, n_a, rep_len);
                 if (n_a > CAP) { routed = true; break; }
@@ -321,17 +338,352 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
                 if (!rechained && n_u == 0 && a.P.max_occ > a.P.mid_occ && rep_len > 0) { rechained = 1; max_occ = a.P.max_occ; continue; }
                 break;
             }
-            if (routed) {
-                int b = bucket_of(n_a);
-                uint32_t li = atomicAdd(&a.ctr->n_large[b], 1u);
-                a.work_large[b][li] = r;
-            } else {
+            if (!routed) {
                 finish_read(a, r, n_mini, n_seed, n_a, rep_len, rechained, n_u, best);
                 host = n_u > 0;
             }
         }
+        uint32_t bi = wave_append(&a.ctr->n_big[0], routed);     // the repeat path starts every read at pass 0
+        if (routed) a.work_big[bi] = r;
         uint64_t mh = __ballot(host);
         if (lane == 0 && mh) atomicAdd(&a.ctr->n_host, (uint32_t)__popcll(mh));
+    }
+}
+
+// ---- wave helpers ------------------------------------------------------------------------------------
+__device__ inline uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ inline uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+    return v;
+}
+__device__ inline uint32_t wave_excl_scan_u32(uint32_t v, uint32_t lane)
+{
+    uint32_t s = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)s, o); if (lane >= (uint32_t)o) s += t; }
+    return s - v;
+}
+// stable sort of the first n lanes' (x, q) by x: rank by comparison with every broadcast key, then push
+__device__ inline void wave_rank_sort(uint64_t &x, uint32_t &q, uint32_t n, uint32_t lane)
+{
+    uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+    uint32_t rank = 0;
+    for (uint32_t b = 0; b < n; ++b) {
+        uint64_t xb = (uint64_t)rdlane(xh, b) << 32 | rdlane(xl, b);
+        rank += (xb < x) || (xb == x && b < lane);
+    }
+    if (lane >= n) rank = lane;
+    int addr = (int)(rank * 4);
+    xl = (uint32_t)__builtin_amdgcn_ds_permute(addr, (int)xl);
+    xh = (uint32_t)__builtin_amdgcn_ds_permute(addr, (int)xh);
+    q = (uint32_t)__builtin_amdgcn_ds_permute(addr, (int)q);
+    x = (uint64_t)xh << 32 | xl;
+}
+
+struct ClusterSink {
+    ClusterDesc *small, *big; Counters *ctr;
+    uint32_t w, qlen; bool keep_single;
+    // every lane calls; pred lanes append the cluster [start, start+len) of this read
+    __device__ inline void emit(bool pred, unsigned long long start, uint32_t len)
+    {
+        pred = pred && (len >= 2 || keep_single);
+        bool sm = pred && len <= DP_SMALL_CAP, bg = pred && len > DP_SMALL_CAP;
+        uint32_t i = wave_append(&ctr->n_clus_small, sm);
+        if (sm) { ClusterDesc d{start, len, w, qlen, 0}; small[i] = d; }
+        i = wave_append(&ctr->n_clus_big, bg);
+        if (bg) { ClusterDesc d{start, len, w, qlen, 0}; big[i] = d; }
+    }
+};
+
+// cluster boundaries of one tile of sorted anchors held in registers (lane i <-> anchor base+i);
+// `open_start` (uniform) = start of the cluster still open from earlier tiles
+__device__ inline void tile_clusters(ClusterSink &sink, uint64_t x, uint64_t x_prev_tile, bool has_prev_tile, uint32_t cnt,
+                                     uint32_t lane, unsigned long long off, uint32_t base, uint32_t &open_start, uint32_t max_dist_x)
+{
+    uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+    uint32_t pl = (uint32_t)__shfl_up((int)xl, 1), ph = (uint32_t)__shfl_up((int)xh, 1);
+    if (lane == 0) { pl = (uint32_t)x_prev_tile; ph = (uint32_t)(x_prev_tile >> 32); }
+    bool first = lane == 0 && !has_prev_tile;
+    bool bnd = lane < cnt && (first || xh != ph || xl - pl > max_dist_x);
+    uint64_t bm = __ballot(bnd);
+    // a boundary closes the cluster that started at the previous boundary
+    uint64_t below = bm & ((1ULL << lane) - 1);
+    uint32_t prev_start = below ? base + (63 - __clzll((unsigned long long)below)) : open_start;
+    bool closes = bnd && !first;
+    sink.emit(closes, off + prev_start, base + lane - prev_start);
+    if (bm) open_start = base + (63 - __clzll((unsigned long long)bm));
+}
+
+struct K3Args {
+    const uint64_t *offsets; const uint64_t *positions;
+    uint4 *records; uint32_t seed_cap;
+    const uint32_t *k1info; uint8_t *flags; sh_trace *trace;
+    const uint32_t *list; const uint32_t *list_count;     // reads of this pass
+    uint32_t *defer_list; uint32_t *defer_count;          // reads that found no arena space
+    uint32_t *next_list; uint32_t *next_count;            // pass 0: reads that must re-chain with max_occ
+    Counters *ctr; BigBufs B; ChainParams P;
+    int32_t pass, max_occ, flag_only;
+};
+
+__device__ inline uint32_t chain_max_dist_x(const ChainParams &P, int32_t qlen)
+{
+    int32_t m;
+    if (P.max_gap_ref > 0) m = P.max_gap_ref;
+    else if (P.max_frag_len > 0) { m = P.max_frag_len - qlen; if (m < P.max_gap) m = P.max_gap; }
+    else m = P.max_gap;
+    if (m < P.bw) m = P.bw;
+    return (uint32_t)m;
+}
+
+// one wave per read: seeds -> filter -> anchors (arena) -> [<= 64: sort + clusters]
+__global__ __launch_bounds__(64) void k_expand(K3Args a)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_items = *a.list_count;
+    const ChainParams &P = a.P;
+    for (uint32_t w = blockIdx.x; w < n_items; w += gridDim.x) {
+        const uint32_t r = a.list[w];
+        const uint32_t info = a.k1info[r];
+        const uint32_t n_seed = info >> 16;
+        const int32_t qlen = (int32_t)(a.offsets[r + 1] - a.offsets[r]);
+        const bool have = lane < n_seed;
+        uint4 *recp = a.records + (size_t)(r >> 6) * a.seed_cap * 64 + (r & 63) + (size_t)lane * 64;
+        uint4 rec = have ? *recp : make_uint4(0, 0, 0, 0);
+        const uint32_t occ = rec.z & 0x7fffffffu, qposz = rec.w;
+        const uint64_t w1 = (uint64_t)rec.y << 32 | rec.x;
+        // ---- mm_seed_select / occurrence cut, one seed per lane ----
+        const bool high = have && occ > (uint32_t)a.max_occ;
+        bool flt = false;
+        if (!(P.occ_dist > 0 && P.max_max_occ > a.max_occ)) flt = high;
+        else {
+            const uint64_t hm = __ballot(high);
+            if (n_seed >= 2 && hm != 0) {
+                const uint64_t low = __ballot(have && !high);
+                const uint64_t below = low & ((1ULL << lane) - 1);
+                const uint64_t above = lane >= 63 ? 0 : low & ~((2ULL << lane) - 1);
+                const int32_t last0 = below ? 63 - __clzll((unsigned long long)below) : -1;
+                const int32_t nxt = above ? __ffsll((unsigned long long)above) - 1 : (int32_t)n_seed;
+                const uint32_t qp_last = (uint32_t)__shfl((int)qposz, last0 < 0 ? 0 : last0);
+                const uint32_t qp_next = (uint32_t)__shfl((int)qposz, nxt >= (int32_t)n_seed ? 0 : nxt);
+                const int32_t ps = last0 < 0 ? 0 : (int32_t)(qp_last >> 1);
+                const int32_t pe = nxt >= (int32_t)n_seed ? qlen : (int32_t)(qp_next >> 1);
+                int32_t mho = (int32_t)((double)(pe - ps) / (double)P.occ_dist + .499);
+                if (mho > 128) mho = 128;
+                int32_t rank = 0;
+                for (uint32_t t = 0; t < n_seed; ++t) {
+                    uint32_t ot = rdlane(occ, t);
+                    bool in = (int32_t)t > last0 && (int32_t)t < nxt;
+                    rank += in && (ot < occ || (ot == occ && t < lane));
+                }
+                if (high) {
+                    flt = !(mho > 0 && rank < mho);
+                    if (occ > (uint32_t)P.max_max_occ) flt = true;
+                }
+            }
+        }
+        // rep_len: union length of the filtered seeds' query intervals
+        const uint64_t fm = __ballot(flt);
+        int32_t contrib = 0;
+        {
+            const int32_t en = (int32_t)(qposz >> 1) + 1, st = en - P.k;
+            const uint64_t belowf = fm & ((1ULL << lane) - 1);
+            const int32_t prev_en_l = (int32_t)(__shfl((int)qposz, belowf ? 63 - __clzll((unsigned long long)belowf) : 0) >> 1) + 1;
+            const int32_t prev_en = belowf ? prev_en_l : 0;
+            if (flt) contrib = en - (st > prev_en ? st : prev_en);
+        }
+        const int32_t rep_len = (int32_t)wave_sum_u32((uint32_t)contrib);
+        const uint32_t my_n = (have && !flt) ? occ : 0u;
+        // anchor count can exceed 32 bits only for absurd inputs; saturate (such a read can never get arena space)
+        unsigned long long n_a64 = my_n;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) n_a64 += (unsigned long long)__shfl_xor((long long)n_a64, o);
+        const uint32_t n_a = n_a64 > 0x7fffffffull ? 0x7fffffffu : (uint32_t)n_a64;
+        if (have) recp->z = occ | (uint32_t)flt << 31;
+
+        unsigned long long off = 0;
+        if (lane == 0 && n_a > 0) off = atomicAdd(&a.ctr->anchor_cursor, (unsigned long long)n_a);
+        off = (unsigned long long)__shfl((long long)off, 0);
+        const bool defer = n_a > 0 && off + n_a > a.B.anchor_cap;
+        if (lane == 0) {
+            BigMeta m{r, n_a, rep_len, defer ? 1u : 0u};
+            a.B.meta[w] = m; a.B.acc_nu[w] = 0; a.B.acc_best[w] = 0;
+            if (defer) { uint32_t di = atomicAdd(a.defer_count, 1u); a.defer_list[di] = r; }
+            else atomicAdd(&a.ctr->sum_anchors, (unsigned long long)n_a);
+        }
+        if (defer || n_a == 0) continue;
+
+        // ---- anchors in generation order (seed order, then occurrence order) ----
+        const uint32_t start = wave_excl_scan_u32(my_n, lane);
+        const bool any_multi = __ballot(my_n > 1) != 0;
+        if (!any_multi) {
+            if (my_n == 1) {
+                uint64_t x; uint32_t q;
+                make_anchor(w1, qposz, qlen, P.k, x, q);
+                a.B.ax[off + start] = x; a.B.aq[off + start] = q;
+            }
+        } else {
+            for (uint32_t s = 0; s < n_seed; ++s) {
+                const uint32_t os = rdlane(my_n, s);
+                if (os == 0) continue;
+                const uint32_t ss = rdlane(start, s), sq = rdlane(qposz, s);
+                const uint64_t sw1 = (uint64_t)rdlane((uint32_t)(w1 >> 32), s) << 32 | rdlane((uint32_t)w1, s);
+                const uint64_t *cr = a.positions + (sw1 >> SH_SLOT_NBITS);
+                for (uint32_t t = lane; t < os; t += 64) {
+                    uint64_t x; uint32_t q;
+                    make_anchor(os == 1 ? sw1 : cr[t], sq, qlen, P.k, x, q);
+                    a.B.ax[off + ss + t] = x; a.B.aq[off + ss + t] = q;
+                }
+            }
+        }
+        __syncthreads();
+        if (n_a <= 64) {
+            uint64_t x = lane < n_a ? a.B.ax[off + lane] : ~0ull;
+            uint32_t q = lane < n_a ? a.B.aq[off + lane] : 0u;
+            uint64_t xp = (uint64_t)__shfl_up((long long)x, 1);
+            bool unsorted = __ballot(lane > 0 && lane < n_a && x < xp) != 0;
+            if (unsorted) {
+                wave_rank_sort(x, q, n_a, lane);
+                if (lane < n_a) { a.B.ax[off + lane] = x; a.B.aq[off + lane] = q; }
+            }
+            ClusterSink sink{a.B.clus_small, a.B.clus_big, a.ctr, w, (uint32_t)qlen, !(P.k < P.min_sc || P.min_cnt > 1)};
+            uint32_t open_start = 0;
+            tile_clusters(sink, x, 0, false, n_a, lane, off, 0, open_start, chain_max_dist_x(P, qlen));
+            sink.emit(lane == 0, off + open_start, n_a - open_start);
+        } else if (lane == 0) {
+            uint32_t si = atomicAdd(&a.ctr->n_sort, 1u);
+            SortItem it{w, n_a, (uint32_t)qlen, 0, off};
+            a.B.sort_items[si] = it;
+        }
+    }
+}
+
+// one wave per read with > 64 anchors: stable merge sort in the arena, then clusters
+__global__ __launch_bounds__(64) void k_sort(K3Args a)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_items = a.ctr->n_sort;
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const SortItem si = a.B.sort_items[it];
+        const uint32_t n = si.n;
+        uint64_t *sx = a.B.ax + si.off, *dx = a.B.bx + si.off;
+        uint32_t *sq = a.B.aq + si.off, *dq = a.B.bq + si.off;
+        // tiles of 64 ranked in registers
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t cnt = n - base < 64 ? n - base : 64;
+            uint64_t x = lane < cnt ? sx[base + lane] : ~0ull;
+            uint32_t q = lane < cnt ? sq[base + lane] : 0u;
+            uint64_t xp = (uint64_t)__shfl_up((long long)x, 1);
+            if (__ballot(lane > 0 && lane < cnt && x < xp) != 0) {
+                wave_rank_sort(x, q, cnt, lane);
+                if (lane < cnt) { sx[base + lane] = x; sq[base + lane] = q; }
+            }
+        }
+        __syncthreads();
+        // merge-path rounds: each lane produces chunks of C consecutive outputs
+        const uint32_t C = 16;
+        const uint32_t n_chunks = (n + C - 1) / C;
+        for (uint32_t width = 64; width < n; width <<= 1) {
+            for (uint32_t c = lane; c < n_chunks; c += 64) {
+                const uint32_t o0 = c * C, o1 = o0 + C < n ? o0 + C : n;
+                const uint32_t pb = o0 / (2 * width) * (2 * width);
+                const uint32_t L0 = pb, L1 = pb + width < n ? pb + width : n, R1 = pb + 2 * width < n ? pb + 2 * width : n;
+                const uint32_t lenL = L1 - L0, lenR = R1 - L1, d = o0 - pb;
+                uint32_t lo = d > lenR ? d - lenR : 0, hi = d < lenL ? d : lenL;
+                while (lo < hi) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    if (sx[L0 + mid] <= sx[L1 + (d - 1 - mid)]) lo = mid + 1; else hi = mid;
+                }
+                uint32_t ia = L0 + lo, ib = L1 + (d - lo);
+                for (uint32_t o = o0; o < o1; ++o) {
+                    bool takeL = ia < L1 && (ib >= R1 || sx[ia] <= sx[ib]);
+                    uint32_t src = takeL ? ia : ib;
+                    dx[o] = sx[src]; dq[o] = sq[src];
+                    ia += takeL; ib += !takeL;
+                }
+            }
+            __syncthreads();
+            uint64_t *tx = sx; sx = dx; dx = tx; uint32_t *tq = sq; sq = dq; dq = tq;
+        }
+        if (sx != a.B.ax + si.off) {     // odd number of rounds: bring the result home
+            for (uint32_t i = lane; i < n; i += 64) { dx[i] = sx[i]; dq[i] = sq[i]; }
+            __syncthreads();
+            sx = dx;
+        }
+        // clusters
+        ClusterSink sink{a.B.clus_small, a.B.clus_big, a.ctr, si.w, si.qlen, !(a.P.k < a.P.min_sc || a.P.min_cnt > 1)};
+        const uint32_t mdx = chain_max_dist_x(a.P, (int32_t)si.qlen);
+        uint32_t open_start = 0;
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t cnt = n - base < 64 ? n - base : 64;
+            uint64_t x = lane < cnt ? sx[base + lane] : ~0ull;
+            uint64_t xprev = base > 0 ? sx[base - 1] : 0;
+            tile_clusters(sink, x, xprev, base > 0, cnt, lane, si.off, base, open_start, mdx);
+        }
+        sink.emit(lane == 0, si.off + open_start, n - open_start);
+    }
+}
+
+// one lane per cluster of <= DP_SMALL_CAP anchors, LDS
+__global__ __launch_bounds__(64) void k_dp_small(K3Args a)
+{
+    __shared__ uint32_t s_lo[DP_SMALL_CAP * 64];
+    __shared__ uint32_t s_aux[DP_SMALL_CAP * 64];
+    __shared__ uint16_t s_q[DP_SMALL_CAP * 64];
+    __shared__ uint8_t s_g[DP_SMALL_CAP * 64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_cl = a.ctr->n_clus_small;
+    SmallStore<DP_SMALL_CAP> S;
+    S.lo = s_lo + lane; S.aux = s_aux + lane; S.qv = s_q + lane; S.gv = s_g + lane;
+    for (uint32_t base = blockIdx.x * 64; base < n_cl; base += gridDim.x * 64) {
+        const uint32_t ci = base + lane;
+        if (ci >= n_cl) continue;
+        const ClusterDesc d = a.B.clus_small[ci];
+        if (a.flag_only && __hip_atomic_load(&a.B.acc_nu[d.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;
+        const uint64_t *x = a.B.ax + d.off; const uint32_t *q = a.B.aq + d.off;
+        for (uint32_t i = 0; i < d.len; ++i) { S.lo[i * 64] = (uint32_t)x[i]; S.qv[i * 64] = (uint16_t)q[i]; S.gv[i * 64] = 0; }
+        int32_t n_u, best;
+        chain_dp<SmallStore<DP_SMALL_CAP>, int>(S, (int)d.len, (int32_t)d.qlen, a.P);
+        backtrack_small(S, (int)d.len, a.P, n_u, best);
+        if (n_u > 0) { atomicAdd(&a.B.acc_nu[d.w], n_u); atomicMax(&a.B.acc_best[d.w], best); }
+    }
+}
+
+// larger clusters over arena slices, one lane per cluster
+__global__ __launch_bounds__(64) void k_dp_big(K3Args a)
+{
+    const uint32_t n_cl = a.ctr->n_clus_big;
+    for (uint32_t ci = blockIdx.x * 64 + threadIdx.x; ci < n_cl; ci += gridDim.x * 64) {
+        const ClusterDesc d = a.B.clus_big[ci];
+        if (a.flag_only && __hip_atomic_load(&a.B.acc_nu[d.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;
+        LargeStore S;
+        S.x = a.B.ax + d.off; S.q = a.B.aq + d.off; S.x2 = nullptr; S.q2 = nullptr;
+        S.z = a.B.az + d.off; S.f = a.B.af + d.off; S.p = a.B.ap + d.off; S.t = a.B.at + d.off;
+        int32_t n_u, best;
+        chain_dp<LargeStore, int64_t>(S, (int64_t)d.len, (int32_t)d.qlen, a.P);
+        backtrack_large(S, (int64_t)d.len, a.P, n_u, best);
+        if (n_u > 0) { atomicAdd(&a.B.acc_nu[d.w], n_u); atomicMax(&a.B.acc_best[d.w], best); }
+    }
+}
+
+__global__ void k_finalize(K3Args a)
+{
+    const uint32_t n_items = *a.list_count;
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n_items; w += gridDim.x * blockDim.x) {
+        const BigMeta m = a.B.meta[w];
+        if (m.state != 0) continue;
+        const int32_t n_u = a.B.acc_nu[w], best = a.B.acc_best[w];
+        if (a.pass == 0 && n_u == 0 && a.P.max_occ > a.P.mid_occ && m.rep_len > 0) {
+            uint32_t i = atomicAdd(a.next_count, 1u);
+            a.next_list[i] = m.r;
+            continue;
+        }
+        const uint32_t info = a.k1info[m.r];
+        int32_t fl = n_u > 0;
+        a.flags[m.r] = (uint8_t)fl;
+        write_trace(a.trace, m.r, (int32_t)(info & 0xffffu), (int32_t)(info >> 16), (int32_t)m.n_a, m.rep_len, a.pass, n_u, best, fl);
+        if (fl) atomicAdd(&a.ctr->n_host, 1u);
     }
 }
 
@@ -343,8 +695,7 @@ __device__ inline uint8_t *arena_alloc(const K2Args &a, size_t bytes)
     return a.arena + off;
 }
 
-// K3: lane per read, arrays in the HBM arena.  mode 1 first rebuilds the seed records by a
-// sequential sketch + probe (runtime w, ring in the arena).
+// legacy lane-per-read path (re-sketch of reads K1 could not finish); arrays in the HBM arena
 __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
 {
     const uint32_t lane = threadIdx.x;
@@ -353,21 +704,13 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
         const uint32_t wi = base + lane;
         bool host = false;
         if (wi < n_work) {
-            const uint32_t entry = a.work[wi];
-            const uint32_t r = entry & 0x7fffffffu;
-            const uint32_t mode = a.mode == 2 ? entry >> 31 : a.mode;     // mode 2: per-entry (deferred reads keep theirs)
+            const uint32_t r = a.work[wi] & 0x7fffffffu;
             const uint64_t o_beg = a.offsets[r];
             const int32_t qlen = (int32_t)(a.offsets[r + 1] - o_beg);
-            int32_t n_mini, n_seed;
+            int32_t n_mini = 0, n_seed = 0;
             SeedView sv;
             bool defer = false;
-            if (mode == 0) {
-                const uint32_t info = a.k1info[r];
-                n_mini = (int32_t)(info & 0xffffu); n_seed = (int32_t)(info >> 16);
-                sv.base = a.records + (size_t)(r >> 6) * a.seed_cap * 64 + (r & 63);
-                sv.stride = 64; sv.n = (uint32_t)n_seed;
-            } else {
-                n_mini = 0; n_seed = 0;
+            {
                 const size_t cap = 2 * (size_t)qlen + 256;
                 uint8_t *m = arena_alloc(a, cap * 16 + (size_t)a.w * 16);
                 if (!m) defer = true;
@@ -421,7 +764,7 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
             }
             if (defer) {
                 uint32_t li = atomicAdd(&a.ctr->n_defer, 1u);
-                a.work_defer[li] = r | mode << 31;
+                a.work_defer[li] = r;
             }
         }
         uint64_t mh = __ballot(host);
@@ -441,11 +784,12 @@ struct sh_ctx {
     bool use_k1 = true;
     uint4 *d_records = nullptr;
     uint32_t *d_k1info = nullptr, *d_work_small = nullptr, *d_work_resketch = nullptr, *d_work_defer = nullptr, *d_work_defer2 = nullptr;
-    uint32_t *d_work_large[N_BUCKETS] = {};
+    uint32_t *d_big[2][2] = {};       // [pass][ping-pong] read lists of the repeat path
     Counters *d_ctr = nullptr;
-    Counters *h_ctr = nullptr;     // pinned
-    uint8_t *d_arena = nullptr;
-    uint64_t arena_bytes = 0;
+    Counters *h_ctr = nullptr;        // pinned
+    uint8_t *d_arena = nullptr;       // legacy path + BigBufs carved from the same allocation
+    uint64_t arena_bytes = 0, legacy_bytes = 0;
+    BigBufs B{};
     hipEvent_t ev[5] = {};
 };
 
@@ -491,14 +835,39 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
     if ((e = hipMalloc(&c->d_work_resketch, max_reads * 4)) != hipSuccess) return fail(e, "work_resketch");
     if ((e = hipMalloc(&c->d_work_defer, max_reads * 4)) != hipSuccess) return fail(e, "work_defer");
     if ((e = hipMalloc(&c->d_work_defer2, max_reads * 4)) != hipSuccess) return fail(e, "work_defer2");
-    for (int b = 0; b < N_BUCKETS; ++b)
-        if ((e = hipMalloc(&c->d_work_large[b], max_reads * 4)) != hipSuccess) return fail(e, "work_large");
+    for (int p = 0; p < 2; ++p) for (int q = 0; q < 2; ++q)
+        if ((e = hipMalloc(&c->d_big[p][q], max_reads * 4)) != hipSuccess) return fail(e, "big lists");
     if ((e = hipMalloc(&c->d_ctr, sizeof(Counters))) != hipSuccess) return fail(e, "counters");
     if ((e = hipHostMalloc(&c->h_ctr, sizeof(Counters))) != hipSuccess) return fail(e, "pinned counters");
-    // arena: anchors of repeat reads; 2 KiB per read of the batch, at least 256 MiB (288 GB of HBM to size against)
-    c->arena_bytes = std::max<uint64_t>(256ull << 20, max_reads * 2048ull);
+    // arena: anchors, DP arrays and cluster lists of the repeat path (60 B per anchor slot) + a slice for the
+    // legacy re-sketch path.  Default 6 KiB per read of the batch (~100 anchor slots per read; the CHM13-sized
+    // workload averages 78), at least 256 MiB; reads that find no room are deferred and re-run.
+    c->arena_bytes = std::max<uint64_t>(256ull << 20, max_reads * 6144ull);
     if (const char *env = getenv("SCRUBBY_HIP_ARENA_MB")) c->arena_bytes = (uint64_t)atoll(env) << 20;
     if ((e = hipMalloc(&c->d_arena, c->arena_bytes)) != hipSuccess) return fail(e, "arena");
+    {
+        c->legacy_bytes = std::min<uint64_t>(c->arena_bytes / 8, 1ull << 30);
+        uint8_t *p = c->d_arena + c->legacy_bytes;
+        uint64_t left = c->arena_bytes - c->legacy_bytes;
+        uint64_t fixed = max_reads * (sizeof(BigMeta) + 8 + sizeof(SortItem)) + 4096;
+        uint64_t per_anchor = 8 + 8 + 8 + 4 + 4 + 4 + 4 + 4 + sizeof(ClusterDesc);   // ax bx az aq bq af ap at + cluster slot
+        uint64_t cap = left > fixed ? (left - fixed) / per_anchor : 0;
+        cap &= ~15ull;
+        if (cap < 1024) { sh_set_error("sh_ctx_create: arena of %llu MiB is too small", (unsigned long long)(c->arena_bytes >> 20)); sh_ctx_destroy(c); return SH_ERR_OOM; }
+        BigBufs &B = c->B;
+        B.anchor_cap = cap;
+        auto take = [&](uint64_t bytes) { uint8_t *q = p; p += (bytes + 255) & ~255ull; return q; };
+        B.ax = (uint64_t *)take(cap * 8); B.bx = (uint64_t *)take(cap * 8); B.az = (uint64_t *)take(cap * 8);
+        B.aq = (uint32_t *)take(cap * 4); B.bq = (uint32_t *)take(cap * 4);
+        B.af = (int32_t *)take(cap * 4); B.ap = (int32_t *)take(cap * 4); B.at = (int32_t *)take(cap * 4);
+        B.clus_small = (ClusterDesc *)take(cap / 2 * sizeof(ClusterDesc)); B.clus_big = (ClusterDesc *)take(cap / 2 * sizeof(ClusterDesc));
+        B.meta = (BigMeta *)take(max_reads * sizeof(BigMeta));
+        B.acc_nu = (int32_t *)take(max_reads * 4); B.acc_best = (int32_t *)take(max_reads * 4);
+        B.sort_items = (SortItem *)take(max_reads * sizeof(SortItem));
+        if ((uint64_t)(p - c->d_arena) > c->arena_bytes) {   // alignment slack: shrink
+            sh_set_error("sh_ctx_create: internal arena carve overflow"); sh_ctx_destroy(c); return SH_ERR_OOM;
+        }
+    }
     for (auto &ev : c->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "event");
     *out = c;
     return SH_OK;
@@ -509,7 +878,7 @@ extern "C" sh_status sh_ctx_destroy(sh_ctx *c)
     if (!c) return SH_OK;
     hipFree(c->d_records); hipFree(c->d_k1info); hipFree(c->d_work_small); hipFree(c->d_work_resketch);
     hipFree(c->d_work_defer); hipFree(c->d_work_defer2);
-    for (auto p : c->d_work_large) hipFree(p);
+    for (auto &pp : c->d_big) for (auto p : pp) hipFree(p);
     hipFree(c->d_ctr); if (c->h_ctr) hipHostFree(c->h_ctr); hipFree(c->d_arena);
     for (auto ev : c->ev) if (ev) hipEventDestroy(ev);
     delete c;
@@ -520,6 +889,21 @@ template <int W>
 static void launch_k1(const K1Args &a, uint32_t n_tiles, size_t lds, hipStream_t s)
 {
     hipLaunchKernelGGL(k_sketch_probe<W>, dim3(n_tiles), dim3(64), lds, s, a);
+}
+
+// one pass of the repeat path over list[*count]: expand -> sort -> DP -> finalize
+static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
+{
+    // per-pass device counters: arena cursor, sort list, cluster lists
+    Counters *ctr = c->d_ctr;
+    SH_HIP(hipMemsetAsync(&ctr->anchor_cursor, 0, 8, s));
+    SH_HIP(hipMemsetAsync(&ctr->n_sort, 0, 12, s));          // n_sort, n_clus_small, n_clus_big
+    hipLaunchKernelGGL(k_expand, dim3(grid * 2), dim3(64), 0, s, k);
+    hipLaunchKernelGGL(k_sort, dim3(grid), dim3(64), 0, s, k);
+    hipLaunchKernelGGL(k_dp_small, dim3(grid), dim3(64), 0, s, k);
+    hipLaunchKernelGGL(k_dp_big, dim3(grid), dim3(64), 0, s, k);
+    hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, s, k);
+    return SH_OK;
 }
 
 static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases,
@@ -556,46 +940,76 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     b.positions = idx->d_positions;
     b.records = c->d_records; b.seed_cap = c->seed_cap;
     b.k1info = c->d_k1info; b.flags = d_flags; b.trace = d_trace;
-    for (int i = 0; i < N_BUCKETS; ++i) b.work_large[i] = c->d_work_large[i];
+    b.work_big = c->d_big[0][0];
     b.work_defer = c->d_work_defer; b.ctr = c->d_ctr;
-    b.arena = c->d_arena; b.arena_bytes = c->arena_bytes;
+    b.arena = c->d_arena; b.arena_bytes = c->legacy_bytes;
     b.P = c->P;
-    const uint32_t grid = std::min<uint32_t>(n_tiles, 256 * 8);
+    const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(n_tiles, 1), 256 * 8);
     if (c->use_k1) {
         b.work = c->d_work_small; b.work_count = &c->d_ctr->n_small; b.mode = 0;
         hipLaunchKernelGGL(k_chain_small<K2_CAP>, dim3(grid), dim3(64), 0, s, b);
     }
     SH_HIP(hipEventRecord(c->ev[2], s));
-    for (int i = 0; i < N_BUCKETS; ++i) {
-        b.work = c->d_work_large[i]; b.work_count = &c->d_ctr->n_large[i]; b.mode = 0;
-        hipLaunchKernelGGL(k_chain_large, dim3(grid), dim3(64), 0, s, b);
-    }
-    b.work = c->d_work_resketch; b.work_count = &c->d_ctr->n_resketch; b.mode = 1;
-    hipLaunchKernelGGL(k_chain_large, dim3(grid), dim3(64), 0, s, b);
-    SH_HIP(hipEventRecord(c->ev[3], s));
-    SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
-    SH_HIP(hipStreamSynchronize(s));
-    SH_HIP(hipGetLastError());
 
-    Counters first = *c->h_ctr;
-    // reads that did not get arena space: rerun them with a fresh arena until none is left
+    K3Args k{};
+    k.offsets = d_offsets; k.positions = idx->d_positions; k.records = c->d_records; k.seed_cap = c->seed_cap;
+    k.k1info = c->d_k1info; k.flags = d_flags; k.trace = d_trace; k.ctr = c->d_ctr; k.B = c->B; k.P = c->P;
+    k.flag_only = d_trace == nullptr;
+    // pass 0 (mid_occ) over the reads K2 routed, pass 1 (max_occ) over the reads pass 0 could not chain;
+    // reads that found no arena room come back in the next iteration
+    int cur0 = 0, cur1 = 0;
+    bool first = true;
+    Counters snap{};
+    for (int iter = 0;; ++iter) {
+        SH_CHECK(iter < 256, SH_ERR_OOM, "chain arena (%llu MiB) too small; set SCRUBBY_HIP_ARENA_MB", (unsigned long long)(c->arena_bytes >> 20));
+        k.pass = 0; k.max_occ = c->P.mid_occ;
+        k.list = c->d_big[0][cur0]; k.list_count = &c->d_ctr->n_big[0];
+        k.defer_list = c->d_big[0][cur0 ^ 1]; k.defer_count = &c->d_ctr->n_big_defer[0];
+        k.next_list = c->d_big[1][cur1]; k.next_count = &c->d_ctr->n_big[1];
+        sh_status st = big_pass(c, k, grid, s);
+        if (st != SH_OK) return st;
+        k.pass = 1; k.max_occ = c->P.max_occ;
+        k.list = c->d_big[1][cur1]; k.list_count = &c->d_ctr->n_big[1];
+        k.defer_list = c->d_big[1][cur1 ^ 1]; k.defer_count = &c->d_ctr->n_big_defer[1];
+        k.next_list = nullptr; k.next_count = nullptr;
+        st = big_pass(c, k, grid, s);
+        if (st != SH_OK) return st;
+        if (first) {     // the rare reads K1 could not finish
+            b.work = c->d_work_resketch; b.work_count = &c->d_ctr->n_resketch; b.mode = 1;
+            hipLaunchKernelGGL(k_chain_large, dim3(grid), dim3(64), 0, s, b);
+        }
+        SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+        SH_HIP(hipStreamSynchronize(s));
+        SH_HIP(hipGetLastError());
+        if (first) { snap = *c->h_ctr; first = false; }
+        const uint32_t d0 = c->h_ctr->n_big_defer[0], d1 = c->h_ctr->n_big_defer[1];
+        if (d0 == 0 && d1 == 0) break;
+        // a read deferred when it was alone in the arena can never fit
+        SH_CHECK(!(d0 == c->h_ctr->n_big[0] && c->h_ctr->n_big[0] == 1 && d1 == 0) && !(d1 == c->h_ctr->n_big[1] && c->h_ctr->n_big[1] == 1 && d0 == 0),
+                 SH_ERR_OOM, "chain arena (%llu MiB) too small for one read; set SCRUBBY_HIP_ARENA_MB", (unsigned long long)(c->arena_bytes >> 20));
+        Counters z = *c->h_ctr;
+        z.n_big[0] = d0; z.n_big[1] = d1; z.n_big_defer[0] = z.n_big_defer[1] = 0;
+        SH_HIP(hipMemcpyAsync(c->d_ctr, &z, sizeof(Counters), hipMemcpyHostToDevice, s));
+        cur0 ^= 1; cur1 ^= 1;
+    }
+    SH_HIP(hipEventRecord(c->ev[3], s));
+
+    // legacy path deferrals
     uint32_t n_defer = c->h_ctr->n_defer;
-    uint32_t n_resk_left = 0;
     int rounds = 0;
     while (n_defer > 0) {
-        SH_CHECK(++rounds < 64, SH_ERR_OOM, "chain arena (%llu MiB) too small for a single read; set SCRUBBY_HIP_ARENA_MB", (unsigned long long)(c->arena_bytes >> 20));
+        SH_CHECK(++rounds < 64, SH_ERR_OOM, "re-sketch arena too small; set SCRUBBY_HIP_ARENA_MB");
         std::swap(c->d_work_defer, c->d_work_defer2);
         Counters z = *c->h_ctr;
         z.n_defer = 0; z.arena_cursor = 0; z.n_resketch = n_defer;
         SH_HIP(hipMemcpyAsync(c->d_ctr, &z, sizeof(Counters), hipMemcpyHostToDevice, s));
-        b.work = c->d_work_defer2; b.work_count = &c->d_ctr->n_resketch; b.mode = 2; b.work_defer = c->d_work_defer;
+        b.work = c->d_work_defer2; b.work_count = &c->d_ctr->n_resketch; b.mode = 1; b.work_defer = c->d_work_defer;
         hipLaunchKernelGGL(k_chain_large, dim3(grid), dim3(64), 0, s, b);
         SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
         SH_HIP(hipStreamSynchronize(s));
         uint32_t nd = c->h_ctr->n_defer;
-        SH_CHECK(nd < n_defer, SH_ERR_OOM, "chain arena (%llu MiB) too small; set SCRUBBY_HIP_ARENA_MB", (unsigned long long)(c->arena_bytes >> 20));
+        SH_CHECK(nd < n_defer, SH_ERR_OOM, "re-sketch arena too small; set SCRUBBY_HIP_ARENA_MB");
         n_defer = nd;
-        (void)n_resk_left;
     }
     SH_HIP(hipEventRecord(c->ev[4], s));
     SH_HIP(hipEventSynchronize(c->ev[4]));
@@ -604,11 +1018,10 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         hipEventElapsedTime(&t01, c->ev[0], c->ev[1]); hipEventElapsedTime(&t12, c->ev[1], c->ev[2]);
         hipEventElapsedTime(&t23, c->ev[2], c->ev[3]); hipEventElapsedTime(&t04, c->ev[0], c->ev[4]);
         stats->n_reads += n_reads; stats->n_bases += n_bases;
-        stats->n_host += c->h_ctr->n_host; stats->n_no_seed += first.n_noseed;
-        uint64_t nl = first.n_resketch;
-        for (int i = 0; i < N_BUCKETS; ++i) nl += first.n_large[i];
-        stats->n_chain_large += nl; stats->n_chain_small += first.n_small - (nl - first.n_resketch);
-        stats->n_minimizers += first.sum_mini;
+        stats->n_host += c->h_ctr->n_host; stats->n_no_seed += snap.n_noseed;
+        uint64_t nl = (uint64_t)snap.n_resketch + snap.n_big[0];
+        stats->n_chain_large += nl; stats->n_chain_small += snap.n_small - snap.n_big[0];
+        stats->n_minimizers += snap.sum_mini;
         stats->ms_sketch_probe += t01; stats->ms_chain_small += t12; stats->ms_chain_large += t23; stats->ms_total += t04;
     }
     return SH_OK;
