@@ -97,6 +97,9 @@ typedef struct sh_stats {
     double   ms_chain_small;
     double   ms_chain_large;
     double   ms_total;         /* first kernel start -> last kernel end */
+    uint64_t n_anchors;        /* anchors generated on the repeat path (both passes) */
+    uint64_t n_clusters;       /* independent anchor clusters chained on the repeat path */
+    uint64_t n_resketch;       /* reads that took the legacy re-sketch path */
 } sh_stats;
 
 typedef struct sh_index sh_index;

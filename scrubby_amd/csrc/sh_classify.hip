@@ -41,10 +41,12 @@
 #define K1_FLUSH_AT 16
 #define K2_CAP 32               // anchors per read chained in LDS
 #define DP_SMALL_CAP 32         // anchors per cluster chained in LDS
+#define SORT_LDS_A 1024         // reads with up to this many anchors are sorted in 24 KiB of LDS
+#define SORT_LDS_B 4096         // ... in 96 KiB of LDS; larger ones between two arena buffers
 
 struct Counters {
     uint32_t n_small, n_resketch, n_big[2], n_big_defer[2], n_defer, n_noseed, n_host;
-    uint32_t n_sort, n_clus_small, n_clus_big, n_big_total, n_clusters_total, pad;
+    uint32_t n_sort[3], n_clus_small, n_clus_big, n_clusters_total;
     unsigned long long arena_cursor, sum_mini, anchor_cursor, sum_anchors;
 };
 
@@ -85,6 +87,30 @@ struct K1Args {
     uint32_t *work_small, *work_resketch; Counters *ctr;
     uint32_t lds_words;
 };
+
+// Slow path of K1: this lane's minimizer queue is full in the middle of a W-step block (tie-heavy,
+// low-complexity reads).  Probe the lane's queued entries now, in order, so that seed records stay in
+// query order; rare, divergent, deliberately not inlined.
+__device__ __noinline__ void k1_lane_flush(const uint64_t *list, uint32_t lane, uint32_t cnt, const uint4 *slots, uint32_t lg_slots,
+                                           uint4 *rec, uint32_t seed_cap, uint32_t *n_seed_io, uint32_t *overflow_io)
+{
+    const uint64_t slot_mask = (1ULL << lg_slots) - 1;
+    uint32_t n_seed = *n_seed_io;
+    for (uint32_t e = 0; e < cnt; ++e) {
+        uint64_t m = list[e * 64 + lane];
+        uint64_t key = m >> 18, idx = sh_slot_home(key, lg_slots);
+        uint4 sl = slots[idx];
+        uint64_t w0 = (uint64_t)sl.y << 32 | sl.x;
+        while (w0 != SH_SLOT_EMPTY && (w0 & SH_SLOT_KEYMASK) != key) { idx = (idx + 1) & slot_mask; sl = slots[idx]; w0 = (uint64_t)sl.y << 32 | sl.x; }
+        if (w0 != SH_SLOT_EMPTY) {
+            uint32_t occ = (w0 & SH_SLOT_MULTI) ? (sl.z & (uint32_t)SH_SLOT_NMASK) : 1u;
+            if (n_seed < seed_cap) rec[(size_t)n_seed * 64] = make_uint4(sl.z, sl.w, occ, (uint32_t)m & 0x3ffffu);
+            else *overflow_io = 1;
+            ++n_seed;
+        }
+    }
+    *n_seed_io = n_seed;
+}
 
 template <int W>
 __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
@@ -156,15 +182,14 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, o));
 
-    uint32_t cnt = 0, n_mini = 0, n_seed = 0;
-    bool overflow = false;
-    auto emit = [&](uint64_t x, uint32_t y) {
-        if (cnt < K1_LIST_CAP) list[cnt * 64 + lane] = (x >> 8) << 18 | (uint64_t)y;
-        else overflow = true;
-        ++cnt; ++n_mini;
-    };
+    uint32_t cnt = 0, n_mini = 0, n_seed = 0, overflow = 0;
     const uint64_t slot_mask = (1ULL << a.lg_slots) - 1;
     uint4 *rec = a.records + (size_t)tile * a.seed_cap * 64 + lane;
+    auto emit = [&](uint64_t x, uint32_t y) {
+        if (cnt >= K1_LIST_CAP) { k1_lane_flush(list, lane, cnt, a.slots, a.lg_slots, rec, a.seed_cap, &n_seed, &overflow); cnt = 0; }
+        list[cnt * 64 + lane] = (x >> 8) << 18 | (uint64_t)y;
+        ++cnt; ++n_mini;
+    };
 
     uint32_t codes = 0, amb = 0;
     uint32_t i0 = 0;
@@ -197,7 +222,7 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
         if (last && valid && len > 0) st.finish(emit);
         if (last || __ballot(cnt >= K1_FLUSH_AT) != 0) {
             // ---- C: probe the index for every queued minimizer --------------------------------
-            const uint32_t c_here = cnt < K1_LIST_CAP ? cnt : K1_LIST_CAP;
+            const uint32_t c_here = cnt;
             for (uint32_t e0 = 0; __ballot(e0 < c_here) != 0; e0 += 4) {
                 uint64_t key[4], idx[4]; uint32_t yq[4]; uint4 s[4]; bool act[4];
 #pragma unroll
@@ -222,7 +247,7 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
                     if (w0 != SH_SLOT_EMPTY) {
                         uint32_t occ = (w0 & SH_SLOT_MULTI) ? (s[u].z & (uint32_t)SH_SLOT_NMASK) : 1u;
                         if (n_seed < a.seed_cap) rec[(size_t)n_seed * 64] = make_uint4(s[u].z, s[u].w, occ, yq[u]);
-                        else overflow = true;
+                        else overflow = 1;
                         ++n_seed;
                     }
                 }
@@ -234,7 +259,7 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
 
     // ---- per-read result ------------------------------------------------------------------------
     if (valid) a.k1info[r] = n_mini | n_seed << 16;
-    const bool to_k3 = valid && overflow;
+    const bool to_k3 = valid && overflow != 0;
     const bool done = valid && !overflow && n_seed == 0;
     const bool to_k2 = valid && !overflow && n_seed > 0;
     if (done) {
@@ -277,7 +302,7 @@ struct BigBufs {        // the repeat path's slice of the arena (all arrays inde
     uint64_t *ax, *bx, *az; uint32_t *aq, *bq; int32_t *af, *ap, *at;
     unsigned long long anchor_cap;
     BigMeta *meta; int32_t *acc_nu, *acc_best;
-    SortItem *sort_items; ClusterDesc *clus_small, *clus_big;
+    SortItem *sort_items[3]; ClusterDesc *clus_small, *clus_big;
 };
 
 struct K2Args {
@@ -291,7 +316,7 @@ struct K2Args {
     Counters *ctr;
     uint8_t *arena; unsigned long long arena_bytes;
     ChainParams P;
-    uint32_t mode;       // k_chain_large: 0 = seeds from tile records, 1 = re-sketch, 2 = per entry
+    uint32_t work_begin; // k_chain_large: first list entry to process
 };
 
 __device__ inline void finish_read(const K2Args &a, uint32_t r, int32_t n_mini, int32_t n_seed, int64_t n_a, int32_t rep_len,
@@ -390,6 +415,8 @@ struct ClusterSink {
     {
         pred = pred && (len >= 2 || keep_single);
         bool sm = pred && len <= DP_SMALL_CAP, bg = pred && len > DP_SMALL_CAP;
+        uint64_t pm = __ballot(pred);
+        if (pm && lane_id() == (uint32_t)(__ffsll((unsigned long long)pm) - 1)) atomicAdd(&ctr->n_clusters_total, (uint32_t)__popcll(pm));
         uint32_t i = wave_append(&ctr->n_clus_small, sm);
         if (sm) { ClusterDesc d{start, len, w, qlen, 0}; small[i] = d; }
         i = wave_append(&ctr->n_clus_big, bg);
@@ -423,6 +450,7 @@ struct K3Args {
     const uint32_t *list; const uint32_t *list_count;     // reads of this pass
     uint32_t *defer_list; uint32_t *defer_count;          // reads that found no arena space
     uint32_t *next_list; uint32_t *next_count;            // pass 0: reads that must re-chain with max_occ
+    uint32_t *resketch_list;                              // reads this path cannot take (see k_expand)
     Counters *ctr; BigBufs B; ChainParams P;
     int32_t pass, max_occ, flag_only;
 };
@@ -438,69 +466,95 @@ __device__ inline uint32_t chain_max_dist_x(const ChainParams &P, int32_t qlen)
 }
 
 // one wave per read: seeds -> filter -> anchors (arena) -> [<= 64: sort + clusters]
+// Seeds are handled 64 at a time, one per lane.  mm_seed_select's streak logic needs a read's seeds in one
+// tile; with more seeds it is only needed when some streak could keep a seed (max_high_occ > 0), which for
+// occ_dist = 500 means reads longer than 250 bp: those go to the legacy path.
 __global__ __launch_bounds__(64) void k_expand(K3Args a)
 {
     const uint32_t lane = threadIdx.x;
     const uint32_t n_items = *a.list_count;
     const ChainParams &P = a.P;
+    const bool plain_cut = !(P.occ_dist > 0 && P.max_max_occ > a.max_occ);
     for (uint32_t w = blockIdx.x; w < n_items; w += gridDim.x) {
         const uint32_t r = a.list[w];
         const uint32_t info = a.k1info[r];
         const uint32_t n_seed = info >> 16;
         const int32_t qlen = (int32_t)(a.offsets[r + 1] - a.offsets[r]);
-        const bool have = lane < n_seed;
-        uint4 *recp = a.records + (size_t)(r >> 6) * a.seed_cap * 64 + (r & 63) + (size_t)lane * 64;
-        uint4 rec = have ? *recp : make_uint4(0, 0, 0, 0);
-        const uint32_t occ = rec.z & 0x7fffffffu, qposz = rec.w;
-        const uint64_t w1 = (uint64_t)rec.y << 32 | rec.x;
-        // ---- mm_seed_select / occurrence cut, one seed per lane ----
-        const bool high = have && occ > (uint32_t)a.max_occ;
-        bool flt = false;
-        if (!(P.occ_dist > 0 && P.max_max_occ > a.max_occ)) flt = high;
-        else {
-            const uint64_t hm = __ballot(high);
-            if (n_seed >= 2 && hm != 0) {
-                const uint64_t low = __ballot(have && !high);
-                const uint64_t below = low & ((1ULL << lane) - 1);
-                const uint64_t above = lane >= 63 ? 0 : low & ~((2ULL << lane) - 1);
-                const int32_t last0 = below ? 63 - __clzll((unsigned long long)below) : -1;
-                const int32_t nxt = above ? __ffsll((unsigned long long)above) - 1 : (int32_t)n_seed;
-                const uint32_t qp_last = (uint32_t)__shfl((int)qposz, last0 < 0 ? 0 : last0);
-                const uint32_t qp_next = (uint32_t)__shfl((int)qposz, nxt >= (int32_t)n_seed ? 0 : nxt);
-                const int32_t ps = last0 < 0 ? 0 : (int32_t)(qp_last >> 1);
-                const int32_t pe = nxt >= (int32_t)n_seed ? qlen : (int32_t)(qp_next >> 1);
-                int32_t mho = (int32_t)((double)(pe - ps) / (double)P.occ_dist + .499);
-                if (mho > 128) mho = 128;
-                int32_t rank = 0;
-                for (uint32_t t = 0; t < n_seed; ++t) {
-                    uint32_t ot = rdlane(occ, t);
-                    bool in = (int32_t)t > last0 && (int32_t)t < nxt;
-                    rank += in && (ot < occ || (ot == occ && t < lane));
-                }
-                if (high) {
-                    flt = !(mho > 0 && rank < mho);
-                    if (occ > (uint32_t)P.max_max_occ) flt = true;
+        const uint32_t n_st = (n_seed + 63) / 64;
+        const bool no_keep = plain_cut || (int32_t)((double)qlen / (double)P.occ_dist + .499) <= 0;   // every streak has max_high_occ == 0
+        if (n_st > 1 && !no_keep) {
+            if (lane == 0) {
+                BigMeta m{r, 0, 0, 2u};
+                a.B.meta[w] = m;
+                uint32_t i = atomicAdd(&a.ctr->n_resketch, 1u);
+                a.resketch_list[i] = r;
+            }
+            continue;
+        }
+        uint4 *recb = a.records + (size_t)(r >> 6) * a.seed_cap * 64 + (r & 63);
+        // occurrence filter of seed tile t: my_n = anchors this lane's seed contributes (0 if filtered / absent)
+        auto eval = [&](uint32_t t, uint4 &rec, uint32_t &my_n, bool &flt, bool &have) {
+            const uint32_t sidx = t * 64 + lane;
+            have = sidx < n_seed;
+            rec = have ? recb[(size_t)sidx * 64] : make_uint4(0, 0, 0, 0);
+            const uint32_t occ = rec.z & 0x7fffffffu, qposz = rec.w;
+            const bool high = have && occ > (uint32_t)a.max_occ;
+            flt = false;
+            if (plain_cut) flt = high;
+            else if (n_st > 1) flt = high && n_seed >= 2;      // no_keep holds
+            else {
+                const uint64_t hm = __ballot(high);
+                if (n_seed >= 2 && hm != 0) {
+                    const uint64_t low = __ballot(have && !high);
+                    const uint64_t below = low & ((1ULL << lane) - 1);
+                    const uint64_t above = lane >= 63 ? 0 : low & ~((2ULL << lane) - 1);
+                    const int32_t last0 = below ? 63 - __clzll((unsigned long long)below) : -1;
+                    const int32_t nxt = above ? __ffsll((unsigned long long)above) - 1 : (int32_t)n_seed;
+                    const uint32_t qp_last = (uint32_t)__shfl((int)qposz, last0 < 0 ? 0 : last0);
+                    const uint32_t qp_next = (uint32_t)__shfl((int)qposz, nxt >= (int32_t)n_seed ? 0 : nxt);
+                    const int32_t ps = last0 < 0 ? 0 : (int32_t)(qp_last >> 1);
+                    const int32_t pe = nxt >= (int32_t)n_seed ? qlen : (int32_t)(qp_next >> 1);
+                    int32_t mho = (int32_t)((double)(pe - ps) / (double)P.occ_dist + .499);
+                    if (mho > 128) mho = 128;
+                    int32_t rank = 0;
+                    if (__ballot(high && mho > 0) != 0) {
+                        for (uint32_t u = 0; u < n_seed; ++u) {
+                            uint32_t ot = rdlane(occ, u);
+                            bool in = (int32_t)u > last0 && (int32_t)u < nxt;
+                            rank += in && (ot < occ || (ot == occ && u < lane));
+                        }
+                    }
+                    if (high) {
+                        flt = !(mho > 0 && rank < mho);
+                        if (occ > (uint32_t)P.max_max_occ) flt = true;
+                    }
                 }
             }
-        }
-        // rep_len: union length of the filtered seeds' query intervals
-        const uint64_t fm = __ballot(flt);
-        int32_t contrib = 0;
-        {
-            const int32_t en = (int32_t)(qposz >> 1) + 1, st = en - P.k;
+            my_n = (have && !flt) ? occ : 0u;
+        };
+        // ---- pass 1 over the seed tiles: anchor count and rep_len ----
+        uint4 rec0 = make_uint4(0, 0, 0, 0); uint32_t my_n0 = 0; bool flt0 = false, have0 = false;
+        unsigned long long n_part = 0;
+        int32_t contrib = 0, carry_en = 0;
+        for (uint32_t t = 0; t < n_st; ++t) {
+            uint4 rec; uint32_t my_n; bool flt, have;
+            eval(t, rec, my_n, flt, have);
+            if (t == 0) { rec0 = rec; my_n0 = my_n; flt0 = flt; have0 = have; }
+            n_part += my_n;
+            // rep_len: union length of the filtered seeds' query intervals (ascending end positions)
+            const uint64_t fm = __ballot(flt);
+            const int32_t en = (int32_t)(rec.w >> 1) + 1, st = en - P.k;
             const uint64_t belowf = fm & ((1ULL << lane) - 1);
-            const int32_t prev_en_l = (int32_t)(__shfl((int)qposz, belowf ? 63 - __clzll((unsigned long long)belowf) : 0) >> 1) + 1;
-            const int32_t prev_en = belowf ? prev_en_l : 0;
-            if (flt) contrib = en - (st > prev_en ? st : prev_en);
+            const int32_t prev_en_l = (int32_t)((uint32_t)__shfl((int)rec.w, belowf ? 63 - __clzll((unsigned long long)belowf) : 0) >> 1) + 1;
+            const int32_t prev_en = belowf ? prev_en_l : carry_en;
+            if (flt) contrib += en - (st > prev_en ? st : prev_en);
+            if (fm) carry_en = (int32_t)(rdlane(rec.w, 63 - __clzll((unsigned long long)fm)) >> 1) + 1;
         }
         const int32_t rep_len = (int32_t)wave_sum_u32((uint32_t)contrib);
-        const uint32_t my_n = (have && !flt) ? occ : 0u;
-        // anchor count can exceed 32 bits only for absurd inputs; saturate (such a read can never get arena space)
-        unsigned long long n_a64 = my_n;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) n_a64 += (unsigned long long)__shfl_xor((long long)n_a64, o);
-        const uint32_t n_a = n_a64 > 0x7fffffffull ? 0x7fffffffu : (uint32_t)n_a64;
-        if (have) recp->z = occ | (uint32_t)flt << 31;
+        for (int o = 32; o > 0; o >>= 1) n_part += (unsigned long long)__shfl_xor((long long)n_part, o);
+        // the count can exceed 31 bits only for absurd inputs; saturate (such a read never gets arena space)
+        const uint32_t n_a = n_part > 0x7fffffffull ? 0x7fffffffu : (uint32_t)n_part;
 
         unsigned long long off = 0;
         if (lane == 0 && n_a > 0) off = atomicAdd(&a.ctr->anchor_cursor, (unsigned long long)n_a);
@@ -514,28 +568,36 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
         }
         if (defer || n_a == 0) continue;
 
-        // ---- anchors in generation order (seed order, then occurrence order) ----
-        const uint32_t start = wave_excl_scan_u32(my_n, lane);
-        const bool any_multi = __ballot(my_n > 1) != 0;
-        if (!any_multi) {
-            if (my_n == 1) {
-                uint64_t x; uint32_t q;
-                make_anchor(w1, qposz, qlen, P.k, x, q);
-                a.B.ax[off + start] = x; a.B.aq[off + start] = q;
-            }
-        } else {
-            for (uint32_t s = 0; s < n_seed; ++s) {
-                const uint32_t os = rdlane(my_n, s);
-                if (os == 0) continue;
-                const uint32_t ss = rdlane(start, s), sq = rdlane(qposz, s);
-                const uint64_t sw1 = (uint64_t)rdlane((uint32_t)(w1 >> 32), s) << 32 | rdlane((uint32_t)w1, s);
-                const uint64_t *cr = a.positions + (sw1 >> SH_SLOT_NBITS);
-                for (uint32_t t = lane; t < os; t += 64) {
+        // ---- pass 2: anchors in generation order (seed order, then occurrence order) ----
+        uint32_t run = 0;
+        for (uint32_t t = 0; t < n_st; ++t) {
+            uint4 rec = rec0; uint32_t my_n = my_n0; bool flt = flt0, have = have0;
+            if (t > 0) eval(t, rec, my_n, flt, have);
+            const uint32_t start = run + wave_excl_scan_u32(my_n, lane);
+            const uint64_t w1 = (uint64_t)rec.y << 32 | rec.x;
+            const bool any_multi = __ballot(my_n > 1) != 0;
+            if (!any_multi) {
+                if (my_n == 1) {
                     uint64_t x; uint32_t q;
-                    make_anchor(os == 1 ? sw1 : cr[t], sq, qlen, P.k, x, q);
-                    a.B.ax[off + ss + t] = x; a.B.aq[off + ss + t] = q;
+                    make_anchor(w1, rec.w, qlen, P.k, x, q);
+                    a.B.ax[off + start] = x; a.B.aq[off + start] = q;
+                }
+            } else {
+                const uint32_t cnt_s = n_seed - t * 64 < 64 ? n_seed - t * 64 : 64;
+                for (uint32_t sdx = 0; sdx < cnt_s; ++sdx) {
+                    const uint32_t os = rdlane(my_n, sdx);
+                    if (os == 0) continue;
+                    const uint32_t ss = rdlane(start, sdx), sq = rdlane(rec.w, sdx);
+                    const uint64_t sw1 = (uint64_t)rdlane((uint32_t)(w1 >> 32), sdx) << 32 | rdlane((uint32_t)w1, sdx);
+                    const uint64_t *cr = a.positions + (sw1 >> SH_SLOT_NBITS);
+                    for (uint32_t u = lane; u < os; u += 64) {
+                        uint64_t x; uint32_t q;
+                        make_anchor(os == 1 ? sw1 : cr[u], sq, qlen, P.k, x, q);
+                        a.B.ax[off + ss + u] = x; a.B.aq[off + ss + u] = q;
+                    }
                 }
             }
+            run += wave_sum_u32(my_n);
         }
         __syncthreads();
         if (n_a <= 64) {
@@ -552,73 +614,111 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
             tile_clusters(sink, x, 0, false, n_a, lane, off, 0, open_start, chain_max_dist_x(P, qlen));
             sink.emit(lane == 0, off + open_start, n_a - open_start);
         } else if (lane == 0) {
-            uint32_t si = atomicAdd(&a.ctr->n_sort, 1u);
+            const int cls = n_a <= SORT_LDS_A ? 0 : (n_a <= SORT_LDS_B ? 1 : 2);
+            uint32_t si = atomicAdd(&a.ctr->n_sort[cls], 1u);
             SortItem it{w, n_a, (uint32_t)qlen, 0, off};
-            a.B.sort_items[si] = it;
+            a.B.sort_items[cls][si] = it;
         }
     }
 }
 
-// one wave per read with > 64 anchors: stable merge sort in the arena, then clusters
-__global__ __launch_bounds__(64) void k_sort(K3Args a)
+// stable wave merge sort: 64-element tiles ranked in registers, then merge-path rounds between (sx,sq) and (dx,dq).
+// Returns true if the result ended in the second buffer.
+template <class PX, class PQ>
+__device__ inline bool wave_merge_sort(PX sx, PQ sq, PX dx, PQ dq, uint32_t n, uint32_t lane)
 {
-    const uint32_t lane = threadIdx.x;
-    const uint32_t n_items = a.ctr->n_sort;
-    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const SortItem si = a.B.sort_items[it];
-        const uint32_t n = si.n;
-        uint64_t *sx = a.B.ax + si.off, *dx = a.B.bx + si.off;
-        uint32_t *sq = a.B.aq + si.off, *dq = a.B.bq + si.off;
-        // tiles of 64 ranked in registers
-        for (uint32_t base = 0; base < n; base += 64) {
-            const uint32_t cnt = n - base < 64 ? n - base : 64;
-            uint64_t x = lane < cnt ? sx[base + lane] : ~0ull;
-            uint32_t q = lane < cnt ? sq[base + lane] : 0u;
-            uint64_t xp = (uint64_t)__shfl_up((long long)x, 1);
-            if (__ballot(lane > 0 && lane < cnt && x < xp) != 0) {
-                wave_rank_sort(x, q, cnt, lane);
-                if (lane < cnt) { sx[base + lane] = x; sq[base + lane] = q; }
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t cnt = n - base < 64 ? n - base : 64;
+        uint64_t x = lane < cnt ? sx[base + lane] : ~0ull;
+        uint32_t q = lane < cnt ? sq[base + lane] : 0u;
+        uint64_t xp = (uint64_t)__shfl_up((long long)x, 1);
+        if (__ballot(lane > 0 && lane < cnt && x < xp) != 0) {
+            wave_rank_sort(x, q, cnt, lane);
+            if (lane < cnt) { sx[base + lane] = x; sq[base + lane] = q; }
+        }
+    }
+    __syncthreads();
+    const uint32_t C = 16;
+    const uint32_t n_chunks = (n + C - 1) / C;
+    bool flipped = false;
+    for (uint32_t width = 64; width < n; width <<= 1) {
+        for (uint32_t c = lane; c < n_chunks; c += 64) {
+            const uint32_t o0 = c * C, o1 = o0 + C < n ? o0 + C : n;
+            const uint32_t pb = o0 / (2 * width) * (2 * width);
+            const uint32_t L0 = pb, L1 = pb + width < n ? pb + width : n, R1 = pb + 2 * width < n ? pb + 2 * width : n;
+            const uint32_t lenL = L1 - L0, lenR = R1 - L1, d = o0 - pb;
+            uint32_t lo = d > lenR ? d - lenR : 0, hi = d < lenL ? d : lenL;
+            while (lo < hi) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (sx[L0 + mid] <= sx[L1 + (d - 1 - mid)]) lo = mid + 1; else hi = mid;
+            }
+            uint32_t ia = L0 + lo, ib = L1 + (d - lo);
+            uint64_t va = ia < L1 ? sx[ia] : ~0ull, vb = ib < R1 ? sx[ib] : ~0ull;
+            for (uint32_t o = o0; o < o1; ++o) {
+                const bool takeL = ia < L1 && (ib >= R1 || va <= vb);
+                if (takeL) { dx[o] = va; dq[o] = sq[ia]; ++ia; va = ia < L1 ? sx[ia] : ~0ull; }
+                else { dx[o] = vb; dq[o] = sq[ib]; ++ib; vb = ib < R1 ? sx[ib] : ~0ull; }
             }
         }
         __syncthreads();
-        // merge-path rounds: each lane produces chunks of C consecutive outputs
-        const uint32_t C = 16;
-        const uint32_t n_chunks = (n + C - 1) / C;
-        for (uint32_t width = 64; width < n; width <<= 1) {
-            for (uint32_t c = lane; c < n_chunks; c += 64) {
-                const uint32_t o0 = c * C, o1 = o0 + C < n ? o0 + C : n;
-                const uint32_t pb = o0 / (2 * width) * (2 * width);
-                const uint32_t L0 = pb, L1 = pb + width < n ? pb + width : n, R1 = pb + 2 * width < n ? pb + 2 * width : n;
-                const uint32_t lenL = L1 - L0, lenR = R1 - L1, d = o0 - pb;
-                uint32_t lo = d > lenR ? d - lenR : 0, hi = d < lenL ? d : lenL;
-                while (lo < hi) {
-                    uint32_t mid = (lo + hi) >> 1;
-                    if (sx[L0 + mid] <= sx[L1 + (d - 1 - mid)]) lo = mid + 1; else hi = mid;
-                }
-                uint32_t ia = L0 + lo, ib = L1 + (d - lo);
-                for (uint32_t o = o0; o < o1; ++o) {
-                    bool takeL = ia < L1 && (ib >= R1 || sx[ia] <= sx[ib]);
-                    uint32_t src = takeL ? ia : ib;
-                    dx[o] = sx[src]; dq[o] = sq[src];
-                    ia += takeL; ib += !takeL;
-                }
-            }
-            __syncthreads();
-            uint64_t *tx = sx; sx = dx; dx = tx; uint32_t *tq = sq; sq = dq; dq = tq;
-        }
-        if (sx != a.B.ax + si.off) {     // odd number of rounds: bring the result home
-            for (uint32_t i = lane; i < n; i += 64) { dx[i] = sx[i]; dq[i] = sq[i]; }
-            __syncthreads();
-            sx = dx;
-        }
-        // clusters
+        PX tx = sx; sx = dx; dx = tx; PQ tq = sq; sq = dq; dq = tq;
+        flipped = !flipped;
+    }
+    return flipped;
+}
+
+// one wave per read with 64 < anchors <= NMAX: sort in LDS, write back, cluster boundaries
+template <int NMAX, int CLS>
+__global__ __launch_bounds__(64) void k_sort_lds(K3Args a)
+{
+    __shared__ uint64_t s_x[2][NMAX];
+    __shared__ uint32_t s_q[2][NMAX];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_items = a.ctr->n_sort[CLS];
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const SortItem si = a.B.sort_items[CLS][it];
+        const uint32_t n = si.n;
+        uint64_t *gx = a.B.ax + si.off; uint32_t *gq = a.B.aq + si.off;
+        for (uint32_t i = lane; i < n; i += 64) { s_x[0][i] = gx[i]; s_q[0][i] = gq[i]; }
+        __syncthreads();
+        const bool fl = wave_merge_sort(&s_x[0][0], &s_q[0][0], &s_x[1][0], &s_q[1][0], n, lane);
+        const uint64_t *rx = fl ? s_x[1] : s_x[0]; const uint32_t *rq = fl ? s_q[1] : s_q[0];
+        for (uint32_t i = lane; i < n; i += 64) { gx[i] = rx[i]; gq[i] = rq[i]; }
         ClusterSink sink{a.B.clus_small, a.B.clus_big, a.ctr, si.w, si.qlen, !(a.P.k < a.P.min_sc || a.P.min_cnt > 1)};
         const uint32_t mdx = chain_max_dist_x(a.P, (int32_t)si.qlen);
         uint32_t open_start = 0;
         for (uint32_t base = 0; base < n; base += 64) {
             const uint32_t cnt = n - base < 64 ? n - base : 64;
-            uint64_t x = lane < cnt ? sx[base + lane] : ~0ull;
-            uint64_t xprev = base > 0 ? sx[base - 1] : 0;
+            uint64_t x = lane < cnt ? rx[base + lane] : ~0ull;
+            uint64_t xprev = base > 0 ? rx[base - 1] : 0;
+            tile_clusters(sink, x, xprev, base > 0, cnt, lane, si.off, base, open_start, mdx);
+        }
+        sink.emit(lane == 0, si.off + open_start, n - open_start);
+        __syncthreads();
+    }
+}
+
+// one wave per read with more anchors than the LDS variants hold: the same sort between two arena buffers
+__global__ __launch_bounds__(64) void k_sort(K3Args a)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_items = a.ctr->n_sort[2];
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const SortItem si = a.B.sort_items[2][it];
+        const uint32_t n = si.n;
+        uint64_t *gx = a.B.ax + si.off, *hx = a.B.bx + si.off;
+        uint32_t *gq = a.B.aq + si.off, *hq = a.B.bq + si.off;
+        if (wave_merge_sort(gx, gq, hx, hq, n, lane)) {      // odd number of rounds: bring the result home
+            for (uint32_t i = lane; i < n; i += 64) { gx[i] = hx[i]; gq[i] = hq[i]; }
+            __syncthreads();
+        }
+        ClusterSink sink{a.B.clus_small, a.B.clus_big, a.ctr, si.w, si.qlen, !(a.P.k < a.P.min_sc || a.P.min_cnt > 1)};
+        const uint32_t mdx = chain_max_dist_x(a.P, (int32_t)si.qlen);
+        uint32_t open_start = 0;
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t cnt = n - base < 64 ? n - base : 64;
+            uint64_t x = lane < cnt ? gx[base + lane] : ~0ull;
+            uint64_t xprev = base > 0 ? gx[base - 1] : 0;
             tile_clusters(sink, x, xprev, base > 0, cnt, lane, si.off, base, open_start, mdx);
         }
         sink.emit(lane == 0, si.off + open_start, n - open_start);
@@ -642,7 +742,13 @@ __global__ __launch_bounds__(64) void k_dp_small(K3Args a)
         const ClusterDesc d = a.B.clus_small[ci];
         if (a.flag_only && __hip_atomic_load(&a.B.acc_nu[d.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;
         const uint64_t *x = a.B.ax + d.off; const uint32_t *q = a.B.aq + d.off;
-        for (uint32_t i = 0; i < d.len; ++i) { S.lo[i * 64] = (uint32_t)x[i]; S.qv[i * 64] = (uint16_t)q[i]; S.gv[i * 64] = 0; }
+        for (uint32_t i = 0; i < d.len; i += 4) {       // 4 independent loads in flight
+            uint64_t xv[4]; uint32_t qv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i + u < d.len) { xv[u] = x[i + u]; qv[u] = q[i + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i + u < d.len) { S.lo[(i + u) * 64] = (uint32_t)xv[u]; S.qv[(i + u) * 64] = (uint16_t)qv[u]; S.gv[(i + u) * 64] = 0; }
+        }
         int32_t n_u, best;
         chain_dp<SmallStore<DP_SMALL_CAP>, int>(S, (int)d.len, (int32_t)d.qlen, a.P);
         backtrack_small(S, (int)d.len, a.P, n_u, best);
@@ -700,7 +806,7 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
 {
     const uint32_t lane = threadIdx.x;
     const uint32_t n_work = *a.work_count;
-    for (uint32_t base = blockIdx.x * 64; base < n_work; base += gridDim.x * 64) {
+    for (uint32_t base = a.work_begin + blockIdx.x * 64; base < n_work; base += gridDim.x * 64) {
         const uint32_t wi = base + lane;
         bool host = false;
         if (wi < n_work) {
@@ -780,7 +886,7 @@ struct sh_ctx {
     sh_opts opts{};
     ChainParams P{};
     uint64_t max_reads = 0, max_bases = 0;
-    uint32_t max_read_len = 0, seed_cap = 32, lds_words = 0;
+    uint32_t max_read_len = 0, seed_cap = 192, lds_words = 0;
     bool use_k1 = true;
     uint4 *d_records = nullptr;
     uint32_t *d_k1info = nullptr, *d_work_small = nullptr, *d_work_resketch = nullptr, *d_work_defer = nullptr, *d_work_defer2 = nullptr;
@@ -849,7 +955,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         c->legacy_bytes = std::min<uint64_t>(c->arena_bytes / 8, 1ull << 30);
         uint8_t *p = c->d_arena + c->legacy_bytes;
         uint64_t left = c->arena_bytes - c->legacy_bytes;
-        uint64_t fixed = max_reads * (sizeof(BigMeta) + 8 + sizeof(SortItem)) + 4096;
+        uint64_t fixed = max_reads * (sizeof(BigMeta) + 8 + 3 * sizeof(SortItem)) + 8192;
         uint64_t per_anchor = 8 + 8 + 8 + 4 + 4 + 4 + 4 + 4 + sizeof(ClusterDesc);   // ax bx az aq bq af ap at + cluster slot
         uint64_t cap = left > fixed ? (left - fixed) / per_anchor : 0;
         cap &= ~15ull;
@@ -863,7 +969,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         B.clus_small = (ClusterDesc *)take(cap / 2 * sizeof(ClusterDesc)); B.clus_big = (ClusterDesc *)take(cap / 2 * sizeof(ClusterDesc));
         B.meta = (BigMeta *)take(max_reads * sizeof(BigMeta));
         B.acc_nu = (int32_t *)take(max_reads * 4); B.acc_best = (int32_t *)take(max_reads * 4);
-        B.sort_items = (SortItem *)take(max_reads * sizeof(SortItem));
+        for (int i = 0; i < 3; ++i) B.sort_items[i] = (SortItem *)take(max_reads * sizeof(SortItem));
         if ((uint64_t)(p - c->d_arena) > c->arena_bytes) {   // alignment slack: shrink
             sh_set_error("sh_ctx_create: internal arena carve overflow"); sh_ctx_destroy(c); return SH_ERR_OOM;
         }
@@ -897,8 +1003,10 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     // per-pass device counters: arena cursor, sort list, cluster lists
     Counters *ctr = c->d_ctr;
     SH_HIP(hipMemsetAsync(&ctr->anchor_cursor, 0, 8, s));
-    SH_HIP(hipMemsetAsync(&ctr->n_sort, 0, 12, s));          // n_sort, n_clus_small, n_clus_big
+    SH_HIP(hipMemsetAsync(&ctr->n_sort[0], 0, 20, s));       // n_sort[3], n_clus_small, n_clus_big
     hipLaunchKernelGGL(k_expand, dim3(grid * 2), dim3(64), 0, s, k);
+    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_A, 0>), dim3(grid), dim3(64), 0, s, k);
+    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_B, 1>), dim3(256), dim3(64), 0, s, k);
     hipLaunchKernelGGL(k_sort, dim3(grid), dim3(64), 0, s, k);
     hipLaunchKernelGGL(k_dp_small, dim3(grid), dim3(64), 0, s, k);
     hipLaunchKernelGGL(k_dp_big, dim3(grid), dim3(64), 0, s, k);
@@ -946,7 +1054,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     b.P = c->P;
     const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(n_tiles, 1), 256 * 8);
     if (c->use_k1) {
-        b.work = c->d_work_small; b.work_count = &c->d_ctr->n_small; b.mode = 0;
+        b.work = c->d_work_small; b.work_count = &c->d_ctr->n_small; b.work_begin = 0;
         hipLaunchKernelGGL(k_chain_small<K2_CAP>, dim3(grid), dim3(64), 0, s, b);
     }
     SH_HIP(hipEventRecord(c->ev[2], s));
@@ -955,6 +1063,8 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     k.offsets = d_offsets; k.positions = idx->d_positions; k.records = c->d_records; k.seed_cap = c->seed_cap;
     k.k1info = c->d_k1info; k.flags = d_flags; k.trace = d_trace; k.ctr = c->d_ctr; k.B = c->B; k.P = c->P;
     k.flag_only = d_trace == nullptr;
+    k.resketch_list = c->d_work_resketch;
+    uint32_t resk_done = 0;
     // pass 0 (mid_occ) over the reads K2 routed, pass 1 (max_occ) over the reads pass 0 could not chain;
     // reads that found no arena room come back in the next iteration
     int cur0 = 0, cur1 = 0;
@@ -974,14 +1084,14 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         k.next_list = nullptr; k.next_count = nullptr;
         st = big_pass(c, k, grid, s);
         if (st != SH_OK) return st;
-        if (first) {     // the rare reads K1 could not finish
-            b.work = c->d_work_resketch; b.work_count = &c->d_ctr->n_resketch; b.mode = 1;
-            hipLaunchKernelGGL(k_chain_large, dim3(grid), dim3(64), 0, s, b);
-        }
+        // the rare reads K1 or k_expand could not take
+        b.work = c->d_work_resketch; b.work_count = &c->d_ctr->n_resketch; b.work_begin = resk_done;
+        hipLaunchKernelGGL(k_chain_large, dim3(grid), dim3(64), 0, s, b);
         SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
         SH_HIP(hipStreamSynchronize(s));
         SH_HIP(hipGetLastError());
         if (first) { snap = *c->h_ctr; first = false; }
+        resk_done = c->h_ctr->n_resketch;
         const uint32_t d0 = c->h_ctr->n_big_defer[0], d1 = c->h_ctr->n_big_defer[1];
         if (d0 == 0 && d1 == 0) break;
         // a read deferred when it was alone in the arena can never fit
@@ -1003,7 +1113,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         Counters z = *c->h_ctr;
         z.n_defer = 0; z.arena_cursor = 0; z.n_resketch = n_defer;
         SH_HIP(hipMemcpyAsync(c->d_ctr, &z, sizeof(Counters), hipMemcpyHostToDevice, s));
-        b.work = c->d_work_defer2; b.work_count = &c->d_ctr->n_resketch; b.mode = 1; b.work_defer = c->d_work_defer;
+        b.work = c->d_work_defer2; b.work_count = &c->d_ctr->n_resketch; b.work_begin = 0; b.work_defer = c->d_work_defer;
         hipLaunchKernelGGL(k_chain_large, dim3(grid), dim3(64), 0, s, b);
         SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
         SH_HIP(hipStreamSynchronize(s));
@@ -1022,6 +1132,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         uint64_t nl = (uint64_t)snap.n_resketch + snap.n_big[0];
         stats->n_chain_large += nl; stats->n_chain_small += snap.n_small - snap.n_big[0];
         stats->n_minimizers += snap.sum_mini;
+        stats->n_anchors += c->h_ctr->sum_anchors; stats->n_clusters += c->h_ctr->n_clusters_total; stats->n_resketch += resk_done;
         stats->ms_sketch_probe += t01; stats->ms_chain_small += t12; stats->ms_chain_large += t23; stats->ms_total += t04;
     }
     return SH_OK;
