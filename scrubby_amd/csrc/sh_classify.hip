@@ -44,13 +44,41 @@
 #define SORT_LDS_A 1024         // reads with up to this many anchors are sorted in 24 KiB of LDS
 #define SORT_LDS_B 4096         // ... in 96 KiB of LDS; larger ones between two arena buffers
 
+__device__ inline uint32_t lane_id() { return threadIdx.x & 63; }
+
+// Device counters.  A single address sustains only ~90 M atomics/s on MI355X, so list tails are advanced
+// by whole chunks per wave (WaveAlloc) and statistics are sharded over 64 addresses.
 struct Counters {
-    uint32_t n_small, n_resketch, n_big[2], n_big_defer[2], n_defer, n_noseed, n_host;
-    uint32_t n_sort[3], n_clus_small, n_clus_big, n_clusters_total;
-    unsigned long long arena_cursor, sum_mini, anchor_cursor, sum_anchors;
+    uint32_t n_small, n_resketch, n_big[2], n_big_defer[2], n_defer, pad0;
+    uint32_t n_sort[3], n_clus_small, n_clus_big, pad1;
+    unsigned long long arena_cursor, anchor_cursor;
+    unsigned long long sh_mini[64], sh_anchors[64];     // sharded sums
+    uint32_t sh_host[64], sh_clusters[64];
+};
+#define SHARD() ((blockIdx.x + (blockIdx.x >> 6)) & 63)
+
+// wave-uniform bump allocator over a global counter: one atomic per `chunk` units
+struct WaveAlloc {
+    uint32_t cur = 0, end = 0;
+    // n is wave-uniform; every lane calls; returns the first index of n consecutive units.
+    // `lo`/`hi` receive the abandoned range of the previous chunk (to be invalidated by list users).
+    __device__ inline uint32_t take(uint32_t *counter, uint32_t n, uint32_t chunk, uint32_t &lo, uint32_t &hi)
+    {
+        lo = hi = 0;
+        if (cur + n > end) {
+            lo = cur; hi = end;
+            const uint32_t want = n > chunk ? n : chunk;
+            uint32_t base = 0;
+            if (lane_id() == 0) base = atomicAdd(counter, want);
+            base = (uint32_t)__shfl((int)base, 0);
+            cur = base; end = base + want;
+        }
+        const uint32_t r = cur;
+        cur += n;
+        return r;
+    }
 };
 
-__device__ inline uint32_t lane_id() { return threadIdx.x & 63; }
 __device__ inline uint32_t prefix_popc(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -271,15 +299,11 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
     if (to_k2) a.work_small[wi] = (uint32_t)r;
     wi = wave_append(&a.ctr->n_resketch, to_k3);
     if (to_k3) a.work_resketch[wi] = (uint32_t)r;
-    // statistics
-    uint64_t mdone = __ballot(done);
+    // statistics (sharded)
     uint32_t msum = n_mini;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) msum += (uint32_t)__shfl_xor((int)msum, o);
-    if (lane == 0) {
-        if (mdone) atomicAdd(&a.ctr->n_noseed, (uint32_t)__popcll(mdone));
-        atomicAdd(&a.ctr->sum_mini, (unsigned long long)msum);
-    }
+    if (lane == 0) atomicAdd(&a.ctr->sh_mini[SHARD()], (unsigned long long)msum);
 }
 
 // route every read of the batch to K3 (k > 23 or reads too long for the LDS stage)
@@ -338,6 +362,7 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
     const uint32_t n_work = *a.work_count;
     SmallStore<CAP> S;
     S.lo = s_lo + lane; S.aux = s_aux + lane; S.qv = s_q + lane; S.gv = s_g + lane;
+    uint32_t n_host_wave = 0;
 
     for (uint32_t base = blockIdx.x * 64; base < n_work; base += gridDim.x * 64) {
         const uint32_t wi = base + lane;
@@ -370,9 +395,9 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
         }
         uint32_t bi = wave_append(&a.ctr->n_big[0], routed);     // the repeat path starts every read at pass 0
         if (routed) a.work_big[bi] = r;
-        uint64_t mh = __ballot(host);
-        if (lane == 0 && mh) atomicAdd(&a.ctr->n_host, (uint32_t)__popcll(mh));
+        n_host_wave += (uint32_t)__popcll(__ballot(host));
     }
+    if (lane == 0 && n_host_wave) atomicAdd(&a.ctr->sh_host[SHARD()], n_host_wave);
 }
 
 // ---- wave helpers ------------------------------------------------------------------------------------
@@ -410,17 +435,36 @@ __device__ inline void wave_rank_sort(uint64_t &x, uint32_t &q, uint32_t n, uint
 struct ClusterSink {
     ClusterDesc *small, *big; Counters *ctr;
     uint32_t w, qlen; bool keep_single;
+    WaveAlloc *as, *ab; uint32_t *n_clusters;      // wave-local state owned by the kernel
+    static __device__ inline void invalidate(ClusterDesc *list, uint32_t lo, uint32_t hi)
+    {
+        for (uint32_t i = lo + lane_id(); i < hi; i += 64) list[i].len = 0;
+    }
     // every lane calls; pred lanes append the cluster [start, start+len) of this read
     __device__ inline void emit(bool pred, unsigned long long start, uint32_t len)
     {
         pred = pred && (len >= 2 || keep_single);
-        bool sm = pred && len <= DP_SMALL_CAP, bg = pred && len > DP_SMALL_CAP;
-        uint64_t pm = __ballot(pred);
-        if (pm && lane_id() == (uint32_t)(__ffsll((unsigned long long)pm) - 1)) atomicAdd(&ctr->n_clusters_total, (uint32_t)__popcll(pm));
-        uint32_t i = wave_append(&ctr->n_clus_small, sm);
-        if (sm) { ClusterDesc d{start, len, w, qlen, 0}; small[i] = d; }
-        i = wave_append(&ctr->n_clus_big, bg);
-        if (bg) { ClusterDesc d{start, len, w, qlen, 0}; big[i] = d; }
+        const bool sm = pred && len <= DP_SMALL_CAP, bg = pred && len > DP_SMALL_CAP;
+        const uint64_t ms = __ballot(sm), mb = __ballot(bg);
+        uint32_t lo, hi;
+        if (ms) {
+            uint32_t base = as->take(&ctr->n_clus_small, (uint32_t)__popcll(ms), 256, lo, hi);
+            invalidate(small, lo, hi);
+            if (sm) { ClusterDesc d{start, len, w, qlen, 0}; small[base + prefix_popc(ms)] = d; }
+        }
+        if (mb) {
+            uint32_t base = ab->take(&ctr->n_clus_big, (uint32_t)__popcll(mb), 64, lo, hi);
+            invalidate(big, lo, hi);
+            if (bg) { ClusterDesc d{start, len, w, qlen, 0}; big[base + prefix_popc(mb)] = d; }
+        }
+        *n_clusters += (uint32_t)__popcll(ms | mb);
+    }
+    // at kernel end: leftover slots of the wave's last chunks must not look like clusters
+    __device__ inline void close()
+    {
+        invalidate(small, as->cur, as->end);
+        invalidate(big, ab->cur, ab->end);
+        if (lane_id() == 0 && *n_clusters) atomicAdd(&ctr->sh_clusters[SHARD()], *n_clusters);
     }
 };
 
@@ -475,6 +519,10 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
     const uint32_t n_items = *a.list_count;
     const ChainParams &P = a.P;
     const bool plain_cut = !(P.occ_dist > 0 && P.max_max_occ > a.max_occ);
+    WaveAlloc al_small, al_big, al_sort[3];
+    uint32_t n_clusters = 0;
+    unsigned long long anchors_wave = 0, a_cur = 0, a_end = 0;      // wave-local slice of the anchor arena
+    ClusterSink sink{a.B.clus_small, a.B.clus_big, a.ctr, 0, 0, !(P.k < P.min_sc || P.min_cnt > 1), &al_small, &al_big, &n_clusters};
     for (uint32_t w = blockIdx.x; w < n_items; w += gridDim.x) {
         const uint32_t r = a.list[w];
         const uint32_t info = a.k1info[r];
@@ -556,17 +604,24 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
         // the count can exceed 31 bits only for absurd inputs; saturate (such a read never gets arena space)
         const uint32_t n_a = n_part > 0x7fffffffull ? 0x7fffffffu : (uint32_t)n_part;
 
-        unsigned long long off = 0;
-        if (lane == 0 && n_a > 0) off = atomicAdd(&a.ctr->anchor_cursor, (unsigned long long)n_a);
-        off = (unsigned long long)__shfl((long long)off, 0);
+        // anchor slots: the wave advances the arena cursor by 16 Ki slots at a time
+        if (n_a > 0 && a_cur + n_a > a_end) {
+            const unsigned long long want = n_a > 16384u ? n_a : 16384u;
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&a.ctr->anchor_cursor, want);
+            base = (unsigned long long)__shfl((long long)base, 0);
+            a_cur = base; a_end = base + want;
+        }
+        const unsigned long long off = a_cur;
         const bool defer = n_a > 0 && off + n_a > a.B.anchor_cap;
         if (lane == 0) {
             BigMeta m{r, n_a, rep_len, defer ? 1u : 0u};
             a.B.meta[w] = m; a.B.acc_nu[w] = 0; a.B.acc_best[w] = 0;
             if (defer) { uint32_t di = atomicAdd(a.defer_count, 1u); a.defer_list[di] = r; }
-            else atomicAdd(&a.ctr->sum_anchors, (unsigned long long)n_a);
         }
-        if (defer || n_a == 0) continue;
+        if (defer) { a_cur = a_end = 0; continue; }
+        if (n_a == 0) continue;
+        a_cur += n_a; anchors_wave += n_a;
 
         // ---- pass 2: anchors in generation order (seed order, then occurrence order) ----
         uint32_t run = 0;
@@ -609,25 +664,32 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
                 wave_rank_sort(x, q, n_a, lane);
                 if (lane < n_a) { a.B.ax[off + lane] = x; a.B.aq[off + lane] = q; }
             }
-            ClusterSink sink{a.B.clus_small, a.B.clus_big, a.ctr, w, (uint32_t)qlen, !(P.k < P.min_sc || P.min_cnt > 1)};
+            sink.w = w; sink.qlen = (uint32_t)qlen;
             uint32_t open_start = 0;
             tile_clusters(sink, x, 0, false, n_a, lane, off, 0, open_start, chain_max_dist_x(P, qlen));
             sink.emit(lane == 0, off + open_start, n_a - open_start);
-        } else if (lane == 0) {
+        } else {
             const int cls = n_a <= SORT_LDS_A ? 0 : (n_a <= SORT_LDS_B ? 1 : 2);
-            uint32_t si = atomicAdd(&a.ctr->n_sort[cls], 1u);
-            SortItem it{w, n_a, (uint32_t)qlen, 0, off};
-            a.B.sort_items[cls][si] = it;
+            uint32_t lo, hi;
+            const uint32_t si = al_sort[cls].take(&a.ctr->n_sort[cls], 1, cls == 0 ? 32u : (cls == 1 ? 4u : 1u), lo, hi);
+            for (uint32_t i = lo + lane; i < hi; i += 64) a.B.sort_items[cls][i].n = 0;
+            if (lane == 0) { SortItem it{w, n_a, (uint32_t)qlen, 0, off}; a.B.sort_items[cls][si] = it; }
         }
     }
+    sink.close();
+    for (int cls = 0; cls < 3; ++cls)
+        for (uint32_t i = al_sort[cls].cur + lane; i < al_sort[cls].end; i += 64) a.B.sort_items[cls][i].n = 0;
+    if (lane == 0 && anchors_wave) atomicAdd(&a.ctr->sh_anchors[SHARD()], anchors_wave);
 }
 
-// stable wave merge sort: 64-element tiles ranked in registers, then merge-path rounds between (sx,sq) and (dx,dq).
-// Returns true if the result ended in the second buffer.
+// stable block merge sort: 64-element tiles ranked in registers (one tile per wave at a time), then merge-path
+// rounds between (sx,sq) and (dx,dq), C outputs per thread and step.  Returns true if the result ended in the
+// second buffer.  Every thread of the block must call.
 template <class PX, class PQ>
-__device__ inline bool wave_merge_sort(PX sx, PQ sq, PX dx, PQ dq, uint32_t n, uint32_t lane)
+__device__ inline bool block_merge_sort(PX sx, PQ sq, PX dx, PQ dq, uint32_t n)
 {
-    for (uint32_t base = 0; base < n; base += 64) {
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+    for (uint32_t base = wave * 64; base < n; base += nwave * 64) {
         const uint32_t cnt = n - base < 64 ? n - base : 64;
         uint64_t x = lane < cnt ? sx[base + lane] : ~0ull;
         uint32_t q = lane < cnt ? sq[base + lane] : 0u;
@@ -642,7 +704,7 @@ __device__ inline bool wave_merge_sort(PX sx, PQ sq, PX dx, PQ dq, uint32_t n, u
     const uint32_t n_chunks = (n + C - 1) / C;
     bool flipped = false;
     for (uint32_t width = 64; width < n; width <<= 1) {
-        for (uint32_t c = lane; c < n_chunks; c += 64) {
+        for (uint32_t c = tid; c < n_chunks; c += nthr) {
             const uint32_t o0 = c * C, o1 = o0 + C < n ? o0 + C : n;
             const uint32_t pb = o0 / (2 * width) * (2 * width);
             const uint32_t L0 = pb, L1 = pb + width < n ? pb + width : n, R1 = pb + 2 * width < n ? pb + 2 * width : n;
@@ -667,62 +729,76 @@ __device__ inline bool wave_merge_sort(PX sx, PQ sq, PX dx, PQ dq, uint32_t n, u
     return flipped;
 }
 
-// one wave per read with 64 < anchors <= NMAX: sort in LDS, write back, cluster boundaries
-template <int NMAX, int CLS>
-__global__ __launch_bounds__(64) void k_sort_lds(K3Args a)
+// cluster boundaries of a sorted anchor array, by the first wave of the block
+template <class PX>
+__device__ inline void emit_clusters(ClusterSink &sink, PX rx, uint32_t n, unsigned long long off, uint32_t mdx)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t open_start = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t cnt = n - base < 64 ? n - base : 64;
+        uint64_t x = lane < cnt ? rx[base + lane] : ~0ull;
+        uint64_t xprev = base > 0 ? rx[base - 1] : 0;
+        tile_clusters(sink, x, xprev, base > 0, cnt, lane, off, base, open_start, mdx);
+    }
+    sink.emit(lane == 0, off + open_start, n - open_start);
+}
+
+// one block per read with 64 < anchors <= NMAX: sort in LDS, write back, cluster boundaries
+template <int NMAX, int CLS, int NTHR>
+__global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
 {
     __shared__ uint64_t s_x[2][NMAX];
     __shared__ uint32_t s_q[2][NMAX];
-    const uint32_t lane = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
     const uint32_t n_items = a.ctr->n_sort[CLS];
+    WaveAlloc al_small, al_big;
+    uint32_t n_clusters = 0;
+    ClusterSink sink{a.B.clus_small, a.B.clus_big, a.ctr, 0, 0, !(a.P.k < a.P.min_sc || a.P.min_cnt > 1), &al_small, &al_big, &n_clusters};
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
         const SortItem si = a.B.sort_items[CLS][it];
         const uint32_t n = si.n;
+        if (n == 0) continue;
         uint64_t *gx = a.B.ax + si.off; uint32_t *gq = a.B.aq + si.off;
-        for (uint32_t i = lane; i < n; i += 64) { s_x[0][i] = gx[i]; s_q[0][i] = gq[i]; }
+        for (uint32_t i = tid; i < n; i += NTHR) { s_x[0][i] = gx[i]; s_q[0][i] = gq[i]; }
         __syncthreads();
-        const bool fl = wave_merge_sort(&s_x[0][0], &s_q[0][0], &s_x[1][0], &s_q[1][0], n, lane);
+        const bool fl = block_merge_sort(&s_x[0][0], &s_q[0][0], &s_x[1][0], &s_q[1][0], n);
         const uint64_t *rx = fl ? s_x[1] : s_x[0]; const uint32_t *rq = fl ? s_q[1] : s_q[0];
-        for (uint32_t i = lane; i < n; i += 64) { gx[i] = rx[i]; gq[i] = rq[i]; }
-        ClusterSink sink{a.B.clus_small, a.B.clus_big, a.ctr, si.w, si.qlen, !(a.P.k < a.P.min_sc || a.P.min_cnt > 1)};
-        const uint32_t mdx = chain_max_dist_x(a.P, (int32_t)si.qlen);
-        uint32_t open_start = 0;
-        for (uint32_t base = 0; base < n; base += 64) {
-            const uint32_t cnt = n - base < 64 ? n - base : 64;
-            uint64_t x = lane < cnt ? rx[base + lane] : ~0ull;
-            uint64_t xprev = base > 0 ? rx[base - 1] : 0;
-            tile_clusters(sink, x, xprev, base > 0, cnt, lane, si.off, base, open_start, mdx);
+        for (uint32_t i = tid; i < n; i += NTHR) { gx[i] = rx[i]; gq[i] = rq[i]; }
+        if (tid < 64) {
+            sink.w = si.w; sink.qlen = si.qlen;
+            emit_clusters(sink, rx, n, si.off, chain_max_dist_x(a.P, (int32_t)si.qlen));
         }
-        sink.emit(lane == 0, si.off + open_start, n - open_start);
         __syncthreads();
     }
+    if (tid < 64) sink.close();
 }
 
-// one wave per read with more anchors than the LDS variants hold: the same sort between two arena buffers
-__global__ __launch_bounds__(64) void k_sort(K3Args a)
+// one block per read with more anchors than the LDS variants hold: the same sort between two arena buffers
+__global__ __launch_bounds__(1024) void k_sort(K3Args a)
 {
-    const uint32_t lane = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
     const uint32_t n_items = a.ctr->n_sort[2];
+    WaveAlloc al_small, al_big;
+    uint32_t n_clusters = 0;
+    ClusterSink sink{a.B.clus_small, a.B.clus_big, a.ctr, 0, 0, !(a.P.k < a.P.min_sc || a.P.min_cnt > 1), &al_small, &al_big, &n_clusters};
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
         const SortItem si = a.B.sort_items[2][it];
         const uint32_t n = si.n;
+        if (n == 0) continue;
         uint64_t *gx = a.B.ax + si.off, *hx = a.B.bx + si.off;
         uint32_t *gq = a.B.aq + si.off, *hq = a.B.bq + si.off;
-        if (wave_merge_sort(gx, gq, hx, hq, n, lane)) {      // odd number of rounds: bring the result home
-            for (uint32_t i = lane; i < n; i += 64) { gx[i] = hx[i]; gq[i] = hq[i]; }
+        if (block_merge_sort(gx, gq, hx, hq, n)) {      // odd number of rounds: bring the result home
+            for (uint32_t i = tid; i < n; i += blockDim.x) { gx[i] = hx[i]; gq[i] = hq[i]; }
             __syncthreads();
         }
-        ClusterSink sink{a.B.clus_small, a.B.clus_big, a.ctr, si.w, si.qlen, !(a.P.k < a.P.min_sc || a.P.min_cnt > 1)};
-        const uint32_t mdx = chain_max_dist_x(a.P, (int32_t)si.qlen);
-        uint32_t open_start = 0;
-        for (uint32_t base = 0; base < n; base += 64) {
-            const uint32_t cnt = n - base < 64 ? n - base : 64;
-            uint64_t x = lane < cnt ? gx[base + lane] : ~0ull;
-            uint64_t xprev = base > 0 ? gx[base - 1] : 0;
-            tile_clusters(sink, x, xprev, base > 0, cnt, lane, si.off, base, open_start, mdx);
+        if (tid < 64) {
+            sink.w = si.w; sink.qlen = si.qlen;
+            emit_clusters(sink, gx, n, si.off, chain_max_dist_x(a.P, (int32_t)si.qlen));
         }
-        sink.emit(lane == 0, si.off + open_start, n - open_start);
+        __syncthreads();
     }
+    if (tid < 64) sink.close();
 }
 
 // one lane per cluster of <= DP_SMALL_CAP anchors, LDS
@@ -736,10 +812,15 @@ __global__ __launch_bounds__(64) void k_dp_small(K3Args a)
     const uint32_t n_cl = a.ctr->n_clus_small;
     SmallStore<DP_SMALL_CAP> S;
     S.lo = s_lo + lane; S.aux = s_aux + lane; S.qv = s_q + lane; S.gv = s_g + lane;
-    for (uint32_t base = blockIdx.x * 64; base < n_cl; base += gridDim.x * 64) {
+    // each block walks one contiguous range of the list: a read's clusters are consecutive, so in flag-only
+    // mode everything after its first accepted chain is skipped
+    const uint32_t per_block = ((n_cl + gridDim.x - 1) / gridDim.x + 63) & ~63u;
+    const uint32_t r_beg = blockIdx.x * per_block, r_end = r_beg + per_block < n_cl ? r_beg + per_block : n_cl;
+    for (uint32_t base = r_beg; base < r_end; base += 64) {
         const uint32_t ci = base + lane;
-        if (ci >= n_cl) continue;
+        if (ci >= r_end) continue;
         const ClusterDesc d = a.B.clus_small[ci];
+        if (d.len == 0) continue;
         if (a.flag_only && __hip_atomic_load(&a.B.acc_nu[d.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;
         const uint64_t *x = a.B.ax + d.off; const uint32_t *q = a.B.aq + d.off;
         for (uint32_t i = 0; i < d.len; i += 4) {       // 4 independent loads in flight
@@ -760,8 +841,11 @@ __global__ __launch_bounds__(64) void k_dp_small(K3Args a)
 __global__ __launch_bounds__(64) void k_dp_big(K3Args a)
 {
     const uint32_t n_cl = a.ctr->n_clus_big;
-    for (uint32_t ci = blockIdx.x * 64 + threadIdx.x; ci < n_cl; ci += gridDim.x * 64) {
+    const uint32_t per_block = ((n_cl + gridDim.x - 1) / gridDim.x + 63) & ~63u;
+    const uint32_t r_beg = blockIdx.x * per_block, r_end = r_beg + per_block < n_cl ? r_beg + per_block : n_cl;
+    for (uint32_t ci = r_beg + threadIdx.x; ci < r_end; ci += 64) {
         const ClusterDesc d = a.B.clus_big[ci];
+        if (d.len == 0) continue;
         if (a.flag_only && __hip_atomic_load(&a.B.acc_nu[d.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;
         LargeStore S;
         S.x = a.B.ax + d.off; S.q = a.B.aq + d.off; S.x2 = nullptr; S.q2 = nullptr;
@@ -776,7 +860,10 @@ __global__ __launch_bounds__(64) void k_dp_big(K3Args a)
 __global__ void k_finalize(K3Args a)
 {
     const uint32_t n_items = *a.list_count;
-    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n_items; w += gridDim.x * blockDim.x) {
+    uint32_t n_host_thr = 0;
+    for (uint32_t w0 = blockIdx.x * blockDim.x; w0 < n_items; w0 += gridDim.x * blockDim.x) {
+        const uint32_t w = w0 + threadIdx.x;
+        if (w >= n_items) continue;
         const BigMeta m = a.B.meta[w];
         if (m.state != 0) continue;
         const int32_t n_u = a.B.acc_nu[w], best = a.B.acc_best[w];
@@ -789,8 +876,9 @@ __global__ void k_finalize(K3Args a)
         int32_t fl = n_u > 0;
         a.flags[m.r] = (uint8_t)fl;
         write_trace(a.trace, m.r, (int32_t)(info & 0xffffu), (int32_t)(info >> 16), (int32_t)m.n_a, m.rep_len, a.pass, n_u, best, fl);
-        if (fl) atomicAdd(&a.ctr->n_host, 1u);
+        n_host_thr += (uint32_t)fl;
     }
+    if (n_host_thr) atomicAdd(&a.ctr->sh_host[(blockIdx.x + threadIdx.x) & 63], n_host_thr);
 }
 
 __device__ inline uint8_t *arena_alloc(const K2Args &a, size_t bytes)
@@ -874,7 +962,7 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
             }
         }
         uint64_t mh = __ballot(host);
-        if (lane == 0 && mh) atomicAdd(&a.ctr->n_host, (uint32_t)__popcll(mh));
+        if (lane == 0 && mh) atomicAdd(&a.ctr->sh_host[SHARD()], (uint32_t)__popcll(mh));
     }
 }
 
@@ -1005,9 +1093,9 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     SH_HIP(hipMemsetAsync(&ctr->anchor_cursor, 0, 8, s));
     SH_HIP(hipMemsetAsync(&ctr->n_sort[0], 0, 20, s));       // n_sort[3], n_clus_small, n_clus_big
     hipLaunchKernelGGL(k_expand, dim3(grid * 2), dim3(64), 0, s, k);
-    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_A, 0>), dim3(grid), dim3(64), 0, s, k);
-    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_B, 1>), dim3(256), dim3(64), 0, s, k);
-    hipLaunchKernelGGL(k_sort, dim3(grid), dim3(64), 0, s, k);
+    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_A, 0, 128>), dim3(grid), dim3(128), 0, s, k);
+    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_B, 1, 512>), dim3(256), dim3(512), 0, s, k);
+    hipLaunchKernelGGL(k_sort, dim3(512), dim3(1024), 0, s, k);
     hipLaunchKernelGGL(k_dp_small, dim3(grid), dim3(64), 0, s, k);
     hipLaunchKernelGGL(k_dp_big, dim3(grid), dim3(64), 0, s, k);
     hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, s, k);
@@ -1127,12 +1215,14 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         float t01 = 0, t12 = 0, t23 = 0, t04 = 0;
         hipEventElapsedTime(&t01, c->ev[0], c->ev[1]); hipEventElapsedTime(&t12, c->ev[1], c->ev[2]);
         hipEventElapsedTime(&t23, c->ev[2], c->ev[3]); hipEventElapsedTime(&t04, c->ev[0], c->ev[4]);
+        uint64_t sum_host = 0, sum_mini = 0, sum_anchors = 0, sum_clusters = 0;
+        for (int i = 0; i < 64; ++i) { sum_host += c->h_ctr->sh_host[i]; sum_mini += c->h_ctr->sh_mini[i]; sum_anchors += c->h_ctr->sh_anchors[i]; sum_clusters += c->h_ctr->sh_clusters[i]; }
         stats->n_reads += n_reads; stats->n_bases += n_bases;
-        stats->n_host += c->h_ctr->n_host; stats->n_no_seed += snap.n_noseed;
+        stats->n_host += sum_host; stats->n_no_seed += n_reads - snap.n_small - snap.n_resketch;
         uint64_t nl = (uint64_t)snap.n_resketch + snap.n_big[0];
         stats->n_chain_large += nl; stats->n_chain_small += snap.n_small - snap.n_big[0];
-        stats->n_minimizers += snap.sum_mini;
-        stats->n_anchors += c->h_ctr->sum_anchors; stats->n_clusters += c->h_ctr->n_clusters_total; stats->n_resketch += resk_done;
+        stats->n_minimizers += sum_mini;
+        stats->n_anchors += sum_anchors; stats->n_clusters += sum_clusters; stats->n_resketch += resk_done;
         stats->ms_sketch_probe += t01; stats->ms_chain_small += t12; stats->ms_chain_large += t23; stats->ms_total += t04;
     }
     return SH_OK;
