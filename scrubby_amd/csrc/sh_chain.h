@@ -321,9 +321,12 @@ __device__ inline void backtrack_visit(Store &S, const ChainParams &P, int32_t z
     else n_v = n_v0;
 }
 
-// candidates (f >= min_sc) in descending (f, index) order; small n: O(n^2) selection, no extra memory
+// candidates (f >= min_sc) in descending (f, index) order; small n: O(n^2) selection, no extra memory.
+// A candidate already absorbed by an earlier chain (t != 0) is a no-op in mg_chain_backtrack, so the scan
+// skips it; with one dominant chain per cluster this ends after two scans.  first_only: stop at the first
+// accepted chain (the caller only needs "is there a mapping").
 template <class Store>
-__device__ inline void backtrack_small(Store &S, int n, const ChainParams &P, int32_t &n_u, int32_t &best)
+__device__ inline void backtrack_small(Store &S, int n, const ChainParams &P, int32_t &n_u, int32_t &best, bool first_only = false)
 {
     n_u = 0; best = 0;
     S.clearT(n);
@@ -333,29 +336,124 @@ __device__ inline void backtrack_small(Store &S, int n, const ChainParams &P, in
         int64_t cur = -1;
         for (int i = 0; i < n; ++i) {
             int32_t f = S.F(i);
-            if (f < P.min_sc) continue;
+            if (f < P.min_sc || S.T(i) != 0) continue;
             int64_t key = (int64_t)f << 32 | (uint32_t)i;
             if (key < bound && key > cur) cur = key;
         }
         if (cur < 0) break;
         bound = cur;
         backtrack_visit<Store, int>(S, P, (int32_t)(cur >> 32), (int)(cur & 0xffffffff), n_v, n_u, best);
+        if (first_only && n_u > 0) break;
     }
 }
 
-// large n: heap sort of (f<<32|index) in the arena, then the same visit order
-__device__ inline void backtrack_large(LargeStore &S, int64_t n, const ChainParams &P, int32_t &n_u, int32_t &best)
+// ---- n <= 64: the t[] array of mg_lchain_dp / mg_chain_backtrack lives in one 64-bit register ---------------
+// In the DP, t[j] == i only asks "was j the predecessor of an anchor already visited in THIS scan", so a mask
+// reset for every i is equivalent.  In the backtrack the transient value 2 never survives a call of
+// mg_chain_bk_end (it is set and cleared on the same path), so only t == 1 persists: one mask again.
+// Without the LDS store -> load dependency through t[] the j loop's loads are independent and pipeline.
+template <class Store>
+__device__ inline void chain_dp_mask(Store &S, int n, int32_t qlen, const ChainParams &P)
+{
+    int32_t max_dist_y = P.is_sr ? (qlen > P.max_gap ? qlen : P.max_gap) : P.max_gap;
+    int32_t max_dist_x;
+    if (P.max_gap_ref > 0) max_dist_x = P.max_gap_ref;
+    else if (P.max_frag_len > 0) { max_dist_x = P.max_frag_len - qlen; if (max_dist_x < P.max_gap) max_dist_x = P.max_gap; }
+    else max_dist_x = P.max_gap;
+    if (max_dist_x < P.bw) max_dist_x = P.bw;
+    if (max_dist_y < P.bw) max_dist_y = P.bw;
+
+    int st = 0, max_ii = -1;
+    for (int i = 0; i < n; ++i) {
+        int max_j = -1, j;
+        const uint32_t gi = S.grp(i), li = S.rlo(i), qi = S.qp(i);
+        int32_t max_f = P.k, n_skip = 0;
+        uint64_t marked = 0;
+        while (st < i && (gi != S.grp(st) || (uint64_t)li > (uint64_t)S.rlo(st) + (uint64_t)max_dist_x)) ++st;
+        if (i - st > P.max_iter) st = i - P.max_iter;
+#pragma unroll 2
+        for (j = i - 1; j >= st; --j) {
+            const int32_t fj = S.F(j), pj = S.Pm(j);
+            int32_t sc = comput_sc(li, qi, S.rlo(j), S.qp(j), max_dist_x, max_dist_y, P);
+            if (sc == SH_SC_NONE) continue;
+            sc += fj;
+            if (sc > max_f) {
+                max_f = sc; max_j = j;
+                if (n_skip > 0) --n_skip;
+            } else if ((marked >> j) & 1) {
+                if (++n_skip > P.max_skip) break;
+            }
+            if (pj >= 0) marked |= 1ULL << pj;
+        }
+        const int end_j = j;
+        bool far = true;
+        if (max_ii >= 0) far = (gi != S.grp(max_ii)) || ((uint64_t)(li - S.rlo(max_ii)) > (uint64_t)max_dist_x);
+        if (max_ii < 0 || far) {
+            int32_t mx = INT32_MIN;
+            max_ii = -1;
+            for (j = i - 1; j >= st; --j) { int32_t fj = S.F(j); if (mx < fj) { mx = fj; max_ii = j; } }
+        }
+        if (max_ii >= 0 && max_ii < end_j) {
+            int32_t tmp = comput_sc(li, qi, S.rlo(max_ii), S.qp(max_ii), max_dist_x, max_dist_y, P);
+            if (tmp != SH_SC_NONE && max_f < tmp + S.F(max_ii)) { max_f = tmp + S.F(max_ii); max_j = max_ii; }
+        }
+        S.setFP(i, max_f, max_j);
+        bool near = false;
+        if (max_ii >= 0) near = (gi == S.grp(max_ii)) && ((uint64_t)(li - S.rlo(max_ii)) <= (uint64_t)max_dist_x);
+        if (max_ii < 0 || (near && S.F(max_ii) < max_f)) max_ii = i;
+    }
+}
+
+template <class Store>
+__device__ inline void backtrack_mask(Store &S, int n, const ChainParams &P, int32_t &n_u, int32_t &best, bool first_only)
 {
     n_u = 0; best = 0;
-    uint64_t *z = S.z;
-    int64_t nz = 0;
-    for (int64_t i = 0; i < n; ++i) if (S.f[i] >= P.min_sc) z[nz++] = (uint64_t)(uint32_t)S.f[i] << 32 | (uint32_t)i;
+    uint64_t done = 0;            // t == 1
+    int64_t n_v = 0, bound = INT64_MAX;
+    for (;;) {
+        int64_t cur = -1;
+        for (int i = 0; i < n; ++i) {
+            int32_t f = S.F(i);
+            if (f < P.min_sc || ((done >> i) & 1)) continue;
+            int64_t key = (int64_t)f << 32 | (uint32_t)i;
+            if (key < bound && key > cur) cur = key;
+        }
+        if (cur < 0) break;
+        bound = cur;
+        const int32_t zf = (int32_t)(cur >> 32);
+        const int zi = (int)(cur & 0xffffffff);
+        // mg_chain_bk_end
+        int i = zi, end_i = -1, max_i = zi;
+        int32_t max_s = 0;
+        do {
+            end_i = i = S.Pm(i);
+            int32_t sc = i < 0 ? zf : zf - S.F(i);
+            if (sc > max_s) { max_s = sc; max_i = i; }
+            else if (max_s - sc > P.bw) break;
+        } while (i >= 0 && !((done >> i) & 1));
+        (void)end_i;
+        const int64_t n_v0 = n_v;
+        for (i = zi; i != max_i; i = S.Pm(i)) { ++n_v; done |= 1ULL << i; }
+        const int32_t sc = i < 0 ? zf : zf - S.F(i);
+        if (sc >= P.min_sc && n_v > n_v0 && n_v - n_v0 >= P.min_cnt) { ++n_u; if (sc > best) best = sc; }
+        else n_v = n_v0;
+        if (first_only && n_u > 0) break;
+    }
+}
+
+// large n: heap sort of (f<<32|index) in caller-provided memory z (n entries), then the same visit order
+template <class Store, class Idx>
+__device__ inline void backtrack_heap(Store &S, Idx n, const ChainParams &P, uint64_t *z, int32_t &n_u, int32_t &best, bool first_only = false)
+{
+    n_u = 0; best = 0;
+    Idx nz = 0;
+    for (Idx i = 0; i < n; ++i) { int32_t f = S.F(i); if (f >= P.min_sc) z[nz++] = (uint64_t)(uint32_t)f << 32 | (uint32_t)i; }
     if (nz == 0) return;
     S.clearT(n);
     // max-heap; pop order = descending (f, index)
-    auto down = [&](int64_t i, int64_t m) {
+    auto down = [&](Idx i, Idx m) {
         uint64_t tmp = z[i];
-        int64_t k = i;
+        Idx k = i;
         while ((k = (k << 1) + 1) < m) {
             if (k != m - 1 && z[k] < z[k + 1]) ++k;
             if (z[k] < tmp) break;
@@ -363,12 +461,43 @@ __device__ inline void backtrack_large(LargeStore &S, int64_t n, const ChainPara
         }
         z[i] = tmp;
     };
-    for (int64_t i = (nz >> 1) - 1; i >= 0; --i) down(i, nz);
+    for (Idx i = (nz >> 1) - 1; i >= 0; --i) down(i, nz);
     int64_t n_v = 0;
-    for (int64_t m = nz; m > 0; --m) {
+    for (Idx m = nz; m > 0; --m) {
         uint64_t top = z[0];
         z[0] = z[m - 1];
         if (m - 1 > 0) down(0, m - 1);
-        backtrack_visit<LargeStore, int64_t>(S, P, (int32_t)(top >> 32), (int64_t)(top & 0xffffffff), n_v, n_u, best);
+        backtrack_visit<Store, Idx>(S, P, (int32_t)(top >> 32), (Idx)(top & 0xffffffff), n_v, n_u, best);
+        if (first_only && n_u > 0) break;
+    }
+}
+
+// A cluster = contiguous slice of a read's sorted anchors on one strand of one contig (so x>>32 is constant).
+// x/q are the sorted anchors, f and pt (p,t interleaved) the DP state; LDS or arena pointers alike.
+struct SliceStore {
+    const uint64_t *x; const uint32_t *q; int32_t *f; int32_t *pt;
+    __device__ inline uint32_t grp(int32_t) const { return 0; }
+    __device__ inline uint32_t rlo(int32_t i) const { return (uint32_t)x[i]; }
+    __device__ inline uint32_t qp(int32_t i) const { return q[i] & 0x7fffffffu; }     // bit 31 = cluster-start mark
+    __device__ inline int32_t F(int32_t i) const { return f[i]; }
+    __device__ inline int32_t Pm(int32_t i) const { return pt[2 * i]; }
+    __device__ inline int32_t T(int32_t i) const { return pt[2 * i + 1]; }
+    __device__ inline void setFP(int32_t i, int32_t fv, int32_t pv) { f[i] = fv; pt[2 * i] = pv; }
+    __device__ inline void setT(int32_t i, int32_t tv) { pt[2 * i + 1] = tv; }
+    __device__ inline void clearT(int32_t n) { for (int32_t i = 0; i < n; ++i) pt[2 * i + 1] = 0; }
+    __device__ inline void clearAux(int32_t n) { clearT(n); }
+};
+
+// DP + backtrack of one cluster.  zbuf: n 8-B words for the heap when n > 32 (may alias the x slice: the
+// anchors are dead once the DP is done).
+__device__ inline void chain_cluster(SliceStore &S, int32_t n, int32_t qlen, const ChainParams &P, uint64_t *zbuf, int32_t &n_u, int32_t &best,
+                                     bool first_only)
+{
+    if (n <= 64) {
+        chain_dp_mask(S, n, qlen, P);
+        backtrack_mask(S, n, P, n_u, best, first_only);
+    } else {
+        chain_dp<SliceStore, int32_t>(S, n, qlen, P);
+        backtrack_heap<SliceStore, int32_t>(S, n, P, zbuf, n_u, best, first_only);
     }
 }

@@ -25,8 +25,10 @@
 //                         anchors written coalesced to the HBM arena, <= 64 anchors sorted in registers
 //          k_sort         one wave per longer read: 64-anchor tiles ranked in registers, then merge-path
 //                         rounds between two arena buffers; cluster boundaries by ballot
-//          k_dp_small     one lane per cluster of <= 32 anchors, DP + backtrack in LDS (the K2 code)
-//          k_dp_big       larger clusters over arena slices
+//                         and chained on the spot (one lane per cluster start, state in 1.5 KiB of LDS)
+//          k_sort_lds     one block per read with <= 1024 / <= 4096 anchors: stable merge sort in LDS, then
+//                         every cluster chained straight from LDS; only the per-read result returns to HBM
+//          k_sort         giant reads: the same between two arena buffers
 //          k_finalize     per read: flag / trace, or hand the read to the second (max_occ) pass
 //   k_chain_large   legacy lane-per-read path over arena slices, kept for the rare reads K1 could not
 //        finish (seed/list overflow), which it re-sketches.
@@ -41,8 +43,10 @@
 #define K1_FLUSH_AT 16
 #define K2_CAP 32               // anchors per read chained in LDS
 #define DP_SMALL_CAP 32         // anchors per cluster chained in LDS
-#define SORT_LDS_A 1024         // reads with up to this many anchors are sorted in 24 KiB of LDS
-#define SORT_LDS_B 4096         // ... in 96 KiB of LDS; larger ones between two arena buffers
+#define SORT_LDS_A 512          // reads with up to this many anchors are sorted and chained in 12 KiB of LDS
+#define SORT_LDS_B 2048         // ... 48 KiB
+#define SORT_LDS_C 4096         // ... 96 KiB; larger ones: 4096-anchor chunks in LDS, then merge rounds in the arena
+#define N_SORT_CLS 4
 
 __device__ inline uint32_t lane_id() { return threadIdx.x & 63; }
 
@@ -50,7 +54,7 @@ __device__ inline uint32_t lane_id() { return threadIdx.x & 63; }
 // by whole chunks per wave (WaveAlloc) and statistics are sharded over 64 addresses.
 struct Counters {
     uint32_t n_small, n_resketch, n_big[2], n_big_defer[2], n_defer, pad0;
-    uint32_t n_sort[3], n_clus_small, n_clus_big, pad1;
+    uint32_t n_sort[N_SORT_CLS], pad1[2];
     unsigned long long arena_cursor, anchor_cursor;
     unsigned long long sh_mini[64], sh_anchors[64];     // sharded sums
     uint32_t sh_host[64], sh_clusters[64];
@@ -320,13 +324,11 @@ __global__ void k_route_all(uint64_t n_reads, uint32_t *work_resketch, Counters 
 // ------------------------------------------------------------------------------------------------
 struct BigMeta { uint32_t r, n_a; int32_t rep_len; uint32_t state; };   // state: 0 expanded, 1 deferred
 struct SortItem { uint32_t w, n, qlen, pad; unsigned long long off; };
-struct ClusterDesc { unsigned long long off; uint32_t len, w; uint32_t qlen, pad; };
-
 struct BigBufs {        // the repeat path's slice of the arena (all arrays indexed by anchor slot)
-    uint64_t *ax, *bx, *az; uint32_t *aq, *bq; int32_t *af, *ap, *at;
+    uint64_t *ax, *bx, *az; uint32_t *aq, *bq; int32_t *af;   // anchors (+ sort ping-pong), DP state f and (p,t)
     unsigned long long anchor_cap;
     BigMeta *meta; int32_t *acc_nu, *acc_best;
-    SortItem *sort_items[3]; ClusterDesc *clus_small, *clus_big;
+    SortItem *sort_items[N_SORT_CLS];
 };
 
 struct K2Args {
@@ -383,8 +385,8 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
                 seed_filter(sv, qlen, max_occ, a.P, n_a, rep_len);
                 if (n_a > CAP) { routed = true; break; }
                 gen_anchors(S, sv, a.positions, qlen, a.P.k);
-                chain_dp<SmallStore<CAP>, int>(S, (int)n_a, qlen, a.P);
-                backtrack_small(S, (int)n_a, a.P, n_u, best);
+                chain_dp_mask(S, (int)n_a, qlen, a.P);
+                backtrack_mask(S, (int)n_a, a.P, n_u, best, a.trace == nullptr);
                 if (!rechained && n_u == 0 && a.P.max_occ > a.P.mid_occ && rep_len > 0) { rechained = 1; max_occ = a.P.max_occ; continue; }
                 break;
             }
@@ -432,59 +434,46 @@ __device__ inline void wave_rank_sort(uint64_t &x, uint32_t &q, uint32_t n, uint
     x = (uint64_t)xh << 32 | xl;
 }
 
-struct ClusterSink {
-    ClusterDesc *small, *big; Counters *ctr;
-    uint32_t w, qlen; bool keep_single;
-    WaveAlloc *as, *ab; uint32_t *n_clusters;      // wave-local state owned by the kernel
-    static __device__ inline void invalidate(ClusterDesc *list, uint32_t lo, uint32_t hi)
-    {
-        for (uint32_t i = lo + lane_id(); i < hi; i += 64) list[i].len = 0;
-    }
-    // every lane calls; pred lanes append the cluster [start, start+len) of this read
-    __device__ inline void emit(bool pred, unsigned long long start, uint32_t len)
-    {
-        pred = pred && (len >= 2 || keep_single);
-        const bool sm = pred && len <= DP_SMALL_CAP, bg = pred && len > DP_SMALL_CAP;
-        const uint64_t ms = __ballot(sm), mb = __ballot(bg);
-        uint32_t lo, hi;
-        if (ms) {
-            uint32_t base = as->take(&ctr->n_clus_small, (uint32_t)__popcll(ms), 256, lo, hi);
-            invalidate(small, lo, hi);
-            if (sm) { ClusterDesc d{start, len, w, qlen, 0}; small[base + prefix_popc(ms)] = d; }
-        }
-        if (mb) {
-            uint32_t base = ab->take(&ctr->n_clus_big, (uint32_t)__popcll(mb), 64, lo, hi);
-            invalidate(big, lo, hi);
-            if (bg) { ClusterDesc d{start, len, w, qlen, 0}; big[base + prefix_popc(mb)] = d; }
-        }
-        *n_clusters += (uint32_t)__popcll(ms | mb);
-    }
-    // at kernel end: leftover slots of the wave's last chunks must not look like clusters
-    __device__ inline void close()
-    {
-        invalidate(small, as->cur, as->end);
-        invalidate(big, ab->cur, ab->end);
-        if (lane_id() == 0 && *n_clusters) atomicAdd(&ctr->sh_clusters[SHARD()], *n_clusters);
-    }
-};
-
-// cluster boundaries of one tile of sorted anchors held in registers (lane i <-> anchor base+i);
-// `open_start` (uniform) = start of the cluster still open from earlier tiles
-__device__ inline void tile_clusters(ClusterSink &sink, uint64_t x, uint64_t x_prev_tile, bool has_prev_tile, uint32_t cnt,
-                                     uint32_t lane, unsigned long long off, uint32_t base, uint32_t &open_start, uint32_t max_dist_x)
+__device__ inline uint32_t chain_max_dist_x(const ChainParams &P, int32_t qlen)
 {
-    uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
-    uint32_t pl = (uint32_t)__shfl_up((int)xl, 1), ph = (uint32_t)__shfl_up((int)xh, 1);
-    if (lane == 0) { pl = (uint32_t)x_prev_tile; ph = (uint32_t)(x_prev_tile >> 32); }
-    bool first = lane == 0 && !has_prev_tile;
-    bool bnd = lane < cnt && (first || xh != ph || xl - pl > max_dist_x);
-    uint64_t bm = __ballot(bnd);
-    // a boundary closes the cluster that started at the previous boundary
-    uint64_t below = bm & ((1ULL << lane) - 1);
-    uint32_t prev_start = below ? base + (63 - __clzll((unsigned long long)below)) : open_start;
-    bool closes = bnd && !first;
-    sink.emit(closes, off + prev_start, base + lane - prev_start);
-    if (bm) open_start = base + (63 - __clzll((unsigned long long)bm));
+    int32_t m;
+    if (P.max_gap_ref > 0) m = P.max_gap_ref;
+    else if (P.max_frag_len > 0) { m = P.max_frag_len - qlen; if (m < P.max_gap) m = P.max_gap; }
+    else m = P.max_gap;
+    if (m < P.bw) m = P.bw;
+    return (uint32_t)m;
+}
+
+// Chains every cluster of a sorted anchor array x[0..n) / q[0..n), one lane per cluster start.
+// f / pt: DP state arrays of n (2n) int32.  Returns this thread's (chains, best score, clusters).
+// `found`: block-shared flag for the flag-only early exit (nullptr: chain everything).
+// Phase A marks cluster starts in bit 31 of q (read-only afterwards), so that in phase B a cluster's owner may
+// recycle its x slice as heap space while other lanes are still measuring their clusters.  All threads call.
+template <class PX, class PQ>
+__device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_t n, uint32_t tid, uint32_t nthr, int32_t qlen,
+                                    const ChainParams &P, volatile int32_t *found, int32_t &n_u_thr, int32_t &best_thr, uint32_t &n_cl_thr)
+{
+    const uint32_t mdx = chain_max_dist_x(P, qlen);
+    const bool keep_single = !(P.k < P.min_sc || P.min_cnt > 1);
+    for (uint32_t i = tid; i < n; i += nthr) {
+        bool start = i == 0;
+        if (!start) { const uint64_t xi = x[i], xp = x[i - 1]; start = (uint32_t)(xi >> 32) != (uint32_t)(xp >> 32) || (uint32_t)xi - (uint32_t)xp > mdx; }
+        if (start) q[i] |= 0x80000000u;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += nthr) {
+        if (!(q[i] >> 31)) continue;
+        uint32_t j = i + 1;
+        while (j < n && !(q[j] >> 31)) ++j;
+        const uint32_t len = j - i;
+        if (len < 2 && !keep_single) continue;
+        if (found && *found) continue;
+        SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i};
+        int32_t n_u, best;
+        chain_cluster(S, (int32_t)len, qlen, P, (uint64_t *)&x[i], n_u, best, found != nullptr);
+        ++n_cl_thr;
+        if (n_u > 0) { n_u_thr += n_u; if (best > best_thr) best_thr = best; if (found) *found = 1; }
+    }
 }
 
 struct K3Args {
@@ -499,15 +488,6 @@ struct K3Args {
     int32_t pass, max_occ, flag_only;
 };
 
-__device__ inline uint32_t chain_max_dist_x(const ChainParams &P, int32_t qlen)
-{
-    int32_t m;
-    if (P.max_gap_ref > 0) m = P.max_gap_ref;
-    else if (P.max_frag_len > 0) { m = P.max_frag_len - qlen; if (m < P.max_gap) m = P.max_gap; }
-    else m = P.max_gap;
-    if (m < P.bw) m = P.bw;
-    return (uint32_t)m;
-}
 
 // one wave per read: seeds -> filter -> anchors (arena) -> [<= 64: sort + clusters]
 // Seeds are handled 64 at a time, one per lane.  mm_seed_select's streak logic needs a read's seeds in one
@@ -519,10 +499,12 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
     const uint32_t n_items = *a.list_count;
     const ChainParams &P = a.P;
     const bool plain_cut = !(P.occ_dist > 0 && P.max_max_occ > a.max_occ);
-    WaveAlloc al_small, al_big, al_sort[3];
+    WaveAlloc al_sort[N_SORT_CLS];
     uint32_t n_clusters = 0;
     unsigned long long anchors_wave = 0, a_cur = 0, a_end = 0;      // wave-local slice of the anchor arena
-    ClusterSink sink{a.B.clus_small, a.B.clus_big, a.ctr, 0, 0, !(P.k < P.min_sc || P.min_cnt > 1), &al_small, &al_big, &n_clusters};
+    __shared__ uint64_t e_x[64];
+    __shared__ uint32_t e_q[64];
+    __shared__ int32_t e_f[64], e_pt[128];
     for (uint32_t w = blockIdx.x; w < n_items; w += gridDim.x) {
         const uint32_t r = a.list[w];
         const uint32_t info = a.k1info[r];
@@ -604,8 +586,9 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
         // the count can exceed 31 bits only for absurd inputs; saturate (such a read never gets arena space)
         const uint32_t n_a = n_part > 0x7fffffffull ? 0x7fffffffu : (uint32_t)n_part;
 
+        const bool in_lds = n_a <= 64;     // short anchor lists never leave the CU
         // anchor slots: the wave advances the arena cursor by 16 Ki slots at a time
-        if (n_a > 0 && a_cur + n_a > a_end) {
+        if (!in_lds && a_cur + n_a > a_end) {
             const unsigned long long want = n_a > 16384u ? n_a : 16384u;
             unsigned long long base = 0;
             if (lane == 0) base = atomicAdd(&a.ctr->anchor_cursor, want);
@@ -613,7 +596,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
             a_cur = base; a_end = base + want;
         }
         const unsigned long long off = a_cur;
-        const bool defer = n_a > 0 && off + n_a > a.B.anchor_cap;
+        const bool defer = !in_lds && off + n_a > a.B.anchor_cap;
         if (lane == 0) {
             BigMeta m{r, n_a, rep_len, defer ? 1u : 0u};
             a.B.meta[w] = m; a.B.acc_nu[w] = 0; a.B.acc_best[w] = 0;
@@ -621,7 +604,10 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
         }
         if (defer) { a_cur = a_end = 0; continue; }
         if (n_a == 0) continue;
-        a_cur += n_a; anchors_wave += n_a;
+        if (!in_lds) a_cur += n_a;
+        anchors_wave += n_a;
+        uint64_t *const gx = in_lds ? e_x : a.B.ax + off;
+        uint32_t *const gq = in_lds ? e_q : a.B.aq + off;
 
         // ---- pass 2: anchors in generation order (seed order, then occurrence order) ----
         uint32_t run = 0;
@@ -635,7 +621,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
                 if (my_n == 1) {
                     uint64_t x; uint32_t q;
                     make_anchor(w1, rec.w, qlen, P.k, x, q);
-                    a.B.ax[off + start] = x; a.B.aq[off + start] = q;
+                    gx[start] = x; gq[start] = q;
                 }
             } else {
                 const uint32_t cnt_s = n_seed - t * 64 < 64 ? n_seed - t * 64 : 64;
@@ -648,38 +634,42 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
                     for (uint32_t u = lane; u < os; u += 64) {
                         uint64_t x; uint32_t q;
                         make_anchor(os == 1 ? sw1 : cr[u], sq, qlen, P.k, x, q);
-                        a.B.ax[off + ss + u] = x; a.B.aq[off + ss + u] = q;
+                        gx[ss + u] = x; gq[ss + u] = q;
                     }
                 }
             }
             run += wave_sum_u32(my_n);
         }
         __syncthreads();
-        if (n_a <= 64) {
-            uint64_t x = lane < n_a ? a.B.ax[off + lane] : ~0ull;
-            uint32_t q = lane < n_a ? a.B.aq[off + lane] : 0u;
+        if (in_lds) {
+            uint64_t x = lane < n_a ? e_x[lane] : ~0ull;
+            uint32_t q = lane < n_a ? e_q[lane] : 0u;
             uint64_t xp = (uint64_t)__shfl_up((long long)x, 1);
-            bool unsorted = __ballot(lane > 0 && lane < n_a && x < xp) != 0;
-            if (unsorted) {
+            if (__ballot(lane > 0 && lane < n_a && x < xp) != 0) {
                 wave_rank_sort(x, q, n_a, lane);
-                if (lane < n_a) { a.B.ax[off + lane] = x; a.B.aq[off + lane] = q; }
+                __syncthreads();
+                if (lane < n_a) { e_x[lane] = x; e_q[lane] = q; }
+                __syncthreads();
             }
-            sink.w = w; sink.qlen = (uint32_t)qlen;
-            uint32_t open_start = 0;
-            tile_clusters(sink, x, 0, false, n_a, lane, off, 0, open_start, chain_max_dist_x(P, qlen));
-            sink.emit(lane == 0, off + open_start, n_a - open_start);
+            int32_t n_u = 0, best = 0;
+            chain_sorted(e_x, e_q, e_f, e_pt, n_a, lane, 64, qlen, P, nullptr, n_u, best, n_clusters);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { n_u += __shfl_xor(n_u, o); int32_t b = __shfl_xor(best, o); best = b > best ? b : best; }
+            if (lane == 0) { a.B.acc_nu[w] = n_u; a.B.acc_best[w] = best; }
+            __syncthreads();
         } else {
-            const int cls = n_a <= SORT_LDS_A ? 0 : (n_a <= SORT_LDS_B ? 1 : 2);
+            const int cls = n_a <= SORT_LDS_A ? 0 : (n_a <= SORT_LDS_B ? 1 : (n_a <= SORT_LDS_C ? 2 : 3));
             uint32_t lo, hi;
-            const uint32_t si = al_sort[cls].take(&a.ctr->n_sort[cls], 1, cls == 0 ? 32u : (cls == 1 ? 4u : 1u), lo, hi);
+            const uint32_t si = al_sort[cls].take(&a.ctr->n_sort[cls], 1, cls == 0 ? 32u : (cls == 1 ? 8u : 1u), lo, hi);
             for (uint32_t i = lo + lane; i < hi; i += 64) a.B.sort_items[cls][i].n = 0;
             if (lane == 0) { SortItem it{w, n_a, (uint32_t)qlen, 0, off}; a.B.sort_items[cls][si] = it; }
         }
     }
-    sink.close();
-    for (int cls = 0; cls < 3; ++cls)
+    for (int cls = 0; cls < N_SORT_CLS; ++cls)
         for (uint32_t i = al_sort[cls].cur + lane; i < al_sort[cls].end; i += 64) a.B.sort_items[cls][i].n = 0;
     if (lane == 0 && anchors_wave) atomicAdd(&a.ctr->sh_anchors[SHARD()], anchors_wave);
+    n_clusters = wave_sum_u32(n_clusters);
+    if (lane == 0 && n_clusters) atomicAdd(&a.ctr->sh_clusters[SHARD()], n_clusters);
 }
 
 // stable block merge sort: 64-element tiles ranked in registers (one tile per wave at a time), then merge-path
@@ -729,131 +719,101 @@ __device__ inline bool block_merge_sort(PX sx, PQ sq, PX dx, PQ dq, uint32_t n)
     return flipped;
 }
 
-// cluster boundaries of a sorted anchor array, by the first wave of the block
-template <class PX>
-__device__ inline void emit_clusters(ClusterSink &sink, PX rx, uint32_t n, unsigned long long off, uint32_t mdx)
+// block reduction of the per-thread chain results of one read; thread 0 stores them
+__device__ inline void store_read_result(const K3Args &a, uint32_t w, int32_t n_u, int32_t best, uint32_t n_cl, int32_t *red)
 {
-    const uint32_t lane = threadIdx.x & 63;
-    uint32_t open_start = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t cnt = n - base < 64 ? n - base : 64;
-        uint64_t x = lane < cnt ? rx[base + lane] : ~0ull;
-        uint64_t xprev = base > 0 ? rx[base - 1] : 0;
-        tile_clusters(sink, x, xprev, base > 0, cnt, lane, off, base, open_start, mdx);
-    }
-    sink.emit(lane == 0, off + open_start, n - open_start);
+    if (threadIdx.x == 0) { red[0] = 0; red[1] = 0; }
+    __syncthreads();
+    if (n_u > 0) { atomicAdd(&red[0], n_u); atomicMax(&red[1], best); }
+    n_cl = wave_sum_u32(n_cl);
+    if ((threadIdx.x & 63) == 0 && n_cl) atomicAdd(&a.ctr->sh_clusters[SHARD()], n_cl);
+    __syncthreads();
+    if (threadIdx.x == 0) { a.B.acc_nu[w] = red[0]; a.B.acc_best[w] = red[1]; }
 }
 
-// one block per read with 64 < anchors <= NMAX: sort in LDS, write back, cluster boundaries
+// one block per read with 64 < anchors <= NMAX: sort in LDS, then chain every cluster straight from LDS
+// (the second sort buffer becomes the DP state).  Nothing but the per-read result goes back to HBM.
 template <int NMAX, int CLS, int NTHR>
 __global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
 {
     __shared__ uint64_t s_x[2][NMAX];
     __shared__ uint32_t s_q[2][NMAX];
+    __shared__ int32_t s_found, s_red[2];
     const uint32_t tid = threadIdx.x;
     const uint32_t n_items = a.ctr->n_sort[CLS];
-    WaveAlloc al_small, al_big;
-    uint32_t n_clusters = 0;
-    ClusterSink sink{a.B.clus_small, a.B.clus_big, a.ctr, 0, 0, !(a.P.k < a.P.min_sc || a.P.min_cnt > 1), &al_small, &al_big, &n_clusters};
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
         const SortItem si = a.B.sort_items[CLS][it];
         const uint32_t n = si.n;
         if (n == 0) continue;
-        uint64_t *gx = a.B.ax + si.off; uint32_t *gq = a.B.aq + si.off;
+        const uint64_t *gx = a.B.ax + si.off; const uint32_t *gq = a.B.aq + si.off;
         for (uint32_t i = tid; i < n; i += NTHR) { s_x[0][i] = gx[i]; s_q[0][i] = gq[i]; }
+        if (tid == 0) s_found = 0;
         __syncthreads();
         const bool fl = block_merge_sort(&s_x[0][0], &s_q[0][0], &s_x[1][0], &s_q[1][0], n);
-        const uint64_t *rx = fl ? s_x[1] : s_x[0]; const uint32_t *rq = fl ? s_q[1] : s_q[0];
-        for (uint32_t i = tid; i < n; i += NTHR) { gx[i] = rx[i]; gq[i] = rq[i]; }
-        if (tid < 64) {
-            sink.w = si.w; sink.qlen = si.qlen;
-            emit_clusters(sink, rx, n, si.off, chain_max_dist_x(a.P, (int32_t)si.qlen));
-        }
+        uint64_t *rx = fl ? s_x[1] : s_x[0]; uint32_t *rq = fl ? s_q[1] : s_q[0];
+        int32_t *f = (int32_t *)(fl ? s_q[0] : s_q[1]), *pt = (int32_t *)(fl ? s_x[0] : s_x[1]);
+        int32_t n_u = 0, best = 0; uint32_t n_cl = 0;
+        chain_sorted(rx, rq, f, pt, n, tid, NTHR, (int32_t)si.qlen, a.P, a.flag_only ? &s_found : nullptr, n_u, best, n_cl);
+        store_read_result(a, si.w, n_u, best, n_cl, s_red);
         __syncthreads();
     }
-    if (tid < 64) sink.close();
 }
 
-// one block per read with more anchors than the LDS variants hold: the same sort between two arena buffers
+// one block per giant read: 4096-anchor chunks sorted in LDS, the remaining merge rounds between two arena
+// buffers, clusters chained over arena slices
 __global__ __launch_bounds__(1024) void k_sort(K3Args a)
 {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t n_items = a.ctr->n_sort[2];
-    WaveAlloc al_small, al_big;
-    uint32_t n_clusters = 0;
-    ClusterSink sink{a.B.clus_small, a.B.clus_big, a.ctr, 0, 0, !(a.P.k < a.P.min_sc || a.P.min_cnt > 1), &al_small, &al_big, &n_clusters};
+    __shared__ uint64_t s_x[2][SORT_LDS_C];
+    __shared__ uint32_t s_q[2][SORT_LDS_C];
+    __shared__ int32_t s_found, s_red[2];
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    const uint32_t n_items = a.ctr->n_sort[3];
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const SortItem si = a.B.sort_items[2][it];
+        const SortItem si = a.B.sort_items[3][it];
         const uint32_t n = si.n;
         if (n == 0) continue;
         uint64_t *gx = a.B.ax + si.off, *hx = a.B.bx + si.off;
         uint32_t *gq = a.B.aq + si.off, *hq = a.B.bq + si.off;
-        if (block_merge_sort(gx, gq, hx, hq, n)) {      // odd number of rounds: bring the result home
-            for (uint32_t i = tid; i < n; i += blockDim.x) { gx[i] = hx[i]; gq[i] = hq[i]; }
+        if (tid == 0) s_found = 0;
+        for (uint32_t c0 = 0; c0 < n; c0 += SORT_LDS_C) {
+            const uint32_t m = n - c0 < SORT_LDS_C ? n - c0 : SORT_LDS_C;
+            for (uint32_t i = tid; i < m; i += nthr) { s_x[0][i] = gx[c0 + i]; s_q[0][i] = gq[c0 + i]; }
+            __syncthreads();
+            const bool fl = block_merge_sort(&s_x[0][0], &s_q[0][0], &s_x[1][0], &s_q[1][0], m);
+            const uint64_t *rx = fl ? s_x[1] : s_x[0]; const uint32_t *rq = fl ? s_q[1] : s_q[0];
+            for (uint32_t i = tid; i < m; i += nthr) { gx[c0 + i] = rx[i]; gq[c0 + i] = rq[i]; }
             __syncthreads();
         }
-        if (tid < 64) {
-            sink.w = si.w; sink.qlen = si.qlen;
-            emit_clusters(sink, gx, n, si.off, chain_max_dist_x(a.P, (int32_t)si.qlen));
+        // merge rounds in the arena, C outputs per thread and step
+        uint64_t *sx = gx, *dx = hx; uint32_t *sq = gq, *dq = hq;
+        const uint32_t C = 16, n_chunks = (n + C - 1) / C;
+        for (uint32_t width = SORT_LDS_C; width < n; width <<= 1) {
+            for (uint32_t c = tid; c < n_chunks; c += nthr) {
+                const uint32_t o0 = c * C, o1 = o0 + C < n ? o0 + C : n;
+                const uint32_t pb = o0 / (2 * width) * (2 * width);
+                const uint32_t L0 = pb, L1 = pb + width < n ? pb + width : n, R1 = pb + 2 * width < n ? pb + 2 * width : n;
+                const uint32_t lenL = L1 - L0, lenR = R1 - L1, d = o0 - pb;
+                uint32_t lo = d > lenR ? d - lenR : 0, hi = d < lenL ? d : lenL;
+                while (lo < hi) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    if (sx[L0 + mid] <= sx[L1 + (d - 1 - mid)]) lo = mid + 1; else hi = mid;
+                }
+                uint32_t ia = L0 + lo, ib = L1 + (d - lo);
+                uint64_t va = ia < L1 ? sx[ia] : ~0ull, vb = ib < R1 ? sx[ib] : ~0ull;
+                for (uint32_t o = o0; o < o1; ++o) {
+                    const bool takeL = ia < L1 && (ib >= R1 || va <= vb);
+                    if (takeL) { dx[o] = va; dq[o] = sq[ia]; ++ia; va = ia < L1 ? sx[ia] : ~0ull; }
+                    else { dx[o] = vb; dq[o] = sq[ib]; ++ib; vb = ib < R1 ? sx[ib] : ~0ull; }
+                }
+            }
+            __syncthreads();
+            uint64_t *tx = sx; sx = dx; dx = tx; uint32_t *tq = sq; sq = dq; dq = tq;
         }
+        int32_t n_u = 0, best = 0; uint32_t n_cl = 0;
+        chain_sorted(sx, sq, a.B.af + si.off, (int32_t *)(a.B.az + si.off), n, tid, nthr, (int32_t)si.qlen, a.P,
+                     a.flag_only ? &s_found : nullptr, n_u, best, n_cl);
+        store_read_result(a, si.w, n_u, best, n_cl, s_red);
         __syncthreads();
-    }
-    if (tid < 64) sink.close();
-}
-
-// one lane per cluster of <= DP_SMALL_CAP anchors, LDS
-__global__ __launch_bounds__(64) void k_dp_small(K3Args a)
-{
-    __shared__ uint32_t s_lo[DP_SMALL_CAP * 64];
-    __shared__ uint32_t s_aux[DP_SMALL_CAP * 64];
-    __shared__ uint16_t s_q[DP_SMALL_CAP * 64];
-    __shared__ uint8_t s_g[DP_SMALL_CAP * 64];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t n_cl = a.ctr->n_clus_small;
-    SmallStore<DP_SMALL_CAP> S;
-    S.lo = s_lo + lane; S.aux = s_aux + lane; S.qv = s_q + lane; S.gv = s_g + lane;
-    // each block walks one contiguous range of the list: a read's clusters are consecutive, so in flag-only
-    // mode everything after its first accepted chain is skipped
-    const uint32_t per_block = ((n_cl + gridDim.x - 1) / gridDim.x + 63) & ~63u;
-    const uint32_t r_beg = blockIdx.x * per_block, r_end = r_beg + per_block < n_cl ? r_beg + per_block : n_cl;
-    for (uint32_t base = r_beg; base < r_end; base += 64) {
-        const uint32_t ci = base + lane;
-        if (ci >= r_end) continue;
-        const ClusterDesc d = a.B.clus_small[ci];
-        if (d.len == 0) continue;
-        if (a.flag_only && __hip_atomic_load(&a.B.acc_nu[d.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;
-        const uint64_t *x = a.B.ax + d.off; const uint32_t *q = a.B.aq + d.off;
-        for (uint32_t i = 0; i < d.len; i += 4) {       // 4 independent loads in flight
-            uint64_t xv[4]; uint32_t qv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (i + u < d.len) { xv[u] = x[i + u]; qv[u] = q[i + u]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (i + u < d.len) { S.lo[(i + u) * 64] = (uint32_t)xv[u]; S.qv[(i + u) * 64] = (uint16_t)qv[u]; S.gv[(i + u) * 64] = 0; }
-        }
-        int32_t n_u, best;
-        chain_dp<SmallStore<DP_SMALL_CAP>, int>(S, (int)d.len, (int32_t)d.qlen, a.P);
-        backtrack_small(S, (int)d.len, a.P, n_u, best);
-        if (n_u > 0) { atomicAdd(&a.B.acc_nu[d.w], n_u); atomicMax(&a.B.acc_best[d.w], best); }
-    }
-}
-
-// larger clusters over arena slices, one lane per cluster
-__global__ __launch_bounds__(64) void k_dp_big(K3Args a)
-{
-    const uint32_t n_cl = a.ctr->n_clus_big;
-    const uint32_t per_block = ((n_cl + gridDim.x - 1) / gridDim.x + 63) & ~63u;
-    const uint32_t r_beg = blockIdx.x * per_block, r_end = r_beg + per_block < n_cl ? r_beg + per_block : n_cl;
-    for (uint32_t ci = r_beg + threadIdx.x; ci < r_end; ci += 64) {
-        const ClusterDesc d = a.B.clus_big[ci];
-        if (d.len == 0) continue;
-        if (a.flag_only && __hip_atomic_load(&a.B.acc_nu[d.w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) continue;
-        LargeStore S;
-        S.x = a.B.ax + d.off; S.q = a.B.aq + d.off; S.x2 = nullptr; S.q2 = nullptr;
-        S.z = a.B.az + d.off; S.f = a.B.af + d.off; S.p = a.B.ap + d.off; S.t = a.B.at + d.off;
-        int32_t n_u, best;
-        chain_dp<LargeStore, int64_t>(S, (int64_t)d.len, (int32_t)d.qlen, a.P);
-        backtrack_large(S, (int64_t)d.len, a.P, n_u, best);
-        if (n_u > 0) { atomicAdd(&a.B.acc_nu[d.w], n_u); atomicMax(&a.B.acc_best[d.w], best); }
     }
 }
 
@@ -947,7 +907,7 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
                     S.carve(m, n_a);
                     gen_anchors(S, sv, a.positions, qlen, a.P.k);
                     chain_dp<LargeStore, int64_t>(S, n_a, qlen, a.P);
-                    backtrack_large(S, n_a, a.P, n_u, best);
+                    backtrack_heap<LargeStore, int64_t>(S, n_a, a.P, S.z, n_u, best);
                     if (!rechained && n_u == 0 && a.P.max_occ > a.P.mid_occ && rep_len > 0) { rechained = 1; max_occ = a.P.max_occ; continue; }
                     break;
                 }
@@ -1033,18 +993,18 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         if ((e = hipMalloc(&c->d_big[p][q], max_reads * 4)) != hipSuccess) return fail(e, "big lists");
     if ((e = hipMalloc(&c->d_ctr, sizeof(Counters))) != hipSuccess) return fail(e, "counters");
     if ((e = hipHostMalloc(&c->h_ctr, sizeof(Counters))) != hipSuccess) return fail(e, "pinned counters");
-    // arena: anchors, DP arrays and cluster lists of the repeat path (60 B per anchor slot) + a slice for the
-    // legacy re-sketch path.  Default 6 KiB per read of the batch (~100 anchor slots per read; the CHM13-sized
-    // workload averages 78), at least 256 MiB; reads that find no room are deferred and re-run.
-    c->arena_bytes = std::max<uint64_t>(256ull << 20, max_reads * 6144ull);
+    // arena: anchors (+ sort buffer) and DP state of reads with > 64 anchors (36 B per anchor slot) + a slice for
+    // the legacy re-sketch path.  Default 4 KiB per read of the batch (~110 anchor slots per read; the CHM13-sized
+    // workload averages 72), at least 256 MiB; reads that find no room are deferred and re-run.
+    c->arena_bytes = std::max<uint64_t>(256ull << 20, max_reads * 4096ull);
     if (const char *env = getenv("SCRUBBY_HIP_ARENA_MB")) c->arena_bytes = (uint64_t)atoll(env) << 20;
     if ((e = hipMalloc(&c->d_arena, c->arena_bytes)) != hipSuccess) return fail(e, "arena");
     {
         c->legacy_bytes = std::min<uint64_t>(c->arena_bytes / 8, 1ull << 30);
         uint8_t *p = c->d_arena + c->legacy_bytes;
         uint64_t left = c->arena_bytes - c->legacy_bytes;
-        uint64_t fixed = max_reads * (sizeof(BigMeta) + 8 + 3 * sizeof(SortItem)) + 8192;
-        uint64_t per_anchor = 8 + 8 + 8 + 4 + 4 + 4 + 4 + 4 + sizeof(ClusterDesc);   // ax bx az aq bq af ap at + cluster slot
+        uint64_t fixed = max_reads * (sizeof(BigMeta) + 8 + N_SORT_CLS * sizeof(SortItem)) + 8192;
+        uint64_t per_anchor = 8 + 8 + 8 + 4 + 4 + 4;   // ax bx az aq bq af
         uint64_t cap = left > fixed ? (left - fixed) / per_anchor : 0;
         cap &= ~15ull;
         if (cap < 1024) { sh_set_error("sh_ctx_create: arena of %llu MiB is too small", (unsigned long long)(c->arena_bytes >> 20)); sh_ctx_destroy(c); return SH_ERR_OOM; }
@@ -1053,11 +1013,10 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         auto take = [&](uint64_t bytes) { uint8_t *q = p; p += (bytes + 255) & ~255ull; return q; };
         B.ax = (uint64_t *)take(cap * 8); B.bx = (uint64_t *)take(cap * 8); B.az = (uint64_t *)take(cap * 8);
         B.aq = (uint32_t *)take(cap * 4); B.bq = (uint32_t *)take(cap * 4);
-        B.af = (int32_t *)take(cap * 4); B.ap = (int32_t *)take(cap * 4); B.at = (int32_t *)take(cap * 4);
-        B.clus_small = (ClusterDesc *)take(cap / 2 * sizeof(ClusterDesc)); B.clus_big = (ClusterDesc *)take(cap / 2 * sizeof(ClusterDesc));
+        B.af = (int32_t *)take(cap * 4);
         B.meta = (BigMeta *)take(max_reads * sizeof(BigMeta));
         B.acc_nu = (int32_t *)take(max_reads * 4); B.acc_best = (int32_t *)take(max_reads * 4);
-        for (int i = 0; i < 3; ++i) B.sort_items[i] = (SortItem *)take(max_reads * sizeof(SortItem));
+        for (int i = 0; i < N_SORT_CLS; ++i) B.sort_items[i] = (SortItem *)take(max_reads * sizeof(SortItem));
         if ((uint64_t)(p - c->d_arena) > c->arena_bytes) {   // alignment slack: shrink
             sh_set_error("sh_ctx_create: internal arena carve overflow"); sh_ctx_destroy(c); return SH_ERR_OOM;
         }
@@ -1091,13 +1050,12 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     // per-pass device counters: arena cursor, sort list, cluster lists
     Counters *ctr = c->d_ctr;
     SH_HIP(hipMemsetAsync(&ctr->anchor_cursor, 0, 8, s));
-    SH_HIP(hipMemsetAsync(&ctr->n_sort[0], 0, 20, s));       // n_sort[3], n_clus_small, n_clus_big
+    SH_HIP(hipMemsetAsync(&ctr->n_sort[0], 0, 4 * N_SORT_CLS, s));
     hipLaunchKernelGGL(k_expand, dim3(grid * 2), dim3(64), 0, s, k);
-    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_A, 0, 128>), dim3(grid), dim3(128), 0, s, k);
-    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_B, 1, 512>), dim3(256), dim3(512), 0, s, k);
-    hipLaunchKernelGGL(k_sort, dim3(512), dim3(1024), 0, s, k);
-    hipLaunchKernelGGL(k_dp_small, dim3(grid), dim3(64), 0, s, k);
-    hipLaunchKernelGGL(k_dp_big, dim3(grid), dim3(64), 0, s, k);
+    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_A, 0, 128>), dim3(grid * 2), dim3(128), 0, s, k);
+    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_B, 1, 256>), dim3(256 * 3), dim3(256), 0, s, k);
+    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_C, 2, 512>), dim3(256), dim3(512), 0, s, k);
+    hipLaunchKernelGGL(k_sort, dim3(256), dim3(1024), 0, s, k);
     hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, s, k);
     return SH_OK;
 }
