@@ -485,7 +485,7 @@ struct K3Args {
     uint32_t *next_list; uint32_t *next_count;            // pass 0: reads that must re-chain with max_occ
     uint32_t *resketch_list;                              // reads this path cannot take (see k_expand)
     Counters *ctr; BigBufs B; ChainParams P;
-    int32_t pass, max_occ, flag_only;
+    int32_t pass, max_occ, flag_only, dbg;
 };
 
 
@@ -690,7 +690,7 @@ __device__ inline bool block_merge_sort(PX sx, PQ sq, PX dx, PQ dq, uint32_t n)
         }
     }
     __syncthreads();
-    const uint32_t C = 16;
+    const uint32_t C = n >= 16 * nthr ? 16 : (n >= 8 * nthr ? 8 : 4);     // outputs per thread and step (divides 128)
     const uint32_t n_chunks = (n + C - 1) / C;
     bool flipped = false;
     for (uint32_t width = 64; width < n; width <<= 1) {
@@ -753,6 +753,7 @@ __global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
         uint64_t *rx = fl ? s_x[1] : s_x[0]; uint32_t *rq = fl ? s_q[1] : s_q[0];
         int32_t *f = (int32_t *)(fl ? s_q[0] : s_q[1]), *pt = (int32_t *)(fl ? s_x[0] : s_x[1]);
         int32_t n_u = 0, best = 0; uint32_t n_cl = 0;
+        if (!(a.dbg & 1))
         chain_sorted(rx, rq, f, pt, n, tid, NTHR, (int32_t)si.qlen, a.P, a.flag_only ? &s_found : nullptr, n_u, best, n_cl);
         store_read_result(a, si.w, n_u, best, n_cl, s_red);
         __syncthreads();
@@ -810,6 +811,7 @@ __global__ __launch_bounds__(1024) void k_sort(K3Args a)
             uint64_t *tx = sx; sx = dx; dx = tx; uint32_t *tq = sq; sq = dq; dq = tq;
         }
         int32_t n_u = 0, best = 0; uint32_t n_cl = 0;
+        if (!(a.dbg & 2))
         chain_sorted(sx, sq, a.B.af + si.off, (int32_t *)(a.B.az + si.off), n, tid, nthr, (int32_t)si.qlen, a.P,
                      a.flag_only ? &s_found : nullptr, n_u, best, n_cl);
         store_read_result(a, si.w, n_u, best, n_cl, s_red);
@@ -1052,8 +1054,8 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     SH_HIP(hipMemsetAsync(&ctr->anchor_cursor, 0, 8, s));
     SH_HIP(hipMemsetAsync(&ctr->n_sort[0], 0, 4 * N_SORT_CLS, s));
     hipLaunchKernelGGL(k_expand, dim3(grid * 2), dim3(64), 0, s, k);
-    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_A, 0, 128>), dim3(grid * 2), dim3(128), 0, s, k);
-    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_B, 1, 256>), dim3(256 * 3), dim3(256), 0, s, k);
+    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_A, 0, 64>), dim3(grid * 2), dim3(64), 0, s, k);
+    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_B, 1, 128>), dim3(256 * 3), dim3(128), 0, s, k);
     hipLaunchKernelGGL((k_sort_lds<SORT_LDS_C, 2, 512>), dim3(256), dim3(512), 0, s, k);
     hipLaunchKernelGGL(k_sort, dim3(256), dim3(1024), 0, s, k);
     hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, s, k);
@@ -1109,6 +1111,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     k.offsets = d_offsets; k.positions = idx->d_positions; k.records = c->d_records; k.seed_cap = c->seed_cap;
     k.k1info = c->d_k1info; k.flags = d_flags; k.trace = d_trace; k.ctr = c->d_ctr; k.B = c->B; k.P = c->P;
     k.flag_only = d_trace == nullptr;
+    k.dbg = getenv("SCRUBBY_HIP_DBG") ? atoi(getenv("SCRUBBY_HIP_DBG")) : 0;
     k.resketch_list = c->d_work_resketch;
     uint32_t resk_done = 0;
     // pass 0 (mid_occ) over the reads K2 routed, pass 1 (max_occ) over the reads pass 0 could not chain;
