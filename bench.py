@@ -93,17 +93,15 @@ def main():
     ctx = S.Context(index, min(a.chunk, n_rec), n_rec * L, L)
     torch.cuda.synchronize()
 
+    from scrubby_amd import dist as D
     n_bits = (n_rec + 7) // 8
-    weights = (2 ** torch.arange(8, device=dev, dtype=torch.int32)).to(torch.uint8)
-    gathered = torch.empty(world * n_bits, dtype=torch.uint8, device=dev) if world > 1 else None
+    union = {"bytes": 0}
 
     def step():
         st = ctx.classify(d_reads[: n_rec * L], d_off, d_flags, None, want_stats=True)
-        if world > 1:   # depleted-record bitmap union: disjoint slices, one all_gather
-            pad = torch.zeros(n_bits * 8, dtype=torch.uint8, device=dev)
-            pad[:n_rec] = (d_flags == 1)
-            bits = (pad.view(-1, 8) * weights).sum(dim=1).to(torch.uint8)
-            dist.all_gather_into_tensor(gathered, bits)
+        if world > 1:   # depleted-record bitmap union: disjoint slices, one all_gather over RCCL
+            gathered, _ = D.union_depleted(d_flags, slice_bytes=n_bits)
+            union["bytes"] = gathered.numel()
         return st
 
     def barrier():
@@ -130,21 +128,35 @@ def main():
     ms_step = dt / a.steps * 1e3
     value = world * n_rec * a.steps / dt
 
-    # ---- roofline of the dominant kernel (HIP events on the launch stream, inside the library) -------
+    # ---- roofline (HIP events on the launch stream, inside the library) ---------------------------------
+    # per-stage algorithmic bytes per step: K1 = L + 8 (offset) + 16 per probe + 1 (flag) per read;
+    # chain stages = 16 B per seed record + 8 B per anchor.  The primary entry is the stage that takes longest.
     k1_ms = float(np.mean([s["ms_sketch_probe"] for s in stats]))      # per step = sum over its launches
     k2_ms = float(np.mean([s["ms_chain_small"] for s in stats]))
     k3_ms = float(np.mean([s["ms_chain_large"] for s in stats]))
     n_launch = (n_rec + ctx_chunk(a, n_rec) - 1) // ctx_chunk(a, n_rec)
     s0 = stats[-1]
-    # algorithmic bytes of k_sketch_probe per step: L + 8 (offset) + 16 per probe + 1 (flag)
-    alg_bytes = s0["n_bases"] + 9 * s0["n_reads"] + 16 * s0["n_minimizers"]
-    achieved = alg_bytes / n_launch / (k1_ms / n_launch * 1e-3) / 1e9
+    k1_bytes = s0["n_bases"] + 9 * s0["n_reads"] + 16 * s0["n_minimizers"]
+    n_seeded = s0["n_reads"] - s0["n_no_seed"]
+    seeds_small = 20 * s0["n_chain_small"]                 # ~20 seed records per read on the LDS path
+    k2_bytes = 16 * seeds_small + 8 * seeds_small
+    k3_bytes = 16 * 20 * s0["n_chain_large"] + 8 * s0["n_anchors"]
+    stages = {
+        "k_sketch_probe": (k1_ms, k1_bytes), "k_chain_small": (k2_ms, k2_bytes),
+        "repeat path (k_expand + k_sort_lds* + k_sort + k_finalize)": (k3_ms, k3_bytes),
+    }
+    dom = max(stages, key=lambda k: stages[k][0])
+    d_ms, d_bytes = stages[dom]
+    achieved = d_bytes / (d_ms * 1e-3) / 1e9
     roofline = {
-        "bound": "hbm", "kernel": "k_sketch_probe", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-        "launches_per_step": n_launch, "avg_launch_ms": round(k1_ms / n_launch, 4),
-        "alg_bytes_per_launch": int(alg_bytes / n_launch),
-        "stage_ms_per_step": {"k_sketch_probe": round(k1_ms, 3), "k_chain_small": round(k2_ms, 3), "k_chain_large": round(k3_ms, 3)},
+        "launches_per_step": n_launch, "avg_launch_ms": round(d_ms / n_launch, 4),
+        "alg_bytes_per_launch": int(d_bytes / n_launch),
+        "stage_ms_per_step": {k: round(v[0], 3) for k, v in stages.items()},
+        "stage_achieved_GBs": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None for k, v in stages.items()},
+        "path_achieved_GBs": round((k1_bytes + k2_bytes + k3_bytes) / ((k1_ms + k2_ms + k3_ms) * 1e-3) / 1e9, 1),
+        "n_seeded_reads": n_seeded,
     }
     traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
     if os.path.exists(traffic_file) and not a.small:
@@ -171,6 +183,7 @@ def main():
             "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64/i32 (f32 in the chain gap penalty)", "data": "synthetic",
+            "union_bytes_gathered": union["bytes"],
             "config": {
                 "workload": ("cfg1-small: 200k records vs 5 Mb" if a.small else
                              "configs[1]: 10M synthetic 2x150bp PE (20M records) vs CHM13v2-sized synthetic reference, sr preset, k-mer/minimizer classifier path"),

@@ -1,0 +1,60 @@
+"""Multi-GPU plumbing for the read-sharded path.
+
+One process per GPU; the index is replicated, reads are sharded by contiguous record ranges and there is no
+data-path collective.  The single exchange is the union of the depleted-record set at the end
+(`HashSet` union at /root/reference/src/cleaner.rs:564-570): each rank packs its flags to 1 bit per record
+and the disjoint slices are all-gathered (RCCL has no bitwise-OR reduction; disjoint slices avoid needing one).
+Works on CUDA tensors over `nccl` (= RCCL on ROCm) and on CPU tensors over `gloo` (tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_records, rank, world):
+    """Contiguous, pair-aligned record range [lo, hi) of `rank` (records 2p, 2p+1 are mates)."""
+    pairs = (n_records + 1) // 2
+    per = (pairs + world - 1) // world
+    lo = min(rank * per * 2, n_records)
+    hi = min((rank + 1) * per * 2, n_records)
+    return lo, hi
+
+
+def pack_flags(flags):
+    """uint8 flags (1 = host) -> little-endian bitmap, 1 bit per record."""
+    n = flags.numel()
+    pad = (-n) % 8
+    b = (flags == 1).to(torch.uint8)
+    if pad:
+        b = torch.cat([b, torch.zeros(pad, dtype=torch.uint8, device=flags.device)])
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=flags.device)
+    return (b.view(-1, 8).to(torch.int32) * w).sum(dim=1).to(torch.uint8)
+
+
+def unpack_flags(bits, n):
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=bits.device)
+    return ((bits.to(torch.int32).unsqueeze(1) & w) != 0).to(torch.uint8).reshape(-1)[:n]
+
+
+def union_depleted(flags, slice_bytes=None, group=None):
+    """All ranks contribute the bitmap of their own record slice; every rank receives all slices.
+
+    flags: this rank's uint8 flags.  slice_bytes: common slice size in bytes (max over ranks); computed with
+    an all_reduce(max) if omitted.  Returns (gathered uint8 [world * slice_bytes], slice_bytes)."""
+    bits = pack_flags(flags)
+    world = dist.get_world_size(group)
+    if slice_bytes is None:
+        m = torch.tensor([bits.numel()], dtype=torch.int64, device=flags.device)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+        slice_bytes = int(m.item())
+    if bits.numel() < slice_bytes:
+        bits = torch.cat([bits, torch.zeros(slice_bytes - bits.numel(), dtype=torch.uint8, device=flags.device)])
+    out = [torch.empty(slice_bytes, dtype=torch.uint8, device=flags.device) for _ in range(world)]
+    dist.all_gather(out, bits, group=group)
+    return torch.cat(out), slice_bytes
+
+
+def sum_counters(values, device, group=None):
+    """all_reduce(sum) of a few int64 counters ({records, depleted, ...})."""
+    t = torch.tensor(list(values), dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return [int(v) for v in t.tolist()]
