@@ -1,6 +1,6 @@
 #!/bin/bash
-# timing experiment: bit0 = skip DP in the LDS sort kernels, bit1 = skip DP in the giant kernel (results invalid)
-for d in 0 1 2 3; do
+# timing experiment on the giant-read kernel: 2 = skip DP, 4 = skip LDS chunk sorts, 8 = skip merge rounds (results invalid)
+for d in 0 2 6 10 14; do
   SCRUBBY_HIP_DBG=$d timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu 2>&1 | grep "^{" > /tmp/o.json
-  python3 -c "import json; d=json.load(open('/tmp/o.json')); print('dbg', $d, d['ms_per_step'], d['roofline']['stage_ms_per_step'])"
+  python3 -c "import json; d=json.load(open('/tmp/o.json')); print('dbg', $d, d['ms_per_step'], list(d['roofline']['stage_ms_per_step'].values()))"
 done

@@ -47,6 +47,7 @@
 #define SORT_LDS_B 2048         // ... 48 KiB
 #define SORT_LDS_C 4096         // ... 96 KiB; larger ones: 4096-anchor chunks in LDS, then merge rounds in the arena
 #define N_SORT_CLS 4
+#define SORT_GIANT_CHUNK 2048    // LDS chunk of the giant-read kernel (48 KiB: two 1024-thread blocks per CU)
 
 __device__ inline uint32_t lane_id() { return threadIdx.x & 63; }
 
@@ -449,30 +450,41 @@ __device__ inline uint32_t chain_max_dist_x(const ChainParams &P, int32_t qlen)
 // `found`: block-shared flag for the flag-only early exit (nullptr: chain everything).
 // Phase A marks cluster starts in bit 31 of q (read-only afterwards), so that in phase B a cluster's owner may
 // recycle its x slice as heap space while other lanes are still measuring their clusters.  All threads call.
-template <class PX, class PQ>
+// CONTIG: each thread owns a contiguous range of anchors (HBM: one miss per cache line) instead of a strided one.
+template <bool CONTIG, class PX, class PQ>
 __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_t n, uint32_t tid, uint32_t nthr, int32_t qlen,
                                     const ChainParams &P, volatile int32_t *found, int32_t &n_u_thr, int32_t &best_thr, uint32_t &n_cl_thr)
 {
     const uint32_t mdx = chain_max_dist_x(P, qlen);
     const bool keep_single = !(P.k < P.min_sc || P.min_cnt > 1);
+    const uint32_t per = CONTIG ? (n + nthr - 1) / nthr : 1;
+    const uint32_t i_beg = CONTIG ? tid * per : tid, i_step = CONTIG ? 1 : nthr;
+    const uint32_t i_end = CONTIG ? (i_beg + per < n ? i_beg + per : n) : n;
     for (uint32_t i = tid; i < n; i += nthr) {
         bool start = i == 0;
         if (!start) { const uint64_t xi = x[i], xp = x[i - 1]; start = (uint32_t)(xi >> 32) != (uint32_t)(xp >> 32) || (uint32_t)xi - (uint32_t)xp > mdx; }
         if (start) q[i] |= 0x80000000u;
     }
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += nthr) {
-        if (!(q[i] >> 31)) continue;
-        uint32_t j = i + 1;
-        while (j < n && !(q[j] >> 31)) ++j;
-        const uint32_t len = j - i;
-        if (len < 2 && !keep_single) continue;
-        if (found && *found) continue;
-        SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i};
-        int32_t n_u, best;
-        chain_cluster(S, (int32_t)len, qlen, P, (uint64_t *)&x[i], n_u, best, found != nullptr);
-        ++n_cl_thr;
-        if (n_u > 0) { n_u_thr += n_u; if (best > best_thr) best_thr = best; if (found) *found = 1; }
+    // Three sweeps by cluster size (<= 6, <= 64 with the register-mask DP, larger).  The per-read result is a
+    // sum / max over clusters, so the order is free; in flag-only mode a read that found a chain in a small
+    // cluster never touches its big ones (the true-locus cluster, dense tandem arrays).
+    for (int sweep = 0; sweep < 3; ++sweep) {
+        for (uint32_t i = i_beg; i < i_end; i += i_step) {
+            if (!(q[i] >> 31)) continue;
+            uint32_t j = i + 1;
+            while (j < n && !(q[j] >> 31)) ++j;
+            const uint32_t len = j - i;
+            if ((len <= 6 ? 0 : (len <= 64 ? 1 : 2)) != sweep) continue;
+            if (len < 2 && !keep_single) continue;
+            if (found && *found) continue;
+            SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i};
+            int32_t n_u, best;
+            chain_cluster(S, (int32_t)len, qlen, P, (uint64_t *)&x[i], n_u, best, found != nullptr);
+            ++n_cl_thr;
+            if (n_u > 0) { n_u_thr += n_u; if (best > best_thr) best_thr = best; if (found) *found = 1; }
+        }
+        __syncthreads();
     }
 }
 
@@ -652,7 +664,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
                 __syncthreads();
             }
             int32_t n_u = 0, best = 0;
-            chain_sorted(e_x, e_q, e_f, e_pt, n_a, lane, 64, qlen, P, nullptr, n_u, best, n_clusters);
+            chain_sorted<false>(e_x, e_q, e_f, e_pt, n_a, lane, 64, qlen, P, nullptr, n_u, best, n_clusters);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { n_u += __shfl_xor(n_u, o); int32_t b = __shfl_xor(best, o); best = b > best ? b : best; }
             if (lane == 0) { a.B.acc_nu[w] = n_u; a.B.acc_best[w] = best; }
@@ -754,7 +766,7 @@ __global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
         int32_t *f = (int32_t *)(fl ? s_q[0] : s_q[1]), *pt = (int32_t *)(fl ? s_x[0] : s_x[1]);
         int32_t n_u = 0, best = 0; uint32_t n_cl = 0;
         if (!(a.dbg & 1))
-        chain_sorted(rx, rq, f, pt, n, tid, NTHR, (int32_t)si.qlen, a.P, a.flag_only ? &s_found : nullptr, n_u, best, n_cl);
+        chain_sorted<false>(rx, rq, f, pt, n, tid, NTHR, (int32_t)si.qlen, a.P, a.flag_only ? &s_found : nullptr, n_u, best, n_cl);
         store_read_result(a, si.w, n_u, best, n_cl, s_red);
         __syncthreads();
     }
@@ -764,8 +776,8 @@ __global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
 // buffers, clusters chained over arena slices
 __global__ __launch_bounds__(1024) void k_sort(K3Args a)
 {
-    __shared__ uint64_t s_x[2][SORT_LDS_C];
-    __shared__ uint32_t s_q[2][SORT_LDS_C];
+    __shared__ uint64_t s_x[2][SORT_GIANT_CHUNK];
+    __shared__ uint32_t s_q[2][SORT_GIANT_CHUNK];
     __shared__ int32_t s_found, s_red[2];
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const uint32_t n_items = a.ctr->n_sort[3];
@@ -776,8 +788,9 @@ __global__ __launch_bounds__(1024) void k_sort(K3Args a)
         uint64_t *gx = a.B.ax + si.off, *hx = a.B.bx + si.off;
         uint32_t *gq = a.B.aq + si.off, *hq = a.B.bq + si.off;
         if (tid == 0) s_found = 0;
-        for (uint32_t c0 = 0; c0 < n; c0 += SORT_LDS_C) {
-            const uint32_t m = n - c0 < SORT_LDS_C ? n - c0 : SORT_LDS_C;
+        if (!(a.dbg & 4))
+        for (uint32_t c0 = 0; c0 < n; c0 += SORT_GIANT_CHUNK) {
+            const uint32_t m = n - c0 < SORT_GIANT_CHUNK ? n - c0 : SORT_GIANT_CHUNK;
             for (uint32_t i = tid; i < m; i += nthr) { s_x[0][i] = gx[c0 + i]; s_q[0][i] = gq[c0 + i]; }
             __syncthreads();
             const bool fl = block_merge_sort(&s_x[0][0], &s_q[0][0], &s_x[1][0], &s_q[1][0], m);
@@ -788,7 +801,7 @@ __global__ __launch_bounds__(1024) void k_sort(K3Args a)
         // merge rounds in the arena, C outputs per thread and step
         uint64_t *sx = gx, *dx = hx; uint32_t *sq = gq, *dq = hq;
         const uint32_t C = 16, n_chunks = (n + C - 1) / C;
-        for (uint32_t width = SORT_LDS_C; width < n; width <<= 1) {
+        for (uint32_t width = SORT_GIANT_CHUNK; width < n && !(a.dbg & 8); width <<= 1) {
             for (uint32_t c = tid; c < n_chunks; c += nthr) {
                 const uint32_t o0 = c * C, o1 = o0 + C < n ? o0 + C : n;
                 const uint32_t pb = o0 / (2 * width) * (2 * width);
@@ -812,7 +825,7 @@ __global__ __launch_bounds__(1024) void k_sort(K3Args a)
         }
         int32_t n_u = 0, best = 0; uint32_t n_cl = 0;
         if (!(a.dbg & 2))
-        chain_sorted(sx, sq, a.B.af + si.off, (int32_t *)(a.B.az + si.off), n, tid, nthr, (int32_t)si.qlen, a.P,
+        chain_sorted<true>(sx, sq, a.B.af + si.off, (int32_t *)(a.B.az + si.off), n, tid, nthr, (int32_t)si.qlen, a.P,
                      a.flag_only ? &s_found : nullptr, n_u, best, n_cl);
         store_read_result(a, si.w, n_u, best, n_cl, s_red);
         __syncthreads();
@@ -1057,7 +1070,7 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     hipLaunchKernelGGL((k_sort_lds<SORT_LDS_A, 0, 64>), dim3(grid * 2), dim3(64), 0, s, k);
     hipLaunchKernelGGL((k_sort_lds<SORT_LDS_B, 1, 128>), dim3(256 * 3), dim3(128), 0, s, k);
     hipLaunchKernelGGL((k_sort_lds<SORT_LDS_C, 2, 512>), dim3(256), dim3(512), 0, s, k);
-    hipLaunchKernelGGL(k_sort, dim3(256), dim3(1024), 0, s, k);
+    hipLaunchKernelGGL(k_sort, dim3(512), dim3(1024), 0, s, k);
     hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, s, k);
     return SH_OK;
 }
