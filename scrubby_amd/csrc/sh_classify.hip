@@ -39,8 +39,8 @@
 #include "sh_chain.h"
 #include <algorithm>
 
-#define K1_LIST_CAP 32          // queued minimizers per lane between two probe phases
-#define K1_FLUSH_AT 16
+#define K1_LIST_CAP 16          // queued minimizers per lane between two probe phases (8 KiB of LDS per wave)
+#define K1_FLUSH_AT 8
 #define K2_CAP 32               // anchors per read chained in LDS
 #define DP_SMALL_CAP 32         // anchors per cluster chained in LDS
 #define SORT_LDS_A 512          // reads with up to this many anchors are sorted and chained in 12 KiB of LDS

@@ -56,27 +56,41 @@ struct SketchState {
             l = 0;
         }
         bx[P] = ix; by[P] = iy;
-        if (l == W + k - 1 && minx != SH_XMAX) {      // first full window: identical k-mers
+        if (l == W + k - 1 && minx != SH_XMAX) {      // first full window: identical k-mers (rare: count first)
+            int eq = 0;
 #pragma unroll
-            for (int j = P + 1; j < W; ++j)
-                if (minx == bx[j] && by[j] != miny) emit(bx[j], by[j]);
+            for (int j = 0; j < W; ++j) if (j != P) eq += (minx == bx[j] && by[j] != miny);
+            if (eq) {
 #pragma unroll
-            for (int j = 0; j < P; ++j)
-                if (minx == bx[j] && by[j] != miny) emit(bx[j], by[j]);
+                for (int j = P + 1; j < W; ++j)
+                    if (minx == bx[j] && by[j] != miny) emit(bx[j], by[j]);
+#pragma unroll
+                for (int j = 0; j < P; ++j)
+                    if (minx == bx[j] && by[j] != miny) emit(bx[j], by[j]);
+            }
         }
         if (ix <= minx) {                              // new minimum, rightmost on ties
             if (l >= W + k && minx != SH_XMAX) emit(minx, miny);
             minx = ix; miny = iy; min_pos = P;
         } else if (min_pos == P) {                     // old minimum left the window
             if (l >= W + k - 1 && minx != SH_XMAX) emit(minx, miny);
+            // rightmost minimum of the window, counting how many entries share it: the tie loops below are
+            // skipped (wave-wide, almost always) unless some k-mer repeats inside the window
             minx = SH_XMAX;
+            int eq = 0;
 #pragma unroll
-            for (int j = P + 1; j < W; ++j)
-                if (minx >= bx[j]) { minx = bx[j]; miny = by[j]; min_pos = j; }
+            for (int j = P + 1; j < W; ++j) {
+                const bool lt = bx[j] < minx, ge = !(bx[j] > minx);
+                eq = lt ? 1 : (ge ? eq + 1 : eq);
+                if (ge) { minx = bx[j]; miny = by[j]; min_pos = j; }
+            }
 #pragma unroll
-            for (int j = 0; j <= P; ++j)
-                if (minx >= bx[j]) { minx = bx[j]; miny = by[j]; min_pos = j; }
-            if (l >= W + k - 1 && minx != SH_XMAX) {
+            for (int j = 0; j <= P; ++j) {
+                const bool lt = bx[j] < minx, ge = !(bx[j] > minx);
+                eq = lt ? 1 : (ge ? eq + 1 : eq);
+                if (ge) { minx = bx[j]; miny = by[j]; min_pos = j; }
+            }
+            if (eq > 1 && l >= W + k - 1 && minx != SH_XMAX) {
 #pragma unroll
                 for (int j = P + 1; j < W; ++j)
                     if (minx == bx[j] && miny != by[j]) emit(bx[j], by[j]);
