@@ -117,15 +117,16 @@ struct K1Args {
     const uint4 *slots; uint32_t lg_slots; int32_t k;
     uint4 *records; uint32_t seed_cap;
     uint32_t *k1info; uint8_t *flags; sh_trace *trace;
-    uint32_t *work_small, *work_resketch; Counters *ctr;
-    uint32_t lds_words;
+    uint32_t *work_small, *work_resketch, *work_big; Counters *ctr;
+    uint32_t lds_words; int32_t mid_occ;
 };
 
 // Slow path of K1: this lane's minimizer queue is full in the middle of a W-step block (tie-heavy,
 // low-complexity reads).  Probe the lane's queued entries now, in order, so that seed records stay in
 // query order; rare, divergent, deliberately not inlined.
 __device__ __noinline__ void k1_lane_flush(const uint64_t *list, uint32_t lane, uint32_t cnt, const uint4 *slots, uint32_t lg_slots,
-                                           uint4 *rec, uint32_t seed_cap, uint32_t *n_seed_io, uint32_t *overflow_io)
+                                           uint4 *rec, uint32_t seed_cap, uint32_t *n_seed_io, uint32_t *overflow_io,
+                                           uint32_t *sum_occ_io, uint32_t *n_high_io, uint32_t mid_occ)
 {
     const uint64_t slot_mask = (1ULL << lg_slots) - 1;
     uint32_t n_seed = *n_seed_io;
@@ -140,6 +141,8 @@ __device__ __noinline__ void k1_lane_flush(const uint64_t *list, uint32_t lane, 
             if (n_seed < seed_cap) rec[(size_t)n_seed * 64] = make_uint4(sl.z, sl.w, occ, (uint32_t)m & 0x3ffffu);
             else *overflow_io = 1;
             ++n_seed;
+            *sum_occ_io = *sum_occ_io + occ < *sum_occ_io ? 0xffffffffu : *sum_occ_io + occ;
+            *n_high_io += occ > mid_occ;
         }
     }
     *n_seed_io = n_seed;
@@ -215,11 +218,11 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, o));
 
-    uint32_t cnt = 0, n_mini = 0, n_seed = 0, overflow = 0;
+    uint32_t cnt = 0, n_mini = 0, n_seed = 0, overflow = 0, sum_occ = 0, n_high = 0;
     const uint64_t slot_mask = (1ULL << a.lg_slots) - 1;
     uint4 *rec = a.records + (size_t)tile * a.seed_cap * 64 + lane;
     auto emit = [&](uint64_t x, uint32_t y) {
-        if (cnt >= K1_LIST_CAP) { k1_lane_flush(list, lane, cnt, a.slots, a.lg_slots, rec, a.seed_cap, &n_seed, &overflow); cnt = 0; }
+        if (cnt >= K1_LIST_CAP) { k1_lane_flush(list, lane, cnt, a.slots, a.lg_slots, rec, a.seed_cap, &n_seed, &overflow, &sum_occ, &n_high, (uint32_t)a.mid_occ); cnt = 0; }
         list[cnt * 64 + lane] = (x >> 8) << 18 | (uint64_t)y;
         ++cnt; ++n_mini;
     };
@@ -282,6 +285,8 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
                         if (n_seed < a.seed_cap) rec[(size_t)n_seed * 64] = make_uint4(s[u].z, s[u].w, occ, yq[u]);
                         else overflow = 1;
                         ++n_seed;
+                        sum_occ = sum_occ + occ < sum_occ ? 0xffffffffu : sum_occ + occ;
+                        n_high += occ > (uint32_t)a.mid_occ;
                     }
                 }
             }
@@ -292,9 +297,13 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
 
     // ---- per-read result ------------------------------------------------------------------------
     if (valid) a.k1info[r] = n_mini | n_seed << 16;
+    // reads whose seeds need no occurrence filtering and give <= K2_CAP anchors are chained by K2 (lane per read);
+    // everything else goes to the repeat path (wave per read)
     const bool to_k3 = valid && overflow != 0;
     const bool done = valid && !overflow && n_seed == 0;
-    const bool to_k2 = valid && !overflow && n_seed > 0;
+    const bool simple = n_high == 0 && sum_occ <= K2_CAP;
+    const bool to_k2 = valid && !overflow && n_seed > 0 && simple;
+    const bool to_big = valid && !overflow && n_seed > 0 && !simple;
     if (done) {
         int32_t fl = len == 0 ? 2 : 0;
         a.flags[r] = (uint8_t)fl;
@@ -302,6 +311,8 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
     }
     uint32_t wi = wave_append(&a.ctr->n_small, to_k2);
     if (to_k2) a.work_small[wi] = (uint32_t)r;
+    wi = wave_append(&a.ctr->n_big[0], to_big);
+    if (to_big) a.work_big[wi] = (uint32_t)r;
     wi = wave_append(&a.ctr->n_resketch, to_k3);
     if (to_k3) a.work_resketch[wi] = (uint32_t)r;
     // statistics (sharded)
@@ -370,34 +381,26 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
     for (uint32_t base = blockIdx.x * 64; base < n_work; base += gridDim.x * 64) {
         const uint32_t wi = base + lane;
         const bool valid = wi < n_work;
-        bool host = false, routed = false;
-        uint32_t r = 0;
+        bool host = false;
         if (valid) {
-            r = a.work[wi];
+            const uint32_t r = a.work[wi];
             const uint32_t info = a.k1info[r];
             const int32_t n_mini = (int32_t)(info & 0xffffu), n_seed = (int32_t)(info >> 16);
             const int32_t qlen = (int32_t)(a.offsets[r + 1] - a.offsets[r]);
             SeedView sv;
             sv.base = a.records + (size_t)(r >> 6) * a.seed_cap * 64 + (r & 63);
             sv.stride = 64; sv.n = (uint32_t)n_seed;
-            int32_t max_occ = a.P.mid_occ, rechained = 0, n_u = 0, best = 0, rep_len = 0;
+            // K1 only sends reads here whose seeds all pass the occurrence filter (none above mid_occ) and expand
+            // to <= CAP anchors: no filtering, rep_len = 0, never re-chained
+            int32_t n_u = 0, best = 0;
+            gen_anchors(S, sv, a.positions, qlen, a.P.k);
             int64_t n_a = 0;
-            for (;;) {
-                seed_filter(sv, qlen, max_occ, a.P, n_a, rep_len);
-                if (n_a > CAP) { routed = true; break; }
-                gen_anchors(S, sv, a.positions, qlen, a.P.k);
-                chain_dp_mask(S, (int)n_a, qlen, a.P);
-                backtrack_mask(S, (int)n_a, a.P, n_u, best, a.trace == nullptr);
-                if (!rechained && n_u == 0 && a.P.max_occ > a.P.mid_occ && rep_len > 0) { rechained = 1; max_occ = a.P.max_occ; continue; }
-                break;
-            }
-            if (!routed) {
-                finish_read(a, r, n_mini, n_seed, n_a, rep_len, rechained, n_u, best);
-                host = n_u > 0;
-            }
+            for (uint32_t i = 0; i < sv.n; ++i) n_a += sv.occ(i);
+            chain_dp_mask(S, (int)n_a, qlen, a.P);
+            backtrack_mask(S, (int)n_a, a.P, n_u, best, a.trace == nullptr);
+            finish_read(a, r, n_mini, n_seed, n_a, 0, 0, n_u, best);
+            host = n_u > 0;
         }
-        uint32_t bi = wave_append(&a.ctr->n_big[0], routed);     // the repeat path starts every read at pass 0
-        if (routed) a.work_big[bi] = r;
         n_host_wave += (uint32_t)__popcll(__ballot(host));
     }
     if (lane == 0 && n_host_wave) atomicAdd(&a.ctr->sh_host[SHARD()], n_host_wave);
@@ -1088,8 +1091,8 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         a.slots = (const uint4 *)idx->d_slots; a.lg_slots = idx->lg_slots; a.k = idx->k;
         a.records = c->d_records; a.seed_cap = c->seed_cap;
         a.k1info = c->d_k1info; a.flags = d_flags; a.trace = d_trace;
-        a.work_small = c->d_work_small; a.work_resketch = c->d_work_resketch; a.ctr = c->d_ctr;
-        a.lds_words = c->lds_words;
+        a.work_small = c->d_work_small; a.work_resketch = c->d_work_resketch; a.work_big = c->d_big[0][0]; a.ctr = c->d_ctr;
+        a.lds_words = c->lds_words; a.mid_occ = c->P.mid_occ;
         size_t lds = (size_t)K1_LIST_CAP * 64 * 8 + ((size_t)c->lds_words + 2) * 4 + (((size_t)c->lds_words + 2) * 2 + 3) / 4 * 4;
         switch (idx->w) {
         case 5: launch_k1<5>(a, n_tiles, lds, s); break;
@@ -1192,9 +1195,9 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         uint64_t sum_host = 0, sum_mini = 0, sum_anchors = 0, sum_clusters = 0;
         for (int i = 0; i < 64; ++i) { sum_host += c->h_ctr->sh_host[i]; sum_mini += c->h_ctr->sh_mini[i]; sum_anchors += c->h_ctr->sh_anchors[i]; sum_clusters += c->h_ctr->sh_clusters[i]; }
         stats->n_reads += n_reads; stats->n_bases += n_bases;
-        stats->n_host += sum_host; stats->n_no_seed += n_reads - snap.n_small - snap.n_resketch;
+        stats->n_host += sum_host; stats->n_no_seed += n_reads - snap.n_small - snap.n_big[0] - snap.n_resketch;
         uint64_t nl = (uint64_t)snap.n_resketch + snap.n_big[0];
-        stats->n_chain_large += nl; stats->n_chain_small += snap.n_small - snap.n_big[0];
+        stats->n_chain_large += nl; stats->n_chain_small += snap.n_small;
         stats->n_minimizers += sum_mini;
         stats->n_anchors += sum_anchors; stats->n_clusters += sum_clusters; stats->n_resketch += resk_done;
         stats->ms_sketch_probe += t01; stats->ms_chain_small += t12; stats->ms_chain_large += t23; stats->ms_total += t04;
