@@ -47,7 +47,7 @@
 #define SORT_LDS_B 2048         // ... 48 KiB
 #define SORT_LDS_C 4096         // ... 96 KiB; larger ones: 4096-anchor chunks in LDS, then merge rounds in the arena
 #define N_SORT_CLS 4
-#define SORT_GIANT_CHUNK 2048    // LDS chunk of the giant-read kernel (48 KiB: two 1024-thread blocks per CU)
+#define GT 2048u                 // tile of the giant-read merge sort
 
 __device__ inline uint32_t lane_id() { return threadIdx.x & 63; }
 
@@ -55,7 +55,7 @@ __device__ inline uint32_t lane_id() { return threadIdx.x & 63; }
 // by whole chunks per wave (WaveAlloc) and statistics are sharded over 64 addresses.
 struct Counters {
     uint32_t n_small, n_resketch, n_big[2], n_big_defer[2], n_defer, pad0;
-    uint32_t n_sort[N_SORT_CLS], pad1[2];
+    uint32_t n_sort[N_SORT_CLS], n_giant_tiles, pad1;
     unsigned long long arena_cursor, anchor_cursor;
     unsigned long long sh_mini[64], sh_anchors[64];     // sharded sums
     uint32_t sh_host[64], sh_clusters[64];
@@ -341,6 +341,7 @@ struct BigBufs {        // the repeat path's slice of the arena (all arrays inde
     unsigned long long anchor_cap;
     BigMeta *meta; int32_t *acc_nu, *acc_best;
     SortItem *sort_items[N_SORT_CLS];
+    uint32_t *tile_base, *tile_split;       // giant reads: tile table and merge-path splits
 };
 
 struct K2Args {
@@ -601,6 +602,15 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
         // the count can exceed 31 bits only for absurd inputs; saturate (such a read never gets arena space)
         const uint32_t n_a = n_part > 0x7fffffffull ? 0x7fffffffu : (uint32_t)n_part;
 
+        if (n_a > (GT << 8)) {             // beyond the giant path's 8 merge rounds: legacy path (never for sr: <= 22 x 5000)
+            if (lane == 0) {
+                BigMeta m{r, 0, 0, 2u};
+                a.B.meta[w] = m;
+                uint32_t i = atomicAdd(&a.ctr->n_resketch, 1u);
+                a.resketch_list[i] = r;
+            }
+            continue;
+        }
         const bool in_lds = n_a <= 64;     // short anchor lists never leave the CU
         // anchor slots: the wave advances the arena cursor by 16 Ki slots at a time
         if (!in_lds && a_cur + n_a > a_end) {
@@ -775,57 +785,151 @@ __global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
     }
 }
 
-// one block per giant read: 4096-anchor chunks sorted in LDS, the remaining merge rounds between two arena
-// buffers, clusters chained over arena slices
-__global__ __launch_bounds__(1024) void k_sort(K3Args a)
+// ---- giant reads (> SORT_LDS_C anchors; almost all are re-chained satellite reads) ------------------------------
+// Bandwidth-oriented merge sort over ALL giant reads of the pass at once:
+//   k_giant_scan       tile table: read i owns tiles [tile_base[i], tile_base[i+1]) of GT anchors
+//   k_giant_chunksort  one block per tile: load coalesced -> stable sort in LDS -> store coalesced
+//   per round (run width GT, 2GT, ...):
+//     k_giant_partition  one thread per output tile: merge-path split of its first output (independent binary searches)
+//     k_giant_merge      one block per output tile: the two input ranges staged coalesced through LDS, merged in LDS,
+//                        GT outputs stored coalesced into the other buffer
+//   k_giant_chain      one block per read: clusters chained over arena slices (chain_sorted)
+// A read needing r rounds ends in buffer (r & 1); reads that are done sit out the later rounds.
+
+__device__ inline uint32_t giant_rounds(uint32_t n)
 {
-    __shared__ uint64_t s_x[2][SORT_GIANT_CHUNK];
-    __shared__ uint32_t s_q[2][SORT_GIANT_CHUNK];
+    uint32_t r = 0;
+    for (uint32_t w = GT; w < n; w <<= 1) ++r;
+    return r;
+}
+
+__global__ __launch_bounds__(64) void k_giant_scan(K3Args a)
+{
+    const uint32_t lane = threadIdx.x, n_items = a.ctr->n_sort[3];
+    uint32_t run = 0;
+    for (uint32_t base = 0; base < n_items; base += 64) {
+        const uint32_t i = base + lane;
+        const uint32_t t = i < n_items ? (a.B.sort_items[3][i].n + GT - 1) / GT : 0;
+        const uint32_t ex = wave_excl_scan_u32(t, lane);
+        if (i < n_items) a.B.tile_base[i] = run + ex;
+        run += wave_sum_u32(t);
+    }
+    if (lane == 0) { a.B.tile_base[n_items] = run; a.ctr->n_giant_tiles = run; }
+}
+
+__device__ inline uint32_t giant_item_of(const uint32_t *tile_base, uint32_t n_items, uint32_t t)
+{
+    uint32_t lo = 0, hi = n_items;           // tile_base[lo] <= t < tile_base[hi]
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (tile_base[mid] <= t) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_giant_chunksort(K3Args a)
+{
+    __shared__ uint64_t s_x[2][GT];
+    __shared__ uint32_t s_q[2][GT];
+    const uint32_t tid = threadIdx.x, n_items = a.ctr->n_sort[3], n_tiles = a.ctr->n_giant_tiles;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint32_t it = giant_item_of(a.B.tile_base, n_items, t);
+        const SortItem si = a.B.sort_items[3][it];
+        const uint32_t c0 = (t - a.B.tile_base[it]) * GT, m = si.n - c0 < GT ? si.n - c0 : GT;
+        uint64_t *gx = a.B.ax + si.off + c0; uint32_t *gq = a.B.aq + si.off + c0;
+        for (uint32_t i = tid; i < m; i += 256) { s_x[0][i] = gx[i]; s_q[0][i] = gq[i]; }
+        __syncthreads();
+        const bool fl = block_merge_sort(&s_x[0][0], &s_q[0][0], &s_x[1][0], &s_q[1][0], m);
+        const uint64_t *rx = fl ? s_x[1] : s_x[0]; const uint32_t *rq = fl ? s_q[1] : s_q[0];
+        for (uint32_t i = tid; i < m; i += 256) { gx[i] = rx[i]; gq[i] = rq[i]; }
+        __syncthreads();
+    }
+}
+
+struct GiantTile { const uint64_t *sx; const uint32_t *sq; uint64_t *dx; uint32_t *dq; uint32_t L0, L1, R1, o0, o1; bool active; };
+
+__device__ inline GiantTile giant_tile(const K3Args &a, uint32_t t, uint32_t n_items, uint32_t round)
+{
+    GiantTile g;
+    const uint32_t it = giant_item_of(a.B.tile_base, n_items, t);
+    const SortItem si = a.B.sort_items[3][it];
+    const uint32_t width = GT << round;
+    g.active = width < si.n;                       // this read still has runs to merge in this round
+    const bool src_b = round & 1;                  // after `round` rounds the data sits in buffer (round & 1)
+    g.sx = (src_b ? a.B.bx : a.B.ax) + si.off; g.sq = (src_b ? a.B.bq : a.B.aq) + si.off;
+    g.dx = (src_b ? a.B.ax : a.B.bx) + si.off; g.dq = (src_b ? a.B.aq : a.B.bq) + si.off;
+    g.o0 = (t - a.B.tile_base[it]) * GT; g.o1 = g.o0 + GT < si.n ? g.o0 + GT : si.n;
+    const uint32_t pb = g.o0 / (2 * width) * (2 * width);
+    g.L0 = pb; g.L1 = pb + width < si.n ? pb + width : si.n; g.R1 = pb + 2 * width < si.n ? pb + 2 * width : si.n;
+    return g;
+}
+
+// split[t] = number of elements the left run contributes before output o0 of tile t
+__global__ __launch_bounds__(256) void k_giant_partition(K3Args a, uint32_t round)
+{
+    const uint32_t n_items = a.ctr->n_sort[3], n_tiles = a.ctr->n_giant_tiles;
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < n_tiles; t += gridDim.x * 256) {
+        const GiantTile g = giant_tile(a, t, n_items, round);
+        if (!g.active) continue;
+        const uint32_t lenL = g.L1 - g.L0, lenR = g.R1 - g.L1, d = g.o0 - g.L0;
+        uint32_t lo = d > lenR ? d - lenR : 0, hi = d < lenL ? d : lenL;
+        while (lo < hi) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (g.sx[g.L0 + mid] <= g.sx[g.L1 + (d - 1 - mid)]) lo = mid + 1; else hi = mid;
+        }
+        a.B.tile_split[t] = lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_giant_merge(K3Args a, uint32_t round)
+{
+    __shared__ uint64_t s_x[GT];          // [0, la): left range, [la, la+lb): right range; la + lb <= GT
+    __shared__ uint32_t s_q[GT];
+    const uint32_t tid = threadIdx.x, n_items = a.ctr->n_sort[3], n_tiles = a.ctr->n_giant_tiles;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const GiantTile g = giant_tile(a, t, n_items, round);
+        if (!g.active) continue;                               // uniform per block
+        const uint32_t d0 = g.o0 - g.L0, d1 = g.o1 - g.L0;
+        const uint32_t a0 = a.B.tile_split[t];
+        // the next tile of the same pair starts where this one ends; the pair's last tile ends at the run ends
+        const bool last_of_pair = g.o1 == g.R1;
+        const uint32_t a1 = last_of_pair ? g.L1 - g.L0 : a.B.tile_split[t + 1];
+        const uint32_t b0 = d0 - a0, b1 = d1 - a1;
+        const uint32_t la = a1 - a0, lb = b1 - b0;
+        for (uint32_t i = tid; i < la; i += 256) { s_x[i] = g.sx[g.L0 + a0 + i]; s_q[i] = g.sq[g.L0 + a0 + i]; }
+        for (uint32_t i = tid; i < lb; i += 256) { s_x[la + i] = g.sx[g.L1 + b0 + i]; s_q[la + i] = g.sq[g.L1 + b0 + i]; }
+        __syncthreads();
+        // merge in LDS: 8 outputs per thread
+        const uint32_t m = la + lb, C = 8;
+        for (uint32_t c = tid; c * C < m; c += 256) {
+            const uint32_t e0 = c * C, e1 = e0 + C < m ? e0 + C : m;
+            uint32_t lo = e0 > lb ? e0 - lb : 0, hi = e0 < la ? e0 : la;
+            while (lo < hi) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (s_x[mid] <= s_x[la + (e0 - 1 - mid)]) lo = mid + 1; else hi = mid;
+            }
+            uint32_t ia = lo, ib = e0 - lo;
+            uint64_t va = ia < la ? s_x[ia] : ~0ull, vb = ib < lb ? s_x[la + ib] : ~0ull;
+            for (uint32_t e = e0; e < e1; ++e) {
+                const bool takeL = ia < la && (ib >= lb || va <= vb);
+                if (takeL) { g.dx[g.o0 + e] = va; g.dq[g.o0 + e] = s_q[ia]; ++ia; va = ia < la ? s_x[ia] : ~0ull; }
+                else { g.dx[g.o0 + e] = vb; g.dq[g.o0 + e] = s_q[la + ib]; ++ib; vb = ib < lb ? s_x[la + ib] : ~0ull; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// one block per giant read: clusters chained over arena slices of the buffer its sort ended in
+__global__ __launch_bounds__(1024) void k_giant_chain(K3Args a)
+{
     __shared__ int32_t s_found, s_red[2];
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const uint32_t n_items = a.ctr->n_sort[3];
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
         const SortItem si = a.B.sort_items[3][it];
         const uint32_t n = si.n;
-        if (n == 0) continue;
-        uint64_t *gx = a.B.ax + si.off, *hx = a.B.bx + si.off;
-        uint32_t *gq = a.B.aq + si.off, *hq = a.B.bq + si.off;
+        const bool in_b = giant_rounds(n) & 1;
+        uint64_t *sx = (in_b ? a.B.bx : a.B.ax) + si.off; uint32_t *sq = (in_b ? a.B.bq : a.B.aq) + si.off;
         if (tid == 0) s_found = 0;
-        if (!(a.dbg & 4))
-        for (uint32_t c0 = 0; c0 < n; c0 += SORT_GIANT_CHUNK) {
-            const uint32_t m = n - c0 < SORT_GIANT_CHUNK ? n - c0 : SORT_GIANT_CHUNK;
-            for (uint32_t i = tid; i < m; i += nthr) { s_x[0][i] = gx[c0 + i]; s_q[0][i] = gq[c0 + i]; }
-            __syncthreads();
-            const bool fl = block_merge_sort(&s_x[0][0], &s_q[0][0], &s_x[1][0], &s_q[1][0], m);
-            const uint64_t *rx = fl ? s_x[1] : s_x[0]; const uint32_t *rq = fl ? s_q[1] : s_q[0];
-            for (uint32_t i = tid; i < m; i += nthr) { gx[c0 + i] = rx[i]; gq[c0 + i] = rq[i]; }
-            __syncthreads();
-        }
-        // merge rounds in the arena, C outputs per thread and step
-        uint64_t *sx = gx, *dx = hx; uint32_t *sq = gq, *dq = hq;
-        const uint32_t C = 16, n_chunks = (n + C - 1) / C;
-        for (uint32_t width = SORT_GIANT_CHUNK; width < n && !(a.dbg & 8); width <<= 1) {
-            for (uint32_t c = tid; c < n_chunks; c += nthr) {
-                const uint32_t o0 = c * C, o1 = o0 + C < n ? o0 + C : n;
-                const uint32_t pb = o0 / (2 * width) * (2 * width);
-                const uint32_t L0 = pb, L1 = pb + width < n ? pb + width : n, R1 = pb + 2 * width < n ? pb + 2 * width : n;
-                const uint32_t lenL = L1 - L0, lenR = R1 - L1, d = o0 - pb;
-                uint32_t lo = d > lenR ? d - lenR : 0, hi = d < lenL ? d : lenL;
-                while (lo < hi) {
-                    uint32_t mid = (lo + hi) >> 1;
-                    if (sx[L0 + mid] <= sx[L1 + (d - 1 - mid)]) lo = mid + 1; else hi = mid;
-                }
-                uint32_t ia = L0 + lo, ib = L1 + (d - lo);
-                uint64_t va = ia < L1 ? sx[ia] : ~0ull, vb = ib < R1 ? sx[ib] : ~0ull;
-                for (uint32_t o = o0; o < o1; ++o) {
-                    const bool takeL = ia < L1 && (ib >= R1 || va <= vb);
-                    if (takeL) { dx[o] = va; dq[o] = sq[ia]; ++ia; va = ia < L1 ? sx[ia] : ~0ull; }
-                    else { dx[o] = vb; dq[o] = sq[ib]; ++ib; vb = ib < R1 ? sx[ib] : ~0ull; }
-                }
-            }
-            __syncthreads();
-            uint64_t *tx = sx; sx = dx; dx = tx; uint32_t *tq = sq; sq = dq; dq = tq;
-        }
+        __syncthreads();
         int32_t n_u = 0, best = 0; uint32_t n_cl = 0;
         if (!(a.dbg & 2))
         chain_sorted<true>(sx, sq, a.B.af + si.off, (int32_t *)(a.B.az + si.off), n, tid, nthr, (int32_t)si.qlen, a.P,
@@ -1021,8 +1125,8 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         c->legacy_bytes = std::min<uint64_t>(c->arena_bytes / 8, 1ull << 30);
         uint8_t *p = c->d_arena + c->legacy_bytes;
         uint64_t left = c->arena_bytes - c->legacy_bytes;
-        uint64_t fixed = max_reads * (sizeof(BigMeta) + 8 + N_SORT_CLS * sizeof(SortItem)) + 8192;
-        uint64_t per_anchor = 8 + 8 + 8 + 4 + 4 + 4;   // ax bx az aq bq af
+        uint64_t fixed = max_reads * (sizeof(BigMeta) + 8 + N_SORT_CLS * sizeof(SortItem) + 8) + 16384;
+        uint64_t per_anchor = 8 + 8 + 8 + 4 + 4 + 4 + 1;   // ax bx az aq bq af (+ tile_split share)
         uint64_t cap = left > fixed ? (left - fixed) / per_anchor : 0;
         cap &= ~15ull;
         if (cap < 1024) { sh_set_error("sh_ctx_create: arena of %llu MiB is too small", (unsigned long long)(c->arena_bytes >> 20)); sh_ctx_destroy(c); return SH_ERR_OOM; }
@@ -1035,6 +1139,8 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         B.meta = (BigMeta *)take(max_reads * sizeof(BigMeta));
         B.acc_nu = (int32_t *)take(max_reads * 4); B.acc_best = (int32_t *)take(max_reads * 4);
         for (int i = 0; i < N_SORT_CLS; ++i) B.sort_items[i] = (SortItem *)take(max_reads * sizeof(SortItem));
+        B.tile_base = (uint32_t *)take((max_reads + 1) * 4);
+        B.tile_split = (uint32_t *)take((cap / GT + max_reads + 2) * 4);
         if ((uint64_t)(p - c->d_arena) > c->arena_bytes) {   // alignment slack: shrink
             sh_set_error("sh_ctx_create: internal arena carve overflow"); sh_ctx_destroy(c); return SH_ERR_OOM;
         }
@@ -1073,7 +1179,13 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     hipLaunchKernelGGL((k_sort_lds<SORT_LDS_A, 0, 64>), dim3(grid * 2), dim3(64), 0, s, k);
     hipLaunchKernelGGL((k_sort_lds<SORT_LDS_B, 1, 128>), dim3(256 * 3), dim3(128), 0, s, k);
     hipLaunchKernelGGL((k_sort_lds<SORT_LDS_C, 2, 512>), dim3(256), dim3(512), 0, s, k);
-    hipLaunchKernelGGL(k_sort, dim3(512), dim3(1024), 0, s, k);
+    hipLaunchKernelGGL(k_giant_scan, dim3(1), dim3(64), 0, s, k);
+    hipLaunchKernelGGL(k_giant_chunksort, dim3(256 * 3), dim3(256), 0, s, k);
+    for (uint32_t round = 0; round < 8; ++round) {      // run widths GT << round: up to 2^19 anchors per read
+        hipLaunchKernelGGL(k_giant_partition, dim3(256), dim3(256), 0, s, k, round);
+        hipLaunchKernelGGL(k_giant_merge, dim3(256 * 3), dim3(256), 0, s, k, round);
+    }
+    hipLaunchKernelGGL(k_giant_chain, dim3(512), dim3(1024), 0, s, k);
     hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, s, k);
     return SH_OK;
 }
