@@ -475,6 +475,7 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
     // cluster never touches its big ones (the true-locus cluster, dense tandem arrays).
     for (int sweep = 0; sweep < 3; ++sweep) {
         for (uint32_t i = i_beg; i < i_end; i += i_step) {
+            if (found && *found) break;            // flag-only: the read is decided
             if (!(q[i] >> 31)) continue;
             uint32_t j = i + 1;
             while (j < n && !(q[j] >> 31)) ++j;
