@@ -152,6 +152,40 @@ sh_status sh_classify_device(sh_ctx *ctx, const uint8_t *d_bases, const uint64_t
 sh_status sh_classify_batch(const sh_index *idx, const sh_opts *opts, const uint8_t *bases, const uint64_t *offsets,
                             uint64_t n_reads, uint8_t *out_flags, sh_trace *out_trace, sh_stats *stats);
 
+/* ---- the whole replaced path:  Cleaner::run_minimap2_rs + clean_reads + ScrubbyReport  ------------------------
+ * (/root/reference/src/cleaner.rs:443-575, :236-254, :731-760; src/report.rs:24-57; src/utils.rs:250-285)
+ * FASTA/FASTQ (plain or gzip) in, filtered files out, optional JSON report and TSV of removed ids.
+ * This is what `scrubby reads -i R1 [R2] -o O1 [O2] -I ref.fa [-p sr] [-e] [-j report.json] [-r ids.tsv]` runs. */
+typedef struct sh_reads_config {
+    const char *input[2];
+    const char *output[2];
+    uint32_t    n_files;      /* 1 (single-end / long reads) or 2 (paired-end) */
+    int32_t     extract;      /* -e: write the mapped reads instead of the unmapped ones */
+    const char *index;        /* -I: reference FASTA(.gz), or a .shidx cache written by sh_index_save */
+    const char *preset;       /* -p: NULL -> "sr" for two files, "map-ont" for one (scrubby.rs:935-951) */
+    const char *json;         /* -j, nullable */
+    const char *read_ids;     /* -r, nullable */
+    const char *command;      /* argv joined by ' ' (terminal.rs:178), for the report */
+    int32_t     threads;      /* -t: accepted for interface parity; the GPU path does not use it */
+    int32_t     device;
+} sh_reads_config;
+
+typedef struct sh_reads_result {
+    uint64_t reads_in, reads_out, reads_removed, reads_extracted;   /* as in the JSON report (records over both files) */
+    uint64_t n_depleted_ids;                                        /* size of the HashSet<String> of cleaner.rs:564-570 */
+    double   ms_index, ms_ingest, ms_classify, ms_write;
+} sh_reads_result;
+
+sh_status sh_reads_run(const sh_reads_config *cfg, sh_reads_result *out);
+
+/* host-side pieces on their own (no GPU needed): get_id (utils.rs:91-103), FastqCleaner::clean_reads
+ * (cleaner.rs:731-760), ReadDifference::get_difference (utils.rs:250-285) */
+sh_status sh_host_get_id(const char *header, char *out, size_t cap);
+sh_status sh_host_filter_fastx(const char *in, const char *out, const char *const *ids, uint64_t n_ids, int32_t extract,
+                               uint64_t *n_in, uint64_t *n_out);
+sh_status sh_host_read_difference(const char *const *inputs, const char *const *outputs, uint32_t n, uint64_t *reads_in,
+                                  uint64_t *reads_out, uint64_t *difference);
+
 /* ---- synthetic workload (bench/test utility) ---------------------------- */
 /* params structs are syn_ref_params / syn_read_params of csrc/sh_synth_core.h, passed opaquely */
 sh_status sh_synth_ref_device(const void *ref_params, uint64_t g0, uint64_t n, uint8_t *d_out, void *stream);

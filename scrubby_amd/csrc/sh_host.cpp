@@ -1,0 +1,348 @@
+// sh_host.cpp — host side of the replaced path, in C++ (the reference's host language, Rust, is not on this
+// image).  Mirrors, function by function, what surrounds the kernel path in the reference:
+//
+//   get_id                         /root/reference/src/utils.rs:91-103     first whitespace token of the header
+//   parse_fastx_file_with_check    /root/reference/src/utils.rs:359-383    None for an empty file; gzip by magic bytes
+//   Cleaner::run_minimap2_rs       /root/reference/src/cleaner.rs:443-575  index, ingest R1(/R2), classify, id set
+//   FastqCleaner::clean_reads      /root/reference/src/cleaner.rs:731-760  keep/drop by id, output compression by extension
+//   ReadDifference::get_difference /root/reference/src/utils.rs:250-285    reads_in / reads_out / difference over both files
+//   ScrubbyReport                  /root/reference/src/report.rs:10-88     JSON schema (key order = struct order), TSV of ids
+//
+// Divergences, all deliberate and documented in DESIGN.md: bz2/xz inputs or outputs are rejected (zlib only);
+// a corrupt FASTQ is an error instead of a logged partial id set.
+#include "sh_common.h"
+#include <zlib.h>
+#include <chrono>
+#include <ctime>
+#include <unordered_set>
+
+namespace {
+
+struct FastxRecord { std::string header, seq, qual; bool fastq = false; };
+
+// FASTA / FASTQ, plain or gzip (gzopen reads both); multi-line FASTA, 4-line FASTQ
+class FastxReader {
+    gzFile f_ = nullptr;
+    std::string line_, pending_;
+    bool have_pending_ = false, eof_ = false;
+    std::vector<char> buf_;
+    bool getline(std::string &out)
+    {
+        out.clear();
+        for (;;) {
+            if (!gzgets(f_, buf_.data(), (int)buf_.size())) { eof_ = true; return !out.empty(); }
+            size_t n = strlen(buf_.data());
+            out.append(buf_.data(), n);
+            if (n && out.back() == '\n') { out.pop_back(); if (!out.empty() && out.back() == '\r') out.pop_back(); return true; }
+        }
+    }
+public:
+    std::string error;
+    explicit FastxReader(const char *path) : buf_(1 << 16) { f_ = gzopen(path, "rb"); if (f_) gzbuffer(f_, 1 << 20); }
+    ~FastxReader() { if (f_) gzclose(f_); }
+    bool ok() const { return f_ != nullptr; }
+    // 1 = record, 0 = end, -1 = malformed
+    int next(FastxRecord &r)
+    {
+        std::string l;
+        if (have_pending_) { l = pending_; have_pending_ = false; }
+        else { do { if (!getline(l)) return 0; } while (l.empty()); }
+        if (l[0] == '@') {
+            r.fastq = true; r.header = l.substr(1);
+            std::string plus;
+            if (!getline(r.seq) || !getline(plus) || plus.empty() || plus[0] != '+' || !getline(r.qual)) { error = "truncated FASTQ record: " + r.header; return -1; }
+            if (r.qual.size() != r.seq.size()) { error = "sequence/quality length mismatch: " + r.header; return -1; }
+            return 1;
+        }
+        if (l[0] == '>') {
+            r.fastq = false; r.header = l.substr(1); r.seq.clear(); r.qual.clear();
+            while (getline(l)) {
+                if (!l.empty() && l[0] == '>') { pending_ = l; have_pending_ = true; break; }
+                r.seq += l;
+            }
+            return 1;
+        }
+        error = "not a FASTA/FASTQ record: " + l.substr(0, 40);
+        return -1;
+    }
+};
+
+bool file_is_empty(const char *path, bool &exists)
+{   // is_file_empty + compression sniffing: an empty gzip stream counts as empty
+    gzFile f = gzopen(path, "rb");
+    exists = f != nullptr;
+    if (!f) return true;
+    char c;
+    int n = gzread(f, &c, 1);
+    gzclose(f);
+    return n <= 0;
+}
+
+// get_id: first whitespace-delimited token of the header; a header without one is an error
+bool get_id(const std::string &header, std::string &id)
+{
+    size_t b = 0, n = header.size();
+    while (b < n && isspace((unsigned char)header[b])) ++b;
+    size_t e = b;
+    while (e < n && !isspace((unsigned char)header[e])) ++e;
+    if (e == b) return false;
+    id.assign(header, b, e - b);
+    return true;
+}
+
+// output compression chosen by extension (CompressionExt::from_path, utils.rs:28-36), level 6
+class FastxWriter {
+    gzFile gz_ = nullptr; FILE *fp_ = nullptr;
+public:
+    std::string error;
+    explicit FastxWriter(const std::string &path, int level = 6)
+    {
+        auto ends = [&](const char *s) { size_t k = strlen(s); return path.size() >= k && path.compare(path.size() - k, k, s) == 0; };
+        if (ends(".gz")) { std::string mode = "wb" + std::to_string(level); gz_ = gzopen(path.c_str(), mode.c_str()); if (!gz_) error = "cannot open " + path; }
+        else if (ends(".bz") || ends(".bz2") || ends(".lzma") || ends(".xz")) error = "bzip2/xz output not supported by the HIP backend: " + path;
+        else { fp_ = fopen(path.c_str(), "wb"); if (!fp_) error = "cannot open " + path; }
+    }
+    ~FastxWriter() { if (gz_) gzclose(gz_); if (fp_) fclose(fp_); }
+    bool ok() const { return error.empty(); }
+    void put(const std::string &s) { if (gz_) gzwrite(gz_, s.data(), (unsigned)s.size()); else fwrite(s.data(), 1, s.size(), fp_); }
+    void write(const FastxRecord &r)
+    {   // needletail record.write(writer, None): '\n' line endings, bare '+', full original header
+        std::string o;
+        o.reserve(r.header.size() + r.seq.size() * 2 + 8);
+        o += r.fastq ? '@' : '>'; o += r.header; o += '\n'; o += r.seq; o += '\n';
+        if (r.fastq) { o += "+\n"; o += r.qual; o += '\n'; }
+        put(o);
+    }
+};
+
+std::string json_escape(const std::string &s)
+{
+    std::string o;
+    for (unsigned char c : s) {
+        if (c == '"') o += "\\\""; else if (c == '\\') o += "\\\\"; else if (c == '\n') o += "\\n"; else if (c == '\t') o += "\\t";
+        else if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o += b; } else o += (char)c;
+    }
+    return o;
+}
+
+const char *preset_variant(const std::string &display)
+{   // Preset serialises as the Rust variant name
+    static const char *tab[][2] = {{"sr", "Sr"}, {"map-ont", "MapOnt"}, {"lr:hq", "LrHq"}, {"lr", "Lr"}, {"asm", "Asm"}, {"asm5", "Asm5"},
+                                   {"asm10", "Asm10"}, {"asm20", "Asm20"}, {"ava-ont", "AvaOnt"}, {"ava-pb", "AvaPb"}, {"map-hifi", "MapHifi"},
+                                   {"map-pb", "MapPb"}, {"splice", "Splice"}, {"splice:hq", "SpliceHq"}};
+    for (auto &t : tab) if (display == t[0]) return t[1];
+    return nullptr;
+}
+
+sh_status filter_fastx(const char *in, const char *out, const std::unordered_set<std::string> &ids, bool extract, uint64_t *n_in, uint64_t *n_out)
+{
+    bool exists;
+    if (file_is_empty(in, exists)) {
+        SH_CHECK(exists, SH_ERR_IO, "cannot open %s", in);
+        fprintf(stderr, "[scrubby-hip] warning: Input file is empty: %s\n", in);     // output file is NOT created (App. C Q6)
+        return SH_OK;
+    }
+    FastxReader rd(in);
+    SH_CHECK(rd.ok(), SH_ERR_IO, "cannot open %s", in);
+    FastxWriter wr(out);
+    SH_CHECK(wr.ok(), SH_ERR_IO, "%s", wr.error.c_str());
+    FastxRecord r; std::string id; int st;
+    while ((st = rd.next(r)) == 1) {
+        SH_CHECK(get_id(r.header, id), SH_ERR_IO, "record without an id in %s", in);
+        if (n_in) ++*n_in;
+        const bool hit = ids.count(id) != 0;
+        if (hit == extract) { wr.write(r); if (n_out) ++*n_out; }        // deplete: keep misses; extract: keep hits
+    }
+    SH_CHECK(st == 0, SH_ERR_IO, "%s: %s", in, rd.error.c_str());
+    return SH_OK;
+}
+
+}  // namespace
+
+// ---- pieces exposed for the CPU tests (no GPU needed) ------------------------------------------------------------
+extern "C" sh_status sh_host_get_id(const char *header, char *out, size_t cap)
+{
+    SH_CHECK(header && out && cap, SH_ERR_BAD_ARG, "sh_host_get_id: null argument");
+    std::string id;
+    SH_CHECK(get_id(header, id), SH_ERR_IO, "NeedletailFastqHeader: header has no id");
+    SH_CHECK(id.size() + 1 <= cap, SH_ERR_BAD_ARG, "id buffer too small");
+    memcpy(out, id.c_str(), id.size() + 1);
+    return SH_OK;
+}
+
+extern "C" sh_status sh_host_filter_fastx(const char *in, const char *out, const char *const *ids, uint64_t n_ids, int32_t extract,
+                                          uint64_t *n_in, uint64_t *n_out)
+{
+    SH_CHECK(in && out && (ids || n_ids == 0), SH_ERR_BAD_ARG, "sh_host_filter_fastx: null argument");
+    std::unordered_set<std::string> set;
+    for (uint64_t i = 0; i < n_ids; ++i) set.insert(ids[i]);
+    uint64_t a = 0, b = 0;
+    sh_status st = filter_fastx(in, out, set, extract != 0, &a, &b);
+    if (n_in) *n_in = a;
+    if (n_out) *n_out = b;
+    return st;
+}
+
+static sh_status read_difference(const char *const *inputs, const char *const *outputs, uint32_t n, uint64_t *reads_in, uint64_t *reads_out,
+                                 uint64_t *difference, std::unordered_set<std::string> *diff_ids)
+{
+    uint64_t in_total = 0, out_total = 0, diff_total = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        std::unordered_set<std::string> out_ids;
+        bool exists;
+        FastxRecord r; std::string id; int st;
+        if (!file_is_empty(outputs[i], exists)) {
+            FastxReader rd(outputs[i]);
+            while ((st = rd.next(r)) == 1) { SH_CHECK(get_id(r.header, id), SH_ERR_IO, "record without an id in %s", outputs[i]); out_ids.insert(id); ++out_total; }
+            SH_CHECK(st == 0, SH_ERR_IO, "%s: %s", outputs[i], rd.error.c_str());
+        }
+        if (!file_is_empty(inputs[i], exists)) {
+            FastxReader rd(inputs[i]);
+            while ((st = rd.next(r)) == 1) {
+                SH_CHECK(get_id(r.header, id), SH_ERR_IO, "record without an id in %s", inputs[i]);
+                if (!out_ids.count(id)) { if (diff_ids) diff_ids->insert(id); ++diff_total; }
+                ++in_total;
+            }
+            SH_CHECK(st == 0, SH_ERR_IO, "%s: %s", inputs[i], rd.error.c_str());
+        } else {
+            SH_CHECK(exists, SH_ERR_IO, "cannot open %s", inputs[i]);
+            fprintf(stderr, "[scrubby-hip] warning: Input file is empty: %s\n", inputs[i]);
+        }
+    }
+    *reads_in = in_total; *reads_out = out_total; *difference = diff_total;
+    return SH_OK;
+}
+
+extern "C" sh_status sh_host_read_difference(const char *const *inputs, const char *const *outputs, uint32_t n, uint64_t *reads_in,
+                                             uint64_t *reads_out, uint64_t *difference)
+{
+    SH_CHECK(inputs && outputs && reads_in && reads_out && difference && n >= 1 && n <= 2, SH_ERR_BAD_ARG, "sh_host_read_difference: bad argument");
+    return read_difference(inputs, outputs, n, reads_in, reads_out, difference, nullptr);
+}
+
+static sh_status write_report(const sh_reads_config *c, const std::string &preset, const sh_reads_result *r, const char *path)
+{
+    FILE *f = fopen(path, "wb");
+    SH_CHECK(f, SH_ERR_IO, "cannot open %s", path);
+    char date[64];
+    time_t now = time(nullptr);
+    struct tm tmv;
+    gmtime_r(&now, &tmv);
+    strftime(date, sizeof date, "%Y-%m-%dT%H:%M:%SZ", &tmv);          // to_rfc3339_opts(SecondsFormat::Secs, true)
+    auto paths = [&](const char *const *p, uint32_t n) {
+        std::string o = "[";
+        for (uint32_t i = 0; i < n; ++i) { o += i ? ",\n    \"" : "\n    \""; o += json_escape(p[i]); o += "\""; }
+        o += n ? "\n  ]" : "]";
+        return o;
+    };
+    const char *pv = preset_variant(preset);
+    std::string o = "{\n";
+    o += "  \"version\": \"1.0.2\",\n";                                 // crate_version!() of the reference this drops into
+    o += std::string("  \"date\": \"") + date + "\",\n";
+    o += "  \"command\": \"" + json_escape(c->command ? c->command : "") + "\",\n";
+    o += "  \"input\": " + paths(c->input, c->n_files) + ",\n";
+    o += "  \"output\": " + paths(c->output, c->n_files) + ",\n";
+    o += "  \"reads_in\": " + std::to_string(r->reads_in) + ",\n";
+    o += "  \"reads_out\": " + std::to_string(r->reads_out) + ",\n";
+    o += "  \"reads_removed\": " + std::to_string(r->reads_removed) + ",\n";
+    o += "  \"reads_extracted\": " + std::to_string(r->reads_extracted) + ",\n";
+    o += "  \"settings\": {\n";
+    o += "    \"aligner\": \"minimap2-rs\",\n    \"classifier\": null,\n";
+    o += "    \"index\": \"" + json_escape(c->index) + "\",\n";
+    o += "    \"alignment\": null,\n    \"reads\": null,\n    \"report\": null,\n    \"taxa\": [],\n    \"taxa_direct\": [],\n";
+    o += "    \"classifier_args\": null,\n    \"aligner_args\": null,\n";
+    o += std::string("    \"preset\": ") + (pv ? "\"" + std::string(pv) + "\"" : "null") + ",\n";
+    o += "    \"min_len\": 0,\n    \"min_cov\": 0.0,\n    \"min_mapq\": 0,\n";
+    o += std::string("    \"extract\": ") + (c->extract ? "true" : "false") + "\n  }\n}";
+    fwrite(o.data(), 1, o.size(), f);
+    fclose(f);
+    return SH_OK;
+}
+
+// ---- Cleaner::run_minimap2_rs + clean_reads + ScrubbyReport::create ------------------------------------------------
+extern "C" sh_status sh_reads_run(const sh_reads_config *c, sh_reads_result *res)
+{
+    SH_CHECK(c && res, SH_ERR_BAD_ARG, "sh_reads_run: null argument");
+    SH_CHECK(c->n_files >= 1 && c->n_files <= 2, SH_ERR_BAD_ARG, "one or two input files are supported (got %u)", c->n_files);
+    for (uint32_t i = 0; i < c->n_files; ++i) SH_CHECK(c->input[i] && c->output[i], SH_ERR_BAD_ARG, "input/output %u missing", i);
+    SH_CHECK(c->index, SH_ERR_BAD_ARG, "MissingAlignmentIndex");
+    memset(res, 0, sizeof(*res));
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+
+    // default preset: Sr for two files, MapOnt for one (/root/reference/src/scrubby.rs:935-951)
+    const std::string preset = c->preset && c->preset[0] ? c->preset : (c->n_files == 2 ? "sr" : "map-ont");
+    sh_opts opts;
+    sh_status st = sh_preset(preset.c_str(), &opts);
+    if (st != SH_OK) return st;
+
+    auto t0 = now();
+    sh_index *idx = nullptr;
+    {
+        const std::string ip = c->index;
+        const bool cache = ip.size() > 6 && ip.compare(ip.size() - 6, 6, ".shidx") == 0;
+        st = cache ? sh_index_load(c->index, c->device, &idx) : sh_index_build_fasta(c->index, &opts, c->device, &idx);
+        if (st != SH_OK) return st == SH_ERR_IO ? st : SH_ERR_INDEX;
+    }
+    auto t1 = now();
+
+    // ingest: every record of R1 then R2 becomes one (id, seq) item (cleaner.rs:484-549)
+    std::vector<std::string> ids;
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> offsets(1, 0);
+    for (uint32_t i = 0; i < c->n_files; ++i) {
+        bool exists;
+        if (file_is_empty(c->input[i], exists)) {
+            if (!exists) { sh_index_free(idx); sh_set_error("cannot open %s", c->input[i]); return SH_ERR_IO; }
+            fprintf(stderr, "[scrubby-hip] warning: Input file is empty: %s\n", c->input[i]);
+            continue;
+        }
+        FastxReader rd(c->input[i]);
+        FastxRecord r; std::string id; int s;
+        while ((s = rd.next(r)) == 1) {
+            if (!get_id(r.header, id)) { sh_index_free(idx); sh_set_error("record without an id in %s", c->input[i]); return SH_ERR_IO; }
+            ids.push_back(id);
+            bases.insert(bases.end(), r.seq.begin(), r.seq.end());
+            offsets.push_back(bases.size());
+        }
+        if (s != 0) { sh_index_free(idx); sh_set_error("%s: %s", c->input[i], rd.error.c_str()); return SH_ERR_IO; }
+    }
+    auto t2 = now();
+
+    // classify: aligner.map(..).len() > 0 per record (cleaner.rs:550-558); any per-read error aborts (:566)
+    std::vector<uint8_t> flags(ids.size() ? ids.size() : 1, 0);
+    bases.resize(bases.size() + 32, 'N');
+    st = sh_classify_batch(idx, &opts, bases.data(), offsets.data(), ids.size(), flags.data(), nullptr, nullptr);
+    sh_index_free(idx);
+    if (st != SH_OK) return st;
+    auto t3 = now();
+
+    // id set (cleaner.rs:564-570), then the filter/writer over each input file (clean_reads, :236-254)
+    std::unordered_set<std::string> depleted;
+    for (size_t i = 0; i < ids.size(); ++i) if (flags[i] == 1) depleted.insert(ids[i]);
+    res->n_depleted_ids = depleted.size();
+    for (uint32_t i = 0; i < c->n_files; ++i) {
+        st = filter_fastx(c->input[i], c->output[i], depleted, c->extract != 0, nullptr, nullptr);
+        if (st != SH_OK) return st;
+    }
+    auto t4 = now();
+
+    // report (only if -j or -r was given, scrubby.rs:276-278): counts come from re-reading the files
+    if (c->json || c->read_ids) {
+        std::unordered_set<std::string> diff_ids;
+        uint64_t rin, rout, diff;
+        st = read_difference(c->input, c->output, c->n_files, &rin, &rout, &diff, &diff_ids);
+        if (st != SH_OK) return st;
+        res->reads_in = rin; res->reads_out = rout;
+        res->reads_removed = c->extract ? 0 : diff; res->reads_extracted = c->extract ? diff : 0;
+        if (c->read_ids) {
+            FastxWriter w(c->read_ids, 9);
+            SH_CHECK(w.ok(), SH_ERR_IO, "%s", w.error.c_str());
+            w.put("id\n");
+            for (auto &id : diff_ids) w.put(id + "\n");
+        }
+        if (c->json) { st = write_report(c, preset, res, c->json); if (st != SH_OK) return st; }
+    }
+    res->ms_index = ms(t0, t1); res->ms_ingest = ms(t1, t2); res->ms_classify = ms(t2, t3); res->ms_write = ms(t3, t4);
+    return SH_OK;
+}

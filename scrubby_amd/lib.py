@@ -67,6 +67,18 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class ReadsConfig(C.Structure):
+    _fields_ = [("input", C.c_char_p * 2), ("output", C.c_char_p * 2), ("n_files", C.c_uint32), ("extract", C.c_int32),
+                ("index", C.c_char_p), ("preset", C.c_char_p), ("json", C.c_char_p), ("read_ids", C.c_char_p),
+                ("command", C.c_char_p), ("threads", C.c_int32), ("device", C.c_int32)]
+
+
+class ReadsResult(C.Structure):
+    _fields_ = [("reads_in", C.c_uint64), ("reads_out", C.c_uint64), ("reads_removed", C.c_uint64),
+                ("reads_extracted", C.c_uint64), ("n_depleted_ids", C.c_uint64), ("ms_index", C.c_double),
+                ("ms_ingest", C.c_double), ("ms_classify", C.c_double), ("ms_write", C.c_double)]
+
+
 class RefParams(C.Structure):
     _fields_ = [
         ("seed", C.c_uint64), ("genome_len", C.c_uint64), ("n_contigs", C.c_uint32),
@@ -87,6 +99,7 @@ EXPORTS = [
     "sh_index_info_get", "sh_index_export", "sh_index_free",
     "sh_ctx_create", "sh_ctx_destroy", "sh_classify_device", "sh_classify_batch",
     "sh_synth_ref_device", "sh_synth_reads_device", "sh_bench_gather",
+    "sh_reads_run", "sh_host_get_id", "sh_host_filter_fastx", "sh_host_read_difference",
 ]
 
 _LIB = None
@@ -123,6 +136,10 @@ def load():
     L.sh_synth_ref_device.argtypes = [C.POINTER(RefParams), u64, u64, vp, vp]
     L.sh_synth_reads_device.argtypes = [C.POINTER(RefParams), C.POINTER(ReadParams), u64, u64, vp, vp, vp]
     L.sh_bench_gather.argtypes = [vp, u64, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.sh_reads_run.argtypes = [C.POINTER(ReadsConfig), C.POINTER(ReadsResult)]
+    L.sh_host_get_id.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    L.sh_host_filter_fastx.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u64, i32, C.POINTER(u64), C.POINTER(u64)]
+    L.sh_host_read_difference.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     for name in EXPORTS:
         if name not in ("sh_version", "sh_device_count", "sh_last_error"):
             getattr(L, name).restype = i32
@@ -305,3 +322,47 @@ def synth_ref_device(P, g0, n, out):
 def synth_reads_device(P, R, r0, n_records, out, offsets=None):
     check(require_gpu().sh_synth_reads_device(C.byref(P), C.byref(R), r0, n_records, C.c_void_p(out.data_ptr()),
                                              C.c_void_p(offsets.data_ptr()) if offsets is not None else None, _stream_ptr()))
+
+
+# ---- host-side mirror of the reference path (C++ in csrc/sh_host.cpp) ------------------------------------------------
+def get_id(header):
+    """utils.rs:91-103: first whitespace token of a FASTX header (bytes or str)."""
+    h = header if isinstance(header, bytes) else header.encode()
+    out = C.create_string_buffer(len(h) + 2)
+    check(load().sh_host_get_id(h, out, len(h) + 2))
+    return out.value.decode()
+
+
+def filter_fastx(inp, out, ids, extract=False):
+    """cleaner.rs:731-760 FastqCleaner::clean_reads; returns (records_in, records_out)."""
+    arr = (C.c_char_p * max(len(ids), 1))(*[i.encode() for i in ids])
+    n_in, n_out = C.c_uint64(), C.c_uint64()
+    check(load().sh_host_filter_fastx(os.fsencode(inp), os.fsencode(out), arr, len(ids), int(extract), C.byref(n_in), C.byref(n_out)))
+    return n_in.value, n_out.value
+
+
+def read_difference(inputs, outputs):
+    """utils.rs:250-285 ReadDifference::get_difference; returns (reads_in, reads_out, difference)."""
+    n = len(inputs)
+    a = (C.c_char_p * n)(*[os.fsencode(p) for p in inputs])
+    b = (C.c_char_p * n)(*[os.fsencode(p) for p in outputs])
+    r = [C.c_uint64(), C.c_uint64(), C.c_uint64()]
+    check(load().sh_host_read_difference(a, b, n, C.byref(r[0]), C.byref(r[1]), C.byref(r[2])))
+    return tuple(x.value for x in r)
+
+
+def reads_run(inputs, outputs, index, preset=None, extract=False, json=None, read_ids=None, command="", threads=4, device=0):
+    """cleaner.rs:443-575 + clean_reads + ScrubbyReport: the whole `scrubby reads` mm2 path on the GPU."""
+    require_gpu()
+    c = ReadsConfig()
+    for i, (a, b) in enumerate(zip(inputs, outputs)):
+        c.input[i] = os.fsencode(a)
+        c.output[i] = os.fsencode(b)
+    c.n_files, c.extract, c.index = len(inputs), int(extract), os.fsencode(index)
+    c.preset = preset.encode() if preset else None
+    c.json = os.fsencode(json) if json else None
+    c.read_ids = os.fsencode(read_ids) if read_ids else None
+    c.command, c.threads, c.device = command.encode(), threads, device
+    r = ReadsResult()
+    check(load().sh_reads_run(C.byref(c), C.byref(r)))
+    return {n: getattr(r, n) for n, _ in ReadsResult._fields_}

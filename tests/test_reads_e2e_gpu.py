@@ -1,0 +1,102 @@
+"""BASELINE.json configs[0] end to end on the GPU: `scrubby reads` over 10k synthetic 2x150 bp pairs vs the 5 Mb
+mini reference, through sh_reads_run (C ABI) and the scrubby-hip CLI.  Expected results come from the CPU oracle's
+per-record flags pushed through the reference's ID-set semantics restated in Python (tests/test_host_cpu.py)."""
+import gzip
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import workloads as W
+from tests.test_host_cpu import py_records, py_clean, py_difference
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dataset(oracle, tmp_path_factory):
+    d = tmp_path_factory.mktemp("cfg0")
+    n_pairs = 10000
+    P, R, ref, seqs, reads, off = W.cfg1(oracle, 2 * n_pairs)
+    fa = d / "ref.fa.gz"
+    with gzip.open(fa, "wt") as f:
+        for i, s in enumerate(seqs):
+            f.write(f">ctg{i} synthetic\n")
+            s = bytes(s).decode()
+            for j in range(0, len(s), 60000):
+                f.write(s[j:j + 60000] + "\n")
+    reads = reads.reshape(-1, 150)
+    r1, r2 = d / "R1.fastq", d / "R2.fastq.gz"
+    with open(r1, "w") as f1, gzip.open(r2, "wt") as f2:
+        for p in range(n_pairs):
+            f1.write(f"@syn.{p} 1:N:0:0\n{bytes(reads[2 * p]).decode()}\n+\n{'I' * 150}\n")
+            f2.write(f"@syn.{p} 2:N:0:0\n{bytes(reads[2 * p + 1]).decode()}\n+\n{'I' * 150}\n")
+    idx = oracle.Index.build(seqs, 11, 21)
+    flags, _ = idx.classify(oracle.preset("sr"), reads.reshape(-1), off, threads=8, want_trace=False)
+    ids = {f"syn.{p}" for p in range(n_pairs) if flags[2 * p] == 1 or flags[2 * p + 1] == 1}    # HashSet union (cleaner.rs:564-570)
+    return d, str(fa), str(r1), str(r2), ids, n_pairs
+
+
+def check_outputs(r1, r2, o1, o2, ids, extract):
+    for i, o in ((r1, o1), (r2, o2)):
+        assert py_records(o) == py_clean(py_records(i), ids, extract)
+
+
+def test_reads_run_deplete_with_report(dataset):
+    from scrubby_amd import lib as S
+    d, fa, r1, r2, ids, n_pairs = dataset
+    o1, o2, js, tsv = str(d / "c1.fastq"), str(d / "c2.fastq.gz"), str(d / "report.json"), str(d / "ids.tsv")
+    res = S.reads_run([r1, r2], [o1, o2], fa, json=js, read_ids=tsv, command="scrubby reads -i R1 R2 -o c1 c2 -I ref.fa.gz")
+    check_outputs(r1, r2, o1, o2, ids, False)
+    exp = py_difference([r1, r2], [o1, o2])
+    assert (res["reads_in"], res["reads_out"], res["reads_removed"], res["reads_extracted"]) == (exp[0], exp[1], exp[2], 0)
+    assert res["reads_in"] == 2 * n_pairs and res["reads_removed"] == 2 * len(ids) and res["n_depleted_ids"] == len(ids)
+    rep = json.load(open(js))
+    assert list(rep.keys()) == ["version", "date", "command", "input", "output", "reads_in", "reads_out", "reads_removed",
+                                "reads_extracted", "settings"]                       # report.rs:10-22, struct order
+    assert list(rep["settings"].keys()) == ["aligner", "classifier", "index", "alignment", "reads", "report", "taxa", "taxa_direct",
+                                            "classifier_args", "aligner_args", "preset", "min_len", "min_cov", "min_mapq", "extract"]
+    assert rep["settings"]["aligner"] == "minimap2-rs" and rep["settings"]["preset"] == "Sr" and rep["settings"]["extract"] is False
+    assert rep["reads_removed"] == 2 * len(ids) and rep["input"] == [r1, r2] and rep["date"].endswith("Z")
+    got_ids = open(tsv).read().split("\n")
+    assert got_ids[0] == "id" and set(x for x in got_ids[1:] if x) == ids
+
+
+def test_reads_run_extract_and_single_end(dataset):
+    from scrubby_amd import lib as S
+    d, fa, r1, r2, ids, n_pairs = dataset
+    o1, o2, js = str(d / "e1.fastq.gz"), str(d / "e2.fastq"), str(d / "e.json")
+    res = S.reads_run([r1, r2], [o1, o2], fa, preset="sr", extract=True, json=js)
+    check_outputs(r1, r2, o1, o2, ids, True)
+    assert res["reads_extracted"] == 2 * (n_pairs - len(ids)) and res["reads_removed"] == 0     # `difference` = records not in the output
+    # one input file: the reference defaults to map-ont (scrubby.rs:941-942); sr given explicitly keeps the decision per record
+    s1 = str(d / "s1.fastq")
+    res = S.reads_run([r1], [s1], fa, preset="sr", json=str(d / "s.json"))
+    assert json.load(open(d / "s.json"))["reads_in"] == n_pairs
+    assert res["reads_out"] == len(py_records(s1))
+
+
+def test_cli_matches_library(dataset):
+    d, fa, r1, r2, ids, n_pairs = dataset
+    exe = os.path.join(ROOT, "scrubby_amd", "scrubby-hip")
+    o1, o2, js = str(d / "k1.fastq"), str(d / "k2.fastq"), str(d / "k.json")
+    cp = subprocess.run([exe, "reads", "-i", r1, r2, "-o", o1, o2, "-I", fa, "-j", js, "-t", "8"], capture_output=True, text=True)
+    assert cp.returncode == 0, cp.stderr
+    check_outputs(r1, r2, o1, o2, ids, False)
+    rep = json.load(open(js))
+    assert rep["reads_removed"] == 2 * len(ids) and rep["command"].startswith(exe + " reads -i")
+    assert subprocess.run([exe, "reads", "-i", r1, "-o", o1, "-I", fa, "-p", "lr"], capture_output=True).returncode == 1   # Preset::Lr rejected
+    assert subprocess.run([exe, "reads", "-i", r1, "-o", o1, "-I", fa, "-a", "bowtie2"], capture_output=True).returncode == 2
+
+
+def test_index_cache_in_reads_run(dataset):
+    from scrubby_amd import lib as S
+    d, fa, r1, r2, ids, n_pairs = dataset
+    cache = str(d / "ref.shidx")
+    S.Index.build_fasta(fa, S.preset("sr")).save(cache)
+    o1, o2 = str(d / "x1.fastq"), str(d / "x2.fastq")
+    res = S.reads_run([r1, r2], [o1, o2], cache, json=str(d / "x.json"))
+    assert res["reads_removed"] == 2 * len(ids)
