@@ -488,6 +488,119 @@ struct SliceStore {
     __device__ inline void clearAux(int32_t n) { clearT(n); }
 };
 
+// ---- wave-cooperative DP: all 64 lanes work on ONE cluster ---------------------------------------------------------
+// mg_lchain_dp scans the predecessors j = i-1 .. st of anchor i sequentially, with a running maximum, the
+// max_skip counter and the t[] marks.  Here the 64 lanes evaluate 64 predecessors at once and the sequential
+// semantics are reproduced exactly with wave scans:
+//   * "sc > running max"  = comparison against an exclusive prefix maximum in scan order;
+//   * t[j] == i           = "j is the predecessor of an anchor scanned earlier": the marks of a chunk are written
+//                           first, then read; a mark written by a lane past the break point can only concern
+//                           anchors that are themselves past the break point, so over-marking is harmless;
+//   * n_skip (saturating decrement on a new maximum, increment on a marked non-maximum, break above max_skip)
+//                         = prefix composition of functions x -> max(x + a, b), which is closed under composition.
+// The critical path of a 20-anchor cluster drops from ~190 dependent pair evaluations to 20 wave steps.
+__device__ inline void wave_mem_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+__device__ inline void chain_dp_wave(const SliceStore &S, int n, int32_t qlen, const ChainParams &P, uint32_t lane)
+{
+    int32_t max_dist_y = P.is_sr ? (qlen > P.max_gap ? qlen : P.max_gap) : P.max_gap;
+    int32_t max_dist_x;
+    if (P.max_gap_ref > 0) max_dist_x = P.max_gap_ref;
+    else if (P.max_frag_len > 0) { max_dist_x = P.max_frag_len - qlen; if (max_dist_x < P.max_gap) max_dist_x = P.max_gap; }
+    else max_dist_x = P.max_gap;
+    if (max_dist_x < P.bw) max_dist_x = P.bw;
+    if (max_dist_y < P.bw) max_dist_y = P.bw;
+    volatile const uint64_t *x = S.x; volatile const uint32_t *q = S.q; volatile int32_t *f = S.f; volatile int32_t *pt = S.pt;
+    const int NEG = -(1 << 28);
+
+    for (int i = (int)lane; i < n; i += 64) pt[2 * i + 1] = 0;
+    wave_mem_sync();
+    int st = 0, max_ii = -1;
+    for (int i = 0; i < n; ++i) {
+        const uint32_t li = (uint32_t)x[i], qi = q[i] & 0x7fffffffu;
+        while (st < i && (uint64_t)li > (uint64_t)(uint32_t)x[st] + (uint64_t)max_dist_x) ++st;
+        if (i - st > P.max_iter) st = i - P.max_iter;
+        int32_t max_f = P.k, n_skip = 0;
+        int max_j = -1, end_j = st - 1;
+        for (int jb = i - 1; jb >= st; jb -= 64) {
+            const int j = jb - (int)lane;
+            const bool valid = j >= st;
+            int32_t sc = SH_SC_NONE, pj = -1;
+            if (valid) {
+                sc = comput_sc(li, qi, (uint32_t)x[j], q[j] & 0x7fffffffu, max_dist_x, max_dist_y, P);
+                if (sc != SH_SC_NONE) { sc += f[j]; pj = pt[2 * j]; }
+            }
+            const bool has = valid && sc != SH_SC_NONE;
+            if (has && pj >= 0) pt[2 * pj + 1] = i;
+            wave_mem_sync();
+            const bool is_t = has && pt[2 * j + 1] == i;
+            // exclusive prefix maximum in scan order (lane 0 = j = jb first), seeded with the running max_f
+            int32_t incl = has ? sc : INT32_MIN;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { int32_t t = __shfl_up(incl, o); if ((int)lane >= o) incl = t > incl ? t : incl; }
+            int32_t excl = __shfl_up(incl, 1);
+            if (lane == 0) excl = INT32_MIN;
+            if (excl < max_f) excl = max_f;
+            const bool new_max = has && sc > excl;
+            const bool inc_ev = has && !new_max && is_t;
+            // n_skip after each lane: inclusive prefix composition of x -> max(x + a, b)
+            int32_t ca = new_max ? -1 : (inc_ev ? 1 : 0), cb = new_max ? 0 : NEG;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                int32_t pa = __shfl_up(ca, o), pb = __shfl_up(cb, o);
+                if ((int)lane >= o) { int32_t nb = pb + ca > cb ? pb + ca : cb; ca = pa + ca; cb = nb; }
+            }
+            const int32_t val = n_skip + ca > cb ? n_skip + ca : cb;
+            const uint64_t brk = __ballot(inc_ev && val > P.max_skip);
+            const int L = brk ? __ffsll((unsigned long long)brk) - 1 : 63;
+            const bool act = (int)lane <= L && has;
+            int32_t mm = act ? sc : INT32_MIN;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { int32_t t = __shfl_xor(mm, o); mm = t > mm ? t : mm; }
+            if (mm > max_f) {
+                max_f = mm;
+                const uint64_t eq = __ballot(act && sc == mm);
+                max_j = jb - (__ffsll((unsigned long long)eq) - 1);
+            }
+            n_skip = __shfl(val, L);
+            if (brk) { end_j = jb - L; break; }
+        }
+        // the max_ii shortcut (uniform)
+        bool far = true;
+        if (max_ii >= 0) far = (uint64_t)(li - (uint32_t)x[max_ii]) > (uint64_t)max_dist_x;
+        if (max_ii < 0 || far) {
+            int32_t bf = INT32_MIN; int bj = -1;
+            for (int jb = i - 1; jb >= st; jb -= 64) {
+                const int j = jb - (int)lane;
+                int32_t fj = j >= st ? f[j] : INT32_MIN;
+                int32_t cm = fj;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { int32_t t = __shfl_xor(cm, o); cm = t > cm ? t : cm; }
+                if (cm > bf) { bf = cm; bj = jb - (__ffsll((unsigned long long)__ballot(j >= st && fj == cm)) - 1); }
+            }
+            max_ii = bj;
+        }
+        if (max_ii >= 0 && max_ii < end_j) {
+            int32_t tmp = comput_sc(li, qi, (uint32_t)x[max_ii], q[max_ii] & 0x7fffffffu, max_dist_x, max_dist_y, P);
+            if (tmp != SH_SC_NONE && max_f < tmp + f[max_ii]) { max_f = tmp + f[max_ii]; max_j = max_ii; }
+        }
+        if (lane == 0) { f[i] = max_f; pt[2 * i] = max_j; }
+        wave_mem_sync();
+        bool near = false;
+        if (max_ii >= 0) near = (uint64_t)(li - (uint32_t)x[max_ii]) <= (uint64_t)max_dist_x;
+        if (max_ii < 0 || (near && f[max_ii] < max_f)) max_ii = i;
+    }
+}
+
+// one cluster, the whole wave: DP in parallel, backtrack executed uniformly by every lane
+__device__ inline void chain_cluster_wave(SliceStore &S, int32_t n, int32_t qlen, const ChainParams &P, uint64_t *zbuf, int32_t &n_u, int32_t &best,
+                                          bool first_only, uint32_t lane)
+{
+    chain_dp_wave(S, n, qlen, P, lane);
+    if (n <= 64) backtrack_mask(S, n, P, n_u, best, first_only);
+    else { backtrack_heap<SliceStore, int32_t>(S, n, P, zbuf, n_u, best, first_only); wave_mem_sync(); }
+}
+
 // DP + backtrack of one cluster.  zbuf: n 8-B words for the heap when n > 32 (may alias the x slice: the
 // anchors are dead once the DP is done).
 __device__ inline void chain_cluster(SliceStore &S, int32_t n, int32_t qlen, const ChainParams &P, uint64_t *zbuf, int32_t &n_u, int32_t &best,

@@ -55,7 +55,7 @@ __device__ inline uint32_t lane_id() { return threadIdx.x & 63; }
 // by whole chunks per wave (WaveAlloc) and statistics are sharded over 64 addresses.
 struct Counters {
     uint32_t n_small, n_resketch, n_big[2], n_big_defer[2], n_defer, pad0;
-    uint32_t n_sort[N_SORT_CLS], n_giant_tiles, pad1;
+    uint32_t n_sort[N_SORT_CLS], n_giant_tiles, n_giant_rounds;
     unsigned long long arena_cursor, anchor_cursor;
     unsigned long long sh_mini[64], sh_anchors[64];     // sharded sums
     uint32_t sh_host[64], sh_clusters[64];
@@ -449,48 +449,67 @@ __device__ inline uint32_t chain_max_dist_x(const ChainParams &P, int32_t qlen)
     return (uint32_t)m;
 }
 
-// Chains every cluster of a sorted anchor array x[0..n) / q[0..n), one lane per cluster start.
-// f / pt: DP state arrays of n (2n) int32.  Returns this thread's (chains, best score, clusters).
-// `found`: block-shared flag for the flag-only early exit (nullptr: chain everything).
-// Phase A marks cluster starts in bit 31 of q (read-only afterwards), so that in phase B a cluster's owner may
-// recycle its x slice as heap space while other lanes are still measuring their clusters.  All threads call.
-// CONTIG: each thread owns a contiguous range of anchors (HBM: one miss per cache line) instead of a strided one.
+// Chains every cluster of a sorted anchor array x[0..n) / q[0..n).  f / pt: DP state arrays of n (2n) int32.
+// Returns this thread's (chains, best score, clusters).  `found`: block-shared flag of the flag-only early exit
+// (nullptr: chain everything).  All threads of the block call.
+//   phase A  cluster starts marked in bit 31 of q (read-only afterwards, so a cluster's owner may recycle its x
+//            slice as heap space while other lanes are still measuring their clusters);
+//   sweep 0  one lane per cluster start: clusters of <= 6 anchors are chained by their lane (register-mask DP);
+//            larger ones are queued in LDS;
+//   sweep 1  the queued clusters, one WAVE per cluster (chain_dp_wave).
+// The per-read result is a sum / max over clusters, so the order is free; in flag-only mode a read that found a
+// chain in a small cluster never touches its big ones (the true-locus cluster, dense tandem arrays).
+struct BigList { uint32_t *start, *len; int32_t *count; uint32_t cap; };
+
 template <bool CONTIG, class PX, class PQ>
 __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_t n, uint32_t tid, uint32_t nthr, int32_t qlen,
-                                    const ChainParams &P, volatile int32_t *found, int32_t &n_u_thr, int32_t &best_thr, uint32_t &n_cl_thr)
+                                    const ChainParams &P, volatile int32_t *found, BigList bl,
+                                    int32_t &n_u_thr, int32_t &best_thr, uint32_t &n_cl_thr)
 {
     const uint32_t mdx = chain_max_dist_x(P, qlen);
     const bool keep_single = !(P.k < P.min_sc || P.min_cnt > 1);
     const uint32_t per = CONTIG ? (n + nthr - 1) / nthr : 1;
     const uint32_t i_beg = CONTIG ? tid * per : tid, i_step = CONTIG ? 1 : nthr;
     const uint32_t i_end = CONTIG ? (i_beg + per < n ? i_beg + per : n) : n;
+    if (tid == 0) *bl.count = 0;
     for (uint32_t i = tid; i < n; i += nthr) {
         bool start = i == 0;
         if (!start) { const uint64_t xi = x[i], xp = x[i - 1]; start = (uint32_t)(xi >> 32) != (uint32_t)(xp >> 32) || (uint32_t)xi - (uint32_t)xp > mdx; }
         if (start) q[i] |= 0x80000000u;
     }
     __syncthreads();
-    // Three sweeps by cluster size (<= 6, <= 64 with the register-mask DP, larger).  The per-read result is a
-    // sum / max over clusters, so the order is free; in flag-only mode a read that found a chain in a small
-    // cluster never touches its big ones (the true-locus cluster, dense tandem arrays).
-    for (int sweep = 0; sweep < 3; ++sweep) {
-        for (uint32_t i = i_beg; i < i_end; i += i_step) {
-            if (found && *found) break;            // flag-only: the read is decided
-            if (!(q[i] >> 31)) continue;
-            uint32_t j = i + 1;
-            while (j < n && !(q[j] >> 31)) ++j;
-            const uint32_t len = j - i;
-            if ((len <= 6 ? 0 : (len <= 64 ? 1 : 2)) != sweep) continue;
-            if (len < 2 && !keep_single) continue;
-            if (found && *found) continue;
-            SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i};
-            int32_t n_u, best;
-            chain_cluster(S, (int32_t)len, qlen, P, (uint64_t *)&x[i], n_u, best, found != nullptr);
+    for (uint32_t i = i_beg; i < i_end; i += i_step) {
+        if (found && *found) break;            // flag-only: the read is decided
+        if (!(q[i] >> 31)) continue;
+        uint32_t j = i + 1;
+        while (j < n && !(q[j] >> 31)) ++j;
+        const uint32_t len = j - i;
+        if (len < 2 && !keep_single) continue;
+        if (len > (CONTIG ? 64u : 6u)) {      // arena path: only clusters beyond the register-mask DP go wave-wide
+            const int32_t slot = atomicAdd(bl.count, 1);
+            if ((uint32_t)slot < bl.cap) { bl.start[slot] = i; bl.len[slot] = len; continue; }
+        }
+        SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i};
+        int32_t n_u, best;
+        chain_cluster(S, (int32_t)len, qlen, P, (uint64_t *)&x[i], n_u, best, found != nullptr);
+        ++n_cl_thr;
+        if (n_u > 0) { n_u_thr += n_u; if (best > best_thr) best_thr = best; if (found) *found = 1; }
+    }
+    __syncthreads();
+    const uint32_t n_big = (uint32_t)*bl.count < bl.cap ? (uint32_t)*bl.count : bl.cap;
+    const uint32_t wave = tid >> 6, n_wave = nthr >> 6, lane = tid & 63;
+    for (uint32_t b = wave; b < n_big; b += n_wave) {
+        if (found && *found) break;
+        const uint32_t i = bl.start[b], len = bl.len[b];
+        SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i};
+        int32_t n_u, best;
+        chain_cluster_wave(S, (int32_t)len, qlen, P, (uint64_t *)&x[i], n_u, best, found != nullptr, lane);
+        if (lane == 0) {
             ++n_cl_thr;
             if (n_u > 0) { n_u_thr += n_u; if (best > best_thr) best_thr = best; if (found) *found = 1; }
         }
-        __syncthreads();
     }
+    __syncthreads();
 }
 
 struct K3Args {
@@ -521,7 +540,8 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
     unsigned long long anchors_wave = 0, a_cur = 0, a_end = 0;      // wave-local slice of the anchor arena
     __shared__ uint64_t e_x[64];
     __shared__ uint32_t e_q[64];
-    __shared__ int32_t e_f[64], e_pt[128];
+    __shared__ int32_t e_f[64], e_pt[128], e_bcount;
+    __shared__ uint32_t e_bstart[8], e_blen[8];
     for (uint32_t w = blockIdx.x; w < n_items; w += gridDim.x) {
         const uint32_t r = a.list[w];
         const uint32_t info = a.k1info[r];
@@ -678,7 +698,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
                 __syncthreads();
             }
             int32_t n_u = 0, best = 0;
-            chain_sorted<false>(e_x, e_q, e_f, e_pt, n_a, lane, 64, qlen, P, nullptr, n_u, best, n_clusters);
+            chain_sorted<false>(e_x, e_q, e_f, e_pt, n_a, lane, 64, qlen, P, nullptr, BigList{e_bstart, e_blen, &e_bcount, 8}, n_u, best, n_clusters);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { n_u += __shfl_xor(n_u, o); int32_t b = __shfl_xor(best, o); best = b > best ? b : best; }
             if (lane == 0) { a.B.acc_nu[w] = n_u; a.B.acc_best[w] = best; }
@@ -764,7 +784,8 @@ __global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
 {
     __shared__ uint64_t s_x[2][NMAX];
     __shared__ uint32_t s_q[2][NMAX];
-    __shared__ int32_t s_found, s_red[2];
+    __shared__ int32_t s_found, s_red[2], s_bcount;
+    __shared__ uint32_t s_bstart[NMAX / 7 + 1], s_blen[NMAX / 7 + 1];
     const uint32_t tid = threadIdx.x;
     const uint32_t n_items = a.ctr->n_sort[CLS];
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
@@ -780,7 +801,8 @@ __global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
         int32_t *f = (int32_t *)(fl ? s_q[0] : s_q[1]), *pt = (int32_t *)(fl ? s_x[0] : s_x[1]);
         int32_t n_u = 0, best = 0; uint32_t n_cl = 0;
         if (!(a.dbg & 1))
-        chain_sorted<false>(rx, rq, f, pt, n, tid, NTHR, (int32_t)si.qlen, a.P, a.flag_only ? &s_found : nullptr, n_u, best, n_cl);
+        chain_sorted<false>(rx, rq, f, pt, n, tid, NTHR, (int32_t)si.qlen, a.P, a.flag_only ? &s_found : nullptr,
+                            BigList{s_bstart, s_blen, &s_bcount, NMAX / 7 + 1}, n_u, best, n_cl);
         store_read_result(a, si.w, n_u, best, n_cl, s_red);
         __syncthreads();
     }
@@ -807,15 +829,19 @@ __device__ inline uint32_t giant_rounds(uint32_t n)
 __global__ __launch_bounds__(64) void k_giant_scan(K3Args a)
 {
     const uint32_t lane = threadIdx.x, n_items = a.ctr->n_sort[3];
-    uint32_t run = 0;
+    uint32_t run = 0, max_n = 0;
     for (uint32_t base = 0; base < n_items; base += 64) {
         const uint32_t i = base + lane;
-        const uint32_t t = i < n_items ? (a.B.sort_items[3][i].n + GT - 1) / GT : 0;
+        const uint32_t n_i = i < n_items ? a.B.sort_items[3][i].n : 0;
+        max_n = n_i > max_n ? n_i : max_n;
+        const uint32_t t = (n_i + GT - 1) / GT;
         const uint32_t ex = wave_excl_scan_u32(t, lane);
         if (i < n_items) a.B.tile_base[i] = run + ex;
         run += wave_sum_u32(t);
     }
-    if (lane == 0) { a.B.tile_base[n_items] = run; a.ctr->n_giant_tiles = run; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint32_t v = (uint32_t)__shfl_xor((int)max_n, o); max_n = v > max_n ? v : max_n; }
+    if (lane == 0) { a.B.tile_base[n_items] = run; a.ctr->n_giant_tiles = run; a.ctr->n_giant_rounds = giant_rounds(max_n); }
 }
 
 __device__ inline uint32_t giant_item_of(const uint32_t *tile_base, uint32_t n_items, uint32_t t)
@@ -865,6 +891,7 @@ __device__ inline GiantTile giant_tile(const K3Args &a, uint32_t t, uint32_t n_i
 // split[t] = number of elements the left run contributes before output o0 of tile t
 __global__ __launch_bounds__(256) void k_giant_partition(K3Args a, uint32_t round)
 {
+    if (round >= a.ctr->n_giant_rounds) return;
     const uint32_t n_items = a.ctr->n_sort[3], n_tiles = a.ctr->n_giant_tiles;
     for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < n_tiles; t += gridDim.x * 256) {
         const GiantTile g = giant_tile(a, t, n_items, round);
@@ -883,6 +910,7 @@ __global__ __launch_bounds__(256) void k_giant_merge(K3Args a, uint32_t round)
 {
     __shared__ uint64_t s_x[GT];          // [0, la): left range, [la, la+lb): right range; la + lb <= GT
     __shared__ uint32_t s_q[GT];
+    if (round >= a.ctr->n_giant_rounds) return;
     const uint32_t tid = threadIdx.x, n_items = a.ctr->n_sort[3], n_tiles = a.ctr->n_giant_tiles;
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const GiantTile g = giant_tile(a, t, n_items, round);
@@ -921,7 +949,8 @@ __global__ __launch_bounds__(256) void k_giant_merge(K3Args a, uint32_t round)
 // one block per giant read: clusters chained over arena slices of the buffer its sort ended in
 __global__ __launch_bounds__(1024) void k_giant_chain(K3Args a)
 {
-    __shared__ int32_t s_found, s_red[2];
+    __shared__ int32_t s_found, s_red[2], s_bcount;
+    __shared__ uint32_t s_bstart[2048], s_blen[2048];
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const uint32_t n_items = a.ctr->n_sort[3];
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
@@ -934,7 +963,7 @@ __global__ __launch_bounds__(1024) void k_giant_chain(K3Args a)
         int32_t n_u = 0, best = 0; uint32_t n_cl = 0;
         if (!(a.dbg & 2))
         chain_sorted<true>(sx, sq, a.B.af + si.off, (int32_t *)(a.B.az + si.off), n, tid, nthr, (int32_t)si.qlen, a.P,
-                     a.flag_only ? &s_found : nullptr, n_u, best, n_cl);
+                     a.flag_only ? &s_found : nullptr, BigList{s_bstart, s_blen, &s_bcount, 2048}, n_u, best, n_cl);
         store_read_result(a, si.w, n_u, best, n_cl, s_red);
         __syncthreads();
     }
