@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--records", type=int, default=20_000_000, help="records per GPU (2 per pair)")
-    ap.add_argument("--chunk", type=int, default=1 << 22, help="records per kernel launch")
+    ap.add_argument("--chunk", type=int, default=1 << 25, help="records per kernel launch (default: the whole batch in one launch)")
     ap.add_argument("--small", action="store_true", help="5 Mb reference / 200k records (plumbing check)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
