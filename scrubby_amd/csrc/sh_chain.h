@@ -21,6 +21,7 @@ struct ChainParams {
     int32_t max_gap, max_gap_ref, max_frag_len, bw;
     int32_t max_skip, max_iter;
     float pen_gap, pen_skip;
+    float q_occ_frac;
 };
 
 // ---- seeds: one 16-B record per query minimizer found in the index ---------------------------

@@ -119,6 +119,7 @@ struct K1Args {
     uint32_t *k1info; uint8_t *flags; sh_trace *trace;
     uint32_t *work_small, *work_resketch, *work_big; Counters *ctr;
     uint32_t lds_words; int32_t mid_occ;
+    uint32_t q_occ_max;     // reads with more minimizers than this need mm_seed_mz_flt: legacy path (UINT32_MAX: never)
 };
 
 // Slow path of K1: this lane's minimizer queue is full in the middle of a W-step block (tie-heavy,
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
     if (valid) a.k1info[r] = n_mini | n_seed << 16;
     // reads whose seeds need no occurrence filtering and give <= K2_CAP anchors are chained by K2 (lane per read);
     // everything else goes to the repeat path (wave per read)
+    if (n_mini > a.q_occ_max) overflow = 1;
     const bool to_k3 = valid && overflow != 0;
     const bool done = valid && !overflow && n_seed == 0;
     const bool simple = n_high == 0 && sum_occ <= K2_CAP;
@@ -995,10 +997,16 @@ __global__ void k_finalize(K3Args a)
 
 __device__ inline uint8_t *arena_alloc(const K2Args &a, size_t bytes)
 {
+    // compare-and-swap bump: a request that does not fit leaves the cursor alone, so the reads that already hold
+    // their sketch buffers can still get their anchor slices (no allocation deadlock when the arena is short)
     bytes = (bytes + 15) & ~(size_t)15;
-    unsigned long long off = atomicAdd(&a.ctr->arena_cursor, (unsigned long long)bytes);
-    if (off + bytes > a.arena_bytes) return nullptr;
-    return a.arena + off;
+    unsigned long long cur = a.ctr->arena_cursor;
+    for (;;) {
+        if (cur + bytes > a.arena_bytes) return nullptr;
+        unsigned long long prev = atomicCAS(&a.ctr->arena_cursor, cur, cur + (unsigned long long)bytes);
+        if (prev == cur) return a.arena + cur;
+        cur = prev;
+    }
 }
 
 // legacy lane-per-read path (re-sketch of reads K1 could not finish); arrays in the HBM arena
@@ -1018,18 +1026,47 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
             bool defer = false;
             {
                 const size_t cap = 2 * (size_t)qlen + 256;
-                uint8_t *m = arena_alloc(a, cap * 16 + (size_t)a.w * 16);
+                // records (16 B) + minimizers (hash, y: 12 B) + sorted hashes (8 B) per possible minimizer, + the ring
+                uint8_t *m = arena_alloc(a, cap * (16 + 8 + 4 + 8) + (size_t)a.w * 16);
                 if (!m) defer = true;
                 else {
                     uint4 *recs = (uint4 *)m;
-                    uint64_t *rbx = (uint64_t *)(m + cap * 16);
+                    uint64_t *mh = (uint64_t *)(m + cap * 16), *hs = mh + cap;
+                    uint32_t *my = (uint32_t *)(hs + cap);
+                    uint64_t *rbx = (uint64_t *)(my + cap);
                     uint32_t *rby = (uint32_t *)(rbx + a.w);
                     SketchStateDyn st;
                     st.init(rbx, rby, a.w, a.P.k);
+                    int32_t nm = 0;
+                    auto emit = [&](uint64_t x, uint32_t y) { mh[nm] = x >> 8; my[nm] = y; ++nm; };
+                    for (int32_t i = 0; i < qlen; ++i) st.step(sh_nt4(a.bases[o_beg + i]), (uint32_t)i, emit);
+                    if (qlen > 0) st.finish(emit);
+                    // mm_seed_mz_flt: drop minimizers whose hash repeats within the query more than
+                    // q_occ_max (= mid_occ) times and more than q_occ_frac of all minimizers
+                    bool thin = a.P.q_occ_frac > 0.0f && a.P.mid_occ > 0 && nm > a.P.mid_occ;
+                    if (thin) {
+                        for (int32_t i = 0; i < nm; ++i) hs[i] = mh[i];
+                        auto down = [&](int32_t i, int32_t mlen) {
+                            uint64_t tmp = hs[i]; int32_t kk = i;
+                            while ((kk = (kk << 1) + 1) < mlen) { if (kk != mlen - 1 && hs[kk] < hs[kk + 1]) ++kk; if (hs[kk] < tmp) break; hs[i] = hs[kk]; i = kk; }
+                            hs[i] = tmp;
+                        };
+                        for (int32_t i = (nm >> 1) - 1; i >= 0; --i) down(i, nm);
+                        for (int32_t e = nm - 1; e > 0; --e) { uint64_t t0 = hs[0]; hs[0] = hs[e]; hs[e] = t0; down(0, e); }
+                    }
                     const uint64_t slot_mask = (1ULL << a.lg_slots) - 1;
-                    auto emit = [&](uint64_t x, uint32_t y) {
+                    for (int32_t i = 0; i < nm; ++i) {
+                        const uint64_t key = mh[i];
+                        if (thin) {     // occurrences of this hash in the query, from the sorted copy
+                            int32_t lo = 0, hi = nm;
+                            while (lo < hi) { int32_t mid = (lo + hi) >> 1; if (hs[mid] < key) lo = mid + 1; else hi = mid; }
+                            int32_t lb = lo; hi = nm;
+                            while (lo < hi) { int32_t mid = (lo + hi) >> 1; if (hs[mid] <= key) lo = mid + 1; else hi = mid; }
+                            const int32_t cnt = lo - lb;
+                            if (cnt > a.P.mid_occ && (float)cnt > (float)nm * a.P.q_occ_frac) continue;
+                        }
                         ++n_mini;
-                        uint64_t key = x >> 8, idx = sh_slot_home(key, a.lg_slots);
+                        uint64_t idx = sh_slot_home(key, a.lg_slots);
                         uint4 s = a.slots[idx];
                         uint64_t w0 = (uint64_t)s.y << 32 | s.x;
                         while (w0 != SH_SLOT_EMPTY && (w0 & SH_SLOT_KEYMASK) != key) {
@@ -1037,11 +1074,9 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
                         }
                         if (w0 != SH_SLOT_EMPTY) {
                             uint32_t occ = (w0 & SH_SLOT_MULTI) ? (s.z & (uint32_t)SH_SLOT_NMASK) : 1u;
-                            recs[n_seed++] = make_uint4(s.z, s.w, occ, y);
+                            recs[n_seed++] = make_uint4(s.z, s.w, occ, my[i]);
                         }
-                    };
-                    for (int32_t i = 0; i < qlen; ++i) st.step(sh_nt4(a.bases[o_beg + i]), (uint32_t)i, emit);
-                    if (qlen > 0) st.finish(emit);
+                    }
                     sv.base = recs; sv.stride = 1; sv.n = (uint32_t)n_seed;
                 }
             }
@@ -1111,6 +1146,7 @@ static void fill_chain_params(const sh_opts &o, int32_t mid_occ, ChainParams &P)
     P.max_skip = o.max_chain_skip; P.max_iter = o.max_chain_iter;
     P.pen_gap = (float)(o.chain_gap_scale * 0.01 * o.k);
     P.pen_skip = (float)(o.chain_skip_scale * 0.01 * o.k);
+    P.q_occ_frac = o.q_occ_frac;
 }
 
 static bool w_supported(int w) { return w == 5 || w == 10 || w == 11 || w == 19; }
@@ -1251,6 +1287,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         a.k1info = c->d_k1info; a.flags = d_flags; a.trace = d_trace;
         a.work_small = c->d_work_small; a.work_resketch = c->d_work_resketch; a.work_big = c->d_big[0][0]; a.ctr = c->d_ctr;
         a.lds_words = c->lds_words; a.mid_occ = c->P.mid_occ;
+        a.q_occ_max = (c->P.q_occ_frac > 0.0f && c->P.mid_occ > 0) ? (uint32_t)c->P.mid_occ : UINT32_MAX;
         size_t lds = (size_t)K1_LIST_CAP * 64 * 8 + ((size_t)c->lds_words + 2) * 4 + (((size_t)c->lds_words + 2) * 2 + 3) / 4 * 4;
         switch (idx->w) {
         case 5: launch_k1<5>(a, n_tiles, lds, s); break;

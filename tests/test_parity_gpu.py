@@ -186,3 +186,46 @@ def test_index_save_load_roundtrip(S, cfg1, gpu_index, tmp_path):
     f1, t1, _, _ = gpu_index.classify(reads[: n * 150], off[: n + 1], want_trace=True)
     f2, t2, _, _ = idx2.classify(reads[: n * 150], off[: n + 1], want_trace=True)
     assert np.array_equal(f1, f2) and np.array_equal(t1, t2)
+
+
+def _ont_like_reads(ref, n, seed, min_len=1200, max_len=30000):
+    """Long noisy reads: log-normal lengths, 2 % substitutions, 1.5 % insertions, 1.5 % deletions, either strand."""
+    rng = np.random.default_rng(seed)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    acgt = b"ACGT"
+    recs = []
+    for i in range(n):
+        L = int(min(max(rng.lognormal(8.0, 0.7), min_len), max_len))
+        if i % 5 == 4:                                     # unrelated read
+            recs.append(bytes(np.frombuffer(acgt, dtype=np.uint8)[rng.integers(0, 4, L)]))
+            continue
+        s = int(rng.integers(0, 1_000_000 - L))
+        src = bytes(ref[s:s + L])
+        out = bytearray()
+        for c in src:
+            u = rng.random()
+            if u < 0.015:
+                continue
+            if u < 0.03:
+                out.append(acgt[rng.integers(0, 4)])
+            out.append(acgt[rng.integers(0, 4)] if u > 0.98 else c)
+        b = bytes(out)
+        recs.append(b.translate(comp)[::-1] if i % 2 else b)
+    bases = np.frombuffer(b"".join(recs), dtype=np.uint8)
+    offs = np.zeros(len(recs) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(x) for x in recs])
+    return recs, bases, offs
+
+
+def test_long_reads_map_ont(S, oracle, cfg1):
+    """BASELINE config 4 in miniature: noisy multi-kb reads, map-ont preset (k=15, w=10, mid_occ from the index)."""
+    P, R, ref, seqs, reads, off = cfg1
+    go = S.preset("map-ont")
+    gidx = S.Index.build([bytes(s) for s in seqs], go)
+    cidx = oracle.Index.build(seqs, 10, 15)
+    oo = cidx.update_opts(oracle.preset("map-ont"))
+    recs, bases, offs = _ont_like_reads(ref, 60, 42)
+    gf, gt, st, rc = gidx.classify(bases, offs, want_trace=True)
+    of, ot = cidx.classify(oo, bases, offs, threads=8)
+    assert_trace_equal(S, gf, gt, of, ot)
+    assert int(gf.sum()) == 48 and int(gf[4::5].sum()) == 0      # every reference-derived read maps, no random one does
