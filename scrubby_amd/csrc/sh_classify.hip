@@ -139,7 +139,7 @@ __device__ __noinline__ void k1_lane_flush(const uint64_t *list, uint32_t lane, 
         while (w0 != SH_SLOT_EMPTY && (w0 & SH_SLOT_KEYMASK) != key) { idx = (idx + 1) & slot_mask; sl = slots[idx]; w0 = (uint64_t)sl.y << 32 | sl.x; }
         if (w0 != SH_SLOT_EMPTY) {
             uint32_t occ = (w0 & SH_SLOT_MULTI) ? (sl.z & (uint32_t)SH_SLOT_NMASK) : 1u;
-            if (n_seed < seed_cap) rec[(size_t)n_seed * 64] = make_uint4(sl.z, sl.w, occ, (uint32_t)m & 0x3ffffu);
+            if (n_seed < seed_cap) rec[n_seed] = make_uint4(sl.z, sl.w, occ, (uint32_t)m & 0x3ffffu);
             else *overflow_io = 1;
             ++n_seed;
             *sum_occ_io = *sum_occ_io + occ < *sum_occ_io ? 0xffffffffu : *sum_occ_io + occ;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
 
     uint32_t cnt = 0, n_mini = 0, n_seed = 0, overflow = 0, sum_occ = 0, n_high = 0;
     const uint64_t slot_mask = (1ULL << a.lg_slots) - 1;
-    uint4 *rec = a.records + (size_t)tile * a.seed_cap * 64 + lane;
+    uint4 *rec = a.records + (size_t)(valid ? r : 0) * a.seed_cap;      // per-read contiguous seed records
     auto emit = [&](uint64_t x, uint32_t y) {
         if (cnt >= K1_LIST_CAP) { k1_lane_flush(list, lane, cnt, a.slots, a.lg_slots, rec, a.seed_cap, &n_seed, &overflow, &sum_occ, &n_high, (uint32_t)a.mid_occ); cnt = 0; }
         list[cnt * 64 + lane] = (x >> 8) << 18 | (uint64_t)y;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
                     }
                     if (w0 != SH_SLOT_EMPTY) {
                         uint32_t occ = (w0 & SH_SLOT_MULTI) ? (s[u].z & (uint32_t)SH_SLOT_NMASK) : 1u;
-                        if (n_seed < a.seed_cap) rec[(size_t)n_seed * 64] = make_uint4(s[u].z, s[u].w, occ, yq[u]);
+                        if (n_seed < a.seed_cap) rec[n_seed] = make_uint4(s[u].z, s[u].w, occ, yq[u]);
                         else overflow = 1;
                         ++n_seed;
                         sum_occ = sum_occ + occ < sum_occ ? 0xffffffffu : sum_occ + occ;
@@ -391,8 +391,8 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
             const int32_t n_mini = (int32_t)(info & 0xffffu), n_seed = (int32_t)(info >> 16);
             const int32_t qlen = (int32_t)(a.offsets[r + 1] - a.offsets[r]);
             SeedView sv;
-            sv.base = a.records + (size_t)(r >> 6) * a.seed_cap * 64 + (r & 63);
-            sv.stride = 64; sv.n = (uint32_t)n_seed;
+            sv.base = a.records + (size_t)r * a.seed_cap;
+            sv.stride = 1; sv.n = (uint32_t)n_seed;
             // K1 only sends reads here whose seeds all pass the occurrence filter (none above mid_occ) and expand
             // to <= CAP anchors: no filtering, rep_len = 0, never re-chained
             int32_t n_u = 0, best = 0;
@@ -560,12 +560,12 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
             }
             continue;
         }
-        uint4 *recb = a.records + (size_t)(r >> 6) * a.seed_cap * 64 + (r & 63);
+        uint4 *recb = a.records + (size_t)r * a.seed_cap;
         // occurrence filter of seed tile t: my_n = anchors this lane's seed contributes (0 if filtered / absent)
         auto eval = [&](uint32_t t, uint4 &rec, uint32_t &my_n, bool &flt, bool &have) {
             const uint32_t sidx = t * 64 + lane;
             have = sidx < n_seed;
-            rec = have ? recb[(size_t)sidx * 64] : make_uint4(0, 0, 0, 0);
+            rec = have ? recb[sidx] : make_uint4(0, 0, 0, 0);
             const uint32_t occ = rec.z & 0x7fffffffu, qposz = rec.w;
             const bool high = have && occ > (uint32_t)a.max_occ;
             flt = false;
@@ -662,31 +662,37 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
         for (uint32_t t = 0; t < n_st; ++t) {
             uint4 rec = rec0; uint32_t my_n = my_n0; bool flt = flt0, have = have0;
             if (t > 0) eval(t, rec, my_n, flt, have);
-            const uint32_t start = run + wave_excl_scan_u32(my_n, lane);
+            // one lane per ANCHOR: anchor a of this seed tile belongs to the seed s with start[s] <= a < start[s] + my_n[s];
+            // s is found by a 6-step binary search over the lanes' prefix sums, so every position load is independent
+            const uint32_t excl = wave_excl_scan_u32(my_n, lane);
+            const uint32_t tile_total = wave_sum_u32(my_n);
+            const uint32_t incl = excl + my_n;                       // non-decreasing over lanes
             const uint64_t w1 = (uint64_t)rec.y << 32 | rec.x;
-            const bool any_multi = __ballot(my_n > 1) != 0;
-            if (!any_multi) {
-                if (my_n == 1) {
-                    uint64_t x; uint32_t q;
-                    make_anchor(w1, rec.w, qlen, P.k, x, q);
-                    gx[start] = x; gq[start] = q;
+            const uint64_t *__restrict__ pos = a.positions;
+            for (uint32_t a0 = 0; a0 < tile_total; a0 += 64) {
+                const uint32_t ai_raw = a0 + lane;
+                const bool live = ai_raw < tile_total;
+                const uint32_t ai = live ? ai_raw : tile_total - 1;       // every lane takes part in the shuffles
+                uint32_t lo = 0, hi = 63;                                    // first lane with incl > ai
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const uint32_t v = (uint32_t)__shfl((int)incl, (int)mid);
+                    if (v > ai) hi = mid; else lo = mid + 1;
                 }
-            } else {
-                const uint32_t cnt_s = n_seed - t * 64 < 64 ? n_seed - t * 64 : 64;
-                for (uint32_t sdx = 0; sdx < cnt_s; ++sdx) {
-                    const uint32_t os = rdlane(my_n, sdx);
-                    if (os == 0) continue;
-                    const uint32_t ss = rdlane(start, sdx), sq = rdlane(rec.w, sdx);
-                    const uint64_t sw1 = (uint64_t)rdlane((uint32_t)(w1 >> 32), sdx) << 32 | rdlane((uint32_t)w1, sdx);
-                    const uint64_t *cr = a.positions + (sw1 >> SH_SLOT_NBITS);
-                    for (uint32_t u = lane; u < os; u += 64) {
-                        uint64_t x; uint32_t q;
-                        make_anchor(os == 1 ? sw1 : cr[u], sq, qlen, P.k, x, q);
-                        gx[ss + u] = x; gq[ss + u] = q;
-                    }
+                const uint32_t sdx = lo;
+                const uint32_t s_ex = (uint32_t)__shfl((int)excl, (int)sdx), s_n = (uint32_t)__shfl((int)my_n, (int)sdx);
+                const uint32_t s_q = (uint32_t)__shfl((int)rec.w, (int)sdx);
+                const uint64_t s_w1 = (uint64_t)(uint32_t)__shfl((int)(uint32_t)(w1 >> 32), (int)sdx) << 32 | (uint32_t)__shfl((int)(uint32_t)w1, (int)sdx);
+                if (live) {
+                    const uint32_t u = ai - s_ex;
+                    const uint64_t rpos = s_n == 1 ? s_w1 : pos[(s_w1 >> SH_SLOT_NBITS) + u];
+                    uint64_t x; uint32_t q;
+                    make_anchor(rpos, s_q, qlen, P.k, x, q);
+                    gx[run + ai] = x; gq[run + ai] = q;
                 }
             }
-            run += wave_sum_u32(my_n);
+            run += tile_total;
         }
         __syncthreads();
         if (in_lds) {
@@ -1174,7 +1180,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         return e == hipErrorOutOfMemory ? SH_ERR_OOM : SH_ERR_HIP;
     };
     hipError_t e;
-    if ((e = hipMalloc(&c->d_records, n_tiles * c->seed_cap * 64 * sizeof(uint4))) != hipSuccess) return fail(e, "records");
+    if ((e = hipMalloc(&c->d_records, (n_tiles * 64) * c->seed_cap * sizeof(uint4))) != hipSuccess) return fail(e, "records");
     if ((e = hipMalloc(&c->d_k1info, max_reads * 4)) != hipSuccess) return fail(e, "k1info");
     if ((e = hipMalloc(&c->d_work_small, max_reads * 4)) != hipSuccess) return fail(e, "work_small");
     if ((e = hipMalloc(&c->d_work_resketch, max_reads * 4)) != hipSuccess) return fail(e, "work_resketch");
