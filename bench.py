@@ -162,8 +162,9 @@ def main():
     if os.path.exists(traffic_file) and not a.small:
         try:
             tj = json.load(open(traffic_file))
-            if tj.get("records_per_launch") == ctx_chunk(a, n_rec):
-                roofline["traffic"] = tj["hbm_bytes_per_launch"]
+            if tj.get("records_per_launch") == ctx_chunk(a, n_rec) and dom in tj.get("stages", {}):
+                roofline["traffic"] = tj["stages"][dom]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, raw)"
         except Exception:
             pass
 

@@ -1,6 +1,6 @@
 """Sum rocprofv3 --pmc counter_collection.csv rows per kernel (classification kernels only)."""
 import csv, glob, sys, collections
-keep = ("k_sketch_probe", "k_chain_small", "k_expand", "k_sort", "k_finalize")
+keep = ("k_sketch_probe", "k_chain_small", "k_expand", "k_sort", "k_finalize", "k_giant", "k_chain_large")
 for d in sys.argv[1:]:
     fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
     if not fs:
