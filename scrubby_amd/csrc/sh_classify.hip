@@ -11,9 +11,10 @@
 //        B  every lane runs the (w,k)-minimizer state machine over its read with the w-entry
 //           window in VGPRs (sh_sketch.h), queueing minimizers in an LDS list;
 //        C  when a list fills (and at the end) the wave probes the HBM hash index for all queued
-//           minimizers, 4 independent 16-B gathers in flight per lane, and writes one 16-B seed
-//           record per hit, lane-interleaved so that the 64 lanes of a tile write one 1-KiB row.
-//        Reads without a single hit are final here (flag 0): no anchor => no mapping.
+//           minimizers, 4 independent 16-B gathers in flight per lane, and appends one 16-B seed
+//           record per hit to the read's own record row.
+//        Reads without a single hit are final here (flag 0): no anchor => no mapping; the others are
+//        routed to K2 (no seed above mid_occ, <= 32 anchors) or to the repeat path.
 //   K2 k_chain_small    one lane per read with >=1 seed: occurrence filter, anchors, chaining DP and
 //        backtrack entirely in LDS (11 B per anchor, lane-interleaved), up to CAP anchors.
 //   K3 the repeat path, for reads with more anchors (29 % of the host reads of the CHM13-sized
