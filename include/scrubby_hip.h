@@ -178,6 +178,32 @@ typedef struct sh_reads_result {
 
 sh_status sh_reads_run(const sh_reads_config *cfg, sh_reads_result *out);
 
+/* ---- `scrubby classifier`: cleaning from precomputed Kraken2 / Metabuli outputs ------------------------------------
+ * Cleaner::run_classifier_output (cleaner.rs:177-194) with the taxid decision rule of src/classifier.rs:
+ * get_taxids_from_report (:124-252), get_tax_level (:345-373), get_taxid_reads_kraken / _metabuli (:270-320).
+ * String / integer logic only: no GPU involved. */
+typedef struct sh_classifier_config {
+    const char *input[2];
+    const char *output[2];
+    uint32_t    n_files;
+    int32_t     extract;
+    const char *report;             /* -k: Kraken-style report */
+    const char *reads;              /* -j: per-read classifications */
+    const char *classifier;         /* -c: "kraken2" | "metabuli" */
+    const char *const *taxa;        /* -T: names or taxids; sub-levels with direct reads are included */
+    uint32_t    n_taxa;
+    const char *const *taxa_direct; /* -D: names or taxids taken as they are */
+    uint32_t    n_taxa_direct;
+    const char *json;               /* --json, nullable */
+    const char *read_ids;           /* -r, nullable */
+    const char *command;
+} sh_classifier_config;
+
+sh_status sh_classifier_run(const sh_classifier_config *cfg, sh_reads_result *out);
+/* the taxid set alone: sorted, newline-separated into `out` */
+sh_status sh_classifier_taxids(const char *report, const char *const *taxa, uint32_t n_taxa, const char *const *taxa_direct,
+                               uint32_t n_direct, char *out, size_t cap, uint64_t *n_out);
+
 /* host-side pieces on their own (no GPU needed): get_id (utils.rs:91-103), FastqCleaner::clean_reads
  * (cleaner.rs:731-760), ReadDifference::get_difference (utils.rs:250-285) */
 sh_status sh_host_get_id(const char *header, char *out, size_t cap);

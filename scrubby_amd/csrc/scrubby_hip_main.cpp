@@ -11,11 +11,59 @@ static void usage()
 {
     fprintf(stderr,
             "scrubby-hip reads -i <R1> [R2] -o <O1> [O2] -I <ref.fa[.gz]|index.shidx> [-p sr|map-ont|lr:hq]\n"
-            "                  [-e] [-j report.json] [-r read_ids.tsv[.gz]] [-t threads] [-a minimap2-rs] [-w workdir]\n");
+            "                  [-e] [-j report.json] [-r read_ids.tsv[.gz]] [-t threads] [-a minimap2-rs] [-w workdir]\n"
+            "scrubby-hip classifier -i <R1> [R2] -o <O1> [O2] -k <report> -j <reads> -c kraken2|metabuli [-T taxa..] [-D taxa..]\n"
+            "                  [-e] [--json report.json] [-r read_ids.tsv]\n");
+}
+
+// `scrubby classifier` (/root/reference/src/terminal.rs:204-279): clean reads from precomputed Kraken2 / Metabuli outputs
+static int main_classifier(int argc, char **argv, const std::string &command)
+{
+    std::vector<std::string> in, out, taxa, direct;
+    std::string report, reads, classifier, json, ids;
+    int extract = 0;
+    for (int i = 2; i < argc; ++i) {
+        std::string a = argv[i];
+        auto val = [&]() -> std::string { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
+        auto multi = [&](std::vector<std::string> &v) { while (i + 1 < argc && argv[i + 1][0] != '-') v.push_back(argv[++i]); };
+        if (a == "-i" || a == "--input") multi(in);
+        else if (a == "-o" || a == "--output") multi(out);
+        else if (a == "-k" || a == "--report") report = val();
+        else if (a == "-j" || a == "--reads") reads = val();          // the reference binds -j to --reads AND --json (App. C Q13): --json has no short here
+        else if (a == "-c" || a == "--classifier") classifier = val();
+        else if (a == "-T" || a == "--taxa") multi(taxa);
+        else if (a == "-D" || a == "--taxa-direct") multi(direct);
+        else if (a == "--json") json = val();
+        else if (a == "-r" || a == "--read-ids") ids = val();
+        else if (a == "-w" || a == "--workdir") val();
+        else if (a == "-e" || a == "--extract") extract = 1;
+        else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    if (in.empty() || in.size() > 2 || in.size() != out.size()) { fprintf(stderr, "error: one or two inputs and as many outputs are required\n"); return 2; }
+    std::vector<const char *> tp, dp;
+    for (auto &t : taxa) tp.push_back(t.c_str());
+    for (auto &t : direct) dp.push_back(t.c_str());
+    sh_classifier_config c{};
+    for (size_t k = 0; k < in.size(); ++k) { c.input[k] = in[k].c_str(); c.output[k] = out[k].c_str(); }
+    c.n_files = (uint32_t)in.size(); c.extract = extract;
+    c.report = report.empty() ? nullptr : report.c_str(); c.reads = reads.empty() ? nullptr : reads.c_str();
+    c.classifier = classifier.empty() ? nullptr : classifier.c_str();
+    c.taxa = tp.data(); c.n_taxa = (uint32_t)tp.size(); c.taxa_direct = dp.data(); c.n_taxa_direct = (uint32_t)dp.size();
+    c.json = json.empty() ? nullptr : json.c_str(); c.read_ids = ids.empty() ? nullptr : ids.c_str(); c.command = command.c_str();
+    sh_reads_result r{};
+    sh_status st = sh_classifier_run(&c, &r);
+    if (st != SH_OK) { fprintf(stderr, "error (%d): %s\n", st, sh_last_error()); return 1; }
+    fprintf(stderr, "[scrubby-hip] read ids selected by taxid: %llu\n", (unsigned long long)r.n_depleted_ids);
+    return 0;
 }
 
 int main(int argc, char **argv)
 {
+    if (argc >= 2 && std::string(argv[1]) == "classifier") {
+        std::string command;
+        for (int i = 0; i < argc; ++i) { if (i) command += ' '; command += argv[i]; }
+        return main_classifier(argc, argv, command);
+    }
     if (argc < 2 || std::string(argv[1]) != "reads") { usage(); return 2; }
     std::vector<std::string> in, out;
     std::string index, preset, json, ids, aligner = "minimap2-rs", command;

@@ -15,6 +15,7 @@
 #include <chrono>
 #include <ctime>
 #include <unordered_set>
+#include <algorithm>
 
 namespace {
 
@@ -220,7 +221,14 @@ extern "C" sh_status sh_host_read_difference(const char *const *inputs, const ch
     return read_difference(inputs, outputs, n, reads_in, reads_out, difference, nullptr);
 }
 
-static sh_status write_report(const sh_reads_config *c, const std::string &preset, const sh_reads_result *r, const char *path)
+struct ReportSettings {       // ScrubbySettings, /root/reference/src/report.rs:71-88 (field order = key order)
+    const char *aligner = nullptr, *classifier = nullptr, *index = nullptr, *reads = nullptr, *report = nullptr, *preset_variant = nullptr;
+    std::vector<std::string> taxa, taxa_direct;
+    bool extract = false;
+};
+
+static sh_status write_report_json(const char *const *input, const char *const *output, uint32_t n_files, const char *command,
+                                   const ReportSettings &st, const sh_reads_result *r, const char *path)
 {
     FILE *f = fopen(path, "wb");
     SH_CHECK(f, SH_ERR_IO, "cannot open %s", path);
@@ -235,28 +243,217 @@ static sh_status write_report(const sh_reads_config *c, const std::string &prese
         o += n ? "\n  ]" : "]";
         return o;
     };
-    const char *pv = preset_variant(preset);
+    auto strs = [&](const std::vector<std::string> &v) {
+        std::string o = "[";
+        for (size_t i = 0; i < v.size(); ++i) { o += i ? ",\n      \"" : "\n      \""; o += json_escape(v[i]); o += "\""; }
+        o += v.empty() ? "]" : "\n    ]";
+        return o;
+    };
+    auto opt = [&](const char *v) { return v ? "\"" + json_escape(v) + "\"" : std::string("null"); };
     std::string o = "{\n";
     o += "  \"version\": \"1.0.2\",\n";                                 // crate_version!() of the reference this drops into
     o += std::string("  \"date\": \"") + date + "\",\n";
-    o += "  \"command\": \"" + json_escape(c->command ? c->command : "") + "\",\n";
-    o += "  \"input\": " + paths(c->input, c->n_files) + ",\n";
-    o += "  \"output\": " + paths(c->output, c->n_files) + ",\n";
+    o += "  \"command\": \"" + json_escape(command ? command : "") + "\",\n";
+    o += "  \"input\": " + paths(input, n_files) + ",\n";
+    o += "  \"output\": " + paths(output, n_files) + ",\n";
     o += "  \"reads_in\": " + std::to_string(r->reads_in) + ",\n";
     o += "  \"reads_out\": " + std::to_string(r->reads_out) + ",\n";
     o += "  \"reads_removed\": " + std::to_string(r->reads_removed) + ",\n";
     o += "  \"reads_extracted\": " + std::to_string(r->reads_extracted) + ",\n";
     o += "  \"settings\": {\n";
-    o += "    \"aligner\": \"minimap2-rs\",\n    \"classifier\": null,\n";
-    o += "    \"index\": \"" + json_escape(c->index) + "\",\n";
-    o += "    \"alignment\": null,\n    \"reads\": null,\n    \"report\": null,\n    \"taxa\": [],\n    \"taxa_direct\": [],\n";
+    o += "    \"aligner\": " + opt(st.aligner) + ",\n    \"classifier\": " + opt(st.classifier) + ",\n";
+    o += "    \"index\": " + opt(st.index) + ",\n";
+    o += "    \"alignment\": null,\n    \"reads\": " + opt(st.reads) + ",\n    \"report\": " + opt(st.report) + ",\n";
+    o += "    \"taxa\": " + strs(st.taxa) + ",\n    \"taxa_direct\": " + strs(st.taxa_direct) + ",\n";
     o += "    \"classifier_args\": null,\n    \"aligner_args\": null,\n";
-    o += std::string("    \"preset\": ") + (pv ? "\"" + std::string(pv) + "\"" : "null") + ",\n";
+    o += "    \"preset\": " + opt(st.preset_variant) + ",\n";
     o += "    \"min_len\": 0,\n    \"min_cov\": 0.0,\n    \"min_mapq\": 0,\n";
-    o += std::string("    \"extract\": ") + (c->extract ? "true" : "false") + "\n  }\n}";
+    o += std::string("    \"extract\": ") + (st.extract ? "true" : "false") + "\n  }\n}";
     fwrite(o.data(), 1, o.size(), f);
     fclose(f);
     return SH_OK;
+}
+
+static sh_status write_report(const sh_reads_config *c, const std::string &preset, const sh_reads_result *r, const char *path)
+{
+    ReportSettings st;
+    st.aligner = "minimap2-rs"; st.index = c->index; st.preset_variant = preset_variant(preset); st.extract = c->extract != 0;
+    return write_report_json(c->input, c->output, c->n_files, c->command, st, r, path);
+}
+
+// after the filter step: counts from re-reading the files, TSV of ids, JSON (ScrubbyReport::create, report.rs:24-57)
+static sh_status finish_report(const char *const *input, const char *const *output, uint32_t n_files, bool extract, const char *json,
+                               const char *read_ids, const char *command, const ReportSettings &st, sh_reads_result *res)
+{
+    if (!json && !read_ids) return SH_OK;
+    std::unordered_set<std::string> diff_ids;
+    uint64_t rin, rout, diff;
+    sh_status s = read_difference(input, output, n_files, &rin, &rout, &diff, &diff_ids);
+    if (s != SH_OK) return s;
+    res->reads_in = rin; res->reads_out = rout;
+    res->reads_removed = extract ? 0 : diff; res->reads_extracted = extract ? diff : 0;
+    if (read_ids) {
+        FastxWriter w(read_ids, 9);
+        SH_CHECK(w.ok(), SH_ERR_IO, "%s", w.error.c_str());
+        w.put("id\n");
+        for (auto &id : diff_ids) w.put(id + "\n");
+    }
+    if (json) return write_report_json(input, output, n_files, command, st, res, json);
+    return SH_OK;
+}
+
+// ---- taxid path: the in-tree decision rule of /root/reference/src/classifier.rs ------------------------------------------
+enum TaxLevel { TL_None, TL_Unclassified, TL_NoRank, TL_Root, TL_Domain, TL_Kingdom, TL_Phylum, TL_Class, TL_Order, TL_Family, TL_Genus, TL_Species, TL_Unspecified };
+
+static TaxLevel tax_level_of(const std::string &s)
+{   // get_tax_level, classifier.rs:345-373: first letter of a Kraken rank code, or Metabuli's lower-case rank words
+    auto sw = [&](const char *p) { return s.compare(0, strlen(p), p) == 0; };
+    if (sw("U")) return TL_Unclassified;
+    if (sw("no rank")) return TL_NoRank;
+    if (sw("R")) return TL_Root;
+    if (sw("D") || sw("superkingdom")) return TL_Domain;
+    if (sw("K") || sw("kingdom")) return TL_Kingdom;
+    if (sw("P") || sw("phylum")) return TL_Phylum;
+    if (sw("C") || sw("class")) return TL_Class;
+    if (sw("O") || sw("order")) return TL_Order;
+    if (sw("F") || sw("family")) return TL_Family;
+    if (sw("G") || sw("genus")) return TL_Genus;
+    if (sw("S") || sw("species")) return TL_Species;
+    return TL_Unspecified;
+}
+
+static std::string trim(const std::string &s)
+{
+    size_t b = 0, e = s.size();
+    while (b < e && isspace((unsigned char)s[b])) ++b;
+    while (e > b && isspace((unsigned char)s[e - 1])) --e;
+    return s.substr(b, e - b);
+}
+
+static std::vector<std::string> split_tab(const std::string &l)
+{
+    std::vector<std::string> f;
+    size_t b = 0;
+    for (;;) { size_t t = l.find('\t', b); f.push_back(l.substr(b, t == std::string::npos ? t : t - b)); if (t == std::string::npos) break; b = t + 1; }
+    return f;
+}
+
+static bool parse_u64_strict(const std::string &s, uint64_t &v)
+{   // Rust str::parse::<u64>: optional '+', digits only, no surrounding white space
+    size_t i = s.size() && s[0] == '+' ? 1 : 0;
+    if (i >= s.size()) return false;
+    v = 0;
+    for (; i < s.size(); ++i) { if (s[i] < '0' || s[i] > '9') return false; v = v * 10 + (uint64_t)(s[i] - '0'); }
+    return true;
+}
+
+static bool read_lines(const char *path, std::vector<std::string> &lines)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    std::string cur; int c;
+    while ((c = fgetc(f)) != EOF) { if (c == '\n') { if (!cur.empty() && cur.back() == '\r') cur.pop_back(); lines.push_back(cur); cur.clear(); } else cur += (char)c; }
+    if (!cur.empty()) lines.push_back(cur);
+    fclose(f);
+    return true;
+}
+
+// get_taxids_from_report, classifier.rs:124-252
+static sh_status taxids_from_report(const char *report, const std::vector<std::string> &taxa_in, const std::vector<std::string> &direct_in,
+                                    std::unordered_set<std::string> &taxids)
+{
+    std::vector<std::string> lines;
+    SH_CHECK(read_lines(report, lines), SH_ERR_IO, "cannot open %s", report);
+    std::vector<std::string> taxa, direct;
+    for (auto &t : taxa_in) taxa.push_back(trim(t));
+    for (auto &t : direct_in) direct.push_back(trim(t));
+    auto has = [](const std::vector<std::string> &v, const std::string &x) { for (auto &e : v) if (e == x) return true; return false; };
+    TaxLevel extract_level = TL_None;
+    std::string extract_parent;
+    for (auto &line : lines) {
+        auto f = split_tab(line);
+        SH_CHECK(f.size() >= 6, SH_ERR_IO, "malformed report line (%zu fields): %s", f.size(), line.c_str());
+        uint64_t reads, reads_direct;
+        SH_CHECK(parse_u64_strict(f[1], reads), SH_ERR_IO, "KrakenReportReadFieldConversion: %s", line.c_str());
+        SH_CHECK(parse_u64_strict(f[2], reads_direct), SH_ERR_IO, "KrakenReportDirectReadFieldConversion: %s", line.c_str());
+        const std::string rank = trim(f[3]), tax_id = trim(f[4]), tax_name = trim(f[5]);
+        const TaxLevel lv = tax_level_of(rank);
+        if (has(direct, tax_name) || has(direct, tax_id)) taxids.insert(tax_id);            // regardless of rank or read count (Q8)
+        if (lv < TL_Domain) continue;                                                       // above Domain: ignored, even inside a window (Q9)
+        if (has(taxa, tax_name) || has(taxa, tax_id)) {
+            extract_level = lv; extract_parent = tax_name;                                  // opens a sub-tree window (Q10)
+            if (reads_direct > 0) taxids.insert(tax_id);
+        } else {
+            if (extract_level == TL_None) continue;
+            if (lv <= extract_level && rank.size() == 1) extract_level = TL_None;           // a single-letter rank at or above closes it
+            else if (reads_direct > 0) {
+                taxids.insert(tax_id);
+                SH_CHECK(!extract_parent.empty(), SH_ERR_IO, "KrakenReportTaxonParent");
+            }
+        }
+    }
+    return SH_OK;
+}
+
+// get_taxid_reads_kraken / _metabuli, classifier.rs:270-320: ids of the reads assigned to one of the taxids
+static sh_status taxid_reads(const std::unordered_set<std::string> &taxids, const char *reads, bool metabuli, std::unordered_set<std::string> &ids)
+{
+    std::vector<std::string> lines;
+    if (!read_lines(reads, lines)) return SH_OK;            // a missing file is an empty set, not an error (Q11)
+    const size_t need = metabuli ? 7 : 5;
+    for (auto &line : lines) {
+        auto f = split_tab(line);
+        SH_CHECK(f.size() >= need, SH_ERR_IO, "malformed read classification line (%zu fields): %s", f.size(), line.c_str());
+        if (taxids.count(trim(f[2]))) ids.insert(trim(f[1]));
+    }
+    return SH_OK;
+}
+
+extern "C" sh_status sh_classifier_taxids(const char *report, const char *const *taxa, uint32_t n_taxa, const char *const *taxa_direct,
+                                          uint32_t n_direct, char *out, size_t cap, uint64_t *n_out)
+{
+    SH_CHECK(report && out && cap && n_out, SH_ERR_BAD_ARG, "sh_classifier_taxids: null argument");
+    std::vector<std::string> t, d;
+    for (uint32_t i = 0; i < n_taxa; ++i) t.push_back(taxa[i]);
+    for (uint32_t i = 0; i < n_direct; ++i) d.push_back(taxa_direct[i]);
+    std::unordered_set<std::string> set;
+    sh_status st = taxids_from_report(report, t, d, set);
+    if (st != SH_OK) return st;
+    std::vector<std::string> v(set.begin(), set.end());
+    std::sort(v.begin(), v.end());
+    std::string joined;
+    for (auto &x : v) { joined += x; joined += '\n'; }
+    SH_CHECK(joined.size() + 1 <= cap, SH_ERR_BAD_ARG, "taxid buffer too small (%zu needed)", joined.size() + 1);
+    memcpy(out, joined.c_str(), joined.size() + 1);
+    *n_out = v.size();
+    return SH_OK;
+}
+
+// `scrubby classifier`: Cleaner::run_classifier_output (cleaner.rs:177-194) -> parse_classifier_output (:375-382) -> clean_reads
+extern "C" sh_status sh_classifier_run(const sh_classifier_config *c, sh_reads_result *res)
+{
+    SH_CHECK(c && res, SH_ERR_BAD_ARG, "sh_classifier_run: null argument");
+    SH_CHECK(c->n_files >= 1 && c->n_files <= 2, SH_ERR_BAD_ARG, "one or two input files are supported (got %u)", c->n_files);
+    SH_CHECK(c->report, SH_ERR_BAD_ARG, "MissingClassifierClassificationReport");
+    SH_CHECK(c->reads, SH_ERR_BAD_ARG, "MissingClassifierReadClassfications");
+    SH_CHECK(c->classifier && (!strcmp(c->classifier, "kraken2") || !strcmp(c->classifier, "metabuli")), SH_ERR_BAD_ARG, "MissingClassifier");
+    SH_CHECK(c->n_taxa + c->n_taxa_direct > 0, SH_ERR_BAD_ARG, "MissingTaxa: --taxa or --taxa-direct is required");    // scrubby.rs:843-845
+    memset(res, 0, sizeof(*res));
+    ReportSettings st;
+    for (uint32_t i = 0; i < c->n_taxa; ++i) st.taxa.push_back(c->taxa[i]);
+    for (uint32_t i = 0; i < c->n_taxa_direct; ++i) st.taxa_direct.push_back(c->taxa_direct[i]);
+    std::unordered_set<std::string> taxids, ids;
+    sh_status s = taxids_from_report(c->report, st.taxa, st.taxa_direct, taxids);
+    if (s != SH_OK) return s;
+    s = taxid_reads(taxids, c->reads, !strcmp(c->classifier, "metabuli"), ids);
+    if (s != SH_OK) return s;
+    res->n_depleted_ids = ids.size();
+    for (uint32_t i = 0; i < c->n_files; ++i) {
+        s = filter_fastx(c->input[i], c->output[i], ids, c->extract != 0, nullptr, nullptr);
+        if (s != SH_OK) return s;
+    }
+    st.classifier = c->classifier; st.reads = c->reads; st.report = c->report; st.extract = c->extract != 0;
+    return finish_report(c->input, c->output, c->n_files, c->extract != 0, c->json, c->read_ids, c->command, st, res);
 }
 
 // ---- Cleaner::run_minimap2_rs + clean_reads + ScrubbyReport::create ------------------------------------------------
@@ -328,20 +525,11 @@ extern "C" sh_status sh_reads_run(const sh_reads_config *c, sh_reads_result *res
     auto t4 = now();
 
     // report (only if -j or -r was given, scrubby.rs:276-278): counts come from re-reading the files
-    if (c->json || c->read_ids) {
-        std::unordered_set<std::string> diff_ids;
-        uint64_t rin, rout, diff;
-        st = read_difference(c->input, c->output, c->n_files, &rin, &rout, &diff, &diff_ids);
+    {
+        ReportSettings rs;
+        rs.aligner = "minimap2-rs"; rs.index = c->index; rs.preset_variant = preset_variant(preset); rs.extract = c->extract != 0;
+        st = finish_report(c->input, c->output, c->n_files, c->extract != 0, c->json, c->read_ids, c->command, rs, res);
         if (st != SH_OK) return st;
-        res->reads_in = rin; res->reads_out = rout;
-        res->reads_removed = c->extract ? 0 : diff; res->reads_extracted = c->extract ? diff : 0;
-        if (c->read_ids) {
-            FastxWriter w(c->read_ids, 9);
-            SH_CHECK(w.ok(), SH_ERR_IO, "%s", w.error.c_str());
-            w.put("id\n");
-            for (auto &id : diff_ids) w.put(id + "\n");
-        }
-        if (c->json) { st = write_report(c, preset, res, c->json); if (st != SH_OK) return st; }
     }
     res->ms_index = ms(t0, t1); res->ms_ingest = ms(t1, t2); res->ms_classify = ms(t2, t3); res->ms_write = ms(t3, t4);
     return SH_OK;

@@ -79,6 +79,14 @@ class ReadsResult(C.Structure):
                 ("ms_ingest", C.c_double), ("ms_classify", C.c_double), ("ms_write", C.c_double)]
 
 
+class ClassifierConfig(C.Structure):
+    _fields_ = [("input", C.c_char_p * 2), ("output", C.c_char_p * 2), ("n_files", C.c_uint32), ("extract", C.c_int32),
+                ("report", C.c_char_p), ("reads", C.c_char_p), ("classifier", C.c_char_p),
+                ("taxa", C.POINTER(C.c_char_p)), ("n_taxa", C.c_uint32),
+                ("taxa_direct", C.POINTER(C.c_char_p)), ("n_taxa_direct", C.c_uint32),
+                ("json", C.c_char_p), ("read_ids", C.c_char_p), ("command", C.c_char_p)]
+
+
 class RefParams(C.Structure):
     _fields_ = [
         ("seed", C.c_uint64), ("genome_len", C.c_uint64), ("n_contigs", C.c_uint32),
@@ -100,6 +108,7 @@ EXPORTS = [
     "sh_ctx_create", "sh_ctx_destroy", "sh_classify_device", "sh_classify_batch",
     "sh_synth_ref_device", "sh_synth_reads_device", "sh_bench_gather",
     "sh_reads_run", "sh_host_get_id", "sh_host_filter_fastx", "sh_host_read_difference",
+    "sh_classifier_run", "sh_classifier_taxids",
 ]
 
 _LIB = None
@@ -137,6 +146,8 @@ def load():
     L.sh_synth_reads_device.argtypes = [C.POINTER(RefParams), C.POINTER(ReadParams), u64, u64, vp, vp, vp]
     L.sh_bench_gather.argtypes = [vp, u64, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.sh_reads_run.argtypes = [C.POINTER(ReadsConfig), C.POINTER(ReadsResult)]
+    L.sh_classifier_run.argtypes = [C.POINTER(ClassifierConfig), C.POINTER(ReadsResult)]
+    L.sh_classifier_taxids.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(C.c_char_p), u32, C.c_char_p, C.c_size_t, C.POINTER(u64)]
     L.sh_host_get_id.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
     L.sh_host_filter_fastx.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u64, i32, C.POINTER(u64), C.POINTER(u64)]
     L.sh_host_read_difference.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
@@ -365,4 +376,33 @@ def reads_run(inputs, outputs, index, preset=None, extract=False, json=None, rea
     c.command, c.threads, c.device = command.encode(), threads, device
     r = ReadsResult()
     check(load().sh_reads_run(C.byref(c), C.byref(r)))
+    return {n: getattr(r, n) for n, _ in ReadsResult._fields_}
+
+
+def classifier_taxids(report, taxa=(), taxa_direct=()):
+    """classifier.rs:124-252 get_taxids_from_report -> set of taxid strings."""
+    t = (C.c_char_p * max(len(taxa), 1))(*[x.encode() for x in taxa])
+    d = (C.c_char_p * max(len(taxa_direct), 1))(*[x.encode() for x in taxa_direct])
+    out = C.create_string_buffer(1 << 20)
+    n = C.c_uint64()
+    check(load().sh_classifier_taxids(os.fsencode(report), t, len(taxa), d, len(taxa_direct), out, len(out), C.byref(n)))
+    return set(x for x in out.value.decode().split("\n") if x != "") if n.value else set()
+
+
+def classifier_run(inputs, outputs, report, reads, classifier, taxa=(), taxa_direct=(), extract=False, json=None, read_ids=None, command=""):
+    """`scrubby classifier`: cleaner.rs:177-194 run_classifier_output."""
+    c = ClassifierConfig()
+    for i, (a, b) in enumerate(zip(inputs, outputs)):
+        c.input[i] = os.fsencode(a)
+        c.output[i] = os.fsencode(b)
+    c.n_files, c.extract = len(inputs), int(extract)
+    c.report, c.reads, c.classifier = os.fsencode(report), os.fsencode(reads), classifier.encode()
+    t = (C.c_char_p * max(len(taxa), 1))(*[x.encode() for x in taxa])
+    d = (C.c_char_p * max(len(taxa_direct), 1))(*[x.encode() for x in taxa_direct])
+    c.taxa, c.n_taxa, c.taxa_direct, c.n_taxa_direct = t, len(taxa), d, len(taxa_direct)
+    c.json = os.fsencode(json) if json else None
+    c.read_ids = os.fsencode(read_ids) if read_ids else None
+    c.command = command.encode()
+    r = ReadsResult()
+    check(load().sh_classifier_run(C.byref(c), C.byref(r)))
     return {n: getattr(r, n) for n, _ in ReadsResult._fields_}
