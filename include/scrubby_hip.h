@@ -204,6 +204,25 @@ sh_status sh_classifier_run(const sh_classifier_config *cfg, sh_reads_result *ou
 sh_status sh_classifier_taxids(const char *report, const char *const *taxa, uint32_t n_taxa, const char *const *taxa_direct,
                                uint32_t n_direct, char *out, size_t cap, uint64_t *n_out);
 
+/* ---- `scrubby alignment`: cleaning from a precomputed alignment (PAF/GAF, or a one-column TXT of read ids) ---------
+ * Cleaner::run_aligner_output (cleaner.rs:206-219), ReadAlignment::from / from_paf / from_txt (alignment.rs:33-114):
+ * a read is selected iff (query aligned length >= min_len OR query coverage >= min_cov) AND mapq >= min_mapq.
+ * SAM/BAM/CRAM need the reference's optional htslib feature and are rejected here. */
+typedef struct sh_alignment_config {
+    const char *input[2];
+    const char *output[2];
+    uint32_t    n_files;
+    int32_t     extract;
+    const char *alignment;    /* -a */
+    const char *format;       /* "paf" | "gaf" | "txt", or NULL: by the file's (last) extension */
+    uint64_t    min_len;      /* -l */
+    double      min_cov;      /* -c */
+    uint32_t    min_mapq;     /* -q */
+    const char *json, *read_ids, *command;
+} sh_alignment_config;
+
+sh_status sh_alignment_run(const sh_alignment_config *cfg, sh_reads_result *out);
+
 /* host-side pieces on their own (no GPU needed): get_id (utils.rs:91-103), FastqCleaner::clean_reads
  * (cleaner.rs:731-760), ReadDifference::get_difference (utils.rs:250-285) */
 sh_status sh_host_get_id(const char *header, char *out, size_t cap);

@@ -57,9 +57,51 @@ static int main_classifier(int argc, char **argv, const std::string &command)
     return 0;
 }
 
+// `scrubby alignment` (/root/reference/src/terminal.rs:281-360)
+static int main_alignment(int argc, char **argv, const std::string &command)
+{
+    std::vector<std::string> in, out;
+    std::string aln, fmt, json, ids;
+    unsigned long long min_len = 0; double min_cov = 0.0; unsigned min_mapq = 0;
+    int extract = 0;
+    for (int i = 2; i < argc; ++i) {
+        std::string a = argv[i];
+        auto val = [&]() -> std::string { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
+        auto multi = [&](std::vector<std::string> &v) { while (i + 1 < argc && argv[i + 1][0] != '-') v.push_back(argv[++i]); };
+        if (a == "-i" || a == "--input") multi(in);
+        else if (a == "-o" || a == "--output") multi(out);
+        else if (a == "-a" || a == "--alignment") aln = val();
+        else if (a == "-f" || a == "--format") fmt = val();
+        else if (a == "-l" || a == "--min-len") min_len = strtoull(val().c_str(), nullptr, 10);
+        else if (a == "-c" || a == "--min-cov") min_cov = atof(val().c_str());
+        else if (a == "-q" || a == "--min-mapq") min_mapq = (unsigned)atoi(val().c_str());
+        else if (a == "-j" || a == "--json") json = val();
+        else if (a == "-r" || a == "--read-ids") ids = val();
+        else if (a == "-w" || a == "--workdir") val();
+        else if (a == "-e" || a == "--extract") extract = 1;
+        else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    if (in.empty() || in.size() > 2 || in.size() != out.size()) { fprintf(stderr, "error: one or two inputs and as many outputs are required\n"); return 2; }
+    sh_alignment_config c{};
+    for (size_t k = 0; k < in.size(); ++k) { c.input[k] = in[k].c_str(); c.output[k] = out[k].c_str(); }
+    c.n_files = (uint32_t)in.size(); c.extract = extract; c.alignment = aln.empty() ? nullptr : aln.c_str();
+    c.format = fmt.empty() ? nullptr : fmt.c_str(); c.min_len = min_len; c.min_cov = min_cov; c.min_mapq = min_mapq;
+    c.json = json.empty() ? nullptr : json.c_str(); c.read_ids = ids.empty() ? nullptr : ids.c_str(); c.command = command.c_str();
+    sh_reads_result r{};
+    sh_status st = sh_alignment_run(&c, &r);
+    if (st != SH_OK) { fprintf(stderr, "error (%d): %s\n", st, sh_last_error()); return 1; }
+    fprintf(stderr, "[scrubby-hip] read ids selected by alignment: %llu\n", (unsigned long long)r.n_depleted_ids);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
-    if (argc >= 2 && std::string(argv[1]) == "classifier") {
+    if (argc >= 2 && (std::string(argv[1]) == "classifier" || std::string(argv[1]) == "alignment")) {
+        std::string command;
+        for (int i = 0; i < argc; ++i) { if (i) command += ' '; command += argv[i]; }
+        return std::string(argv[1]) == "alignment" ? main_alignment(argc, argv, command) : main_classifier(argc, argv, command);
+    }
+    if (false) {
         std::string command;
         for (int i = 0; i < argc; ++i) { if (i) command += ' '; command += argv[i]; }
         return main_classifier(argc, argv, command);

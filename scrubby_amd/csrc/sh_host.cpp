@@ -222,10 +222,20 @@ extern "C" sh_status sh_host_read_difference(const char *const *inputs, const ch
 }
 
 struct ReportSettings {       // ScrubbySettings, /root/reference/src/report.rs:71-88 (field order = key order)
-    const char *aligner = nullptr, *classifier = nullptr, *index = nullptr, *reads = nullptr, *report = nullptr, *preset_variant = nullptr;
+    const char *aligner = nullptr, *classifier = nullptr, *index = nullptr, *alignment = nullptr, *reads = nullptr, *report = nullptr, *preset_variant = nullptr;
     std::vector<std::string> taxa, taxa_direct;
+    uint64_t min_len = 0; double min_cov = 0.0; uint32_t min_mapq = 0;
     bool extract = false;
 };
+
+static std::string json_f64(double v)
+{   // serde_json prints f64 with the shortest round-trip form and always a fractional part
+    char b[64];
+    for (int prec = 1; prec <= 17; ++prec) { snprintf(b, sizeof b, "%.*g", prec, v); if (strtod(b, nullptr) == v) break; }
+    std::string o = b;
+    if (o.find('.') == std::string::npos && o.find('e') == std::string::npos && o.find("inf") == std::string::npos && o.find("nan") == std::string::npos) o += ".0";
+    return o;
+}
 
 static sh_status write_report_json(const char *const *input, const char *const *output, uint32_t n_files, const char *command,
                                    const ReportSettings &st, const sh_reads_result *r, const char *path)
@@ -263,11 +273,11 @@ static sh_status write_report_json(const char *const *input, const char *const *
     o += "  \"settings\": {\n";
     o += "    \"aligner\": " + opt(st.aligner) + ",\n    \"classifier\": " + opt(st.classifier) + ",\n";
     o += "    \"index\": " + opt(st.index) + ",\n";
-    o += "    \"alignment\": null,\n    \"reads\": " + opt(st.reads) + ",\n    \"report\": " + opt(st.report) + ",\n";
+    o += "    \"alignment\": " + opt(st.alignment) + ",\n    \"reads\": " + opt(st.reads) + ",\n    \"report\": " + opt(st.report) + ",\n";
     o += "    \"taxa\": " + strs(st.taxa) + ",\n    \"taxa_direct\": " + strs(st.taxa_direct) + ",\n";
     o += "    \"classifier_args\": null,\n    \"aligner_args\": null,\n";
     o += "    \"preset\": " + opt(st.preset_variant) + ",\n";
-    o += "    \"min_len\": 0,\n    \"min_cov\": 0.0,\n    \"min_mapq\": 0,\n";
+    o += "    \"min_len\": " + std::to_string(st.min_len) + ",\n    \"min_cov\": " + json_f64(st.min_cov) + ",\n    \"min_mapq\": " + std::to_string(st.min_mapq) + ",\n";
     o += std::string("    \"extract\": ") + (st.extract ? "true" : "false") + "\n  }\n}";
     fwrite(o.data(), 1, o.size(), f);
     fclose(f);
@@ -533,4 +543,71 @@ extern "C" sh_status sh_reads_run(const sh_reads_config *c, sh_reads_result *res
     }
     res->ms_index = ms(t0, t1); res->ms_ingest = ms(t1, t2); res->ms_classify = ms(t2, t3); res->ms_write = ms(t3, t4);
     return SH_OK;
+}
+
+// ---- `scrubby alignment`: Cleaner::run_aligner_output (cleaner.rs:206-219) with ReadAlignment (src/alignment.rs:33-114,242-276) ----
+static bool gz_lines(const char *path, std::vector<std::string> &lines)
+{
+    gzFile f = gzopen(path, "rb");
+    if (!f) return false;
+    std::vector<char> buf(1 << 16);
+    std::string cur;
+    while (gzgets(f, buf.data(), (int)buf.size())) {
+        cur += buf.data();
+        if (!cur.empty() && cur.back() == '\n') { cur.pop_back(); if (!cur.empty() && cur.back() == '\r') cur.pop_back(); lines.push_back(cur); cur.clear(); }
+    }
+    if (!cur.empty()) lines.push_back(cur);
+    gzclose(f);
+    return true;
+}
+
+static sh_status alignment_ids(const char *path, const char *format, uint64_t min_len, double min_cov, uint32_t min_mapq, std::unordered_set<std::string> &ids)
+{
+    std::string fmt = format ? format : "";
+    if (fmt.empty()) {       // Path::extension(): only the LAST extension counts, so "x.paf.gz" is not recognised (alignment.rs:47-55)
+        std::string p = path;
+        size_t dot = p.rfind('.'), slash = p.rfind('/');
+        std::string ext = (dot != std::string::npos && (slash == std::string::npos || dot > slash)) ? p.substr(dot + 1) : "";
+        if (ext == "paf" || ext == "gaf") fmt = "paf"; else if (ext == "txt") fmt = "txt";
+        else { sh_set_error("AlignmentInputFormatNotRecognized: %s", path); return SH_ERR_BAD_ARG; }
+    }
+    if (fmt == "gaf") fmt = "paf";
+    SH_CHECK(fmt == "paf" || fmt == "txt", SH_ERR_BAD_ARG, "AlignmentInputFormatInvalid: %s (SAM/BAM/CRAM need the reference's htslib feature)", fmt.c_str());
+    bool exists;
+    if (file_is_empty(path, exists)) { SH_CHECK(exists, SH_ERR_IO, "cannot open %s", path); return SH_OK; }
+    std::vector<std::string> lines;
+    SH_CHECK(gz_lines(path, lines), SH_ERR_IO, "cannot open %s", path);
+    if (fmt == "txt") { for (auto &l : lines) ids.insert(l); return SH_OK; }       // one id per line, verbatim
+    for (auto &l : lines) {
+        auto f = split_tab(l);
+        SH_CHECK(f.size() >= 12, SH_ERR_IO, "malformed PAF line (%zu fields): %s", f.size(), l.c_str());
+        uint64_t qlen, qs, qe, v, mapq;
+        for (int k : {1, 2, 3, 6, 7, 8, 9, 10, 11}) SH_CHECK(parse_u64_strict(f[k], v), SH_ERR_IO, "PAF integer field %d: %s", k + 1, l.c_str());
+        parse_u64_strict(f[1], qlen); parse_u64_strict(f[2], qs); parse_u64_strict(f[3], qe); parse_u64_strict(f[11], mapq);
+        SH_CHECK(mapq <= 255, SH_ERR_IO, "PAF mapq out of range: %s", l.c_str());
+        SH_CHECK(qe >= qs, SH_ERR_IO, "PAF query end before start: %s", l.c_str());
+        const uint64_t qalen = qe - qs;
+        const double qcov = qlen == 0 ? 0.0 : (double)qalen / (double)qlen;
+        if ((qalen >= min_len || qcov >= min_cov) && mapq >= min_mapq) ids.insert(f[0]);
+    }
+    return SH_OK;
+}
+
+extern "C" sh_status sh_alignment_run(const sh_alignment_config *c, sh_reads_result *res)
+{
+    SH_CHECK(c && res, SH_ERR_BAD_ARG, "sh_alignment_run: null argument");
+    SH_CHECK(c->n_files >= 1 && c->n_files <= 2, SH_ERR_BAD_ARG, "one or two input files are supported (got %u)", c->n_files);
+    SH_CHECK(c->alignment, SH_ERR_BAD_ARG, "MissingAlignment");
+    memset(res, 0, sizeof(*res));
+    std::unordered_set<std::string> ids;
+    sh_status s = alignment_ids(c->alignment, c->format, c->min_len, c->min_cov, c->min_mapq, ids);
+    if (s != SH_OK) return s;
+    res->n_depleted_ids = ids.size();
+    for (uint32_t i = 0; i < c->n_files; ++i) {
+        s = filter_fastx(c->input[i], c->output[i], ids, c->extract != 0, nullptr, nullptr);
+        if (s != SH_OK) return s;
+    }
+    ReportSettings st;
+    st.alignment = c->alignment; st.min_len = c->min_len; st.min_cov = c->min_cov; st.min_mapq = c->min_mapq; st.extract = c->extract != 0;
+    return finish_report(c->input, c->output, c->n_files, c->extract != 0, c->json, c->read_ids, c->command, st, res);
 }

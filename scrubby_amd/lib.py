@@ -87,6 +87,12 @@ class ClassifierConfig(C.Structure):
                 ("json", C.c_char_p), ("read_ids", C.c_char_p), ("command", C.c_char_p)]
 
 
+class AlignmentConfig(C.Structure):
+    _fields_ = [("input", C.c_char_p * 2), ("output", C.c_char_p * 2), ("n_files", C.c_uint32), ("extract", C.c_int32),
+                ("alignment", C.c_char_p), ("format", C.c_char_p), ("min_len", C.c_uint64), ("min_cov", C.c_double),
+                ("min_mapq", C.c_uint32), ("json", C.c_char_p), ("read_ids", C.c_char_p), ("command", C.c_char_p)]
+
+
 class RefParams(C.Structure):
     _fields_ = [
         ("seed", C.c_uint64), ("genome_len", C.c_uint64), ("n_contigs", C.c_uint32),
@@ -108,7 +114,7 @@ EXPORTS = [
     "sh_ctx_create", "sh_ctx_destroy", "sh_classify_device", "sh_classify_batch",
     "sh_synth_ref_device", "sh_synth_reads_device", "sh_bench_gather",
     "sh_reads_run", "sh_host_get_id", "sh_host_filter_fastx", "sh_host_read_difference",
-    "sh_classifier_run", "sh_classifier_taxids",
+    "sh_classifier_run", "sh_classifier_taxids", "sh_alignment_run",
 ]
 
 _LIB = None
@@ -147,6 +153,7 @@ def load():
     L.sh_bench_gather.argtypes = [vp, u64, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.sh_reads_run.argtypes = [C.POINTER(ReadsConfig), C.POINTER(ReadsResult)]
     L.sh_classifier_run.argtypes = [C.POINTER(ClassifierConfig), C.POINTER(ReadsResult)]
+    L.sh_alignment_run.argtypes = [C.POINTER(AlignmentConfig), C.POINTER(ReadsResult)]
     L.sh_classifier_taxids.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(C.c_char_p), u32, C.c_char_p, C.c_size_t, C.POINTER(u64)]
     L.sh_host_get_id.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
     L.sh_host_filter_fastx.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u64, i32, C.POINTER(u64), C.POINTER(u64)]
@@ -405,4 +412,21 @@ def classifier_run(inputs, outputs, report, reads, classifier, taxa=(), taxa_dir
     c.command = command.encode()
     r = ReadsResult()
     check(load().sh_classifier_run(C.byref(c), C.byref(r)))
+    return {n: getattr(r, n) for n, _ in ReadsResult._fields_}
+
+
+def alignment_run(inputs, outputs, alignment, fmt=None, min_len=0, min_cov=0.0, min_mapq=0, extract=False, json=None, read_ids=None, command=""):
+    """`scrubby alignment`: cleaner.rs:206-219 run_aligner_output with alignment.rs filters."""
+    c = AlignmentConfig()
+    for i, (a, b) in enumerate(zip(inputs, outputs)):
+        c.input[i] = os.fsencode(a)
+        c.output[i] = os.fsencode(b)
+    c.n_files, c.extract, c.alignment = len(inputs), int(extract), os.fsencode(alignment)
+    c.format = fmt.encode() if fmt else None
+    c.min_len, c.min_cov, c.min_mapq = min_len, min_cov, min_mapq
+    c.json = os.fsencode(json) if json else None
+    c.read_ids = os.fsencode(read_ids) if read_ids else None
+    c.command = command.encode()
+    r = ReadsResult()
+    check(load().sh_alignment_run(C.byref(c), C.byref(r)))
     return {n: getattr(r, n) for n, _ in ReadsResult._fields_}
