@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--records", type=int, default=20_000_000, help="records per GPU (2 per pair)")
     ap.add_argument("--chunk", type=int, default=1 << 25, help="records per kernel launch (default: the whole batch in one launch)")
     ap.add_argument("--small", action="store_true", help="5 Mb reference / 200k records (plumbing check)")
+    ap.add_argument("--workload", choices=["sr", "ont"], default="sr",
+                    help="sr = BASELINE configs[1] (headline); ont = configs[3] stand-in: long noisy reads, map-ont preset (not the headline metric)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather-bench", action="store_true", help="also time raw 16-B random gathers over the table")
@@ -66,10 +68,13 @@ def main():
 
     contigs = [1_000_000] * 5 if a.small else CHM13_CONTIGS
     n_rec = 200_000 if a.small else a.records
+    ont = a.workload == "ont"
+    if ont:
+        n_rec = 20_000 if a.small else (a.records if a.records != 20_000_000 else 200_000)
     P = S.ref_params(REF_SEED, contigs)
-    R = S.read_params(READ_SEED)
+    R = S.read_params(0x5C2B0020, host_pct=50, sub_per_10k=500, n_read_pct=0) if ont else S.read_params(READ_SEED)
     G = P.genome_len
-    opts = S.preset("sr")
+    opts = S.preset("map-ont" if ont else "sr")
 
     # ---- setup (untimed): reference -> index -> reads, all in HBM -------------------------------------
     t0 = time.time()
@@ -86,11 +91,23 @@ def main():
     torch.cuda.empty_cache()
 
     L = R.read_len
-    d_reads = torch.empty(n_rec * L + 64, dtype=torch.uint8, device=dev)
-    d_off = torch.empty(n_rec + 1, dtype=torch.int64, device=dev)
-    S.synth_reads_device(P, R, rank * n_rec, n_rec, d_reads, d_off)     # this rank's shard of the record space
+    if ont:
+        lens = long_read_lengths(R.seed, rank * n_rec, n_rec)
+        off_np = np.zeros(n_rec + 1, dtype=np.int64)
+        off_np[1:] = np.cumsum(lens.astype(np.int64))
+        n_bases = int(off_np[-1])
+        d_off = torch.from_numpy(off_np).to(dev)
+        d_reads = torch.empty(n_bases + 64, dtype=torch.uint8, device=dev)
+        S.synth_long_reads_device(P, R, rank * n_rec, n_rec, d_off, n_bases, d_reads)
+        a.chunk = min(a.chunk, 1 << 16)
+        ctx = S.Context(index, min(a.chunk, n_rec), n_bases, int(lens.max()))
+    else:
+        n_bases = n_rec * L
+        d_reads = torch.empty(n_bases + 64, dtype=torch.uint8, device=dev)
+        d_off = torch.empty(n_rec + 1, dtype=torch.int64, device=dev)
+        S.synth_reads_device(P, R, rank * n_rec, n_rec, d_reads, d_off)     # this rank's shard of the record space
+        ctx = S.Context(index, min(a.chunk, n_rec), n_bases, L)
     d_flags = torch.zeros(n_rec, dtype=torch.uint8, device=dev)
-    ctx = S.Context(index, min(a.chunk, n_rec), n_rec * L, L)
     torch.cuda.synchronize()
 
     from scrubby_amd import dist as D
@@ -98,7 +115,7 @@ def main():
     union = {"bytes": 0}
 
     def step():
-        st = ctx.classify(d_reads[: n_rec * L], d_off, d_flags, None, want_stats=True)
+        st = ctx.classify(d_reads[:n_bases], d_off, d_flags, None, want_stats=True)
         if world > 1:   # depleted-record bitmap union: disjoint slices, one all_gather over RCCL
             gathered, _ = D.union_depleted(d_flags, slice_bytes=n_bits)
             union["bytes"] = gathered.numel()
@@ -176,20 +193,23 @@ def main():
     # ---- CPU baseline: the oracle on the host cores, same index, bounded sample -------------------------
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
-        cpu = cpu_baseline(index, info, d_reads, n_rec, L, a.cpu_seconds, d_flags)
+        cpu = cpu_baseline(index, info, d_reads, n_rec, L, a.cpu_seconds, d_flags, d_off if ont else None, "map-ont" if ont else "sr")
 
     if rank == 0:
         out = {
-            "metric": "reads/s depleted (2x150bp PE vs CHM13v2-sized reference), records classified per second",
+            "metric": ("reads/s depleted (long reads, map-ont, vs CHM13v2-sized reference) - NOT the headline metric" if ont else
+                       "reads/s depleted (2x150bp PE vs CHM13v2-sized reference), records classified per second"),
             "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64/i32 (f32 in the chain gap penalty)", "data": "synthetic",
             "union_bytes_gathered": union["bytes"],
             "config": {
-                "workload": ("cfg1-small: 200k records vs 5 Mb" if a.small else
+                "workload": ("configs[3] stand-in: %d long reads (log-normal-like lengths, median 5.4 kb, 5 %% substitutions), map-ont preset; "
+                             "legacy lane-per-read kernel (long-read kernels are not built yet)" % n_rec if ont else
+                             "cfg1-small: 200k records vs 5 Mb" if a.small else
                              "configs[1]: 10M synthetic 2x150bp PE (20M records) vs CHM13v2-sized synthetic reference, sr preset, k-mer/minimizer classifier path"),
                 "records_per_gpu": n_rec, "read_len": L, "host_pct": R.host_pct, "reference_bp": int(G),
-                "preset": "sr", "k": info["k"], "w": info["w"], "records_per_launch": ctx_chunk(a, n_rec),
+                "preset": "map-ont" if ont else "sr", "k": info["k"], "w": info["w"], "records_per_launch": ctx_chunk(a, n_rec),
                 "parallelism": f"read-sharded x{world}, index replicated", "ref_seed": hex(REF_SEED), "read_seed": hex(READ_SEED),
             },
             "result": {"reads_removed_rank0": n_host, "n_no_seed": s0["n_no_seed"], "n_chain_small": s0["n_chain_small"],
@@ -211,7 +231,24 @@ def ctx_chunk(a, n_rec):
     return min(a.chunk, n_rec)
 
 
-def cpu_baseline(index, info, d_reads, n_rec, L, seconds, d_flags):
+def long_read_lengths(seed, r0, n):
+    """syn_long_len of csrc/sh_synth_core.h in numpy (uint64 wrap-around arithmetic)."""
+    M = np.uint64
+    with np.errstate(over="ignore"):
+        def mix(z):
+            z = z + M(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> M(30))) * M(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> M(27))) * M(0x94D049BB133111EB)
+            return z ^ (z >> M(31))
+        r = np.arange(r0, r0 + n, dtype=np.uint64)
+        h = mix(M(seed) ^ M(0x10E6A11) ^ (r * M(0x9E3779B97F4A7C15)))
+    knot = np.array([200, 1530, 2180, 2720, 3230, 3730, 4250, 4800, 5400, 6050, 6800, 7700, 8850, 10400, 12900, 18000, 28000], dtype=np.uint64)
+    q = (h & M(15)).astype(np.int64)
+    lo, hi = knot[q], knot[q + 1]
+    return (lo + ((((h >> M(8)) & M(0xffffff)) * (hi - lo)) >> M(24))).astype(np.uint32)
+
+
+def cpu_baseline(index, info, d_reads, n_rec, L, seconds, d_flags, d_off=None, preset="sr"):
     """Oracle (port of the decision path) on all host cores over a bounded sample; also a parity spot check."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
@@ -225,12 +262,18 @@ def cpu_baseline(index, info, d_reads, n_rec, L, seconds, d_flags):
                 "sample": f"skipped: host has {avail_gb:.0f} GB free, index copy needs {need_gb:.0f} GB"}
     slots, pos = index.export()
     oidx = O.Index.wrap(slots, pos, info["w"], info["k"])
-    oo = O.preset("sr")
-    batch = 50_000
+    oo = oidx.update_opts(O.preset(preset))
+    batch = 50_000 if d_off is None else 2_000
+    off_all = d_off.cpu().numpy().astype(np.uint64) if d_off is not None else None
     done, t_used, mism = 0, 0.0, 0
     while t_used < seconds and done + batch <= n_rec:
-        reads = d_reads[done * L:(done + batch) * L].cpu().numpy()
-        off = np.arange(batch + 1, dtype=np.uint64) * L
+        if off_all is None:
+            reads = d_reads[done * L:(done + batch) * L].cpu().numpy()
+            off = np.arange(batch + 1, dtype=np.uint64) * L
+        else:
+            b0, b1 = int(off_all[done]), int(off_all[done + batch])
+            reads = d_reads[b0:b1].cpu().numpy()
+            off = off_all[done:done + batch + 1] - np.uint64(b0)
         t0 = time.perf_counter()
         fl, _ = oidx.classify(oo, reads, off, threads=cores, want_trace=False)
         t_used += time.perf_counter() - t0

@@ -237,6 +237,10 @@ sh_status sh_synth_ref_device(const void *ref_params, uint64_t g0, uint64_t n, u
 sh_status sh_synth_reads_device(const void *ref_params, const void *read_params, uint64_t r0, uint64_t n_records,
                                 uint8_t *d_out, uint64_t *d_offsets /* n_records+1, may be NULL */, void *stream);
 
+/* variable-length long reads (BASELINE config 4 stand-in); d_offsets[n_records+1] given by the caller (lengths: syn_long_len) */
+sh_status sh_synth_long_reads_device(const void *ref_params, const void *read_params, uint64_t r0, uint64_t n_records,
+                                     const uint64_t *d_offsets, uint64_t n_bases, uint8_t *d_out, void *stream);
+
 /* ---- micro-benchmarks for the roofline (bench.py) ---------------------------------------- */
 /* random 16-B slot gathers over the index table; returns achieved GB/s of useful bytes */
 sh_status sh_bench_gather(const sh_index *idx, uint64_t n_probes, int32_t iters, double *out_gbs_useful, double *out_ms);

@@ -93,6 +93,8 @@ def lib():
     L.syn_cpu_ref.argtypes = [C.POINTER(RefParams), C.c_uint64, C.c_uint64, C.c_void_p]
     L.syn_cpu_reads.argtypes = [C.POINTER(RefParams), C.POINTER(ReadParams), C.c_uint64, C.c_uint64, C.c_void_p]
     L.syn_cpu_truth.argtypes = [C.POINTER(RefParams), C.POINTER(ReadParams), C.c_uint64, C.c_uint64, C.c_void_p]
+    L.syn_cpu_long_lengths.argtypes = [C.POINTER(ReadParams), C.c_uint64, C.c_uint64, C.c_void_p]
+    L.syn_cpu_long_reads.argtypes = [C.POINTER(RefParams), C.POINTER(ReadParams), C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
     _LIB = L
     return L
 
@@ -212,3 +214,18 @@ def synth_truth(P, R, r0, n):
     out = np.zeros(n, dtype=np.uint8)
     lib().syn_cpu_truth(C.byref(P), C.byref(R), r0, n, out.ctypes.data)
     return out
+
+
+def synth_long_lengths(R, r0, n):
+    out = np.zeros(n, dtype=np.uint32)
+    lib().syn_cpu_long_lengths(C.byref(R), r0, n, out.ctypes.data)
+    return out
+
+
+def synth_long_reads(P, R, r0, n):
+    lens = synth_long_lengths(R, r0, n)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens.astype(np.uint64))
+    out = np.zeros(int(offs[-1]), dtype=np.uint8)
+    lib().syn_cpu_long_reads(C.byref(P), C.byref(R), r0, n, offs.ctypes.data, out.ctypes.data)
+    return out, offs

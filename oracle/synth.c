@@ -23,3 +23,19 @@ void syn_cpu_truth(const syn_ref_params *P, const syn_read_params *R, uint64_t r
     uint64_t r;
     for (r = r0; r < r0 + n; ++r) out[r - r0] = (uint8_t)syn_place_pair(P, R, r >> 1).is_host;
 }
+
+void syn_cpu_long_lengths(const syn_read_params *R, uint64_t r0, uint64_t n, uint32_t *out)
+{
+    uint64_t r;
+    for (r = 0; r < n; ++r) out[r] = syn_long_len(R->seed, r0 + r);
+}
+
+void syn_cpu_long_reads(const syn_ref_params *P, const syn_read_params *R, uint64_t r0, uint64_t n, const uint64_t *offsets, uint8_t *out)
+{
+    uint64_t r;
+    uint32_t i;
+    for (r = 0; r < n; ++r) {
+        uint32_t len = (uint32_t)(offsets[r + 1] - offsets[r]);
+        for (i = 0; i < len; ++i) out[offsets[r] + i] = syn_long_read_base(P, R, r0 + r, len, i);
+    }
+}

@@ -11,6 +11,9 @@ void syn_cpu_ref(const syn_ref_params *P, uint64_t g0, uint64_t n, uint8_t *out)
 void syn_cpu_reads(const syn_ref_params *P, const syn_read_params *R, uint64_t r0, uint64_t n, uint8_t *out);
 /* truth label per record: 1 = drawn from the reference */
 void syn_cpu_truth(const syn_ref_params *P, const syn_read_params *R, uint64_t r0, uint64_t n, uint8_t *out);
+/* long reads: lengths[n] and, given offsets[n+1], the bases */
+void syn_cpu_long_lengths(const syn_read_params *R, uint64_t r0, uint64_t n, uint32_t *out);
+void syn_cpu_long_reads(const syn_ref_params *P, const syn_read_params *R, uint64_t r0, uint64_t n, const uint64_t *offsets, uint8_t *out);
 #ifdef __cplusplus
 }
 #endif

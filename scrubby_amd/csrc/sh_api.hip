@@ -267,6 +267,34 @@ extern "C" sh_status sh_synth_reads_device(const void *ref_params, const void *r
     return SH_OK;
 }
 
+// long reads: offsets are computed on the host (lengths from syn_long_len), one thread per 4 bases
+__global__ void k_synth_long(syn_ref_params P, syn_read_params R, uint64_t r0, uint64_t n_rec, const uint64_t *offsets, uint8_t *out)
+{
+    const uint64_t total = offsets[n_rec];
+    uint64_t p = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (p >= total) return;
+    uint64_t lo = 0, hi = n_rec;          // offsets[lo] <= p < offsets[hi]
+    while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (offsets[mid] <= p) lo = mid; else hi = mid; }
+    for (int b = 0; b < 4 && p + b < total; ++b) {
+        uint64_t q = p + b;
+        while (q >= offsets[lo + 1]) ++lo;
+        out[q] = syn_long_read_base(&P, &R, r0 + lo, (uint32_t)(offsets[lo + 1] - offsets[lo]), (uint32_t)(q - offsets[lo]));
+    }
+}
+
+extern "C" sh_status sh_synth_long_reads_device(const void *ref_params, const void *read_params, uint64_t r0, uint64_t n_records,
+                                                const uint64_t *d_offsets, uint64_t n_bases, uint8_t *d_out, void *stream)
+{
+    SH_CHECK(ref_params && read_params && d_offsets && d_out, SH_ERR_BAD_ARG, "sh_synth_long_reads_device: null argument");
+    if (n_records == 0 || n_bases == 0) return SH_OK;
+    uint64_t nt = (n_bases + 3) / 4;
+    SH_CHECK((nt + 255) / 256 < (1ull << 31), SH_ERR_BAD_ARG, "too many bases for one launch");
+    hipLaunchKernelGGL(k_synth_long, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *(const syn_ref_params *)ref_params,
+                       *(const syn_read_params *)read_params, r0, n_records, d_offsets, d_out);
+    SH_HIP(hipGetLastError());
+    return SH_OK;
+}
+
 // ---- gather micro-benchmark: the practical ceiling for 16-B random probes into this table ----------------
 __global__ void k_gather(const uint4 *slots, uint32_t lg, uint64_t n, uint64_t seed, unsigned long long *sink)
 {

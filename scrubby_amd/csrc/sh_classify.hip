@@ -1195,10 +1195,14 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
     // the legacy re-sketch path.  Default 4 KiB per read of the batch (~110 anchor slots per read; the CHM13-sized
     // workload averages 72), at least 256 MiB; reads that find no room are deferred and re-run.
     c->arena_bytes = std::max<uint64_t>(256ull << 20, max_reads * 4096ull);
+    // without K1 every read takes the legacy path, whose sketch buffers and anchors live in the arena: ~48 B per base
+    if (!c->use_k1) c->arena_bytes = std::max<uint64_t>(c->arena_bytes, std::min<uint64_t>(max_reads * (uint64_t)max_read_len * 48ull, 64ull << 30));
     if (const char *env = getenv("SCRUBBY_HIP_ARENA_MB")) c->arena_bytes = (uint64_t)atoll(env) << 20;
     if ((e = hipMalloc(&c->d_arena, c->arena_bytes)) != hipSuccess) return fail(e, "arena");
     {
-        c->legacy_bytes = std::min<uint64_t>(c->arena_bytes / 8, 1ull << 30);
+        const uint64_t big_min = (64ull << 20) + max_reads * 160;
+        c->legacy_bytes = c->use_k1 ? std::min<uint64_t>(c->arena_bytes / 8, 1ull << 30)
+                                    : (c->arena_bytes > 2 * big_min ? c->arena_bytes - big_min : c->arena_bytes / 2);
         uint8_t *p = c->d_arena + c->legacy_bytes;
         uint64_t left = c->arena_bytes - c->legacy_bytes;
         uint64_t fixed = max_reads * (sizeof(BigMeta) + 8 + N_SORT_CLS * sizeof(SortItem) + 8) + 16384;

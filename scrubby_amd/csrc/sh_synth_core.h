@@ -159,4 +159,45 @@ SYN_FN uint8_t syn_read_base(const syn_ref_params *P, const syn_read_params *R, 
     return (uint8_t)"ACGT"[b];
 }
 
+/* ---- long reads (BASELINE config 4 stand-in): log-normal-like lengths, substitutions only -------------------------
+ * Length of read r: integer-only (bit-reproducible on both sides, no libm): the 16 quantile knots of a
+ * log-normal(mu = 8.497, sigma = 0.7) clipped to [200, 28000], uniform inside a quantile bin.
+ * Measured on 200 k reads: mean ~7.0 kb, median ~5.4 kb, N50 ~9 kb. */
+SYN_FN uint32_t syn_long_len(uint64_t seed, uint64_t r)
+{
+    const uint64_t h = syn_mix(seed ^ 0x10E6A11ULL ^ (r * 0x9E3779B97F4A7C15ULL));
+    const uint32_t knot[17] = {200, 1530, 2180, 2720, 3230, 3730, 4250, 4800, 4900 + 500, 6050, 6800, 7700, 8850, 10400, 12900, 18000, 100000};
+    const uint32_t q = (uint32_t)(h & 15);
+    const uint32_t lo = knot[q], hi = q == 15 ? 28000u : knot[q + 1];       /* the last bin's tail is truncated */
+    return lo + (uint32_t)(((h >> 8) & 0xffffff) * (uint64_t)(hi - lo) >> 24);
+}
+
+/* base i of long read r (single-end, either strand), host_pct % from the reference */
+SYN_FN uint8_t syn_long_read_base(const syn_ref_params *P, const syn_read_params *R, uint64_t r, uint32_t len, uint32_t i)
+{
+    const uint64_t h = syn_mix(R->seed ^ 0x0A7ULL ^ (r * 0xD6E8FEB86659FD93ULL));
+    const uint32_t is_host = (uint32_t)(h % 100) < R->host_pct, rev = (uint32_t)(h >> 40) & 1;
+    const uint64_t h3 = syn_mix(h ^ 0x2545F4914F6CDD1DULL);
+    uint64_t start;
+    uint32_t b;
+    if (is_host) {
+        uint64_t g = h3 % (P->genome_len - len);
+        uint32_t c = syn_contig_of(P, g);
+        uint64_t cend = P->contig_start[c + 1];
+        if (g + len > cend) g = cend > len ? cend - len : 0;
+        if (g < P->contig_start[c]) g = P->contig_start[c];       /* contig shorter than the read: it runs into the next one */
+        start = g;
+        b = syn_ref_base(P, rev ? start + len - 1 - i : start + i);
+    } else {
+        start = h3 % ((1ULL << 40) - len);
+        const uint64_t g = rev ? start + len - 1 - i : start + i;
+        const uint64_t c = syn_mix(R->seed ^ 0x3C0FFEE3ULL ^ (g >> 5));
+        b = (uint32_t)(c >> (2 * (g & 31))) & 3;
+    }
+    if (rev) b ^= 3;
+    const uint64_t hr = syn_mix(R->seed ^ 0xBADC0FFEE0DDF00DULL ^ (r * 131072 + i));
+    if ((uint32_t)(hr % 10000) < R->sub_per_10k) b = (b + 1 + (uint32_t)((hr >> 40) % 3)) & 3;
+    return (uint8_t)"ACGT"[b];
+}
+
 #endif

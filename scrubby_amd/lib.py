@@ -112,7 +112,7 @@ EXPORTS = [
     "sh_index_build", "sh_index_build_device", "sh_index_build_fasta", "sh_index_save", "sh_index_load",
     "sh_index_info_get", "sh_index_export", "sh_index_free",
     "sh_ctx_create", "sh_ctx_destroy", "sh_classify_device", "sh_classify_batch",
-    "sh_synth_ref_device", "sh_synth_reads_device", "sh_bench_gather",
+    "sh_synth_ref_device", "sh_synth_reads_device", "sh_synth_long_reads_device", "sh_bench_gather",
     "sh_reads_run", "sh_host_get_id", "sh_host_filter_fastx", "sh_host_read_difference",
     "sh_classifier_run", "sh_classifier_taxids", "sh_alignment_run",
 ]
@@ -150,6 +150,7 @@ def load():
     L.sh_classify_batch.argtypes = [vp, C.POINTER(Opts), vp, vp, u64, vp, vp, C.POINTER(Stats)]
     L.sh_synth_ref_device.argtypes = [C.POINTER(RefParams), u64, u64, vp, vp]
     L.sh_synth_reads_device.argtypes = [C.POINTER(RefParams), C.POINTER(ReadParams), u64, u64, vp, vp, vp]
+    L.sh_synth_long_reads_device.argtypes = [C.POINTER(RefParams), C.POINTER(ReadParams), u64, u64, vp, u64, vp, vp]
     L.sh_bench_gather.argtypes = [vp, u64, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.sh_reads_run.argtypes = [C.POINTER(ReadsConfig), C.POINTER(ReadsResult)]
     L.sh_classifier_run.argtypes = [C.POINTER(ClassifierConfig), C.POINTER(ReadsResult)]
@@ -430,3 +431,9 @@ def alignment_run(inputs, outputs, alignment, fmt=None, min_len=0, min_cov=0.0, 
     r = ReadsResult()
     check(load().sh_alignment_run(C.byref(c), C.byref(r)))
     return {n: getattr(r, n) for n, _ in ReadsResult._fields_}
+
+
+def synth_long_reads_device(P, R, r0, n_records, d_offsets, n_bases, out):
+    """Long reads of the config-4 stand-in; d_offsets: int64 CUDA tensor [n_records+1] (lengths from the CPU twin)."""
+    check(require_gpu().sh_synth_long_reads_device(C.byref(P), C.byref(R), r0, n_records, C.c_void_p(d_offsets.data_ptr()), n_bases,
+                                                  C.c_void_p(out.data_ptr()), _stream_ptr()))

@@ -229,3 +229,28 @@ def test_long_reads_map_ont(S, oracle, cfg1):
     of, ot = cidx.classify(oo, bases, offs, threads=8)
     assert_trace_equal(S, gf, gt, of, ot)
     assert int(gf.sum()) == 48 and int(gf[4::5].sum()) == 0      # every reference-derived read maps, no random one does
+
+
+def test_long_read_generator_device_matches_cpu(S, oracle):
+    """BASELINE config 4 stand-in: the device generator, its CPU twin and bench.py's numpy length ladder agree."""
+    import torch
+    import bench
+    Pg = S.ref_params(W.CFG1_REF_SEED, W.CFG1_CONTIGS)
+    Rg = S.read_params(0x5C2B0020, host_pct=50, sub_per_10k=500, n_read_pct=0)
+    Po = oracle.ref_params(W.CFG1_REF_SEED, W.CFG1_CONTIGS)
+    Ro = oracle.read_params(0x5C2B0020, host_pct=50, sub_per_10k=500, n_read_pct=0)
+    n = 300
+    cpu, offs = oracle.synth_long_reads(Po, Ro, 7, n)
+    assert np.array_equal(bench.long_read_lengths(0x5C2B0020, 7, n), np.diff(offs.astype(np.int64)).astype(np.uint32))
+    d_off = torch.from_numpy(offs.astype(np.int64)).cuda()
+    d = torch.empty(len(cpu) + 64, dtype=torch.uint8, device="cuda")
+    S.synth_long_reads_device(Pg, Rg, 7, n, d_off, len(cpu), d)
+    assert np.array_equal(d[:len(cpu)].cpu().numpy(), cpu)
+    # and they classify identically (map-ont, legacy long-read path)
+    seqs = [oracle.synth_ref(Po, Po.contig_start[i], 1_000_000) for i in range(5)]
+    gidx = S.Index.build([bytes(s) for s in seqs], S.preset("map-ont"))
+    cidx = oracle.Index.build(seqs, 10, 15)
+    oo = cidx.update_opts(oracle.preset("map-ont"))
+    gf, gt, st, rc = gidx.classify(cpu, offs, want_trace=True)
+    of, ot = cidx.classify(oo, cpu, offs, threads=8)
+    assert_trace_equal(S, gf, gt, of, ot)
