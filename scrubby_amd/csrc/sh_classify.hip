@@ -325,6 +325,185 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
     if (lane == 0) atomicAdd(&a.ctr->sh_mini[SHARD()], (unsigned long long)msum);
 }
 
+// ---- wave helpers ------------------------------------------------------------------------------------
+__device__ inline uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ inline uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+    return v;
+}
+__device__ inline uint32_t wave_excl_scan_u32(uint32_t v, uint32_t lane)
+{
+    uint32_t s = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)s, o); if (lane >= (uint32_t)o) s += t; }
+    return s - v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// long reads (any length): segment-parallel sketch, then per read thinning screen + probe + compaction
+// ------------------------------------------------------------------------------------------------
+#define LSEG 256u          // bases per sketch segment (plus w + k warm-up)
+
+struct LongArgs {
+    const uint8_t *bases; const uint64_t *offsets; uint64_t n_reads;
+    const uint4 *slots; uint32_t lg_slots; int32_t k;
+    uint32_t *seg_base;            // n_reads + 1: first segment of each read
+    uint32_t *seg_cnt;             // minimizers per segment
+    unsigned long long *seg_off;   // exclusive scan of seg_cnt (n_segs + 1)
+    uint64_t *mz_hash; uint32_t *mz_y; unsigned long long mz_cap;
+    uint4 *lrec;                   // seed records, compacted per read in place of its minimizers
+    unsigned long long *seed_off;  // per read
+    uint32_t *k1info; uint8_t *flags; sh_trace *trace;
+    uint32_t *work_big, *work_resketch; Counters *ctr;
+    int32_t mid_occ; uint32_t q_occ_max;
+    uint32_t *n_segs_out;
+};
+
+__global__ __launch_bounds__(64) void k_long_segtable(LongArgs a)
+{
+    const uint32_t lane = threadIdx.x;
+    uint32_t run = 0;
+    for (uint64_t base = 0; base < a.n_reads; base += 64) {
+        const uint64_t r = base + lane;
+        const uint32_t t = r < a.n_reads ? (uint32_t)((a.offsets[r + 1] - a.offsets[r] + LSEG - 1) / LSEG) : 0;
+        const uint32_t ex = wave_excl_scan_u32(t, lane);
+        if (r < a.n_reads) a.seg_base[r] = run + ex;
+        run += wave_sum_u32(t);
+    }
+    if (lane == 0) { a.seg_base[a.n_reads] = run; *a.n_segs_out = run; }
+}
+
+template <int W, bool EMIT>
+__global__ __launch_bounds__(256) void k_long_sketch(LongArgs a)
+{
+    const uint32_t n_segs = *a.n_segs_out;
+    for (uint32_t seg = blockIdx.x * 256 + threadIdx.x; seg < n_segs; seg += gridDim.x * 256) {
+        uint32_t lo = 0, hi = (uint32_t)a.n_reads;
+        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (a.seg_base[mid] <= seg) lo = mid; else hi = mid; }
+        const uint32_t r = lo;
+        const uint64_t o_beg = a.offsets[r];
+        const uint32_t len = (uint32_t)(a.offsets[r + 1] - o_beg);
+        const uint32_t start = (seg - a.seg_base[r]) * LSEG, end = start + LSEG < len ? start + LSEG : len;
+        const uint32_t warm = (uint32_t)(W + a.k), from = start > warm ? start - warm : 0;
+        const uint8_t *seq = a.bases + o_beg;
+        SketchState<W> st;
+        st.init(a.k);
+        uint32_t n = 0, cur = 0;
+        const unsigned long long o0 = EMIT ? a.seg_off[seg] : 0;
+        auto emit = [&](uint64_t x, uint32_t y) {
+            if (cur < start) return;
+            if (EMIT && o0 + n < a.mz_cap) { a.mz_hash[o0 + n] = x >> 8; a.mz_y[o0 + n] = y; }
+            ++n;
+        };
+        for (uint32_t i0 = from; i0 < end; i0 += W) {
+            auto one = [&](auto Pc) {
+                constexpr int Pk = decltype(Pc)::value;
+                const uint32_t i = i0 + Pk;
+                if (i < end) { cur = i; st.template step<Pk>(sh_nt4(seq[i]), i, emit); }
+            };
+            [&]<int... Ps>(std::integer_sequence<int, Ps...>) { (one(std::integral_constant<int, Ps>{}), ...); }
+            (std::make_integer_sequence<int, W>{});
+        }
+        if (end == len) { cur = end; st.finish(emit); }
+        if (!EMIT) a.seg_cnt[seg] = n;
+    }
+}
+
+// exclusive scan of seg_cnt[0..n] into seg_off[0..n] (n = n_segs, so seg_off[n] = total): one block, sequential chunks
+__global__ __launch_bounds__(1024) void k_long_scan(LongArgs a)
+{
+    __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned long long s_run;
+    const uint32_t n = *a.n_segs_out, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base <= n; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint32_t v = i < n ? a.seg_cnt[i] : 0;
+        const uint32_t ex = wave_excl_scan_u32(v, lane);
+        const uint32_t tot = wave_sum_u32(v);
+        if (lane == 0) s_wave[wv] = tot;
+        __syncthreads();
+        unsigned long long pre = s_run;
+        for (uint32_t q = 0; q < wv; ++q) pre += s_wave[q];
+        if (i <= n) a.seg_off[i] = pre + ex;
+        __syncthreads();
+        if (tid == 0) { unsigned long long t = 0; for (int q = 0; q < 16; ++q) t += s_wave[q]; s_run += t; }
+        __syncthreads();
+    }
+}
+
+// one wave per read: mm_seed_mz_flt screen, probes, compaction of the hits, routing
+__global__ __launch_bounds__(64) void k_long_probe(LongArgs a)
+{
+    __shared__ uint16_t s_cnt[4096];
+    const uint32_t lane = threadIdx.x;
+    uint32_t n_host_dummy = 0; (void)n_host_dummy;
+    for (uint64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+        const uint32_t len = (uint32_t)(a.offsets[r + 1] - a.offsets[r]);
+        const unsigned long long base = a.seg_off[a.seg_base[r]], top = a.seg_off[a.seg_base[r + 1]];
+        const unsigned long long n_mini = top - base;
+        bool legacy = top > a.mz_cap || n_mini >= 65536;         // out of room, or counts that do not fit k1info
+        if (!legacy && n_mini > a.q_occ_max) {
+            // mm_seed_mz_flt drops hashes repeated > mid_occ times within the query.  Screen: per-bin counts of the hash's
+            // low 12 bits bound the true counts from above; only reads with a bin above mid_occ need the exact version.
+            for (uint32_t i = lane; i < 4096; i += 64) s_cnt[i] = 0;
+            __syncthreads();
+            for (unsigned long long i = lane; i < n_mini; i += 64) {
+                uint32_t bin = (uint32_t)a.mz_hash[base + i] & 4095u;
+                atomicAdd((unsigned int *)&s_cnt[bin & ~1u], (bin & 1u) ? 0x10000u : 1u);      // two 16-bit counters per dword
+            }
+            __syncthreads();
+            uint32_t mx = 0;
+            for (uint32_t i = lane; i < 4096; i += 64) mx = s_cnt[i] > mx ? s_cnt[i] : mx;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { uint32_t v = (uint32_t)__shfl_xor((int)mx, o); mx = v > mx ? v : mx; }
+            legacy = mx > (uint32_t)a.mid_occ;
+            __syncthreads();
+        }
+        if (legacy || len == 0) {
+            if (lane == 0) { uint32_t i = atomicAdd(&a.ctr->n_resketch, 1u); a.work_resketch[i] = (uint32_t)r; }
+            continue;
+        }
+        const uint64_t slot_mask = (1ULL << a.lg_slots) - 1;
+        uint32_t n_seed = 0;
+        for (unsigned long long t0 = 0; t0 < n_mini; t0 += 64) {
+            const bool have = t0 + lane < n_mini;
+            uint4 sl = make_uint4(0, 0, 0, 0);
+            uint64_t w0 = SH_SLOT_EMPTY; uint32_t y = 0;
+            if (have) {
+                const uint64_t key = a.mz_hash[base + t0 + lane];
+                y = a.mz_y[base + t0 + lane];
+                uint64_t idx = sh_slot_home(key, a.lg_slots);
+                sl = a.slots[idx];
+                w0 = (uint64_t)sl.y << 32 | sl.x;
+                while (w0 != SH_SLOT_EMPTY && (w0 & SH_SLOT_KEYMASK) != key) { idx = (idx + 1) & slot_mask; sl = a.slots[idx]; w0 = (uint64_t)sl.y << 32 | sl.x; }
+            }
+            const bool hit = have && w0 != SH_SLOT_EMPTY;
+            const uint64_t hm = __ballot(hit);
+            if (hit) {
+                const uint32_t occ = (w0 & SH_SLOT_MULTI) ? (sl.z & (uint32_t)SH_SLOT_NMASK) : 1u;
+                a.lrec[base + n_seed + prefix_popc(hm)] = make_uint4(sl.z, sl.w, occ, y);
+            }
+            n_seed += (uint32_t)__popcll(hm);
+        }
+        if (lane == 0) {
+            a.k1info[r] = (uint32_t)n_mini | n_seed << 16;
+            a.seed_off[r] = base;
+            atomicAdd(&a.ctr->sh_mini[SHARD()], (unsigned long long)n_mini);
+            if (n_seed == 0) {
+                a.flags[r] = 0;
+                write_trace(a.trace, r, (int32_t)n_mini, 0, 0, 0, 0, 0, 0, 0);
+            } else {
+                uint32_t i = atomicAdd(&a.ctr->n_big[0], 1u);
+                a.work_big[i] = (uint32_t)r;
+            }
+        }
+    }
+}
+
 // route every read of the batch to K3 (k > 23 or reads too long for the LDS stage)
 __global__ void k_route_all(uint64_t n_reads, uint32_t *work_resketch, Counters *ctr)
 {
@@ -410,21 +589,6 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
     if (lane == 0 && n_host_wave) atomicAdd(&a.ctr->sh_host[SHARD()], n_host_wave);
 }
 
-// ---- wave helpers ------------------------------------------------------------------------------------
-__device__ inline uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
-__device__ inline uint32_t wave_sum_u32(uint32_t v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
-    return v;
-}
-__device__ inline uint32_t wave_excl_scan_u32(uint32_t v, uint32_t lane)
-{
-    uint32_t s = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)s, o); if (lane >= (uint32_t)o) s += t; }
-    return s - v;
-}
 // stable sort of the first n lanes' (x, q) by x: rank by comparison with every broadcast key, then push
 __device__ inline void wave_rank_sort(uint64_t &x, uint32_t &q, uint32_t n, uint32_t lane)
 {
@@ -523,6 +687,8 @@ struct K3Args {
     uint32_t *defer_list; uint32_t *defer_count;          // reads that found no arena space
     uint32_t *next_list; uint32_t *next_count;            // pass 0: reads that must re-chain with max_occ
     uint32_t *resketch_list;                              // reads this path cannot take (see k_expand)
+    const unsigned long long *seed_off;                   // long reads: first seed record of read r (nullptr: r * seed_cap)
+    uint32_t *sel_scratch;                                // long reads: >= 2 u32 per seed at [2 * seed_off[r]] for mm_seed_select
     Counters *ctr; BigBufs B; ChainParams P;
     int32_t pass, max_occ, flag_only, dbg;
 };
@@ -552,7 +718,8 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
         const int32_t qlen = (int32_t)(a.offsets[r + 1] - a.offsets[r]);
         const uint32_t n_st = (n_seed + 63) / 64;
         const bool no_keep = plain_cut || (int32_t)((double)qlen / (double)P.occ_dist + .499) <= 0;   // every streak has max_high_occ == 0
-        if (n_st > 1 && !no_keep) {
+        const bool general_mt = n_st > 1 && !no_keep && a.seed_off != nullptr;     // streak logic across seed tiles (long reads)
+        if (n_st > 1 && !no_keep && !general_mt) {
             if (lane == 0) {
                 BigMeta m{r, 0, 0, 2u};
                 a.B.meta[w] = m;
@@ -561,7 +728,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
             }
             continue;
         }
-        uint4 *recb = a.records + (size_t)r * a.seed_cap;
+        uint4 *recb = a.records + (a.seed_off ? (size_t)a.seed_off[r] : (size_t)r * a.seed_cap);
         // occurrence filter of seed tile t: my_n = anchors this lane's seed contributes (0 if filtered / absent)
         auto eval = [&](uint32_t t, uint4 &rec, uint32_t &my_n, bool &flt, bool &have) {
             const uint32_t sidx = t * 64 + lane;
@@ -571,6 +738,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
             const bool high = have && occ > (uint32_t)a.max_occ;
             flt = false;
             if (plain_cut) flt = high;
+            else if (general_mt) flt = (rec.z >> 31) != 0;      // decided by select_multi_tile below
             else if (n_st > 1) flt = high && n_seed >= 2;      // no_keep holds
             else {
                 const uint64_t hm = __ballot(high);
@@ -602,6 +770,57 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
             }
             my_n = (have && !flt) ? occ : 0u;
         };
+        if (general_mt) {
+            // mm_seed_select over more than 64 seeds.  Forward sweep: index of the nearest low-occurrence seed before
+            // each seed; backward sweep: the one after it, then the streak's max_high_occ and the seed's rank in it.
+            uint32_t *scr = a.sel_scratch + 2 * (size_t)a.seed_off[r];
+            int32_t carry = -1;
+            uint32_t n_high_total = 0;
+            for (uint32_t t = 0; t < n_st; ++t) {
+                const uint32_t sidx = t * 64 + lane;
+                const bool have = sidx < n_seed;
+                const uint32_t occ = have ? recb[sidx].z & 0x7fffffffu : 0u;
+                const bool high = have && occ > (uint32_t)a.max_occ;
+                const uint64_t low = __ballot(have && !high);
+                const uint64_t below = low & ((1ULL << lane) - 1);
+                const int32_t prev = below ? (int32_t)(t * 64) + 63 - __clzll((unsigned long long)below) : carry;
+                if (have) scr[2 * sidx] = (uint32_t)prev;
+                if (low) carry = (int32_t)(t * 64) + 63 - __clzll((unsigned long long)low);
+                n_high_total += (uint32_t)__popcll(__ballot(high));
+            }
+            int32_t carry_next = (int32_t)n_seed;
+            for (int32_t t = (int32_t)n_st - 1; t >= 0; --t) {
+                const uint32_t sidx = (uint32_t)t * 64 + lane;
+                const bool have = sidx < n_seed;
+                const uint4 rec = have ? recb[sidx] : make_uint4(0, 0, 0, 0);
+                const uint32_t occ = rec.z & 0x7fffffffu;
+                const bool high = have && occ > (uint32_t)a.max_occ;
+                const uint64_t low = __ballot(have && !high);
+                const uint64_t above = lane >= 63 ? 0 : low & ~((2ULL << lane) - 1);
+                const int32_t nxt = above ? t * 64 + (int32_t)__ffsll((unsigned long long)above) - 1 : carry_next;
+                bool flt = false;
+                if (high && n_seed >= 2 && n_high_total > 0) {
+                    const int32_t last0 = (int32_t)scr[2 * sidx];
+                    const int32_t ps = last0 < 0 ? 0 : (int32_t)(recb[last0].w >> 1);
+                    const int32_t pe = nxt >= (int32_t)n_seed ? qlen : (int32_t)(recb[nxt].w >> 1);
+                    int32_t mho = (int32_t)((double)(pe - ps) / (double)P.occ_dist + .499);
+                    if (mho > 128) mho = 128;
+                    flt = true;
+                    if (mho > 0) {      // keep the mho smallest by (occ, index) of the streak (last0, nxt)
+                        int32_t rank = 0;
+                        for (int32_t u = last0 + 1; u < nxt && rank < mho; ++u) {
+                            const uint32_t ou = recb[u].z & 0x7fffffffu;
+                            rank += (ou < occ) || (ou == occ && u < (int32_t)sidx);
+                        }
+                        if (rank < mho) flt = false;
+                    }
+                    if (occ > (uint32_t)P.max_max_occ) flt = true;
+                }
+                if (have) recb[sidx].z = occ | (uint32_t)flt << 31;
+                if (low) carry_next = t * 64 + (int32_t)__ffsll((unsigned long long)low) - 1;
+            }
+            __syncthreads();
+        }
         // ---- pass 1 over the seed tiles: anchor count and rep_len ----
         uint4 rec0 = make_uint4(0, 0, 0, 0); uint32_t my_n0 = 0; bool flt0 = false, have0 = false;
         unsigned long long n_part = 0;
