@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--small", action="store_true", help="5 Mb reference / 200k records (plumbing check)")
     ap.add_argument("--workload", choices=["sr", "ont"], default="sr",
                     help="sr = BASELINE configs[1] (headline); ont = configs[3] stand-in: long noisy reads, map-ont preset (not the headline metric)")
+    ap.add_argument("--ont-chunk", type=int, default=1 << 16, help="long reads per launch (--workload ont)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather-bench", action="store_true", help="also time raw 16-B random gathers over the table")
@@ -99,7 +100,7 @@ def main():
         d_off = torch.from_numpy(off_np).to(dev)
         d_reads = torch.empty(n_bases + 64, dtype=torch.uint8, device=dev)
         S.synth_long_reads_device(P, R, rank * n_rec, n_rec, d_off, n_bases, d_reads)
-        a.chunk = min(a.chunk, 1 << 16)
+        a.chunk = min(a.chunk, a.ont_chunk)
         ctx = S.Context(index, min(a.chunk, n_rec), n_bases, int(lens.max()))
     else:
         n_bases = n_rec * L
@@ -205,7 +206,7 @@ def main():
             "union_bytes_gathered": union["bytes"],
             "config": {
                 "workload": ("configs[3] stand-in: %d long reads (log-normal-like lengths, median 5.4 kb, 5 %% substitutions), map-ont preset; "
-                             "legacy lane-per-read kernel (long-read kernels are not built yet)" % n_rec if ont else
+                             "segment-parallel long-read front end + repeat path" % n_rec if ont else
                              "cfg1-small: 200k records vs 5 Mb" if a.small else
                              "configs[1]: 10M synthetic 2x150bp PE (20M records) vs CHM13v2-sized synthetic reference, sr preset, k-mer/minimizer classifier path"),
                 "records_per_gpu": n_rec, "read_len": L, "host_pct": R.host_pct, "reference_bp": int(G),

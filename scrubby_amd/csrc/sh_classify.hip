@@ -57,6 +57,8 @@ __device__ inline uint32_t lane_id() { return threadIdx.x & 63; }
 struct Counters {
     uint32_t n_small, n_resketch, n_big[2], n_big_defer[2], n_defer, pad0;
     uint32_t n_sort[N_SORT_CLS], n_giant_tiles, n_giant_rounds;
+    uint32_t n_long_segs, pad2;
+    uint32_t n_leg_reason[4];     // why reads left the long-read front end: 0 room/segments, 1 thinning screen, 2 anchors beyond the giant path, 3 unused
     unsigned long long arena_cursor, anchor_cursor;
     unsigned long long sh_mini[64], sh_anchors[64];     // sharded sums
     uint32_t sh_host[64], sh_clusters[64];
@@ -357,8 +359,8 @@ struct LongArgs {
     unsigned long long *seed_off;  // per read
     uint32_t *k1info; uint8_t *flags; sh_trace *trace;
     uint32_t *work_big, *work_resketch; Counters *ctr;
-    int32_t mid_occ; uint32_t q_occ_max;
-    uint32_t *n_segs_out;
+    int32_t mid_occ; uint32_t q_occ_max; float q_occ_frac;
+    uint32_t *n_segs_out; uint32_t max_segs;
 };
 
 __global__ __launch_bounds__(64) void k_long_segtable(LongArgs a)
@@ -367,7 +369,18 @@ __global__ __launch_bounds__(64) void k_long_segtable(LongArgs a)
     uint32_t run = 0;
     for (uint64_t base = 0; base < a.n_reads; base += 64) {
         const uint64_t r = base + lane;
-        const uint32_t t = r < a.n_reads ? (uint32_t)((a.offsets[r + 1] - a.offsets[r] + LSEG - 1) / LSEG) : 0;
+        uint32_t t = r < a.n_reads ? (uint32_t)((a.offsets[r + 1] - a.offsets[r] + LSEG - 1) / LSEG) : 0;
+        // a chunk with more bases than the context was sized for: the reads past the segment table get no segments
+        // (k_long_probe sends them to the legacy path)
+        if (__ballot((uint64_t)run + wave_excl_scan_u32(t, lane) + t > a.max_segs) != 0) {
+            uint32_t acc = run;
+            for (uint32_t l = 0; l < 64; ++l) {
+                uint32_t tl = rdlane(t, l);
+                if ((uint64_t)acc + tl > a.max_segs) tl = 0;
+                if (lane == l) t = tl;
+                acc += tl;
+            }
+        }
         const uint32_t ex = wave_excl_scan_u32(t, lane);
         if (r < a.n_reads) a.seg_base[r] = run + ex;
         run += wave_sum_u32(t);
@@ -438,17 +451,22 @@ __global__ __launch_bounds__(1024) void k_long_scan(LongArgs a)
 // one wave per read: mm_seed_mz_flt screen, probes, compaction of the hits, routing
 __global__ __launch_bounds__(64) void k_long_probe(LongArgs a)
 {
+    constexpr uint32_t LT_CAP = 4096;          // distinct hashes of the over-full bins of one read
     __shared__ uint16_t s_cnt[4096];
+    __shared__ uint64_t s_tkey[LT_CAP];
+    __shared__ uint32_t s_tcnt[LT_CAP], s_tover;
     const uint32_t lane = threadIdx.x;
-    uint32_t n_host_dummy = 0; (void)n_host_dummy;
     for (uint64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
         const uint32_t len = (uint32_t)(a.offsets[r + 1] - a.offsets[r]);
         const unsigned long long base = a.seg_off[a.seg_base[r]], top = a.seg_off[a.seg_base[r + 1]];
-        const unsigned long long n_mini = top - base;
+        unsigned long long n_mini = top - base;
         bool legacy = top > a.mz_cap || n_mini >= 65536;         // out of room, or counts that do not fit k1info
+        legacy |= a.seg_base[r + 1] - a.seg_base[r] != (len + LSEG - 1) / LSEG;
         if (!legacy && n_mini > a.q_occ_max) {
-            // mm_seed_mz_flt drops hashes repeated > mid_occ times within the query.  Screen: per-bin counts of the hash's
-            // low 12 bits bound the true counts from above; only reads with a bin above mid_occ need the exact version.
+            // mm_seed_mz_flt drops hashes repeated within the query more than mid_occ times and more
+            // than q_occ_frac of all minimizers.  Screen: per-bin counts of the hash's low 12 bits bound the true counts
+            // from above.  Reads with a bin above mid_occ (satellite reads) count the hashes of those bins exactly in an
+            // LDS table and compact the survivors in place.
             for (uint32_t i = lane; i < 4096; i += 64) s_cnt[i] = 0;
             __syncthreads();
             for (unsigned long long i = lane; i < n_mini; i += 64) {
@@ -460,7 +478,47 @@ __global__ __launch_bounds__(64) void k_long_probe(LongArgs a)
             for (uint32_t i = lane; i < 4096; i += 64) mx = s_cnt[i] > mx ? s_cnt[i] : mx;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { uint32_t v = (uint32_t)__shfl_xor((int)mx, o); mx = v > mx ? v : mx; }
-            legacy = mx > (uint32_t)a.mid_occ;
+            if (mx > (uint32_t)a.mid_occ) {
+                for (uint32_t i = lane; i < LT_CAP; i += 64) { s_tkey[i] = ~0ull; s_tcnt[i] = 0; }
+                if (lane == 0) s_tover = 0;
+                __syncthreads();
+                for (unsigned long long i = lane; i < n_mini; i += 64) {
+                    const uint64_t key = a.mz_hash[base + i];
+                    if (s_cnt[(uint32_t)key & 4095u] <= (uint32_t)a.mid_occ) continue;
+                    uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> 52) & (LT_CAP - 1);
+                    for (uint32_t step = 0;; ++step) {
+                        if (step >= LT_CAP / 2) { s_tover = 1; break; }      // table (nearly) full: legacy path
+                        unsigned long long prev = atomicCAS((unsigned long long *)&s_tkey[slot], ~0ull, (unsigned long long)key);
+                        if (prev == ~0ull || prev == key) { atomicAdd(&s_tcnt[slot], 1u); break; }
+                        slot = (slot + 1) & (LT_CAP - 1);
+                    }
+                }
+                __syncthreads();
+                if (s_tover) {
+                    legacy = true;
+                    if (lane == 0) atomicAdd(&a.ctr->n_leg_reason[1], 1u);
+                } else {
+                    const float lim = (float)n_mini * a.q_occ_frac;
+                    unsigned long long kept = 0;
+                    for (unsigned long long t0 = 0; t0 < n_mini; t0 += 64) {
+                        const bool have = t0 + lane < n_mini;
+                        uint64_t key = 0; uint32_t y = 0; bool keep = have;
+                        if (have) {
+                            key = a.mz_hash[base + t0 + lane]; y = a.mz_y[base + t0 + lane];
+                            if (s_cnt[(uint32_t)key & 4095u] > (uint32_t)a.mid_occ) {
+                                uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> 52) & (LT_CAP - 1);
+                                while (s_tkey[slot] != key) slot = (slot + 1) & (LT_CAP - 1);      // present: inserted above
+                                const uint32_t cnt = s_tcnt[slot];
+                                keep = !(cnt > (uint32_t)a.mid_occ && (float)cnt > lim);
+                            }
+                        }
+                        const uint64_t km = __ballot(keep);
+                        if (keep) { a.mz_hash[base + kept + prefix_popc(km)] = key; a.mz_y[base + kept + prefix_popc(km)] = y; }
+                        kept += (unsigned long long)__popcll(km);
+                    }
+                    n_mini = kept;
+                }
+            }
             __syncthreads();
         }
         if (legacy || len == 0) {
@@ -847,6 +905,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
 
         if (n_a > (GT << 8)) {             // beyond the giant path's 8 merge rounds: legacy path (never for sr: <= 22 x 5000)
             if (lane == 0) {
+                atomicAdd(&a.ctr->n_leg_reason[2], 1u);
                 BigMeta m{r, 0, 0, 2u};
                 a.B.meta[w] = m;
                 uint32_t i = atomicAdd(&a.ctr->n_resketch, 1u);
@@ -1358,6 +1417,11 @@ struct sh_ctx {
     uint64_t arena_bytes = 0, legacy_bytes = 0;
     BigBufs B{};
     hipEvent_t ev[5] = {};
+    bool use_long = false;           // reads longer than K1 takes: segment-parallel long-read front end
+    uint8_t *d_long = nullptr; uint64_t long_bytes = 0, mz_cap = 0, max_segs = 0;
+    uint32_t *d_seg_base = nullptr, *d_seg_cnt = nullptr, *d_mz_y = nullptr;
+    unsigned long long *d_seg_off = nullptr, *d_seed_off = nullptr;
+    uint64_t *d_mz_hash = nullptr; uint4 *d_lrec = nullptr;
     hipStream_t sx[4] = {};          // side streams: K2 and the sort classes run beside the main stream
     int par = 1;                     // bit 0: K2 on a side stream (+2 %), bit 1: sort classes side by side (measured: -9 %, off) (SCRUBBY_HIP_STREAMS)
     hipEvent_t evx[6] = {};
@@ -1420,11 +1484,15 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
     if ((e = hipMalloc(&c->d_arena, c->arena_bytes)) != hipSuccess) return fail(e, "arena");
     {
         const uint64_t big_min = (64ull << 20) + max_reads * 160;
-        c->legacy_bytes = c->use_k1 ? std::min<uint64_t>(c->arena_bytes / 8, 1ull << 30)
-                                    : (c->arena_bytes > 2 * big_min ? c->arena_bytes - big_min : c->arena_bytes / 2);
+        const bool long_fe = !c->use_k1 && w_supported(opts->w);      // the long-read front end feeds the repeat path
+        c->legacy_bytes = (c->use_k1 || long_fe) ? std::min<uint64_t>(c->arena_bytes / 8, 1ull << 30)
+                                                 : (c->arena_bytes > 2 * big_min ? c->arena_bytes - big_min : c->arena_bytes / 2);
         uint8_t *p = c->d_arena + c->legacy_bytes;
         uint64_t left = c->arena_bytes - c->legacy_bytes;
-        uint64_t fixed = max_reads * (sizeof(BigMeta) + 8 + N_SORT_CLS * sizeof(SortItem) + 8) + 16384;
+        // k_expand's waves reserve sort-list entries in chunks (<= 32): up to one abandoned chunk per wave and class
+        const uint64_t waves = 2 * std::min<uint64_t>(std::max<uint64_t>(n_tiles, 1), 256 * 8);      // k_expand's grid (big_pass)
+        const uint64_t sort_cap[N_SORT_CLS] = {max_reads + 32 * waves, max_reads + 8 * waves, max_reads + waves, max_reads + waves};
+        uint64_t fixed = max_reads * (sizeof(BigMeta) + 8 + 8) + (sort_cap[0] + sort_cap[1] + sort_cap[2] + sort_cap[3]) * sizeof(SortItem) + 16384;
         uint64_t per_anchor = 8 + 8 + 8 + 4 + 4 + 4 + 1;   // ax bx az aq bq af (+ tile_split share)
         uint64_t cap = left > fixed ? (left - fixed) / per_anchor : 0;
         cap &= ~15ull;
@@ -1437,12 +1505,26 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         B.af = (int32_t *)take(cap * 4);
         B.meta = (BigMeta *)take(max_reads * sizeof(BigMeta));
         B.acc_nu = (int32_t *)take(max_reads * 4); B.acc_best = (int32_t *)take(max_reads * 4);
-        for (int i = 0; i < N_SORT_CLS; ++i) B.sort_items[i] = (SortItem *)take(max_reads * sizeof(SortItem));
+        for (int i = 0; i < N_SORT_CLS; ++i) B.sort_items[i] = (SortItem *)take(sort_cap[i] * sizeof(SortItem));
         B.tile_base = (uint32_t *)take((max_reads + 1) * 4);
         B.tile_split = (uint32_t *)take((cap / GT + max_reads + 2) * 4);
         if ((uint64_t)(p - c->d_arena) > c->arena_bytes) {   // alignment slack: shrink
             sh_set_error("sh_ctx_create: internal arena carve overflow"); sh_ctx_destroy(c); return SH_ERR_OOM;
         }
+    }
+    c->use_long = !c->use_k1 && w_supported(opts->w);
+    if (c->use_long) {
+        const uint64_t cb = std::min<uint64_t>(max_bases + 64, max_reads * (uint64_t)max_read_len + 64);     // bases of one chunk, at most
+        c->max_segs = cb / LSEG + max_reads + 2;
+        c->mz_cap = cb * 5 / (2 * ((uint64_t)opts->w + 1)) + 4096;   // minimizer density is ~2/(w+1), + 25 %; reads beyond the cap take the legacy path
+        auto al = [](uint64_t b) { return (b + 255) & ~255ull; };
+        c->long_bytes = al((max_reads + 1) * 4) + al(c->max_segs * 4) + al((c->max_segs + 1) * 8) + al(c->mz_cap * 8) + al(c->mz_cap * 4) + al(c->mz_cap * 16) + al(max_reads * 8);
+        if ((e = hipMalloc(&c->d_long, c->long_bytes)) != hipSuccess) return fail(e, "long-read buffers");
+        uint8_t *p = c->d_long;
+        auto take = [&](uint64_t b) { uint8_t *q = p; p += al(b); return q; };
+        c->d_seg_base = (uint32_t *)take((max_reads + 1) * 4); c->d_seg_cnt = (uint32_t *)take(c->max_segs * 4);
+        c->d_seg_off = (unsigned long long *)take((c->max_segs + 1) * 8); c->d_mz_hash = (uint64_t *)take(c->mz_cap * 8);
+        c->d_mz_y = (uint32_t *)take(c->mz_cap * 4); c->d_lrec = (uint4 *)take(c->mz_cap * 16); c->d_seed_off = (unsigned long long *)take(max_reads * 8);
     }
     for (auto &ev : c->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "event");
     for (auto &ev : c->evx) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "event");
@@ -1458,7 +1540,7 @@ extern "C" sh_status sh_ctx_destroy(sh_ctx *c)
     hipFree(c->d_records); hipFree(c->d_k1info); hipFree(c->d_work_small); hipFree(c->d_work_resketch);
     hipFree(c->d_work_defer); hipFree(c->d_work_defer2);
     for (auto &pp : c->d_big) for (auto p : pp) hipFree(p);
-    hipFree(c->d_ctr); if (c->h_ctr) hipHostFree(c->h_ctr); hipFree(c->d_arena);
+    hipFree(c->d_ctr); if (c->h_ctr) hipHostFree(c->h_ctr); hipFree(c->d_arena); hipFree(c->d_long);
     for (auto ev : c->ev) if (ev) hipEventDestroy(ev);
     for (auto ev : c->evx) if (ev) hipEventDestroy(ev);
     for (auto st : c->sx) if (st) hipStreamDestroy(st);
@@ -1470,6 +1552,16 @@ template <int W>
 static void launch_k1(const K1Args &a, uint32_t n_tiles, size_t lds, hipStream_t s)
 {
     hipLaunchKernelGGL(k_sketch_probe<W>, dim3(n_tiles), dim3(64), lds, s, a);
+}
+
+template <int W>
+static void launch_long(const LongArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_long_segtable, dim3(1), dim3(64), 0, s, a);
+    hipLaunchKernelGGL((k_long_sketch<W, false>), dim3(256 * 8), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_long_scan, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL((k_long_sketch<W, true>), dim3(256 * 8), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_long_probe, dim3(256 * 16), dim3(64), 0, s, a);
 }
 
 // one pass of the repeat path over list[*count]: expand -> sort -> DP -> finalize
@@ -1526,6 +1618,25 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         case 19: launch_k1<19>(a, n_tiles, lds, s); break;
         default: sh_set_error("unsupported w"); return SH_ERR_BAD_ARG;
         }
+    } else if (c->use_long) {
+        LongArgs a{};
+        a.bases = d_bases; a.offsets = d_offsets; a.n_reads = n_reads;
+        a.slots = (const uint4 *)idx->d_slots; a.lg_slots = idx->lg_slots; a.k = idx->k;
+        a.seg_base = c->d_seg_base; a.seg_cnt = c->d_seg_cnt; a.seg_off = c->d_seg_off;
+        a.mz_hash = c->d_mz_hash; a.mz_y = c->d_mz_y; a.mz_cap = c->mz_cap; a.lrec = c->d_lrec; a.seed_off = c->d_seed_off;
+        a.k1info = c->d_k1info; a.flags = d_flags; a.trace = d_trace;
+        a.work_big = c->d_big[0][0]; a.work_resketch = c->d_work_resketch; a.ctr = c->d_ctr;
+        a.mid_occ = c->P.mid_occ;
+        a.q_occ_max = (c->P.q_occ_frac > 0.0f && c->P.mid_occ > 0) ? (uint32_t)c->P.mid_occ : UINT32_MAX;
+        a.q_occ_frac = c->P.q_occ_frac;
+        a.n_segs_out = &c->d_ctr->n_long_segs; a.max_segs = (uint32_t)std::min<uint64_t>(c->max_segs, UINT32_MAX);
+        switch (idx->w) {
+        case 5: launch_long<5>(a, s); break;
+        case 10: launch_long<10>(a, s); break;
+        case 11: launch_long<11>(a, s); break;
+        case 19: launch_long<19>(a, s); break;
+        default: sh_set_error("unsupported w"); return SH_ERR_BAD_ARG;
+        }
     } else {
         hipLaunchKernelGGL(k_route_all, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, s, n_reads, c->d_work_resketch, c->d_ctr);
     }
@@ -1553,7 +1664,8 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     } else SH_HIP(hipEventRecord(c->ev[2], s));
 
     K3Args k{};
-    k.offsets = d_offsets; k.positions = idx->d_positions; k.records = c->d_records; k.seed_cap = c->seed_cap;
+    k.offsets = d_offsets; k.positions = idx->d_positions; k.records = c->use_long ? c->d_lrec : c->d_records; k.seed_cap = c->seed_cap;
+    k.seed_off = c->use_long ? c->d_seed_off : nullptr; k.sel_scratch = c->use_long ? (uint32_t *)c->d_mz_hash : nullptr;
     k.k1info = c->d_k1info; k.flags = d_flags; k.trace = d_trace; k.ctr = c->d_ctr; k.B = c->B; k.P = c->P;
     k.flag_only = d_trace == nullptr;
     k.dbg = getenv("SCRUBBY_HIP_DBG") ? atoi(getenv("SCRUBBY_HIP_DBG")) : 0;
@@ -1586,6 +1698,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         SH_HIP(hipStreamSynchronize(s));
         SH_HIP(hipGetLastError());
         if (first) { snap = *c->h_ctr; first = false; }
+        if (k.dbg & 16) fprintf(stderr, "[dbg] iter %d resketch %u reasons %u %u %u segs %u big %u/%u defer %u/%u\n", iter, c->h_ctr->n_resketch, c->h_ctr->n_leg_reason[0], c->h_ctr->n_leg_reason[1], c->h_ctr->n_leg_reason[2], c->h_ctr->n_long_segs, c->h_ctr->n_big[0], c->h_ctr->n_big[1], c->h_ctr->n_big_defer[0], c->h_ctr->n_big_defer[1]);
         resk_done = c->h_ctr->n_resketch;
         const uint32_t d0 = c->h_ctr->n_big_defer[0], d1 = c->h_ctr->n_big_defer[1];
         if (d0 == 0 && d1 == 0) break;
