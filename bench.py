@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--small", action="store_true", help="5 Mb reference / 200k records (plumbing check)")
     ap.add_argument("--workload", choices=["sr", "ont"], default="sr",
                     help="sr = BASELINE configs[1] (headline); ont = configs[3] stand-in: long noisy reads, map-ont preset (not the headline metric)")
-    ap.add_argument("--ont-chunk", type=int, default=1 << 16, help="long reads per launch (--workload ont)")
+    ap.add_argument("--ont-chunk", type=int, default=1 << 25, help="long reads per launch (--workload ont)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather-bench", action="store_true", help="also time raw 16-B random gathers over the table")

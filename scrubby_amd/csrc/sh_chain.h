@@ -593,6 +593,201 @@ __device__ inline void chain_dp_wave(const SliceStore &S, int n, int32_t qlen, c
     }
 }
 
+// ---- wave scans on the DPP network (gfx9: row_shr within rows of 16, row_bcast:15 / :31 across rows, wave_shr:1) ----
+template <int CTRL, int ROWS>
+__device__ inline int32_t dpp_mov(int32_t old, int32_t v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROWS, 0xf, false); }
+
+__device__ inline int32_t wave_scan_max_incl(int32_t v)
+{
+    int32_t t;
+    t = dpp_mov<0x111, 0xf>(INT32_MIN, v); v = t > v ? t : v;
+    t = dpp_mov<0x112, 0xf>(INT32_MIN, v); v = t > v ? t : v;
+    t = dpp_mov<0x114, 0xf>(INT32_MIN, v); v = t > v ? t : v;
+    t = dpp_mov<0x118, 0xf>(INT32_MIN, v); v = t > v ? t : v;
+    t = dpp_mov<0x142, 0xa>(INT32_MIN, v); v = t > v ? t : v;
+    t = dpp_mov<0x143, 0xc>(INT32_MIN, v); v = t > v ? t : v;
+    return v;
+}
+// lane l receives lane l-1's value, lane 0 receives `fill`
+__device__ inline int32_t wave_shr1(int32_t v, int32_t fill) { return dpp_mov<0x138, 0xf>(fill, v); }
+
+// inclusive prefix composition (lane order) of the functions x -> max(x + a, b)
+#define SH_COMP_STEP(CTRL, ROWS) { const int32_t pa = dpp_mov<CTRL, ROWS>(0, a), pb = dpp_mov<CTRL, ROWS>(-(1 << 29), b); \
+                                   const int32_t nb = pb + a > b ? pb + a : b; a = pa + a; b = nb; }
+__device__ inline void wave_scan_compose(int32_t &a, int32_t &b)
+{
+    SH_COMP_STEP(0x111, 0xf) SH_COMP_STEP(0x112, 0xf) SH_COMP_STEP(0x114, 0xf) SH_COMP_STEP(0x118, 0xf)
+    SH_COMP_STEP(0x142, 0xa) SH_COMP_STEP(0x143, 0xc)
+}
+
+// ---- wave-cooperative DP with the recent anchors in LDS -------------------------------------------------------------
+// Same exact scheme as chain_dp_wave, built for clusters of thousands of anchors (the true locus of a long read):
+// the last RING_WIN anchors' (x, q, f, p, t) live in a per-wave LDS ring, so a step whose scan ends within that
+// window - nearly all of them, max_skip ends a scan after a few dozen predecessors - never waits for HBM/L2.  Older
+// predecessors are read from the arena arrays (f, p are written through), their t marks live in the arena too: for a
+// given i an anchor is either inside the window or not, so its mark for that i has exactly one home.
+#define RING_CAP 256
+#define RING_WIN 192
+struct RingMem { uint32_t x[RING_CAP], q[RING_CAP]; int32_t f[RING_CAP], p[RING_CAP], t[RING_CAP]; };
+
+__device__ inline void chain_dp_ring(const uint64_t *gx, const uint32_t *gq, int32_t *gf, int32_t *gpt, int n, int32_t qlen,
+                                     const ChainParams &P, uint32_t lane, RingMem *rm)
+{
+    int32_t max_dist_y = P.is_sr ? (qlen > P.max_gap ? qlen : P.max_gap) : P.max_gap;
+    int32_t max_dist_x;
+    if (P.max_gap_ref > 0) max_dist_x = P.max_gap_ref;
+    else if (P.max_frag_len > 0) { max_dist_x = P.max_frag_len - qlen; if (max_dist_x < P.max_gap) max_dist_x = P.max_gap; }
+    else max_dist_x = P.max_gap;
+    if (max_dist_x < P.bw) max_dist_x = P.bw;
+    if (max_dist_y < P.bw) max_dist_y = P.bw;
+    constexpr int M = RING_CAP - 1;
+    volatile uint32_t *rx = rm->x, *rq = rm->q; volatile int32_t *rf = rm->f, *rp = rm->p, *rt = rm->t;
+    volatile const uint64_t *vx = gx; volatile const uint32_t *vq = gq; volatile int32_t *vf = gf, *vpt = gpt;
+    const int NEG = -(1 << 28);
+
+    for (int i = (int)lane; i < n; i += 64) gpt[2 * i + 1] = 0;      // stale arena contents must never equal a later i
+    wave_mem_sync();
+    int st = 0, sb = 0, max_ii = -1;
+    uint32_t sxv = (int)lane < n ? (uint32_t)gx[lane] : 0xffffffffu;      // x of anchor sb + lane (start-of-window search)
+    uint32_t mi_x = 0, mi_q = 0; int32_t mi_f = 0;                           // anchor max_ii
+    uint32_t nx = 0, nq = 0;                                                  // anchors of the current block of 64
+    for (int i = 0; i < n; ++i) {
+        if ((i & 63) == 0) {
+            const int a = i + (int)lane;
+            nx = a < n ? (uint32_t)gx[a] : 0u; nq = a < n ? gq[a] & 0x7fffffffu : 0u;
+            rx[a & M] = nx; rq[a & M] = nq; rt[a & M] = -1;               // overwrites anchors [i-256, i-193]: outside every window of this block
+        }
+        const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)nx, i & 63), qi = (uint32_t)__builtin_amdgcn_readlane((int)nq, i & 63);
+        for (;;) {      // while (st < i && x[i] > x[st] + max_dist_x) ++st, 64 candidates at a time
+            const int idx = sb + (int)lane;
+            const bool ok = idx >= i || (uint64_t)li <= (uint64_t)sxv + (uint64_t)max_dist_x;
+            const uint64_t m = __ballot(idx >= st && ok);
+            if (m) { st = sb + __ffsll((unsigned long long)m) - 1; break; }
+            sb += 64;
+            const int a = sb + (int)lane;
+            sxv = a < n ? (uint32_t)gx[a] : 0xffffffffu;
+        }
+        if (i - st > P.max_iter) st = i - P.max_iter;
+        int32_t max_f = P.k, n_skip = 0;
+        int max_j = -1, end_j = st - 1;
+        bool synced = false;
+        int c = 0;
+        for (int jb = i - 1; jb >= st; jb -= 64, ++c) {
+            const int j = jb - (int)lane;
+            const bool valid = j >= st;
+            const bool inw = c < RING_WIN / 64;             // the whole chunk is inside the ring window
+            if (!inw && !synced) { wave_mem_sync(); synced = true; }
+            uint32_t xj = 0, qj = 0; int32_t fj = 0, pj = -1;
+            if (valid) {
+                if (inw) { const int sl = j & M; xj = rx[sl]; qj = rq[sl]; fj = rf[sl]; pj = rp[sl]; }
+                else { xj = (uint32_t)vx[j]; qj = vq[j] & 0x7fffffffu; fj = vf[j]; pj = vpt[2 * j]; }
+            }
+            int32_t sc = SH_SC_NONE;
+            if (valid) sc = comput_sc(li, qi, xj, qj, max_dist_x, max_dist_y, P);
+            const bool has = valid && sc != SH_SC_NONE;
+            if (has) sc += fj;
+            if (has && pj >= 0) { if (pj >= i - RING_WIN) rt[pj & M] = i; else vpt[2 * pj + 1] = i; }
+            if (!inw) wave_mem_sync();
+            bool is_t = false;
+            if (has) is_t = (inw ? rt[j & M] : vpt[2 * j + 1]) == i;
+            // exclusive prefix maximum in scan order (lane 0 = j = jb first), seeded with the running max_f
+            const int32_t incl = wave_scan_max_incl(has ? sc : INT32_MIN);
+            int32_t excl = wave_shr1(incl, INT32_MIN);
+            if (excl < max_f) excl = max_f;
+            const bool new_max = has && sc > excl;
+            const bool inc_ev = has && !new_max && is_t;
+            int32_t ca = new_max ? -1 : (inc_ev ? 1 : 0), cb = new_max ? 0 : NEG;
+            wave_scan_compose(ca, cb);
+            const int32_t val = n_skip + ca > cb ? n_skip + ca : cb;
+            const uint64_t brk = __ballot(inc_ev && val > P.max_skip);
+            const int L = brk ? __ffsll((unsigned long long)brk) - 1 : 63;
+            const int32_t mm = __builtin_amdgcn_readlane(incl, L);      // max over the lanes up to the break point
+            if (mm > max_f) {
+                max_f = mm;
+                const uint64_t eq = __ballot((int)lane <= L && has && sc == mm);
+                max_j = jb - (__ffsll((unsigned long long)eq) - 1);
+            }
+            n_skip = __builtin_amdgcn_readlane(val, L);
+            if (brk) { end_j = jb - L; break; }
+        }
+        // the max_ii shortcut (uniform)
+        bool far = true;
+        if (max_ii >= 0) far = (uint64_t)(li - mi_x) > (uint64_t)max_dist_x;
+        if (max_ii < 0 || far) {
+            int32_t bf = INT32_MIN; int bj = -1;
+            int c2 = 0;
+            for (int jb = i - 1; jb >= st; jb -= 64, ++c2) {
+                const int j = jb - (int)lane;
+                const bool inw = c2 < RING_WIN / 64;
+                if (!inw && !synced) { wave_mem_sync(); synced = true; }
+                int32_t fj = INT32_MIN;
+                if (j >= st) fj = inw ? rf[j & M] : vf[j];
+                int32_t cm = fj;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { int32_t t = __shfl_xor(cm, o); cm = t > cm ? t : cm; }
+                if (cm > bf) { bf = cm; bj = jb - (__ffsll((unsigned long long)__ballot(j >= st && fj == cm)) - 1); }
+            }
+            max_ii = bj;
+            if (bj >= 0) {
+                if (bj >= i - RING_WIN) { mi_x = rx[bj & M]; mi_q = rq[bj & M]; }
+                else { mi_x = (uint32_t)vx[bj]; mi_q = vq[bj] & 0x7fffffffu; }
+                mi_f = bf;
+            }
+        }
+        if (max_ii >= 0 && max_ii < end_j) {
+            int32_t tmp = comput_sc(li, qi, mi_x, mi_q, max_dist_x, max_dist_y, P);
+            if (tmp != SH_SC_NONE && max_f < tmp + mi_f) { max_f = tmp + mi_f; max_j = max_ii; }
+        }
+        if (lane == 0) { rf[i & M] = max_f; rp[i & M] = max_j; vf[i] = max_f; vpt[2 * i] = max_j; }
+        bool near = false;
+        if (max_ii >= 0) near = (uint64_t)(li - mi_x) <= (uint64_t)max_dist_x;
+        if (max_ii < 0 || (near && mi_f < max_f)) { max_ii = i; mi_x = li; mi_q = qi; mi_f = max_f; }
+    }
+    wave_mem_sync();
+}
+
+// Flag-only shortcut of mg_chain_backtrack: the first candidate popped is the maximum (f, index) with f >= min_sc.  Its
+// chain is accepted as soon as the best score seen on the way back reaches min_sc over >= min_cnt anchors (both only
+// grow along the walk).  Returns 1 accepted, 0 no candidate at all, -1 undecided (the caller runs the full procedure).
+__device__ inline int first_chain_quick(const int32_t *gf, const int32_t *gpt, int n, const ChainParams &P, uint32_t lane)
+{
+    volatile const int32_t *vf = gf, *vpt = gpt;
+    long long key = -1;
+    for (int i = (int)lane; i < n; i += 64) {
+        const int32_t f = vf[i];
+        if (f >= P.min_sc) { const long long kk = (long long)f << 32 | (uint32_t)i; key = kk > key ? kk : key; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const long long t = __shfl_xor(key, o); key = t > key ? t : key; }
+    if (key < 0) return 0;
+    const int32_t zf = (int32_t)(key >> 32);
+    int i = (int)(key & 0xffffffff), steps = 0, cnt = 0;
+    int32_t max_s = 0;
+    do {
+        i = vpt[2 * i]; ++steps;
+        const int32_t s = i < 0 ? zf : zf - vf[i];
+        if (s > max_s) { max_s = s; cnt = steps; }
+        else if (max_s - s > P.bw) break;
+        if (max_s >= P.min_sc && cnt >= P.min_cnt) return 1;
+    } while (i >= 0);
+    return (max_s >= P.min_sc && cnt >= 1 && cnt >= P.min_cnt) ? 1 : -1;
+}
+
+// one big cluster, one wave, DP state through the LDS ring
+__device__ inline void chain_cluster_ring(const uint64_t *gx, uint32_t *gq, int32_t *gf, int32_t *gpt, int32_t n, int32_t qlen, const ChainParams &P,
+                                          int32_t &n_u, int32_t &best, bool first_only, uint32_t lane, RingMem *rm)
+{
+    chain_dp_ring(gx, gq, gf, gpt, n, qlen, P, lane, rm);
+    n_u = 0; best = 0;
+    if (first_only) {
+        const int rc = first_chain_quick(gf, gpt, n, P, lane);
+        if (rc >= 0) { n_u = rc; return; }
+    }
+    SliceStore S{gx, gq, gf, gpt};
+    backtrack_heap<SliceStore, int32_t>(S, n, P, (uint64_t *)gx, n_u, best, first_only);
+    wave_mem_sync();
+}
+
 // one cluster, the whole wave: DP in parallel, backtrack executed uniformly by every lane
 __device__ inline void chain_cluster_wave(SliceStore &S, int32_t n, int32_t qlen, const ChainParams &P, uint64_t *zbuf, int32_t &n_u, int32_t &best,
                                           bool first_only, uint32_t lane)

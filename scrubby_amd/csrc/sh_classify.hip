@@ -58,6 +58,7 @@ struct Counters {
     uint32_t n_small, n_resketch, n_big[2], n_big_defer[2], n_defer, pad0;
     uint32_t n_sort[N_SORT_CLS], n_giant_tiles, n_giant_rounds;
     uint32_t n_long_segs, pad2;
+    uint32_t n_cl[4], cl_ticket, pad3;      // global queue of big clusters (k_cluster_dp), by size class
     uint32_t n_leg_reason[4];     // why reads left the long-read front end: 0 room/segments, 1 thinning screen, 2 anchors beyond the giant path, 3 unused
     unsigned long long arena_cursor, anchor_cursor;
     unsigned long long sh_mini[64], sh_anchors[64];     // sharded sums
@@ -582,6 +583,7 @@ struct BigBufs {        // the repeat path's slice of the arena (all arrays inde
     BigMeta *meta; int32_t *acc_nu, *acc_best;
     SortItem *sort_items[N_SORT_CLS];
     uint32_t *tile_base, *tile_split;       // giant reads: tile table and merge-path splits
+    SortItem *cl_items[4]; uint32_t cl_cap[4];   // big clusters of giant reads (w, n, qlen, pad = buffer, off = first anchor slot)
 };
 
 struct K2Args {
@@ -685,11 +687,14 @@ __device__ inline uint32_t chain_max_dist_x(const ChainParams &P, int32_t qlen)
 // The per-read result is a sum / max over clusters, so the order is free; in flag-only mode a read that found a
 // chain in a small cluster never touches its big ones (the true-locus cluster, dense tandem arrays).
 struct BigList { uint32_t *start, *len; int32_t *count; uint32_t cap; };
+// clusters of the giant path that go to k_cluster_dp instead (one wave per cluster, across reads)
+struct GlobalQ { SortItem *const *items; const uint32_t *cap; uint32_t *count; uint32_t w, in_b; unsigned long long off; };
+__device__ inline int cl_class(uint32_t len) { return len > 4096 ? 0 : (len > 1024 ? 1 : (len > 256 ? 2 : 3)); }
 
 template <bool CONTIG, class PX, class PQ>
 __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_t n, uint32_t tid, uint32_t nthr, int32_t qlen,
                                     const ChainParams &P, volatile int32_t *found, BigList bl,
-                                    int32_t &n_u_thr, int32_t &best_thr, uint32_t &n_cl_thr)
+                                    int32_t &n_u_thr, int32_t &best_thr, uint32_t &n_cl_thr, const GlobalQ *gq = nullptr)
 {
     const uint32_t mdx = chain_max_dist_x(P, qlen);
     const bool keep_single = !(P.k < P.min_sc || P.min_cnt > 1);
@@ -711,6 +716,11 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
         const uint32_t len = j - i;
         if (len < 2 && !keep_single) continue;
         if (len > (CONTIG ? 64u : 6u)) {      // arena path: only clusters beyond the register-mask DP go wave-wide
+            if (gq) {
+                const int cc = cl_class(len);
+                const uint32_t gs = atomicAdd(&gq->count[cc], 1u);
+                if (gs < gq->cap[cc]) { SortItem ci{gq->w, len, (uint32_t)qlen, gq->in_b, gq->off + i}; gq->items[cc][gs] = ci; continue; }
+            }
             const int32_t slot = atomicAdd(bl.count, 1);
             if ((uint32_t)slot < bl.cap) { bl.start[slot] = i; bl.len[slot] = len; continue; }
         }
@@ -1248,12 +1258,41 @@ __global__ __launch_bounds__(1024) void k_giant_chain(K3Args a)
         if (tid == 0) s_found = 0;
         __syncthreads();
         int32_t n_u = 0, best = 0; uint32_t n_cl = 0;
+        const GlobalQ gq{a.B.cl_items, a.B.cl_cap, a.ctr->n_cl, si.w, in_b ? 1u : 0u, si.off};
         if (!(a.dbg & 2))
         chain_sorted<true>(sx, sq, a.B.af + si.off, (int32_t *)(a.B.az + si.off), n, tid, nthr, (int32_t)si.qlen, a.P,
-                     a.flag_only ? &s_found : nullptr, BigList{s_bstart, s_blen, &s_bcount, 2048}, n_u, best, n_cl);
+                     a.flag_only ? &s_found : nullptr, BigList{s_bstart, s_blen, &s_bcount, 2048}, n_u, best, n_cl, &gq);
         store_read_result(a, si.w, n_u, best, n_cl, s_red);
         __syncthreads();
     }
+}
+
+// The big clusters of all giant reads, largest class first, one wave per cluster (persistent waves drawing tickets).
+// Results are merged into the per-read accumulators k_giant_chain stored.
+__global__ __launch_bounds__(256) void k_cluster_dp(K3Args a)
+{
+    __shared__ RingMem s_ring[4];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t cnt[4], total = 0;
+    for (int c = 0; c < 4; ++c) { cnt[c] = a.ctr->n_cl[c] < a.B.cl_cap[c] ? a.ctr->n_cl[c] : a.B.cl_cap[c]; total += cnt[c]; }
+    uint32_t n_cl = 0;
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&a.ctr->cl_ticket, 1u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= total) break;
+        int c = 0;
+        while (t >= cnt[c]) { t -= cnt[c]; ++c; }
+        const SortItem ci = a.B.cl_items[c][t];
+        if (a.flag_only && __atomic_load_n(&a.B.acc_nu[ci.w], __ATOMIC_RELAXED) > 0) continue;      // the read is decided
+        const uint64_t *gx = (ci.pad ? a.B.bx : a.B.ax) + ci.off; uint32_t *gq = (ci.pad ? a.B.bq : a.B.aq) + ci.off;
+        int32_t n_u, best;
+        chain_cluster_ring(gx, gq, a.B.af + ci.off, (int32_t *)(a.B.az + ci.off), (int32_t)ci.n, (int32_t)ci.qlen, a.P, n_u, best,
+                           a.flag_only != 0, lane, &s_ring[wv]);
+        ++n_cl;
+        if (lane == 0 && n_u > 0) { atomicAdd(&a.B.acc_nu[ci.w], n_u); atomicMax(&a.B.acc_best[ci.w], best); }
+    }
+    if (lane == 0 && n_cl) atomicAdd(&a.ctr->sh_clusters[(blockIdx.x * 4 + wv) & 63], n_cl);
 }
 
 __global__ void k_finalize(K3Args a)
@@ -1492,8 +1531,8 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         // k_expand's waves reserve sort-list entries in chunks (<= 32): up to one abandoned chunk per wave and class
         const uint64_t waves = 2 * std::min<uint64_t>(std::max<uint64_t>(n_tiles, 1), 256 * 8);      // k_expand's grid (big_pass)
         const uint64_t sort_cap[N_SORT_CLS] = {max_reads + 32 * waves, max_reads + 8 * waves, max_reads + waves, max_reads + waves};
-        uint64_t fixed = max_reads * (sizeof(BigMeta) + 8 + 8) + (sort_cap[0] + sort_cap[1] + sort_cap[2] + sort_cap[3]) * sizeof(SortItem) + 16384;
-        uint64_t per_anchor = 8 + 8 + 8 + 4 + 4 + 4 + 1;   // ax bx az aq bq af (+ tile_split share)
+        uint64_t fixed = 4 * 64 * sizeof(SortItem) + 4096 + max_reads * (sizeof(BigMeta) + 8 + 8) + (sort_cap[0] + sort_cap[1] + sort_cap[2] + sort_cap[3]) * sizeof(SortItem) + 16384;
+        uint64_t per_anchor = 8 + 8 + 8 + 4 + 4 + 4 + 2;   // ax bx az aq bq af (+ tile_split and cluster queue shares)
         uint64_t cap = left > fixed ? (left - fixed) / per_anchor : 0;
         cap &= ~15ull;
         if (cap < 1024) { sh_set_error("sh_ctx_create: arena of %llu MiB is too small", (unsigned long long)(c->arena_bytes >> 20)); sh_ctx_destroy(c); return SH_ERR_OOM; }
@@ -1508,6 +1547,10 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         for (int i = 0; i < N_SORT_CLS; ++i) B.sort_items[i] = (SortItem *)take(sort_cap[i] * sizeof(SortItem));
         B.tile_base = (uint32_t *)take((max_reads + 1) * 4);
         B.tile_split = (uint32_t *)take((cap / GT + max_reads + 2) * 4);
+        {   // a cluster of class c has more than {4096, 1024, 256, 64} anchors
+            const uint64_t div[4] = {4096, 1024, 256, 64};
+            for (int i = 0; i < 4; ++i) { B.cl_cap[i] = (uint32_t)std::min<uint64_t>(cap / div[i] + 64, UINT32_MAX); B.cl_items[i] = (SortItem *)take((uint64_t)B.cl_cap[i] * sizeof(SortItem)); }
+        }
         if ((uint64_t)(p - c->d_arena) > c->arena_bytes) {   // alignment slack: shrink
             sh_set_error("sh_ctx_create: internal arena carve overflow"); sh_ctx_destroy(c); return SH_ERR_OOM;
         }
@@ -1571,6 +1614,7 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     Counters *ctr = c->d_ctr;
     SH_HIP(hipMemsetAsync(&ctr->anchor_cursor, 0, 8, s));
     SH_HIP(hipMemsetAsync(&ctr->n_sort[0], 0, 4 * N_SORT_CLS, s));
+    SH_HIP(hipMemsetAsync(&ctr->n_cl[0], 0, 4 * 6, s));
     hipLaunchKernelGGL(k_expand, dim3(grid * 2), dim3(64), 0, s, k);
     // the four sort classes are independent: run them side by side so that they fill each other's tails
     const bool side = (c->par & 2) != 0;
@@ -1589,6 +1633,7 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
         hipLaunchKernelGGL(k_giant_merge, dim3(256 * 3), dim3(256), 0, g, k, round);
     }
     hipLaunchKernelGGL(k_giant_chain, dim3(512), dim3(1024), 0, g, k);
+    if (!(k.dbg & 32)) hipLaunchKernelGGL(k_cluster_dp, dim3(256 * 4), dim3(256), 0, g, k);
     if (side) for (int i = 0; i < 3; ++i) { SH_HIP(hipEventRecord(c->evx[1 + i], c->sx[i])); SH_HIP(hipStreamWaitEvent(s, c->evx[1 + i], 0)); }
     hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, s, k);
     return SH_OK;
