@@ -121,20 +121,19 @@ __device__ inline float sh_mg_log2(float x)
 __device__ inline int32_t comput_sc(uint32_t lo_i, uint32_t q_i, uint32_t lo_j, uint32_t q_j, int32_t max_dist_x,
                                     int32_t max_dist_y, const ChainParams &P)
 {
-    int32_t dq = (int32_t)q_i - (int32_t)q_j, dr, dd, dg, sc;
-    if (dq <= 0 || dq > max_dist_x) return SH_SC_NONE;
-    dr = (int32_t)(lo_i - lo_j);
-    if (dr == 0 || dq > max_dist_y) return SH_SC_NONE;
-    dd = dr > dq ? dr - dq : dq - dr;
-    if (dd > P.bw) return SH_SC_NONE;
-    dg = dr < dq ? dr : dq;
-    sc = P.k < dg ? P.k : dg;
-    if (dd || dg > P.k) {
-        float lin_pen = P.pen_gap * (float)dd + P.pen_skip * (float)dg;
-        float log_pen = dd >= 1 ? sh_mg_log2((float)(dd + 1)) : 0.0f;
-        sc -= (int32_t)(lin_pen + .5f * log_pen);
-    }
-    return sc;
+    // branch-free: the lanes of a wave disagree on every early exit of the original
+    const int32_t dq = (int32_t)q_i - (int32_t)q_j, dr = (int32_t)(lo_i - lo_j);
+    int32_t dd = dr > dq ? dr - dq : dq - dr;
+    const bool ok = dq > 0 && dq <= max_dist_x && dr != 0 && dq <= max_dist_y && dd <= P.bw;
+    dd = ok ? dd : 0;
+    int32_t dg = dr < dq ? dr : dq;
+    dg = ok ? dg : 0;
+    int32_t sc = P.k < dg ? P.k : dg;
+    const float lin_pen = P.pen_gap * (float)dd + P.pen_skip * (float)dg;
+    const float log_pen = dd >= 1 ? sh_mg_log2((float)(dd + 1)) : 0.0f;
+    const int32_t pen = (int32_t)(lin_pen + .5f * log_pen);
+    sc -= (dd != 0 || dg > P.k) ? pen : 0;
+    return ok ? sc : SH_SC_NONE;
 }
 
 // ---- stores -----------------------------------------------------------------------------------
@@ -593,6 +592,11 @@ __device__ inline void chain_dp_wave(const SliceStore &S, int n, int32_t qlen, c
     }
 }
 
+__device__ inline uint32_t prefix_popc64(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 // ---- wave scans on the DPP network (gfx9: row_shr within rows of 16, row_bcast:15 / :31 across rows, wave_shr:1) ----
 template <int CTRL, int ROWS>
 __device__ inline int32_t dpp_mov(int32_t old, int32_t v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROWS, 0xf, false); }
@@ -628,11 +632,33 @@ __device__ inline void wave_scan_compose(int32_t &a, int32_t &b)
 // given i an anchor is either inside the window or not, so its mark for that i has exactly one home.
 #define RING_CAP 256
 #define RING_WIN 192
-struct RingMem { uint32_t x[RING_CAP], q[RING_CAP]; int32_t f[RING_CAP], p[RING_CAP], t[RING_CAP]; };
+#define RING_TBITS 8192         // t marks: one bit per anchor of the look-back window (max_chain_iter <= RING_TMAX_ITER)
+#define RING_TMAX_ITER 8000
+struct RingMem { uint4 rec[RING_CAP]; uint32_t tb[RING_TBITS / 32]; };       // rec = (x, q, f, p)
 
-__device__ inline void chain_dp_ring(const uint64_t *gx, const uint32_t *gq, int32_t *gf, int32_t *gpt, int n, int32_t qlen,
-                                     const ChainParams &P, uint32_t lane, RingMem *rm)
+__device__ inline int32_t wave_scan_min_incl(int32_t v)
 {
+    int32_t t;
+    t = dpp_mov<0x111, 0xf>(INT32_MAX, v); v = t < v ? t : v;
+    t = dpp_mov<0x112, 0xf>(INT32_MAX, v); v = t < v ? t : v;
+    t = dpp_mov<0x114, 0xf>(INT32_MAX, v); v = t < v ? t : v;
+    t = dpp_mov<0x118, 0xf>(INT32_MAX, v); v = t < v ? t : v;
+    t = dpp_mov<0x142, 0xa>(INT32_MAX, v); v = t < v ? t : v;
+    t = dpp_mov<0x143, 0xc>(INT32_MAX, v); v = t < v ? t : v;
+    return v;
+}
+__device__ inline int32_t ld_agent(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// `rm` must be a __shared__ object (the accesses below compile to ds_* once inlined; nothing here is volatile: one
+// wave's LDS operations execute in program order, and the compiler keeps may-aliasing stores and loads ordered).
+// The t[] marks of mg_lchain_dp ("t[j] == i") only live for one i: they are one bit per anchor of the current
+// look-back window [st, i), cleared after the step.  f and p are written through to the arena without waiting; a scan
+// that leaves the ring window fences once and reads them past the L1 (the next chunk's loads are issued a chunk ahead).
+// Requires P.max_iter <= RING_TMAX_ITER.
+__device__ inline void chain_dp_ring(const uint64_t *gx, const uint32_t *gq, int32_t *gf, int32_t *gpt, int n, int32_t qlen,
+                                     const ChainParams &P, uint32_t lane, RingMem &rm, unsigned long long *dbg_cnt = nullptr)
+{
+    unsigned long long n_ch_in = 0, n_ch_out = 0, n_far = 0;
     int32_t max_dist_y = P.is_sr ? (qlen > P.max_gap ? qlen : P.max_gap) : P.max_gap;
     int32_t max_dist_x;
     if (P.max_gap_ref > 0) max_dist_x = P.max_gap_ref;
@@ -641,12 +667,9 @@ __device__ inline void chain_dp_ring(const uint64_t *gx, const uint32_t *gq, int
     if (max_dist_x < P.bw) max_dist_x = P.bw;
     if (max_dist_y < P.bw) max_dist_y = P.bw;
     constexpr int M = RING_CAP - 1;
-    volatile uint32_t *rx = rm->x, *rq = rm->q; volatile int32_t *rf = rm->f, *rp = rm->p, *rt = rm->t;
-    volatile const uint64_t *vx = gx; volatile const uint32_t *vq = gq; volatile int32_t *vf = gf, *vpt = gpt;
-    const int NEG = -(1 << 28);
+    constexpr int TW = RING_TBITS / 32;
 
-    for (int i = (int)lane; i < n; i += 64) gpt[2 * i + 1] = 0;      // stale arena contents must never equal a later i
-    wave_mem_sync();
+    for (int d = (int)lane; d < TW; d += 64) rm.tb[d] = 0;
     int st = 0, sb = 0, max_ii = -1;
     uint32_t sxv = (int)lane < n ? (uint32_t)gx[lane] : 0xffffffffu;      // x of anchor sb + lane (start-of-window search)
     uint32_t mi_x = 0, mi_q = 0; int32_t mi_f = 0;                           // anchor max_ii
@@ -655,7 +678,8 @@ __device__ inline void chain_dp_ring(const uint64_t *gx, const uint32_t *gq, int
         if ((i & 63) == 0) {
             const int a = i + (int)lane;
             nx = a < n ? (uint32_t)gx[a] : 0u; nq = a < n ? gq[a] & 0x7fffffffu : 0u;
-            rx[a & M] = nx; rq[a & M] = nq; rt[a & M] = -1;               // overwrites anchors [i-256, i-193]: outside every window of this block
+            // overwrites anchors [i-256, i-193]: outside every window of this block
+            rm.rec[a & M].x = nx; rm.rec[a & M].y = nq;
         }
         const uint32_t li = (uint32_t)__builtin_amdgcn_readlane((int)nx, i & 63), qi = (uint32_t)__builtin_amdgcn_readlane((int)nq, i & 63);
         for (;;) {      // while (st < i && x[i] > x[st] + max_dist_x) ++st, 64 candidates at a time
@@ -670,58 +694,72 @@ __device__ inline void chain_dp_ring(const uint64_t *gx, const uint32_t *gq, int
         if (i - st > P.max_iter) st = i - P.max_iter;
         int32_t max_f = P.k, n_skip = 0;
         int max_j = -1, end_j = st - 1;
-        bool synced = false;
+        bool synced = false, marked = false;
         int c = 0;
+        uint32_t px = 0, pq = 0; int32_t pf = 0, pp = -1;       // the next chunk beyond the ring window, loaded a chunk ahead
         for (int jb = i - 1; jb >= st; jb -= 64, ++c) {
             const int j = jb - (int)lane;
             const bool valid = j >= st;
-            const bool inw = c < RING_WIN / 64;             // the whole chunk is inside the ring window
-            if (!inw && !synced) { wave_mem_sync(); synced = true; }
-            uint32_t xj = 0, qj = 0; int32_t fj = 0, pj = -1;
-            if (valid) {
-                if (inw) { const int sl = j & M; xj = rx[sl]; qj = rq[sl]; fj = rf[sl]; pj = rp[sl]; }
-                else { xj = (uint32_t)vx[j]; qj = vq[j] & 0x7fffffffu; fj = vf[j]; pj = vpt[2 * j]; }
+            const bool inw = c < RING_WIN / 64;             // uniform: the whole chunk is inside the ring window
+            if (inw) ++n_ch_in; else ++n_ch_out;
+            uint32_t xj, qj; int32_t fj, pj;
+            if (inw) {
+                const uint4 rc = rm.rec[j & M];
+                xj = rc.x; qj = rc.y; fj = (int32_t)rc.z; pj = (int32_t)rc.w;
+            } else { xj = px; qj = pq; fj = pf; pj = pp; }
+            if (c + 1 >= RING_WIN / 64 && jb - 64 >= st) {      // issue the loads of the next chunk
+                if (!synced) { wave_mem_sync(); synced = true; }
+                const int jn = j - 64;
+                if (jn >= st) { px = (uint32_t)gx[jn]; pq = gq[jn] & 0x7fffffffu; pf = ld_agent(gf + jn); pp = ld_agent(gpt + 2 * jn); }
             }
-            int32_t sc = SH_SC_NONE;
-            if (valid) sc = comput_sc(li, qi, xj, qj, max_dist_x, max_dist_y, P);
+            int32_t sc = comput_sc(li, qi, xj, qj, max_dist_x, max_dist_y, P);
             const bool has = valid && sc != SH_SC_NONE;
-            if (has) sc += fj;
-            if (has && pj >= 0) { if (pj >= i - RING_WIN) rt[pj & M] = i; else vpt[2 * pj + 1] = i; }
-            if (!inw) wave_mem_sync();
-            bool is_t = false;
-            if (has) is_t = (inw ? rt[j & M] : vpt[2 * j + 1]) == i;
+            sc = has ? sc + fj : INT32_MIN;
+            const bool mk = has && pj >= st;               // marks below st are never read in this step
+            if (mk) atomicOr(&rm.tb[(pj & (RING_TBITS - 1)) >> 5], 1u << (pj & 31));
+            marked |= __ballot(mk) != 0;
+            const bool is_t = has && ((rm.tb[(j & (RING_TBITS - 1)) >> 5] >> (j & 31)) & 1u);
             // exclusive prefix maximum in scan order (lane 0 = j = jb first), seeded with the running max_f
-            const int32_t incl = wave_scan_max_incl(has ? sc : INT32_MIN);
+            const int32_t incl = wave_scan_max_incl(sc);
             int32_t excl = wave_shr1(incl, INT32_MIN);
             if (excl < max_f) excl = max_f;
             const bool new_max = has && sc > excl;
             const bool inc_ev = has && !new_max && is_t;
-            int32_t ca = new_max ? -1 : (inc_ev ? 1 : 0), cb = new_max ? 0 : NEG;
-            wave_scan_compose(ca, cb);
-            const int32_t val = n_skip + ca > cb ? n_skip + ca : cb;
+            // n_skip is a walk reflected at zero (new maximum: max(x - 1, 0); marked non-maximum: x + 1):
+            // x_l = Y_l - min(0, min_{m <= l} Y_m) with the free walk Y_l = n_skip + #inc(<= l) - #new_max(<= l)
+            const uint64_t inc_m = __ballot(inc_ev), nm_m = __ballot(new_max);
+            const int32_t yl = n_skip + (int32_t)prefix_popc64(inc_m) + (inc_ev ? 1 : 0) - (int32_t)prefix_popc64(nm_m) - (new_max ? 1 : 0);
+            const int32_t mn = wave_scan_min_incl(yl);
+            const int32_t val = yl - (mn < 0 ? mn : 0);
             const uint64_t brk = __ballot(inc_ev && val > P.max_skip);
             const int L = brk ? __ffsll((unsigned long long)brk) - 1 : 63;
             const int32_t mm = __builtin_amdgcn_readlane(incl, L);      // max over the lanes up to the break point
             if (mm > max_f) {
                 max_f = mm;
-                const uint64_t eq = __ballot((int)lane <= L && has && sc == mm);
+                const uint64_t eq = __ballot((int)lane <= L && sc == mm);
                 max_j = jb - (__ffsll((unsigned long long)eq) - 1);
             }
             n_skip = __builtin_amdgcn_readlane(val, L);
             if (brk) { end_j = jb - L; break; }
+        }
+        if (marked) {       // clear the marks of this step: they all lie in [st, i)
+            const int d1 = (i - 1) >> 5;
+            for (int d = (st >> 5) + (int)lane; d <= d1; d += 64) rm.tb[d & (TW - 1)] = 0;
         }
         // the max_ii shortcut (uniform)
         bool far = true;
         if (max_ii >= 0) far = (uint64_t)(li - mi_x) > (uint64_t)max_dist_x;
         if (max_ii < 0 || far) {
             int32_t bf = INT32_MIN; int bj = -1;
-            int c2 = 0;
+            int c2 = 0; ++n_far;
             for (int jb = i - 1; jb >= st; jb -= 64, ++c2) {
                 const int j = jb - (int)lane;
-                const bool inw = c2 < RING_WIN / 64;
-                if (!inw && !synced) { wave_mem_sync(); synced = true; }
                 int32_t fj = INT32_MIN;
-                if (j >= st) fj = inw ? rf[j & M] : vf[j];
+                if (c2 < RING_WIN / 64) { if (j >= st) fj = (int32_t)rm.rec[j & M].z; }
+                else {
+                    if (!synced) { wave_mem_sync(); synced = true; }
+                    if (j >= st) fj = ld_agent(gf + j);
+                }
                 int32_t cm = fj;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) { int32_t t = __shfl_xor(cm, o); cm = t > cm ? t : cm; }
@@ -729,8 +767,8 @@ __device__ inline void chain_dp_ring(const uint64_t *gx, const uint32_t *gq, int
             }
             max_ii = bj;
             if (bj >= 0) {
-                if (bj >= i - RING_WIN) { mi_x = rx[bj & M]; mi_q = rq[bj & M]; }
-                else { mi_x = (uint32_t)vx[bj]; mi_q = vq[bj] & 0x7fffffffu; }
+                if (bj >= i - RING_WIN) { mi_x = rm.rec[bj & M].x; mi_q = rm.rec[bj & M].y; }
+                else { mi_x = (uint32_t)gx[bj]; mi_q = gq[bj] & 0x7fffffffu; }
                 mi_f = bf;
             }
         }
@@ -738,12 +776,13 @@ __device__ inline void chain_dp_ring(const uint64_t *gx, const uint32_t *gq, int
             int32_t tmp = comput_sc(li, qi, mi_x, mi_q, max_dist_x, max_dist_y, P);
             if (tmp != SH_SC_NONE && max_f < tmp + mi_f) { max_f = tmp + mi_f; max_j = max_ii; }
         }
-        if (lane == 0) { rf[i & M] = max_f; rp[i & M] = max_j; vf[i] = max_f; vpt[2 * i] = max_j; }
+        if (lane == 0) { rm.rec[i & M].z = (uint32_t)max_f; rm.rec[i & M].w = (uint32_t)max_j; gf[i] = max_f; gpt[2 * i] = max_j; }
         bool near = false;
         if (max_ii >= 0) near = (uint64_t)(li - mi_x) <= (uint64_t)max_dist_x;
         if (max_ii < 0 || (near && mi_f < max_f)) { max_ii = i; mi_x = li; mi_q = qi; mi_f = max_f; }
     }
     wave_mem_sync();
+    if (dbg_cnt && lane == 0) { atomicAdd(&dbg_cnt[0], n_ch_in); atomicAdd(&dbg_cnt[1], n_ch_out); atomicAdd(&dbg_cnt[2], n_far); }
 }
 
 // Flag-only shortcut of mg_chain_backtrack: the first candidate popped is the maximum (f, index) with f >= min_sc.  Its
@@ -775,9 +814,9 @@ __device__ inline int first_chain_quick(const int32_t *gf, const int32_t *gpt, i
 
 // one big cluster, one wave, DP state through the LDS ring
 __device__ inline void chain_cluster_ring(const uint64_t *gx, uint32_t *gq, int32_t *gf, int32_t *gpt, int32_t n, int32_t qlen, const ChainParams &P,
-                                          int32_t &n_u, int32_t &best, bool first_only, uint32_t lane, RingMem *rm)
+                                          int32_t &n_u, int32_t &best, bool first_only, uint32_t lane, RingMem &rm, unsigned long long *dbg_cnt = nullptr)
 {
-    chain_dp_ring(gx, gq, gf, gpt, n, qlen, P, lane, rm);
+    chain_dp_ring(gx, gq, gf, gpt, n, qlen, P, lane, rm, dbg_cnt);
     n_u = 0; best = 0;
     if (first_only) {
         const int rc = first_chain_quick(gf, gpt, n, P, lane);

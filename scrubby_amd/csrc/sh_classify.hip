@@ -61,6 +61,7 @@ struct Counters {
     uint32_t n_cl[4], cl_ticket, pad3;      // global queue of big clusters (k_cluster_dp), by size class
     uint32_t n_leg_reason[4];     // why reads left the long-read front end: 0 room/segments, 1 thinning screen, 2 anchors beyond the giant path, 3 unused
     unsigned long long arena_cursor, anchor_cursor;
+    unsigned long long cl_tot[4], cl_anchor_tot[4], cl_dbg[4];     // statistics of k_cluster_dp by size class (whole chunk)
     unsigned long long sh_mini[64], sh_anchors[64];     // sharded sums
     uint32_t sh_host[64], sh_clusters[64];
 };
@@ -1287,9 +1288,15 @@ __global__ __launch_bounds__(256) void k_cluster_dp(K3Args a)
         if (a.flag_only && __atomic_load_n(&a.B.acc_nu[ci.w], __ATOMIC_RELAXED) > 0) continue;      // the read is decided
         const uint64_t *gx = (ci.pad ? a.B.bx : a.B.ax) + ci.off; uint32_t *gq = (ci.pad ? a.B.bq : a.B.aq) + ci.off;
         int32_t n_u, best;
-        chain_cluster_ring(gx, gq, a.B.af + ci.off, (int32_t *)(a.B.az + ci.off), (int32_t)ci.n, (int32_t)ci.qlen, a.P, n_u, best,
-                           a.flag_only != 0, lane, &s_ring[wv]);
+        if (a.P.max_iter <= RING_TMAX_ITER)
+            chain_cluster_ring(gx, gq, a.B.af + ci.off, (int32_t *)(a.B.az + ci.off), (int32_t)ci.n, (int32_t)ci.qlen, a.P, n_u, best,
+                               a.flag_only != 0, lane, s_ring[wv], (a.dbg & 16) ? a.ctr->cl_dbg : nullptr);
+        else {      // look-back windows beyond the LDS mark bitmap: DP state in the arena throughout
+            SliceStore S{gx, gq, a.B.af + ci.off, (int32_t *)(a.B.az + ci.off)};
+            chain_cluster_wave(S, (int32_t)ci.n, (int32_t)ci.qlen, a.P, (uint64_t *)gx, n_u, best, a.flag_only != 0, lane);
+        }
         ++n_cl;
+        if (lane == 0) { atomicAdd(&a.ctr->cl_tot[c], 1ull); atomicAdd(&a.ctr->cl_anchor_tot[c], (unsigned long long)ci.n); }
         if (lane == 0 && n_u > 0) { atomicAdd(&a.B.acc_nu[ci.w], n_u); atomicMax(&a.B.acc_best[ci.w], best); }
     }
     if (lane == 0 && n_cl) atomicAdd(&a.ctr->sh_clusters[(blockIdx.x * 4 + wv) & 63], n_cl);
@@ -1744,6 +1751,8 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         SH_HIP(hipGetLastError());
         if (first) { snap = *c->h_ctr; first = false; }
         if (k.dbg & 16) fprintf(stderr, "[dbg] iter %d resketch %u reasons %u %u %u segs %u big %u/%u defer %u/%u\n", iter, c->h_ctr->n_resketch, c->h_ctr->n_leg_reason[0], c->h_ctr->n_leg_reason[1], c->h_ctr->n_leg_reason[2], c->h_ctr->n_long_segs, c->h_ctr->n_big[0], c->h_ctr->n_big[1], c->h_ctr->n_big_defer[0], c->h_ctr->n_big_defer[1]);
+        if (k.dbg & 16) fprintf(stderr, "[dbg] clusters chained by k_cluster_dp by class: %llu %llu %llu %llu, their anchors %llu %llu %llu %llu\n", c->h_ctr->cl_tot[0], c->h_ctr->cl_tot[1], c->h_ctr->cl_tot[2], c->h_ctr->cl_tot[3], c->h_ctr->cl_anchor_tot[0], c->h_ctr->cl_anchor_tot[1], c->h_ctr->cl_anchor_tot[2], c->h_ctr->cl_anchor_tot[3]);
+        if (k.dbg & 16) fprintf(stderr, "[dbg] ring DP: chunks in window %llu, beyond %llu, far rescans %llu\n", c->h_ctr->cl_dbg[0], c->h_ctr->cl_dbg[1], c->h_ctr->cl_dbg[2]);
         resk_done = c->h_ctr->n_resketch;
         const uint32_t d0 = c->h_ctr->n_big_defer[0], d1 = c->h_ctr->n_big_defer[1];
         if (d0 == 0 && d1 == 0) break;
