@@ -254,3 +254,61 @@ def test_long_read_generator_device_matches_cpu(S, oracle):
     gf, gt, st, rc = gidx.classify(cpu, offs, want_trace=True)
     of, ot = cidx.classify(oo, cpu, offs, threads=8)
     assert_trace_equal(S, gf, gt, of, ot)
+
+
+def _short_indel_reads(ref, n, seed, L=150):
+    """150-bp reads with 1 % substitutions, 1 % insertions, 1 % deletions, either strand (the gap-penalty float path)."""
+    rng = np.random.default_rng(seed)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    acgt = b"ACGT"
+    recs = []
+    for i in range(n):
+        s = int(rng.integers(0, len(ref) - 2 * L))
+        out = bytearray()
+        p = s
+        while len(out) < L:
+            u = rng.random()
+            if u < 0.01:
+                p += 1
+                continue
+            if u < 0.02:
+                out.append(acgt[rng.integers(0, 4)])
+                continue
+            out.append(acgt[rng.integers(0, 4)] if u > 0.99 else ref[p])
+            p += 1
+        b = bytes(out[:L])
+        recs.append(b.translate(comp)[::-1] if i % 2 else b)
+    bases = np.frombuffer(b"".join(recs), dtype=np.uint8)
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    return bases, offs
+
+
+def test_short_reads_with_indels(S, oracle, cfg1, gpu_index, cpu_index):
+    """Indels put dd != 0 into nearly every chain: comput_sc's linear + log2 gap penalty decides scores."""
+    P, R, ref, seqs, reads, off = cfg1
+    bases, offs = _short_indel_reads(ref, 4000, 11)
+    gf, gt, st, rc = gpu_index.classify(bases, offs, want_trace=True)
+    of, ot = cpu_index.classify(oracle.preset("sr"), bases, offs, threads=8)
+    assert_trace_equal(S, gf, gt, of, ot)
+    assert int(gf.sum()) > 3500
+
+
+def test_long_read_front_end_all_paths(S, oracle):
+    """1500 stand-in long reads (satellite reads included): the segment-parallel front end takes every read (no
+    re-sketch), query-minimizer thinning, multi-tile seed selection, the giant sort and the cluster queue all run;
+    traces match the oracle, and the flag-only mode (first-chain shortcut) gives the same flags."""
+    Po = oracle.ref_params(W.CFG1_REF_SEED, W.CFG1_CONTIGS)
+    Ro = oracle.read_params(0x5C2B0021, host_pct=60, sub_per_10k=500, n_read_pct=0)
+    n = 1500
+    bases, offs = oracle.synth_long_reads(Po, Ro, 11, n)
+    seqs = [oracle.synth_ref(Po, Po.contig_start[i], 1_000_000) for i in range(5)]
+    gidx = S.Index.build([bytes(s) for s in seqs], S.preset("map-ont"))
+    cidx = oracle.Index.build(seqs, 10, 15)
+    oo = cidx.update_opts(oracle.preset("map-ont"))
+    gf, gt, st, rc = gidx.classify(bases, offs, want_trace=True)
+    of, ot = cidx.classify(oo, bases, offs, threads=8)
+    assert_trace_equal(S, gf, gt, of, ot)
+    assert st["n_resketch"] == 0 and st["n_clusters"] > 0
+    assert int((ot["n_mini"] < ot["n_seed"]).sum()) == 0
+    gf2, _, st2, _ = gidx.classify(bases, offs, want_trace=False)
+    assert np.array_equal(gf2, of)
