@@ -241,6 +241,94 @@ sh_status sh_synth_reads_device(const void *ref_params, const void *read_params,
 sh_status sh_synth_long_reads_device(const void *ref_params, const void *read_params, uint64_t r0, uint64_t n_records,
                                      const uint64_t *d_offsets, uint64_t n_bases, uint8_t *d_out, void *stream);
 
+/* ---- Kraken2-style taxid classifier (BASELINE configs[4]) ------------------------
+ * Replaces the external process of Cleaner::run_kraken (/root/reference/src/cleaner.rs:288-330):
+ *     kraken2 --threads T --db DB [--paired] IN.. --output kraken.reads --report kraken.report
+ * The database (compact hash table of 32-bit cells + taxonomy) is resident in HBM; reads are scanned for (k, l)
+ * minimizers, each distinct consecutive minimizer is probed once, every k-mer counts for its minimizer's taxon and the
+ * call is Kraken2's ResolveTree.  File formats of a database directory: hash.k2d, opts.k2d, taxo.k2d. */
+typedef struct sh_k2_db sh_k2_db;
+
+typedef struct sh_k2_opts {
+    int32_t  k, l;                  /* 35, 31 */
+    uint64_t spaced_seed_mask;      /* --minimizer-spaces 7 */
+    uint64_t toggle_mask;           /* 0xe37e28c4271b5a2d */
+    uint64_t min_acceptable_hash;   /* down-sampled databases ("standard-8"): minimizers hashing below it are not looked up */
+    int32_t  value_bits;            /* low bits of a cell = internal taxid (set from hash.k2d on open) */
+    int32_t  min_hit_groups;        /* --minimum-hit-groups, default 2 */
+    double   confidence;            /* --confidence, default 0 (a double, as Kraken 2 parses it: ceil(c * kmers) decides) */
+} sh_k2_opts;
+
+typedef struct sh_k2_taxnode {      /* taxo.k2d node: 7 x u64 */
+    uint64_t parent, first_child, child_count, name_offset, rank_offset, external_id, godparent;
+} sh_k2_taxnode;
+
+typedef struct sh_k2_result {
+    uint32_t taxid;         /* external (NCBI) taxid of the call, 0 = unclassified */
+    uint32_t call;          /* internal taxid */
+    uint32_t total_kmers;   /* k-mers of the read / pair (ambiguous ones included) */
+    uint32_t hit_groups;    /* distinct consecutive minimizers found in the table */
+} sh_k2_result;
+
+typedef struct sh_k2_info {
+    uint64_t capacity, size, n_nodes, hbm_bytes;
+    int32_t  k, l, value_bits, key_bits;
+} sh_k2_info;
+
+typedef struct sh_k2_stats {
+    uint64_t n_units, n_classified, n_probes, n_kmers, n_overflow;
+    float    ms_classify, ms_total;
+} sh_k2_stats;
+
+sh_status sh_k2_default_opts(sh_k2_opts *out);
+/* open a Kraken2 database directory (hash.k2d, opts.k2d, taxo.k2d) into HBM */
+sh_status sh_k2_open(const char *dbdir, int device, sh_k2_db **out);
+/* an empty table of `capacity` cells over a caller-supplied taxonomy (synthetic databases, tests).  Node 0 is the
+ * unused sentinel, node 1 the root; parents precede children (breadth-first ids). */
+sh_status sh_k2_create(const sh_k2_opts *opts, uint64_t capacity, const sh_k2_taxnode *nodes, uint64_t n_nodes,
+                       const char *names, uint64_t names_len, const char *ranks, uint64_t ranks_len, int device, sh_k2_db **out);
+/* insert (minimizer, internal taxid) pairs that are resident in HBM; a key already present keeps the LCA */
+sh_status sh_k2_insert_device(sh_k2_db *db, const uint64_t *d_keys, const uint32_t *d_taxa, uint64_t n, void *stream);
+/* insert every minimizer of a device-resident sequence [d_bases, d_bases + n) with one taxid (down-sampled by
+ * opts.min_acceptable_hash); *n_inserted (nullable) receives the number of minimizer runs inserted */
+sh_status sh_k2_insert_sequence_device(sh_k2_db *db, const uint8_t *d_bases, uint64_t n, uint32_t taxon, void *stream, uint64_t *n_inserted);
+/* pseudo-random filler keys (synthetic databases): n keys derived from `seed`, taxa uniform in [taxon_lo, taxon_hi] */
+sh_status sh_k2_insert_random(sh_k2_db *db, uint64_t seed, uint64_t n, uint32_t taxon_lo, uint32_t taxon_hi, void *stream);
+sh_status sh_k2_save(const sh_k2_db *db, const char *dbdir);
+sh_status sh_k2_info_get(const sh_k2_db *db, sh_k2_info *out);
+/* the option set stored with the database (k, l, masks, down-sampling threshold) plus the default thresholds */
+sh_status sh_k2_db_opts(const sh_k2_db *db, sh_k2_opts *out);
+/* host copies for the test oracle: cells[capacity], parent[n_nodes], external[n_nodes] (any pointer may be NULL) */
+sh_status sh_k2_export(const sh_k2_db *db, uint32_t *cells, uint32_t *parent, uint32_t *external);
+sh_status sh_k2_free(sh_k2_db *db);
+/* classify device-resident records.  paired != 0: records 2i and 2i+1 are the mates of pair i (n_records even), one
+ * result per pair; else one result per record.  d_bases needs 8 readable bytes past the last base. */
+sh_status sh_k2_classify_device(const sh_k2_db *db, const sh_k2_opts *opts, const uint8_t *d_bases, const uint64_t *d_offsets,
+                                uint64_t n_records, int32_t paired, sh_k2_result *d_out, void *stream, sh_k2_stats *stats);
+/* the same from host memory */
+sh_status sh_k2_classify_batch(const sh_k2_db *db, const sh_k2_opts *opts, const uint8_t *bases, const uint64_t *offsets,
+                               uint64_t n_records, int32_t paired, sh_k2_result *out, sh_k2_stats *stats);
+/* Kraken-style report (pct, clade reads, direct reads, rank code, taxid, indented name) from per-unit calls */
+sh_status sh_k2_write_report(const sh_k2_db *db, const sh_k2_result *results, uint64_t n_units, const char *path);
+
+/* `scrubby reads -c kraken2 -I DB -T .. -D ..`: Cleaner::run_kraken (cleaner.rs:288-330) in process: classify on the GPU,
+ * write kraken.reads / kraken.report into workdir, then the taxid depletion of parse_classifier_output + clean_reads. */
+typedef struct sh_kraken_config {
+    const char *input[2];
+    const char *output[2];
+    uint32_t    n_files;            /* 2 = paired-end (kraken2 --paired) */
+    int32_t     extract;
+    const char *db;                 /* -I: database directory */
+    const char *workdir;            /* -w, nullable: system temp dir */
+    const char *const *taxa;        uint32_t n_taxa;
+    const char *const *taxa_direct; uint32_t n_taxa_direct;
+    double      confidence;         /* from -C "--confidence x"; < 0: default */
+    int32_t     min_hit_groups;     /* <= 0: default */
+    const char *json, *read_ids, *command;
+    int32_t     device, threads;
+} sh_kraken_config;
+sh_status sh_kraken_run(const sh_kraken_config *cfg, sh_reads_result *out);
+
 /* ---- micro-benchmarks for the roofline (bench.py) ---------------------------------------- */
 /* random 16-B slot gathers over the index table; returns achieved GB/s of useful bytes */
 sh_status sh_bench_gather(const sh_index *idx, uint64_t n_probes, int32_t iters, double *out_gbs_useful, double *out_ms);

@@ -49,6 +49,16 @@ class ReadParams(C.Structure):
                 ("sub_per_10k", C.c_uint32), ("n_read_pct", C.c_uint32)]
 
 
+class K2Opts(C.Structure):
+    _fields_ = [("k", C.c_int32), ("l", C.c_int32), ("spaced_seed_mask", C.c_uint64), ("toggle_mask", C.c_uint64),
+                ("min_acceptable_hash", C.c_uint64), ("value_bits", C.c_int32), ("min_hit_groups", C.c_int32),
+                ("confidence", C.c_double)]
+
+
+K2_RESULT_DTYPE = np.dtype([("call", "<u4"), ("total_kmers", "<u4"), ("hit_groups", "<u4"), ("n_probes", "<u4")])
+K2_AMBIG, K2_BORDER = 0xFFFFFFFF, 0xFFFFFFFE
+
+
 def build():
     """Compile liboracle from oracle/Makefile (gcc)."""
     subprocess.check_call(["make", "-s", "-C", _HERE])
@@ -95,6 +105,27 @@ def lib():
     L.syn_cpu_truth.argtypes = [C.POINTER(RefParams), C.POINTER(ReadParams), C.c_uint64, C.c_uint64, C.c_void_p]
     L.syn_cpu_long_lengths.argtypes = [C.POINTER(ReadParams), C.c_uint64, C.c_uint64, C.c_void_p]
     L.syn_cpu_long_reads.argtypes = [C.POINTER(RefParams), C.POINTER(ReadParams), C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.k2o_default_opts.argtypes = [C.POINTER(K2Opts)]
+    L.k2o_hash.argtypes = [C.c_uint64]
+    L.k2o_hash.restype = C.c_uint64
+    L.k2o_canonical.argtypes = [C.c_uint64, C.c_int]
+    L.k2o_canonical.restype = C.c_uint64
+    L.k2o_scan.argtypes = [C.c_void_p, C.c_int64, C.POINTER(K2Opts), C.c_void_p, C.c_void_p, C.c_int64]
+    L.k2o_scan.restype = C.c_int64
+    L.k2o_cht_get.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint64]
+    L.k2o_cht_get.restype = C.c_uint32
+    L.k2o_cht_set.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p]
+    L.k2o_cht_set.restype = C.c_int
+    L.k2o_is_ancestor.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.k2o_is_ancestor.restype = C.c_int
+    L.k2o_lca.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.k2o_lca.restype = C.c_uint32
+    L.k2o_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_double]
+    L.k2o_resolve.restype = C.c_uint32
+    L.k2o_classify_pair.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(K2Opts), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.k2o_classify_batch.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(K2Opts), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
+                                     C.c_void_p, C.c_int]
     _LIB = L
     return L
 
@@ -229,3 +260,79 @@ def synth_long_reads(P, R, r0, n):
     out = np.zeros(int(offs[-1]), dtype=np.uint8)
     lib().syn_cpu_long_reads(C.byref(P), C.byref(R), r0, n, offs.ctypes.data, out.ctypes.data)
     return out, offs
+
+
+# ---- Kraken2-style classifier (k2_oracle.c; PARITY UNPINNED, see k2_oracle.h) ----------------------------------------
+def k2_default_opts():
+    o = K2Opts()
+    lib().k2o_default_opts(C.byref(o))
+    return o
+
+
+def k2_scan(seq, o):
+    seq = np.frombuffer(bytes(seq), dtype=np.uint8) if not isinstance(seq, np.ndarray) else np.ascontiguousarray(seq)
+    cap = max(len(seq), 1)
+    mins = np.zeros(cap, dtype=np.uint64)
+    amb = np.zeros(cap, dtype=np.uint8)
+    n = lib().k2o_scan(seq.ctypes.data, len(seq), C.byref(o), mins.ctypes.data, amb.ctypes.data, cap)
+    return mins[:n].copy(), amb[:n].copy()
+
+
+class K2Table:
+    """A compact hash table + parent array on the host (built here with k2o_cht_set, or wrapped from the product's export)."""
+
+    def __init__(self, cells, parent, value_bits):
+        self.cells = np.ascontiguousarray(cells, dtype=np.uint32)
+        self.parent = np.ascontiguousarray(parent, dtype=np.uint32)
+        self.value_bits = value_bits
+
+    @classmethod
+    def empty(cls, capacity, parent, value_bits):
+        return cls(np.zeros(capacity, dtype=np.uint32), parent, value_bits)
+
+    def set(self, key, value, lca=True):
+        return lib().k2o_cht_set(self.cells.ctypes.data, len(self.cells), self.value_bits, C.c_uint64(int(key)), int(value),
+                                 self.parent.ctypes.data if lca else None)
+
+    def get(self, key):
+        return lib().k2o_cht_get(self.cells.ctypes.data, len(self.cells), self.value_bits, C.c_uint64(int(key)))
+
+    def classify_pair(self, o, seq1, seq2=None, want_taxa=False):
+        a = np.frombuffer(bytes(seq1), dtype=np.uint8)
+        b = np.frombuffer(bytes(seq2), dtype=np.uint8) if seq2 is not None else None
+        res = np.zeros(1, dtype=K2_RESULT_DTYPE)
+        cap = len(a) + (len(b) if b is not None else 0) + 4
+        taxa = np.zeros(cap, dtype=np.uint32)
+        nt = C.c_int64()
+        lib().k2o_classify_pair(self.cells.ctypes.data, len(self.cells), self.parent.ctypes.data, C.byref(o), a.ctypes.data, len(a),
+                                b.ctypes.data if b is not None else None, len(b) if b is not None else 0, res.ctypes.data,
+                                taxa.ctypes.data, cap, C.byref(nt))
+        r = {n: int(res[0][n]) for n in K2_RESULT_DTYPE.names}
+        return (r, taxa[:nt.value].copy()) if want_taxa else r
+
+    def classify(self, o, bases, offsets, paired=False, threads=8):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n_rec = len(offsets) - 1
+        n_units = n_rec // 2 if paired else n_rec
+        res = np.zeros(max(n_units, 1), dtype=K2_RESULT_DTYPE)
+        lib().k2o_classify_batch(self.cells.ctypes.data, len(self.cells), self.parent.ctypes.data, C.byref(o), bases.ctypes.data,
+                                 offsets.ctypes.data, n_rec, 1 if paired else 0, res.ctypes.data, threads)
+        return res[:n_units]
+
+
+def k2_lca(parent, a, b):
+    parent = np.ascontiguousarray(parent, dtype=np.uint32)
+    return lib().k2o_lca(parent.ctypes.data, a, b)
+
+
+def k2_is_ancestor(parent, a, b):
+    parent = np.ascontiguousarray(parent, dtype=np.uint32)
+    return bool(lib().k2o_is_ancestor(parent.ctypes.data, a, b))
+
+
+def k2_resolve(taxa, counts, parent, total_kmers, confidence=0.0):
+    taxa = np.ascontiguousarray(taxa, dtype=np.uint32)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    parent = np.ascontiguousarray(parent, dtype=np.uint32)
+    return lib().k2o_resolve(taxa.ctypes.data, counts.ctypes.data, len(taxa), parent.ctypes.data, total_kmers, confidence)

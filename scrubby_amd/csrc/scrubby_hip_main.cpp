@@ -12,6 +12,8 @@ static void usage()
     fprintf(stderr,
             "scrubby-hip reads -i <R1> [R2] -o <O1> [O2] -I <ref.fa[.gz]|index.shidx> [-p sr|map-ont|lr:hq]\n"
             "                  [-e] [-j report.json] [-r read_ids.tsv[.gz]] [-t threads] [-a minimap2-rs] [-w workdir]\n"
+            "scrubby-hip reads -i <R1> [R2] -o <O1> [O2] -c kraken2 -I <kraken2 db dir> [-T taxa..] [-D taxa..] [-w workdir]\n"
+            "                  [-C \"--confidence x --minimum-hit-groups n\"] [-e] [-j report.json] [-r read_ids.tsv[.gz]]\n"
             "scrubby-hip classifier -i <R1> [R2] -o <O1> [O2] -k <report> -j <reads> -c kraken2|metabuli [-T taxa..] [-D taxa..]\n"
             "                  [-e] [--json report.json] [-r read_ids.tsv]\n");
 }
@@ -101,14 +103,9 @@ int main(int argc, char **argv)
         for (int i = 0; i < argc; ++i) { if (i) command += ' '; command += argv[i]; }
         return std::string(argv[1]) == "alignment" ? main_alignment(argc, argv, command) : main_classifier(argc, argv, command);
     }
-    if (false) {
-        std::string command;
-        for (int i = 0; i < argc; ++i) { if (i) command += ' '; command += argv[i]; }
-        return main_classifier(argc, argv, command);
-    }
     if (argc < 2 || std::string(argv[1]) != "reads") { usage(); return 2; }
-    std::vector<std::string> in, out;
-    std::string index, preset, json, ids, aligner = "minimap2-rs", command;
+    std::vector<std::string> in, out, taxa, taxa_direct;
+    std::string index, preset, json, ids, aligner, classifier, workdir, cargs, command;
     int extract = 0, threads = 4;
     for (int i = 0; i < argc; ++i) { if (i) command += ' '; command += argv[i]; }      // terminal.rs:178
     for (int i = 2; i < argc; ++i) {
@@ -120,17 +117,48 @@ int main(int argc, char **argv)
         else if (a == "-I" || a == "--index") index = val();
         else if (a == "-p" || a == "--preset") preset = val();
         else if (a == "-a" || a == "--aligner") aligner = val();
+        else if (a == "-c" || a == "--classifier") classifier = val();
+        else if (a == "-T" || a == "--taxa") multi(taxa);
+        else if (a == "-D" || a == "--taxa-direct") multi(taxa_direct);
+        else if (a == "-C" || a == "--classifier-args") cargs = val();
         else if (a == "-j" || a == "--json") json = val();
         else if (a == "-r" || a == "--read-ids") ids = val();
         else if (a == "-t" || a == "--threads") threads = atoi(val().c_str());
-        else if (a == "-w" || a == "--workdir" || a == "-l" || a == "--log-file" || a == "-A" || a == "--aligner-args") val();
+        else if (a == "-w" || a == "--workdir") workdir = val();
+        else if (a == "-l" || a == "--log-file" || a == "-A" || a == "--aligner-args") val();
         else if (a == "-e" || a == "--extract") extract = 1;
-        else if (a == "-c" || a == "--classifier" || a == "-T" || a == "--taxa" || a == "-D" || a == "--taxa-direct" || a == "-C" || a == "--classifier-args") {
-            fprintf(stderr, "error: classifier paths are not part of the HIP backend yet (%s)\n", a.c_str()); return 2;
-        } else { fprintf(stderr, "unknown argument %s\n", a.c_str()); usage(); return 2; }
+        else { fprintf(stderr, "unknown argument %s\n", a.c_str()); usage(); return 2; }
     }
-    if (aligner != "minimap2-rs") { fprintf(stderr, "error: the HIP backend replaces --aligner minimap2-rs only (got %s)\n", aligner.c_str()); return 2; }
     if (in.empty() || in.size() > 2 || in.size() != out.size()) { fprintf(stderr, "error: one or two inputs and as many outputs are required\n"); return 2; }
+    if (!classifier.empty()) {       // Cleaner::run_classifier (cleaner.rs:159-163): kraken2 on the GPU
+        if (classifier != "kraken2") { fprintf(stderr, "error: the HIP backend replaces --classifier kraken2 only (got %s)\n", classifier.c_str()); return 2; }
+        if (!aligner.empty()) { fprintf(stderr, "error: AlignerAndClassifierConfigured\n"); return 2; }
+        if (index.empty()) { fprintf(stderr, "error: MissingClassifierIndex (-I)\n"); return 2; }
+        sh_kraken_config k{};
+        std::vector<const char *> tp, dp;
+        for (auto &x : taxa) tp.push_back(x.c_str());
+        for (auto &x : taxa_direct) dp.push_back(x.c_str());
+        for (size_t q = 0; q < in.size(); ++q) { k.input[q] = in[q].c_str(); k.output[q] = out[q].c_str(); }
+        k.n_files = (uint32_t)in.size(); k.extract = extract; k.db = index.c_str(); k.workdir = workdir.empty() ? nullptr : workdir.c_str();
+        k.taxa = tp.data(); k.n_taxa = (uint32_t)tp.size(); k.taxa_direct = dp.data(); k.n_taxa_direct = (uint32_t)dp.size();
+        k.confidence = -1.0; k.min_hit_groups = 0;
+        {   // the two Kraken 2 thresholds out of --classifier-args
+            size_t p = cargs.find("--confidence");
+            if (p != std::string::npos) k.confidence = atof(cargs.c_str() + p + 12);
+            p = cargs.find("--minimum-hit-groups");
+            if (p != std::string::npos) k.min_hit_groups = atoi(cargs.c_str() + p + 20);
+        }
+        k.json = json.empty() ? nullptr : json.c_str(); k.read_ids = ids.empty() ? nullptr : ids.c_str();
+        k.command = command.c_str(); k.device = 0; k.threads = threads;
+        sh_reads_result r{};
+        sh_status st = sh_kraken_run(&k, &r);
+        if (st != SH_OK) { fprintf(stderr, "error (%d): %s\n", st, sh_last_error()); return 1; }
+        fprintf(stderr, "[scrubby-hip] depleted ids: %llu | database %.0f ms, ingest %.0f ms, classify %.0f ms, write %.0f ms\n",
+                (unsigned long long)r.n_depleted_ids, r.ms_index, r.ms_ingest, r.ms_classify, r.ms_write);
+        return 0;
+    }
+    if (aligner.empty()) aligner = "minimap2-rs";
+    if (aligner != "minimap2-rs") { fprintf(stderr, "error: the HIP backend replaces --aligner minimap2-rs only (got %s)\n", aligner.c_str()); return 2; }
     if (index.empty()) { fprintf(stderr, "error: MissingAlignmentIndex (-I)\n"); return 2; }
     sh_reads_config c{};
     for (size_t k = 0; k < in.size(); ++k) { c.input[k] = in[k].c_str(); c.output[k] = out[k].c_str(); }

@@ -12,6 +12,7 @@
 // a corrupt FASTQ is an error instead of a logged partial id set.
 #include "sh_common.h"
 #include <zlib.h>
+#include <sys/stat.h>
 #include <chrono>
 #include <ctime>
 #include <unordered_set>
@@ -541,6 +542,117 @@ extern "C" sh_status sh_reads_run(const sh_reads_config *c, sh_reads_result *res
         st = finish_report(c->input, c->output, c->n_files, c->extract != 0, c->json, c->read_ids, c->command, rs, res);
         if (st != SH_OK) return st;
     }
+    res->ms_index = ms(t0, t1); res->ms_ingest = ms(t1, t2); res->ms_classify = ms(t2, t3); res->ms_write = ms(t3, t4);
+    return SH_OK;
+}
+
+static void mkdir_p(const std::string &dir)
+{
+    for (size_t i = 1; i <= dir.size(); ++i)
+        if (i == dir.size() || dir[i] == '/') mkdir(dir.substr(0, i).c_str(), 0777);
+}
+
+// ---- Cleaner::run_kraken (cleaner.rs:288-330) in process: GPU classification instead of the external kraken2 ---------
+// kraken.reads / kraken.report are written into the workdir exactly where the reference expects them (:296-297), then
+// the same parse_classifier_output + clean_reads steps run on those files.  Divergence: column 5 of
+// kraken.reads carries the k-mer and hit-group totals, not Kraken2's positional hit list (the reference only stores it,
+// classifier.rs:401-419).
+extern "C" sh_status sh_kraken_run(const sh_kraken_config *c, sh_reads_result *res)
+{
+    SH_CHECK(c && res, SH_ERR_BAD_ARG, "sh_kraken_run: null argument");
+    SH_CHECK(c->n_files >= 1 && c->n_files <= 2, SH_ERR_BAD_ARG, "one or two input files are supported (got %u)", c->n_files);
+    for (uint32_t i = 0; i < c->n_files; ++i) SH_CHECK(c->input[i] && c->output[i], SH_ERR_BAD_ARG, "input/output %u missing", i);
+    SH_CHECK(c->db, SH_ERR_BAD_ARG, "MissingClassifierIndex");
+    SH_CHECK(c->n_taxa + c->n_taxa_direct > 0, SH_ERR_BAD_ARG, "MissingTaxa: --taxa or --taxa-direct is required");
+    memset(res, 0, sizeof(*res));
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const bool paired = c->n_files == 2;
+
+    auto t0 = now();
+    sh_k2_db *db = nullptr;
+    sh_status st = sh_k2_open(c->db, c->device, &db);
+    if (st != SH_OK) return st;
+    sh_k2_opts opts;                 // k, l, masks and the down-sampling threshold come from the database
+    sh_k2_db_opts(db, &opts);
+    if (c->confidence >= 0.0) opts.confidence = c->confidence;           // -C "--confidence x"
+    if (c->min_hit_groups > 0) opts.min_hit_groups = c->min_hit_groups;   // -C "--minimum-hit-groups n"
+    auto t1 = now();
+
+    // ingest: mates interleaved (records 2i, 2i+1); the id Kraken 2 prints for a pair is mate 1's first token with a trailing /1 removed
+    std::vector<std::string> ids;
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> offsets(1, 0);
+    std::vector<uint32_t> len1, len2;
+    auto fail = [&](sh_status s) { sh_k2_free(db); return s; };
+    {
+        bool ex0 = true, ex1 = true;
+        const bool empty0 = file_is_empty(c->input[0], ex0), empty1 = paired ? file_is_empty(c->input[1], ex1) : false;
+        if (!ex0 || !ex1) { sh_set_error("cannot open %s", !ex0 ? c->input[0] : c->input[1]); return fail(SH_ERR_IO); }
+        if (!empty0 && !(paired && empty1)) {
+            FastxReader r1(c->input[0]);
+            FastxReader *r2 = paired ? new FastxReader(c->input[1]) : nullptr;
+            FastxRecord a, b; std::string id; int s1;
+            while ((s1 = r1.next(a)) == 1) {
+                if (!get_id(a.header, id)) { delete r2; sh_set_error("record without an id in %s", c->input[0]); return fail(SH_ERR_IO); }
+                if (paired && id.size() > 2 && id.compare(id.size() - 2, 2, "/1") == 0) id.resize(id.size() - 2);
+                ids.push_back(id);
+                bases.insert(bases.end(), a.seq.begin(), a.seq.end()); offsets.push_back(bases.size()); len1.push_back((uint32_t)a.seq.size());
+                if (paired) {
+                    const int s2 = r2->next(b);
+                    if (s2 != 1) { std::string e = s2 == 0 ? "fewer records than mate 1" : r2->error; delete r2; sh_set_error("%s: %s", c->input[1], e.c_str()); return fail(SH_ERR_IO); }
+                    bases.insert(bases.end(), b.seq.begin(), b.seq.end()); offsets.push_back(bases.size()); len2.push_back((uint32_t)b.seq.size());
+                }
+            }
+            if (s1 != 0) { std::string e = r1.error; delete r2; sh_set_error("%s: %s", c->input[0], e.c_str()); return fail(SH_ERR_IO); }
+            if (paired && r2->next(b) != 0) { delete r2; sh_set_error("%s: more records than mate 1", c->input[1]); return fail(SH_ERR_IO); }
+            delete r2;
+        }
+    }
+    auto t2 = now();
+
+    std::vector<sh_k2_result> results(std::max<size_t>(ids.size(), 1));
+    bases.resize(bases.size() + 64, 'N');
+    st = sh_k2_classify_batch(db, &opts, bases.data(), offsets.data(), offsets.size() - 1, paired ? 1 : 0, results.data(), nullptr);
+    if (st != SH_OK) return fail(st);
+    auto t3 = now();
+
+    // kraken.reads and kraken.report in the workdir (cleaner.rs:291-297)
+    std::string dir = c->workdir && c->workdir[0] ? c->workdir : (getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp");
+    if (c->workdir && c->workdir[0]) mkdir_p(dir);                         // create_dir_all (cleaner.rs:293)
+    const std::string reads_path = dir + "/kraken.reads", report_path = dir + "/kraken.report";
+    {
+        FILE *f = fopen(reads_path.c_str(), "w");
+        if (!f) { sh_set_error("cannot write %s", reads_path.c_str()); return fail(SH_ERR_IO); }
+        for (size_t i = 0; i < ids.size(); ++i) {
+            const sh_k2_result &r = results[i];
+            if (paired) fprintf(f, "%c\t%s\t%u\t%u|%u\tkmers=%u groups=%u\n", r.call ? 'C' : 'U', ids[i].c_str(), r.taxid, len1[i], len2[i], r.total_kmers, r.hit_groups);
+            else fprintf(f, "%c\t%s\t%u\t%u\tkmers=%u groups=%u\n", r.call ? 'C' : 'U', ids[i].c_str(), r.taxid, len1[i], r.total_kmers, r.hit_groups);
+        }
+        if (fclose(f) != 0) { sh_set_error("short write to %s", reads_path.c_str()); return fail(SH_ERR_IO); }
+    }
+    st = sh_k2_write_report(db, results.data(), ids.size(), report_path.c_str());
+    sh_k2_free(db);
+    if (st != SH_OK) return st;
+
+    // parse_classifier_output (cleaner.rs:375-382) + clean_reads on what was just written
+    ReportSettings rs;
+    for (uint32_t i = 0; i < c->n_taxa; ++i) rs.taxa.push_back(c->taxa[i]);
+    for (uint32_t i = 0; i < c->n_taxa_direct; ++i) rs.taxa_direct.push_back(c->taxa_direct[i]);
+    std::unordered_set<std::string> taxids, dep;
+    st = taxids_from_report(report_path.c_str(), rs.taxa, rs.taxa_direct, taxids);
+    if (st != SH_OK) return st;
+    st = taxid_reads(taxids, reads_path.c_str(), false, dep);
+    if (st != SH_OK) return st;
+    res->n_depleted_ids = dep.size();
+    for (uint32_t i = 0; i < c->n_files; ++i) {
+        st = filter_fastx(c->input[i], c->output[i], dep, c->extract != 0, nullptr, nullptr);
+        if (st != SH_OK) return st;
+    }
+    auto t4 = now();
+    rs.classifier = "kraken2"; rs.index = c->db; rs.extract = c->extract != 0;
+    st = finish_report(c->input, c->output, c->n_files, c->extract != 0, c->json, c->read_ids, c->command, rs, res);
+    if (st != SH_OK) return st;
     res->ms_index = ms(t0, t1); res->ms_ingest = ms(t1, t2); res->ms_classify = ms(t2, t3); res->ms_write = ms(t3, t4);
     return SH_OK;
 }

@@ -115,6 +115,9 @@ EXPORTS = [
     "sh_synth_ref_device", "sh_synth_reads_device", "sh_synth_long_reads_device", "sh_bench_gather",
     "sh_reads_run", "sh_host_get_id", "sh_host_filter_fastx", "sh_host_read_difference",
     "sh_classifier_run", "sh_classifier_taxids", "sh_alignment_run",
+    "sh_k2_default_opts", "sh_k2_open", "sh_k2_create", "sh_k2_insert_device", "sh_k2_insert_sequence_device",
+    "sh_k2_insert_random", "sh_k2_save", "sh_k2_info_get", "sh_k2_db_opts", "sh_k2_export", "sh_k2_free",
+    "sh_k2_classify_device", "sh_k2_classify_batch", "sh_k2_write_report", "sh_kraken_run",
 ]
 
 _LIB = None

@@ -33,3 +33,51 @@ def edge_reads(ref, seed=7):
     offs = np.zeros(len(recs) + 1, dtype=np.uint64)
     offs[1:] = np.cumsum([len(x) for x in recs])
     return recs, bases, offs
+
+
+def k2_taxonomy(n_random=300, seed=3):
+    """A small NCBI-shaped taxonomy in Kraken 2's layout: breadth-first internal ids, children consecutive.
+    Contains the true lineage root -> cellular organisms -> Eukaryota -> Metazoa -> Chordata -> Mammalia -> Primates ->
+    Hominidae -> Homo -> Homo sapiens (+ a sibling species and genus), and a random bacterial tree.
+    Returns (parents, externals, names, ranks, ids) with ids = {name: internal id}."""
+    rng = np.random.default_rng(seed)
+    # tree as nested spec: (name, ext, rank, children)
+    human = ("Homo", 9605, "genus", [("Homo sapiens", 9606, "species", []), ("Homo heidelbergensis", 1425170, "species", [])])
+    pan = ("Pan", 9596, "genus", [("Pan troglodytes", 9598, "species", [])])
+    euk = ("Eukaryota", 2759, "superkingdom", [("Opisthokonta", 33154, "clade", [("Metazoa", 33208, "kingdom", [
+        ("Chordata", 7711, "phylum", [("Mammalia", 40674, "class", [("Primates", 9443, "order", [
+            ("Hominidae", 9604, "family", [human, pan])])])])])])])
+    next_ext = [100000]
+
+    def rand_tree(depth, ranks):
+        ext = next_ext[0]; next_ext[0] += 1
+        kids = []
+        if depth < len(ranks) - 1:
+            for _ in range(int(rng.integers(1, 4))):
+                kids.append(rand_tree(depth + 1, ranks))
+        return (f"{ranks[depth]}_{ext}", ext, ranks[depth], kids)
+
+    branks = ["phylum", "class", "order", "family", "genus", "species"]
+    bact_kids = []
+    while sum(1 for _ in _iter_spec(bact_kids)) < n_random:
+        bact_kids.append(rand_tree(0, branks))
+    bact = ("Bacteria", 2, "superkingdom", bact_kids)
+    root = ("root", 1, "no rank", [("cellular organisms", 131567, "no rank", [euk, bact])])
+    parents, externals, names, ranks, ids = [0], [0], [""], [""], {}
+    queue = [(root, 0)]
+    # breadth-first numbering; a node's children are appended together, so their ids are consecutive
+    order = []
+    while queue:
+        spec, par = queue.pop(0)
+        my = len(parents)
+        parents.append(par); externals.append(spec[1]); names.append(spec[0]); ranks.append(spec[2]); ids[spec[0]] = my
+        order.append((spec, my))
+        for ch in spec[3]:
+            queue.append((ch, my))
+    return parents, externals, names, ranks, ids
+
+
+def _iter_spec(specs):
+    for s in specs:
+        yield s
+        yield from _iter_spec(s[3])
