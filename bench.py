@@ -45,8 +45,11 @@ def parse():
     ap.add_argument("--records", type=int, default=20_000_000, help="records per GPU (2 per pair)")
     ap.add_argument("--chunk", type=int, default=1 << 25, help="records per kernel launch (default: the whole batch in one launch)")
     ap.add_argument("--small", action="store_true", help="5 Mb reference / 200k records (plumbing check)")
-    ap.add_argument("--workload", choices=["sr", "ont"], default="sr",
-                    help="sr = BASELINE configs[1] (headline); ont = configs[3] stand-in: long noisy reads, map-ont preset (not the headline metric)")
+    ap.add_argument("--workload", choices=["sr", "ont", "k2"], default="sr",
+                    help="sr = BASELINE configs[1] (headline); ont = configs[3] stand-in: long noisy reads, map-ont preset; "
+                         "k2 = configs[4] stand-in: Kraken2-style taxid classification of 2x150 bp pairs against an 8 GB table (not the headline metric)")
+    ap.add_argument("--k2-cells", type=int, default=2_000_000_000, help="cells of the compact hash table (4 B each)")
+    ap.add_argument("--k2-nodes", type=int, default=50_000, help="taxonomy nodes of the synthetic database")
     ap.add_argument("--ont-chunk", type=int, default=1 << 25, help="long reads per launch (--workload ont)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -66,6 +69,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     S.require_gpu()
+    if a.workload == "k2":
+        return main_k2(a, rank, world, local, dev)
 
     contigs = [1_000_000] * 5 if a.small else CHM13_CONTIGS
     n_rec = 200_000 if a.small else a.records
@@ -225,6 +230,155 @@ def main():
             out["gather_ceiling"] = gather
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.destroy_process_group()
+
+
+def k2_taxonomy(n_nodes, seed):
+    """Synthetic taxonomy in Kraken 2's layout (breadth-first ids, children consecutive): the true human lineage plus a
+    random bacterial tree with real rank names, >= n_nodes nodes."""
+    rng = np.random.default_rng(seed)
+    lineage = [("root", 1, "no rank"), ("cellular organisms", 131567, "no rank"), ("Eukaryota", 2759, "superkingdom"),
+               ("Opisthokonta", 33154, "clade"), ("Metazoa", 33208, "kingdom"), ("Chordata", 7711, "phylum"), ("Mammalia", 40674, "class"),
+               ("Primates", 9443, "order"), ("Hominidae", 9604, "family"), ("Homo", 9605, "genus"), ("Homo sapiens", 9606, "species")]
+    branks = ["superkingdom", "phylum", "class", "order", "family", "genus", "species", "strain"]
+    parents, externals, names, ranks = [0], [0], [""], [""]
+    # queue entries: (parent id, lineage index or -1, bacterial depth or -1)
+    queue = [(0, 0, -1)]
+    next_ext = 1_000_000
+    qi = 0
+    while qi < len(queue):
+        par, li, bd = queue[qi]; qi += 1
+        me = len(parents)
+        parents.append(par)
+        if li >= 0:
+            names.append(lineage[li][0]); externals.append(lineage[li][1]); ranks.append(lineage[li][2])
+            if li + 1 < len(lineage):
+                queue.append((me, li + 1, -1))
+            if li == 1:
+                queue.append((me, -1, 0))                  # Bacteria beside Eukaryota
+        else:
+            if bd == 0:
+                names.append("Bacteria"); externals.append(2)
+            else:
+                names.append(f"{branks[bd]} {next_ext}"); externals.append(next_ext); next_ext += 1
+            ranks.append(branks[bd])
+            if bd + 1 < len(branks) and len(queue) < n_nodes:
+                for _ in range(int(rng.integers(3, 9))):
+                    queue.append((me, -1, bd + 1))
+    ids = {n: i for i, n in enumerate(names)}
+    return parents, externals, names, ranks, ids
+
+
+def main_k2(a, rank, world, local, dev):
+    """BASELINE configs[4] stand-in: Kraken2-style classification of 2x150 bp pairs against a table of --k2-cells 32-bit
+    cells in HBM (default 2e9 = 8 GB, load ~0.7: every minimizer of the CHM13v2-sized synthetic reference under Homo
+    sapiens + pseudo-random filler keys over the bacterial taxa), taxonomy of >= 50 000 nodes."""
+    from scrubby_amd import k2 as K
+    contigs = [1_000_000] * 5 if a.small else CHM13_CONTIGS
+    n_rec = 200_000 if a.small else (a.records if a.records != 20_000_000 else 40_000_000)
+    n_rec -= n_rec & 1
+    cells = 12_000_017 if a.small else a.k2_cells
+    P = S.ref_params(REF_SEED, contigs)
+    R = S.read_params(0x5C2B0030)
+    G = P.genome_len
+    t0 = time.time()
+    parents, externals, names, ranks, ids = k2_taxonomy(2_000 if a.small else a.k2_nodes, 0x5C2B0030)
+    o = K.default_opts()
+    db = K.K2Db.create(o, cells, parents, externals, names, ranks, device=local)
+    d_ref = torch.empty(G + 64, dtype=torch.uint8, device=dev)
+    S.synth_ref_device(P, 0, G, d_ref)
+    n_runs = db.insert_sequence_device(d_ref, G, ids["Homo sapiens"])
+    del d_ref
+    torch.cuda.empty_cache()
+    size_host = db.info()["size"]
+    fill = max(int(0.70 * cells) - size_host, 0)
+    db.insert_random(0x5C2B0031, fill, ids["Bacteria"], len(parents) - 1)
+    torch.cuda.synchronize()
+    info = db.info()
+    t_db = time.time() - t0
+
+    L = R.read_len
+    n_bases = n_rec * L
+    d_reads = torch.empty(n_bases + 64, dtype=torch.uint8, device=dev)
+    d_off = torch.empty(n_rec + 1, dtype=torch.int64, device=dev)
+    S.synth_reads_device(P, R, rank * n_rec, n_rec, d_reads, d_off)
+    n_units = n_rec // 2
+    d_out = torch.zeros((n_units, 4), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    st = None
+    for _ in range(a.warmup):
+        st = db.classify_device(d_reads, d_off, n_rec, True, d_out)
+    barrier()
+    t0 = time.time()
+    ms_kernel = 0.0
+    for _ in range(a.steps):
+        st = db.classify_device(d_reads, d_off, n_rec, True, d_out)
+        ms_kernel += st["ms_classify"]
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_step = dt * 1e3 / max(a.steps, 1)
+    value = n_rec * world / (ms_step * 1e-3)
+    res = d_out.cpu().numpy().view(K.RESULT_DTYPE).reshape(-1)
+    # algorithmic bytes per pair (SURVEY.md §8d): L1 + L2 + 8 + 4 * P + 4
+    alg = n_bases + 8 * n_units + 4 * st["n_probes"] + 4 * n_units
+    avg_ms = ms_kernel / max(a.steps, 1)
+    roof = {"bound": "hbm", "kernel": "k_k2_classify", "achieved": round(alg / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "launches_per_step": 1, "avg_launch_ms": round(avg_ms, 3),
+            "alg_bytes_per_launch": int(alg), "probes_per_launch": int(st["n_probes"]),
+            "probe_rate_G_per_s": round(st["n_probes"] / (avg_ms * 1e-3) / 1e9, 2)}
+    cpu = None
+    if rank == 0 and not a.no_cpu:
+        from oracle import oracle as O
+        cells_h, parent_h, ext_h = db.export()
+        tab = O.K2Table(cells_h, parent_h, info["value_bits"])
+        cores = os.cpu_count() or 1
+        n_s = min(n_rec, 200_000)
+        sample = d_reads[: n_s * L].cpu().numpy()
+        offs = np.arange(n_s + 1, dtype=np.uint64) * L
+        oo = O.k2_default_opts()
+        t1 = time.time()
+        tab.classify(oo, sample[: 20_000 * L], offs[: 20_001], paired=True, threads=cores)
+        rate = 20_000 / max(time.time() - t1, 1e-6)
+        n_s = int(min(n_rec, max(20_000, rate * a.cpu_seconds))) & ~1
+        sample = d_reads[: n_s * L].cpu().numpy()
+        offs = np.arange(n_s + 1, dtype=np.uint64) * L
+        t1 = time.time()
+        c = tab.classify(oo, sample, offs, paired=True, threads=cores)
+        dtc = time.time() - t1
+        diff = int((c["call"] != res["call"][: n_s // 2]).sum())
+        cpu = {"value": round(n_s / dtc, 1), "unit": "reads/s", "cores": cores, "kind": "port",
+               "sample": f"first {n_s} records of the same batch, same table (copied from HBM), {cores} threads, {dtc:.1f} s; "
+                         f"restatement baseline - not kraken2; calls differing from the GPU on the sample: {diff}"}
+    if rank == 0:
+        out = {"metric": "reads/s classified (Kraken2-style taxid path, 2x150bp PE vs 8 GB table) - NOT the headline metric",
+               "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (minimizers) / u32 (cells, taxa)", "data": "synthetic",
+               "config": {"workload": "configs[4] stand-in: %d synthetic 2x150bp pairs vs a Kraken2-format table of %d cells (%.1f GB, load %.2f), "
+                                      "taxonomy of %d nodes, k=35 l=31, confidence 0, minimum-hit-groups 2" %
+                                      (n_units, info["capacity"], info["capacity"] * 4 / 1e9, info["size"] / info["capacity"], info["n_nodes"]),
+                          "records_per_gpu": n_rec, "read_len": L, "parallelism": "pair-sharded x%d, table replicated" % world,
+                          "ref_seed": hex(REF_SEED), "read_seed": hex(0x5C2B0030)},
+               "result": {"pairs_classified_rank0": int(st["n_classified"]), "pairs_human_rank0": int((res["taxid"] == 9606).sum()),
+                          "probes": int(st["n_probes"]), "kmers": int(st["n_kmers"]), "overflow_units": int(st["n_overflow"])},
+               "database": {"cells": info["capacity"], "occupied": info["size"], "reference_minimizer_runs": int(n_runs), "nodes": info["n_nodes"],
+                            "build_s": round(t_db, 2)},
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    db.close()
+    if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

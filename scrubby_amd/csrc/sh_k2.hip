@@ -20,8 +20,8 @@
 #include <string>
 #include <vector>
 
-#define K2_QCAP 16          // pending runs per lane
-#define K2_HCAP 16          // distinct taxa per unit kept in LDS
+#define K2_QCAP 8           // pending runs per lane
+#define K2_HCAP 8           // distinct taxa per unit kept in LDS (10 KiB of LDS per wave with the queue: 16 waves per CU)
 #define K2_BIG_CAP 4096     // ... in HBM for the overflow pass
 
 struct sh_k2_db {
@@ -59,7 +59,19 @@ __device__ static inline bool k2_is_ancestor(const uint32_t *__restrict__ parent
     return a == b;
 }
 
-struct K2Table { const uint32_t *cells; uint64_t capacity; int32_t value_bits; };
+struct K2Table { const uint32_t *cells; uint64_t capacity; int32_t value_bits; double inv_capacity; };
+
+// hc % capacity without the 64-bit division sequence: the double-precision quotient estimate is off by at most one for
+// capacity >= 2^20 (q < 2^44, relative error 2^-52), which one conditional add / subtract repairs
+__device__ static inline uint64_t k2_mod(uint64_t hc, uint64_t capacity, double inv_capacity)
+{
+    if (capacity < (1ull << 20)) return hc % capacity;
+    const uint64_t q = (uint64_t)((double)hc * inv_capacity);
+    int64_t r = (int64_t)(hc - q * capacity);
+    if (r < 0) r += (int64_t)capacity;
+    else if (r >= (int64_t)capacity) r -= (int64_t)capacity;
+    return (uint64_t)r;
+}
 
 // rolling scanner state of one lane; the window holds k - l + 1 candidates (<= W; the instantiations are W = 1, 5 and,
 // for every other (k, l), 16 with the live part given at run time)
@@ -80,24 +92,23 @@ struct K2Scan {
         return step_w(code, pos, k, l, lmask, spaced, toggle, m, k - l + 1);
     }
     __device__ inline int step_w(uint32_t code, int32_t pos, int32_t k, int32_t l, uint64_t lmask, uint64_t spaced, uint64_t toggle, uint64_t &m, int32_t wlim)
-    {
-        if (code > 3) { reset(); return pos >= k ? 1 : 0; }
-        fw = ((fw << 2) | code) & lmask;
-        rc = (rc >> 2) | ((uint64_t)(3u - code) << (2 * (l - 1)));
-        if (loaded < l) ++loaded;
-        if (loaded < l) return pos >= k ? 1 : 0;
+    {   // branch-free: 64 lanes scan 64 different reads
+        const bool amb = code > 3;
+        fw = amb ? 0ull : ((fw << 2) | code) & lmask;
+        rc = amb ? 0ull : (rc >> 2) | ((uint64_t)(3u - code) << (2 * (l - 1)));
+        loaded = amb ? 0 : (loaded < l ? loaded + 1 : l);
+        const bool full = loaded == l;
         uint64_t canon = fw < rc ? fw : rc;
         if (spaced) canon &= spaced;
         const uint64_t cand = canon ^ toggle;
 #pragma unroll
-        for (int i = W - 1; i > 0; --i) c[i] = c[i - 1];
-        c[0] = cand;
-        if (pos < k) return 0;
+        for (int i = W - 1; i > 0; --i) c[i] = amb ? ~0ull : (full ? c[i - 1] : c[i]);
+        c[0] = amb ? ~0ull : (full ? cand : c[0]);
         uint64_t mn = c[0];
 #pragma unroll
         for (int i = 1; i < W; ++i) mn = (i < wlim && c[i] < mn) ? c[i] : mn;
         m = mn ^ toggle;
-        return 2;
+        return pos >= k ? (full ? 2 : 1) : 0;
     }
 };
 
@@ -167,14 +178,71 @@ __device__ static inline uint32_t k2_finish_probe(const K2Table &T, uint64_t idx
     }
 }
 
+// Linear probing walks consecutive cells, so a probe reads whole 32-B groups of 8 cells (one HBM sector) instead of one
+// cell per dependent load: at load 0.7 a miss inspects ~6 cells = 1-2 groups, and the slowest lane of a wave (which every
+// other lane waits for) needs 3-4 steps instead of 30.
+struct K2Group { uint4 lo, hi; };
+__device__ static inline K2Group k2_load_group(const uint32_t *cells, uint64_t g)
+{
+    const uint4 *p = (const uint4 *)(cells + 8 * g);
+    return K2Group{p[0], p[1]};
+}
+// first terminating cell (empty, or same truncated key) at or after `start`; returns false if the group has none
+__device__ static inline bool k2_scan_group(const K2Group &G, uint32_t start, uint32_t vmask, int32_t vb, uint32_t comp, uint32_t &taxon)
+{
+    const uint32_t c[8] = {G.lo.x, G.lo.y, G.lo.z, G.lo.w, G.hi.x, G.hi.y, G.hi.z, G.hi.w};
+    uint32_t term = 0, match = 0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const bool e = !(c[t] & vmask), mm = (c[t] >> vb) == comp;
+        term |= (uint32_t)(e || mm) << t; match |= (uint32_t)(mm && !e) << t;
+    }
+    term &= 0xffu << start;
+    if (!term) return false;
+    const int t0 = __ffs((int)term) - 1;
+    uint32_t v = 0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v = t == t0 ? c[t] : v;
+    taxon = ((match >> t0) & 1u) ? v & vmask : 0u;
+    return true;
+}
+// the rest of a probe whose first group did not decide it
+__device__ static inline uint32_t k2_probe_rest(const K2Table &T, uint64_t g, uint32_t comp)
+{
+    const uint32_t vmask = (1u << T.value_bits) - 1;
+    const uint64_t n_full = T.capacity / 8;          // groups [0, n_full) lie entirely inside the table
+    for (uint64_t step = 0; step <= n_full + 1; ++step) {
+        ++g;
+        if (g >= n_full) {                            // the ragged tail group and the wrap to cell 0: cell by cell
+            uint64_t idx = g * 8 < T.capacity ? g * 8 : 0;
+            for (; idx < T.capacity && idx >= n_full * 8; ++idx) {
+                const uint32_t c = T.cells[idx];
+                if (!(c & vmask)) return 0;
+                if ((c >> T.value_bits) == comp) return c & vmask;
+            }
+            g = 0;
+            if (n_full == 0) continue;
+            const K2Group G0 = k2_load_group(T.cells, 0);
+            uint32_t taxon;
+            if (k2_scan_group(G0, 0, vmask, T.value_bits, comp, taxon)) return taxon;
+            continue;
+        }
+        const K2Group G = k2_load_group(T.cells, g);
+        uint32_t taxon;
+        if (k2_scan_group(G, 0, vmask, T.value_bits, comp, taxon)) return taxon;
+    }
+    return 0;
+}
+
 template <int W, bool BIG>
 __global__ __launch_bounds__(64) void k_k2_classify(K2Args a)
 {
-    __shared__ uint64_t s_qmin[K2_QCAP * 64];
-    __shared__ uint32_t s_qlen[K2_QCAP * 64];
+    __shared__ uint64_t s_qmin[(K2_QCAP + 1) * 64];       // slot n_pend is written unconditionally, so one spare
+    __shared__ uint32_t s_qlen[(K2_QCAP + 1) * 64];
     __shared__ uint32_t s_htax[BIG ? 1 : K2_HCAP * 64], s_hcnt[BIG ? 1 : K2_HCAP * 64];
     const uint32_t lane = threadIdx.x;
     const uint64_t lmask = a.l < 32 ? ((1ULL << (2 * a.l)) - 1) : ~0ULL;
+    const int32_t wlim = a.k - a.l + 1;
     const uint64_t n_work = BIG ? a.n_list : a.n_units;
     unsigned long long probes_thr = 0, kmers_thr = 0; uint32_t class_thr = 0;
     for (uint64_t base = (uint64_t)blockIdx.x * 64; base < n_work; base += (uint64_t)gridDim.x * 64) {
@@ -188,62 +256,94 @@ __global__ __launch_bounds__(64) void k_k2_classify(K2Args a)
         uint32_t total = 0, groups = 0, n_pend = 0, probes_unit = 0;
         const int n_frag = a.paired ? 2 : 1;
         auto drain = [&]() {       // every lane probes its pending runs, four gathers in flight
+            const uint32_t vmask = (1u << a.T.value_bits) - 1;
+            const uint64_t n_full = a.T.capacity / 8;
             for (uint32_t e0 = 0; e0 < K2_QCAP; e0 += 4) {
                 if (__ballot(e0 < n_pend) == 0) break;
-                uint64_t idx[4]; uint32_t cell[4], comp[4]; bool go[4];
+                uint64_t idx[4]; uint32_t comp[4]; bool go[4]; K2Group G[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     go[q] = e0 + q < n_pend;
-                    idx[q] = 0; comp[q] = 0; cell[q] = 0;
+                    idx[q] = 0; comp[q] = 0;
                     if (go[q]) {
                         const uint64_t hc = k2_fmix64(s_qmin[(e0 + q) * 64 + lane]);
                         if (a.min_hash && hc < a.min_hash) go[q] = false;      // down-sampled database: not looked up (taxon 0)
-                        else { comp[q] = (uint32_t)(hc >> (32 + a.T.value_bits)); idx[q] = hc % a.T.capacity; }
+                        else { comp[q] = (uint32_t)(hc >> (32 + a.T.value_bits)); idx[q] = k2_mod(hc, a.T.capacity, a.T.inv_capacity); }
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (go[q]) cell[q] = a.T.cells[idx[q]];
+                for (int q = 0; q < 4; ++q) {       // eight 16-B gathers in flight per lane
+                    const bool whole = go[q] && (idx[q] >> 3) < n_full;
+                    G[q] = whole ? k2_load_group(a.T.cells, idx[q] >> 3) : K2Group{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (!go[q]) continue;
                     ++probes_unit;
-                    const uint32_t taxon = k2_finish_probe(a.T, idx[q], cell[q], comp[q]);
+                    uint32_t taxon = 0;
+                    if ((idx[q] >> 3) < n_full) {
+                        if (!k2_scan_group(G[q], (uint32_t)idx[q] & 7u, vmask, a.T.value_bits, comp[q], taxon)) taxon = k2_probe_rest(a.T, idx[q] >> 3, comp[q]);
+                    } else taxon = k2_finish_probe(a.T, idx[q], a.T.cells[idx[q]], comp[q]);      // home cell in the ragged tail group
                     if (taxon) { ++groups; H.add(taxon, s_qlen[(e0 + q) * 64 + lane]); }
                 }
             }
             n_pend = 0;
         };
+        // Both fragments run through ONE character loop (one call site of drain): fragment f covers the chunk range
+        // [f * n_chunks_max, (f + 1) * n_chunks_max) of the wave, each lane idling past its own read's end.
+        uint64_t o_beg[2] = {0, 0}; int32_t len[2] = {0, 0};
+        int32_t max_len = 0;
         for (int f = 0; f < n_frag; ++f) {
             const uint64_t rec = a.paired ? 2 * u + (uint64_t)f : u;
-            const uint64_t o_beg = active ? a.offsets[rec] : 0;
-            const int32_t len = active ? (int32_t)(a.offsets[rec + 1] - o_beg) : 0;
-            int32_t max_len = len;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { int32_t t = __shfl_xor(max_len, o); max_len = t > max_len ? t : max_len; }
-            K2Scan<W> S; S.reset();
-            uint64_t last_min = ~0ull; uint32_t run = 0;
-            uint64_t w8 = 0;
-            const uint8_t *p0 = a.bases + o_beg;
-            for (int32_t i = 0; i < max_len; ++i) {
-                if (__ballot(n_pend >= K2_QCAP - 1) != 0) drain();       // wave-uniform: every lane is here
-                if (i < len) {
-                    const uintptr_t ad = (uintptr_t)(p0 + i);
-                    if (i == 0 || (ad & 7) == 0) w8 = *(const uint64_t *)(ad & ~(uintptr_t)7);
-                    const uint32_t ch = (uint32_t)(w8 >> (8 * (ad & 7))) & 0xffu;
-                    uint64_t m = 0;
-                    const int ev = S.step(sh_nt4(ch), i + 1, a.k, a.l, lmask, a.spaced, a.toggle, m);
-                    total += ev != 0;
-                    if (ev == 2) {
-                        if (m != last_min) {
-                            if (run) { s_qmin[n_pend * 64 + lane] = last_min; s_qlen[n_pend * 64 + lane] = run; ++n_pend; }
-                            last_min = m; run = 1;
-                        } else ++run;
-                    }
-                }
-            }
-            if (__ballot(n_pend >= K2_QCAP - 1) != 0) drain();
-            if (run) { s_qmin[n_pend * 64 + lane] = last_min; s_qlen[n_pend * 64 + lane] = run; ++n_pend; }
+            o_beg[f] = active ? a.offsets[rec] : 0;
+            len[f] = active ? (int32_t)(a.offsets[rec + 1] - o_beg[f]) : 0;
+            max_len = len[f] > max_len ? len[f] : max_len;
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { int32_t t = __shfl_xor(max_len, o); max_len = t > max_len ? t : max_len; }
+        const int32_t n_chunks = (max_len + 7) / 8;
+        K2Scan<W> S; S.reset();
+        uint64_t last_min = ~0ull; uint32_t run = 0;
+        int32_t my_len = 0, off8 = 0; uint32_t sh = 0;
+        const uint64_t *wp = nullptr;
+        uint64_t w_cur = 0, w_next = 0;
+#pragma nounroll
+        for (int32_t cc = 0; cc < n_chunks * n_frag; ++cc) {
+            const int32_t c = cc < n_chunks ? cc : cc - n_chunks;
+            if (c == 0) {          // (wave-uniform) next fragment: flush the last run, restart the scanner
+                const int f = cc < n_chunks ? 0 : 1;
+                s_qmin[n_pend * 64 + lane] = last_min; s_qlen[n_pend * 64 + lane] = run;
+                n_pend += run != 0;
+                S.reset(); last_min = ~0ull; run = 0;
+                my_len = len[f];
+                const uintptr_t pa = (uintptr_t)(a.bases + o_beg[f]);
+                wp = (const uint64_t *)(pa & ~(uintptr_t)7); off8 = (int32_t)(pa & 7); sh = (uint32_t)off8 * 8;
+                // only the aligned words that overlap the read are ever loaded
+                w_cur = my_len > 0 ? wp[0] : 0;
+                w_next = my_len + off8 > 8 ? wp[1] : 0;
+            }
+            uint64_t w = sh ? (w_cur >> sh) | (w_next << (64 - sh)) : w_cur;
+            w_cur = w_next;
+            w_next = (c + 2) * 8 < my_len + off8 ? wp[c + 2] : 0;          // two words ahead: the load has a whole chunk to land
+#pragma nounroll
+            for (int32_t b = 0; b < 8; ++b) {
+                if (__ballot(n_pend >= K2_QCAP - 1) != 0) drain();       // wave-uniform: every lane is here
+                const int32_t i = c * 8 + b;
+                uint64_t m;
+                int ev = S.step_w(sh_nt4((uint32_t)w & 0xffu), i + 1, a.k, a.l, lmask, a.spaced, a.toggle, m, wlim);
+                w >>= 8;
+                ev = i < my_len ? ev : 0;
+                total += ev != 0;
+                const bool fresh = ev == 2 && m != last_min;
+                s_qmin[n_pend * 64 + lane] = last_min; s_qlen[n_pend * 64 + lane] = run;      // kept only if the run just ended
+                n_pend += fresh && run != 0;
+                run = fresh ? 1u : run + (ev == 2);
+                last_min = fresh ? m : last_min;
+            }
+        }
+        if (__ballot(n_pend >= K2_QCAP - 1) != 0) drain();
+        s_qmin[n_pend * 64 + lane] = last_min; s_qlen[n_pend * 64 + lane] = run;
+        n_pend += run != 0;
         drain();
         if (active) {
             kmers_thr += total;
@@ -659,7 +759,7 @@ extern "C" sh_status sh_k2_classify_device(const sh_k2_db *db, const sh_k2_opts 
     SH_HIP(hipMemsetAsync(ctr, 0, K2C_WORDS * 8, s));
     K2Args a{};
     a.bases = d_bases; a.offsets = d_offsets; a.n_units = n_units; a.paired = paired;
-    a.T = K2Table{db->d_cells, db->capacity, db->value_bits}; a.parent = db->d_parent; a.ext = db->d_ext; a.n_nodes = (uint32_t)db->nodes.size();
+    a.T = K2Table{db->d_cells, db->capacity, db->value_bits, 1.0 / (double)db->capacity}; a.parent = db->d_parent; a.ext = db->d_ext; a.n_nodes = (uint32_t)db->nodes.size();
     a.k = o.k; a.l = o.l; a.spaced = o.spaced_seed_mask; a.toggle = o.toggle_mask; a.min_hash = o.min_acceptable_hash;
     a.min_hit_groups = o.min_hit_groups; a.confidence = o.confidence;
     a.out = d_out; a.over_list = over; a.ctr = ctr;

@@ -347,3 +347,24 @@ def test_kraken_run_single_end_and_cli(K, oracle, db, table, cfg1, tmp_path):
     p = subprocess.run([exe, "reads", "-i", str(tmp_path / "in.fastq"), "-o", str(tmp_path / "o2.fastq"), "-c", "metabuli", "-I", str(dbdir), "-T", "x"],
                        capture_output=True, text=True)
     assert p.returncode == 2
+
+
+def test_tiny_tables_wrap_and_ragged_tail(K, oracle, cfg1, tax):
+    """Probe chains that run through the ragged last group of cells, wrap to cell 0, or lap a full table."""
+    P, R, ref, seqs, reads, off = cfg1
+    parents, externals, names, ranks, ids = tax
+    rng = np.random.default_rng(17)
+    n = 1500
+    for cap, n_keys in ((1009, 900), (1024, 1000), (13, 12), (5, 5), (64, 64)):
+        d = K.K2Db.create(K.default_opts(), cap, parents, externals, names, ranks)
+        keys = rng.integers(0, 1 << 62, n_keys, dtype=np.uint64)
+        if cap >= 1000:            # some true minimizers of the reads, so that there are real hits too
+            m, a = oracle.k2_scan(bytes(reads[:150]), oracle.k2_default_opts())
+            keys[:20] = m[:20]
+        d.insert(keys, rng.integers(1, len(parents), n_keys, dtype=np.uint32))
+        cells, parent, ext = d.export()
+        g, st = d.classify(reads[: n * 150], off[: n + 1], paired=True)
+        c = oracle.K2Table(cells, parent, 17).classify(oracle.k2_default_opts(), reads[: n * 150], off[: n + 1], paired=True)
+        _same(oracle, g, c, ext)
+        assert st["n_probes"] == int(c["n_probes"].sum())
+        d.close()
