@@ -255,9 +255,12 @@ __global__ __launch_bounds__(64) void k_k2_classify(K2Args a)
         H.n = 0; H.over = false;
         uint32_t total = 0, groups = 0, n_pend = 0, probes_unit = 0;
         const int n_frag = a.paired ? 2 : 1;
-        auto drain = [&]() {       // every lane probes its pending runs, four gathers in flight
+        auto drain = [&]() {
+            // pass 1: every lane gathers the home group of each pending run, eight 16-B loads in flight; the outcome goes
+            // back into the queue slot: the taxon, or (undecided | truncated key | group) for the rare longer chain
             const uint32_t vmask = (1u << a.T.value_bits) - 1;
             const uint64_t n_full = a.T.capacity / 8;
+            uint32_t undecided = 0, skipped = 0;         // per-lane bit e: entry e needs the long-chain code / was not looked up
             for (uint32_t e0 = 0; e0 < K2_QCAP; e0 += 4) {
                 if (__ballot(e0 < n_pend) == 0) break;
                 uint64_t idx[4]; uint32_t comp[4]; bool go[4]; K2Group G[4];
@@ -267,24 +270,42 @@ __global__ __launch_bounds__(64) void k_k2_classify(K2Args a)
                     idx[q] = 0; comp[q] = 0;
                     if (go[q]) {
                         const uint64_t hc = k2_fmix64(s_qmin[(e0 + q) * 64 + lane]);
-                        if (a.min_hash && hc < a.min_hash) go[q] = false;      // down-sampled database: not looked up (taxon 0)
+                        if (a.min_hash && hc < a.min_hash) { go[q] = false; skipped |= 1u << (e0 + q); }      // down-sampled database: not looked up
                         else { comp[q] = (uint32_t)(hc >> (32 + a.T.value_bits)); idx[q] = k2_mod(hc, a.T.capacity, a.T.inv_capacity); }
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {       // eight 16-B gathers in flight per lane
+                for (int q = 0; q < 4; ++q) {
                     const bool whole = go[q] && (idx[q] >> 3) < n_full;
                     G[q] = whole ? k2_load_group(a.T.cells, idx[q] >> 3) : K2Group{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (!go[q]) continue;
-                    ++probes_unit;
                     uint32_t taxon = 0;
-                    if ((idx[q] >> 3) < n_full) {
-                        if (!k2_scan_group(G[q], (uint32_t)idx[q] & 7u, vmask, a.T.value_bits, comp[q], taxon)) taxon = k2_probe_rest(a.T, idx[q] >> 3, comp[q]);
-                    } else taxon = k2_finish_probe(a.T, idx[q], a.T.cells[idx[q]], comp[q]);      // home cell in the ragged tail group
-                    if (taxon) { ++groups; H.add(taxon, s_qlen[(e0 + q) * 64 + lane]); }
+                    const bool whole = (idx[q] >> 3) < n_full;
+                    const bool done = whole && k2_scan_group(G[q], (uint32_t)idx[q] & 7u, vmask, a.T.value_bits, comp[q], taxon);
+                    if (done) s_qmin[(e0 + q) * 64 + lane] = taxon;      // else the slot keeps the minimizer for pass 2
+                    else undecided |= 1u << (e0 + q);
+                }
+            }
+            // pass 2: one copy of the long-chain code and of the hit-list update
+#pragma nounroll
+            for (uint32_t e = 0; e < K2_QCAP; ++e) {
+                if (__ballot(e < n_pend) == 0) break;
+                if (e < n_pend) {
+                    const uint64_t v = s_qmin[e * 64 + lane];
+                    if (!((skipped >> e) & 1u)) {
+                        ++probes_unit;
+                        uint32_t taxon = (uint32_t)v;
+                        if ((undecided >> e) & 1u) {        // the chain leaves the home group (or starts in the ragged tail group)
+                            const uint64_t hc = k2_fmix64(v);
+                            const uint32_t comp = (uint32_t)(hc >> (32 + a.T.value_bits));
+                            const uint64_t idx = k2_mod(hc, a.T.capacity, a.T.inv_capacity);
+                            taxon = (idx >> 3) < n_full ? k2_probe_rest(a.T, idx >> 3, comp) : k2_finish_probe(a.T, idx, a.T.cells[idx], comp);
+                        }
+                        if (taxon) { ++groups; H.add(taxon, s_qlen[e * 64 + lane]); }
+                    }
                 }
             }
             n_pend = 0;
@@ -307,44 +328,49 @@ __global__ __launch_bounds__(64) void k_k2_classify(K2Args a)
         int32_t my_len = 0, off8 = 0; uint32_t sh = 0;
         const uint64_t *wp = nullptr;
         uint64_t w_cur = 0, w_next = 0;
+        // ONE loop over the characters of both fragments with ONE call site of drain (the probe code is large): step s is
+        // character (s & 7) of chunk (s >> 3); the step after the last one flushes the final run and empties the queues.
+        const int32_t n_steps = n_chunks * n_frag * 8;
+        uint64_t w = 0;
 #pragma nounroll
-        for (int32_t cc = 0; cc < n_chunks * n_frag; ++cc) {
-            const int32_t c = cc < n_chunks ? cc : cc - n_chunks;
-            if (c == 0) {          // (wave-uniform) next fragment: flush the last run, restart the scanner
-                const int f = cc < n_chunks ? 0 : 1;
-                s_qmin[n_pend * 64 + lane] = last_min; s_qlen[n_pend * 64 + lane] = run;
-                n_pend += run != 0;
-                S.reset(); last_min = ~0ull; run = 0;
-                my_len = len[f];
-                const uintptr_t pa = (uintptr_t)(a.bases + o_beg[f]);
-                wp = (const uint64_t *)(pa & ~(uintptr_t)7); off8 = (int32_t)(pa & 7); sh = (uint32_t)off8 * 8;
-                // only the aligned words that overlap the read are ever loaded
-                w_cur = my_len > 0 ? wp[0] : 0;
-                w_next = my_len + off8 > 8 ? wp[1] : 0;
+        for (int32_t s = 0;; ++s) {
+            const bool end = s == n_steps;
+            const int32_t cc = s >> 3, c = cc < n_chunks ? cc : cc - n_chunks;
+            if ((s & 7) == 0) {
+                if (c == 0 || end) {       // (wave-uniform) fragment boundary: flush the last run, restart the scanner
+                    s_qmin[n_pend * 64 + lane] = last_min; s_qlen[n_pend * 64 + lane] = run;
+                    n_pend += run != 0;
+                    S.reset(); last_min = ~0ull; run = 0;
+                    if (!end) {
+                        const int f = cc < n_chunks ? 0 : 1;
+                        my_len = len[f];
+                        const uintptr_t pa = (uintptr_t)(a.bases + o_beg[f]);
+                        wp = (const uint64_t *)(pa & ~(uintptr_t)7); off8 = (int32_t)(pa & 7); sh = (uint32_t)off8 * 8;
+                        // only the aligned words that overlap the read are ever loaded
+                        w_cur = my_len > 0 ? wp[0] : 0;
+                        w_next = my_len + off8 > 8 ? wp[1] : 0;
+                    }
+                }
+                if (!end) {
+                    w = sh ? (w_cur >> sh) | (w_next << (64 - sh)) : w_cur;
+                    w_cur = w_next;
+                    w_next = (c + 2) * 8 < my_len + off8 ? wp[c + 2] : 0;      // two words ahead: the load has a whole chunk to land
+                }
             }
-            uint64_t w = sh ? (w_cur >> sh) | (w_next << (64 - sh)) : w_cur;
-            w_cur = w_next;
-            w_next = (c + 2) * 8 < my_len + off8 ? wp[c + 2] : 0;          // two words ahead: the load has a whole chunk to land
-#pragma nounroll
-            for (int32_t b = 0; b < 8; ++b) {
-                if (__ballot(n_pend >= K2_QCAP - 1) != 0) drain();       // wave-uniform: every lane is here
-                const int32_t i = c * 8 + b;
-                uint64_t m;
-                int ev = S.step_w(sh_nt4((uint32_t)w & 0xffu), i + 1, a.k, a.l, lmask, a.spaced, a.toggle, m, wlim);
-                w >>= 8;
-                ev = i < my_len ? ev : 0;
-                total += ev != 0;
-                const bool fresh = ev == 2 && m != last_min;
-                s_qmin[n_pend * 64 + lane] = last_min; s_qlen[n_pend * 64 + lane] = run;      // kept only if the run just ended
-                n_pend += fresh && run != 0;
-                run = fresh ? 1u : run + (ev == 2);
-                last_min = fresh ? m : last_min;
-            }
+            if (__ballot(n_pend >= (end ? 1u : (uint32_t)K2_QCAP - 1)) != 0) drain();       // wave-uniform: every lane is here
+            if (end) break;
+            const int32_t i = c * 8 + (s & 7);
+            uint64_t m;
+            int ev = S.step_w(sh_nt4((uint32_t)w & 0xffu), i + 1, a.k, a.l, lmask, a.spaced, a.toggle, m, wlim);
+            w >>= 8;
+            ev = i < my_len ? ev : 0;
+            total += ev != 0;
+            const bool fresh = ev == 2 && m != last_min;
+            s_qmin[n_pend * 64 + lane] = last_min; s_qlen[n_pend * 64 + lane] = run;      // kept only if the run just ended
+            n_pend += fresh && run != 0;
+            run = fresh ? 1u : run + (ev == 2);
+            last_min = fresh ? m : last_min;
         }
-        if (__ballot(n_pend >= K2_QCAP - 1) != 0) drain();
-        s_qmin[n_pend * 64 + lane] = last_min; s_qlen[n_pend * 64 + lane] = run;
-        n_pend += run != 0;
-        drain();
         if (active) {
             kmers_thr += total;
             if (BIG || !H.over) probes_thr += probes_unit;       // a unit redone by the overflow pass is counted there
