@@ -488,6 +488,50 @@ struct SliceStore {
     __device__ inline void clearAux(int32_t n) { clearT(n); }
 };
 
+__device__ inline uint32_t prefix_popc64(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// ---- wave scans on the DPP network (gfx9: row_shr within rows of 16, row_bcast:15 / :31 across rows, wave_shr:1) ----
+template <int CTRL, int ROWS>
+__device__ inline int32_t dpp_mov(int32_t old, int32_t v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROWS, 0xf, false); }
+
+__device__ inline int32_t wave_scan_max_incl(int32_t v)
+{
+    int32_t t;
+    t = dpp_mov<0x111, 0xf>(INT32_MIN, v); v = t > v ? t : v;
+    t = dpp_mov<0x112, 0xf>(INT32_MIN, v); v = t > v ? t : v;
+    t = dpp_mov<0x114, 0xf>(INT32_MIN, v); v = t > v ? t : v;
+    t = dpp_mov<0x118, 0xf>(INT32_MIN, v); v = t > v ? t : v;
+    t = dpp_mov<0x142, 0xa>(INT32_MIN, v); v = t > v ? t : v;
+    t = dpp_mov<0x143, 0xc>(INT32_MIN, v); v = t > v ? t : v;
+    return v;
+}
+// lane l receives lane l-1's value, lane 0 receives `fill`
+__device__ inline int32_t wave_shr1(int32_t v, int32_t fill) { return dpp_mov<0x138, 0xf>(fill, v); }
+
+// inclusive prefix composition (lane order) of the functions x -> max(x + a, b)
+#define SH_COMP_STEP(CTRL, ROWS) { const int32_t pa = dpp_mov<CTRL, ROWS>(0, a), pb = dpp_mov<CTRL, ROWS>(-(1 << 29), b); \
+                                   const int32_t nb = pb + a > b ? pb + a : b; a = pa + a; b = nb; }
+__device__ inline void wave_scan_compose(int32_t &a, int32_t &b)
+{
+    SH_COMP_STEP(0x111, 0xf) SH_COMP_STEP(0x112, 0xf) SH_COMP_STEP(0x114, 0xf) SH_COMP_STEP(0x118, 0xf)
+    SH_COMP_STEP(0x142, 0xa) SH_COMP_STEP(0x143, 0xc)
+}
+
+__device__ inline int32_t wave_scan_min_incl(int32_t v)
+{
+    int32_t t;
+    t = dpp_mov<0x111, 0xf>(INT32_MAX, v); v = t < v ? t : v;
+    t = dpp_mov<0x112, 0xf>(INT32_MAX, v); v = t < v ? t : v;
+    t = dpp_mov<0x114, 0xf>(INT32_MAX, v); v = t < v ? t : v;
+    t = dpp_mov<0x118, 0xf>(INT32_MAX, v); v = t < v ? t : v;
+    t = dpp_mov<0x142, 0xa>(INT32_MAX, v); v = t < v ? t : v;
+    t = dpp_mov<0x143, 0xc>(INT32_MAX, v); v = t < v ? t : v;
+    return v;
+}
+
 // ---- wave-cooperative DP: all 64 lanes work on ONE cluster ---------------------------------------------------------
 // mg_lchain_dp scans the predecessors j = i-1 .. st of anchor i sequentially, with a running maximum, the
 // max_skip counter and the t[] marks.  Here the 64 lanes evaluate 64 predecessors at once and the sequential
@@ -535,34 +579,26 @@ __device__ inline void chain_dp_wave(const SliceStore &S, int n, int32_t qlen, c
             wave_mem_sync();
             const bool is_t = has && pt[2 * j + 1] == i;
             // exclusive prefix maximum in scan order (lane 0 = j = jb first), seeded with the running max_f
-            int32_t incl = has ? sc : INT32_MIN;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { int32_t t = __shfl_up(incl, o); if ((int)lane >= o) incl = t > incl ? t : incl; }
-            int32_t excl = __shfl_up(incl, 1);
-            if (lane == 0) excl = INT32_MIN;
+            const int32_t scv = has ? sc : INT32_MIN;
+            const int32_t incl = wave_scan_max_incl(scv);
+            int32_t excl = wave_shr1(incl, INT32_MIN);
             if (excl < max_f) excl = max_f;
             const bool new_max = has && sc > excl;
             const bool inc_ev = has && !new_max && is_t;
-            // n_skip after each lane: inclusive prefix composition of x -> max(x + a, b)
-            int32_t ca = new_max ? -1 : (inc_ev ? 1 : 0), cb = new_max ? 0 : NEG;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                int32_t pa = __shfl_up(ca, o), pb = __shfl_up(cb, o);
-                if ((int)lane >= o) { int32_t nb = pb + ca > cb ? pb + ca : cb; ca = pa + ca; cb = nb; }
-            }
-            const int32_t val = n_skip + ca > cb ? n_skip + ca : cb;
+            // n_skip is a walk reflected at zero (see chain_dp_ring)
+            const uint64_t inc_m = __ballot(inc_ev), nm_m = __ballot(new_max);
+            const int32_t yl = n_skip + (int32_t)prefix_popc64(inc_m) + (inc_ev ? 1 : 0) - (int32_t)prefix_popc64(nm_m) - (new_max ? 1 : 0);
+            const int32_t mn = wave_scan_min_incl(yl);
+            const int32_t val = yl - (mn < 0 ? mn : 0);
             const uint64_t brk = __ballot(inc_ev && val > P.max_skip);
             const int L = brk ? __ffsll((unsigned long long)brk) - 1 : 63;
-            const bool act = (int)lane <= L && has;
-            int32_t mm = act ? sc : INT32_MIN;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { int32_t t = __shfl_xor(mm, o); mm = t > mm ? t : mm; }
+            const int32_t mm = __builtin_amdgcn_readlane(incl, L);
             if (mm > max_f) {
                 max_f = mm;
-                const uint64_t eq = __ballot(act && sc == mm);
+                const uint64_t eq = __ballot((int)lane <= L && scv == mm);
                 max_j = jb - (__ffsll((unsigned long long)eq) - 1);
             }
-            n_skip = __shfl(val, L);
+            n_skip = __builtin_amdgcn_readlane(val, L);
             if (brk) { end_j = jb - L; break; }
         }
         // the max_ii shortcut (uniform)
@@ -592,38 +628,6 @@ __device__ inline void chain_dp_wave(const SliceStore &S, int n, int32_t qlen, c
     }
 }
 
-__device__ inline uint32_t prefix_popc64(uint64_t mask)
-{
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-
-// ---- wave scans on the DPP network (gfx9: row_shr within rows of 16, row_bcast:15 / :31 across rows, wave_shr:1) ----
-template <int CTRL, int ROWS>
-__device__ inline int32_t dpp_mov(int32_t old, int32_t v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROWS, 0xf, false); }
-
-__device__ inline int32_t wave_scan_max_incl(int32_t v)
-{
-    int32_t t;
-    t = dpp_mov<0x111, 0xf>(INT32_MIN, v); v = t > v ? t : v;
-    t = dpp_mov<0x112, 0xf>(INT32_MIN, v); v = t > v ? t : v;
-    t = dpp_mov<0x114, 0xf>(INT32_MIN, v); v = t > v ? t : v;
-    t = dpp_mov<0x118, 0xf>(INT32_MIN, v); v = t > v ? t : v;
-    t = dpp_mov<0x142, 0xa>(INT32_MIN, v); v = t > v ? t : v;
-    t = dpp_mov<0x143, 0xc>(INT32_MIN, v); v = t > v ? t : v;
-    return v;
-}
-// lane l receives lane l-1's value, lane 0 receives `fill`
-__device__ inline int32_t wave_shr1(int32_t v, int32_t fill) { return dpp_mov<0x138, 0xf>(fill, v); }
-
-// inclusive prefix composition (lane order) of the functions x -> max(x + a, b)
-#define SH_COMP_STEP(CTRL, ROWS) { const int32_t pa = dpp_mov<CTRL, ROWS>(0, a), pb = dpp_mov<CTRL, ROWS>(-(1 << 29), b); \
-                                   const int32_t nb = pb + a > b ? pb + a : b; a = pa + a; b = nb; }
-__device__ inline void wave_scan_compose(int32_t &a, int32_t &b)
-{
-    SH_COMP_STEP(0x111, 0xf) SH_COMP_STEP(0x112, 0xf) SH_COMP_STEP(0x114, 0xf) SH_COMP_STEP(0x118, 0xf)
-    SH_COMP_STEP(0x142, 0xa) SH_COMP_STEP(0x143, 0xc)
-}
-
 // ---- wave-cooperative DP with the recent anchors in LDS -------------------------------------------------------------
 // Same exact scheme as chain_dp_wave, built for clusters of thousands of anchors (the true locus of a long read):
 // the last RING_WIN anchors' (x, q, f, p, t) live in a per-wave LDS ring, so a step whose scan ends within that
@@ -636,17 +640,6 @@ __device__ inline void wave_scan_compose(int32_t &a, int32_t &b)
 #define RING_TMAX_ITER 8000
 struct RingMem { uint4 rec[RING_CAP]; uint32_t tb[RING_TBITS / 32]; };       // rec = (x, q, f, p)
 
-__device__ inline int32_t wave_scan_min_incl(int32_t v)
-{
-    int32_t t;
-    t = dpp_mov<0x111, 0xf>(INT32_MAX, v); v = t < v ? t : v;
-    t = dpp_mov<0x112, 0xf>(INT32_MAX, v); v = t < v ? t : v;
-    t = dpp_mov<0x114, 0xf>(INT32_MAX, v); v = t < v ? t : v;
-    t = dpp_mov<0x118, 0xf>(INT32_MAX, v); v = t < v ? t : v;
-    t = dpp_mov<0x142, 0xa>(INT32_MAX, v); v = t < v ? t : v;
-    t = dpp_mov<0x143, 0xc>(INT32_MAX, v); v = t < v ? t : v;
-    return v;
-}
 __device__ inline int32_t ld_agent(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // `rm` must be a __shared__ object (the accesses below compile to ds_* once inlined; nothing here is volatile: one
