@@ -61,7 +61,8 @@ struct Counters {
     uint32_t n_cl[4], cl_ticket, pad3;      // global queue of big clusters (k_cluster_dp), by size class
     uint32_t n_leg_reason[4];     // why reads left the long-read front end: 0 room/segments, 1 thinning screen, 2 anchors beyond the giant path, 3 unused
     unsigned long long arena_cursor, anchor_cursor;
-    unsigned long long cl_tot[4], cl_anchor_tot[4], cl_dbg[4];     // statistics of k_cluster_dp by size class (whole chunk)
+    unsigned long long cl_tot[4], cl_anchor_tot[4], cl_dbg[4];
+    unsigned long long sort_tot[5], sort_anchor_tot[5];    // SCRUBBY_HIP_DBG & 16: reads / anchors per sort class (4 = chained inside k_expand)     // statistics of k_cluster_dp by size class (whole chunk)
     unsigned long long sh_mini[64], sh_anchors[64];     // sharded sums
     uint32_t sh_host[64], sh_clusters[64];
 };
@@ -1000,6 +1001,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { n_u += __shfl_xor(n_u, o); int32_t b = __shfl_xor(best, o); best = b > best ? b : best; }
             if (lane == 0) { a.B.acc_nu[w] = n_u; a.B.acc_best[w] = best; }
+            if ((a.dbg & 16) && lane == 0) { atomicAdd(&a.ctr->sort_tot[4], 1ull); atomicAdd(&a.ctr->sort_anchor_tot[4], (unsigned long long)n_a); }
             __syncthreads();
         } else {
             const int cls = n_a <= SORT_LDS_A ? 0 : (n_a <= SORT_LDS_B ? 1 : (n_a <= SORT_LDS_C ? 2 : 3));
@@ -1007,6 +1009,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
             const uint32_t si = al_sort[cls].take(&a.ctr->n_sort[cls], 1, cls == 0 ? 32u : (cls == 1 ? 8u : 1u), lo, hi);
             for (uint32_t i = lo + lane; i < hi; i += 64) a.B.sort_items[cls][i].n = 0;
             if (lane == 0) { SortItem it{w, n_a, (uint32_t)qlen, 0, off}; a.B.sort_items[cls][si] = it; }
+            if ((a.dbg & 16) && lane == 0) { atomicAdd(&a.ctr->sort_tot[cls], 1ull); atomicAdd(&a.ctr->sort_anchor_tot[cls], (unsigned long long)n_a); }
         }
     }
     for (int cls = 0; cls < N_SORT_CLS; ++cls)
@@ -1752,6 +1755,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         if (first) { snap = *c->h_ctr; first = false; }
         if (k.dbg & 16) fprintf(stderr, "[dbg] iter %d resketch %u reasons %u %u %u segs %u big %u/%u defer %u/%u\n", iter, c->h_ctr->n_resketch, c->h_ctr->n_leg_reason[0], c->h_ctr->n_leg_reason[1], c->h_ctr->n_leg_reason[2], c->h_ctr->n_long_segs, c->h_ctr->n_big[0], c->h_ctr->n_big[1], c->h_ctr->n_big_defer[0], c->h_ctr->n_big_defer[1]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] clusters chained by k_cluster_dp by class: %llu %llu %llu %llu, their anchors %llu %llu %llu %llu\n", c->h_ctr->cl_tot[0], c->h_ctr->cl_tot[1], c->h_ctr->cl_tot[2], c->h_ctr->cl_tot[3], c->h_ctr->cl_anchor_tot[0], c->h_ctr->cl_anchor_tot[1], c->h_ctr->cl_anchor_tot[2], c->h_ctr->cl_anchor_tot[3]);
+        if (k.dbg & 16) fprintf(stderr, "[dbg] reads (anchors) by sort class: <=64 %llu (%llu), <=512 %llu (%llu), <=2048 %llu (%llu), <=4096 %llu (%llu), giant %llu (%llu)\n", c->h_ctr->sort_tot[4], c->h_ctr->sort_anchor_tot[4], c->h_ctr->sort_tot[0], c->h_ctr->sort_anchor_tot[0], c->h_ctr->sort_tot[1], c->h_ctr->sort_anchor_tot[1], c->h_ctr->sort_tot[2], c->h_ctr->sort_anchor_tot[2], c->h_ctr->sort_tot[3], c->h_ctr->sort_anchor_tot[3]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] ring DP: chunks in window %llu, beyond %llu, far rescans %llu\n", c->h_ctr->cl_dbg[0], c->h_ctr->cl_dbg[1], c->h_ctr->cl_dbg[2]);
         resk_done = c->h_ctr->n_resketch;
         const uint32_t d0 = c->h_ctr->n_big_defer[0], d1 = c->h_ctr->n_big_defer[1];
