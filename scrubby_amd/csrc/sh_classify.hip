@@ -47,7 +47,8 @@
 #define SORT_LDS_A 512          // reads with up to this many anchors are sorted and chained in 12 KiB of LDS
 #define SORT_LDS_B 2048         // ... 48 KiB
 #define SORT_LDS_C 4096         // ... 96 KiB; larger ones: 4096-anchor chunks in LDS, then merge rounds in the arena
-#define N_SORT_CLS 4
+#define N_SORT_CLS 6             // LDS classes <= 256, 512, 1024, 2048, 4096 anchors (block LDS sized to the class: occupancy), then giant
+#define SORT_CLS_GIANT 5
 #define GT 2048u                 // tile of the giant-read merge sort
 
 __device__ inline uint32_t lane_id() { return threadIdx.x & 63; }
@@ -62,7 +63,7 @@ struct Counters {
     uint32_t n_leg_reason[4];     // why reads left the long-read front end: 0 room/segments, 1 thinning screen, 2 anchors beyond the giant path, 3 unused
     unsigned long long arena_cursor, anchor_cursor;
     unsigned long long cl_tot[4], cl_anchor_tot[4], cl_dbg[4];
-    unsigned long long sort_tot[5], sort_anchor_tot[5];    // SCRUBBY_HIP_DBG & 16: reads / anchors per sort class (4 = chained inside k_expand)     // statistics of k_cluster_dp by size class (whole chunk)
+    unsigned long long sort_tot[N_SORT_CLS + 1], sort_anchor_tot[N_SORT_CLS + 1];    // SCRUBBY_HIP_DBG & 16: reads / anchors per sort class (4 = chained inside k_expand)     // statistics of k_cluster_dp by size class (whole chunk)
     unsigned long long sh_mini[64], sh_anchors[64];     // sharded sums
     uint32_t sh_host[64], sh_clusters[64];
 };
@@ -1001,12 +1002,12 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { n_u += __shfl_xor(n_u, o); int32_t b = __shfl_xor(best, o); best = b > best ? b : best; }
             if (lane == 0) { a.B.acc_nu[w] = n_u; a.B.acc_best[w] = best; }
-            if ((a.dbg & 16) && lane == 0) { atomicAdd(&a.ctr->sort_tot[4], 1ull); atomicAdd(&a.ctr->sort_anchor_tot[4], (unsigned long long)n_a); }
+            if ((a.dbg & 16) && lane == 0) { atomicAdd(&a.ctr->sort_tot[N_SORT_CLS], 1ull); atomicAdd(&a.ctr->sort_anchor_tot[N_SORT_CLS], (unsigned long long)n_a); }
             __syncthreads();
         } else {
-            const int cls = n_a <= SORT_LDS_A ? 0 : (n_a <= SORT_LDS_B ? 1 : (n_a <= SORT_LDS_C ? 2 : 3));
+            const int cls = n_a <= 256 ? 0 : (n_a <= SORT_LDS_A ? 1 : (n_a <= 1024 ? 2 : (n_a <= SORT_LDS_B ? 3 : (n_a <= SORT_LDS_C ? 4 : SORT_CLS_GIANT))));
             uint32_t lo, hi;
-            const uint32_t si = al_sort[cls].take(&a.ctr->n_sort[cls], 1, cls == 0 ? 32u : (cls == 1 ? 8u : 1u), lo, hi);
+            const uint32_t si = al_sort[cls].take(&a.ctr->n_sort[cls], 1, cls <= 1 ? 32u : (cls <= 3 ? 8u : 1u), lo, hi);
             for (uint32_t i = lo + lane; i < hi; i += 64) a.B.sort_items[cls][i].n = 0;
             if (lane == 0) { SortItem it{w, n_a, (uint32_t)qlen, 0, off}; a.B.sort_items[cls][si] = it; }
             if ((a.dbg & 16) && lane == 0) { atomicAdd(&a.ctr->sort_tot[cls], 1ull); atomicAdd(&a.ctr->sort_anchor_tot[cls], (unsigned long long)n_a); }
@@ -1129,11 +1130,11 @@ __device__ inline uint32_t giant_rounds(uint32_t n)
 
 __global__ __launch_bounds__(64) void k_giant_scan(K3Args a)
 {
-    const uint32_t lane = threadIdx.x, n_items = a.ctr->n_sort[3];
+    const uint32_t lane = threadIdx.x, n_items = a.ctr->n_sort[SORT_CLS_GIANT];
     uint32_t run = 0, max_n = 0;
     for (uint32_t base = 0; base < n_items; base += 64) {
         const uint32_t i = base + lane;
-        const uint32_t n_i = i < n_items ? a.B.sort_items[3][i].n : 0;
+        const uint32_t n_i = i < n_items ? a.B.sort_items[SORT_CLS_GIANT][i].n : 0;
         max_n = n_i > max_n ? n_i : max_n;
         const uint32_t t = (n_i + GT - 1) / GT;
         const uint32_t ex = wave_excl_scan_u32(t, lane);
@@ -1156,10 +1157,10 @@ __global__ __launch_bounds__(256) void k_giant_chunksort(K3Args a)
 {
     __shared__ uint64_t s_x[2][GT];
     __shared__ uint32_t s_q[2][GT];
-    const uint32_t tid = threadIdx.x, n_items = a.ctr->n_sort[3], n_tiles = a.ctr->n_giant_tiles;
+    const uint32_t tid = threadIdx.x, n_items = a.ctr->n_sort[SORT_CLS_GIANT], n_tiles = a.ctr->n_giant_tiles;
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint32_t it = giant_item_of(a.B.tile_base, n_items, t);
-        const SortItem si = a.B.sort_items[3][it];
+        const SortItem si = a.B.sort_items[SORT_CLS_GIANT][it];
         const uint32_t c0 = (t - a.B.tile_base[it]) * GT, m = si.n - c0 < GT ? si.n - c0 : GT;
         uint64_t *gx = a.B.ax + si.off + c0; uint32_t *gq = a.B.aq + si.off + c0;
         for (uint32_t i = tid; i < m; i += 256) { s_x[0][i] = gx[i]; s_q[0][i] = gq[i]; }
@@ -1177,7 +1178,7 @@ __device__ inline GiantTile giant_tile(const K3Args &a, uint32_t t, uint32_t n_i
 {
     GiantTile g;
     const uint32_t it = giant_item_of(a.B.tile_base, n_items, t);
-    const SortItem si = a.B.sort_items[3][it];
+    const SortItem si = a.B.sort_items[SORT_CLS_GIANT][it];
     const uint32_t width = GT << round;
     g.active = width < si.n;                       // this read still has runs to merge in this round
     const bool src_b = round & 1;                  // after `round` rounds the data sits in buffer (round & 1)
@@ -1193,7 +1194,7 @@ __device__ inline GiantTile giant_tile(const K3Args &a, uint32_t t, uint32_t n_i
 __global__ __launch_bounds__(256) void k_giant_partition(K3Args a, uint32_t round)
 {
     if (round >= a.ctr->n_giant_rounds) return;
-    const uint32_t n_items = a.ctr->n_sort[3], n_tiles = a.ctr->n_giant_tiles;
+    const uint32_t n_items = a.ctr->n_sort[SORT_CLS_GIANT], n_tiles = a.ctr->n_giant_tiles;
     for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < n_tiles; t += gridDim.x * 256) {
         const GiantTile g = giant_tile(a, t, n_items, round);
         if (!g.active) continue;
@@ -1212,7 +1213,7 @@ __global__ __launch_bounds__(256) void k_giant_merge(K3Args a, uint32_t round)
     __shared__ uint64_t s_x[GT];          // [0, la): left range, [la, la+lb): right range; la + lb <= GT
     __shared__ uint32_t s_q[GT];
     if (round >= a.ctr->n_giant_rounds) return;
-    const uint32_t tid = threadIdx.x, n_items = a.ctr->n_sort[3], n_tiles = a.ctr->n_giant_tiles;
+    const uint32_t tid = threadIdx.x, n_items = a.ctr->n_sort[SORT_CLS_GIANT], n_tiles = a.ctr->n_giant_tiles;
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const GiantTile g = giant_tile(a, t, n_items, round);
         if (!g.active) continue;                               // uniform per block
@@ -1253,9 +1254,9 @@ __global__ __launch_bounds__(1024) void k_giant_chain(K3Args a)
     __shared__ int32_t s_found, s_red[2], s_bcount;
     __shared__ uint32_t s_bstart[2048], s_blen[2048];
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
-    const uint32_t n_items = a.ctr->n_sort[3];
+    const uint32_t n_items = a.ctr->n_sort[SORT_CLS_GIANT];
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const SortItem si = a.B.sort_items[3][it];
+        const SortItem si = a.B.sort_items[SORT_CLS_GIANT][it];
         const uint32_t n = si.n;
         const bool in_b = giant_rounds(n) & 1;
         uint64_t *sx = (in_b ? a.B.bx : a.B.ax) + si.off; uint32_t *sq = (in_b ? a.B.bq : a.B.aq) + si.off;
@@ -1540,8 +1541,10 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         uint64_t left = c->arena_bytes - c->legacy_bytes;
         // k_expand's waves reserve sort-list entries in chunks (<= 32): up to one abandoned chunk per wave and class
         const uint64_t waves = 2 * std::min<uint64_t>(std::max<uint64_t>(n_tiles, 1), 256 * 8);      // k_expand's grid (big_pass)
-        const uint64_t sort_cap[N_SORT_CLS] = {max_reads + 32 * waves, max_reads + 8 * waves, max_reads + waves, max_reads + waves};
-        uint64_t fixed = 4 * 64 * sizeof(SortItem) + 4096 + max_reads * (sizeof(BigMeta) + 8 + 8) + (sort_cap[0] + sort_cap[1] + sort_cap[2] + sort_cap[3]) * sizeof(SortItem) + 16384;
+        const uint64_t sort_cap[N_SORT_CLS] = {max_reads + 32 * waves, max_reads + 32 * waves, max_reads + 8 * waves, max_reads + 8 * waves, max_reads + waves, max_reads + waves};
+        uint64_t sort_cap_sum = 0;
+        for (int i = 0; i < N_SORT_CLS; ++i) sort_cap_sum += sort_cap[i];
+        uint64_t fixed = 4 * 64 * sizeof(SortItem) + 4096 + max_reads * (sizeof(BigMeta) + 8 + 8) + sort_cap_sum * sizeof(SortItem) + 16384;
         uint64_t per_anchor = 8 + 8 + 8 + 4 + 4 + 4 + 2;   // ax bx az aq bq af (+ tile_split and cluster queue shares)
         uint64_t cap = left > fixed ? (left - fixed) / per_anchor : 0;
         cap &= ~15ull;
@@ -1633,9 +1636,11 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
         SH_HIP(hipEventRecord(c->evx[0], s));
         for (int i = 0; i < 3; ++i) SH_HIP(hipStreamWaitEvent(c->sx[i], c->evx[0], 0));
     }
-    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_A, 0, 64>), dim3(grid * 2), dim3(64), 0, s, k);
-    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_B, 1, 128>), dim3(256 * 3), dim3(128), 0, s0, k);
-    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_C, 2, 512>), dim3(256), dim3(512), 0, s1, k);
+    hipLaunchKernelGGL((k_sort_lds<256, 0, 64>), dim3(grid * 2), dim3(64), 0, s, k);
+    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_A, 1, 64>), dim3(grid * 2), dim3(64), 0, s, k);
+    hipLaunchKernelGGL((k_sort_lds<1024, 2, 128>), dim3(256 * 6), dim3(128), 0, s0, k);
+    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_B, 3, 128>), dim3(256 * 3), dim3(128), 0, s0, k);
+    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_C, 4, 512>), dim3(256), dim3(512), 0, s1, k);
     hipLaunchKernelGGL(k_giant_scan, dim3(1), dim3(64), 0, g, k);
     hipLaunchKernelGGL(k_giant_chunksort, dim3(256 * 3), dim3(256), 0, g, k);
     for (uint32_t round = 0; round < 8; ++round) {      // run widths GT << round: up to 2^19 anchors per read
@@ -1755,7 +1760,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         if (first) { snap = *c->h_ctr; first = false; }
         if (k.dbg & 16) fprintf(stderr, "[dbg] iter %d resketch %u reasons %u %u %u segs %u big %u/%u defer %u/%u\n", iter, c->h_ctr->n_resketch, c->h_ctr->n_leg_reason[0], c->h_ctr->n_leg_reason[1], c->h_ctr->n_leg_reason[2], c->h_ctr->n_long_segs, c->h_ctr->n_big[0], c->h_ctr->n_big[1], c->h_ctr->n_big_defer[0], c->h_ctr->n_big_defer[1]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] clusters chained by k_cluster_dp by class: %llu %llu %llu %llu, their anchors %llu %llu %llu %llu\n", c->h_ctr->cl_tot[0], c->h_ctr->cl_tot[1], c->h_ctr->cl_tot[2], c->h_ctr->cl_tot[3], c->h_ctr->cl_anchor_tot[0], c->h_ctr->cl_anchor_tot[1], c->h_ctr->cl_anchor_tot[2], c->h_ctr->cl_anchor_tot[3]);
-        if (k.dbg & 16) fprintf(stderr, "[dbg] reads (anchors) by sort class: <=64 %llu (%llu), <=512 %llu (%llu), <=2048 %llu (%llu), <=4096 %llu (%llu), giant %llu (%llu)\n", c->h_ctr->sort_tot[4], c->h_ctr->sort_anchor_tot[4], c->h_ctr->sort_tot[0], c->h_ctr->sort_anchor_tot[0], c->h_ctr->sort_tot[1], c->h_ctr->sort_anchor_tot[1], c->h_ctr->sort_tot[2], c->h_ctr->sort_anchor_tot[2], c->h_ctr->sort_tot[3], c->h_ctr->sort_anchor_tot[3]);
+        if (k.dbg & 16) fprintf(stderr, "[dbg] reads (anchors) by sort class: <=64 %llu (%llu), <=256 %llu (%llu), <=512 %llu (%llu), <=1024 %llu (%llu), <=2048 %llu (%llu), <=4096 %llu (%llu), giant %llu (%llu)\n", c->h_ctr->sort_tot[6], c->h_ctr->sort_anchor_tot[6], c->h_ctr->sort_tot[0], c->h_ctr->sort_anchor_tot[0], c->h_ctr->sort_tot[1], c->h_ctr->sort_anchor_tot[1], c->h_ctr->sort_tot[2], c->h_ctr->sort_anchor_tot[2], c->h_ctr->sort_tot[3], c->h_ctr->sort_anchor_tot[3], c->h_ctr->sort_tot[4], c->h_ctr->sort_anchor_tot[4], c->h_ctr->sort_tot[5], c->h_ctr->sort_anchor_tot[5]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] ring DP: chunks in window %llu, beyond %llu, far rescans %llu\n", c->h_ctr->cl_dbg[0], c->h_ctr->cl_dbg[1], c->h_ctr->cl_dbg[2]);
         resk_done = c->h_ctr->n_resketch;
         const uint32_t d0 = c->h_ctr->n_big_defer[0], d1 = c->h_ctr->n_big_defer[1];
