@@ -1637,9 +1637,9 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
         for (int i = 0; i < 3; ++i) SH_HIP(hipStreamWaitEvent(c->sx[i], c->evx[0], 0));
     }
     hipLaunchKernelGGL((k_sort_lds<256, 0, 64>), dim3(grid * 2), dim3(64), 0, s, k);
-    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_A, 1, 64>), dim3(grid * 2), dim3(64), 0, s, k);
-    hipLaunchKernelGGL((k_sort_lds<1024, 2, 128>), dim3(256 * 6), dim3(128), 0, s0, k);
-    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_B, 3, 128>), dim3(256 * 3), dim3(128), 0, s0, k);
+    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_A, 1, 128>), dim3(grid * 2), dim3(128), 0, s, k);
+    hipLaunchKernelGGL((k_sort_lds<1024, 2, 256>), dim3(256 * 6), dim3(256), 0, s0, k);
+    hipLaunchKernelGGL((k_sort_lds<SORT_LDS_B, 3, 256>), dim3(256 * 3), dim3(256), 0, s0, k);
     hipLaunchKernelGGL((k_sort_lds<SORT_LDS_C, 4, 512>), dim3(256), dim3(512), 0, s1, k);
     hipLaunchKernelGGL(k_giant_scan, dim3(1), dim3(64), 0, g, k);
     hipLaunchKernelGGL(k_giant_chunksort, dim3(256 * 3), dim3(256), 0, g, k);
