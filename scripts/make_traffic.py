@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; kernel-trace only) of ONE bench step.
+
+usage: make_traffic.py <fetch_dir> <write_dir> <records_per_launch> <out.json>
+Counter values are KiB (x 1024 -> bytes), summed per bench stage; raw, i.e. without the gfx950 correction for wide
+coalesced streams (MI355X_MICROARCH.md, HBM section: FETCH_SIZE reports half of a 16-B/lane streaming read; other access
+widths - the 16-B random gathers and 12-B anchor records here - are uncalibrated), so the figures are a lower bound."""
+import csv, glob, json, sys, collections
+
+STAGES = {
+    "k_sketch_probe": ("k_sketch_probe",),
+    "k_chain_small": ("k_chain_small",),
+    "repeat path (k_expand + k_sort_lds* + k_sort + k_finalize)": ("k_expand", "k_sort_lds", "k_giant", "k_cluster_dp", "k_finalize", "k_chain_large"),
+}
+
+
+def collect(d, counter):
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    acc = collections.defaultdict(float)
+    kern = collections.defaultdict(float)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"]
+        for st, pats in STAGES.items():
+            if any(p in name for p in pats):
+                acc[st] += float(r["Counter_Value"]) * 1024.0
+                kern[name.split("(")[0].replace("void ", "")[:40]] += float(r["Counter_Value"]) * 1024.0
+    return acc, kern
+
+
+fd, wd, n_rec, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+fe, fk = collect(fd, "FETCH_SIZE")
+we, wk = collect(wd, "WRITE_SIZE")
+doc = {"comment": __doc__.split("\n\n")[1].replace("\n", " "), "records_per_launch": n_rec, "stages": {}, "kernels": {}}
+for st in STAGES:
+    doc["stages"][st] = {"fetch": fe[st], "write": we[st], "hbm_bytes_per_launch": fe[st] + we[st]}
+for k in sorted(set(fk) | set(wk)):
+    doc["kernels"][k] = {"fetch": fk.get(k, 0.0), "write": wk.get(k, 0.0)}
+json.dump(doc, open(out, "w"), indent=1)
+for st, v in doc["stages"].items():
+    print(f"{st[:40]:40s} fetch {v['fetch'] / 1e9:8.2f} GB  write {v['write'] / 1e9:8.2f} GB")
