@@ -312,3 +312,35 @@ def test_long_read_front_end_all_paths(S, oracle):
     assert int((ot["n_mini"] < ot["n_seed"]).sum()) == 0
     gf2, _, st2, _ = gidx.classify(bases, offs, want_trace=False)
     assert np.array_equal(gf2, of)
+
+
+def test_long_reads_chunked_context_and_small_arena(S, oracle, monkeypatch):
+    """Long reads through a device Context in several launches (offsets of a chunk do not start at 0), then with a chain
+    arena far too small for the batch (deferral loop with the cluster queue): flags and traces must not change."""
+    import torch
+    Po = oracle.ref_params(W.CFG1_REF_SEED, W.CFG1_CONTIGS)
+    Ro = oracle.read_params(0x5C2B0022, host_pct=60, sub_per_10k=500, n_read_pct=0)
+    n = 900
+    bases, offs = oracle.synth_long_reads(Po, Ro, 3, n)
+    seqs = [oracle.synth_ref(Po, Po.contig_start[i], 1_000_000) for i in range(5)]
+    gidx = S.Index.build([bytes(s) for s in seqs], S.preset("map-ont"))
+    cidx = oracle.Index.build(seqs, 10, 15)
+    oo = cidx.update_opts(oracle.preset("map-ont"))
+    of, ot = cidx.classify(oo, bases, offs, threads=8)
+    d_reads = torch.from_numpy(np.concatenate([bases, np.zeros(64, np.uint8)])).cuda()
+    d_off = torch.from_numpy(offs.astype(np.int64)).cuda()
+    max_len = int(np.diff(offs.astype(np.int64)).max())
+    for chunk in (n, 256):
+        ctx = S.Context(gidx, chunk, len(bases), max_len)
+        fl = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        tr = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+        ctx.classify(d_reads[: len(bases)], d_off, fl, tr)
+        gt = tr.cpu().numpy().view(S.TRACE_DTYPE).reshape(-1)
+        assert_trace_equal(S, fl.cpu().numpy(), gt, of, ot)
+        fl.zero_()
+        ctx.classify(d_reads[: len(bases)], d_off, fl, None)            # flag-only mode
+        assert np.array_equal(fl.cpu().numpy(), of)
+        ctx.close()
+    monkeypatch.setenv("SCRUBBY_HIP_ARENA_MB", "96")
+    gf, gt, st, rc = gidx.classify(bases, offs, want_trace=True)
+    assert_trace_equal(S, gf, gt, of, ot)
