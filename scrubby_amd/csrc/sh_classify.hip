@@ -697,12 +697,13 @@ __device__ inline int cl_class(uint32_t len) { return len > 4096 ? 0 : (len > 10
 template <bool CONTIG, class PX, class PQ>
 __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_t n, uint32_t tid, uint32_t nthr, int32_t qlen,
                                     const ChainParams &P, volatile int32_t *found, BigList bl,
-                                    int32_t &n_u_thr, int32_t &best_thr, uint32_t &n_cl_thr, const GlobalQ *gq = nullptr)
+                                    int32_t &n_u_thr, int32_t &best_thr, uint32_t &n_cl_thr, const GlobalQ *gq = nullptr,
+                                    uint32_t *nxt = nullptr)
 {
     const uint32_t mdx = chain_max_dist_x(P, qlen);
     const bool keep_single = !(P.k < P.min_sc || P.min_cnt > 1);
     const uint32_t per = CONTIG ? (n + nthr - 1) / nthr : 1;
-    const uint32_t i_beg = CONTIG ? tid * per : tid, i_step = CONTIG ? 1 : nthr;
+    const uint32_t i_beg = CONTIG ? (tid * per < n ? tid * per : n) : tid, i_step = CONTIG ? 1 : nthr;
     const uint32_t i_end = CONTIG ? (i_beg + per < n ? i_beg + per : n) : n;
     if (tid == 0) *bl.count = 0;
     for (uint32_t i = tid; i < n; i += nthr) {
@@ -711,27 +712,63 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
         if (start) q[i] |= 0x80000000u;
     }
     __syncthreads();
-    for (uint32_t i = i_beg; i < i_end; i += i_step) {
-        if (found && *found) break;            // flag-only: the read is decided
-        if (!(q[i] >> 31)) continue;
-        uint32_t j = i + 1;
-        while (j < n && !(q[j] >> 31)) ++j;
-        const uint32_t len = j - i;
-        if (len < 2 && !keep_single) continue;
+    // one cluster [i, i + len): chained by this lane if small, else queued for a whole wave
+    auto handle = [&](uint32_t i, uint32_t len) {
+        if (len < 2 && !keep_single) return;
         if (len > (CONTIG ? 64u : 6u)) {      // arena path: only clusters beyond the register-mask DP go wave-wide
             if (gq) {
                 const int cc = cl_class(len);
                 const uint32_t gs = atomicAdd(&gq->count[cc], 1u);
-                if (gs < gq->cap[cc]) { SortItem ci{gq->w, len, (uint32_t)qlen, gq->in_b, gq->off + i}; gq->items[cc][gs] = ci; continue; }
+                if (gs < gq->cap[cc]) { SortItem ci{gq->w, len, (uint32_t)qlen, gq->in_b, gq->off + i}; gq->items[cc][gs] = ci; return; }
             }
             const int32_t slot = atomicAdd(bl.count, 1);
-            if ((uint32_t)slot < bl.cap) { bl.start[slot] = i; bl.len[slot] = len; continue; }
+            if ((uint32_t)slot < bl.cap) { bl.start[slot] = i; bl.len[slot] = len; return; }
         }
         SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i};
         int32_t n_u, best;
         chain_cluster(S, (int32_t)len, qlen, P, (uint64_t *)&x[i], n_u, best, found != nullptr);
         ++n_cl_thr;
         if (n_u > 0) { n_u_thr += n_u; if (best > best_thr) best_thr = best; if (found) *found = 1; }
+    };
+    if (CONTIG && nxt) {
+        // Cluster lengths without walking the clusters: nxt[t] = first cluster start at or after thread t's range (suffix
+        // minimum over the threads' first starts), so a start's cluster ends at the next start inside the own range or at
+        // nxt[tid + 1].  A tandem-array cluster of 10^5 anchors used to be measured by one thread, one load at a time.
+        uint32_t fs = n;
+        for (uint32_t i = i_beg; i < i_end; ++i) if (q[i] >> 31) { fs = i; break; }
+        nxt[tid] = fs;
+        __syncthreads();
+        for (uint32_t off = 1; off < nthr; off <<= 1) {
+            const uint32_t v = tid + off < nthr ? nxt[tid + off] : n;
+            __syncthreads();
+            if (v < nxt[tid]) nxt[tid] = v;
+            __syncthreads();
+        }
+        const uint32_t after = tid + 1 < nthr ? nxt[tid + 1] : n;
+        // sweeps by cluster size: the clusters a lane chains itself in rising order of cost (the DP is quadratic and a wave
+        // waits for its slowest lane), then - only if the read is still undecided in flag-only mode - the big ones go to
+        // the queue.  Lengths are free now, so one sweep would queue every big cluster before the first chain is found.
+        const uint32_t thr[5] = {0u, 8u, 24u, 64u, 0xffffffffu};
+        for (int sweep = 0; sweep < 4; ++sweep) {
+            uint32_t i = fs < i_end ? fs : i_end;
+            while (i < i_end) {
+                if (found && *found) break;            // flag-only: the read is decided
+                uint32_t j = i + 1;
+                while (j < i_end && !(q[j] >> 31)) ++j;
+                const uint32_t len = (j < i_end ? j : after) - i;
+                if (len > thr[sweep] && len <= thr[sweep + 1]) handle(i, len);
+                i = j;
+            }
+            __syncthreads();
+        }
+    } else {
+        for (uint32_t i = i_beg; i < i_end; i += i_step) {
+            if (found && *found) break;            // flag-only: the read is decided
+            if (!(q[i] >> 31)) continue;
+            uint32_t j = i + 1;
+            while (j < n && !(q[j] >> 31)) ++j;
+            handle(i, j - i);
+        }
     }
     __syncthreads();
     const uint32_t n_big = (uint32_t)*bl.count < bl.cap ? (uint32_t)*bl.count : bl.cap;
@@ -1252,7 +1289,7 @@ __global__ __launch_bounds__(256) void k_giant_merge(K3Args a, uint32_t round)
 __global__ __launch_bounds__(1024) void k_giant_chain(K3Args a)
 {
     __shared__ int32_t s_found, s_red[2], s_bcount;
-    __shared__ uint32_t s_bstart[2048], s_blen[2048];
+    __shared__ uint32_t s_bstart[2048], s_blen[2048], s_nxt[1024];
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const uint32_t n_items = a.ctr->n_sort[SORT_CLS_GIANT];
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
@@ -1266,7 +1303,7 @@ __global__ __launch_bounds__(1024) void k_giant_chain(K3Args a)
         const GlobalQ gq{a.B.cl_items, a.B.cl_cap, a.ctr->n_cl, si.w, in_b ? 1u : 0u, si.off};
         if (!(a.dbg & 2))
         chain_sorted<true>(sx, sq, a.B.af + si.off, (int32_t *)(a.B.az + si.off), n, tid, nthr, (int32_t)si.qlen, a.P,
-                     a.flag_only ? &s_found : nullptr, BigList{s_bstart, s_blen, &s_bcount, 2048}, n_u, best, n_cl, &gq);
+                     a.flag_only ? &s_found : nullptr, BigList{s_bstart, s_blen, &s_bcount, 2048}, n_u, best, n_cl, &gq, s_nxt);
         store_read_result(a, si.w, n_u, best, n_cl, s_red);
         __syncthreads();
     }
