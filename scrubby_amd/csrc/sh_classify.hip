@@ -82,7 +82,7 @@ struct WaveAlloc {
             const uint32_t want = n > chunk ? n : chunk;
             uint32_t base = 0;
             if (lane_id() == 0) base = atomicAdd(counter, want);
-            base = (uint32_t)__shfl((int)base, 0);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);      // wave-uniform: stays in scalar registers
             cur = base; end = base + want;
         }
         const uint32_t r = cur;
@@ -806,6 +806,7 @@ struct K3Args {
 // Seeds are handled 64 at a time, one per lane.  mm_seed_select's streak logic needs a read's seeds in one
 // tile; with more seeds it is only needed when some streak could keep a seed (max_high_occ > 0), which for
 // occ_dist = 500 means reads longer than 250 bp: those go to the legacy path.
+template <bool LONG>      // LONG: per-read seed offsets and mm_seed_select across seed tiles (the long-read front end's records)
 __global__ __launch_bounds__(64) void k_expand(K3Args a)
 {
     const uint32_t lane = threadIdx.x;
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
         const int32_t qlen = (int32_t)(a.offsets[r + 1] - a.offsets[r]);
         const uint32_t n_st = (n_seed + 63) / 64;
         const bool no_keep = plain_cut || (int32_t)((double)qlen / (double)P.occ_dist + .499) <= 0;   // every streak has max_high_occ == 0
-        const bool general_mt = n_st > 1 && !no_keep && a.seed_off != nullptr;     // streak logic across seed tiles (long reads)
+        const bool general_mt = LONG && n_st > 1 && !no_keep;     // streak logic across seed tiles (long reads)
         if (n_st > 1 && !no_keep && !general_mt) {
             if (lane == 0) {
                 BigMeta m{r, 0, 0, 2u};
@@ -836,7 +837,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
             }
             continue;
         }
-        uint4 *recb = a.records + (a.seed_off ? (size_t)a.seed_off[r] : (size_t)r * a.seed_cap);
+        uint4 *recb = a.records + (LONG ? (size_t)a.seed_off[r] : (size_t)r * a.seed_cap);
         // occurrence filter of seed tile t: my_n = anchors this lane's seed contributes (0 if filtered / absent)
         auto eval = [&](uint32_t t, uint4 &rec, uint32_t &my_n, bool &flt, bool &have) {
             const uint32_t sidx = t * 64 + lane;
@@ -969,7 +970,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
             const unsigned long long want = n_a > 16384u ? n_a : 16384u;
             unsigned long long base = 0;
             if (lane == 0) base = atomicAdd(&a.ctr->anchor_cursor, want);
-            base = (unsigned long long)__shfl((long long)base, 0);
+            base = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32;
             a_cur = base; a_end = base + want;
         }
         const unsigned long long off = a_cur;
@@ -1577,7 +1578,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         uint8_t *p = c->d_arena + c->legacy_bytes;
         uint64_t left = c->arena_bytes - c->legacy_bytes;
         // k_expand's waves reserve sort-list entries in chunks (<= 32): up to one abandoned chunk per wave and class
-        const uint64_t waves = 2 * std::min<uint64_t>(std::max<uint64_t>(n_tiles, 1), 256 * 8);      // k_expand's grid (big_pass)
+        const uint64_t waves = 3 * std::min<uint64_t>(std::max<uint64_t>(n_tiles, 1), 256 * 8);      // k_expand's grid (big_pass)
         const uint64_t sort_cap[N_SORT_CLS] = {max_reads + 32 * waves, max_reads + 32 * waves, max_reads + 8 * waves, max_reads + 8 * waves, max_reads + waves, max_reads + waves};
         uint64_t sort_cap_sum = 0;
         for (int i = 0; i < N_SORT_CLS; ++i) sort_cap_sum += sort_cap[i];
@@ -1665,7 +1666,8 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     SH_HIP(hipMemsetAsync(&ctr->anchor_cursor, 0, 8, s));
     SH_HIP(hipMemsetAsync(&ctr->n_sort[0], 0, 4 * N_SORT_CLS, s));
     SH_HIP(hipMemsetAsync(&ctr->n_cl[0], 0, 4 * 6, s));
-    hipLaunchKernelGGL(k_expand, dim3(grid * 2), dim3(64), 0, s, k);
+    if (k.seed_off) hipLaunchKernelGGL(k_expand<true>, dim3(grid * 3), dim3(64), 0, s, k);
+    else hipLaunchKernelGGL(k_expand<false>, dim3(grid * 3), dim3(64), 0, s, k);
     // the four sort classes are independent: run them side by side so that they fill each other's tails
     const bool side = (c->par & 2) != 0;
     hipStream_t s0 = side ? c->sx[0] : s, s1 = side ? c->sx[1] : s, g = side ? c->sx[2] : s;
