@@ -22,6 +22,13 @@ struct ChainParams {
     int32_t max_skip, max_iter;
     float pen_gap, pen_skip;
     float q_occ_frac;
+    // Flag-only shortcut (host-computed, INT32_MAX = off): a cluster yields a mapping iff some anchor reaches f >= min_sc.
+    // mg_chain_backtrack pops the maximum f first (nothing is marked yet); its walk either reaches the chain's root, where
+    // the score is zf >= min_sc over >= ceil(min_sc / k) anchors (a link adds at most k), or stops on a drop > bw, where the
+    // kept part scores > bw over > bw / k anchors.  With ceil(min_sc / k) >= min_cnt, bw >= min_sc and bw / k + 1 >= min_cnt
+    // (true for every preset) that chain is always accepted, so the DP can stop at the first f >= flag_stop = min_sc and
+    // no backtrack is needed; if no anchor gets there, there is no candidate at all.
+    int32_t flag_stop;
 };
 
 // ---- seeds: one 16-B record per query minimizer found in the index ---------------------------
@@ -240,7 +247,7 @@ __device__ inline void gen_anchors(Store &S, SeedView sv, const uint64_t *__rest
 
 // mg_lchain_dp: fills f/p; t is scratch
 template <class Store, class Idx>
-__device__ inline void chain_dp(Store &S, Idx n, int32_t qlen, const ChainParams &P)
+__device__ inline bool chain_dp(Store &S, Idx n, int32_t qlen, const ChainParams &P, int32_t stop_at = INT32_MAX)
 {
     int32_t max_dist_y = P.is_sr ? (qlen > P.max_gap ? qlen : P.max_gap) : P.max_gap;
     int32_t max_dist_x;
@@ -284,10 +291,12 @@ __device__ inline void chain_dp(Store &S, Idx n, int32_t qlen, const ChainParams
             if (tmp != SH_SC_NONE && max_f < tmp + S.F(max_ii)) { max_f = tmp + S.F(max_ii); max_j = max_ii; }
         }
         S.setFP(i, max_f, (int32_t)max_j);
+        if (max_f >= stop_at) return true;
         bool near = false;
         if (max_ii >= 0) near = (gi == S.grp(max_ii)) && ((uint64_t)(li - S.rlo(max_ii)) <= (uint64_t)max_dist_x);
         if (max_ii < 0 || (near && S.F(max_ii) < max_f)) max_ii = i;
     }
+    return false;
 }
 
 // mg_chain_bk_end
@@ -353,7 +362,7 @@ __device__ inline void backtrack_small(Store &S, int n, const ChainParams &P, in
 // mg_chain_bk_end (it is set and cleared on the same path), so only t == 1 persists: one mask again.
 // Without the LDS store -> load dependency through t[] the j loop's loads are independent and pipeline.
 template <class Store>
-__device__ inline void chain_dp_mask(Store &S, int n, int32_t qlen, const ChainParams &P)
+__device__ inline bool chain_dp_mask(Store &S, int n, int32_t qlen, const ChainParams &P, int32_t stop_at = INT32_MAX)
 {
     int32_t max_dist_y = P.is_sr ? (qlen > P.max_gap ? qlen : P.max_gap) : P.max_gap;
     int32_t max_dist_x;
@@ -398,10 +407,12 @@ __device__ inline void chain_dp_mask(Store &S, int n, int32_t qlen, const ChainP
             if (tmp != SH_SC_NONE && max_f < tmp + S.F(max_ii)) { max_f = tmp + S.F(max_ii); max_j = max_ii; }
         }
         S.setFP(i, max_f, max_j);
+        if (max_f >= stop_at) return true;
         bool near = false;
         if (max_ii >= 0) near = (gi == S.grp(max_ii)) && ((uint64_t)(li - S.rlo(max_ii)) <= (uint64_t)max_dist_x);
         if (max_ii < 0 || (near && S.F(max_ii) < max_f)) max_ii = i;
     }
+    return false;
 }
 
 template <class Store>
@@ -545,7 +556,7 @@ __device__ inline int32_t wave_scan_min_incl(int32_t v)
 // The critical path of a 20-anchor cluster drops from ~190 dependent pair evaluations to 20 wave steps.
 __device__ inline void wave_mem_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
-__device__ inline void chain_dp_wave(const SliceStore &S, int n, int32_t qlen, const ChainParams &P, uint32_t lane)
+__device__ inline bool chain_dp_wave(const SliceStore &S, int n, int32_t qlen, const ChainParams &P, uint32_t lane, int32_t stop_at = INT32_MAX)
 {
     int32_t max_dist_y = P.is_sr ? (qlen > P.max_gap ? qlen : P.max_gap) : P.max_gap;
     int32_t max_dist_x;
@@ -622,10 +633,12 @@ __device__ inline void chain_dp_wave(const SliceStore &S, int n, int32_t qlen, c
         }
         if (lane == 0) { f[i] = max_f; pt[2 * i] = max_j; }
         wave_mem_sync();
+        if (max_f >= stop_at) return true;           // wave-uniform
         bool near = false;
         if (max_ii >= 0) near = (uint64_t)(li - (uint32_t)x[max_ii]) <= (uint64_t)max_dist_x;
         if (max_ii < 0 || (near && f[max_ii] < max_f)) max_ii = i;
     }
+    return false;
 }
 
 // ---- wave-cooperative DP with the recent anchors in LDS -------------------------------------------------------------
@@ -648,8 +661,8 @@ __device__ inline int32_t ld_agent(const int32_t *p) { return __hip_atomic_load(
 // look-back window [st, i), cleared after the step.  f and p are written through to the arena without waiting; a scan
 // that leaves the ring window fences once and reads them past the L1 (the next chunk's loads are issued a chunk ahead).
 // Requires P.max_iter <= RING_TMAX_ITER.
-__device__ inline void chain_dp_ring(const uint64_t *gx, const uint32_t *gq, int32_t *gf, int32_t *gpt, int n, int32_t qlen,
-                                     const ChainParams &P, uint32_t lane, RingMem &rm, unsigned long long *dbg_cnt = nullptr)
+__device__ inline bool chain_dp_ring(const uint64_t *gx, const uint32_t *gq, int32_t *gf, int32_t *gpt, int n, int32_t qlen,
+                                     const ChainParams &P, uint32_t lane, RingMem &rm, unsigned long long *dbg_cnt = nullptr, int32_t stop_at = INT32_MAX)
 {
     unsigned long long n_ch_in = 0, n_ch_out = 0, n_far = 0;
     int32_t max_dist_y = P.is_sr ? (qlen > P.max_gap ? qlen : P.max_gap) : P.max_gap;
@@ -770,12 +783,14 @@ __device__ inline void chain_dp_ring(const uint64_t *gx, const uint32_t *gq, int
             if (tmp != SH_SC_NONE && max_f < tmp + mi_f) { max_f = tmp + mi_f; max_j = max_ii; }
         }
         if (lane == 0) { rm.rec[i & M].z = (uint32_t)max_f; rm.rec[i & M].w = (uint32_t)max_j; gf[i] = max_f; gpt[2 * i] = max_j; }
+        if (max_f >= stop_at) { wave_mem_sync(); return true; }      // wave-uniform
         bool near = false;
         if (max_ii >= 0) near = (uint64_t)(li - mi_x) <= (uint64_t)max_dist_x;
         if (max_ii < 0 || (near && mi_f < max_f)) { max_ii = i; mi_x = li; mi_q = qi; mi_f = max_f; }
     }
     wave_mem_sync();
     if (dbg_cnt && lane == 0) { atomicAdd(&dbg_cnt[0], n_ch_in); atomicAdd(&dbg_cnt[1], n_ch_out); atomicAdd(&dbg_cnt[2], n_far); }
+    return false;
 }
 
 // Flag-only shortcut of mg_chain_backtrack: the first candidate popped is the maximum (f, index) with f >= min_sc.  Its
@@ -809,8 +824,9 @@ __device__ inline int first_chain_quick(const int32_t *gf, const int32_t *gpt, i
 __device__ inline void chain_cluster_ring(const uint64_t *gx, uint32_t *gq, int32_t *gf, int32_t *gpt, int32_t n, int32_t qlen, const ChainParams &P,
                                           int32_t &n_u, int32_t &best, bool first_only, uint32_t lane, RingMem &rm, unsigned long long *dbg_cnt = nullptr)
 {
-    chain_dp_ring(gx, gq, gf, gpt, n, qlen, P, lane, rm, dbg_cnt);
     n_u = 0; best = 0;
+    if (first_only && P.flag_stop != INT32_MAX) { n_u = chain_dp_ring(gx, gq, gf, gpt, n, qlen, P, lane, rm, dbg_cnt, P.flag_stop) ? 1 : 0; return; }
+    chain_dp_ring(gx, gq, gf, gpt, n, qlen, P, lane, rm, dbg_cnt);
     if (first_only) {
         const int rc = first_chain_quick(gf, gpt, n, P, lane);
         if (rc >= 0) { n_u = rc; return; }
@@ -824,6 +840,7 @@ __device__ inline void chain_cluster_ring(const uint64_t *gx, uint32_t *gq, int3
 __device__ inline void chain_cluster_wave(SliceStore &S, int32_t n, int32_t qlen, const ChainParams &P, uint64_t *zbuf, int32_t &n_u, int32_t &best,
                                           bool first_only, uint32_t lane)
 {
+    if (first_only && P.flag_stop != INT32_MAX) { n_u = chain_dp_wave(S, n, qlen, P, lane, P.flag_stop) ? 1 : 0; best = 0; return; }
     chain_dp_wave(S, n, qlen, P, lane);
     if (n <= 64) backtrack_mask(S, n, P, n_u, best, first_only);
     else { backtrack_heap<SliceStore, int32_t>(S, n, P, zbuf, n_u, best, first_only); wave_mem_sync(); }
@@ -834,6 +851,11 @@ __device__ inline void chain_cluster_wave(SliceStore &S, int32_t n, int32_t qlen
 __device__ inline void chain_cluster(SliceStore &S, int32_t n, int32_t qlen, const ChainParams &P, uint64_t *zbuf, int32_t &n_u, int32_t &best,
                                      bool first_only)
 {
+    if (first_only && P.flag_stop != INT32_MAX) {
+        n_u = (n <= 64 ? chain_dp_mask(S, n, qlen, P, P.flag_stop) : chain_dp<SliceStore, int32_t>(S, n, qlen, P, P.flag_stop)) ? 1 : 0;
+        best = 0;
+        return;
+    }
     if (n <= 64) {
         chain_dp_mask(S, n, qlen, P);
         backtrack_mask(S, n, P, n_u, best, first_only);

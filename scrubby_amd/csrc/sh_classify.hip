@@ -642,8 +642,11 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
             gen_anchors(S, sv, a.positions, qlen, a.P.k);
             int64_t n_a = 0;
             for (uint32_t i = 0; i < sv.n; ++i) n_a += sv.occ(i);
-            chain_dp_mask(S, (int)n_a, qlen, a.P);
-            backtrack_mask(S, (int)n_a, a.P, n_u, best, a.trace == nullptr);
+            if (a.trace == nullptr && a.P.flag_stop != INT32_MAX) n_u = chain_dp_mask(S, (int)n_a, qlen, a.P, a.P.flag_stop) ? 1 : 0;     // flag-only: see ChainParams::flag_stop
+            else {
+                chain_dp_mask(S, (int)n_a, qlen, a.P);
+                backtrack_mask(S, (int)n_a, a.P, n_u, best, a.trace == nullptr);
+            }
             finish_read(a, r, n_mini, n_seed, n_a, 0, 0, n_u, best);
             host = n_u > 0;
         }
@@ -1525,6 +1528,8 @@ static void fill_chain_params(const sh_opts &o, int32_t mid_occ, ChainParams &P)
     P.pen_gap = (float)(o.chain_gap_scale * 0.01 * o.k);
     P.pen_skip = (float)(o.chain_skip_scale * 0.01 * o.k);
     P.q_occ_frac = o.q_occ_frac;
+    const bool early_ok = o.k > 0 && (o.min_chain_score + o.k - 1) / o.k >= o.min_cnt && o.bw >= o.min_chain_score && o.bw / o.k + 1 >= o.min_cnt;
+    P.flag_stop = early_ok && !getenv("SCRUBBY_HIP_NO_FLAG_STOP") ? o.min_chain_score : INT32_MAX;
 }
 
 static bool w_supported(int w) { return w == 5 || w == 10 || w == 11 || w == 19; }
