@@ -1151,6 +1151,88 @@ __global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
     }
 }
 
+// Flag-only shortcut for reads with thousands of anchors, run BEFORE their full sort.  Anchors on different (strand,
+// contig) never share a cluster, so each such group is an independent set of DP problems and a mapping found in ONE group
+// decides the read (ChainParams::flag_stop).  One block per read: histogram of x >> 32 in LDS, the largest group that fits
+// the LDS sort is compacted in generation order (stable, so ties in x keep the order of the full sort), sorted and
+// chained; on success the read is done (acc_nu = 1) and its sort item is emptied, so the sort kernels skip it; otherwise
+// nothing has changed and the full path runs.  For a long host read that group holds the true locus (~1 k of ~8 k
+// anchors); for a re-chained satellite read any group of its tandem arrays does.
+#define GP_CAP 2048
+#define GP_SLOTS 256
+__global__ __launch_bounds__(256) void k_group_probe(K3Args a, int cls)
+{
+    __shared__ uint64_t s_x[2][GP_CAP];
+    __shared__ uint32_t s_q[2][GP_CAP];
+    __shared__ uint32_t s_key[GP_SLOTS], s_cnt[GP_SLOTS], s_wtot[4], s_sel[2], s_bstart[GP_CAP / 7 + 1], s_blen[GP_CAP / 7 + 1];
+    __shared__ int32_t s_found, s_bcount, s_over;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t n_items = a.ctr->n_sort[cls];
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const SortItem si = a.B.sort_items[cls][it];
+        const uint32_t n = si.n;
+        if (n == 0) continue;
+        const uint64_t *gx = a.B.ax + si.off; const uint32_t *gq = a.B.aq + si.off;
+        for (uint32_t i = tid; i < GP_SLOTS; i += 256) { s_key[i] = 0xffffffffu; s_cnt[i] = 0; }
+        if (tid == 0) { s_found = 0; s_over = 0; s_sel[0] = 0xffffffffu; s_sel[1] = 0; }
+        __syncthreads();
+        // histogram of the groups; a thread walks a contiguous slice and adds whole runs (a seed's occurrences are sorted by contig)
+        const uint32_t per = (n + 255) / 256, i0 = tid * per < n ? tid * per : n, i1 = i0 + per < n ? i0 + per : n;
+        auto add = [&](uint32_t key, uint32_t c) {
+            uint32_t slot = (key * 2654435761u) >> 24;
+            for (uint32_t step = 0; step < GP_SLOTS; ++step) {
+                const uint32_t prev = atomicCAS(&s_key[slot], 0xffffffffu, key);
+                if (prev == 0xffffffffu || prev == key) { atomicAdd(&s_cnt[slot], c); return; }
+                slot = (slot + 1) & (GP_SLOTS - 1);
+            }
+            s_over = 1;
+        };
+        uint32_t run_key = 0, run_n = 0;
+        for (uint32_t i = i0; i < i1; ++i) {
+            const uint32_t key = (uint32_t)(gx[i] >> 32);
+            if (run_n && key != run_key) { add(run_key, run_n); run_n = 0; }
+            run_key = key; ++run_n;
+        }
+        if (run_n) add(run_key, run_n);
+        __syncthreads();
+        // the largest group that fits (ties: the smaller key), at least min_cnt anchors
+        {
+            const uint32_t c = s_cnt[tid], k = s_key[tid];
+            if (k != 0xffffffffu && c <= GP_CAP && (int32_t)c >= a.P.min_cnt && c >= 2) atomicMax(&s_sel[1], c);
+            __syncthreads();
+            if (k != 0xffffffffu && c == s_sel[1] && c != 0) atomicMin(&s_sel[0], k);
+            __syncthreads();
+        }
+        const uint32_t g = s_sel[0], m = s_sel[1];
+        if (s_over || g == 0xffffffffu || m == 0) { __syncthreads(); continue; }
+        // stable compaction of the group into LDS
+        uint32_t run = 0;
+        for (uint32_t base = 0; base < n; base += 256) {
+            const uint32_t i = base + tid;
+            uint64_t x = 0; uint32_t q = 0; bool in = false;
+            if (i < n) { x = gx[i]; in = (uint32_t)(x >> 32) == g; if (in) q = gq[i]; }
+            const uint64_t bm = __ballot(in);
+            if (lane == 0) s_wtot[wv] = (uint32_t)__popcll(bm);
+            __syncthreads();
+            uint32_t off = run;
+            for (uint32_t w2 = 0; w2 < wv; ++w2) off += s_wtot[w2];
+            if (in) { const uint32_t d = off + prefix_popc(bm); s_x[0][d] = x; s_q[0][d] = q; }
+            run += s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+            __syncthreads();
+        }
+        const bool fl = block_merge_sort(&s_x[0][0], &s_q[0][0], &s_x[1][0], &s_q[1][0], m);
+        uint64_t *rx = fl ? s_x[1] : s_x[0]; uint32_t *rq = fl ? s_q[1] : s_q[0];
+        int32_t *f = (int32_t *)(fl ? s_q[0] : s_q[1]), *pt = (int32_t *)(fl ? s_x[0] : s_x[1]);
+        int32_t n_u = 0, best = 0; uint32_t n_cl = 0;
+        chain_sorted<false>(rx, rq, f, pt, m, tid, 256, (int32_t)si.qlen, a.P, &s_found, BigList{s_bstart, s_blen, &s_bcount, GP_CAP / 7 + 1}, n_u, best, n_cl);
+        __syncthreads();
+        if (tid == 0 && s_found) { a.B.acc_nu[si.w] = 1; a.B.acc_best[si.w] = 0; a.B.sort_items[cls][it].n = 0; }
+        n_cl = wave_sum_u32(n_cl);
+        if (lane == 0 && n_cl) atomicAdd(&a.ctr->sh_clusters[SHARD()], n_cl);
+        __syncthreads();
+    }
+}
+
 // ---- giant reads (> SORT_LDS_C anchors; almost all are re-chained satellite reads) ------------------------------
 // Bandwidth-oriented merge sort over ALL giant reads of the pass at once:
 //   k_giant_scan       tile table: read i owns tiles [tile_base[i], tile_base[i+1]) of GT anchors
@@ -1299,6 +1381,7 @@ __global__ __launch_bounds__(1024) void k_giant_chain(K3Args a)
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
         const SortItem si = a.B.sort_items[SORT_CLS_GIANT][it];
         const uint32_t n = si.n;
+        if (n == 0) continue;                 // decided by k_group_probe
         const bool in_b = giant_rounds(n) & 1;
         uint64_t *sx = (in_b ? a.B.bx : a.B.ax) + si.off; uint32_t *sq = (in_b ? a.B.bq : a.B.aq) + si.off;
         if (tid == 0) s_found = 0;
@@ -1679,6 +1762,10 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     if (side) {
         SH_HIP(hipEventRecord(c->evx[0], s));
         for (int i = 0; i < 3; ++i) SH_HIP(hipStreamWaitEvent(c->sx[i], c->evx[0], 0));
+    }
+    if (k.flag_only && k.P.flag_stop != INT32_MAX && !(k.dbg & 64)) {      // reads with thousands of anchors: try one (strand, contig) group first
+        hipLaunchKernelGGL(k_group_probe, dim3(256 * 3), dim3(256), 0, s, k, 4);
+        hipLaunchKernelGGL(k_group_probe, dim3(256 * 3), dim3(256), 0, s, k, (int)SORT_CLS_GIANT);
     }
     hipLaunchKernelGGL((k_sort_lds<256, 0, 64>), dim3(grid * 2), dim3(64), 0, s, k);
     hipLaunchKernelGGL((k_sort_lds<SORT_LDS_A, 1, 128>), dim3(grid * 2), dim3(128), 0, s, k);
