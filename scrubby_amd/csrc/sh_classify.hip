@@ -1120,6 +1120,105 @@ __device__ inline void store_read_result(const K3Args &a, uint32_t w, int32_t n_
     if (threadIdx.x == 0) { a.B.acc_nu[w] = red[0]; a.B.acc_best[w] = red[1]; }
 }
 
+// Flag-only shortcut for reads with thousands of anchors, run BEFORE their full sort.  Anchors on different (strand,
+// contig) never share a cluster, so each such group is an independent set of DP problems and a mapping found in ONE group
+// decides the read (ChainParams::flag_stop).  One block per read: histogram of x >> 32 in LDS, the largest group that fits
+// the LDS sort is compacted in generation order (stable, so ties in x keep the order of the full sort), sorted and
+// chained; on success the read is done (acc_nu = 1) and its sort item is emptied, so the sort kernels skip it; otherwise
+// nothing has changed and the full path runs.  For a long host read that group holds the true locus (~1 k of ~8 k
+// anchors); for a re-chained satellite read any group of its tandem arrays does.
+#define GP_CAP 2048
+#define GP_SLOTS 256
+struct GroupScratch { uint32_t *key, *cnt, *wtot, *sel; int32_t *over; };      // LDS: key/cnt[GP_SLOTS], wtot[16], sel[2]
+
+// The probe proper.  src: the read's n anchors in generation order (HBM or LDS); (ax, aq) / (bx, bq): LDS sort buffers of
+// at least `cap` entries, ax != src.  Groups of lo < size <= cap qualify.  Returns (block-uniform) whether a mapping was
+// found; src is intact unless bx aliases it.  All threads of the block call.
+template <class SX, class SQ>
+__device__ inline bool group_probe(SX src_x, SQ src_q, uint32_t n, uint64_t *ax, uint32_t *aq, uint64_t *bx, uint32_t *bq, uint32_t lo, uint32_t cap,
+                                   const GroupScratch &G, int32_t *found, BigList bl, const ChainParams &P, int32_t qlen, uint32_t &n_cl)
+{
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, n_wv = nthr >> 6;
+    for (uint32_t i = tid; i < GP_SLOTS; i += nthr) { G.key[i] = 0xffffffffu; G.cnt[i] = 0; }
+    if (tid == 0) { *found = 0; *G.over = 0; G.sel[0] = 0xffffffffu; G.sel[1] = 0; }
+    __syncthreads();
+    // histogram of the groups; a thread walks a contiguous slice and adds whole runs (a seed's occurrences are sorted by contig)
+    const uint32_t per = (n + nthr - 1) / nthr, i0 = tid * per < n ? tid * per : n, i1 = i0 + per < n ? i0 + per : n;
+    auto add = [&](uint32_t key, uint32_t c) {
+        uint32_t slot = (key * 2654435761u) >> 24;
+        for (uint32_t step = 0; step < GP_SLOTS; ++step) {
+            const uint32_t prev = atomicCAS(&G.key[slot], 0xffffffffu, key);
+            if (prev == 0xffffffffu || prev == key) { atomicAdd(&G.cnt[slot], c); return; }
+            slot = (slot + 1) & (GP_SLOTS - 1);
+        }
+        *G.over = 1;
+    };
+    uint32_t run_key = 0, run_n = 0;
+    for (uint32_t i = i0; i < i1; ++i) {
+        const uint32_t key = (uint32_t)(src_x[i] >> 32);
+        if (run_n && key != run_key) { add(run_key, run_n); run_n = 0; }
+        run_key = key; ++run_n;
+    }
+    if (run_n) add(run_key, run_n);
+    __syncthreads();
+    // the largest qualifying group (ties: the smaller key), at least min_cnt anchors
+    for (uint32_t sl = tid; sl < GP_SLOTS; sl += nthr) {
+        const uint32_t c = G.cnt[sl];
+        if (G.key[sl] != 0xffffffffu && c > lo && c <= cap && (int32_t)c >= P.min_cnt && c >= 2) atomicMax(&G.sel[1], c);
+    }
+    __syncthreads();
+    for (uint32_t sl = tid; sl < GP_SLOTS; sl += nthr)
+        if (G.key[sl] != 0xffffffffu && G.cnt[sl] == G.sel[1] && G.sel[1] != 0) atomicMin(&G.sel[0], G.key[sl]);
+    __syncthreads();
+    const uint32_t g = G.sel[0], m = G.sel[1];
+    if (*G.over || g == 0xffffffffu || m == 0 || m == n) return false;      // m == n: the full sort is the same work
+    // stable compaction of the group into (ax, aq)
+    uint32_t run = 0;
+    for (uint32_t base = 0; base < n; base += nthr) {
+        const uint32_t i = base + tid;
+        uint64_t x = 0; uint32_t q = 0; bool in = false;
+        if (i < n) { x = src_x[i]; in = (uint32_t)(x >> 32) == g; if (in) q = src_q[i]; }
+        const uint64_t bm = __ballot(in);
+        if (lane == 0) G.wtot[wv] = (uint32_t)__popcll(bm);
+        __syncthreads();
+        uint32_t off = run, tot = 0;
+        for (uint32_t w2 = 0; w2 < n_wv; ++w2) { if (w2 < wv) off += G.wtot[w2]; tot += G.wtot[w2]; }
+        if (in) { const uint32_t d = off + prefix_popc(bm); ax[d] = x; aq[d] = q; }
+        run += tot;
+        __syncthreads();
+    }
+    const bool fl = block_merge_sort(ax, aq, bx, bq, m);
+    uint64_t *rx = fl ? bx : ax; uint32_t *rq = fl ? bq : aq;
+    int32_t *f = (int32_t *)(fl ? aq : bq), *pt = (int32_t *)(fl ? ax : bx);
+    int32_t n_u = 0, best = 0;
+    chain_sorted<false>(rx, rq, f, pt, m, tid, nthr, qlen, P, found, bl, n_u, best, n_cl);
+    __syncthreads();
+    return *found != 0;
+}
+
+__global__ __launch_bounds__(256) void k_group_probe(K3Args a, int cls)
+{
+    __shared__ uint64_t s_x[2][GP_CAP];
+    __shared__ uint32_t s_q[2][GP_CAP];
+    __shared__ uint32_t s_key[GP_SLOTS], s_cnt[GP_SLOTS], s_wtot[16], s_sel[2], s_bstart[GP_CAP / 7 + 1], s_blen[GP_CAP / 7 + 1];
+    __shared__ int32_t s_found, s_bcount, s_over;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t n_items = a.ctr->n_sort[cls];
+    const GroupScratch G{s_key, s_cnt, s_wtot, s_sel, &s_over};
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const SortItem si = a.B.sort_items[cls][it];
+        const uint32_t n = si.n;
+        if (n == 0) continue;
+        uint32_t n_cl = 0;
+        const bool hit = group_probe(a.B.ax + si.off, a.B.aq + si.off, n, s_x[0], s_q[0], s_x[1], s_q[1], 0u, (uint32_t)GP_CAP, G, &s_found,
+                                     BigList{s_bstart, s_blen, &s_bcount, GP_CAP / 7 + 1}, a.P, (int32_t)si.qlen, n_cl);
+        if (tid == 0 && hit) { a.B.acc_nu[si.w] = 1; a.B.acc_best[si.w] = 0; a.B.sort_items[cls][it].n = 0; }
+        n_cl = wave_sum_u32(n_cl);
+        if (lane == 0 && n_cl) atomicAdd(&a.ctr->sh_clusters[SHARD()], n_cl);
+        __syncthreads();
+    }
+}
+
 // one block per read with 64 < anchors <= NMAX: sort in LDS, then chain every cluster straight from LDS
 // (the second sort buffer becomes the DP state).  Nothing but the per-read result goes back to HBM.
 template <int NMAX, int CLS, int NTHR>
@@ -1127,8 +1226,8 @@ __global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
 {
     __shared__ uint64_t s_x[2][NMAX];
     __shared__ uint32_t s_q[2][NMAX];
-    __shared__ int32_t s_found, s_red[2], s_bcount;
-    __shared__ uint32_t s_bstart[NMAX / 7 + 1], s_blen[NMAX / 7 + 1];
+    __shared__ int32_t s_found, s_red[2], s_bcount, s_gover;
+    __shared__ uint32_t s_bstart[NMAX / 7 + 1], s_blen[NMAX / 7 + 1], s_gkey[GP_SLOTS], s_gcnt[GP_SLOTS], s_gw[16], s_gsel[2];
     const uint32_t tid = threadIdx.x;
     const uint32_t n_items = a.ctr->n_sort[CLS];
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
@@ -1139,6 +1238,17 @@ __global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
         for (uint32_t i = tid; i < n; i += NTHR) { s_x[0][i] = gx[i]; s_q[0][i] = gq[i]; }
         if (tid == 0) s_found = 0;
         __syncthreads();
+        if (a.flag_only && a.P.flag_stop != INT32_MAX && n >= 96 && !(a.dbg & 64)) {
+            // flag-only: the largest (strand, contig) group first (see k_group_probe); its sort ping-pongs over the loaded
+            // anchors, so a miss reloads them for the full sort
+            uint32_t n_cl0 = 0;
+            const bool hit = group_probe(&s_x[0][0], &s_q[0][0], n, &s_x[1][0], &s_q[1][0], &s_x[0][0], &s_q[0][0], 0u, n, GroupScratch{s_gkey, s_gcnt, s_gw, s_gsel, &s_gover},
+                                         (int32_t *)&s_found, BigList{s_bstart, s_blen, &s_bcount, NMAX / 7 + 1}, a.P, (int32_t)si.qlen, n_cl0);
+            if (hit) { store_read_result(a, si.w, tid == 0 ? 1 : 0, 0, n_cl0, s_red); __syncthreads(); continue; }
+            for (uint32_t i = tid; i < n; i += NTHR) { s_x[0][i] = gx[i]; s_q[0][i] = gq[i]; }
+            if (tid == 0) s_found = 0;
+            __syncthreads();
+        }
         const bool fl = block_merge_sort(&s_x[0][0], &s_q[0][0], &s_x[1][0], &s_q[1][0], n);
         uint64_t *rx = fl ? s_x[1] : s_x[0]; uint32_t *rq = fl ? s_q[1] : s_q[0];
         int32_t *f = (int32_t *)(fl ? s_q[0] : s_q[1]), *pt = (int32_t *)(fl ? s_x[0] : s_x[1]);
@@ -1147,88 +1257,6 @@ __global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
         chain_sorted<false>(rx, rq, f, pt, n, tid, NTHR, (int32_t)si.qlen, a.P, a.flag_only ? &s_found : nullptr,
                             BigList{s_bstart, s_blen, &s_bcount, NMAX / 7 + 1}, n_u, best, n_cl);
         store_read_result(a, si.w, n_u, best, n_cl, s_red);
-        __syncthreads();
-    }
-}
-
-// Flag-only shortcut for reads with thousands of anchors, run BEFORE their full sort.  Anchors on different (strand,
-// contig) never share a cluster, so each such group is an independent set of DP problems and a mapping found in ONE group
-// decides the read (ChainParams::flag_stop).  One block per read: histogram of x >> 32 in LDS, the largest group that fits
-// the LDS sort is compacted in generation order (stable, so ties in x keep the order of the full sort), sorted and
-// chained; on success the read is done (acc_nu = 1) and its sort item is emptied, so the sort kernels skip it; otherwise
-// nothing has changed and the full path runs.  For a long host read that group holds the true locus (~1 k of ~8 k
-// anchors); for a re-chained satellite read any group of its tandem arrays does.
-#define GP_CAP 2048
-#define GP_SLOTS 256
-__global__ __launch_bounds__(256) void k_group_probe(K3Args a, int cls)
-{
-    __shared__ uint64_t s_x[2][GP_CAP];
-    __shared__ uint32_t s_q[2][GP_CAP];
-    __shared__ uint32_t s_key[GP_SLOTS], s_cnt[GP_SLOTS], s_wtot[4], s_sel[2], s_bstart[GP_CAP / 7 + 1], s_blen[GP_CAP / 7 + 1];
-    __shared__ int32_t s_found, s_bcount, s_over;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t n_items = a.ctr->n_sort[cls];
-    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const SortItem si = a.B.sort_items[cls][it];
-        const uint32_t n = si.n;
-        if (n == 0) continue;
-        const uint64_t *gx = a.B.ax + si.off; const uint32_t *gq = a.B.aq + si.off;
-        for (uint32_t i = tid; i < GP_SLOTS; i += 256) { s_key[i] = 0xffffffffu; s_cnt[i] = 0; }
-        if (tid == 0) { s_found = 0; s_over = 0; s_sel[0] = 0xffffffffu; s_sel[1] = 0; }
-        __syncthreads();
-        // histogram of the groups; a thread walks a contiguous slice and adds whole runs (a seed's occurrences are sorted by contig)
-        const uint32_t per = (n + 255) / 256, i0 = tid * per < n ? tid * per : n, i1 = i0 + per < n ? i0 + per : n;
-        auto add = [&](uint32_t key, uint32_t c) {
-            uint32_t slot = (key * 2654435761u) >> 24;
-            for (uint32_t step = 0; step < GP_SLOTS; ++step) {
-                const uint32_t prev = atomicCAS(&s_key[slot], 0xffffffffu, key);
-                if (prev == 0xffffffffu || prev == key) { atomicAdd(&s_cnt[slot], c); return; }
-                slot = (slot + 1) & (GP_SLOTS - 1);
-            }
-            s_over = 1;
-        };
-        uint32_t run_key = 0, run_n = 0;
-        for (uint32_t i = i0; i < i1; ++i) {
-            const uint32_t key = (uint32_t)(gx[i] >> 32);
-            if (run_n && key != run_key) { add(run_key, run_n); run_n = 0; }
-            run_key = key; ++run_n;
-        }
-        if (run_n) add(run_key, run_n);
-        __syncthreads();
-        // the largest group that fits (ties: the smaller key), at least min_cnt anchors
-        {
-            const uint32_t c = s_cnt[tid], k = s_key[tid];
-            if (k != 0xffffffffu && c <= GP_CAP && (int32_t)c >= a.P.min_cnt && c >= 2) atomicMax(&s_sel[1], c);
-            __syncthreads();
-            if (k != 0xffffffffu && c == s_sel[1] && c != 0) atomicMin(&s_sel[0], k);
-            __syncthreads();
-        }
-        const uint32_t g = s_sel[0], m = s_sel[1];
-        if (s_over || g == 0xffffffffu || m == 0) { __syncthreads(); continue; }
-        // stable compaction of the group into LDS
-        uint32_t run = 0;
-        for (uint32_t base = 0; base < n; base += 256) {
-            const uint32_t i = base + tid;
-            uint64_t x = 0; uint32_t q = 0; bool in = false;
-            if (i < n) { x = gx[i]; in = (uint32_t)(x >> 32) == g; if (in) q = gq[i]; }
-            const uint64_t bm = __ballot(in);
-            if (lane == 0) s_wtot[wv] = (uint32_t)__popcll(bm);
-            __syncthreads();
-            uint32_t off = run;
-            for (uint32_t w2 = 0; w2 < wv; ++w2) off += s_wtot[w2];
-            if (in) { const uint32_t d = off + prefix_popc(bm); s_x[0][d] = x; s_q[0][d] = q; }
-            run += s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
-            __syncthreads();
-        }
-        const bool fl = block_merge_sort(&s_x[0][0], &s_q[0][0], &s_x[1][0], &s_q[1][0], m);
-        uint64_t *rx = fl ? s_x[1] : s_x[0]; uint32_t *rq = fl ? s_q[1] : s_q[0];
-        int32_t *f = (int32_t *)(fl ? s_q[0] : s_q[1]), *pt = (int32_t *)(fl ? s_x[0] : s_x[1]);
-        int32_t n_u = 0, best = 0; uint32_t n_cl = 0;
-        chain_sorted<false>(rx, rq, f, pt, m, tid, 256, (int32_t)si.qlen, a.P, &s_found, BigList{s_bstart, s_blen, &s_bcount, GP_CAP / 7 + 1}, n_u, best, n_cl);
-        __syncthreads();
-        if (tid == 0 && s_found) { a.B.acc_nu[si.w] = 1; a.B.acc_best[si.w] = 0; a.B.sort_items[cls][it].n = 0; }
-        n_cl = wave_sum_u32(n_cl);
-        if (lane == 0 && n_cl) atomicAdd(&a.ctr->sh_clusters[SHARD()], n_cl);
         __syncthreads();
     }
 }
