@@ -45,12 +45,16 @@ def parse():
     ap.add_argument("--records", type=int, default=20_000_000, help="records per GPU (2 per pair)")
     ap.add_argument("--chunk", type=int, default=1 << 25, help="records per kernel launch (default: the whole batch in one launch)")
     ap.add_argument("--small", action="store_true", help="5 Mb reference / 200k records (plumbing check)")
-    ap.add_argument("--workload", choices=["sr", "ont", "k2"], default="sr",
+    ap.add_argument("--workload", choices=["sr", "ont", "k2", "e2e"], default="sr",
                     help="sr = BASELINE configs[1] (headline); ont = configs[3] stand-in: long noisy reads, map-ont preset; "
                          "k2 = configs[4] stand-in: Kraken2-style taxid classification of 2x150 bp pairs against an 8 GB table (not the headline metric)")
     ap.add_argument("--k2-cells", type=int, default=2_000_000_000, help="cells of the compact hash table (4 B each)")
     ap.add_argument("--k2-nodes", type=int, default=50_000, help="taxonomy nodes of the synthetic database")
     ap.add_argument("--ont-chunk", type=int, default=1 << 25, help="long reads per launch (--workload ont)")
+    ap.add_argument("--e2e-threads", type=int, default=0, help="-t of `scrubby reads` for --workload e2e (0: min(16, cores))")
+    ap.add_argument("--e2e-gz", action="store_true", help="--workload e2e: write .fastq.gz outputs")
+    ap.add_argument("--e2e-legacy", action="store_true", help="--workload e2e: also time the collect-then-map host path")
+    ap.add_argument("--e2e-dir", default=None, help="--workload e2e: scratch directory (default: a temp dir)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather-bench", action="store_true", help="also time raw 16-B random gathers over the table")
@@ -71,6 +75,8 @@ def main():
     S.require_gpu()
     if a.workload == "k2":
         return main_k2(a, rank, world, local, dev)
+    if a.workload == "e2e":
+        return main_e2e(a, rank, world, local, dev)
 
     contigs = [1_000_000] * 5 if a.small else CHM13_CONTIGS
     n_rec = 200_000 if a.small else a.records
@@ -383,6 +389,110 @@ def main_k2(a, rank, world, local, dev):
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def fastq_file(path, reads, mate, first_ordinal):
+    """n x 150 uint8 reads -> FASTQ with headers `@syn.<ordinal, 9 digits> <mate>:N:0:0`, qualities `I`."""
+    n, L = reads.shape
+    head = b"@syn.000000000 %d:N:0:0\n" % mate
+    row = np.frombuffer(head + b"A" * L + b"\n+\n" + b"I" * L + b"\n", dtype=np.uint8)
+    arr = np.empty((n, row.size), dtype=np.uint8)
+    arr[:] = row
+    o = np.arange(first_ordinal, first_ordinal + n, dtype=np.int64)
+    for d in range(9):
+        arr[:, 5 + 8 - d] = 48 + (o % 10)
+        o //= 10
+    arr[:, len(head):len(head) + L] = reads
+    arr.tofile(path)
+    return arr.size
+
+
+def main_e2e(a, rank, world, local, dev):
+    """End-to-end scope of SURVEY.md §8d: FASTQ files in -> filtered FASTQ files + JSON report out (`scrubby reads`, rows
+    a3-a8), through sh_reads_run.  Not the headline metric: the timed region includes file IO, parsing and the writer."""
+    import shutil
+    import tempfile
+    assert world == 1, "--workload e2e is a single-process measurement"
+    contigs = [1_000_000] * 5 if a.small else CHM13_CONTIGS
+    n_rec = 200_000 if a.small else a.records
+    n_pairs = n_rec // 2
+    P, R = S.ref_params(REF_SEED, contigs), S.read_params(READ_SEED)
+    G, L = P.genome_len, R.read_len
+    opts = S.preset("sr")
+    work = a.e2e_dir or tempfile.mkdtemp(prefix="scrubby_e2e_")
+    os.makedirs(work, exist_ok=True)
+    t0 = time.time()
+    d_ref = torch.empty(G + 64, dtype=torch.uint8, device=dev)
+    S.synth_ref_device(P, 0, G, d_ref)
+    index = S.Index.build_device(d_ref, [P.contig_start[i] for i in range(len(contigs) + 1)], opts, device=local)
+    h_ref = d_ref[:G].cpu().numpy()
+    fa = os.path.join(work, "ref.fa")
+    with open(fa, "wb") as f:
+        for i in range(len(contigs)):
+            f.write(b">ctg%d synthetic\n" % i)
+            h_ref[P.contig_start[i]:P.contig_start[i + 1]].tofile(f)
+            f.write(b"\n")
+    del d_ref, h_ref
+    d_reads = torch.empty(n_rec * L + 64, dtype=torch.uint8, device=dev)
+    d_off = torch.empty(n_rec + 1, dtype=torch.int64, device=dev)
+    S.synth_reads_device(P, R, 0, n_rec, d_reads, d_off)
+    ctx = S.Context(index, n_rec, n_rec * L, L)
+    d_flags = torch.zeros(n_rec, dtype=torch.uint8, device=dev)
+    ctx.classify(d_reads[:n_rec * L], d_off, d_flags, None, want_stats=True)
+    torch.cuda.synchronize()
+    fl = d_flags.cpu().numpy().reshape(n_pairs, 2)
+    expect_pairs = int(((fl[:, 0] == 1) | (fl[:, 1] == 1)).sum())      # HashSet union over both files (cleaner.rs:564-570)
+    reads = d_reads[:n_rec * L].cpu().numpy().reshape(n_pairs, 2, L)
+    r1, r2 = os.path.join(work, "R1.fastq"), os.path.join(work, "R2.fastq")
+    in_bytes = fastq_file(r1, reads[:, 0, :], 1, 0) + fastq_file(r2, reads[:, 1, :], 2, 0)
+    del reads, ctx, index, d_reads, d_flags, d_off
+    torch.cuda.empty_cache()
+    t_setup = time.time() - t0
+    ext = ".fastq.gz" if a.e2e_gz else ".fastq"
+    o1, o2, js = os.path.join(work, "clean_1" + ext), os.path.join(work, "clean_2" + ext), os.path.join(work, "report.json")
+    threads = a.e2e_threads or min(16, os.cpu_count() or 4)
+
+    def run():
+        t = time.perf_counter()
+        res = S.reads_run([r1, r2], [o1, o2], fa, json=js, command="scrubby reads -i R1 R2 -o clean_1 clean_2 -I ref.fa", threads=threads, device=local)
+        return time.perf_counter() - t, res
+
+    for _ in range(a.warmup):
+        run()
+    runs = [run() for _ in range(a.steps)]
+    dt = sum(r[0] for r in runs)
+    res = runs[-1][1]
+    rep = json.load(open(js))
+    ok = rep["reads_in"] == n_rec and rep["reads_removed"] == 2 * expect_pairs and res["n_depleted_ids"] == expect_pairs
+    out_bytes = os.path.getsize(o1) + os.path.getsize(o2)
+    mean = lambda k: round(float(np.mean([r[1][k] for r in runs])), 1)
+    out = {
+        "metric": "reads/s end to end (FASTQ files in -> filtered FASTQ files + JSON report; index built from FASTA excluded) - NOT the headline metric",
+        "value": round(n_rec * a.steps / (dt - sum(r[1]["ms_index"] for r in runs) / 1e3), 1), "unit": "reads/s", "n_gpus": 1,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 1), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "configs[1] end to end: `scrubby reads -i R1 R2 -o O1 O2 -I ref.fa -j report.json` on %d synthetic 2x150bp pairs, sr preset" % n_pairs,
+                   "records": n_rec, "reference_bp": int(G), "host_threads": threads, "gz_outputs": bool(a.e2e_gz),
+                   "input_bytes": int(in_bytes), "output_bytes": int(out_bytes)},
+        "stages_ms": {"index (FASTA -> HBM)": mean("ms_index"), "pass 1 (read + parse + classify + id set)": mean("ms_ingest"),
+                      "of which device thread busy": mean("ms_classify"), "pass 2 (filter + write) + report": mean("ms_write")},
+        "reads_per_s_incl_index": round(n_rec * a.steps / dt, 1),
+        "result": {"reads_in": rep["reads_in"], "reads_out": rep["reads_out"], "reads_removed": rep["reads_removed"],
+                   "expected_removed (device flags, id union over mates)": 2 * expect_pairs, "identical": bool(ok)},
+        "setup_s": round(t_setup, 1),
+    }
+    if a.e2e_legacy:
+        os.environ["SCRUBBY_HIP_LEGACY_HOST"] = "1"
+        t, lres = run()
+        os.environ.pop("SCRUBBY_HIP_LEGACY_HOST")
+        out["legacy_host_path"] = {"reads_per_s_excl_index": round(n_rec / (t - lres["ms_index"] / 1e3), 1), "s": round(t, 2),
+                                   "ms_index": round(lres["ms_index"], 1), "ms_ingest": round(lres["ms_ingest"], 1),
+                                   "ms_classify": round(lres["ms_classify"], 1), "ms_write": round(lres["ms_write"], 1),
+                                   "reads_removed": lres["reads_removed"]}
+    print(json.dumps(out), flush=True)
+    if not a.e2e_dir:
+        shutil.rmtree(work, ignore_errors=True)
+    assert ok, "end-to-end result differs from the device flags"
 
 
 def ctx_chunk(a, n_rec):

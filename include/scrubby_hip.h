@@ -166,7 +166,7 @@ typedef struct sh_reads_config {
     const char *json;         /* -j, nullable */
     const char *read_ids;     /* -r, nullable */
     const char *command;      /* argv joined by ' ' (terminal.rs:178), for the report */
-    int32_t     threads;      /* -t: accepted for interface parity; the GPU path does not use it */
+    int32_t     threads;      /* -t: host threads of the filter/compress stage (<= 0: 4, the reference's default) */
     int32_t     device;
 } sh_reads_config;
 
@@ -230,6 +230,12 @@ sh_status sh_host_filter_fastx(const char *in, const char *out, const char *cons
                                uint64_t *n_in, uint64_t *n_out);
 sh_status sh_host_read_difference(const char *const *inputs, const char *const *outputs, uint32_t n, uint64_t *reads_in,
                                   uint64_t *reads_out, uint64_t *difference);
+/* the chunked, multi-threaded form of the same filter that sh_reads_run uses (pass 2 of csrc/sh_stream.cpp): the input is cut
+ * into chunks of ~chunk_bytes at record boundaries, `threads` workers filter (and deflate, for .gz outputs), one writer
+ * appends in order; retain != 0 keeps the parsed chunks in memory first, as pass 1 does.  Same bytes out as
+ * sh_host_filter_fastx for plain outputs; .gz outputs are multi-member gzip with the same decompressed content. */
+sh_status sh_host_filter_fastx_stream(const char *in, const char *out, const char *const *ids, uint64_t n_ids, int32_t extract,
+                                      uint64_t chunk_bytes, int32_t threads, int32_t retain, uint64_t *n_in, uint64_t *n_out);
 
 /* ---- synthetic workload (bench/test utility) ---------------------------- */
 /* params structs are syn_ref_params / syn_read_params of csrc/sh_synth_core.h, passed opaquely */

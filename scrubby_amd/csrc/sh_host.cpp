@@ -11,6 +11,7 @@
 // Divergences, all deliberate and documented in DESIGN.md: bz2/xz inputs or outputs are rejected (zlib only);
 // a corrupt FASTQ is an error instead of a logged partial id set.
 #include "sh_common.h"
+#include "sh_host.h"
 #include <zlib.h>
 #include <sys/stat.h>
 #include <chrono>
@@ -161,6 +162,8 @@ sh_status filter_fastx(const char *in, const char *out, const std::unordered_set
 
 }  // namespace
 
+const char *shi_preset_variant(const std::string &display) { return preset_variant(display); }
+
 // ---- pieces exposed for the CPU tests (no GPU needed) ------------------------------------------------------------
 extern "C" sh_status sh_host_get_id(const char *header, char *out, size_t cap)
 {
@@ -222,12 +225,6 @@ extern "C" sh_status sh_host_read_difference(const char *const *inputs, const ch
     return read_difference(inputs, outputs, n, reads_in, reads_out, difference, nullptr);
 }
 
-struct ReportSettings {       // ScrubbySettings, /root/reference/src/report.rs:71-88 (field order = key order)
-    const char *aligner = nullptr, *classifier = nullptr, *index = nullptr, *alignment = nullptr, *reads = nullptr, *report = nullptr, *preset_variant = nullptr;
-    std::vector<std::string> taxa, taxa_direct;
-    uint64_t min_len = 0; double min_cov = 0.0; uint32_t min_mapq = 0;
-    bool extract = false;
-};
 
 static std::string json_f64(double v)
 {   // serde_json prints f64 with the shortest round-trip form and always a fractional part
@@ -238,7 +235,7 @@ static std::string json_f64(double v)
     return o;
 }
 
-static sh_status write_report_json(const char *const *input, const char *const *output, uint32_t n_files, const char *command,
+sh_status shi_write_report_json(const char *const *input, const char *const *output, uint32_t n_files, const char *command,
                                    const ReportSettings &st, const sh_reads_result *r, const char *path)
 {
     FILE *f = fopen(path, "wb");
@@ -285,13 +282,6 @@ static sh_status write_report_json(const char *const *input, const char *const *
     return SH_OK;
 }
 
-static sh_status write_report(const sh_reads_config *c, const std::string &preset, const sh_reads_result *r, const char *path)
-{
-    ReportSettings st;
-    st.aligner = "minimap2-rs"; st.index = c->index; st.preset_variant = preset_variant(preset); st.extract = c->extract != 0;
-    return write_report_json(c->input, c->output, c->n_files, c->command, st, r, path);
-}
-
 // after the filter step: counts from re-reading the files, TSV of ids, JSON (ScrubbyReport::create, report.rs:24-57)
 static sh_status finish_report(const char *const *input, const char *const *output, uint32_t n_files, bool extract, const char *json,
                                const char *read_ids, const char *command, const ReportSettings &st, sh_reads_result *res)
@@ -309,7 +299,7 @@ static sh_status finish_report(const char *const *input, const char *const *outp
         w.put("id\n");
         for (auto &id : diff_ids) w.put(id + "\n");
     }
-    if (json) return write_report_json(input, output, n_files, command, st, res, json);
+    if (json) return shi_write_report_json(input, output, n_files, command, st, res, json);
     return SH_OK;
 }
 
@@ -467,8 +457,10 @@ extern "C" sh_status sh_classifier_run(const sh_classifier_config *c, sh_reads_r
     return finish_report(c->input, c->output, c->n_files, c->extract != 0, c->json, c->read_ids, c->command, st, res);
 }
 
-// ---- Cleaner::run_minimap2_rs + clean_reads + ScrubbyReport::create ------------------------------------------------
-extern "C" sh_status sh_reads_run(const sh_reads_config *c, sh_reads_result *res)
+// ---- Cleaner::run_minimap2_rs + clean_reads + ScrubbyReport::create, collect-then-map form -------------------------
+// The reference's own shape (three passes, everything materialised first).  sh_reads_run (sh_stream.cpp) is the streaming
+// form and hands over to this one only for the corner case of an empty input file (App. C Q6).
+sh_status shi_reads_run_legacy(const sh_reads_config *c, sh_reads_result *res)
 {
     SH_CHECK(c && res, SH_ERR_BAD_ARG, "sh_reads_run: null argument");
     SH_CHECK(c->n_files >= 1 && c->n_files <= 2, SH_ERR_BAD_ARG, "one or two input files are supported (got %u)", c->n_files);

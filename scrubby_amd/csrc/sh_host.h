@@ -1,0 +1,18 @@
+// sh_host.h — declarations shared by the two host-side translation units (sh_host.cpp, sh_stream.cpp).
+#pragma once
+#include "sh_common.h"
+
+struct ReportSettings {       // ScrubbySettings, /root/reference/src/report.rs:71-88 (field order = key order)
+    const char *aligner = nullptr, *classifier = nullptr, *index = nullptr, *alignment = nullptr, *reads = nullptr, *report = nullptr, *preset_variant = nullptr;
+    std::vector<std::string> taxa, taxa_direct;
+    uint64_t min_len = 0; double min_cov = 0.0; uint32_t min_mapq = 0;
+    bool extract = false;
+};
+
+// ScrubbyReport JSON (report.rs:10-88)
+sh_status shi_write_report_json(const char *const *input, const char *const *output, uint32_t n_files, const char *command,
+                                const ReportSettings &st, const sh_reads_result *r, const char *path);
+// Preset's serde name ("Sr", "MapOnt", ...) from its Display form
+const char *shi_preset_variant(const std::string &display);
+// collect-then-map form of the whole path (sh_host.cpp)
+sh_status shi_reads_run_legacy(const sh_reads_config *c, sh_reads_result *res);

@@ -1,0 +1,771 @@
+// sh_stream.cpp — streaming host side of the replaced path (§8f N1).
+//
+// The reference materialises every (id, sequence) before the first read is mapped (/root/reference/src/cleaner.rs:484-549,
+// the author's own note at :445-447), filters by re-reading the inputs (:236-254, :731-760) and counts by re-reading inputs
+// AND outputs (src/utils.rs:250-285).  Same results here, different shape:
+//
+//   pass 1  one reader thread per input file cuts the decompressed byte stream into chunks at record boundaries and parses
+//           them in place (a record = seven offsets into its chunk, no per-record allocation).  A device thread classifies
+//           chunk after chunk (sh_classify_device, one context) while the readers carry on, and folds the ids of the flagged
+//           records into a flat hash set (cleaner.rs:564-570).
+//   pass 2  per file, pool workers decide every record by its id (FastqCleaner::clean_reads), format the kept ones - a run
+//           of kept records already in the writer's form is one memcpy - and, for .gz outputs, deflate each chunk as its
+//           own gzip member (level 6, niffler's default in get_fastx_writer, utils.rs:56-74); an ordered writer appends.
+//           Chunks retained in host memory (budget: half of MemAvailable, SCRUBBY_HIP_RETAIN_MB) are not read again;
+//           past the budget the files are streamed a second time.
+//   report  reads_in / reads_out / difference come from pass 2's counters: keep/drop is a function of the id alone, so
+//           "input records whose id is not among that file's output ids" (utils.rs:265-279) = records not written.
+//
+// An empty input file (App. C Q6: warning, output not created, counts from whatever the output path holds) is the one
+// case handed to the collect-then-map form in sh_host.cpp.
+#include "sh_host.h"
+#include <zlib.h>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+constexpr size_t NPOS = ~(size_t)0;
+
+struct Rec {
+    uint32_t beg, hdr, hdr_len, seq, seq_len, qual, end;   // offsets into Chunk::data; [beg, end) = the record as it stands in the file
+    uint8_t fastq, canon;                                  // canon: [beg, end) is byte for byte what the writer would emit
+};
+
+struct Chunk {
+    char *data = nullptr;
+    size_t len = 0;
+    std::vector<Rec> recs;
+    std::vector<uint8_t> bases;       // the read batch of include/scrubby_hip.h; dropped once classified
+    std::vector<uint64_t> offsets;
+    Chunk() = default;
+    Chunk(const Chunk &) = delete;
+    ~Chunk() { free(data); }
+    size_t footprint() const { return len + recs.capacity() * sizeof(Rec); }
+};
+
+// Cuts a FASTA / FASTQ byte stream (plain or gzip: gzread passes plain bytes through) into chunks that end on record
+// boundaries.  Accepts what the legacy line reader accepts: 4-line FASTQ, multi-line FASTA, CRLF, blank lines between
+// records, a last line without '\n'.
+class ChunkReader {
+    gzFile f_ = nullptr;
+    size_t target_;
+    bool batch_;                      // also lay out the read batch (pass 1); pass 2 only needs the records
+    std::vector<char> carry_;
+    bool eof_ = false;
+
+    size_t eol(const char *d, size_t from, size_t n) const
+    {
+        if (from >= n) return NPOS;
+        const void *q = memchr(d + from, '\n', n - from);
+        return q ? (size_t)((const char *)q - d) : NPOS;
+    }
+    bool fail(const std::string &m) { error = m; return false; }
+
+    // parses records from the start of c; *consumed = start of the first incomplete record.  false = malformed.
+    bool parse(Chunk &c, bool at_eof, size_t *consumed)
+    {
+        char *d = c.data;
+        const size_t n = c.len;
+        size_t p = 0;
+        uint64_t n_bases = 0;
+        for (;;) {
+            for (;;) {      // blank lines before a record
+                if (p < n && d[p] == '\n') { ++p; continue; }
+                if (p + 1 < n && d[p] == '\r' && d[p + 1] == '\n') { p += 2; continue; }
+                if (p + 1 == n && d[p] == '\r' && at_eof) { ++p; continue; }
+                break;
+            }
+            *consumed = p;
+            if (p >= n || (p + 1 == n && d[p] == '\r')) break;
+            Rec r{};
+            r.beg = (uint32_t)p;
+            bool cr = false;
+            auto strip = [&](size_t b, size_t e) { if (e > b && d[e - 1] == '\r') { cr = true; return e - 1; } return e; };
+            if (d[p] == '@') {
+                const size_t e1 = eol(d, p + 1, n);
+                const size_t e2 = e1 == NPOS ? NPOS : eol(d, e1 + 1, n);
+                const size_t e3 = e2 == NPOS ? NPOS : eol(d, e2 + 1, n);
+                if (e3 == NPOS) {
+                    if (!at_eof) break;
+                    return fail("truncated FASTQ record: " + std::string(d + p + 1, std::min<size_t>(n - p - 1, 80)));
+                }
+                size_t e4 = eol(d, e3 + 1, n);
+                bool term = true;
+                if (e4 == NPOS) {
+                    if (!at_eof) break;
+                    if (e3 + 1 >= n) return fail("truncated FASTQ record: " + std::string(d + p + 1, strip(p + 1, e1) - p - 1));
+                    e4 = n; term = false;
+                }
+                r.fastq = 1;
+                r.hdr = (uint32_t)(p + 1); r.hdr_len = (uint32_t)(strip(p + 1, e1) - (p + 1));
+                r.seq = (uint32_t)(e1 + 1); r.seq_len = (uint32_t)(strip(e1 + 1, e2) - (e1 + 1));
+                const size_t pl = strip(e2 + 1, e3) - (e2 + 1);
+                if (pl == 0 || d[e2 + 1] != '+') return fail("truncated FASTQ record: " + std::string(d + r.hdr, r.hdr_len));
+                r.qual = (uint32_t)(e3 + 1);
+                const size_t ql = strip(e3 + 1, e4) - (e3 + 1);
+                if (ql != r.seq_len) return fail("sequence/quality length mismatch: " + std::string(d + r.hdr, r.hdr_len));
+                r.end = (uint32_t)(term ? e4 + 1 : e4);
+                r.canon = !cr && pl == 1 && term;
+            } else if (d[p] == '>') {
+                size_t e1 = eol(d, p + 1, n);
+                if (e1 == NPOS) { if (!at_eof) break; e1 = n; }
+                // the record runs to the next line that starts with '>'
+                size_t next = NPOS;
+                for (size_t s = e1 + 1; s < n;) {
+                    if (d[s] == '>') { next = s; break; }
+                    const size_t e = eol(d, s, n);
+                    if (e == NPOS) break;
+                    s = e + 1;
+                }
+                if (next == NPOS && !at_eof) break;
+                const size_t rec_end = next == NPOS ? n : next;
+                r.hdr = (uint32_t)(p + 1); r.hdr_len = (uint32_t)(strip(p + 1, e1) - (p + 1));
+                const size_t q = std::min(e1 + 1, rec_end);
+                size_t w = q, lines = 0;
+                bool term_last = e1 < n;
+                for (size_t s = q; s < rec_end;) {     // join the sequence lines in place
+                    size_t e = eol(d, s, rec_end);
+                    bool t = true;
+                    if (e == NPOS) { e = rec_end; t = false; }
+                    const size_t l = strip(s, e) - s;
+                    if (l) { if (w != s) memmove(d + w, d + s, l); w += l; }
+                    ++lines; term_last = t;
+                    s = t ? e + 1 : e;
+                }
+                r.seq = (uint32_t)q; r.seq_len = (uint32_t)(w - q);
+                r.qual = 0;
+                r.end = (uint32_t)rec_end;
+                r.canon = !cr && lines == 1 && term_last;
+            } else {
+                return fail("not a FASTA/FASTQ record: " + std::string(d + p, std::min<size_t>(n - p, 40)));
+            }
+            n_bases += r.seq_len;
+            c.recs.push_back(r);
+            p = r.end;
+        }
+        if (!batch_) return true;
+        // the read batch: concatenated sequences + offsets
+        c.offsets.resize(c.recs.size() + 1);
+        c.bases.resize(n_bases);
+        uint64_t o = 0;
+        for (size_t i = 0; i < c.recs.size(); ++i) {
+            c.offsets[i] = o;
+            memcpy(c.bases.data() + o, d + c.recs[i].seq, c.recs[i].seq_len);
+            o += c.recs[i].seq_len;
+        }
+        c.offsets[c.recs.size()] = o;
+        return true;
+    }
+
+public:
+    std::string error;
+    ChunkReader(const char *path, size_t target, bool batch) : target_(std::max<size_t>(target, 64)), batch_(batch)
+    {
+        f_ = gzopen(path, "rb");
+        if (f_) gzbuffer(f_, 1 << 20);
+    }
+    ~ChunkReader() { if (f_) gzclose(f_); }
+    ChunkReader(const ChunkReader &) = delete;
+    bool ok() const { return f_ != nullptr; }
+
+    // 1 = a chunk with at least one record, 0 = end of input, -1 = malformed input (error set)
+    int next(Chunk &c)
+    {
+        if (eof_ && carry_.empty()) return 0;
+        size_t cap = carry_.size() + target_;
+        c.data = (char *)malloc(cap + 1);
+        if (!c.data) { error = "out of host memory"; return -1; }
+        c.len = carry_.size();
+        if (c.len) memcpy(c.data, carry_.data(), c.len);
+        carry_.clear();
+        for (;;) {
+            while (!eof_ && c.len < cap) {
+                const unsigned want = (unsigned)std::min<size_t>(cap - c.len, 1u << 30);
+                const int got = gzread(f_, c.data + c.len, want);
+                if (got < 0) { int e; error = std::string("read error: ") + gzerror(f_, &e); return -1; }
+                if ((unsigned)got < want) eof_ = true;
+                c.len += (size_t)got;
+            }
+            size_t consumed = 0;
+            c.recs.clear();
+            c.recs.reserve(c.len / 256 + 16);
+            if (!parse(c, eof_, &consumed)) return -1;
+            if (!c.recs.empty() || eof_) {
+                carry_.assign(c.data + consumed, c.data + c.len);
+                c.len = consumed;
+                return c.recs.empty() ? 0 : 1;
+            }
+            // not one complete record in cap bytes: a record longer than the chunk - grow and read on
+            if (cap >= (3ull << 30)) { error = "record longer than 3 GiB"; return -1; }
+            cap = std::min<size_t>(cap * 2, 3ull << 30);
+            char *nd = (char *)realloc(c.data, cap + 1);
+            if (!nd) { error = "out of host memory"; return -1; }
+            c.data = nd;
+        }
+    }
+};
+
+bool file_is_empty(const char *path, bool &exists)
+{
+    gzFile f = gzopen(path, "rb");
+    exists = f != nullptr;
+    if (!f) return true;
+    char ch;
+    const int n = gzread(f, &ch, 1);
+    gzclose(f);
+    return n <= 0;
+}
+
+// get_id (utils.rs:91-103): first whitespace-delimited token of the header
+inline bool id_of(const char *h, uint32_t n, const char **id, uint32_t *len)
+{
+    auto sp = [](unsigned char ch) { return ch == ' ' || (ch >= '\t' && ch <= '\r'); };
+    uint32_t b = 0;
+    while (b < n && sp((unsigned char)h[b])) ++b;
+    uint32_t e = b;
+    while (e < n && !sp((unsigned char)h[e])) ++e;
+    *id = h + b; *len = e - b;
+    return e > b;
+}
+
+inline uint64_t hash_bytes(const char *s, size_t n)
+{
+    uint64_t h = 0x9E3779B97F4A7C15ULL ^ (n * 0xff51afd7ed558ccdULL);
+    while (n >= 8) { uint64_t v; memcpy(&v, s, 8); h = (h ^ v) * 0x9FB21C651E98DF25ULL; h ^= h >> 29; s += 8; n -= 8; }
+    if (n) { uint64_t v = 0; memcpy(&v, s, n); h = (h ^ v) * 0x9FB21C651E98DF25ULL; h ^= h >> 29; }
+    h *= 0xff51afd7ed558ccdULL;
+    return h ^ (h >> 32);
+}
+
+// the HashSet<String> of cleaner.rs:564-570: open addressing over (hash, offset:40 | length:24) into one byte arena;
+// built by one thread, read by many
+class IdSet {
+    struct Ent { uint64_t h, ol; };
+    static constexpr uint64_t EMPTY = ~0ull;
+    std::vector<Ent> tab_;
+    std::vector<char> arena_;
+    size_t n_ = 0, mask_;
+    void grow()
+    {
+        std::vector<Ent> old;
+        old.swap(tab_);
+        tab_.assign(old.size() * 2, Ent{0, EMPTY});
+        mask_ = tab_.size() - 1;
+        for (const Ent &e : old)
+            if (e.ol != EMPTY) { size_t i = e.h & mask_; while (tab_[i].ol != EMPTY) i = (i + 1) & mask_; tab_[i] = e; }
+    }
+public:
+    IdSet() : tab_(1 << 16, Ent{0, EMPTY}), mask_((1 << 16) - 1) {}
+    size_t size() const { return n_; }
+    bool insert(const char *s, uint32_t len)
+    {
+        if (len >= (1u << 24)) len = (1u << 24) - 1;          // ids are compared on their first 16 MiB
+        if ((n_ + 1) * 10 > tab_.size() * 7) grow();
+        const uint64_t h = hash_bytes(s, len);
+        for (size_t i = h & mask_;; i = (i + 1) & mask_) {
+            Ent &e = tab_[i];
+            if (e.ol == EMPTY) {
+                e.h = h; e.ol = ((uint64_t)arena_.size() << 24) | len;
+                arena_.insert(arena_.end(), s, s + len);
+                ++n_;
+                return true;
+            }
+            if (e.h == h && (e.ol & 0xFFFFFF) == len && !memcmp(arena_.data() + (e.ol >> 24), s, len)) return false;
+        }
+    }
+    bool contains(const char *s, uint32_t len) const
+    {
+        if (len >= (1u << 24)) len = (1u << 24) - 1;
+        const uint64_t h = hash_bytes(s, len);
+        for (size_t i = h & mask_;; i = (i + 1) & mask_) {
+            const Ent &e = tab_[i];
+            if (e.ol == EMPTY) return false;
+            if (e.h == h && (e.ol & 0xFFFFFF) == len && !memcmp(arena_.data() + (e.ol >> 24), s, len)) return true;
+        }
+    }
+    template <class F> void for_each(F f) const
+    {
+        for (const Ent &e : tab_) if (e.ol != EMPTY) f(arena_.data() + (e.ol >> 24), (uint32_t)(e.ol & 0xFFFFFF));
+    }
+};
+
+bool ends_with(const std::string &s, const char *suf)
+{
+    const size_t k = strlen(suf);
+    return s.size() >= k && s.compare(s.size() - k, k, suf) == 0;
+}
+
+// one complete gzip member
+bool gz_member(const char *src, size_t n, int level, std::string &dst)
+{
+    z_stream zs{};
+    if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    dst.resize(deflateBound(&zs, (uLong)n) + 64);
+    zs.next_out = (Bytef *)dst.data();
+    size_t out_left = dst.size(), in_left = n;
+    const Bytef *in = (const Bytef *)src;
+    int rc = Z_OK;
+    for (;;) {
+        const uInt ai = (uInt)std::min<size_t>(in_left, 1u << 30), ao = (uInt)std::min<size_t>(out_left, 1u << 30);
+        zs.next_in = (Bytef *)in; zs.avail_in = ai; zs.avail_out = ao;
+        rc = deflate(&zs, in_left == ai ? Z_FINISH : Z_NO_FLUSH);
+        const size_t used_in = ai - zs.avail_in, used_out = ao - zs.avail_out;
+        in += used_in; in_left -= used_in; out_left -= used_out;
+        if (rc != Z_OK && rc != Z_BUF_ERROR) break;
+        if (used_in == 0 && used_out == 0) break;        // no progress: out of space
+    }
+    const bool ok = rc == Z_STREAM_END;
+    dst.resize(dst.size() - out_left);
+    deflateEnd(&zs);
+    return ok;
+}
+
+// FastqCleaner::clean_reads over one chunk (cleaner.rs:731-760): keep a record iff (id in set) == extract
+struct FilterOut {
+    std::string bytes;
+    uint64_t n_in = 0, n_out = 0;
+    std::vector<std::string> dropped;       // ids of records not written; collected only on request
+    std::string error;
+};
+
+void filter_chunk(const Chunk &c, const IdSet &ids, bool extract, bool gz, bool want_dropped, FilterOut &o)
+{
+    std::string plain;
+    plain.reserve(c.len + 64);
+    const char *d = c.data;
+    size_t run_b = NPOS, run_e = 0;
+    auto flush = [&]() { if (run_b != NPOS) { plain.append(d + run_b, run_e - run_b); run_b = NPOS; } };
+    for (const Rec &r : c.recs) {
+        const char *id; uint32_t il;
+        if (!id_of(d + r.hdr, r.hdr_len, &id, &il)) { o.error = "record without an id"; return; }
+        ++o.n_in;
+        if (ids.contains(id, il) != extract) { if (want_dropped) o.dropped.emplace_back(id, il); continue; }
+        ++o.n_out;
+        if (r.canon) {
+            if (run_b != NPOS && run_e == r.beg) run_e = r.end;
+            else { flush(); run_b = r.beg; run_e = r.end; }
+        } else {     // needletail record.write(writer, None): '\n' endings, bare '+', full header, sequence on one line
+            flush();
+            plain += r.fastq ? '@' : '>';
+            plain.append(d + r.hdr, r.hdr_len); plain += '\n';
+            plain.append(d + r.seq, r.seq_len); plain += '\n';
+            if (r.fastq) { plain += "+\n"; plain.append(d + r.qual, r.seq_len); plain += '\n'; }
+        }
+    }
+    flush();
+    if (!gz) { o.bytes.swap(plain); return; }
+    if (!plain.empty() && !gz_member(plain.data(), plain.size(), 6, o.bytes)) o.error = "deflate failed";
+}
+
+// pass 2 for one file: sources chunks (retained, or streamed again), filters on `n_workers` threads, writes in order
+struct FileFilter {
+    const char *in_path, *out_path;
+    const std::vector<std::shared_ptr<Chunk>> *retained;    // nullptr: stream the file again
+    size_t chunk_bytes;
+    const IdSet *ids;
+    bool extract, want_dropped;
+    int n_workers;
+    uint64_t n_in = 0, n_out = 0;
+    std::vector<std::string> dropped;
+    std::string error;
+
+    sh_status run()
+    {
+        const std::string op = out_path;
+        const bool gz = ends_with(op, ".gz");
+        if (ends_with(op, ".bz") || ends_with(op, ".bz2") || ends_with(op, ".lzma") || ends_with(op, ".xz")) {
+            sh_set_error("bzip2/xz output not supported by the HIP backend: %s", out_path);
+            return SH_ERR_IO;
+        }
+        std::unique_ptr<ChunkReader> rd;
+        if (!retained) {
+            rd.reset(new ChunkReader(in_path, chunk_bytes, false));
+            SH_CHECK(rd->ok(), SH_ERR_IO, "cannot open %s", in_path);
+        }
+        FILE *fp = fopen(out_path, "wb");
+        SH_CHECK(fp, SH_ERR_IO, "cannot open %s", out_path);
+        setvbuf(fp, nullptr, _IOFBF, 4 << 20);
+
+        std::mutex src_mu, out_mu;
+        std::condition_variable cv;
+        std::map<size_t, FilterOut> done;
+        size_t next = 0, written = 0;
+        int active = n_workers;
+        bool src_done = false, failed = false;
+        const size_t window = (size_t)n_workers * 2 + 2;
+
+        auto worker = [&]() {
+            for (;;) {
+                std::shared_ptr<Chunk> ch;
+                size_t i = 0;
+                {
+                    std::lock_guard<std::mutex> lk(src_mu);
+                    if (src_done) break;
+                    if (retained) {
+                        if (next >= retained->size()) { src_done = true; break; }
+                        ch = (*retained)[next];
+                    } else {
+                        ch = std::make_shared<Chunk>();
+                        const int r = rd->next(*ch);
+                        if (r <= 0) {
+                            src_done = true;
+                            if (r < 0) { std::lock_guard<std::mutex> l2(out_mu); failed = true; error = std::string(in_path) + ": " + rd->error; cv.notify_all(); }
+                            break;
+                        }
+                    }
+                    i = next++;
+                }
+                {
+                    std::unique_lock<std::mutex> lk(out_mu);
+                    cv.wait(lk, [&] { return failed || i < written + window; });
+                    if (failed) break;
+                }
+                FilterOut o;
+                filter_chunk(*ch, *ids, extract, gz, want_dropped, o);
+                std::lock_guard<std::mutex> lk(out_mu);
+                if (!o.error.empty()) { failed = true; error = o.error + " in " + in_path; }
+                else done.emplace(i, std::move(o));
+                cv.notify_all();
+                if (failed) break;
+            }
+            std::lock_guard<std::mutex> lk(out_mu);
+            --active;
+            cv.notify_all();
+        };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_workers; ++t) pool.emplace_back(worker);
+
+        bool any = false, io_ok = true;
+        for (size_t i = 0;; ++i) {
+            std::unique_lock<std::mutex> lk(out_mu);
+            cv.wait(lk, [&] { return failed || done.count(i) || active == 0; });
+            if (failed || !done.count(i)) break;
+            FilterOut o = std::move(done[i]);
+            done.erase(i);
+            lk.unlock();
+            n_in += o.n_in; n_out += o.n_out;
+            for (auto &s : o.dropped) dropped.push_back(std::move(s));
+            if (!o.bytes.empty()) { any = true; io_ok = io_ok && fwrite(o.bytes.data(), 1, o.bytes.size(), fp) == o.bytes.size(); }
+            lk.lock();
+            written = i + 1;
+            cv.notify_all();
+        }
+        { std::lock_guard<std::mutex> lk(out_mu); if (!io_ok) failed = true; cv.notify_all(); }
+        for (auto &t : pool) t.join();
+        if (gz && !any && error.empty()) {     // no record kept: still a valid (empty) gzip stream, as gzclose would leave
+            std::string m;
+            gz_member("", 0, 6, m);
+            io_ok = io_ok && fwrite(m.data(), 1, m.size(), fp) == m.size();
+        }
+        io_ok = (fclose(fp) == 0) && io_ok;
+        SH_CHECK(error.empty(), SH_ERR_IO, "%s", error.c_str());
+        SH_CHECK(io_ok, SH_ERR_IO, "short write to %s", out_path);
+        return SH_OK;
+    }
+};
+
+size_t env_mb(const char *name, size_t dflt_bytes)
+{
+    const char *e = getenv(name);
+    return e && *e ? (size_t)strtoull(e, nullptr, 10) << 20 : dflt_bytes;
+}
+
+size_t retain_budget()
+{
+    size_t avail_kb = 0;
+    if (FILE *f = fopen("/proc/meminfo", "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, f))
+            if (sscanf(line, "MemAvailable: %zu kB", &avail_kb) == 1) break;
+        fclose(f);
+    }
+    return env_mb("SCRUBBY_HIP_RETAIN_MB", avail_kb * 1024 / 2);
+}
+
+bool write_id_table(const char *path, const std::string &body)
+{   // ReadDifference::write_read_ids (utils.rs:207-214): header `id`, one id per line; compression by extension (level 9, legacy writer)
+    std::string out;
+    const std::string p = path;
+    const std::string *src = &body;
+    if (ends_with(p, ".gz")) { if (!gz_member(body.data(), body.size(), 9, out)) return false; src = &out; }
+    FILE *f = fopen(path, "wb");
+    if (!f) return false;
+    const bool ok = fwrite(src->data(), 1, src->size(), f) == src->size();
+    return (fclose(f) == 0) && ok;
+}
+
+// the device side of pass 1: one context, one stream, buffers that grow with the largest chunk seen
+struct DeviceSide {
+    const sh_index *idx;
+    sh_opts opts;
+    sh_ctx *ctx = nullptr;
+    uint64_t ctx_reads = 0, ctx_bases = 0;
+    uint32_t ctx_len = 0;
+    hipStream_t s = nullptr;
+    uint8_t *d_bases = nullptr, *d_flags = nullptr;
+    uint64_t *d_off = nullptr;
+    size_t cap_bases = 0, cap_reads = 0;
+    std::vector<uint8_t> flags;
+
+    ~DeviceSide()
+    {
+        if (ctx) sh_ctx_destroy(ctx);
+        if (d_bases) hipFree(d_bases);
+        if (d_flags) hipFree(d_flags);
+        if (d_off) hipFree(d_off);
+        if (s) hipStreamDestroy(s);
+    }
+    sh_status classify(const Chunk &c)
+    {
+        const uint64_t n = c.recs.size(), nb = c.offsets[n];
+        uint32_t max_len = 0;
+        for (const Rec &r : c.recs) max_len = std::max(max_len, r.seq_len);
+        if (!s) SH_HIP(hipStreamCreate(&s));
+        if (!ctx || n > ctx_reads || nb > ctx_bases || max_len > ctx_len) {
+            if (ctx) { sh_ctx_destroy(ctx); ctx = nullptr; }
+            ctx_reads = std::max<uint64_t>(ctx_reads, n + n / 4 + 1024);
+            ctx_bases = std::max<uint64_t>(ctx_bases, nb + nb / 4 + 4096);
+            ctx_len = std::max<uint32_t>(ctx_len, max_len <= 1024 ? std::max<uint32_t>(max_len, 256) : (uint32_t)std::min<uint64_t>((uint64_t)max_len * 5 / 4, UINT32_MAX));
+            sh_status st = sh_ctx_create(idx, &opts, ctx_reads, ctx_bases, ctx_len, &ctx);
+            if (st != SH_OK) return st;
+        }
+        if (nb + 64 > cap_bases) { if (d_bases) hipFree(d_bases); d_bases = nullptr; cap_bases = ctx_bases + 64; SH_HIP(hipMalloc(&d_bases, cap_bases)); }
+        if (n + 1 > cap_reads) {
+            if (d_off) hipFree(d_off);
+            if (d_flags) hipFree(d_flags);
+            d_off = nullptr; d_flags = nullptr;
+            cap_reads = ctx_reads + 1;
+            SH_HIP(hipMalloc(&d_off, cap_reads * 8));
+            SH_HIP(hipMalloc(&d_flags, cap_reads));
+        }
+        flags.resize(n);
+        if (nb) SH_HIP(hipMemcpyAsync(d_bases, c.bases.data(), nb, hipMemcpyHostToDevice, s));
+        SH_HIP(hipMemcpyAsync(d_off, c.offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+        sh_status st = sh_classify_device(ctx, d_bases, d_off, n, nb, d_flags, nullptr, s, nullptr);
+        if (st != SH_OK) return st;
+        SH_HIP(hipMemcpyAsync(flags.data(), d_flags, n, hipMemcpyDeviceToHost, s));
+        SH_HIP(hipStreamSynchronize(s));
+        return SH_OK;
+    }
+};
+
+struct ChunkQueue {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<Chunk>> q;
+    size_t cap;
+    int producers;
+    bool abort = false;
+    bool push(std::shared_ptr<Chunk> c)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return abort || q.size() < cap; });
+        if (abort) return false;
+        q.push_back(std::move(c));
+        cv.notify_all();
+        return true;
+    }
+    void producer_done() { std::lock_guard<std::mutex> lk(mu); --producers; cv.notify_all(); }
+    std::shared_ptr<Chunk> pop()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !q.empty() || producers == 0; });
+        if (q.empty()) return nullptr;
+        auto c = std::move(q.front());
+        q.pop_front();
+        cv.notify_all();
+        return c;
+    }
+    void stop() { std::lock_guard<std::mutex> lk(mu); abort = true; cv.notify_all(); }
+};
+
+}  // namespace
+
+// ---- test hook (no GPU): the chunked filter of pass 2 on its own, ids given by the caller --------------------------
+extern "C" sh_status sh_host_filter_fastx_stream(const char *in, const char *out, const char *const *ids, uint64_t n_ids, int32_t extract,
+                                                 uint64_t chunk_bytes, int32_t threads, int32_t retain, uint64_t *n_in, uint64_t *n_out)
+{
+    SH_CHECK(in && out && (ids || n_ids == 0), SH_ERR_BAD_ARG, "sh_host_filter_fastx_stream: null argument");
+    IdSet set;
+    for (uint64_t i = 0; i < n_ids; ++i) set.insert(ids[i], (uint32_t)strlen(ids[i]));
+    std::vector<std::shared_ptr<Chunk>> kept;
+    if (retain) {
+        ChunkReader rd(in, chunk_bytes, false);
+        SH_CHECK(rd.ok(), SH_ERR_IO, "cannot open %s", in);
+        for (;;) {
+            auto c = std::make_shared<Chunk>();
+            const int r = rd.next(*c);
+            SH_CHECK(r >= 0, SH_ERR_IO, "%s: %s", in, rd.error.c_str());
+            if (r == 0) break;
+            kept.push_back(std::move(c));
+        }
+    }
+    FileFilter ff{in, out, retain ? &kept : nullptr, (size_t)chunk_bytes, &set, extract != 0, false, std::max(1, threads)};
+    sh_status st = ff.run();
+    if (n_in) *n_in = ff.n_in;
+    if (n_out) *n_out = ff.n_out;
+    return st;
+}
+
+// ---- Cleaner::run_minimap2_rs + clean_reads + ScrubbyReport::create (cleaner.rs:443-575, :236-254; report.rs:24-57) ------
+extern "C" sh_status sh_reads_run(const sh_reads_config *c, sh_reads_result *res)
+{
+    SH_CHECK(c && res, SH_ERR_BAD_ARG, "sh_reads_run: null argument");
+    SH_CHECK(c->n_files >= 1 && c->n_files <= 2, SH_ERR_BAD_ARG, "one or two input files are supported (got %u)", c->n_files);
+    for (uint32_t i = 0; i < c->n_files; ++i) SH_CHECK(c->input[i] && c->output[i], SH_ERR_BAD_ARG, "input/output %u missing", i);
+    SH_CHECK(c->index, SH_ERR_BAD_ARG, "MissingAlignmentIndex");
+    if (const char *e = getenv("SCRUBBY_HIP_LEGACY_HOST")) if (*e == '1') return shi_reads_run_legacy(c, res);     // A/B switch for bench.py
+    for (uint32_t i = 0; i < c->n_files; ++i) {
+        bool exists;
+        if (file_is_empty(c->input[i], exists)) return shi_reads_run_legacy(c, res);
+    }
+    memset(res, 0, sizeof(*res));
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const int threads = c->threads > 0 ? c->threads : 4;
+    const size_t chunk_bytes = env_mb("SCRUBBY_HIP_CHUNK_MB", 64ull << 20);
+    const size_t budget = retain_budget();
+
+    // default preset: Sr for two files, MapOnt for one (/root/reference/src/scrubby.rs:935-951)
+    const std::string preset = c->preset && c->preset[0] ? c->preset : (c->n_files == 2 ? "sr" : "map-ont");
+    sh_opts opts;
+    sh_status st = sh_preset(preset.c_str(), &opts);
+    if (st != SH_OK) return st;
+
+    const auto t0 = now();
+    sh_index *idx = nullptr;
+    {
+        const std::string ip = c->index;
+        st = ends_with(ip, ".shidx") ? sh_index_load(c->index, c->device, &idx) : sh_index_build_fasta(c->index, &opts, c->device, &idx);
+        if (st != SH_OK) return st == SH_ERR_IO ? st : SH_ERR_INDEX;
+    }
+    const auto t1 = now();
+
+    // ---- pass 1: read + parse per file, classify on the device thread, fold flagged ids ----
+    std::vector<std::shared_ptr<Chunk>> kept[2];
+    std::atomic<size_t> kept_bytes{0};
+    std::atomic<bool> retain{budget > 0};
+    ChunkQueue queue;
+    queue.cap = 4; queue.producers = (int)c->n_files;
+    std::mutex err_mu;
+    sh_status err_st = SH_OK;
+    std::string err_msg;
+    auto set_err = [&](sh_status s, const std::string &m) {
+        std::lock_guard<std::mutex> lk(err_mu);
+        if (err_st == SH_OK) { err_st = s; err_msg = m; }
+    };
+    std::vector<std::thread> readers;
+    for (uint32_t i = 0; i < c->n_files; ++i)
+        readers.emplace_back([&, i]() {
+            ChunkReader rd(c->input[i], chunk_bytes, true);
+            if (!rd.ok()) { set_err(SH_ERR_IO, std::string("cannot open ") + c->input[i]); queue.stop(); queue.producer_done(); return; }
+            for (;;) {
+                auto ch = std::make_shared<Chunk>();
+                const int r = rd.next(*ch);
+                if (r < 0) { set_err(SH_ERR_IO, std::string(c->input[i]) + ": " + rd.error); queue.stop(); break; }
+                if (r == 0) break;
+                bool ids_ok = true;
+                for (const Rec &rc : ch->recs) {
+                    const char *id; uint32_t il;
+                    if (!id_of(ch->data + rc.hdr, rc.hdr_len, &id, &il)) { ids_ok = false; break; }
+                }
+                if (!ids_ok) { set_err(SH_ERR_IO, std::string("record without an id in ") + c->input[i]); queue.stop(); break; }
+                if (retain.load()) {
+                    if (kept_bytes.fetch_add(ch->footprint()) + ch->footprint() > budget) retain.store(false);
+                    else kept[i].push_back(ch);
+                }
+                if (!queue.push(ch)) break;
+            }
+            queue.producer_done();
+        });
+
+    IdSet depleted;
+    double classify_ms = 0;
+    {
+        DeviceSide dev{idx, opts};
+        if (hipSetDevice(idx->device) != hipSuccess) { set_err(SH_ERR_HIP, "hipSetDevice failed"); queue.stop(); }
+        while (auto ch = queue.pop()) {
+            { std::lock_guard<std::mutex> lk(err_mu); if (err_st != SH_OK) continue; }      // drain
+            const auto a = now();
+            st = dev.classify(*ch);
+            classify_ms += ms(a, now());
+            if (st != SH_OK) { set_err(st, sh_last_error()); queue.stop(); continue; }
+            const size_t n = ch->recs.size();
+            for (size_t r = 0; r < n; ++r) {
+                const uint8_t f = dev.flags[r];
+                if (f == 1) {
+                    const char *id; uint32_t il;
+                    id_of(ch->data + ch->recs[r].hdr, ch->recs[r].hdr_len, &id, &il);
+                    depleted.insert(id, il);
+                } else if (f == 2) {        // minimap2-rs: Err("Sequence is empty") aborts the run (cleaner.rs:552,566)
+                    set_err(SH_ERR_EMPTY_READ, "Sequence is empty (read " + std::string(ch->data + ch->recs[r].hdr, ch->recs[r].hdr_len) + ")");
+                    queue.stop();
+                    break;
+                }
+            }
+            std::vector<uint8_t>().swap(ch->bases);
+            std::vector<uint64_t>().swap(ch->offsets);
+        }
+    }
+    for (auto &t : readers) t.join();
+    sh_index_free(idx);
+    if (err_st != SH_OK) { sh_set_error("%s", err_msg.c_str()); return err_st; }
+    if (!retain.load()) { kept[0].clear(); kept[1].clear(); }
+    res->n_depleted_ids = depleted.size();
+    const auto t2 = now();
+
+    // ---- pass 2: filter + write, the files side by side (clean_reads' par_iter over files, cleaner.rs:239) ----
+    const bool want_dropped = c->read_ids && c->extract;      // deplete: the dropped ids ARE the depleted set
+    FileFilter ff[2];
+    sh_status fst[2] = {SH_OK, SH_OK};
+    std::string ferr[2];
+    std::vector<std::thread> filters;
+    for (uint32_t i = 0; i < c->n_files; ++i) {
+        ff[i] = FileFilter{c->input[i], c->output[i], retain.load() ? &kept[i] : nullptr, chunk_bytes, &depleted, c->extract != 0, (bool)want_dropped,
+                           std::max(1, threads / (int)c->n_files)};
+        filters.emplace_back([&, i]() { fst[i] = ff[i].run(); if (fst[i] != SH_OK) ferr[i] = sh_last_error(); });
+    }
+    for (auto &t : filters) t.join();
+    for (uint32_t i = 0; i < c->n_files; ++i)
+        if (fst[i] != SH_OK) { sh_set_error("%s", ferr[i].c_str()); return fst[i]; }
+    kept[0].clear(); kept[1].clear();
+    const auto t3 = now();
+
+    // ---- report (ScrubbyReport::create, report.rs:24-57; ReadDifference, utils.rs:250-285) ----
+    uint64_t rin = 0, rout = 0;
+    for (uint32_t i = 0; i < c->n_files; ++i) { rin += ff[i].n_in; rout += ff[i].n_out; }
+    res->reads_in = rin; res->reads_out = rout;
+    res->reads_removed = c->extract ? 0 : rin - rout;
+    res->reads_extracted = c->extract ? rin - rout : 0;
+    if (c->read_ids) {
+        std::string body = "id\n";
+        if (!c->extract) depleted.for_each([&](const char *s, uint32_t n) { body.append(s, n); body += '\n'; });
+        else {
+            IdSet uniq;
+            for (uint32_t i = 0; i < c->n_files; ++i)
+                for (auto &s : ff[i].dropped)
+                    if (uniq.insert(s.data(), (uint32_t)s.size())) { body += s; body += '\n'; }
+        }
+        const std::string p = c->read_ids;
+        SH_CHECK(!(ends_with(p, ".bz") || ends_with(p, ".bz2") || ends_with(p, ".lzma") || ends_with(p, ".xz")), SH_ERR_IO,
+                 "bzip2/xz output not supported by the HIP backend: %s", c->read_ids);
+        SH_CHECK(write_id_table(c->read_ids, body), SH_ERR_IO, "cannot write %s", c->read_ids);
+    }
+    if (c->json) {
+        ReportSettings rs;
+        rs.aligner = "minimap2-rs"; rs.index = c->index; rs.preset_variant = shi_preset_variant(preset); rs.extract = c->extract != 0;
+        st = shi_write_report_json(c->input, c->output, c->n_files, c->command, rs, res, c->json);
+        if (st != SH_OK) return st;
+    }
+    res->ms_index = ms(t0, t1); res->ms_ingest = ms(t1, t2); res->ms_classify = classify_ms; res->ms_write = ms(t2, now());
+    (void)t3;
+    return SH_OK;
+}

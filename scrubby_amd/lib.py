@@ -113,7 +113,7 @@ EXPORTS = [
     "sh_index_info_get", "sh_index_export", "sh_index_free",
     "sh_ctx_create", "sh_ctx_destroy", "sh_classify_device", "sh_classify_batch",
     "sh_synth_ref_device", "sh_synth_reads_device", "sh_synth_long_reads_device", "sh_bench_gather",
-    "sh_reads_run", "sh_host_get_id", "sh_host_filter_fastx", "sh_host_read_difference",
+    "sh_reads_run", "sh_host_get_id", "sh_host_filter_fastx", "sh_host_filter_fastx_stream", "sh_host_read_difference",
     "sh_classifier_run", "sh_classifier_taxids", "sh_alignment_run",
     "sh_k2_default_opts", "sh_k2_open", "sh_k2_create", "sh_k2_insert_device", "sh_k2_insert_sequence_device",
     "sh_k2_insert_random", "sh_k2_save", "sh_k2_info_get", "sh_k2_db_opts", "sh_k2_export", "sh_k2_free",
@@ -161,6 +161,7 @@ def load():
     L.sh_classifier_taxids.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(C.c_char_p), u32, C.c_char_p, C.c_size_t, C.POINTER(u64)]
     L.sh_host_get_id.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
     L.sh_host_filter_fastx.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u64, i32, C.POINTER(u64), C.POINTER(u64)]
+    L.sh_host_filter_fastx_stream.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u64, i32, u64, i32, i32, C.POINTER(u64), C.POINTER(u64)]
     L.sh_host_read_difference.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     for name in EXPORTS:
         if name not in ("sh_version", "sh_device_count", "sh_last_error"):
@@ -360,6 +361,15 @@ def filter_fastx(inp, out, ids, extract=False):
     arr = (C.c_char_p * max(len(ids), 1))(*[i.encode() for i in ids])
     n_in, n_out = C.c_uint64(), C.c_uint64()
     check(load().sh_host_filter_fastx(os.fsencode(inp), os.fsencode(out), arr, len(ids), int(extract), C.byref(n_in), C.byref(n_out)))
+    return n_in.value, n_out.value
+
+
+def filter_fastx_stream(inp, out, ids, extract=False, chunk_bytes=64 << 20, threads=4, retain=True):
+    """The same filter as sh_reads_run's pass 2 runs it (csrc/sh_stream.cpp): chunked, multi-threaded, ordered writer."""
+    arr = (C.c_char_p * max(len(ids), 1))(*[i.encode() for i in ids])
+    n_in, n_out = C.c_uint64(), C.c_uint64()
+    check(load().sh_host_filter_fastx_stream(os.fsencode(inp), os.fsencode(out), arr, len(ids), int(extract), chunk_bytes, threads, int(retain),
+                                             C.byref(n_in), C.byref(n_out)))
     return n_in.value, n_out.value
 
 

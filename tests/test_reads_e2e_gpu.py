@@ -100,3 +100,43 @@ def test_index_cache_in_reads_run(dataset):
     o1, o2 = str(d / "x1.fastq"), str(d / "x2.fastq")
     res = S.reads_run([r1, r2], [o1, o2], cache, json=str(d / "x.json"))
     assert res["reads_removed"] == 2 * len(ids)
+
+
+def test_streaming_pipeline_small_chunks_and_second_pass(dataset, monkeypatch):
+    """sh_reads_run's streaming host path (csrc/sh_stream.cpp): many chunks per file, with the parsed chunks retained
+    in memory and with the files streamed a second time, against the collect-then-map path and the oracle's id set."""
+    from scrubby_amd import lib as S
+    d, fa, r1, r2, ids, n_pairs = dataset
+    monkeypatch.setenv("SCRUBBY_HIP_CHUNK_MB", "1")            # R1 is ~3.3 MB: several chunks, records straddle the cuts
+    outs = {}
+    for name, env in (("retained", {}), ("streamed", {"SCRUBBY_HIP_RETAIN_MB": "0"}), ("legacy", {"SCRUBBY_HIP_LEGACY_HOST": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        o1, o2, js, tsv = (str(d / f"{name}_{x}") for x in ("1.fastq", "2.fastq.gz", "r.json", "ids.tsv.gz"))
+        res = S.reads_run([r1, r2], [o1, o2], fa, json=js, read_ids=tsv, threads=6)
+        for k in env:
+            monkeypatch.delenv(k)
+        check_outputs(r1, r2, o1, o2, ids, False)
+        got = gzip.open(tsv, "rt").read().split("\n")
+        assert got[0] == "id" and set(x for x in got[1:] if x) == ids
+        outs[name] = (res["reads_in"], res["reads_out"], res["reads_removed"], res["reads_extracted"], res["n_depleted_ids"],
+                      open(o1, "rb").read(), gzip.open(o2, "rb").read())
+    assert outs["retained"] == outs["streamed"] == outs["legacy"]
+    assert outs["retained"][:3] == (2 * n_pairs, 2 * (n_pairs - len(ids)), 2 * len(ids))
+    # extract mode with the id table: the ids NOT written are the complement
+    o1, o2, tsv = str(d / "sx1.fastq"), str(d / "sx2.fastq"), str(d / "sx.tsv")
+    res = S.reads_run([r1, r2], [o1, o2], fa, extract=True, read_ids=tsv, threads=3)
+    check_outputs(r1, r2, o1, o2, ids, True)
+    got = open(tsv).read().split("\n")
+    assert set(x for x in got[1:] if x) == {f"syn.{p}" for p in range(n_pairs)} - ids
+    assert res["reads_extracted"] == 2 * (n_pairs - len(ids))
+
+
+def test_streaming_pipeline_empty_read_aborts(dataset, tmp_path):
+    from scrubby_amd import lib as S
+    d, fa, r1, r2, ids, n_pairs = dataset
+    bad = tmp_path / "empty_read.fastq"
+    bad.write_text("@a\nACGTACGTACGTACGTACGTACGTACGTACGT\n+\n" + "I" * 32 + "\n@b\n\n+\n\n")
+    with pytest.raises(S.ScrubbyHipError) as e:
+        S.reads_run([str(bad)], [str(tmp_path / "o.fastq")], fa, preset="sr")
+    assert "Sequence is empty" in str(e.value)                 # minimap2-rs' Err aborts the run (cleaner.rs:552,566)

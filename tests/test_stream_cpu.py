@@ -1,0 +1,145 @@
+"""The streaming host pipeline's parser and filter (scrubby_amd/csrc/sh_stream.cpp, pass 2 of sh_reads_run) against the
+line-by-line filter (sh_host_filter_fastx, the restated FastqCleaner::clean_reads, /root/reference/src/cleaner.rs:731-760)
+and the Python restatement in tests/test_host_cpu.py: same bytes out for plain outputs, same decompressed content for
+gzip, same counts - for every chunk size (records straddling chunk ends), thread count, and with or without retention."""
+import gzip
+import os
+import random
+
+import pytest
+
+from scrubby_amd import lib as S
+from tests.test_host_cpu import py_records, py_clean
+
+
+def content(path):
+    with open(path, "rb") as f:
+        b = f.read()
+    return gzip.decompress(b) if b[:2] == b"\x1f\x8b" else b
+
+
+def make_fastq(n, rng, crlf=False, plus_hdr=False, blank=False, last_nl=True):
+    nl = "\r\n" if crlf else "\n"
+    out, ids = [], []
+    for i in range(n):
+        L = rng.choice([1, 7, 150, 151, 300])
+        seq = "".join(rng.choice("ACGTN") for _ in range(L))
+        q = "".join(chr(33 + rng.randrange(41)) for _ in range(L))       # '@' (64) and '+' (43) occur as first quality chars
+        if i % 5 == 0:
+            q = "@" + q[1:]
+        hid = f"r{i}"
+        hdr = hid + rng.choice(["", " 1:N:0:0", "\tx y", "/1"])
+        ids.append(hdr.split()[0])
+        out.append(f"@{hdr}{nl}{seq}{nl}+{hdr if plus_hdr and i % 3 == 0 else ''}{nl}{q}{nl}")
+        if blank and i % 7 == 0:
+            out.append(nl)
+    s = "".join(out)
+    if not last_nl:
+        s = s.rstrip("\r\n")
+    return s, ids
+
+
+def make_fasta(n, rng, width):
+    out, ids = [], []
+    for i in range(n):
+        L = rng.choice([0, 1, 59, 60, 61, 500])
+        seq = "".join(rng.choice("ACGT") for _ in range(L))
+        ids.append(f"c{i}")
+        out.append(f">c{i} desc {i}\n")
+        if width:
+            out.extend(seq[j:j + width] + "\n" for j in range(0, L, width))
+        else:
+            out.append(seq + "\n")
+    return "".join(out), ids
+
+
+CASES = {
+    "plain": dict(),
+    "crlf": dict(crlf=True),
+    "plus_hdr": dict(plus_hdr=True),
+    "blank_lines": dict(blank=True),
+    "no_final_newline": dict(last_nl=False),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+@pytest.mark.parametrize("chunk", [64, 1000, 1 << 20])
+def test_stream_filter_matches_line_filter_fastq(tmp_path, case, chunk):
+    rng = random.Random(list(CASES).index(case) * 131 + chunk)
+    text, ids = make_fastq(400, rng, **CASES[case])
+    src = tmp_path / "in.fastq"
+    src.write_bytes(text.encode())
+    drop = [i for i in ids if rng.random() < 0.4] + ["not-there"]
+    for extract in (False, True):
+        ref = tmp_path / "ref.fastq"
+        cnt = S.filter_fastx(str(src), str(ref), drop, extract)
+        for threads, retain in ((1, True), (3, False), (4, True)):
+            out = tmp_path / f"o_{threads}_{int(retain)}.fastq"
+            assert S.filter_fastx_stream(str(src), str(out), drop, extract, chunk_bytes=chunk, threads=threads, retain=retain) == cnt
+            assert out.read_bytes() == ref.read_bytes()
+        assert py_records(str(ref)) == py_clean(py_records(str(src)), set(drop), extract)
+
+
+@pytest.mark.parametrize("width", [0, 60, 7])
+def test_stream_filter_fasta_multiline(tmp_path, width):
+    rng = random.Random(width)
+    text, ids = make_fasta(120, rng, width)
+    src = tmp_path / "in.fa"
+    src.write_bytes(text.encode())
+    drop = ids[::3]
+    ref = tmp_path / "ref.fa"
+    cnt = S.filter_fastx(str(src), str(ref), drop, False)
+    for chunk in (64, 333, 1 << 20):
+        out = tmp_path / f"o{chunk}.fa"
+        assert S.filter_fastx_stream(str(src), str(out), drop, False, chunk_bytes=chunk, threads=2) == cnt
+        assert out.read_bytes() == ref.read_bytes()
+
+
+def test_stream_filter_gzip_in_and_out(tmp_path):
+    rng = random.Random(5)
+    text, ids = make_fastq(3000, rng)
+    src = tmp_path / "in.fastq.gz"
+    with gzip.open(src, "wb") as f:
+        f.write(text.encode())
+    drop = ids[::2]
+    ref, out = tmp_path / "ref.fastq.gz", tmp_path / "out.fastq.gz"
+    cnt = S.filter_fastx(str(src), str(ref), drop, False)
+    assert S.filter_fastx_stream(str(src), str(out), drop, False, chunk_bytes=20000, threads=4, retain=False) == cnt
+    assert out.read_bytes()[:2] == b"\x1f\x8b"
+    assert content(out) == content(ref)                       # multi-member gzip, same decompressed bytes
+    assert len(py_records(str(out))) == cnt[1]                # and the Python reader (gzip module) sees every member
+    # nothing kept: still a valid, empty gzip stream
+    none = tmp_path / "none.fastq.gz"
+    assert S.filter_fastx_stream(str(src), str(none), ids, False, chunk_bytes=20000)[1] == 0
+    assert content(none) == b""
+
+
+def test_stream_filter_errors(tmp_path):
+    bad = tmp_path / "bad.fastq"
+    bad.write_text("@r1\nACGT\n+\nIIII\n@r2\nACGT\n+\nIII\n")        # quality shorter than sequence
+    with pytest.raises(S.ScrubbyHipError):
+        S.filter_fastx_stream(str(bad), str(tmp_path / "o.fastq"), [], False)
+    trunc = tmp_path / "trunc.fastq"
+    trunc.write_text("@r1\nACGT\n+\nIIII\n@r2\nACGT\n")
+    with pytest.raises(S.ScrubbyHipError):
+        S.filter_fastx_stream(str(trunc), str(tmp_path / "o.fastq"), [], False, chunk_bytes=64)
+    junk = tmp_path / "junk.txt"
+    junk.write_text("hello\nworld\n")
+    with pytest.raises(S.ScrubbyHipError):
+        S.filter_fastx_stream(str(junk), str(tmp_path / "o.fastq"), [], False)
+    ok = tmp_path / "ok.fastq"
+    ok.write_text("@r1\nACGT\n+\nIIII\n")
+    with pytest.raises(S.ScrubbyHipError):
+        S.filter_fastx_stream(str(ok), str(tmp_path / "o.fastq.xz"), [], False)
+    with pytest.raises(S.ScrubbyHipError):
+        S.filter_fastx_stream(str(tmp_path / "missing.fastq"), str(tmp_path / "o.fastq"), [], False, retain=False)
+
+
+def test_stream_filter_long_record_grows_chunk(tmp_path):
+    # one record much longer than the chunk target: the reader grows the chunk instead of splitting the record
+    seq = "ACGT" * 50000
+    src = tmp_path / "long.fastq"
+    src.write_text(f"@a\nAC\n+\nII\n@long x\n{seq}\n+\n{'I' * len(seq)}\n@b\nGG\n+\nII\n")
+    out = tmp_path / "o.fastq"
+    assert S.filter_fastx_stream(str(src), str(out), ["a"], False, chunk_bytes=128, threads=2) == (3, 2)
+    assert out.read_text() == f"@long x\n{seq}\n+\n{'I' * len(seq)}\n@b\nGG\n+\nII\n"
