@@ -45,129 +45,161 @@ struct Chunk {
     std::vector<Rec> recs;
     std::vector<uint8_t> bases;       // the read batch of include/scrubby_hip.h; dropped once classified
     std::vector<uint64_t> offsets;
+    uint32_t file = 0;                // which input file, and which chunk of it
+    size_t seq_no = 0;
+    bool parsed = false;
     Chunk() = default;
     Chunk(const Chunk &) = delete;
     ~Chunk() { free(data); }
     size_t footprint() const { return len + recs.capacity() * sizeof(Rec); }
 };
 
+size_t eol(const char *d, size_t from, size_t n)
+{
+    if (from >= n) return NPOS;
+    const void *q = memchr(d + from, '\n', n - from);
+    return q ? (size_t)((const char *)q - d) : NPOS;
+}
+
+// parses records from the start of c; *consumed = start of the first incomplete record.  false = malformed (error set).
+// batch: also lay out the read batch (pass 1); pass 2 only needs the records.
+bool parse_chunk(Chunk &c, bool at_eof, bool batch, size_t *consumed, std::string &error)
+{
+    auto fail = [&](const std::string &m) { error = m; return false; };
+    char *d = c.data;
+    const size_t n = c.len;
+    size_t p = 0;
+    uint64_t n_bases = 0;
+    for (;;) {
+        for (;;) {      // blank lines before a record
+            if (p < n && d[p] == '\n') { ++p; continue; }
+            if (p + 1 < n && d[p] == '\r' && d[p + 1] == '\n') { p += 2; continue; }
+            if (p + 1 == n && d[p] == '\r' && at_eof) { ++p; continue; }
+            break;
+        }
+        *consumed = p;
+        if (p >= n || (p + 1 == n && d[p] == '\r')) break;
+        Rec r{};
+        r.beg = (uint32_t)p;
+        bool cr = false;
+        auto strip = [&](size_t b, size_t e) { if (e > b && d[e - 1] == '\r') { cr = true; return e - 1; } return e; };
+        if (d[p] == '@') {
+            const size_t e1 = eol(d, p + 1, n);
+            const size_t e2 = e1 == NPOS ? NPOS : eol(d, e1 + 1, n);
+            const size_t e3 = e2 == NPOS ? NPOS : eol(d, e2 + 1, n);
+            if (e3 == NPOS) {
+                if (!at_eof) break;
+                return fail("truncated FASTQ record: " + std::string(d + p + 1, std::min<size_t>(n - p - 1, 80)));
+            }
+            size_t e4 = eol(d, e3 + 1, n);
+            bool term = true;
+            if (e4 == NPOS) {
+                if (!at_eof) break;
+                if (e3 + 1 >= n) return fail("truncated FASTQ record: " + std::string(d + p + 1, strip(p + 1, e1) - p - 1));
+                e4 = n; term = false;
+            }
+            r.fastq = 1;
+            r.hdr = (uint32_t)(p + 1); r.hdr_len = (uint32_t)(strip(p + 1, e1) - (p + 1));
+            r.seq = (uint32_t)(e1 + 1); r.seq_len = (uint32_t)(strip(e1 + 1, e2) - (e1 + 1));
+            const size_t pl = strip(e2 + 1, e3) - (e2 + 1);
+            if (pl == 0 || d[e2 + 1] != '+') return fail("truncated FASTQ record: " + std::string(d + r.hdr, r.hdr_len));
+            r.qual = (uint32_t)(e3 + 1);
+            const size_t ql = strip(e3 + 1, e4) - (e3 + 1);
+            if (ql != r.seq_len) return fail("sequence/quality length mismatch: " + std::string(d + r.hdr, r.hdr_len));
+            r.end = (uint32_t)(term ? e4 + 1 : e4);
+            r.canon = !cr && pl == 1 && term;
+        } else if (d[p] == '>') {
+            size_t e1 = eol(d, p + 1, n);
+            if (e1 == NPOS) { if (!at_eof) break; e1 = n; }
+            // the record runs to the next line that starts with '>'
+            size_t next = NPOS;
+            for (size_t s = e1 + 1; s < n;) {
+                if (d[s] == '>') { next = s; break; }
+                const size_t e = eol(d, s, n);
+                if (e == NPOS) break;
+                s = e + 1;
+            }
+            if (next == NPOS && !at_eof) break;
+            const size_t rec_end = next == NPOS ? n : next;
+            r.hdr = (uint32_t)(p + 1); r.hdr_len = (uint32_t)(strip(p + 1, e1) - (p + 1));
+            const size_t q = std::min(e1 + 1, rec_end);
+            size_t w = q, lines = 0;
+            bool term_last = e1 < n;
+            for (size_t s = q; s < rec_end;) {     // join the sequence lines in place
+                size_t e = eol(d, s, rec_end);
+                bool t = true;
+                if (e == NPOS) { e = rec_end; t = false; }
+                const size_t l = strip(s, e) - s;
+                if (l) { if (w != s) memmove(d + w, d + s, l); w += l; }
+                ++lines; term_last = t;
+                s = t ? e + 1 : e;
+            }
+            r.seq = (uint32_t)q; r.seq_len = (uint32_t)(w - q);
+            r.qual = 0;
+            r.end = (uint32_t)rec_end;
+            r.canon = !cr && lines == 1 && term_last;
+        } else {
+            return fail("not a FASTA/FASTQ record: " + std::string(d + p, std::min<size_t>(n - p, 40)));
+        }
+        n_bases += r.seq_len;
+        c.recs.push_back(r);
+        p = r.end;
+    }
+    c.parsed = true;
+    if (!batch) return true;
+    // the read batch: concatenated sequences + offsets
+    c.offsets.resize(c.recs.size() + 1);
+    c.bases.resize(n_bases);
+    uint64_t o = 0;
+    for (size_t i = 0; i < c.recs.size(); ++i) {
+        c.offsets[i] = o;
+        memcpy(c.bases.data() + o, d + c.recs[i].seq, c.recs[i].seq_len);
+        o += c.recs[i].seq_len;
+    }
+    c.offsets[c.recs.size()] = o;
+    return true;
+}
+
+
+// A record boundary near the end of d[0, n), found without parsing from the start: the last line that starts a FASTA record
+// ('>'), or the last line that starts with '@' whose second line after starts with '+'.  A quality line may start with
+// '@' too, but then the second line after it is a sequence; on input odd enough to fool this (a sequence line starting
+// with '+' ...) the chunk BEFORE the cut ends in an incomplete record, its parse fails, and the caller falls back to the
+// sequential reader - so a cut that survives parsing is a true boundary (induction from the start of the file).
+size_t find_split(const char *d, size_t n, bool fasta)
+{
+    size_t pos = n;
+    while (pos > 0) {
+        const void *q = memrchr(d, '\n', pos - 1);
+        if (!q) return NPOS;
+        const size_t nl = (size_t)((const char *)q - d), L = nl + 1;
+        pos = nl;
+        if (L >= n || nl == 0) continue;
+        if (fasta) { if (d[L] == '>') return L; continue; }
+        if (d[L] != '@') continue;
+        const size_t e1 = eol(d, L, n);
+        const size_t e2 = e1 == NPOS ? NPOS : eol(d, e1 + 1, n);
+        if (e2 == NPOS || e2 + 1 >= n) continue;
+        if (d[e2 + 1] == '+') return L;
+    }
+    return NPOS;
+}
+
 // Cuts a FASTA / FASTQ byte stream (plain or gzip: gzread passes plain bytes through) into chunks that end on record
 // boundaries.  Accepts what the legacy line reader accepts: 4-line FASTQ, multi-line FASTA, CRLF, blank lines between
-// records, a last line without '\n'.
+// records, a last line without '\n'.  Sequential mode parses as it cuts; split-only mode cuts at find_split() and leaves
+// the parsing (and its verification) to whoever takes the chunk.
 class ChunkReader {
     gzFile f_ = nullptr;
     size_t target_;
-    bool batch_;                      // also lay out the read batch (pass 1); pass 2 only needs the records
+    bool batch_, split_only_;
+    int fasta_ = -1;
     std::vector<char> carry_;
     bool eof_ = false;
 
-    size_t eol(const char *d, size_t from, size_t n) const
-    {
-        if (from >= n) return NPOS;
-        const void *q = memchr(d + from, '\n', n - from);
-        return q ? (size_t)((const char *)q - d) : NPOS;
-    }
-    bool fail(const std::string &m) { error = m; return false; }
-
-    // parses records from the start of c; *consumed = start of the first incomplete record.  false = malformed.
-    bool parse(Chunk &c, bool at_eof, size_t *consumed)
-    {
-        char *d = c.data;
-        const size_t n = c.len;
-        size_t p = 0;
-        uint64_t n_bases = 0;
-        for (;;) {
-            for (;;) {      // blank lines before a record
-                if (p < n && d[p] == '\n') { ++p; continue; }
-                if (p + 1 < n && d[p] == '\r' && d[p + 1] == '\n') { p += 2; continue; }
-                if (p + 1 == n && d[p] == '\r' && at_eof) { ++p; continue; }
-                break;
-            }
-            *consumed = p;
-            if (p >= n || (p + 1 == n && d[p] == '\r')) break;
-            Rec r{};
-            r.beg = (uint32_t)p;
-            bool cr = false;
-            auto strip = [&](size_t b, size_t e) { if (e > b && d[e - 1] == '\r') { cr = true; return e - 1; } return e; };
-            if (d[p] == '@') {
-                const size_t e1 = eol(d, p + 1, n);
-                const size_t e2 = e1 == NPOS ? NPOS : eol(d, e1 + 1, n);
-                const size_t e3 = e2 == NPOS ? NPOS : eol(d, e2 + 1, n);
-                if (e3 == NPOS) {
-                    if (!at_eof) break;
-                    return fail("truncated FASTQ record: " + std::string(d + p + 1, std::min<size_t>(n - p - 1, 80)));
-                }
-                size_t e4 = eol(d, e3 + 1, n);
-                bool term = true;
-                if (e4 == NPOS) {
-                    if (!at_eof) break;
-                    if (e3 + 1 >= n) return fail("truncated FASTQ record: " + std::string(d + p + 1, strip(p + 1, e1) - p - 1));
-                    e4 = n; term = false;
-                }
-                r.fastq = 1;
-                r.hdr = (uint32_t)(p + 1); r.hdr_len = (uint32_t)(strip(p + 1, e1) - (p + 1));
-                r.seq = (uint32_t)(e1 + 1); r.seq_len = (uint32_t)(strip(e1 + 1, e2) - (e1 + 1));
-                const size_t pl = strip(e2 + 1, e3) - (e2 + 1);
-                if (pl == 0 || d[e2 + 1] != '+') return fail("truncated FASTQ record: " + std::string(d + r.hdr, r.hdr_len));
-                r.qual = (uint32_t)(e3 + 1);
-                const size_t ql = strip(e3 + 1, e4) - (e3 + 1);
-                if (ql != r.seq_len) return fail("sequence/quality length mismatch: " + std::string(d + r.hdr, r.hdr_len));
-                r.end = (uint32_t)(term ? e4 + 1 : e4);
-                r.canon = !cr && pl == 1 && term;
-            } else if (d[p] == '>') {
-                size_t e1 = eol(d, p + 1, n);
-                if (e1 == NPOS) { if (!at_eof) break; e1 = n; }
-                // the record runs to the next line that starts with '>'
-                size_t next = NPOS;
-                for (size_t s = e1 + 1; s < n;) {
-                    if (d[s] == '>') { next = s; break; }
-                    const size_t e = eol(d, s, n);
-                    if (e == NPOS) break;
-                    s = e + 1;
-                }
-                if (next == NPOS && !at_eof) break;
-                const size_t rec_end = next == NPOS ? n : next;
-                r.hdr = (uint32_t)(p + 1); r.hdr_len = (uint32_t)(strip(p + 1, e1) - (p + 1));
-                const size_t q = std::min(e1 + 1, rec_end);
-                size_t w = q, lines = 0;
-                bool term_last = e1 < n;
-                for (size_t s = q; s < rec_end;) {     // join the sequence lines in place
-                    size_t e = eol(d, s, rec_end);
-                    bool t = true;
-                    if (e == NPOS) { e = rec_end; t = false; }
-                    const size_t l = strip(s, e) - s;
-                    if (l) { if (w != s) memmove(d + w, d + s, l); w += l; }
-                    ++lines; term_last = t;
-                    s = t ? e + 1 : e;
-                }
-                r.seq = (uint32_t)q; r.seq_len = (uint32_t)(w - q);
-                r.qual = 0;
-                r.end = (uint32_t)rec_end;
-                r.canon = !cr && lines == 1 && term_last;
-            } else {
-                return fail("not a FASTA/FASTQ record: " + std::string(d + p, std::min<size_t>(n - p, 40)));
-            }
-            n_bases += r.seq_len;
-            c.recs.push_back(r);
-            p = r.end;
-        }
-        if (!batch_) return true;
-        // the read batch: concatenated sequences + offsets
-        c.offsets.resize(c.recs.size() + 1);
-        c.bases.resize(n_bases);
-        uint64_t o = 0;
-        for (size_t i = 0; i < c.recs.size(); ++i) {
-            c.offsets[i] = o;
-            memcpy(c.bases.data() + o, d + c.recs[i].seq, c.recs[i].seq_len);
-            o += c.recs[i].seq_len;
-        }
-        c.offsets[c.recs.size()] = o;
-        return true;
-    }
-
 public:
     std::string error;
-    ChunkReader(const char *path, size_t target, bool batch) : target_(std::max<size_t>(target, 64)), batch_(batch)
+    ChunkReader(const char *path, size_t target, bool batch, bool split_only = false) : target_(std::max<size_t>(target, 64)), batch_(batch), split_only_(split_only)
     {
         f_ = gzopen(path, "rb");
         if (f_) gzbuffer(f_, 1 << 20);
@@ -195,13 +227,23 @@ public:
                 c.len += (size_t)got;
             }
             size_t consumed = 0;
-            c.recs.clear();
-            c.recs.reserve(c.len / 256 + 16);
-            if (!parse(c, eof_, &consumed)) return -1;
-            if (!c.recs.empty() || eof_) {
-                carry_.assign(c.data + consumed, c.data + c.len);
-                c.len = consumed;
-                return c.recs.empty() ? 0 : 1;
+            if (split_only_) {
+                if (fasta_ < 0) { size_t p = 0; while (p < c.len && (c.data[p] == '\n' || c.data[p] == '\r')) ++p; if (p < c.len) fasta_ = c.data[p] == '>'; }
+                consumed = eof_ ? c.len : find_split(c.data, c.len, fasta_ == 1);
+                if (consumed != NPOS) {
+                    carry_.assign(c.data + consumed, c.data + c.len);
+                    c.len = consumed;
+                    return c.len ? 1 : 0;
+                }
+            } else {
+                c.recs.clear();
+                c.recs.reserve(c.len / 256 + 16);
+                if (!parse_chunk(c, eof_, batch_, &consumed, error)) return -1;
+                if (!c.recs.empty() || eof_) {
+                    carry_.assign(c.data + consumed, c.data + c.len);
+                    c.len = consumed;
+                    return c.recs.empty() ? 0 : 1;
+                }
             }
             // not one complete record in cap bytes: a record longer than the chunk - grow and read on
             if (cap >= (3ull << 30)) { error = "record longer than 3 GiB"; return -1; }
@@ -587,6 +629,122 @@ struct ChunkQueue {
     void stop() { std::lock_guard<std::mutex> lk(mu); abort = true; cv.notify_all(); }
 };
 
+constexpr sh_status SH_RETRY_SEQUENTIAL = -1000;     // internal: never crosses the ABI
+
+// pass 1 of sh_reads_run.  parallel: one reader per file only reads and cuts (find_split), `threads` workers parse the
+// chunks (a chunk that does not parse cleanly to its last byte -> SH_RETRY_SEQUENTIAL); else the readers parse as they cut.
+struct Pass1 {
+    const sh_reads_config *c;
+    const sh_index *idx;
+    sh_opts opts;
+    size_t chunk_bytes, budget;
+    int threads;
+    std::vector<std::shared_ptr<Chunk>> *kept;      // [2]
+    IdSet *depleted;
+    double classify_ms = 0;
+    std::atomic<bool> retain{true};
+    std::atomic<size_t> kept_bytes{0};
+    std::mutex mu;                                  // errors + the kept vectors
+    sh_status err_st = SH_OK;
+    std::string err_msg;
+    ChunkQueue rawq, devq;
+
+    void set_err(sh_status s, const std::string &m)
+    {
+        { std::lock_guard<std::mutex> lk(mu); if (err_st == SH_OK) { err_st = s; err_msg = m; } }
+        rawq.stop(); devq.stop();
+    }
+    bool has_err() { std::lock_guard<std::mutex> lk(mu); return err_st != SH_OK; }
+
+    void reader(uint32_t i, bool parallel)
+    {
+        ChunkReader rd(c->input[i], chunk_bytes, true, parallel);
+        if (!rd.ok()) set_err(SH_ERR_IO, std::string("cannot open ") + c->input[i]);
+        else
+            for (size_t k = 0;; ++k) {
+                auto ch = std::make_shared<Chunk>();
+                const int r = rd.next(*ch);
+                if (r < 0) { set_err(SH_ERR_IO, std::string(c->input[i]) + ": " + rd.error); break; }
+                if (r == 0) break;
+                ch->file = i; ch->seq_no = k;
+                if (!rawq.push(ch)) break;
+            }
+        rawq.producer_done();
+    }
+
+    void parser(bool parallel)
+    {
+        while (auto ch = rawq.pop()) {
+            if (has_err()) continue;
+            if (!ch->parsed) {
+                size_t consumed = 0;
+                std::string e;
+                ch->recs.reserve(ch->len / 256 + 16);
+                if (!parse_chunk(*ch, true, true, &consumed, e) || consumed != ch->len) {
+                    set_err(parallel ? SH_RETRY_SEQUENTIAL : SH_ERR_IO, std::string(c->input[ch->file]) + ": " + e);
+                    continue;
+                }
+            }
+            bool ids_ok = true;
+            for (const Rec &rc : ch->recs) {
+                const char *id; uint32_t il;
+                if (!id_of(ch->data + rc.hdr, rc.hdr_len, &id, &il)) { ids_ok = false; break; }
+            }
+            if (!ids_ok) { set_err(SH_ERR_IO, std::string("record without an id in ") + c->input[ch->file]); continue; }
+            if (retain.load()) {
+                if (kept_bytes.fetch_add(ch->footprint()) + ch->footprint() > budget) retain.store(false);
+                else {
+                    std::lock_guard<std::mutex> lk(mu);
+                    auto &v = kept[ch->file];
+                    if (v.size() <= ch->seq_no) v.resize(ch->seq_no + 1);
+                    v[ch->seq_no] = ch;
+                }
+            }
+            if (!ch->recs.empty()) devq.push(ch);
+        }
+        devq.producer_done();
+    }
+
+    sh_status run(bool parallel)
+    {
+        retain.store(budget > 0);
+        const int n_parse = std::max(1, threads);
+        rawq.cap = (size_t)n_parse + 2; rawq.producers = (int)c->n_files;
+        devq.cap = 4; devq.producers = n_parse;
+        std::vector<std::thread> pool;
+        for (uint32_t i = 0; i < c->n_files; ++i) pool.emplace_back([this, i, parallel] { reader(i, parallel); });
+        for (int t = 0; t < n_parse; ++t) pool.emplace_back([this, parallel] { parser(parallel); });
+        {
+            DeviceSide dev{idx, opts};
+            if (hipSetDevice(idx->device) != hipSuccess) set_err(SH_ERR_HIP, "hipSetDevice failed");
+            while (auto ch = devq.pop()) {
+                if (has_err()) continue;      // drain
+                const auto a = std::chrono::steady_clock::now();
+                const sh_status st = dev.classify(*ch);
+                classify_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+                if (st != SH_OK) { set_err(st, sh_last_error()); continue; }
+                const size_t n = ch->recs.size();
+                for (size_t r = 0; r < n; ++r) {
+                    const uint8_t f = dev.flags[r];
+                    if (f == 1) {
+                        const char *id; uint32_t il;
+                        id_of(ch->data + ch->recs[r].hdr, ch->recs[r].hdr_len, &id, &il);
+                        depleted->insert(id, il);
+                    } else if (f == 2) {        // minimap2-rs: Err("Sequence is empty") aborts the run (cleaner.rs:552,566)
+                        set_err(SH_ERR_EMPTY_READ, "Sequence is empty (read " + std::string(ch->data + ch->recs[r].hdr, ch->recs[r].hdr_len) + ")");
+                        break;
+                    }
+                }
+                std::vector<uint8_t>().swap(ch->bases);
+                std::vector<uint64_t>().swap(ch->offsets);
+            }
+        }
+        for (auto &t : pool) t.join();
+        if (err_st != SH_OK) { if (err_st != SH_RETRY_SEQUENTIAL) sh_set_error("%s", err_msg.c_str()); return err_st; }
+        return SH_OK;
+    }
+};
+
 }  // namespace
 
 // ---- test hook (no GPU): the chunked filter of pass 2 on its own, ids given by the caller --------------------------
@@ -597,14 +755,20 @@ extern "C" sh_status sh_host_filter_fastx_stream(const char *in, const char *out
     IdSet set;
     for (uint64_t i = 0; i < n_ids; ++i) set.insert(ids[i], (uint32_t)strlen(ids[i]));
     std::vector<std::shared_ptr<Chunk>> kept;
-    if (retain) {
-        ChunkReader rd(in, chunk_bytes, false);
+    if (retain) {       // 1: the sequential reader; 2: cut at guessed boundaries, then parse each chunk on its own (pass 1's parallel form)
+        ChunkReader rd(in, chunk_bytes, false, retain == 2);
         SH_CHECK(rd.ok(), SH_ERR_IO, "cannot open %s", in);
         for (;;) {
             auto c = std::make_shared<Chunk>();
             const int r = rd.next(*c);
             SH_CHECK(r >= 0, SH_ERR_IO, "%s: %s", in, rd.error.c_str());
             if (r == 0) break;
+            if (retain == 2) {
+                size_t consumed = 0;
+                std::string e;
+                SH_CHECK(parse_chunk(*c, true, false, &consumed, e) && consumed == c->len, SH_ERR_IO, "boundary guess failed (%s): the sequential reader decides", e.c_str());
+                if (c->recs.empty()) continue;
+            }
             kept.push_back(std::move(c));
         }
     }
@@ -649,76 +813,25 @@ extern "C" sh_status sh_reads_run(const sh_reads_config *c, sh_reads_result *res
     }
     const auto t1 = now();
 
-    // ---- pass 1: read + parse per file, classify on the device thread, fold flagged ids ----
+    // ---- pass 1: read -> parse -> classify, fold flagged ids ----
     std::vector<std::shared_ptr<Chunk>> kept[2];
-    std::atomic<size_t> kept_bytes{0};
-    std::atomic<bool> retain{budget > 0};
-    ChunkQueue queue;
-    queue.cap = 4; queue.producers = (int)c->n_files;
-    std::mutex err_mu;
-    sh_status err_st = SH_OK;
-    std::string err_msg;
-    auto set_err = [&](sh_status s, const std::string &m) {
-        std::lock_guard<std::mutex> lk(err_mu);
-        if (err_st == SH_OK) { err_st = s; err_msg = m; }
-    };
-    std::vector<std::thread> readers;
-    for (uint32_t i = 0; i < c->n_files; ++i)
-        readers.emplace_back([&, i]() {
-            ChunkReader rd(c->input[i], chunk_bytes, true);
-            if (!rd.ok()) { set_err(SH_ERR_IO, std::string("cannot open ") + c->input[i]); queue.stop(); queue.producer_done(); return; }
-            for (;;) {
-                auto ch = std::make_shared<Chunk>();
-                const int r = rd.next(*ch);
-                if (r < 0) { set_err(SH_ERR_IO, std::string(c->input[i]) + ": " + rd.error); queue.stop(); break; }
-                if (r == 0) break;
-                bool ids_ok = true;
-                for (const Rec &rc : ch->recs) {
-                    const char *id; uint32_t il;
-                    if (!id_of(ch->data + rc.hdr, rc.hdr_len, &id, &il)) { ids_ok = false; break; }
-                }
-                if (!ids_ok) { set_err(SH_ERR_IO, std::string("record without an id in ") + c->input[i]); queue.stop(); break; }
-                if (retain.load()) {
-                    if (kept_bytes.fetch_add(ch->footprint()) + ch->footprint() > budget) retain.store(false);
-                    else kept[i].push_back(ch);
-                }
-                if (!queue.push(ch)) break;
-            }
-            queue.producer_done();
-        });
-
     IdSet depleted;
     double classify_ms = 0;
+    bool retained = false;
     {
-        DeviceSide dev{idx, opts};
-        if (hipSetDevice(idx->device) != hipSuccess) { set_err(SH_ERR_HIP, "hipSetDevice failed"); queue.stop(); }
-        while (auto ch = queue.pop()) {
-            { std::lock_guard<std::mutex> lk(err_mu); if (err_st != SH_OK) continue; }      // drain
-            const auto a = now();
-            st = dev.classify(*ch);
-            classify_ms += ms(a, now());
-            if (st != SH_OK) { set_err(st, sh_last_error()); queue.stop(); continue; }
-            const size_t n = ch->recs.size();
-            for (size_t r = 0; r < n; ++r) {
-                const uint8_t f = dev.flags[r];
-                if (f == 1) {
-                    const char *id; uint32_t il;
-                    id_of(ch->data + ch->recs[r].hdr, ch->recs[r].hdr_len, &id, &il);
-                    depleted.insert(id, il);
-                } else if (f == 2) {        // minimap2-rs: Err("Sequence is empty") aborts the run (cleaner.rs:552,566)
-                    set_err(SH_ERR_EMPTY_READ, "Sequence is empty (read " + std::string(ch->data + ch->recs[r].hdr, ch->recs[r].hdr_len) + ")");
-                    queue.stop();
-                    break;
-                }
-            }
-            std::vector<uint8_t>().swap(ch->bases);
-            std::vector<uint64_t>().swap(ch->offsets);
-        }
+        Pass1 p1{c, idx, opts, chunk_bytes, budget, threads, kept, &depleted};
+        st = p1.run(true);
+        if (st == SH_RETRY_SEQUENTIAL) {     // a chunk cut at a guessed boundary did not parse: let the sequential reader decide
+            kept[0].clear(); kept[1].clear();
+            depleted = IdSet();
+            Pass1 p1s{c, idx, opts, chunk_bytes, budget, threads, kept, &depleted};
+            st = p1s.run(false);
+            classify_ms = p1s.classify_ms; retained = p1s.retain.load();
+        } else { classify_ms = p1.classify_ms; retained = p1.retain.load(); }
     }
-    for (auto &t : readers) t.join();
     sh_index_free(idx);
-    if (err_st != SH_OK) { sh_set_error("%s", err_msg.c_str()); return err_st; }
-    if (!retain.load()) { kept[0].clear(); kept[1].clear(); }
+    if (st != SH_OK) return st;
+    if (!retained) { kept[0].clear(); kept[1].clear(); }
     res->n_depleted_ids = depleted.size();
     const auto t2 = now();
 
@@ -729,7 +842,7 @@ extern "C" sh_status sh_reads_run(const sh_reads_config *c, sh_reads_result *res
     std::string ferr[2];
     std::vector<std::thread> filters;
     for (uint32_t i = 0; i < c->n_files; ++i) {
-        ff[i] = FileFilter{c->input[i], c->output[i], retain.load() ? &kept[i] : nullptr, chunk_bytes, &depleted, c->extract != 0, (bool)want_dropped,
+        ff[i] = FileFilter{c->input[i], c->output[i], retained ? &kept[i] : nullptr, chunk_bytes, &depleted, c->extract != 0, (bool)want_dropped,
                            std::max(1, threads / (int)c->n_files)};
         filters.emplace_back([&, i]() { fst[i] = ff[i].run(); if (fst[i] != SH_OK) ferr[i] = sh_last_error(); });
     }

@@ -12,7 +12,7 @@ import pytest
 from tests import workloads as W
 from tests.test_host_cpu import py_records, py_clean, py_difference
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -140,3 +140,19 @@ def test_streaming_pipeline_empty_read_aborts(dataset, tmp_path):
     with pytest.raises(S.ScrubbyHipError) as e:
         S.reads_run([str(bad)], [str(tmp_path / "o.fastq")], fa, preset="sr")
     assert "Sequence is empty" in str(e.value)                 # minimap2-rs' Err aborts the run (cleaner.rs:552,566)
+
+
+def test_streaming_pipeline_falls_back_when_a_cut_is_wrong(dataset, tmp_path, monkeypatch):
+    """Sequence lines starting with '@' above quality lines starting with '+' fool the backward boundary scan; the chunk
+    before the wrong cut fails to parse and pass 1 reruns with the sequential reader: same outputs as the legacy path."""
+    from scrubby_amd import lib as S
+    d, fa, r1, r2, ids, n_pairs = dataset
+    odd = tmp_path / "odd.fastq"
+    odd.write_text("".join(f"@r{i} x\n@CGTACGTACGTACGTACGTACGTACGTACG\n+\n+{'I' * 31}\n" for i in range(30000)))
+    monkeypatch.setenv("SCRUBBY_HIP_CHUNK_MB", "1")
+    o_new, o_old = tmp_path / "new.fastq", tmp_path / "old.fastq"
+    a = S.reads_run([str(odd)], [str(o_new)], fa, preset="sr", json=str(tmp_path / "a.json"))
+    monkeypatch.setenv("SCRUBBY_HIP_LEGACY_HOST", "1")
+    b = S.reads_run([str(odd)], [str(o_old)], fa, preset="sr", json=str(tmp_path / "b.json"))
+    assert o_new.read_bytes() == o_old.read_bytes()
+    assert (a["reads_in"], a["reads_out"], a["n_depleted_ids"]) == (b["reads_in"], b["reads_out"], b["n_depleted_ids"]) == (30000, 30000, 0)

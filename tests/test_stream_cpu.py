@@ -8,6 +8,8 @@ import random
 
 import pytest
 
+pytestmark = pytest.mark.timeout(300)          # a deadlock in the pipeline fails instead of hanging the suite
+
 from scrubby_amd import lib as S
 from tests.test_host_cpu import py_records, py_clean
 
@@ -73,7 +75,7 @@ def test_stream_filter_matches_line_filter_fastq(tmp_path, case, chunk):
     for extract in (False, True):
         ref = tmp_path / "ref.fastq"
         cnt = S.filter_fastx(str(src), str(ref), drop, extract)
-        for threads, retain in ((1, True), (3, False), (4, True)):
+        for threads, retain in ((1, 1), (3, 0), (4, 1), (2, 2)):
             out = tmp_path / f"o_{threads}_{int(retain)}.fastq"
             assert S.filter_fastx_stream(str(src), str(out), drop, extract, chunk_bytes=chunk, threads=threads, retain=retain) == cnt
             assert out.read_bytes() == ref.read_bytes()
@@ -91,8 +93,9 @@ def test_stream_filter_fasta_multiline(tmp_path, width):
     cnt = S.filter_fastx(str(src), str(ref), drop, False)
     for chunk in (64, 333, 1 << 20):
         out = tmp_path / f"o{chunk}.fa"
-        assert S.filter_fastx_stream(str(src), str(out), drop, False, chunk_bytes=chunk, threads=2) == cnt
-        assert out.read_bytes() == ref.read_bytes()
+        for retain in (1, 2):
+            assert S.filter_fastx_stream(str(src), str(out), drop, False, chunk_bytes=chunk, threads=2, retain=retain) == cnt
+            assert out.read_bytes() == ref.read_bytes()
 
 
 def test_stream_filter_gzip_in_and_out(tmp_path):
@@ -143,3 +146,28 @@ def test_stream_filter_long_record_grows_chunk(tmp_path):
     out = tmp_path / "o.fastq"
     assert S.filter_fastx_stream(str(src), str(out), ["a"], False, chunk_bytes=128, threads=2) == (3, 2)
     assert out.read_text() == f"@long x\n{seq}\n+\n{'I' * len(seq)}\n@b\nGG\n+\nII\n"
+
+
+def test_boundary_guess_is_verified(tmp_path):
+    """A sequence line that starts with '@' two lines above a quality line that starts with '+' looks like a record start to
+    the backward scan (find_split).  The chunk before such a cut cannot end on a complete record, so its parse fails
+    and the caller falls back to the sequential reader - the guess never changes a result."""
+    recs = []
+    for i in range(40):
+        recs.append(f"@r{i}\n@CGTACGTAC\n+\n+IIIIIIIII\n")      # seq starts with '@', quality with '+'
+    src = tmp_path / "odd.fastq"
+    src.write_text("".join(recs))
+    ref = tmp_path / "ref.fastq"
+    cnt = S.filter_fastx(str(src), str(ref), ["r3"], False)
+    assert cnt == (40, 39)
+    out = tmp_path / "o.fastq"
+    assert S.filter_fastx_stream(str(src), str(out), ["r3"], False, chunk_bytes=100, threads=2, retain=1) == cnt     # sequential: exact
+    assert out.read_bytes() == ref.read_bytes()
+    with pytest.raises(S.ScrubbyHipError, match="boundary guess failed"):
+        S.filter_fastx_stream(str(src), str(out), ["r3"], False, chunk_bytes=100, threads=2, retain=2)
+    # quality lines that start with '@' (common in real data) do not fool the scan
+    ok = tmp_path / "q_at.fastq"
+    ok.write_text("".join(f"@r{i}\nACGTACGTAC\n+\n@IIIIIIIII\n" for i in range(40)))
+    cnt = S.filter_fastx(str(ok), str(ref), ["r3"], False)
+    assert S.filter_fastx_stream(str(ok), str(out), ["r3"], False, chunk_bytes=100, threads=2, retain=2) == cnt
+    assert out.read_bytes() == ref.read_bytes()
