@@ -1680,8 +1680,8 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
     if ((e = hipHostMalloc(&c->h_ctr, sizeof(Counters))) != hipSuccess) return fail(e, "pinned counters");
     // arena: anchors (+ sort buffer) and DP state of reads with > 64 anchors (36 B per anchor slot) + a slice for
     // the legacy re-sketch path.  Default 4 KiB per read of the batch (~110 anchor slots per read; the CHM13-sized
-    // workload averages 72), at least 256 MiB; reads that find no room are deferred and re-run.
-    c->arena_bytes = std::max<uint64_t>(256ull << 20, max_reads * 4096ull);
+    // workload averages 72), at least 4 GiB; reads that find no room are deferred and re-run.
+    c->arena_bytes = std::max<uint64_t>(4ull << 30, max_reads * 4096ull);      // floor: a small batch still meets reads with 10^5 anchors (4 MB each); a starved arena means deferral rounds of ~1.5 ms
     // without K1 every read takes the legacy path, whose sketch buffers and anchors live in the arena: ~48 B per base
     if (!c->use_k1) c->arena_bytes = std::max<uint64_t>(c->arena_bytes, std::min<uint64_t>(max_reads * (uint64_t)max_read_len * 48ull, 64ull << 30));
     if (const char *env = getenv("SCRUBBY_HIP_ARENA_MB")) c->arena_bytes = (uint64_t)atoll(env) << 20;

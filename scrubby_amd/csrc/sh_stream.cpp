@@ -39,6 +39,7 @@ struct Rec {
     uint8_t fastq, canon;                                  // canon: [beg, end) is byte for byte what the writer would emit
 };
 
+struct DevBuf;
 struct Chunk {
     char *data = nullptr;
     size_t len = 0;
@@ -48,6 +49,10 @@ struct Chunk {
     uint32_t file = 0;                // which input file, and which chunk of it
     size_t seq_no = 0;
     bool parsed = false;
+    DevBuf *dev = nullptr;     // pass 1: where a parse worker has put the batch in HBM
+    uint64_t n_bases = 0;
+    uint32_t max_len = 0;
+    std::vector<uint8_t> flags;       // pass 1: the device's verdicts, on their way to the fold threads
     Chunk() = default;
     Chunk(const Chunk &) = delete;
     ~Chunk() { free(data); }
@@ -307,11 +312,12 @@ class IdSet {
 public:
     IdSet() : tab_(1 << 16, Ent{0, EMPTY}), mask_((1 << 16) - 1) {}
     size_t size() const { return n_; }
-    bool insert(const char *s, uint32_t len)
+    static uint32_t clip(uint32_t len) { return len >= (1u << 24) ? (1u << 24) - 1 : len; }     // ids are compared on their first 16 MiB
+    bool insert(const char *s, uint32_t len) { len = clip(len); return insert_h(s, len, hash_bytes(s, len)); }
+    bool contains(const char *s, uint32_t len) const { len = clip(len); return contains_h(s, len, hash_bytes(s, len)); }
+    bool insert_h(const char *s, uint32_t len, uint64_t h)
     {
-        if (len >= (1u << 24)) len = (1u << 24) - 1;          // ids are compared on their first 16 MiB
         if ((n_ + 1) * 10 > tab_.size() * 7) grow();
-        const uint64_t h = hash_bytes(s, len);
         for (size_t i = h & mask_;; i = (i + 1) & mask_) {
             Ent &e = tab_[i];
             if (e.ol == EMPTY) {
@@ -323,10 +329,8 @@ public:
             if (e.h == h && (e.ol & 0xFFFFFF) == len && !memcmp(arena_.data() + (e.ol >> 24), s, len)) return false;
         }
     }
-    bool contains(const char *s, uint32_t len) const
+    bool contains_h(const char *s, uint32_t len, uint64_t h) const
     {
-        if (len >= (1u << 24)) len = (1u << 24) - 1;
-        const uint64_t h = hash_bytes(s, len);
         for (size_t i = h & mask_;; i = (i + 1) & mask_) {
             const Ent &e = tab_[i];
             if (e.ol == EMPTY) return false;
@@ -337,6 +341,31 @@ public:
     {
         for (const Ent &e : tab_) if (e.ol != EMPTY) f(arena_.data() + (e.ol >> 24), (uint32_t)(e.ol & 0xFFFFFF));
     }
+};
+
+// the same set, split 64 ways by the top hash bits so that several threads can fold ids into it at once; reads take no lock
+class ShardedIdSet {
+    static constexpr int N = 64;
+    struct Shard { IdSet set; std::mutex mu; };
+    std::unique_ptr<Shard[]> sh_{new Shard[N]};
+public:
+    bool insert(const char *s, uint32_t len)
+    {
+        len = IdSet::clip(len);
+        const uint64_t h = hash_bytes(s, len);
+        Shard &x = sh_[h >> 58];
+        std::lock_guard<std::mutex> lk(x.mu);
+        return x.set.insert_h(s, len, h);
+    }
+    bool contains(const char *s, uint32_t len) const
+    {
+        len = IdSet::clip(len);
+        const uint64_t h = hash_bytes(s, len);
+        return sh_[h >> 58].set.contains_h(s, len, h);
+    }
+    size_t size() const { size_t n = 0; for (int i = 0; i < N; ++i) n += sh_[i].set.size(); return n; }
+    template <class F> void for_each(F f) const { for (int i = 0; i < N; ++i) sh_[i].set.for_each(f); }
+    void clear() { sh_.reset(new Shard[N]); }
 };
 
 bool ends_with(const std::string &s, const char *suf)
@@ -378,7 +407,7 @@ struct FilterOut {
     std::string error;
 };
 
-void filter_chunk(const Chunk &c, const IdSet &ids, bool extract, bool gz, bool want_dropped, FilterOut &o)
+void filter_chunk(const Chunk &c, const ShardedIdSet &ids, bool extract, bool gz, bool want_dropped, FilterOut &o)
 {
     std::string plain;
     plain.reserve(c.len + 64);
@@ -412,7 +441,7 @@ struct FileFilter {
     const char *in_path, *out_path;
     const std::vector<std::shared_ptr<Chunk>> *retained;    // nullptr: stream the file again
     size_t chunk_bytes;
-    const IdSet *ids;
+    const ShardedIdSet *ids;
     bool extract, want_dropped;
     int n_workers;
     uint64_t n_in = 0, n_out = 0;
@@ -544,7 +573,66 @@ bool write_id_table(const char *path, const std::string &body)
     return (fclose(f) == 0) && ok;
 }
 
-// the device side of pass 1: one context, one stream, buffers that grow with the largest chunk seen
+// a batch's place in HBM; filled by a parse worker (its own stream), consumed by the device thread
+struct DevBuf {
+    uint8_t *d_bases = nullptr, *d_flags = nullptr;
+    uint64_t *d_off = nullptr;
+    size_t cap_bases = 0, cap_reads = 0;
+    void release()
+    {
+        if (d_bases) hipFree(d_bases);
+        if (d_flags) hipFree(d_flags);
+        if (d_off) hipFree(d_off);
+        d_bases = d_flags = nullptr; d_off = nullptr; cap_bases = cap_reads = 0;
+    }
+    // H2D from pageable memory is staged by the calling thread: done by the parse workers, it scales with them
+    sh_status upload(Chunk &c, hipStream_t s)
+    {
+        const uint64_t n = c.recs.size(), nb = c.offsets[n];
+        if (nb + 64 > cap_bases) { if (d_bases) hipFree(d_bases); d_bases = nullptr; cap_bases = nb + nb / 8 + 64; SH_HIP(hipMalloc(&d_bases, cap_bases)); }
+        if (n + 1 > cap_reads) {
+            if (d_off) hipFree(d_off);
+            if (d_flags) hipFree(d_flags);
+            d_off = nullptr; d_flags = nullptr;
+            cap_reads = n + n / 8 + 1;
+            SH_HIP(hipMalloc(&d_off, cap_reads * 8));
+            SH_HIP(hipMalloc(&d_flags, cap_reads));
+        }
+        if (nb) SH_HIP(hipMemcpyAsync(d_bases, c.bases.data(), nb, hipMemcpyHostToDevice, s));
+        SH_HIP(hipMemcpyAsync(d_off, c.offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+        SH_HIP(hipStreamSynchronize(s));
+        c.n_bases = nb;
+        c.max_len = 0;
+        for (const Rec &r : c.recs) c.max_len = std::max(c.max_len, r.seq_len);
+        std::vector<uint8_t>().swap(c.bases);
+        std::vector<uint64_t>().swap(c.offsets);
+        return SH_OK;
+    }
+};
+
+class DevBufPool {
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<DevBuf *> free_;
+    std::vector<std::unique_ptr<DevBuf>> all_;
+    bool abort_ = false;
+public:
+    explicit DevBufPool(size_t n) { for (size_t i = 0; i < n; ++i) { all_.emplace_back(new DevBuf); free_.push_back(all_.back().get()); } }
+    ~DevBufPool() { for (auto &b : all_) b->release(); }
+    DevBuf *take()
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return abort_ || !free_.empty(); });
+        if (abort_) return nullptr;
+        DevBuf *b = free_.back();
+        free_.pop_back();
+        return b;
+    }
+    void give(DevBuf *b) { std::lock_guard<std::mutex> lk(mu_); free_.push_back(b); cv_.notify_one(); }
+    void stop() { std::lock_guard<std::mutex> lk(mu_); abort_ = true; cv_.notify_all(); }
+};
+
+// the device thread's side of pass 1: one context (minimap2's thread buffer), one stream; kernels and the flags' way back
 struct DeviceSide {
     const sh_index *idx;
     sh_opts opts;
@@ -552,48 +640,28 @@ struct DeviceSide {
     uint64_t ctx_reads = 0, ctx_bases = 0;
     uint32_t ctx_len = 0;
     hipStream_t s = nullptr;
-    uint8_t *d_bases = nullptr, *d_flags = nullptr;
-    uint64_t *d_off = nullptr;
-    size_t cap_bases = 0, cap_reads = 0;
-    std::vector<uint8_t> flags;
 
     ~DeviceSide()
     {
         if (ctx) sh_ctx_destroy(ctx);
-        if (d_bases) hipFree(d_bases);
-        if (d_flags) hipFree(d_flags);
-        if (d_off) hipFree(d_off);
         if (s) hipStreamDestroy(s);
     }
-    sh_status classify(const Chunk &c)
+    sh_status classify(Chunk &c)
     {
-        const uint64_t n = c.recs.size(), nb = c.offsets[n];
-        uint32_t max_len = 0;
-        for (const Rec &r : c.recs) max_len = std::max(max_len, r.seq_len);
-        if (!s) SH_HIP(hipStreamCreate(&s));
-        if (!ctx || n > ctx_reads || nb > ctx_bases || max_len > ctx_len) {
+        const uint64_t n = c.recs.size(), nb = c.n_bases;
+        if (!s) SH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        if (!ctx || n > ctx_reads || nb > ctx_bases || c.max_len > ctx_len) {
             if (ctx) { sh_ctx_destroy(ctx); ctx = nullptr; }
             ctx_reads = std::max<uint64_t>(ctx_reads, n + n / 4 + 1024);
             ctx_bases = std::max<uint64_t>(ctx_bases, nb + nb / 4 + 4096);
-            ctx_len = std::max<uint32_t>(ctx_len, max_len <= 1024 ? std::max<uint32_t>(max_len, 256) : (uint32_t)std::min<uint64_t>((uint64_t)max_len * 5 / 4, UINT32_MAX));
+            ctx_len = std::max<uint32_t>(ctx_len, c.max_len <= 1024 ? std::max<uint32_t>(c.max_len, 256) : (uint32_t)std::min<uint64_t>((uint64_t)c.max_len * 5 / 4, UINT32_MAX));
             sh_status st = sh_ctx_create(idx, &opts, ctx_reads, ctx_bases, ctx_len, &ctx);
             if (st != SH_OK) return st;
         }
-        if (nb + 64 > cap_bases) { if (d_bases) hipFree(d_bases); d_bases = nullptr; cap_bases = ctx_bases + 64; SH_HIP(hipMalloc(&d_bases, cap_bases)); }
-        if (n + 1 > cap_reads) {
-            if (d_off) hipFree(d_off);
-            if (d_flags) hipFree(d_flags);
-            d_off = nullptr; d_flags = nullptr;
-            cap_reads = ctx_reads + 1;
-            SH_HIP(hipMalloc(&d_off, cap_reads * 8));
-            SH_HIP(hipMalloc(&d_flags, cap_reads));
-        }
-        flags.resize(n);
-        if (nb) SH_HIP(hipMemcpyAsync(d_bases, c.bases.data(), nb, hipMemcpyHostToDevice, s));
-        SH_HIP(hipMemcpyAsync(d_off, c.offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
-        sh_status st = sh_classify_device(ctx, d_bases, d_off, n, nb, d_flags, nullptr, s, nullptr);
+        c.flags.resize(n);
+        sh_status st = sh_classify_device(ctx, c.dev->d_bases, c.dev->d_off, n, nb, c.dev->d_flags, nullptr, s, nullptr);
         if (st != SH_OK) return st;
-        SH_HIP(hipMemcpyAsync(flags.data(), d_flags, n, hipMemcpyDeviceToHost, s));
+        SH_HIP(hipMemcpyAsync(c.flags.data(), c.dev->d_flags, n, hipMemcpyDeviceToHost, s));
         SH_HIP(hipStreamSynchronize(s));
         return SH_OK;
     }
@@ -640,19 +708,24 @@ struct Pass1 {
     size_t chunk_bytes, budget;
     int threads;
     std::vector<std::shared_ptr<Chunk>> *kept;      // [2]
-    IdSet *depleted;
+    ShardedIdSet *depleted;
     double classify_ms = 0;
     std::atomic<bool> retain{true};
     std::atomic<size_t> kept_bytes{0};
+    std::atomic<uint64_t> us_read{0}, us_rpush{0}, us_parse{0}, us_ppush{0}, us_dev_wait{0}, us_ids{0}, us_h2d{0};     // SCRUBBY_HIP_DBG_HOST=1
     std::mutex mu;                                  // errors + the kept vectors
     sh_status err_st = SH_OK;
     std::string err_msg;
-    ChunkQueue rawq, devq;
+    ChunkQueue rawq, devq, foldq;
+    DevBufPool pool{6};
+
+    static std::chrono::steady_clock::time_point tick() { return std::chrono::steady_clock::now(); }
+    static uint64_t us(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); }
 
     void set_err(sh_status s, const std::string &m)
     {
         { std::lock_guard<std::mutex> lk(mu); if (err_st == SH_OK) { err_st = s; err_msg = m; } }
-        rawq.stop(); devq.stop();
+        rawq.stop(); devq.stop(); foldq.stop(); pool.stop();
     }
     bool has_err() { std::lock_guard<std::mutex> lk(mu); return err_st != SH_OK; }
 
@@ -663,19 +736,27 @@ struct Pass1 {
         else
             for (size_t k = 0;; ++k) {
                 auto ch = std::make_shared<Chunk>();
+                const auto t0 = tick();
                 const int r = rd.next(*ch);
+                const auto t1 = tick();
+                us_read += us(t0, t1);
                 if (r < 0) { set_err(SH_ERR_IO, std::string(c->input[i]) + ": " + rd.error); break; }
                 if (r == 0) break;
                 ch->file = i; ch->seq_no = k;
-                if (!rawq.push(ch)) break;
+                const bool pushed = rawq.push(ch);
+                us_rpush += us(t1, tick());
+                if (!pushed) break;
             }
         rawq.producer_done();
     }
 
     void parser(bool parallel)
     {
+        hipStream_t hs = nullptr;
+        if (hipSetDevice(idx->device) != hipSuccess || hipStreamCreateWithFlags(&hs, hipStreamNonBlocking) != hipSuccess) set_err(SH_ERR_HIP, "parse worker: no HIP stream");
         while (auto ch = rawq.pop()) {
             if (has_err()) continue;
+            const auto t0 = tick();
             if (!ch->parsed) {
                 size_t consumed = 0;
                 std::string e;
@@ -700,9 +781,44 @@ struct Pass1 {
                     v[ch->seq_no] = ch;
                 }
             }
-            if (!ch->recs.empty()) devq.push(ch);
+            const auto t1 = tick();
+            us_parse += us(t0, t1);
+            if (!ch->recs.empty()) {
+                DevBuf *b = pool.take();
+                if (!b) continue;
+                const auto t2 = tick();
+                ch->dev = b;
+                if (b->upload(*ch, hs) != SH_OK) { set_err(SH_ERR_HIP, sh_last_error()); continue; }
+                us_h2d += us(t2, tick());
+                devq.push(ch);
+            }
+            us_ppush += us(t1, tick());
         }
+        if (hs) hipStreamDestroy(hs);
         devq.producer_done();
+    }
+
+    // cleaner.rs:564-570: ids of the mapped records into the set; an empty read's Err aborts the run (:552,566)
+    void folder()
+    {
+        while (auto ch = foldq.pop()) {
+            if (has_err()) continue;
+            const auto t0 = tick();
+            const size_t n = ch->recs.size();
+            for (size_t r = 0; r < n; ++r) {
+                const uint8_t f = ch->flags[r];
+                if (f == 1) {
+                    const char *id; uint32_t il;
+                    id_of(ch->data + ch->recs[r].hdr, ch->recs[r].hdr_len, &id, &il);
+                    depleted->insert(id, il);
+                } else if (f == 2) {
+                    set_err(SH_ERR_EMPTY_READ, "Sequence is empty (read " + std::string(ch->data + ch->recs[r].hdr, ch->recs[r].hdr_len) + ")");
+                    break;
+                }
+            }
+            std::vector<uint8_t>().swap(ch->flags);
+            us_ids += us(t0, tick());
+        }
     }
 
     sh_status run(bool parallel)
@@ -710,36 +826,38 @@ struct Pass1 {
         retain.store(budget > 0);
         const int n_parse = std::max(1, threads);
         rawq.cap = (size_t)n_parse + 2; rawq.producers = (int)c->n_files;
-        devq.cap = 4; devq.producers = n_parse;
-        std::vector<std::thread> pool;
-        for (uint32_t i = 0; i < c->n_files; ++i) pool.emplace_back([this, i, parallel] { reader(i, parallel); });
-        for (int t = 0; t < n_parse; ++t) pool.emplace_back([this, parallel] { parser(parallel); });
+        const int n_fold = std::max(1, std::min(4, threads / 2));
+        devq.cap = 8; devq.producers = n_parse;          // the device-buffer pool is what bounds the chunks in flight
+        foldq.cap = 8; foldq.producers = 1;
+        std::vector<std::thread> thr;
+        for (uint32_t i = 0; i < c->n_files; ++i) thr.emplace_back([this, i, parallel] { reader(i, parallel); });
+        for (int t = 0; t < n_parse; ++t) thr.emplace_back([this, parallel] { parser(parallel); });
+        for (int t = 0; t < n_fold; ++t) thr.emplace_back([this] { folder(); });
         {
             DeviceSide dev{idx, opts};
             if (hipSetDevice(idx->device) != hipSuccess) set_err(SH_ERR_HIP, "hipSetDevice failed");
-            while (auto ch = devq.pop()) {
-                if (has_err()) continue;      // drain
-                const auto a = std::chrono::steady_clock::now();
-                const sh_status st = dev.classify(*ch);
-                classify_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
-                if (st != SH_OK) { set_err(st, sh_last_error()); continue; }
-                const size_t n = ch->recs.size();
-                for (size_t r = 0; r < n; ++r) {
-                    const uint8_t f = dev.flags[r];
-                    if (f == 1) {
-                        const char *id; uint32_t il;
-                        id_of(ch->data + ch->recs[r].hdr, ch->recs[r].hdr_len, &id, &il);
-                        depleted->insert(id, il);
-                    } else if (f == 2) {        // minimap2-rs: Err("Sequence is empty") aborts the run (cleaner.rs:552,566)
-                        set_err(SH_ERR_EMPTY_READ, "Sequence is empty (read " + std::string(ch->data + ch->recs[r].hdr, ch->recs[r].hdr_len) + ")");
-                        break;
-                    }
+            for (;;) {
+                const auto w0 = tick();
+                auto ch = devq.pop();
+                us_dev_wait += us(w0, tick());
+                if (!ch) break;
+                if (!has_err()) {
+                    const auto a = tick();
+                    const sh_status st = dev.classify(*ch);
+                    classify_ms += us(a, tick()) / 1e3;
+                    if (st != SH_OK) set_err(st, sh_last_error());
                 }
-                std::vector<uint8_t>().swap(ch->bases);
-                std::vector<uint64_t>().swap(ch->offsets);
+                pool.give(ch->dev);
+                ch->dev = nullptr;
+                if (!has_err()) foldq.push(ch);
             }
+            foldq.producer_done();
         }
-        for (auto &t : pool) t.join();
+        for (auto &t : thr) t.join();
+        if (const char *e = getenv("SCRUBBY_HIP_DBG_HOST")) if (*e == '1')
+            fprintf(stderr, "[scrubby-hip] pass 1 (%s): readers read %.0f ms, blocked on push %.0f ms | %d parse workers: parse %.0f ms, H2D %.0f ms, blocked %.0f ms | device thread: "
+                    "waiting %.0f ms, classify %.0f ms | %d fold threads: id set %.0f ms\n", parallel ? "cut + parallel parse" : "sequential parse", us_read / 1e3, us_rpush / 1e3, n_parse,
+                    us_parse / 1e3, us_h2d / 1e3, (us_ppush - us_h2d) / 1e3, us_dev_wait / 1e3, classify_ms, n_fold, us_ids / 1e3);
         if (err_st != SH_OK) { if (err_st != SH_RETRY_SEQUENTIAL) sh_set_error("%s", err_msg.c_str()); return err_st; }
         return SH_OK;
     }
@@ -752,7 +870,7 @@ extern "C" sh_status sh_host_filter_fastx_stream(const char *in, const char *out
                                                  uint64_t chunk_bytes, int32_t threads, int32_t retain, uint64_t *n_in, uint64_t *n_out)
 {
     SH_CHECK(in && out && (ids || n_ids == 0), SH_ERR_BAD_ARG, "sh_host_filter_fastx_stream: null argument");
-    IdSet set;
+    ShardedIdSet set;
     for (uint64_t i = 0; i < n_ids; ++i) set.insert(ids[i], (uint32_t)strlen(ids[i]));
     std::vector<std::shared_ptr<Chunk>> kept;
     if (retain) {       // 1: the sequential reader; 2: cut at guessed boundaries, then parse each chunk on its own (pass 1's parallel form)
@@ -815,7 +933,7 @@ extern "C" sh_status sh_reads_run(const sh_reads_config *c, sh_reads_result *res
 
     // ---- pass 1: read -> parse -> classify, fold flagged ids ----
     std::vector<std::shared_ptr<Chunk>> kept[2];
-    IdSet depleted;
+    ShardedIdSet depleted;
     double classify_ms = 0;
     bool retained = false;
     {
@@ -823,7 +941,7 @@ extern "C" sh_status sh_reads_run(const sh_reads_config *c, sh_reads_result *res
         st = p1.run(true);
         if (st == SH_RETRY_SEQUENTIAL) {     // a chunk cut at a guessed boundary did not parse: let the sequential reader decide
             kept[0].clear(); kept[1].clear();
-            depleted = IdSet();
+            depleted.clear();
             Pass1 p1s{c, idx, opts, chunk_bytes, budget, threads, kept, &depleted};
             st = p1s.run(false);
             classify_ms = p1s.classify_ms; retained = p1s.retain.load();

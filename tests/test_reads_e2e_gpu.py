@@ -148,7 +148,7 @@ def test_streaming_pipeline_falls_back_when_a_cut_is_wrong(dataset, tmp_path, mo
     from scrubby_amd import lib as S
     d, fa, r1, r2, ids, n_pairs = dataset
     odd = tmp_path / "odd.fastq"
-    odd.write_text("".join(f"@r{i} x\n@CGTACGTACGTACGTACGTACGTACGTACG\n+\n+{'I' * 31}\n" for i in range(30000)))
+    odd.write_text("".join(f"@r{i} x\n@CGTACGTACGTACGTACGTACGTACGTACG\n+\n+{'I' * 30}\n" for i in range(30000)))
     monkeypatch.setenv("SCRUBBY_HIP_CHUNK_MB", "1")
     o_new, o_old = tmp_path / "new.fastq", tmp_path / "old.fastq"
     a = S.reads_run([str(odd)], [str(o_new)], fa, preset="sr", json=str(tmp_path / "a.json"))
