@@ -29,6 +29,13 @@ struct ChainParams {
     // (true for every preset) that chain is always accepted, so the DP can stop at the first f >= flag_stop = min_sc and
     // no backtrack is needed; if no anchor gets there, there is no candidate at all.
     int32_t flag_stop;
+    // Flag-only pair test (host-computed, pair_dq_max = 0: off; see pair_decides in sh_classify.hip): two anchors of one
+    // strand / contig on one diagonal, pair_dq_min <= dq = dr <= pair_dq_max apart, decide the read when all selected seeds
+    // have distinct keys.  A reference position holds at most one minimizer, so at most dq - 1 <= max_skip - 2 anchors
+    // sort between the two: mg_lchain_dp's look-back from the later one cannot break (n_skip), run out (max_iter) or leave the
+    // window before it scores the earlier one, with sc = min(k, dq) and no penalty (dd = 0, pen_skip = 0):
+    // f >= k + min(k, dq) >= min_sc = flag_stop, which decides the cluster (above).
+    int32_t pair_dq_min, pair_dq_max, pair_min_anchors;
 };
 
 // ---- seeds: one 16-B record per query minimizer found in the index ---------------------------

@@ -60,7 +60,7 @@ struct Counters {
     uint32_t n_sort[N_SORT_CLS], n_giant_tiles, n_giant_rounds;
     uint32_t n_long_segs, pad2;
     uint32_t n_cl[4], cl_ticket, pad3;      // global queue of big clusters (k_cluster_dp), by size class
-    uint32_t n_leg_reason[4];     // why reads left the long-read front end: 0 room/segments, 1 thinning screen, 2 anchors beyond the giant path, 3 unused
+    uint32_t n_leg_reason[4];     // why reads left the long-read front end: 0 room/segments, 1 thinning screen, 2 anchors beyond the giant path; 3 = reads decided by the pair test (dbg & 16)
     unsigned long long arena_cursor, anchor_cursor;
     unsigned long long cl_tot[4], cl_anchor_tot[4], cl_dbg[4];
     unsigned long long sort_tot[N_SORT_CLS + 1], sort_anchor_tot[N_SORT_CLS + 1];    // SCRUBBY_HIP_DBG & 16: reads / anchors per sort class (4 = chained inside k_expand)     // statistics of k_cluster_dp by size class (whole chunk)
@@ -805,6 +805,61 @@ struct K3Args {
 };
 
 
+// Flag-only pair test (ChainParams::pair_dq_*).  One wave, the read's seeds one per lane (my_n = anchors the seed would
+// contribute, 0 = filtered).  Picks the pair of selected seeds pair_dq_min..pair_dq_max apart in the query whose shorter
+// occurrence list is shortest, walks that list 64 occurrences at a time and looks each one's co-diagonal partner up in the
+// other seed's (ascending) list by binary search.  true: the read has a mapping.  false: nothing is known.
+#define PAIR_MAX_ITER 2048u
+__device__ inline bool pair_decides(const uint4 rec, uint32_t my_n, uint32_t n_seed, uint32_t lane, const uint64_t *__restrict__ pos, const ChainParams &P)
+{
+    const uint32_t qp = rec.w >> 1;
+    const bool sel = my_n > 0;
+    bool dup = false;
+    uint32_t p_occ = UINT32_MAX, p_u = 0;
+    for (uint32_t u = 0; u < n_seed; ++u) {
+        const uint32_t ou = rdlane(my_n, u);
+        if (ou == 0) continue;
+        const uint32_t xu = rdlane(rec.x, u), yu = rdlane(rec.y, u), qu = rdlane(qp, u);
+        dup |= sel && u != lane && xu == rec.x && yu == rec.y;
+        const int32_t d = (int32_t)qu - (int32_t)qp;
+        if (sel && d >= P.pair_dq_min && d <= P.pair_dq_max && ou < p_occ) { p_occ = ou; p_u = u; }
+    }
+    if (__ballot(dup) != 0) return false;
+    const uint32_t cost = p_occ == UINT32_MAX ? UINT32_MAX : (my_n < p_occ ? my_n : p_occ);
+    unsigned long long key = (unsigned long long)cost << 32 | lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = (unsigned long long)__shfl_xor((long long)key, o); key = other < key ? other : key; }
+    if ((uint32_t)(key >> 32) > PAIR_MAX_ITER) return false;
+    const uint32_t lf = (uint32_t)key & 63u, lg = rdlane(p_u, lf);          // F: earlier in the query, G: later
+    const uint32_t nF = rdlane(my_n, lf), nG = rdlane(my_n, lg);
+    const uint32_t D = (rdlane(rec.w, lg) >> 1) - (rdlane(rec.w, lf) >> 1);
+    const bool iter_f = nF <= nG;
+    const uint32_t li = iter_f ? lf : lg, ls = iter_f ? lg : lf;
+    const uint32_t nI = iter_f ? nF : nG, nS = iter_f ? nG : nF;
+    const uint64_t w1I = (uint64_t)rdlane(rec.y, li) << 32 | rdlane(rec.x, li), w1S = (uint64_t)rdlane(rec.y, ls) << 32 | rdlane(rec.x, ls);
+    const uint32_t qsI = rdlane(rec.w, li) & 1u, qsS = rdlane(rec.w, ls) & 1u;
+    const int64_t delta = iter_f ? (int64_t)D : -(int64_t)D;                  // qpos_S - qpos_I
+    const uint64_t *__restrict__ pi = pos + (w1I >> SH_SLOT_NBITS), *__restrict__ ps = pos + (w1S >> SH_SLOT_NBITS);
+    for (uint32_t base = 0; base < nI; base += 64) {
+        const uint32_t idx = base + lane;
+        const bool live = idx < nI;
+        const uint64_t oI = nI == 1 ? w1I : pi[live ? idx : nI - 1];
+        const bool fw = (uint32_t)(oI & 1u) == qsI;                            // make_anchor: same strand -> forward anchor
+        const int64_t rS = (int64_t)((uint32_t)oI >> 1) + (fw ? delta : -delta);
+        const bool ok = live && rS >= 0 && rS < (1ll << 31);
+        const uint64_t target = (oI & 0xffffffff00000000ULL) | (uint64_t)rS << 1 | (uint64_t)(fw ? qsS : qsS ^ 1u);
+        bool found;
+        if (nS == 1) found = ok && target == w1S;
+        else {
+            uint32_t lo = 0, len = nS;
+            while (len > 1) { const uint32_t half = len >> 1; const uint64_t v = ps[lo + half]; lo = v <= target ? lo + half : lo; len -= half; }
+            found = ok && ps[lo] == target;
+        }
+        if (__ballot(found) != 0) return true;
+    }
+    return false;
+}
+
 // one wave per read: seeds -> filter -> anchors (arena) -> [<= 64: sort + clusters]
 // Seeds are handled 64 at a time, one per lane.  mm_seed_select's streak logic needs a read's seeds in one
 // tile; with more seeds it is only needed when some streak could keep a seed (max_high_occ > 0), which for
@@ -965,6 +1020,13 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
                 uint32_t i = atomicAdd(&a.ctr->n_resketch, 1u);
                 a.resketch_list[i] = r;
             }
+            continue;
+        }
+        if (!LONG && a.flag_only && P.pair_dq_max > 0 && n_st == 1 && n_a > (uint32_t)P.pair_min_anchors && pair_decides(rec0, my_n0, n_seed, lane, a.positions, P)) {
+            // decided without a single anchor: sh_stats.n_anchors still counts what the occurrence filter admitted
+            if (lane == 0) { BigMeta m{r, n_a, rep_len, 0u}; a.B.meta[w] = m; a.B.acc_nu[w] = 1; a.B.acc_best[w] = P.min_sc; }
+            anchors_wave += n_a;
+            if ((a.dbg & 16) && lane == 0) atomicAdd(&a.ctr->n_leg_reason[3], 1u);
             continue;
         }
         const bool in_lds = n_a <= 64;     // short anchor lists never leave the CU
@@ -1641,6 +1703,13 @@ static void fill_chain_params(const sh_opts &o, int32_t mid_occ, ChainParams &P)
     P.q_occ_frac = o.q_occ_frac;
     const bool early_ok = o.k > 0 && (o.min_chain_score + o.k - 1) / o.k >= o.min_cnt && o.bw >= o.min_chain_score && o.bw / o.k + 1 >= o.min_cnt;
     P.flag_stop = early_ok && !getenv("SCRUBBY_HIP_NO_FLAG_STOP") ? o.min_chain_score : INT32_MAX;
+    // pair test (ChainParams::pair_dq_*): needs flag_stop, two anchors enough (min_cnt, 2k >= min_sc), no skip penalty
+    const bool pair_ok = P.flag_stop != INT32_MAX && o.chain_skip_scale == 0.0f && o.min_cnt <= 2 && 2 * o.k >= o.min_chain_score && !getenv("SCRUBBY_HIP_NO_PAIR");
+    const int32_t dmin = std::max(1, o.min_chain_score - o.k);
+    const int32_t dmax = std::min(std::min(std::min(24, o.max_chain_skip - 1), std::min(o.max_chain_iter - 1, o.bw)), o.max_gap);
+    P.pair_dq_min = pair_ok && dmin <= dmax ? dmin : 0;
+    P.pair_dq_max = pair_ok && dmin <= dmax ? dmax : 0;
+    P.pair_min_anchors = getenv("SCRUBBY_HIP_PAIR_MIN") ? atoi(getenv("SCRUBBY_HIP_PAIR_MIN")) : 64;
 }
 
 static bool w_supported(int w) { return w == 5 || w == 10 || w == 11 || w == 19; }
@@ -1917,7 +1986,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         SH_HIP(hipStreamSynchronize(s));
         SH_HIP(hipGetLastError());
         if (first) { snap = *c->h_ctr; first = false; }
-        if (k.dbg & 16) fprintf(stderr, "[dbg] iter %d resketch %u reasons %u %u %u segs %u big %u/%u defer %u/%u\n", iter, c->h_ctr->n_resketch, c->h_ctr->n_leg_reason[0], c->h_ctr->n_leg_reason[1], c->h_ctr->n_leg_reason[2], c->h_ctr->n_long_segs, c->h_ctr->n_big[0], c->h_ctr->n_big[1], c->h_ctr->n_big_defer[0], c->h_ctr->n_big_defer[1]);
+        if (k.dbg & 16) fprintf(stderr, "[dbg] iter %d resketch %u reasons %u %u %u pair-decided %u segs %u big %u/%u defer %u/%u\n", iter, c->h_ctr->n_resketch, c->h_ctr->n_leg_reason[0], c->h_ctr->n_leg_reason[1], c->h_ctr->n_leg_reason[2], c->h_ctr->n_leg_reason[3], c->h_ctr->n_long_segs, c->h_ctr->n_big[0], c->h_ctr->n_big[1], c->h_ctr->n_big_defer[0], c->h_ctr->n_big_defer[1]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] clusters chained by k_cluster_dp by class: %llu %llu %llu %llu, their anchors %llu %llu %llu %llu\n", c->h_ctr->cl_tot[0], c->h_ctr->cl_tot[1], c->h_ctr->cl_tot[2], c->h_ctr->cl_tot[3], c->h_ctr->cl_anchor_tot[0], c->h_ctr->cl_anchor_tot[1], c->h_ctr->cl_anchor_tot[2], c->h_ctr->cl_anchor_tot[3]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] reads (anchors) by sort class: <=64 %llu (%llu), <=256 %llu (%llu), <=512 %llu (%llu), <=1024 %llu (%llu), <=2048 %llu (%llu), <=4096 %llu (%llu), giant %llu (%llu)\n", c->h_ctr->sort_tot[6], c->h_ctr->sort_anchor_tot[6], c->h_ctr->sort_tot[0], c->h_ctr->sort_anchor_tot[0], c->h_ctr->sort_tot[1], c->h_ctr->sort_anchor_tot[1], c->h_ctr->sort_tot[2], c->h_ctr->sort_anchor_tot[2], c->h_ctr->sort_tot[3], c->h_ctr->sort_anchor_tot[3], c->h_ctr->sort_tot[4], c->h_ctr->sort_anchor_tot[4], c->h_ctr->sort_tot[5], c->h_ctr->sort_anchor_tot[5]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] ring DP: chunks in window %llu, beyond %llu, far rescans %llu\n", c->h_ctr->cl_dbg[0], c->h_ctr->cl_dbg[1], c->h_ctr->cl_dbg[2]);
