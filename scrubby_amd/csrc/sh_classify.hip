@@ -809,7 +809,7 @@ struct K3Args {
 // contribute, 0 = filtered).  Picks the pair of selected seeds pair_dq_min..pair_dq_max apart in the query whose shorter
 // occurrence list is shortest, walks that list 64 occurrences at a time and looks each one's co-diagonal partner up in the
 // other seed's (ascending) list by binary search.  true: the read has a mapping.  false: nothing is known.
-#define PAIR_MAX_ITER 2048u
+#define PAIR_MAX_COST 512u        // load rounds a pair may cost before the full path is the better deal
 __device__ inline bool pair_decides(const uint4 rec, uint32_t my_n, uint32_t n_seed, uint32_t lane, const uint64_t *__restrict__ pos, const ChainParams &P)
 {
     const uint32_t qp = rec.w >> 1;
@@ -825,11 +825,16 @@ __device__ inline bool pair_decides(const uint4 rec, uint32_t my_n, uint32_t n_s
         if (sel && d >= P.pair_dq_min && d <= P.pair_dq_max && ou < p_occ) { p_occ = ou; p_u = u; }
     }
     if (__ballot(dup) != 0) return false;
-    const uint32_t cost = p_occ == UINT32_MAX ? UINT32_MAX : (my_n < p_occ ? my_n : p_occ);
+    // cost of a pair ~ dependent loads: the shorter list is walked (one load round per 64), each step a binary search of the longer
+    uint32_t cost = UINT32_MAX;
+    if (p_occ != UINT32_MAX) {
+        const uint32_t mn = my_n < p_occ ? my_n : p_occ, mx = my_n < p_occ ? p_occ : my_n;
+        cost = (mn > 1 ? (mn + 63) / 64 : 0) + ((mn + 63) / 64) * (mx > 1 ? 32 - __clz(mx) : 0);
+    }
     unsigned long long key = (unsigned long long)cost << 32 | lane;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = (unsigned long long)__shfl_xor((long long)key, o); key = other < key ? other : key; }
-    if ((uint32_t)(key >> 32) > PAIR_MAX_ITER) return false;
+    if ((uint32_t)(key >> 32) > PAIR_MAX_COST) return false;
     const uint32_t lf = (uint32_t)key & 63u, lg = rdlane(p_u, lf);          // F: earlier in the query, G: later
     const uint32_t nF = rdlane(my_n, lf), nG = rdlane(my_n, lg);
     const uint32_t D = (rdlane(rec.w, lg) >> 1) - (rdlane(rec.w, lf) >> 1);
@@ -1709,7 +1714,7 @@ static void fill_chain_params(const sh_opts &o, int32_t mid_occ, ChainParams &P)
     const int32_t dmax = std::min(std::min(std::min(24, o.max_chain_skip - 1), std::min(o.max_chain_iter - 1, o.bw)), o.max_gap);
     P.pair_dq_min = pair_ok && dmin <= dmax ? dmin : 0;
     P.pair_dq_max = pair_ok && dmin <= dmax ? dmax : 0;
-    P.pair_min_anchors = getenv("SCRUBBY_HIP_PAIR_MIN") ? atoi(getenv("SCRUBBY_HIP_PAIR_MIN")) : 64;
+    P.pair_min_anchors = getenv("SCRUBBY_HIP_PAIR_MIN") ? atoi(getenv("SCRUBBY_HIP_PAIR_MIN")) : 32;
 }
 
 static bool w_supported(int w) { return w == 5 || w == 10 || w == 11 || w == 19; }
