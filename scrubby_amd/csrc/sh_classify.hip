@@ -40,8 +40,7 @@
 #include "sh_chain.h"
 #include <algorithm>
 
-#define K1_LIST_CAP 16          // queued minimizers per lane between two probe phases (8 KiB of LDS per wave)
-#define K1_FLUSH_AT 8
+#define K1_LIST_CAP 8           // ring of queued minimizers per lane (power of two; 4 KiB of LDS per wave); 4 are drained per W-step block
 #define K2_CAP 32               // anchors per read chained in LDS
 #define DP_SMALL_CAP 32         // anchors per cluster chained in LDS
 #define SORT_LDS_A 512          // reads with up to this many anchors are sorted and chained in 12 KiB of LDS
@@ -132,28 +131,27 @@ struct K1Args {
 // Slow path of K1: this lane's minimizer queue is full in the middle of a W-step block (tie-heavy,
 // low-complexity reads).  Probe the lane's queued entries now, in order, so that seed records stay in
 // query order; rare, divergent, deliberately not inlined.
-__device__ __noinline__ void k1_lane_flush(const uint64_t *list, uint32_t lane, uint32_t cnt, const uint4 *slots, uint32_t lg_slots,
-                                           uint4 *rec, uint32_t seed_cap, uint32_t *n_seed_io, uint32_t *overflow_io,
-                                           uint32_t *sum_occ_io, uint32_t *n_high_io, uint32_t mid_occ)
+__device__ __noinline__ uint4 k1_lane_flush(const uint64_t *list, uint32_t lane, uint32_t head, uint32_t tail, const uint4 *slots, uint32_t lg_slots,
+                                            uint4 *rec, uint32_t seed_cap, uint4 acc /* n_seed, overflow, sum_occ, n_high: by value, so the caller's stay in registers */,
+                                            uint32_t mid_occ)
 {
     const uint64_t slot_mask = (1ULL << lg_slots) - 1;
-    uint32_t n_seed = *n_seed_io;
-    for (uint32_t e = 0; e < cnt; ++e) {
-        uint64_t m = list[e * 64 + lane];
+    for (uint32_t e = head; e != tail; ++e) {
+        uint64_t m = list[(e & (K1_LIST_CAP - 1)) * 64 + lane];
         uint64_t key = m >> 18, idx = sh_slot_home(key, lg_slots);
         uint4 sl = slots[idx];
         uint64_t w0 = (uint64_t)sl.y << 32 | sl.x;
         while (w0 != SH_SLOT_EMPTY && (w0 & SH_SLOT_KEYMASK) != key) { idx = (idx + 1) & slot_mask; sl = slots[idx]; w0 = (uint64_t)sl.y << 32 | sl.x; }
         if (w0 != SH_SLOT_EMPTY) {
             uint32_t occ = (w0 & SH_SLOT_MULTI) ? (sl.z & (uint32_t)SH_SLOT_NMASK) : 1u;
-            if (n_seed < seed_cap) rec[n_seed] = make_uint4(sl.z, sl.w, occ, (uint32_t)m & 0x3ffffu);
-            else *overflow_io = 1;
-            ++n_seed;
-            *sum_occ_io = *sum_occ_io + occ < *sum_occ_io ? 0xffffffffu : *sum_occ_io + occ;
-            *n_high_io += occ > mid_occ;
+            if (acc.x < seed_cap) rec[acc.x] = make_uint4(sl.z, sl.w, occ, (uint32_t)m & 0x3ffffu);
+            else acc.y = 1;
+            ++acc.x;
+            acc.z = acc.z + occ < acc.z ? 0xffffffffu : acc.z + occ;
+            acc.w += occ > mid_occ;
         }
     }
-    *n_seed_io = n_seed;
+    return acc;
 }
 
 template <int W>
@@ -226,18 +224,67 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, o));
 
-    uint32_t cnt = 0, n_mini = 0, n_seed = 0, overflow = 0, sum_occ = 0, n_high = 0;
+    // The minimizer queue is a ring of K1_LIST_CAP entries per lane in LDS: [qh, qt), of which the first `pend` have their
+    // home-slot gathers in flight (sl[]).  Every W-step block starts by issuing up to 4 gathers per lane for what earlier blocks
+    // queued and ends by consuming them, so a lane's HBM latency is covered by its own sketch arithmetic, not only by the
+    // other waves of the SIMD.  Seed records stay in query order: the ring is FIFO.
+    uint32_t qh = 0, qt = 0, pend = 0, n_mini = 0, n_seed = 0, overflow = 0, sum_occ = 0, n_high = 0;
     const uint64_t slot_mask = (1ULL << a.lg_slots) - 1;
     uint4 *rec = a.records + (size_t)(valid ? r : 0) * a.seed_cap;      // per-read contiguous seed records
     auto emit = [&](uint64_t x, uint32_t y) {
-        if (cnt >= K1_LIST_CAP) { k1_lane_flush(list, lane, cnt, a.slots, a.lg_slots, rec, a.seed_cap, &n_seed, &overflow, &sum_occ, &n_high, (uint32_t)a.mid_occ); cnt = 0; }
-        list[cnt * 64 + lane] = (x >> 8) << 18 | (uint64_t)y;
-        ++cnt; ++n_mini;
+        if (qt - qh >= K1_LIST_CAP) {      // tie-heavy read: the lane drains its whole ring now, in order; gathers in flight are dropped
+            const uint4 acc = k1_lane_flush(list, lane, qh, qt, a.slots, a.lg_slots, rec, a.seed_cap, make_uint4(n_seed, overflow, sum_occ, n_high), (uint32_t)a.mid_occ);
+            n_seed = acc.x; overflow = acc.y; sum_occ = acc.z; n_high = acc.w;
+            qh = qt; pend = 0;
+        }
+        list[(qt & (K1_LIST_CAP - 1)) * 64 + lane] = (x >> 8) << 18 | (uint64_t)y;
+        ++qt; ++n_mini;
+    };
+    auto consume = [&](const uint4 (&sl)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if ((uint32_t)u < pend) {
+                const uint64_t m = list[((qh + u) & (K1_LIST_CAP - 1)) * 64 + lane];
+                const uint64_t key = m >> 18;
+                uint4 v = sl[u];
+                uint64_t w0 = (uint64_t)v.y << 32 | v.x;
+                if (w0 != SH_SLOT_EMPTY && (w0 & SH_SLOT_KEYMASK) != key) {
+                    uint64_t idx = sh_slot_home(key, a.lg_slots);
+                    do { idx = (idx + 1) & slot_mask; v = a.slots[idx]; w0 = (uint64_t)v.y << 32 | v.x; } while (w0 != SH_SLOT_EMPTY && (w0 & SH_SLOT_KEYMASK) != key);
+                }
+                if (w0 != SH_SLOT_EMPTY) {
+                    const uint32_t occ = (w0 & SH_SLOT_MULTI) ? (v.z & (uint32_t)SH_SLOT_NMASK) : 1u;
+                    if (n_seed < a.seed_cap) rec[n_seed] = make_uint4(v.z, v.w, occ, (uint32_t)m & 0x3ffffu);
+                    else overflow = 1;
+                    ++n_seed;
+                    sum_occ = sum_occ + occ < sum_occ ? 0xffffffffu : sum_occ + occ;
+                    n_high += occ > (uint32_t)a.mid_occ;
+                }
+            }
+        }
+        qh += pend; pend = 0;
+    };
+    auto issue = [&](uint4 (&sl)[4]) {
+        // straight-line: every lane issues its 4 gathers back to back; a lane with fewer queued entries points the spare ones
+        // at slot 0 (one cached line for the whole device), so no exec-mask branch separates the loads
+        const uint32_t n = min(qt - qh, 4u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool on = (uint32_t)u < n;
+            const uint64_t m = list[((qh + (on ? (uint32_t)u : 0u)) & (K1_LIST_CAP - 1)) * 64 + lane];
+            const uint64_t idx = on ? sh_slot_home(m >> 18, a.lg_slots) : 0ull;
+            sl[u] = a.slots[idx];
+        }
+        pend = n;
     };
 
     uint32_t codes = 0, amb = 0;
     uint32_t i0 = 0;
     for (;;) {
+        // ---- C, first half: gathers for what the previous blocks queued; they fly during this block's sketch (issued and
+        // consumed inside one iteration, so no gather result is carried around the loop)
+        uint4 sl[4];
+        issue(sl);          // unconditional: no merge of old and new gather registers, so no wait lands right behind the loads
         if (i0 < maxlen) {
             // W steps with compile-time ring slots
             auto one = [&](auto Pc) {
@@ -264,43 +311,12 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
         }
         const bool last = i0 >= maxlen;
         if (last && valid && len > 0) st.finish(emit);
-        if (last || __ballot(cnt >= K1_FLUSH_AT) != 0) {
-            // ---- C: probe the index for every queued minimizer --------------------------------
-            const uint32_t c_here = cnt;
-            for (uint32_t e0 = 0; __ballot(e0 < c_here) != 0; e0 += 4) {
-                uint64_t key[4], idx[4]; uint32_t yq[4]; uint4 s[4]; bool act[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    act[u] = e0 + u < c_here;
-                    if (act[u]) {
-                        uint64_t m = list[(e0 + u) * 64 + lane];
-                        key[u] = m >> 18; yq[u] = (uint32_t)m & 0x3ffffu;
-                        idx[u] = sh_slot_home(key[u], a.lg_slots);
-                        s[u] = a.slots[idx[u]];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (!act[u]) continue;
-                    uint64_t w0 = (uint64_t)s[u].y << 32 | s[u].x;
-                    while (w0 != SH_SLOT_EMPTY && (w0 & SH_SLOT_KEYMASK) != key[u]) {
-                        idx[u] = (idx[u] + 1) & slot_mask;
-                        s[u] = a.slots[idx[u]];
-                        w0 = (uint64_t)s[u].y << 32 | s[u].x;
-                    }
-                    if (w0 != SH_SLOT_EMPTY) {
-                        uint32_t occ = (w0 & SH_SLOT_MULTI) ? (s[u].z & (uint32_t)SH_SLOT_NMASK) : 1u;
-                        if (n_seed < a.seed_cap) rec[n_seed] = make_uint4(s[u].z, s[u].w, occ, yq[u]);
-                        else overflow = 1;
-                        ++n_seed;
-                        sum_occ = sum_occ + occ < sum_occ ? 0xffffffffu : sum_occ + occ;
-                        n_high += occ > (uint32_t)a.mid_occ;
-                    }
-                }
-            }
-            cnt = 0;
+        // ---- C, second half ----
+        if (__ballot(pend != 0) != 0) consume(sl);
+        if (last) {
+            while (__ballot(qt != qh) != 0) { uint4 sl2[4]; issue(sl2); consume(sl2); }
+            break;
         }
-        if (last) break;
     }
 
     // ---- per-read result ------------------------------------------------------------------------
