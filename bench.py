@@ -226,7 +226,8 @@ def main():
             },
             "result": {"reads_removed_rank0": n_host, "n_no_seed": s0["n_no_seed"], "n_chain_small": s0["n_chain_small"],
                        "n_chain_large": s0["n_chain_large"], "probes": s0["n_minimizers"],
-                       "repeat_path_anchors": s0["n_anchors"], "repeat_path_clusters": s0["n_clusters"], "n_resketch": s0["n_resketch"]},
+                       "repeat_path_anchors": s0["n_anchors"], "repeat_path_clusters": s0["n_clusters"], "n_resketch": s0["n_resketch"],
+                       "pair_decided": s0["n_pair_decided"]},
             "index": {"n_keys": info["n_keys"], "n_minimizers": info["n_minimizers"], "n_slots": info["n_slots"],
                       "n_positions": info["n_positions"], "hbm_GB": round(info["hbm_bytes"] / 1e9, 2),
                       "build_s": round(t_idx, 2), "ref_synth_s": round(t_ref, 2)},

@@ -59,12 +59,12 @@ struct Counters {
     uint32_t n_sort[N_SORT_CLS], n_giant_tiles, n_giant_rounds;
     uint32_t n_long_segs, pad2;
     uint32_t n_cl[4], cl_ticket, pad3;      // global queue of big clusters (k_cluster_dp), by size class
-    uint32_t n_leg_reason[4];     // why reads left the long-read front end: 0 room/segments, 1 thinning screen, 2 anchors beyond the giant path; 3 = reads decided by the pair test (dbg & 16)
+    uint32_t n_leg_reason[4];     // why reads left the long-read front end: 0 room/segments, 1 thinning screen, 2 anchors beyond the giant path, 3 unused
     unsigned long long arena_cursor, anchor_cursor;
     unsigned long long cl_tot[4], cl_anchor_tot[4], cl_dbg[4];
     unsigned long long sort_tot[N_SORT_CLS + 1], sort_anchor_tot[N_SORT_CLS + 1];    // SCRUBBY_HIP_DBG & 16: reads / anchors per sort class (4 = chained inside k_expand)     // statistics of k_cluster_dp by size class (whole chunk)
     unsigned long long sh_mini[64], sh_anchors[64];     // sharded sums
-    uint32_t sh_host[64], sh_clusters[64];
+    uint32_t sh_host[64], sh_clusters[64], sh_pair[64];      // sh_pair: reads decided by the pair test
 };
 #define SHARD() ((blockIdx.x + (blockIdx.x >> 6)) & 63)
 
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
     const ChainParams &P = a.P;
     const bool plain_cut = !(P.occ_dist > 0 && P.max_max_occ > a.max_occ);
     WaveAlloc al_sort[N_SORT_CLS];
-    uint32_t n_clusters = 0;
+    uint32_t n_clusters = 0, n_pair = 0;
     unsigned long long anchors_wave = 0, a_cur = 0, a_end = 0;      // wave-local slice of the anchor arena
     __shared__ uint64_t e_x[64];
     __shared__ uint32_t e_q[64];
@@ -1046,8 +1046,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
         if (!LONG && a.flag_only && P.pair_dq_max > 0 && n_st == 1 && n_a > (uint32_t)P.pair_min_anchors && pair_decides(rec0, my_n0, n_seed, lane, a.positions, P)) {
             // decided without a single anchor: sh_stats.n_anchors still counts what the occurrence filter admitted
             if (lane == 0) { BigMeta m{r, n_a, rep_len, 0u}; a.B.meta[w] = m; a.B.acc_nu[w] = 1; a.B.acc_best[w] = P.min_sc; }
-            anchors_wave += n_a;
-            if ((a.dbg & 16) && lane == 0) atomicAdd(&a.ctr->n_leg_reason[3], 1u);
+            anchors_wave += n_a; ++n_pair;
             continue;
         }
         const bool in_lds = n_a <= 64;     // short anchor lists never leave the CU
@@ -1142,6 +1141,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
     if (lane == 0 && anchors_wave) atomicAdd(&a.ctr->sh_anchors[SHARD()], anchors_wave);
     n_clusters = wave_sum_u32(n_clusters);
     if (lane == 0 && n_clusters) atomicAdd(&a.ctr->sh_clusters[SHARD()], n_clusters);
+    if (lane == 0 && n_pair) atomicAdd(&a.ctr->sh_pair[SHARD()], n_pair);
 }
 
 // stable block merge sort: 64-element tiles ranked in registers (one tile per wave at a time), then merge-path
@@ -2008,7 +2008,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         SH_HIP(hipStreamSynchronize(s));
         SH_HIP(hipGetLastError());
         if (first) { snap = *c->h_ctr; first = false; }
-        if (k.dbg & 16) fprintf(stderr, "[dbg] iter %d resketch %u reasons %u %u %u pair-decided %u segs %u big %u/%u defer %u/%u\n", iter, c->h_ctr->n_resketch, c->h_ctr->n_leg_reason[0], c->h_ctr->n_leg_reason[1], c->h_ctr->n_leg_reason[2], c->h_ctr->n_leg_reason[3], c->h_ctr->n_long_segs, c->h_ctr->n_big[0], c->h_ctr->n_big[1], c->h_ctr->n_big_defer[0], c->h_ctr->n_big_defer[1]);
+        if (k.dbg & 16) fprintf(stderr, "[dbg] iter %d resketch %u reasons %u %u %u pair-decided(dbg) %u segs %u big %u/%u defer %u/%u\n", iter, c->h_ctr->n_resketch, c->h_ctr->n_leg_reason[0], c->h_ctr->n_leg_reason[1], c->h_ctr->n_leg_reason[2], c->h_ctr->n_leg_reason[3], c->h_ctr->n_long_segs, c->h_ctr->n_big[0], c->h_ctr->n_big[1], c->h_ctr->n_big_defer[0], c->h_ctr->n_big_defer[1]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] clusters chained by k_cluster_dp by class: %llu %llu %llu %llu, their anchors %llu %llu %llu %llu\n", c->h_ctr->cl_tot[0], c->h_ctr->cl_tot[1], c->h_ctr->cl_tot[2], c->h_ctr->cl_tot[3], c->h_ctr->cl_anchor_tot[0], c->h_ctr->cl_anchor_tot[1], c->h_ctr->cl_anchor_tot[2], c->h_ctr->cl_anchor_tot[3]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] reads (anchors) by sort class: <=64 %llu (%llu), <=256 %llu (%llu), <=512 %llu (%llu), <=1024 %llu (%llu), <=2048 %llu (%llu), <=4096 %llu (%llu), giant %llu (%llu)\n", c->h_ctr->sort_tot[6], c->h_ctr->sort_anchor_tot[6], c->h_ctr->sort_tot[0], c->h_ctr->sort_anchor_tot[0], c->h_ctr->sort_tot[1], c->h_ctr->sort_anchor_tot[1], c->h_ctr->sort_tot[2], c->h_ctr->sort_anchor_tot[2], c->h_ctr->sort_tot[3], c->h_ctr->sort_anchor_tot[3], c->h_ctr->sort_tot[4], c->h_ctr->sort_anchor_tot[4], c->h_ctr->sort_tot[5], c->h_ctr->sort_anchor_tot[5]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] ring DP: chunks in window %llu, beyond %llu, far rescans %llu\n", c->h_ctr->cl_dbg[0], c->h_ctr->cl_dbg[1], c->h_ctr->cl_dbg[2]);
@@ -2048,14 +2048,14 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         float t01 = 0, t12 = 0, t23 = 0, t04 = 0;
         hipEventElapsedTime(&t01, c->ev[0], c->ev[1]); hipEventElapsedTime(&t12, c->ev[1], c->ev[2]);
         hipEventElapsedTime(&t23, c->ev[1], c->ev[3]); hipEventElapsedTime(&t04, c->ev[0], c->ev[4]);
-        uint64_t sum_host = 0, sum_mini = 0, sum_anchors = 0, sum_clusters = 0;
-        for (int i = 0; i < 64; ++i) { sum_host += c->h_ctr->sh_host[i]; sum_mini += c->h_ctr->sh_mini[i]; sum_anchors += c->h_ctr->sh_anchors[i]; sum_clusters += c->h_ctr->sh_clusters[i]; }
+        uint64_t sum_host = 0, sum_mini = 0, sum_anchors = 0, sum_clusters = 0, sum_pair = 0;
+        for (int i = 0; i < 64; ++i) { sum_host += c->h_ctr->sh_host[i]; sum_mini += c->h_ctr->sh_mini[i]; sum_anchors += c->h_ctr->sh_anchors[i]; sum_clusters += c->h_ctr->sh_clusters[i]; sum_pair += c->h_ctr->sh_pair[i]; }
         stats->n_reads += n_reads; stats->n_bases += n_bases;
         stats->n_host += sum_host; stats->n_no_seed += n_reads - snap.n_small - snap.n_big[0] - snap.n_resketch;
         uint64_t nl = (uint64_t)snap.n_resketch + snap.n_big[0];
         stats->n_chain_large += nl; stats->n_chain_small += snap.n_small;
         stats->n_minimizers += sum_mini;
-        stats->n_anchors += sum_anchors; stats->n_clusters += sum_clusters; stats->n_resketch += resk_done;
+        stats->n_anchors += sum_anchors; stats->n_clusters += sum_clusters; stats->n_resketch += resk_done; stats->n_pair_decided += sum_pair;
         stats->ms_sketch_probe += t01; stats->ms_chain_small += t12; stats->ms_chain_large += t23; stats->ms_total += t04;
     }
     return SH_OK;

@@ -60,7 +60,7 @@ class Stats(C.Structure):
         ("n_chain_small", C.c_uint64), ("n_chain_large", C.c_uint64), ("n_minimizers", C.c_uint64),
         ("n_bases", C.c_uint64), ("ms_sketch_probe", C.c_double), ("ms_chain_small", C.c_double),
         ("ms_chain_large", C.c_double), ("ms_total", C.c_double),
-        ("n_anchors", C.c_uint64), ("n_clusters", C.c_uint64), ("n_resketch", C.c_uint64),
+        ("n_anchors", C.c_uint64), ("n_clusters", C.c_uint64), ("n_resketch", C.c_uint64), ("n_pair_decided", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -344,3 +344,42 @@ def test_long_reads_chunked_context_and_small_arena(S, oracle, monkeypatch):
     monkeypatch.setenv("SCRUBBY_HIP_ARENA_MB", "96")
     gf, gt, st, rc = gidx.classify(bases, offs, want_trace=True)
     assert_trace_equal(S, gf, gt, of, ot)
+
+
+def test_pair_test_flag_only_on_repeat_rich_reference(S, oracle, monkeypatch):
+    """The flag-only pair test (k_expand / pair_decides) on a reference made of few, large repeat families, so
+    that most reads reach the repeat path with dozens to thousands of anchors: flags with the shortcut, without it
+    (SCRUBBY_HIP_NO_PAIR) and from the oracle's full chaining + backtrack must be identical.  Reads: substitution-only
+    (either strand), indel reads (dd != 0: the test must fall through), reads with an internal duplication (two seeds
+    with one key: the distinct-key premise fails and the read takes the full path), and non-host reads."""
+    contigs = [600_000, 400_000]
+    Po = oracle.ref_params(0x5C2B0A01, contigs, sat_pct=10, rep_pct=70, n_sat_fam=4, n_rep_fam=6)
+    ref = oracle.synth_ref(Po, 0, Po.genome_len)
+    seqs = [ref[Po.contig_start[i]:Po.contig_start[i + 1]] for i in range(len(contigs))]
+    Ro = oracle.read_params(0x5C2B0A02)
+    n = 12000
+    plain = oracle.synth_reads(Po, Ro, 0, n).reshape(n, 150)
+    indel, _ = _short_indel_reads(ref, 3000, 23)
+    rng = np.random.default_rng(5)
+    dup = []
+    for _ in range(1500):                      # 60 bases, then the same 45 again, then on: repeated k-mers inside the read
+        s = int(rng.integers(0, len(ref) - 200))
+        r = bytes(ref[s:s + 60]) + bytes(ref[s + 15:s + 60]) + bytes(ref[s + 60:s + 105])
+        dup.append(np.frombuffer(r, dtype=np.uint8))
+    bases = np.concatenate([plain.reshape(-1), indel, np.concatenate(dup)])
+    offs = np.arange(len(bases) // 150 + 1, dtype=np.uint64) * 150
+    gidx = S.Index.build([bytes(s) for s in seqs], S.preset("sr"))
+    cidx = oracle.Index.build(seqs, 11, 21)
+    of, ot = cidx.classify(oracle.preset("sr"), bases, offs, threads=8)
+    f_on, _, st_on, rc = gidx.classify(bases, offs, want_trace=False)
+    assert rc == 0 and np.array_equal(f_on, of), f"{int((f_on != of).sum())} flags differ with the pair test"
+    print({k: st_on[k] for k in ("n_reads", "n_host", "n_no_seed", "n_chain_small", "n_chain_large", "n_anchors", "n_pair_decided")})
+    assert st_on["n_chain_large"] > 1500 and st_on["n_pair_decided"] > 500, st_on      # the shortcut did the deciding
+    assert st_on["n_pair_decided"] < st_on["n_chain_large"]                              # and some reads fell through
+    monkeypatch.setenv("SCRUBBY_HIP_NO_PAIR", "1")
+    f_off, _, st_off, rc = gidx.classify(bases, offs, want_trace=False)
+    assert np.array_equal(f_off, of) and st_off["n_pair_decided"] == 0
+    monkeypatch.delenv("SCRUBBY_HIP_NO_PAIR")
+    gf, gt, st, rc = gidx.classify(bases, offs, want_trace=True)                         # trace mode never takes the shortcut
+    assert_trace_equal(S, gf, gt, of, ot)
+    assert st["n_pair_decided"] == 0
