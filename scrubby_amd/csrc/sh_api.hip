@@ -170,7 +170,9 @@ extern "C" sh_status sh_index_load(const char *path, int32_t device, sh_index **
 }
 
 // ---- FASTA -> index -----------------------------------------------------------------------------------
-extern "C" sh_status sh_index_build_fasta(const char *path, const sh_opts *opts, int32_t device, sh_index **out)
+// line-by-line host reader: FASTQ references, files that do not start with a FASTA header, and the A/B baseline of the
+// GPU reader in sh_index.hip (SCRUBBY_HIP_FASTA_HOST=1)
+sh_status shi_index_build_fasta_host(const char *path, const sh_opts *opts, int32_t device, sh_index **out)
 {
     SH_CHECK(path && opts && out, SH_ERR_BAD_ARG, "sh_index_build_fasta: null argument");
     // plain or gzip, sniffed by magic bytes like needletail does; gzip through zcat

@@ -77,5 +77,6 @@ __host__ __device__ static inline uint32_t sh_nt4(uint32_t c)
 }
 
 // internal entry points implemented across translation units
+sh_status shi_index_build_fasta_host(const char *path, const sh_opts *opts, int32_t device, sh_index **out);
 sh_status shi_index_build_device(const uint8_t *d_bases, const uint64_t *contig_starts, uint32_t n_contigs,
                                  const sh_opts *opts, int32_t device, hipStream_t stream, sh_index **out);

@@ -10,7 +10,8 @@
 //           records into a flat hash set (cleaner.rs:564-570).
 //   pass 2  per file, pool workers decide every record by its id (FastqCleaner::clean_reads), format the kept ones - a run
 //           of kept records already in the writer's form is one memcpy - and, for .gz outputs, deflate each chunk as its
-//           own gzip member (level 6, niffler's default in get_fastx_writer, utils.rs:56-74); an ordered writer appends.
+//           own gzip member (level 6, niffler's default in get_fastx_writer, utils.rs:56-74); output sizes are published in chunk
+//           order, which fixes each chunk's file offset, and the workers pwrite side by side.
 //           Chunks retained in host memory (budget: half of MemAvailable, SCRUBBY_HIP_RETAIN_MB) are not read again;
 //           past the budget the files are streamed a second time.
 //   report  reads_in / reads_out / difference come from pass 2's counters: keep/drop is a function of the id alone, so
@@ -20,6 +21,9 @@
 // case handed to the collect-then-map form in sh_host.cpp.
 #include "sh_host.h"
 #include <zlib.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/mman.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -38,6 +42,19 @@ struct Rec {
     uint32_t beg, hdr, hdr_len, seq, seq_len, qual, end;   // offsets into Chunk::data; [beg, end) = the record as it stands in the file
     uint8_t fastq, canon;                                  // canon: [beg, end) is byte for byte what the writer would emit
 };
+
+// chunk buffers: 2 MiB-aligned and advised as huge pages - 6.5 GB of 4 KiB pages cost ~1 s to fault in (pass 1's readers) and
+// ~1 s to give back (munmap serialises on the address-space lock, whichever thread frees)
+inline char *chunk_alloc(size_t bytes)
+{
+    const size_t HP = 2u << 20;
+    if (bytes < 2 * HP) return (char *)malloc(bytes);
+    const size_t sz = (bytes + HP - 1) / HP * HP;
+    void *p = nullptr;
+    if (posix_memalign(&p, HP, sz) != 0) return nullptr;
+    madvise(p, sz, MADV_HUGEPAGE);
+    return (char *)p;
+}
 
 struct DevBuf;
 struct Chunk {
@@ -218,7 +235,7 @@ public:
     {
         if (eof_ && carry_.empty()) return 0;
         size_t cap = carry_.size() + target_;
-        c.data = (char *)malloc(cap + 1);
+        c.data = chunk_alloc(cap + 1);
         if (!c.data) { error = "out of host memory"; return -1; }
         c.len = carry_.size();
         if (c.len) memcpy(c.data, carry_.data(), c.len);
@@ -253,8 +270,10 @@ public:
             // not one complete record in cap bytes: a record longer than the chunk - grow and read on
             if (cap >= (3ull << 30)) { error = "record longer than 3 GiB"; return -1; }
             cap = std::min<size_t>(cap * 2, 3ull << 30);
-            char *nd = (char *)realloc(c.data, cap + 1);
+            char *nd = chunk_alloc(cap + 1);
             if (!nd) { error = "out of host memory"; return -1; }
+            memcpy(nd, c.data, c.len);
+            free(c.data);
             c.data = nd;
         }
     }
@@ -439,7 +458,7 @@ void filter_chunk(const Chunk &c, const ShardedIdSet &ids, bool extract, bool gz
 // pass 2 for one file: sources chunks (retained, or streamed again), filters on `n_workers` threads, writes in order
 struct FileFilter {
     const char *in_path, *out_path;
-    const std::vector<std::shared_ptr<Chunk>> *retained;    // nullptr: stream the file again
+    std::vector<std::shared_ptr<Chunk>> *retained;          // nullptr: stream the file again; else consumed: a chunk is released by the worker that filtered it
     size_t chunk_bytes;
     const ShardedIdSet *ids;
     bool extract, want_dropped;
@@ -461,17 +480,20 @@ struct FileFilter {
             rd.reset(new ChunkReader(in_path, chunk_bytes, false));
             SH_CHECK(rd->ok(), SH_ERR_IO, "cannot open %s", in_path);
         }
-        FILE *fp = fopen(out_path, "wb");
-        SH_CHECK(fp, SH_ERR_IO, "cannot open %s", out_path);
-        setvbuf(fp, nullptr, _IOFBF, 4 << 20);
+        const int fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        SH_CHECK(fd >= 0, SH_ERR_IO, "cannot open %s", out_path);
 
+        // Chunks are taken in file order; a worker filters (and deflates) its chunk, then publishes the size of its output
+        // in chunk order - which fixes its offset in the file - and writes with pwrite beside the other workers.  Only the
+        // size publication is ordered, so the copies into the page cache run in parallel.
         std::mutex src_mu, out_mu;
         std::condition_variable cv;
-        std::map<size_t, FilterOut> done;
-        size_t next = 0, written = 0;
-        int active = n_workers;
-        bool src_done = false, failed = false;
-        const size_t window = (size_t)n_workers * 2 + 2;
+        size_t next = 0, published = 0;
+        uint64_t cur_off = 0;
+        bool src_done = false, failed = false, io_ok = true;
+        std::atomic<uint64_t> us_filter{0}, us_wait{0}, us_write{0};       // SCRUBBY_HIP_DBG_HOST=1
+        auto tick = [] { return std::chrono::steady_clock::now(); };
+        auto usd = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
 
         auto worker = [&]() {
             for (;;) {
@@ -494,49 +516,51 @@ struct FileFilter {
                     }
                     i = next++;
                 }
+                FilterOut o;
+                const auto t0 = tick();
+                filter_chunk(*ch, *ids, extract, gz, want_dropped, o);
+                if (retained) (*retained)[i].reset();      // each index is visited once; the unmap of ~64 MB happens here, on this worker
+                ch.reset();
+                const auto t1 = tick();
+                us_filter += usd(t0, t1);
+                uint64_t my_off = 0;
                 {
                     std::unique_lock<std::mutex> lk(out_mu);
-                    cv.wait(lk, [&] { return failed || i < written + window; });
+                    cv.wait(lk, [&] { return failed || published == i; });
+                    us_wait += usd(t1, tick());
+                    if (!o.error.empty() && !failed) { failed = true; error = o.error + " in " + in_path; }
+                    if (!failed) {
+                        my_off = cur_off; cur_off += o.bytes.size();
+                        n_in += o.n_in; n_out += o.n_out;
+                        for (auto &s : o.dropped) dropped.push_back(std::move(s));
+                    }
+                    published = i + 1;          // also on failure: nobody may wait for this chunk for ever
+                    cv.notify_all();
                     if (failed) break;
                 }
-                FilterOut o;
-                filter_chunk(*ch, *ids, extract, gz, want_dropped, o);
-                std::lock_guard<std::mutex> lk(out_mu);
-                if (!o.error.empty()) { failed = true; error = o.error + " in " + in_path; }
-                else done.emplace(i, std::move(o));
-                cv.notify_all();
-                if (failed) break;
+                const auto t2 = tick();
+                size_t done = 0;
+                while (done < o.bytes.size()) {
+                    const ssize_t w = pwrite(fd, o.bytes.data() + done, o.bytes.size() - done, (off_t)(my_off + done));
+                    if (w <= 0) { std::lock_guard<std::mutex> lk(out_mu); io_ok = false; failed = true; cv.notify_all(); break; }
+                    done += (size_t)w;
+                }
+                us_write += usd(t2, tick());
             }
-            std::lock_guard<std::mutex> lk(out_mu);
-            --active;
-            cv.notify_all();
         };
+        const auto t_run = tick();
         std::vector<std::thread> pool;
         for (int t = 0; t < n_workers; ++t) pool.emplace_back(worker);
-
-        bool any = false, io_ok = true;
-        for (size_t i = 0;; ++i) {
-            std::unique_lock<std::mutex> lk(out_mu);
-            cv.wait(lk, [&] { return failed || done.count(i) || active == 0; });
-            if (failed || !done.count(i)) break;
-            FilterOut o = std::move(done[i]);
-            done.erase(i);
-            lk.unlock();
-            n_in += o.n_in; n_out += o.n_out;
-            for (auto &s : o.dropped) dropped.push_back(std::move(s));
-            if (!o.bytes.empty()) { any = true; io_ok = io_ok && fwrite(o.bytes.data(), 1, o.bytes.size(), fp) == o.bytes.size(); }
-            lk.lock();
-            written = i + 1;
-            cv.notify_all();
-        }
-        { std::lock_guard<std::mutex> lk(out_mu); if (!io_ok) failed = true; cv.notify_all(); }
         for (auto &t : pool) t.join();
-        if (gz && !any && error.empty()) {     // no record kept: still a valid (empty) gzip stream, as gzclose would leave
+        if (const char *e = getenv("SCRUBBY_HIP_DBG_HOST")) if (*e == '1')
+            fprintf(stderr, "[scrubby-hip] pass 2 %s: %d workers, wall %.0f ms; filter%s %.0f ms, waiting for the offset %.0f ms, pwrite %.0f ms (summed over workers)\n", out_path,
+                    n_workers, usd(t_run, tick()) / 1e3, gz ? " + deflate" : "", us_filter / 1e3, us_wait / 1e3, us_write / 1e3);
+        if (gz && cur_off == 0 && error.empty() && io_ok) {     // no record kept: still a valid (empty) gzip stream, as gzclose would leave
             std::string m;
             gz_member("", 0, 6, m);
-            io_ok = io_ok && fwrite(m.data(), 1, m.size(), fp) == m.size();
+            io_ok = pwrite(fd, m.data(), m.size(), 0) == (ssize_t)m.size();
         }
-        io_ok = (fclose(fp) == 0) && io_ok;
+        io_ok = (close(fd) == 0) && io_ok;
         SH_CHECK(error.empty(), SH_ERR_IO, "%s", error.c_str());
         SH_CHECK(io_ok, SH_ERR_IO, "short write to %s", out_path);
         return SH_OK;

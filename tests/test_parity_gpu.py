@@ -383,3 +383,44 @@ def test_pair_test_flag_only_on_repeat_rich_reference(S, oracle, monkeypatch):
     gf, gt, st, rc = gidx.classify(bases, offs, want_trace=True)                         # trace mode never takes the shortcut
     assert_trace_equal(S, gf, gt, of, ot)
     assert st["n_pair_decided"] == 0
+
+
+def test_fasta_taken_apart_on_the_gpu(S, oracle, cfg1, gpu_index, tmp_path, monkeypatch):
+    """sh_index_build_fasta: raw file bytes go to HBM and the text is split there (transition-function scan + compaction,
+    csrc/sh_index.hip).  Layouts that stress the line machine - 60-column lines, one line per contig, CRLF, blank lines,
+    a '>' inside a header, lower case, no final newline, gzip - must give the index that the parsed sequences give, and
+    the line-by-line host reader (SCRUBBY_HIP_FASTA_HOST=1) must agree."""
+    import gzip
+    P, R, ref, seqs, reads, off = cfg1
+    want = oracle.Index.wrap(*gpu_index.export(), 11, 21).dump()
+    texts = {}
+    recs60 = []
+    for i, s in enumerate(seqs):
+        t = bytes(s).decode()
+        recs60.append(f">ctg{i} len={len(t)} >not a header\n" + "\n".join(t[j:j + 60] for j in range(0, len(t), 60)) + "\n")
+    texts["cols60"] = "".join(recs60)
+    texts["one_line_no_final_newline"] = "".join(f">c{i}\n{bytes(s).decode()}\n" for i, s in enumerate(seqs)).rstrip("\n")
+    texts["crlf_blank_lines"] = "\r\n\r\n" + "".join(f">c{i} x\r\n" + "\r\n".join(bytes(s).decode()[j:j + 70000] for j in range(0, len(s), 70000)) + "\r\n\r\n"
+                                                  for i, s in enumerate(seqs))
+    texts["lower_case"] = texts["cols60"].lower().replace(">ctg", ">CTG")
+    for name, text in texts.items():
+        fa = tmp_path / f"{name}.fa"
+        fa.write_bytes(text.encode())
+        for env in ("0", "1"):
+            monkeypatch.setenv("SCRUBBY_HIP_FASTA_HOST", env)
+            idx = S.Index.build_fasta(str(fa), S.preset("sr"))
+            got = oracle.Index.wrap(*idx.export(), 11, 21).dump()
+            assert all(np.array_equal(x, y) for x, y in zip(got, want)), (name, env)
+            inf = idx.info()
+            assert inf["n_contigs"] == len(seqs) and inf["n_bases"] == sum(len(s) for s in seqs), (name, env, inf)
+    monkeypatch.setenv("SCRUBBY_HIP_FASTA_HOST", "0")
+    gz = tmp_path / "ref.fa.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(texts["cols60"].encode())
+    got = oracle.Index.wrap(*S.Index.build_fasta(str(gz), S.preset("sr")).export(), 11, 21).dump()
+    assert all(np.array_equal(x, y) for x, y in zip(got, want))
+    # a file that does not open with a header goes to the line reader, which skips the leading junk as before
+    junk = tmp_path / "junk_first.fa"
+    junk.write_bytes(("ACGTACGT\n" + texts["cols60"]).encode())
+    got = oracle.Index.wrap(*S.Index.build_fasta(str(junk), S.preset("sr")).export(), 11, 21).dump()
+    assert all(np.array_equal(x, y) for x, y in zip(got, want))
