@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
     __syncthreads();
 
     // ---- B + C ----------------------------------------------------------------------------------
-    SketchState<W> st;
+    SketchPacked<W> st;      // reads of this kernel are <= 1024 bases and k <= 23: one 64-bit word per ring entry (sh_sketch.h)
     st.init(a.k);
     const uint32_t b0 = (uint32_t)((base_addr + o_beg) - a0);    // tile-relative index of this read's first base
     uint32_t maxlen = len;
@@ -231,13 +231,13 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
     uint32_t qh = 0, qt = 0, pend = 0, n_mini = 0, n_seed = 0, overflow = 0, sum_occ = 0, n_high = 0;
     const uint64_t slot_mask = (1ULL << a.lg_slots) - 1;
     uint4 *rec = a.records + (size_t)(valid ? r : 0) * a.seed_cap;      // per-read contiguous seed records
-    auto emit = [&](uint64_t x, uint32_t y) {
+    auto emit = [&](uint64_t packed) {
         if (qt - qh >= K1_LIST_CAP) {      // tie-heavy read: the lane drains its whole ring now, in order; gathers in flight are dropped
             const uint4 acc = k1_lane_flush(list, lane, qh, qt, a.slots, a.lg_slots, rec, a.seed_cap, make_uint4(n_seed, overflow, sum_occ, n_high), (uint32_t)a.mid_occ);
             n_seed = acc.x; overflow = acc.y; sum_occ = acc.z; n_high = acc.w;
             qh = qt; pend = 0;
         }
-        list[(qt & (K1_LIST_CAP - 1)) * 64 + lane] = (x >> 8) << 18 | (uint64_t)y;
+        list[(qt & (K1_LIST_CAP - 1)) * 64 + lane] = sh_packed_entry(packed);      // hash << 18 | pos << 1 | strand
         ++qt; ++n_mini;
     };
     auto consume = [&](const uint4 (&sl)[4]) {

@@ -108,6 +108,93 @@ struct SketchState {
     }
 };
 
+// Packed variant for the read kernel (K1): reads of at most 1024 bases (positions < 2^17) and k <= 23 (hashes < 2^46), so a ring
+// entry fits one 64-bit word   hash << 18 | (0x1FFFF - pos) << 1 | strand   (SH_XMAX = no k-mer).  An unsigned minimum over such
+// words is the window minimum with "rightmost on ties" built in (equal hashes: the larger position has the smaller word), so
+// the rescan after the minimum leaves the window is a plain 11-way minimum: 3 VALU per entry instead of 10, and no second
+// array for y.  "The minimum sits in the slot being overwritten" becomes "its position is pos - W".  Ties (the same k-mer
+// twice in a window) are looked for on the hashes' low 32 bits first (hl[]); only if that count exceeds one do the exact
+// tie loops run, in the reference's slot order.  Same statement order and emission order as SketchState::step.
+//   emit(p) receives the packed word; sh_packed_entry() turns it into the queue entry  hash << 18 | pos << 1 | strand.
+__device__ inline uint64_t sh_packed_entry(uint64_t p)
+{
+    const uint32_t low = (uint32_t)p & 0x3ffffu;
+    return (p & ~0x3ffffULL) | (uint64_t)(((0x1ffffu - (low >> 1)) << 1) | (low & 1u));
+}
+
+template <int W>
+struct SketchPacked {
+    uint64_t b[W];
+    uint32_t hl[W];
+    uint64_t minp, kf, kr, mask;
+    uint32_t shift1;
+    int32_t l, k;
+
+    __device__ __forceinline__ void init(int k_)
+    {
+#pragma unroll
+        for (int j = 0; j < W; ++j) b[j] = SH_XMAX, hl[j] = 0xffffffffu;
+        minp = SH_XMAX; l = 0; kf = kr = 0;
+        k = k_; mask = (1ULL << 2 * k_) - 1; shift1 = 2 * (k_ - 1);
+    }
+
+    template <int P, class Emit>
+    __device__ __forceinline__ void ties(Emit &&emit, bool with_p)
+    {   // every other entry with the minimum's hash, oldest first: slots P+1 .. W-1, then 0 .. P (P itself only after a rescan)
+        const uint64_t mh = minp >> 18;
+#pragma unroll
+        for (int j = P + 1; j < W; ++j) if ((b[j] >> 18) == mh && b[j] != minp && b[j] != SH_XMAX) emit(b[j]);
+#pragma unroll
+        for (int j = 0; j < P; ++j) if ((b[j] >> 18) == mh && b[j] != minp && b[j] != SH_XMAX) emit(b[j]);
+        if (with_p && (b[P] >> 18) == mh && b[P] != minp && b[P] != SH_XMAX) emit(b[P]);
+    }
+
+    __device__ __forceinline__ int same_low() const
+    {
+        const uint32_t ml = (uint32_t)(minp >> 18);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < W; ++j) c += hl[j] == ml;
+        return c;
+    }
+
+    template <int P, class Emit>
+    __device__ __forceinline__ void step(uint32_t c, uint32_t pos, Emit &&emit)
+    {
+        uint64_t ip = SH_XMAX;
+        if (c < 4) {
+            kf = (kf << 2 | (uint64_t)c) & mask;
+            kr = (kr >> 2) | ((uint64_t)(3u ^ c) << shift1);
+            const uint32_t z = kf < kr ? 0u : 1u;
+            ++l;
+            if (l >= k) ip = sh_hash64(z ? kr : kf, mask) << 18 | (uint64_t)(0x1ffffu - pos) << 1 | z;
+        } else {
+            l = 0;
+        }
+        b[P] = ip; hl[P] = (uint32_t)(ip >> 18);
+        if (l == W + k - 1 && minp != SH_XMAX) {       // first full window: identical k-mers
+            if (same_low() > 1) ties<P>(emit, false);
+        }
+        if (ip < minp) {                                // new minimum (an equal hash at a later position is the smaller word)
+            if (l >= W + k && minp != SH_XMAX) emit(minp);
+            minp = ip;
+        } else if (minp != SH_XMAX && (((uint32_t)minp >> 1) & 0x1ffffu) == 0x1ffffu - (pos - (uint32_t)W)) {   // old minimum left the window
+            if (l >= W + k - 1) emit(minp);
+            uint64_t m = b[0];
+#pragma unroll
+            for (int j = 1; j < W; ++j) m = b[j] < m ? b[j] : m;
+            minp = m;
+            if (l >= W + k - 1 && minp != SH_XMAX && same_low() > 1) ties<P>(emit, true);
+        }
+    }
+
+    template <class Emit>
+    __device__ __forceinline__ void finish(Emit &&emit)
+    {
+        if (minp != SH_XMAX) emit(minp);
+    }
+};
+
 // Runtime-w variant with the ring in caller-provided memory (HBM arena); used only by the
 // rare re-sketch path of the large-read kernel.  Same statement order as SketchState::step.
 struct SketchStateDyn {
