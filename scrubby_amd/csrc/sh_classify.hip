@@ -1872,9 +1872,9 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     SH_HIP(hipMemsetAsync(&ctr->anchor_cursor, 0, 8, s));
     SH_HIP(hipMemsetAsync(&ctr->n_sort[0], 0, 4 * N_SORT_CLS, s));
     SH_HIP(hipMemsetAsync(&ctr->n_cl[0], 0, 4 * 6, s));
-    static const uint32_t xmul = getenv("SCRUBBY_HIP_EXPAND_GRID") ? (uint32_t)atoi(getenv("SCRUBBY_HIP_EXPAND_GRID")) : 3u;
+    // 6144 waves for 4096 resident (103 VGPRs: 4 per SIMD): measured best; 4096 or 5120 waves, or 5 waves per SIMD at 96 VGPRs, are 0-3 % slower
     if (k.seed_off) hipLaunchKernelGGL(k_expand<true>, dim3(grid * 3), dim3(64), 0, s, k);
-    else hipLaunchKernelGGL(k_expand<false>, dim3(grid * std::min(std::max(xmul, 1u), 3u)), dim3(64), 0, s, k);
+    else hipLaunchKernelGGL(k_expand<false>, dim3(grid * 3), dim3(64), 0, s, k);
     // the four sort classes are independent: run them side by side so that they fill each other's tails
     const bool side = (c->par & 2) != 0;
     hipStream_t s0 = side ? c->sx[0] : s, s1 = side ? c->sx[1] : s, g = side ? c->sx[2] : s;
