@@ -4,7 +4,10 @@
 #include "sh_synth_core.h"
 #include <cstdarg>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <thread>
+#include <mutex>
 
 // ---- errors ----------------------------------------------------------------------------------
 static thread_local char g_err[1024] = "";
@@ -62,6 +65,39 @@ extern "C" sh_status sh_preset(const char *name, sh_opts *o)
 }
 
 // ---- host-buffer classification ----------------------------------------------------------------
+// What a call needs besides the index: a context (minimap2's thread buffer), device copies of the batch, two streams.  Creating
+// and freeing ~30 GB of it per call is not free (the driver wipes freed HBM before handing it out again: 0.1 s became 0.6 s),
+// so the index keeps what calls leave behind and the next call - from any thread - takes the first set that is large enough.
+struct BatchScratch {
+    sh_ctx *ctx = nullptr;
+    sh_opts opts{};
+    std::string env;          // the environment switches a context captures when it is created
+    uint64_t ctx_reads = 0, ctx_bases = 0;
+    uint32_t ctx_len = 0;
+    uint8_t *d_bases = nullptr, *d_flags = nullptr;
+    uint64_t *d_off = nullptr;
+    sh_trace *d_tr = nullptr;
+    size_t cap_bases = 0, cap_reads = 0, cap_tr = 0;
+    hipStream_t s = nullptr, us = nullptr;
+    void release()
+    {
+        if (ctx) sh_ctx_destroy(ctx);
+        if (d_bases) hipFree(d_bases);
+        if (d_flags) hipFree(d_flags);
+        if (d_off) hipFree(d_off);
+        if (d_tr) hipFree(d_tr);
+        if (s) hipStreamDestroy(s);
+        if (us) hipStreamDestroy(us);
+    }
+};
+
+void shi_batch_pool_release(sh_index *idx)
+{
+    std::lock_guard<std::mutex> lk(idx->pool_mu);
+    for (void *p : idx->pool) { ((BatchScratch *)p)->release(); delete (BatchScratch *)p; }
+    idx->pool.clear();
+}
+
 extern "C" sh_status sh_classify_batch(const sh_index *idx, const sh_opts *opts, const uint8_t *bases, const uint64_t *offsets,
                                        uint64_t n_reads, uint8_t *out_flags, sh_trace *out_trace, sh_stats *stats)
 {
@@ -69,29 +105,54 @@ extern "C" sh_status sh_classify_batch(const sh_index *idx, const sh_opts *opts,
     if (stats) memset(stats, 0, sizeof(*stats));
     if (n_reads == 0) return SH_OK;
     SH_HIP(hipSetDevice(idx->device));
-    const uint64_t CH = 1ull << 22;       // reads per chunk
+    const uint64_t CH = 1ull << 22;       // reads per piece
     const uint64_t n_bases = offsets[n_reads] - offsets[0];
     uint32_t max_len = 0;
+    uint64_t piece_bases = 0;
     for (uint64_t r = 0; r < n_reads; ++r) max_len = std::max<uint32_t>(max_len, (uint32_t)std::min<uint64_t>(offsets[r + 1] - offsets[r], UINT32_MAX));
-    sh_ctx *ctx = nullptr;
-    sh_status st = sh_ctx_create(idx, opts, std::min(CH, n_reads), n_bases, max_len, &ctx);
-    if (st != SH_OK) return st;
-    uint8_t *d_bases = nullptr, *d_flags = nullptr; uint64_t *d_off = nullptr; sh_trace *d_tr = nullptr;
-    hipStream_t s = nullptr;
-    auto cleanup = [&]() {
-        if (d_bases) hipFree(d_bases);
-        if (d_flags) hipFree(d_flags);
-        if (d_off) hipFree(d_off);
-        if (d_tr) hipFree(d_tr);
-        if (s) hipStreamDestroy(s);
-        sh_ctx_destroy(ctx);
+    for (uint64_t r0 = 0; r0 < n_reads; r0 += CH) piece_bases = std::max(piece_bases, offsets[std::min(n_reads, r0 + CH)] - offsets[r0]);
+    const uint64_t need_reads = std::min(CH, n_reads);
+    std::string env_sig;
+    for (const char *v : {"SCRUBBY_HIP_ARENA_MB", "SCRUBBY_HIP_NO_FLAG_STOP", "SCRUBBY_HIP_NO_PAIR", "SCRUBBY_HIP_PAIR_MIN"}) { const char *e = getenv(v); env_sig += e ? e : "-"; env_sig += '|'; }
+    const bool no_pool = false;
+
+    BatchScratch *B = nullptr;
+    if (!no_pool) {
+        std::lock_guard<std::mutex> lk(idx->pool_mu);
+        for (size_t i = 0; i < idx->pool.size(); ++i) {
+            BatchScratch *c = (BatchScratch *)idx->pool[i];
+            if (!memcmp(&c->opts, opts, sizeof(sh_opts)) && c->env == env_sig) { B = c; idx->pool.erase(idx->pool.begin() + (long)i); break; }
+        }
+    }
+    if (!B) { B = new BatchScratch; B->opts = *opts; B->env = env_sig; }
+    auto give_back = [&](bool keep) {
+        if (keep && !no_pool) { std::lock_guard<std::mutex> lk(idx->pool_mu); idx->pool.push_back(B); }
+        else { B->release(); delete B; }
     };
-#define CB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { sh_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); cleanup(); return e_ == hipErrorOutOfMemory ? SH_ERR_OOM : SH_ERR_HIP; } } while (0)
-    CB_HIP(hipStreamCreate(&s));
-    CB_HIP(hipMalloc(&d_bases, n_bases + 32));
-    CB_HIP(hipMalloc(&d_off, (n_reads + 1) * 8));
-    CB_HIP(hipMalloc(&d_flags, n_reads));
-    if (out_trace) CB_HIP(hipMalloc(&d_tr, n_reads * sizeof(sh_trace)));
+#define CB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { sh_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); give_back(false); return e_ == hipErrorOutOfMemory ? SH_ERR_OOM : SH_ERR_HIP; } } while (0)
+    sh_status st = SH_OK;
+    if (!B->ctx || need_reads > B->ctx_reads || piece_bases > B->ctx_bases || max_len > B->ctx_len) {
+        if (B->ctx) { sh_ctx_destroy(B->ctx); B->ctx = nullptr; }
+        B->ctx_reads = std::max(B->ctx_reads, need_reads);
+        B->ctx_bases = std::max(B->ctx_bases, piece_bases);
+        B->ctx_len = std::max(B->ctx_len, max_len);
+        st = sh_ctx_create(idx, opts, B->ctx_reads, B->ctx_bases, B->ctx_len, &B->ctx);
+        if (st != SH_OK) { give_back(false); return st; }
+    }
+    if (!B->s) CB_HIP(hipStreamCreate(&B->s));
+    if (!B->us) CB_HIP(hipStreamCreateWithFlags(&B->us, hipStreamNonBlocking));
+    if (n_bases + 32 > B->cap_bases) { if (B->d_bases) hipFree(B->d_bases); B->d_bases = nullptr; B->cap_bases = n_bases + 32; CB_HIP(hipMalloc(&B->d_bases, B->cap_bases)); }
+    if (n_reads + 1 > B->cap_reads) {
+        if (B->d_off) hipFree(B->d_off);
+        if (B->d_flags) hipFree(B->d_flags);
+        B->d_off = nullptr; B->d_flags = nullptr; B->cap_reads = n_reads + 1;
+        CB_HIP(hipMalloc(&B->d_off, B->cap_reads * 8));
+        CB_HIP(hipMalloc(&B->d_flags, B->cap_reads));
+    }
+    if (out_trace && n_reads > B->cap_tr) { if (B->d_tr) hipFree(B->d_tr); B->d_tr = nullptr; B->cap_tr = n_reads; CB_HIP(hipMalloc(&B->d_tr, B->cap_tr * sizeof(sh_trace))); }
+    sh_ctx *ctx = B->ctx;
+    uint8_t *d_bases = B->d_bases, *d_flags = B->d_flags; uint64_t *d_off = B->d_off; sh_trace *d_tr = out_trace ? B->d_tr : nullptr;
+    hipStream_t s = B->s, us = B->us;
     // offsets are rebased so that d_bases[0] is the first base of the batch
     std::vector<uint64_t> off0;
     const uint64_t *offp = offsets;
@@ -100,14 +161,46 @@ extern "C" sh_status sh_classify_batch(const sh_index *idx, const sh_opts *opts,
         for (uint64_t r = 0; r <= n_reads; ++r) off0[r] = offsets[r] - offsets[0];
         offp = off0.data();
     }
-    CB_HIP(hipMemcpyAsync(d_bases, bases + offsets[0], n_bases, hipMemcpyHostToDevice, s));
     CB_HIP(hipMemcpyAsync(d_off, offp, (n_reads + 1) * 8, hipMemcpyHostToDevice, s));
-    st = sh_classify_device(ctx, d_bases, d_off, n_reads, n_bases, d_flags, d_tr, s, stats);
-    if (st != SH_OK) { cleanup(); return st; }
+    CB_HIP(hipStreamSynchronize(s));
+    // bases go up piece by piece (CH reads each) from the calling thread on a stream of their own, while a worker thread classifies
+    // the pieces that have arrived: piece i + 1 crosses PCIe while piece i is in the kernels
+    const uint64_t n_pieces = (n_reads + CH - 1) / CH;
+    std::vector<std::atomic<int>> ready(n_pieces);
+    for (auto &r : ready) r.store(0);
+    std::atomic<int> up_err{0};
+    std::string werr;
+    std::thread worker([&]() {
+        for (uint64_t p = 0; p < n_pieces && st == SH_OK; ++p) {
+            while (!ready[p].load(std::memory_order_acquire)) std::this_thread::yield();
+            if (up_err.load()) break;
+            const uint64_t r0 = p * CH, r1 = std::min(n_reads, r0 + CH);
+            sh_stats ps;
+            st = sh_classify_device(ctx, d_bases, d_off + r0, r1 - r0, n_bases, d_flags + r0, d_tr ? d_tr + r0 : nullptr, s, stats ? &ps : nullptr);
+            if (st != SH_OK) werr = sh_last_error();
+            if (stats && st == SH_OK) {
+                stats->n_reads += ps.n_reads; stats->n_host += ps.n_host; stats->n_no_seed += ps.n_no_seed; stats->n_chain_small += ps.n_chain_small;
+                stats->n_chain_large += ps.n_chain_large; stats->n_minimizers += ps.n_minimizers; stats->n_bases += ps.n_bases;
+                stats->ms_sketch_probe += ps.ms_sketch_probe; stats->ms_chain_small += ps.ms_chain_small; stats->ms_chain_large += ps.ms_chain_large; stats->ms_total += ps.ms_total;
+                stats->n_anchors += ps.n_anchors; stats->n_clusters += ps.n_clusters; stats->n_resketch += ps.n_resketch; stats->n_pair_decided += ps.n_pair_decided;
+            }
+        }
+    });
+    for (uint64_t p = 0; p < n_pieces; ++p) {
+        const uint64_t r0 = p * CH, r1 = std::min(n_reads, r0 + CH);
+        const uint64_t b0 = offp[r0], b1 = offp[r1];
+        if (!up_err.load() && b1 > b0 &&
+            (hipMemcpyAsync(d_bases + b0, bases + offsets[0] + b0, b1 - b0, hipMemcpyHostToDevice, us) != hipSuccess || hipStreamSynchronize(us) != hipSuccess)) up_err = 1;
+        ready[p].store(1, std::memory_order_release);
+    }
+    worker.join();
+    if (up_err.load() && st == SH_OK) { sh_set_error("sh_classify_batch: host-to-device copy failed"); st = SH_ERR_HIP; }
+    else if (st != SH_OK) sh_set_error("%s", werr.c_str());
+    if (st != SH_OK) { give_back(false); return st; }
     CB_HIP(hipMemcpyAsync(out_flags, d_flags, n_reads, hipMemcpyDeviceToHost, s));
     if (out_trace) CB_HIP(hipMemcpyAsync(out_trace, d_tr, n_reads * sizeof(sh_trace), hipMemcpyDeviceToHost, s));
     CB_HIP(hipStreamSynchronize(s));
-    cleanup();
+    give_back(true);
 #undef CB_HIP
     for (uint64_t r = 0; r < n_reads; ++r)
         if (out_flags[r] == 2) {   // minimap2-rs: Err("Sequence is empty") aborts the run (cleaner.rs:552,566)

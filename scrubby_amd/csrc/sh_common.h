@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <string>
 #include <vector>
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include "../../include/scrubby_hip.h"
 
@@ -30,6 +31,8 @@ struct sh_index {
     uint64_t *d_positions = nullptr;  // n_positions (+1)
     std::vector<uint64_t> contig_len;
     double build_ms = 0;
+    mutable std::mutex pool_mu;          // scratch that sh_classify_batch calls leave behind for the next one (sh_api.hip)
+    mutable std::vector<void *> pool;
 };
 
 // ---- errors ----------------------------------------------------------------------------------
@@ -77,6 +80,7 @@ __host__ __device__ static inline uint32_t sh_nt4(uint32_t c)
 }
 
 // internal entry points implemented across translation units
+void shi_batch_pool_release(sh_index *idx);
 sh_status shi_index_build_fasta_host(const char *path, const sh_opts *opts, int32_t device, sh_index **out);
 sh_status shi_index_build_device(const uint8_t *d_bases, const uint64_t *contig_starts, uint32_t n_contigs,
                                  const sh_opts *opts, int32_t device, hipStream_t stream, sh_index **out);

@@ -592,6 +592,7 @@ extern "C" sh_status sh_index_free(sh_index *idx)
 {
     if (!idx) return SH_OK;
     hipSetDevice(idx->device);
+    shi_batch_pool_release(idx);
     if (idx->d_slots) hipFree(idx->d_slots);
     if (idx->d_positions) hipFree(idx->d_positions);
     delete idx;
