@@ -424,3 +424,33 @@ def test_fasta_taken_apart_on_the_gpu(S, oracle, cfg1, gpu_index, tmp_path, monk
     junk.write_bytes(("ACGTACGT\n" + texts["cols60"]).encode())
     got = oracle.Index.wrap(*S.Index.build_fasta(str(junk), S.preset("sr")).export(), 11, 21).dump()
     assert all(np.array_equal(x, y) for x, y in zip(got, want))
+
+
+def test_classify_batch_from_concurrent_host_threads(S, oracle, cfg1, gpu_index, cpu_index):
+    """The reference shares one aligner between rayon workers (cleaner.rs:546-552); sh_classify_batch must take concurrent
+    calls on one index the same way (each call its own context, taken from / returned to the index's pool)."""
+    import threading
+    P, R, ref, seqs, reads, off = cfg1
+    n = len(off) - 1
+    parts = [(i * n // 4, (i + 1) * n // 4) for i in range(4)]
+    of, _ = cpu_index.classify(oracle.preset("sr"), reads, off, threads=8, want_trace=False)
+    out, errs = {}, []
+
+    def work(i, rounds):
+        try:
+            a, b = parts[i]
+            for _ in range(rounds):
+                f, _, st, rc = gpu_index.classify(reads[int(off[a]):int(off[b])], off[a:b + 1] - off[a], want_trace=False)
+                assert rc == 0 and st["n_reads"] == b - a
+                out[i] = f
+        except Exception as e:                     # surfaced in the main thread
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i, 3)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    got = np.concatenate([out[i] for i in range(4)])
+    assert np.array_equal(got, of)
