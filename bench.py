@@ -174,7 +174,10 @@ def main():
         "k_sketch_probe": (k1_ms, k1_bytes), "k_chain_small": (k2_ms, k2_bytes),
         "repeat path (k_expand + k_sort_lds* + k_sort + k_finalize)": (k3_ms, k3_bytes),
     }
-    dom = max(stages, key=lambda k: stages[k][0])
+    # the roofline object describes ONE kernel, the longest by rocprofv3's per-kernel average (profiles/r01_kernel_summary.txt): for
+    # short reads that is k_sketch_probe (the repeat path is a stage of ~12 kernels, the largest of which, k_expand, is half as long);
+    # the per-stage table stays beside it.  Long reads: the stage that takes longest.
+    dom = "k_sketch_probe" if (not ont and stages["k_sketch_probe"][0] > 0) else max(stages, key=lambda k: stages[k][0])
     d_ms, d_bytes = stages[dom]
     achieved = d_bytes / (d_ms * 1e-3) / 1e9
     roofline = {
@@ -235,7 +238,7 @@ def main():
                              "segment-parallel long-read front end + repeat path" % n_rec if ont else
                              "cfg1-small: 200k records vs 5 Mb" if a.small else
                              "configs[1]: 10M synthetic 2x150bp PE (20M records) vs CHM13v2-sized synthetic reference, sr preset, k-mer/minimizer classifier path"),
-                "records_per_gpu": n_rec, "read_len": L, "host_pct": R.host_pct, "reference_bp": int(G),
+                "records_per_gpu": n_rec, "read_len": (round(n_bases / n_rec, 1) if ont else L), "host_pct": R.host_pct, "reference_bp": int(G),
                 "preset": "map-ont" if ont else "sr", "k": info["k"], "w": info["w"], "records_per_launch": ctx_chunk(a, n_rec),
                 "parallelism": f"read-sharded x{world}, index replicated", "ref_seed": hex(REF_SEED), "read_seed": hex(READ_SEED),
             },
