@@ -100,7 +100,7 @@ typedef struct sh_stats {
     uint64_t n_anchors;        /* anchors the occurrence filter admits on the repeat path (both passes); flag-only calls generate fewer (n_pair_decided) */
     uint64_t n_clusters;       /* independent anchor clusters chained on the repeat path */
     uint64_t n_resketch;       /* reads that took the legacy re-sketch path */
-    uint64_t n_pair_decided;   /* flag-only calls: repeat-path reads decided by two co-diagonal seeds, before any anchor exists */
+    uint64_t n_pair_decided;   /* flag-only calls: reads (LDS path and repeat path) decided by two co-diagonal seeds, before any anchor exists */
 } sh_stats;
 
 typedef struct sh_index sh_index;

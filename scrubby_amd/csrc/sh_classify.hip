@@ -55,7 +55,7 @@ __device__ inline uint32_t lane_id() { return threadIdx.x & 63; }
 // Device counters.  A single address sustains only ~90 M atomics/s on MI355X, so list tails are advanced
 // by whole chunks per wave (WaveAlloc) and statistics are sharded over 64 addresses.
 struct Counters {
-    uint32_t n_small, n_resketch, n_big[2], n_big_defer[2], n_defer, pad0;
+    uint32_t n_small, n_resketch, n_big[2], n_big_defer[2], n_defer, n_small2;      // n_small2: LDS-path reads the pair pass left undecided
     uint32_t n_sort[N_SORT_CLS], n_giant_tiles, n_giant_rounds;
     uint32_t n_long_segs, pad2;
     uint32_t n_cl[4], cl_ticket, pad3;      // global queue of big clusters (k_cluster_dp), by size class
@@ -617,6 +617,7 @@ struct K2Args {
     uint8_t *arena; unsigned long long arena_bytes;
     ChainParams P;
     uint32_t work_begin; // k_chain_large: first list entry to process
+    uint32_t *leftover; int32_t mode;   // k_chain_small: 0 = chain every read; 1 = pair pass (decide or append to `leftover`, counted in ctr->n_small2)
 };
 
 __device__ inline void finish_read(const K2Args &a, uint32_t r, int32_t n_mini, int32_t n_seed, int64_t n_a, int32_t rep_len,
@@ -640,11 +641,54 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
     S.lo = s_lo + lane; S.aux = s_aux + lane; S.qv = s_q + lane; S.gv = s_g + lane;
     uint32_t n_host_wave = 0;
 
+    uint32_t n_pair_wave = 0;
     for (uint32_t base = blockIdx.x * 64; base < n_work; base += gridDim.x * 64) {
         const uint32_t wi = base + lane;
         const bool valid = wi < n_work;
         bool host = false;
-        if (valid) {
+        if (a.mode == 1) {
+            // Pair pass (flag-only).  A read of this path has no filtered seed and at most CAP anchors; with n_a <= max_skip + 1
+            // at most max_skip - 1 anchors sort between any two of them, so two anchors on one diagonal pair_dq_min..pair_dq_max
+            // apart decide it whatever the other seeds' keys are (ChainParams::pair_dq_*: the look-back from the later anchor must
+            // score the earlier one).  Singleton seeds carry their position word in the record: the test costs no gather.
+            // Undecided reads are compacted into `leftover` for a dense second launch (a straggler would otherwise make its whole
+            // wave pay for the sort and the DP).
+            bool undecided = false;
+            uint32_t r = 0;
+            if (valid) {
+                r = a.work[wi];
+                const uint32_t info = a.k1info[r];
+                const uint32_t n_seed = info >> 16;
+                const uint4 *rec = a.records + (size_t)r * a.seed_cap;
+                uint32_t tot = 0;
+                uint64_t w_p = 0, w_pp = 0; uint32_t q_p = 0, q_pp = 0; int have = 0;
+                bool found = false;
+                auto codiag = [&](uint64_t wf, uint32_t qf, uint64_t wg, uint32_t qg) {
+                    const int32_t D = (int32_t)(qg >> 1) - (int32_t)(qf >> 1);
+                    const bool fwf = (uint32_t)(wf & 1u) == (qf & 1u), fwg = (uint32_t)(wg & 1u) == (qg & 1u);
+                    const int32_t dr = (int32_t)((uint32_t)wg >> 1) - (int32_t)((uint32_t)wf >> 1);
+                    return D >= a.P.pair_dq_min && D <= a.P.pair_dq_max && (wf >> 32) == (wg >> 32) && fwf == fwg && (fwf ? dr == D : dr == -D);
+                };
+                for (uint32_t i = 0; i < n_seed; ++i) {
+                    const uint4 sd = rec[i];
+                    const uint32_t occ = sd.z & 0x7fffffffu;
+                    tot += occ;
+                    if (occ == 1) {
+                        const uint64_t w1 = (uint64_t)sd.y << 32 | sd.x;
+                        if (have >= 1) found |= codiag(w_p, q_p, w1, sd.w);
+                        if (have >= 2) found |= codiag(w_pp, q_pp, w1, sd.w);
+                        w_pp = w_p; q_pp = q_p; w_p = w1; q_p = sd.w; ++have;
+                    }
+                }
+                if (found && tot <= (uint32_t)a.P.max_skip + 1u) {
+                    finish_read(a, r, (int32_t)(info & 0xffffu), (int32_t)n_seed, (int64_t)tot, 0, 0, 1, a.P.min_sc);
+                    host = true;
+                } else undecided = true;
+            }
+            n_pair_wave += (uint32_t)__popcll(__ballot(host));
+            const uint32_t li = wave_append(&a.ctr->n_small2, undecided);
+            if (undecided) a.leftover[li] = r;
+        } else if (valid) {
             const uint32_t r = a.work[wi];
             const uint32_t info = a.k1info[r];
             const int32_t n_mini = (int32_t)(info & 0xffffu), n_seed = (int32_t)(info >> 16);
@@ -669,6 +713,7 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
         n_host_wave += (uint32_t)__popcll(__ballot(host));
     }
     if (lane == 0 && n_host_wave) atomicAdd(&a.ctr->sh_host[SHARD()], n_host_wave);
+    if (lane == 0 && n_pair_wave) atomicAdd(&a.ctr->sh_pair[SHARD()], n_pair_wave);
 }
 
 // stable sort of the first n lanes' (x, q) by x: rank by comparison with every broadcast key, then push
@@ -1694,7 +1739,7 @@ struct sh_ctx {
     uint32_t max_read_len = 0, seed_cap = 192, lds_words = 0;
     bool use_k1 = true;
     uint4 *d_records = nullptr;
-    uint32_t *d_k1info = nullptr, *d_work_small = nullptr, *d_work_resketch = nullptr, *d_work_defer = nullptr, *d_work_defer2 = nullptr;
+    uint32_t *d_k1info = nullptr, *d_work_small = nullptr, *d_work_small2 = nullptr, *d_work_resketch = nullptr, *d_work_defer = nullptr, *d_work_defer2 = nullptr;
     uint32_t *d_big[2][2] = {};       // [pass][ping-pong] read lists of the repeat path
     Counters *d_ctr = nullptr;
     Counters *h_ctr = nullptr;        // pinned
@@ -1761,6 +1806,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
     if ((e = hipMalloc(&c->d_records, (n_tiles * 64) * c->seed_cap * sizeof(uint4))) != hipSuccess) return fail(e, "records");
     if ((e = hipMalloc(&c->d_k1info, max_reads * 4)) != hipSuccess) return fail(e, "k1info");
     if ((e = hipMalloc(&c->d_work_small, max_reads * 4)) != hipSuccess) return fail(e, "work_small");
+    if ((e = hipMalloc(&c->d_work_small2, max_reads * 4)) != hipSuccess) return fail(e, "work_small2");
     if ((e = hipMalloc(&c->d_work_resketch, max_reads * 4)) != hipSuccess) return fail(e, "work_resketch");
     if ((e = hipMalloc(&c->d_work_defer, max_reads * 4)) != hipSuccess) return fail(e, "work_defer");
     if ((e = hipMalloc(&c->d_work_defer2, max_reads * 4)) != hipSuccess) return fail(e, "work_defer2");
@@ -1837,7 +1883,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
 extern "C" sh_status sh_ctx_destroy(sh_ctx *c)
 {
     if (!c) return SH_OK;
-    hipFree(c->d_records); hipFree(c->d_k1info); hipFree(c->d_work_small); hipFree(c->d_work_resketch);
+    hipFree(c->d_records); hipFree(c->d_k1info); hipFree(c->d_work_small); hipFree(c->d_work_small2); hipFree(c->d_work_resketch);
     hipFree(c->d_work_defer); hipFree(c->d_work_defer2);
     for (auto &pp : c->d_big) for (auto p : pp) hipFree(p);
     hipFree(c->d_ctr); if (c->h_ctr) hipHostFree(c->h_ctr); hipFree(c->d_arena); hipFree(c->d_long);
@@ -1967,7 +2013,12 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         hipStream_t sk = (c->par & 1) ? c->sx[3] : s;
         SH_HIP(hipEventRecord(c->evx[4], s));
         SH_HIP(hipStreamWaitEvent(sk, c->evx[4], 0));
-        b.work = c->d_work_small; b.work_count = &c->d_ctr->n_small; b.work_begin = 0;
+        b.work = c->d_work_small; b.work_count = &c->d_ctr->n_small; b.work_begin = 0; b.leftover = c->d_work_small2; b.mode = 0;
+        if (d_trace == nullptr && c->P.pair_dq_max > 0) {      // flag-only: pair pass over all reads of the path, then the undecided ones, dense
+            b.mode = 1;
+            hipLaunchKernelGGL(k_chain_small<K2_CAP>, dim3(grid), dim3(64), 0, sk, b);
+            b.mode = 0; b.work = c->d_work_small2; b.work_count = &c->d_ctr->n_small2;
+        }
         hipLaunchKernelGGL(k_chain_small<K2_CAP>, dim3(grid), dim3(64), 0, sk, b);
         SH_HIP(hipEventRecord(c->ev[2], sk));
         SH_HIP(hipEventRecord(c->evx[5], sk));
