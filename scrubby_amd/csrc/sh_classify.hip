@@ -56,6 +56,7 @@ __device__ inline uint32_t lane_id() { return threadIdx.x & 63; }
 // by whole chunks per wave (WaveAlloc) and statistics are sharded over 64 addresses.
 struct Counters {
     uint32_t n_small, n_resketch, n_big[2], n_big_defer[2], n_defer, n_small2;      // n_small2: LDS-path reads the pair pass left undecided
+    uint32_t n_big_total, pad1;   // repeat-path reads before the pair pass took its share (0: no pair pass)
     uint32_t n_sort[N_SORT_CLS], n_giant_tiles, n_giant_rounds;
     uint32_t n_long_segs, pad2;
     uint32_t n_cl[4], cl_ticket, pad3;      // global queue of big clusters (k_cluster_dp), by size class
@@ -617,7 +618,7 @@ struct K2Args {
     uint8_t *arena; unsigned long long arena_bytes;
     ChainParams P;
     uint32_t work_begin; // k_chain_large: first list entry to process
-    uint32_t *leftover; int32_t mode;   // k_chain_small: 0 = chain every read; 1 = pair pass (decide or append to `leftover`, counted in ctr->n_small2)
+    uint32_t *leftover; uint32_t *leftover_count;   // k_pair_pass: reads it leaves undecided
 };
 
 __device__ inline void finish_read(const K2Args &a, uint32_t r, int32_t n_mini, int32_t n_seed, int64_t n_a, int32_t rep_len,
@@ -641,54 +642,11 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
     S.lo = s_lo + lane; S.aux = s_aux + lane; S.qv = s_q + lane; S.gv = s_g + lane;
     uint32_t n_host_wave = 0;
 
-    uint32_t n_pair_wave = 0;
     for (uint32_t base = blockIdx.x * 64; base < n_work; base += gridDim.x * 64) {
         const uint32_t wi = base + lane;
         const bool valid = wi < n_work;
         bool host = false;
-        if (a.mode == 1) {
-            // Pair pass (flag-only).  A read of this path has no filtered seed and at most CAP anchors; with n_a <= max_skip + 1
-            // at most max_skip - 1 anchors sort between any two of them, so two anchors on one diagonal pair_dq_min..pair_dq_max
-            // apart decide it whatever the other seeds' keys are (ChainParams::pair_dq_*: the look-back from the later anchor must
-            // score the earlier one).  Singleton seeds carry their position word in the record: the test costs no gather.
-            // Undecided reads are compacted into `leftover` for a dense second launch (a straggler would otherwise make its whole
-            // wave pay for the sort and the DP).
-            bool undecided = false;
-            uint32_t r = 0;
-            if (valid) {
-                r = a.work[wi];
-                const uint32_t info = a.k1info[r];
-                const uint32_t n_seed = info >> 16;
-                const uint4 *rec = a.records + (size_t)r * a.seed_cap;
-                uint32_t tot = 0;
-                uint64_t w_p = 0, w_pp = 0; uint32_t q_p = 0, q_pp = 0; int have = 0;
-                bool found = false;
-                auto codiag = [&](uint64_t wf, uint32_t qf, uint64_t wg, uint32_t qg) {
-                    const int32_t D = (int32_t)(qg >> 1) - (int32_t)(qf >> 1);
-                    const bool fwf = (uint32_t)(wf & 1u) == (qf & 1u), fwg = (uint32_t)(wg & 1u) == (qg & 1u);
-                    const int32_t dr = (int32_t)((uint32_t)wg >> 1) - (int32_t)((uint32_t)wf >> 1);
-                    return D >= a.P.pair_dq_min && D <= a.P.pair_dq_max && (wf >> 32) == (wg >> 32) && fwf == fwg && (fwf ? dr == D : dr == -D);
-                };
-                for (uint32_t i = 0; i < n_seed; ++i) {
-                    const uint4 sd = rec[i];
-                    const uint32_t occ = sd.z & 0x7fffffffu;
-                    tot += occ;
-                    if (occ == 1) {
-                        const uint64_t w1 = (uint64_t)sd.y << 32 | sd.x;
-                        if (have >= 1) found |= codiag(w_p, q_p, w1, sd.w);
-                        if (have >= 2) found |= codiag(w_pp, q_pp, w1, sd.w);
-                        w_pp = w_p; q_pp = q_p; w_p = w1; q_p = sd.w; ++have;
-                    }
-                }
-                if (found && tot <= (uint32_t)a.P.max_skip + 1u) {
-                    finish_read(a, r, (int32_t)(info & 0xffffu), (int32_t)n_seed, (int64_t)tot, 0, 0, 1, a.P.min_sc);
-                    host = true;
-                } else undecided = true;
-            }
-            n_pair_wave += (uint32_t)__popcll(__ballot(host));
-            const uint32_t li = wave_append(&a.ctr->n_small2, undecided);
-            if (undecided) a.leftover[li] = r;
-        } else if (valid) {
+        if (valid) {
             const uint32_t r = a.work[wi];
             const uint32_t info = a.k1info[r];
             const int32_t n_mini = (int32_t)(info & 0xffffu), n_seed = (int32_t)(info >> 16);
@@ -713,7 +671,92 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
         n_host_wave += (uint32_t)__popcll(__ballot(host));
     }
     if (lane == 0 && n_host_wave) atomicAdd(&a.ctr->sh_host[SHARD()], n_host_wave);
-    if (lane == 0 && n_pair_wave) atomicAdd(&a.ctr->sh_pair[SHARD()], n_pair_wave);
+}
+
+// Pair pass (flag-only; ChainParams::pair_dq_*), one lane per read over a work list.  Two singleton seeds (their position words
+// are in the seed records: no gather) whose anchors lie on one diagonal pair_dq_min..pair_dq_max apart decide a read as mapped,
+// because mg_lchain_dp's look-back from the later anchor must then score the earlier one - provided at most max_skip - 1 anchors
+// can sort between the two:
+//   distinct == 0  reads of the LDS path (no filtered seed): true whenever the read has at most max_skip + 1 anchors in all;
+//   distinct == 1  reads of the repeat path: true when all seeds of the read have different keys (a reference position holds
+//                  one minimizer, so each of the <= 23 positions between the two anchors contributes at most one anchor).  Keys
+//                  are compared through a 32-bit function of the slot payload in a lane-private LDS strip (equal keys always
+//                  collide, so a duplicate is never missed); singletons are never filtered by mm_seed_select, and checking all
+//                  seeds instead of the selected ones only makes the premise stronger.  Reads with more than 32 seeds are left.
+// Undecided reads are compacted into `leftover` (dense input for k_chain_small / k_expand: a straggler would otherwise make
+// its whole wave pay for the full path).
+__global__ __launch_bounds__(64) void k_pair_pass(K2Args a, int distinct)
+{
+    __shared__ uint32_t s_key[32 * 64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_work = *a.work_count;
+    uint32_t n_host_wave = 0;
+    unsigned long long anchors_wave = 0;
+    for (uint32_t base = blockIdx.x * 64; base < n_work; base += gridDim.x * 64) {
+        const uint32_t wi = base + lane;
+        const bool valid = wi < n_work;
+        uint32_t r = 0, info = 0, n_seed = 0, tot = 0;
+        bool found = false;
+        if (valid) {
+            r = a.work[wi];
+            info = a.k1info[r];
+            n_seed = info >> 16;
+            const uint4 *rec = a.records + (size_t)r * a.seed_cap;
+            uint64_t w_p = 0, w_pp = 0; uint32_t q_p = 0, q_pp = 0; int have = 0;
+            auto codiag = [&](uint64_t wf, uint32_t qf, uint64_t wg, uint32_t qg) {
+                const int32_t D = (int32_t)(qg >> 1) - (int32_t)(qf >> 1);
+                const bool fwf = (uint32_t)(wf & 1u) == (qf & 1u), fwg = (uint32_t)(wg & 1u) == (qg & 1u);
+                const int32_t dr = (int32_t)((uint32_t)wg >> 1) - (int32_t)((uint32_t)wf >> 1);
+                return D >= a.P.pair_dq_min && D <= a.P.pair_dq_max && (wf >> 32) == (wg >> 32) && fwf == fwg && (fwf ? dr == D : dr == -D);
+            };
+            const uint32_t lim = distinct ? (n_seed <= 32u ? n_seed : 0u) : n_seed;
+            for (uint32_t i = 0; i < lim; ++i) {
+                const uint4 sd = rec[i];
+                const uint32_t occ = sd.z & 0x7fffffffu;
+                if (occ <= (uint32_t)a.P.mid_occ) tot += occ;
+                if (distinct) s_key[i * 64 + lane] = sd.x ^ (sd.y * 0x9E3779B1u);
+                if (occ == 1) {
+                    const uint64_t w1 = (uint64_t)sd.y << 32 | sd.x;
+                    if (have >= 1) found |= codiag(w_p, q_p, w1, sd.w);
+                    if (have >= 2) found |= codiag(w_pp, q_pp, w1, sd.w);
+                    w_pp = w_p; q_pp = q_p; w_p = w1; q_p = sd.w; ++have;
+                }
+            }
+            if (!distinct) found = found && tot <= (uint32_t)a.P.max_skip + 1u;
+        }
+        if (distinct && __ballot(found) != 0) {
+            uint32_t mx = found ? n_seed : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+            bool dup = false;
+            for (uint32_t i = 1; i < mx; ++i) {
+                const uint32_t ki = s_key[i * 64 + lane];
+                for (uint32_t j = 0; j < i; ++j) dup |= (i < n_seed) && s_key[j * 64 + lane] == ki;
+            }
+            found = found && !dup;
+        }
+        if (found) {
+            a.flags[r] = 1;
+            write_trace(a.trace, r, (int32_t)(info & 0xffffu), (int32_t)n_seed, (int32_t)tot, 0, 0, 1, a.P.min_sc, 1);
+            anchors_wave += distinct ? tot : 0u;
+        }
+        n_host_wave += (uint32_t)__popcll(__ballot(found));
+        const bool undecided = valid && !found;
+        const uint32_t li = wave_append(a.leftover_count, undecided);
+        if (undecided) a.leftover[li] = r;
+    }
+    if (lane == 0 && n_host_wave) { atomicAdd(&a.ctr->sh_host[SHARD()], n_host_wave); atomicAdd(&a.ctr->sh_pair[SHARD()], n_host_wave); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) anchors_wave += (unsigned long long)__shfl_xor((long long)anchors_wave, o);
+    if (lane == 0 && anchors_wave) atomicAdd(&a.ctr->sh_anchors[SHARD()], anchors_wave);
+}
+
+// after the pair pass over the repeat path's list: the survivors (collected in the deferral list) become the list
+__global__ void k_pair_swap(Counters *ctr)
+{
+    ctr->n_big_total = ctr->n_big[0];
+    ctr->n_big[0] = ctr->n_big_defer[0];
+    ctr->n_big_defer[0] = 0;
 }
 
 // stable sort of the first n lanes' (x, q) by x: rank by comparison with every broadcast key, then push
@@ -871,7 +914,7 @@ struct K3Args {
 // occurrence list is shortest, walks that list 64 occurrences at a time and looks each one's co-diagonal partner up in the
 // other seed's (ascending) list by binary search.  true: the read has a mapping.  false: nothing is known.
 #define PAIR_MAX_COST 512u        // load rounds a pair may cost before the full path is the better deal
-__device__ inline bool pair_decides(const uint4 rec, uint32_t my_n, uint32_t n_seed, uint32_t lane, const uint64_t *__restrict__ pos, const ChainParams &P)
+__device__ inline bool pair_decides(const uint4 rec, uint32_t my_n, uint32_t n_seed, uint32_t lane, const uint64_t *__restrict__ pos, const ChainParams &P, uint32_t *dbg_cost0 = nullptr)
 {
     const uint32_t qp = rec.w >> 1;
     const bool sel = my_n > 0;
@@ -896,6 +939,7 @@ __device__ inline bool pair_decides(const uint4 rec, uint32_t my_n, uint32_t n_s
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = (unsigned long long)__shfl_xor((long long)key, o); key = other < key ? other : key; }
     if ((uint32_t)(key >> 32) > PAIR_MAX_COST) return false;
+    if (dbg_cost0 && (uint32_t)(key >> 32) == 0 && lane == 0) atomicAdd(dbg_cost0, 1u);
     const uint32_t lf = (uint32_t)key & 63u, lg = rdlane(p_u, lf);          // F: earlier in the query, G: later
     const uint32_t nF = rdlane(my_n, lf), nG = rdlane(my_n, lg);
     const uint32_t D = (rdlane(rec.w, lg) >> 1) - (rdlane(rec.w, lf) >> 1);
@@ -1088,7 +1132,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
             }
             continue;
         }
-        if (!LONG && a.flag_only && P.pair_dq_max > 0 && n_st == 1 && n_a > (uint32_t)P.pair_min_anchors && pair_decides(rec0, my_n0, n_seed, lane, a.positions, P)) {
+        if (!LONG && a.flag_only && P.pair_dq_max > 0 && n_st == 1 && n_a > (uint32_t)P.pair_min_anchors && pair_decides(rec0, my_n0, n_seed, lane, a.positions, P, (a.dbg & 16) ? &a.ctr->n_leg_reason[3] : nullptr)) {
             // decided without a single anchor: sh_stats.n_anchors still counts what the occurrence filter admitted
             if (lane == 0) { BigMeta m{r, n_a, rep_len, 0u}; a.B.meta[w] = m; a.B.acc_nu[w] = 1; a.B.acc_best[w] = P.min_sc; }
             anchors_wave += n_a; ++n_pair;
@@ -1998,6 +2042,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     }
     SH_HIP(hipEventRecord(c->ev[1], s));
 
+    const bool pair_pass = d_trace == nullptr && c->P.pair_dq_max > 0 && c->use_k1;
     K2Args b{};
     b.offsets = d_offsets; b.bases = d_bases; b.n_reads = n_reads;
     b.slots = (const uint4 *)idx->d_slots; b.lg_slots = idx->lg_slots; b.w = idx->w;
@@ -2013,11 +2058,11 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         hipStream_t sk = (c->par & 1) ? c->sx[3] : s;
         SH_HIP(hipEventRecord(c->evx[4], s));
         SH_HIP(hipStreamWaitEvent(sk, c->evx[4], 0));
-        b.work = c->d_work_small; b.work_count = &c->d_ctr->n_small; b.work_begin = 0; b.leftover = c->d_work_small2; b.mode = 0;
-        if (d_trace == nullptr && c->P.pair_dq_max > 0) {      // flag-only: pair pass over all reads of the path, then the undecided ones, dense
-            b.mode = 1;
-            hipLaunchKernelGGL(k_chain_small<K2_CAP>, dim3(grid), dim3(64), 0, sk, b);
-            b.mode = 0; b.work = c->d_work_small2; b.work_count = &c->d_ctr->n_small2;
+        b.work = c->d_work_small; b.work_count = &c->d_ctr->n_small; b.work_begin = 0;
+        if (pair_pass) {      // flag-only: pair pass over all reads of the path, then the undecided ones, dense
+            b.leftover = c->d_work_small2; b.leftover_count = &c->d_ctr->n_small2;
+            hipLaunchKernelGGL(k_pair_pass, dim3(grid), dim3(64), 0, sk, b, 0);
+            b.work = c->d_work_small2; b.work_count = &c->d_ctr->n_small2;
         }
         hipLaunchKernelGGL(k_chain_small<K2_CAP>, dim3(grid), dim3(64), 0, sk, b);
         SH_HIP(hipEventRecord(c->ev[2], sk));
@@ -2035,6 +2080,14 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     // pass 0 (mid_occ) over the reads K2 routed, pass 1 (max_occ) over the reads pass 0 could not chain;
     // reads that found no arena room come back in the next iteration
     int cur0 = 0, cur1 = 0;
+    if (pair_pass) {      // the repeat path's list: reads two singleton seeds decide never reach k_expand; the rest moves to the other list
+        K2Args pb = b;
+        pb.work = c->d_big[0][0]; pb.work_count = &c->d_ctr->n_big[0];
+        pb.leftover = c->d_big[0][1]; pb.leftover_count = &c->d_ctr->n_big_defer[0];
+        hipLaunchKernelGGL(k_pair_pass, dim3(grid), dim3(64), 0, s, pb, 1);
+        hipLaunchKernelGGL(k_pair_swap, dim3(1), dim3(1), 0, s, c->d_ctr);
+        cur0 = 1;
+    }
     bool first = true;
     Counters snap{};
     for (int iter = 0;; ++iter) {
@@ -2059,7 +2112,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         SH_HIP(hipStreamSynchronize(s));
         SH_HIP(hipGetLastError());
         if (first) { snap = *c->h_ctr; first = false; }
-        if (k.dbg & 16) fprintf(stderr, "[dbg] iter %d resketch %u reasons %u %u %u pair-decided(dbg) %u segs %u big %u/%u defer %u/%u\n", iter, c->h_ctr->n_resketch, c->h_ctr->n_leg_reason[0], c->h_ctr->n_leg_reason[1], c->h_ctr->n_leg_reason[2], c->h_ctr->n_leg_reason[3], c->h_ctr->n_long_segs, c->h_ctr->n_big[0], c->h_ctr->n_big[1], c->h_ctr->n_big_defer[0], c->h_ctr->n_big_defer[1]);
+        if (k.dbg & 16) fprintf(stderr, "[dbg] iter %d resketch %u reasons %u %u %u pair tests between two singletons (dbg) %u segs %u big %u/%u defer %u/%u\n", iter, c->h_ctr->n_resketch, c->h_ctr->n_leg_reason[0], c->h_ctr->n_leg_reason[1], c->h_ctr->n_leg_reason[2], c->h_ctr->n_leg_reason[3], c->h_ctr->n_long_segs, c->h_ctr->n_big[0], c->h_ctr->n_big[1], c->h_ctr->n_big_defer[0], c->h_ctr->n_big_defer[1]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] clusters chained by k_cluster_dp by class: %llu %llu %llu %llu, their anchors %llu %llu %llu %llu\n", c->h_ctr->cl_tot[0], c->h_ctr->cl_tot[1], c->h_ctr->cl_tot[2], c->h_ctr->cl_tot[3], c->h_ctr->cl_anchor_tot[0], c->h_ctr->cl_anchor_tot[1], c->h_ctr->cl_anchor_tot[2], c->h_ctr->cl_anchor_tot[3]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] reads (anchors) by sort class: <=64 %llu (%llu), <=256 %llu (%llu), <=512 %llu (%llu), <=1024 %llu (%llu), <=2048 %llu (%llu), <=4096 %llu (%llu), giant %llu (%llu)\n", c->h_ctr->sort_tot[6], c->h_ctr->sort_anchor_tot[6], c->h_ctr->sort_tot[0], c->h_ctr->sort_anchor_tot[0], c->h_ctr->sort_tot[1], c->h_ctr->sort_anchor_tot[1], c->h_ctr->sort_tot[2], c->h_ctr->sort_anchor_tot[2], c->h_ctr->sort_tot[3], c->h_ctr->sort_anchor_tot[3], c->h_ctr->sort_tot[4], c->h_ctr->sort_anchor_tot[4], c->h_ctr->sort_tot[5], c->h_ctr->sort_anchor_tot[5]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] ring DP: chunks in window %llu, beyond %llu, far rescans %llu\n", c->h_ctr->cl_dbg[0], c->h_ctr->cl_dbg[1], c->h_ctr->cl_dbg[2]);
@@ -2102,8 +2155,9 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         uint64_t sum_host = 0, sum_mini = 0, sum_anchors = 0, sum_clusters = 0, sum_pair = 0;
         for (int i = 0; i < 64; ++i) { sum_host += c->h_ctr->sh_host[i]; sum_mini += c->h_ctr->sh_mini[i]; sum_anchors += c->h_ctr->sh_anchors[i]; sum_clusters += c->h_ctr->sh_clusters[i]; sum_pair += c->h_ctr->sh_pair[i]; }
         stats->n_reads += n_reads; stats->n_bases += n_bases;
-        stats->n_host += sum_host; stats->n_no_seed += n_reads - snap.n_small - snap.n_big[0] - snap.n_resketch;
-        uint64_t nl = (uint64_t)snap.n_resketch + snap.n_big[0];
+        stats->n_host += sum_host; const uint32_t n_big0 = snap.n_big_total ? snap.n_big_total : snap.n_big[0];
+        stats->n_no_seed += n_reads - snap.n_small - n_big0 - snap.n_resketch;
+        uint64_t nl = (uint64_t)snap.n_resketch + n_big0;
         stats->n_chain_large += nl; stats->n_chain_small += snap.n_small;
         stats->n_minimizers += sum_mini;
         stats->n_anchors += sum_anchors; stats->n_clusters += sum_clusters; stats->n_resketch += resk_done; stats->n_pair_decided += sum_pair;
