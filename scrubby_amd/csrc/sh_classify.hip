@@ -1797,7 +1797,7 @@ struct sh_ctx {
     unsigned long long *d_seg_off = nullptr, *d_seed_off = nullptr;
     uint64_t *d_mz_hash = nullptr; uint4 *d_lrec = nullptr;
     hipStream_t sx[4] = {};          // side streams: K2 and the sort classes run beside the main stream
-    int par = 1;                     // bit 0: K2 on a side stream (+2 %), bit 1: sort classes side by side (measured: -9 %, off) (SCRUBBY_HIP_STREAMS)
+    int par = 1;                     // bit 0: K2 on a side stream (SCRUBBY_HIP_STREAMS=0: on the main stream)
     hipEvent_t evx[6] = {};
 };
 
@@ -1965,8 +1965,9 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     // 6144 waves for 4096 resident (103 VGPRs: 4 per SIMD): measured best; 4096 or 5120 waves, or 5 waves per SIMD at 96 VGPRs, are 0-3 % slower
     if (k.seed_off) hipLaunchKernelGGL(k_expand<true>, dim3(grid * 3), dim3(64), 0, s, k);
     else hipLaunchKernelGGL(k_expand<false>, dim3(grid * 3), dim3(64), 0, s, k);
-    // the four sort classes are independent: run them side by side so that they fill each other's tails
-    const bool side = (c->par & 2) != 0;
+    // the sort classes run one after the other.  Side by side (streams sx[0..2]) measured 9 % slower when they carried the whole repeat
+    // path (they fight for LDS); that mode predates k_group_probe, which the class-4 and giant kernels must follow: it stays off.
+    const bool side = false;
     hipStream_t s0 = side ? c->sx[0] : s, s1 = side ? c->sx[1] : s, g = side ? c->sx[2] : s;
     if (side) {
         SH_HIP(hipEventRecord(c->evx[0], s));
