@@ -913,7 +913,8 @@ struct K3Args {
 // contribute, 0 = filtered).  Picks the pair of selected seeds pair_dq_min..pair_dq_max apart in the query whose shorter
 // occurrence list is shortest, walks that list 64 occurrences at a time and looks each one's co-diagonal partner up in the
 // other seed's (ascending) list by binary search.  true: the read has a mapping.  false: nothing is known.
-#define PAIR_MAX_COST 512u        // load rounds a pair may cost before the full path is the better deal
+#define PAIR_MAX_COST 4096u       // load rounds a pair may cost before the full path is the better deal (a satellite read: ~600 rounds against 26 k anchors to expand, sort and chain)
+#define PAIR_ATTEMPTS 3
 __device__ inline bool pair_decides(const uint4 rec, uint32_t my_n, uint32_t n_seed, uint32_t lane, const uint64_t *__restrict__ pos, const ChainParams &P, uint32_t *dbg_cost0 = nullptr)
 {
     const uint32_t qp = rec.w >> 1;
@@ -928,18 +929,19 @@ __device__ inline bool pair_decides(const uint4 rec, uint32_t my_n, uint32_t n_s
         const int32_t d = (int32_t)qu - (int32_t)qp;
         if (sel && d >= P.pair_dq_min && d <= P.pair_dq_max && ou < p_occ) { p_occ = ou; p_u = u; }
     }
-    if (__ballot(dup) != 0) return false;
+    if (__ballot(dup) != 0) { if (dbg_cost0 && lane == 0) atomicAdd(dbg_cost0 - 3, 1u); return false; }       // dbg: n_leg_reason[0] = duplicate keys
     // cost of a pair ~ dependent loads: the shorter list is walked (one load round per 64), each step a binary search of the longer
     uint32_t cost = UINT32_MAX;
     if (p_occ != UINT32_MAX) {
         const uint32_t mn = my_n < p_occ ? my_n : p_occ, mx = my_n < p_occ ? p_occ : my_n;
         cost = (mn > 1 ? (mn + 63) / 64 : 0) + ((mn + 63) / 64) * (mx > 1 ? 32 - __clz(mx) : 0);
     }
+  for (int attempt = 0; attempt < PAIR_ATTEMPTS; ++attempt) {      // the cheapest pair first; a pair that finds nothing retires its earlier seed
     unsigned long long key = (unsigned long long)cost << 32 | lane;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = (unsigned long long)__shfl_xor((long long)key, o); key = other < key ? other : key; }
-    if ((uint32_t)(key >> 32) > PAIR_MAX_COST) return false;
-    if (dbg_cost0 && (uint32_t)(key >> 32) == 0 && lane == 0) atomicAdd(dbg_cost0, 1u);
+    if ((uint32_t)(key >> 32) > PAIR_MAX_COST) { if (dbg_cost0 && lane == 0 && attempt == 0) atomicAdd(dbg_cost0 - 2, 1u); break; }   // dbg: [1] = no pair in range / too costly
+    if (dbg_cost0 && (uint32_t)(key >> 32) == 0 && lane == 0 && attempt == 0) atomicAdd(dbg_cost0, 1u);
     const uint32_t lf = (uint32_t)key & 63u, lg = rdlane(p_u, lf);          // F: earlier in the query, G: later
     const uint32_t nF = rdlane(my_n, lf), nG = rdlane(my_n, lg);
     const uint32_t D = (rdlane(rec.w, lg) >> 1) - (rdlane(rec.w, lf) >> 1);
@@ -967,6 +969,9 @@ __device__ inline bool pair_decides(const uint4 rec, uint32_t my_n, uint32_t n_s
         }
         if (__ballot(found) != 0) return true;
     }
+    if (lane == lf) cost = UINT32_MAX;
+  }
+    if (dbg_cost0 && lane == 0) atomicAdd(dbg_cost0 - 1, 1u);      // dbg: [2] = searched, no co-diagonal partner
     return false;
 }
 
