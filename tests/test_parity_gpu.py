@@ -454,3 +454,31 @@ def test_classify_batch_from_concurrent_host_threads(S, oracle, cfg1, gpu_index,
     assert not errs, errs
     got = np.concatenate([out[i] for i in range(4)])
     assert np.array_equal(got, of)
+
+
+def test_pair_test_on_satellite_heavy_reference(S, oracle, monkeypatch):
+    """Tandem arrays (171 / 68 / 5 bp monomers) fill 45 % of this reference: seeds with thousands of occurrences (the pair
+    test walks one list and binary-searches the other, retries, cost cap), reads whose k-mers repeat inside the read (68-bp and
+    5-bp arrays: the distinct-key premise fails) and re-chained reads (max_occ pass).  Flag-only results with and without the
+    pair tests must equal the oracle's."""
+    contigs = [700_000, 500_000]
+    Po = oracle.ref_params(0x5C2B0B01, contigs, sat_pct=45, rep_pct=30, n_sat_fam=3, n_rep_fam=20)
+    ref = oracle.synth_ref(Po, 0, Po.genome_len)
+    seqs = [ref[Po.contig_start[i]:Po.contig_start[i + 1]] for i in range(len(contigs))]
+    Ro = oracle.read_params(0x5C2B0B02)
+    n = 6000
+    bases = oracle.synth_reads(Po, Ro, 0, n)
+    offs = np.arange(n + 1, dtype=np.uint64) * 150
+    gidx = S.Index.build([bytes(s) for s in seqs], S.preset("sr"))
+    cidx = oracle.Index.build(seqs, 11, 21)
+    of, ot = cidx.classify(oracle.preset("sr"), bases, offs, threads=8)
+    f_on, _, st_on, rc = gidx.classify(bases, offs, want_trace=False)
+    assert rc == 0 and np.array_equal(f_on, of), f"{int((f_on != of).sum())} flags differ with the pair tests"
+    print({k: st_on[k] for k in ("n_reads", "n_host", "n_chain_small", "n_chain_large", "n_anchors", "n_pair_decided")})
+    assert st_on["n_chain_large"] > 500 and 0 < st_on["n_pair_decided"] < st_on["n_chain_large"] + st_on["n_chain_small"]
+    monkeypatch.setenv("SCRUBBY_HIP_NO_PAIR", "1")
+    f_off, _, st_off, rc = gidx.classify(bases, offs, want_trace=False)
+    assert np.array_equal(f_off, of) and st_off["n_pair_decided"] == 0
+    monkeypatch.delenv("SCRUBBY_HIP_NO_PAIR")
+    gf, gt, st, rc = gidx.classify(bases, offs, want_trace=True)
+    assert_trace_equal(S, gf, gt, of, ot)
