@@ -3,36 +3,41 @@
 // Replaces the hot loop of the reference's in-process aligner path
 //     .map(|(id, sequence)| aligner.map(&sequence, false, false, None, None) ... mappings.len() > 0)
 //     /root/reference/src/cleaner.rs:550-558
-// with three hand-written HIP kernels over a read batch resident in HBM:
+// with hand-written HIP kernels over a read batch resident in HBM (DESIGN.md §3 has the table with what bounds each):
 //
 //   K1 k_sketch_probe   one wave per tile of 64 consecutive reads, one lane per read.
 //        A  the tile's bases (one contiguous byte range) are loaded coalesced, 16 B per lane,
 //           converted to 2-bit codes + an ambiguity bit and staged in LDS;
 //        B  every lane runs the (w,k)-minimizer state machine over its read with the w-entry
-//           window in VGPRs (sh_sketch.h), queueing minimizers in an LDS list;
-//        C  when a list fills (and at the end) the wave probes the HBM hash index for all queued
-//           minimizers, 4 independent 16-B gathers in flight per lane, and appends one 16-B seed
-//           record per hit to the read's own record row.
+//           window in VGPRs (sh_sketch.h: SketchPacked, one 64-bit word per ring entry), queueing
+//           minimizers in a per-lane LDS ring;
+//        C  every W-step block starts by issuing up to 4 home-slot gathers per lane for what earlier
+//           blocks queued and ends by consuming them (one 16-B seed record per hit, per-read row).
 //        Reads without a single hit are final here (flag 0): no anchor => no mapping; the others are
-//        routed to K2 (no seed above mid_occ, <= 32 anchors) or to the repeat path.
-//   K2 k_chain_small    one lane per read with >=1 seed: occurrence filter, anchors, chaining DP and
-//        backtrack entirely in LDS (11 B per anchor, lane-interleaved), up to CAP anchors.
+//        routed to the LDS path (no seed above mid_occ, <= 32 anchors) or to the repeat path.
+//   k_pair_pass         flag-only calls: one lane per read over either list; two singleton seeds on one
+//        diagonal decide a read from its seed records alone (ChainParams::pair_dq_*); the undecided
+//        reads are compacted for the kernels below.
+//   K2 k_chain_small    one lane per read of the LDS path: anchors, chaining DP and backtrack
+//        entirely in LDS (11 B per anchor, lane-interleaved), up to CAP anchors.
 //   K3 the repeat path, for reads with more anchors (29 % of the host reads of the CHM13-sized
 //        workload, carrying 90 % of all anchors).  Sorted anchors split into CLUSTERS at every gap
 //        > max_dist_x (or strand / contig change); the chaining DP window, its max_ii shortcut and
 //        the backtrack never cross such a gap, so clusters are independent DP problems and the
 //        per-read result is (sum of chains, max score) over its clusters:
-//          k_expand       one wave per read: lane-per-seed occurrence filter (mm_seed_select by ballots),
-//                         anchors written coalesced to the HBM arena, <= 64 anchors sorted in registers
-//          k_sort         one wave per longer read: 64-anchor tiles ranked in registers, then merge-path
-//                         rounds between two arena buffers; cluster boundaries by ballot
-//                         and chained on the spot (one lane per cluster start, state in 1.5 KiB of LDS)
-//          k_sort_lds     one block per read with <= 1024 / <= 4096 anchors: stable merge sort in LDS, then
+//          k_expand       one wave per read: lane-per-seed occurrence filter (mm_seed_select by ballots);
+//                         flag-only: the general pair test (pair_decides: occurrence lists walked and
+//                         binary-searched); else anchors written to the HBM arena, <= 64 anchors sorted in
+//                         registers and chained on the spot
+//          k_group_probe  flag-only: reads with thousands of anchors, decided from their largest
+//                         (strand, contig) group when possible
+//          k_sort_lds     one block per read with <= 256 ... 4096 anchors: stable merge sort in LDS, then
 //                         every cluster chained straight from LDS; only the per-read result returns to HBM
-//          k_sort         giant reads: the same between two arena buffers
+//          k_giant_*      more anchors: grid-wide tiled merge sort in the arena, then k_giant_chain /
+//                         k_cluster_dp (one wave per large cluster, LDS ring DP)
 //          k_finalize     per read: flag / trace, or hand the read to the second (max_occ) pass
-//   k_chain_large   legacy lane-per-read path over arena slices, kept for the rare reads K1 could not
-//        finish (seed/list overflow), which it re-sketches.
+//   k_long_*        long reads (any length): segment-parallel sketch, thinning, probe; feeds the repeat path.
+//   k_chain_large   legacy lane-per-read path over arena slices, kept for the rare reads no front end takes.
 //
 // Results are bit-identical to oracle/mm_oracle.c (tests/test_parity_gpu.py).
 #include "sh_common.h"

@@ -29,7 +29,6 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
-#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
