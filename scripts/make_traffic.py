@@ -2,9 +2,12 @@
 """profiles/traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; kernel-trace only) of ONE bench step.
 
 usage: make_traffic.py <fetch_dir> <write_dir> <records_per_launch> <out.json>
-Counter values are KiB (x 1024 -> bytes), summed per bench stage; raw, i.e. without the gfx950 correction for wide
-coalesced streams (MI355X_MICROARCH.md, HBM section: FETCH_SIZE reports half of a 16-B/lane streaming read; other access
-widths - the 16-B random gathers and 12-B anchor records here - are uncalibrated), so the figures are a lower bound."""
+Counter values are KiB (x 1024 -> bytes), summed per bench stage.  Calibration for this path's access pattern, as
+MI355X_MICROARCH.md (HBM section) asks for widths other than wide streams: `scripts/pmc_gather_calib.sh` runs the gather
+micro-benchmark (a known number of random 16-B slot loads over the index table) under the same counter and finds exactly 64.0 B
+per probe (profiles/r01_pmc_gather_calib.txt): one 64-B sector per 16-B gather, counted exactly.  The guide's x2 correction
+applies only to the coalesced 16-B/lane streams (K1's 3 GB of bases: FETCH_SIZE shows half of them), so the figures are exact
+for the gathers and a lower bound by at most that amount overall."""
 import csv, glob, json, sys, collections
 
 STAGES = {
