@@ -236,7 +236,8 @@ sh_status sh_host_read_difference(const char *const *inputs, const char *const *
                                   uint64_t *reads_out, uint64_t *difference);
 /* the chunked, multi-threaded form of the same filter that sh_reads_run uses (pass 2 of csrc/sh_stream.cpp): the input is cut
  * into chunks of ~chunk_bytes at record boundaries, `threads` workers filter (and deflate, for .gz outputs), one writer
- * appends in order; retain != 0 keeps the parsed chunks in memory first, as pass 1 does.  Same bytes out as
+ * write side by side; retain: 0 = stream the file, 1 = keep the parsed chunks of the sequential reader, 2 = of the boundary-guessing
+ * reader, 3 = of several byte-range readers (pass 1's forms).  Same bytes out as
  * sh_host_filter_fastx for plain outputs; .gz outputs are multi-member gzip with the same decompressed content. */
 sh_status sh_host_filter_fastx_stream(const char *in, const char *out, const char *const *ids, uint64_t n_ids, int32_t extract,
                                       uint64_t chunk_bytes, int32_t threads, int32_t retain, uint64_t *n_in, uint64_t *n_out);

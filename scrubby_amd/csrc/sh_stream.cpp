@@ -24,6 +24,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -62,7 +63,7 @@ struct Chunk {
     std::vector<Rec> recs;
     std::vector<uint8_t> bases;       // the read batch of include/scrubby_hip.h; dropped once classified
     std::vector<uint64_t> offsets;
-    uint32_t file = 0;                // which input file, and which chunk of it
+    uint32_t file = 0, range = 0;     // which input file, which byte range of it (0: the only one), and which chunk of that
     size_t seq_no = 0;
     bool parsed = false;
     DevBuf *dev = nullptr;     // pass 1: where a parse worker has put the batch in HBM
@@ -206,12 +207,67 @@ size_t find_split(const char *d, size_t n, bool fasta)
     return NPOS;
 }
 
+// The same guess looking forward: the first record start after d[0] (d[0] itself may be anywhere in a line).
+size_t find_split_forward(const char *d, size_t n, bool fasta)
+{
+    size_t nl = eol(d, 0, n);
+    while (nl != NPOS && nl + 1 < n) {
+        const size_t L = nl + 1;
+        if (fasta) { if (d[L] == '>') return L; }
+        else if (d[L] == '@') {
+            const size_t e1 = eol(d, L, n);
+            const size_t e2 = e1 == NPOS ? NPOS : eol(d, e1 + 1, n);
+            if (e2 == NPOS || e2 + 1 >= n) return NPOS;
+            if (d[e2 + 1] == '+') return L;
+        }
+        nl = eol(d, L, n);
+    }
+    return NPOS;
+}
+
+// Plain (not gzip) regular files big enough to bother are read by several readers, each over a byte range that starts at a
+// guessed record boundary.  Verified like every other cut: each chunk must parse to its last byte, so a range that starts inside
+// a record makes the previous range's last chunk fail and pass 1 is rerun with the sequential reader.
+struct FilePlan { int fd = -1; bool fasta = false; std::vector<uint64_t> bounds; };     // bounds.size() - 1 ranges; empty: one stream reader
+FilePlan plan_ranges(const char *path, int max_ranges, uint64_t min_range_bytes)
+{
+    FilePlan p;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return p;
+    struct stat sb;
+    unsigned char head[256];
+    ssize_t hl = 0;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || (hl = pread(fd, head, sizeof head, 0)) < 2 || (head[0] == 0x1f && head[1] == 0x8b)) { close(fd); return p; }
+    ssize_t q = 0;
+    while (q < hl && (head[q] == '\n' || head[q] == '\r')) ++q;
+    if (q >= hl || (head[q] != '>' && head[q] != '@')) { close(fd); return p; }
+    const uint64_t size = (uint64_t)sb.st_size;
+    const int R = (int)std::min<uint64_t>((uint64_t)std::max(1, max_ranges), size / std::max<uint64_t>(min_range_bytes, 1));
+    if (R < 2) { close(fd); return p; }
+    p.fasta = head[q] == '>';
+    p.bounds.push_back(0);
+    std::vector<char> win(4u << 20);
+    for (int k = 1; k < R; ++k) {
+        const uint64_t nominal = size / (uint64_t)R * (uint64_t)k;
+        const ssize_t got = pread(fd, win.data(), win.size(), (off_t)nominal);
+        if (got <= 0) continue;
+        const size_t L = find_split_forward(win.data(), (size_t)got, p.fasta);
+        if (L != NPOS && nominal + L > p.bounds.back()) p.bounds.push_back(nominal + L);     // no boundary in the window: the range merges with its neighbour
+    }
+    p.bounds.push_back(size);
+    if (p.bounds.size() < 3) { p.bounds.clear(); close(fd); return p; }
+    p.fd = fd;
+    return p;
+}
+
 // Cuts a FASTA / FASTQ byte stream (plain or gzip: gzread passes plain bytes through) into chunks that end on record
 // boundaries.  Accepts what the legacy line reader accepts: 4-line FASTQ, multi-line FASTA, CRLF, blank lines between
 // records, a last line without '\n'.  Sequential mode parses as it cuts; split-only mode cuts at find_split() and leaves
 // the parsing (and its verification) to whoever takes the chunk.
 class ChunkReader {
     gzFile f_ = nullptr;
+    int fd_ = -1;                     // byte-range source (plain files): pread from pos_ up to end_
+    uint64_t pos_ = 0, end_ = 0;
     size_t target_;
     bool batch_, split_only_;
     int fasta_ = -1;
@@ -225,9 +281,12 @@ public:
         f_ = gzopen(path, "rb");
         if (f_) gzbuffer(f_, 1 << 20);
     }
+    // one byte range [begin, end) of a plain file; `fasta` as the whole file's first record says (the range may start anywhere in it)
+    ChunkReader(int fd, uint64_t begin, uint64_t end, bool fasta, size_t target, bool batch) : fd_(fd), pos_(begin), end_(end), target_(std::max<size_t>(target, 64)),
+                                                                                            batch_(batch), split_only_(true), fasta_(fasta ? 1 : 0) {}
     ~ChunkReader() { if (f_) gzclose(f_); }
     ChunkReader(const ChunkReader &) = delete;
-    bool ok() const { return f_ != nullptr; }
+    bool ok() const { return f_ != nullptr || fd_ >= 0; }
 
     // 1 = a chunk with at least one record, 0 = end of input, -1 = malformed input (error set)
     int next(Chunk &c)
@@ -240,6 +299,13 @@ public:
         if (c.len) memcpy(c.data, carry_.data(), c.len);
         carry_.clear();
         for (;;) {
+            while (!eof_ && c.len < cap && fd_ >= 0) {
+                const size_t want = (size_t)std::min<uint64_t>(cap - c.len, end_ - pos_);
+                const ssize_t got = want ? pread(fd_, c.data + c.len, want, (off_t)pos_) : 0;
+                if (got < 0 || (want && got == 0)) { error = "read error"; return -1; }
+                pos_ += (uint64_t)got; c.len += (size_t)got;
+                if (pos_ >= end_) eof_ = true;
+            }
             while (!eof_ && c.len < cap) {
                 const unsigned want = (unsigned)std::min<size_t>(cap - c.len, 1u << 30);
                 const int got = gzread(f_, c.data + c.len, want);
@@ -752,20 +818,25 @@ struct Pass1 {
     }
     bool has_err() { std::lock_guard<std::mutex> lk(mu); return err_st != SH_OK; }
 
-    void reader(uint32_t i, bool parallel)
+    FilePlan plan[2];
+    std::vector<std::vector<std::shared_ptr<Chunk>>> kept_r[2];      // [file][range]: chunks in range order; concatenated into kept[] at the end
+
+    void reader(uint32_t i, uint32_t range, bool parallel)
     {
-        ChunkReader rd(c->input[i], chunk_bytes, true, parallel);
-        if (!rd.ok()) set_err(SH_ERR_IO, std::string("cannot open ") + c->input[i]);
+        std::unique_ptr<ChunkReader> rd;
+        if (!plan[i].bounds.empty()) rd.reset(new ChunkReader(plan[i].fd, plan[i].bounds[range], plan[i].bounds[range + 1], plan[i].fasta, chunk_bytes, true));
+        else rd.reset(new ChunkReader(c->input[i], chunk_bytes, true, parallel));
+        if (!rd->ok()) set_err(SH_ERR_IO, std::string("cannot open ") + c->input[i]);
         else
             for (size_t k = 0;; ++k) {
                 auto ch = std::make_shared<Chunk>();
                 const auto t0 = tick();
-                const int r = rd.next(*ch);
+                const int r = rd->next(*ch);
                 const auto t1 = tick();
                 us_read += us(t0, t1);
-                if (r < 0) { set_err(SH_ERR_IO, std::string(c->input[i]) + ": " + rd.error); break; }
+                if (r < 0) { set_err(SH_ERR_IO, std::string(c->input[i]) + ": " + rd->error); break; }
                 if (r == 0) break;
-                ch->file = i; ch->seq_no = k;
+                ch->file = i; ch->range = range; ch->seq_no = k;
                 const bool pushed = rawq.push(ch);
                 us_rpush += us(t1, tick());
                 if (!pushed) break;
@@ -799,7 +870,7 @@ struct Pass1 {
                 if (kept_bytes.fetch_add(ch->footprint()) + ch->footprint() > budget) retain.store(false);
                 else {
                     std::lock_guard<std::mutex> lk(mu);
-                    auto &v = kept[ch->file];
+                    auto &v = kept_r[ch->file][ch->range];
                     if (v.size() <= ch->seq_no) v.resize(ch->seq_no + 1);
                     v[ch->seq_no] = ch;
                 }
@@ -848,12 +919,23 @@ struct Pass1 {
     {
         retain.store(budget > 0);
         const int n_parse = std::max(1, threads);
-        rawq.cap = (size_t)n_parse + 2; rawq.producers = (int)c->n_files;
-        const int n_fold = std::max(1, std::min(4, threads / 2));
+        // plain files of >= 256 MB: up to 4 range readers each, none under 128 MB (SCRUBBY_HIP_READERS; 1 = one stream reader per file, as for gzip)
+        const int max_readers = getenv("SCRUBBY_HIP_READERS") ? atoi(getenv("SCRUBBY_HIP_READERS")) : 4;
+        const uint64_t min_range = env_mb("SCRUBBY_HIP_RANGE_MB", 128ull << 20);
+        int n_readers = 0;
+        for (uint32_t i = 0; i < c->n_files; ++i) {
+            if (parallel && max_readers > 1) plan[i] = plan_ranges(c->input[i], max_readers, min_range);
+            const size_t nr = plan[i].bounds.empty() ? 1 : plan[i].bounds.size() - 1;
+            kept_r[i].assign(nr, {});
+            n_readers += (int)nr;
+        }
+        rawq.cap = (size_t)n_parse + 2; rawq.producers = n_readers;
+        const int n_fold = std::max(1, std::min(8, threads / 2));          // id-set inserts are cache-missy (~0.4 us each): with range readers they bound pass 1
         devq.cap = 8; devq.producers = n_parse;          // the device-buffer pool is what bounds the chunks in flight
         foldq.cap = 8; foldq.producers = 1;
         std::vector<std::thread> thr;
-        for (uint32_t i = 0; i < c->n_files; ++i) thr.emplace_back([this, i, parallel] { reader(i, parallel); });
+        for (uint32_t i = 0; i < c->n_files; ++i)
+            for (uint32_t rg = 0; rg < kept_r[i].size(); ++rg) thr.emplace_back([this, i, rg, parallel] { reader(i, rg, parallel); });
         for (int t = 0; t < n_parse; ++t) thr.emplace_back([this, parallel] { parser(parallel); });
         for (int t = 0; t < n_fold; ++t) thr.emplace_back([this] { folder(); });
         {
@@ -877,6 +959,11 @@ struct Pass1 {
             foldq.producer_done();
         }
         for (auto &t : thr) t.join();
+        for (uint32_t i = 0; i < c->n_files; ++i) {
+            if (plan[i].fd >= 0) close(plan[i].fd);
+            for (auto &v : kept_r[i]) for (auto &ch : v) if (ch) kept[i].push_back(std::move(ch));       // file order = range order, then chunk order
+            kept_r[i].clear();
+        }
         if (const char *e = getenv("SCRUBBY_HIP_DBG_HOST")) if (*e == '1')
             fprintf(stderr, "[scrubby-hip] pass 1 (%s): readers read %.0f ms, blocked on push %.0f ms | %d parse workers: parse %.0f ms, H2D %.0f ms, blocked %.0f ms | device thread: "
                     "waiting %.0f ms, classify %.0f ms | %d fold threads: id set %.0f ms\n", parallel ? "cut + parallel parse" : "sequential parse", us_read / 1e3, us_rpush / 1e3, n_parse,
@@ -896,15 +983,32 @@ extern "C" sh_status sh_host_filter_fastx_stream(const char *in, const char *out
     ShardedIdSet set;
     for (uint64_t i = 0; i < n_ids; ++i) set.insert(ids[i], (uint32_t)strlen(ids[i]));
     std::vector<std::shared_ptr<Chunk>> kept;
-    if (retain) {       // 1: the sequential reader; 2: cut at guessed boundaries, then parse each chunk on its own (pass 1's parallel form)
-        ChunkReader rd(in, chunk_bytes, false, retain == 2);
+    FilePlan plan;
+    if (retain == 3) plan = plan_ranges(in, 4, std::max<uint64_t>(chunk_bytes, 64));      // 3: several byte ranges, each cut and parsed like 2
+    if (retain == 3 && !plan.bounds.empty()) {
+        for (size_t k = 0; k + 1 < plan.bounds.size(); ++k) {
+            ChunkReader rd(plan.fd, plan.bounds[k], plan.bounds[k + 1], plan.fasta, chunk_bytes, false);
+            for (;;) {
+                auto c = std::make_shared<Chunk>();
+                const int r = rd.next(*c);
+                if (r < 0) { close(plan.fd); sh_set_error("%s: %s", in, rd.error.c_str()); return SH_ERR_IO; }
+                if (r == 0) break;
+                size_t consumed = 0;
+                std::string e;
+                if (!(parse_chunk(*c, true, false, &consumed, e) && consumed == c->len)) { close(plan.fd); sh_set_error("boundary guess failed (%s): the sequential reader decides", e.c_str()); return SH_ERR_IO; }
+                if (!c->recs.empty()) kept.push_back(std::move(c));
+            }
+        }
+        close(plan.fd);
+    } else if (retain) {       // 1: the sequential reader; 2: cut at guessed boundaries, then parse each chunk on its own (pass 1's parallel form)
+        ChunkReader rd(in, chunk_bytes, false, retain >= 2);
         SH_CHECK(rd.ok(), SH_ERR_IO, "cannot open %s", in);
         for (;;) {
             auto c = std::make_shared<Chunk>();
             const int r = rd.next(*c);
             SH_CHECK(r >= 0, SH_ERR_IO, "%s: %s", in, rd.error.c_str());
             if (r == 0) break;
-            if (retain == 2) {
+            if (retain >= 2) {
                 size_t consumed = 0;
                 std::string e;
                 SH_CHECK(parse_chunk(*c, true, false, &consumed, e) && consumed == c->len, SH_ERR_IO, "boundary guess failed (%s): the sequential reader decides", e.c_str());

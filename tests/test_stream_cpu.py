@@ -75,7 +75,7 @@ def test_stream_filter_matches_line_filter_fastq(tmp_path, case, chunk):
     for extract in (False, True):
         ref = tmp_path / "ref.fastq"
         cnt = S.filter_fastx(str(src), str(ref), drop, extract)
-        for threads, retain in ((1, 1), (3, 0), (4, 1), (2, 2)):
+        for threads, retain in ((1, 1), (3, 0), (4, 1), (2, 2), (2, 3)):
             out = tmp_path / f"o_{threads}_{int(retain)}.fastq"
             assert S.filter_fastx_stream(str(src), str(out), drop, extract, chunk_bytes=chunk, threads=threads, retain=retain) == cnt
             assert out.read_bytes() == ref.read_bytes()
@@ -93,7 +93,7 @@ def test_stream_filter_fasta_multiline(tmp_path, width):
     cnt = S.filter_fastx(str(src), str(ref), drop, False)
     for chunk in (64, 333, 1 << 20):
         out = tmp_path / f"o{chunk}.fa"
-        for retain in (1, 2):
+        for retain in (1, 2, 3):
             assert S.filter_fastx_stream(str(src), str(out), drop, False, chunk_bytes=chunk, threads=2, retain=retain) == cnt
             assert out.read_bytes() == ref.read_bytes()
 
@@ -163,11 +163,13 @@ def test_boundary_guess_is_verified(tmp_path):
     out = tmp_path / "o.fastq"
     assert S.filter_fastx_stream(str(src), str(out), ["r3"], False, chunk_bytes=100, threads=2, retain=1) == cnt     # sequential: exact
     assert out.read_bytes() == ref.read_bytes()
-    with pytest.raises(S.ScrubbyHipError, match="boundary guess failed"):
-        S.filter_fastx_stream(str(src), str(out), ["r3"], False, chunk_bytes=100, threads=2, retain=2)
+    for mode in (2, 3):          # chunk cuts of one reader; byte ranges of several
+        with pytest.raises(S.ScrubbyHipError, match="boundary guess failed"):
+            S.filter_fastx_stream(str(src), str(out), ["r3"], False, chunk_bytes=100, threads=2, retain=mode)
     # quality lines that start with '@' (common in real data) do not fool the scan
     ok = tmp_path / "q_at.fastq"
     ok.write_text("".join(f"@r{i}\nACGTACGTAC\n+\n@IIIIIIIII\n" for i in range(40)))
     cnt = S.filter_fastx(str(ok), str(ref), ["r3"], False)
-    assert S.filter_fastx_stream(str(ok), str(out), ["r3"], False, chunk_bytes=100, threads=2, retain=2) == cnt
-    assert out.read_bytes() == ref.read_bytes()
+    for mode in (2, 3):
+        assert S.filter_fastx_stream(str(ok), str(out), ["r3"], False, chunk_bytes=100, threads=2, retain=mode) == cnt
+        assert out.read_bytes() == ref.read_bytes()
