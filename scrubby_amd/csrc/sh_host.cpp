@@ -360,7 +360,7 @@ static bool read_lines(const char *path, std::vector<std::string> &lines)
 }
 
 // get_taxids_from_report, classifier.rs:124-252
-static sh_status taxids_from_report(const char *report, const std::vector<std::string> &taxa_in, const std::vector<std::string> &direct_in,
+sh_status shi_taxids_from_report(const char *report, const std::vector<std::string> &taxa_in, const std::vector<std::string> &direct_in,
                                     std::unordered_set<std::string> &taxids)
 {
     std::vector<std::string> lines;
@@ -418,7 +418,7 @@ extern "C" sh_status sh_classifier_taxids(const char *report, const char *const 
     for (uint32_t i = 0; i < n_taxa; ++i) t.push_back(taxa[i]);
     for (uint32_t i = 0; i < n_direct; ++i) d.push_back(taxa_direct[i]);
     std::unordered_set<std::string> set;
-    sh_status st = taxids_from_report(report, t, d, set);
+    sh_status st = shi_taxids_from_report(report, t, d, set);
     if (st != SH_OK) return st;
     std::vector<std::string> v(set.begin(), set.end());
     std::sort(v.begin(), v.end());
@@ -444,7 +444,7 @@ extern "C" sh_status sh_classifier_run(const sh_classifier_config *c, sh_reads_r
     for (uint32_t i = 0; i < c->n_taxa; ++i) st.taxa.push_back(c->taxa[i]);
     for (uint32_t i = 0; i < c->n_taxa_direct; ++i) st.taxa_direct.push_back(c->taxa_direct[i]);
     std::unordered_set<std::string> taxids, ids;
-    sh_status s = taxids_from_report(c->report, st.taxa, st.taxa_direct, taxids);
+    sh_status s = shi_taxids_from_report(c->report, st.taxa, st.taxa_direct, taxids);
     if (s != SH_OK) return s;
     s = taxid_reads(taxids, c->reads, !strcmp(c->classifier, "metabuli"), ids);
     if (s != SH_OK) return s;
@@ -538,7 +538,7 @@ sh_status shi_reads_run_legacy(const sh_reads_config *c, sh_reads_result *res)
     return SH_OK;
 }
 
-static void mkdir_p(const std::string &dir)
+void shi_mkdir_p(const std::string &dir)
 {
     for (size_t i = 1; i <= dir.size(); ++i)
         if (i == dir.size() || dir[i] == '/') mkdir(dir.substr(0, i).c_str(), 0777);
@@ -549,7 +549,8 @@ static void mkdir_p(const std::string &dir)
 // the same parse_classifier_output + clean_reads steps run on those files.  Divergence: column 5 of
 // kraken.reads carries the k-mer and hit-group totals, not Kraken2's positional hit list (the reference only stores it,
 // classifier.rs:401-419).
-extern "C" sh_status sh_kraken_run(const sh_kraken_config *c, sh_reads_result *res)
+// collect-then-classify form; sh_kraken_run (sh_stream.cpp) hands over for empty inputs and as the A/B baseline
+sh_status shi_kraken_run_legacy(const sh_kraken_config *c, sh_reads_result *res)
 {
     SH_CHECK(c && res, SH_ERR_BAD_ARG, "sh_kraken_run: null argument");
     SH_CHECK(c->n_files >= 1 && c->n_files <= 2, SH_ERR_BAD_ARG, "one or two input files are supported (got %u)", c->n_files);
@@ -611,7 +612,7 @@ extern "C" sh_status sh_kraken_run(const sh_kraken_config *c, sh_reads_result *r
 
     // kraken.reads and kraken.report in the workdir (cleaner.rs:291-297)
     std::string dir = c->workdir && c->workdir[0] ? c->workdir : (getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp");
-    if (c->workdir && c->workdir[0]) mkdir_p(dir);                         // create_dir_all (cleaner.rs:293)
+    if (c->workdir && c->workdir[0]) shi_mkdir_p(dir);                         // create_dir_all (cleaner.rs:293)
     const std::string reads_path = dir + "/kraken.reads", report_path = dir + "/kraken.report";
     {
         FILE *f = fopen(reads_path.c_str(), "w");
@@ -632,7 +633,7 @@ extern "C" sh_status sh_kraken_run(const sh_kraken_config *c, sh_reads_result *r
     for (uint32_t i = 0; i < c->n_taxa; ++i) rs.taxa.push_back(c->taxa[i]);
     for (uint32_t i = 0; i < c->n_taxa_direct; ++i) rs.taxa_direct.push_back(c->taxa_direct[i]);
     std::unordered_set<std::string> taxids, dep;
-    st = taxids_from_report(report_path.c_str(), rs.taxa, rs.taxa_direct, taxids);
+    st = shi_taxids_from_report(report_path.c_str(), rs.taxa, rs.taxa_direct, taxids);
     if (st != SH_OK) return st;
     st = taxid_reads(taxids, reads_path.c_str(), false, dep);
     if (st != SH_OK) return st;

@@ -1,6 +1,7 @@
 // sh_host.h — declarations shared by the two host-side translation units (sh_host.cpp, sh_stream.cpp).
 #pragma once
 #include "sh_common.h"
+#include <unordered_set>
 
 struct ReportSettings {       // ScrubbySettings, /root/reference/src/report.rs:71-88 (field order = key order)
     const char *aligner = nullptr, *classifier = nullptr, *index = nullptr, *alignment = nullptr, *reads = nullptr, *report = nullptr, *preset_variant = nullptr;
@@ -16,3 +17,9 @@ sh_status shi_write_report_json(const char *const *input, const char *const *out
 const char *shi_preset_variant(const std::string &display);
 // collect-then-map form of the whole path (sh_host.cpp)
 sh_status shi_reads_run_legacy(const sh_reads_config *c, sh_reads_result *res);
+// `scrubby reads -c kraken2`, collect-then-classify form (sh_host.cpp)
+sh_status shi_kraken_run_legacy(const sh_kraken_config *c, sh_reads_result *res);
+// get_taxids_from_report (/root/reference/src/classifier.rs:124-252)
+sh_status shi_taxids_from_report(const char *report, const std::vector<std::string> &taxa_in, const std::vector<std::string> &direct_in,
+                                 std::unordered_set<std::string> &out);
+void shi_mkdir_p(const std::string &dir);

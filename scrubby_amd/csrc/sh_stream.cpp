@@ -33,6 +33,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <unordered_set>
 
 namespace {
 
@@ -1125,5 +1126,247 @@ extern "C" sh_status sh_reads_run(const sh_reads_config *c, sh_reads_result *res
     }
     res->ms_index = ms(t0, t1); res->ms_ingest = ms(t1, t2); res->ms_classify = classify_ms; res->ms_write = ms(t2, now());
     (void)t3;
+    return SH_OK;
+}
+
+// ---- `scrubby reads -c kraken2`: Cleaner::run_kraken (cleaner.rs:288-330) with the chunked reader, the GPU classifier, and the
+// parallel filter of pass 2.  The reference runs the external kraken2, which writes kraken.reads / kraken.report, then reads both
+// files back (parse_classifier_output, :375-382) and filters (clean_reads).  Here: both inputs are parsed in place side by side
+// (chunks retained), mates are interleaved into one batch (records 2i, 2i + 1), sh_k2_classify_batch classifies it, the two text
+// files still land in the workdir (formatted by a pool, written at their offsets), the taxid set comes from the report exactly
+// as the reference derives it (shi_taxids_from_report), and a read is selected iff the taxid printed on its line is in that set -
+// decided from the results in memory instead of re-reading the 10^7 lines just written (get_taxid_reads_kraken compares the
+// same decimal string).
+namespace {
+
+struct RecRef { const Chunk *ch; const Rec *r; };
+
+// all chunks of a file, sequentially parsed, plus a flat record index
+struct ParsedFile {
+    std::vector<std::shared_ptr<Chunk>> chunks;
+    std::vector<uint64_t> first;        // ordinal of each chunk's first record; first.back() = record count
+    std::string error;
+    sh_status read(const char *path, size_t chunk_bytes)
+    {
+        ChunkReader rd(path, chunk_bytes, false);
+        if (!rd.ok()) { error = std::string("cannot open ") + path; return SH_ERR_IO; }
+        first.assign(1, 0);
+        for (;;) {
+            auto c = std::make_shared<Chunk>();
+            const int r = rd.next(*c);
+            if (r < 0) { error = std::string(path) + ": " + rd.error; return SH_ERR_IO; }
+            if (r == 0) break;
+            first.push_back(first.back() + c->recs.size());
+            chunks.push_back(std::move(c));
+        }
+        return SH_OK;
+    }
+    uint64_t n() const { return first.back(); }
+    // cursor over records [lo, hi)
+    template <class F> void for_range(uint64_t lo, uint64_t hi, F f) const
+    {
+        if (lo >= hi) return;
+        size_t ci = (size_t)(std::upper_bound(first.begin(), first.end(), lo) - first.begin()) - 1;
+        uint64_t o = lo;
+        while (o < hi) {
+            const Chunk &c = *chunks[ci];
+            const uint64_t end = std::min<uint64_t>(hi, first[ci + 1]);
+            for (uint64_t k = o; k < end; ++k) f(k, c, c.recs[(size_t)(k - first[ci])]);
+            o = end; ++ci;
+        }
+    }
+};
+
+template <class F> void parallel_ranges(uint64_t n, int threads, F f)
+{
+    const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(1, threads), n / 65536 + 1));
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back([=] { f(t, n * (uint64_t)t / (uint64_t)T, n * (uint64_t)(t + 1) / (uint64_t)T); });
+    for (auto &x : th) x.join();
+}
+
+}  // namespace
+
+extern "C" sh_status sh_kraken_run(const sh_kraken_config *c, sh_reads_result *res)
+{
+    SH_CHECK(c && res, SH_ERR_BAD_ARG, "sh_kraken_run: null argument");
+    SH_CHECK(c->n_files >= 1 && c->n_files <= 2, SH_ERR_BAD_ARG, "one or two input files are supported (got %u)", c->n_files);
+    for (uint32_t i = 0; i < c->n_files; ++i) SH_CHECK(c->input[i] && c->output[i], SH_ERR_BAD_ARG, "input/output %u missing", i);
+    SH_CHECK(c->db, SH_ERR_BAD_ARG, "MissingClassifierIndex");
+    SH_CHECK(c->n_taxa + c->n_taxa_direct > 0, SH_ERR_BAD_ARG, "MissingTaxa: --taxa or --taxa-direct is required");
+    if (const char *e = getenv("SCRUBBY_HIP_LEGACY_HOST")) if (*e == '1') return shi_kraken_run_legacy(c, res);
+    for (uint32_t i = 0; i < c->n_files; ++i) {
+        bool exists;
+        if (file_is_empty(c->input[i], exists)) return shi_kraken_run_legacy(c, res);       // App. C Q6 corner: the line-by-line form keeps its behaviour
+    }
+    memset(res, 0, sizeof(*res));
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const bool paired = c->n_files == 2;
+    const int threads = c->threads > 0 ? c->threads : 4;
+    const size_t chunk_bytes = env_mb("SCRUBBY_HIP_CHUNK_MB", 64ull << 20);
+
+    const auto t0 = now();
+    sh_k2_db *db = nullptr;
+    sh_status st = sh_k2_open(c->db, c->device, &db);
+    if (st != SH_OK) return st;
+    struct DbGuard { sh_k2_db *d; ~DbGuard() { if (d) sh_k2_free(d); } } guard{db};
+    sh_k2_opts opts;                 // k, l, masks and the down-sampling threshold come from the database
+    sh_k2_db_opts(db, &opts);
+    if (c->confidence >= 0.0) opts.confidence = c->confidence;           // -C "--confidence x"
+    if (c->min_hit_groups > 0) opts.min_hit_groups = c->min_hit_groups;   // -C "--minimum-hit-groups n"
+    const auto t1 = now();
+
+    // ---- ingest: both files side by side, parsed in place ----
+    ParsedFile pf[2];
+    sh_status pst[2] = {SH_OK, SH_OK};
+    {
+        std::vector<std::thread> th;
+        for (uint32_t i = 0; i < c->n_files; ++i) th.emplace_back([&, i] { pst[i] = pf[i].read(c->input[i], chunk_bytes); });
+        for (auto &x : th) x.join();
+    }
+    for (uint32_t i = 0; i < c->n_files; ++i) if (pst[i] != SH_OK) { sh_set_error("%s", pf[i].error.c_str()); return pst[i]; }
+    const uint64_t n_units = pf[0].n();
+    if (paired && pf[1].n() != n_units) {
+        sh_set_error("%s: %s", c->input[1], pf[1].n() < n_units ? "fewer records than mate 1" : "more records than mate 1");
+        return SH_ERR_IO;
+    }
+    // mates interleaved: records 2i, 2i + 1 (kraken2 --paired); lengths first, then the bases in parallel
+    const uint64_t n_rec = paired ? 2 * n_units : n_units;
+    std::vector<uint64_t> offsets(n_rec + 1, 0);
+    std::atomic<int> bad_id{0};
+    for (uint32_t f = 0; f < c->n_files; ++f)
+        parallel_ranges(n_units, threads, [&, f](int, uint64_t lo, uint64_t hi) {
+            pf[f].for_range(lo, hi, [&](uint64_t k, const Chunk &ch, const Rec &r) {
+                offsets[(paired ? 2 * k + f : k) + 1] = r.seq_len;
+                const char *id; uint32_t il;
+                if (f == 0 && !id_of(ch.data + r.hdr, r.hdr_len, &id, &il)) bad_id = 1;
+            });
+        });
+    if (bad_id.load()) { sh_set_error("record without an id in %s", c->input[0]); return SH_ERR_IO; }
+    for (uint64_t i = 0; i < n_rec; ++i) offsets[i + 1] += offsets[i];
+    std::vector<uint8_t> bases(offsets[n_rec] + 64, (uint8_t)'N');
+    for (uint32_t f = 0; f < c->n_files; ++f)
+        parallel_ranges(n_units, threads, [&, f](int, uint64_t lo, uint64_t hi) {
+            pf[f].for_range(lo, hi, [&](uint64_t k, const Chunk &ch, const Rec &r) { memcpy(bases.data() + offsets[paired ? 2 * k + f : k], ch.data + r.seq, r.seq_len); });
+        });
+    const auto t2 = now();
+
+    std::vector<sh_k2_result> results(std::max<uint64_t>(n_units, 1));
+    st = sh_k2_classify_batch(db, &opts, bases.data(), offsets.data(), n_rec, paired ? 1 : 0, results.data(), nullptr);
+    if (st != SH_OK) return st;
+    std::vector<uint8_t>().swap(bases);
+    const auto t3 = now();
+
+    // ---- kraken.reads and kraken.report in the workdir (cleaner.rs:291-297) ----
+    std::string dir = c->workdir && c->workdir[0] ? c->workdir : (getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp");
+    if (c->workdir && c->workdir[0]) shi_mkdir_p(dir);                       // create_dir_all (cleaner.rs:293)
+    const std::string reads_path = dir + "/kraken.reads", report_path = dir + "/kraken.report";
+    // the id Kraken 2 prints for a pair is mate 1's first token with a trailing /1 removed
+    auto unit_id = [&](const Chunk &ch, const Rec &r, const char **id, uint32_t *il) {
+        id_of(ch.data + r.hdr, r.hdr_len, id, il);
+        if (paired && *il > 2 && (*id)[*il - 2] == '/' && (*id)[*il - 1] == '1') *il -= 2;
+    };
+    {
+        const int fd = open(reads_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        SH_CHECK(fd >= 0, SH_ERR_IO, "cannot write %s", reads_path.c_str());
+        const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)threads, n_units / 65536 + 1));
+        std::vector<std::string> part((size_t)T);
+        parallel_ranges(n_units, T, [&](int t, uint64_t lo, uint64_t hi) {
+            std::string &o = part[(size_t)t];
+            o.reserve((size_t)(hi - lo) * 64);
+            char num[96];
+            pf[0].for_range(lo, hi, [&](uint64_t k, const Chunk &ch, const Rec &r) {
+                const sh_k2_result &x = results[k];
+                const char *id; uint32_t il;
+                unit_id(ch, r, &id, &il);
+                o += x.call ? 'C' : 'U'; o += '\t'; o.append(id, il);
+                int m;
+                if (paired) m = snprintf(num, sizeof num, "\t%u\t%u|%u\tkmers=%u groups=%u\n", x.taxid, r.seq_len, (uint32_t)(offsets[2 * k + 2] - offsets[2 * k + 1]), x.total_kmers, x.hit_groups);
+                else m = snprintf(num, sizeof num, "\t%u\t%u\tkmers=%u groups=%u\n", x.taxid, r.seq_len, x.total_kmers, x.hit_groups);
+                o.append(num, (size_t)m);
+            });
+        });
+        bool ok = true;
+        uint64_t off = 0;
+        std::vector<uint64_t> offs((size_t)T);
+        for (int t = 0; t < T; ++t) { offs[(size_t)t] = off; off += part[(size_t)t].size(); }
+        parallel_ranges((uint64_t)T, T, [&](int, uint64_t lo, uint64_t hi) {
+            for (uint64_t t = lo; t < hi; ++t) {
+                size_t done = 0;
+                while (done < part[t].size()) { const ssize_t w = pwrite(fd, part[t].data() + done, part[t].size() - done, (off_t)(offs[t] + done)); if (w <= 0) break; done += (size_t)w; }
+            }
+        });
+        struct stat sb;
+        ok = fstat(fd, &sb) == 0 && (uint64_t)sb.st_size == off;
+        ok = (close(fd) == 0) && ok;
+        SH_CHECK(ok, SH_ERR_IO, "short write to %s", reads_path.c_str());
+    }
+    st = sh_k2_write_report(db, results.data(), n_units, report_path.c_str());
+    if (st != SH_OK) return st;
+
+    // ---- parse_classifier_output (cleaner.rs:375-382): taxids from the report, then the reads carrying one of them ----
+    ReportSettings rs;
+    for (uint32_t i = 0; i < c->n_taxa; ++i) rs.taxa.push_back(c->taxa[i]);
+    for (uint32_t i = 0; i < c->n_taxa_direct; ++i) rs.taxa_direct.push_back(c->taxa_direct[i]);
+    std::unordered_set<std::string> taxids;
+    st = shi_taxids_from_report(report_path.c_str(), rs.taxa, rs.taxa_direct, taxids);
+    if (st != SH_OK) return st;
+    std::unordered_set<uint32_t> tax_num;          // a line's taxid column is printed with %u: only canonical decimal strings can equal it
+    for (const std::string &t : taxids) {
+        if (t.empty() || t.size() > 10 || (t.size() > 1 && t[0] == '0')) continue;
+        bool dig = true; uint64_t v = 0;
+        for (char ch : t) { if (ch < '0' || ch > '9') { dig = false; break; } v = v * 10 + (uint64_t)(ch - '0'); }
+        if (dig && v <= 0xffffffffull) tax_num.insert((uint32_t)v);
+    }
+    ShardedIdSet dep;
+    parallel_ranges(n_units, threads, [&](int, uint64_t lo, uint64_t hi) {
+        pf[0].for_range(lo, hi, [&](uint64_t k, const Chunk &ch, const Rec &r) {
+            if (!tax_num.count(results[k].taxid)) return;
+            const char *id; uint32_t il;
+            unit_id(ch, r, &id, &il);
+            dep.insert(id, il);
+        });
+    });
+    res->n_depleted_ids = dep.size();
+
+    // ---- clean_reads over the retained chunks ----
+    const bool want_dropped = c->read_ids && c->extract;
+    FileFilter ff[2];
+    sh_status fst[2] = {SH_OK, SH_OK};
+    std::string ferr[2];
+    {
+        std::vector<std::thread> filters;
+        for (uint32_t i = 0; i < c->n_files; ++i) {
+            ff[i] = FileFilter{c->input[i], c->output[i], &pf[i].chunks, chunk_bytes, &dep, c->extract != 0, (bool)want_dropped, std::max(1, threads / (int)c->n_files)};
+            filters.emplace_back([&, i]() { fst[i] = ff[i].run(); if (fst[i] != SH_OK) ferr[i] = sh_last_error(); });
+        }
+        for (auto &t : filters) t.join();
+    }
+    for (uint32_t i = 0; i < c->n_files; ++i) if (fst[i] != SH_OK) { sh_set_error("%s", ferr[i].c_str()); return fst[i]; }
+    const auto t4 = now();
+
+    uint64_t rin = 0, rout = 0;
+    for (uint32_t i = 0; i < c->n_files; ++i) { rin += ff[i].n_in; rout += ff[i].n_out; }
+    res->reads_in = rin; res->reads_out = rout;
+    res->reads_removed = c->extract ? 0 : rin - rout;
+    res->reads_extracted = c->extract ? rin - rout : 0;
+    if (c->read_ids) {
+        std::string body = "id\n";
+        if (!c->extract) dep.for_each([&](const char *s, uint32_t n) { body.append(s, n); body += '\n'; });
+        else {
+            IdSet uniq;
+            for (uint32_t i = 0; i < c->n_files; ++i)
+                for (auto &s : ff[i].dropped)
+                    if (uniq.insert(s.data(), (uint32_t)s.size())) { body += s; body += '\n'; }
+        }
+        SH_CHECK(write_id_table(c->read_ids, body), SH_ERR_IO, "cannot write %s", c->read_ids);
+    }
+    if (c->json) {
+        rs.classifier = "kraken2"; rs.index = c->db; rs.extract = c->extract != 0;
+        st = shi_write_report_json(c->input, c->output, c->n_files, c->command, rs, res, c->json);
+        if (st != SH_OK) return st;
+    }
+    res->ms_index = ms(t0, t1); res->ms_ingest = ms(t1, t2); res->ms_classify = ms(t2, t3); res->ms_write = ms(t3, t4);
     return SH_OK;
 }

@@ -368,3 +368,48 @@ def test_tiny_tables_wrap_and_ragged_tail(K, oracle, cfg1, tax):
         _same(oracle, g, c, ext)
         assert st["n_probes"] == int(c["n_probes"].sum())
         d.close()
+
+
+def test_kraken_run_streaming_equals_collect_then_classify(K, oracle, db, cfg1, tmp_path, monkeypatch):
+    """sh_kraken_run's streaming form (chunked in-place parser, parallel formatting of kraken.reads, taxid selection from
+    the results in memory, parallel filter; csrc/sh_stream.cpp) against the collect-then-classify form
+    (SCRUBBY_HIP_LEGACY_HOST=1): every file they write must be the same, with small chunks so that records straddle cuts."""
+    import json
+    import gzip
+    P, R, ref, seqs, reads, off = cfg1
+    dbdir = tmp_path / "db"; dbdir.mkdir()
+    db.save(dbdir)
+    n_pairs = 6000
+    with open(tmp_path / "a_1.fastq", "w") as f1, gzip.open(tmp_path / "a_2.fastq.gz", "wt") as f2:
+        for i in range(n_pairs):
+            s1, s2 = bytes(reads[(2 * i) * 150:(2 * i + 1) * 150]).decode(), bytes(reads[(2 * i + 1) * 150:(2 * i + 2) * 150]).decode()
+            f1.write(f"@syn.{i} 1:N:0\n{s1}\n+\n{'I' * 150}\n")
+            f2.write(f"@syn.{i} 2:N:0\n{s2[:100 + i % 50]}\n+\n{'I' * (100 + i % 50)}\n")          # ragged mate 2
+    monkeypatch.setenv("SCRUBBY_HIP_CHUNK_MB", "1")
+    out = {}
+    for name, env in (("stream", "0"), ("legacy", "1")):
+        monkeypatch.setenv("SCRUBBY_HIP_LEGACY_HOST", env)
+        w = tmp_path / f"w_{name}"
+        res = K.kraken_run([tmp_path / "a_1.fastq", tmp_path / "a_2.fastq.gz"], [tmp_path / f"{name}_1.fastq", tmp_path / f"{name}_2.fastq.gz"], dbdir,
+                           taxa=["Chordata"], taxa_direct=["9606"], workdir=w, json=tmp_path / f"{name}.json", read_ids=tmp_path / f"{name}.tsv")
+        rep = json.load(open(tmp_path / f"{name}.json"))
+        out[name] = (res["reads_in"], res["reads_out"], res["reads_removed"], res["n_depleted_ids"],
+                     open(w / "kraken.reads").read(), open(w / "kraken.report").read(),
+                     open(tmp_path / f"{name}_1.fastq").read(), gzip.open(tmp_path / f"{name}_2.fastq.gz", "rt").read(),
+                     sorted(open(tmp_path / f"{name}.tsv").read().split()), {k: v for k, v in rep.items() if k not in ("date", "output")})
+    assert out["stream"] == out["legacy"]
+    assert out["stream"][3] > 500 and out["stream"][2] == 2 * out["stream"][3]
+    # single-end, extract mode
+    for name, env in (("s_stream", "0"), ("s_legacy", "1")):
+        monkeypatch.setenv("SCRUBBY_HIP_LEGACY_HOST", env)
+        res = K.kraken_run([tmp_path / "a_1.fastq"], [tmp_path / f"{name}.fastq"], dbdir, taxa_direct=["9606"], workdir=tmp_path / f"w_{name}", extract=True,
+                           json=tmp_path / f"{name}.json")      # counts are filled with a report only in the collect-then-classify form
+        out[name] = (res["reads_in"], res["reads_out"], res["reads_extracted"], open(tmp_path / f"w_{name}" / "kraken.reads").read(), open(tmp_path / f"{name}.fastq").read())
+    assert out["s_stream"] == out["s_legacy"]
+    # a mate file with a different record count is an error, as before
+    with open(tmp_path / "short_2.fastq", "w") as f:
+        f.write("@syn.0 2\nACGT\n+\nIIII\n")
+    monkeypatch.setenv("SCRUBBY_HIP_LEGACY_HOST", "0")
+    from scrubby_amd import lib as S
+    with pytest.raises(S.ScrubbyHipError, match="fewer records than mate 1"):
+        K.kraken_run([tmp_path / "a_1.fastq", tmp_path / "short_2.fastq"], [tmp_path / "x1.fastq", tmp_path / "x2.fastq"], dbdir, taxa_direct=["9606"], workdir=tmp_path / "wx")
