@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--records", type=int, default=20_000_000, help="records per GPU (2 per pair)")
     ap.add_argument("--chunk", type=int, default=1 << 25, help="records per kernel launch (default: the whole batch in one launch)")
     ap.add_argument("--small", action="store_true", help="5 Mb reference / 200k records (plumbing check)")
-    ap.add_argument("--workload", choices=["sr", "ont", "k2", "e2e"], default="sr",
+    ap.add_argument("--workload", choices=["sr", "ont", "k2", "e2e", "e2e-k2"], default="sr",
                     help="sr = BASELINE configs[1] (headline); ont = configs[3] stand-in: long noisy reads, map-ont preset; "
                          "k2 = configs[4] stand-in: Kraken2-style taxid classification of 2x150 bp pairs against an 8 GB table (not the headline metric)")
     ap.add_argument("--k2-cells", type=int, default=2_000_000_000, help="cells of the compact hash table (4 B each)")
@@ -77,6 +77,8 @@ def main():
         return main_k2(a, rank, world, local, dev)
     if a.workload == "e2e":
         return main_e2e(a, rank, world, local, dev)
+    if a.workload == "e2e-k2":
+        return main_e2e_k2(a, rank, world, local, dev)
 
     contigs = [1_000_000] * 5 if a.small else CHM13_CONTIGS
     n_rec = 200_000 if a.small else a.records
@@ -521,6 +523,86 @@ def main_e2e(a, rank, world, local, dev):
     if not a.e2e_dir:
         shutil.rmtree(work, ignore_errors=True)
     assert ok, "end-to-end result differs from the device flags"
+
+
+def main_e2e_k2(a, rank, world, local, dev):
+    """End-to-end scope of the taxid arm: `scrubby reads -c kraken2 -I DB -T Chordata -D 9606` (rows a9-a11, a4, a7, a8) through
+    sh_kraken_run - database directory on disk, FASTQ pairs in, kraken.reads / kraken.report + filtered FASTQ + JSON out.
+    Not the headline metric.  The table is 5e8 cells (2 GB) here so that writing and re-reading the database stays short."""
+    import shutil
+    import tempfile
+    from scrubby_amd import k2 as K
+    assert world == 1
+    contigs = [1_000_000] * 5 if a.small else CHM13_CONTIGS
+    n_rec = 200_000 if a.small else a.records
+    n_rec -= n_rec & 1
+    n_pairs = n_rec // 2
+    cells = 12_000_017 if a.small else min(a.k2_cells, 500_000_009)
+    P, R = S.ref_params(REF_SEED, contigs), S.read_params(0x5C2B0030)
+    G, L = P.genome_len, R.read_len
+    work = a.e2e_dir or tempfile.mkdtemp(prefix="scrubby_e2e_k2_")
+    os.makedirs(work, exist_ok=True)
+    t0 = time.time()
+    parents, externals, names, ranks, ids = k2_taxonomy(2_000 if a.small else a.k2_nodes, 0x5C2B0030)
+    db = K.K2Db.create(K.default_opts(), cells, parents, externals, names, ranks, device=local)
+    d_ref = torch.empty(G + 64, dtype=torch.uint8, device=dev)
+    S.synth_ref_device(P, 0, G, d_ref)
+    # the table is too small for every minimizer of the 3.1 Gbp reference: the first 400 Mbp under Homo sapiens, filler to load 0.7
+    g_ins = G if a.small else min(G, 400_000_000)
+    db.insert_sequence_device(d_ref, g_ins, ids["Homo sapiens"])
+    del d_ref
+    fill = max(int(0.70 * cells) - db.info()["size"], 0)
+    db.insert_random(0x5C2B0031, fill, ids["Bacteria"], len(parents) - 1)
+    torch.cuda.synchronize()
+    dbdir = os.path.join(work, "db")
+    os.makedirs(dbdir, exist_ok=True)
+    db.save(dbdir)
+    d_reads = torch.empty(n_rec * L + 64, dtype=torch.uint8, device=dev)
+    d_off = torch.empty(n_rec + 1, dtype=torch.int64, device=dev)
+    S.synth_reads_device(P, R, 0, n_rec, d_reads, d_off)
+    reads = d_reads[:n_rec * L].cpu().numpy().reshape(n_pairs, 2, L)
+    r1, r2 = os.path.join(work, "R1.fastq"), os.path.join(work, "R2.fastq")
+    in_bytes = fastq_file(r1, reads[:, 0, :], 1, 0) + fastq_file(r2, reads[:, 1, :], 2, 0)
+    del reads, d_reads, d_off, db
+    torch.cuda.empty_cache()
+    t_setup = time.time() - t0
+    o1, o2, js, wd = (os.path.join(work, x) for x in ("clean_1.fastq", "clean_2.fastq", "report.json", "work"))
+    threads = a.e2e_threads or min(16, os.cpu_count() or 4)
+
+    def run():
+        for f in (o1, o2, js):
+            if os.path.exists(f):
+                os.remove(f)
+        t = time.perf_counter()
+        res = K.kraken_run([r1, r2], [o1, o2], dbdir, taxa=["Chordata"], taxa_direct=["9606"], workdir=wd, json=js, threads=threads, device=local,
+                           command="scrubby reads -c kraken2 -i R1 R2 -o clean_1 clean_2 -I db -T Chordata -D 9606")
+        return time.perf_counter() - t, res
+
+    for _ in range(a.warmup):
+        run()
+    runs = [run() for _ in range(a.steps)]
+    dt = sum(r[0] for r in runs)
+    rep = json.load(open(js))
+    out = {
+        "metric": "reads/s end to end, taxid arm (FASTQ pairs + Kraken2-format database directory in -> kraken.reads / kraken.report + filtered FASTQ + JSON) - NOT the headline metric",
+        "value": round(n_rec * a.steps / dt, 1), "unit": "reads/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "configs[4] end to end at reduced table size: %d synthetic 2x150bp pairs, table of %d cells (%.1f GB), -T Chordata -D 9606" % (n_pairs, cells, cells * 4 / 1e9),
+                   "records": n_rec, "host_threads": threads, "input_bytes": int(in_bytes)},
+        "runs_ms": [{"total": round(r[0] * 1e3, 1), "db_open": round(r[1]["ms_index"], 1), "ingest": round(r[1]["ms_ingest"], 1),
+                     "classify": round(r[1]["ms_classify"], 1), "files + filter": round(r[1]["ms_write"], 1)} for r in runs],
+        "result": {"reads_in": rep["reads_in"], "reads_out": rep["reads_out"], "reads_removed": rep["reads_removed"]},
+        "setup_s": round(t_setup, 1),
+    }
+    if a.e2e_legacy:
+        os.environ["SCRUBBY_HIP_LEGACY_HOST"] = "1"
+        t, lres = run()
+        os.environ.pop("SCRUBBY_HIP_LEGACY_HOST")
+        out["legacy_host_path"] = {"reads_per_s": round(n_rec / t, 1), "s": round(t, 2), "reads_removed": lres["reads_removed"],
+                                   "identical_counts": bool(lres["reads_removed"] == rep["reads_removed"] and lres["reads_out"] == rep["reads_out"])}
+    print(json.dumps(out), flush=True)
+    if not a.e2e_dir:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def ctx_chunk(a, n_rec):

@@ -166,7 +166,7 @@ class K2Db:
 
 
 def kraken_run(inputs, outputs, db, taxa=(), taxa_direct=(), workdir=None, confidence=-1.0, min_hit_groups=0, extract=False,
-               json=None, read_ids=None, command="", device=0):
+               json=None, read_ids=None, command="", device=0, threads=4):
     c = KrakenConfig()
     for i, (a, b) in enumerate(zip(inputs, outputs)):
         c.input[i], c.output[i] = str(a).encode(), str(b).encode()
@@ -178,7 +178,7 @@ def kraken_run(inputs, outputs, db, taxa=(), taxa_direct=(), workdir=None, confi
     c.confidence, c.min_hit_groups = confidence, min_hit_groups
     c.json = str(json).encode() if json else None
     c.read_ids = str(read_ids).encode() if read_ids else None
-    c.command, c.device, c.threads = command.encode(), device, 4
+    c.command, c.device, c.threads = command.encode(), device, threads
     r = S.ReadsResult()
     S.check(S.load().sh_kraken_run(C.byref(c), C.byref(r)))
     return {n: getattr(r, n) for n, _ in S.ReadsResult._fields_}
