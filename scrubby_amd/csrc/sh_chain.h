@@ -31,7 +31,8 @@ struct ChainParams {
     int32_t flag_stop;
     // Flag-only pair test (host-computed, pair_dq_max = 0: off; see pair_decides in sh_classify.hip): two anchors of one
     // strand / contig on one diagonal, pair_dq_min <= dq = dr <= pair_dq_max apart, decide the read when all selected seeds
-    // have distinct keys.  A reference position holds at most one minimizer, so at most dq - 1 <= max_skip - 2 anchors
+    // have distinct keys (k_expand also takes key multiplicity M with dq <= (max_skip + 1) / M - 1).  A reference position holds at
+    // most one minimizer, so at most dq - 1 <= max_skip - 2 anchors (M > 1: (dq + 1) * M - 2 <= max_skip - 1)
     // sort between the two: mg_lchain_dp's look-back from the later one cannot break (n_skip), run out (max_iter) or leave the
     // window before it scores the earlier one, with sc = min(k, dq) and no penalty (dd = 0, pen_skip = 0):
     // f >= k + min(k, dq) >= min_sc = flag_stop, which decides the cluster (above).

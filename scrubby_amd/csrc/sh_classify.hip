@@ -924,17 +924,31 @@ __device__ inline bool pair_decides(const uint4 rec, uint32_t my_n, uint32_t n_s
 {
     const uint32_t qp = rec.w >> 1;
     const bool sel = my_n > 0;
-    bool dup = false;
-    uint32_t p_occ = UINT32_MAX, p_u = 0;
-    for (uint32_t u = 0; u < n_seed; ++u) {
-        const uint32_t ou = rdlane(my_n, u);
-        if (ou == 0) continue;
-        const uint32_t xu = rdlane(rec.x, u), yu = rdlane(rec.y, u), qu = rdlane(qp, u);
-        dup |= sel && u != lane && xu == rec.x && yu == rec.y;
-        const int32_t d = (int32_t)qu - (int32_t)qp;
-        if (sel && d >= P.pair_dq_min && d <= P.pair_dq_max && ou < p_occ) { p_occ = ou; p_u = u; }
+    // one sweep over the seeds: how many selected seeds share this lane's key (itself included), and the lane's cheapest partner ahead
+    // of it in the query.  With key multiplicity M a reference position contributes up to M anchors, so at most (D + 1) * M - 2 sort
+    // between two co-diagonal anchors D apart: D is capped at (max_skip + 1) / M - 1 (M = 1: pair_dq_max; tandem arrays whose k-mers
+    // recur inside the read: M = 2 -> 12, 3 -> 7, 5 -> 4, more: no pair can be trusted).
+    uint32_t mult = 0, p_occ = UINT32_MAX, p_u = 0;
+    auto sweep = [&](int32_t dmax, bool count) {
+        p_occ = UINT32_MAX; p_u = 0;
+        for (uint32_t u = 0; u < n_seed; ++u) {
+            const uint32_t ou = rdlane(my_n, u);
+            if (ou == 0) continue;
+            const uint32_t xu = rdlane(rec.x, u), yu = rdlane(rec.y, u), qu = rdlane(qp, u);
+            if (count) mult += sel && xu == rec.x && yu == rec.y;
+            const int32_t d = (int32_t)qu - (int32_t)qp;
+            if (sel && d >= P.pair_dq_min && d <= dmax && ou < p_occ) { p_occ = ou; p_u = u; }
+        }
+    };
+    sweep(P.pair_dq_max, true);
+    uint32_t M = sel ? mult : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) M = max(M, (uint32_t)__shfl_xor((int)M, o));
+    if (M > 1) {
+        const int32_t dmax = min((int32_t)(((uint32_t)P.max_skip + 1u) / M) - 1, P.pair_dq_max);
+        if (dmax < P.pair_dq_min) { if (dbg_cost0 && lane == 0) atomicAdd(dbg_cost0 - 3, 1u); return false; }       // dbg: n_leg_reason[0] = keys repeat too often
+        sweep(dmax, false);
     }
-    if (__ballot(dup) != 0) { if (dbg_cost0 && lane == 0) atomicAdd(dbg_cost0 - 3, 1u); return false; }       // dbg: n_leg_reason[0] = duplicate keys
     // cost of a pair ~ dependent loads: the shorter list is walked (one load round per 64), each step a binary search of the longer
     uint32_t cost = UINT32_MAX;
     if (p_occ != UINT32_MAX) {
@@ -1142,7 +1156,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
             }
             continue;
         }
-        if (!LONG && a.flag_only && P.pair_dq_max > 0 && n_st == 1 && n_a > (uint32_t)P.pair_min_anchors && pair_decides(rec0, my_n0, n_seed, lane, a.positions, P, (a.dbg & 16) ? &a.ctr->n_leg_reason[3] : nullptr)) {
+        if (!LONG && a.flag_only && P.pair_dq_max > 0 && n_st == 1 && n_a > (uint32_t)P.pair_min_anchors && pair_decides(rec0, my_n0, n_seed, lane, a.positions, P, ((a.dbg & 16) && (!(a.dbg & 128) || n_a > 4096u)) ? &a.ctr->n_leg_reason[3] : nullptr)) {
             // decided without a single anchor: sh_stats.n_anchors still counts what the occurrence filter admitted
             if (lane == 0) { BigMeta m{r, n_a, rep_len, 0u}; a.B.meta[w] = m; a.B.acc_nu[w] = 1; a.B.acc_best[w] = P.min_sc; }
             anchors_wave += n_a; ++n_pair;
