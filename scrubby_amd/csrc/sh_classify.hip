@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
                 }
                 if (i < len) {
                     uint32_t c = (amb & 1u) ? 4u : (codes & 3u);
-                    st.template step<P>(c, i, emit);
+                    st.template step<P>(c, i, emit, emit);
                 }
                 codes >>= 2; amb >>= 1;
             };

@@ -139,7 +139,7 @@ struct SketchPacked {
     }
 
     template <int P, class Emit>
-    __device__ __forceinline__ void ties(Emit &&emit, bool with_p)
+    __device__ __forceinline__ void ties(Emit &&emit, bool with_p)      // emit: the caller's push for tie entries (may differ from the main one)
     {   // every other entry with the minimum's hash, oldest first: slots P+1 .. W-1, then 0 .. P (P itself only after a rescan)
         const uint64_t mh = minp >> 18;
 #pragma unroll
@@ -158,8 +158,11 @@ struct SketchPacked {
         return c;
     }
 
-    template <int P, class Emit>
-    __device__ __forceinline__ void step(uint32_t c, uint32_t pos, Emit &&emit)
+    // emit: push of the window minimum (one site per step); tie_emit: push used inside the tie loops (2 x W sites per step).  The read
+    // kernel passes the same push for both: these cold sites make up most of its 15 k-instruction loop body (without them it is 4 k
+    // and 9 % faster, an instruction-cache effect), but handing tie-heavy reads to the re-sketch path instead costs more than that.
+    template <int P, class Emit, class TieEmit>
+    __device__ __forceinline__ void step(uint32_t c, uint32_t pos, Emit &&emit, TieEmit &&tie_emit)
     {
         uint64_t ip = SH_XMAX;
         if (c < 4) {
@@ -172,20 +175,23 @@ struct SketchPacked {
             l = 0;
         }
         b[P] = ip; hl[P] = (uint32_t)(ip >> 18);
-        if (l == W + k - 1 && minp != SH_XMAX) {       // first full window: identical k-mers
-            if (same_low() > 1) ties<P>(emit, false);
+        const uint64_t old = minp;
+        if (l == W + k - 1 && old != SH_XMAX) {        // first full window: identical k-mers
+            if (same_low() > 1) ties<P>(tie_emit, false);
         }
-        if (ip < minp) {                                // new minimum (an equal hash at a later position is the smaller word)
-            if (l >= W + k && minp != SH_XMAX) emit(minp);
-            minp = ip;
-        } else if (minp != SH_XMAX && (((uint32_t)minp >> 1) & 0x1ffffu) == 0x1ffffu - (pos - (uint32_t)W)) {   // old minimum left the window
-            if (l >= W + k - 1) emit(minp);
-            uint64_t m = b[0];
+        // The reference's two branches, flattened.  "New minimum" (ix <= minx; an equal hash at a later position is the smaller word)
+        // and "old minimum left the window" (its position is pos - W) both push the OLD minimum, under l >= W + k and l >= W + k - 1
+        // respectively; and in every case the minimum afterwards is the minimum over the ring (a new minimum is below everything in
+        // it, an expired one is no longer in it, otherwise the old one still is).  So: one push site, one unconditional 11-way minimum,
+        // no divergent rescan.  Ties are looked for only after an expiry, as in the reference.
+        const bool newmin = ip < old;
+        const bool expired = !newmin && old != SH_XMAX && (((uint32_t)old >> 1) & 0x1ffffu) == 0x1ffffu - (pos - (uint32_t)W);
+        if ((newmin && l >= W + k && old != SH_XMAX) || (expired && l >= W + k - 1)) emit(old);
+        uint64_t m = b[0];
 #pragma unroll
-            for (int j = 1; j < W; ++j) m = b[j] < m ? b[j] : m;
-            minp = m;
-            if (l >= W + k - 1 && minp != SH_XMAX && same_low() > 1) ties<P>(emit, true);
-        }
+        for (int j = 1; j < W; ++j) m = b[j] < m ? b[j] : m;
+        minp = m;
+        if (expired && l >= W + k - 1 && m != SH_XMAX && same_low() > 1) ties<P>(tie_emit, true);
     }
 
     template <class Emit>
