@@ -140,13 +140,27 @@ struct SketchPacked {
 
     template <int P, class Emit>
     __device__ __forceinline__ void ties(Emit &&emit, bool with_p)      // emit: the caller's push for tie entries (may differ from the main one)
-    {   // every other entry with the minimum's hash, oldest first: slots P+1 .. W-1, then 0 .. P (P itself only after a rescan)
+    {   // every other entry with the minimum's hash, oldest first: slots P+1 .. W-1, then 0 .. P-1, then P itself (only after a rescan).
+        // Which slots tie is a bitmask from W compares; the pushes come from ONE site inside a loop that is deliberately not unrolled
+        // (the slot's value is fetched by a select chain): ties are rare, and 2 x W inlined push sites per unrolled step, each with its
+        // drain call, would make up three quarters of the read kernel's loop body and push it out of the instruction cache.
         const uint64_t mh = minp >> 18;
+        uint32_t mask = 0;
 #pragma unroll
-        for (int j = P + 1; j < W; ++j) if ((b[j] >> 18) == mh && b[j] != minp && b[j] != SH_XMAX) emit(b[j]);
+        for (int j = 0; j < W; ++j) mask |= (uint32_t)((b[j] >> 18) == mh && b[j] != minp && b[j] != SH_XMAX) << j;
+        if (!with_p) mask &= ~(1u << P);
+#pragma clang loop unroll(disable)
+        for (int t = 1; t <= W && mask != 0; ++t) {
+            int slot = P + t;
+            if (slot >= W) slot -= W;
+            if ((mask >> slot) & 1u) {
+                mask &= ~(1u << slot);
+                uint64_t v = b[0];
 #pragma unroll
-        for (int j = 0; j < P; ++j) if ((b[j] >> 18) == mh && b[j] != minp && b[j] != SH_XMAX) emit(b[j]);
-        if (with_p && (b[P] >> 18) == mh && b[P] != minp && b[P] != SH_XMAX) emit(b[P]);
+                for (int j = 1; j < W; ++j) v = slot == j ? b[j] : v;
+                emit(v);
+            }
+        }
     }
 
     __device__ __forceinline__ int same_low() const
