@@ -86,7 +86,8 @@ def main():
     if ont:
         n_rec = 20_000 if a.small else (a.records if a.records != 20_000_000 else 200_000)
     P = S.ref_params(REF_SEED, contigs)
-    R = S.read_params(0x5C2B0020, host_pct=50, sub_per_10k=500, n_read_pct=0) if ont else S.read_params(READ_SEED)
+    # long reads: 2 % substitutions + 1.56 % insertions + 1.56 % deletions (n_read_pct = 1 switches the generator's indels on)
+    R = S.read_params(0x5C2B0020, host_pct=50, sub_per_10k=200, n_read_pct=1) if ont else S.read_params(READ_SEED)
     G = P.genome_len
     opts = S.preset("map-ont" if ont else "sr")
 
@@ -236,7 +237,7 @@ def main():
             "dtype": "u64/i32 (f32 in the chain gap penalty)", "data": "synthetic",
             "union_bytes_gathered": union["bytes"],
             "config": {
-                "workload": ("configs[3] stand-in: %d long reads (log-normal-like lengths, median 5.4 kb, 5 %% substitutions), map-ont preset; "
+                "workload": ("configs[3] stand-in: %d long reads (log-normal-like lengths, median 5.4 kb; 2 %% substitutions, 1.56 %% insertions, 1.56 %% deletions), map-ont preset; "
                              "segment-parallel long-read front end + repeat path" % n_rec if ont else
                              "cfg1-small: 200k records vs 5 Mb" if a.small else
                              "configs[1]: 10M synthetic 2x150bp PE (20M records) vs CHM13v2-sized synthetic reference, sr preset, k-mer/minimizer classifier path"),

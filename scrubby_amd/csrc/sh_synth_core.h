@@ -159,7 +159,7 @@ SYN_FN uint8_t syn_read_base(const syn_ref_params *P, const syn_read_params *R, 
     return (uint8_t)"ACGT"[b];
 }
 
-/* ---- long reads (BASELINE config 4 stand-in): log-normal-like lengths, substitutions only -------------------------
+/* ---- long reads (BASELINE config 4 stand-in): log-normal-like lengths, substitutions and (optionally) indels -----------
  * Length of read r: integer-only (bit-reproducible on both sides, no libm): the 16 quantile knots of a
  * log-normal(mu = 8.497, sigma = 0.7) clipped to [200, 28000], uniform inside a quantile bin.
  * Measured on 200 k reads: mean ~7.0 kb, median ~5.4 kb, N50 ~9 kb. */
@@ -172,27 +172,55 @@ SYN_FN uint32_t syn_long_len(uint64_t seed, uint64_t r)
     return lo + (uint32_t)(((h >> 8) & 0xffffff) * (uint64_t)(hi - lo) >> 24);
 }
 
-/* base i of long read r (single-end, either strand), host_pct % from the reference */
+/* base i of long read r (single-end, either strand), host_pct % from the reference.
+ * R->n_read_pct != 0 switches indels on (the field is the short-read generator's; long reads have no N reads): along the walk
+ * over the reference every 32-base block of the read carries, each with probability 1/2 (one bit of a hash word per block, 64
+ * blocks per word), one inserted base and one skipped reference base at hash-chosen offsets - 1.56 % insertions and 1.56 %
+ * deletions per base (1.5 % each).  The reference offset of walk position t is t - insertions before + deletions
+ * up to t, in closed form: popcounts of the whole words before t's word, of the bits below t's block, and the block's own events. */
 SYN_FN uint8_t syn_long_read_base(const syn_ref_params *P, const syn_read_params *R, uint64_t r, uint32_t len, uint32_t i)
 {
     const uint64_t h = syn_mix(R->seed ^ 0x0A7ULL ^ (r * 0xD6E8FEB86659FD93ULL));
     const uint32_t is_host = (uint32_t)(h % 100) < R->host_pct, rev = (uint32_t)(h >> 40) & 1;
     const uint64_t h3 = syn_mix(h ^ 0x2545F4914F6CDD1DULL);
+    const uint32_t indel = R->n_read_pct != 0;
+    const uint32_t t = rev ? len - 1 - i : i;                 /* walk order along the reference */
+    const uint32_t span = indel ? len + (len >> 5) + 64 : len;  /* reference bases the read can cover */
+    int64_t ref_off = t;
+    uint32_t inserted = 0, ins_base = 0;
+    if (indel) {
+        const uint32_t blk = t >> 5, grp = blk >> 6, bit = blk & 63, o = t & 31;
+        const uint64_t kr = r * 0xA24BAED4963EE407ULL;
+        int64_t shift = 0;
+        uint32_t g;
+        for (g = 0; g < grp; ++g)
+            shift += (int64_t)__builtin_popcountll(syn_mix(R->seed ^ 0xDE1E7EULL ^ (kr + g))) - (int64_t)__builtin_popcountll(syn_mix(R->seed ^ 0x1A5E27ULL ^ (kr + g)));
+        {
+            const uint64_t ins_w = syn_mix(R->seed ^ 0x1A5E27ULL ^ (kr + grp)), del_w = syn_mix(R->seed ^ 0xDE1E7EULL ^ (kr + grp));
+            const uint64_t below = bit ? (~0ULL >> (64 - bit)) : 0ULL;
+            const uint64_t hb = syn_mix(R->seed ^ 0xB10C0FF5ULL ^ (kr + blk));
+            const uint32_t io = (uint32_t)hb & 31, dofs = (uint32_t)(hb >> 8) & 31;
+            shift += (int64_t)__builtin_popcountll(del_w & below) - (int64_t)__builtin_popcountll(ins_w & below);
+            if ((ins_w >> bit) & 1) { if (io < o) shift -= 1; else if (io == o) { inserted = 1; ins_base = (uint32_t)(hb >> 16) & 3; } }
+            if (((del_w >> bit) & 1) && dofs <= o) shift += 1;
+        }
+        ref_off = (int64_t)t + shift;
+    }
     uint64_t start;
     uint32_t b;
     if (is_host) {
-        uint64_t g = h3 % (P->genome_len - len);
+        uint64_t g = h3 % (P->genome_len - span);
         uint32_t c = syn_contig_of(P, g);
         uint64_t cend = P->contig_start[c + 1];
-        if (g + len > cend) g = cend > len ? cend - len : 0;
+        if (g + span > cend) g = cend > span ? cend - span : 0;
         if (g < P->contig_start[c]) g = P->contig_start[c];       /* contig shorter than the read: it runs into the next one */
         start = g;
-        b = syn_ref_base(P, rev ? start + len - 1 - i : start + i);
+        b = inserted ? ins_base : syn_ref_base(P, start + (uint64_t)ref_off);
     } else {
-        start = h3 % ((1ULL << 40) - len);
-        const uint64_t g = rev ? start + len - 1 - i : start + i;
+        start = h3 % ((1ULL << 40) - span);
+        const uint64_t g = start + (uint64_t)ref_off;
         const uint64_t c = syn_mix(R->seed ^ 0x3C0FFEE3ULL ^ (g >> 5));
-        b = (uint32_t)(c >> (2 * (g & 31))) & 3;
+        b = inserted ? ins_base : (uint32_t)(c >> (2 * (g & 31))) & 3;
     }
     if (rev) b ^= 3;
     const uint64_t hr = syn_mix(R->seed ^ 0xBADC0FFEE0DDF00DULL ^ (r * 131072 + i));

@@ -246,6 +246,13 @@ def test_long_read_generator_device_matches_cpu(S, oracle):
     d = torch.empty(len(cpu) + 64, dtype=torch.uint8, device="cuda")
     S.synth_long_reads_device(Pg, Rg, 7, n, d_off, len(cpu), d)
     assert np.array_equal(d[:len(cpu)].cpu().numpy(), cpu)
+    # with indels switched on (n_read_pct != 0: 2 % substitutions + 1.56 % insertions + 1.56 % deletions, bench.py --workload ont)
+    Rgi = S.read_params(0x5C2B0020, host_pct=50, sub_per_10k=200, n_read_pct=1)
+    Roi = oracle.read_params(0x5C2B0020, host_pct=50, sub_per_10k=200, n_read_pct=1)
+    cpu_i, offs_i = oracle.synth_long_reads(Po, Roi, 7, n)
+    assert np.array_equal(offs_i, offs) and not np.array_equal(cpu_i, cpu)
+    S.synth_long_reads_device(Pg, Rgi, 7, n, d_off, len(cpu_i), d)
+    assert np.array_equal(d[:len(cpu_i)].cpu().numpy(), cpu_i)
     # and they classify identically (map-ont, legacy long-read path)
     seqs = [oracle.synth_ref(Po, Po.contig_start[i], 1_000_000) for i in range(5)]
     gidx = S.Index.build([bytes(s) for s in seqs], S.preset("map-ont"))
@@ -298,7 +305,7 @@ def test_long_read_front_end_all_paths(S, oracle):
     re-sketch), query-minimizer thinning, multi-tile seed selection, the giant sort and the cluster queue all run;
     traces match the oracle, and the flag-only mode (first-chain shortcut) gives the same flags."""
     Po = oracle.ref_params(W.CFG1_REF_SEED, W.CFG1_CONTIGS)
-    Ro = oracle.read_params(0x5C2B0021, host_pct=60, sub_per_10k=500, n_read_pct=0)
+    Ro = oracle.read_params(0x5C2B0021, host_pct=60, sub_per_10k=200, n_read_pct=1)      # substitutions + indels
     n = 1500
     bases, offs = oracle.synth_long_reads(Po, Ro, 11, n)
     seqs = [oracle.synth_ref(Po, Po.contig_start[i], 1_000_000) for i in range(5)]
