@@ -340,6 +340,11 @@ typedef struct sh_kraken_config {
 } sh_kraken_config;
 sh_status sh_kraken_run(const sh_kraken_config *cfg, sh_reads_result *out);
 
+/* ---- multi-GPU: the one exchange of the read-sharded path (HashSet union of cleaner.rs:564-570) --------------
+ * d_flags[n] (1 = host) -> d_bits[(n + 7) / 8], bit i of byte j = record 8j + i; each rank packs its own slice and the disjoint
+ * slices are all-gathered over RCCL (scrubby_amd/dist.py). */
+sh_status sh_pack_flags_device(const uint8_t *d_flags, uint64_t n, uint8_t *d_bits, void *stream);
+
 /* ---- micro-benchmarks for the roofline (bench.py) ---------------------------------------- */
 /* random 16-B slot gathers over the index table; returns achieved GB/s of useful bytes */
 sh_status sh_bench_gather(const sh_index *idx, uint64_t n_probes, int32_t iters, double *out_gbs_useful, double *out_ms);

@@ -390,6 +390,30 @@ extern "C" sh_status sh_synth_long_reads_device(const void *ref_params, const vo
     return SH_OK;
 }
 
+// ---- depleted-record bitmap: flags -> 1 bit per record, for the one exchange of the sharded path -------------
+// one wave per 64 records: the ballot of (flag == 1) IS the 8 bytes of the bitmap (bit i of byte j = record 8j + i, as
+// scrubby_amd/dist.py's pack_flags lays it out)
+__global__ __launch_bounds__(256) void k_pack_flags(const uint8_t *flags, uint64_t n, uint8_t *bits)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool host = i < n && flags[i] == 1;
+    const unsigned long long m = __ballot(host);
+    if ((threadIdx.x & 63) == 0) {
+        const uint64_t byte0 = i >> 3, n_bytes = (n + 7) >> 3;
+        for (int b = 0; b < 8 && byte0 + b < n_bytes; ++b) bits[byte0 + b] = (uint8_t)(m >> (8 * b));
+    }
+}
+
+extern "C" sh_status sh_pack_flags_device(const uint8_t *d_flags, uint64_t n, uint8_t *d_bits, void *stream)
+{
+    SH_CHECK(d_flags && d_bits, SH_ERR_BAD_ARG, "sh_pack_flags_device: null argument");
+    if (n == 0) return SH_OK;
+    SH_CHECK((n + 255) / 256 < (1ull << 31), SH_ERR_BAD_ARG, "too many records for one launch");
+    hipLaunchKernelGGL(k_pack_flags, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_flags, n, d_bits);
+    SH_HIP(hipGetLastError());
+    return SH_OK;
+}
+
 // ---- gather micro-benchmark: the practical ceiling for 16-B random probes into this table ----------------
 __global__ void k_gather(const uint4 *slots, uint32_t lg, uint64_t n, uint64_t seed, unsigned long long *sink)
 {

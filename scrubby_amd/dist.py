@@ -22,6 +22,9 @@ def shard_range(n_records, rank, world):
 def pack_flags(flags):
     """uint8 flags (1 = host) -> little-endian bitmap, 1 bit per record."""
     n = flags.numel()
+    if flags.is_cuda and flags.dtype == torch.uint8 and flags.is_contiguous():      # the library's ballot kernel (csrc/sh_api.hip)
+        from scrubby_amd import lib as S
+        return S.pack_flags_device(flags)
     pad = (-n) % 8
     b = (flags == 1).to(torch.uint8)
     if pad:

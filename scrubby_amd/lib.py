@@ -112,7 +112,7 @@ EXPORTS = [
     "sh_index_build", "sh_index_build_device", "sh_index_build_fasta", "sh_index_save", "sh_index_load",
     "sh_index_info_get", "sh_index_export", "sh_index_free",
     "sh_ctx_create", "sh_ctx_destroy", "sh_classify_device", "sh_classify_batch",
-    "sh_synth_ref_device", "sh_synth_reads_device", "sh_synth_long_reads_device", "sh_bench_gather",
+    "sh_synth_ref_device", "sh_synth_reads_device", "sh_synth_long_reads_device", "sh_bench_gather", "sh_pack_flags_device",
     "sh_reads_run", "sh_host_get_id", "sh_host_filter_fastx", "sh_host_filter_fastx_stream", "sh_host_read_difference",
     "sh_classifier_run", "sh_classifier_taxids", "sh_alignment_run",
     "sh_k2_default_opts", "sh_k2_open", "sh_k2_create", "sh_k2_insert_device", "sh_k2_insert_sequence_device",
@@ -155,6 +155,7 @@ def load():
     L.sh_synth_reads_device.argtypes = [C.POINTER(RefParams), C.POINTER(ReadParams), u64, u64, vp, vp, vp]
     L.sh_synth_long_reads_device.argtypes = [C.POINTER(RefParams), C.POINTER(ReadParams), u64, u64, vp, u64, vp, vp]
     L.sh_bench_gather.argtypes = [vp, u64, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.sh_pack_flags_device.argtypes = [vp, u64, vp, vp]
     L.sh_reads_run.argtypes = [C.POINTER(ReadsConfig), C.POINTER(ReadsResult)]
     L.sh_classifier_run.argtypes = [C.POINTER(ClassifierConfig), C.POINTER(ReadsResult)]
     L.sh_alignment_run.argtypes = [C.POINTER(AlignmentConfig), C.POINTER(ReadsResult)]
@@ -348,6 +349,15 @@ def synth_reads_device(P, R, r0, n_records, out, offsets=None):
 
 
 # ---- host-side mirror of the reference path (C++ in csrc/sh_host.cpp) ------------------------------------------------
+def pack_flags_device(d_flags):
+    """uint8 CUDA flags (1 = host) -> little-endian bitmap on the device (wave ballots; one launch on the current stream)."""
+    import torch
+    n = d_flags.numel()
+    bits = torch.empty((n + 7) // 8, dtype=torch.uint8, device=d_flags.device)
+    check(load().sh_pack_flags_device(C.c_void_p(d_flags.data_ptr()), n, C.c_void_p(bits.data_ptr()), _stream_ptr()))
+    return bits
+
+
 def get_id(header):
     """utils.rs:91-103: first whitespace token of a FASTX header (bytes or str)."""
     h = header if isinstance(header, bytes) else header.encode()

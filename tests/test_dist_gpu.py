@@ -22,6 +22,7 @@ def test_union_on_device_tensors_single_rank_nccl():
         flags = (rng.random(n) < 0.5).astype(np.uint8)
         flags[::101] = 2
         d = torch.from_numpy(flags).cuda()
+        assert np.array_equal(D.pack_flags(d).cpu().numpy(), D.pack_flags(torch.from_numpy(flags)).numpy())      # ballot kernel == torch ops
         gathered, sb = D.union_depleted(d, slice_bytes=(n + 7) // 8)
         assert gathered.is_cuda and gathered.numel() == sb == (n + 7) // 8
         back = D.unpack_flags(gathered, n).cpu().numpy()
