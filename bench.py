@@ -6,11 +6,19 @@ Workload (BASELINE.json configs[1]): 10 M synthetic 2x150 b
 synthetic reference with the `sr` preset.  No network on the GPU box, so the reference and the
 reads are generated on the device from fixed seeds (scrubby_amd/csrc/sh_synth_core.h).
 
-A "step" = one pass of the hot path (sketch+probe -> chain -> flags) over this rank's batch of
-records, inputs already resident in HBM.  With N > 1 every rank holds its own shard of the
-global record space (weak scaling: 20 M records per GPU) and a replica of the index; the only
-exchange is the final union of the depleted-record bitmap (all_gather over RCCL), done inside
-the timed region.
+A "step" = one pass of the hot path (sketch+probe -> chain -> extension filter -> flags) over this
+rank's batch of records, inputs already resident in HBM.  With N > 1 (BASELINE.json configs[2]) the SAME
+20 M records are cut into contiguous pair-aligned shards (scrubby_amd/dist.py shard_range), one per rank,
+every rank holds a replica of the index, and the only exchange is the final union of the depleted-record
+bitmap (all_gather over RCCL), done inside the timed region: strong scaling, `value` = 20 M records /
+max-over-ranks step time.  The weak-scaling figure (20 M records per GPU) is measured right after it and
+reported as the secondary object `weak_scaling`.
+
+Launch: `python bench.py --gpus N ...` starts the N ranks itself (child processes, spawned before anything
+touches a GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` it takes
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher instead.  Ranks that have to share one device
+(N larger than the visible device count, e.g. a rehearsal on a one-GPU box) do the union over gloo with
+CPU copies of the bitmap, since RCCL refuses two ranks on one device.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      dominant kernel (k_sketch_probe): algorithmic bytes / HIP-event kernel time vs 8 TB/s
@@ -56,20 +64,52 @@ def parse():
     ap.add_argument("--e2e-legacy", action="store_true", help="--workload e2e: also time the collect-then-map host path")
     ap.add_argument("--e2e-dir", default=None, help="--workload e2e: scratch directory (default: a temp dir)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the secondary weak-scaling measurement (20 M records per GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather-bench", action="store_true", help="also time raw 16-B random gathers over the table")
     return ap.parse_args()
 
 
+def spawn_ranks(a):
+    """`bench.py --gpus N` outside a launcher: start the N ranks as child processes of this one, which has not touched a GPU
+    (no exec from a process with an initialised HIP runtime), hand them the rendezvous through the environment, pass rank 0's
+    JSON line through and return the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    n_dev = torch.cuda.device_count()              # does not initialise the runtime
+    shared_device = world > max(n_dev, 1)          # rehearsal: more ranks than devices
+    local = local % max(n_dev, 1)
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        backend = "gloo" if shared_device else "nccl"
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     S.require_gpu()
@@ -79,7 +119,12 @@ def main():
         return main_e2e(a, rank, world, local, dev)
     if a.workload == "e2e-k2":
         return main_e2e_k2(a, rank, world, local, dev)
+    return main_reads(a, rank, world, local, dev, backend)
 
+
+def main_reads(a, rank, world, local, dev, backend):
+    if world > 1:
+        import torch.distributed as dist
     contigs = [1_000_000] * 5 if a.small else CHM13_CONTIGS
     n_rec = 200_000 if a.small else a.records
     ont = a.workload == "ont"
@@ -106,35 +151,33 @@ def main():
     torch.cuda.empty_cache()
 
     L = R.read_len
-    if ont:
-        lens = long_read_lengths(R.seed, rank * n_rec, n_rec)
-        off_np = np.zeros(n_rec + 1, dtype=np.int64)
-        off_np[1:] = np.cumsum(lens.astype(np.int64))
-        n_bases = int(off_np[-1])
-        d_off = torch.from_numpy(off_np).to(dev)
-        d_reads = torch.empty(n_bases + 64, dtype=torch.uint8, device=dev)
-        S.synth_long_reads_device(P, R, rank * n_rec, n_rec, d_off, n_bases, d_reads)
-        a.chunk = min(a.chunk, a.ont_chunk)
-        ctx = S.Context(index, min(a.chunk, n_rec), n_bases, int(lens.max()))
-    else:
-        n_bases = n_rec * L
-        d_reads = torch.empty(n_bases + 64, dtype=torch.uint8, device=dev)
-        d_off = torch.empty(n_rec + 1, dtype=torch.int64, device=dev)
-        S.synth_reads_device(P, R, rank * n_rec, n_rec, d_reads, d_off)     # this rank's shard of the record space
-        ctx = S.Context(index, min(a.chunk, n_rec), n_bases, L)
-    d_flags = torch.zeros(n_rec, dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize()
-
     from scrubby_amd import dist as D
-    n_bits = (n_rec + 7) // 8
+    via_host = backend == "gloo"
+    n_total = n_rec                      # records of the whole job (strong scaling: cut over the ranks)
     union = {"bytes": 0}
 
-    def step():
-        st = ctx.classify(d_reads[:n_bases], d_off, d_flags, None, want_stats=True)
-        if world > 1:   # depleted-record bitmap union: disjoint slices, one all_gather over RCCL
-            gathered, _ = D.union_depleted(d_flags, slice_bytes=n_bits)
-            union["bytes"] = gathered.numel()
-        return st
+    def make_batch(r_lo, n):
+        """Records [r_lo, r_lo + n) of the global record space, resident in HBM, with a context sized for them."""
+        b = {"r_lo": r_lo, "n": n}
+        if ont:
+            lens = long_read_lengths(R.seed, r_lo, n)
+            off_np = np.zeros(n + 1, dtype=np.int64)
+            off_np[1:] = np.cumsum(lens.astype(np.int64))
+            b["n_bases"] = int(off_np[-1])
+            b["d_off"] = torch.from_numpy(off_np).to(dev)
+            b["d_reads"] = torch.empty(b["n_bases"] + 64, dtype=torch.uint8, device=dev)
+            S.synth_long_reads_device(P, R, r_lo, n, b["d_off"], b["n_bases"], b["d_reads"])
+            a.chunk = min(a.chunk, a.ont_chunk)
+            b["ctx"] = S.Context(index, max(min(a.chunk, n), 1), b["n_bases"], int(lens.max()) if n else 1)
+        else:
+            b["n_bases"] = n * L
+            b["d_reads"] = torch.empty(b["n_bases"] + 64, dtype=torch.uint8, device=dev)
+            b["d_off"] = torch.empty(n + 1, dtype=torch.int64, device=dev)
+            S.synth_reads_device(P, R, r_lo, n, b["d_reads"], b["d_off"])
+            b["ctx"] = S.Context(index, max(min(a.chunk, n), 1), b["n_bases"], L)
+        b["d_flags"] = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)[:n]
+        torch.cuda.synchronize()
+        return b
 
     def barrier():
         torch.cuda.synchronize()
@@ -142,23 +185,60 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    stats = []
-    for _ in range(a.steps):
-        stats.append(step())
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(b, slice_bytes, steps, warmup):
+        """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks."""
+        def step():
+            st = b["ctx"].classify(b["d_reads"][:b["n_bases"]], b["d_off"], b["d_flags"], None, want_stats=True)
+            if world > 1:   # depleted-record bitmap union: disjoint slices, one all_gather (RCCL) - SURVEY.md §8e, cleaner.rs:564-570
+                gathered, _ = D.union_depleted(b["d_flags"], slice_bytes=slice_bytes, via_host=via_host)
+                union["bytes"] = gathered.numel()
+                b["gathered"] = gathered
+            return st
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        sts = [step() for _ in range(steps)]
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if via_host else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, sts
 
+    # ---- headline: the job's n_total records, cut over the ranks (N = 1: the whole batch) -------------------
+    if ont and world > 1:      # ragged reads: shards of equal bases, not equal counts (SURVEY.md §8e)
+        cum = np.cumsum(long_read_lengths(R.seed, 0, n_total).astype(np.int64))
+        cuts = [0] + [int(np.searchsorted(cum, cum[-1] * r // world)) for r in range(1, world)] + [n_total]
+        lo, hi = cuts[rank], cuts[rank + 1]
+        slice_bytes = (max(cuts[r + 1] - cuts[r] for r in range(world)) + 7) // 8
+    else:
+        lo, hi = D.shard_range(n_total, rank, world)
+        slice_bytes = (D.shard_range(n_total, 0, world)[1] + 7) // 8
+    B = make_batch(lo, hi - lo)
+    dt, stats = timed(B, slice_bytes, a.steps, a.warmup)
+    union_bytes = union["bytes"]
+    n_rec = hi - lo                       # this rank's records: what its kernels saw
+    n_bases, ctx, d_reads, d_flags, d_off = B["n_bases"], B["ctx"], B["d_reads"], B["d_flags"], B["d_off"]
     n_host = int((d_flags == 1).sum().item())
     ms_step = dt / a.steps * 1e3
-    value = world * n_rec * a.steps / dt
+    value = n_total * a.steps / dt
+    removed_total = n_host
+    if world > 1 and not ont:
+        removed_total = int(D.gathered_to_flags(B["gathered"], slice_bytes, n_total, world).sum().item())
+
+    # ---- secondary: weak scaling (n_total records PER GPU), N > 1 only ----------------------------------------
+    weak = None
+    if world > 1 and not a.no_weak:
+        del B, ctx, d_reads, d_flags, d_off
+        torch.cuda.empty_cache()
+        Bw = make_batch(rank * n_total, n_total)
+        dtw, _ = timed(Bw, (n_total + 7) // 8, a.steps, max(a.warmup, 1))
+        weak = {"value": round(world * n_total * a.steps / dtw, 1), "unit": "reads/s", "ms_per_step": round(dtw / a.steps * 1e3, 3),
+                "records_per_gpu": n_total, "scaling": "weak"}
+        B = Bw
+        n_bases, ctx, d_reads, d_flags, d_off = B["n_bases"], B["ctx"], B["d_reads"], B["d_flags"], B["d_off"]
 
     # ---- roofline (HIP events on the launch stream, inside the library) ---------------------------------
     # per-stage algorithmic bytes per step (SURVEY.md §8d): K1 = L + 8 (offset) + 16 per probe + 1 (flag) per read;
@@ -233,19 +313,21 @@ def main():
             "metric": ("reads/s depleted (long reads, map-ont, vs CHM13v2-sized reference) - NOT the headline metric" if ont else
                        "reads/s depleted (2x150bp PE vs CHM13v2-sized reference), records classified per second"),
             "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64/i32 (f32 in the chain gap penalty)", "data": "synthetic",
-            "union_bytes_gathered": union["bytes"],
+            "union_bytes_gathered": union_bytes, "collective_backend": backend, "weak_scaling": weak,
             "config": {
                 "workload": ("configs[3] stand-in: %d long reads (log-normal-like lengths, median 5.4 kb; 2 %% substitutions, 1.56 %% insertions, 1.56 %% deletions), map-ont preset; "
                              "segment-parallel long-read front end + repeat path" % n_rec if ont else
                              "cfg1-small: 200k records vs 5 Mb" if a.small else
+                             ("configs[2]: the 10M synthetic 2x150bp PE (20M records) of configs[1], read-sharded over %d GPUs, vs CHM13v2-sized synthetic reference, sr preset" % world) if world > 1 else
                              "configs[1]: 10M synthetic 2x150bp PE (20M records) vs CHM13v2-sized synthetic reference, sr preset, k-mer/minimizer classifier path"),
-                "records_per_gpu": n_rec, "read_len": (round(n_bases / n_rec, 1) if ont else L), "host_pct": R.host_pct, "reference_bp": int(G),
+                "records_total": n_total, "records_rank0": n_rec, "read_len": (round(n_bases / n_rec, 1) if ont else L), "host_pct": R.host_pct, "reference_bp": int(G),
                 "preset": "map-ont" if ont else "sr", "k": info["k"], "w": info["w"], "records_per_launch": ctx_chunk(a, n_rec),
-                "parallelism": f"read-sharded x{world}, index replicated", "ref_seed": hex(REF_SEED), "read_seed": hex(READ_SEED),
+                "parallelism": f"read-sharded x{world} (contiguous pair-aligned ranges of the same records), index replicated",
+                "ref_seed": hex(REF_SEED), "read_seed": hex(R.seed),
             },
-            "result": {"reads_removed_rank0": n_host, "n_no_seed": s0["n_no_seed"], "n_chain_small": s0["n_chain_small"],
+            "result": {"reads_removed": removed_total, "reads_removed_rank0": n_host, "n_no_seed": s0["n_no_seed"], "n_chain_small": s0["n_chain_small"],
                        "n_chain_large": s0["n_chain_large"], "probes": s0["n_minimizers"],
                        "repeat_path_anchors": s0["n_anchors"], "repeat_path_clusters": s0["n_clusters"], "n_resketch": s0["n_resketch"],
                        "pair_decided": s0["n_pair_decided"]},
@@ -356,7 +438,7 @@ def main_k2(a, rank, world, local, dev):
     dt = time.time() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_step = dt * 1e3 / max(a.steps, 1)

@@ -38,22 +38,35 @@ def unpack_flags(bits, n):
     return ((bits.to(torch.int32).unsqueeze(1) & w) != 0).to(torch.uint8).reshape(-1)[:n]
 
 
-def union_depleted(flags, slice_bytes=None, group=None):
+def union_depleted(flags, slice_bytes=None, group=None, via_host=False):
     """All ranks contribute the bitmap of their own record slice; every rank receives all slices.
 
     flags: this rank's uint8 flags.  slice_bytes: common slice size in bytes (max over ranks); computed with
-    an all_reduce(max) if omitted.  Returns (gathered uint8 [world * slice_bytes], slice_bytes)."""
+    an all_reduce(max) if omitted.  via_host: device flags, but a CPU collective (gloo) - the bitmap is packed on
+    the device and its 1 bit per record crosses PCIe (ranks sharing one device, where RCCL cannot be used).
+    Returns (gathered uint8 [world * slice_bytes], slice_bytes)."""
     bits = pack_flags(flags)
+    if via_host:
+        bits = bits.cpu()
     world = dist.get_world_size(group)
     if slice_bytes is None:
-        m = torch.tensor([bits.numel()], dtype=torch.int64, device=flags.device)
+        m = torch.tensor([bits.numel()], dtype=torch.int64, device=bits.device)
         dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
         slice_bytes = int(m.item())
     if bits.numel() < slice_bytes:
-        bits = torch.cat([bits, torch.zeros(slice_bytes - bits.numel(), dtype=torch.uint8, device=flags.device)])
-    out = [torch.empty(slice_bytes, dtype=torch.uint8, device=flags.device) for _ in range(world)]
+        bits = torch.cat([bits, torch.zeros(slice_bytes - bits.numel(), dtype=torch.uint8, device=bits.device)])
+    out = [torch.empty(slice_bytes, dtype=torch.uint8, device=bits.device) for _ in range(world)]
     dist.all_gather(out, bits, group=group)
     return torch.cat(out), slice_bytes
+
+
+def gathered_to_flags(gathered, slice_bytes, n_records, world):
+    """The all-gathered slices back to one uint8 vector over the global record space (1 = depleted)."""
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(n_records, r, world)
+        parts.append(unpack_flags(gathered[r * slice_bytes:(r + 1) * slice_bytes], hi - lo))
+    return torch.cat(parts)
 
 
 def sum_counters(values, device, group=None):

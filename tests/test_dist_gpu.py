@@ -30,3 +30,47 @@ def test_union_on_device_tensors_single_rank_nccl():
         assert D.sum_counters([n, int((flags == 1).sum())], d.device) == [n, int((flags == 1).sum())]
     finally:
         dist.destroy_process_group()
+
+
+def test_two_ranks_classify_their_shards_and_unite(tmp_path):
+    """BASELINE configs[2] in miniature: 2 processes (device 0 shared, so gloo carries the union), each classifying its
+    shard_range of the cfg1-mini records; the gathered bitmap must equal the single-rank flags and the oracle's."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    out = tmp_path / "res.json"
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "dist_gpu_worker.py"), str(out), "20001"], env=env))
+    for p in procs:
+        assert p.wait(timeout=280) == 0
+    res = json.load(open(out))
+    assert res["shards"] == [[0, 10002], [10002, 20001]]
+    assert res["union_equals_single_rank"] and res["union_equals_oracle"] and res["same_union_on_every_rank"]
+    assert res["counters"] == [20001, res["depleted"]] and 0 < res["depleted"] < 20001
+
+
+def test_bench_spawns_its_ranks(tmp_path):
+    """`bench.py --gpus 2` starts two ranks itself and reports n_gpus 2 with the same records cut in two (strong scaling)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--small", "--steps", "2", "--warmup", "1", "--no-cpu"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["records_total"] == 200_000 and j["config"]["records_rank0"] == 100_000
+    assert j["weak_scaling"]["records_per_gpu"] == 200_000 and j["union_bytes_gathered"] == 2 * 12500
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--small", "--steps", "2", "--warmup", "1", "--no-cpu"],
+                         env=env, capture_output=True, text=True, timeout=280)
+    j1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j1["n_gpus"] == 1 and j1["result"]["reads_removed"] == j["result"]["reads_removed"]
