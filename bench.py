@@ -722,7 +722,7 @@ def cpu_baseline(index, info, d_reads, n_rec, L, seconds, d_flags, d_off=None, p
         return {"value": None, "unit": "reads/s", "cores": cores, "kind": "port",
                 "sample": f"skipped: host has {avail_gb:.0f} GB free, index copy needs {need_gb:.0f} GB"}
     slots, pos = index.export()
-    oidx = O.Index.wrap(slots, pos, info["w"], info["k"])
+    oidx = O.Index.wrap(slots, pos, info["w"], info["k"], ref=index.export_ref())      # the reference too: the extension stage aligns against it
     oo = oidx.update_opts(O.preset(preset))
     batch = 50_000 if d_off is None else 2_000
     off_all = d_off.cpu().numpy().astype(np.uint64) if d_off is not None else None

@@ -65,11 +65,23 @@ typedef struct sh_opts {
     int32_t max_gap, max_gap_ref, max_frag_len, bw;
     int32_t max_chain_skip, max_chain_iter;
     float   chain_gap_scale, chain_skip_scale;
+    /* the base-level extension stage that `.with_cigar()` switches on (cleaner.rs:473): with
+     * SH_F_CIGAR a read only counts as mapped when a region of one of its chains survives the banded alignment and
+     * minimap2's mm_filter_regs (cnt >= min_cnt, mlen >= min_chain_score, dp_max >= min_dp_max).  sh_preset sets it. */
+    int32_t flags;
+    int32_t a, b, q, e, q2, e2, sc_ambi;          /* ksw2 scores: match, mismatch, gap open / extend (two affine pieces), N */
+    int32_t zdrop, zdrop_inv, end_bonus, min_dp_max;
+    int32_t best_n, bw_long, min_ksw_len;
+    float   pri_ratio, mask_level, max_clip_ratio;
 } sh_opts;
+#define SH_F_CIGAR 1
 
 /* Per-read decision trace (optional output; used by the parity tests). */
 typedef struct sh_trace {
     int32_t n_mini, n_seed, n_anchor, rep_len, rechained, n_chain, best_score, flag;
+    /* extension stage (0 without SH_F_CIGAR or without a chain): regions aligned, regions left (= mappings.len()),
+     * their largest dp_max, a fingerprint of their coordinates / mlen / blen / dp_max / cnt */
+    int32_t n_aligned, n_regs, dp_max; uint32_t sig;
 } sh_trace;
 
 typedef struct sh_index_info {
@@ -101,6 +113,10 @@ typedef struct sh_stats {
     uint64_t n_clusters;       /* independent anchor clusters chained on the repeat path */
     uint64_t n_resketch;       /* reads that took the legacy re-sketch path */
     uint64_t n_pair_decided;   /* flag-only calls: reads (LDS path and repeat path) decided by two co-diagonal seeds, before any anchor exists */
+    uint64_t n_ext_reads;      /* SH_F_CIGAR: reads whose chains went through the extension stage (not decided by a shortcut) */
+    uint64_t n_ext_regions;    /* regions aligned for them */
+    uint64_t n_ext_dropped;    /* reads with a chain but no surviving region: the flags this stage flips */
+    double   ms_ext;           /* HIP-event time of the extension stage */
 } sh_stats;
 
 typedef struct sh_index sh_index;
@@ -132,6 +148,10 @@ sh_status sh_index_load(const char *path, int32_t device, sh_index **out);
 sh_status sh_index_info_get(const sh_index *idx, sh_index_info *out);
 /* Copy table and position array to host (tests, CPU baseline).  Either pointer may be NULL. */
 sh_status sh_index_export(const sh_index *idx, uint64_t *slots /* 2*n_slots */, uint64_t *positions);
+/* The reference bases the extension stage aligns against (minimap2 keeps them in the index too: mi->S), as resident in HBM:
+ * 4-bit nt4 codes (A C G T = 0..3, anything else 4), two per byte, low nibble = even position, contigs back to back;
+ * packed[(n_bases + 1) / 2], contig_start[n_contigs + 1].  Either pointer may be NULL. */
+sh_status sh_index_export_ref(const sh_index *idx, uint8_t *packed, uint64_t *contig_start);
 sh_status sh_index_free(sh_index *idx);
 
 /* ---- classification:  aligner.map(&seq,false,false,None,None) -> len()>0  (cleaner.rs:550-558) --- */

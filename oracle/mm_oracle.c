@@ -11,6 +11,7 @@
  * path that must not be fused if it is to match the HIP kernels bit for bit).
  */
 #include "mm_oracle.h"
+#include "mm_align.h"
 #include <stdlib.h>
 #include <string.h>
 #include <pthread.h>
@@ -31,6 +32,12 @@ static void opts_default(mmo_opts *o)
     o->max_gap = 5000; o->max_gap_ref = -1; o->max_frag_len = 0; o->bw = 500;
     o->max_chain_skip = 25; o->max_chain_iter = 5000;
     o->chain_gap_scale = 0.8f; o->chain_skip_scale = 0.0f;
+    /* mm_mapopt_init; .with_cigar() (cleaner.rs:473) sets MM_F_CIGAR on every preset */
+    o->flags = MMO_F_CIGAR;
+    o->a = 2; o->b = 4; o->q = 4; o->e = 2; o->q2 = 24; o->e2 = 1; o->sc_ambi = 1;
+    o->zdrop = 400; o->zdrop_inv = 200; o->end_bonus = -1; o->min_dp_max = o->min_chain_score * o->a;
+    o->best_n = 5; o->bw_long = 20000; o->min_ksw_len = 200;
+    o->pri_ratio = 0.8f; o->mask_level = 0.5f; o->max_clip_ratio = 1.0f;
 }
 
 int mmo_preset(const char *name, mmo_opts *o)
@@ -41,6 +48,9 @@ int mmo_preset(const char *name, mmo_opts *o)
         o->max_frag_len = 800; o->max_gap = 100; o->bw = 100;
         o->min_cnt = 2; o->min_chain_score = 25;
         o->mid_occ = 1000; o->max_occ = 5000;
+        o->a = 2; o->b = 8; o->q = 12; o->e = 2; o->q2 = 24; o->e2 = 1;
+        o->zdrop = o->zdrop_inv = 100; o->end_bonus = 10; o->bw_long = 100;
+        o->pri_ratio = 0.5f; o->min_dp_max = 40; o->best_n = 20;
         return 0;
     }
     if (strcmp(name, "map-ont") == 0) {         /* Preset::MapOnt, cleaner.rs:457 */
@@ -163,6 +173,8 @@ struct mmo_index {
     uint64_t *slots;       /* 2 * n_slots */
     uint64_t *positions;
     int owned;
+    /* reference sequence for A.6 (mm_idx_getseq): 4-bit packed nt4 codes + contig starts */
+    uint8_t *ref; uint64_t *cstart; uint32_t n_contigs; int ref_owned;
 };
 
 static inline uint64_t slot_home(uint64_t key, uint64_t lg)
@@ -206,6 +218,18 @@ mmo_index *mmo_index_build(int n_seq, const uint8_t *const *seqs, const int64_t 
     }
     idx = (mmo_index *)calloc(1, sizeof(*idx));
     idx->w = w; idx->k = k; idx->owned = 1;
+    {   /* mi->S: the reference as 4-bit nt4 codes */
+        uint64_t g = 0, tot = 0;
+        for (s = 0; s < n_seq; ++s) tot += lens[s] > 0 ? (uint64_t)lens[s] : 0;
+        idx->ref = (uint8_t *)calloc((size_t)(tot / 2 + 2), 1);
+        idx->cstart = (uint64_t *)calloc((size_t)n_seq + 1, 8);
+        idx->n_contigs = (uint32_t)n_seq; idx->ref_owned = 1;
+        for (s = 0; s < n_seq; ++s) {
+            idx->cstart[s] = g;
+            for (i = 0; i < lens[s]; ++i, ++g) idx->ref[g >> 1] |= (uint8_t)(nt4_table[seqs[s][i]] << ((g & 1) * 4));
+        }
+        idx->cstart[n_seq] = g;
+    }
     for (lg = 4; (1ULL << lg) < 2 * n_keys + 1; ++lg) {}
     idx->lg_slots = lg; idx->n_slots = 1ULL << lg; idx->n_keys = n_keys; idx->n_positions = n_pos;
     idx->slots = (uint64_t *)malloc(16 * (size_t)idx->n_slots);
@@ -248,7 +272,21 @@ void mmo_index_free(mmo_index *idx)
 {
     if (!idx) return;
     if (idx->owned) { free(idx->slots); free(idx->positions); }
+    if (idx->ref_owned) { free(idx->ref); free(idx->cstart); }
     free(idx);
+}
+
+void mmo_index_set_ref(mmo_index *idx, const uint8_t *packed, const uint64_t *contig_start, uint32_t n_contigs)
+{
+    if (idx->ref_owned) { free(idx->ref); free(idx->cstart); }
+    idx->ref = (uint8_t *)packed; idx->cstart = (uint64_t *)contig_start; idx->n_contigs = n_contigs; idx->ref_owned = 0;
+}
+
+const uint8_t *mmo_index_ref(const mmo_index *idx, const uint64_t **contig_start, uint32_t *n_contigs)
+{
+    if (contig_start) *contig_start = idx->cstart;
+    if (n_contigs) *n_contigs = idx->n_contigs;
+    return idx->ref;
 }
 
 uint64_t mmo_index_n_keys(const mmo_index *idx) { return idx->n_keys; }
@@ -346,6 +384,8 @@ typedef struct {          /* per-thread scratch, grown on demand */
     m128 *a, *a2; int64_t cap_a;
     int32_t *f, *t; int64_t *p; m128 *z; int64_t cap_dp;
     m128 *srt; int64_t cap_srt;
+    uint64_t *u; int32_t *v; m128 *b; int64_t cap_u, cap_v;      /* chains: u[i] = score<<32 | cnt, v = anchor indices; b = compact_a's output */
+    int32_t n_u; int64_t n_v;
 } scratch_t;
 
 static void *grow(void *p, int64_t *cap, int64_t need, size_t sz)
@@ -359,6 +399,7 @@ static void scratch_free(scratch_t *s)
 {
     free(s->mx); free(s->my); free(s->seeds); free(s->a); free(s->a2);
     free(s->f); free(s->t); free(s->p); free(s->z); free(s->srt);
+    free(s->u); free(s->v); free(s->b);
 }
 
 /* stable merge sort on x (ties keep input order) — radix_sort_128x is stable for the small
@@ -623,21 +664,53 @@ static int32_t chain_dp(const mmo_opts *o, scratch_t *s, int64_t n, int k_idx, i
     if (n_z == 0) return 0;
     sort128x(z, z + n_z, n_z);
     memset(t, 0, 4 * (size_t)n);
+    if (n > s->cap_v) { s->cap_v = n + (n >> 1) + 16; s->v = (int32_t *)realloc(s->v, 4 * (size_t)s->cap_v); }
     for (k = n_z - 1; k >= 0; --k) {
         if (t[z[k].y] == 0) {
             int64_t n_v0 = n_v, end_i;
             int32_t sc;
             end_i = chain_bk_end(max_drop, z, f, p, t, k);
-            for (i = (int64_t)z[k].y; i != end_i; i = p[i]) ++n_v, t[i] = 1;
+            for (i = (int64_t)z[k].y; i != end_i; i = p[i]) s->v[n_v++] = (int32_t)i, t[i] = 1;
             sc = i < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - f[i];
             if (sc >= o->min_chain_score && n_v > n_v0 && n_v - n_v0 >= o->min_cnt) {
-                ++n_u;
+                if (n_u >= s->cap_u) { s->cap_u = s->cap_u * 2 + 16; s->u = (uint64_t *)realloc(s->u, 8 * (size_t)s->cap_u); }
+                s->u[n_u++] = (uint64_t)sc << 32 | (uint64_t)(n_v - n_v0);
                 if (sc > best) best = sc;
             } else n_v = n_v0;
         }
     }
+    s->n_u = n_u; s->n_v = n_v;
     *best_score = best;
     return n_u;
+}
+
+/* compact_a of mg_lchain_dp: each chain's anchors in ascending order, chains re-ordered by the target position of their
+ * first anchor (stable for equal keys); u[] follows.  Result in s->b. */
+static void compact_chains(scratch_t *s)
+{
+    const int32_t n_u = s->n_u;
+    int64_t i, j, k;
+    m128 *b, *w, *a = s->a;
+    uint64_t *u2;
+    b = (m128 *)malloc(sizeof(m128) * (size_t)(s->n_v + 1));
+    for (i = 0, k = 0; i < n_u; ++i) {
+        const int64_t k0 = k; const int32_t ni = (int32_t)s->u[i];
+        for (j = 0; j < ni; ++j) b[k++] = a[s->v[k0 + (ni - j - 1)]];
+    }
+    w = (m128 *)malloc(sizeof(m128) * (size_t)(n_u + 1) * 2);
+    for (i = k = 0; i < n_u; ++i) { w[i].x = b[k].x; w[i].y = (uint64_t)k << 32 | (uint64_t)i; k += (int32_t)s->u[i]; }
+    sort128x(w, w + n_u, n_u);
+    u2 = (uint64_t *)malloc(8 * (size_t)(n_u + 1));
+    free(s->b);
+    s->b = (m128 *)malloc(sizeof(m128) * (size_t)(s->n_v + 1));
+    for (i = k = 0; i < n_u; ++i) {
+        const int32_t jj = (int32_t)w[i].y, n = (int32_t)s->u[jj];
+        u2[i] = s->u[jj];
+        memcpy(&s->b[k], &b[w[i].y >> 32], (size_t)n * sizeof(m128));
+        k += n;
+    }
+    memcpy(s->u, u2, 8 * (size_t)n_u);
+    free(b); free(w); free(u2);
 }
 
 static void map_one(const mmo_index *idx, const mmo_opts *o, scratch_t *s, const uint8_t *seq, int64_t len, mmo_trace *tr)
@@ -663,6 +736,15 @@ static void map_one(const mmo_index *idx, const mmo_opts *o, scratch_t *s, const
     }
     tr->n_seed = n_seed; tr->n_anchor = (int32_t)n_a; tr->rep_len = rep_len;
     tr->n_chain = n_u; tr->best_score = best; tr->flag = n_u > 0;
+    /* A.6: with MM_F_CIGAR (`.with_cigar()`, cleaner.rs:473) a chain only counts once a region of it survives the base-level
+     * alignment and mm_filter_regs.  Restated for the short-read mode; long-read presets keep the chain-level decision. */
+    if (n_u > 0 && (o->flags & MMO_F_CIGAR) && o->is_sr && idx->ref) {
+        mma_result res;
+        compact_chains(s);
+        mma_align_read(o, idx->ref, idx->cstart, idx->n_contigs, seq, (int32_t)len, n_u, s->u, (mma_anchor *)s->b, &res);
+        tr->n_aligned = res.n_aligned; tr->n_regs = res.n_regs; tr->dp_max = res.dp_max; tr->sig = res.sig;
+        tr->flag = res.n_regs > 0;
+    }
 }
 
 void mmo_map(const mmo_index *idx, const mmo_opts *o, const uint8_t *seq, int64_t len, mmo_trace *tr)

@@ -22,8 +22,9 @@
  *   A.3 index                 (mmo_index_*)
  *   A.4 seed collection, occurrence filter, sr re-chain with max_occ
  *   A.5 chaining DP + backtrack; decision = "at least one chain kept"
- * NOT restated (documented divergence): A.6, the base-level ksw2
- * extension filter that `.with_cigar()` switches on (cleaner.rs:473).
+ *   A.6 base-level extension stage and mm_filter_regs (mm_align.c), for the short-read
+ *       mode (MM_F_SR: preset sr); for long-read presets the decision stays at A.5
+ *       (documented divergence)
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  The product (scrubby_amd/) never links or calls it.
@@ -52,7 +53,15 @@ typedef struct {
     int32_t max_gap, max_gap_ref, max_frag_len, bw;
     int32_t max_chain_skip, max_chain_iter;
     float   chain_gap_scale, chain_skip_scale;
+    /* A.6, the base-level extension stage (mm_align.c); flags bit 0 = MM_F_CIGAR, which `.with_cigar()` sets
+     * (/root/reference/src/cleaner.rs:473): with it the decision is "a region survives mm_filter_regs" */
+    int32_t flags;
+    int32_t a, b, q, e, q2, e2, sc_ambi;
+    int32_t zdrop, zdrop_inv, end_bonus, min_dp_max;
+    int32_t best_n, bw_long, min_ksw_len;
+    float   pri_ratio, mask_level, max_clip_ratio;
 } mmo_opts;
+#define MMO_F_CIGAR 1
 
 /* per-read trace of the decision, every field compared bit-exactly with the HIP path */
 typedef struct {
@@ -63,7 +72,11 @@ typedef struct {
     int32_t rechained;   /* 1 if the max_occ second pass ran */
     int32_t n_chain;     /* chains kept by backtrack (n_regs0) */
     int32_t best_score;  /* max chain score among kept chains, 0 if none */
-    int32_t flag;        /* 1 = host (n_chain>0), 0 = retained, 2 = empty read (reference: Err) */
+    int32_t flag;        /* 1 = host, 0 = retained, 2 = empty read (reference: Err).  host = n_chain > 0 without MM_F_CIGAR, n_regs > 0 with it */
+    int32_t n_aligned;   /* A.6: regions entering mm_align_skeleton (after mm_set_parent / mm_select_sub); 0 without MM_F_CIGAR */
+    int32_t n_regs;      /* A.6: regions left by mm_filter_regs = mappings.len() */
+    int32_t dp_max;      /* A.6: largest dp_max among them */
+    uint32_t sig;        /* A.6: fingerprint of the surviving regions (coordinates, mlen, blen, dp_max, cnt) */
 } mmo_trace;
 
 typedef struct mmo_index mmo_index;
@@ -81,6 +94,10 @@ mmo_index *mmo_index_build(int n_seq, const uint8_t *const *seqs, const int64_t 
 /* wrap an index in the product's HBM layout (16-B slots + position array), copied to host */
 mmo_index *mmo_index_wrap(const uint64_t *slots, uint64_t n_slots, const uint64_t *positions,
                           uint64_t n_positions, int w, int k);
+/* the reference sequence a wrapped index aligns against (A.6): 4-bit packed nt4 codes (low nibble = even position) of all
+ * contigs back to back, contig_start[n_contigs + 1]; borrowed, not copied.  mmo_index_build keeps its own. */
+void mmo_index_set_ref(mmo_index *idx, const uint8_t *packed, const uint64_t *contig_start, uint32_t n_contigs);
+const uint8_t *mmo_index_ref(const mmo_index *idx, const uint64_t **contig_start, uint32_t *n_contigs);
 void mmo_index_free(mmo_index *idx);
 const uint64_t *mmo_index_get(const mmo_index *idx, uint64_t minier, int32_t *n);
 uint64_t mmo_index_n_keys(const mmo_index *idx);

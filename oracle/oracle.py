@@ -24,15 +24,24 @@ class Opts(C.Structure):
         ("max_gap", C.c_int32), ("max_gap_ref", C.c_int32), ("max_frag_len", C.c_int32),
         ("bw", C.c_int32), ("max_chain_skip", C.c_int32), ("max_chain_iter", C.c_int32),
         ("chain_gap_scale", C.c_float), ("chain_skip_scale", C.c_float),
+        # A.6 (mm_align.c): flags bit 0 = MM_F_CIGAR
+        ("flags", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("q", C.c_int32), ("e", C.c_int32), ("q2", C.c_int32),
+        ("e2", C.c_int32), ("sc_ambi", C.c_int32), ("zdrop", C.c_int32), ("zdrop_inv", C.c_int32), ("end_bonus", C.c_int32),
+        ("min_dp_max", C.c_int32), ("best_n", C.c_int32), ("bw_long", C.c_int32), ("min_ksw_len", C.c_int32),
+        ("pri_ratio", C.c_float), ("mask_level", C.c_float), ("max_clip_ratio", C.c_float),
     ]
+
+
+F_CIGAR = 1
 
 
 class Trace(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("n_mini", "n_seed", "n_anchor", "rep_len", "rechained", "n_chain", "best_score", "flag")]
+                ("n_mini", "n_seed", "n_anchor", "rep_len", "rechained", "n_chain", "best_score", "flag",
+                 "n_aligned", "n_regs", "dp_max")] + [("sig", C.c_uint32)]
 
 
-TRACE_DTYPE = np.dtype([(n, "<i4") for n, _ in Trace._fields_])
+TRACE_DTYPE = np.dtype([(n, "<u4" if n == "sig" else "<i4") for n, _ in Trace._fields_])
 
 
 class RefParams(C.Structure):
@@ -84,6 +93,10 @@ def lib():
     L.mmo_index_wrap.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_int]
     L.mmo_index_wrap.restype = C.c_void_p
     L.mmo_index_free.argtypes = [C.c_void_p]
+    L.mmo_index_set_ref.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.mma_ksw_extd2.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int8, C.c_void_p, C.c_int8, C.c_int8, C.c_int8, C.c_int8,
+                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.mma_gen_simple_mat.argtypes = [C.c_int, C.c_void_p, C.c_int8, C.c_int8, C.c_int8]
     L.mmo_index_n_keys.argtypes = [C.c_void_p]
     L.mmo_index_n_keys.restype = C.c_uint64
     L.mmo_index_n_positions.argtypes = [C.c_void_p]
@@ -162,12 +175,31 @@ class Index:
         return cls(lib().mmo_index_build(len(arrs), ptrs, lens, w, k), keep=arrs)
 
     @classmethod
-    def wrap(cls, slots, positions, w, k):
-        """slots: uint64[2*n_slots] in the product's HBM layout; positions: uint64[]."""
+    def wrap(cls, slots, positions, w, k, ref=None):
+        """slots: uint64[2*n_slots] in the product's HBM layout; positions: uint64[]; ref = (packed nt4 uint8[], contig_start
+        uint64[n+1]) as the product exports it (Index.export_ref): what the A.6 stage aligns against."""
         slots = np.ascontiguousarray(slots, dtype=np.uint64)
         positions = np.ascontiguousarray(positions, dtype=np.uint64)
         h = lib().mmo_index_wrap(slots.ctypes.data, len(slots) // 2, positions.ctypes.data, len(positions), w, k)
-        return cls(h, keep=(slots, positions))
+        keep = [slots, positions]
+        if ref is not None:
+            packed = np.ascontiguousarray(ref[0], dtype=np.uint8)
+            starts = np.ascontiguousarray(ref[1], dtype=np.uint64)
+            lib().mmo_index_set_ref(h, packed.ctypes.data, starts.ctypes.data, len(starts) - 1)
+            keep += [packed, starts]
+        return cls(h, keep=keep)
+
+    def ref(self):
+        """(packed nt4 codes, contig_start) of the reference this index aligns against (None if it has none)."""
+        cs, n = C.c_void_p(), C.c_uint32()
+        lib().mmo_index_ref.restype = C.c_void_p
+        lib().mmo_index_ref.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
+        p = lib().mmo_index_ref(self.h, C.byref(cs), C.byref(n))
+        if not p:
+            return None
+        starts = np.ctypeslib.as_array(C.cast(cs, C.POINTER(C.c_uint64)), shape=(n.value + 1,)).copy()
+        packed = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=((int(starts[-1]) + 1) // 2,)).copy()
+        return packed, starts
 
     def dump(self):
         nk, npos = lib().mmo_index_n_keys(self.h), None

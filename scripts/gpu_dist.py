@@ -14,7 +14,7 @@ del d_ref
 N = 1_000_000
 d_reads = torch.empty(N * 150 + 64, dtype=torch.uint8, device=dev); d_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
 S.synth_reads_device(P, R, 0, N, d_reads, d_off)
-fl = torch.zeros(N, dtype=torch.uint8, device=dev); tr = torch.zeros((N, 8), dtype=torch.int32, device=dev)
+fl = torch.zeros(N, dtype=torch.uint8, device=dev); tr = torch.zeros((N, len(S.TRACE_FIELDS)), dtype=torch.int32, device=dev)
 ctx = S.Context(index, N, N * 150, 150)
 st = ctx.classify(d_reads[:N*150], d_off, fl, tr)
 print(st)

@@ -81,7 +81,7 @@ stage("classify parity sr", t_classify)
 def t_device_ctx():
     ctx = S.Context(gidx, N, N * 150, 150)
     fl = torch.zeros(N, dtype=torch.uint8, device=dev)
-    tr = torch.zeros((N, 8), dtype=torch.int32, device=dev)
+    tr = torch.zeros((N, len(S.TRACE_FIELDS)), dtype=torch.int32, device=dev)
     for it in range(3):
         st = ctx.classify(d_reads[:N*150], d_off, fl, tr)
     of, ot = oidx.classify(oo_sr, reads, off, threads=8)

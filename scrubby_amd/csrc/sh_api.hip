@@ -39,6 +39,12 @@ static void opts_default(sh_opts *o)
     o->max_gap = 5000; o->max_gap_ref = -1; o->max_frag_len = 0; o->bw = 500;
     o->max_chain_skip = 25; o->max_chain_iter = 5000;
     o->chain_gap_scale = 0.8f; o->chain_skip_scale = 0.0f;
+    // mm_mapopt_init; `.with_cigar()` (cleaner.rs:473) sets MM_F_CIGAR on whatever preset was chosen
+    o->flags = SH_F_CIGAR;
+    o->a = 2; o->b = 4; o->q = 4; o->e = 2; o->q2 = 24; o->e2 = 1; o->sc_ambi = 1;
+    o->zdrop = 400; o->zdrop_inv = 200; o->end_bonus = -1; o->min_dp_max = o->min_chain_score * o->a;
+    o->best_n = 5; o->bw_long = 20000; o->min_ksw_len = 200;
+    o->pri_ratio = 0.8f; o->mask_level = 0.5f; o->max_clip_ratio = 1.0f;
 }
 
 extern "C" sh_status sh_preset(const char *name, sh_opts *o)
@@ -49,6 +55,9 @@ extern "C" sh_status sh_preset(const char *name, sh_opts *o)
     if (n == "sr") {
         o->k = 21; o->w = 11; o->is_sr = 1; o->max_frag_len = 800; o->max_gap = 100; o->bw = 100;
         o->min_cnt = 2; o->min_chain_score = 25; o->mid_occ = 1000; o->max_occ = 5000;
+        o->a = 2; o->b = 8; o->q = 12; o->e = 2; o->q2 = 24; o->e2 = 1;
+        o->zdrop = o->zdrop_inv = 100; o->end_bonus = 10; o->bw_long = 100;
+        o->pri_ratio = 0.5f; o->min_dp_max = 40; o->best_n = 20;
         return SH_OK;
     }
     if (n == "map-ont") { o->k = 15; o->w = 10; return SH_OK; }
@@ -183,6 +192,7 @@ extern "C" sh_status sh_classify_batch(const sh_index *idx, const sh_opts *opts,
                 stats->n_chain_large += ps.n_chain_large; stats->n_minimizers += ps.n_minimizers; stats->n_bases += ps.n_bases;
                 stats->ms_sketch_probe += ps.ms_sketch_probe; stats->ms_chain_small += ps.ms_chain_small; stats->ms_chain_large += ps.ms_chain_large; stats->ms_total += ps.ms_total;
                 stats->n_anchors += ps.n_anchors; stats->n_clusters += ps.n_clusters; stats->n_resketch += ps.n_resketch; stats->n_pair_decided += ps.n_pair_decided;
+                stats->n_ext_reads += ps.n_ext_reads; stats->n_ext_regions += ps.n_ext_regions; stats->n_ext_dropped += ps.n_ext_dropped; stats->ms_ext += ps.ms_ext;
             }
         }
     });

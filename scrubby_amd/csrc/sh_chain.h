@@ -13,6 +13,11 @@
 // of an HBM arena.
 #pragma once
 #include "sh_common.h"
+#include "sh_align.h"
+
+// Chain hand-over to the extension stage (sh_align.h): every backtrack below takes an emitter that is called once per ACCEPTED
+// chain with (last anchor zi, stop index end_i (exclusive, -1 = root), score, anchors, f of zi).  NoEmit compiles to nothing.
+struct NoEmit { __device__ inline void operator()(int64_t, int64_t, int32_t, int64_t, int32_t) const {} };
 
 struct ChainParams {
     int32_t k, is_sr;
@@ -37,6 +42,10 @@ struct ChainParams {
     // window before it scores the earlier one, with sc = min(k, dq) and no penalty (dd = 0, pen_skip = 0):
     // f >= k + min(k, dq) >= min_sc = flag_stop, which decides the cluster (above).
     int32_t pair_dq_min, pair_dq_max, pair_min_anchors;
+    // SH_F_CIGAR shortcut of k_pair_pass (mode 2; host-computed, 0 = off): the premises that make a read of co-diagonal singleton
+    // seeds a decided case - short-read mode, a * k >= min_dp_max, 2k >= min_chain_score, max_clip_ratio >= 1, no skip penalty;
+    // ext_unc_max = zdrop / b, the bases outside the k-mers that cannot yet trigger mm_test_zdrop
+    int32_t ext_s1, ext_unc_max;
 };
 
 // ---- seeds: one 16-B record per query minimizer found in the index ---------------------------
@@ -216,6 +225,7 @@ struct LargeStore {
         if (sx != x) { uint64_t *tx = x; x = x2; x2 = tx; uint32_t *tq = q; q = q2; q2 = tq; }
     }
     __device__ inline uint32_t grp(int64_t i) const { return (uint32_t)(x[i] >> 32); }
+    __device__ inline uint64_t X(int64_t i) const { return x[i]; }
     __device__ inline uint32_t rlo(int64_t i) const { return (uint32_t)x[i]; }
     __device__ inline uint32_t qp(int64_t i) const { return q[i]; }
     __device__ inline int32_t F(int64_t i) const { return f[i]; }
@@ -326,15 +336,15 @@ __device__ inline Idx chain_bk_end(Store &S, int32_t max_drop, int32_t zf, Idx z
 }
 
 // one candidate of mg_chain_backtrack's first loop
-template <class Store, class Idx>
-__device__ inline void backtrack_visit(Store &S, const ChainParams &P, int32_t zf, Idx zi, int64_t &n_v, int32_t &n_u, int32_t &best)
+template <class Store, class Idx, class EM = NoEmit>
+__device__ inline void backtrack_visit(Store &S, const ChainParams &P, int32_t zf, Idx zi, int64_t &n_v, int32_t &n_u, int32_t &best, const EM &em = EM())
 {
     if (S.T(zi) != 0) return;
     int64_t n_v0 = n_v;
     Idx end_i = chain_bk_end<Store, Idx>(S, P.bw, zf, zi), i;
     for (i = zi; i != end_i; i = (Idx)S.Pm(i)) { ++n_v; S.setT(i, 1); }
     int32_t sc = i < 0 ? zf : zf - S.F(i);
-    if (sc >= P.min_sc && n_v > n_v0 && n_v - n_v0 >= P.min_cnt) { ++n_u; if (sc > best) best = sc; }
+    if (sc >= P.min_sc && n_v > n_v0 && n_v - n_v0 >= P.min_cnt) { ++n_u; if (sc > best) best = sc; em((int64_t)zi, (int64_t)end_i, sc, n_v - n_v0, zf); }
     else n_v = n_v0;
 }
 
@@ -423,8 +433,8 @@ __device__ inline bool chain_dp_mask(Store &S, int n, int32_t qlen, const ChainP
     return false;
 }
 
-template <class Store>
-__device__ inline void backtrack_mask(Store &S, int n, const ChainParams &P, int32_t &n_u, int32_t &best, bool first_only)
+template <class Store, class EM = NoEmit>
+__device__ inline void backtrack_mask(Store &S, int n, const ChainParams &P, int32_t &n_u, int32_t &best, bool first_only, const EM &em = EM())
 {
     n_u = 0; best = 0;
     uint64_t done = 0;            // t == 1
@@ -454,15 +464,15 @@ __device__ inline void backtrack_mask(Store &S, int n, const ChainParams &P, int
         const int64_t n_v0 = n_v;
         for (i = zi; i != max_i; i = S.Pm(i)) { ++n_v; done |= 1ULL << i; }
         const int32_t sc = i < 0 ? zf : zf - S.F(i);
-        if (sc >= P.min_sc && n_v > n_v0 && n_v - n_v0 >= P.min_cnt) { ++n_u; if (sc > best) best = sc; }
+        if (sc >= P.min_sc && n_v > n_v0 && n_v - n_v0 >= P.min_cnt) { ++n_u; if (sc > best) best = sc; em((int64_t)zi, (int64_t)max_i, sc, n_v - n_v0, zf); }
         else n_v = n_v0;
         if (first_only && n_u > 0) break;
     }
 }
 
 // large n: heap sort of (f<<32|index) in caller-provided memory z (n entries), then the same visit order
-template <class Store, class Idx>
-__device__ inline void backtrack_heap(Store &S, Idx n, const ChainParams &P, uint64_t *z, int32_t &n_u, int32_t &best, bool first_only = false)
+template <class Store, class Idx, class EM = NoEmit>
+__device__ inline void backtrack_heap(Store &S, Idx n, const ChainParams &P, uint64_t *z, int32_t &n_u, int32_t &best, bool first_only = false, const EM &em = EM())
 {
     n_u = 0; best = 0;
     Idx nz = 0;
@@ -486,7 +496,7 @@ __device__ inline void backtrack_heap(Store &S, Idx n, const ChainParams &P, uin
         uint64_t top = z[0];
         z[0] = z[m - 1];
         if (m - 1 > 0) down(0, m - 1);
-        backtrack_visit<Store, Idx>(S, P, (int32_t)(top >> 32), (Idx)(top & 0xffffffff), n_v, n_u, best);
+        backtrack_visit<Store, Idx, EM>(S, P, (int32_t)(top >> 32), (Idx)(top & 0xffffffff), n_v, n_u, best, em);
         if (first_only && n_u > 0) break;
     }
 }
@@ -498,6 +508,7 @@ struct SliceStore {
     __device__ inline uint32_t grp(int32_t) const { return 0; }
     __device__ inline uint32_t rlo(int32_t i) const { return (uint32_t)x[i]; }
     __device__ inline uint32_t qp(int32_t i) const { return q[i] & 0x7fffffffu; }     // bit 31 = cluster-start mark
+    __device__ inline uint64_t X(int32_t i) const { return x[i]; }
     __device__ inline int32_t F(int32_t i) const { return f[i]; }
     __device__ inline int32_t Pm(int32_t i) const { return pt[2 * i]; }
     __device__ inline int32_t T(int32_t i) const { return pt[2 * i + 1]; }
@@ -505,6 +516,21 @@ struct SliceStore {
     __device__ inline void setT(int32_t i, int32_t tv) { pt[2 * i + 1] = tv; }
     __device__ inline void clearT(int32_t n) { for (int32_t i = 0; i < n; ++i) pt[2 * i + 1] = 0; }
     __device__ inline void clearAux(int32_t n) { clearT(n); }
+};
+
+// emitter over a store that still holds the full x of its anchors.  base = index of the store's anchor 0 in the read's sorted
+// anchor array (the discovery key of mg_chain_backtrack is (f, that global index)); on = this lane does the writing.
+template <class Store>
+struct StoreEmit {
+    const ChainSink *sk; Store *S; uint32_t read, base; bool on;
+    __device__ inline void operator()(int64_t zi, int64_t end_i, int32_t sc, int64_t cnt, int32_t zf) const
+    {
+        if (!sk || !on) return;
+        Store &St = *S;
+        sink_emit(*sk, read, (int32_t)zi, (int32_t)end_i, sc, (uint32_t)cnt, (uint32_t)zf, base + (uint32_t)zi,
+                  [&](int32_t i, uint64_t &x, uint32_t &q) { x = St.X(i); q = St.qp(i); },
+                  [&](int32_t i) { return (int32_t)St.Pm(i); });
+    }
 };
 
 __device__ inline uint32_t prefix_popc64(uint64_t mask)
@@ -830,9 +856,18 @@ __device__ inline int first_chain_quick(const int32_t *gf, const int32_t *gpt, i
 
 // one big cluster, one wave, DP state through the LDS ring
 __device__ inline void chain_cluster_ring(const uint64_t *gx, uint32_t *gq, int32_t *gf, int32_t *gpt, int32_t n, int32_t qlen, const ChainParams &P,
-                                          int32_t &n_u, int32_t &best, bool first_only, uint32_t lane, RingMem &rm, unsigned long long *dbg_cnt = nullptr)
+                                          int32_t &n_u, int32_t &best, bool first_only, uint32_t lane, RingMem &rm, unsigned long long *dbg_cnt = nullptr,
+                                          const ChainSink *sk = nullptr, uint32_t read = 0, uint32_t base = 0, uint64_t *heap = nullptr)
 {
     n_u = 0; best = 0;
+    if (sk) {      // hand-over mode: every chain, anchors intact (the heap lives in `heap`, not over the x slice)
+        chain_dp_ring(gx, gq, gf, gpt, n, qlen, P, lane, rm, dbg_cnt);
+        SliceStore S{gx, gq, gf, gpt};
+        const StoreEmit<SliceStore> em{sk, &S, read, base, lane == 0};
+        backtrack_heap<SliceStore, int32_t, StoreEmit<SliceStore>>(S, n, P, heap, n_u, best, false, em);
+        wave_mem_sync();
+        return;
+    }
     if (first_only && P.flag_stop != INT32_MAX) { n_u = chain_dp_ring(gx, gq, gf, gpt, n, qlen, P, lane, rm, dbg_cnt, P.flag_stop) ? 1 : 0; return; }
     chain_dp_ring(gx, gq, gf, gpt, n, qlen, P, lane, rm, dbg_cnt);
     if (first_only) {
@@ -846,8 +881,15 @@ __device__ inline void chain_cluster_ring(const uint64_t *gx, uint32_t *gq, int3
 
 // one cluster, the whole wave: DP in parallel, backtrack executed uniformly by every lane
 __device__ inline void chain_cluster_wave(SliceStore &S, int32_t n, int32_t qlen, const ChainParams &P, uint64_t *zbuf, int32_t &n_u, int32_t &best,
-                                          bool first_only, uint32_t lane)
+                                          bool first_only, uint32_t lane, const ChainSink *sk = nullptr, uint32_t read = 0, uint32_t base = 0)
 {
+    if (sk) {      // hand-over mode (zbuf must not alias the anchors)
+        const StoreEmit<SliceStore> em{sk, &S, read, base, lane == 0};
+        chain_dp_wave(S, n, qlen, P, lane);
+        if (n <= 64) backtrack_mask(S, n, P, n_u, best, false, em);
+        else { backtrack_heap<SliceStore, int32_t, StoreEmit<SliceStore>>(S, n, P, zbuf, n_u, best, false, em); wave_mem_sync(); }
+        return;
+    }
     if (first_only && P.flag_stop != INT32_MAX) { n_u = chain_dp_wave(S, n, qlen, P, lane, P.flag_stop) ? 1 : 0; best = 0; return; }
     chain_dp_wave(S, n, qlen, P, lane);
     if (n <= 64) backtrack_mask(S, n, P, n_u, best, first_only);
@@ -857,8 +899,14 @@ __device__ inline void chain_cluster_wave(SliceStore &S, int32_t n, int32_t qlen
 // DP + backtrack of one cluster.  zbuf: n 8-B words for the heap when n > 32 (may alias the x slice: the
 // anchors are dead once the DP is done).
 __device__ inline void chain_cluster(SliceStore &S, int32_t n, int32_t qlen, const ChainParams &P, uint64_t *zbuf, int32_t &n_u, int32_t &best,
-                                     bool first_only)
+                                     bool first_only, const ChainSink *sk = nullptr, uint32_t read = 0, uint32_t base = 0)
 {
+    if (sk) {      // hand-over mode (zbuf must not alias the anchors)
+        const StoreEmit<SliceStore> em{sk, &S, read, base, true};
+        if (n <= 64) { chain_dp_mask(S, n, qlen, P); backtrack_mask(S, n, P, n_u, best, false, em); }
+        else { chain_dp<SliceStore, int32_t>(S, n, qlen, P); backtrack_heap<SliceStore, int32_t, StoreEmit<SliceStore>>(S, n, P, zbuf, n_u, best, false, em); }
+        return;
+    }
     if (first_only && P.flag_stop != INT32_MAX) {
         n_u = (n <= 64 ? chain_dp_mask(S, n, qlen, P, P.flag_stop) : chain_dp<SliceStore, int32_t>(S, n, qlen, P, P.flag_stop)) ? 1 : 0;
         best = 0;

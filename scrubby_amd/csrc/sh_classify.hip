@@ -45,6 +45,7 @@
 #include "sh_chain.h"
 #include <algorithm>
 
+#define SH_SPLIT ((sh_status)-2)      // internal: classify_chunk asks for smaller chunks
 #define K1_LIST_CAP 8           // ring of queued minimizers per lane (power of two; 4 KiB of LDS per wave); 4 are drained per W-step block
 #define K2_CAP 32               // anchors per read chained in LDS
 #define DP_SMALL_CAP 32         // anchors per cluster chained in LDS
@@ -64,6 +65,8 @@ struct Counters {
     uint32_t n_big_total, pad1;   // repeat-path reads before the pair pass took its share (0: no pair pass)
     uint32_t n_sort[N_SORT_CLS], n_giant_tiles, n_giant_rounds;
     uint32_t n_long_segs, pad2;
+    uint32_t ext_n_recs, ext_overflow, ext_n_list, ext_ticket, ext_regions, ext_dropped;      // extension stage (sh_align.h): chain records, work list
+    unsigned long long ext_n_anch;
     uint32_t n_cl[4], cl_ticket, pad3;      // global queue of big clusters (k_cluster_dp), by size class
     uint32_t n_leg_reason[4];     // why reads left the long-read front end: 0 room/segments, 1 thinning screen, 2 anchors beyond the giant path, 3 unused
     unsigned long long arena_cursor, anchor_cursor;
@@ -119,6 +122,7 @@ __device__ inline void write_trace(sh_trace *tr, uint64_t r, int32_t n_mini, int
     int4 *p = (int4 *)(tr + r);
     p[0] = make_int4(n_mini, n_seed, n_anchor, rep_len);
     p[1] = make_int4(rechained, n_chain, best, flag);
+    p[2] = make_int4(0, 0, 0, 0);      // n_aligned, n_regs, dp_max, sig: the extension stage fills them for reads with a chain
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -604,6 +608,7 @@ struct BigMeta { uint32_t r, n_a; int32_t rep_len; uint32_t state; };   // state
 struct SortItem { uint32_t w, n, qlen, pad; unsigned long long off; };
 struct BigBufs {        // the repeat path's slice of the arena (all arrays indexed by anchor slot)
     uint64_t *ax, *bx, *az; uint32_t *aq, *bq; int32_t *af;   // anchors (+ sort ping-pong), DP state f and (p,t)
+    uint64_t *hz;                                             // SH_F_CIGAR: backtrack heap of clusters chained from LDS (the anchors must survive for the hand-over)
     unsigned long long anchor_cap;
     BigMeta *meta; int32_t *acc_nu, *acc_best;
     SortItem *sort_items[N_SORT_CLS];
@@ -624,7 +629,32 @@ struct K2Args {
     ChainParams P;
     uint32_t work_begin; // k_chain_large: first list entry to process
     uint32_t *leftover; uint32_t *leftover_count;   // k_pair_pass: reads it leaves undecided
+    ChainSink sink; int32_t emit;                   // SH_F_CIGAR: every kept chain is handed to the extension stage; no flag-only shortcut in the DP
 };
+
+// hi word (strand | contig) of anchor group g of a read chained in a SmallStore: the store keeps group ranks only, so the
+// g-th smallest distinct x >> 32 is recomputed from the seeds (<= K2_CAP anchors)
+__device__ inline uint32_t small_group_hi(SeedView sv, const uint64_t *__restrict__ positions, int32_t qlen, int32_t k, uint32_t g)
+{
+    long long prev = -1;
+    for (uint32_t round = 0; round <= g; ++round) {
+        long long cur = 1ll << 40;
+        for (uint32_t i = 0; i < sv.n; ++i) {
+            const uint4 sd = sv.get(i);
+            if (sd.z >> 31) continue;
+            const uint64_t w1 = (uint64_t)sd.y << 32 | sd.x;
+            for (uint32_t t = 0; t < sd.z; ++t) {
+                const uint64_t rp = sd.z == 1 ? w1 : positions[(w1 >> SH_SLOT_NBITS) + t];
+                uint64_t x; uint32_t q;
+                make_anchor(rp, sd.w, qlen, k, x, q);
+                const long long hi = (long long)(x >> 32);
+                if (hi > prev && hi < cur) cur = hi;
+            }
+        }
+        prev = cur;
+    }
+    return (uint32_t)prev;
+}
 
 __device__ inline void finish_read(const K2Args &a, uint32_t r, int32_t n_mini, int32_t n_seed, int64_t n_a, int32_t rep_len,
                                    int32_t rechained, int32_t n_u, int32_t best)
@@ -665,7 +695,16 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
             gen_anchors(S, sv, a.positions, qlen, a.P.k);
             int64_t n_a = 0;
             for (uint32_t i = 0; i < sv.n; ++i) n_a += sv.occ(i);
-            if (a.trace == nullptr && a.P.flag_stop != INT32_MAX) n_u = chain_dp_mask(S, (int)n_a, qlen, a.P, a.P.flag_stop) ? 1 : 0;     // flag-only: see ChainParams::flag_stop
+            if (a.emit) {      // every chain goes to the extension stage, which decides the read
+                chain_dp_mask(S, (int)n_a, qlen, a.P);
+                auto em = [&](int64_t zi, int64_t end_i, int32_t sc, int64_t cnt, int32_t zf) {
+                    const uint32_t hi = small_group_hi(sv, a.positions, qlen, a.P.k, S.grp((int)zi));
+                    sink_emit(a.sink, r, (int32_t)zi, (int32_t)end_i, sc, (uint32_t)cnt, (uint32_t)zf, (uint32_t)zi,
+                              [&](int32_t i, uint64_t &x, uint32_t &q) { x = (uint64_t)hi << 32 | S.rlo(i); q = S.qp(i); },
+                              [&](int32_t i) { return S.Pm(i); });
+                };
+                backtrack_mask(S, (int)n_a, a.P, n_u, best, false, em);
+            } else if (a.trace == nullptr && a.P.flag_stop != INT32_MAX) n_u = chain_dp_mask(S, (int)n_a, qlen, a.P, a.P.flag_stop) ? 1 : 0;     // flag-only: see ChainParams::flag_stop
             else {
                 chain_dp_mask(S, (int)n_a, qlen, a.P);
                 backtrack_mask(S, (int)n_a, a.P, n_u, best, a.trace == nullptr);
@@ -702,7 +741,47 @@ __global__ __launch_bounds__(64) void k_pair_pass(K2Args a, int distinct)
         const bool valid = wi < n_work;
         uint32_t r = 0, info = 0, n_seed = 0, tot = 0;
         bool found = false;
-        if (valid) {
+        if (valid && distinct == 2) {
+            // SH_F_CIGAR (ChainParams::ext_*): the read is decided here only if the whole outcome of minimap2 is known from its seed
+            // records - every seed a singleton (none is filtered, anchors = seeds), all anchors on ONE diagonal of one contig /
+            // strand, consecutive anchors d <= min(max_dist_x, max_dist_y) apart.  Then mg_lchain_dp links each anchor to its
+            // predecessor (f[i-1] + min(k, d) >= f[j] + min(k, d_ij) for every j, first scanned wins ties), the backtrack returns ONE
+            // chain with all anchors, the region is primary and is aligned; its max stretch is the whole chain, the ungapped
+            // middle has U = sum max(0, d - k) bases outside the exact k-mers, so mm_test_zdrop sees a drop <= b * U <= zdrop and
+            // no second pass runs; mlen >= covered = k + sum min(k, d) >= 2k >= min_chain_score (span >= k); one gap at most
+            // can be left-aligned into the middle (mm_fix_cigar, from the right extension), so the first or the last k-mer stays a
+            // run of k matches: dp_max >= a * k >= min_dp_max; max_clip_ratio >= 1 disables the clip test.  Host-checked premises
+            // in fill_chain_params.  Everything else goes through the full path.
+            r = a.work[wi];
+            info = a.k1info[r];
+            n_seed = info >> 16;
+            const uint4 *rec = a.records + (size_t)r * a.seed_cap;
+            const int32_t qlen = (int32_t)(a.offsets[r + 1] - a.offsets[r]);
+            int32_t mdy = a.P.is_sr ? (qlen > a.P.max_gap ? qlen : a.P.max_gap) : a.P.max_gap, mdx;
+            if (a.P.max_gap_ref > 0) mdx = a.P.max_gap_ref;
+            else if (a.P.max_frag_len > 0) { mdx = a.P.max_frag_len - qlen; if (mdx < a.P.max_gap) mdx = a.P.max_gap; }
+            else mdx = a.P.max_gap;
+            if (mdx < a.P.bw) mdx = a.P.bw;
+            if (mdy < a.P.bw) mdy = a.P.bw;
+            const int32_t dmax = mdx < mdy ? mdx : mdy;
+            bool ok = a.P.ext_s1 != 0 && n_seed >= 2 && (int32_t)n_seed >= a.P.min_cnt && n_seed <= a.seed_cap;
+            uint64_t w0 = 0; uint32_t q0 = 0, qp = 0; int32_t unc = 0;
+            for (uint32_t i = 0; ok && i < n_seed; ++i) {
+                const uint4 sd = rec[i];
+                const uint64_t w1 = (uint64_t)sd.y << 32 | sd.x;
+                if ((sd.z & 0x7fffffffu) != 1u) { ok = false; break; }
+                if (i == 0) { w0 = w1; q0 = sd.w; qp = sd.w >> 1; continue; }
+                const bool fw0 = (uint32_t)(w0 & 1u) == (q0 & 1u), fwi = (uint32_t)(w1 & 1u) == (sd.w & 1u);
+                const int32_t D = (int32_t)(sd.w >> 1) - (int32_t)(q0 >> 1), d = (int32_t)(sd.w >> 1) - (int32_t)qp;
+                const int32_t dr = (int32_t)((uint32_t)w1 >> 1) - (int32_t)((uint32_t)w0 >> 1);
+                ok = (w1 >> 32) == (w0 >> 32) && fwi == fw0 && (fw0 ? dr == D : dr == -D) && d > 0 && d <= dmax;
+                unc += d > a.P.k ? d - a.P.k : 0;
+                qp = sd.w >> 1;
+            }
+            const int32_t span = (int32_t)qp - (int32_t)(q0 >> 1);
+            found = ok && span >= a.P.k && unc <= a.P.ext_unc_max;
+            tot = n_seed;
+        } else if (valid) {
             r = a.work[wi];
             info = a.k1info[r];
             n_seed = info >> 16;
@@ -729,7 +808,7 @@ __global__ __launch_bounds__(64) void k_pair_pass(K2Args a, int distinct)
             }
             if (!distinct) found = found && tot <= (uint32_t)a.P.max_skip + 1u;
         }
-        if (distinct && __ballot(found) != 0) {
+        if (distinct == 1 && __ballot(found) != 0) {
             uint32_t mx = found ? n_seed : 0u;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
@@ -743,7 +822,7 @@ __global__ __launch_bounds__(64) void k_pair_pass(K2Args a, int distinct)
         if (found) {
             a.flags[r] = 1;
             write_trace(a.trace, r, (int32_t)(info & 0xffffu), (int32_t)n_seed, (int32_t)tot, 0, 0, 1, a.P.min_sc, 1);
-            anchors_wave += distinct ? tot : 0u;
+            anchors_wave += distinct == 1 ? tot : 0u;
         }
         n_host_wave += (uint32_t)__popcll(__ballot(found));
         const bool undecided = valid && !found;
@@ -810,8 +889,9 @@ template <bool CONTIG, class PX, class PQ>
 __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_t n, uint32_t tid, uint32_t nthr, int32_t qlen,
                                     const ChainParams &P, volatile int32_t *found, BigList bl,
                                     int32_t &n_u_thr, int32_t &best_thr, uint32_t &n_cl_thr, const GlobalQ *gq = nullptr,
-                                    uint32_t *nxt = nullptr)
-{
+                                    uint32_t *nxt = nullptr, const ChainSink *sk = nullptr, uint32_t read = 0, uint64_t *heap = nullptr)
+{   // sk: hand-over mode - every chain of every cluster is emitted (found must be nullptr); heap: n words for the backtrack
+    // heaps of clusters with more than 64 anchors (nullptr: the x slice itself, which the hand-over must not destroy)
     const uint32_t mdx = chain_max_dist_x(P, qlen);
     const bool keep_single = !(P.k < P.min_sc || P.min_cnt > 1);
     const uint32_t per = CONTIG ? (n + nthr - 1) / nthr : 1;
@@ -831,14 +911,14 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
             if (gq) {
                 const int cc = cl_class(len);
                 const uint32_t gs = atomicAdd(&gq->count[cc], 1u);
-                if (gs < gq->cap[cc]) { SortItem ci{gq->w, len, (uint32_t)qlen, gq->in_b, gq->off + i}; gq->items[cc][gs] = ci; return; }
+                if (gs < gq->cap[cc]) { SortItem ci{gq->w, len, (uint32_t)qlen, gq->in_b | i << 1, gq->off + i}; gq->items[cc][gs] = ci; return; }     // pad = buffer | cluster start << 1
             }
             const int32_t slot = atomicAdd(bl.count, 1);
             if ((uint32_t)slot < bl.cap) { bl.start[slot] = i; bl.len[slot] = len; return; }
         }
         SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i};
         int32_t n_u, best;
-        chain_cluster(S, (int32_t)len, qlen, P, (uint64_t *)&x[i], n_u, best, found != nullptr);
+        chain_cluster(S, (int32_t)len, qlen, P, heap ? heap + i : (uint64_t *)&x[i], n_u, best, found != nullptr, sk, read, i);
         ++n_cl_thr;
         if (n_u > 0) { n_u_thr += n_u; if (best > best_thr) best_thr = best; if (found) *found = 1; }
     };
@@ -890,7 +970,7 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
         const uint32_t i = bl.start[b], len = bl.len[b];
         SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i};
         int32_t n_u, best;
-        chain_cluster_wave(S, (int32_t)len, qlen, P, (uint64_t *)&x[i], n_u, best, found != nullptr, lane);
+        chain_cluster_wave(S, (int32_t)len, qlen, P, heap ? heap + i : (uint64_t *)&x[i], n_u, best, found != nullptr, lane, sk, read, i);
         if (lane == 0) {
             ++n_cl_thr;
             if (n_u > 0) { n_u_thr += n_u; if (best > best_thr) best_thr = best; if (found) *found = 1; }
@@ -911,6 +991,7 @@ struct K3Args {
     uint32_t *sel_scratch;                                // long reads: >= 2 u32 per seed at [2 * seed_off[r]] for mm_seed_select
     Counters *ctr; BigBufs B; ChainParams P;
     int32_t pass, max_occ, flag_only, dbg;
+    ChainSink sink; int32_t emit;      // SH_F_CIGAR: chains are handed to the extension stage (flag_only is 0 then: no early exit)
 };
 
 
@@ -1156,7 +1237,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
             }
             continue;
         }
-        if (!LONG && a.flag_only && P.pair_dq_max > 0 && n_st == 1 && n_a > (uint32_t)P.pair_min_anchors && pair_decides(rec0, my_n0, n_seed, lane, a.positions, P, ((a.dbg & 16) && (!(a.dbg & 128) || n_a > 4096u)) ? &a.ctr->n_leg_reason[3] : nullptr)) {
+        if (!LONG && a.flag_only && !a.emit && P.pair_dq_max > 0 && n_st == 1 && n_a > (uint32_t)P.pair_min_anchors && pair_decides(rec0, my_n0, n_seed, lane, a.positions, P, ((a.dbg & 16) && (!(a.dbg & 128) || n_a > 4096u)) ? &a.ctr->n_leg_reason[3] : nullptr)) {
             // decided without a single anchor: sh_stats.n_anchors still counts what the occurrence filter admitted
             if (lane == 0) { BigMeta m{r, n_a, rep_len, 0u}; a.B.meta[w] = m; a.B.acc_nu[w] = 1; a.B.acc_best[w] = P.min_sc; }
             anchors_wave += n_a; ++n_pair;
@@ -1234,7 +1315,8 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
                 __syncthreads();
             }
             int32_t n_u = 0, best = 0;
-            chain_sorted<false>(e_x, e_q, e_f, e_pt, n_a, lane, 64, qlen, P, nullptr, BigList{e_bstart, e_blen, &e_bcount, 8}, n_u, best, n_clusters);
+            chain_sorted<false>(e_x, e_q, e_f, e_pt, n_a, lane, 64, qlen, P, nullptr, BigList{e_bstart, e_blen, &e_bcount, 8}, n_u, best, n_clusters,
+                                nullptr, nullptr, a.emit ? &a.sink : nullptr, r, nullptr);      // <= 64 anchors: no cluster needs a heap
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { n_u += __shfl_xor(n_u, o); int32_t b = __shfl_xor(best, o); best = b > best ? b : best; }
             if (lane == 0) { a.B.acc_nu[w] = n_u; a.B.acc_best[w] = best; }
@@ -1434,7 +1516,7 @@ __global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
         for (uint32_t i = tid; i < n; i += NTHR) { s_x[0][i] = gx[i]; s_q[0][i] = gq[i]; }
         if (tid == 0) s_found = 0;
         __syncthreads();
-        if (a.flag_only && a.P.flag_stop != INT32_MAX && n >= 96 && !(a.dbg & 64)) {
+        if (a.flag_only && !a.emit && a.P.flag_stop != INT32_MAX && n >= 96 && !(a.dbg & 64)) {
             // flag-only: the largest (strand, contig) group first (see k_group_probe); its sort ping-pongs over the loaded
             // anchors, so a miss reloads them for the full sort
             uint32_t n_cl0 = 0;
@@ -1451,7 +1533,8 @@ __global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
         int32_t n_u = 0, best = 0; uint32_t n_cl = 0;
         if (!(a.dbg & 1))
         chain_sorted<false>(rx, rq, f, pt, n, tid, NTHR, (int32_t)si.qlen, a.P, a.flag_only ? &s_found : nullptr,
-                            BigList{s_bstart, s_blen, &s_bcount, NMAX / 7 + 1}, n_u, best, n_cl);
+                            BigList{s_bstart, s_blen, &s_bcount, NMAX / 7 + 1}, n_u, best, n_cl, nullptr, nullptr,
+                            a.emit ? &a.sink : nullptr, a.B.meta[si.w].r, a.emit ? a.B.hz + si.off : nullptr);
         store_read_result(a, si.w, n_u, best, n_cl, s_red);
         __syncthreads();
     }
@@ -1614,7 +1697,8 @@ __global__ __launch_bounds__(1024) void k_giant_chain(K3Args a)
         const GlobalQ gq{a.B.cl_items, a.B.cl_cap, a.ctr->n_cl, si.w, in_b ? 1u : 0u, si.off};
         if (!(a.dbg & 2))
         chain_sorted<true>(sx, sq, a.B.af + si.off, (int32_t *)(a.B.az + si.off), n, tid, nthr, (int32_t)si.qlen, a.P,
-                     a.flag_only ? &s_found : nullptr, BigList{s_bstart, s_blen, &s_bcount, 2048}, n_u, best, n_cl, &gq, s_nxt);
+                     a.flag_only ? &s_found : nullptr, BigList{s_bstart, s_blen, &s_bcount, 2048}, n_u, best, n_cl, &gq, s_nxt,
+                     a.emit ? &a.sink : nullptr, a.B.meta[si.w].r, a.emit ? (in_b ? a.B.ax : a.B.bx) + si.off : nullptr);      // heap: the sort's other buffer
         store_read_result(a, si.w, n_u, best, n_cl, s_red);
         __syncthreads();
     }
@@ -1638,14 +1722,18 @@ __global__ __launch_bounds__(256) void k_cluster_dp(K3Args a)
         while (t >= cnt[c]) { t -= cnt[c]; ++c; }
         const SortItem ci = a.B.cl_items[c][t];
         if (a.flag_only && __atomic_load_n(&a.B.acc_nu[ci.w], __ATOMIC_RELAXED) > 0) continue;      // the read is decided
-        const uint64_t *gx = (ci.pad ? a.B.bx : a.B.ax) + ci.off; uint32_t *gq = (ci.pad ? a.B.bq : a.B.aq) + ci.off;
+        const bool in_b = (ci.pad & 1u) != 0;
+        const uint64_t *gx = (in_b ? a.B.bx : a.B.ax) + ci.off; uint32_t *gq = (in_b ? a.B.bq : a.B.aq) + ci.off;
+        uint64_t *heap = a.emit ? (in_b ? a.B.ax : a.B.bx) + ci.off : (uint64_t *)gx;      // hand-over: the anchors must survive the backtrack
+        const ChainSink *sk = a.emit ? &a.sink : nullptr;
+        const uint32_t rd = a.emit ? a.B.meta[ci.w].r : 0u, cbase = ci.pad >> 1;
         int32_t n_u, best;
         if (a.P.max_iter <= RING_TMAX_ITER)
             chain_cluster_ring(gx, gq, a.B.af + ci.off, (int32_t *)(a.B.az + ci.off), (int32_t)ci.n, (int32_t)ci.qlen, a.P, n_u, best,
-                               a.flag_only != 0, lane, s_ring[wv], (a.dbg & 16) ? a.ctr->cl_dbg : nullptr);
+                               a.flag_only != 0, lane, s_ring[wv], (a.dbg & 16) ? a.ctr->cl_dbg : nullptr, sk, rd, cbase, heap);
         else {      // look-back windows beyond the LDS mark bitmap: DP state in the arena throughout
             SliceStore S{gx, gq, a.B.af + ci.off, (int32_t *)(a.B.az + ci.off)};
-            chain_cluster_wave(S, (int32_t)ci.n, (int32_t)ci.qlen, a.P, (uint64_t *)gx, n_u, best, a.flag_only != 0, lane);
+            chain_cluster_wave(S, (int32_t)ci.n, (int32_t)ci.qlen, a.P, heap, n_u, best, a.flag_only != 0, lane, sk, rd, cbase);
         }
         ++n_cl;
         if (lane == 0) { atomicAdd(&a.ctr->cl_tot[c], 1ull); atomicAdd(&a.ctr->cl_anchor_tot[c], (unsigned long long)ci.n); }
@@ -1777,6 +1865,10 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
                     S.carve(m, n_a);
                     gen_anchors(S, sv, a.positions, qlen, a.P.k);
                     chain_dp<LargeStore, int64_t>(S, n_a, qlen, a.P);
+                    if (a.emit) {
+                        const StoreEmit<LargeStore> em{&a.sink, &S, r, 0u, true};
+                        backtrack_heap<LargeStore, int64_t, StoreEmit<LargeStore>>(S, n_a, a.P, S.z, n_u, best, false, em);
+                    } else
                     backtrack_heap<LargeStore, int64_t>(S, n_a, a.P, S.z, n_u, best);
                     if (!rechained && n_u == 0 && a.P.max_occ > a.P.mid_occ && rep_len > 0) { rechained = 1; max_occ = a.P.max_occ; continue; }
                     break;
@@ -1794,6 +1886,53 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
         uint64_t mh = __ballot(host);
         if (lane == 0 && mh) atomicAdd(&a.ctr->sh_host[SHARD()], (uint32_t)__popcll(mh));
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// extension stage (SH_F_CIGAR; sh_align.h): reads with at least one chain, one wave each
+// ------------------------------------------------------------------------------------------------
+struct ExtArgs {
+    AlignIn in; AlignParams P;
+    uint8_t *scratch; unsigned long long scratch_per_wave; uint32_t max_read_len, reg_cap;
+    uint32_t *list; Counters *ctr; uint8_t *flags; sh_trace *trace; int32_t flag_only; uint64_t n_reads;
+};
+
+__global__ void k_ext_list(ExtArgs a)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool has = r < a.n_reads && a.in.head[r] != ~0u;
+    const uint32_t li = wave_append(&a.ctr->ext_n_list, has);
+    if (has) a.list[li] = (uint32_t)r;
+}
+
+__global__ __launch_bounds__(64) void k_regs_align(ExtArgs a)
+{
+    __shared__ AlignLds Ls;
+    const uint32_t lane = threadIdx.x;
+    AlignScratch A;
+    align_scratch_carve(A, a.scratch + (unsigned long long)blockIdx.x * a.scratch_per_wave, a.max_read_len, a.reg_cap);
+    const uint32_t n_list = a.ctr->ext_n_list;
+    uint32_t n_regions = 0, n_dropped = 0;
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&a.ctr->ext_ticket, 1u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= n_list) break;
+        const uint32_t r = a.list[t];
+        AlignOut o;
+        if (!align_read_wave(a.in, a.P, r, a.flag_only != 0, A, Ls, o, &a.ctr->ext_overflow)) continue;
+        if (lane == 0) {
+            a.flags[r] = o.n_regs > 0 ? 1 : 0;
+            if (a.trace) {
+                int32_t *tr = (int32_t *)(a.trace + r);
+                tr[7] = o.n_regs > 0;
+                ((int4 *)tr)[2] = make_int4(o.n_aligned, o.n_regs, o.dp_max, (int32_t)o.sig);
+            }
+        }
+        n_regions += (uint32_t)o.n_aligned; n_dropped += o.n_regs == 0;
+        __syncthreads();
+    }
+    if (lane == 0) { if (n_regions) atomicAdd(&a.ctr->ext_regions, n_regions); if (n_dropped) atomicAdd(&a.ctr->ext_dropped, n_dropped); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1820,6 +1959,14 @@ struct sh_ctx {
     uint32_t *d_seg_base = nullptr, *d_seg_cnt = nullptr, *d_mz_y = nullptr;
     unsigned long long *d_seg_off = nullptr, *d_seed_off = nullptr;
     uint64_t *d_mz_hash = nullptr; uint4 *d_lrec = nullptr;
+    // extension stage (SH_F_CIGAR, short-read mode): chain hand-over buffers and the per-wave scratch of k_regs_align
+    bool ext = false;
+    AlignParams AP{};
+    ChainSink sink{};
+    uint8_t *d_ext = nullptr; uint64_t ext_bytes = 0;
+    uint32_t *d_ext_list = nullptr; uint8_t *d_ext_scratch = nullptr;
+    unsigned long long ext_scratch_per_wave = 0; uint32_t ext_waves = 0, ext_reg_cap = 0;
+    hipEvent_t ev_ext[2] = {};
     hipStream_t sx[4] = {};          // side streams: K2 and the sort classes run beside the main stream
     int par = 1;                     // bit 0: K2 on a side stream (SCRUBBY_HIP_STREAMS=0: on the main stream)
     hipEvent_t evx[6] = {};
@@ -1844,6 +1991,24 @@ static void fill_chain_params(const sh_opts &o, int32_t mid_occ, ChainParams &P)
     P.pair_dq_min = pair_ok && dmin <= dmax ? dmin : 0;
     P.pair_dq_max = pair_ok && dmin <= dmax ? dmax : 0;
     P.pair_min_anchors = getenv("SCRUBBY_HIP_PAIR_MIN") ? atoi(getenv("SCRUBBY_HIP_PAIR_MIN")) : 32;
+    // SH_F_CIGAR: the decision is taken by the extension stage from ALL chains of a read, so the DP shortcuts above are off; the one
+    // shortcut left is k_pair_pass mode 2 (ChainParams::ext_*)
+    P.ext_s1 = 0; P.ext_unc_max = 0;
+    if ((o.flags & SH_F_CIGAR) && o.is_sr) {
+        P.flag_stop = INT32_MAX; P.pair_dq_min = P.pair_dq_max = 0;
+        const bool s1 = o.a > 0 && o.b > 0 && o.a * o.k >= o.min_dp_max && 2 * o.k >= o.min_chain_score && o.max_clip_ratio >= 1.0f &&
+                        o.chain_skip_scale == 0.0f && o.min_cnt <= 2 && o.zdrop >= 0 && o.bw >= 0 && !getenv("SCRUBBY_HIP_NO_S1");
+        P.ext_s1 = s1 ? 1 : 0;
+        P.ext_unc_max = s1 ? o.zdrop / o.b : 0;
+    }
+}
+
+static void fill_align_params(const sh_opts &o, AlignParams &A)
+{
+    A.k = o.k; A.min_cnt = o.min_cnt; A.min_sc = o.min_chain_score; A.max_gap = o.max_gap; A.bw = o.bw; A.bw_long = o.bw_long;
+    A.a = o.a; A.b = o.b; A.q = o.q; A.e = o.e; A.q2 = o.q2; A.e2 = o.e2; A.sc_ambi = o.sc_ambi;
+    A.zdrop = o.zdrop; A.zdrop_inv = o.zdrop_inv; A.end_bonus = o.end_bonus; A.min_dp_max = o.min_dp_max; A.best_n = o.best_n;
+    A.pri_ratio = o.pri_ratio; A.mask_level = o.mask_level; A.max_clip_ratio = o.max_clip_ratio;
 }
 
 static bool w_supported(int w) { return w == 5 || w == 10 || w == 11 || w == 19; }
@@ -1859,6 +2024,21 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
     c->idx = idx; c->opts = *opts; c->max_reads = max_reads; c->max_bases = max_bases; c->max_read_len = max_read_len;
     int32_t mid_occ = opts->mid_occ > 0 ? opts->mid_occ : idx->mid_occ;
     fill_chain_params(*opts, mid_occ, c->P);
+    fill_align_params(*opts, c->AP);
+    c->ext = (opts->flags & SH_F_CIGAR) && opts->is_sr;
+    if ((opts->flags & SH_F_CIGAR) && !opts->is_sr) {
+        static bool warned = false;
+        if (!warned) {
+            warned = true;
+            fprintf(stderr, "[scrubby-hip] WARNING: the base-level extension filter that `.with_cigar()` enables (minimap2 mm_align_skeleton / mm_filter_regs) is only "
+                            "implemented for the short-read mode (preset sr).  For this preset a read counts as mapped as soon as one chain is kept; "
+                            "reads whose chains would all fail min_dp_max / min_chain_score after alignment are depleted although the reference keeps them.\n");
+        }
+    }
+    if (c->ext) {
+        SH_CHECK(idx->d_ref && idx->d_cstart, SH_ERR_INDEX, "sh_ctx_create: this index holds no reference bases, which the extension stage (SH_F_CIGAR) aligns against: rebuild it from FASTA");
+        SH_CHECK(opts->a > 0 && opts->e > 0 && opts->q + opts->e < 100 && opts->q2 + opts->e2 < 100, SH_ERR_BAD_ARG, "sh_ctx_create: alignment scores out of the int8 range of ksw2");
+    }
     // K1 stages a tile of 64 reads in LDS; it needs k <= 23 (hash and position share 64 bits),
     // read positions < 2^17 and a supported compile-time window
     c->use_k1 = opts->k <= 23 && max_read_len <= 1024 && w_supported(opts->w);
@@ -1903,7 +2083,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         uint64_t sort_cap_sum = 0;
         for (int i = 0; i < N_SORT_CLS; ++i) sort_cap_sum += sort_cap[i];
         uint64_t fixed = 4 * 64 * sizeof(SortItem) + 4096 + max_reads * (sizeof(BigMeta) + 8 + 8) + sort_cap_sum * sizeof(SortItem) + 16384;
-        uint64_t per_anchor = 8 + 8 + 8 + 4 + 4 + 4 + 2;   // ax bx az aq bq af (+ tile_split and cluster queue shares)
+        uint64_t per_anchor = 8 + 8 + 8 + 4 + 4 + 4 + 2 + (c->ext ? 8 : 0);   // ax bx az aq bq af (+ tile_split and cluster queue shares) (+ hz)
         uint64_t cap = left > fixed ? (left - fixed) / per_anchor : 0;
         cap &= ~15ull;
         if (cap < 1024) { sh_set_error("sh_ctx_create: arena of %llu MiB is too small", (unsigned long long)(c->arena_bytes >> 20)); sh_ctx_destroy(c); return SH_ERR_OOM; }
@@ -1913,6 +2093,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         B.ax = (uint64_t *)take(cap * 8); B.bx = (uint64_t *)take(cap * 8); B.az = (uint64_t *)take(cap * 8);
         B.aq = (uint32_t *)take(cap * 4); B.bq = (uint32_t *)take(cap * 4);
         B.af = (int32_t *)take(cap * 4);
+        B.hz = c->ext ? (uint64_t *)take(cap * 8) : nullptr;
         B.meta = (BigMeta *)take(max_reads * sizeof(BigMeta));
         B.acc_nu = (int32_t *)take(max_reads * 4); B.acc_best = (int32_t *)take(max_reads * 4);
         for (int i = 0; i < N_SORT_CLS; ++i) B.sort_items[i] = (SortItem *)take(sort_cap[i] * sizeof(SortItem));
@@ -1940,6 +2121,29 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         c->d_seg_off = (unsigned long long *)take((c->max_segs + 1) * 8); c->d_mz_hash = (uint64_t *)take(c->mz_cap * 8);
         c->d_mz_y = (uint32_t *)take(c->mz_cap * 4); c->d_lrec = (uint4 *)take(c->mz_cap * 16); c->d_seed_off = (unsigned long long *)take(max_reads * 8);
     }
+    if (c->ext) {
+        // chain hand-over: 32-B records, 12 B per chain anchor, one list head per read; sized for ~2 chains and ~32 chain anchors per
+        // read of the chunk (a chunk that needs more is cut in two and re-run: classify_chunk returns SH_SPLIT)
+        uint64_t cap_recs = std::max<uint64_t>(1ull << 20, 2 * max_reads), cap_anch = std::max<uint64_t>(1ull << 24, 32 * max_reads);
+        if (const char *env = getenv("SCRUBBY_HIP_EXT_MB")) { cap_anch = std::max<uint64_t>(1 << 16, ((uint64_t)atoll(env) << 20) / 16); cap_recs = std::max<uint64_t>(1 << 12, cap_anch / 16); }
+        cap_recs = std::min<uint64_t>(cap_recs, 0xfffffff0ull);
+        auto al = [](uint64_t b) { return (b + 255) & ~255ull; };
+        c->ext_bytes = al(cap_recs * sizeof(ChainRec)) + al(cap_anch * 8) + al(cap_anch * 4) + al(max_reads * 4) + al(max_reads * 4);
+        if ((e = hipMalloc(&c->d_ext, c->ext_bytes)) != hipSuccess) return fail(e, "extension-stage buffers");
+        uint8_t *p = c->d_ext;
+        auto take = [&](uint64_t b) { uint8_t *q = p; p += al(b); return q; };
+        c->sink.recs = (ChainRec *)take(cap_recs * sizeof(ChainRec)); c->sink.cap_recs = (uint32_t)cap_recs;
+        c->sink.cx = (uint64_t *)take(cap_anch * 8); c->sink.cq = (uint32_t *)take(cap_anch * 4); c->sink.cap_anch = cap_anch;
+        c->sink.head = (uint32_t *)take(max_reads * 4);
+        c->d_ext_list = (uint32_t *)take(max_reads * 4);
+        c->sink.n_recs = &c->d_ctr->ext_n_recs; c->sink.n_anch = &c->d_ctr->ext_n_anch; c->sink.overflow = &c->d_ctr->ext_overflow;
+        c->ext_reg_cap = 16384;
+        c->ext_scratch_per_wave = align_scratch_layout(max_read_len, c->ext_reg_cap, nullptr, nullptr, nullptr);
+        const uint64_t budget = 4ull << 30;
+        c->ext_waves = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)256 * 3, budget / c->ext_scratch_per_wave, (max_reads + 3) / 4}));
+        if ((e = hipMalloc(&c->d_ext_scratch, (uint64_t)c->ext_waves * c->ext_scratch_per_wave)) != hipSuccess) return fail(e, "extension-stage scratch");
+        for (auto &ev : c->ev_ext) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "event");
+    }
     for (auto &ev : c->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "event");
     for (auto &ev : c->evx) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "event");
     for (auto &st : c->sx) if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return fail(e, "stream");
@@ -1955,6 +2159,8 @@ extern "C" sh_status sh_ctx_destroy(sh_ctx *c)
     hipFree(c->d_work_defer); hipFree(c->d_work_defer2);
     for (auto &pp : c->d_big) for (auto p : pp) hipFree(p);
     hipFree(c->d_ctr); if (c->h_ctr) hipHostFree(c->h_ctr); hipFree(c->d_arena); hipFree(c->d_long);
+    hipFree(c->d_ext); hipFree(c->d_ext_scratch);
+    for (auto ev : c->ev_ext) if (ev) hipEventDestroy(ev);
     for (auto ev : c->ev) if (ev) hipEventDestroy(ev);
     for (auto ev : c->evx) if (ev) hipEventDestroy(ev);
     for (auto st : c->sx) if (st) hipStreamDestroy(st);
@@ -2024,6 +2230,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
 {
     const sh_index *idx = c->idx;
     SH_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), s));
+    if (c->ext) SH_HIP(hipMemsetAsync(c->sink.head, 0xff, n_reads * 4, s));
     SH_HIP(hipEventRecord(c->ev[0], s));
     const uint32_t n_tiles = (uint32_t)((n_reads + 63) / 64);
     if (c->use_k1) {
@@ -2067,7 +2274,9 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     }
     SH_HIP(hipEventRecord(c->ev[1], s));
 
-    const bool pair_pass = d_trace == nullptr && c->P.pair_dq_max > 0 && c->use_k1;
+    // flag-only shortcuts over the seed records: the pair test (chain-level decision), or with SH_F_CIGAR mode 2 (co-diagonal singletons)
+    const bool pair_pass = d_trace == nullptr && (c->P.pair_dq_max > 0 || c->P.ext_s1) && c->use_k1;
+    const int pair_mode_small = c->ext ? 2 : 0, pair_mode_big = c->ext ? 2 : 1;
     K2Args b{};
     b.offsets = d_offsets; b.bases = d_bases; b.n_reads = n_reads;
     b.slots = (const uint4 *)idx->d_slots; b.lg_slots = idx->lg_slots; b.w = idx->w;
@@ -2078,6 +2287,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     b.work_defer = c->d_work_defer; b.ctr = c->d_ctr;
     b.arena = c->d_arena; b.arena_bytes = c->legacy_bytes;
     b.P = c->P;
+    b.sink = c->sink; b.emit = c->ext ? 1 : 0;
     const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(n_tiles, 1), 256 * 8);
     if (c->use_k1) {     // K2 only needs K1's output: it runs beside the repeat path
         hipStream_t sk = (c->par & 1) ? c->sx[3] : s;
@@ -2086,7 +2296,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         b.work = c->d_work_small; b.work_count = &c->d_ctr->n_small; b.work_begin = 0;
         if (pair_pass) {      // flag-only: pair pass over all reads of the path, then the undecided ones, dense
             b.leftover = c->d_work_small2; b.leftover_count = &c->d_ctr->n_small2;
-            hipLaunchKernelGGL(k_pair_pass, dim3(grid), dim3(64), 0, sk, b, 0);
+            hipLaunchKernelGGL(k_pair_pass, dim3(grid), dim3(64), 0, sk, b, pair_mode_small);
             b.work = c->d_work_small2; b.work_count = &c->d_ctr->n_small2;
         }
         hipLaunchKernelGGL(k_chain_small<K2_CAP>, dim3(grid), dim3(64), 0, sk, b);
@@ -2098,7 +2308,8 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     k.offsets = d_offsets; k.positions = idx->d_positions; k.records = c->use_long ? c->d_lrec : c->d_records; k.seed_cap = c->seed_cap;
     k.seed_off = c->use_long ? c->d_seed_off : nullptr; k.sel_scratch = c->use_long ? (uint32_t *)c->d_mz_hash : nullptr;
     k.k1info = c->d_k1info; k.flags = d_flags; k.trace = d_trace; k.ctr = c->d_ctr; k.B = c->B; k.P = c->P;
-    k.flag_only = d_trace == nullptr;
+    k.flag_only = d_trace == nullptr && !c->ext;      // SH_F_CIGAR: every chain is needed, no early exit
+    k.sink = c->sink; k.emit = c->ext ? 1 : 0;
     k.dbg = getenv("SCRUBBY_HIP_DBG") ? atoi(getenv("SCRUBBY_HIP_DBG")) : 0;
     k.resketch_list = c->d_work_resketch;
     uint32_t resk_done = 0;
@@ -2109,7 +2320,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         K2Args pb = b;
         pb.work = c->d_big[0][0]; pb.work_count = &c->d_ctr->n_big[0];
         pb.leftover = c->d_big[0][1]; pb.leftover_count = &c->d_ctr->n_big_defer[0];
-        hipLaunchKernelGGL(k_pair_pass, dim3(grid), dim3(64), 0, s, pb, 1);
+        hipLaunchKernelGGL(k_pair_pass, dim3(grid), dim3(64), 0, s, pb, pair_mode_big);
         hipLaunchKernelGGL(k_pair_swap, dim3(1), dim3(1), 0, s, c->d_ctr);
         cur0 = 1;
     }
@@ -2171,6 +2382,27 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         SH_CHECK(nd < n_defer, SH_ERR_OOM, "re-sketch arena too small; set SCRUBBY_HIP_ARENA_MB");
         n_defer = nd;
     }
+    uint32_t ext_list = 0, ext_regions = 0, ext_dropped = 0;
+    float ms_ext = 0;
+    if (c->ext) {
+        // every read that handed over a chain: mm_gen_regs .. mm_filter_regs decide it (one wave per read, persistent grid)
+        ExtArgs x{};
+        x.in.ref = idx->d_ref; x.in.cstart = idx->d_cstart; x.in.n_contigs = idx->n_contigs;
+        x.in.bases = d_bases; x.in.offsets = d_offsets; x.in.cx = c->sink.cx; x.in.cq = c->sink.cq; x.in.recs = c->sink.recs; x.in.head = c->sink.head;
+        x.P = c->AP; x.scratch = c->d_ext_scratch; x.scratch_per_wave = c->ext_scratch_per_wave; x.max_read_len = c->max_read_len; x.reg_cap = c->ext_reg_cap;
+        x.list = c->d_ext_list; x.ctr = c->d_ctr; x.flags = d_flags; x.trace = d_trace; x.flag_only = d_trace == nullptr; x.n_reads = n_reads;
+        SH_HIP(hipEventRecord(c->ev_ext[0], s));
+        hipLaunchKernelGGL(k_ext_list, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, s, x);
+        hipLaunchKernelGGL(k_regs_align, dim3(c->ext_waves), dim3(64), 0, s, x);
+        SH_HIP(hipEventRecord(c->ev_ext[1], s));
+        SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+        SH_HIP(hipStreamSynchronize(s));
+        SH_HIP(hipGetLastError());
+        if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;       // hand-over buffers full: the caller cuts the chunk in two
+        SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "extension stage: a read exceeds the per-wave working memory (code %u: 2 chains, 3 primaries, 4 read length, 5 window, 6 regions)", c->h_ctr->ext_overflow);
+        ext_list = c->h_ctr->ext_n_list; ext_regions = c->h_ctr->ext_regions; ext_dropped = c->h_ctr->ext_dropped;
+        hipEventElapsedTime(&ms_ext, c->ev_ext[0], c->ev_ext[1]);
+    }
     SH_HIP(hipEventRecord(c->ev[4], s));
     SH_HIP(hipEventSynchronize(c->ev[4]));
     if (stats) {
@@ -2180,7 +2412,8 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         uint64_t sum_host = 0, sum_mini = 0, sum_anchors = 0, sum_clusters = 0, sum_pair = 0;
         for (int i = 0; i < 64; ++i) { sum_host += c->h_ctr->sh_host[i]; sum_mini += c->h_ctr->sh_mini[i]; sum_anchors += c->h_ctr->sh_anchors[i]; sum_clusters += c->h_ctr->sh_clusters[i]; sum_pair += c->h_ctr->sh_pair[i]; }
         stats->n_reads += n_reads; stats->n_bases += n_bases;
-        stats->n_host += sum_host; const uint32_t n_big0 = snap.n_big_total ? snap.n_big_total : snap.n_big[0];
+        stats->n_host += sum_host - ext_dropped;
+        stats->n_ext_reads += ext_list; stats->n_ext_regions += ext_regions; stats->n_ext_dropped += ext_dropped; stats->ms_ext += ms_ext; const uint32_t n_big0 = snap.n_big_total ? snap.n_big_total : snap.n_big[0];
         stats->n_no_seed += n_reads - snap.n_small - n_big0 - snap.n_resketch;
         uint64_t nl = (uint64_t)snap.n_resketch + n_big0;
         stats->n_chain_large += nl; stats->n_chain_small += snap.n_small;
@@ -2198,9 +2431,17 @@ extern "C" sh_status sh_classify_device(sh_ctx *c, const uint8_t *d_bases, const
     SH_HIP(hipSetDevice(c->idx->device));
     hipStream_t s = (hipStream_t)stream;
     if (stats) memset(stats, 0, sizeof(*stats));
-    for (uint64_t r0 = 0; r0 < n_reads; r0 += c->max_reads) {
-        uint64_t n = std::min<uint64_t>(c->max_reads, n_reads - r0);
+    std::vector<std::pair<uint64_t, uint64_t>> todo;      // (first read, count), processed back to front
+    for (uint64_t r0 = n_reads; r0 > 0;) { const uint64_t n = (r0 - 1) % c->max_reads + 1; r0 -= n; todo.push_back({r0, n}); }
+    while (!todo.empty()) {
+        const auto [r0, n] = todo.back();
+        todo.pop_back();
         sh_status st = classify_chunk(c, d_bases, d_offsets + r0, n, n_bases, d_flags + r0, d_trace ? d_trace + r0 : nullptr, s, stats);
+        if (st == SH_SPLIT) {      // the chains of this chunk did not fit the hand-over buffers of the extension stage
+            SH_CHECK(n > 1, SH_ERR_OOM, "extension stage: the chains of a single read exceed the hand-over buffers; raise SCRUBBY_HIP_EXT_MB");
+            todo.push_back({r0 + n / 2, n - n / 2}); todo.push_back({r0, n / 2});
+            continue;
+        }
         if (st != SH_OK) return st;
     }
     return SH_OK;

@@ -29,6 +29,8 @@ struct sh_index {
     uint32_t lg_slots = 0;
     uint64_t *d_slots = nullptr;      // 2 * n_slots
     uint64_t *d_positions = nullptr;  // n_positions (+1)
+    uint8_t *d_ref = nullptr;         // reference bases as 4-bit nt4 codes (mi->S of minimap2), (n_bases + 1) / 2 bytes + 16 of padding
+    uint64_t *d_cstart = nullptr;     // n_contigs + 1: first base of each contig in d_ref
     std::vector<uint64_t> contig_len;
     double build_ms = 0;
     mutable std::mutex pool_mu;          // scratch that sh_classify_batch calls leave behind for the next one (sh_api.hip)

@@ -134,6 +134,21 @@ static sh_status dispatch_ref_sketch(int w, bool emit, const RefArgs &a, hipStre
     return SH_OK;
 }
 
+// mi->S of minimap2: the reference as 4-bit nt4 codes, what mm_idx_getseq hands the base-level alignment (sh_align.h).
+// One thread per 16 output bytes = 32 bases.
+__global__ void k_ref_pack(const uint8_t *bases, uint64_t n, uint8_t *packed)
+{
+    const uint64_t o = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (o * 2 >= n) return;
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (uint32_t j = 0; j < 32; ++j) {
+        const uint64_t g = o * 2 + j;
+        const uint32_t c = g < n ? sh_nt4(bases[g]) : 0u;
+        w[j >> 3] |= c << (4 * (j & 7));
+    }
+    *(uint4 *)(packed + o) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 struct DevBuf {   // frees on scope exit
     void *p = nullptr;
     ~DevBuf() { if (p) hipFree(p); }
@@ -281,6 +296,17 @@ sh_status shi_index_build_device(const uint8_t *d_bases, const uint64_t *contig_
         IDX_HIP(hipMalloc(&idx->d_positions, 16));
     }
 
+    {   // the reference itself stays in HBM for the extension stage (half a byte per base)
+        const uint64_t pbytes = ((n_bases + 31) / 32) * 16 + 16;
+        IDX_HIP(hipMalloc(&idx->d_ref, pbytes));
+        IDX_HIP(hipMalloc(&idx->d_cstart, (n_contigs + 1) * 8));
+        std::vector<uint64_t> rel(n_contigs + 1);
+        for (uint32_t i = 0; i <= n_contigs; ++i) rel[i] = contig_starts[i] - contig_starts[0];
+        IDX_HIP(hipMemcpyAsync(idx->d_cstart, rel.data(), (n_contigs + 1) * 8, hipMemcpyHostToDevice, s));
+        IDX_HIP(hipMemsetAsync(idx->d_ref + pbytes - 16, 0, 16, s));
+        if (n_bases) hipLaunchKernelGGL(k_ref_pack, dim3((uint32_t)((n_bases + 32 * 256 - 1) / (32 * 256))), dim3(256), 0, s, d_bases + contig_starts[0], n_bases, idx->d_ref);
+        IDX_HIP(hipStreamSynchronize(s));
+    }
     // mm_mapopt_update: mid_occ from the occurrence distribution unless the preset fixes it
     idx->mid_occ = opts->mid_occ;
     if (opts->mid_occ <= 0) {
@@ -588,6 +614,16 @@ extern "C" sh_status sh_index_export(const sh_index *idx, uint64_t *slots, uint6
     return SH_OK;
 }
 
+extern "C" sh_status sh_index_export_ref(const sh_index *idx, uint8_t *packed, uint64_t *contig_start)
+{
+    SH_CHECK(idx, SH_ERR_BAD_ARG, "sh_index_export_ref: null index");
+    SH_CHECK(idx->d_ref && idx->d_cstart, SH_ERR_INDEX, "sh_index_export_ref: this index holds no reference bases (loaded from a cache written without them)");
+    SH_HIP(hipSetDevice(idx->device));
+    if (packed) SH_HIP(hipMemcpy(packed, idx->d_ref, (idx->n_bases + 1) / 2, hipMemcpyDeviceToHost));
+    if (contig_start) SH_HIP(hipMemcpy(contig_start, idx->d_cstart, (idx->n_contigs + 1) * 8, hipMemcpyDeviceToHost));
+    return SH_OK;
+}
+
 extern "C" sh_status sh_index_free(sh_index *idx)
 {
     if (!idx) return SH_OK;
@@ -595,6 +631,8 @@ extern "C" sh_status sh_index_free(sh_index *idx)
     shi_batch_pool_release(idx);
     if (idx->d_slots) hipFree(idx->d_slots);
     if (idx->d_positions) hipFree(idx->d_positions);
+    if (idx->d_ref) hipFree(idx->d_ref);
+    if (idx->d_cstart) hipFree(idx->d_cstart);
     delete idx;
     return SH_OK;
 }

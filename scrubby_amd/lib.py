@@ -38,11 +38,18 @@ class Opts(C.Structure):
         ("max_gap", C.c_int32), ("max_gap_ref", C.c_int32), ("max_frag_len", C.c_int32),
         ("bw", C.c_int32), ("max_chain_skip", C.c_int32), ("max_chain_iter", C.c_int32),
         ("chain_gap_scale", C.c_float), ("chain_skip_scale", C.c_float),
+        # the extension stage `.with_cigar()` enables (flags bit 0 = SH_F_CIGAR) and its ksw2 scores
+        ("flags", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("q", C.c_int32), ("e", C.c_int32), ("q2", C.c_int32),
+        ("e2", C.c_int32), ("sc_ambi", C.c_int32), ("zdrop", C.c_int32), ("zdrop_inv", C.c_int32), ("end_bonus", C.c_int32),
+        ("min_dp_max", C.c_int32), ("best_n", C.c_int32), ("bw_long", C.c_int32), ("min_ksw_len", C.c_int32),
+        ("pri_ratio", C.c_float), ("mask_level", C.c_float), ("max_clip_ratio", C.c_float),
     ]
 
 
-TRACE_FIELDS = ("n_mini", "n_seed", "n_anchor", "rep_len", "rechained", "n_chain", "best_score", "flag")
-TRACE_DTYPE = np.dtype([(n, "<i4") for n in TRACE_FIELDS])
+SH_F_CIGAR = 1
+TRACE_FIELDS = ("n_mini", "n_seed", "n_anchor", "rep_len", "rechained", "n_chain", "best_score", "flag",
+                "n_aligned", "n_regs", "dp_max", "sig")
+TRACE_DTYPE = np.dtype([(n, "<u4" if n == "sig" else "<i4") for n in TRACE_FIELDS])
 
 
 class IndexInfo(C.Structure):
@@ -61,6 +68,7 @@ class Stats(C.Structure):
         ("n_bases", C.c_uint64), ("ms_sketch_probe", C.c_double), ("ms_chain_small", C.c_double),
         ("ms_chain_large", C.c_double), ("ms_total", C.c_double),
         ("n_anchors", C.c_uint64), ("n_clusters", C.c_uint64), ("n_resketch", C.c_uint64), ("n_pair_decided", C.c_uint64),
+        ("n_ext_reads", C.c_uint64), ("n_ext_regions", C.c_uint64), ("n_ext_dropped", C.c_uint64), ("ms_ext", C.c_double),
     ]
 
     def as_dict(self):
@@ -110,7 +118,7 @@ class ReadParams(C.Structure):
 EXPORTS = [
     "sh_version", "sh_device_count", "sh_last_error", "sh_preset",
     "sh_index_build", "sh_index_build_device", "sh_index_build_fasta", "sh_index_save", "sh_index_load",
-    "sh_index_info_get", "sh_index_export", "sh_index_free",
+    "sh_index_info_get", "sh_index_export", "sh_index_export_ref", "sh_index_free",
     "sh_ctx_create", "sh_ctx_destroy", "sh_classify_device", "sh_classify_batch",
     "sh_synth_ref_device", "sh_synth_reads_device", "sh_synth_long_reads_device", "sh_bench_gather", "sh_pack_flags_device",
     "sh_reads_run", "sh_host_get_id", "sh_host_filter_fastx", "sh_host_filter_fastx_stream", "sh_host_read_difference",
@@ -146,6 +154,7 @@ def load():
     L.sh_index_load.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
     L.sh_index_info_get.argtypes = [vp, C.POINTER(IndexInfo)]
     L.sh_index_export.argtypes = [vp, vp, vp]
+    L.sh_index_export_ref.argtypes = [vp, vp, vp]
     L.sh_index_free.argtypes = [vp]
     L.sh_ctx_create.argtypes = [vp, C.POINTER(Opts), u64, u64, u32, C.POINTER(vp)]
     L.sh_ctx_destroy.argtypes = [vp]
@@ -251,6 +260,14 @@ class Index:
         pos = np.zeros(max(inf["n_positions"], 1), dtype=np.uint64)
         check(load().sh_index_export(self.h, slots.ctypes.data, pos.ctypes.data))
         return slots, pos[: inf["n_positions"]]
+
+    def export_ref(self):
+        """(packed nt4 codes uint8[(n_bases + 1) // 2], contig_start uint64[n_contigs + 1]): the reference as resident in HBM."""
+        inf = self.info()
+        packed = np.zeros((inf["n_bases"] + 1) // 2 + 1, dtype=np.uint8)
+        starts = np.zeros(inf["n_contigs"] + 1, dtype=np.uint64)
+        check(load().sh_index_export_ref(self.h, packed.ctypes.data, starts.ctypes.data))
+        return packed, starts
 
     def classify(self, bases, offsets, want_trace=False):
         """Host buffers in, host flags (and trace) out: sh_classify_batch."""

@@ -59,7 +59,7 @@ def main():
         alone = (alone.cpu().numpy() == 1).astype(np.uint8)
         from oracle import oracle as O
         slots, pos = index.export()
-        oidx = O.Index.wrap(slots, pos, 11, 21)
+        oidx = O.Index.wrap(slots, pos, 11, 21, ref=index.export_ref())
         reads = d_reads[:n_records * L].cpu().numpy()
         of, _ = oidx.classify(O.preset("sr"), reads, np.arange(n_records + 1, dtype=np.uint64) * L, threads=4, want_trace=False)
         res = {"world": world, "shards": [list(D.shard_range(n_records, r, world)) for r in range(world)],

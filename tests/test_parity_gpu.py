@@ -133,7 +133,7 @@ def test_device_context_repeatable_and_chunked(S, oracle, cfg1, gpu_index, cpu_i
     for chunk in (n, 4096 + 64):                     # one launch, and several launches with a ragged tail
         ctx = S.Context(gpu_index, chunk, n * 150, 150)
         fl = torch.zeros(n, dtype=torch.uint8, device="cuda")
-        tr = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+        tr = torch.zeros((n, len(S.TRACE_FIELDS)), dtype=torch.int32, device="cuda")
         for _ in range(2):
             ctx.classify(d_reads[: n * 150], d_off, fl, tr)
         gt = tr.cpu().numpy().view(S.TRACE_DTYPE).reshape(-1)
@@ -340,7 +340,7 @@ def test_long_reads_chunked_context_and_small_arena(S, oracle, monkeypatch):
     for chunk in (n, 256):
         ctx = S.Context(gidx, chunk, len(bases), max_len)
         fl = torch.zeros(n, dtype=torch.uint8, device="cuda")
-        tr = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+        tr = torch.zeros((n, len(S.TRACE_FIELDS)), dtype=torch.int32, device="cuda")
         ctx.classify(d_reads[: len(bases)], d_off, fl, tr)
         gt = tr.cpu().numpy().view(S.TRACE_DTYPE).reshape(-1)
         assert_trace_equal(S, fl.cpu().numpy(), gt, of, ot)
