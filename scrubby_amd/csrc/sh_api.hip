@@ -8,6 +8,7 @@
 #include <chrono>
 #include <thread>
 #include <mutex>
+#include <zlib.h>
 
 // ---- errors ----------------------------------------------------------------------------------
 static thread_local char g_err[1024] = "";
@@ -122,7 +123,7 @@ extern "C" sh_status sh_classify_batch(const sh_index *idx, const sh_opts *opts,
     for (uint64_t r0 = 0; r0 < n_reads; r0 += CH) piece_bases = std::max(piece_bases, offsets[std::min(n_reads, r0 + CH)] - offsets[r0]);
     const uint64_t need_reads = std::min(CH, n_reads);
     std::string env_sig;
-    for (const char *v : {"SCRUBBY_HIP_ARENA_MB", "SCRUBBY_HIP_NO_FLAG_STOP", "SCRUBBY_HIP_NO_PAIR", "SCRUBBY_HIP_PAIR_MIN"}) { const char *e = getenv(v); env_sig += e ? e : "-"; env_sig += '|'; }
+    for (const char *v : {"SCRUBBY_HIP_ARENA_MB", "SCRUBBY_HIP_NO_FLAG_STOP", "SCRUBBY_HIP_NO_PAIR", "SCRUBBY_HIP_PAIR_MIN", "SCRUBBY_HIP_NO_S1", "SCRUBBY_HIP_EXT_MB"}) { const char *e = getenv(v); env_sig += e ? e : "-"; env_sig += '|'; }
     const bool no_pool = false;
 
     BatchScratch *B = nullptr;
@@ -221,27 +222,75 @@ extern "C" sh_status sh_classify_batch(const sh_index *idx, const sh_opts *opts,
 }
 
 // ---- index cache -----------------------------------------------------------------
+// The reference rebuilds the index on every run (`.with_index(path, None)`, cleaner.rs:475-479: no output file).  The cache is
+// one file: header, contig lengths, the 16-B slots, the position array, the 4-bit reference (what the extension stage aligns
+// against).  The header carries the sketch parameters, the occurrence parameters mid_occ was derived with, and a checksum per
+// section (order-sensitive 64-bit sums computed on the device), the reference's among them: an index is keyed by
+// (reference checksum, k, w).  Sections stream between the file and HBM in 64 MiB pieces through one pinned buffer.
 struct CacheHeader {
-    char magic[8];                 // "SHIDX001"
-    int32_t k, w, mid_occ; uint32_t n_contigs, lg_slots, pad;
+    char magic[8];                 // "SHIDX002"
+    int32_t k, w, mid_occ; uint32_t n_contigs, lg_slots, has_ref;
     uint64_t n_bases, n_minimizers, n_keys, n_slots, n_positions;
+    int32_t o_mid_occ, o_min_mid_occ, o_max_mid_occ; float o_mid_occ_frac;
+    uint64_t cs_slots, cs_positions, cs_ref, cs_contigs;
 };
+
+__global__ void k_checksum(const uint64_t *w, uint64_t n, unsigned long long *out)
+{
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        acc += (w[i] ^ 0x9E3779B97F4A7C15ULL) * (2 * i + 1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += (unsigned long long)__shfl_xor((long long)acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+static sh_status device_checksum(const void *d, uint64_t n_words, uint64_t *out)
+{
+    unsigned long long *d_acc = nullptr;
+    *out = 0;
+    if (n_words == 0) return SH_OK;
+    SH_HIP(hipMalloc(&d_acc, 8));
+    hipError_t e = hipMemset(d_acc, 0, 8);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, 0, (const uint64_t *)d, n_words, d_acc); e = hipMemcpy(out, d_acc, 8, hipMemcpyDeviceToHost); }
+    hipFree(d_acc);
+    SH_HIP(e);
+    return SH_OK;
+}
+
+static uint64_t ref_words(uint64_t n_bases) { return ((n_bases + 31) / 32) * 2; }      // the packed reference is written in 16-B units
 
 extern "C" sh_status sh_index_save(const sh_index *idx, const char *path)
 {
     SH_CHECK(idx && path, SH_ERR_BAD_ARG, "sh_index_save: null argument");
+    SH_HIP(hipSetDevice(idx->device));
+    CacheHeader h{};
+    memcpy(h.magic, "SHIDX002", 8);
+    h.k = idx->k; h.w = idx->w; h.mid_occ = idx->mid_occ; h.n_contigs = idx->n_contigs; h.lg_slots = idx->lg_slots; h.has_ref = idx->d_ref ? 1 : 0;
+    h.n_bases = idx->n_bases; h.n_minimizers = idx->n_minimizers; h.n_keys = idx->n_keys; h.n_slots = idx->n_slots; h.n_positions = idx->n_positions;
+    h.o_mid_occ = idx->o_mid_occ; h.o_min_mid_occ = idx->o_min_mid_occ; h.o_max_mid_occ = idx->o_max_mid_occ; h.o_mid_occ_frac = idx->o_mid_occ_frac;
+    sh_status st;
+    if ((st = device_checksum(idx->d_slots, idx->n_slots * 2, &h.cs_slots)) != SH_OK) return st;
+    if ((st = device_checksum(idx->d_positions, idx->n_positions, &h.cs_positions)) != SH_OK) return st;
+    if (idx->d_ref && (st = device_checksum(idx->d_ref, ref_words(idx->n_bases), &h.cs_ref)) != SH_OK) return st;
+    for (uint32_t i = 0; i < idx->n_contigs; ++i) h.cs_contigs += (idx->contig_len[i] ^ 0x9E3779B97F4A7C15ULL) * (2 * (uint64_t)i + 1);
     FILE *f = fopen(path, "wb");
     SH_CHECK(f, SH_ERR_IO, "cannot open %s for writing", path);
-    CacheHeader h{};
-    memcpy(h.magic, "SHIDX001", 8);
-    h.k = idx->k; h.w = idx->w; h.mid_occ = idx->mid_occ; h.n_contigs = idx->n_contigs; h.lg_slots = idx->lg_slots;
-    h.n_bases = idx->n_bases; h.n_minimizers = idx->n_minimizers; h.n_keys = idx->n_keys; h.n_slots = idx->n_slots; h.n_positions = idx->n_positions;
-    std::vector<uint64_t> slots(idx->n_slots * 2), pos(idx->n_positions);
-    sh_status st = sh_index_export(idx, slots.data(), pos.data());
-    if (st != SH_OK) { fclose(f); return st; }
-    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(idx->contig_len.data(), 8, idx->n_contigs, f) == idx->n_contigs &&
-              fwrite(slots.data(), 16, idx->n_slots, f) == idx->n_slots && fwrite(pos.data(), 8, idx->n_positions, f) == idx->n_positions;
-    fclose(f);
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(idx->contig_len.data(), 8, idx->n_contigs, f) == idx->n_contigs;
+    const size_t CH = 64u << 20;
+    void *pin = nullptr;
+    if (hipHostMalloc(&pin, CH) != hipSuccess) { fclose(f); sh_set_error("sh_index_save: no pinned staging buffer"); return SH_ERR_OOM; }
+    auto section = [&](const void *d, uint64_t bytes) {
+        for (uint64_t o = 0; ok && o < bytes; o += CH) {
+            const size_t n = (size_t)std::min<uint64_t>(CH, bytes - o);
+            ok = hipMemcpy(pin, (const uint8_t *)d + o, n, hipMemcpyDeviceToHost) == hipSuccess && fwrite(pin, 1, n, f) == n;
+        }
+    };
+    section(idx->d_slots, idx->n_slots * 16);
+    section(idx->d_positions, idx->n_positions * 8);
+    if (idx->d_ref) { section(idx->d_ref, ref_words(idx->n_bases) * 8); }
+    hipHostFree(pin);
+    ok = fclose(f) == 0 && ok;
     SH_CHECK(ok, SH_ERR_IO, "short write to %s", path);
     return SH_OK;
 }
@@ -252,49 +301,92 @@ extern "C" sh_status sh_index_load(const char *path, int32_t device, sh_index **
     FILE *f = fopen(path, "rb");
     SH_CHECK(f, SH_ERR_IO, "cannot open %s", path);
     CacheHeader h{};
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SHIDX001", 8) != 0) { fclose(f); sh_set_error("%s is not a scrubby-hip index", path); return SH_ERR_IO; }
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SHIDX002", 8) != 0) {
+        const bool old = memcmp(h.magic, "SHIDX001", 8) == 0;
+        fclose(f);
+        sh_set_error(old ? "%s was written by an older scrubby-hip (no reference bases, no checksums): rebuild it" : "%s is not a scrubby-hip index", path);
+        return SH_ERR_IO;
+    }
+    // nothing of the header is trusted before it has been checked against itself and against the file
+    bool sane = h.k > 0 && h.k <= 28 && (h.k & 1) && h.w > 0 && h.w < 256 && h.lg_slots >= 4 && h.lg_slots < 40 && h.n_slots == (1ULL << h.lg_slots) &&
+                h.n_keys <= h.n_slots && h.n_positions <= h.n_minimizers && h.n_minimizers <= h.n_bases && h.n_contigs > 0 && h.n_contigs <= h.n_bases + 1 && h.mid_occ > 0 && h.has_ref <= 1;
+    long long fsize = -1;
+    if (sane && fseeko(f, 0, SEEK_END) == 0) fsize = (long long)ftello(f);
+    const unsigned long long want = sizeof(h) + 8ull * h.n_contigs + 16ull * h.n_slots + 8ull * h.n_positions + (h.has_ref ? 8ull * ref_words(h.n_bases) : 0ull);
+    sane = sane && fsize >= 0 && (unsigned long long)fsize == want && fseeko(f, (off_t)sizeof(h), SEEK_SET) == 0;
+    if (!sane) { fclose(f); sh_set_error("%s: corrupt or truncated index (header fields and file size disagree)", path); return SH_ERR_IO; }
     sh_index *idx = new sh_index();
     idx->device = device; idx->k = h.k; idx->w = h.w; idx->mid_occ = h.mid_occ; idx->n_contigs = h.n_contigs; idx->lg_slots = h.lg_slots;
     idx->n_bases = h.n_bases; idx->n_minimizers = h.n_minimizers; idx->n_keys = h.n_keys; idx->n_slots = h.n_slots; idx->n_positions = h.n_positions;
+    idx->o_mid_occ = h.o_mid_occ; idx->o_min_mid_occ = h.o_min_mid_occ; idx->o_max_mid_occ = h.o_max_mid_occ; idx->o_mid_occ_frac = h.o_mid_occ_frac;
     idx->contig_len.resize(h.n_contigs);
-    std::vector<uint64_t> slots(h.n_slots * 2), pos(h.n_positions);
-    bool ok = fread(idx->contig_len.data(), 8, h.n_contigs, f) == h.n_contigs && fread(slots.data(), 16, h.n_slots, f) == h.n_slots &&
-              fread(pos.data(), 8, h.n_positions, f) == h.n_positions;
-    fclose(f);
-    if (!ok) { delete idx; sh_set_error("short read from %s", path); return SH_ERR_IO; }
+    auto fail = [&](sh_status code) { fclose(f); sh_index_free(idx); return code; };
+    if (fread(idx->contig_len.data(), 8, h.n_contigs, f) != h.n_contigs) { sh_set_error("short read from %s", path); return fail(SH_ERR_IO); }
+    uint64_t tot = 0, cs = 0;
+    std::vector<uint64_t> starts(h.n_contigs + 1, 0);
+    for (uint32_t i = 0; i < h.n_contigs; ++i) { cs += (idx->contig_len[i] ^ 0x9E3779B97F4A7C15ULL) * (2 * (uint64_t)i + 1); tot += idx->contig_len[i]; starts[i + 1] = tot; if (idx->contig_len[i] >= (1ULL << 31) - 1) tot = ~0ull >> 1; }
+    if (cs != h.cs_contigs || tot != h.n_bases) { sh_set_error("%s: contig table does not match its checksum", path); return fail(SH_ERR_IO); }
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc(&idx->d_slots, h.n_slots * 16);
     if (e == hipSuccess) e = hipMalloc(&idx->d_positions, (h.n_positions + 2) * 8);
-    if (e == hipSuccess) e = hipMemcpy(idx->d_slots, slots.data(), h.n_slots * 16, hipMemcpyHostToDevice);
-    if (e == hipSuccess && h.n_positions) e = hipMemcpy(idx->d_positions, pos.data(), h.n_positions * 8, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { sh_set_error("sh_index_load: %s", hipGetErrorString(e)); sh_index_free(idx); return e == hipErrorOutOfMemory ? SH_ERR_OOM : SH_ERR_HIP; }
+    if (e == hipSuccess && h.has_ref) e = hipMalloc(&idx->d_ref, ref_words(h.n_bases) * 8 + 16);
+    if (e == hipSuccess && h.has_ref) e = hipMalloc(&idx->d_cstart, (h.n_contigs + 1) * 8);
+    if (e == hipSuccess && h.has_ref) e = hipMemcpy(idx->d_cstart, starts.data(), (h.n_contigs + 1) * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && h.has_ref) e = hipMemset(idx->d_ref + ref_words(h.n_bases) * 8, 0, 16);
+    const size_t CH = 64u << 20;
+    void *pin = nullptr;
+    if (e == hipSuccess) e = hipHostMalloc(&pin, CH);
+    if (e != hipSuccess) { sh_set_error("sh_index_load: %s", hipGetErrorString(e)); return fail(e == hipErrorOutOfMemory ? SH_ERR_OOM : SH_ERR_HIP); }
+    bool ok = true;
+    auto section = [&](void *d, uint64_t bytes) {
+        for (uint64_t o = 0; ok && o < bytes; o += CH) {
+            const size_t n = (size_t)std::min<uint64_t>(CH, bytes - o);
+            ok = fread(pin, 1, n, f) == n && hipMemcpy((uint8_t *)d + o, pin, n, hipMemcpyHostToDevice) == hipSuccess;
+        }
+    };
+    section(idx->d_slots, h.n_slots * 16);
+    section(idx->d_positions, h.n_positions * 8);
+    if (h.has_ref) section(idx->d_ref, ref_words(h.n_bases) * 8);
+    hipHostFree(pin);
+    if (!ok) { sh_set_error("short read from %s", path); return fail(SH_ERR_IO); }
+    uint64_t c1 = 0, c2 = 0, c3 = 0;
+    sh_status st = device_checksum(idx->d_slots, h.n_slots * 2, &c1);
+    if (st == SH_OK) st = device_checksum(idx->d_positions, h.n_positions, &c2);
+    if (st == SH_OK && h.has_ref) st = device_checksum(idx->d_ref, ref_words(h.n_bases), &c3);
+    if (st != SH_OK) return fail(st);
+    if (c1 != h.cs_slots || c2 != h.cs_positions || (h.has_ref && c3 != h.cs_ref)) { sh_set_error("%s: payload does not match its checksums (corrupt index)", path); return fail(SH_ERR_IO); }
+    idx->ref_checksum = h.cs_ref;
+    fclose(f);
     *out = idx;
     return SH_OK;
 }
 
 // ---- FASTA -> index -----------------------------------------------------------------------------------
 // line-by-line host reader: FASTQ references, files that do not start with a FASTA header, and the A/B baseline of the
-// GPU reader in sh_index.hip (SCRUBBY_HIP_FASTA_HOST=1)
+// GPU reader in sh_index.hip (SCRUBBY_HIP_FASTA_HOST=1).  Plain or gzip, sniffed by zlib the way needletail sniffs the magic
+// bytes; a truncated or corrupt gzip stream is an error, not a short reference.
 sh_status shi_index_build_fasta_host(const char *path, const sh_opts *opts, int32_t device, sh_index **out)
 {
     SH_CHECK(path && opts && out, SH_ERR_BAD_ARG, "sh_index_build_fasta: null argument");
-    // plain or gzip, sniffed by magic bytes like needletail does; gzip through zcat
-    FILE *f = fopen(path, "rb");
+    gzFile f = gzopen(path, "rb");
     SH_CHECK(f, SH_ERR_IO, "cannot open %s", path);
-    unsigned char mg[2] = {0, 0};
-    size_t got = fread(mg, 1, 2, f);
-    bool gz = got == 2 && mg[0] == 0x1f && mg[1] == 0x8b;
-    if (gz) {
-        fclose(f);
-        std::string cmd = "gzip -dc '" + std::string(path) + "'";
-        f = popen(cmd.c_str(), "r");
-        SH_CHECK(f, SH_ERR_IO, "cannot run gzip on %s", path);
-    } else rewind(f);
+    gzbuffer(f, 1 << 20);
     std::vector<std::vector<uint8_t>> seqs;
-    std::vector<char> line(1 << 16);
+    std::vector<char> buf(1 << 16);
+    std::string line;
     bool fastq = false; int fq_state = 0;
-    while (fgets(line.data(), (int)line.size(), f)) {
-        size_t n = strlen(line.data());
+    for (;;) {
+        // one LINE, however long: gzgets returns pieces of at most the buffer's size
+        line.clear();
+        bool got = false;
+        while (gzgets(f, buf.data(), (int)buf.size())) {
+            got = true;
+            const size_t n = strlen(buf.data());
+            line.append(buf.data(), n);
+            if (n && buf[n - 1] == '\n') break;
+        }
+        if (!got) break;
+        size_t n = line.size();
         while (n && (line[n - 1] == '\n' || line[n - 1] == '\r')) --n;
         if (seqs.empty() && n && line[0] == '@') fastq = true;
         if (!fastq) {
@@ -308,10 +400,15 @@ sh_status shi_index_build_fasta_host(const char *path, const sh_opts *opts, int3
             else fq_state = 0;
         }
     }
-    if (gz) pclose(f); else fclose(f);
+    int zerr = Z_OK;
+    const char *zmsg = gzerror(f, &zerr);
+    const bool bad = zerr != Z_OK && zerr != Z_STREAM_END;
+    std::string msg = bad && zmsg ? zmsg : "";
+    const int crc = gzclose(f);
+    SH_CHECK(!bad && crc == Z_OK, SH_ERR_IO, "%s: gzip stream is truncated or corrupt (%s)", path, msg.empty() ? "unexpected end of file" : msg.c_str());
     SH_CHECK(!seqs.empty(), SH_ERR_INDEX, "no sequences in %s", path);
     std::vector<const uint8_t *> ptr; std::vector<uint64_t> len;
-    for (auto &s : seqs) { ptr.push_back(s.data()); len.push_back(s.size()); }
+    for (auto &sq : seqs) { ptr.push_back(sq.data()); len.push_back(sq.size()); }
     return sh_index_build(ptr.data(), len.data(), (uint32_t)seqs.size(), opts, device, out);
 }
 

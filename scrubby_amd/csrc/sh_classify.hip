@@ -2019,6 +2019,10 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
     SH_CHECK(idx && opts && out, SH_ERR_BAD_ARG, "sh_ctx_create: null argument");
     SH_CHECK(opts->k == idx->k && opts->w == idx->w, SH_ERR_BAD_ARG, "sh_ctx_create: opts (k=%d,w=%d) do not match index (k=%d,w=%d)", opts->k, opts->w, idx->k, idx->w);
     SH_CHECK(max_reads > 0 && max_reads < (1ULL << 31), SH_ERR_BAD_ARG, "sh_ctx_create: max_reads must be in [1, 2^31)");
+    // an index (a cached one in particular) resolved mid_occ with the occurrence parameters of the preset it was built for
+    SH_CHECK(opts->mid_occ > 0 || (idx->o_mid_occ <= 0 && idx->o_min_mid_occ == opts->min_mid_occ && idx->o_max_mid_occ == opts->max_mid_occ && idx->o_mid_occ_frac == opts->mid_occ_frac),
+             SH_ERR_BAD_ARG, "sh_ctx_create: the index derived mid_occ with other occurrence parameters (min %d, max %d, frac %g) than this preset's (min %d, max %d, frac %g): rebuild it for this preset",
+             idx->o_min_mid_occ, idx->o_max_mid_occ, (double)idx->o_mid_occ_frac, opts->min_mid_occ, opts->max_mid_occ, (double)opts->mid_occ_frac);
     SH_HIP(hipSetDevice(idx->device));
     sh_ctx *c = new sh_ctx();
     c->idx = idx; c->opts = *opts; c->max_reads = max_reads; c->max_bases = max_bases; c->max_read_len = max_read_len;

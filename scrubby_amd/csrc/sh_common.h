@@ -32,6 +32,9 @@ struct sh_index {
     uint8_t *d_ref = nullptr;         // reference bases as 4-bit nt4 codes (mi->S of minimap2), (n_bases + 1) / 2 bytes + 16 of padding
     uint64_t *d_cstart = nullptr;     // n_contigs + 1: first base of each contig in d_ref
     std::vector<uint64_t> contig_len;
+    // occurrence parameters mid_occ was resolved with (mm_mapopt_update), and the checksum of the packed reference: the identity a cache is checked by
+    int32_t o_mid_occ = 0, o_min_mid_occ = 0, o_max_mid_occ = 0; float o_mid_occ_frac = 0;
+    uint64_t ref_checksum = 0;
     double build_ms = 0;
     mutable std::mutex pool_mu;          // scratch that sh_classify_batch calls leave behind for the next one (sh_api.hip)
     mutable std::vector<void *> pool;

@@ -308,6 +308,7 @@ sh_status shi_index_build_device(const uint8_t *d_bases, const uint64_t *contig_
         IDX_HIP(hipStreamSynchronize(s));
     }
     // mm_mapopt_update: mid_occ from the occurrence distribution unless the preset fixes it
+    idx->o_mid_occ = opts->mid_occ; idx->o_min_mid_occ = opts->min_mid_occ; idx->o_max_mid_occ = opts->max_mid_occ; idx->o_mid_occ_frac = opts->mid_occ_frac;
     idx->mid_occ = opts->mid_occ;
     if (opts->mid_occ <= 0) {
         int32_t mo = INT32_MAX;
@@ -494,9 +495,12 @@ static sh_status fasta_to_device(const char *path, int32_t device, DevBuf &d_bas
             if (r < 0) { gzclose(g); sh_set_error("read error in %s", path); return SH_ERR_IO; }
             if (r == 0) break;
             n += (uint64_t)r; lens.push_back((size_t)r); blocks.push_back(std::move(b));
-            if ((size_t)r < BLK) break;
         }
-        gzclose(g);
+        // a short read is only the end of the file if zlib says so: a truncated or corrupt stream is an error, not a short reference
+        int zerr = Z_OK;
+        gzerror(g, &zerr);
+        const int zc = gzclose(g);
+        SH_CHECK((zerr == Z_OK || zerr == Z_STREAM_END) && zc == Z_OK, SH_ERR_IO, "%s: gzip stream is truncated or corrupt", path);
         size_t q = 0;
         while (!blocks.empty() && q < lens[0] && (blocks[0][q] == '\n' || blocks[0][q] == '\r')) ++q;
         if (blocks.empty() || q >= lens[0] || blocks[0][q] != '>') return SH_OK;

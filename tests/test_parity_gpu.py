@@ -186,6 +186,70 @@ def test_index_save_load_roundtrip(S, cfg1, gpu_index, tmp_path):
     f1, t1, _, _ = gpu_index.classify(reads[: n * 150], off[: n + 1], want_trace=True)
     f2, t2, _, _ = idx2.classify(reads[: n * 150], off[: n + 1], want_trace=True)
     assert np.array_equal(f1, f2) and np.array_equal(t1, t2)
+    a, b = gpu_index.export_ref(), idx2.export_ref()          # the cache carries the reference bases the extension stage needs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_index_cache_is_checked_before_it_is_trusted(S, gpu_index, tmp_path):
+    """A corrupt, truncated, stale or foreign cache is an error, never an index (ADVICE: header trusted blindly)."""
+    good = tmp_path / "good.shidx"
+    gpu_index.save(str(good))
+    raw = bytearray(good.read_bytes())
+
+    def load_fails(data, what):
+        p = tmp_path / "bad.shidx"
+        p.write_bytes(bytes(data))
+        with pytest.raises(S.ScrubbyHipError) as ei:
+            S.Index.load(str(p), S.preset("sr"))
+        assert ei.value.status == 7 and what in ei.value.message, ei.value.message
+
+    load_fails(raw[:len(raw) - 4096], "file size")                       # truncated
+    load_fails(raw + b"\0" * 16, "file size")                            # trailing bytes
+    flipped = bytearray(raw); flipped[len(raw) // 2] ^= 0x40
+    load_fails(flipped, "checksum")                                      # one bit of the payload
+    hdr = bytearray(raw); hdr[8 + 4 * 4] ^= 0x01                         # lg_slots no longer matches n_slots
+    load_fails(hdr, "header fields")
+    old = bytearray(raw); old[:8] = b"SHIDX001"
+    load_fails(old, "older scrubby-hip")
+    load_fails(b"not an index at all" * 10, "not a scrubby-hip index")
+    # an index derived its mid_occ for one preset's occurrence parameters: another preset with the same k, w must not reuse it silently
+    ont = S.Index.build([b"ACGT" * 5000 + b"GATTACA" * 3000], S.preset("map-ont"))
+    p = tmp_path / "ont.shidx"
+    ont.save(str(p))
+    o = S.preset("map-ont"); o.min_mid_occ = 50; o.max_mid_occ = 500
+    re = S.Index.load(str(p), o)
+    with pytest.raises(S.ScrubbyHipError) as ei:
+        re.classify(np.frombuffer(b"ACGT" * 100, np.uint8), np.array([0, 400], np.uint64))
+    assert "occurrence parameters" in ei.value.message
+
+
+def test_gzip_reference_is_read_with_zlib_and_truncation_is_an_error(S, oracle, cfg1, gpu_index, tmp_path):
+    """ADVICE: the gzip reference used to go through popen("gzip -dc '<path>'") - a quote in the path ran in a shell, and a
+    truncated stream gave a silently short reference."""
+    import gzip
+    P, R, ref, seqs, reads, off = cfg1
+    fa = b"".join(b">c%d\n" % i + bytes(s) + b"\n" for i, s in enumerate(seqs))
+    odd = tmp_path / "it's a ref; echo pwned > x.fa.gz"
+    odd.write_bytes(gzip.compress(fa))
+    import os
+    os.environ["SCRUBBY_HIP_FASTA_HOST"] = "1"
+    try:
+        got = oracle.Index.wrap(*S.Index.build_fasta(str(odd), S.preset("sr")).export(), 11, 21).dump()
+        want = oracle.Index.wrap(*gpu_index.export(), 11, 21).dump()
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+        cut = tmp_path / "cut.fa.gz"
+        cut.write_bytes(gzip.compress(fa)[:-2000])
+        with pytest.raises(S.ScrubbyHipError) as ei:
+            S.Index.build_fasta(str(cut), S.preset("sr"))
+        assert ei.value.status == 7
+        long_line = tmp_path / "long.fq"                                # a FASTQ reference whose sequence line is longer than the reader's buffer
+        seq = bytes(seqs[0][:200_000])
+        long_line.write_bytes(b"@r\n" + seq + b"\n+\n" + b"I" * len(seq) + b"\n")
+        i2 = S.Index.build_fasta(str(long_line), S.preset("sr"))
+        assert i2.info()["n_contigs"] == 1 and i2.info()["n_bases"] == len(seq)
+    finally:
+        os.environ.pop("SCRUBBY_HIP_FASTA_HOST")
+    assert not (tmp_path / "x.fa.gz").exists() and not os.path.exists("x.fa.gz")
 
 
 def _ont_like_reads(ref, n, seed, min_len=1200, max_len=30000):
@@ -375,9 +439,12 @@ def test_pair_test_flag_only_on_repeat_rich_reference(S, oracle, monkeypatch):
         dup.append(np.frombuffer(r, dtype=np.uint8))
     bases = np.concatenate([plain.reshape(-1), indel, np.concatenate(dup)])
     offs = np.arange(len(bases) // 150 + 1, dtype=np.uint64) * 150
-    gidx = S.Index.build([bytes(s) for s in seqs], S.preset("sr"))
     cidx = oracle.Index.build(seqs, 11, 21)
-    of, ot = cidx.classify(oracle.preset("sr"), bases, offs, threads=8)
+    # (a) the chain-level decision (no SH_F_CIGAR): the pair tests of DESIGN.md section 3, on and off
+    g0, o0 = S.preset("sr"), oracle.preset("sr")
+    g0.flags = 0; o0.flags = 0
+    gidx = S.Index.build([bytes(s) for s in seqs], g0)
+    of, ot = cidx.classify(o0, bases, offs, threads=8)
     f_on, _, st_on, rc = gidx.classify(bases, offs, want_trace=False)
     assert rc == 0 and np.array_equal(f_on, of), f"{int((f_on != of).sum())} flags differ with the pair test"
     print({k: st_on[k] for k in ("n_reads", "n_host", "n_no_seed", "n_chain_small", "n_chain_large", "n_anchors", "n_pair_decided")})
@@ -390,6 +457,19 @@ def test_pair_test_flag_only_on_repeat_rich_reference(S, oracle, monkeypatch):
     gf, gt, st, rc = gidx.classify(bases, offs, want_trace=True)                         # trace mode never takes the shortcut
     assert_trace_equal(S, gf, gt, of, ot)
     assert st["n_pair_decided"] == 0
+    # (b) with the extension stage (the preset's default, as `.with_cigar()` sets it): the co-diagonal-singleton shortcut on and off,
+    #     and the trace of every region
+    gidx1 = S.Index.build([bytes(s) for s in seqs], S.preset("sr"))
+    of1, ot1 = cidx.classify(oracle.preset("sr"), bases, offs, threads=8)
+    f1, _, st1, rc = gidx1.classify(bases, offs, want_trace=False)
+    assert rc == 0 and np.array_equal(f1, of1) and st1["n_pair_decided"] > 0 and st1["n_ext_reads"] > 0
+    monkeypatch.setenv("SCRUBBY_HIP_NO_S1", "1")
+    f2, _, st2, rc = gidx1.classify(bases, offs, want_trace=False)
+    assert np.array_equal(f2, of1) and st2["n_pair_decided"] == 0 and st2["n_ext_reads"] == int((ot1["n_chain"] > 0).sum())
+    monkeypatch.delenv("SCRUBBY_HIP_NO_S1")
+    gf1, gt1, st3, rc = gidx1.classify(bases, offs, want_trace=True)
+    assert_trace_equal(S, gf1, gt1, of1, ot1)
+    assert st3["n_ext_dropped"] == int(((ot1["n_chain"] > 0) & (ot1["n_regs"] == 0)).sum())
 
 
 def test_fasta_taken_apart_on_the_gpu(S, oracle, cfg1, gpu_index, tmp_path, monkeypatch):
@@ -476,9 +556,11 @@ def test_pair_test_on_satellite_heavy_reference(S, oracle, monkeypatch):
     n = 6000
     bases = oracle.synth_reads(Po, Ro, 0, n)
     offs = np.arange(n + 1, dtype=np.uint64) * 150
-    gidx = S.Index.build([bytes(s) for s in seqs], S.preset("sr"))
     cidx = oracle.Index.build(seqs, 11, 21)
-    of, ot = cidx.classify(oracle.preset("sr"), bases, offs, threads=8)
+    g0, o0 = S.preset("sr"), oracle.preset("sr")          # chain-level decision: the pair tests
+    g0.flags = 0; o0.flags = 0
+    gidx = S.Index.build([bytes(s) for s in seqs], g0)
+    of, ot = cidx.classify(o0, bases, offs, threads=8)
     f_on, _, st_on, rc = gidx.classify(bases, offs, want_trace=False)
     assert rc == 0 and np.array_equal(f_on, of), f"{int((f_on != of).sum())} flags differ with the pair tests"
     print({k: st_on[k] for k in ("n_reads", "n_host", "n_chain_small", "n_chain_large", "n_anchors", "n_pair_decided")})
@@ -489,3 +571,11 @@ def test_pair_test_on_satellite_heavy_reference(S, oracle, monkeypatch):
     monkeypatch.delenv("SCRUBBY_HIP_NO_PAIR")
     gf, gt, st, rc = gidx.classify(bases, offs, want_trace=True)
     assert_trace_equal(S, gf, gt, of, ot)
+    # with the extension stage: thousands of chains per read go through mm_set_parent / mm_select_sub (best_n) before alignment
+    gidx1 = S.Index.build([bytes(s) for s in seqs], S.preset("sr"))
+    of1, ot1 = cidx.classify(oracle.preset("sr"), bases, offs, threads=8)
+    assert int(ot1["n_chain"].max()) > 20 and int(ot1["n_aligned"].max()) >= 20
+    f1, _, st1, rc = gidx1.classify(bases, offs, want_trace=False)
+    assert rc == 0 and np.array_equal(f1, of1)
+    gf1, gt1, _, rc = gidx1.classify(bases, offs, want_trace=True)
+    assert_trace_equal(S, gf1, gt1, of1, ot1)
