@@ -330,7 +330,10 @@ def main_reads(a, rank, world, local, dev, backend):
             "result": {"reads_removed": removed_total, "reads_removed_rank0": n_host, "n_no_seed": s0["n_no_seed"], "n_chain_small": s0["n_chain_small"],
                        "n_chain_large": s0["n_chain_large"], "probes": s0["n_minimizers"],
                        "repeat_path_anchors": s0["n_anchors"], "repeat_path_clusters": s0["n_clusters"], "n_resketch": s0["n_resketch"],
-                       "pair_decided": s0["n_pair_decided"]},
+                       "pair_decided": s0["n_pair_decided"],
+                       # the extension stage `.with_cigar()` enables: reads it had to align, regions, and the flags it flips
+                       "ext_shortcut_reads": s0["n_ext_shortcut"], "ext_reads": s0["n_ext_reads"], "ext_regions": s0["n_ext_regions"],
+                       "ext_flags_flipped": s0["n_ext_dropped"], "ext_ms_per_step": round(float(np.mean([x["ms_ext"] for x in stats])), 3)},
             "index": {"n_keys": info["n_keys"], "n_minimizers": info["n_minimizers"], "n_slots": info["n_slots"],
                       "n_positions": info["n_positions"], "hbm_GB": round(info["hbm_bytes"] / 1e9, 2),
                       "build_s": round(t_idx, 2), "ref_synth_s": round(t_ref, 2)},

@@ -117,6 +117,7 @@ typedef struct sh_stats {
     uint64_t n_ext_regions;    /* regions aligned for them */
     uint64_t n_ext_dropped;    /* reads with a chain but no surviving region: the flags this stage flips */
     double   ms_ext;           /* HIP-event time of the extension stage */
+    uint64_t n_ext_shortcut;   /* SH_F_CIGAR flag-only: reads decided inside a chaining kernel - their top chain's max stretch alone passes mm_filter_regs */
 } sh_stats;
 
 typedef struct sh_index sh_index;

@@ -26,32 +26,81 @@ struct AlignParams {
     int32_t k, min_cnt, min_sc, max_gap, bw, bw_long;
     int32_t a, b, q, e, q2, e2, sc_ambi, zdrop, zdrop_inv, end_bonus, min_dp_max, best_n;
     float pri_ratio, mask_level, max_clip_ratio;
+    int32_t lemma, unc_max;      // flag-only: ChainParams::ext_lemma / ext_unc_max
 };
 
 // a chain as the chaining kernels hand it over: anchors cx/cq[off .. off + cnt) in ascending order
-struct ChainRec { uint32_t next, cnt; int32_t score; uint32_t key_f, key_i, pad; unsigned long long off; };
+struct ChainRec { uint32_t next, cnt; int32_t score; uint32_t key_f, key_i, pad; unsigned long long off, z; };
+#define SINK_SHARDS 64
 struct ChainSink {
-    ChainRec *recs; uint32_t *n_recs; uint32_t cap_recs;
-    uint64_t *cx; uint32_t *cq; unsigned long long *n_anch; unsigned long long cap_anch;
+    ChainRec *recs; uint32_t *n_recs; uint32_t cap_recs;                 // 64 shards of cap_recs records (one cursor each: a single address
+    uint64_t *cx; uint32_t *cq; unsigned long long *n_anch; unsigned long long cap_anch;   // only sustains ~90 M atomics/s), likewise cap_anch anchors
     uint32_t *head;        // per read of the chunk: newest record, ~0u = none
     uint32_t *overflow;
+    // flag-only calls: only a chain that can still be regs[0] of mm_gen_regs - the largest z = (score << 32 | cnt) ^ h of its read - is
+    // worth handing over; best[read] is the largest z seen so far (atomicMax), tie[read] is set when two chains share it.
+    // nullptr: every chain is kept (trace mode, and the second pass over reads whose top chain did not settle them).
+    unsigned long long *best; uint32_t *tie;
 };
 
-// append one chain.  walk(i) -> predecessor; xq(i, x, q) reads an anchor.  Called by ONE lane.
+__device__ inline uint64_t al_hash64(uint64_t key)
+{
+    key = (~key + (key << 21));
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8));
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4));
+    key = key ^ key >> 28;
+    key = (key + (key << 31));
+    return key;
+}
+__device__ inline uint32_t al_wang(uint32_t key)
+{
+    key += ~(key << 15); key ^= (key >> 10); key += (key << 3); key ^= (key >> 6); key += ~(key << 11); key ^= (key >> 16);
+    return key;
+}
+// mm_map_frag's hash of the (absent) query name, the query length and opt->seed = 11
+__device__ inline uint32_t region_hash(int32_t qlen)
+{
+    uint32_t h = 0;
+    h ^= al_wang((uint32_t)qlen) + al_wang(11u);
+    return al_wang(h);
+}
+// mm_gen_regs' sort key of a chain whose first anchor is (x0, q0)
+__device__ inline unsigned long long chain_z(uint64_t x0, uint32_t q0, int32_t k, int32_t score, uint32_t cnt, uint32_t rhash)
+{
+    const uint64_t y0 = (uint64_t)(uint32_t)k << 32 | q0;
+    const uint32_t h = (uint32_t)al_hash64((al_hash64(x0) + al_hash64(y0)) ^ rhash);
+    return ((unsigned long long)(uint32_t)score << 32 | cnt) ^ h;
+}
+
+// append one chain.  pred(i) -> predecessor; xq(i, x, q) reads an anchor.  Called by ONE lane.
 template <class XQ, class PRED>
 __device__ inline void sink_emit(const ChainSink &sk, uint32_t read, int32_t zi, int32_t end_i, int32_t score, uint32_t cnt,
-                                 uint32_t key_f, uint32_t key_i, XQ xq, PRED pred)
+                                 uint32_t key_f, uint32_t key_i, int32_t k, uint32_t rhash, XQ xq, PRED pred)
 {
-    const uint32_t idx = atomicAdd(sk.n_recs, 1u);
-    const unsigned long long off = atomicAdd(sk.n_anch, (unsigned long long)cnt);
-    if (idx >= sk.cap_recs || off + cnt > sk.cap_anch) { atomicExch(sk.overflow, 1u); return; }
+    int32_t first = zi;
+    for (int32_t p = pred(first); p != end_i; p = pred(first)) first = p;
+    uint64_t x0; uint32_t q0;
+    xq(first, x0, q0);
+    const unsigned long long z = chain_z(x0, q0, k, score, cnt, rhash);
+    if (sk.best) {
+        const unsigned long long old = atomicMax(&sk.best[read], z);
+        if (z < old) return;
+        if (z == old) { atomicExch(&sk.tie[read], 1u); return; }
+    }
+    const uint32_t sh = (blockIdx.x * 7u + (threadIdx.x >> 6) * 3u + (uint32_t)(zi & 7)) & (SINK_SHARDS - 1);
+    const uint32_t li = atomicAdd(&sk.n_recs[sh], 1u);
+    const unsigned long long lo = atomicAdd(&sk.n_anch[sh], (unsigned long long)cnt);
+    if (li >= sk.cap_recs || lo + cnt > sk.cap_anch) { atomicExch(sk.overflow, 1u); return; }
+    const uint32_t idx = sh * sk.cap_recs + li;
+    const unsigned long long off = (unsigned long long)sh * sk.cap_anch + lo;
     uint32_t j = cnt;
     for (int32_t i = zi; i != end_i && j > 0; i = pred(i)) { --j; uint64_t x; uint32_t q; xq(i, x, q); sk.cx[off + j] = x; sk.cq[off + j] = q; }
-    ChainRec rc{0u, cnt, score, key_f, key_i, 0u, off};
+    ChainRec rc{0u, cnt, score, key_f, key_i, 0u, off, z};
     rc.next = atomicExch(&sk.head[read], idx);
     sk.recs[idx] = rc;
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // memory of one wave
@@ -380,23 +429,6 @@ __device__ inline void ksw_extd2_wave(int32_t qlen, const uint8_t *query, bool q
 // ------------------------------------------------------------------------------------------------
 // regions: mm_gen_regs, mm_set_parent, mm_select_sub (hit.c), then mm_align_skeleton (align.c)
 // ------------------------------------------------------------------------------------------------
-__device__ inline uint64_t al_hash64(uint64_t key)
-{
-    key = (~key + (key << 21));
-    key = key ^ key >> 24;
-    key = ((key + (key << 3)) + (key << 8));
-    key = key ^ key >> 14;
-    key = ((key + (key << 2)) + (key << 4));
-    key = key ^ key >> 28;
-    key = (key + (key << 31));
-    return key;
-}
-__device__ inline uint32_t al_wang(uint32_t key)
-{
-    key += ~(key << 15); key ^= (key >> 10); key += (key << 3); key ^= (key >> 6); key += ~(key << 11); key ^= (key >> 16);
-    return key;
-}
-
 struct AlignIn {
     const uint8_t *ref; const uint64_t *cstart; uint32_t n_contigs;       // reference: 4-bit codes
     const uint8_t *bases; const uint64_t *offsets;                         // reads (ASCII)
@@ -547,24 +579,78 @@ __device__ inline void update_extra0(RegLite &r, uint32_t *c, int32_t &n_cigar, 
     mlen_o = mlen; blen_o = blen; dp_max_o = (int32_t)(max + .499);
 }
 
+// Flag-only first pass (ChainSink::best): the read's list holds the chains that were, when they were found, the largest z of the read;
+// the one whose z equals best[read] is regs[0] of mm_gen_regs - primary, hence always aligned.  1: its max stretch alone guarantees
+// that it survives mm_filter_regs (same test as sh_chain.h chain_lemma, over the handed-over anchors): the read is mapped.  0: not
+// settled here (a tie in z, a stretch the test cannot vouch for): the read goes through the full procedure with all its chains.
+__device__ inline int32_t top_chain_settles(const AlignIn &in, const AlignParams &P, uint32_t read, unsigned long long best, uint32_t tie)
+{
+    // returns 1 settled, or minus the reason it is not: -1 tie / off, -2 record missing, -3 stretch too short, -4 z-drop in the stretch
+    if (tie || !P.lemma) return -1;
+    uint32_t h = in.head[read];
+    while (h != ~0u && in.recs[h].z != best) h = in.recs[h].next;
+    if (h == ~0u) return -2;
+    const ChainRec rc = in.recs[h];
+    int32_t run_score = P.k, run_unc = 0, best_score = -1, best_unc = 0;
+    uint32_t xp = (uint32_t)in.cx[rc.off], qp = in.cq[rc.off], run_first = 0, run_last = 0, b_first = 0, b_last = 0;
+    for (uint32_t j = 1; j < rc.cnt; ++j) {
+        const uint32_t xj = (uint32_t)in.cx[rc.off + j], qj = in.cq[rc.off + j];
+        const int32_t lr = (int32_t)(xj - xp), lq = (int32_t)(qj - qp);
+        if (lq == lr) { run_score += lq < P.k ? lq : P.k; run_unc += lq > P.k ? lq - P.k : 0; run_last = j; }
+        else {
+            if (run_score > best_score) { best_score = run_score; best_unc = run_unc; b_first = run_first; b_last = run_last; }
+            run_score = P.k; run_unc = 0; run_first = run_last = j;
+        }
+        xp = xj; qp = qj;
+    }
+    if (run_score > best_score) { best_score = run_score; best_unc = run_unc; b_first = run_first; b_last = run_last; }
+    const int32_t qf = (int32_t)in.cq[rc.off + b_first], ql = (int32_t)in.cq[rc.off + b_last];
+    if (!(best_score >= P.min_sc && ql - qf >= P.k)) return -3;
+    if (best_unc <= P.unc_max) return 1;
+    // mm_test_zdrop over the ungapped stretch, on the bases
+    const uint64_t x0 = in.cx[rc.off + b_first];
+    const int32_t rid = (int32_t)(x0 << 1 >> 33), rev = (int32_t)(x0 >> 63), qs = qf + 1 - P.k, qe = ql + 1, rs = (int32_t)x0 + 1 - P.k;
+    const int32_t qlen = (int32_t)(in.offsets[read + 1] - in.offsets[read]);
+    const uint8_t *seq = in.bases + in.offsets[read];
+    const uint64_t g0 = in.cstart[rid] + (uint64_t)rs;
+    const int32_t sa = P.a < 0 ? -P.a : P.a, sb = P.b > 0 ? -P.b : P.b, sn = P.sc_ambi > 0 ? -P.sc_ambi : P.sc_ambi;
+    int32_t score = 0, mx = INT32_MIN, zd = 0;
+    for (int32_t j = 0; j < qe - qs; ++j) {
+        const int32_t qi = qs + j;
+        uint32_t cq = sh_nt4(seq[rev ? qlen - 1 - qi : qi]);
+        if (rev && cq < 4) cq = 3 - cq;
+        const uint64_t g = g0 + (uint64_t)j;
+        const uint32_t ct = (in.ref[g >> 1] >> ((g & 1) * 4)) & 15u;
+        score += (cq > 3 || ct > 3) ? sn : (cq == ct ? sa : sb);
+        if (score < mx) { const int32_t z = mx - score; zd = z > zd ? z : zd; }
+        else mx = score;
+    }
+    return zd <= P.zdrop ? 1 : -4;
+}
+
 // The whole stage for one read, one wave.  flag_only: stop at the first surviving region (the boundary only returns
 // `mappings.len() > 0`); else every region is aligned and the counts / fingerprint are those of the oracle's trace.
+// top_z != 0: only the chain with that z - regs[0] of mm_gen_regs, which is aligned whatever the other chains are - goes through
+// mm_align1; a surviving region settles the read (n_regs > 0), none means the caller must run the full procedure on all chains.
 __device__ inline bool align_read_wave(const AlignIn &in, const AlignParams &P, uint32_t read, bool flag_only, AlignScratch &A, AlignLds &Ls,
-                                       AlignOut &out, uint32_t *overflow)
+                                       AlignOut &out, uint32_t *overflow, unsigned long long top_z = 0)
 {
     const uint32_t lane = al_lane();
     const int32_t qlen = (int32_t)(in.offsets[read + 1] - in.offsets[read]);
     out.n_aligned = out.n_regs = out.dp_max = 0; out.sig = 0;
     // ---- the read's chains (a linked list, newest first; every lane walks it)
     int32_t n_u = 0;
-    for (uint32_t h = in.head[read]; h != ~0u; h = in.recs[h].next) ++n_u;
+    uint32_t h_top = ~0u;
+    for (uint32_t h = in.head[read]; h != ~0u; h = in.recs[h].next) { ++n_u; if (top_z != 0 && in.recs[h].z == top_z) h_top = h; }
     if (n_u == 0) return true;
+    if (top_z != 0) { if (h_top == ~0u) return true; n_u = 1; }
     if ((uint32_t)n_u > A.reg_cap) { if (lane == 0) atomicExch(overflow, 2u); return false; }
     const bool rg = n_u > AL_R;                 // region arrays in HBM scratch
     RegLite *regs = rg ? A.regs : Ls.regs;
     uint64_t *kz = rg ? A.kz : Ls.kz, *kx = rg ? A.kx : Ls.kx, *kk = rg ? A.kk : Ls.kk;
     uint32_t *kh = rg ? A.kh : Ls.kh, *ord = rg ? A.ord : Ls.ord;
-    {   // list position j -> lane j & 63 parks the record index in kh[j] (read back by the same lane)
+    if (top_z != 0) { if (lane == 0) kh[0] = h_top; }
+    else {   // list position j -> lane j & 63 parks the record index in kh[j] (read back by the same lane)
         int32_t j = 0;
         for (uint32_t h = in.head[read]; h != ~0u; h = in.recs[h].next, ++j) if ((uint32_t)(j & 63) == lane) kh[j] = h;
     }

@@ -46,7 +46,35 @@ struct ChainParams {
     // seeds a decided case - short-read mode, a * k >= min_dp_max, 2k >= min_chain_score, max_clip_ratio >= 1, no skip penalty;
     // ext_unc_max = zdrop / b, the bases outside the k-mers that cannot yet trigger mm_test_zdrop
     int32_t ext_s1, ext_unc_max;
+    // SH_F_CIGAR, flag-only: a region passes mm_filter_regs WITHOUT any base-level work when its max stretch (mm_max_stretch: the
+    // co-diagonal run of anchors with the largest covered length) has covered = k + sum min(k, d) >= min_chain_score, spans >= k
+    // between its first and last anchor and leaves U = sum max(0, d - k) <= ext_unc_max bases outside the exact k-mers - the same
+    // argument as k_pair_pass mode 2, applied to one region (chain_lemma below).  ext_lemma = the host-checked premises.
+    int32_t ext_lemma;
+    int32_t ext_a, ext_b, ext_amb, ext_zdrop;      // scores of the middle check (mm_test_zdrop over the ungapped stretch)
 };
+
+// what the middle check reads: the reference (4-bit codes) and the reads (ASCII)
+struct BaseCtx { const uint8_t *ref; const uint64_t *cstart; const uint8_t *bases; };
+
+// mm_test_zdrop over the ungapped alignment of query [qs, qe) (on strand rev of the read at `seq`) with reference [rs, rs + qe - qs) of
+// contig rid: true = no z-drop, i.e. mm_align1 keeps the single M (sh_align.h / oracle mm_align.c test_zdrop).  One thread.
+__device__ inline bool middle_no_zdrop(const BaseCtx &B, const uint8_t *seq, int32_t qlen, int32_t rid, int32_t rev, int32_t qs, int32_t qe, int32_t rs, const ChainParams &P)
+{
+    const uint64_t g0 = B.cstart[rid] + (uint64_t)rs;
+    int32_t score = 0, mx = INT32_MIN, zd = 0;
+    for (int32_t j = 0; j < qe - qs; ++j) {
+        const int32_t qi = qs + j;
+        uint32_t cq = sh_nt4(seq[rev ? qlen - 1 - qi : qi]);
+        if (rev && cq < 4) cq = 3 - cq;
+        const uint64_t g = g0 + (uint64_t)j;
+        const uint32_t ct = (B.ref[g >> 1] >> ((g & 1) * 4)) & 15u;
+        score += (cq > 3 || ct > 3) ? P.ext_amb : (cq == ct ? P.ext_a : P.ext_b);
+        if (score < mx) { const int32_t z = mx - score; zd = z > zd ? z : zd; }
+        else mx = score;
+    }
+    return zd <= P.ext_zdrop;
+}
 
 // ---- seeds: one 16-B record per query minimizer found in the index ---------------------------
 //   .x,.y = w1 of the slot (position word, or off<<28|n)   .z = n | flt<<31   .w = qpos<<1|strand
@@ -522,16 +550,67 @@ struct SliceStore {
 // anchor array (the discovery key of mg_chain_backtrack is (f, that global index)); on = this lane does the writing.
 template <class Store>
 struct StoreEmit {
-    const ChainSink *sk; Store *S; uint32_t read, base; bool on;
+    const ChainSink *sk; Store *S; uint32_t read, base; bool on; int32_t k; uint32_t rhash;
     __device__ inline void operator()(int64_t zi, int64_t end_i, int32_t sc, int64_t cnt, int32_t zf) const
     {
         if (!sk || !on) return;
         Store &St = *S;
-        sink_emit(*sk, read, (int32_t)zi, (int32_t)end_i, sc, (uint32_t)cnt, (uint32_t)zf, base + (uint32_t)zi,
+        sink_emit(*sk, read, (int32_t)zi, (int32_t)end_i, sc, (uint32_t)cnt, (uint32_t)zf, base + (uint32_t)zi, k, rhash,
                   [&](int32_t i, uint64_t &x, uint32_t &q) { x = St.X(i); q = St.qp(i); },
                   [&](int32_t i) { return (int32_t)St.Pm(i); });
     }
 };
+
+// ---- SH_F_CIGAR, flag-only: the decision inside a chaining kernel that holds ALL chains of a read ---------------------------------
+// regs[0] of mm_gen_regs is the chain with the largest z = (score << 32 | cnt) ^ h (h: hash of the first anchor and the query
+// length); it is primary whatever mm_set_parent does to the others, so it is always aligned: if it passes (chain_lemma), the read is
+// mapped.  Anything else - a tie in z, a top chain the lemma cannot vouch for - hands all chains to the extension stage.
+struct BestChain { unsigned long long z; int32_t zi, end_i, score, cnt; uint32_t base; int32_t tie, n; };
+
+__device__ inline void best_update(BestChain &b, unsigned long long z, int32_t zi, int32_t end_i, int32_t sc, int32_t cnt, uint32_t base)
+{
+    ++b.n;
+    if (b.n == 1 || z > b.z) { b.z = z; b.zi = zi; b.end_i = end_i; b.score = sc; b.cnt = cnt; b.base = base; b.tie = 0; }
+    else if (z == b.z) b.tie = 1;
+}
+// emitter that only remembers the top chain; hi(i) = x >> 32 of anchor i
+template <class Store, class HI>
+struct BestEmit {
+    Store *S; BestChain *b; uint32_t rhash; int32_t k; uint32_t base; HI hi; bool on;
+    __device__ inline void operator()(int64_t zi, int64_t end_i, int32_t sc, int64_t cnt, int32_t) const
+    {
+        if (!on) return;
+        int32_t first = (int32_t)zi;
+        for (int32_t p = (int32_t)S->Pm(first); p != (int32_t)end_i; p = (int32_t)S->Pm(first)) first = p;
+        const uint64_t x0 = (uint64_t)hi(first) << 32 | S->rlo(first);
+        best_update(*b, chain_z(x0, S->qp(first), k, sc, (uint32_t)cnt, rhash), (int32_t)zi, (int32_t)end_i, sc, (int32_t)cnt, base);
+    }
+};
+// mm_max_stretch over the chain zi -> end_i (exclusive), walked backwards, and the test on it.  hi = x >> 32 of the chain's anchors
+// (strand | contig); B / seq / qlen: for the base-level check of the stretch when its k-mers leave too many bases uncovered.
+template <class Store>
+__device__ inline bool chain_lemma(Store &S, int32_t zi, int32_t end_i, const ChainParams &P, uint32_t hi, const BaseCtx &B, const uint8_t *seq, int32_t qlen)
+{
+    if (!P.ext_lemma) return false;
+    int32_t run_score = P.k, run_unc = 0, run_last = zi, run_first = zi;
+    int32_t best_score = -1, best_unc = 0, b_first = zi, b_last = zi;
+    for (int32_t i = zi;;) {
+        const int32_t p = (int32_t)S.Pm(i);
+        if (p == end_i) break;
+        const int32_t lr = (int32_t)(S.rlo(i) - S.rlo(p)), lq = (int32_t)S.qp(i) - (int32_t)S.qp(p);
+        if (lq == lr) { run_score += lq < P.k ? lq : P.k; run_unc += lq > P.k ? lq - P.k : 0; run_first = p; }
+        else {
+            if (run_score >= best_score) { best_score = run_score; best_unc = run_unc; b_first = run_first; b_last = run_last; }      // >=: of equal runs the EARLIER one is the stretch
+            run_score = P.k; run_unc = 0; run_last = run_first = p;
+        }
+        i = p;
+    }
+    if (run_score >= best_score) { best_score = run_score; best_unc = run_unc; b_first = run_first; b_last = run_last; }
+    const int32_t qf = (int32_t)S.qp(b_first), ql = (int32_t)S.qp(b_last);
+    if (!(best_score >= P.min_sc && ql - qf >= P.k)) return false;
+    if (best_unc <= P.ext_unc_max) return true;
+    return middle_no_zdrop(B, seq, qlen, (int32_t)(hi & 0x7fffffffu), (int32_t)(hi >> 31), qf + 1 - P.k, ql + 1, (int32_t)S.rlo(b_first) + 1 - P.k, P);
+}
 
 __device__ inline uint32_t prefix_popc64(uint64_t mask)
 {
@@ -863,7 +942,7 @@ __device__ inline void chain_cluster_ring(const uint64_t *gx, uint32_t *gq, int3
     if (sk) {      // hand-over mode: every chain, anchors intact (the heap lives in `heap`, not over the x slice)
         chain_dp_ring(gx, gq, gf, gpt, n, qlen, P, lane, rm, dbg_cnt);
         SliceStore S{gx, gq, gf, gpt};
-        const StoreEmit<SliceStore> em{sk, &S, read, base, lane == 0};
+        const StoreEmit<SliceStore> em{sk, &S, read, base, lane == 0, P.k, region_hash(qlen)};
         backtrack_heap<SliceStore, int32_t, StoreEmit<SliceStore>>(S, n, P, heap, n_u, best, false, em);
         wave_mem_sync();
         return;
@@ -884,7 +963,7 @@ __device__ inline void chain_cluster_wave(SliceStore &S, int32_t n, int32_t qlen
                                           bool first_only, uint32_t lane, const ChainSink *sk = nullptr, uint32_t read = 0, uint32_t base = 0)
 {
     if (sk) {      // hand-over mode (zbuf must not alias the anchors)
-        const StoreEmit<SliceStore> em{sk, &S, read, base, lane == 0};
+        const StoreEmit<SliceStore> em{sk, &S, read, base, lane == 0, P.k, region_hash(qlen)};
         chain_dp_wave(S, n, qlen, P, lane);
         if (n <= 64) backtrack_mask(S, n, P, n_u, best, false, em);
         else { backtrack_heap<SliceStore, int32_t, StoreEmit<SliceStore>>(S, n, P, zbuf, n_u, best, false, em); wave_mem_sync(); }
@@ -902,7 +981,7 @@ __device__ inline void chain_cluster(SliceStore &S, int32_t n, int32_t qlen, con
                                      bool first_only, const ChainSink *sk = nullptr, uint32_t read = 0, uint32_t base = 0)
 {
     if (sk) {      // hand-over mode (zbuf must not alias the anchors)
-        const StoreEmit<SliceStore> em{sk, &S, read, base, true};
+        const StoreEmit<SliceStore> em{sk, &S, read, base, true, P.k, region_hash(qlen)};
         if (n <= 64) { chain_dp_mask(S, n, qlen, P); backtrack_mask(S, n, P, n_u, best, false, em); }
         else { chain_dp<SliceStore, int32_t>(S, n, qlen, P); backtrack_heap<SliceStore, int32_t, StoreEmit<SliceStore>>(S, n, P, zbuf, n_u, best, false, em); }
         return;

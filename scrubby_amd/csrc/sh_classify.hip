@@ -65,8 +65,9 @@ struct Counters {
     uint32_t n_big_total, pad1;   // repeat-path reads before the pair pass took its share (0: no pair pass)
     uint32_t n_sort[N_SORT_CLS], n_giant_tiles, n_giant_rounds;
     uint32_t n_long_segs, pad2;
-    uint32_t ext_n_recs, ext_overflow, ext_n_list, ext_ticket, ext_regions, ext_dropped;      // extension stage (sh_align.h): chain records, work list
-    unsigned long long ext_n_anch;
+    uint32_t ext_reason[8];       // why the top chain did not settle a read (k_ext_top)
+    uint32_t ext_overflow, ext_n_list, ext_ticket, ext_regions, ext_dropped, ext_n_redo, ext_n_list2, ext_ticket2, ext_n_redo2, ext_ticket3;      // extension stage (sh_align.h)
+    uint32_t ext_n_recs[SINK_SHARDS]; unsigned long long ext_n_anch[SINK_SHARDS];                 // hand-over cursors, one per shard
     uint32_t n_cl[4], cl_ticket, pad3;      // global queue of big clusters (k_cluster_dp), by size class
     uint32_t n_leg_reason[4];     // why reads left the long-read front end: 0 room/segments, 1 thinning screen, 2 anchors beyond the giant path, 3 unused
     unsigned long long arena_cursor, anchor_cursor;
@@ -74,6 +75,7 @@ struct Counters {
     unsigned long long sort_tot[N_SORT_CLS + 1], sort_anchor_tot[N_SORT_CLS + 1];    // SCRUBBY_HIP_DBG & 16: reads / anchors per sort class (4 = chained inside k_expand)     // statistics of k_cluster_dp by size class (whole chunk)
     unsigned long long sh_mini[64], sh_anchors[64];     // sharded sums
     uint32_t sh_host[64], sh_clusters[64], sh_pair[64];      // sh_pair: reads decided by the pair test
+    uint32_t sh_lemma[64];       // SH_F_CIGAR flag-only: reads decided inside a chaining kernel (top chain + chain_lemma)
 };
 #define SHARD() ((blockIdx.x + (blockIdx.x >> 6)) & 63)
 
@@ -630,6 +632,8 @@ struct K2Args {
     uint32_t work_begin; // k_chain_large: first list entry to process
     uint32_t *leftover; uint32_t *leftover_count;   // k_pair_pass: reads it leaves undecided
     ChainSink sink; int32_t emit;                   // SH_F_CIGAR: every kept chain is handed to the extension stage; no flag-only shortcut in the DP
+    BaseCtx BC;
+    int32_t quiet;      // k_chain_large re-running reads that were counted before: no statistics
 };
 
 // hi word (strand | contig) of anchor group g of a read chained in a SmallStore: the store keeps group ranks only, so the
@@ -675,12 +679,12 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
     const uint32_t n_work = *a.work_count;
     SmallStore<CAP> S;
     S.lo = s_lo + lane; S.aux = s_aux + lane; S.qv = s_q + lane; S.gv = s_g + lane;
-    uint32_t n_host_wave = 0;
+    uint32_t n_host_wave = 0, n_lemma_wave = 0;
 
     for (uint32_t base = blockIdx.x * 64; base < n_work; base += gridDim.x * 64) {
         const uint32_t wi = base + lane;
         const bool valid = wi < n_work;
-        bool host = false;
+        bool host = false, lemma_hit = false;
         if (valid) {
             const uint32_t r = a.work[wi];
             const uint32_t info = a.k1info[r];
@@ -695,11 +699,22 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
             gen_anchors(S, sv, a.positions, qlen, a.P.k);
             int64_t n_a = 0;
             for (uint32_t i = 0; i < sv.n; ++i) n_a += sv.occ(i);
-            if (a.emit) {      // every chain goes to the extension stage, which decides the read
+            bool decided = false;
+            if (a.emit && a.trace == nullptr && a.P.ext_lemma) {      // flag-only: the top chain, vouched for by chain_lemma, decides without a hand-over
+                chain_dp_mask(S, (int)n_a, qlen, a.P);
+                BestChain bc{};
+                auto hi = [&](int32_t i) { return small_group_hi(sv, a.positions, qlen, a.P.k, S.grp(i)); };
+                const BestEmit<SmallStore<CAP>, decltype(hi)> be{&S, &bc, region_hash(qlen), a.P.k, 0u, hi, true};
+                backtrack_mask(S, (int)n_a, a.P, n_u, best, false, be);
+                decided = n_u == 0 || (!bc.tie && chain_lemma(S, bc.zi, bc.end_i, a.P, hi(bc.zi), a.BC, a.bases + a.offsets[r], qlen));
+                lemma_hit = n_u > 0 && decided;
+            }
+            if (decided) {}
+            else if (a.emit) {      // every chain goes to the extension stage, which decides the read
                 chain_dp_mask(S, (int)n_a, qlen, a.P);
                 auto em = [&](int64_t zi, int64_t end_i, int32_t sc, int64_t cnt, int32_t zf) {
                     const uint32_t hi = small_group_hi(sv, a.positions, qlen, a.P.k, S.grp((int)zi));
-                    sink_emit(a.sink, r, (int32_t)zi, (int32_t)end_i, sc, (uint32_t)cnt, (uint32_t)zf, (uint32_t)zi,
+                    sink_emit(a.sink, r, (int32_t)zi, (int32_t)end_i, sc, (uint32_t)cnt, (uint32_t)zf, (uint32_t)zi, a.P.k, region_hash(qlen),
                               [&](int32_t i, uint64_t &x, uint32_t &q) { x = (uint64_t)hi << 32 | S.rlo(i); q = S.qp(i); },
                               [&](int32_t i) { return S.Pm(i); });
                 };
@@ -713,8 +728,10 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
             host = n_u > 0;
         }
         n_host_wave += (uint32_t)__popcll(__ballot(host));
+        n_lemma_wave += (uint32_t)__popcll(__ballot(lemma_hit));
     }
     if (lane == 0 && n_host_wave) atomicAdd(&a.ctr->sh_host[SHARD()], n_host_wave);
+    if (lane == 0 && n_lemma_wave) atomicAdd(&a.ctr->sh_lemma[SHARD()], n_lemma_wave);
 }
 
 // Pair pass (flag-only; ChainParams::pair_dq_*), one lane per read over a work list.  Two singleton seeds (their position words
@@ -889,8 +906,10 @@ template <bool CONTIG, class PX, class PQ>
 __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_t n, uint32_t tid, uint32_t nthr, int32_t qlen,
                                     const ChainParams &P, volatile int32_t *found, BigList bl,
                                     int32_t &n_u_thr, int32_t &best_thr, uint32_t &n_cl_thr, const GlobalQ *gq = nullptr,
-                                    uint32_t *nxt = nullptr, const ChainSink *sk = nullptr, uint32_t read = 0, uint64_t *heap = nullptr)
-{   // sk: hand-over mode - every chain of every cluster is emitted (found must be nullptr); heap: n words for the backtrack
+                                    uint32_t *nxt = nullptr, const ChainSink *sk = nullptr, uint32_t read = 0, uint64_t *heap = nullptr,
+                                    BestChain *bc = nullptr, uint32_t rhash = 0)
+{   // bc: SH_F_CIGAR flag-only, n <= 64: every lane chains its clusters itself and remembers its top chain (BestChain), nothing is emitted
+    // sk: hand-over mode - every chain of every cluster is emitted (found must be nullptr); heap: n words for the backtrack
     // heaps of clusters with more than 64 anchors (nullptr: the x slice itself, which the hand-over must not destroy)
     const uint32_t mdx = chain_max_dist_x(P, qlen);
     const bool keep_single = !(P.k < P.min_sc || P.min_cnt > 1);
@@ -907,6 +926,17 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
     // one cluster [i, i + len): chained by this lane if small, else queued for a whole wave
     auto handle = [&](uint32_t i, uint32_t len) {
         if (len < 2 && !keep_single) return;
+        if (bc) {      // len <= 64 (the caller's n is)
+            SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i};
+            int32_t n_u, best;
+            auto hi = [&](int32_t j) { return (uint32_t)(S.X(j) >> 32); };
+            const BestEmit<SliceStore, decltype(hi)> be{&S, bc, rhash, P.k, i, hi, true};
+            chain_dp_mask(S, (int)len, qlen, P);
+            backtrack_mask(S, (int)len, P, n_u, best, false, be);
+            ++n_cl_thr;
+            if (n_u > 0) { n_u_thr += n_u; if (best > best_thr) best_thr = best; }
+            return;
+        }
         if (len > (CONTIG ? 64u : 6u)) {      // arena path: only clusters beyond the register-mask DP go wave-wide
             if (gq) {
                 const int cc = cl_class(len);
@@ -992,6 +1022,7 @@ struct K3Args {
     Counters *ctr; BigBufs B; ChainParams P;
     int32_t pass, max_occ, flag_only, dbg;
     ChainSink sink; int32_t emit;      // SH_F_CIGAR: chains are handed to the extension stage (flag_only is 0 then: no early exit)
+    BaseCtx BC;
 };
 
 
@@ -1087,7 +1118,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
     const ChainParams &P = a.P;
     const bool plain_cut = !(P.occ_dist > 0 && P.max_max_occ > a.max_occ);
     WaveAlloc al_sort[N_SORT_CLS];
-    uint32_t n_clusters = 0, n_pair = 0;
+    uint32_t n_clusters = 0, n_pair = 0, n_lemma = 0;
     unsigned long long anchors_wave = 0, a_cur = 0, a_end = 0;      // wave-local slice of the anchor arena
     __shared__ uint64_t e_x[64];
     __shared__ uint32_t e_q[64];
@@ -1315,6 +1346,33 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
                 __syncthreads();
             }
             int32_t n_u = 0, best = 0;
+            bool lemma_done = false;
+            if (a.emit && a.trace == nullptr && P.ext_lemma) {
+                // flag-only: every lane chains its clusters and keeps its top chain; the read's top chain (largest z over the lanes) is
+                // regs[0] of mm_gen_regs - if chain_lemma vouches for it the read is mapped and nothing is handed over
+                BestChain bc{};
+                chain_sorted<false>(e_x, e_q, e_f, e_pt, n_a, lane, 64, qlen, P, nullptr, BigList{e_bstart, e_blen, &e_bcount, 8}, n_u, best, n_clusters,
+                                    nullptr, nullptr, nullptr, r, nullptr, &bc, region_hash(qlen));
+                unsigned long long zmax = bc.n ? bc.z : 0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = (unsigned long long)__shfl_xor((long long)zmax, o); zmax = other > zmax ? other : zmax; }
+                const uint64_t holders = __ballot(bc.n > 0 && bc.z == zmax);
+                const uint64_t any = __ballot(bc.n > 0);
+                bool ok = false;
+                if (any == 0) ok = true;                                       // no chain at all: unmapped
+                else if (__popcll(holders) == 1) {
+                    bool mine = false;
+                    if (bc.n > 0 && bc.z == zmax && !bc.tie) {
+                        SliceStore S{(const uint64_t *)&e_x[bc.base], (const uint32_t *)&e_q[bc.base], e_f + bc.base, e_pt + 2 * (size_t)bc.base};
+                        mine = chain_lemma(S, bc.zi, bc.end_i, P, (uint32_t)(S.X(bc.zi) >> 32), a.BC, a.BC.bases + a.offsets[r], qlen);
+                    }
+                    ok = __ballot(mine) != 0;
+                }
+                lemma_done = ok;
+                if (ok && any != 0) ++n_lemma;
+                if (!ok) { n_u = 0; best = 0; __syncthreads(); }
+            }
+            if (!lemma_done)
             chain_sorted<false>(e_x, e_q, e_f, e_pt, n_a, lane, 64, qlen, P, nullptr, BigList{e_bstart, e_blen, &e_bcount, 8}, n_u, best, n_clusters,
                                 nullptr, nullptr, a.emit ? &a.sink : nullptr, r, nullptr);      // <= 64 anchors: no cluster needs a heap
 #pragma unroll
@@ -1337,6 +1395,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
     n_clusters = wave_sum_u32(n_clusters);
     if (lane == 0 && n_clusters) atomicAdd(&a.ctr->sh_clusters[SHARD()], n_clusters);
     if (lane == 0 && n_pair) atomicAdd(&a.ctr->sh_pair[SHARD()], n_pair);
+    if (lane == 0 && n_lemma) atomicAdd(&a.ctr->sh_lemma[SHARD()], n_lemma);
 }
 
 // stable block merge sort: 64-element tiles ranked in registers (one tile per wave at a time), then merge-path
@@ -1866,7 +1925,7 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
                     gen_anchors(S, sv, a.positions, qlen, a.P.k);
                     chain_dp<LargeStore, int64_t>(S, n_a, qlen, a.P);
                     if (a.emit) {
-                        const StoreEmit<LargeStore> em{&a.sink, &S, r, 0u, true};
+                        const StoreEmit<LargeStore> em{&a.sink, &S, r, 0u, true, a.P.k, region_hash(qlen)};
                         backtrack_heap<LargeStore, int64_t, StoreEmit<LargeStore>>(S, n_a, a.P, S.z, n_u, best, false, em);
                     } else
                     backtrack_heap<LargeStore, int64_t>(S, n_a, a.P, S.z, n_u, best);
@@ -1884,7 +1943,7 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
             }
         }
         uint64_t mh = __ballot(host);
-        if (lane == 0 && mh) atomicAdd(&a.ctr->sh_host[SHARD()], (uint32_t)__popcll(mh));
+        if (lane == 0 && mh && !a.quiet) atomicAdd(&a.ctr->sh_host[SHARD()], (uint32_t)__popcll(mh));
     }
 }
 
@@ -1894,15 +1953,46 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
 struct ExtArgs {
     AlignIn in; AlignParams P;
     uint8_t *scratch; unsigned long long scratch_per_wave; uint32_t max_read_len, reg_cap;
-    uint32_t *list; Counters *ctr; uint8_t *flags; sh_trace *trace; int32_t flag_only; uint64_t n_reads;
+    uint32_t *list; uint32_t *n_list, *ticket; Counters *ctr; uint8_t *flags; sh_trace *trace; int32_t flag_only; uint64_t n_reads;
+    const unsigned long long *best; const uint32_t *tie;      // first pass of a flag-only call: decide from the top chain, or queue for the full pass
+    uint32_t *redo, *redo2; int32_t top_only;                 // k_regs_align, top_only: align regs[0] alone; reads it does not settle go to redo2
 };
 
 __global__ void k_ext_list(ExtArgs a)
 {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool has = r < a.n_reads && a.in.head[r] != ~0u;
-    const uint32_t li = wave_append(&a.ctr->ext_n_list, has);
+    const uint32_t li = wave_append(a.n_list, has);
     if (has) a.list[li] = (uint32_t)r;
+}
+
+// flag-only first pass, one LANE per read of the list: regs[0] settles nearly every read (top_chain_settles); the others are queued
+__global__ __launch_bounds__(64) void k_ext_top(ExtArgs a)
+{
+    const uint32_t n_list = *a.n_list;
+    uint32_t n_redo_wave = 0;
+    for (uint32_t base = blockIdx.x * 64; base < n_list; base += gridDim.x * 64) {
+        const uint32_t t = base + threadIdx.x;
+        bool redo = false;
+        uint32_t r = 0;
+        if (t < n_list) {
+            r = a.list[t];
+            const int32_t rc = top_chain_settles(a.in, a.P, r, a.best[r], a.tie[r]);
+            if (rc > 0) a.flags[r] = 1;
+            else { redo = true; atomicAdd(&a.ctr->ext_reason[-rc & 7], 1u); }
+        }
+        const uint32_t li = wave_append(&a.ctr->ext_n_redo, redo);
+        if (redo) a.redo[li] = r;
+        n_redo_wave += (uint32_t)__popcll(__ballot(redo));
+    }
+    (void)n_redo_wave;
+}
+
+// reads queued for the full pass start over with an empty chain list
+__global__ void k_ext_reset(ExtArgs a)
+{
+    const uint32_t n = *a.n_list;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) ((uint32_t *)a.in.head)[a.list[i]] = ~0u;
 }
 
 __global__ __launch_bounds__(64) void k_regs_align(ExtArgs a)
@@ -1911,16 +2001,25 @@ __global__ __launch_bounds__(64) void k_regs_align(ExtArgs a)
     const uint32_t lane = threadIdx.x;
     AlignScratch A;
     align_scratch_carve(A, a.scratch + (unsigned long long)blockIdx.x * a.scratch_per_wave, a.max_read_len, a.reg_cap);
-    const uint32_t n_list = a.ctr->ext_n_list;
+    const uint32_t n_list = *a.n_list;
     uint32_t n_regions = 0, n_dropped = 0;
     for (;;) {
         uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(&a.ctr->ext_ticket, 1u);
+        if (lane == 0) t = atomicAdd(a.ticket, 1u);
         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
         if (t >= n_list) break;
         const uint32_t r = a.list[t];
         AlignOut o;
-        if (!align_read_wave(a.in, a.P, r, a.flag_only != 0, A, Ls, o, &a.ctr->ext_overflow)) continue;
+        if (!align_read_wave(a.in, a.P, r, a.flag_only != 0, A, Ls, o, &a.ctr->ext_overflow, a.top_only ? a.best[r] : 0ull)) continue;
+        if (a.top_only) {      // regs[0] alone: a survivor settles the read, otherwise every chain is needed
+            if (lane == 0) {
+                if (o.n_regs > 0) a.flags[r] = 1;
+                else a.redo2[atomicAdd(&a.ctr->ext_n_redo2, 1u)] = r;
+            }
+            n_regions += (uint32_t)o.n_aligned;
+            __syncthreads();
+            continue;
+        }
         if (lane == 0) {
             a.flags[r] = o.n_regs > 0 ? 1 : 0;
             if (a.trace) {
@@ -1964,7 +2063,7 @@ struct sh_ctx {
     AlignParams AP{};
     ChainSink sink{};
     uint8_t *d_ext = nullptr; uint64_t ext_bytes = 0;
-    uint32_t *d_ext_list = nullptr; uint8_t *d_ext_scratch = nullptr;
+    uint32_t *d_ext_list = nullptr, *d_ext_redo = nullptr; uint8_t *d_ext_scratch = nullptr;
     unsigned long long ext_scratch_per_wave = 0; uint32_t ext_waves = 0, ext_reg_cap = 0;
     hipEvent_t ev_ext[2] = {};
     hipStream_t sx[4] = {};          // side streams: K2 and the sort classes run beside the main stream
@@ -1993,13 +2092,16 @@ static void fill_chain_params(const sh_opts &o, int32_t mid_occ, ChainParams &P)
     P.pair_min_anchors = getenv("SCRUBBY_HIP_PAIR_MIN") ? atoi(getenv("SCRUBBY_HIP_PAIR_MIN")) : 32;
     // SH_F_CIGAR: the decision is taken by the extension stage from ALL chains of a read, so the DP shortcuts above are off; the one
     // shortcut left is k_pair_pass mode 2 (ChainParams::ext_*)
-    P.ext_s1 = 0; P.ext_unc_max = 0;
+    P.ext_s1 = 0; P.ext_unc_max = 0; P.ext_lemma = 0; P.ext_a = P.ext_b = P.ext_amb = P.ext_zdrop = 0;
     if ((o.flags & SH_F_CIGAR) && o.is_sr) {
         P.flag_stop = INT32_MAX; P.pair_dq_min = P.pair_dq_max = 0;
         const bool s1 = o.a > 0 && o.b > 0 && o.a * o.k >= o.min_dp_max && 2 * o.k >= o.min_chain_score && o.max_clip_ratio >= 1.0f &&
                         o.chain_skip_scale == 0.0f && o.min_cnt <= 2 && o.zdrop >= 0 && o.bw >= 0 && !getenv("SCRUBBY_HIP_NO_S1");
         P.ext_s1 = s1 ? 1 : 0;
-        P.ext_unc_max = s1 ? o.zdrop / o.b : 0;
+        const bool lem = o.a > 0 && o.b > 0 && o.a * o.k >= o.min_dp_max && 2 * o.k >= o.min_chain_score && o.max_clip_ratio >= 1.0f && o.zdrop >= 0 && !getenv("SCRUBBY_HIP_NO_LEMMA");
+        P.ext_lemma = lem ? 1 : 0;
+        P.ext_unc_max = (s1 || lem) ? o.zdrop / o.b : 0;
+        P.ext_a = o.a; P.ext_b = -o.b; P.ext_amb = o.sc_ambi > 0 ? -o.sc_ambi : o.sc_ambi; P.ext_zdrop = o.zdrop;
     }
 }
 
@@ -2009,6 +2111,7 @@ static void fill_align_params(const sh_opts &o, AlignParams &A)
     A.a = o.a; A.b = o.b; A.q = o.q; A.e = o.e; A.q2 = o.q2; A.e2 = o.e2; A.sc_ambi = o.sc_ambi;
     A.zdrop = o.zdrop; A.zdrop_inv = o.zdrop_inv; A.end_bonus = o.end_bonus; A.min_dp_max = o.min_dp_max; A.best_n = o.best_n;
     A.pri_ratio = o.pri_ratio; A.mask_level = o.mask_level; A.max_clip_ratio = o.max_clip_ratio;
+    A.lemma = 0; A.unc_max = 0;
 }
 
 static bool w_supported(int w) { return w == 5 || w == 10 || w == 11 || w == 19; }
@@ -2029,6 +2132,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
     int32_t mid_occ = opts->mid_occ > 0 ? opts->mid_occ : idx->mid_occ;
     fill_chain_params(*opts, mid_occ, c->P);
     fill_align_params(*opts, c->AP);
+    c->AP.lemma = c->P.ext_lemma; c->AP.unc_max = c->P.ext_unc_max;
     c->ext = (opts->flags & SH_F_CIGAR) && opts->is_sr;
     if ((opts->flags & SH_F_CIGAR) && !opts->is_sr) {
         static bool warned = false;
@@ -2130,17 +2234,21 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         // read of the chunk (a chunk that needs more is cut in two and re-run: classify_chunk returns SH_SPLIT)
         uint64_t cap_recs = std::max<uint64_t>(1ull << 20, 2 * max_reads), cap_anch = std::max<uint64_t>(1ull << 24, 32 * max_reads);
         if (const char *env = getenv("SCRUBBY_HIP_EXT_MB")) { cap_anch = std::max<uint64_t>(1 << 16, ((uint64_t)atoll(env) << 20) / 16); cap_recs = std::max<uint64_t>(1 << 12, cap_anch / 16); }
-        cap_recs = std::min<uint64_t>(cap_recs, 0xfffffff0ull);
+        cap_recs = std::min<uint64_t>((cap_recs + SINK_SHARDS - 1) / SINK_SHARDS, 0xfffffff0ull / SINK_SHARDS);      // per shard
+        cap_anch = (cap_anch + SINK_SHARDS - 1) / SINK_SHARDS;
         auto al = [](uint64_t b) { return (b + 255) & ~255ull; };
-        c->ext_bytes = al(cap_recs * sizeof(ChainRec)) + al(cap_anch * 8) + al(cap_anch * 4) + al(max_reads * 4) + al(max_reads * 4);
+        c->ext_bytes = al(SINK_SHARDS * cap_recs * sizeof(ChainRec)) + al(SINK_SHARDS * cap_anch * 8) + al(SINK_SHARDS * cap_anch * 4) + 3 * al(max_reads * 4) + al(max_reads * 8) + al(max_reads * 4);
         if ((e = hipMalloc(&c->d_ext, c->ext_bytes)) != hipSuccess) return fail(e, "extension-stage buffers");
         uint8_t *p = c->d_ext;
         auto take = [&](uint64_t b) { uint8_t *q = p; p += al(b); return q; };
-        c->sink.recs = (ChainRec *)take(cap_recs * sizeof(ChainRec)); c->sink.cap_recs = (uint32_t)cap_recs;
-        c->sink.cx = (uint64_t *)take(cap_anch * 8); c->sink.cq = (uint32_t *)take(cap_anch * 4); c->sink.cap_anch = cap_anch;
+        c->sink.recs = (ChainRec *)take(SINK_SHARDS * cap_recs * sizeof(ChainRec)); c->sink.cap_recs = (uint32_t)cap_recs;
+        c->sink.cx = (uint64_t *)take(SINK_SHARDS * cap_anch * 8); c->sink.cq = (uint32_t *)take(SINK_SHARDS * cap_anch * 4); c->sink.cap_anch = cap_anch;
         c->sink.head = (uint32_t *)take(max_reads * 4);
         c->d_ext_list = (uint32_t *)take(max_reads * 4);
-        c->sink.n_recs = &c->d_ctr->ext_n_recs; c->sink.n_anch = &c->d_ctr->ext_n_anch; c->sink.overflow = &c->d_ctr->ext_overflow;
+        c->d_ext_redo = (uint32_t *)take(max_reads * 4);
+        c->sink.best = (unsigned long long *)take(max_reads * 8);
+        c->sink.tie = (uint32_t *)take(max_reads * 4);
+        c->sink.n_recs = c->d_ctr->ext_n_recs; c->sink.n_anch = c->d_ctr->ext_n_anch; c->sink.overflow = &c->d_ctr->ext_overflow;
         c->ext_reg_cap = 16384;
         c->ext_scratch_per_wave = align_scratch_layout(max_read_len, c->ext_reg_cap, nullptr, nullptr, nullptr);
         const uint64_t budget = 4ull << 30;
@@ -2234,7 +2342,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
 {
     const sh_index *idx = c->idx;
     SH_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), s));
-    if (c->ext) SH_HIP(hipMemsetAsync(c->sink.head, 0xff, n_reads * 4, s));
+    if (c->ext) { SH_HIP(hipMemsetAsync(c->sink.head, 0xff, n_reads * 4, s)); SH_HIP(hipMemsetAsync(c->sink.best, 0, n_reads * 8, s)); SH_HIP(hipMemsetAsync(c->sink.tie, 0, n_reads * 4, s)); }
     SH_HIP(hipEventRecord(c->ev[0], s));
     const uint32_t n_tiles = (uint32_t)((n_reads + 63) / 64);
     if (c->use_k1) {
@@ -2292,6 +2400,8 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     b.arena = c->d_arena; b.arena_bytes = c->legacy_bytes;
     b.P = c->P;
     b.sink = c->sink; b.emit = c->ext ? 1 : 0;
+    b.BC = BaseCtx{idx->d_ref, idx->d_cstart, d_bases};
+    if (c->ext && d_trace != nullptr) { b.sink.best = nullptr; b.sink.tie = nullptr; }      // trace mode: every chain is handed over
     const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(n_tiles, 1), 256 * 8);
     if (c->use_k1) {     // K2 only needs K1's output: it runs beside the repeat path
         hipStream_t sk = (c->par & 1) ? c->sx[3] : s;
@@ -2313,7 +2423,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     k.seed_off = c->use_long ? c->d_seed_off : nullptr; k.sel_scratch = c->use_long ? (uint32_t *)c->d_mz_hash : nullptr;
     k.k1info = c->d_k1info; k.flags = d_flags; k.trace = d_trace; k.ctr = c->d_ctr; k.B = c->B; k.P = c->P;
     k.flag_only = d_trace == nullptr && !c->ext;      // SH_F_CIGAR: every chain is needed, no early exit
-    k.sink = c->sink; k.emit = c->ext ? 1 : 0;
+    k.sink = b.sink; k.emit = c->ext ? 1 : 0; k.BC = b.BC;
     k.dbg = getenv("SCRUBBY_HIP_DBG") ? atoi(getenv("SCRUBBY_HIP_DBG")) : 0;
     k.resketch_list = c->d_work_resketch;
     uint32_t resk_done = 0;
@@ -2389,22 +2499,83 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     uint32_t ext_list = 0, ext_regions = 0, ext_dropped = 0;
     float ms_ext = 0;
     if (c->ext) {
-        // every read that handed over a chain: mm_gen_regs .. mm_filter_regs decide it (one wave per read, persistent grid)
         ExtArgs x{};
         x.in.ref = idx->d_ref; x.in.cstart = idx->d_cstart; x.in.n_contigs = idx->n_contigs;
         x.in.bases = d_bases; x.in.offsets = d_offsets; x.in.cx = c->sink.cx; x.in.cq = c->sink.cq; x.in.recs = c->sink.recs; x.in.head = c->sink.head;
         x.P = c->AP; x.scratch = c->d_ext_scratch; x.scratch_per_wave = c->ext_scratch_per_wave; x.max_read_len = c->max_read_len; x.reg_cap = c->ext_reg_cap;
-        x.list = c->d_ext_list; x.ctr = c->d_ctr; x.flags = d_flags; x.trace = d_trace; x.flag_only = d_trace == nullptr; x.n_reads = n_reads;
+        x.list = c->d_ext_list; x.n_list = &c->d_ctr->ext_n_list; x.ticket = &c->d_ctr->ext_ticket;
+        x.ctr = c->d_ctr; x.flags = d_flags; x.trace = d_trace; x.flag_only = d_trace == nullptr; x.n_reads = n_reads;
+        x.best = c->sink.best; x.tie = c->sink.tie; x.redo = c->d_ext_redo;
         SH_HIP(hipEventRecord(c->ev_ext[0], s));
         hipLaunchKernelGGL(k_ext_list, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, s, x);
-        hipLaunchKernelGGL(k_regs_align, dim3(c->ext_waves), dim3(64), 0, s, x);
-        SH_HIP(hipEventRecord(c->ev_ext[1], s));
+        if (d_trace != nullptr) {
+            // trace mode: every read that handed over a chain goes through mm_gen_regs .. mm_filter_regs (one wave per read)
+            hipLaunchKernelGGL(k_regs_align, dim3(c->ext_waves), dim3(64), 0, s, x);
+        } else {
+            // flag-only: the lists hold each read's candidates for regs[0]; the top chain settles nearly every read (one lane each)
+            hipLaunchKernelGGL(k_ext_top, dim3(grid), dim3(64), 0, s, x);
+        }
         SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
         SH_HIP(hipStreamSynchronize(s));
         SH_HIP(hipGetLastError());
         if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;       // hand-over buffers full: the caller cuts the chunk in two
         SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "extension stage: a read exceeds the per-wave working memory (code %u: 2 chains, 3 primaries, 4 read length, 5 window, 6 regions)", c->h_ctr->ext_overflow);
-        ext_list = c->h_ctr->ext_n_list; ext_regions = c->h_ctr->ext_regions; ext_dropped = c->h_ctr->ext_dropped;
+        ext_list = c->h_ctr->ext_n_list;
+        const uint32_t n_redo = c->h_ctr->ext_n_redo;
+        if (getenv("SCRUBBY_HIP_DBG")) fprintf(stderr, "[dbg] extension stage: %u reads handed over chains, %u not settled by their top chain (tie %u, missing %u, short stretch %u, z-drop %u)\n", ext_list, n_redo, c->h_ctr->ext_reason[1], c->h_ctr->ext_reason[2], c->h_ctr->ext_reason[3], c->h_ctr->ext_reason[4]);
+        uint32_t n_redo2 = 0;
+        if (d_trace == nullptr && n_redo > 0) {
+            // second pass: regs[0] of the reads its max stretch could not vouch for goes through mm_align1 (one wave per read)
+            ExtArgs x1 = x;
+            x1.list = c->d_ext_redo; x1.n_list = &c->d_ctr->ext_n_redo; x1.ticket = &c->d_ctr->ext_ticket2; x1.top_only = 1; x1.redo2 = c->d_ext_list;     // the first list is spent
+            hipLaunchKernelGGL(k_regs_align, dim3(c->ext_waves), dim3(64), 0, s, x1);
+            SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+            SH_HIP(hipStreamSynchronize(s));
+            SH_HIP(hipGetLastError());
+            SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "extension stage: a read exceeds the per-wave working memory (code %u)", c->h_ctr->ext_overflow);
+            n_redo2 = c->h_ctr->ext_n_redo2;
+        }
+        if (n_redo2 > 0) {
+            // third pass, reads whose top chain does not survive: all their chains (legacy lane-per-read chaining, nothing filtered), then the
+            // full procedure.  The hand-over buffers start over.
+            Counters z = *c->h_ctr;
+            memset(z.ext_n_recs, 0, sizeof(z.ext_n_recs)); memset(z.ext_n_anch, 0, sizeof(z.ext_n_anch));
+            z.n_defer = 0; z.arena_cursor = 0; z.n_resketch = n_redo2; z.ext_n_list2 = n_redo2; z.ext_ticket3 = 0;
+            SH_HIP(hipMemcpyAsync(c->d_ctr, &z, sizeof(Counters), hipMemcpyHostToDevice, s));
+            ExtArgs x2 = x;
+            x2.list = c->d_ext_list; x2.n_list = &c->d_ctr->ext_n_list2; x2.ticket = &c->d_ctr->ext_ticket3;
+            hipLaunchKernelGGL(k_ext_reset, dim3(64), dim3(256), 0, s, x2);
+            K2Args rb = b;
+            rb.sink.best = nullptr; rb.sink.tie = nullptr; rb.quiet = 1;
+            rb.work = c->d_ext_list; rb.work_count = &c->d_ctr->n_resketch; rb.work_begin = 0; rb.work_defer = c->d_work_defer;
+            uint32_t left = n_redo2;
+            int rounds2 = 0;
+            for (;;) {
+                hipLaunchKernelGGL(k_chain_large, dim3(grid), dim3(64), 0, s, rb);
+                SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+                SH_HIP(hipStreamSynchronize(s));
+                const uint32_t nd = c->h_ctr->n_defer;
+                if (nd == 0) break;
+                SH_CHECK(nd < left && ++rounds2 < 64, SH_ERR_OOM, "re-sketch arena too small for the extension stage's last pass; set SCRUBBY_HIP_ARENA_MB");
+                left = nd;
+                std::swap(c->d_work_defer, c->d_work_defer2);
+                Counters z2 = *c->h_ctr;
+                z2.n_defer = 0; z2.arena_cursor = 0; z2.n_resketch = nd;
+                SH_HIP(hipMemcpyAsync(c->d_ctr, &z2, sizeof(Counters), hipMemcpyHostToDevice, s));
+                rb.work = c->d_work_defer2; rb.work_defer = c->d_work_defer;
+            }
+            if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
+            hipLaunchKernelGGL(k_regs_align, dim3(c->ext_waves), dim3(64), 0, s, x2);
+            SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+            SH_HIP(hipStreamSynchronize(s));
+            SH_HIP(hipGetLastError());
+            if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
+            SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "extension stage: a read exceeds the per-wave working memory (code %u)", c->h_ctr->ext_overflow);
+        }
+        SH_HIP(hipEventRecord(c->ev_ext[1], s));
+        SH_HIP(hipEventSynchronize(c->ev_ext[1]));
+        ext_regions = c->h_ctr->ext_regions; ext_dropped = c->h_ctr->ext_dropped;
+        if (d_trace == nullptr) ext_list = n_redo;      // reads that needed base-level alignment
         hipEventElapsedTime(&ms_ext, c->ev_ext[0], c->ev_ext[1]);
     }
     SH_HIP(hipEventRecord(c->ev[4], s));
@@ -2413,7 +2584,9 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         float t01 = 0, t12 = 0, t23 = 0, t04 = 0;
         hipEventElapsedTime(&t01, c->ev[0], c->ev[1]); hipEventElapsedTime(&t12, c->ev[1], c->ev[2]);
         hipEventElapsedTime(&t23, c->ev[1], c->ev[3]); hipEventElapsedTime(&t04, c->ev[0], c->ev[4]);
-        uint64_t sum_host = 0, sum_mini = 0, sum_anchors = 0, sum_clusters = 0, sum_pair = 0;
+        uint64_t sum_host = 0, sum_mini = 0, sum_anchors = 0, sum_clusters = 0, sum_pair = 0, sum_lemma = 0;
+        for (int i = 0; i < 64; ++i) sum_lemma += c->h_ctr->sh_lemma[i];
+        stats->n_ext_shortcut += sum_lemma;
         for (int i = 0; i < 64; ++i) { sum_host += c->h_ctr->sh_host[i]; sum_mini += c->h_ctr->sh_mini[i]; sum_anchors += c->h_ctr->sh_anchors[i]; sum_clusters += c->h_ctr->sh_clusters[i]; sum_pair += c->h_ctr->sh_pair[i]; }
         stats->n_reads += n_reads; stats->n_bases += n_bases;
         stats->n_host += sum_host - ext_dropped;

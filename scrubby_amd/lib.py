@@ -69,6 +69,7 @@ class Stats(C.Structure):
         ("ms_chain_large", C.c_double), ("ms_total", C.c_double),
         ("n_anchors", C.c_uint64), ("n_clusters", C.c_uint64), ("n_resketch", C.c_uint64), ("n_pair_decided", C.c_uint64),
         ("n_ext_reads", C.c_uint64), ("n_ext_regions", C.c_uint64), ("n_ext_dropped", C.c_uint64), ("ms_ext", C.c_double),
+        ("n_ext_shortcut", C.c_uint64),
     ]
 
     def as_dict(self):
