@@ -74,11 +74,19 @@ __device__ inline unsigned long long chain_z(uint64_t x0, uint32_t q0, int32_t k
     return ((unsigned long long)(uint32_t)score << 32 | cnt) ^ h;
 }
 
+// flag-only: the score of the best chain of `read` handed over so far (0: none).  z's high word IS the score (h only touches the low
+// word), so a chain, a cluster or the rest of a backtrack whose score cannot reach it can be skipped outright.
+__device__ inline int32_t sink_best_score(const ChainSink &sk, uint32_t read)
+{
+    return sk.best ? (int32_t)(__hip_atomic_load(&sk.best[read], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) : 0;
+}
+
 // append one chain.  pred(i) -> predecessor; xq(i, x, q) reads an anchor.  Called by ONE lane.
 template <class XQ, class PRED>
 __device__ inline void sink_emit(const ChainSink &sk, uint32_t read, int32_t zi, int32_t end_i, int32_t score, uint32_t cnt,
                                  uint32_t key_f, uint32_t key_i, int32_t k, uint32_t rhash, XQ xq, PRED pred)
 {
+    if (score < sink_best_score(sk, read)) return;
     int32_t first = zi;
     for (int32_t p = pred(first); p != end_i; p = pred(first)) first = p;
     uint64_t x0; uint32_t q0;

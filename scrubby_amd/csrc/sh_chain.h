@@ -17,7 +17,10 @@
 
 // Chain hand-over to the extension stage (sh_align.h): every backtrack below takes an emitter that is called once per ACCEPTED
 // chain with (last anchor zi, stop index end_i (exclusive, -1 = root), score, anchors, f of zi).  NoEmit compiles to nothing.
-struct NoEmit { __device__ inline void operator()(int64_t, int64_t, int32_t, int64_t, int32_t) const {} };
+struct NoEmit {
+    __device__ inline void operator()(int64_t, int64_t, int32_t, int64_t, int32_t) const {}
+    __device__ inline bool done(int32_t) const { return false; }      // done(zf): no chain ending in an anchor with f <= zf is wanted any more
+};
 
 struct ChainParams {
     int32_t k, is_sr;
@@ -479,6 +482,7 @@ __device__ inline void backtrack_mask(Store &S, int n, const ChainParams &P, int
         bound = cur;
         const int32_t zf = (int32_t)(cur >> 32);
         const int zi = (int)(cur & 0xffffffff);
+        if (em.done(zf)) break;
         // mg_chain_bk_end
         int i = zi, end_i = -1, max_i = zi;
         int32_t max_s = 0;
@@ -522,6 +526,7 @@ __device__ inline void backtrack_heap(Store &S, Idx n, const ChainParams &P, uin
     int64_t n_v = 0;
     for (Idx m = nz; m > 0; --m) {
         uint64_t top = z[0];
+        if (em.done((int32_t)(top >> 32))) break;
         z[0] = z[m - 1];
         if (m - 1 > 0) down(0, m - 1);
         backtrack_visit<Store, Idx, EM>(S, P, (int32_t)(top >> 32), (Idx)(top & 0xffffffff), n_v, n_u, best, em);
@@ -559,6 +564,8 @@ struct StoreEmit {
                   [&](int32_t i, uint64_t &x, uint32_t &q) { x = St.X(i); q = St.qp(i); },
                   [&](int32_t i) { return (int32_t)St.Pm(i); });
     }
+    // a chain's score is at most the f of its last anchor: once that falls below the best score handed over, the rest is not wanted
+    __device__ inline bool done(int32_t zf) const { return sk && sk->best && zf < sink_best_score(*sk, read); }
 };
 
 // ---- SH_F_CIGAR, flag-only: the decision inside a chaining kernel that holds ALL chains of a read ---------------------------------
@@ -585,6 +592,7 @@ struct BestEmit {
         const uint64_t x0 = (uint64_t)hi(first) << 32 | S->rlo(first);
         best_update(*b, chain_z(x0, S->qp(first), k, sc, (uint32_t)cnt, rhash), (int32_t)zi, (int32_t)end_i, sc, (int32_t)cnt, base);
     }
+    __device__ inline bool done(int32_t zf) const { return b->n > 0 && zf < b->score; }
 };
 // mm_max_stretch over the chain zi -> end_i (exclusive), walked backwards, and the test on it.  hi = x >> 32 of the chain's anchors
 // (strand | contig); B / seq / qlen: for the base-level check of the stretch when its k-mers leave too many bases uncovered.

@@ -712,12 +712,16 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
             if (decided) {}
             else if (a.emit) {      // every chain goes to the extension stage, which decides the read
                 chain_dp_mask(S, (int)n_a, qlen, a.P);
-                auto em = [&](int64_t zi, int64_t end_i, int32_t sc, int64_t cnt, int32_t zf) {
+                auto emf = [&](int64_t zi, int64_t end_i, int32_t sc, int64_t cnt, int32_t zf) {
                     const uint32_t hi = small_group_hi(sv, a.positions, qlen, a.P.k, S.grp((int)zi));
                     sink_emit(a.sink, r, (int32_t)zi, (int32_t)end_i, sc, (uint32_t)cnt, (uint32_t)zf, (uint32_t)zi, a.P.k, region_hash(qlen),
                               [&](int32_t i, uint64_t &x, uint32_t &q) { x = (uint64_t)hi << 32 | S.rlo(i); q = S.qp(i); },
                               [&](int32_t i) { return S.Pm(i); });
                 };
+                struct Em { decltype(emf) &f; const ChainSink &sk; uint32_t r;
+                            __device__ void operator()(int64_t a1, int64_t a2, int32_t a3, int64_t a4, int32_t a5) const { f(a1, a2, a3, a4, a5); }
+                            __device__ bool done(int32_t zf) const { return sk.best && zf < sink_best_score(sk, r); } };
+                const Em em{emf, a.sink, r};
                 backtrack_mask(S, (int)n_a, a.P, n_u, best, false, em);
             } else if (a.trace == nullptr && a.P.flag_stop != INT32_MAX) n_u = chain_dp_mask(S, (int)n_a, qlen, a.P, a.P.flag_stop) ? 1 : 0;     // flag-only: see ChainParams::flag_stop
             else {
@@ -926,6 +930,9 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
     // one cluster [i, i + len): chained by this lane if small, else queued for a whole wave
     auto handle = [&](uint32_t i, uint32_t len) {
         if (len < 2 && !keep_single) return;
+        // flag-only hand-over: a cluster of len anchors cannot chain to more than k * len; below the best score already handed over it is moot
+        if (sk && sk->best && (int64_t)P.k * (int64_t)len < (int64_t)sink_best_score(*sk, read)) return;
+        if (bc && bc->n > 0 && (int64_t)P.k * (int64_t)len < (int64_t)bc->score) return;
         if (bc) {      // len <= 64 (the caller's n is)
             SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i};
             int32_t n_u, best;
@@ -1023,6 +1030,7 @@ struct K3Args {
     int32_t pass, max_occ, flag_only, dbg;
     ChainSink sink; int32_t emit;      // SH_F_CIGAR: chains are handed to the extension stage (flag_only is 0 then: no early exit)
     BaseCtx BC;
+    int32_t t_mode;                    // SH_F_CIGAR and no trace wanted: only regs[0] matters, shortcuts allowed
 };
 
 
@@ -1274,6 +1282,118 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
             anchors_wave += n_a; ++n_pair;
             continue;
         }
+        if (!LONG && a.t_mode && P.ext_lemma && n_st == 1 && a.pass == 0 && n_a > 64 && !(a.dbg & 256)) {
+            // SH_F_CIGAR, flag-only: the cluster(s) around the read's singleton seeds, alone (ChainParams::ext_*).
+            // A read with unique seeds has its true locus there; the other occurrences of its repeated seeds - hundreds of loci - need
+            // not be expanded, sorted and chained if they cannot matter:
+            //   1. K = every anchor of the read on the singletons' strand / contig within reach of them: the window [lo - mdx, hi + mdx]
+            //      around the anchors found so far is searched in each seed's (sorted) occurrence list until nothing new turns up, so K is
+            //      a union of COMPLETE clusters (no anchor within max_dist_x outside it) and mg_lchain_dp + the backtrack over K give
+            //      exactly the chains the full anchor set gives there (clusters are independent DP problems);
+            //   2. a chain made of anchors outside K only uses seeds that have occurrences outside K; its score is at most the query
+            //      bases those seeds' k-mers cover (U_out: a link adds min(k, dq) at most);
+            //   3. so if K's top chain scores more than U_out it is regs[0] of mm_gen_regs whatever the rest holds, it is aligned, and
+            //      chain_lemma decides whether it survives.  Anything else (no singleton, a filtered seed, K too large, no such margin,
+            //      a stretch the lemma cannot vouch for) takes the full path below.
+            const uint32_t occ0 = rec0.z & 0x7fffffffu;
+            const bool single = have0 && occ0 == 1u;
+            const uint64_t sm = __ballot(single);
+            bool s3_ok = sm != 0 && __ballot(have0 && (flt0 || my_n0 != occ0)) == 0;
+            uint64_t xs = 0; uint32_t qs_ = 0;
+            if (single) make_anchor((uint64_t)rec0.y << 32 | rec0.x, rec0.w, qlen, P.k, xs, qs_);
+            const int fl = sm ? __ffsll((unsigned long long)sm) - 1 : 0;
+            const uint32_t hiw = (uint32_t)__shfl((int)(uint32_t)(xs >> 32), fl);
+            s3_ok = s3_ok && __ballot(single && (uint32_t)(xs >> 32) != hiw) == 0;
+            uint32_t lo = single ? (uint32_t)xs : 0xffffffffu, hi = single ? (uint32_t)xs : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o)); }
+            const uint32_t mdx = chain_max_dist_x(P, qlen);
+            const uint32_t rel = hiw >> 31;                      // strand relation of K's anchors
+            const uint64_t w1m = (uint64_t)rec0.y << 32 | rec0.x;
+            const uint64_t *__restrict__ lst = a.positions + (w1m >> SH_SLOT_NBITS);
+            const bool multi = have0 && occ0 > 1u;
+            uint32_t c_l = single ? 1u : 0u, first_l = 0;
+            if (s3_ok) {
+                for (int round = 0; round < 4; ++round) {
+                    const uint32_t wlo = lo > mdx ? lo - mdx : 0u, whi = hi + mdx < hi ? 0xffffffffu : hi + mdx;
+                    uint32_t nlo = lo, nhi = hi;
+                    if (multi) {
+                        const uint64_t key_lo = (uint64_t)(hiw & 0x7fffffffu) << 32 | (uint64_t)wlo << 1;
+                        uint32_t b = 0, len = occ0;
+                        while (len > 0) { const uint32_t half = len >> 1; if (lst[b + half] < key_lo) { b += half + 1; len -= half + 1; } else len = half; }
+                        first_l = b; c_l = 0;
+                        for (uint32_t t = b; t < occ0 && c_l <= 16u; ++t) {
+                            const uint64_t pw = lst[t];
+                            if ((uint32_t)(pw >> 32) != (hiw & 0x7fffffffu) || ((uint32_t)pw >> 1) > whi) break;
+                            if ((((uint32_t)pw & 1u) != (rec0.w & 1u)) == (rel != 0)) { ++c_l; const uint32_t xp = (uint32_t)pw >> 1; nlo = min(nlo, xp); nhi = max(nhi, xp); }
+                        }
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) { nlo = min(nlo, (uint32_t)__shfl_xor((int)nlo, o)); nhi = max(nhi, (uint32_t)__shfl_xor((int)nhi, o)); }
+                    if (__ballot(c_l > 16u) != 0) { s3_ok = false; break; }
+                    if (nlo == lo && nhi == hi) break;
+                    if (round == 3) { s3_ok = false; break; }
+                    lo = nlo; hi = nhi;
+                }
+            }
+            const uint32_t n_k = s3_ok ? wave_sum_u32(c_l) : 0u;
+            if (s3_ok && n_k >= 2 && n_k <= 64) {
+                // K's anchors in generation order (seed order, then occurrence order): the order the full expansion gives them
+                const uint32_t ex = wave_excl_scan_u32(c_l, lane);
+                const uint32_t wlo = lo > mdx ? lo - mdx : 0u, whi = hi + mdx < hi ? 0xffffffffu : hi + mdx;
+                if (single) { e_x[ex] = xs; e_q[ex] = qs_; }
+                else if (multi && c_l) {
+                    uint32_t o = 0;
+                    for (uint32_t t = first_l; t < occ0 && o < c_l; ++t) {
+                        const uint64_t pw = lst[t];
+                        if ((((uint32_t)pw & 1u) != (rec0.w & 1u)) != (rel != 0)) continue;
+                        if (((uint32_t)pw >> 1) > whi || ((uint32_t)pw >> 1) < wlo) continue;
+                        uint64_t x; uint32_t q;
+                        make_anchor(pw, rec0.w, qlen, P.k, x, q);
+                        e_x[ex + o] = x; e_q[ex + o] = q; ++o;
+                    }
+                }
+                __syncthreads();
+                uint64_t x = lane < n_k ? e_x[lane] : ~0ull;
+                uint32_t q = lane < n_k ? e_q[lane] : 0u;
+                const uint64_t xp = (uint64_t)__shfl_up((long long)x, 1);
+                if (__ballot(lane > 0 && lane < n_k && x < xp) != 0) {
+                    wave_rank_sort(x, q, n_k, lane);
+                    __syncthreads();
+                    if (lane < n_k) { e_x[lane] = x; e_q[lane] = q; }
+                }
+                __syncthreads();
+                int32_t n_u = 0, best = 0;
+                BestChain bc{};
+                uint32_t ncl = 0;
+                chain_sorted<false>(e_x, e_q, e_f, e_pt, n_k, lane, 64, qlen, P, nullptr, BigList{e_bstart, e_blen, &e_bcount, 8}, n_u, best, ncl,
+                                    nullptr, nullptr, nullptr, r, nullptr, &bc, region_hash(qlen));
+                unsigned long long zmax = bc.n ? bc.z : 0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = (unsigned long long)__shfl_xor((long long)zmax, o); zmax = other > zmax ? other : zmax; }
+                const uint64_t holders = __ballot(bc.n > 0 && bc.z == zmax);
+                // U_out: query bases covered by the k-mers of the seeds that have occurrences outside K (lanes are in query order)
+                const bool outside = have0 && occ0 > c_l;
+                const uint64_t om = __ballot(outside);
+                const uint64_t below = om & ((1ULL << lane) - 1);
+                const int32_t prev_en = (int32_t)((uint32_t)__shfl((int)rec0.w, below ? 63 - __clzll((unsigned long long)below) : 0) >> 1) + 1;
+                const int32_t en = (int32_t)(rec0.w >> 1) + 1, st = en - P.k;
+                const int32_t cover = outside ? en - (below && prev_en > st ? prev_en : st) : 0;
+                const int32_t u_out = (int32_t)wave_sum_u32((uint32_t)cover);
+                bool mine = false;
+                if (__popcll(holders) == 1 && bc.n > 0 && bc.z == zmax && !bc.tie && bc.score > u_out) {
+                    SliceStore S{(const uint64_t *)&e_x[bc.base], (const uint32_t *)&e_q[bc.base], e_f + bc.base, e_pt + 2 * (size_t)bc.base};
+                    mine = chain_lemma(S, bc.zi, bc.end_i, P, (uint32_t)(S.X(bc.zi) >> 32), a.BC, a.BC.bases + a.offsets[r], qlen);
+                }
+                __syncthreads();
+                if (__ballot(mine) != 0) {
+                    if (lane == 0) { BigMeta m{r, n_a, rep_len, 0u}; a.B.meta[w] = m; a.B.acc_nu[w] = 1; a.B.acc_best[w] = P.min_sc; }
+                    anchors_wave += n_a; ++n_lemma;
+                    continue;
+                }
+            }
+            __syncthreads();
+        }
         const bool in_lds = n_a <= 64;     // short anchor lists never leave the CU
         // anchor slots: the wave advances the arena cursor by 16 Ki slots at a time
         if (!in_lds && a_cur + n_a > a_end) {
@@ -1347,7 +1467,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
             }
             int32_t n_u = 0, best = 0;
             bool lemma_done = false;
-            if (a.emit && a.trace == nullptr && P.ext_lemma) {
+            if (a.t_mode && P.ext_lemma) {
                 // flag-only: every lane chains its clusters and keeps its top chain; the read's top chain (largest z over the lanes) is
                 // regs[0] of mm_gen_regs - if chain_lemma vouches for it the read is mapped and nothing is handed over
                 BestChain bc{};
@@ -2423,7 +2543,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     k.seed_off = c->use_long ? c->d_seed_off : nullptr; k.sel_scratch = c->use_long ? (uint32_t *)c->d_mz_hash : nullptr;
     k.k1info = c->d_k1info; k.flags = d_flags; k.trace = d_trace; k.ctr = c->d_ctr; k.B = c->B; k.P = c->P;
     k.flag_only = d_trace == nullptr && !c->ext;      // SH_F_CIGAR: every chain is needed, no early exit
-    k.sink = b.sink; k.emit = c->ext ? 1 : 0; k.BC = b.BC;
+    k.sink = b.sink; k.emit = c->ext ? 1 : 0; k.BC = b.BC; k.t_mode = (c->ext && d_trace == nullptr) ? 1 : 0;
     k.dbg = getenv("SCRUBBY_HIP_DBG") ? atoi(getenv("SCRUBBY_HIP_DBG")) : 0;
     k.resketch_list = c->d_work_resketch;
     uint32_t resk_done = 0;
