@@ -911,8 +911,11 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
                                     const ChainParams &P, volatile int32_t *found, BigList bl,
                                     int32_t &n_u_thr, int32_t &best_thr, uint32_t &n_cl_thr, const GlobalQ *gq = nullptr,
                                     uint32_t *nxt = nullptr, const ChainSink *sk = nullptr, uint32_t read = 0, uint64_t *heap = nullptr,
-                                    BestChain *bc = nullptr, uint32_t rhash = 0)
-{   // bc: SH_F_CIGAR flag-only, n <= 64: every lane chains its clusters itself and remembers its top chain (BestChain), nothing is emitted
+                                    BestChain *bc = nullptr, uint32_t rhash = 0, int phase = -1)
+{   // phase (flag-only hand-over, where a cluster that cannot beat the best score found so far is skipped): the BIG clusters first -
+    //   CONTIG: 0 = only clusters of more than 64 anchors (queued for k_cluster_dp), 1 = only the others, afterwards; -1 = all at once
+    //   else:   the clusters a wave chains (> 6 anchors) before the ones a lane chains, inside this call
+    // bc: SH_F_CIGAR flag-only, n <= 64: every lane chains its clusters itself and remembers its top chain (BestChain), nothing is emitted
     // sk: hand-over mode - every chain of every cluster is emitted (found must be nullptr); heap: n words for the backtrack
     // heaps of clusters with more than 64 anchors (nullptr: the x slice itself, which the hand-over must not destroy)
     const uint32_t mdx = chain_max_dist_x(P, qlen);
@@ -978,7 +981,7 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
         // waits for its slowest lane), then - only if the read is still undecided in flag-only mode - the big ones go to
         // the queue.  Lengths are free now, so one sweep would queue every big cluster before the first chain is found.
         const uint32_t thr[5] = {0u, 8u, 24u, 64u, 0xffffffffu};
-        for (int sweep = 0; sweep < 4; ++sweep) {
+        for (int sweep = phase == 0 ? 3 : 0; sweep < (phase == 1 ? 3 : 4); ++sweep) {
             uint32_t i = fs < i_end ? fs : i_end;
             while (i < i_end) {
                 if (found && *found) break;            // flag-only: the read is decided
@@ -991,12 +994,13 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
             __syncthreads();
         }
     } else {
+        const bool big_first = sk && sk->best && !bc;      // flag-only hand-over: the clusters most likely to hold regs[0] first
         for (uint32_t i = i_beg; i < i_end; i += i_step) {
             if (found && *found) break;            // flag-only: the read is decided
             if (!(q[i] >> 31)) continue;
             uint32_t j = i + 1;
             while (j < n && !(q[j] >> 31)) ++j;
-            handle(i, j - i);
+            if (!big_first || j - i > 6u) handle(i, j - i);
         }
     }
     __syncthreads();
@@ -1014,6 +1018,15 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
         }
     }
     __syncthreads();
+    if (!CONTIG && sk && sk->best && !bc) {      // ... then the small ones, most of which the bound k * len now rules out
+        for (uint32_t i = i_beg; i < i_end; i += i_step) {
+            if (!(q[i] >> 31)) continue;
+            uint32_t j = i + 1;
+            while (j < n && !(q[j] >> 31)) ++j;
+            if (j - i <= 6u) handle(i, j - i);
+        }
+        __syncthreads();
+    }
 }
 
 struct K3Args {
@@ -1318,14 +1331,42 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
                     const uint32_t wlo = lo > mdx ? lo - mdx : 0u, whi = hi + mdx < hi ? 0xffffffffu : hi + mdx;
                     uint32_t nlo = lo, nhi = hi;
                     if (multi) {
+                        // lower bound of the window in this seed's ascending occurrence list: 8-ary steps (7 independent loads a round instead
+                        // of one), then the entries from there 8 at a time
                         const uint64_t key_lo = (uint64_t)(hiw & 0x7fffffffu) << 32 | (uint64_t)wlo << 1;
                         uint32_t b = 0, len = occ0;
-                        while (len > 0) { const uint32_t half = len >> 1; if (lst[b + half] < key_lo) { b += half + 1; len -= half + 1; } else len = half; }
+                        while (len > 8u) {
+                            const uint32_t step = (len + 7u) >> 3;
+                            uint64_t pv[7];
+#pragma unroll
+                            for (uint32_t j = 0; j < 7u; ++j) { const uint32_t ix = b + (j + 1u) * step - 1u; pv[j] = ix < b + len ? lst[ix] : ~0ull; }
+                            uint32_t cnt = 0;
+#pragma unroll
+                            for (uint32_t j = 0; j < 7u; ++j) cnt += pv[j] < key_lo;
+                            const uint32_t nb = b + cnt * step;
+                            len = min(step, b + len - nb); b = nb;
+                        }
+                        {
+                            uint64_t pv[8];
+#pragma unroll
+                            for (uint32_t j = 0; j < 8u; ++j) pv[j] = j < len ? lst[b + j] : ~0ull;
+                            uint32_t cnt = 0;
+#pragma unroll
+                            for (uint32_t j = 0; j < 8u; ++j) cnt += pv[j] < key_lo;
+                            b += cnt;
+                        }
                         first_l = b; c_l = 0;
-                        for (uint32_t t = b; t < occ0 && c_l <= 16u; ++t) {
-                            const uint64_t pw = lst[t];
-                            if ((uint32_t)(pw >> 32) != (hiw & 0x7fffffffu) || ((uint32_t)pw >> 1) > whi) break;
-                            if ((((uint32_t)pw & 1u) != (rec0.w & 1u)) == (rel != 0)) { ++c_l; const uint32_t xp = (uint32_t)pw >> 1; nlo = min(nlo, xp); nhi = max(nhi, xp); }
+                        bool more = true;
+                        for (uint32_t t0 = b; more && t0 < occ0 && c_l <= 16u; t0 += 8u) {
+                            uint64_t pv[8];
+#pragma unroll
+                            for (uint32_t j = 0; j < 8u; ++j) pv[j] = t0 + j < occ0 ? lst[t0 + j] : ~0ull;
+#pragma unroll
+                            for (uint32_t j = 0; j < 8u; ++j) {
+                                const uint64_t pw = pv[j];
+                                if (!more || (uint32_t)(pw >> 32) != (hiw & 0x7fffffffu) || ((uint32_t)pw >> 1) > whi) { more = false; continue; }
+                                if ((((uint32_t)pw & 1u) != (rec0.w & 1u)) == (rel != 0)) { ++c_l; const uint32_t xp = (uint32_t)pw >> 1; nlo = min(nlo, xp); nhi = max(nhi, xp); }
+                            }
                         }
                     }
 #pragma unroll
@@ -1566,7 +1607,7 @@ __device__ inline bool block_merge_sort(PX sx, PQ sq, PX dx, PQ dq, uint32_t n)
 }
 
 // block reduction of the per-thread chain results of one read; thread 0 stores them
-__device__ inline void store_read_result(const K3Args &a, uint32_t w, int32_t n_u, int32_t best, uint32_t n_cl, int32_t *red)
+__device__ inline void store_read_result(const K3Args &a, uint32_t w, int32_t n_u, int32_t best, uint32_t n_cl, int32_t *red, bool accumulate = false)
 {
     if (threadIdx.x == 0) { red[0] = 0; red[1] = 0; }
     __syncthreads();
@@ -1574,7 +1615,10 @@ __device__ inline void store_read_result(const K3Args &a, uint32_t w, int32_t n_
     n_cl = wave_sum_u32(n_cl);
     if ((threadIdx.x & 63) == 0 && n_cl) atomicAdd(&a.ctr->sh_clusters[SHARD()], n_cl);
     __syncthreads();
-    if (threadIdx.x == 0) { a.B.acc_nu[w] = red[0]; a.B.acc_best[w] = red[1]; }
+    if (threadIdx.x == 0) {
+        if (accumulate) { if (red[0]) { atomicAdd(&a.B.acc_nu[w], red[0]); atomicMax(&a.B.acc_best[w], red[1]); } }
+        else { a.B.acc_nu[w] = red[0]; a.B.acc_best[w] = red[1]; }
+    }
 }
 
 // Flag-only shortcut for reads with thousands of anchors, run BEFORE their full sort.  Anchors on different (strand,
@@ -1858,7 +1902,7 @@ __global__ __launch_bounds__(256) void k_giant_merge(K3Args a, uint32_t round)
 }
 
 // one block per giant read: clusters chained over arena slices of the buffer its sort ended in
-__global__ __launch_bounds__(1024) void k_giant_chain(K3Args a)
+__global__ __launch_bounds__(1024) void k_giant_chain(K3Args a, int phase)
 {
     __shared__ int32_t s_found, s_red[2], s_bcount;
     __shared__ uint32_t s_bstart[2048], s_blen[2048], s_nxt[1024];
@@ -1877,8 +1921,9 @@ __global__ __launch_bounds__(1024) void k_giant_chain(K3Args a)
         if (!(a.dbg & 2))
         chain_sorted<true>(sx, sq, a.B.af + si.off, (int32_t *)(a.B.az + si.off), n, tid, nthr, (int32_t)si.qlen, a.P,
                      a.flag_only ? &s_found : nullptr, BigList{s_bstart, s_blen, &s_bcount, 2048}, n_u, best, n_cl, &gq, s_nxt,
-                     a.emit ? &a.sink : nullptr, a.B.meta[si.w].r, a.emit ? (in_b ? a.B.ax : a.B.bx) + si.off : nullptr);      // heap: the sort's other buffer
-        store_read_result(a, si.w, n_u, best, n_cl, s_red);
+                     a.emit ? &a.sink : nullptr, a.B.meta[si.w].r, a.emit ? (in_b ? a.B.ax : a.B.bx) + si.off : nullptr,      // heap: the sort's other buffer
+                     nullptr, 0u, phase);
+        store_read_result(a, si.w, n_u, best, n_cl, s_red, phase == 1);
         __syncthreads();
     }
 }
@@ -2450,8 +2495,11 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
         hipLaunchKernelGGL(k_giant_partition, dim3(256), dim3(256), 0, g, k, round);
         hipLaunchKernelGGL(k_giant_merge, dim3(256 * 3), dim3(256), 0, g, k, round);
     }
-    hipLaunchKernelGGL(k_giant_chain, dim3(512), dim3(1024), 0, g, k);
+    // flag-only hand-over (t_mode): the big clusters first (k_cluster_dp), then the small ones against the best score those gave
+    const bool two_phase = k.t_mode && k.sink.best != nullptr;
+    hipLaunchKernelGGL(k_giant_chain, dim3(512), dim3(1024), 0, g, k, two_phase ? 0 : -1);
     if (!(k.dbg & 32)) hipLaunchKernelGGL(k_cluster_dp, dim3(256 * 4), dim3(256), 0, g, k);
+    if (two_phase) hipLaunchKernelGGL(k_giant_chain, dim3(512), dim3(1024), 0, g, k, 1);
     if (side) for (int i = 0; i < 3; ++i) { SH_HIP(hipEventRecord(c->evx[1 + i], c->sx[i])); SH_HIP(hipStreamWaitEvent(s, c->evx[1 + i], 0)); }
     hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, s, k);
     return SH_OK;
