@@ -58,7 +58,7 @@ def parse():
                          "k2 = configs[4] stand-in: Kraken2-style taxid classification of 2x150 bp pairs against an 8 GB table (not the headline metric)")
     ap.add_argument("--k2-cells", type=int, default=2_000_000_000, help="cells of the compact hash table (4 B each)")
     ap.add_argument("--k2-nodes", type=int, default=50_000, help="taxonomy nodes of the synthetic database")
-    ap.add_argument("--ont-chunk", type=int, default=1 << 25, help="long reads per launch (--workload ont)")
+    ap.add_argument("--ont-chunk", type=int, default=200_000, help="long reads per launch (--workload ont)")
     ap.add_argument("--e2e-threads", type=int, default=0, help="-t of `scrubby reads` for --workload e2e (0: min(16, cores))")
     ap.add_argument("--e2e-gz", action="store_true", help="--workload e2e: write .fastq.gz outputs")
     ap.add_argument("--e2e-legacy", action="store_true", help="--workload e2e: also time the collect-then-map host path")
@@ -129,7 +129,7 @@ def main_reads(a, rank, world, local, dev, backend):
     n_rec = 200_000 if a.small else a.records
     ont = a.workload == "ont"
     if ont:
-        n_rec = 20_000 if a.small else (a.records if a.records != 20_000_000 else 200_000)
+        n_rec = 20_000 if a.small else (a.records if a.records != 20_000_000 else 2_000_000)      # BASELINE configs[3]: 2 M reads
     P = S.ref_params(REF_SEED, contigs)
     # long reads: 2 % substitutions + 1.56 % insertions + 1.56 % deletions (n_read_pct = 1 switches the generator's indels on)
     R = S.read_params(0x5C2B0020, host_pct=50, sub_per_10k=200, n_read_pct=1) if ont else S.read_params(READ_SEED)
@@ -137,18 +137,30 @@ def main_reads(a, rank, world, local, dev, backend):
     opts = S.preset("map-ont" if ont else "sr")
 
     # ---- setup (untimed): reference -> index -> reads, all in HBM -------------------------------------
+    real_ref = os.environ.get("SCRUBBY_CHM13")
+    real_ref = real_ref if real_ref and os.path.exists(real_ref) and not a.small and not ont else None
+    ref_source = ("real FASTA from $SCRUBBY_CHM13: " + real_ref) if real_ref else "synthetic, CHM13v2-sized (sh_synth_core.h; no real CHM13 on a box without network)"
     t0 = time.time()
-    d_ref = torch.empty(G + 64, dtype=torch.uint8, device=dev)
-    S.synth_ref_device(P, 0, G, d_ref)
-    torch.cuda.synchronize()
-    t_ref = time.time() - t0
-    t0 = time.time()
-    index = S.Index.build_device(d_ref, [P.contig_start[i] for i in range(len(contigs) + 1)], opts, device=local)
+    if real_ref:
+        t_ref = 0.0
+        index = S.Index.build_fasta(real_ref, opts, device=local)
+    else:
+        d_ref = torch.empty(G + 64, dtype=torch.uint8, device=dev)
+        S.synth_ref_device(P, 0, G, d_ref)
+        torch.cuda.synchronize()
+        t_ref = time.time() - t0
+        t0 = time.time()
+        index = S.Index.build_device(d_ref, [P.contig_start[i] for i in range(len(contigs) + 1)], opts, device=local)
+        del d_ref
     torch.cuda.synchronize()
     t_idx = time.time() - t0
     info = index.info()
-    del d_ref
     torch.cuda.empty_cache()
+    if real_ref:
+        G = info["n_bases"]
+        packed_h, starts_h = index.export_ref()
+        d_packed = torch.from_numpy(packed_h).to(dev)
+        del packed_h
 
     L = R.read_len
     from scrubby_amd import dist as D
@@ -173,7 +185,10 @@ def main_reads(a, rank, world, local, dev, backend):
             b["n_bases"] = n * L
             b["d_reads"] = torch.empty(b["n_bases"] + 64, dtype=torch.uint8, device=dev)
             b["d_off"] = torch.empty(n + 1, dtype=torch.int64, device=dev)
-            S.synth_reads_device(P, R, r_lo, n, b["d_reads"], b["d_off"])
+            if real_ref:
+                reads_from_packed(d_packed, G, r_lo, n, L, R.host_pct, R.sub_per_10k, READ_SEED, b["d_reads"], b["d_off"])
+            else:
+                S.synth_reads_device(P, R, r_lo, n, b["d_reads"], b["d_off"])
             b["ctx"] = S.Context(index, max(min(a.chunk, n), 1), b["n_bases"], L)
         b["d_flags"] = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)[:n]
         torch.cuda.synchronize()
@@ -276,12 +291,16 @@ def main_reads(a, rank, world, local, dev, backend):
     traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
     if os.path.exists(traffic_file) and not a.small:
         try:
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts"))
+            from make_traffic import source_hash
             tj = json.load(open(traffic_file))
-            if tj.get("records_per_launch") == ctx_chunk(a, n_rec) and dom in tj.get("stages", {}):
+            if tj.get("source_sha1") != source_hash():
+                roofline["traffic_source"] = "profiles/traffic.json is stale (measured on other kernel sources): refused"
+            elif tj.get("records_per_launch") == ctx_chunk(a, n_rec) and dom in tj.get("stages", {}):
                 roofline["traffic"] = tj["stages"][dom]["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, raw)"
-        except Exception:
-            pass
+                roofline["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, raw; same kernel sources: sha1 " + tj["source_sha1"][:12] + ")"
+        except Exception as ex:
+            roofline["traffic_source"] = f"profiles/traffic.json unreadable: {ex}"
 
     gather = None
     if a.gather_bench and rank == 0:
@@ -292,6 +311,9 @@ def main_reads(a, rank, world, local, dev, backend):
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
         cpu = cpu_baseline(index, info, d_reads, n_rec, L, a.cpu_seconds, d_flags, d_off if ont else None, "map-ont" if ont else "sr")
+    ext_oracle = None
+    if rank == 0 and world == 1 and not a.no_cpu and not ont:
+        ext_oracle = external_oracle(index, d_reads, n_rec, L, d_flags, contigs, P, dev, real_ref)
 
     # ---- the host-buffer entry point (sh_classify_batch: what a Rust caller binds), PCIe included; never `value` -----------
     host_path = None
@@ -338,6 +360,9 @@ def main_reads(a, rank, world, local, dev, backend):
                       "n_positions": info["n_positions"], "hbm_GB": round(info["hbm_bytes"] / 1e9, 2),
                       "build_s": round(t_idx, 2), "ref_synth_s": round(t_ref, 2)},
             "roofline": roofline, "cpu_baseline": cpu, "host_buffer_path": host_path,
+            # the real tools, if this box has them (it has no network, so normally it does not); a real CHM13v2 FASTA
+            # given through $SCRUBBY_CHM13 replaces the synthetic reference of the same size
+            "external_oracle": ext_oracle, "reference_source": ref_source,
         }
         if gather:
             out["gather_ceiling"] = gather
@@ -691,6 +716,37 @@ def main_e2e_k2(a, rank, world, local, dev):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def reads_from_packed(d_packed, G, r_lo, n, L, host_pct, sub_per_10k, seed, d_out, d_off):
+    """$SCRUBBY_CHM13: records [r_lo, r_lo + n) drawn from a REAL reference resident in HBM as 4-bit codes - host_pct % of the pairs
+    are fragments of it (mate 1 forward at a hashed position, mate 2 the reverse complement 200 bases downstream, substitutions at
+    sub_per_10k per 10^4 bases), the rest random bases; torch ops in pieces of 2^20 records."""
+    dev = d_out.device
+    acgt = torch.tensor([65, 67, 71, 84, 78], dtype=torch.uint8, device=dev)
+
+    def mix(z):
+        z = (z + 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B) & 0x7FFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111E) & 0x7FFFFFFFFFFFFFFF
+        return z ^ (z >> 31)
+    for c0 in range(0, n, 1 << 20):
+        c1 = min(n, c0 + (1 << 20))
+        rec = torch.arange(r_lo + c0, r_lo + c1, dtype=torch.int64, device=dev)
+        pair, mate = rec >> 1, rec & 1
+        h = mix(pair * 0x5851F42D4C957F2D ^ seed)
+        host = (h % 100) < host_pct
+        pos = (mix(h ^ 0x1234567) % max(G - L - 400, 1)) + mate * 200
+        j = torch.arange(L, dtype=torch.int64, device=dev)[None, :]
+        g = pos[:, None] + torch.where(mate[:, None] == 1, (L - 1) - j, j)
+        code = ((d_packed[g >> 1].to(torch.int64) >> ((g & 1) * 4)) & 15).clamp(max=4)
+        code = torch.where((mate[:, None] == 1) & (code < 4), 3 - code, code)
+        hj = mix(rec[:, None] * 1000003 + j * 7919 + seed)
+        sub = (hj % 10000) < sub_per_10k
+        code = torch.where(sub & (code < 4), (code + 1 + (hj >> 20) % 3) % 4, code)
+        code = torch.where(host[:, None], code, (hj >> 8) % 4)
+        d_out[c0 * L:c1 * L] = acgt[code].reshape(-1)
+    d_off.copy_(torch.arange(n + 1, dtype=torch.int64, device=dev) * L)
+
+
 def ctx_chunk(a, n_rec):
     return min(a.chunk, n_rec)
 
@@ -706,46 +762,114 @@ def long_read_lengths(seed, r0, n):
             return z ^ (z >> M(31))
         r = np.arange(r0, r0 + n, dtype=np.uint64)
         h = mix(M(seed) ^ M(0x10E6A11) ^ (r * M(0x9E3779B97F4A7C15)))
-    knot = np.array([200, 1530, 2180, 2720, 3230, 3730, 4250, 4800, 5400, 6050, 6800, 7700, 8850, 10400, 12900, 18000, 28000], dtype=np.uint64)
-    q = (h & M(15)).astype(np.int64)
-    lo, hi = knot[q], knot[q + 1]
+    k1 = np.array([200, 1674, 2190, 2633, 3056, 3480, 3920, 4389, 4900, 5470, 6124, 6899, 7857, 9118, 10963, 14341, 14341], dtype=np.uint64)
+    k2 = np.array([14341, 14672, 15029, 15415, 15838, 16302, 16817, 17395, 18050, 18806, 19697, 20774, 22131, 23941, 26617, 31541, 31541], dtype=np.uint64)
+    k3 = np.array([31541, 32023, 32543, 33106, 33721, 34397, 35146, 35985, 36936, 38032, 39321, 40878, 42834, 45437, 49268, 56273, 100000], dtype=np.uint64)
+    q1, q2, q3 = (h & M(15)).astype(np.int64), ((h >> M(4)) & M(15)).astype(np.int64), ((h >> M(32)) & M(15)).astype(np.int64)
+    lo = np.where(q1 < 15, k1[q1], np.where(q2 < 15, k2[q2], k3[q3]))
+    hi = np.where(q1 < 15, k1[np.minimum(q1 + 1, 16)], np.where(q2 < 15, k2[np.minimum(q2 + 1, 16)], k3[q3 + 1]))
     return (lo + ((((h >> M(8)) & M(0xffffff)) * (hi - lo)) >> M(24))).astype(np.uint32)
 
 
+def physical_cores():
+    """Physical cores of this host (unique (package, core id) pairs); the logical count if /proc/cpuinfo does not say."""
+    try:
+        seen, pkg = set(), "0"
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                pkg = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                seen.add((pkg, ln.split(":")[1].strip()))
+        if seen:
+            return min(len(seen), len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
 def cpu_baseline(index, info, d_reads, n_rec, L, seconds, d_flags, d_off=None, preset="sr"):
-    """Oracle (port of the decision path) on all host cores over a bounded sample; also a parity spot check."""
+    """The oracle (restated decision path incl. the extension stage; NOT minimap2-rs) on the host cores: ONE call over a large
+    contiguous sample (threads pull 64-read chunks off an atomic counter, so every core works to the end), sized from a short
+    calibration call to take about `seconds`.  Also a parity check: flags differing from the GPU's on the sample."""
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    cores, logical = physical_cores(), os.cpu_count() or 1
     try:
         avail_gb = int(open("/proc/meminfo").read().split("MemAvailable:")[1].split()[0]) / 1e6
     except Exception:
         avail_gb = 0.0
-    need_gb = (info["n_slots"] * 16 + info["n_positions"] * 8) / 1e9 * 1.1 + 2
+    need_gb = (info["n_slots"] * 16 + info["n_positions"] * 8 + info["n_bases"] / 2) / 1e9 * 1.1 + 2
     if avail_gb and avail_gb < need_gb:
         return {"value": None, "unit": "reads/s", "cores": cores, "kind": "port",
                 "sample": f"skipped: host has {avail_gb:.0f} GB free, index copy needs {need_gb:.0f} GB"}
     slots, pos = index.export()
     oidx = O.Index.wrap(slots, pos, info["w"], info["k"], ref=index.export_ref())      # the reference too: the extension stage aligns against it
     oo = oidx.update_opts(O.preset(preset))
-    batch = 50_000 if d_off is None else 2_000
     off_all = d_off.cpu().numpy().astype(np.uint64) if d_off is not None else None
-    done, t_used, mism = 0, 0.0, 0
-    while t_used < seconds and done + batch <= n_rec:
+
+    def run(first, count, threads):
         if off_all is None:
-            reads = d_reads[done * L:(done + batch) * L].cpu().numpy()
-            off = np.arange(batch + 1, dtype=np.uint64) * L
+            reads = d_reads[first * L:(first + count) * L].cpu().numpy()
+            off = np.arange(count + 1, dtype=np.uint64) * L
         else:
-            b0, b1 = int(off_all[done]), int(off_all[done + batch])
+            b0, b1 = int(off_all[first]), int(off_all[first + count])
             reads = d_reads[b0:b1].cpu().numpy()
-            off = off_all[done:done + batch + 1] - np.uint64(b0)
+            off = off_all[first:first + count + 1] - np.uint64(b0)
         t0 = time.perf_counter()
-        fl, _ = oidx.classify(oo, reads, off, threads=cores, want_trace=False)
-        t_used += time.perf_counter() - t0
-        mism += int((fl != d_flags[done:done + batch].cpu().numpy()).sum())
-        done += batch
-    return {"value": round(done / t_used, 1), "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": f"first {done} records of the same batch, same index (copied from HBM), {cores} threads, {t_used:.1f} s; "
+        fl, _ = oidx.classify(oo, reads, off, threads=threads, want_trace=False)
+        dt = time.perf_counter() - t0
+        return dt, int((fl != d_flags[first:first + count].cpu().numpy()).sum())
+
+    n_cal = min(n_rec, 200_000 if off_all is None else 4_000)
+    dt_cal, _ = run(0, n_cal, cores)                                    # calibration (also warms the index pages)
+    n_s = int(min(n_rec, max(n_cal, n_cal / max(dt_cal, 1e-6) * seconds)))
+    dt, mism = run(0, n_s, cores)
+    return {"value": round(n_s / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
+            "reads_per_s_per_thread": round(n_s / dt / cores, 1), "logical_cpus": logical,
+            "sample": f"first {n_s} records of the same batch in ONE call, same index and reference (copied from HBM), {cores} threads (one per physical core), {dt:.1f} s; "
                       f"restatement baseline - not minimap2-rs; flags differing from the GPU on the sample: {mism}"}
+
+
+def external_oracle(index, d_reads, n_rec, L, d_flags, contigs, P, dev, real_ref=None, max_reads=400_000):
+    """if a `minimap2` binary exists on this box, map a bounded sample single-end (`-c -x sr`, as the reference maps
+    each mate on its own with CIGAR on: cleaner.rs:473,499-501,527-529,552) and diff the mapped-read set with the GPU flags - the only
+    route by which parity can become pinned.  Absent: says so."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("minimap2")
+    if exe is None:
+        return {"minimap2": "absent", "kraken2": "present" if shutil.which("kraken2") else "absent"}
+    n = min(n_rec, max_reads)
+    work = tempfile.mkdtemp(prefix="scrubby_mm2_")
+    try:
+        fa = real_ref
+        if fa is None:
+            G = P.genome_len
+            d_ref = torch.empty(G + 64, dtype=torch.uint8, device=dev)
+            S.synth_ref_device(P, 0, G, d_ref)
+            h_ref = d_ref[:G].cpu().numpy()
+            del d_ref
+            fa = os.path.join(work, "ref.fa")
+            with open(fa, "wb") as f:
+                for i in range(len(contigs)):
+                    f.write(b">ctg%d\n" % i)
+                    h_ref[P.contig_start[i]:P.contig_start[i + 1]].tofile(f)
+                    f.write(b"\n")
+        reads = d_reads[:n * L].cpu().numpy().reshape(n, L)
+        fq = os.path.join(work, "reads.fq")
+        fastq_file(fq, reads, 1, 0)
+        t0 = time.perf_counter()
+        out = subprocess.run([exe, "-c", "-x", "sr", "-t", str(physical_cores()), fa, fq], capture_output=True, check=True).stdout
+        dt = time.perf_counter() - t0
+        mapped = np.zeros(n, dtype=np.uint8)
+        for ln in out.splitlines():
+            mapped[int(ln.split(b"\t", 1)[0][4:])] = 1
+        gpu = (d_flags[:n].cpu().numpy() == 1).astype(np.uint8)
+        return {"minimap2": "present", "version": subprocess.run([exe, "--version"], capture_output=True).stdout.decode().strip(),
+                "sample_reads": n, "mapped_by_minimap2": int(mapped.sum()), "mapped_by_gpu": int(gpu.sum()), "differ": int((mapped != gpu).sum()),
+                "reads_per_s_incl_index": round(n / dt, 1), "threads": physical_cores()}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -134,24 +134,29 @@ void mma_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
     if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
     long_diff = long_thres * (e - e2) - (q2 - q) - e2;
 
-    /* one zero-filled block laid out as upstream: u v x y x2 y2 s | sf (target) | qr (reversed query) | 16 spare bytes */
+    /* one zero-filled block laid out as upstream: u v x y x2 y2 s | sf (target) | qr (reversed query) | 16 spare bytes.
+     * The buffers are per-thread and grow-only: a CPU baseline that spent its time in calloc would flatter the GPU. */
     cap = ((size_t)tlen_ * 8 + qlen_ + 1) * 16;
-    mem = (uint8_t *)calloc(cap + 64, 1);
+    {
+        static __thread uint8_t *t_mem, *t_p; static __thread int8_t *t_ox; static __thread int32_t *t_H; static __thread int *t_off;
+        static __thread size_t c_mem, c_p, c_ox, c_H, c_off;
+        const size_t n_p = ((size_t)(qlen + tlen - 1) * n_col_ + 1) * 16, n_off = (size_t)(qlen + tlen - 1) * 2;
+        if (cap + 64 > c_mem) { c_mem = (cap + 64) * 2; t_mem = (uint8_t *)realloc(t_mem, c_mem); }
+        if ((size_t)tlen_ * 16 * 3 > c_ox) { c_ox = (size_t)tlen_ * 16 * 6; t_ox = (int8_t *)realloc(t_ox, c_ox); }
+        if ((size_t)tlen_ * 16 > c_H) { c_H = (size_t)tlen_ * 32; t_H = (int32_t *)realloc(t_H, c_H * 4); }
+        if (with_cigar && n_p > c_p) { c_p = n_p * 2; t_p = (uint8_t *)realloc(t_p, c_p); }
+        if (with_cigar && n_off > c_off) { c_off = n_off * 2; t_off = (int *)realloc(t_off, c_off * sizeof(int)); }
+        mem = t_mem; memset(mem, 0, cap + 64);
+        ox = t_ox; H = approx_max ? 0 : t_H; p = with_cigar ? t_p : 0; off = with_cigar ? t_off : 0;
+    }
     u = (int8_t *)mem; v = u + tlen_ * 16; x = v + tlen_ * 16; y = x + tlen_ * 16; x2 = y + tlen_ * 16; y2 = x2 + tlen_ * 16;
     s = y2 + tlen_ * 16; sf = (uint8_t *)(s + tlen_ * 16); qr = sf + tlen_ * 16;
     memset(u, -q - e, (size_t)tlen_ * 16); memset(v, -q - e, (size_t)tlen_ * 16);
     memset(x, -q - e, (size_t)tlen_ * 16); memset(y, -q - e, (size_t)tlen_ * 16);
     memset(x2, -q2 - e2, (size_t)tlen_ * 16); memset(y2, -q2 - e2, (size_t)tlen_ * 16);
-    ox = (int8_t *)malloc((size_t)tlen_ * 16 * 3); ov = ox + tlen_ * 16; ox2 = ov + tlen_ * 16;
-    if (!approx_max) {
-        H = (int32_t *)malloc((size_t)tlen_ * 16 * 4);
-        for (t = 0; t < tlen_ * 16; ++t) H[t] = KSW_NEG_INF;
-    }
-    if (with_cigar) {
-        p = (uint8_t *)calloc(((size_t)(qlen + tlen - 1) * n_col_ + 1) * 16, 1);
-        off = (int *)malloc((size_t)(qlen + tlen - 1) * sizeof(int) * 2);
-        off_end = off + qlen + tlen - 1;
-    }
+    ov = ox + tlen_ * 16; ox2 = ov + tlen_ * 16;
+    if (!approx_max) for (t = 0; t < tlen_ * 16; ++t) H[t] = KSW_NEG_INF;
+    if (with_cigar) off_end = off + qlen + tlen - 1;      /* every direction byte the backtrack reads was written by this call */
     for (t = 0; t < qlen; ++t) qr[t] = query[qlen - 1 - t];
     memcpy(sf, target, (size_t)tlen);
     sc_mch = mat[0]; sc_mis = mat[1]; sc_N = mat[m * m - 1] == 0 ? (int8_t)-e2 : mat[m * m - 1];
@@ -274,7 +279,6 @@ void mma_ksw_extd2(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
         } else if (ez->max_t >= 0 && ez->max_q >= 0)
             backtrack(rev_cigar, p, off, off_end, n_col, ez->max_t, ez->max_q, &ez->m_cigar, &ez->n_cigar, &ez->cigar);
     }
-    free(mem); free(ox); free(H); free(p); free(off);
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -757,20 +757,18 @@ void mmo_map(const mmo_index *idx, const mmo_opts *o, const uint8_t *seq, int64_
 
 typedef struct {
     const mmo_index *idx; const mmo_opts *o; const uint8_t *bases; const uint64_t *offsets;
-    uint64_t n_reads; uint8_t *flags; mmo_trace *traces; uint64_t *next; pthread_mutex_t *mu;
+    uint64_t n_reads; uint8_t *flags; mmo_trace *traces; uint64_t *next;
 } job_t;
 
 static void *worker(void *arg)
 {
     job_t *jb = (job_t *)arg;
     scratch_t s;
-    const uint64_t CH = 256;
+    const uint64_t CH = 64;       /* small chunks off one atomic counter: every thread stays busy to the end of the batch */
     memset(&s, 0, sizeof(s));
     for (;;) {
         uint64_t b, e, r;
-        pthread_mutex_lock(jb->mu);
-        b = *jb->next; *jb->next = b + CH;
-        pthread_mutex_unlock(jb->mu);
+        b = __atomic_fetch_add(jb->next, CH, __ATOMIC_RELAXED);
         if (b >= jb->n_reads) break;
         e = b + CH < jb->n_reads ? b + CH : jb->n_reads;
         for (r = b; r < e; ++r) {
@@ -788,14 +786,13 @@ void mmo_classify_batch(const mmo_index *idx, const mmo_opts *o, const uint8_t *
                         const uint64_t *offsets, uint64_t n_reads, uint8_t *flags,
                         mmo_trace *traces, int n_threads)
 {
-    pthread_t th[256];
-    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    pthread_t th[1024];
     uint64_t next = 0;
-    job_t jb = { idx, o, bases, offsets, n_reads, flags, traces, &next, &mu };
+    job_t jb = { idx, o, bases, offsets, n_reads, flags, traces, &next };
     int i;
     pthread_once(&nt4_once, nt4_fill);
     if (n_threads < 1) n_threads = 1;
-    if (n_threads > 256) n_threads = 256;
+    if (n_threads > 1024) n_threads = 1024;
     if (n_threads == 1) { worker(&jb); return; }
     for (i = 0; i < n_threads; ++i) pthread_create(&th[i], 0, worker, &jb);
     for (i = 0; i < n_threads; ++i) pthread_join(th[i], 0);

@@ -8,12 +8,25 @@ micro-benchmark (a known number of random 16-B slot loads over the index table) 
 per probe (profiles/r01_pmc_gather_calib.txt): one 64-B sector per 16-B gather, counted exactly.  The guide's x2 correction
 applies only to the coalesced 16-B/lane streams (K1's 3 GB of bases: FETCH_SIZE shows half of them), so the figures are exact
 for the gathers and a lower bound by at most that amount overall."""
-import csv, glob, json, sys, collections
+import csv, glob, hashlib, json, os, sys, collections
+
+KERNEL_SOURCES = ("sh_classify.hip", "sh_sketch.h", "sh_chain.h", "sh_align.h")
+
+
+def source_hash():
+    """sha1 over the kernel sources the counters belong to: bench.py refuses a traffic.json measured on other code."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scrubby_amd", "csrc")
+    h = hashlib.sha1()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()
+
 
 STAGES = {
     "k_sketch_probe": ("k_sketch_probe",),
     "k_chain_small": ("k_chain_small",),
     "repeat path (k_expand + k_sort_lds* + k_sort + k_finalize)": ("k_expand", "k_sort_lds", "k_giant", "k_cluster_dp", "k_finalize", "k_chain_large"),
+    "extension stage (k_ext_* + k_regs_align)": ("k_ext_", "k_regs_align"),
 }
 
 
@@ -35,7 +48,7 @@ def collect(d, counter):
 fd, wd, n_rec, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 fe, fk = collect(fd, "FETCH_SIZE")
 we, wk = collect(wd, "WRITE_SIZE")
-doc = {"comment": __doc__.split("\n\n")[1].replace("\n", " "), "records_per_launch": n_rec, "stages": {}, "kernels": {}}
+doc = {"comment": __doc__.split("\n\n")[1].replace("\n", " "), "records_per_launch": n_rec, "source_sha1": source_hash(), "stages": {}, "kernels": {}}
 for st in STAGES:
     doc["stages"][st] = {"fetch": fe[st], "write": we[st], "hbm_bytes_per_launch": fe[st] + we[st]}
 for k in sorted(set(fk) | set(wk)):

@@ -160,15 +160,20 @@ SYN_FN uint8_t syn_read_base(const syn_ref_params *P, const syn_read_params *R, 
 }
 
 /* ---- long reads (BASELINE config 4 stand-in): log-normal-like lengths, substitutions and (optionally) indels -----------
- * Length of read r: integer-only (bit-reproducible on both sides, no libm): the 16 quantile knots of a
- * log-normal(mu = 8.497, sigma = 0.7) clipped to [200, 28000], uniform inside a quantile bin.
- * Measured on 200 k reads: mean ~7.0 kb, median ~5.4 kb, N50 ~9 kb. */
+ * Length of read r: integer-only (bit-reproducible on both sides, no libm): quantile knots of a log-normal(mu = 8.497, sigma = 0.7)
+ * clipped to [200, 100 000] (mean ~6.26 kb, median ~4.9 kb, N50 ~8.0 kb), uniform inside a quantile bin; the top
+ * sixteenth is cut into sixteenths again, and so is its top, so the tail out to 100 kb keeps its weight (1 read in 4096 beyond 56 kb). */
 SYN_FN uint32_t syn_long_len(uint64_t seed, uint64_t r)
 {
     const uint64_t h = syn_mix(seed ^ 0x10E6A11ULL ^ (r * 0x9E3779B97F4A7C15ULL));
-    const uint32_t knot[17] = {200, 1530, 2180, 2720, 3230, 3730, 4250, 4800, 4900 + 500, 6050, 6800, 7700, 8850, 10400, 12900, 18000, 100000};
-    const uint32_t q = (uint32_t)(h & 15);
-    const uint32_t lo = knot[q], hi = q == 15 ? 28000u : knot[q + 1];       /* the last bin's tail is truncated */
+    const uint32_t k1[17] = {200, 1674, 2190, 2633, 3056, 3480, 3920, 4389, 4900, 5470, 6124, 6899, 7857, 9118, 10963, 14341, 14341};
+    const uint32_t k2[17] = {14341, 14672, 15029, 15415, 15838, 16302, 16817, 17395, 18050, 18806, 19697, 20774, 22131, 23941, 26617, 31541, 31541};
+    const uint32_t k3[17] = {31541, 32023, 32543, 33106, 33721, 34397, 35146, 35985, 36936, 38032, 39321, 40878, 42834, 45437, 49268, 56273, 100000};
+    const uint32_t q1 = (uint32_t)(h & 15), q2 = (uint32_t)(h >> 4) & 15, q3 = (uint32_t)(h >> 32) & 15;
+    uint32_t lo, hi;
+    if (q1 < 15) { lo = k1[q1]; hi = k1[q1 + 1]; }
+    else if (q2 < 15) { lo = k2[q2]; hi = k2[q2 + 1]; }
+    else { lo = k3[q3]; hi = k3[q3 + 1]; }
     return lo + (uint32_t)(((h >> 8) & 0xffffff) * (uint64_t)(hi - lo) >> 24);
 }
 
