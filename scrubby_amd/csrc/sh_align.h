@@ -604,9 +604,12 @@ __device__ inline void update_extra0(RegLite &r, uint32_t *c, int32_t &n_cigar, 
 // the one whose z equals best[read] is regs[0] of mm_gen_regs - primary, hence always aligned.  1: its max stretch alone guarantees
 // that it survives mm_filter_regs (same test as sh_chain.h chain_lemma, over the handed-over anchors): the read is mapped.  0: not
 // settled here (a tie in z, a stretch the test cannot vouch for): the read goes through the full procedure with all its chains.
-__device__ inline int32_t top_chain_settles(const AlignIn &in, const AlignParams &P, uint32_t read, unsigned long long best, uint32_t tie)
+struct MidReq;
+template <class MID>
+__device__ inline int32_t top_chain_settles(const AlignIn &in, const AlignParams &P, uint32_t read, unsigned long long best, uint32_t tie, MID &mid)
 {
-    // returns 1 settled, or minus the reason it is not: -1 tie / off, -2 record missing, -3 stretch too short, -4 z-drop in the stretch
+    // returns 1 settled, 2 settled if the stretch described in `mid` shows no z-drop on the bases (the caller's wave checks:
+    // middle_no_zdrop_wave), or minus the reason it is not: -1 tie / off, -2 record missing, -3 stretch too short, -4 z-drop in the stretch
     if (tie || !P.lemma) return -1;
     uint32_t h = in.head[read];
     while (h != ~0u && in.recs[h].z != best) h = in.recs[h].next;
@@ -628,25 +631,9 @@ __device__ inline int32_t top_chain_settles(const AlignIn &in, const AlignParams
     const int32_t qf = (int32_t)in.cq[rc.off + b_first], ql = (int32_t)in.cq[rc.off + b_last];
     if (!(best_score >= P.min_sc && ql - qf >= P.k)) return -3;
     if (best_unc <= P.unc_max) return 1;
-    // mm_test_zdrop over the ungapped stretch, on the bases
     const uint64_t x0 = in.cx[rc.off + b_first];
-    const int32_t rid = (int32_t)(x0 << 1 >> 33), rev = (int32_t)(x0 >> 63), qs = qf + 1 - P.k, qe = ql + 1, rs = (int32_t)x0 + 1 - P.k;
-    const int32_t qlen = (int32_t)(in.offsets[read + 1] - in.offsets[read]);
-    const uint8_t *seq = in.bases + in.offsets[read];
-    const uint64_t g0 = in.cstart[rid] + (uint64_t)rs;
-    const int32_t sa = P.a < 0 ? -P.a : P.a, sb = P.b > 0 ? -P.b : P.b, sn = P.sc_ambi > 0 ? -P.sc_ambi : P.sc_ambi;
-    int32_t score = 0, mx = INT32_MIN, zd = 0;
-    for (int32_t j = 0; j < qe - qs; ++j) {
-        const int32_t qi = qs + j;
-        uint32_t cq = sh_nt4(seq[rev ? qlen - 1 - qi : qi]);
-        if (rev && cq < 4) cq = 3 - cq;
-        const uint64_t g = g0 + (uint64_t)j;
-        const uint32_t ct = (in.ref[g >> 1] >> ((g & 1) * 4)) & 15u;
-        score += (cq > 3 || ct > 3) ? sn : (cq == ct ? sa : sb);
-        if (score < mx) { const int32_t z = mx - score; zd = z > zd ? z : zd; }
-        else mx = score;
-    }
-    return zd <= P.zdrop ? 1 : -4;
+    mid.rid = (int32_t)(x0 << 1 >> 33); mid.rev = (int32_t)(x0 >> 63); mid.qs = qf + 1 - P.k; mid.qe = ql + 1; mid.rs = (int32_t)x0 + 1 - P.k;
+    return 2;
 }
 
 // The whole stage for one read, one wave.  flag_only: stop at the first surviving region (the boundary only returns

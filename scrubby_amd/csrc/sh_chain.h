@@ -60,23 +60,65 @@ struct ChainParams {
 // what the middle check reads: the reference (4-bit codes) and the reads (ASCII)
 struct BaseCtx { const uint8_t *ref; const uint64_t *cstart; const uint8_t *bases; };
 
-// mm_test_zdrop over the ungapped alignment of query [qs, qe) (on strand rev of the read at `seq`) with reference [rs, rs + qe - qs) of
-// contig rid: true = no z-drop, i.e. mm_align1 keeps the single M (sh_align.h / oracle mm_align.c test_zdrop).  One thread.
-__device__ inline bool middle_no_zdrop(const BaseCtx &B, const uint8_t *seq, int32_t qlen, int32_t rid, int32_t rev, int32_t qs, int32_t qe, int32_t rs, const ChainParams &P)
+// The stretch whose ungapped alignment has to be checked on the bases, and the check: mm_test_zdrop over query [qs, qe) (on strand
+// rev of the read at `seq`) against reference [rs, rs + qe - qs) of contig rid.  true = no z-drop, i.e. mm_align1 keeps the single M
+// (sh_align.h / oracle mm_align.c test_zdrop).  The WAVE does it, 64 bases at a time (coalesced byte loads, prefix sums on the lanes):
+// max drop = max_j (max_{i <= j} S_i - S_j) over the running score S.  A per-lane loop over 150 dependent byte loads cost ~90 us a read.
+struct MidReq { int32_t rid, rev, qs, qe, rs; };
+
+__device__ inline bool middle_no_zdrop_wave(const BaseCtx &B, const uint8_t *seq, int32_t qlen, const MidReq &m, const ChainParams &P)
 {
-    const uint64_t g0 = B.cstart[rid] + (uint64_t)rs;
-    int32_t score = 0, mx = INT32_MIN, zd = 0;
-    for (int32_t j = 0; j < qe - qs; ++j) {
-        const int32_t qi = qs + j;
-        uint32_t cq = sh_nt4(seq[rev ? qlen - 1 - qi : qi]);
-        if (rev && cq < 4) cq = 3 - cq;
-        const uint64_t g = g0 + (uint64_t)j;
-        const uint32_t ct = (B.ref[g >> 1] >> ((g & 1) * 4)) & 15u;
-        score += (cq > 3 || ct > 3) ? P.ext_amb : (cq == ct ? P.ext_a : P.ext_b);
-        if (score < mx) { const int32_t z = mx - score; zd = z > zd ? z : zd; }
-        else mx = score;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t g0 = B.cstart[m.rid] + (uint64_t)m.rs;
+    int32_t carry_s = 0, carry_mx = INT32_MIN, zd = 0;
+    for (int32_t j0 = 0; j0 < m.qe - m.qs; j0 += 64) {
+        const int32_t j = j0 + (int32_t)lane;
+        int32_t sc = 0;
+        const bool on = j < m.qe - m.qs;
+        if (on) {
+            const int32_t qi = m.qs + j;
+            uint32_t cq = sh_nt4(seq[m.rev ? qlen - 1 - qi : qi]);
+            if (m.rev && cq < 4) cq = 3 - cq;
+            const uint64_t g = g0 + (uint64_t)j;
+            const uint32_t ct = (B.ref[g >> 1] >> ((g & 1) * 4)) & 15u;
+            sc = (cq > 3 || ct > 3) ? P.ext_amb : (cq == ct ? P.ext_a : P.ext_b);
+        }
+        int32_t ps = sc;                                  // inclusive prefix sum over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int32_t t = __shfl_up(ps, o); if ((int)lane >= o) ps += t; }
+        ps += carry_s;
+        int32_t pm = on ? ps : INT32_MIN;                 // inclusive prefix maximum, seeded with the chunks before
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int32_t t = __shfl_up(pm, o); if ((int)lane >= o) pm = t > pm ? t : pm; }
+        pm = pm > carry_mx ? pm : carry_mx;
+        int32_t d = on ? pm - ps : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int32_t t = __shfl_xor(d, o); d = t > d ? t : d; }
+        zd = d > zd ? d : zd;
+        const int32_t last = (m.qe - m.qs - j0) < 64 ? (m.qe - m.qs - j0) - 1 : 63;
+        carry_s = __shfl(ps, last); carry_mx = __shfl(pm, last);
     }
     return zd <= P.ext_zdrop;
+}
+
+// Settles the stretches a wave's lanes could not vouch for from their k-mers alone: lane by lane, the whole wave on one request.
+// need / req / seq / qlen are per lane; every lane of the wave must call.
+__device__ inline bool resolve_mid_wave(bool need, const MidReq &req, const uint8_t *seq, int32_t qlen, const BaseCtx &B, const ChainParams &P)
+{
+    bool res = false;
+    uint64_t todo = __ballot(need);
+    const uint32_t lane = threadIdx.x & 63;
+    while (todo) {
+        const int l = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        MidReq m;
+        m.rid = __shfl(req.rid, l); m.rev = __shfl(req.rev, l); m.qs = __shfl(req.qs, l); m.qe = __shfl(req.qe, l); m.rs = __shfl(req.rs, l);
+        const uint64_t sp = (uint64_t)(uintptr_t)seq;
+        const uint64_t p = (uint64_t)(uint32_t)__shfl((int)(uint32_t)sp, l) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(sp >> 32), l) << 32;
+        const bool ok = middle_no_zdrop_wave(B, (const uint8_t *)(uintptr_t)p, __shfl(qlen, l), m, P);
+        if ((int)lane == l) res = ok;
+    }
+    return res;
 }
 
 // ---- seeds: one 16-B record per query minimizer found in the index ---------------------------
@@ -595,11 +637,11 @@ struct BestEmit {
     __device__ inline bool done(int32_t zf) const { return b->n > 0 && zf < b->score; }
 };
 // mm_max_stretch over the chain zi -> end_i (exclusive), walked backwards, and the test on it.  hi = x >> 32 of the chain's anchors
-// (strand | contig); B / seq / qlen: for the base-level check of the stretch when its k-mers leave too many bases uncovered.
+// (strand | contig).
 template <class Store>
-__device__ inline bool chain_lemma(Store &S, int32_t zi, int32_t end_i, const ChainParams &P, uint32_t hi, const BaseCtx &B, const uint8_t *seq, int32_t qlen)
-{
-    if (!P.ext_lemma) return false;
+__device__ inline int32_t chain_lemma(Store &S, int32_t zi, int32_t end_i, const ChainParams &P, uint32_t hi, MidReq &mid)
+{   // 1: the region passes mm_filter_regs; 2: it does if its stretch shows no z-drop on the bases (mid says where: middle_no_zdrop_wave); 0: unknown
+    if (!P.ext_lemma) return 0;
     int32_t run_score = P.k, run_unc = 0, run_last = zi, run_first = zi;
     int32_t best_score = -1, best_unc = 0, b_first = zi, b_last = zi;
     for (int32_t i = zi;;) {
@@ -615,9 +657,10 @@ __device__ inline bool chain_lemma(Store &S, int32_t zi, int32_t end_i, const Ch
     }
     if (run_score >= best_score) { best_score = run_score; best_unc = run_unc; b_first = run_first; b_last = run_last; }
     const int32_t qf = (int32_t)S.qp(b_first), ql = (int32_t)S.qp(b_last);
-    if (!(best_score >= P.min_sc && ql - qf >= P.k)) return false;
-    if (best_unc <= P.ext_unc_max) return true;
-    return middle_no_zdrop(B, seq, qlen, (int32_t)(hi & 0x7fffffffu), (int32_t)(hi >> 31), qf + 1 - P.k, ql + 1, (int32_t)S.rlo(b_first) + 1 - P.k, P);
+    if (!(best_score >= P.min_sc && ql - qf >= P.k)) return 0;
+    if (best_unc <= P.ext_unc_max) return 1;
+    mid.rid = (int32_t)(hi & 0x7fffffffu); mid.rev = (int32_t)(hi >> 31); mid.qs = qf + 1 - P.k; mid.qe = ql + 1; mid.rs = (int32_t)S.rlo(b_first) + 1 - P.k;
+    return 2;
 }
 
 __device__ inline uint32_t prefix_popc64(uint64_t mask)
@@ -941,6 +984,39 @@ __device__ inline int first_chain_quick(const int32_t *gf, const int32_t *gpt, i
     return (max_s >= P.min_sc && cnt >= 1 && cnt >= P.min_cnt) ? 1 : -1;
 }
 
+
+// Hand-over backtrack of one cluster when only candidates for regs[0] are wanted (ChainSink::best): mg_chain_backtrack visits the
+// candidates in descending (f, index) order, and the emitter's done(zf) ends the visit once f falls below the best score handed over -
+// after one or two chains, typically.  A heap over thousands of candidates in HBM costs far more than that: the next candidate is
+// found by a wave-wide argmax over the cluster's f instead (n / 64 coalesced loads per chain).  Wave-uniform; stores by the emitter.
+template <class EM>
+__device__ inline void backtrack_wave_top(SliceStore &S, int32_t n, const ChainParams &P, int32_t &n_u, int32_t &best, const EM &em, uint32_t lane)
+{
+    n_u = 0; best = 0;
+    for (int32_t i = (int32_t)lane; i < n; i += 64) S.setT(i, 0);
+    wave_mem_sync();
+    volatile const int32_t *vf = S.f, *vpt = S.pt;
+    long long bound = (1ll << 62);
+    int64_t n_v = 0;
+    for (;;) {
+        long long key = -1;
+        for (int32_t i = (int32_t)lane; i < n; i += 64) {
+            const int32_t f = vf[i];
+            if (f < P.min_sc || vpt[2 * i + 1] != 0) continue;
+            const long long kk = (long long)f << 32 | (uint32_t)i;
+            if (kk < bound && kk > key) key = kk;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const long long t = __shfl_xor(key, o); key = t > key ? t : key; }
+        if (key < 0) break;
+        bound = key;
+        const int32_t zf = (int32_t)(key >> 32), zi = (int32_t)(key & 0xffffffff);
+        if (em.done(zf)) break;
+        backtrack_visit<SliceStore, int32_t, EM>(S, P, zf, zi, n_v, n_u, best, em);       // uniform: every lane walks, lane 0's emitter writes
+        wave_mem_sync();
+    }
+}
+
 // one big cluster, one wave, DP state through the LDS ring
 __device__ inline void chain_cluster_ring(const uint64_t *gx, uint32_t *gq, int32_t *gf, int32_t *gpt, int32_t n, int32_t qlen, const ChainParams &P,
                                           int32_t &n_u, int32_t &best, bool first_only, uint32_t lane, RingMem &rm, unsigned long long *dbg_cnt = nullptr,
@@ -951,7 +1027,8 @@ __device__ inline void chain_cluster_ring(const uint64_t *gx, uint32_t *gq, int3
         chain_dp_ring(gx, gq, gf, gpt, n, qlen, P, lane, rm, dbg_cnt);
         SliceStore S{gx, gq, gf, gpt};
         const StoreEmit<SliceStore> em{sk, &S, read, base, lane == 0, P.k, region_hash(qlen)};
-        backtrack_heap<SliceStore, int32_t, StoreEmit<SliceStore>>(S, n, P, heap, n_u, best, false, em);
+        if (sk->best) backtrack_wave_top(S, n, P, n_u, best, em, lane);
+        else backtrack_heap<SliceStore, int32_t, StoreEmit<SliceStore>>(S, n, P, heap, n_u, best, false, em);
         wave_mem_sync();
         return;
     }
@@ -974,6 +1051,7 @@ __device__ inline void chain_cluster_wave(SliceStore &S, int32_t n, int32_t qlen
         const StoreEmit<SliceStore> em{sk, &S, read, base, lane == 0, P.k, region_hash(qlen)};
         chain_dp_wave(S, n, qlen, P, lane);
         if (n <= 64) backtrack_mask(S, n, P, n_u, best, false, em);
+        else if (sk->best) backtrack_wave_top(S, n, P, n_u, best, em, lane);
         else { backtrack_heap<SliceStore, int32_t, StoreEmit<SliceStore>>(S, n, P, zbuf, n_u, best, false, em); wave_mem_sync(); }
         return;
     }

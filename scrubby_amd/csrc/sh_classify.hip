@@ -66,6 +66,7 @@ struct Counters {
     uint32_t n_sort[N_SORT_CLS], n_giant_tiles, n_giant_rounds;
     uint32_t n_long_segs, pad2;
     uint32_t ext_reason[8];       // why the top chain did not settle a read (k_ext_top)
+    uint32_t ext_s3[8];           // SCRUBBY_HIP_DBG & 16: outcome of the local-cluster shortcut (k_expand): 0 tried, 1 no singleton / filtered seed, 2 singletons apart, 3 window grew / too many, 4 K > 64, 5 no margin over U_out, 6 lemma, 7 decided
     uint32_t ext_overflow, ext_n_list, ext_ticket, ext_regions, ext_dropped, ext_n_redo, ext_n_list2, ext_ticket2, ext_n_redo2, ext_ticket3;      // extension stage (sh_align.h)
     uint32_t ext_n_recs[SINK_SHARDS]; unsigned long long ext_n_anch[SINK_SHARDS];                 // hand-over cursors, one per shard
     uint32_t n_cl[4], cl_ticket, pad3;      // global queue of big clusters (k_cluster_dp), by size class
@@ -684,7 +685,9 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
     for (uint32_t base = blockIdx.x * 64; base < n_work; base += gridDim.x * 64) {
         const uint32_t wi = base + lane;
         const bool valid = wi < n_work;
-        bool host = false, lemma_hit = false;
+        bool host = false, lemma_hit = false, decided = false, need_mid = false, tried = false;
+        MidReq mid{0, 0, 0, 0, 0};
+        uint32_t r_ = 0; int32_t qlen_ = 0, n_mini_ = 0, n_seed_ = 0, n_u_ = 0, best_ = 0; int64_t n_a_ = 0; SeedView sv_{nullptr, 1, 0};
         if (valid) {
             const uint32_t r = a.work[wi];
             const uint32_t info = a.k1info[r];
@@ -699,19 +702,33 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
             gen_anchors(S, sv, a.positions, qlen, a.P.k);
             int64_t n_a = 0;
             for (uint32_t i = 0; i < sv.n; ++i) n_a += sv.occ(i);
-            bool decided = false;
             if (a.emit && a.trace == nullptr && a.P.ext_lemma) {      // flag-only: the top chain, vouched for by chain_lemma, decides without a hand-over
                 chain_dp_mask(S, (int)n_a, qlen, a.P);
                 BestChain bc{};
                 auto hi = [&](int32_t i) { return small_group_hi(sv, a.positions, qlen, a.P.k, S.grp(i)); };
                 const BestEmit<SmallStore<CAP>, decltype(hi)> be{&S, &bc, region_hash(qlen), a.P.k, 0u, hi, true};
                 backtrack_mask(S, (int)n_a, a.P, n_u, best, false, be);
-                decided = n_u == 0 || (!bc.tie && chain_lemma(S, bc.zi, bc.end_i, a.P, hi(bc.zi), a.BC, a.bases + a.offsets[r], qlen));
-                lemma_hit = n_u > 0 && decided;
+                tried = true;
+                if (n_u == 0) decided = true;
+                else if (!bc.tie) { const int32_t code = chain_lemma(S, bc.zi, bc.end_i, a.P, hi(bc.zi), mid); decided = code == 1; need_mid = code == 2; }
             }
+            r_ = r; qlen_ = qlen; n_a_ = n_a; n_mini_ = n_mini; n_seed_ = n_seed; n_u_ = n_u; best_ = best; sv_ = sv;
+        }
+        // stretches with too many bases outside their k-mers: mm_test_zdrop on the bases, the wave on one lane's request at a time
+        if (a.emit && a.trace == nullptr && a.P.ext_lemma) {
+            const bool mid_ok = resolve_mid_wave(need_mid, mid, a.bases + a.offsets[valid ? r_ : 0], qlen_, a.BC, a.P);
+            if (need_mid && mid_ok) decided = true;
+        }
+        if (valid) {
+            const uint32_t r = r_;
+            const int32_t qlen = qlen_, n_mini = n_mini_, n_seed = n_seed_;
+            const int64_t n_a = n_a_;
+            int32_t n_u = n_u_, best = best_;
+            SeedView sv = sv_;
+            lemma_hit = tried && n_u > 0 && decided;
             if (decided) {}
             else if (a.emit) {      // every chain goes to the extension stage, which decides the read
-                chain_dp_mask(S, (int)n_a, qlen, a.P);
+                if (!tried) chain_dp_mask(S, (int)n_a, qlen, a.P);
                 auto emf = [&](int64_t zi, int64_t end_i, int32_t sc, int64_t cnt, int32_t zf) {
                     const uint32_t hi = small_group_hi(sv, a.positions, qlen, a.P.k, S.grp((int)zi));
                     sink_emit(a.sink, r, (int32_t)zi, (int32_t)end_i, sc, (uint32_t)cnt, (uint32_t)zf, (uint32_t)zi, a.P.k, region_hash(qlen),
@@ -859,7 +876,7 @@ __global__ __launch_bounds__(64) void k_pair_pass(K2Args a, int distinct)
 // after the pair pass over the repeat path's list: the survivors (collected in the deferral list) become the list
 __global__ void k_pair_swap(Counters *ctr)
 {
-    ctr->n_big_total = ctr->n_big[0];
+    if (ctr->n_big_total == 0) ctr->n_big_total = ctr->n_big[0];
     ctr->n_big[0] = ctr->n_big_defer[0];
     ctr->n_big_defer[0] = 0;
 }
@@ -890,6 +907,178 @@ __device__ inline uint32_t chain_max_dist_x(const ChainParams &P, int32_t qlen)
     if (m < P.bw) m = P.bw;
     return (uint32_t)m;
 }
+
+// SH_F_CIGAR, flag-only (ChainParams::ext_*): the cluster(s) around a read's singleton seeds, alone.
+// One wave per read of the repeat path's list, one lane per seed.  A read with unique seeds has its true locus there; the other
+// occurrences of its repeated seeds - hundreds of loci - need not be expanded, sorted and chained if they cannot matter:
+//   1. K = every anchor of the read on the singletons' strand / contig within reach of them: the window [lo - mdx, hi + mdx] around
+//      the anchors found so far is searched in each seed's (sorted) occurrence list until nothing new turns up, so K is a union of
+//      COMPLETE clusters (no anchor within max_dist_x outside it) and mg_lchain_dp + the backtrack over K give exactly the chains the
+//      full anchor set gives there (clusters are independent DP problems);
+//   2. a chain made of anchors outside K only uses seeds that have occurrences outside K; its score is at most the query bases
+//      those seeds' k-mers cover (U_out: a link adds min(k, dq) at most);
+//   3. so if K's top chain scores more than U_out it is regs[0] of mm_gen_regs whatever the rest holds, it is aligned, and chain_lemma
+//      decides whether it survives.  Anything else (no singleton, a seed above mid_occ, singletons at several loci, K beyond 64 anchors,
+//      no such margin, a stretch the lemma cannot vouch for) stays on the list for the full path.
+// Its own kernel (not a step of k_expand): ~60 registers instead of ~150, so three times the waves hide the dependent list probes.
+__global__ __launch_bounds__(64) void k_local_cluster(K2Args a)
+{
+    __shared__ uint64_t e_x[64];
+    __shared__ uint32_t e_q[64];
+    __shared__ int32_t e_f[64], e_pt[128];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_work = *a.work_count;
+    const ChainParams &P = a.P;
+    uint32_t n_hit = 0;
+    for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const uint32_t r = a.work[w];
+        const uint32_t info = a.k1info[r];
+        const uint32_t n_seed = info >> 16;
+        const int32_t qlen = (int32_t)(a.offsets[r + 1] - a.offsets[r]);
+        bool decided = false;
+        if (n_seed <= 64u && n_seed >= 2u) {
+            const bool have0 = lane < n_seed;
+            const uint4 rec0 = have0 ? a.records[(size_t)r * a.seed_cap + lane] : make_uint4(0, 0, 0, 0);
+            const uint32_t occ0 = rec0.z & 0x7fffffffu;
+            const bool single = have0 && occ0 == 1u;
+            const uint64_t sm = __ballot(single);
+            bool ok = sm != 0 && __ballot(have0 && occ0 > (uint32_t)P.mid_occ) == 0;       // no seed is filtered: every occurrence is an anchor
+            uint64_t xs = 0; uint32_t qs_ = 0;
+            if (single) make_anchor((uint64_t)rec0.y << 32 | rec0.x, rec0.w, qlen, P.k, xs, qs_);
+            const int fl = sm ? __ffsll((unsigned long long)sm) - 1 : 0;
+            const uint32_t hiw = (uint32_t)__shfl((int)(uint32_t)(xs >> 32), fl);
+            // singletons elsewhere (another contig / strand) count as seeds with occurrences outside K
+            const bool s_in = single && (uint32_t)(xs >> 32) == hiw;
+            uint32_t lo = s_in ? (uint32_t)xs : 0xffffffffu, hi = s_in ? (uint32_t)xs : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o)); }
+            const uint32_t mdx = chain_max_dist_x(P, qlen);
+            ok = ok && hi - lo <= 4u * mdx;                       // singletons of one locus; far-apart ones on one contig: full path
+            const uint32_t rel = hiw >> 31;                      // strand relation of K's anchors
+            const uint64_t w1m = (uint64_t)rec0.y << 32 | rec0.x;
+            const uint64_t *__restrict__ lst = a.positions + (w1m >> SH_SLOT_NBITS);
+            const bool multi = have0 && occ0 > 1u;
+            uint32_t c_l = s_in ? 1u : 0u, first_l = 0;
+            if (ok) {
+                for (int round = 0; round < 4; ++round) {
+                    const uint32_t wlo = lo > mdx ? lo - mdx : 0u, whi = hi + mdx < hi ? 0xffffffffu : hi + mdx;
+                    uint32_t nlo = lo, nhi = hi;
+                    if (multi) {
+                        // lower bound of the window in this seed's ascending occurrence list: 8-ary steps (7 independent loads a round instead
+                        // of one), then the entries from there 8 at a time
+                        const uint64_t key_lo = (uint64_t)(hiw & 0x7fffffffu) << 32 | (uint64_t)wlo << 1;
+                        uint32_t b = 0, len = occ0;
+                        while (len > 8u) {
+                            const uint32_t step = (len + 7u) >> 3;
+                            uint64_t pv[7];
+#pragma unroll
+                            for (uint32_t j = 0; j < 7u; ++j) { const uint32_t ix = b + (j + 1u) * step - 1u; pv[j] = ix < b + len ? lst[ix] : ~0ull; }
+                            uint32_t cnt = 0;
+#pragma unroll
+                            for (uint32_t j = 0; j < 7u; ++j) cnt += pv[j] < key_lo;
+                            const uint32_t nb = b + cnt * step;
+                            len = min(step, b + len - nb); b = nb;
+                        }
+                        {
+                            uint64_t pv[8];
+#pragma unroll
+                            for (uint32_t j = 0; j < 8u; ++j) pv[j] = j < len ? lst[b + j] : ~0ull;
+                            uint32_t cnt = 0;
+#pragma unroll
+                            for (uint32_t j = 0; j < 8u; ++j) cnt += pv[j] < key_lo;
+                            b += cnt;
+                        }
+                        first_l = b; c_l = 0;
+                        bool more = true;
+                        for (uint32_t t0 = b; more && t0 < occ0 && c_l <= 16u; t0 += 8u) {
+                            uint64_t pv[8];
+#pragma unroll
+                            for (uint32_t j = 0; j < 8u; ++j) pv[j] = t0 + j < occ0 ? lst[t0 + j] : ~0ull;
+#pragma unroll
+                            for (uint32_t j = 0; j < 8u; ++j) {
+                                const uint64_t pw = pv[j];
+                                if (!more || (uint32_t)(pw >> 32) != (hiw & 0x7fffffffu) || ((uint32_t)pw >> 1) > whi) { more = false; continue; }
+                                if ((((uint32_t)pw & 1u) != (rec0.w & 1u)) == (rel != 0)) { ++c_l; const uint32_t xp = (uint32_t)pw >> 1; nlo = min(nlo, xp); nhi = max(nhi, xp); }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) { nlo = min(nlo, (uint32_t)__shfl_xor((int)nlo, o)); nhi = max(nhi, (uint32_t)__shfl_xor((int)nhi, o)); }
+                    if (__ballot(c_l > 16u) != 0) { ok = false; break; }
+                    if (nlo == lo && nhi == hi) break;
+                    if (round == 3) { ok = false; break; }
+                    lo = nlo; hi = nhi;
+                }
+            }
+            const uint32_t n_k = ok ? wave_sum_u32(c_l) : 0u;
+            if (ok && n_k >= 2 && n_k <= 64) {
+                // K's anchors in generation order (seed order, then occurrence order): the order the full expansion gives them
+                const uint32_t ex = wave_excl_scan_u32(c_l, lane);
+                const uint32_t wlo = lo > mdx ? lo - mdx : 0u, whi = hi + mdx < hi ? 0xffffffffu : hi + mdx;
+                if (s_in) { e_x[ex] = xs; e_q[ex] = qs_; }
+                else if (multi && c_l) {
+                    uint32_t o = 0;
+                    for (uint32_t t = first_l; t < occ0 && o < c_l; ++t) {
+                        const uint64_t pw = lst[t];
+                        if ((((uint32_t)pw & 1u) != (rec0.w & 1u)) != (rel != 0)) continue;
+                        if (((uint32_t)pw >> 1) > whi || ((uint32_t)pw >> 1) < wlo) continue;
+                        uint64_t x; uint32_t q;
+                        make_anchor(pw, rec0.w, qlen, P.k, x, q);
+                        e_x[ex + o] = x; e_q[ex + o] = q; ++o;
+                    }
+                }
+                __syncthreads();
+                uint64_t x = lane < n_k ? e_x[lane] : ~0ull;
+                uint32_t q = lane < n_k ? e_q[lane] : 0u;
+                const uint64_t xp = (uint64_t)__shfl_up((long long)x, 1);
+                if (__ballot(lane > 0 && lane < n_k && x < xp) != 0) wave_rank_sort(x, q, n_k, lane);
+                __syncthreads();
+                if (lane < n_k) { e_x[lane] = x; e_q[lane] = q; }
+                // clusters: lane i owns the cluster that starts at anchor i
+                const uint64_t xq = (uint64_t)__shfl_up((long long)x, 1);
+                const bool start = lane < n_k && (lane == 0 || (uint32_t)(x >> 32) != (uint32_t)(xq >> 32) || (uint32_t)x - (uint32_t)xq > mdx);
+                const uint64_t stm = __ballot(start);
+                const uint64_t above = lane >= 63 ? 0ull : stm & ~((2ULL << lane) - 1);
+                const uint32_t clen = start ? (above ? (uint32_t)__ffsll((unsigned long long)above) - 1u : n_k) - lane : 0u;
+                __syncthreads();
+                BestChain bc{};
+                if (start && clen >= 2u) {
+                    SliceStore S{(const uint64_t *)&e_x[lane], (const uint32_t *)&e_q[lane], e_f + lane, e_pt + 2 * (size_t)lane};
+                    int32_t n_u, best;
+                    auto hif = [&](int32_t j) { return (uint32_t)(S.X(j) >> 32); };
+                    const BestEmit<SliceStore, decltype(hif)> be{&S, &bc, region_hash(qlen), P.k, lane, hif, true};
+                    chain_dp_mask(S, (int)clen, qlen, P);
+                    backtrack_mask(S, (int)clen, P, n_u, best, false, be);
+                }
+                unsigned long long zmax = bc.n ? bc.z : 0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = (unsigned long long)__shfl_xor((long long)zmax, o); zmax = other > zmax ? other : zmax; }
+                const uint64_t holders = __ballot(bc.n > 0 && bc.z == zmax);
+                // U_out: query bases covered by the k-mers of the seeds that have occurrences outside K (lanes are in query order)
+                const bool outside = have0 && occ0 > c_l;
+                const uint64_t om = __ballot(outside);
+                const uint64_t below = om & ((1ULL << lane) - 1);
+                const int32_t prev_en = (int32_t)((uint32_t)__shfl((int)rec0.w, below ? 63 - __clzll((unsigned long long)below) : 0) >> 1) + 1;
+                const int32_t en = (int32_t)(rec0.w >> 1) + 1, st = en - P.k;
+                const int32_t cover = outside ? en - (below && prev_en > st ? prev_en : st) : 0;
+                const int32_t u_out = (int32_t)wave_sum_u32((uint32_t)cover);
+                int32_t code = 0;
+                MidReq mid{0, 0, 0, 0, 0};
+                if (__popcll(holders) == 1 && bc.n > 0 && bc.z == zmax && !bc.tie && bc.score > u_out) {
+                    SliceStore S{(const uint64_t *)&e_x[bc.base], (const uint32_t *)&e_q[bc.base], e_f + bc.base, e_pt + 2 * (size_t)bc.base};
+                    code = chain_lemma(S, bc.zi, bc.end_i, P, (uint32_t)(S.X(bc.zi) >> 32), mid);
+                }
+                const bool mid_ok = resolve_mid_wave(code == 2, mid, a.bases + a.offsets[r], qlen, a.BC, P);
+                decided = __ballot(code == 1 || (code == 2 && mid_ok)) != 0;
+                __syncthreads();
+            }
+        }
+        if (decided) { if (lane == 0) a.flags[r] = 1; ++n_hit; }
+        else if (lane == 0) a.leftover[atomicAdd(a.leftover_count, 1u)] = r;
+    }
+    if (lane == 0 && n_hit) { atomicAdd(&a.ctr->sh_host[SHARD()], n_hit); atomicAdd(&a.ctr->sh_lemma[SHARD()], n_hit); }
+}
+
 
 // Chains every cluster of a sorted anchor array x[0..n) / q[0..n).  f / pt: DP state arrays of n (2n) int32.
 // Returns this thread's (chains, best score, clusters).  `found`: block-shared flag of the flag-only early exit
@@ -947,7 +1136,8 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
             if (n_u > 0) { n_u_thr += n_u; if (best > best_thr) best_thr = best; }
             return;
         }
-        if (len > (CONTIG ? 64u : 6u)) {      // arena path: only clusters beyond the register-mask DP go wave-wide
+        if (len > (CONTIG ? 64u : 6u)) {      // arena path: only clusters beyond the register-mask DP go wave-wide (flag-only hand-over: beyond 8 -
+                                                                       // a lane chaining 64 anchors out of HBM holds its whole block up, and most small ones are ruled out anyway)
             if (gq) {
                 const int cc = cl_class(len);
                 const uint32_t gs = atomicAdd(&gq->count[cc], 1u);
@@ -980,7 +1170,8 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
         // sweeps by cluster size: the clusters a lane chains itself in rising order of cost (the DP is quadratic and a wave
         // waits for its slowest lane), then - only if the read is still undecided in flag-only mode - the big ones go to
         // the queue.  Lengths are free now, so one sweep would queue every big cluster before the first chain is found.
-        const uint32_t thr[5] = {0u, 8u, 24u, 64u, 0xffffffffu};
+        const bool tq = sk && sk->best;
+        const uint32_t thr[5] = {0u, 8u, 24u, 64u, 0xffffffffu}; (void)tq;
         for (int sweep = phase == 0 ? 3 : 0; sweep < (phase == 1 ? 3 : 4); ++sweep) {
             uint32_t i = fs < i_end ? fs : i_end;
             while (i < i_end) {
@@ -1295,146 +1486,6 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
             anchors_wave += n_a; ++n_pair;
             continue;
         }
-        if (!LONG && a.t_mode && P.ext_lemma && n_st == 1 && a.pass == 0 && n_a > 64 && !(a.dbg & 256)) {
-            // SH_F_CIGAR, flag-only: the cluster(s) around the read's singleton seeds, alone (ChainParams::ext_*).
-            // A read with unique seeds has its true locus there; the other occurrences of its repeated seeds - hundreds of loci - need
-            // not be expanded, sorted and chained if they cannot matter:
-            //   1. K = every anchor of the read on the singletons' strand / contig within reach of them: the window [lo - mdx, hi + mdx]
-            //      around the anchors found so far is searched in each seed's (sorted) occurrence list until nothing new turns up, so K is
-            //      a union of COMPLETE clusters (no anchor within max_dist_x outside it) and mg_lchain_dp + the backtrack over K give
-            //      exactly the chains the full anchor set gives there (clusters are independent DP problems);
-            //   2. a chain made of anchors outside K only uses seeds that have occurrences outside K; its score is at most the query
-            //      bases those seeds' k-mers cover (U_out: a link adds min(k, dq) at most);
-            //   3. so if K's top chain scores more than U_out it is regs[0] of mm_gen_regs whatever the rest holds, it is aligned, and
-            //      chain_lemma decides whether it survives.  Anything else (no singleton, a filtered seed, K too large, no such margin,
-            //      a stretch the lemma cannot vouch for) takes the full path below.
-            const uint32_t occ0 = rec0.z & 0x7fffffffu;
-            const bool single = have0 && occ0 == 1u;
-            const uint64_t sm = __ballot(single);
-            bool s3_ok = sm != 0 && __ballot(have0 && (flt0 || my_n0 != occ0)) == 0;
-            uint64_t xs = 0; uint32_t qs_ = 0;
-            if (single) make_anchor((uint64_t)rec0.y << 32 | rec0.x, rec0.w, qlen, P.k, xs, qs_);
-            const int fl = sm ? __ffsll((unsigned long long)sm) - 1 : 0;
-            const uint32_t hiw = (uint32_t)__shfl((int)(uint32_t)(xs >> 32), fl);
-            s3_ok = s3_ok && __ballot(single && (uint32_t)(xs >> 32) != hiw) == 0;
-            uint32_t lo = single ? (uint32_t)xs : 0xffffffffu, hi = single ? (uint32_t)xs : 0u;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o)); }
-            const uint32_t mdx = chain_max_dist_x(P, qlen);
-            const uint32_t rel = hiw >> 31;                      // strand relation of K's anchors
-            const uint64_t w1m = (uint64_t)rec0.y << 32 | rec0.x;
-            const uint64_t *__restrict__ lst = a.positions + (w1m >> SH_SLOT_NBITS);
-            const bool multi = have0 && occ0 > 1u;
-            uint32_t c_l = single ? 1u : 0u, first_l = 0;
-            if (s3_ok) {
-                for (int round = 0; round < 4; ++round) {
-                    const uint32_t wlo = lo > mdx ? lo - mdx : 0u, whi = hi + mdx < hi ? 0xffffffffu : hi + mdx;
-                    uint32_t nlo = lo, nhi = hi;
-                    if (multi) {
-                        // lower bound of the window in this seed's ascending occurrence list: 8-ary steps (7 independent loads a round instead
-                        // of one), then the entries from there 8 at a time
-                        const uint64_t key_lo = (uint64_t)(hiw & 0x7fffffffu) << 32 | (uint64_t)wlo << 1;
-                        uint32_t b = 0, len = occ0;
-                        while (len > 8u) {
-                            const uint32_t step = (len + 7u) >> 3;
-                            uint64_t pv[7];
-#pragma unroll
-                            for (uint32_t j = 0; j < 7u; ++j) { const uint32_t ix = b + (j + 1u) * step - 1u; pv[j] = ix < b + len ? lst[ix] : ~0ull; }
-                            uint32_t cnt = 0;
-#pragma unroll
-                            for (uint32_t j = 0; j < 7u; ++j) cnt += pv[j] < key_lo;
-                            const uint32_t nb = b + cnt * step;
-                            len = min(step, b + len - nb); b = nb;
-                        }
-                        {
-                            uint64_t pv[8];
-#pragma unroll
-                            for (uint32_t j = 0; j < 8u; ++j) pv[j] = j < len ? lst[b + j] : ~0ull;
-                            uint32_t cnt = 0;
-#pragma unroll
-                            for (uint32_t j = 0; j < 8u; ++j) cnt += pv[j] < key_lo;
-                            b += cnt;
-                        }
-                        first_l = b; c_l = 0;
-                        bool more = true;
-                        for (uint32_t t0 = b; more && t0 < occ0 && c_l <= 16u; t0 += 8u) {
-                            uint64_t pv[8];
-#pragma unroll
-                            for (uint32_t j = 0; j < 8u; ++j) pv[j] = t0 + j < occ0 ? lst[t0 + j] : ~0ull;
-#pragma unroll
-                            for (uint32_t j = 0; j < 8u; ++j) {
-                                const uint64_t pw = pv[j];
-                                if (!more || (uint32_t)(pw >> 32) != (hiw & 0x7fffffffu) || ((uint32_t)pw >> 1) > whi) { more = false; continue; }
-                                if ((((uint32_t)pw & 1u) != (rec0.w & 1u)) == (rel != 0)) { ++c_l; const uint32_t xp = (uint32_t)pw >> 1; nlo = min(nlo, xp); nhi = max(nhi, xp); }
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) { nlo = min(nlo, (uint32_t)__shfl_xor((int)nlo, o)); nhi = max(nhi, (uint32_t)__shfl_xor((int)nhi, o)); }
-                    if (__ballot(c_l > 16u) != 0) { s3_ok = false; break; }
-                    if (nlo == lo && nhi == hi) break;
-                    if (round == 3) { s3_ok = false; break; }
-                    lo = nlo; hi = nhi;
-                }
-            }
-            const uint32_t n_k = s3_ok ? wave_sum_u32(c_l) : 0u;
-            if (s3_ok && n_k >= 2 && n_k <= 64) {
-                // K's anchors in generation order (seed order, then occurrence order): the order the full expansion gives them
-                const uint32_t ex = wave_excl_scan_u32(c_l, lane);
-                const uint32_t wlo = lo > mdx ? lo - mdx : 0u, whi = hi + mdx < hi ? 0xffffffffu : hi + mdx;
-                if (single) { e_x[ex] = xs; e_q[ex] = qs_; }
-                else if (multi && c_l) {
-                    uint32_t o = 0;
-                    for (uint32_t t = first_l; t < occ0 && o < c_l; ++t) {
-                        const uint64_t pw = lst[t];
-                        if ((((uint32_t)pw & 1u) != (rec0.w & 1u)) != (rel != 0)) continue;
-                        if (((uint32_t)pw >> 1) > whi || ((uint32_t)pw >> 1) < wlo) continue;
-                        uint64_t x; uint32_t q;
-                        make_anchor(pw, rec0.w, qlen, P.k, x, q);
-                        e_x[ex + o] = x; e_q[ex + o] = q; ++o;
-                    }
-                }
-                __syncthreads();
-                uint64_t x = lane < n_k ? e_x[lane] : ~0ull;
-                uint32_t q = lane < n_k ? e_q[lane] : 0u;
-                const uint64_t xp = (uint64_t)__shfl_up((long long)x, 1);
-                if (__ballot(lane > 0 && lane < n_k && x < xp) != 0) {
-                    wave_rank_sort(x, q, n_k, lane);
-                    __syncthreads();
-                    if (lane < n_k) { e_x[lane] = x; e_q[lane] = q; }
-                }
-                __syncthreads();
-                int32_t n_u = 0, best = 0;
-                BestChain bc{};
-                uint32_t ncl = 0;
-                chain_sorted<false>(e_x, e_q, e_f, e_pt, n_k, lane, 64, qlen, P, nullptr, BigList{e_bstart, e_blen, &e_bcount, 8}, n_u, best, ncl,
-                                    nullptr, nullptr, nullptr, r, nullptr, &bc, region_hash(qlen));
-                unsigned long long zmax = bc.n ? bc.z : 0ull;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = (unsigned long long)__shfl_xor((long long)zmax, o); zmax = other > zmax ? other : zmax; }
-                const uint64_t holders = __ballot(bc.n > 0 && bc.z == zmax);
-                // U_out: query bases covered by the k-mers of the seeds that have occurrences outside K (lanes are in query order)
-                const bool outside = have0 && occ0 > c_l;
-                const uint64_t om = __ballot(outside);
-                const uint64_t below = om & ((1ULL << lane) - 1);
-                const int32_t prev_en = (int32_t)((uint32_t)__shfl((int)rec0.w, below ? 63 - __clzll((unsigned long long)below) : 0) >> 1) + 1;
-                const int32_t en = (int32_t)(rec0.w >> 1) + 1, st = en - P.k;
-                const int32_t cover = outside ? en - (below && prev_en > st ? prev_en : st) : 0;
-                const int32_t u_out = (int32_t)wave_sum_u32((uint32_t)cover);
-                bool mine = false;
-                if (__popcll(holders) == 1 && bc.n > 0 && bc.z == zmax && !bc.tie && bc.score > u_out) {
-                    SliceStore S{(const uint64_t *)&e_x[bc.base], (const uint32_t *)&e_q[bc.base], e_f + bc.base, e_pt + 2 * (size_t)bc.base};
-                    mine = chain_lemma(S, bc.zi, bc.end_i, P, (uint32_t)(S.X(bc.zi) >> 32), a.BC, a.BC.bases + a.offsets[r], qlen);
-                }
-                __syncthreads();
-                if (__ballot(mine) != 0) {
-                    if (lane == 0) { BigMeta m{r, n_a, rep_len, 0u}; a.B.meta[w] = m; a.B.acc_nu[w] = 1; a.B.acc_best[w] = P.min_sc; }
-                    anchors_wave += n_a; ++n_lemma;
-                    continue;
-                }
-            }
-            __syncthreads();
-        }
         const bool in_lds = n_a <= 64;     // short anchor lists never leave the CU
         // anchor slots: the wave advances the arena cursor by 16 Ki slots at a time
         if (!in_lds && a_cur + n_a > a_end) {
@@ -1522,12 +1573,14 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
                 bool ok = false;
                 if (any == 0) ok = true;                                       // no chain at all: unmapped
                 else if (__popcll(holders) == 1) {
-                    bool mine = false;
+                    int32_t code = 0;
+                    MidReq mid{0, 0, 0, 0, 0};
                     if (bc.n > 0 && bc.z == zmax && !bc.tie) {
                         SliceStore S{(const uint64_t *)&e_x[bc.base], (const uint32_t *)&e_q[bc.base], e_f + bc.base, e_pt + 2 * (size_t)bc.base};
-                        mine = chain_lemma(S, bc.zi, bc.end_i, P, (uint32_t)(S.X(bc.zi) >> 32), a.BC, a.BC.bases + a.offsets[r], qlen);
+                        code = chain_lemma(S, bc.zi, bc.end_i, P, (uint32_t)(S.X(bc.zi) >> 32), mid);
                     }
-                    ok = __ballot(mine) != 0;
+                    const bool mid_ok = resolve_mid_wave(code == 2, mid, a.BC.bases + a.offsets[r], qlen, a.BC, P);
+                    ok = __ballot(code == 1 || (code == 2 && mid_ok)) != 0;
                 }
                 lemma_done = ok;
                 if (ok && any != 0) ++n_lemma;
@@ -2140,9 +2193,20 @@ __global__ __launch_bounds__(64) void k_ext_top(ExtArgs a)
         const uint32_t t = base + threadIdx.x;
         bool redo = false;
         uint32_t r = 0;
+        int32_t rc = 0;
+        MidReq mid{0, 0, 0, 0, 0};
         if (t < n_list) {
             r = a.list[t];
-            const int32_t rc = top_chain_settles(a.in, a.P, r, a.best[r], a.tie[r]);
+            rc = top_chain_settles(a.in, a.P, r, a.best[r], a.tie[r], mid);
+        }
+        {   // rc == 2: the stretch's k-mers leave too many bases uncovered - mm_test_zdrop on the bases, the wave on one lane's request at a time
+            ChainParams cp{}; cp.ext_a = a.P.a < 0 ? -a.P.a : a.P.a; cp.ext_b = a.P.b > 0 ? -a.P.b : a.P.b; cp.ext_amb = a.P.sc_ambi > 0 ? -a.P.sc_ambi : a.P.sc_ambi; cp.ext_zdrop = a.P.zdrop;
+            const BaseCtx bcx{a.in.ref, a.in.cstart, a.in.bases};
+            const int32_t ql = t < n_list ? (int32_t)(a.in.offsets[r + 1] - a.in.offsets[r]) : 0;
+            const bool mid_ok = resolve_mid_wave(rc == 2, mid, a.in.bases + a.in.offsets[t < n_list ? r : 0], ql, bcx, cp);
+            if (rc == 2) rc = mid_ok ? 1 : -4;
+        }
+        if (t < n_list) {
             if (rc > 0) a.flags[r] = 1;
             else { redo = true; atomicAdd(&a.ctr->ext_reason[-rc & 7], 1u); }
         }
@@ -2356,7 +2420,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         uint64_t sort_cap_sum = 0;
         for (int i = 0; i < N_SORT_CLS; ++i) sort_cap_sum += sort_cap[i];
         uint64_t fixed = 4 * 64 * sizeof(SortItem) + 4096 + max_reads * (sizeof(BigMeta) + 8 + 8) + sort_cap_sum * sizeof(SortItem) + 16384;
-        uint64_t per_anchor = 8 + 8 + 8 + 4 + 4 + 4 + 2 + (c->ext ? 8 : 0);   // ax bx az aq bq af (+ tile_split and cluster queue shares) (+ hz)
+        uint64_t per_anchor = 8 + 8 + 8 + 4 + 4 + 4 + 2 + (c->ext ? 8 + 3 : 0);   // ax bx az aq bq af (+ tile_split and cluster queue shares) (+ hz)
         uint64_t cap = left > fixed ? (left - fixed) / per_anchor : 0;
         cap &= ~15ull;
         if (cap < 1024) { sh_set_error("sh_ctx_create: arena of %llu MiB is too small", (unsigned long long)(c->arena_bytes >> 20)); sh_ctx_destroy(c); return SH_ERR_OOM; }
@@ -2373,7 +2437,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         B.tile_base = (uint32_t *)take((max_reads + 1) * 4);
         B.tile_split = (uint32_t *)take((cap / GT + max_reads + 2) * 4);
         {   // a cluster of class c has more than {4096, 1024, 256, 64} anchors
-            const uint64_t div[4] = {4096, 1024, 256, 64};
+            const uint64_t div[4] = {4096, 1024, 256, c->ext ? 8u : 64u};
             for (int i = 0; i < 4; ++i) { B.cl_cap[i] = (uint32_t)std::min<uint64_t>(cap / div[i] + 64, UINT32_MAX); B.cl_items[i] = (SortItem *)take((uint64_t)B.cl_cap[i] * sizeof(SortItem)); }
         }
         if ((uint64_t)(p - c->d_arena) > c->arena_bytes) {   // alignment slack: shrink
@@ -2606,6 +2670,14 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         hipLaunchKernelGGL(k_pair_swap, dim3(1), dim3(1), 0, s, c->d_ctr);
         cur0 = 1;
     }
+    if (k.t_mode && c->P.ext_lemma && c->use_k1 && !c->use_long && !(k.dbg & 256)) {      // reads whose singleton seeds' locus settles them
+        K2Args pb = b;
+        pb.work = c->d_big[0][cur0]; pb.work_count = &c->d_ctr->n_big[0];
+        pb.leftover = c->d_big[0][cur0 ^ 1]; pb.leftover_count = &c->d_ctr->n_big_defer[0];
+        hipLaunchKernelGGL(k_local_cluster, dim3(256 * 24), dim3(64), 0, s, pb);      // latency-bound list probes: every wave slot
+        hipLaunchKernelGGL(k_pair_swap, dim3(1), dim3(1), 0, s, c->d_ctr);
+        cur0 ^= 1;
+    }
     bool first = true;
     Counters snap{};
     for (int iter = 0;; ++iter) {
@@ -2633,6 +2705,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         if (k.dbg & 16) fprintf(stderr, "[dbg] iter %d resketch %u reasons %u %u %u pair tests between two singletons (dbg) %u segs %u big %u/%u defer %u/%u\n", iter, c->h_ctr->n_resketch, c->h_ctr->n_leg_reason[0], c->h_ctr->n_leg_reason[1], c->h_ctr->n_leg_reason[2], c->h_ctr->n_leg_reason[3], c->h_ctr->n_long_segs, c->h_ctr->n_big[0], c->h_ctr->n_big[1], c->h_ctr->n_big_defer[0], c->h_ctr->n_big_defer[1]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] clusters chained by k_cluster_dp by class: %llu %llu %llu %llu, their anchors %llu %llu %llu %llu\n", c->h_ctr->cl_tot[0], c->h_ctr->cl_tot[1], c->h_ctr->cl_tot[2], c->h_ctr->cl_tot[3], c->h_ctr->cl_anchor_tot[0], c->h_ctr->cl_anchor_tot[1], c->h_ctr->cl_anchor_tot[2], c->h_ctr->cl_anchor_tot[3]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] reads (anchors) by sort class: <=64 %llu (%llu), <=256 %llu (%llu), <=512 %llu (%llu), <=1024 %llu (%llu), <=2048 %llu (%llu), <=4096 %llu (%llu), giant %llu (%llu)\n", c->h_ctr->sort_tot[6], c->h_ctr->sort_anchor_tot[6], c->h_ctr->sort_tot[0], c->h_ctr->sort_anchor_tot[0], c->h_ctr->sort_tot[1], c->h_ctr->sort_anchor_tot[1], c->h_ctr->sort_tot[2], c->h_ctr->sort_anchor_tot[2], c->h_ctr->sort_tot[3], c->h_ctr->sort_anchor_tot[3], c->h_ctr->sort_tot[4], c->h_ctr->sort_anchor_tot[4], c->h_ctr->sort_tot[5], c->h_ctr->sort_anchor_tot[5]);
+        if (k.dbg & 16) fprintf(stderr, "[dbg] local-cluster shortcut: tried %u, no singleton / filtered %u, singletons apart %u, window %u, K size %u, no margin %u, decided %u\n", c->h_ctr->ext_s3[0], c->h_ctr->ext_s3[1], c->h_ctr->ext_s3[2], c->h_ctr->ext_s3[3], c->h_ctr->ext_s3[4], c->h_ctr->ext_s3[5], c->h_ctr->ext_s3[7]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] ring DP: chunks in window %llu, beyond %llu, far rescans %llu\n", c->h_ctr->cl_dbg[0], c->h_ctr->cl_dbg[1], c->h_ctr->cl_dbg[2]);
         resk_done = c->h_ctr->n_resketch;
         const uint32_t d0 = c->h_ctr->n_big_defer[0], d1 = c->h_ctr->n_big_defer[1];
