@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--e2e-gz", action="store_true", help="--workload e2e: write .fastq.gz outputs")
     ap.add_argument("--e2e-legacy", action="store_true", help="--workload e2e: also time the collect-then-map host path")
     ap.add_argument("--e2e-dir", default=None, help="--workload e2e: scratch directory (default: a temp dir)")
+    ap.add_argument("--chain-only", action="store_true",
+                    help="decide at chain level (opts.flags without SH_F_CIGAR: round 1's decision, what the reference computes WITHOUT .with_cigar()); "
+                         "a comparison line, not the headline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the secondary weak-scaling measurement (20 M records per GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -135,6 +138,8 @@ def main_reads(a, rank, world, local, dev, backend):
     R = S.read_params(0x5C2B0020, host_pct=50, sub_per_10k=200, n_read_pct=1) if ont else S.read_params(READ_SEED)
     G = P.genome_len
     opts = S.preset("map-ont" if ont else "sr")
+    if a.chain_only:
+        opts.flags &= ~S.SH_F_CIGAR
 
     # ---- setup (untimed): reference -> index -> reads, all in HBM -------------------------------------
     real_ref = os.environ.get("SCRUBBY_CHM13")
@@ -272,10 +277,14 @@ def main_reads(a, rank, world, local, dev, backend):
         "k_sketch_probe": (k1_ms, k1_bytes), "k_chain_small": (k2_ms, k2_bytes),
         "repeat path (k_expand + k_sort_lds* + k_sort + k_finalize)": (k3_ms, k3_bytes),
     }
-    # the roofline object describes ONE kernel, the longest by rocprofv3's per-kernel average (profiles/r01_kernel_summary.txt): for
-    # short reads that is k_sketch_probe (the repeat path is a stage of ~12 kernels, the largest of which, k_expand, is half as long);
-    # the per-stage table stays beside it.  Long reads: the stage that takes longest.
-    dom = "k_sketch_probe" if (not ont and stages["k_sketch_probe"][0] > 0) else max(stages, key=lambda k: stages[k][0])
+    ext_ms = float(np.mean([s.get("ms_ext", 0.0) for s in stats]))
+    if ext_ms > 0:      # SH_F_CIGAR: list building + base-level alignment of the reads no shortcut settles (reads + their reference windows + 40-B chain records)
+        stages["extension stage (k_ext_* + k_regs_align)"] = (ext_ms, 40 * s0.get("n_ext_regions", 0) + 2 * s0["n_bases"] // max(s0["n_reads"], 1) * s0.get("n_ext_reads", 0))
+    # the roofline object describes the stage that takes LONGEST.  Round 1 (chain-level decision, --chain-only): k_sketch_probe, one streaming
+    # kernel.  With the extension stage (SH_F_CIGAR, the default, what .with_cigar() makes the reference compute) the repeat path leads:
+    # a few thousand satellite reads re-chained with max_occ hold most of the anchors, and their sort + sequential DP is latency-bound,
+    # far from the HBM roof - the fraction says so.  `streaming_kernel` keeps K1's own figure beside it.
+    dom = max(stages, key=lambda k: stages[k][0])
     d_ms, d_bytes = stages[dom]
     achieved = d_bytes / (d_ms * 1e-3) / 1e9
     roofline = {
@@ -287,6 +296,8 @@ def main_reads(a, rank, world, local, dev, backend):
         "stage_achieved_GBs": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None for k, v in stages.items()},
         "path_achieved_GBs": round((k1_bytes + k2_bytes + k3_bytes) / ((k1_ms + k2_ms + k3_ms) * 1e-3) / 1e9, 1),
         "n_seeded_reads": n_seeded,
+        "streaming_kernel": {"kernel": "k_sketch_probe", "achieved": round(k1_bytes / (k1_ms * 1e-3) / 1e9, 1) if k1_ms > 0 else None,
+                             "frac": round(k1_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k1_ms > 0 else None},
     }
     traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
     if os.path.exists(traffic_file) and not a.small:
@@ -310,7 +321,7 @@ def main_reads(a, rank, world, local, dev, backend):
     # ---- CPU baseline: the oracle on the host cores, same index, bounded sample -------------------------
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
-        cpu = cpu_baseline(index, info, d_reads, n_rec, L, a.cpu_seconds, d_flags, d_off if ont else None, "map-ont" if ont else "sr")
+        cpu = cpu_baseline(index, info, d_reads, n_rec, L, a.cpu_seconds, d_flags, d_off if ont else None, "map-ont" if ont else "sr", a.chain_only)
     ext_oracle = None
     if rank == 0 and world == 1 and not a.no_cpu and not ont:
         ext_oracle = external_oracle(index, d_reads, n_rec, L, d_flags, contigs, P, dev, real_ref)
@@ -345,7 +356,7 @@ def main_reads(a, rank, world, local, dev, backend):
                              ("configs[2]: the 10M synthetic 2x150bp PE (20M records) of configs[1], read-sharded over %d GPUs, vs CHM13v2-sized synthetic reference, sr preset" % world) if world > 1 else
                              "configs[1]: 10M synthetic 2x150bp PE (20M records) vs CHM13v2-sized synthetic reference, sr preset, k-mer/minimizer classifier path"),
                 "records_total": n_total, "records_rank0": n_rec, "read_len": (round(n_bases / n_rec, 1) if ont else L), "host_pct": R.host_pct, "reference_bp": int(G),
-                "preset": "map-ont" if ont else "sr", "k": info["k"], "w": info["w"], "records_per_launch": ctx_chunk(a, n_rec),
+                "preset": "map-ont" if ont else "sr", "decision": "chain level (no extension stage)" if a.chain_only else "mappings.len() > 0 after the extension filter (with_cigar)", "k": info["k"], "w": info["w"], "records_per_launch": ctx_chunk(a, n_rec),
                 "parallelism": f"read-sharded x{world} (contiguous pair-aligned ranges of the same records), index replicated",
                 "ref_seed": hex(REF_SEED), "read_seed": hex(R.seed),
             },
@@ -787,7 +798,7 @@ def physical_cores():
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
 
-def cpu_baseline(index, info, d_reads, n_rec, L, seconds, d_flags, d_off=None, preset="sr"):
+def cpu_baseline(index, info, d_reads, n_rec, L, seconds, d_flags, d_off=None, preset="sr", chain_only=False):
     """The oracle (restated decision path incl. the extension stage; NOT minimap2-rs) on the host cores: ONE call over a large
     contiguous sample (threads pull 64-read chunks off an atomic counter, so every core works to the end), sized from a short
     calibration call to take about `seconds`.  Also a parity check: flags differing from the GPU's on the sample."""
@@ -803,7 +814,10 @@ def cpu_baseline(index, info, d_reads, n_rec, L, seconds, d_flags, d_off=None, p
                 "sample": f"skipped: host has {avail_gb:.0f} GB free, index copy needs {need_gb:.0f} GB"}
     slots, pos = index.export()
     oidx = O.Index.wrap(slots, pos, info["w"], info["k"], ref=index.export_ref())      # the reference too: the extension stage aligns against it
-    oo = oidx.update_opts(O.preset(preset))
+    po = O.preset(preset)
+    if chain_only:
+        po.flags &= ~1      # MMO_F_CIGAR
+    oo = oidx.update_opts(po)
     off_all = d_off.cpu().numpy().astype(np.uint64) if d_off is not None else None
 
     def run(first, count, threads):
