@@ -168,7 +168,7 @@ __device__ __noinline__ uint4 k1_lane_flush(const uint64_t *list, uint32_t lane,
 }
 
 template <int W>
-__global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sketch_probe(K1Args a)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     uint64_t *list = (uint64_t *)smem;
@@ -320,6 +320,7 @@ __global__ __launch_bounds__(64) void k_sketch_probe(K1Args a)
             };
             [&]<int... Ps>(std::integer_sequence<int, Ps...>) { (one(std::integral_constant<int, Ps>{}), ...); }
             (std::make_integer_sequence<int, W>{});
+            st.block_end();
             i0 += W;
         }
         const bool last = i0 >= maxlen;

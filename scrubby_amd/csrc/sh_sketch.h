@@ -113,8 +113,11 @@ struct SketchState {
 // words is the window minimum with "rightmost on ties" built in (equal hashes: the larger position has the smaller word), so
 // the rescan after the minimum leaves the window is a plain 11-way minimum: 3 VALU per entry instead of 10, and no second
 // array for y.  "The minimum sits in the slot being overwritten" becomes "its position is pos - W".  Ties (the same k-mer
-// twice in a window) are looked for on the hashes' low 32 bits first (hl[]); only if that count exceeds one do the exact
-// tie loops run, in the reference's slot order.  Same statement order and emission order as SketchState::step.
+// twice in a window) are looked for on the hashes' low 32 bits first; only if that count exceeds one do the exact tie loops run, in the
+// reference's slot order.  Same statement order and emission order as SketchState::step.
+// Round 2: the window minimum is the two-block (van Herk / Gil-Werman) scheme - 2 minima a step + W-1 a block instead of W-1 a step -
+// and the separate low-word array is gone; k_sketch_probe is pinned at 4 waves/SIMD (128 VGPRs).  Measured: the VALU count drops, the
+// kernel time does not (21.4 -> 21.2 ms for 20 M reads): at 4 waves/SIMD it waits on its ~15 k-instruction loop body, not on the ALUs.
 //   emit(p) receives the packed word; sh_packed_entry() turns it into the queue entry  hash << 18 | pos << 1 | strand.
 __device__ inline uint64_t sh_packed_entry(uint64_t p)
 {
@@ -125,16 +128,16 @@ __device__ inline uint64_t sh_packed_entry(uint64_t p)
 template <int W>
 struct SketchPacked {
     uint64_t b[W];
-    uint32_t hl[W];
-    uint64_t minp, kf, kr, mask;
+    uint64_t suf[W];      // suf[j] = min(b[j .. W-1]) of the PREVIOUS block of W steps (block_end)
+    uint64_t minp, pre, kf, kr, mask;
     uint32_t shift1;
     int32_t l, k;
 
     __device__ __forceinline__ void init(int k_)
     {
 #pragma unroll
-        for (int j = 0; j < W; ++j) b[j] = SH_XMAX, hl[j] = 0xffffffffu;
-        minp = SH_XMAX; l = 0; kf = kr = 0;
+        for (int j = 0; j < W; ++j) b[j] = SH_XMAX, suf[j] = SH_XMAX;
+        minp = SH_XMAX; pre = SH_XMAX; l = 0; kf = kr = 0;
         k = k_; mask = (1ULL << 2 * k_) - 1; shift1 = 2 * (k_ - 1);
     }
 
@@ -168,7 +171,7 @@ struct SketchPacked {
         const uint32_t ml = (uint32_t)(minp >> 18);
         int c = 0;
 #pragma unroll
-        for (int j = 0; j < W; ++j) c += hl[j] == ml;
+        for (int j = 0; j < W; ++j) c += (uint32_t)(b[j] >> 18) == ml;
         return c;
     }
 
@@ -188,7 +191,7 @@ struct SketchPacked {
         } else {
             l = 0;
         }
-        b[P] = ip; hl[P] = (uint32_t)(ip >> 18);
+        b[P] = ip;
         const uint64_t old = minp;
         if (l == W + k - 1 && old != SH_XMAX) {        // first full window: identical k-mers
             if (same_low() > 1) ties<P>(tie_emit, false);
@@ -196,16 +199,27 @@ struct SketchPacked {
         // The reference's two branches, flattened.  "New minimum" (ix <= minx; an equal hash at a later position is the smaller word)
         // and "old minimum left the window" (its position is pos - W) both push the OLD minimum, under l >= W + k and l >= W + k - 1
         // respectively; and in every case the minimum afterwards is the minimum over the ring (a new minimum is below everything in
-        // it, an expired one is no longer in it, otherwise the old one still is).  So: one push site, one unconditional 11-way minimum,
+        // it, an expired one is no longer in it, otherwise the old one still is).  So: one push site, one unconditional window minimum,
         // no divergent rescan.  Ties are looked for only after an expiry, as in the reference.
+        // The window minimum itself is the two-block scheme (van Herk / Gil-Werman): the caller steps in blocks of W with P = step mod W,
+        // so at slot P the ring holds slots P+1 .. W-1 of the previous block and 0 .. P of this one - min(suffix minimum of the old block,
+        // running minimum of the new one): 2 minima a step + W-1 a block (block_end) instead of W-1 a step.  Same value, bit for bit.
         const bool newmin = ip < old;
         const bool expired = !newmin && old != SH_XMAX && (((uint32_t)old >> 1) & 0x1ffffu) == 0x1ffffu - (pos - (uint32_t)W);
         if ((newmin && l >= W + k && old != SH_XMAX) || (expired && l >= W + k - 1)) emit(old);
-        uint64_t m = b[0];
-#pragma unroll
-        for (int j = 1; j < W; ++j) m = b[j] < m ? b[j] : m;
+        pre = (P == 0 || ip < pre) ? ip : pre;
+        uint64_t m = pre;
+        if (P + 1 < W) m = suf[P + 1 < W ? P + 1 : 0] < m ? suf[P + 1 < W ? P + 1 : 0] : m;
         minp = m;
         if (expired && l >= W + k - 1 && m != SH_XMAX && same_low() > 1) ties<P>(tie_emit, true);
+    }
+
+    // after the W steps of a block (slots 0 .. W-1 all rewritten): the suffix minima the next block combines with
+    __device__ __forceinline__ void block_end()
+    {
+        suf[W - 1] = b[W - 1];
+#pragma unroll
+        for (int j = W - 2; j >= 1; --j) suf[j] = b[j] < suf[j + 1] ? b[j] : suf[j + 1];
     }
 
     template <class Emit>
