@@ -413,3 +413,33 @@ def test_kraken_run_streaming_equals_collect_then_classify(K, oracle, db, cfg1, 
     from scrubby_amd import lib as S
     with pytest.raises(S.ScrubbyHipError, match="fewer records than mate 1"):
         K.kraken_run([tmp_path / "a_1.fastq", tmp_path / "short_2.fastq"], [tmp_path / "x1.fastq", tmp_path / "x2.fastq"], dbdir, taxa_direct=["9606"], workdir=tmp_path / "wx")
+
+
+def test_database_written_by_plain_python(K, oracle):
+    """hash.k2d / opts.k2d / taxo.k2d packed byte by byte by tests/golden/make_k2_pydb.py (not by sh_k2_save), opened by sh_k2_open:
+    the table, the taxonomy and every call must equal that script's longhand expectations, and the oracle's."""
+    from tests.test_k2_oracle_cpu import load_pydb, pydb_units
+    raw, exp = load_pydb(), pydb_units()
+    d = K.K2Db.open(os.path.join(os.path.dirname(__file__), "golden", "k2_pydb"))
+    i = d.info()
+    assert (i["capacity"], i["size"], i["k"], i["l"], i["value_bits"], i["key_bits"], i["n_nodes"]) == (exp["capacity"], exp["size"], 35, 31, 6, 26, 13)
+    cells, parent, ext = d.export()
+    assert np.array_equal(cells, raw["cells"]) and list(parent) == exp["parents"] and list(ext) == exp["external"]
+    t = oracle.K2Table(raw["cells"], raw["parent"], raw["value_bits"])
+    for conf, mhg in ((0.0, 2), (0.5, 2), (0.0, 1), (1.0, 3)):
+        units = [u for u in exp["units"] if (u["confidence"], u["min_hit_groups"]) == (conf, mhg)]
+        for paired in (False, True):
+            us = [u for u in units if (len(u["mates"]) == 2) == paired]
+            seqs = [m.encode() for u in us for m in u["mates"]]
+            bases = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+            off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint64)
+            go = d.opts(); go.confidence, go.min_hit_groups = conf, mhg
+            g, _ = d.classify(bases, off, paired=paired, opts=go)
+            assert [int(x) for x in g["call"]] == [u["call"] for u in us], (conf, mhg, paired)
+            assert [int(x) for x in g["total_kmers"]] == [u["total_kmers"] for u in us]
+            assert [int(x) for x in g["hit_groups"]] == [u["hit_groups"] for u in us]
+            assert [int(x) for x in g["taxid"]] == [u["taxid"] for u in us]
+            oo = oracle.k2_default_opts(); oo.value_bits, oo.confidence, oo.min_hit_groups = 6, conf, mhg
+            c = t.classify(oo, bases, off, paired=paired, threads=1)
+            assert np.array_equal(g["call"], c["call"]) and np.array_equal(g["hit_groups"], c["hit_groups"])
+    d.close()

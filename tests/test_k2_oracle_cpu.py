@@ -169,3 +169,48 @@ def test_batch_equals_single(oracle):
     paired = t.classify(o, bases, offs, paired=True, threads=2)
     for i in range(len(recs) // 2):
         assert t.classify_pair(o, recs[2 * i], recs[2 * i + 1]) == {n: int(paired[i][n]) for n in oracle.K2_RESULT_DTYPE.names}
+
+
+# ---- a database written byte by byte by plain Python (tests/golden/make_k2_pydb.py): file formats + classification, independently ----
+def load_pydb():
+    """parse tests/golden/k2_pydb/{opts,taxo,hash}.k2d with numpy/struct, from the published layouts"""
+    import struct
+    d = os.path.join(os.path.dirname(__file__), "golden", "k2_pydb")
+    raw = open(os.path.join(d, "opts.k2d"), "rb").read()
+    assert len(raw) == 64
+    k, l, spaced, toggle, dna, min_hash, revcom, dbv, dbt = struct.unpack("<QQQQB7xQiii4x", raw)
+    raw = open(os.path.join(d, "taxo.k2d"), "rb").read()
+    assert raw[:8] == b"K2TAXDAT"
+    n_nodes, n_name, n_rank = struct.unpack("<QQQ", raw[8:32])
+    nodes = np.frombuffer(raw, dtype="<u8", count=7 * n_nodes, offset=32).reshape(n_nodes, 7)
+    assert len(raw) == 32 + 56 * n_nodes + n_name + n_rank
+    raw = open(os.path.join(d, "hash.k2d"), "rb").read()
+    cap, size, kb, vb = struct.unpack("<QQQQ", raw[:32])
+    cells = np.frombuffer(raw, dtype="<u4", count=cap, offset=32)
+    assert len(raw) == 32 + 4 * cap and kb + vb == 32
+    return dict(k=k, l=l, spaced=spaced, toggle=toggle, dna=dna, min_hash=min_hash, cells=cells, value_bits=vb, size=size,
+                parent=nodes[:, 0].astype(np.uint32), external=nodes[:, 5].astype(np.uint32))
+
+
+def pydb_units():
+    exp = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "k2_pydb_expected.json")))
+    return exp
+
+
+def test_oracle_on_the_python_written_database(oracle):
+    db, exp = load_pydb(), pydb_units()
+    assert (db["k"], db["l"], db["value_bits"], db["size"]) == (exp["k"], exp["l"], exp["value_bits"], exp["size"]) and db["dna"] == 1
+    assert list(db["parent"]) == exp["parents"] and list(db["external"]) == exp["external"]
+    assert int((db["cells"] != 0).sum()) == exp["size"]
+    t = oracle.K2Table(db["cells"], db["parent"], db["value_bits"])
+    assert len(exp["units"]) == 64
+    n_called = 0
+    for u in exp["units"]:
+        o = oracle.k2_default_opts()
+        o.k, o.l, o.spaced_seed_mask, o.toggle_mask, o.value_bits = db["k"], db["l"], db["spaced"], db["toggle"], db["value_bits"]
+        o.confidence, o.min_hit_groups = u["confidence"], u["min_hit_groups"]
+        m = [s.encode() for s in u["mates"]]
+        r = t.classify_pair(o, m[0], m[1] if len(m) > 1 else None)
+        assert (r["call"], r["total_kmers"], r["hit_groups"]) == (u["call"], u["total_kmers"], u["hit_groups"]), u["what"]
+        n_called += r["call"] != 0
+    assert n_called > 30
