@@ -358,6 +358,7 @@ typedef struct sh_kraken_config {
     int32_t     min_hit_groups;     /* <= 0: default */
     const char *json, *read_ids, *command;
     int32_t     device, threads;
+    const char *classifier_args;    /* -C verbatim, nullable: echoed as settings.classifier_args in the JSON (report.rs:81) */
 } sh_kraken_config;
 sh_status sh_kraken_run(const sh_kraken_config *cfg, sh_reads_result *out);
 

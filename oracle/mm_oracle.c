@@ -57,9 +57,12 @@ int mmo_preset(const char *name, mmo_opts *o)
         o->k = 15; o->w = 10;
         return 0;
     }
-    if (strcmp(name, "lr:hq") == 0) {           /* Preset::LrHq, cleaner.rs:458 */
+    if (strcmp(name, "lr:hq") == 0 || strcmp(name, "map-hifi") == 0) {      /* Preset::LrHq, Preset::MapHifi: cleaner.rs:458,465 */
         o->k = 19; o->w = 19; o->max_gap = 10000;
         o->min_mid_occ = 50; o->max_mid_occ = 500;
+        if (strcmp(name, "map-hifi") == 0) {    /* its own scores and dp_max floor; the sketch and the chain set-up are lr:hq's */
+            o->a = 1; o->b = 4; o->q = 6; o->q2 = 26; o->e = 2; o->e2 = 1; o->min_dp_max = 200;
+        }
         return 0;
     }
     if (strcmp(name, "lr") == 0) return -2;     /* Preset::Lr rejected, cleaner.rs:469 */

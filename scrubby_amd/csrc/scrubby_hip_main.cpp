@@ -10,7 +10,7 @@
 static void usage()
 {
     fprintf(stderr,
-            "scrubby-hip reads -i <R1> [R2] -o <O1> [O2] -I <ref.fa[.gz]|index.shidx> [-p sr|map-ont|lr:hq]\n"
+            "scrubby-hip reads -i <R1> [R2] -o <O1> [O2] -I <ref.fa[.gz]|index.shidx> [-p sr|map-ont|lr:hq|map-hifi]\n"
             "                  [-e] [-j report.json] [-r read_ids.tsv[.gz]] [-t threads] [-a minimap2-rs] [-w workdir]\n"
             "scrubby-hip reads -i <R1> [R2] -o <O1> [O2] -c kraken2 -I <kraken2 db dir> [-T taxa..] [-D taxa..] [-w workdir]\n"
             "                  [-C \"--confidence x --minimum-hit-groups n\"] [-e] [-j report.json] [-r read_ids.tsv[.gz]]\n"
@@ -150,6 +150,7 @@ int main(int argc, char **argv)
         }
         k.json = json.empty() ? nullptr : json.c_str(); k.read_ids = ids.empty() ? nullptr : ids.c_str();
         k.command = command.c_str(); k.device = 0; k.threads = threads;
+        k.classifier_args = cargs.empty() ? nullptr : cargs.c_str();
         sh_reads_result r{};
         sh_status st = sh_kraken_run(&k, &r);
         if (st != SH_OK) { fprintf(stderr, "error (%d): %s\n", st, sh_last_error()); return 1; }

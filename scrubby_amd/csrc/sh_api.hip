@@ -62,14 +62,26 @@ extern "C" sh_status sh_preset(const char *name, sh_opts *o)
         return SH_OK;
     }
     if (n == "map-ont") { o->k = 15; o->w = 10; return SH_OK; }
-    if (n == "lr:hq") { o->k = 19; o->w = 19; o->max_gap = 10000; o->min_mid_occ = 50; o->max_mid_occ = 500; return SH_OK; }
+    if (n == "lr:hq" || n == "map-hifi") {      // Preset::LrHq / Preset::MapHifi, cleaner.rs:458,465: one sketch and chaining set-up ...
+        o->k = 19; o->w = 19; o->max_gap = 10000; o->min_mid_occ = 50; o->max_mid_occ = 500;
+        if (n == "map-hifi") {                  // ... map-hifi adds its own alignment scores and a higher dp_max floor (extension stage)
+            o->a = 1; o->b = 4; o->q = 6; o->q2 = 26; o->e = 2; o->e2 = 1; o->min_dp_max = 200;
+        }
+        return SH_OK;
+    }
     if (n == "lr") {   // ScrubbyError::Minimap2PresetNotSupported(Preset::Lr), cleaner.rs:469
         sh_set_error("Minimap2 preset not supported: lr");
         return SH_ERR_PRESET_UNSUPPORTED;
     }
-    static const char *later[] = {"asm", "asm5", "asm10", "asm20", "ava-ont", "ava-pb", "map-hifi", "map-pb", "splice", "splice:hq"};
+    static const char *later[] = {"asm", "asm5", "asm10", "asm20", "ava-ont", "ava-pb", "map-pb", "splice", "splice:hq"};
     for (const char *l : later)
-        if (n == l) { sh_set_error("preset %s: chaining variant (RMQ / splice / all-vs-all) not implemented on the HIP path yet", name); return SH_ERR_PRESET_UNSUPPORTED; }
+        if (n == l) {
+            sh_set_error("preset %s: %s not implemented on the HIP path yet", name,
+                         n == "map-pb" || n == "ava-pb" ? "homopolymer-compressed minimizers (MM_I_HPC: variable k-mer spans in sketch and chain)" :
+                         n.rfind("splice", 0) == 0 ? "splice-aware chaining and alignment" :
+                         n.rfind("ava", 0) == 0 ? "all-vs-all overlap mode" : "RMQ chaining (MM_F_RMQ)");
+            return SH_ERR_PRESET_UNSUPPORTED;
+        }
     sh_set_error("unknown preset: %s", name);
     return SH_ERR_PRESET_UNKNOWN;
 }

@@ -33,7 +33,12 @@ class FastxReader {
     {
         out.clear();
         for (;;) {
-            if (!gzgets(f_, buf_.data(), (int)buf_.size())) { eof_ = true; return !out.empty(); }
+            if (!gzgets(f_, buf_.data(), (int)buf_.size())) {
+                int e = Z_OK;
+                const char *msg = gzerror(f_, &e);       // a truncated .gz ends with Z_BUF_ERROR, not with a clean end of stream
+                if (e != Z_OK && e != Z_STREAM_END) error = std::string("read error: ") + (msg && *msg ? msg : "truncated gzip stream");
+                eof_ = true; return !out.empty();
+            }
             size_t n = strlen(buf_.data());
             out.append(buf_.data(), n);
             if (n && out.back() == '\n') { out.pop_back(); if (!out.empty() && out.back() == '\r') out.pop_back(); return true; }
@@ -49,7 +54,8 @@ public:
     {
         std::string l;
         if (have_pending_) { l = pending_; have_pending_ = false; }
-        else { do { if (!getline(l)) return 0; } while (l.empty()); }
+        else { do { if (!getline(l)) return error.empty() ? 0 : -1; } while (l.empty()); }
+        if (!error.empty()) return -1;
         if (l[0] == '@') {
             r.fastq = true; r.header = l.substr(1);
             std::string plus;
@@ -63,7 +69,7 @@ public:
                 if (!l.empty() && l[0] == '>') { pending_ = l; have_pending_ = true; break; }
                 r.seq += l;
             }
-            return 1;
+            return error.empty() ? 1 : -1;
         }
         error = "not a FASTA/FASTQ record: " + l.substr(0, 40);
         return -1;
@@ -273,7 +279,7 @@ sh_status shi_write_report_json(const char *const *input, const char *const *out
     o += "    \"index\": " + opt(st.index) + ",\n";
     o += "    \"alignment\": " + opt(st.alignment) + ",\n    \"reads\": " + opt(st.reads) + ",\n    \"report\": " + opt(st.report) + ",\n";
     o += "    \"taxa\": " + strs(st.taxa) + ",\n    \"taxa_direct\": " + strs(st.taxa_direct) + ",\n";
-    o += "    \"classifier_args\": null,\n    \"aligner_args\": null,\n";
+    o += "    \"classifier_args\": " + opt(st.classifier_args) + ",\n    \"aligner_args\": null,\n";
     o += "    \"preset\": " + opt(st.preset_variant) + ",\n";
     o += "    \"min_len\": " + std::to_string(st.min_len) + ",\n    \"min_cov\": " + json_f64(st.min_cov) + ",\n    \"min_mapq\": " + std::to_string(st.min_mapq) + ",\n";
     o += std::string("    \"extract\": ") + (st.extract ? "true" : "false") + "\n  }\n}";
@@ -662,8 +668,10 @@ static bool gz_lines(const char *path, std::vector<std::string> &lines)
         if (!cur.empty() && cur.back() == '\n') { cur.pop_back(); if (!cur.empty() && cur.back() == '\r') cur.pop_back(); lines.push_back(cur); cur.clear(); }
     }
     if (!cur.empty()) lines.push_back(cur);
-    gzclose(f);
-    return true;
+    int e = Z_OK;
+    gzerror(f, &e);
+    const bool clean = e == Z_OK || e == Z_STREAM_END;      // Z_BUF_ERROR: the .gz stops in the middle of its stream
+    return gzclose(f) == Z_OK && clean;
 }
 
 static sh_status alignment_ids(const char *path, const char *format, uint64_t min_len, double min_cov, uint32_t min_mapq, std::unordered_set<std::string> &ids)
@@ -681,7 +689,7 @@ static sh_status alignment_ids(const char *path, const char *format, uint64_t mi
     bool exists;
     if (file_is_empty(path, exists)) { SH_CHECK(exists, SH_ERR_IO, "cannot open %s", path); return SH_OK; }
     std::vector<std::string> lines;
-    SH_CHECK(gz_lines(path, lines), SH_ERR_IO, "cannot open %s", path);
+    SH_CHECK(gz_lines(path, lines), SH_ERR_IO, "cannot read %s (missing, or a truncated gzip stream)", path);
     if (fmt == "txt") { for (auto &l : lines) ids.insert(l); return SH_OK; }       // one id per line, verbatim
     for (auto &l : lines) {
         auto f = split_tab(l);

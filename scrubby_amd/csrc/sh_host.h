@@ -8,6 +8,7 @@ struct ReportSettings {       // ScrubbySettings, /root/reference/src/report.rs:
     std::vector<std::string> taxa, taxa_direct;
     uint64_t min_len = 0; double min_cov = 0.0; uint32_t min_mapq = 0;
     bool extract = false;
+    const char *classifier_args = nullptr;
 };
 
 // ScrubbyReport JSON (report.rs:10-88)

@@ -311,7 +311,14 @@ public:
                 const unsigned want = (unsigned)std::min<size_t>(cap - c.len, 1u << 30);
                 const int got = gzread(f_, c.data + c.len, want);
                 if (got < 0) { int e; error = std::string("read error: ") + gzerror(f_, &e); return -1; }
-                if ((unsigned)got < want) eof_ = true;
+                if ((unsigned)got < want) {
+                    // a short read is the end of the stream only if zlib says so: a truncated .gz stops short with Z_BUF_ERROR
+                    // ("unexpected end of file") and would otherwise give a silently partial output (the reference's reader errors)
+                    int e = Z_OK;
+                    const char *msg = gzerror(f_, &e);
+                    if (e != Z_OK && e != Z_STREAM_END) { error = std::string("read error: ") + (msg && *msg ? msg : "truncated gzip stream"); return -1; }
+                    eof_ = true;
+                }
                 c.len += (size_t)got;
             }
             size_t consumed = 0;
@@ -1331,7 +1338,14 @@ extern "C" sh_status sh_kraken_run(const sh_kraken_config *c, sh_reads_result *r
     res->n_depleted_ids = dep.size();
 
     // ---- clean_reads over the retained chunks ----
-    const bool want_dropped = c->read_ids && c->extract;
+    if (c->read_ids) {
+        const std::string p = c->read_ids;
+        SH_CHECK(!(ends_with(p, ".bz") || ends_with(p, ".bz2") || ends_with(p, ".lzma") || ends_with(p, ".xz")), SH_ERR_IO,
+                 "bzip2/xz output not supported by the HIP backend: %s", c->read_ids);
+    }
+    // the id table lists the input records MISSING from the outputs (ReadDifference, utils.rs:265-279), not the depletion set: a pair id
+    // with its "/1" stripped may match no record at all
+    const bool want_dropped = c->read_ids != nullptr;
     FileFilter ff[2];
     sh_status fst[2] = {SH_OK, SH_OK};
     std::string ferr[2];
@@ -1353,17 +1367,14 @@ extern "C" sh_status sh_kraken_run(const sh_kraken_config *c, sh_reads_result *r
     res->reads_extracted = c->extract ? rin - rout : 0;
     if (c->read_ids) {
         std::string body = "id\n";
-        if (!c->extract) dep.for_each([&](const char *s, uint32_t n) { body.append(s, n); body += '\n'; });
-        else {
-            IdSet uniq;
-            for (uint32_t i = 0; i < c->n_files; ++i)
-                for (auto &s : ff[i].dropped)
-                    if (uniq.insert(s.data(), (uint32_t)s.size())) { body += s; body += '\n'; }
-        }
+        IdSet uniq;
+        for (uint32_t i = 0; i < c->n_files; ++i)
+            for (auto &s : ff[i].dropped)
+                if (uniq.insert(s.data(), (uint32_t)s.size())) { body += s; body += '\n'; }
         SH_CHECK(write_id_table(c->read_ids, body), SH_ERR_IO, "cannot write %s", c->read_ids);
     }
     if (c->json) {
-        rs.classifier = "kraken2"; rs.index = c->db; rs.extract = c->extract != 0;
+        rs.classifier = "kraken2"; rs.classifier_args = c->classifier_args && c->classifier_args[0] ? c->classifier_args : nullptr; rs.index = c->db; rs.extract = c->extract != 0;
         st = shi_write_report_json(c->input, c->output, c->n_files, c->command, rs, res, c->json);
         if (st != SH_OK) return st;
     }

@@ -37,7 +37,7 @@ class KrakenConfig(C.Structure):
                 ("taxa_direct", C.POINTER(C.c_char_p)), ("n_taxa_direct", C.c_uint32),
                 ("confidence", C.c_double), ("min_hit_groups", C.c_int32),
                 ("json", C.c_char_p), ("read_ids", C.c_char_p), ("command", C.c_char_p),
-                ("device", C.c_int32), ("threads", C.c_int32)]
+                ("device", C.c_int32), ("threads", C.c_int32), ("classifier_args", C.c_char_p)]
 
 
 RESULT_DTYPE = np.dtype([("taxid", "<u4"), ("call", "<u4"), ("total_kmers", "<u4"), ("hit_groups", "<u4")])
@@ -166,7 +166,7 @@ class K2Db:
 
 
 def kraken_run(inputs, outputs, db, taxa=(), taxa_direct=(), workdir=None, confidence=-1.0, min_hit_groups=0, extract=False,
-               json=None, read_ids=None, command="", device=0, threads=4):
+               json=None, read_ids=None, command="", device=0, threads=4, classifier_args=None):
     c = KrakenConfig()
     for i, (a, b) in enumerate(zip(inputs, outputs)):
         c.input[i], c.output[i] = str(a).encode(), str(b).encode()
@@ -179,6 +179,7 @@ def kraken_run(inputs, outputs, db, taxa=(), taxa_direct=(), workdir=None, confi
     c.json = str(json).encode() if json else None
     c.read_ids = str(read_ids).encode() if read_ids else None
     c.command, c.device, c.threads = command.encode(), device, threads
+    c.classifier_args = classifier_args.encode() if classifier_args else None
     r = S.ReadsResult()
     S.check(S.load().sh_kraken_run(C.byref(c), C.byref(r)))
     return {n: getattr(r, n) for n, _ in S.ReadsResult._fields_}

@@ -43,7 +43,7 @@ def assert_trace_equal(S, gf, gt, of, ot):
 
 
 def test_presets_match_oracle(S, oracle):
-    for name in ("sr", "map-ont", "lr:hq"):
+    for name in ("sr", "map-ont", "lr:hq", "map-hifi"):
         g, o = S.preset(name), oracle.preset(name)
         for f, _ in S.Opts._fields_:
             assert getattr(g, f) == getattr(o, f), (name, f)
@@ -252,8 +252,8 @@ def test_gzip_reference_is_read_with_zlib_and_truncation_is_an_error(S, oracle, 
     assert not (tmp_path / "x.fa.gz").exists() and not os.path.exists("x.fa.gz")
 
 
-def _ont_like_reads(ref, n, seed, min_len=1200, max_len=30000):
-    """Long noisy reads: log-normal lengths, 2 % substitutions, 1.5 % insertions, 1.5 % deletions, either strand."""
+def _ont_like_reads(ref, n, seed, min_len=1200, max_len=30000, sub=0.02, indel=0.015):
+    """Long noisy reads: log-normal lengths, 2 % substitutions, 1.5 % insertions, 1.5 % deletions (defaults), either strand."""
     rng = np.random.default_rng(seed)
     comp = bytes.maketrans(b"ACGT", b"TGCA")
     acgt = b"ACGT"
@@ -268,11 +268,11 @@ def _ont_like_reads(ref, n, seed, min_len=1200, max_len=30000):
         out = bytearray()
         for c in src:
             u = rng.random()
-            if u < 0.015:
+            if u < indel:
                 continue
-            if u < 0.03:
+            if u < 2 * indel:
                 out.append(acgt[rng.integers(0, 4)])
-            out.append(acgt[rng.integers(0, 4)] if u > 0.98 else c)
+            out.append(acgt[rng.integers(0, 4)] if u > 1.0 - sub else c)
         b = bytes(out)
         recs.append(b.translate(comp)[::-1] if i % 2 else b)
     bases = np.frombuffer(b"".join(recs), dtype=np.uint8)
@@ -293,6 +293,27 @@ def test_long_reads_map_ont(S, oracle, cfg1):
     of, ot = cidx.classify(oo, bases, offs, threads=8)
     assert_trace_equal(S, gf, gt, of, ot)
     assert int(gf.sum()) == 48 and int(gf[4::5].sum()) == 0      # every reference-derived read maps, no random one does
+
+
+def test_long_reads_map_hifi_and_lr_hq(S, oracle, cfg1):
+    """Preset::MapHifi / Preset::LrHq (cleaner.rs:458,465): k = w = 19, max_gap 10000, mid_occ clamped to [50, 500]; accurate multi-kb reads."""
+    from scrubby_amd.lib import ScrubbyHipError
+    P, R, ref, seqs, reads, off = cfg1
+    recs, bases, offs = _ont_like_reads(ref, 40, 43, sub=0.005, indel=0.002)
+    for name in ("map-hifi", "lr:hq"):
+        go = S.preset(name)
+        assert (go.k, go.w, go.max_gap, go.min_mid_occ, go.max_mid_occ) == (19, 19, 10000, 50, 500)
+        gidx = S.Index.build([bytes(s) for s in seqs], go)
+        cidx = oracle.Index.build(seqs, 19, 19)
+        oo = cidx.update_opts(oracle.preset(name))
+        gf, gt, st, rc = gidx.classify(bases, offs, want_trace=True)
+        of, ot = cidx.classify(oo, bases, offs, threads=8)
+        assert_trace_equal(S, gf, gt, of, ot)
+        assert int(gf.sum()) == 32 and int(gf[4::5].sum()) == 0
+    assert S.preset("map-hifi").min_dp_max == 200 and S.preset("lr:hq").min_dp_max != 200
+    for name, why in (("map-pb", "homopolymer"), ("splice", "splice"), ("ava-ont", "all-vs-all"), ("asm5", "RMQ")):
+        with pytest.raises(ScrubbyHipError, match=why):
+            S.preset(name)
 
 
 def test_long_read_generator_device_matches_cpu(S, oracle):

@@ -173,3 +173,25 @@ def test_boundary_guess_is_verified(tmp_path):
     for mode in (2, 3):
         assert S.filter_fastx_stream(str(ok), str(out), ["r3"], False, chunk_bytes=100, threads=2, retain=mode) == cnt
         assert out.read_bytes() == ref.read_bytes()
+
+
+def test_truncated_gzip_is_an_error_not_a_short_file(tmp_path):
+    """A .gz cut off in the middle of its deflate stream must not pass as a clean end of file (the reference's reader errors):
+    the chunked reader (sh_stream.cpp ChunkReader) and the line reader (sh_host.cpp FastxReader) both report it."""
+    import gzip
+    import random
+    rng = random.Random(5)
+    recs = "".join(f"@r{i}\n{''.join(rng.choice('ACGT') for _ in range(100))}\n+\n{'I' * 100}\n" for i in range(3000))
+    whole = tmp_path / "whole.fastq.gz"
+    with gzip.open(whole, "wt") as f:
+        f.write(recs)
+    raw = whole.read_bytes()
+    assert S.filter_fastx_stream(str(whole), str(tmp_path / "o.fastq"), [], False, chunk_bytes=50000, threads=2) == (3000, 3000)
+    for cut in (len(raw) // 2, len(raw) - 9):         # mid-stream, and with only the CRC/length trailer missing
+        part = tmp_path / f"cut{cut}.fastq.gz"
+        part.write_bytes(raw[:cut])
+        for retain in (0, 1):
+            with pytest.raises(S.ScrubbyHipError, match="read error|truncated|unexpected end"):
+                S.filter_fastx_stream(str(part), str(tmp_path / "p.fastq"), [], False, chunk_bytes=50000, threads=2, retain=retain)
+        with pytest.raises(S.ScrubbyHipError, match="read error|truncated|unexpected end"):
+            S.filter_fastx(str(part), str(tmp_path / "q.fastq"), [], False)
