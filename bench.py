@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--k2-cells", type=int, default=2_000_000_000, help="cells of the compact hash table (4 B each)")
     ap.add_argument("--k2-nodes", type=int, default=50_000, help="taxonomy nodes of the synthetic database")
     ap.add_argument("--ont-chunk", type=int, default=200_000, help="long reads per launch (--workload ont)")
-    ap.add_argument("--e2e-threads", type=int, default=0, help="-t of `scrubby reads` for --workload e2e (0: min(16, cores))")
+    ap.add_argument("--e2e-threads", type=int, default=0, help="-t of `scrubby reads` for --workload e2e (0: the usable cores - physical, capped by the cgroup quota)")
     ap.add_argument("--e2e-gz", action="store_true", help="--workload e2e: write .fastq.gz outputs")
     ap.add_argument("--e2e-legacy", action="store_true", help="--workload e2e: also time the collect-then-map host path")
     ap.add_argument("--e2e-dir", default=None, help="--workload e2e: scratch directory (default: a temp dir)")
@@ -495,7 +495,7 @@ def main_k2(a, rank, world, local, dev):
         from oracle import oracle as O
         cells_h, parent_h, ext_h = db.export()
         tab = O.K2Table(cells_h, parent_h, info["value_bits"])
-        cores = os.cpu_count() or 1
+        cores = usable_cores()      # physical cores capped by the cgroup CPU quota
         n_s = min(n_rec, 200_000)
         sample = d_reads[: n_s * L].cpu().numpy()
         offs = np.arange(n_s + 1, dtype=np.uint64) * L
@@ -598,7 +598,7 @@ def main_e2e(a, rank, world, local, dev):
     t_setup = time.time() - t0
     ext = ".fastq.gz" if a.e2e_gz else ".fastq"
     o1, o2, js = os.path.join(work, "clean_1" + ext), os.path.join(work, "clean_2" + ext), os.path.join(work, "report.json")
-    threads = a.e2e_threads or min(16, os.cpu_count() or 4)
+    threads = a.e2e_threads or usable_cores()
 
     def run():
         for f in (o1, o2, js):          # a fresh run writes new files; truncating the previous run's 1.6 GB outputs costs ~0.4 s of page-cache work
@@ -689,7 +689,7 @@ def main_e2e_k2(a, rank, world, local, dev):
     torch.cuda.empty_cache()
     t_setup = time.time() - t0
     o1, o2, js, wd = (os.path.join(work, x) for x in ("clean_1.fastq", "clean_2.fastq", "report.json", "work"))
-    threads = a.e2e_threads or min(16, os.cpu_count() or 4)
+    threads = a.e2e_threads or usable_cores()
 
     def run():
         for f in (o1, o2, js):
@@ -798,12 +798,37 @@ def physical_cores():
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
 
+def cpu_quota():
+    """CPUs this process may actually use: the cgroup CPU quota (cpu.max of cgroup v2, cfs_quota of v1) if there is one - a GPU box
+    shows all 256 logical CPUs of its host but grants 16 - else None."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(int(q) / int(p)))
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, q // p)
+    except Exception:
+        pass
+    return None
+
+
+def usable_cores():
+    """threads worth starting: physical cores, capped by the cgroup quota (more threads than the quota only time-slice)"""
+    q = cpu_quota()
+    return min(physical_cores(), q) if q else physical_cores()
+
+
 def cpu_baseline(index, info, d_reads, n_rec, L, seconds, d_flags, d_off=None, preset="sr", chain_only=False):
     """The oracle (restated decision path incl. the extension stage; NOT minimap2-rs) on the host cores: ONE call over a large
     contiguous sample (threads pull 64-read chunks off an atomic counter, so every core works to the end), sized from a short
     calibration call to take about `seconds`.  Also a parity check: flags differing from the GPU's on the sample."""
     from oracle import oracle as O
-    cores, logical = physical_cores(), os.cpu_count() or 1
+    cores, logical = usable_cores(), os.cpu_count() or 1
     try:
         avail_gb = int(open("/proc/meminfo").read().split("MemAvailable:")[1].split()[0]) / 1e6
     except Exception:
@@ -838,8 +863,8 @@ def cpu_baseline(index, info, d_reads, n_rec, L, seconds, d_flags, d_off=None, p
     n_s = int(min(n_rec, max(n_cal, n_cal / max(dt_cal, 1e-6) * seconds)))
     dt, mism = run(0, n_s, cores)
     return {"value": round(n_s / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
-            "reads_per_s_per_thread": round(n_s / dt / cores, 1), "logical_cpus": logical,
-            "sample": f"first {n_s} records of the same batch in ONE call, same index and reference (copied from HBM), {cores} threads (one per physical core), {dt:.1f} s; "
+            "reads_per_s_per_thread": round(n_s / dt / cores, 1), "logical_cpus": logical, "physical_cores": physical_cores(), "cgroup_cpu_quota": cpu_quota(),
+            "sample": f"first {n_s} records of the same batch in ONE call, same index and reference (copied from HBM), {cores} threads (one per usable core: physical cores capped by the cgroup CPU quota), {dt:.1f} s; "
                       f"restatement baseline - not minimap2-rs; flags differing from the GPU on the sample: {mism}"}
 
 
@@ -873,7 +898,7 @@ def external_oracle(index, d_reads, n_rec, L, d_flags, contigs, P, dev, real_ref
         fq = os.path.join(work, "reads.fq")
         fastq_file(fq, reads, 1, 0)
         t0 = time.perf_counter()
-        out = subprocess.run([exe, "-c", "-x", "sr", "-t", str(physical_cores()), fa, fq], capture_output=True, check=True).stdout
+        out = subprocess.run([exe, "-c", "-x", "sr", "-t", str(usable_cores()), fa, fq], capture_output=True, check=True).stdout
         dt = time.perf_counter() - t0
         mapped = np.zeros(n, dtype=np.uint8)
         for ln in out.splitlines():
@@ -881,7 +906,7 @@ def external_oracle(index, d_reads, n_rec, L, d_flags, contigs, P, dev, real_ref
         gpu = (d_flags[:n].cpu().numpy() == 1).astype(np.uint8)
         return {"minimap2": "present", "version": subprocess.run([exe, "--version"], capture_output=True).stdout.decode().strip(),
                 "sample_reads": n, "mapped_by_minimap2": int(mapped.sum()), "mapped_by_gpu": int(gpu.sum()), "differ": int((mapped != gpu).sum()),
-                "reads_per_s_incl_index": round(n / dt, 1), "threads": physical_cores()}
+                "reads_per_s_incl_index": round(n / dt, 1), "threads": usable_cores()}
     finally:
         shutil.rmtree(work, ignore_errors=True)
 

@@ -191,7 +191,7 @@ typedef struct sh_reads_config {
     const char *json;         /* -j, nullable */
     const char *read_ids;     /* -r, nullable */
     const char *command;      /* argv joined by ' ' (terminal.rs:178), for the report */
-    int32_t     threads;      /* -t: host threads of the filter/compress stage (<= 0: 4, the reference's default) */
+    int32_t     threads;      /* -t: host threads of the parse / filter / deflate stages (> 0: as given; <= 0: the CPUs this process may use - hardware threads capped by the cgroup quota and by 64) */
     int32_t     device;
 } sh_reads_config;
 

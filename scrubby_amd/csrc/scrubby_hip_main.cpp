@@ -106,7 +106,7 @@ int main(int argc, char **argv)
     if (argc < 2 || std::string(argv[1]) != "reads") { usage(); return 2; }
     std::vector<std::string> in, out, taxa, taxa_direct;
     std::string index, preset, json, ids, aligner, classifier, workdir, cargs, command;
-    int extract = 0, threads = 4;
+    int extract = 0, threads = 0;      // 0: the CPUs this process may use (the deflate stage of .gz outputs scales with them)
     for (int i = 0; i < argc; ++i) { if (i) command += ' '; command += argv[i]; }      // terminal.rs:178
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i];

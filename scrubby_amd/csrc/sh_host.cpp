@@ -15,6 +15,7 @@
 #include <zlib.h>
 #include <sys/stat.h>
 #include <chrono>
+#include <thread>
 #include <ctime>
 #include <unordered_set>
 #include <algorithm>
@@ -123,6 +124,24 @@ public:
         put(o);
     }
 };
+
+int shi_default_threads()
+{
+    long n = (long)std::thread::hardware_concurrency();
+    if (n <= 0) n = 4;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {          // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[64]; long p = 0;
+        if (fscanf(f, "%63s %ld", q, &p) == 2 && strcmp(q, "max") != 0 && p > 0) n = std::min(n, std::max(1L, atol(q) / p));
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        long q = -1, p = 100000;
+        if (fscanf(g, "%ld", &q) != 1) q = -1;
+        fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%ld", &p) != 1) p = 100000; fclose(h); }
+        if (q > 0 && p > 0) n = std::min(n, std::max(1L, q / p));
+    }
+    return (int)std::min(n, 64L);
+}
 
 std::string json_escape(const std::string &s)
 {

@@ -14,6 +14,8 @@ struct ReportSettings {       // ScrubbySettings, /root/reference/src/report.rs:
 // ScrubbyReport JSON (report.rs:10-88)
 sh_status shi_write_report_json(const char *const *input, const char *const *output, uint32_t n_files, const char *command,
                                 const ReportSettings &st, const sh_reads_result *r, const char *path);
+// -t <= 0: the CPUs this process may use (hardware threads, capped by the cgroup CPU quota and by 64)
+int shi_default_threads();
 // Preset's serde name ("Sr", "MapOnt", ...) from its Display form
 const char *shi_preset_variant(const std::string &display);
 // collect-then-map form of the whole path (sh_host.cpp)

@@ -1047,7 +1047,7 @@ extern "C" sh_status sh_reads_run(const sh_reads_config *c, sh_reads_result *res
     memset(res, 0, sizeof(*res));
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    const int threads = c->threads > 0 ? c->threads : 4;
+    const int threads = c->threads > 0 ? c->threads : shi_default_threads();
     const size_t chunk_bytes = env_mb("SCRUBBY_HIP_CHUNK_MB", 64ull << 20);
     const size_t budget = retain_budget();
 
@@ -1210,7 +1210,7 @@ extern "C" sh_status sh_kraken_run(const sh_kraken_config *c, sh_reads_result *r
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const bool paired = c->n_files == 2;
-    const int threads = c->threads > 0 ? c->threads : 4;
+    const int threads = c->threads > 0 ? c->threads : shi_default_threads();
     const size_t chunk_bytes = env_mb("SCRUBBY_HIP_CHUNK_MB", 64ull << 20);
 
     const auto t0 = now();
