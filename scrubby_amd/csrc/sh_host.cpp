@@ -125,24 +125,6 @@ public:
     }
 };
 
-int shi_default_threads()
-{
-    long n = (long)std::thread::hardware_concurrency();
-    if (n <= 0) n = 4;
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {          // cgroup v2: "<quota> <period>" or "max <period>"
-        char q[64]; long p = 0;
-        if (fscanf(f, "%63s %ld", q, &p) == 2 && strcmp(q, "max") != 0 && p > 0) n = std::min(n, std::max(1L, atol(q) / p));
-        fclose(f);
-    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
-        long q = -1, p = 100000;
-        if (fscanf(g, "%ld", &q) != 1) q = -1;
-        fclose(g);
-        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%ld", &p) != 1) p = 100000; fclose(h); }
-        if (q > 0 && p > 0) n = std::min(n, std::max(1L, q / p));
-    }
-    return (int)std::min(n, 64L);
-}
-
 std::string json_escape(const std::string &s)
 {
     std::string o;
@@ -186,6 +168,25 @@ sh_status filter_fastx(const char *in, const char *out, const std::unordered_set
 }
 
 }  // namespace
+
+int shi_default_threads()
+{
+    long n = (long)std::thread::hardware_concurrency();
+    if (n <= 0) n = 4;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {          // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[64]; long p = 0;
+        if (fscanf(f, "%63s %ld", q, &p) == 2 && strcmp(q, "max") != 0 && p > 0) n = std::min(n, std::max(1L, atol(q) / p));
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        long q = -1, p = 100000;
+        if (fscanf(g, "%ld", &q) != 1) q = -1;
+        fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%ld", &p) != 1) p = 100000; fclose(h); }
+        if (q > 0 && p > 0) n = std::min(n, std::max(1L, q / p));
+    }
+    return (int)std::min(n, 64L);
+}
+
 
 const char *shi_preset_variant(const std::string &display) { return preset_variant(display); }
 
