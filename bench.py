@@ -299,19 +299,7 @@ def main_reads(a, rank, world, local, dev, backend):
         "streaming_kernel": {"kernel": "k_sketch_probe", "achieved": round(k1_bytes / (k1_ms * 1e-3) / 1e9, 1) if k1_ms > 0 else None,
                              "frac": round(k1_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k1_ms > 0 else None},
     }
-    traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
-    if os.path.exists(traffic_file) and not a.small:
-        try:
-            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts"))
-            from make_traffic import source_hash
-            tj = json.load(open(traffic_file))
-            if tj.get("source_sha1") != source_hash():
-                roofline["traffic_source"] = "profiles/traffic.json is stale (measured on other kernel sources): refused"
-            elif tj.get("records_per_launch") == ctx_chunk(a, n_rec) and dom in tj.get("stages", {}):
-                roofline["traffic"] = tj["stages"][dom]["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, raw; same kernel sources: sha1 " + tj["source_sha1"][:12] + ")"
-        except Exception as ex:
-            roofline["traffic_source"] = f"profiles/traffic.json unreadable: {ex}"
+    attach_traffic(roofline, "ont" if ont else "sr", dom, ctx_chunk(a, n_rec), skip=a.small)
 
     gather = None
     if a.gather_bench and rank == 0:
@@ -490,6 +478,7 @@ def main_k2(a, rank, world, local, dev):
             "frac": round(alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "launches_per_step": 1, "avg_launch_ms": round(avg_ms, 3),
             "alg_bytes_per_launch": int(alg), "probes_per_launch": int(st["n_probes"]),
             "probe_rate_G_per_s": round(st["n_probes"] / (avg_ms * 1e-3) / 1e9, 2)}
+    attach_traffic(roof, "k2", "k_k2_classify", n_rec)
     cpu = None
     if rank == 0 and not a.no_cpu:
         from oracle import oracle as O
@@ -796,6 +785,28 @@ def physical_cores():
     except Exception:
         pass
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
+def attach_traffic(roofline, workload, stage, records_per_launch, skip=False):
+    """roofline.traffic from profiles/traffic[_<workload>].json (scripts/make_traffic.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    command), only if it was measured on the kernel sources this library was built from and at this launch size."""
+    name = "traffic.json" if workload == "sr" else f"traffic_{workload}.json"
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+    if skip or not os.path.exists(path):
+        return
+    try:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts"))
+        from make_traffic import source_hash
+        tj = json.load(open(path))
+        if tj.get("source_sha1") != source_hash(workload):
+            roofline["traffic_source"] = f"profiles/{name} is stale (measured on other kernel sources): refused"
+        elif tj.get("records_per_launch") != records_per_launch:
+            roofline["traffic_source"] = f"profiles/{name} was measured at {tj.get('records_per_launch')} records per launch, this run uses {records_per_launch}: refused"
+        elif stage in tj.get("stages", {}):
+            roofline["traffic"] = tj["stages"][stage]["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, raw; same kernel sources: sha1 " + tj["source_sha1"][:12] + ")"
+    except Exception as ex:
+        roofline["traffic_source"] = f"profiles/{name} unreadable: {ex}"
 
 
 def cpu_quota():

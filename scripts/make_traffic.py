@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """profiles/traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; kernel-trace only) of ONE bench step.
 
-usage: make_traffic.py <fetch_dir> <write_dir> <records_per_launch> <out.json>
+usage: make_traffic.py <fetch_dir> <write_dir> <records_per_launch> <out.json> [sr|ont|k2] [launches_in_the_profiled_step]
+(one file per workload: profiles/traffic.json for the headline, traffic_ont.json, traffic_k2.json)
 Counter values are KiB (x 1024 -> bytes), summed per bench stage.  Calibration for this path's access pattern, as
 MI355X_MICROARCH.md (HBM section) asks for widths other than wide streams: `scripts/pmc_gather_calib.sh` runs the gather
 micro-benchmark (a known number of random 16-B slot loads over the index table) under the same counter and finds exactly 64.0 B
@@ -11,22 +12,24 @@ for the gathers and a lower bound by at most that amount overall."""
 import csv, glob, hashlib, json, os, sys, collections
 
 KERNEL_SOURCES = ("sh_classify.hip", "sh_sketch.h", "sh_chain.h", "sh_align.h")
+K2_SOURCES = ("sh_k2.hip",)
 
 
-def source_hash():
+def source_hash(workload="sr"):
     """sha1 over the kernel sources the counters belong to: bench.py refuses a traffic.json measured on other code."""
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scrubby_amd", "csrc")
     h = hashlib.sha1()
-    for f in KERNEL_SOURCES:
+    for f in (K2_SOURCES if workload == "k2" else KERNEL_SOURCES):
         h.update(open(os.path.join(root, f), "rb").read())
     return h.hexdigest()
 
 
-STAGES = {
-    "k_sketch_probe": ("k_sketch_probe",),
-    "k_chain_small": ("k_chain_small",),
-    "repeat path (k_expand + k_sort_lds* + k_sort + k_finalize)": ("k_expand", "k_sort_lds", "k_giant", "k_cluster_dp", "k_finalize", "k_chain_large"),
+STAGES = {      # bench.py's stage names -> kernel name prefixes
+    "k_sketch_probe": ("k_sketch_probe", "k_long_"),      # long reads: the segment-parallel front end stands where K1 does
+    "k_chain_small": ("k_chain_small", "k_pair_pass"),
+    "repeat path (k_expand + k_sort_lds* + k_sort + k_finalize)": ("k_local_cluster", "k_expand", "k_group_probe", "k_sort_lds", "k_giant", "k_cluster_dp", "k_finalize", "k_chain_large"),
     "extension stage (k_ext_* + k_regs_align)": ("k_ext_", "k_regs_align"),
+    "k_k2_classify": ("k_k2_classify",),
 }
 
 
@@ -45,14 +48,23 @@ def collect(d, counter):
     return acc, kern
 
 
-fd, wd, n_rec, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-fe, fk = collect(fd, "FETCH_SIZE")
-we, wk = collect(wd, "WRITE_SIZE")
-doc = {"comment": __doc__.split("\n\n")[1].replace("\n", " "), "records_per_launch": n_rec, "source_sha1": source_hash(), "stages": {}, "kernels": {}}
-for st in STAGES:
-    doc["stages"][st] = {"fetch": fe[st], "write": we[st], "hbm_bytes_per_launch": fe[st] + we[st]}
-for k in sorted(set(fk) | set(wk)):
-    doc["kernels"][k] = {"fetch": fk.get(k, 0.0), "write": wk.get(k, 0.0)}
-json.dump(doc, open(out, "w"), indent=1)
-for st, v in doc["stages"].items():
-    print(f"{st[:40]:40s} fetch {v['fetch'] / 1e9:8.2f} GB  write {v['write'] / 1e9:8.2f} GB")
+def main():
+    fd, wd, n_rec, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    workload = sys.argv[5] if len(sys.argv) > 5 else "sr"
+    launches = int(sys.argv[6]) if len(sys.argv) > 6 else 1      # launches the profiled step made (long reads: records / --ont-chunk)
+    fe, fk = collect(fd, "FETCH_SIZE")
+    we, wk = collect(wd, "WRITE_SIZE")
+    doc = {"comment": __doc__.split("\n\n")[1].replace("\n", " "), "workload": workload, "records_per_launch": n_rec,
+           "source_sha1": source_hash(workload), "stages": {}, "kernels": {}}
+    for st in STAGES:
+        if fe[st] + we[st] > 0:
+            doc["stages"][st] = {"fetch": fe[st], "write": we[st], "launches": launches, "hbm_bytes_per_launch": (fe[st] + we[st]) / launches}
+    for k in sorted(set(fk) | set(wk)):
+        doc["kernels"][k] = {"fetch": fk.get(k, 0.0), "write": wk.get(k, 0.0)}
+    json.dump(doc, open(out, "w"), indent=1)
+    for st, v in doc["stages"].items():
+        print(f"{st[:40]:40s} fetch {v['fetch'] / 1e9:8.2f} GB  write {v['write'] / 1e9:8.2f} GB")
+
+
+if __name__ == "__main__":
+    main()
