@@ -344,7 +344,9 @@ def main_reads(a, rank, world, local, dev, backend):
                              ("configs[2]: the 10M synthetic 2x150bp PE (20M records) of configs[1], read-sharded over %d GPUs, vs CHM13v2-sized synthetic reference, sr preset" % world) if world > 1 else
                              "configs[1]: 10M synthetic 2x150bp PE (20M records) vs CHM13v2-sized synthetic reference, sr preset, k-mer/minimizer classifier path"),
                 "records_total": n_total, "records_rank0": n_rec, "read_len": (round(n_bases / n_rec, 1) if ont else L), "host_pct": R.host_pct, "reference_bp": int(G),
-                "preset": "map-ont" if ont else "sr", "decision": "chain level (no extension stage)" if a.chain_only else "mappings.len() > 0 after the extension filter (with_cigar)", "k": info["k"], "w": info["w"], "records_per_launch": ctx_chunk(a, n_rec),
+                "preset": "map-ont" if ont else "sr", "decision": ("chain level (--chain-only: no extension stage)" if a.chain_only else
+                                                                      "chain level: the extension filter is implemented for the short-read branch only (the library warns)" if ont else
+                                                                      "mappings.len() > 0 after the extension filter (with_cigar)"), "k": info["k"], "w": info["w"], "records_per_launch": ctx_chunk(a, n_rec),
                 "parallelism": f"read-sharded x{world} (contiguous pair-aligned ranges of the same records), index replicated",
                 "ref_seed": hex(REF_SEED), "read_seed": hex(R.seed),
             },
