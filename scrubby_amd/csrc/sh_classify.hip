@@ -2269,6 +2269,7 @@ __global__ __launch_bounds__(64) void k_regs_align(ExtArgs a)
 // ------------------------------------------------------------------------------------------------
 struct sh_ctx {
     const sh_index *idx = nullptr;
+    int idx_device = 0;
     sh_opts opts{};
     ChainParams P{};
     uint64_t max_reads = 0, max_bases = 0;
@@ -2346,6 +2347,27 @@ static void fill_align_params(const sh_opts &o, AlignParams &A)
 
 static bool w_supported(int w) { return w == 5 || w == 10 || w == 11 || w == 19; }
 
+// A context built for one index serves another of the same shape (same device, k, w, occurrence thresholds resolved the same way):
+// only the index pointer and the occurrence cut-off taken from it change.  The streaming host path keeps its context between runs
+// this way (sh_stream.cpp): the reference rebuilds the index on every run, but re-creating ~35 GB of scratch each time means waiting
+// for the driver to wipe the memory the previous run has just freed (seconds, not the ~60 ms of a first allocation).
+sh_status shi_ctx_rebind(sh_ctx *c, const sh_index *idx)
+{
+    SH_CHECK(c && idx, SH_ERR_BAD_ARG, "shi_ctx_rebind: null argument");
+    SH_CHECK(idx->device == c->idx_device && idx->k == c->opts.k && idx->w == c->opts.w, SH_ERR_BAD_ARG, "shi_ctx_rebind: index of another shape");
+    SH_CHECK(!c->ext || (idx->d_ref && idx->d_cstart), SH_ERR_INDEX, "shi_ctx_rebind: this index holds no reference bases");
+    SH_CHECK(c->opts.mid_occ > 0 || (idx->o_mid_occ <= 0 && idx->o_min_mid_occ == c->opts.min_mid_occ && idx->o_max_mid_occ == c->opts.max_mid_occ && idx->o_mid_occ_frac == c->opts.mid_occ_frac),
+             SH_ERR_BAD_ARG, "shi_ctx_rebind: the index resolved its occurrence threshold under other parameters");
+    c->idx = idx;
+    const int32_t mid_occ = c->opts.mid_occ > 0 ? c->opts.mid_occ : idx->mid_occ;
+    fill_chain_params(c->opts, mid_occ, c->P);
+    c->AP.lemma = c->P.ext_lemma; c->AP.unc_max = c->P.ext_unc_max;
+    return SH_OK;
+}
+uint64_t shi_ctx_max_reads(const sh_ctx *c) { return c->max_reads; }
+uint64_t shi_ctx_max_bases(const sh_ctx *c) { return c->max_bases; }
+uint32_t shi_ctx_max_len(const sh_ctx *c) { return c->max_read_len; }
+
 extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uint64_t max_reads, uint64_t max_bases,
                                    uint32_t max_read_len, sh_ctx **out)
 {
@@ -2358,7 +2380,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
              idx->o_min_mid_occ, idx->o_max_mid_occ, (double)idx->o_mid_occ_frac, opts->min_mid_occ, opts->max_mid_occ, (double)opts->mid_occ_frac);
     SH_HIP(hipSetDevice(idx->device));
     sh_ctx *c = new sh_ctx();
-    c->idx = idx; c->opts = *opts; c->max_reads = max_reads; c->max_bases = max_bases; c->max_read_len = max_read_len;
+    c->idx = idx; c->idx_device = idx->device; c->opts = *opts; c->max_reads = max_reads; c->max_bases = max_bases; c->max_read_len = max_read_len;
     int32_t mid_occ = opts->mid_occ > 0 ? opts->mid_occ : idx->mid_occ;
     fill_chain_params(*opts, mid_occ, c->P);
     fill_align_params(*opts, c->AP);

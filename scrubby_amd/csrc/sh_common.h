@@ -89,3 +89,9 @@ void shi_batch_pool_release(sh_index *idx);
 sh_status shi_index_build_fasta_host(const char *path, const sh_opts *opts, int32_t device, sh_index **out);
 sh_status shi_index_build_device(const uint8_t *d_bases, const uint64_t *contig_starts, uint32_t n_contigs,
                                  const sh_opts *opts, int32_t device, hipStream_t stream, sh_index **out);
+
+// sh_classify.hip: a context re-pointed at another index of the same shape (the streaming host path keeps one between runs)
+sh_status shi_ctx_rebind(sh_ctx *c, const sh_index *idx);
+uint64_t shi_ctx_max_reads(const sh_ctx *c);
+uint64_t shi_ctx_max_bases(const sh_ctx *c);
+uint32_t shi_ctx_max_len(const sh_ctx *c);

@@ -729,6 +729,46 @@ public:
     void stop() { std::lock_guard<std::mutex> lk(mu_); abort_ = true; cv_.notify_all(); }
 };
 
+// dst[i] = src[i] + add: a chunk's read offsets moved to its place in a concatenated batch
+__global__ void k_rebase_offsets(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, uint64_t n, uint64_t add)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] + add;
+}
+
+// The context the last run left behind (one per process): taken by the next run if it was built with the same options and is large
+// enough, re-pointed at that run's index (shi_ctx_rebind).  Freed only at process exit, by the driver.
+struct CtxCache {
+    std::mutex mu;
+    sh_ctx *ctx = nullptr;
+    sh_opts opts{};
+    std::string env;          // the environment switches a context captures when it is created
+    static std::string env_sig()
+    {
+        std::string e;
+        for (const char *v : {"SCRUBBY_HIP_ARENA_MB", "SCRUBBY_HIP_NO_FLAG_STOP", "SCRUBBY_HIP_NO_PAIR", "SCRUBBY_HIP_PAIR_MIN", "SCRUBBY_HIP_NO_S1", "SCRUBBY_HIP_NO_LEMMA", "SCRUBBY_HIP_EXT_MB", "SCRUBBY_HIP_DBG"}) {
+            const char *x = getenv(v); e += x ? x : "-"; e += '|';
+        }
+        return e;
+    }
+    sh_ctx *take(const sh_opts &o, const sh_index *idx)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!ctx) return nullptr;
+        sh_ctx *c = ctx;
+        ctx = nullptr;
+        if (memcmp(&opts, &o, sizeof(o)) != 0 || env != env_sig() || shi_ctx_rebind(c, idx) != SH_OK) { sh_ctx_destroy(c); return nullptr; }
+        return c;
+    }
+    void give(sh_ctx *c, const sh_opts &o)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (ctx) sh_ctx_destroy(ctx);
+        ctx = c; opts = o; env = env_sig();
+    }
+};
+CtxCache g_ctx_cache;
+
 // the device thread's side of pass 1: one context (minimap2's thread buffer), one stream; kernels and the flags' way back
 struct DeviceSide {
     const sh_index *idx;
@@ -740,26 +780,92 @@ struct DeviceSide {
 
     ~DeviceSide()
     {
-        if (ctx) sh_ctx_destroy(ctx);
+        if (ctx) g_ctx_cache.give(ctx, opts);
         if (s) hipStreamDestroy(s);
+        if (cat_bases) hipFree(cat_bases);
+        if (cat_off) hipFree(cat_off);
+        if (cat_flags) hipFree(cat_flags);
     }
+    // A context for 4 Mi short reads holds ~35 GB; creating one costs ~0.6 s (the driver wipes HBM it hands out), so it must not grow in
+    // small steps: the first one is sized from the input files (hint_reads, set by the caller), a later one at least 4x its predecessor.
+    uint64_t hint_reads = 0;
+    bool tried_cache = false;
+    sh_status ensure_ctx(uint64_t n, uint64_t nb, uint32_t max_len)
+    {
+        if (!s) SH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        if (!ctx && !tried_cache) {
+            tried_cache = true;
+            ctx = g_ctx_cache.take(opts, idx);
+            if (ctx) { ctx_reads = shi_ctx_max_reads(ctx); ctx_bases = shi_ctx_max_bases(ctx); ctx_len = shi_ctx_max_len(ctx); }
+        }
+        if (!ctx || n > ctx_reads || nb > ctx_bases || max_len > ctx_len) {
+            if (ctx) { sh_ctx_destroy(ctx); ctx = nullptr; }
+            const uint64_t avg = n ? (nb + n - 1) / n : 1;
+            uint64_t want = std::max<uint64_t>(n + n / 4 + 1024, std::min<uint64_t>(hint_reads, (5ull << 20)));
+            want = std::max<uint64_t>(want, std::min<uint64_t>(ctx_reads * 4, 5ull << 20));
+            const uint64_t base_cap = avg > 1024 ? (1ull << 30) : (5ull << 30);      // long reads: the front end's per-base buffers bound the batch
+            if (want * avg > base_cap) want = std::max<uint64_t>(n + n / 4 + 1024, base_cap / std::max<uint64_t>(avg, 1));
+            ctx_reads = std::max<uint64_t>(ctx_reads, want);
+            ctx_bases = std::max<uint64_t>(ctx_bases, std::max<uint64_t>(nb + nb / 4 + 4096, want * avg + want * avg / 8 + 4096));
+            ctx_len = std::max<uint32_t>(ctx_len, max_len <= 1024 ? std::max<uint32_t>(max_len, 256) : (uint32_t)std::min<uint64_t>((uint64_t)max_len * 5 / 4, UINT32_MAX));
+            const auto t0 = std::chrono::steady_clock::now();
+            sh_status st = sh_ctx_create(idx, &opts, ctx_reads, ctx_bases, ctx_len, &ctx);
+            ms_ctx += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            ++n_ctx;
+            if (st != SH_OK) return st;
+        }
+        return SH_OK;
+    }
+    double ms_ctx = 0; int n_ctx = 0;
     sh_status classify(Chunk &c)
     {
         const uint64_t n = c.recs.size(), nb = c.n_bases;
-        if (!s) SH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        if (!ctx || n > ctx_reads || nb > ctx_bases || c.max_len > ctx_len) {
-            if (ctx) { sh_ctx_destroy(ctx); ctx = nullptr; }
-            ctx_reads = std::max<uint64_t>(ctx_reads, n + n / 4 + 1024);
-            ctx_bases = std::max<uint64_t>(ctx_bases, nb + nb / 4 + 4096);
-            ctx_len = std::max<uint32_t>(ctx_len, c.max_len <= 1024 ? std::max<uint32_t>(c.max_len, 256) : (uint32_t)std::min<uint64_t>((uint64_t)c.max_len * 5 / 4, UINT32_MAX));
-            sh_status st = sh_ctx_create(idx, &opts, ctx_reads, ctx_bases, ctx_len, &ctx);
-            if (st != SH_OK) return st;
-        }
+        sh_status st = ensure_ctx(n, nb, c.max_len);
+        if (st != SH_OK) return st;
         c.flags.resize(n);
-        sh_status st = sh_classify_device(ctx, c.dev->d_bases, c.dev->d_off, n, nb, c.dev->d_flags, nullptr, s, nullptr);
+        st = sh_classify_device(ctx, c.dev->d_bases, c.dev->d_off, n, nb, c.dev->d_flags, nullptr, s, nullptr);
         if (st != SH_OK) return st;
         SH_HIP(hipMemcpyAsync(c.flags.data(), c.dev->d_flags, n, hipMemcpyDeviceToHost, s));
         SH_HIP(hipStreamSynchronize(s));
+        return SH_OK;
+    }
+    // Several chunks in ONE call: a call has a floor of tens of milliseconds whatever its size (the passes of the repeat path and of the
+    // extension stage synchronise with the host, and one satellite read's cluster is thousands of dependent DP steps), so the chunks that
+    // piled up while the previous call ran are concatenated in HBM (device-to-device copies, offsets rebased by a kernel) and classified
+    // together.  The slower the device side is relative to the parsers, the larger its batches get.
+    uint8_t *cat_bases = nullptr, *cat_flags = nullptr; uint64_t *cat_off = nullptr;
+    uint64_t cat_cap_bases = 0, cat_cap_reads = 0;
+    std::vector<uint8_t> h_flags;
+    sh_status classify_many(std::vector<std::shared_ptr<Chunk>> &v)
+    {
+        if (v.size() == 1) return classify(*v[0]);
+        uint64_t n = 0, nb = 0; uint32_t max_len = 0;
+        for (auto &c : v) { n += c->recs.size(); nb += c->n_bases; max_len = std::max(max_len, c->max_len); }
+        sh_status st = ensure_ctx(n, nb, max_len);
+        if (st != SH_OK) return st;
+        if (nb + 64 > cat_cap_bases) { if (cat_bases) hipFree(cat_bases); cat_bases = nullptr; cat_cap_bases = nb + nb / 4 + 64; SH_HIP(hipMalloc(&cat_bases, cat_cap_bases)); }
+        if (n + 1 > cat_cap_reads) {
+            if (cat_off) hipFree(cat_off);
+            if (cat_flags) hipFree(cat_flags);
+            cat_off = nullptr; cat_flags = nullptr;
+            cat_cap_reads = n + n / 4 + 1;
+            SH_HIP(hipMalloc(&cat_off, cat_cap_reads * 8));
+            SH_HIP(hipMalloc(&cat_flags, cat_cap_reads));
+        }
+        uint64_t r0 = 0, b0 = 0;
+        for (auto &c : v) {
+            const uint64_t ni = c->recs.size();
+            if (c->n_bases) SH_HIP(hipMemcpyAsync(cat_bases + b0, c->dev->d_bases, c->n_bases, hipMemcpyDeviceToDevice, s));
+            hipLaunchKernelGGL(k_rebase_offsets, dim3((uint32_t)((ni + 1 + 255) / 256)), dim3(256), 0, s, c->dev->d_off, cat_off + r0, ni + 1, b0);
+            r0 += ni; b0 += c->n_bases;
+        }
+        st = sh_classify_device(ctx, cat_bases, cat_off, n, nb, cat_flags, nullptr, s, nullptr);
+        if (st != SH_OK) return st;
+        h_flags.resize(n);
+        SH_HIP(hipMemcpyAsync(h_flags.data(), cat_flags, n, hipMemcpyDeviceToHost, s));
+        SH_HIP(hipStreamSynchronize(s));
+        r0 = 0;
+        for (auto &c : v) { const uint64_t ni = c->recs.size(); c->flags.assign(h_flags.begin() + r0, h_flags.begin() + r0 + ni); r0 += ni; }
         return SH_OK;
     }
 };
@@ -791,6 +897,15 @@ struct ChunkQueue {
         cv.notify_all();
         return c;
     }
+    std::shared_ptr<Chunk> try_pop()      // what is waiting right now, never blocks
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (q.empty()) return nullptr;
+        auto c = std::move(q.front());
+        q.pop_front();
+        cv.notify_all();
+        return c;
+    }
     void stop() { std::lock_guard<std::mutex> lk(mu); abort = true; cv.notify_all(); }
 };
 
@@ -814,7 +929,9 @@ struct Pass1 {
     sh_status err_st = SH_OK;
     std::string err_msg;
     ChunkQueue rawq, devq, foldq;
-    DevBufPool pool{6};
+    DevBufPool pool{24};         // chunks uploaded and waiting for the device thread: it classifies all of them in one call
+    uint64_t n_calls = 0;
+    double ms_ctx = 0; int n_ctx = 0;
 
     static std::chrono::steady_clock::time_point tick() { return std::chrono::steady_clock::now(); }
     static uint64_t us(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); }
@@ -939,7 +1056,8 @@ struct Pass1 {
         }
         rawq.cap = (size_t)n_parse + 2; rawq.producers = n_readers;
         const int n_fold = std::max(1, std::min(8, threads / 2));          // id-set inserts are cache-missy (~0.4 us each): with range readers they bound pass 1
-        devq.cap = 8; devq.producers = n_parse;          // the device-buffer pool is what bounds the chunks in flight
+        devq.cap = 32; devq.producers = n_parse;
+        const bool coalesce = !(getenv("SCRUBBY_HIP_NO_COALESCE") && *getenv("SCRUBBY_HIP_NO_COALESCE") == '1');          // the device-buffer pool is what bounds the chunks in flight
         foldq.cap = 8; foldq.producers = 1;
         std::vector<std::thread> thr;
         for (uint32_t i = 0; i < c->n_files; ++i)
@@ -948,23 +1066,43 @@ struct Pass1 {
         for (int t = 0; t < n_fold; ++t) thr.emplace_back([this] { folder(); });
         {
             DeviceSide dev{idx, opts};
+            if (coalesce) {        // records to expect, from the file sizes (~300 B of FASTQ per 150-base record; gzip ~4x): sizes the first context
+                uint64_t bytes = 0;
+                for (uint32_t i = 0; i < c->n_files; ++i) {
+                    struct stat sb;
+                    if (stat(c->input[i], &sb) == 0) bytes += (uint64_t)sb.st_size * (ends_with(c->input[i], ".gz") ? 4 : 1);
+                }
+                dev.hint_reads = bytes / 300;
+            }
             if (hipSetDevice(idx->device) != hipSuccess) set_err(SH_ERR_HIP, "hipSetDevice failed");
             for (;;) {
                 const auto w0 = tick();
                 auto ch = devq.pop();
                 us_dev_wait += us(w0, tick());
                 if (!ch) break;
+                std::vector<std::shared_ptr<Chunk>> batch{ch};
+                uint64_t bn = ch->recs.size(), bb = ch->n_bases;
+                while (coalesce && bn < (4ull << 20) && bb < (1ull << 30)) {      // whatever else has arrived, up to 4 Mi records / 1 GiB of bases a call
+                    auto more = devq.try_pop();
+                    if (!more) break;
+                    bn += more->recs.size(); bb += more->n_bases;
+                    batch.push_back(std::move(more));
+                }
                 if (!has_err()) {
                     const auto a = tick();
-                    const sh_status st = dev.classify(*ch);
+                    const sh_status st = dev.classify_many(batch);
                     classify_ms += us(a, tick()) / 1e3;
+                    ++n_calls;
                     if (st != SH_OK) set_err(st, sh_last_error());
                 }
-                pool.give(ch->dev);
-                ch->dev = nullptr;
-                if (!has_err()) foldq.push(ch);
+                for (auto &b : batch) {
+                    pool.give(b->dev);
+                    b->dev = nullptr;
+                    if (!has_err()) foldq.push(b);
+                }
             }
             foldq.producer_done();
+            ms_ctx = dev.ms_ctx; n_ctx = dev.n_ctx;
         }
         for (auto &t : thr) t.join();
         for (uint32_t i = 0; i < c->n_files; ++i) {
@@ -974,8 +1112,8 @@ struct Pass1 {
         }
         if (const char *e = getenv("SCRUBBY_HIP_DBG_HOST")) if (*e == '1')
             fprintf(stderr, "[scrubby-hip] pass 1 (%s): readers read %.0f ms, blocked on push %.0f ms | %d parse workers: parse %.0f ms, H2D %.0f ms, blocked %.0f ms | device thread: "
-                    "waiting %.0f ms, classify %.0f ms | %d fold threads: id set %.0f ms\n", parallel ? "cut + parallel parse" : "sequential parse", us_read / 1e3, us_rpush / 1e3, n_parse,
-                    us_parse / 1e3, us_h2d / 1e3, (us_ppush - us_h2d) / 1e3, us_dev_wait / 1e3, classify_ms, n_fold, us_ids / 1e3);
+                    "waiting %.0f ms, classify %.0f ms in %llu calls (of which %.0f ms creating %d contexts) | %d fold threads: id set %.0f ms\n", parallel ? "cut + parallel parse" : "sequential parse", us_read / 1e3, us_rpush / 1e3, n_parse,
+                    us_parse / 1e3, us_h2d / 1e3, (us_ppush - us_h2d) / 1e3, us_dev_wait / 1e3, classify_ms, (unsigned long long)n_calls, ms_ctx, n_ctx, n_fold, us_ids / 1e3);
         if (err_st != SH_OK) { if (err_st != SH_RETRY_SEQUENTIAL) sh_set_error("%s", err_msg.c_str()); return err_st; }
         return SH_OK;
     }
