@@ -139,9 +139,9 @@ struct RegLite {            // mm_reg1_t, the fields the decision reads
 
 #define AL_Q 320            // reads up to this length keep their codes and reference window in LDS
 #define AL_T (2 * AL_Q + 96)
-#define AL_T16 640          // ksw buffers in LDS up to this many target bases (rounded to 16) ...
+#define AL_T16 448          // ksw buffers in LDS up to this many target bases (rounded to 16) ...
 #define AL_Q16 336          // ... and this many query bases
-#define AL_P 24576          // ... and this many direction bytes
+#define AL_P 4096            // ... and this many direction bytes (measured: 24576 -> 72 ms for the bench's 66 k alignments at 3 waves/CU, 4096 -> 33 ms at 8: occupancy beats LDS residency)
 #define AL_R 64             // chains of a read kept in LDS
 #define AL_PRI 256          // primaries mm_set_parent may find (a 150-bp read has a handful)
 

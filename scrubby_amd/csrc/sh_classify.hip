@@ -2504,7 +2504,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         c->ext_reg_cap = 16384;
         c->ext_scratch_per_wave = align_scratch_layout(max_read_len, c->ext_reg_cap, nullptr, nullptr, nullptr);
         const uint64_t budget = 4ull << 30;
-        c->ext_waves = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)256 * 3, budget / c->ext_scratch_per_wave, (max_reads + 3) / 4}));
+        c->ext_waves = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)256 * std::max<uint64_t>(1, (160u << 10) / sizeof(AlignLds)), budget / c->ext_scratch_per_wave, (max_reads + 3) / 4}));
         if ((e = hipMalloc(&c->d_ext_scratch, (uint64_t)c->ext_waves * c->ext_scratch_per_wave)) != hipSuccess) return fail(e, "extension-stage scratch");
         for (auto &ev : c->ev_ext) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "event");
     }
