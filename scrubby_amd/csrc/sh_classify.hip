@@ -383,11 +383,12 @@ __device__ inline uint32_t wave_excl_scan_u32(uint32_t v, uint32_t lane)
 #define LSEG 256u          // bases per sketch segment (plus w + k warm-up)
 
 struct LongArgs {
-    const uint8_t *bases; const uint64_t *offsets; uint64_t n_reads;
+    const uint8_t *bases; const uint64_t *offsets; uint64_t n_reads, n_bases;
     const uint4 *slots; uint32_t lg_slots; int32_t k;
     uint32_t *seg_base;            // n_reads + 1: first segment of each read
     uint32_t *seg_cnt;             // minimizers per segment
     unsigned long long *seg_off;   // exclusive scan of seg_cnt (n_segs + 1)
+    unsigned long long *scan_tot;  // k_long_scan: one sum per block of 16 384 segments
     uint64_t *mz_hash; uint32_t *mz_y; unsigned long long mz_cap;
     uint4 *lrec;                   // seed records, compacted per read in place of its minimizers
     unsigned long long *seed_off;  // per read
@@ -444,11 +445,33 @@ __global__ __launch_bounds__(256) void k_long_sketch(LongArgs a)
             if (EMIT && o0 + n < a.mz_cap) { a.mz_hash[o0 + n] = x >> 8; a.mz_y[o0 + n] = y; }
             ++n;
         };
+        // the lane's bases 16 at a time (one aligned 128-bit load per 16 steps): byte loads made every lane touch its cache line 128 times,
+        // and with 64 lines per wave load in flight the lines were evicted from L2 before they were used up (PMC: 42 B fetched per base)
+        const uintptr_t b_lo = (uintptr_t)a.bases, b_hi = b_lo + a.n_bases;
+        uintptr_t blk = ~(uintptr_t)0;
+        uint64_t w_lo = 0, w_hi = 0;
+        auto base_at = [&](uint32_t i) -> uint32_t {
+            const uintptr_t p = (uintptr_t)(seq + i), pb = p & ~(uintptr_t)15;
+            if (pb != blk) {
+                blk = pb;
+                if (pb >= b_lo && pb + 16 <= b_hi) { const uint4 v = *(const uint4 *)pb; w_lo = (uint64_t)v.y << 32 | v.x; w_hi = (uint64_t)v.w << 32 | v.z; }
+                else {
+                    w_lo = w_hi = 0;
+                    for (int t = 0; t < 16; ++t) {
+                        const uintptr_t q = pb + t;
+                        const uint64_t ch = (q >= b_lo && q < b_hi) ? *(const uint8_t *)q : (uint64_t)'N';
+                        if (t < 8) w_lo |= ch << (8 * t); else w_hi |= ch << (8 * (t - 8));
+                    }
+                }
+            }
+            const uint32_t b = (uint32_t)(p & 15);
+            return (uint32_t)((b < 8 ? w_lo : w_hi) >> (8 * (b & 7))) & 0xffu;
+        };
         for (uint32_t i0 = from; i0 < end; i0 += W) {
             auto one = [&](auto Pc) {
                 constexpr int Pk = decltype(Pc)::value;
                 const uint32_t i = i0 + Pk;
-                if (i < end) { cur = i; st.template step<Pk>(sh_nt4(seq[i]), i, emit); }
+                if (i < end) { cur = i; st.template step<Pk>(sh_nt4((uint8_t)base_at(i)), i, emit); }
             };
             [&]<int... Ps>(std::integer_sequence<int, Ps...>) { (one(std::integral_constant<int, Ps>{}), ...); }
             (std::make_integer_sequence<int, W>{});
@@ -459,25 +482,51 @@ __global__ __launch_bounds__(256) void k_long_sketch(LongArgs a)
 }
 
 // exclusive scan of seg_cnt[0..n] into seg_off[0..n] (n = n_segs, so seg_off[n] = total): one block, sequential chunks
-__global__ __launch_bounds__(1024) void k_long_scan(LongArgs a)
+// exclusive scan of seg_cnt[0..n] into seg_off[0..n] in three launches: (0) every block sums its 16 384 counts, (1) one block scans the
+// block sums, (2) every block scans its counts from its base.  A single block walking the whole table took 8 ms per launch of 200 k long reads.
+#define LSCAN_PER 16u
+__global__ __launch_bounds__(1024) void k_long_scan(LongArgs a, int mode)
 {
     __shared__ unsigned long long s_wave[16];
-    __shared__ unsigned long long s_run;
     const uint32_t n = *a.n_segs_out, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) s_run = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base <= n; base += 1024) {
-        const uint32_t i = base + tid;
-        const uint32_t v = i < n ? a.seg_cnt[i] : 0;
-        const uint32_t ex = wave_excl_scan_u32(v, lane);
-        const uint32_t tot = wave_sum_u32(v);
-        if (lane == 0) s_wave[wv] = tot;
+    const uint32_t n_blocks = n / (1024u * LSCAN_PER) + 1;
+    if (mode == 1) {       // one block: exclusive scan of the block sums in place (n_blocks <= a few hundred)
+        unsigned long long run = 0;
+        for (uint32_t base = 0; base < n_blocks; base += 1024) {
+            const uint32_t i = base + tid;
+            const unsigned long long v = i < n_blocks ? a.scan_tot[i] : 0ull;
+            unsigned long long inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = (unsigned long long)__shfl_up((long long)inc, o); if ((int)lane >= o) inc += t; }
+            if (lane == 63) s_wave[wv] = inc;
+            __syncthreads();
+            unsigned long long pre = run;
+            for (uint32_t q = 0; q < wv; ++q) pre += s_wave[q];
+            if (i < n_blocks) a.scan_tot[i] = pre + inc - v;
+            unsigned long long all = 0;
+            for (int q = 0; q < 16; ++q) all += s_wave[q];
+            run += all;
+            __syncthreads();
+        }
+        return;
+    }
+    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const uint32_t i0 = blk * 1024u * LSCAN_PER + tid * LSCAN_PER;
+        uint32_t v[LSCAN_PER], tot = 0;
+#pragma unroll
+        for (uint32_t t = 0; t < LSCAN_PER; ++t) { v[t] = i0 + t < n ? a.seg_cnt[i0 + t] : 0; tot += v[t]; }
+        const uint32_t ex = wave_excl_scan_u32(tot, lane);
+        const uint32_t wtot = wave_sum_u32(tot);
+        if (lane == 0) s_wave[wv] = wtot;
         __syncthreads();
-        unsigned long long pre = s_run;
-        for (uint32_t q = 0; q < wv; ++q) pre += s_wave[q];
-        if (i <= n) a.seg_off[i] = pre + ex;
-        __syncthreads();
-        if (tid == 0) { unsigned long long t = 0; for (int q = 0; q < 16; ++q) t += s_wave[q]; s_run += t; }
+        if (mode == 0) {
+            if (tid == 0) { unsigned long long t = 0; for (int q = 0; q < 16; ++q) t += s_wave[q]; a.scan_tot[blk] = t; }
+        } else {
+            unsigned long long pre = a.scan_tot[blk] + ex;
+            for (uint32_t q = 0; q < wv; ++q) pre += s_wave[q];
+#pragma unroll
+            for (uint32_t t = 0; t < LSCAN_PER; ++t) { if (i0 + t <= n) a.seg_off[i0 + t] = pre; pre += v[t]; }
+        }
         __syncthreads();
     }
 }
@@ -1096,6 +1145,7 @@ struct BigList { uint32_t *start, *len; int32_t *count; uint32_t cap; };
 struct GlobalQ { SortItem *const *items; const uint32_t *cap; uint32_t *count; uint32_t w, in_b; unsigned long long off; };
 __device__ inline int cl_class(uint32_t len) { return len > 4096 ? 0 : (len > 1024 ? 1 : (len > 256 ? 2 : 3)); }
 
+__device__ unsigned long long g_dbg_cs[16];
 template <bool CONTIG, class PX, class PQ>
 __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_t n, uint32_t tid, uint32_t nthr, int32_t qlen,
                                     const ChainParams &P, volatile int32_t *found, BigList bl,
@@ -1124,7 +1174,16 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
     auto handle = [&](uint32_t i, uint32_t len) {
         if (len < 2 && !keep_single) return;
         // flag-only hand-over: a cluster of len anchors cannot chain to more than k * len; below the best score already handed over it is moot
+        if (CONTIG && phase == 1) { atomicAdd(&g_dbg_cs[0], 1ull); atomicAdd(&g_dbg_cs[1], (unsigned long long)len); }
         if (sk && sk->best && (int64_t)P.k * (int64_t)len < (int64_t)sink_best_score(*sk, read)) return;
+        if (CONTIG && phase == 1 && sk && sk->best && qlen <= 256) {
+            unsigned long long m[4] = {0, 0, 0, 0};
+            for (uint32_t t = 0; t < len; ++t) { const uint32_t qq = (uint32_t)q[i + t] & 0xffu; m[qq >> 6] |= 1ull << (qq & 63); }
+            int32_t cover = 0, last = -1000;
+            for (int w = 0; w < 4; ++w) { unsigned long long b = m[w]; while (b) { const int pos = w * 64 + __ffsll(b) - 1; b &= b - 1; cover += pos - last < P.k ? pos - last : P.k; last = pos; } }
+            if (cover < sink_best_score(*sk, read)) { atomicAdd(&g_dbg_cs[9], 1ull); atomicAdd(&g_dbg_cs[10], (unsigned long long)len); }
+        }
+        if (CONTIG && phase == 1) { atomicAdd(&g_dbg_cs[2], 1ull); atomicAdd(&g_dbg_cs[3], (unsigned long long)len); atomicAdd(&g_dbg_cs[4 + (len > 8) + (len > 24)], 1ull); if (sk && sk->best) atomicAdd(&g_dbg_cs[8], (unsigned long long)sink_best_score(*sk, read)); }
         if (bc && bc->n > 0 && (int64_t)P.k * (int64_t)len < (int64_t)bc->score) return;
         if (bc) {      // len <= 64 (the caller's n is)
             SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i};
@@ -2287,7 +2346,7 @@ struct sh_ctx {
     bool use_long = false;           // reads longer than K1 takes: segment-parallel long-read front end
     uint8_t *d_long = nullptr; uint64_t long_bytes = 0, mz_cap = 0, max_segs = 0;
     uint32_t *d_seg_base = nullptr, *d_seg_cnt = nullptr, *d_mz_y = nullptr;
-    unsigned long long *d_seg_off = nullptr, *d_seed_off = nullptr;
+    unsigned long long *d_seg_off = nullptr, *d_seed_off = nullptr, *d_scan_tot = nullptr;
     uint64_t *d_mz_hash = nullptr; uint4 *d_lrec = nullptr;
     // extension stage (SH_F_CIGAR, short-read mode): chain hand-over buffers and the per-wave scratch of k_regs_align
     bool ext = false;
@@ -2473,12 +2532,12 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         c->max_segs = cb / LSEG + max_reads + 2;
         c->mz_cap = cb * 5 / (2 * ((uint64_t)opts->w + 1)) + 4096;   // minimizer density is ~2/(w+1), + 25 %; reads beyond the cap take the legacy path
         auto al = [](uint64_t b) { return (b + 255) & ~255ull; };
-        c->long_bytes = al((max_reads + 1) * 4) + al(c->max_segs * 4) + al((c->max_segs + 1) * 8) + al(c->mz_cap * 8) + al(c->mz_cap * 4) + al(c->mz_cap * 16) + al(max_reads * 8);
+        c->long_bytes = al((max_reads + 1) * 4) + al(c->max_segs * 4) + al((c->max_segs + 1) * 8) + al((c->max_segs / 16384 + 2) * 8) + al(c->mz_cap * 8) + al(c->mz_cap * 4) + al(c->mz_cap * 16) + al(max_reads * 8);
         if ((e = hipMalloc(&c->d_long, c->long_bytes)) != hipSuccess) return fail(e, "long-read buffers");
         uint8_t *p = c->d_long;
         auto take = [&](uint64_t b) { uint8_t *q = p; p += al(b); return q; };
         c->d_seg_base = (uint32_t *)take((max_reads + 1) * 4); c->d_seg_cnt = (uint32_t *)take(c->max_segs * 4);
-        c->d_seg_off = (unsigned long long *)take((c->max_segs + 1) * 8); c->d_mz_hash = (uint64_t *)take(c->mz_cap * 8);
+        c->d_seg_off = (unsigned long long *)take((c->max_segs + 1) * 8); c->d_scan_tot = (unsigned long long *)take((c->max_segs / 16384 + 2) * 8); c->d_mz_hash = (uint64_t *)take(c->mz_cap * 8);
         c->d_mz_y = (uint32_t *)take(c->mz_cap * 4); c->d_lrec = (uint4 *)take(c->mz_cap * 16); c->d_seed_off = (unsigned long long *)take(max_reads * 8);
     }
     if (c->ext) {
@@ -2543,7 +2602,9 @@ static void launch_long(const LongArgs &a, hipStream_t s)
 {
     hipLaunchKernelGGL(k_long_segtable, dim3(1), dim3(64), 0, s, a);
     hipLaunchKernelGGL((k_long_sketch<W, false>), dim3(256 * 8), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_long_scan, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k_long_scan, dim3(512), dim3(1024), 0, s, a, 0);
+    hipLaunchKernelGGL(k_long_scan, dim3(1), dim3(1024), 0, s, a, 1);
+    hipLaunchKernelGGL(k_long_scan, dim3(512), dim3(1024), 0, s, a, 2);
     hipLaunchKernelGGL((k_long_sketch<W, true>), dim3(256 * 8), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_long_probe, dim3(256 * 16), dim3(64), 0, s, a);
 }
@@ -2619,9 +2680,9 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         }
     } else if (c->use_long) {
         LongArgs a{};
-        a.bases = d_bases; a.offsets = d_offsets; a.n_reads = n_reads;
+        a.bases = d_bases; a.offsets = d_offsets; a.n_reads = n_reads; a.n_bases = n_bases;
         a.slots = (const uint4 *)idx->d_slots; a.lg_slots = idx->lg_slots; a.k = idx->k;
-        a.seg_base = c->d_seg_base; a.seg_cnt = c->d_seg_cnt; a.seg_off = c->d_seg_off;
+        a.seg_base = c->d_seg_base; a.seg_cnt = c->d_seg_cnt; a.seg_off = c->d_seg_off; a.scan_tot = c->d_scan_tot;
         a.mz_hash = c->d_mz_hash; a.mz_y = c->d_mz_y; a.mz_cap = c->mz_cap; a.lrec = c->d_lrec; a.seed_off = c->d_seed_off;
         a.k1info = c->d_k1info; a.flags = d_flags; a.trace = d_trace;
         a.work_big = c->d_big[0][0]; a.work_resketch = c->d_work_resketch; a.ctr = c->d_ctr;
@@ -2729,6 +2790,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         if (k.dbg & 16) fprintf(stderr, "[dbg] clusters chained by k_cluster_dp by class: %llu %llu %llu %llu, their anchors %llu %llu %llu %llu\n", c->h_ctr->cl_tot[0], c->h_ctr->cl_tot[1], c->h_ctr->cl_tot[2], c->h_ctr->cl_tot[3], c->h_ctr->cl_anchor_tot[0], c->h_ctr->cl_anchor_tot[1], c->h_ctr->cl_anchor_tot[2], c->h_ctr->cl_anchor_tot[3]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] reads (anchors) by sort class: <=64 %llu (%llu), <=256 %llu (%llu), <=512 %llu (%llu), <=1024 %llu (%llu), <=2048 %llu (%llu), <=4096 %llu (%llu), giant %llu (%llu)\n", c->h_ctr->sort_tot[6], c->h_ctr->sort_anchor_tot[6], c->h_ctr->sort_tot[0], c->h_ctr->sort_anchor_tot[0], c->h_ctr->sort_tot[1], c->h_ctr->sort_anchor_tot[1], c->h_ctr->sort_tot[2], c->h_ctr->sort_anchor_tot[2], c->h_ctr->sort_tot[3], c->h_ctr->sort_anchor_tot[3], c->h_ctr->sort_tot[4], c->h_ctr->sort_anchor_tot[4], c->h_ctr->sort_tot[5], c->h_ctr->sort_anchor_tot[5]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] local-cluster shortcut: tried %u, no singleton / filtered %u, singletons apart %u, window %u, K size %u, no margin %u, decided %u\n", c->h_ctr->ext_s3[0], c->h_ctr->ext_s3[1], c->h_ctr->ext_s3[2], c->h_ctr->ext_s3[3], c->h_ctr->ext_s3[4], c->h_ctr->ext_s3[5], c->h_ctr->ext_s3[7]);
+        if (k.dbg & 16) { unsigned long long h[16]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg_cs), sizeof(h)); fprintf(stderr, "[dbg] giant phase 1 small clusters: seen %llu (%llu anchors), after k*len pruning %llu (%llu anchors): <=8 %llu, <=24 %llu, <=64 %llu; sum best %llu; coverage bound would prune %llu (%llu anchors)\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[10]); }
         if (k.dbg & 16) fprintf(stderr, "[dbg] ring DP: chunks in window %llu, beyond %llu, far rescans %llu\n", c->h_ctr->cl_dbg[0], c->h_ctr->cl_dbg[1], c->h_ctr->cl_dbg[2]);
         resk_done = c->h_ctr->n_resketch;
         const uint32_t d0 = c->h_ctr->n_big_defer[0], d1 = c->h_ctr->n_big_defer[1];
