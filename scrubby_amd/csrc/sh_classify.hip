@@ -610,25 +610,35 @@ __global__ __launch_bounds__(64) void k_long_probe(LongArgs a)
         }
         const uint64_t slot_mask = (1ULL << a.lg_slots) - 1;
         uint32_t n_seed = 0;
-        for (unsigned long long t0 = 0; t0 < n_mini; t0 += 64) {
-            const bool have = t0 + lane < n_mini;
-            uint4 sl = make_uint4(0, 0, 0, 0);
-            uint64_t w0 = SH_SLOT_EMPTY; uint32_t y = 0;
-            if (have) {
-                const uint64_t key = a.mz_hash[base + t0 + lane];
-                y = a.mz_y[base + t0 + lane];
-                uint64_t idx = sh_slot_home(key, a.lg_slots);
-                sl = a.slots[idx];
-                w0 = (uint64_t)sl.y << 32 | sl.x;
-                while (w0 != SH_SLOT_EMPTY && (w0 & SH_SLOT_KEYMASK) != key) { idx = (idx + 1) & slot_mask; sl = a.slots[idx]; w0 = (uint64_t)sl.y << 32 | sl.x; }
+        // four rounds of 64 home-slot gathers in flight per wave (the 56 KB of LDS above leave two waves per CU: one round at a time left the
+        // probes latency-bound at 11.6 G/s); the records are written in minimizer order all the same
+        for (unsigned long long t0 = 0; t0 < n_mini; t0 += 256) {
+            uint64_t key[4]; uint32_t y[4]; uint4 sl[4]; bool have[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned long long t = t0 + 64ull * u + lane;
+                have[u] = t < n_mini;
+                key[u] = have[u] ? a.mz_hash[base + t] : 0ull;
+                y[u] = have[u] ? a.mz_y[base + t] : 0u;
             }
-            const bool hit = have && w0 != SH_SLOT_EMPTY;
-            const uint64_t hm = __ballot(hit);
-            if (hit) {
-                const uint32_t occ = (w0 & SH_SLOT_MULTI) ? (sl.z & (uint32_t)SH_SLOT_NMASK) : 1u;
-                a.lrec[base + n_seed + prefix_popc(hm)] = make_uint4(sl.z, sl.w, occ, y);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sl[u] = a.slots[have[u] ? sh_slot_home(key[u], a.lg_slots) : 0ull];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                uint64_t w0 = SH_SLOT_EMPTY;
+                if (have[u]) {
+                    uint64_t idx = sh_slot_home(key[u], a.lg_slots);
+                    w0 = (uint64_t)sl[u].y << 32 | sl[u].x;
+                    while (w0 != SH_SLOT_EMPTY && (w0 & SH_SLOT_KEYMASK) != key[u]) { idx = (idx + 1) & slot_mask; sl[u] = a.slots[idx]; w0 = (uint64_t)sl[u].y << 32 | sl[u].x; }
+                }
+                const bool hit = have[u] && w0 != SH_SLOT_EMPTY;
+                const uint64_t hm = __ballot(hit);
+                if (hit) {
+                    const uint32_t occ = (w0 & SH_SLOT_MULTI) ? (sl[u].z & (uint32_t)SH_SLOT_NMASK) : 1u;
+                    a.lrec[base + n_seed + prefix_popc(hm)] = make_uint4(sl[u].z, sl[u].w, occ, y[u]);
+                }
+                n_seed += (uint32_t)__popcll(hm);
             }
-            n_seed += (uint32_t)__popcll(hm);
         }
         if (lane == 0) {
             a.k1info[r] = (uint32_t)n_mini | n_seed << 16;
