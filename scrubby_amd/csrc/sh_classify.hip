@@ -1140,6 +1140,49 @@ __global__ __launch_bounds__(64) void k_local_cluster(K2Args a)
 }
 
 
+// Flag-only hand-over (short-read mode): can the cluster [s, s + len), len <= 64, hold a chain that reaches the score `bs`?  The WAVE
+// answers from the anchors' geometry, one lane per anchor, before any lane chains it:
+//   * a link needs |d_ref - d_query| <= bw (comput_sc; the max_ii shortcut goes through the same test), so with the anchors' diagonals
+//     binned at width bw + 1 a chain never leaves a run of adjacent occupied bins - tandem-array copies of a read sit one monomer
+//     (171 > bw) apart in diagonal and fall into different runs;
+//   * a chain visits each query position once (dq > 0) and a link adds at most min(k, dq): it scores at most the bases that the
+//     k-mers at the DISTINCT query positions of its run cover.
+// false = it might (or the diagonals span more than 64 bins): chain it.
+__device__ inline bool cluster_cannot_reach(const uint64_t *__restrict__ x, const uint32_t *__restrict__ q, uint32_t s, uint32_t len, int32_t bs,
+                                            const ChainParams &P, uint32_t lane)
+{
+    const bool on = lane < len;
+    const uint32_t lo = on ? (uint32_t)x[s + lane] : 0u, qv = on ? q[s + lane] & 0x7fffffffu : 0u;
+    const int32_t dg = (int32_t)(lo - qv);
+    int32_t mn = on ? dg : INT32_MAX;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int32_t t = __shfl_xor(mn, o); mn = t < mn ? t : mn; }
+    const uint32_t bin = on ? (uint32_t)(dg - mn) / (uint32_t)(P.bw + 1) : 0u;
+    if (__ballot(on && bin >= 64u) != 0) return false;
+    uint32_t ol = on && bin < 32u ? 1u << bin : 0u, oh = on && bin >= 32u ? 1u << (bin - 32u) : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ol |= (uint32_t)__shfl_xor((int)ol, o); oh |= (uint32_t)__shfl_xor((int)oh, o); }
+    const uint64_t occ = (uint64_t)oh << 32 | ol, starts = occ & ~(occ << 1);
+    const uint32_t comp = (uint32_t)__popcll(starts & (bin == 63u ? ~0ull : (2ull << bin) - 1ull));
+    uint64_t key = on ? (uint64_t)comp << 32 | qv : ~0ull;
+    uint32_t dummy = 0;
+    wave_rank_sort(key, dummy, len, lane);
+    const uint64_t prev = (uint64_t)__shfl_up((long long)key, 1);
+    const uint32_t kc = (uint32_t)(key >> 32);
+    const bool first = lane == 0 || kc != (uint32_t)(prev >> 32);
+    int32_t c = !on ? 0 : (first ? P.k : min(P.k, (int32_t)((uint32_t)key - (uint32_t)prev)));
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t t = __shfl_up(c, o);
+        const uint32_t tk = (uint32_t)__shfl_up((int)kc, o);
+        if ((int)lane >= o && tk == kc) c += t;
+    }
+    int32_t mx = on ? c : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int32_t t = __shfl_xor(mx, o); mx = t > mx ? t : mx; }
+    return mx < bs;
+}
+
 // Chains every cluster of a sorted anchor array x[0..n) / q[0..n).  f / pt: DP state arrays of n (2n) int32.
 // Returns this thread's (chains, best score, clusters).  `found`: block-shared flag of the flag-only early exit
 // (nullptr: chain everything).  All threads of the block call.
@@ -1155,7 +1198,6 @@ struct BigList { uint32_t *start, *len; int32_t *count; uint32_t cap; };
 struct GlobalQ { SortItem *const *items; const uint32_t *cap; uint32_t *count; uint32_t w, in_b; unsigned long long off; };
 __device__ inline int cl_class(uint32_t len) { return len > 4096 ? 0 : (len > 1024 ? 1 : (len > 256 ? 2 : 3)); }
 
-__device__ unsigned long long g_dbg_cs[16];
 template <bool CONTIG, class PX, class PQ>
 __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_t n, uint32_t tid, uint32_t nthr, int32_t qlen,
                                     const ChainParams &P, volatile int32_t *found, BigList bl,
@@ -1174,7 +1216,7 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
     const uint32_t i_beg = CONTIG ? (tid * per < n ? tid * per : n) : tid, i_step = CONTIG ? 1 : nthr;
     const uint32_t i_end = CONTIG ? (i_beg + per < n ? i_beg + per : n) : n;
     if (tid == 0) *bl.count = 0;
-    for (uint32_t i = tid; i < n; i += nthr) {
+    for (uint32_t i = tid; i < n && !(CONTIG && phase == 1); i += nthr) {      // phase 1 finds the marks of phase 0 in place
         bool start = i == 0;
         if (!start) { const uint64_t xi = x[i], xp = x[i - 1]; start = (uint32_t)(xi >> 32) != (uint32_t)(xp >> 32) || (uint32_t)xi - (uint32_t)xp > mdx; }
         if (start) q[i] |= 0x80000000u;
@@ -1184,16 +1226,22 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
     auto handle = [&](uint32_t i, uint32_t len) {
         if (len < 2 && !keep_single) return;
         // flag-only hand-over: a cluster of len anchors cannot chain to more than k * len; below the best score already handed over it is moot
-        if (CONTIG && phase == 1) { atomicAdd(&g_dbg_cs[0], 1ull); atomicAdd(&g_dbg_cs[1], (unsigned long long)len); }
-        if (sk && sk->best && (int64_t)P.k * (int64_t)len < (int64_t)sink_best_score(*sk, read)) return;
-        if (CONTIG && phase == 1 && sk && sk->best && qlen <= 256) {
-            unsigned long long m[4] = {0, 0, 0, 0};
-            for (uint32_t t = 0; t < len; ++t) { const uint32_t qq = (uint32_t)q[i + t] & 0xffu; m[qq >> 6] |= 1ull << (qq & 63); }
-            int32_t cover = 0, last = -1000;
-            for (int w = 0; w < 4; ++w) { unsigned long long b = m[w]; while (b) { const int pos = w * 64 + __ffsll(b) - 1; b &= b - 1; cover += pos - last < P.k ? pos - last : P.k; last = pos; } }
-            if (cover < sink_best_score(*sk, read)) { atomicAdd(&g_dbg_cs[9], 1ull); atomicAdd(&g_dbg_cs[10], (unsigned long long)len); }
+        if (CONTIG && phase == 1 && sk && sk->best && P.is_sr && P.ext_lemma && len <= 64u && f[i] == INT32_MIN) return;      // ruled out by its wave (prefilter below)
+        if (sk && sk->best) {
+            const int32_t bs = sink_best_score(*sk, read);
+            if ((int64_t)P.k * (int64_t)len < (int64_t)bs) return;
+            if (CONTIG && bs > P.k && len <= 64u && qlen <= 256) {
+                // tighter: a chain visits each query position once (dq > 0) and a link adds at most min(k, dq), so it scores at most the
+                // bases the k-mers at the cluster's DISTINCT query positions cover.  Tandem-array reads: a cluster of 20 anchors is often
+                // the same 2-3 seeds over and over.
+                unsigned long long m[4] = {0, 0, 0, 0};
+                for (uint32_t t = 0; t < len; ++t) { const uint32_t qq = (uint32_t)q[i + t] & 0xffu; m[qq >> 6] |= 1ull << (qq & 63); }
+                int32_t cover = 0, last = -100000;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { unsigned long long b = m[w]; while (b) { const int32_t pos = w * 64 + __ffsll(b) - 1; b &= b - 1; cover += pos - last < P.k ? pos - last : P.k; last = pos; } }
+                if (cover < bs) return;
+            }
         }
-        if (CONTIG && phase == 1) { atomicAdd(&g_dbg_cs[2], 1ull); atomicAdd(&g_dbg_cs[3], (unsigned long long)len); atomicAdd(&g_dbg_cs[4 + (len > 8) + (len > 24)], 1ull); if (sk && sk->best) atomicAdd(&g_dbg_cs[8], (unsigned long long)sink_best_score(*sk, read)); }
         if (bc && bc->n > 0 && (int64_t)P.k * (int64_t)len < (int64_t)bc->score) return;
         if (bc) {      // len <= 64 (the caller's n is)
             SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i};
@@ -1237,12 +1285,69 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
             __syncthreads();
         }
         const uint32_t after = tid + 1 < nthr ? nxt[tid + 1] : n;
+        // Phase 1 of the flag-only hand-over: the big clusters have set the score to beat.  Before a lane spends ~100 dependent loads chaining
+        // a small cluster out of HBM, its wave rules out the clusters whose geometry cannot reach that score (cluster_cannot_reach):
+        // verdict in f[start] (every small cluster of the read gets one; the DP of a surviving cluster overwrites it).
+        const bool prefilter = phase == 1 && sk && sk->best && P.is_sr && P.ext_lemma;
+        bool run_sweeps = true;      // block-uniform
+        if (prefilter) {
+            const int32_t bs0 = sink_best_score(*sk, read);
+            const uint32_t wv = tid >> 6, ln = tid & 63;
+            const uint32_t wb = min(n, wv * 64u * per), we = min(n, (wv + 1u) * 64u * per);
+            for (uint32_t c0 = wb; c0 < we; c0 += 64) {
+                const uint32_t i0 = c0 + ln;
+                // marks of this chunk and of the next one (a cluster may end in another wave's span); the starts below `we` are this wave's
+                const uint64_t m0 = __ballot(i0 < n && (q[i0] >> 31)), m1 = __ballot(i0 + 64 < n && (q[i0 + 64] >> 31));
+                uint64_t todo = m0 & __ballot(i0 < we);
+                while (todo) {
+                    const uint32_t b = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
+                    todo &= todo - 1;
+                    const uint64_t above = b == 63u ? 0ull : m0 >> (b + 1u);
+                    uint32_t len;
+                    if (above) len = (uint32_t)__ffsll((unsigned long long)above);
+                    else if (c0 + 64 >= n) len = n - (c0 + b);
+                    else if (m1) len = 64u - b + (uint32_t)__ffsll((unsigned long long)m1) - 1u;
+                    else len = c0 + 128 >= n ? n - (c0 + b) : 65u;
+                    if (len > 64u) continue;
+                    const uint32_t st = c0 + b;
+                    bool dead = (int64_t)P.k * (int64_t)len < (int64_t)bs0;
+                    if (!dead && bs0 > P.k && len >= 2u) dead = cluster_cannot_reach((const uint64_t *)&x[0], (const uint32_t *)&q[0], st, len, bs0, P, ln);
+                    if (ln == 0) {
+                        // survivors are packed into the block's LDS list, so that every thread gets one instead of the few threads whose ranges
+                        // hold them chaining two or three in a row while the rest of their waves idle; a full list leaves them to the sweeps
+                        bool listed = false;
+                        if (!dead) {
+                            const int32_t slot = atomicAdd(bl.count, 1);
+                            if ((uint32_t)slot < bl.cap) { bl.start[slot] = st; bl.len[slot] = len; listed = true; }
+                        }
+                        f[st] = dead || listed ? INT32_MIN : 0;
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t n_list = (uint32_t)*bl.count < bl.cap ? (uint32_t)*bl.count : bl.cap;
+            for (uint32_t b = tid; b < n_list; b += nthr) {
+                const uint32_t ci = bl.start[b], cl = bl.len[b];
+                if ((int64_t)P.k * (int64_t)cl < (int64_t)sink_best_score(*sk, read)) continue;      // the score to beat has risen since
+                SliceStore S{(const uint64_t *)&x[ci], (const uint32_t *)&q[ci], f + ci, pt + 2 * (size_t)ci};
+                int32_t n_u, best;
+                chain_cluster(S, (int32_t)cl, qlen, P, heap ? heap + ci : (uint64_t *)&x[ci], n_u, best, false, sk, read, ci);
+                ++n_cl_thr;
+                if (n_u > 0) { n_u_thr += n_u; if (best > best_thr) best_thr = best; }
+            }
+            __syncthreads();
+            const bool overflow = (uint32_t)*bl.count > bl.cap;
+            __syncthreads();
+            if (tid == 0) *bl.count = 0;      // the wave-level list of the code below starts empty
+            __syncthreads();
+            run_sweeps = overflow;
+        }
         // sweeps by cluster size: the clusters a lane chains itself in rising order of cost (the DP is quadratic and a wave
         // waits for its slowest lane), then - only if the read is still undecided in flag-only mode - the big ones go to
         // the queue.  Lengths are free now, so one sweep would queue every big cluster before the first chain is found.
         const bool tq = sk && sk->best;
         const uint32_t thr[5] = {0u, 8u, 24u, 64u, 0xffffffffu}; (void)tq;
-        for (int sweep = phase == 0 ? 3 : 0; sweep < (phase == 1 ? 3 : 4); ++sweep) {
+        for (int sweep = phase == 0 ? 3 : 0; run_sweeps && sweep < (phase == 1 ? 3 : 4); ++sweep) {
             uint32_t i = fs < i_end ? fs : i_end;
             while (i < i_end) {
                 if (found && *found) break;            // flag-only: the read is decided
@@ -1270,6 +1375,10 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
     for (uint32_t b = wave; b < n_big; b += n_wave) {
         if (found && *found) break;
         const uint32_t i = bl.start[b], len = bl.len[b];
+        if (sk && sk->best && !bc && P.is_sr && P.ext_lemma && len <= 64u) {      // flag-only hand-over: the geometry first (cluster_cannot_reach), then the DP
+            const int32_t bs = sink_best_score(*sk, read);
+            if (bs > P.k && cluster_cannot_reach((const uint64_t *)&x[0], (const uint32_t *)&q[0], i, len, bs, P, lane)) continue;
+        }
         SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i};
         int32_t n_u, best;
         chain_cluster_wave(S, (int32_t)len, qlen, P, heap ? heap + i : (uint64_t *)&x[i], n_u, best, found != nullptr, lane, sk, read, i);
@@ -2800,7 +2909,6 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         if (k.dbg & 16) fprintf(stderr, "[dbg] clusters chained by k_cluster_dp by class: %llu %llu %llu %llu, their anchors %llu %llu %llu %llu\n", c->h_ctr->cl_tot[0], c->h_ctr->cl_tot[1], c->h_ctr->cl_tot[2], c->h_ctr->cl_tot[3], c->h_ctr->cl_anchor_tot[0], c->h_ctr->cl_anchor_tot[1], c->h_ctr->cl_anchor_tot[2], c->h_ctr->cl_anchor_tot[3]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] reads (anchors) by sort class: <=64 %llu (%llu), <=256 %llu (%llu), <=512 %llu (%llu), <=1024 %llu (%llu), <=2048 %llu (%llu), <=4096 %llu (%llu), giant %llu (%llu)\n", c->h_ctr->sort_tot[6], c->h_ctr->sort_anchor_tot[6], c->h_ctr->sort_tot[0], c->h_ctr->sort_anchor_tot[0], c->h_ctr->sort_tot[1], c->h_ctr->sort_anchor_tot[1], c->h_ctr->sort_tot[2], c->h_ctr->sort_anchor_tot[2], c->h_ctr->sort_tot[3], c->h_ctr->sort_anchor_tot[3], c->h_ctr->sort_tot[4], c->h_ctr->sort_anchor_tot[4], c->h_ctr->sort_tot[5], c->h_ctr->sort_anchor_tot[5]);
         if (k.dbg & 16) fprintf(stderr, "[dbg] local-cluster shortcut: tried %u, no singleton / filtered %u, singletons apart %u, window %u, K size %u, no margin %u, decided %u\n", c->h_ctr->ext_s3[0], c->h_ctr->ext_s3[1], c->h_ctr->ext_s3[2], c->h_ctr->ext_s3[3], c->h_ctr->ext_s3[4], c->h_ctr->ext_s3[5], c->h_ctr->ext_s3[7]);
-        if (k.dbg & 16) { unsigned long long h[16]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg_cs), sizeof(h)); fprintf(stderr, "[dbg] giant phase 1 small clusters: seen %llu (%llu anchors), after k*len pruning %llu (%llu anchors): <=8 %llu, <=24 %llu, <=64 %llu; sum best %llu; coverage bound would prune %llu (%llu anchors)\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[10]); }
         if (k.dbg & 16) fprintf(stderr, "[dbg] ring DP: chunks in window %llu, beyond %llu, far rescans %llu\n", c->h_ctr->cl_dbg[0], c->h_ctr->cl_dbg[1], c->h_ctr->cl_dbg[2]);
         resk_done = c->h_ctr->n_resketch;
         const uint32_t d0 = c->h_ctr->n_big_defer[0], d1 = c->h_ctr->n_big_defer[1];
