@@ -2741,7 +2741,8 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     else hipLaunchKernelGGL(k_expand<false>, dim3(grid * 3), dim3(64), 0, s, k);
     // the sort classes run one after the other.  Side by side (streams sx[0..2]) measured 9 % slower when they carried the whole repeat
     // path (they fight for LDS); that mode predates k_group_probe, which the class-4 and giant kernels must follow: it stays off.
-    const bool side = false;
+    static const int side_env = getenv("SCRUBBY_HIP_SIDE") ? atoi(getenv("SCRUBBY_HIP_SIDE")) : -1;
+    const bool side = side_env > 0;      // round 2, extension filter on (no k_group_probe, so race-free): still 2-3 % slower at 2.5 M and at 20 M records
     hipStream_t s0 = side ? c->sx[0] : s, s1 = side ? c->sx[1] : s, g = side ? c->sx[2] : s;
     if (side) {
         SH_HIP(hipEventRecord(c->evx[0], s));
