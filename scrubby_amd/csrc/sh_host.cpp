@@ -169,6 +169,22 @@ sh_status filter_fastx(const char *in, const char *out, const std::unordered_set
 
 }  // namespace
 
+bool shi_unsupported_compression(const char *path)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    unsigned char m[6] = {0, 0, 0, 0, 0, 0};
+    const size_t n = fread(m, 1, 6, f);
+    fclose(f);
+    const char *what = nullptr;
+    if (n >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') what = "bzip2";
+    else if (n >= 6 && m[0] == 0xFD && m[1] == '7' && m[2] == 'z' && m[3] == 'X' && m[4] == 'Z' && m[5] == 0x00) what = "xz";
+    else if (n >= 3 && m[0] == 0x5D && m[1] == 0x00 && m[2] == 0x00) what = "lzma";
+    if (!what) return false;
+    sh_set_error("%s-compressed input is not supported by the HIP backend (plain or gzip only): %s", what, path);
+    return true;
+}
+
 int shi_default_threads()
 {
     long n = (long)std::thread::hardware_concurrency();
@@ -205,6 +221,7 @@ extern "C" sh_status sh_host_filter_fastx(const char *in, const char *out, const
                                           uint64_t *n_in, uint64_t *n_out)
 {
     SH_CHECK(in && out && (ids || n_ids == 0), SH_ERR_BAD_ARG, "sh_host_filter_fastx: null argument");
+    if (shi_unsupported_compression(in)) return SH_ERR_IO;
     std::unordered_set<std::string> set;
     for (uint64_t i = 0; i < n_ids; ++i) set.insert(ids[i]);
     uint64_t a = 0, b = 0;

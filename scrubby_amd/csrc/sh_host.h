@@ -14,6 +14,9 @@ struct ReportSettings {       // ScrubbySettings, /root/reference/src/report.rs:
 // ScrubbyReport JSON (report.rs:10-88)
 sh_status shi_write_report_json(const char *const *input, const char *const *output, uint32_t n_files, const char *command,
                                 const ReportSettings &st, const sh_reads_result *r, const char *path);
+// bzip2 / xz inputs (the reference reads them through niffler, utils.rs:377-383): recognised by their magic bytes and refused by name -
+// this image ships libbz2 / liblzma without headers, so the backend links zlib only.  true = refused, error set.
+bool shi_unsupported_compression(const char *path);
 // -t <= 0: the CPUs this process may use (hardware threads, capped by the cgroup CPU quota and by 64)
 int shi_default_threads();
 // Preset's serde name ("Sr", "MapOnt", ...) from its Display form

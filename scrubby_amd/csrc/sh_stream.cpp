@@ -1126,6 +1126,7 @@ extern "C" sh_status sh_host_filter_fastx_stream(const char *in, const char *out
                                                  uint64_t chunk_bytes, int32_t threads, int32_t retain, uint64_t *n_in, uint64_t *n_out)
 {
     SH_CHECK(in && out && (ids || n_ids == 0), SH_ERR_BAD_ARG, "sh_host_filter_fastx_stream: null argument");
+    if (shi_unsupported_compression(in)) return SH_ERR_IO;
     ShardedIdSet set;
     for (uint64_t i = 0; i < n_ids; ++i) set.insert(ids[i], (uint32_t)strlen(ids[i]));
     std::vector<std::shared_ptr<Chunk>> kept;
@@ -1180,6 +1181,7 @@ extern "C" sh_status sh_reads_run(const sh_reads_config *c, sh_reads_result *res
     if (const char *e = getenv("SCRUBBY_HIP_LEGACY_HOST")) if (*e == '1') return shi_reads_run_legacy(c, res);     // A/B switch for bench.py
     for (uint32_t i = 0; i < c->n_files; ++i) {
         bool exists;
+        if (shi_unsupported_compression(c->input[i])) return SH_ERR_IO;
         if (file_is_empty(c->input[i], exists)) return shi_reads_run_legacy(c, res);
     }
     memset(res, 0, sizeof(*res));
@@ -1342,6 +1344,7 @@ extern "C" sh_status sh_kraken_run(const sh_kraken_config *c, sh_reads_result *r
     if (const char *e = getenv("SCRUBBY_HIP_LEGACY_HOST")) if (*e == '1') return shi_kraken_run_legacy(c, res);
     for (uint32_t i = 0; i < c->n_files; ++i) {
         bool exists;
+        if (shi_unsupported_compression(c->input[i])) return SH_ERR_IO;
         if (file_is_empty(c->input[i], exists)) return shi_kraken_run_legacy(c, res);       // App. C Q6 corner: the line-by-line form keeps its behaviour
     }
     memset(res, 0, sizeof(*res));

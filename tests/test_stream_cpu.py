@@ -195,3 +195,16 @@ def test_truncated_gzip_is_an_error_not_a_short_file(tmp_path):
                 S.filter_fastx_stream(str(part), str(tmp_path / "p.fastq"), [], False, chunk_bytes=50000, threads=2, retain=retain)
         with pytest.raises(S.ScrubbyHipError, match="read error|truncated|unexpected end"):
             S.filter_fastx(str(part), str(tmp_path / "q.fastq"), [], False)
+
+
+def test_bzip2_and_xz_inputs_are_refused_by_name(tmp_path):
+    """The reference reads bz2 / xz through niffler; this backend links zlib only and says so instead of failing on 'not a FASTQ record'."""
+    import bz2
+    import lzma
+    text = b"@r1\nACGT\n+\nIIII\n"
+    for name, data, what in (("a.fastq.bz2", bz2.compress(text), "bzip2"), ("a.fastq.xz", lzma.compress(text), "xz")):
+        p = tmp_path / name
+        p.write_bytes(data)
+        for fn in (S.filter_fastx, lambda a, b, c, d: S.filter_fastx_stream(a, b, c, d, chunk_bytes=1000)):
+            with pytest.raises(S.ScrubbyHipError, match=what + "-compressed input is not supported"):
+                fn(str(p), str(tmp_path / "o.fastq"), [], False)
