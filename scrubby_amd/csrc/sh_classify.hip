@@ -2839,20 +2839,30 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     b.BC = BaseCtx{idx->d_ref, idx->d_cstart, d_bases};
     if (c->ext && d_trace != nullptr) { b.sink.best = nullptr; b.sink.tie = nullptr; }      // trace mode: every chain is handed over
     const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(n_tiles, 1), 256 * 8);
-    if (c->use_k1) {     // K2 only needs K1's output: it runs beside the repeat path
+    // K2 only needs K1's output and nothing waits for it before the end of the call: it runs on a side stream, beside k_local_cluster /
+    // k_expand / the sort classes.  Starting it late instead, beside the giant reads' DP kernels of the second pass (SCRUBBY_HIP_K2_LATE=1),
+    // was measured with the extension filter on: K2 itself 64 -> 22 ms, but the step 408 -> 428 ms - it does not find room beside those
+    // persistent grids and ends up serialised.
+    static const int k2_late_env = getenv("SCRUBBY_HIP_K2_LATE") ? atoi(getenv("SCRUBBY_HIP_K2_LATE")) : -1;
+    const bool k2_late = c->use_k1 && (c->par & 1) && k2_late_env > 0;
+    K2Args kb = b;
+    auto launch_k2 = [&]() -> sh_status {
         hipStream_t sk = (c->par & 1) ? c->sx[3] : s;
         SH_HIP(hipEventRecord(c->evx[4], s));
         SH_HIP(hipStreamWaitEvent(sk, c->evx[4], 0));
-        b.work = c->d_work_small; b.work_count = &c->d_ctr->n_small; b.work_begin = 0;
+        kb.work = c->d_work_small; kb.work_count = &c->d_ctr->n_small; kb.work_begin = 0;
         if (pair_pass) {      // flag-only: pair pass over all reads of the path, then the undecided ones, dense
-            b.leftover = c->d_work_small2; b.leftover_count = &c->d_ctr->n_small2;
-            hipLaunchKernelGGL(k_pair_pass, dim3(grid), dim3(64), 0, sk, b, pair_mode_small);
-            b.work = c->d_work_small2; b.work_count = &c->d_ctr->n_small2;
+            kb.leftover = c->d_work_small2; kb.leftover_count = &c->d_ctr->n_small2;
+            hipLaunchKernelGGL(k_pair_pass, dim3(grid), dim3(64), 0, sk, kb, pair_mode_small);
+            kb.work = c->d_work_small2; kb.work_count = &c->d_ctr->n_small2;
         }
-        hipLaunchKernelGGL(k_chain_small<K2_CAP>, dim3(grid), dim3(64), 0, sk, b);
+        hipLaunchKernelGGL(k_chain_small<K2_CAP>, dim3(grid), dim3(64), 0, sk, kb);
         SH_HIP(hipEventRecord(c->ev[2], sk));
         SH_HIP(hipEventRecord(c->evx[5], sk));
-    } else SH_HIP(hipEventRecord(c->ev[2], s));
+        return SH_OK;
+    };
+    if (c->use_k1 && !k2_late) { sh_status st = launch_k2(); if (st != SH_OK) return st; }
+    else if (!c->use_k1) SH_HIP(hipEventRecord(c->ev[2], s));
 
     K3Args k{};
     k.offsets = d_offsets; k.positions = idx->d_positions; k.records = c->use_long ? c->d_lrec : c->d_records; k.seed_cap = c->seed_cap;
@@ -2892,6 +2902,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         k.next_list = c->d_big[1][cur1]; k.next_count = &c->d_ctr->n_big[1];
         sh_status st = big_pass(c, k, grid, s);
         if (st != SH_OK) return st;
+        if (first && k2_late) { st = launch_k2(); if (st != SH_OK) return st; }
         k.pass = 1; k.max_occ = c->P.max_occ;
         k.list = c->d_big[1][cur1]; k.list_count = &c->d_ctr->n_big[1];
         k.defer_list = c->d_big[1][cur1 ^ 1]; k.defer_count = &c->d_ctr->n_big_defer[1];
