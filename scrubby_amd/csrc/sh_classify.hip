@@ -1101,19 +1101,21 @@ __global__ __launch_bounds__(64) void k_local_cluster(K2Args a)
                 const uint64_t above = lane >= 63 ? 0ull : stm & ~((2ULL << lane) - 1);
                 const uint32_t clen = start ? (above ? (uint32_t)__ffsll((unsigned long long)above) - 1u : n_k) - lane : 0u;
                 __syncthreads();
+                // K's clusters one after the other, each chained by the WHOLE wave (64 predecessors at a time, then the backtrack executed uniformly):
+                // a single lane walking a 13-anchor cluster through LDS took ~70 us a read, 84 % of this kernel.  Every lane ends with the same bc.
                 BestChain bc{};
-                if (start && clen >= 2u) {
-                    SliceStore S{(const uint64_t *)&e_x[lane], (const uint32_t *)&e_q[lane], e_f + lane, e_pt + 2 * (size_t)lane};
+                uint64_t todo = __ballot(start && clen >= 2u);
+                while (todo) {
+                    const uint32_t cb = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
+                    todo &= todo - 1;
+                    const int32_t cl = __shfl((int)clen, (int)cb);
+                    SliceStore S{(const uint64_t *)&e_x[cb], (const uint32_t *)&e_q[cb], e_f + cb, e_pt + 2 * (size_t)cb};
                     int32_t n_u, best;
                     auto hif = [&](int32_t j) { return (uint32_t)(S.X(j) >> 32); };
-                    const BestEmit<SliceStore, decltype(hif)> be{&S, &bc, region_hash(qlen), P.k, lane, hif, true};
-                    chain_dp_mask(S, (int)clen, qlen, P);
-                    backtrack_mask(S, (int)clen, P, n_u, best, false, be);
+                    const BestEmit<SliceStore, decltype(hif)> be{&S, &bc, region_hash(qlen), P.k, cb, hif, true};
+                    chain_dp_wave(S, cl, qlen, P, lane);
+                    backtrack_mask(S, cl, P, n_u, best, false, be);
                 }
-                unsigned long long zmax = bc.n ? bc.z : 0ull;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = (unsigned long long)__shfl_xor((long long)zmax, o); zmax = other > zmax ? other : zmax; }
-                const uint64_t holders = __ballot(bc.n > 0 && bc.z == zmax);
                 // U_out: query bases covered by the k-mers of the seeds that have occurrences outside K (lanes are in query order)
                 const bool outside = have0 && occ0 > c_l;
                 const uint64_t om = __ballot(outside);
@@ -1124,7 +1126,7 @@ __global__ __launch_bounds__(64) void k_local_cluster(K2Args a)
                 const int32_t u_out = (int32_t)wave_sum_u32((uint32_t)cover);
                 int32_t code = 0;
                 MidReq mid{0, 0, 0, 0, 0};
-                if (__popcll(holders) == 1 && bc.n > 0 && bc.z == zmax && !bc.tie && bc.score > u_out) {
+                if (bc.n > 0 && !bc.tie && bc.score > u_out) {      // uniform
                     SliceStore S{(const uint64_t *)&e_x[bc.base], (const uint32_t *)&e_q[bc.base], e_f + bc.base, e_pt + 2 * (size_t)bc.base};
                     code = chain_lemma(S, bc.zi, bc.end_i, P, (uint32_t)(S.X(bc.zi) >> 32), mid);
                 }
