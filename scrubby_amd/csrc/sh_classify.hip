@@ -1101,10 +1101,50 @@ __global__ __launch_bounds__(64) void k_local_cluster(K2Args a)
                 const uint64_t above = lane >= 63 ? 0ull : stm & ~((2ULL << lane) - 1);
                 const uint32_t clen = start ? (above ? (uint32_t)__ffsll((unsigned long long)above) - 1u : n_k) - lane : 0u;
                 __syncthreads();
-                // K's clusters one after the other, each chained by the WHOLE wave (64 predecessors at a time, then the backtrack executed uniformly):
-                // a single lane walking a 13-anchor cluster through LDS took ~70 us a read, 84 % of this kernel.  Every lane ends with the same bc.
+                // U_out: query bases covered by the k-mers of the seeds that have occurrences outside K (lanes are in query order)
+                const bool outside = have0 && occ0 > c_l;
+                const uint64_t om = __ballot(outside);
+                const uint64_t below = om & ((1ULL << lane) - 1);
+                const int32_t prev_en = (int32_t)((uint32_t)__shfl((int)rec0.w, below ? 63 - __clzll((unsigned long long)below) : 0) >> 1) + 1;
+                const int32_t en = (int32_t)(rec0.w >> 1) + 1, st = en - P.k;
+                const int32_t cover = outside ? en - (below && prev_en > st ? prev_en : st) : 0;
+                const int32_t u_out = (int32_t)wave_sum_u32((uint32_t)cover);
+                int32_t code = 0;
+                MidReq mid{0, 0, 0, 0, 0};
+                // K is one cluster of co-diagonal anchors, d <= min(max_dist_x, max_dist_y) apart (a read that matches its locus up to
+                // substitutions): the situation of k_pair_pass mode 2 - mg_lchain_dp links every anchor to its predecessor, the backtrack returns
+                // one chain, its stretch is the chain - with K in place of the read's seeds.  No DP: covered, U and the span come from the lanes.
+                bool fast = false;
+                {
+                    int32_t mdy = P.is_sr ? (qlen > P.max_gap ? qlen : P.max_gap) : P.max_gap;
+                    if (mdy < P.bw) mdy = P.bw;
+                    const int32_t dmax = (int32_t)mdx < mdy ? (int32_t)mdx : mdy;
+                    const bool in = lane < n_k;
+                    const uint32_t dg = (uint32_t)x - q, dg0 = (uint32_t)__shfl((int)dg, 0);
+                    const uint32_t qpv = (uint32_t)__shfl_up((int)q, 1);
+                    const int32_t dq = (int32_t)q - (int32_t)qpv;
+                    const bool good = !in || (dg == dg0 && (lane == 0 || (dq > 0 && dq <= dmax)));
+                    fast = P.ext_s1 != 0 && __popcll(stm) == 1 && (int32_t)n_k >= P.min_cnt && __ballot(!good) == 0;
+                    if (fast) {
+                        const bool link = in && lane > 0;
+                        const int32_t covered = P.k + (int32_t)wave_sum_u32(link ? (uint32_t)(dq < P.k ? dq : P.k) : 0u);
+                        const int32_t unc = (int32_t)wave_sum_u32(link && dq > P.k ? (uint32_t)(dq - P.k) : 0u);
+                        const uint32_t q_first = (uint32_t)__shfl((int)q, 0), q_last = (uint32_t)__shfl((int)q, (int)n_k - 1);
+                        const uint32_t lo_first = (uint32_t)__shfl((int)(uint32_t)x, 0), hi_w = (uint32_t)__shfl((int)(uint32_t)(x >> 32), 0);
+                        if (covered > u_out && (int32_t)(q_last - q_first) >= P.k && covered >= P.min_sc) {
+                            if (unc <= P.ext_unc_max) code = 1;
+                            else {
+                                code = 2;
+                                mid.rid = (int32_t)(hi_w & 0x7fffffffu); mid.rev = (int32_t)(hi_w >> 31);
+                                mid.qs = (int32_t)q_first + 1 - P.k; mid.qe = (int32_t)q_last + 1; mid.rs = (int32_t)lo_first + 1 - P.k;
+                            }
+                        } else fast = false;      // not regs[0] for sure, or too short: the general way (which will also decline)
+                    }
+                }
+                // else K's clusters one after the other, each chained by the WHOLE wave (64 predecessors at a time, then the backtrack executed
+                // uniformly): a single lane walking a 13-anchor cluster through LDS took ~70 us a read, 84 % of this kernel.  Every lane ends with the same bc.
                 BestChain bc{};
-                uint64_t todo = __ballot(start && clen >= 2u);
+                uint64_t todo = fast ? 0ull : __ballot(start && clen >= 2u);
                 while (todo) {
                     const uint32_t cb = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
                     todo &= todo - 1;
@@ -1116,17 +1156,7 @@ __global__ __launch_bounds__(64) void k_local_cluster(K2Args a)
                     chain_dp_wave(S, cl, qlen, P, lane);
                     backtrack_mask(S, cl, P, n_u, best, false, be);
                 }
-                // U_out: query bases covered by the k-mers of the seeds that have occurrences outside K (lanes are in query order)
-                const bool outside = have0 && occ0 > c_l;
-                const uint64_t om = __ballot(outside);
-                const uint64_t below = om & ((1ULL << lane) - 1);
-                const int32_t prev_en = (int32_t)((uint32_t)__shfl((int)rec0.w, below ? 63 - __clzll((unsigned long long)below) : 0) >> 1) + 1;
-                const int32_t en = (int32_t)(rec0.w >> 1) + 1, st = en - P.k;
-                const int32_t cover = outside ? en - (below && prev_en > st ? prev_en : st) : 0;
-                const int32_t u_out = (int32_t)wave_sum_u32((uint32_t)cover);
-                int32_t code = 0;
-                MidReq mid{0, 0, 0, 0, 0};
-                if (bc.n > 0 && !bc.tie && bc.score > u_out) {      // uniform
+                if (!fast && bc.n > 0 && !bc.tie && bc.score > u_out) {      // uniform
                     SliceStore S{(const uint64_t *)&e_x[bc.base], (const uint32_t *)&e_q[bc.base], e_f + bc.base, e_pt + 2 * (size_t)bc.base};
                     code = chain_lemma(S, bc.zi, bc.end_i, P, (uint32_t)(S.X(bc.zi) >> 32), mid);
                 }
