@@ -64,6 +64,7 @@ struct Counters {
     uint32_t n_small, n_resketch, n_big[2], n_big_defer[2], n_defer, n_small2;      // n_small2: LDS-path reads the pair pass left undecided
     uint32_t n_big_total, pad1;   // repeat-path reads before the pair pass took its share (0: no pair pass)
     uint32_t n_sort[N_SORT_CLS], n_giant_tiles, n_giant_rounds;
+    uint32_t sort_ticket[N_SORT_CLS];      // k_sort_lds: next item of the class (blocks draw reads one by one: their costs differ a hundredfold)
     uint32_t n_long_segs, pad2;
     uint32_t ext_reason[8];       // why the top chain did not settle a read (k_ext_top)
     uint32_t ext_s3[8];           // SCRUBBY_HIP_DBG & 16: outcome of the local-cluster shortcut (k_expand): 0 tried, 1 no singleton / filtered seed, 2 singletons apart, 3 window grew / too many, 4 K > 64, 5 no margin over U_out, 6 lemma, 7 decided
@@ -1995,7 +1996,15 @@ __global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
     __shared__ uint32_t s_bstart[NMAX / 7 + 1], s_blen[NMAX / 7 + 1], s_gkey[GP_SLOTS], s_gcnt[GP_SLOTS], s_gw[16], s_gsel[2];
     const uint32_t tid = threadIdx.x;
     const uint32_t n_items = a.ctr->n_sort[CLS];
-    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+    __shared__ uint32_t s_it;
+    for (;;) {
+        // a ticket per read instead of a fixed stride: a read whose anchors are one 500-anchor cluster takes ten times the typical one, and with a
+        // few reads per block (small batches: an eighth of the records on each of 8 GPUs) the stride left most blocks waiting for the unlucky ones
+        if (tid == 0) s_it = atomicAdd(&a.ctr->sort_ticket[CLS], 1u);
+        __syncthreads();
+        const uint32_t it = s_it;
+        __syncthreads();
+        if (it >= n_items) break;
         const SortItem si = a.B.sort_items[CLS][it];
         const uint32_t n = si.n;
         if (n == 0) continue;
@@ -2172,7 +2181,13 @@ __global__ __launch_bounds__(1024) void k_giant_chain(K3Args a, int phase)
     __shared__ uint32_t s_bstart[2048], s_blen[2048], s_nxt[1024];
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const uint32_t n_items = a.ctr->n_sort[SORT_CLS_GIANT];
-    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+    __shared__ uint32_t s_it;
+    for (;;) {
+        if (tid == 0) s_it = atomicAdd(&a.ctr->sort_ticket[SORT_CLS_GIANT], 1u);      // a ticket per read (reset before every launch): giant reads differ a hundredfold
+        __syncthreads();
+        const uint32_t it = s_it;
+        __syncthreads();
+        if (it >= n_items) break;
         const SortItem si = a.B.sort_items[SORT_CLS_GIANT][it];
         const uint32_t n = si.n;
         if (n == 0) continue;                 // decided by k_group_probe
@@ -2767,6 +2782,7 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     Counters *ctr = c->d_ctr;
     SH_HIP(hipMemsetAsync(&ctr->anchor_cursor, 0, 8, s));
     SH_HIP(hipMemsetAsync(&ctr->n_sort[0], 0, 4 * N_SORT_CLS, s));
+    SH_HIP(hipMemsetAsync(&ctr->sort_ticket[0], 0, 4 * N_SORT_CLS, s));
     SH_HIP(hipMemsetAsync(&ctr->n_cl[0], 0, 4 * 6, s));
     // 6144 waves for 4096 resident (103 VGPRs: 4 per SIMD): measured best; 4096 or 5120 waves, or 5 waves per SIMD at 96 VGPRs, are 0-3 % slower
     if (k.seed_off) hipLaunchKernelGGL(k_expand<true>, dim3(grid * 3), dim3(64), 0, s, k);
@@ -2799,7 +2815,10 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     const bool two_phase = k.t_mode && k.sink.best != nullptr;
     hipLaunchKernelGGL(k_giant_chain, dim3(512), dim3(1024), 0, g, k, two_phase ? 0 : -1);
     if (!(k.dbg & 32)) hipLaunchKernelGGL(k_cluster_dp, dim3(256 * 4), dim3(256), 0, g, k);
-    if (two_phase) hipLaunchKernelGGL(k_giant_chain, dim3(512), dim3(1024), 0, g, k, 1);
+    if (two_phase) {
+        SH_HIP(hipMemsetAsync(&ctr->sort_ticket[SORT_CLS_GIANT], 0, 4, g));
+        hipLaunchKernelGGL(k_giant_chain, dim3(512), dim3(1024), 0, g, k, 1);
+    }
     if (side) for (int i = 0; i < 3; ++i) { SH_HIP(hipEventRecord(c->evx[1 + i], c->sx[i])); SH_HIP(hipStreamWaitEvent(s, c->evx[1 + i], 0)); }
     hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, s, k);
     return SH_OK;
