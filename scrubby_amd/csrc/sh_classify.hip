@@ -677,6 +677,7 @@ struct BigBufs {        // the repeat path's slice of the arena (all arrays inde
     BigMeta *meta; int32_t *acc_nu, *acc_best;
     SortItem *sort_items[N_SORT_CLS];
     uint32_t *tile_base, *tile_split;       // giant reads: tile table and merge-path splits
+    uint32_t *giant_order;                  // giant reads by falling size class (k_giant_scan): k_giant_chain draws the largest first
     SortItem *cl_items[4]; uint32_t cl_cap[4];   // big clusters of giant reads (w, n, qlen, pad = buffer, off = first anchor slot)
 };
 
@@ -2070,6 +2071,22 @@ __global__ __launch_bounds__(64) void k_giant_scan(K3Args a)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { uint32_t v = (uint32_t)__shfl_xor((int)max_n, o); max_n = v > max_n ? v : max_n; }
     if (lane == 0) { a.B.tile_base[n_items] = run; a.ctr->n_giant_tiles = run; a.ctr->n_giant_rounds = giant_rounds(max_n); }
+    // largest first: a read of 500 k anchors drawn last would run on alone after every other block has finished.  Counting sort by
+    // floor(log2 n), falling; the order inside a size class does not matter.
+    __shared__ uint32_t s_cnt[33];
+    if (lane < 33) s_cnt[lane] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_items; base += 64) {
+        const uint32_t i = base + lane;
+        if (i < n_items) { const uint32_t n_i = a.B.sort_items[SORT_CLS_GIANT][i].n; atomicAdd(&s_cnt[n_i ? 32 - __clz((int)n_i) : 0], 1u); }
+    }
+    __syncthreads();
+    if (lane == 0) { uint32_t acc = 0; for (int b = 32; b >= 0; --b) { const uint32_t c = s_cnt[b]; s_cnt[b] = acc; acc += c; } }
+    __syncthreads();
+    for (uint32_t base = 0; base < n_items; base += 64) {
+        const uint32_t i = base + lane;
+        if (i < n_items) { const uint32_t n_i = a.B.sort_items[SORT_CLS_GIANT][i].n; a.B.giant_order[atomicAdd(&s_cnt[n_i ? 32 - __clz((int)n_i) : 0], 1u)] = i; }
+    }
 }
 
 __device__ inline uint32_t giant_item_of(const uint32_t *tile_base, uint32_t n_items, uint32_t t)
@@ -2188,7 +2205,7 @@ __global__ __launch_bounds__(1024) void k_giant_chain(K3Args a, int phase)
         const uint32_t it = s_it;
         __syncthreads();
         if (it >= n_items) break;
-        const SortItem si = a.B.sort_items[SORT_CLS_GIANT][it];
+        const SortItem si = a.B.sort_items[SORT_CLS_GIANT][a.B.giant_order[it]];
         const uint32_t n = si.n;
         if (n == 0) continue;                 // decided by k_group_probe
         const bool in_b = giant_rounds(n) & 1;
@@ -2667,7 +2684,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         const uint64_t sort_cap[N_SORT_CLS] = {max_reads + 32 * waves, max_reads + 32 * waves, max_reads + 8 * waves, max_reads + 8 * waves, max_reads + waves, max_reads + waves};
         uint64_t sort_cap_sum = 0;
         for (int i = 0; i < N_SORT_CLS; ++i) sort_cap_sum += sort_cap[i];
-        uint64_t fixed = 4 * 64 * sizeof(SortItem) + 4096 + max_reads * (sizeof(BigMeta) + 8 + 8) + sort_cap_sum * sizeof(SortItem) + 16384;
+        uint64_t fixed = 4 * 64 * sizeof(SortItem) + 4096 + max_reads * (sizeof(BigMeta) + 8 + 8) + sort_cap_sum * sizeof(SortItem) + sort_cap[N_SORT_CLS - 1] * 4 + 16384;
         uint64_t per_anchor = 8 + 8 + 8 + 4 + 4 + 4 + 2 + (c->ext ? 8 + 3 : 0);   // ax bx az aq bq af (+ tile_split and cluster queue shares) (+ hz)
         uint64_t cap = left > fixed ? (left - fixed) / per_anchor : 0;
         cap &= ~15ull;
@@ -2683,6 +2700,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         B.acc_nu = (int32_t *)take(max_reads * 4); B.acc_best = (int32_t *)take(max_reads * 4);
         for (int i = 0; i < N_SORT_CLS; ++i) B.sort_items[i] = (SortItem *)take(sort_cap[i] * sizeof(SortItem));
         B.tile_base = (uint32_t *)take((max_reads + 1) * 4);
+        B.giant_order = (uint32_t *)take(sort_cap[N_SORT_CLS - 1] * 4);
         B.tile_split = (uint32_t *)take((cap / GT + max_reads + 2) * 4);
         {   // a cluster of class c has more than {4096, 1024, 256, 64} anchors
             const uint64_t div[4] = {4096, 1024, 256, c->ext ? 8u : 64u};
