@@ -64,6 +64,7 @@ struct Counters {
     uint32_t n_small, n_resketch, n_big[2], n_big_defer[2], n_defer, n_small2;      // n_small2: LDS-path reads the pair pass left undecided
     uint32_t n_big_total, pad1;   // repeat-path reads before the pair pass took its share (0: no pair pass)
     uint32_t n_sort[N_SORT_CLS], n_giant_tiles, n_giant_rounds;
+    uint32_t expand_ticket, pad_t;         // k_expand: next read of the pass's list
     uint32_t sort_ticket[N_SORT_CLS];      // k_sort_lds: next item of the class (blocks draw reads one by one: their costs differ a hundredfold)
     uint32_t n_long_segs, pad2;
     uint32_t ext_reason[8];       // why the top chain did not settle a read (k_ext_top)
@@ -1549,7 +1550,12 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
     __shared__ uint32_t e_q[64];
     __shared__ int32_t e_f[64], e_pt[128], e_bcount;
     __shared__ uint32_t e_bstart[8], e_blen[8];
-    for (uint32_t w = blockIdx.x; w < n_items; w += gridDim.x) {
+    for (;;) {
+        // reads by ticket (one wave per read: a long read expands 100 to 100 000 anchors)
+        uint32_t w = 0;
+        if (lane == 0) w = atomicAdd(&a.ctr->expand_ticket, 1u);
+        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+        if (w >= n_items) break;
         const uint32_t r = a.list[w];
         const uint32_t info = a.k1info[r];
         const uint32_t n_seed = info >> 16;
@@ -2801,6 +2807,7 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     SH_HIP(hipMemsetAsync(&ctr->anchor_cursor, 0, 8, s));
     SH_HIP(hipMemsetAsync(&ctr->n_sort[0], 0, 4 * N_SORT_CLS, s));
     SH_HIP(hipMemsetAsync(&ctr->sort_ticket[0], 0, 4 * N_SORT_CLS, s));
+    SH_HIP(hipMemsetAsync(&ctr->expand_ticket, 0, 4, s));
     SH_HIP(hipMemsetAsync(&ctr->n_cl[0], 0, 4 * 6, s));
     // 6144 waves for 4096 resident (103 VGPRs: 4 per SIMD): measured best; 4096 or 5120 waves, or 5 waves per SIMD at 96 VGPRs, are 0-3 % slower
     if (k.seed_off) hipLaunchKernelGGL(k_expand<true>, dim3(grid * 3), dim3(64), 0, s, k);
