@@ -2061,38 +2061,34 @@ __device__ inline uint32_t giant_rounds(uint32_t n)
     return r;
 }
 
-__global__ __launch_bounds__(64) void k_giant_scan(K3Args a)
+__global__ __launch_bounds__(1024) void k_giant_scan(K3Args a)
 {
-    const uint32_t lane = threadIdx.x, n_items = a.ctr->n_sort[SORT_CLS_GIANT];
-    uint32_t run = 0, max_n = 0;
-    for (uint32_t base = 0; base < n_items; base += 64) {
-        const uint32_t i = base + lane;
-        const uint32_t n_i = i < n_items ? a.B.sort_items[SORT_CLS_GIANT][i].n : 0;
-        max_n = n_i > max_n ? n_i : max_n;
-        const uint32_t t = (n_i + GT - 1) / GT;
-        const uint32_t ex = wave_excl_scan_u32(t, lane);
-        if (i < n_items) a.B.tile_base[i] = run + ex;
-        run += wave_sum_u32(t);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { uint32_t v = (uint32_t)__shfl_xor((int)max_n, o); max_n = v > max_n ? v : max_n; }
-    if (lane == 0) { a.B.tile_base[n_items] = run; a.ctr->n_giant_tiles = run; a.ctr->n_giant_rounds = giant_rounds(max_n); }
-    // largest first: a read of 500 k anchors drawn last would run on alone after every other block has finished.  Counting sort by
-    // floor(log2 n), falling; the order inside a size class does not matter.
+    const uint32_t tid = threadIdx.x, lane = tid & 63, n_items = a.ctr->n_sort[SORT_CLS_GIANT];
     __shared__ uint32_t s_cnt[33];
-    if (lane < 33) s_cnt[lane] = 0;
+    if (tid < 33) s_cnt[tid] = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < n_items; base += 64) {
-        const uint32_t i = base + lane;
-        if (i < n_items) { const uint32_t n_i = a.B.sort_items[SORT_CLS_GIANT][i].n; atomicAdd(&s_cnt[n_i ? 32 - __clz((int)n_i) : 0], 1u); }
+    if (tid < 64) {      // the tile table: a running sum, one wave
+        uint32_t run = 0, max_n = 0;
+        for (uint32_t base = 0; base < n_items; base += 64) {
+            const uint32_t i = base + lane;
+            const uint32_t n_i = i < n_items ? a.B.sort_items[SORT_CLS_GIANT][i].n : 0;
+            max_n = n_i > max_n ? n_i : max_n;
+            const uint32_t t = (n_i + GT - 1) / GT;
+            const uint32_t ex = wave_excl_scan_u32(t, lane);
+            if (i < n_items) a.B.tile_base[i] = run + ex;
+            run += wave_sum_u32(t);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { uint32_t v = (uint32_t)__shfl_xor((int)max_n, o); max_n = v > max_n ? v : max_n; }
+        if (lane == 0) { a.B.tile_base[n_items] = run; a.ctr->n_giant_tiles = run; a.ctr->n_giant_rounds = giant_rounds(max_n); }
     }
+    // largest first: a read of 500 k anchors drawn last would run on alone after every other block has finished.  Counting sort by
+    // floor(log2 n), falling (the whole block); the order inside a size class does not matter.
+    for (uint32_t i = tid; i < n_items; i += 1024) { const uint32_t n_i = a.B.sort_items[SORT_CLS_GIANT][i].n; atomicAdd(&s_cnt[n_i ? 32 - __clz((int)n_i) : 0], 1u); }
     __syncthreads();
-    if (lane == 0) { uint32_t acc = 0; for (int b = 32; b >= 0; --b) { const uint32_t c = s_cnt[b]; s_cnt[b] = acc; acc += c; } }
+    if (tid == 0) { uint32_t acc = 0; for (int b = 32; b >= 0; --b) { const uint32_t c = s_cnt[b]; s_cnt[b] = acc; acc += c; } }
     __syncthreads();
-    for (uint32_t base = 0; base < n_items; base += 64) {
-        const uint32_t i = base + lane;
-        if (i < n_items) { const uint32_t n_i = a.B.sort_items[SORT_CLS_GIANT][i].n; a.B.giant_order[atomicAdd(&s_cnt[n_i ? 32 - __clz((int)n_i) : 0], 1u)] = i; }
-    }
+    for (uint32_t i = tid; i < n_items; i += 1024) { const uint32_t n_i = a.B.sort_items[SORT_CLS_GIANT][i].n; a.B.giant_order[atomicAdd(&s_cnt[n_i ? 32 - __clz((int)n_i) : 0], 1u)] = i; }
 }
 
 __device__ inline uint32_t giant_item_of(const uint32_t *tile_base, uint32_t n_items, uint32_t t)
@@ -2830,7 +2826,7 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     hipLaunchKernelGGL((k_sort_lds<1024, 2, 256>), dim3(256 * 6), dim3(256), 0, s0, k);
     hipLaunchKernelGGL((k_sort_lds<SORT_LDS_B, 3, 256>), dim3(256 * 3), dim3(256), 0, s0, k);
     hipLaunchKernelGGL((k_sort_lds<SORT_LDS_C, 4, 512>), dim3(256), dim3(512), 0, s1, k);
-    hipLaunchKernelGGL(k_giant_scan, dim3(1), dim3(64), 0, g, k);
+    hipLaunchKernelGGL(k_giant_scan, dim3(1), dim3(1024), 0, g, k);
     hipLaunchKernelGGL(k_giant_chunksort, dim3(256 * 3), dim3(256), 0, g, k);
     for (uint32_t round = 0; round < 8; ++round) {      // run widths GT << round: up to 2^19 anchors per read
         hipLaunchKernelGGL(k_giant_partition, dim3(256), dim3(256), 0, g, k, round);
