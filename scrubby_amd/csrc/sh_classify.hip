@@ -1550,12 +1550,18 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
     __shared__ uint32_t e_q[64];
     __shared__ int32_t e_f[64], e_pt[128], e_bcount;
     __shared__ uint32_t e_bstart[8], e_blen[8];
+    // reads by ticket, 4 to a draw (one wave per read: a long read expands 100 to 100 000 anchors; one atomic per read on a single address
+    // cost more than the imbalance it removed - a single address sustains ~90 M atomics/s)
+    uint32_t w_next = 0, w_stop = 0;
     for (;;) {
-        // reads by ticket (one wave per read: a long read expands 100 to 100 000 anchors)
-        uint32_t w = 0;
-        if (lane == 0) w = atomicAdd(&a.ctr->expand_ticket, 1u);
-        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
-        if (w >= n_items) break;
+        if (w_next >= w_stop) {
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(&a.ctr->expand_ticket, 4u);
+            w_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            w_stop = w_next + 4u < n_items ? w_next + 4u : n_items;
+            if (w_next >= n_items) break;
+        }
+        const uint32_t w = w_next++;
         const uint32_t r = a.list[w];
         const uint32_t info = a.k1info[r];
         const uint32_t n_seed = info >> 16;
