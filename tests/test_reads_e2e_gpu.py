@@ -109,7 +109,9 @@ def test_streaming_pipeline_small_chunks_and_second_pass(dataset, monkeypatch):
     d, fa, r1, r2, ids, n_pairs = dataset
     monkeypatch.setenv("SCRUBBY_HIP_CHUNK_MB", "1")            # R1 is ~3.3 MB: several chunks, records straddle the cuts
     outs = {}
-    for name, env in (("retained", {}), ("streamed", {"SCRUBBY_HIP_RETAIN_MB": "0"}), ("legacy", {"SCRUBBY_HIP_LEGACY_HOST": "1"})):
+    # "retained": the device thread classifies whatever chunks have piled up in one call (concatenated in HBM); "per_chunk": one call each
+    for name, env in (("retained", {}), ("streamed", {"SCRUBBY_HIP_RETAIN_MB": "0"}), ("per_chunk", {"SCRUBBY_HIP_NO_COALESCE": "1"}),
+                      ("legacy", {"SCRUBBY_HIP_LEGACY_HOST": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         o1, o2, js, tsv = (str(d / f"{name}_{x}") for x in ("1.fastq", "2.fastq.gz", "r.json", "ids.tsv.gz"))
@@ -121,7 +123,7 @@ def test_streaming_pipeline_small_chunks_and_second_pass(dataset, monkeypatch):
         assert got[0] == "id" and set(x for x in got[1:] if x) == ids
         outs[name] = (res["reads_in"], res["reads_out"], res["reads_removed"], res["reads_extracted"], res["n_depleted_ids"],
                       open(o1, "rb").read(), gzip.open(o2, "rb").read())
-    assert outs["retained"] == outs["streamed"] == outs["legacy"]
+    assert outs["retained"] == outs["streamed"] == outs["per_chunk"] == outs["legacy"]
     assert outs["retained"][:3] == (2 * n_pairs, 2 * (n_pairs - len(ids)), 2 * len(ids))
     # extract mode with the id table: the ids NOT written are the complement
     o1, o2, tsv = str(d / "sx1.fastq"), str(d / "sx2.fastq"), str(d / "sx.tsv")
