@@ -826,8 +826,11 @@ __device__ inline int32_t ld_agent(const int32_t *p) { return __hip_atomic_load(
 // that leaves the ring window fences once and reads them past the L1 (the next chunk's loads are issued a chunk ahead).
 // Requires P.max_iter <= RING_TMAX_ITER.
 __device__ inline bool chain_dp_ring(const uint64_t *gx, const uint32_t *gq, int32_t *gf, int32_t *gpt, int n, int32_t qlen,
-                                     const ChainParams &P, uint32_t lane, RingMem &rm, unsigned long long *dbg_cnt = nullptr, int32_t stop_at = INT32_MAX)
+                                     const ChainParams &P_in, uint32_t lane, RingMem &rm, unsigned long long *dbg_cnt = nullptr, int32_t stop_at = INT32_MAX)
 {
+    // the parameters by value: through the reference they live in the kernel's private copy of its argument struct, and every use inside the
+    // loops below was a scratch load (five per chunk of predecessors in the ISA)
+    const ChainParams P = P_in;
     unsigned long long n_ch_in = 0, n_ch_out = 0, n_far = 0;
     int32_t max_dist_y = P.is_sr ? (qlen > P.max_gap ? qlen : P.max_gap) : P.max_gap;
     int32_t max_dist_x;

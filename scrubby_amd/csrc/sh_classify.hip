@@ -671,6 +671,10 @@ __global__ void k_route_all(uint64_t n_reads, uint32_t *work_resketch, Counters 
 // ------------------------------------------------------------------------------------------------
 struct BigMeta { uint32_t r, n_a; int32_t rep_len; uint32_t state; };   // state: 0 expanded, 1 deferred
 struct SortItem { uint32_t w, n, qlen, pad; unsigned long long off; };
+// The class tables once more, in HBM: a kernel that indexes an array INSIDE its argument struct with a run-time value (the sort class a
+// read falls into, the size class of a cluster) gets the whole struct copied to scratch, and every later a.X becomes a scratch load - the
+// ISA of k_cluster_dp had five of them per chunk of predecessors.  Run-time indices go through BigBufs::tabs; compile-time ones keep the copy.
+struct BigTables { struct SortItem *sort_items[N_SORT_CLS]; struct SortItem *cl_items[4]; uint32_t cl_cap[4]; };
 struct BigBufs {        // the repeat path's slice of the arena (all arrays indexed by anchor slot)
     uint64_t *ax, *bx, *az; uint32_t *aq, *bq; int32_t *af;   // anchors (+ sort ping-pong), DP state f and (p,t)
     uint64_t *hz;                                             // SH_F_CIGAR: backtrack heap of clusters chained from LDS (the anchors must survive for the hand-over)
@@ -680,6 +684,7 @@ struct BigBufs {        // the repeat path's slice of the arena (all arrays inde
     uint32_t *tile_base, *tile_split;       // giant reads: tile table and merge-path splits
     uint32_t *giant_order;                  // giant reads by falling size class (k_giant_scan): k_giant_chain draws the largest first
     SortItem *cl_items[4]; uint32_t cl_cap[4];   // big clusters of giant reads (w, n, qlen, pad = buffer, off = first anchor slot)
+    const BigTables *tabs;                       // the three arrays above in HBM, for run-time indices
 };
 
 struct K2Args {
@@ -1541,7 +1546,8 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
 {
     const uint32_t lane = threadIdx.x;
     const uint32_t n_items = *a.list_count;
-    const ChainParams &P = a.P;
+    const ChainParams P = a.P;      // local copies (see k_giant_chain)
+    const ChainSink sink_l = a.sink;
     const bool plain_cut = !(P.occ_dist > 0 && P.max_max_occ > a.max_occ);
     WaveAlloc al_sort[N_SORT_CLS];
     uint32_t n_clusters = 0, n_pair = 0, n_lemma = 0;
@@ -1813,7 +1819,7 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
             }
             if (!lemma_done)
             chain_sorted<false>(e_x, e_q, e_f, e_pt, n_a, lane, 64, qlen, P, nullptr, BigList{e_bstart, e_blen, &e_bcount, 8}, n_u, best, n_clusters,
-                                nullptr, nullptr, a.emit ? &a.sink : nullptr, r, nullptr);      // <= 64 anchors: no cluster needs a heap
+                                nullptr, nullptr, a.emit ? &sink_l : nullptr, r, nullptr);      // <= 64 anchors: no cluster needs a heap
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { n_u += __shfl_xor(n_u, o); int32_t b = __shfl_xor(best, o); best = b > best ? b : best; }
             if (lane == 0) { a.B.acc_nu[w] = n_u; a.B.acc_best[w] = best; }
@@ -1823,13 +1829,14 @@ __global__ __launch_bounds__(64) void k_expand(K3Args a)
             const int cls = n_a <= 256 ? 0 : (n_a <= SORT_LDS_A ? 1 : (n_a <= 1024 ? 2 : (n_a <= SORT_LDS_B ? 3 : (n_a <= SORT_LDS_C ? 4 : SORT_CLS_GIANT))));
             uint32_t lo, hi;
             const uint32_t si = al_sort[cls].take(&a.ctr->n_sort[cls], 1, cls <= 1 ? 32u : (cls <= 3 ? 8u : 1u), lo, hi);
-            for (uint32_t i = lo + lane; i < hi; i += 64) a.B.sort_items[cls][i].n = 0;
-            if (lane == 0) { SortItem it{w, n_a, (uint32_t)qlen, 0, off}; a.B.sort_items[cls][si] = it; }
+            SortItem *const items = a.B.tabs->sort_items[cls];
+            for (uint32_t i = lo + lane; i < hi; i += 64) items[i].n = 0;
+            if (lane == 0) { SortItem it{w, n_a, (uint32_t)qlen, 0, off}; items[si] = it; }
             if ((a.dbg & 16) && lane == 0) { atomicAdd(&a.ctr->sort_tot[cls], 1ull); atomicAdd(&a.ctr->sort_anchor_tot[cls], (unsigned long long)n_a); }
         }
     }
     for (int cls = 0; cls < N_SORT_CLS; ++cls)
-        for (uint32_t i = al_sort[cls].cur + lane; i < al_sort[cls].end; i += 64) a.B.sort_items[cls][i].n = 0;
+        for (uint32_t i = al_sort[cls].cur + lane; i < al_sort[cls].end; i += 64) a.B.tabs->sort_items[cls][i].n = 0;
     if (lane == 0 && anchors_wave) atomicAdd(&a.ctr->sh_anchors[SHARD()], anchors_wave);
     n_clusters = wave_sum_u32(n_clusters);
     if (lane == 0 && n_clusters) atomicAdd(&a.ctr->sh_clusters[SHARD()], n_clusters);
@@ -1985,13 +1992,13 @@ __global__ __launch_bounds__(256) void k_group_probe(K3Args a, int cls)
     const uint32_t n_items = a.ctr->n_sort[cls];
     const GroupScratch G{s_key, s_cnt, s_wtot, s_sel, &s_over};
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const SortItem si = a.B.sort_items[cls][it];
+        const SortItem si = a.B.tabs->sort_items[cls][it];
         const uint32_t n = si.n;
         if (n == 0) continue;
         uint32_t n_cl = 0;
         const bool hit = group_probe(a.B.ax + si.off, a.B.aq + si.off, n, s_x[0], s_q[0], s_x[1], s_q[1], 0u, (uint32_t)GP_CAP, G, &s_found,
                                      BigList{s_bstart, s_blen, &s_bcount, GP_CAP / 7 + 1}, a.P, (int32_t)si.qlen, n_cl);
-        if (tid == 0 && hit) { a.B.acc_nu[si.w] = 1; a.B.acc_best[si.w] = 0; a.B.sort_items[cls][it].n = 0; }
+        if (tid == 0 && hit) { a.B.acc_nu[si.w] = 1; a.B.acc_best[si.w] = 0; a.B.tabs->sort_items[cls][it].n = 0; }
         n_cl = wave_sum_u32(n_cl);
         if (lane == 0 && n_cl) atomicAdd(&a.ctr->sh_clusters[SHARD()], n_cl);
         __syncthreads();
@@ -2200,10 +2207,13 @@ __global__ __launch_bounds__(256) void k_giant_merge(K3Args a, uint32_t round)
 }
 
 // one block per giant read: clusters chained over arena slices of the buffer its sort ended in
-__global__ __launch_bounds__(1024) void k_giant_chain(K3Args a, int phase)
+__global__ __launch_bounds__(512) void k_giant_chain(K3Args a, int phase)
 {
     __shared__ int32_t s_found, s_red[2], s_bcount;
     __shared__ uint32_t s_bstart[2048], s_blen[2048], s_nxt[1024];
+    // local copies: a pointer or reference INTO the argument struct makes the compiler copy all ~640 B of it to scratch at entry and read
+    // every a.X from there afterwards
+    const ChainSink sink_l = a.sink; const ChainParams P_l = a.P;
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const uint32_t n_items = a.ctr->n_sort[SORT_CLS_GIANT];
     __shared__ uint32_t s_it;
@@ -2221,11 +2231,11 @@ __global__ __launch_bounds__(1024) void k_giant_chain(K3Args a, int phase)
         if (tid == 0) s_found = 0;
         __syncthreads();
         int32_t n_u = 0, best = 0; uint32_t n_cl = 0;
-        const GlobalQ gq{a.B.cl_items, a.B.cl_cap, a.ctr->n_cl, si.w, in_b ? 1u : 0u, si.off};
+        const GlobalQ gq{a.B.tabs->cl_items, a.B.tabs->cl_cap, a.ctr->n_cl, si.w, in_b ? 1u : 0u, si.off};
         if (!(a.dbg & 2))
-        chain_sorted<true>(sx, sq, a.B.af + si.off, (int32_t *)(a.B.az + si.off), n, tid, nthr, (int32_t)si.qlen, a.P,
+        chain_sorted<true>(sx, sq, a.B.af + si.off, (int32_t *)(a.B.az + si.off), n, tid, nthr, (int32_t)si.qlen, P_l,
                      a.flag_only ? &s_found : nullptr, BigList{s_bstart, s_blen, &s_bcount, 2048}, n_u, best, n_cl, &gq, s_nxt,
-                     a.emit ? &a.sink : nullptr, a.B.meta[si.w].r, a.emit ? (in_b ? a.B.ax : a.B.bx) + si.off : nullptr,      // heap: the sort's other buffer
+                     a.emit ? &sink_l : nullptr, a.B.meta[si.w].r, a.emit ? (in_b ? a.B.ax : a.B.bx) + si.off : nullptr,      // heap: the sort's other buffer
                      nullptr, 0u, phase);
         store_read_result(a, si.w, n_u, best, n_cl, s_red, phase == 1);
         __syncthreads();
@@ -2238,17 +2248,23 @@ __global__ __launch_bounds__(256) void k_cluster_dp(K3Args a)
 {
     __shared__ RingMem s_ring[4];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t cnt[4], total = 0;
-    for (int c = 0; c < 4; ++c) { cnt[c] = a.ctr->n_cl[c] < a.B.cl_cap[c] ? a.ctr->n_cl[c] : a.B.cl_cap[c]; total += cnt[c]; }
+    // the four class counts in scalars (an array indexed by the class would live in scratch)
+    const uint32_t cnt0 = min(a.ctr->n_cl[0], a.B.cl_cap[0]), cnt1 = min(a.ctr->n_cl[1], a.B.cl_cap[1]);
+    const uint32_t cnt2 = min(a.ctr->n_cl[2], a.B.cl_cap[2]), cnt3 = min(a.ctr->n_cl[3], a.B.cl_cap[3]);
+    const uint32_t total = cnt0 + cnt1 + cnt2 + cnt3;
     uint32_t n_cl = 0;
     for (;;) {
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(&a.ctr->cl_ticket, 1u);
         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
         if (t >= total) break;
-        int c = 0;
-        while (t >= cnt[c]) { t -= cnt[c]; ++c; }
-        const SortItem ci = a.B.cl_items[c][t];
+        int c;
+        const SortItem *items;
+        if (t < cnt0) { c = 0; items = a.B.cl_items[0]; }
+        else if (t < cnt0 + cnt1) { c = 1; t -= cnt0; items = a.B.cl_items[1]; }
+        else if (t < cnt0 + cnt1 + cnt2) { c = 2; t -= cnt0 + cnt1; items = a.B.cl_items[2]; }
+        else { c = 3; t -= cnt0 + cnt1 + cnt2; items = a.B.cl_items[3]; }
+        const SortItem ci = items[t];
         if (a.flag_only && __atomic_load_n(&a.B.acc_nu[ci.w], __ATOMIC_RELAXED) > 0) continue;      // the read is decided
         const bool in_b = (ci.pad & 1u) != 0;
         const uint64_t *gx = (in_b ? a.B.bx : a.B.ax) + ci.off; uint32_t *gq = (in_b ? a.B.bq : a.B.aq) + ci.off;
@@ -2714,6 +2730,14 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             const uint64_t div[4] = {4096, 1024, 256, c->ext ? 8u : 64u};
             for (int i = 0; i < 4; ++i) { B.cl_cap[i] = (uint32_t)std::min<uint64_t>(cap / div[i] + 64, UINT32_MAX); B.cl_items[i] = (SortItem *)take((uint64_t)B.cl_cap[i] * sizeof(SortItem)); }
         }
+        {
+            BigTables h{};
+            for (int i = 0; i < N_SORT_CLS; ++i) h.sort_items[i] = B.sort_items[i];
+            for (int i = 0; i < 4; ++i) { h.cl_items[i] = B.cl_items[i]; h.cl_cap[i] = B.cl_cap[i]; }
+            BigTables *d_t = (BigTables *)take(sizeof(BigTables));
+            if (hipMemcpy(d_t, &h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) { sh_set_error("sh_ctx_create: class tables"); sh_ctx_destroy(c); return SH_ERR_HIP; }
+            B.tabs = d_t;
+        }
         if ((uint64_t)(p - c->d_arena) > c->arena_bytes) {   // alignment slack: shrink
             sh_set_error("sh_ctx_create: internal arena carve overflow"); sh_ctx_destroy(c); return SH_ERR_OOM;
         }
@@ -2840,11 +2864,11 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     }
     // flag-only hand-over (t_mode): the big clusters first (k_cluster_dp), then the small ones against the best score those gave
     const bool two_phase = k.t_mode && k.sink.best != nullptr;
-    hipLaunchKernelGGL(k_giant_chain, dim3(512), dim3(1024), 0, g, k, two_phase ? 0 : -1);
+    hipLaunchKernelGGL(k_giant_chain, dim3(1024), dim3(512), 0, g, k, two_phase ? 0 : -1);
     if (!(k.dbg & 32)) hipLaunchKernelGGL(k_cluster_dp, dim3(256 * 4), dim3(256), 0, g, k);
     if (two_phase) {
         SH_HIP(hipMemsetAsync(&ctr->sort_ticket[SORT_CLS_GIANT], 0, 4, g));
-        hipLaunchKernelGGL(k_giant_chain, dim3(512), dim3(1024), 0, g, k, 1);
+        hipLaunchKernelGGL(k_giant_chain, dim3(1024), dim3(512), 0, g, k, 1);
     }
     if (side) for (int i = 0; i < 3; ++i) { SH_HIP(hipEventRecord(c->evx[1 + i], c->sx[i])); SH_HIP(hipStreamWaitEvent(s, c->evx[1 + i], 0)); }
     hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, s, k);
