@@ -989,7 +989,7 @@ __device__ inline uint32_t chain_max_dist_x(const ChainParams &P, int32_t qlen)
 //      decides whether it survives.  Anything else (no singleton, a seed above mid_occ, singletons at several loci, K beyond 64 anchors,
 //      no such margin, a stretch the lemma cannot vouch for) stays on the list for the full path.
 // Its own kernel (not a step of k_expand): ~60 registers instead of ~150, so three times the waves hide the dependent list probes.
-__global__ __launch_bounds__(64) void k_local_cluster(K2Args a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_local_cluster(K2Args a)
 {
     __shared__ uint64_t e_x[64];
     __shared__ uint32_t e_q[64];
@@ -2244,7 +2244,7 @@ __global__ __launch_bounds__(512) void k_giant_chain(K3Args a, int phase)
 
 // The big clusters of all giant reads, largest class first, one wave per cluster (persistent waves drawing tickets).
 // Results are merged into the per-read accumulators k_giant_chain stored.
-__global__ __launch_bounds__(256) void k_cluster_dp(K3Args a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_cluster_dp(K3Args a)
 {
     __shared__ RingMem s_ring[4];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -2865,7 +2865,7 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     // flag-only hand-over (t_mode): the big clusters first (k_cluster_dp), then the small ones against the best score those gave
     const bool two_phase = k.t_mode && k.sink.best != nullptr;
     hipLaunchKernelGGL(k_giant_chain, dim3(1024), dim3(512), 0, g, k, two_phase ? 0 : -1);
-    if (!(k.dbg & 32)) hipLaunchKernelGGL(k_cluster_dp, dim3(256 * 4), dim3(256), 0, g, k);
+    if (!(k.dbg & 32)) hipLaunchKernelGGL(k_cluster_dp, dim3(256 * 7), dim3(256), 0, g, k);      // 72 VGPRs: 7 waves per SIMD (4: 74 ms, 6: 60, 8 with spills: 57)
     if (two_phase) {
         SH_HIP(hipMemsetAsync(&ctr->sort_ticket[SORT_CLS_GIANT], 0, 4, g));
         hipLaunchKernelGGL(k_giant_chain, dim3(1024), dim3(512), 0, g, k, 1);
@@ -2990,7 +2990,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         K2Args pb = b;
         pb.work = c->d_big[0][cur0]; pb.work_count = &c->d_ctr->n_big[0];
         pb.leftover = c->d_big[0][cur0 ^ 1]; pb.leftover_count = &c->d_ctr->n_big_defer[0];
-        hipLaunchKernelGGL(k_local_cluster, dim3(256 * 24), dim3(64), 0, s, pb);      // latency-bound list probes: every wave slot
+        hipLaunchKernelGGL(k_local_cluster, dim3(256 * 32), dim3(64), 0, s, pb);      // latency-bound list probes: every wave slot
         hipLaunchKernelGGL(k_pair_swap, dim3(1), dim3(1), 0, s, c->d_ctr);
         cur0 ^= 1;
     }
