@@ -251,7 +251,9 @@ __device__ inline void ksw_backtrack_dev(bool is_rev, RD rd, const int32_t *off,
 // ksw_extd2_sse on one wave (oracle/mm_align.c mma_ksw_extd2 is the scalar statement of the same thing).
 // query / target: codes 0..4, readable by every lane (qg / tg: they are HBM scratch).
 // G = the buffers are the wave's HBM scratch; false = LDS (every pointer then derives from Ls alone, so the accesses compile to ds_*)
-template <bool G>
+// G: the DP state (u v x y x2 y2 s | sf | qr, H) in the wave's HBM scratch instead of LDS; GP: the direction bytes there.  Three forms: all in
+// LDS (short extensions), state in LDS + directions in HBM (written once, read by the backtrack only), all in HBM (beyond AL_T16 / AL_Q16).
+template <bool G, bool GP>
 __device__ inline void ksw_extd2_core(int32_t qlen, const uint8_t *query, bool qg, int32_t tlen, const uint8_t *target, bool tg,
                                       int8_t sc_mch, int8_t sc_mis, int8_t sc_N, int32_t q, int32_t e, int32_t q2, int32_t e2, int32_t w,
                                       int32_t zdrop, int32_t end_bonus, int32_t flag, Ez &ez, uint32_t *cigar, AlignScratch &A, AlignLds &Ls)
@@ -275,11 +277,11 @@ __device__ inline void ksw_extd2_core(int32_t qlen, const uint8_t *query, bool q
     if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
     const int32_t long_diff = long_thres * (e - e2) - (q2 - q) - e2;
     const unsigned long long p_need = (unsigned long long)(qlen + tlen - 1) * (unsigned long long)n_col;
-    constexpr bool g = G, in_lds = !G;
-    if (g && ((uint32_t)T16 > A.tcap || (uint32_t)(qlen_ * 16 + 16) > A.qcap + 32 || p_need > A.pcap || (uint32_t)(qlen + tlen) > A.qcap + A.tcap)) { ez.zdropped = 1; return; }   // outside the context's sizing (never for reads within max_read_len)
+    constexpr bool g = G, in_lds = !GP;
+    if ((g || GP) && ((uint32_t)T16 > A.tcap || (uint32_t)(qlen_ * 16 + 16) > A.qcap + 32 || p_need > A.pcap || (uint32_t)(qlen + tlen) > A.qcap + A.tcap)) { ez.zdropped = 1; return; }   // outside the context's sizing (never for reads within max_read_len)
     uint8_t *mem = G ? A.kmem : Ls.kmem;
     int32_t *H = G ? A.kH : Ls.kH;
-    uint8_t *p = G ? A.kp : Ls.kp;
+    uint8_t *p = GP ? A.kp : Ls.kp;
     int32_t *off = A.koff, *off_end = A.koff + (qlen + tlen);
     int8_t *u = (int8_t *)mem, *v = u + T16, *x = v + T16, *y = x + T16, *x2 = y + T16, *y2 = x2 + T16, *s = y2 + T16;
     uint8_t *sf = (uint8_t *)(s + T16), *qr = sf + T16;
@@ -442,9 +444,11 @@ __device__ inline void ksw_extd2_wave(int32_t qlen, const uint8_t *query, bool q
     const int32_t T16 = (tlen + 15) / 16 * 16, Q16 = (qlen + 15) / 16 * 16;
     int32_t ww = w < 0 ? (tlen > qlen ? tlen : qlen) : w, nc = qlen < tlen ? qlen : tlen;
     nc = (((nc < ww + 1 ? nc : ww + 1) + 15) / 16 + 1) * 16;
-    const bool in_lds = qlen > 0 && tlen > 0 && T16 <= AL_T16 && Q16 <= AL_Q16 && (unsigned long long)(qlen + tlen - 1) * (unsigned long long)nc <= AL_P;
-    if (in_lds) ksw_extd2_core<false>(qlen, query, qg, tlen, target, tg, sc_mch, sc_mis, sc_N, q, e, q2, e2, w, zdrop, end_bonus, flag, ez, cigar, A, Ls);
-    else ksw_extd2_core<true>(qlen, query, qg, tlen, target, tg, sc_mch, sc_mis, sc_N, q, e, q2, e2, w, zdrop, end_bonus, flag, ez, cigar, A, Ls);
+    const bool mem_lds = qlen > 0 && tlen > 0 && T16 <= AL_T16 && Q16 <= AL_Q16;
+    const bool p_lds = mem_lds && (unsigned long long)(qlen + tlen - 1) * (unsigned long long)nc <= AL_P;
+    if (p_lds) ksw_extd2_core<false, false>(qlen, query, qg, tlen, target, tg, sc_mch, sc_mis, sc_N, q, e, q2, e2, w, zdrop, end_bonus, flag, ez, cigar, A, Ls);
+    else if (mem_lds) ksw_extd2_core<false, true>(qlen, query, qg, tlen, target, tg, sc_mch, sc_mis, sc_N, q, e, q2, e2, w, zdrop, end_bonus, flag, ez, cigar, A, Ls);
+    else ksw_extd2_core<true, true>(qlen, query, qg, tlen, target, tg, sc_mch, sc_mis, sc_N, q, e, q2, e2, w, zdrop, end_bonus, flag, ez, cigar, A, Ls);
 }
 
 // ------------------------------------------------------------------------------------------------
