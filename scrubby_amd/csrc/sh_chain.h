@@ -1052,6 +1052,38 @@ __device__ inline void chain_cluster_wave(SliceStore &S, int32_t n, int32_t qlen
 {
     if (sk) {      // hand-over mode (zbuf must not alias the anchors)
         const StoreEmit<SliceStore> em{sk, &S, read, base, lane == 0, P.k, region_hash(qlen)};
+        if (P.ext_s1 && n >= 2 && n <= 64) {
+            // A cluster whose anchors all lie on ONE diagonal, d <= min(max_dist_x, max_dist_y) apart (a copy of the read up to substitutions -
+            // the true locus nearly always): the outcome of mg_lchain_dp + mg_chain_backtrack is known without running them (the argument of
+            // k_pair_pass mode 2; no skip penalty: ext_s1) - every anchor links to its predecessor (it is scanned first and no earlier one can
+            // beat f[i-1] + min(k, d)), f is the running sum, and the backtrack returns the one chain of all n anchors if it clears min_sc /
+            // min_cnt.  f and p are written as the DP would have, then the chain is handed over.
+            int32_t mdy = P.is_sr ? (qlen > P.max_gap ? qlen : P.max_gap) : P.max_gap, mdx;
+            if (P.max_gap_ref > 0) mdx = P.max_gap_ref;
+            else if (P.max_frag_len > 0) { mdx = P.max_frag_len - qlen; if (mdx < P.max_gap) mdx = P.max_gap; }
+            else mdx = P.max_gap;
+            if (mdx < P.bw) mdx = P.bw;
+            if (mdy < P.bw) mdy = P.bw;
+            const int32_t dmax = mdx < mdy ? mdx : mdy;
+            const bool in = (int32_t)lane < n;
+            const uint32_t lo = in ? S.rlo((int32_t)lane) : 0u, qv = in ? S.qp((int32_t)lane) : 0u;
+            const uint32_t dg = lo - qv, dg0 = (uint32_t)__shfl((int)dg, 0);
+            const int32_t dq = (int32_t)qv - (int32_t)(uint32_t)__shfl_up((int)qv, 1);
+            const bool good = !in || (dg == dg0 && (lane == 0 || (dq > 0 && dq <= dmax)));
+            if (__ballot(!good) == 0) {
+                int32_t v = !in ? 0 : (lane == 0 ? P.k : (dq < P.k ? dq : P.k));
+                int32_t fl = v;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int32_t t = __shfl_up(fl, o); if ((int)lane >= o) fl += t; }
+                if (in) { S.setFP((int32_t)lane, fl, (int32_t)lane - 1); S.setT((int32_t)lane, 0); }
+                wave_mem_sync();
+                const int32_t sc = __shfl(fl, n - 1);
+                n_u = 0; best = 0;
+                if (sc >= P.min_sc && n >= P.min_cnt) { n_u = 1; best = sc; em((int64_t)(n - 1), (int64_t)-1, sc, (int64_t)n, sc); }
+                wave_mem_sync();
+                return;
+            }
+        }
         chain_dp_wave(S, n, qlen, P, lane);
         if (n <= 64) backtrack_mask(S, n, P, n_u, best, false, em);
         else if (sk->best) backtrack_wave_top(S, n, P, n_u, best, em, lane);

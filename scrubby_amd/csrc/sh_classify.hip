@@ -2207,7 +2207,7 @@ __global__ __launch_bounds__(256) void k_giant_merge(K3Args a, uint32_t round)
 }
 
 // one block per giant read: clusters chained over arena slices of the buffer its sort ended in
-__global__ __launch_bounds__(512) void k_giant_chain(K3Args a, int phase)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_giant_chain(K3Args a, int phase)      // 128 VGPRs: two blocks per CU (at 133 it is one)
 {
     __shared__ int32_t s_found, s_red[2], s_bcount;
     __shared__ uint32_t s_bstart[2048], s_blen[2048], s_nxt[1024];
