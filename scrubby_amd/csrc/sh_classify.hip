@@ -536,7 +536,7 @@ __global__ __launch_bounds__(1024) void k_long_scan(LongArgs a, int mode)
 // one wave per read: mm_seed_mz_flt screen, probes, compaction of the hits, routing
 __global__ __launch_bounds__(64) void k_long_probe(LongArgs a)
 {
-    constexpr uint32_t LT_CAP = 4096;          // distinct hashes of the over-full bins of one read
+    constexpr uint32_t LT_CAP = 2048;          // distinct hashes of the over-full bins of one read (4096: 56 KB of LDS, two waves per CU)
     __shared__ uint16_t s_cnt[4096];
     __shared__ uint64_t s_tkey[LT_CAP];
     __shared__ uint32_t s_tcnt[LT_CAP], s_tover;
@@ -1542,7 +1542,7 @@ __device__ inline bool pair_decides(const uint4 rec, uint32_t my_n, uint32_t n_s
 // tile; with more seeds it is only needed when some streak could keep a seed (max_high_occ > 0), which for
 // occ_dist = 500 means reads longer than 250 bp: those go to the legacy path.
 template <bool LONG>      // LONG: per-read seed offsets and mm_seed_select across seed tiles (the long-read front end's records)
-__global__ __launch_bounds__(64) void k_expand(K3Args a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_expand(K3Args a)
 {
     const uint32_t lane = threadIdx.x;
     const uint32_t n_items = *a.list_count;
