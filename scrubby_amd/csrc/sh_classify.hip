@@ -2860,7 +2860,7 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     hipLaunchKernelGGL(k_giant_chunksort, dim3(256 * 3), dim3(256), 0, g, k);
     for (uint32_t round = 0; round < 8; ++round) {      // run widths GT << round: up to 2^19 anchors per read
         hipLaunchKernelGGL(k_giant_partition, dim3(256), dim3(256), 0, g, k, round);
-        hipLaunchKernelGGL(k_giant_merge, dim3(256 * 3), dim3(256), 0, g, k, round);
+        hipLaunchKernelGGL(k_giant_merge, dim3(256 * 6), dim3(256), 0, g, k, round);      // 24 KB of LDS per block: six per CU
     }
     // flag-only hand-over (t_mode): the big clusters first (k_cluster_dp), then the small ones against the best score those gave
     const bool two_phase = k.t_mode && k.sink.best != nullptr;
@@ -2955,7 +2955,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         kb.work = c->d_work_small; kb.work_count = &c->d_ctr->n_small; kb.work_begin = 0;
         if (pair_pass) {      // flag-only: pair pass over all reads of the path, then the undecided ones, dense
             kb.leftover = c->d_work_small2; kb.leftover_count = &c->d_ctr->n_small2;
-            hipLaunchKernelGGL(k_pair_pass, dim3(grid), dim3(64), 0, sk, kb, pair_mode_small);
+            hipLaunchKernelGGL(k_pair_pass, dim3(grid * 2), dim3(64), 0, sk, kb, pair_mode_small);
             kb.work = c->d_work_small2; kb.work_count = &c->d_ctr->n_small2;
         }
         hipLaunchKernelGGL(k_chain_small<K2_CAP>, dim3(grid), dim3(64), 0, sk, kb);
@@ -2982,7 +2982,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         K2Args pb = b;
         pb.work = c->d_big[0][0]; pb.work_count = &c->d_ctr->n_big[0];
         pb.leftover = c->d_big[0][1]; pb.leftover_count = &c->d_ctr->n_big_defer[0];
-        hipLaunchKernelGGL(k_pair_pass, dim3(grid), dim3(64), 0, s, pb, pair_mode_big);
+        hipLaunchKernelGGL(k_pair_pass, dim3(grid * 2), dim3(64), 0, s, pb, pair_mode_big);
         hipLaunchKernelGGL(k_pair_swap, dim3(1), dim3(1), 0, s, c->d_ctr);
         cur0 = 1;
     }
@@ -3071,7 +3071,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
             hipLaunchKernelGGL(k_regs_align, dim3(c->ext_waves), dim3(64), 0, s, x);
         } else {
             // flag-only: the lists hold each read's candidates for regs[0]; the top chain settles nearly every read (one lane each)
-            hipLaunchKernelGGL(k_ext_top, dim3(grid), dim3(64), 0, s, x);
+            hipLaunchKernelGGL(k_ext_top, dim3(grid * 4), dim3(64), 0, s, x);
         }
         SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
         SH_HIP(hipStreamSynchronize(s));
