@@ -11,13 +11,19 @@
  *     mm_filter_regs: cnt < min_cnt | mlen < min_chain_score | dp_max < min_dp_max | both clips too long
  * ksw_extd2_sse is restated as a literal scalar emulation of its 16-lane int8 difference recurrence, buffer layout
  * included, because its band edges read cells that the rounded vector ranges computed outside the band.
- * Long-read presets (no MM_F_SR) additionally need mm_est_err, the RMQ re-chain of map.c and the gap-filling branch of
- * mm_align1; they are not restated here: mma_align_read refuses them (the caller keeps the chain-level decision).
+ * Long-read presets (no MM_F_SR: map-ont, lr:hq, map-hifi; cleaner.rs:457-458,465) take the other branch of mm_align1 -
+ * mm_fix_bad_ends, mm_filter_bad_seeds(_alt), left extension, ksw_extd2 between anchor mid-points every >= min_ksw_len
+ * bases (first pass with the approximate maximum, second pass when mm_test_zdrop objects, inversion test through a
+ * local alignment = ksw_ll_i16), right extension, mm_update_extra with the logarithmic gap cost - preceded by mm_est_err /
+ * mm_filter_strand_retained and followed by mm_align1_inv.  The RMQ re-chain that map.c runs before all this is in
+ * mm_rmq.c.  mm_update_dp_max and mm_set_mapq run AFTER mm_filter_regs and cannot change the number of mappings; they
+ * are not restated.
  */
 #include "mm_align.h"
 #include <stdlib.h>
 #include <string.h>
 #include <limits.h>
+#include <math.h>
 
 #define KSW_NEG_INF (-0x40000000)
 #define CIG_MATCH 0
@@ -292,9 +298,14 @@ typedef struct {
 typedef struct {
     int32_t id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, mlen, blen, n_sub;
     uint32_t hash;
-    int rev, inv, split_inv, seg_split, strand_retained;
+    int rev, inv, split_inv, seg_split, strand_retained, split;
+    float div;
     extra_t *p;
 } reg_t;
+
+#define SEED_LONG_JOIN (1ULL << 40)
+#define SEED_IGNORE    (1ULL << 41)
+#define SEED_TANDEM    (1ULL << 42)
 
 #define PARENT_UNSET (-1)
 #define PARENT_TMP_PRI (-2)
@@ -336,6 +347,18 @@ static void reg_set_coor(reg_t *r, int32_t qlen, const mma_anchor *a)
         r->qs = qlen - ((int32_t)a[k + r->cnt - 1].y + 1);
         r->qe = qlen - ((int32_t)a[k].y + 1 - q_span);
     }
+    {   /* mm_cal_fuzzy_len: what mlen / blen hold until mm_update_extra replaces them (mm_fix_bad_ends reads mlen) */
+        int32_t i;
+        r->mlen = r->blen = 0;
+        if (r->cnt <= 0) return;
+        r->mlen = r->blen = (int32_t)(a[r->as].y >> 32 & 0xff);
+        for (i = r->as + 1; i < r->as + r->cnt; ++i) {
+            const int32_t span = (int32_t)(a[i].y >> 32 & 0xff);
+            const int32_t tl = (int32_t)a[i].x - (int32_t)a[i - 1].x, ql = (int32_t)a[i].y - (int32_t)a[i - 1].y;
+            r->blen += tl > ql ? tl : ql;
+            r->mlen += tl > span && ql > span ? span : tl < ql ? tl : ql;
+        }
+    }
 }
 
 typedef struct { uint64_t x, y; } u128;
@@ -373,6 +396,7 @@ static reg_t *gen_regs(uint32_t hash, int qlen, int n_u, const uint64_t *u, cons
         ri->hash = (uint32_t)z[i].x;
         ri->cnt = (int32_t)z[i].y;
         ri->as = (int32_t)(z[i].y >> 32);
+        ri->div = -1.0f;
         reg_set_coor(ri, qlen, a);
     }
     free(z);
@@ -435,6 +459,25 @@ static void set_parent(float mask_level, int mask_len, int n, reg_t *r)
     free(cov); free(w);
 }
 
+static void sync_regs(int n_regs, reg_t *regs)
+{   /* mm_sync_regs: id = position; parent follows (a dropped parent leaves PARENT_UNSET) */
+    int *tmp, i, max_id = -1, n_tmp;
+    if (n_regs <= 0) return;
+    for (i = 0; i < n_regs; ++i) max_id = max_id > regs[i].id ? max_id : regs[i].id;
+    n_tmp = max_id + 1;
+    tmp = (int *)malloc((size_t)(n_tmp + 1) * sizeof(int));
+    for (i = 0; i < n_tmp; ++i) tmp[i] = -1;
+    for (i = 0; i < n_regs; ++i) if (regs[i].id >= 0) tmp[regs[i].id] = i;
+    for (i = 0; i < n_regs; ++i) {
+        reg_t *r = &regs[i];
+        r->id = i;
+        if (r->parent == PARENT_TMP_PRI) r->parent = i;
+        else if (r->parent >= 0 && tmp[r->parent] >= 0) r->parent = tmp[r->parent];
+        else r->parent = PARENT_UNSET;
+    }
+    free(tmp);
+}
+
 static void select_sub(float pri_ratio, int min_diff, int best_n, int check_strand, int min_strand_sc, int *n_, reg_t *r)
 {
     if (pri_ratio > 0.0f && *n_ > 0) {
@@ -449,7 +492,7 @@ static void select_sub(float pri_ratio, int min_diff, int best_n, int check_stra
                 r[k++] = r[i]; ++n_2nd;
             }
         }
-        /* mm_sync_regs only renumbers id / parent; nothing after this point reads them before mm_filter_regs */
+        if (k != n) sync_regs(k, r);
         *n_ = k;
     }
 }
@@ -464,7 +507,7 @@ static void select_sub(float pri_ratio, int min_diff, int best_n, int check_stra
 typedef struct {
     const mmo_opts *o; const uint8_t *ref; const uint64_t *cstart; uint32_t n_contigs;
     int32_t qlen; uint8_t *qseq0[2];
-    mma_anchor *a;
+    mma_anchor *a; int32_t n_a;      /* n_a: anchors left by mm_squeeze_a (the long-read branch looks at its neighbours') */
 } actx_t;
 
 static int32_t contig_len(const actx_t *c, int32_t rid) { return (int32_t)(c->cstart[rid + 1] - c->cstart[rid]); }
@@ -577,6 +620,7 @@ static void split_reg(reg_t *r, reg_t *r2, int n, int qlen, const mma_anchor *a)
     r->cnt -= r2->cnt;
     r->score -= r2->score;
     reg_set_coor(r, qlen, a);
+    r->split |= 1; r2->split |= 2;
 }
 
 static void fix_cigar(reg_t *r, const uint8_t *qseq, const uint8_t *tseq, int *qshift, int *tshift)
@@ -640,8 +684,8 @@ static void fix_cigar(reg_t *r, const uint8_t *qseq, const uint8_t *tseq, int *q
     }
 }
 
-static void update_extra(reg_t *r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e)
-{   /* mm_update_extra with log_gap = 0 (MM_F_SR) */
+static void update_extra(reg_t *r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e, int log_gap)
+{   /* mm_update_extra; log_gap = !MM_F_SR: a gap of len costs q + e * log2(1 + len) in the running score behind dp_max */
     int k;
     uint32_t l;
     int32_t qshift, tshift, toff = 0, qoff = 0;
@@ -669,14 +713,16 @@ static void update_extra(reg_t *r, const uint8_t *qseq, const uint8_t *tseq, con
             int n_ambi = 0;
             for (l = 0; l < len; ++l) if (qseq[qoff + (int32_t)l] > 3) ++n_ambi;
             r->blen += (int32_t)len - n_ambi; p->n_ambi += n_ambi;
-            s -= q + e * (int32_t)len;
+            if (log_gap) s -= q + (double)e * mmo_log2((float)(1.0 + len));
+            else s -= q + e * (int32_t)len;
             if (s < 0) s = 0;
             qoff += (int32_t)len;
         } else if (op == CIG_DEL) {
             int n_ambi = 0;
             for (l = 0; l < len; ++l) if (tseq[toff + (int32_t)l] > 3) ++n_ambi;
             r->blen += (int32_t)len - n_ambi; p->n_ambi += n_ambi;
-            s -= q + e * (int32_t)len;
+            if (log_gap) s -= q + (double)e * mmo_log2((float)(1.0 + len));
+            else s -= q + e * (int32_t)len;
             if (s < 0) s = 0;
             toff += (int32_t)len;
         }
@@ -777,9 +823,524 @@ static void align1_sr(actx_t *c, reg_t *r, reg_t *r2, mma_ez *ez)
         free(tseq);
         tseq = (uint8_t *)malloc((size_t)(re1 - rs1) + 16);
         getseq(c, rid, rs1, re1, tseq);
-        update_extra(r, &c->qseq0[r->rev][qs1], tseq, mat, (int8_t)o->q, (int8_t)o->e);
+        update_extra(r, &c->qseq0[r->rev][qs1], tseq, mat, (int8_t)o->q, (int8_t)o->e, 0);
     }
     free(tseq);
+}
+
+
+/* ------------------------------------------------------------------------------------------------
+ * long-read presets: what runs between chain_post and mm_align_skeleton (map.c), then mm_align1 without MM_F_SR
+ * ---------------------------------------------------------------------------------------------- */
+static inline int32_t get_for_qpos(int32_t qlen, const mma_anchor *a)
+{   /* the position on the forward strand of the query */
+    int32_t x = (int32_t)a->y;
+    const int32_t q_span = (int32_t)(a->y >> 32 & 0xff);
+    if (a->x >> 63) x = qlen - 1 - (x + 1 - q_span);
+    return x;
+}
+
+static int get_mini_idx(int qlen, const mma_anchor *a, int32_t n, const uint64_t *mini_pos)
+{
+    int32_t x, L = 0, R = n - 1;
+    x = get_for_qpos(qlen, a);
+    while (L <= R) {
+        const int32_t m = (int32_t)(((uint64_t)L + (uint64_t)R) >> 1);
+        const int32_t y = (int32_t)mini_pos[m];
+        if (y < x) L = m + 1;
+        else if (y > x) R = m - 1;
+        else return m;
+    }
+    return -1;
+}
+
+/* mm_est_err: per-region divergence from the fraction of the read's (unfiltered) minimizers that are anchors of the chain */
+static void est_err(const actx_t *c, int n_regs, reg_t *regs, int32_t n, const uint64_t *mini_pos)
+{
+    const mma_anchor *a = c->a;
+    const int32_t qlen = c->qlen;
+    int i;
+    uint64_t sum_k = 0;
+    float avg_k;
+    if (n == 0) return;
+    for (i = 0; i < n; ++i) sum_k += mini_pos[i] >> 32 & 0xff;
+    avg_k = (float)sum_k / n;
+    for (i = 0; i < n_regs; ++i) {
+        reg_t *r = &regs[i];
+        int32_t st, en, j, k, n_match, n_tot, l_ref;
+        r->div = -1.0f;
+        if (r->cnt == 0) continue;
+        st = en = get_mini_idx(qlen, r->rev ? &a[r->as + r->cnt - 1] : &a[r->as], n, mini_pos);
+        if (st < 0) continue;
+        l_ref = contig_len(c, r->rid);
+        for (k = 1, j = st + 1, n_match = 1; j < n && k < r->cnt; ++j) {
+            const int32_t q = get_for_qpos(qlen, r->rev ? &a[r->as + r->cnt - 1 - k] : &a[r->as + k]);
+            if (q == (int32_t)mini_pos[j]) { ++k; en = j; ++n_match; }
+        }
+        n_tot = en - st + 1;
+        if (r->qs > avg_k && r->rs > avg_k) ++n_tot;
+        if (qlen - r->qe > avg_k && l_ref - r->re > avg_k) ++n_tot;
+        r->div = n_match >= n_tot ? 0.0f : (float)(1.0 - pow((double)n_match / n_tot, 1.0 / avg_k));
+    }
+}
+
+static int filter_strand_retained(int n_regs, reg_t *r)
+{   /* in place like upstream: r[p] is read after earlier regions moved up */
+    int i, k;
+    for (i = k = 0; i < n_regs; ++i) {
+        const int p = r[i].parent;
+        if (!r[i].strand_retained || r[i].div < r[p].div * 5.0f || r[i].div < 0.01f) {
+            if (k < i) r[k++] = r[i];
+            else ++k;
+        }
+    }
+    return k;
+}
+
+static int cmp_u64v(const void *a, const void *b)
+{
+    const uint64_t p = *(const uint64_t *)a, q = *(const uint64_t *)b;
+    return p < q ? -1 : p > q;
+}
+
+static int squeeze_a(int n_regs, reg_t *regs, mma_anchor *a)
+{   /* mm_squeeze_a: keep only the anchors some region refers to, in the order of as */
+    int i, as = 0;
+    uint64_t *aux = (uint64_t *)malloc(((size_t)n_regs + 1) * 8);
+    for (i = 0; i < n_regs; ++i) aux[i] = (uint64_t)(uint32_t)regs[i].as << 32 | (uint32_t)i;
+    qsort(aux, (size_t)n_regs, 8, cmp_u64v);
+    for (i = 0; i < n_regs; ++i) {
+        reg_t *r = &regs[(int32_t)aux[i]];
+        if (r->as != as) {
+            memmove(&a[as], &a[r->as], (size_t)r->cnt * 16);
+            r->as = as;
+        }
+        as += r->cnt;
+    }
+    free(aux);
+    return as;
+}
+
+static void fix_bad_ends(const reg_t *r, const mma_anchor *a, int bw, int min_match, int32_t *as, int32_t *cnt)
+{
+    int32_t i, l, m;
+    *as = r->as; *cnt = r->cnt;
+    if (r->cnt < 3) return;
+    m = l = (int32_t)(a[r->as].y >> 32 & 0xff);
+    for (i = r->as + 1; i < r->as + r->cnt - 1; ++i) {
+        int32_t lq, lr, min, max;
+        const int32_t q_span = (int32_t)(a[i].y >> 32 & 0xff);
+        if (a[i].y & SEED_LONG_JOIN) break;
+        lr = (int32_t)a[i].x - (int32_t)a[i - 1].x;
+        lq = (int32_t)a[i].y - (int32_t)a[i - 1].y;
+        min = lr < lq ? lr : lq;
+        max = lr > lq ? lr : lq;
+        if (max - min > l >> 1) *as = i;
+        l += min;
+        m += min < q_span ? min : q_span;
+        if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r->mlen >> 1) break;
+    }
+    *cnt = r->as + r->cnt - *as;
+    m = l = (int32_t)(a[r->as + r->cnt - 1].y >> 32 & 0xff);
+    for (i = r->as + r->cnt - 2; i > *as; --i) {
+        int32_t lq, lr, min, max;
+        const int32_t q_span = (int32_t)(a[i + 1].y >> 32 & 0xff);
+        if (a[i + 1].y & SEED_LONG_JOIN) break;
+        lr = (int32_t)a[i + 1].x - (int32_t)a[i].x;
+        lq = (int32_t)a[i + 1].y - (int32_t)a[i].y;
+        min = lr < lq ? lr : lq;
+        max = lr > lq ? lr : lq;
+        if (max - min > l >> 1) *cnt = i + 1 - *as;
+        l += min;
+        m += min < q_span ? min : q_span;
+        if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r->mlen >> 1) break;
+    }
+}
+
+/* the difference in gap length between anchor i and its predecessor (low 32 bits, as upstream's mixed-width arithmetic leaves it) */
+static inline int32_t gap_at(const mma_anchor *a, int32_t i)
+{
+    return (int32_t)((uint32_t)a[i].y - (uint32_t)a[i - 1].y - ((uint32_t)a[i].x - (uint32_t)a[i - 1].x));
+}
+
+static int *collect_long_gaps(int as1, int cnt1, const mma_anchor *a, int min_gap, int *n_)
+{
+    int i, n, *K;
+    *n_ = 0;
+    for (i = 1, n = 0; i < cnt1; ++i) {
+        const int gap = gap_at(a, as1 + i);
+        if (gap < -min_gap || gap > min_gap) ++n;
+    }
+    if (n <= 1) return 0;
+    K = (int *)malloc((size_t)n * sizeof(int));
+    for (i = 1, n = 0; i < cnt1; ++i) {
+        const int gap = gap_at(a, as1 + i);
+        if (gap < -min_gap || gap > min_gap) K[n++] = i;
+    }
+    *n_ = n;
+    return K;
+}
+
+static void filter_bad_seeds(int as1, int cnt1, mma_anchor *a, int min_gap, int diff_thres, int max_ext_len, int max_ext_cnt)
+{
+    int max_st, max_en, n, i, k, max, *K;
+    K = collect_long_gaps(as1, cnt1, a, min_gap, &n);
+    if (K == 0) return;
+    max = 0; max_st = max_en = -1;
+    for (k = 0;; ++k) {
+        int gap, l, n_ins = 0, n_del = 0, qs, rs, max_diff = 0, max_diff_l = -1;
+        if (k == n || k >= max_en) {
+            if (max_en > 0)
+                for (i = K[max_st]; i < K[max_en]; ++i) a[as1 + i].y |= SEED_IGNORE;
+            max = 0; max_st = max_en = -1;
+            if (k == n) break;
+        }
+        i = K[k];
+        gap = gap_at(a, as1 + i);
+        if (gap > 0) n_ins += gap;
+        else n_del += -gap;
+        qs = (int32_t)a[as1 + i - 1].y;
+        rs = (int32_t)a[as1 + i - 1].x;
+        for (l = k + 1; l < n && l <= k + max_ext_cnt; ++l) {
+            const int j = K[l];
+            int diff;
+            if ((int32_t)a[as1 + j].y - qs > max_ext_len || (int32_t)a[as1 + j].x - rs > max_ext_len) break;
+            gap = gap_at(a, as1 + j);
+            if (gap > 0) n_ins += gap;
+            else n_del += -gap;
+            diff = n_ins + n_del - abs(n_ins - n_del);
+            if (max_diff < diff) { max_diff = diff; max_diff_l = l; }
+        }
+        if (max_diff > diff_thres && max_diff > max) { max = max_diff; max_st = k; max_en = max_diff_l; }
+    }
+    free(K);
+}
+
+static void filter_bad_seeds_alt(int as1, int cnt1, mma_anchor *a, int min_gap, int max_ext)
+{
+    int n, k, *K;
+    K = collect_long_gaps(as1, cnt1, a, min_gap, &n);
+    if (K == 0) return;
+    for (k = 0; k < n;) {
+        const int i = K[k];
+        int l;
+        int gap1 = gap_at(a, as1 + i);
+        int re1 = (int32_t)a[as1 + i].x;
+        int qe1 = (int32_t)a[as1 + i].y;
+        gap1 = gap1 > 0 ? gap1 : -gap1;
+        for (l = k + 1; l < n; ++l) {
+            const int j = K[l];
+            int gap2, q_span_pre, rs2, qs2, m;
+            if ((int32_t)a[as1 + j].y - qe1 > max_ext || (int32_t)a[as1 + j].x - re1 > max_ext) break;
+            gap2 = gap_at(a, as1 + j);
+            q_span_pre = (int)(a[as1 + j - 1].y >> 32 & 0xff);
+            rs2 = (int32_t)a[as1 + j - 1].x + q_span_pre;
+            qs2 = (int32_t)a[as1 + j - 1].y + q_span_pre;
+            m = rs2 - re1 < qs2 - qe1 ? rs2 - re1 : qs2 - qe1;
+            gap2 = gap2 > 0 ? gap2 : -gap2;
+            if (m > gap1 + gap2) break;
+            re1 = (int32_t)a[as1 + j].x;
+            qe1 = (int32_t)a[as1 + j].y;
+            gap1 = gap2;
+        }
+        if (l > k + 1) {
+            int j;
+            const int end = K[l - 1];
+            for (j = K[k]; j < end; ++j) a[as1 + j].y |= SEED_IGNORE;
+            a[as1 + end].y |= SEED_LONG_JOIN;
+        }
+        k = l;
+    }
+    free(K);
+}
+
+/* ksw_ll_i16 (ksw.c; SSE2 striped Smith-Waterman on 16-bit lanes) as the plain recurrence it evaluates: local alignment,
+ * gap of length l costs gapo + l * gape, H >= 0.  The query is padded to a multiple of 8 with columns that score 0 against
+ * everything, as the striped profile pads it; *te = the LAST target row whose maximum equals the global one, *qe = the LAST
+ * column in striped memory order (position = i / 8 + i % 8 * slen for memory index i) holding it in that row. */
+int mma_ksw_ll(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int gapo, int gape, int *qe, int *te)
+{
+    const int slen = (qlen + 7) / 8, qp = slen * 8, gapoe = gapo + gape;
+    int32_t *H0, *H1, *E, *Hmax, gmax = 0;
+    int i, j;
+    *qe = *te = -1;
+    if (qlen <= 0) return 0;
+    H0 = (int32_t *)calloc((size_t)qp * 4, 4);
+    H1 = H0 + qp; E = H1 + qp; Hmax = E + qp;
+    for (i = 0; i < tlen; ++i) {
+        int32_t f = 0, imax = 0, hd = 0;      /* hd = H(i-1, j-1) */
+        const int8_t *row = mat + target[i] * 5;
+        for (j = 0; j < qp; ++j) {
+            int32_t h = hd + (j < qlen ? row[query[j]] : 0), e = E[j], t;
+            h = h > e ? h : e;
+            h = h > f ? h : f;
+            imax = imax > h ? imax : h;
+            H1[j] = h;
+            t = h - gapoe; if (t < 0) t = 0;
+            e -= gape; if (e < 0) e = 0;
+            E[j] = e > t ? e : t;
+            f -= gape; if (f < 0) f = 0;
+            f = f > t ? f : t;
+            hd = H0[j];
+        }
+        if (imax >= gmax) { gmax = imax; *te = i; memcpy(Hmax, H1, (size_t)qp * 4); }
+        { int32_t *S = H1; H1 = H0; H0 = S; }
+    }
+    {   /* the last hit in memory order: memory index m <-> position m / 8 + m % 8 * slen */
+        int m;
+        for (m = 0; m < qp; ++m) { const int pos = m / 8 + m % 8 * slen; if (Hmax[pos] == gmax) *qe = pos; }
+    }
+    free(H0 < H1 ? H0 : H1);
+    return gmax;
+}
+
+static void update_max_zdrop2(int32_t score, int i, int j, int32_t *max, int *max_i, int *max_j, int e, int *max_zdrop, int pos[2][2])
+{
+    if (score < *max) {
+        const int li = i - *max_i, lj = j - *max_j;
+        const int diff = li > lj ? li - lj : lj - li;
+        const int z = *max - score - diff * e;
+        if (z > *max_zdrop) {
+            *max_zdrop = z;
+            pos[0][0] = *max_i; pos[0][1] = *max_j;
+            pos[1][0] = i; pos[1][1] = j;
+        }
+    } else { *max = score; *max_i = i; *max_j = j; }
+}
+
+static int test_zdrop_lr(const mmo_opts *o, const uint8_t *qseq, const uint8_t *tseq, int n_cigar, const uint32_t *cigar, const int8_t *mat)
+{   /* mm_test_zdrop, long-read form: 2 = the most dropped stretch aligns to its own reverse complement (a potential inversion) */
+    int k;
+    int32_t score = 0, max = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
+    int pos[2][2] = {{-1, -1}, {-1, -1}}, q_len, t_len;
+    for (k = 0; k < n_cigar; ++k) {
+        const uint32_t op = cigar[k] & 0xf, len = cigar[k] >> 4;
+        uint32_t l;
+        if (op == CIG_MATCH) {
+            for (l = 0; l < len; ++l) {
+                score += mat[tseq[i + l] * 5 + qseq[j + l]];
+                update_max_zdrop2(score, i + (int)l, j + (int)l, &max, &max_i, &max_j, o->e, &max_zdrop, pos);
+            }
+            i += (int)len; j += (int)len;
+        } else if (op == CIG_INS || op == CIG_DEL) {
+            score -= o->q + o->e * (int32_t)len;
+            if (op == CIG_INS) j += (int)len; else i += (int)len;
+            update_max_zdrop2(score, i, j, &max, &max_i, &max_j, o->e, &max_zdrop, pos);
+        }
+    }
+    q_len = pos[1][1] - pos[0][1]; t_len = pos[1][0] - pos[0][0];
+    if (max_zdrop > o->zdrop_inv && q_len < o->max_gap && t_len < o->max_gap) {
+        uint8_t *qseq2 = (uint8_t *)malloc((size_t)(q_len > 0 ? q_len : 1));
+        int q_off, t_off;
+        for (i = 0; i < q_len; ++i) { const int c = qseq[pos[1][1] - i - 1]; qseq2[i] = c >= 4 ? 4 : 3 - c; }
+        score = mma_ksw_ll(q_len, qseq2, t_len, tseq + pos[0][0], mat, o->q, o->e, &q_off, &t_off);
+        free(qseq2);
+        if (score >= o->min_chain_score * o->a && score >= o->min_dp_max) return 2;
+    }
+    return max_zdrop > o->zdrop ? 1 : 0;
+}
+
+static void align1_lr(actx_t *c, reg_t *r, reg_t *r2, mma_ez *ez)
+{
+    const mmo_opts *o = c->o;
+    mma_anchor *a = c->a;
+    const int32_t qlen = c->qlen, n_a = c->n_a, hk = o->k >> 1;
+    const int32_t rid = (int32_t)(a[r->as].x << 1 >> 33), rev = (int32_t)(a[r->as].x >> 63);
+    const int32_t clen = contig_len(c, rid);
+    uint8_t *tseq, *qseq;
+    int32_t i, l, bw, bw_long, dropped = 0, rs0, re0, qs0, qe0, as1, cnt1;
+    int32_t rs, re, qs, qe, rs1, qs1, re1, qe1;
+    int8_t mat[25];
+
+    r2->cnt = 0;
+    if (r->cnt == 0) return;
+    mma_gen_simple_mat(5, mat, (int8_t)o->a, (int8_t)o->b, (int8_t)o->sc_ambi);
+    bw = (int)(o->bw * 1.5 + 1.);
+    bw_long = (int)(o->bw_long * 1.5 + 1.);
+    if (bw_long < bw) bw_long = bw;
+
+    fix_bad_ends(r, a, o->bw, o->min_chain_score * 2, &as1, &cnt1);
+    filter_bad_seeds(as1, cnt1, a, 10, 40, o->max_gap >> 1, 10);
+    filter_bad_seeds_alt(as1, cnt1, a, 30, o->max_gap >> 1);
+    rs = (int32_t)a[as1].x - hk; qs = (int32_t)a[as1].y - hk;                              /* mm_adjust_minier, no HPC */
+    re = (int32_t)a[as1 + cnt1 - 1].x - hk; qe = (int32_t)a[as1 + cnt1 - 1].y - hk;
+
+    /* the window the end extensions may use: bounded by neighbouring chains' anchors on the same strand / contig */
+    rs0 = (int32_t)a[r->as].x + 1 - (int32_t)(a[r->as].y >> 32 & 0xff);
+    qs0 = (int32_t)a[r->as].y + 1 - (int32_t)(a[r->as].y >> 32 & 0xff);
+    if (rs0 < 0) rs0 = 0;
+    rs1 = qs1 = 0;
+    for (i = r->as - 1, l = 0; i >= 0 && a[i].x >> 32 == a[r->as].x >> 32; --i) {
+        const int32_t x = (int32_t)a[i].x + 1 - (int32_t)(a[i].y >> 32 & 0xff);
+        const int32_t y = (int32_t)a[i].y + 1 - (int32_t)(a[i].y >> 32 & 0xff);
+        if (x < rs0 && y < qs0) {
+            if (++l > o->min_cnt) {
+                l = rs0 - x > qs0 - y ? rs0 - x : qs0 - y;
+                rs1 = rs0 - l; qs1 = qs0 - l;
+                if (rs1 < 0) rs1 = 0;
+                break;
+            }
+        }
+    }
+    if (qs > 0 && rs > 0) {
+        l = qs < o->max_gap ? qs : o->max_gap;
+        qs1 = qs1 > qs - l ? qs1 : qs - l;
+        qs0 = qs0 < qs1 ? qs0 : qs1;
+        l += l * o->a > o->q ? (l * o->a - o->q) / o->e : 0;
+        l = l < o->max_gap ? l : o->max_gap;
+        l = l < rs ? l : rs;
+        rs1 = rs1 > rs - l ? rs1 : rs - l;
+        rs0 = rs0 < rs1 ? rs0 : rs1;
+        rs0 = rs0 < rs ? rs0 : rs;
+    } else { rs0 = rs; qs0 = qs; }
+    re0 = (int32_t)a[r->as + r->cnt - 1].x + 1;
+    qe0 = (int32_t)a[r->as + r->cnt - 1].y + 1;
+    re1 = clen; qe1 = qlen;
+    for (i = r->as + r->cnt, l = 0; i < n_a && a[i].x >> 32 == a[r->as].x >> 32; ++i) {
+        const int32_t x = (int32_t)a[i].x + 1;
+        const int32_t y = (int32_t)a[i].y + 1;
+        if (x > re0 && y > qe0) {
+            if (++l > o->min_cnt) {
+                l = x - re0 > y - qe0 ? x - re0 : y - qe0;
+                re1 = re0 + l; qe1 = qe0 + l;
+                break;
+            }
+        }
+    }
+    if (qe < qlen && re < clen) {
+        l = qlen - qe < o->max_gap ? qlen - qe : o->max_gap;
+        qe1 = qe1 < qe + l ? qe1 : qe + l;
+        qe0 = qe0 > qe1 ? qe0 : qe1;
+        l += l * o->a > o->q ? (l * o->a - o->q) / o->e : 0;
+        l = l < o->max_gap ? l : o->max_gap;
+        l = l < clen - re ? l : clen - re;
+        re1 = re1 < re + l ? re1 : re + l;
+        re0 = re0 > re1 ? re0 : re1;
+    } else { re0 = re; qe0 = qe; }
+
+    tseq = (uint8_t *)malloc((size_t)(re0 - rs0 > 0 ? re0 - rs0 : 0) + 16);
+
+    if (qs > 0 && rs > 0) {       /* left extension */
+        qseq = &c->qseq0[rev][qs0];
+        getseq(c, rid, rs0, rs, tseq);
+        seq_rev(qs - qs0, qseq);
+        seq_rev(rs - rs0, tseq);
+        align_pair(o, qs - qs0, qseq, rs - rs0, tseq, mat, bw, o->end_bonus, r->split_inv ? o->zdrop_inv : o->zdrop,
+                   MMA_EZ_EXTZ_ONLY | MMA_EZ_RIGHT | MMA_EZ_REV_CIGAR, ez);
+        if (ez->n_cigar > 0) { append_cigar(r, ez->n_cigar, ez->cigar); r->p->dp_score += (int32_t)ez->max; }
+        rs1 = rs - (ez->reach_end ? ez->mqe_t + 1 : ez->max_t + 1);
+        qs1 = qs - (ez->reach_end ? qs - qs0 : ez->max_q + 1);
+        seq_rev(qs - qs0, qseq);
+    } else { rs1 = rs; qs1 = qs; }
+    re1 = rs; qe1 = qs;
+
+    for (i = 1; i < cnt1; ++i) {       /* gap filling */
+        if ((a[as1 + i].y & (SEED_IGNORE | SEED_TANDEM)) && i != cnt1 - 1) continue;
+        re = (int32_t)a[as1 + i].x - hk; qe = (int32_t)a[as1 + i].y - hk;
+        re1 = re; qe1 = qe;
+        if (i == cnt1 - 1 || (a[as1 + i].y & SEED_LONG_JOIN) || (qe - qs >= o->min_ksw_len && re - rs >= o->min_ksw_len)) {
+            int j, bw1 = bw_long, zdrop_code;
+            if (a[as1 + i].y & SEED_LONG_JOIN) bw1 = qe - qs > re - rs ? qe - qs : re - rs;
+            qseq = &c->qseq0[rev][qs];
+            getseq(c, rid, rs, re, tseq);
+            align_pair(o, qe - qs, qseq, re - rs, tseq, mat, bw1, -1, o->zdrop, MMA_EZ_APPROX_MAX, ez);      /* first pass: approximate maximum */
+            if ((zdrop_code = test_zdrop_lr(o, qseq, tseq, ez->n_cigar, ez->cigar, mat)) != 0)
+                align_pair(o, qe - qs, qseq, re - rs, tseq, mat, bw1, -1, zdrop_code == 2 ? o->zdrop_inv : o->zdrop, 0, ez);
+            if (ez->n_cigar > 0) append_cigar(r, ez->n_cigar, ez->cigar);
+            if (ez->zdropped) {
+                if (!r->p) r->p = (extra_t *)calloc(1, sizeof(extra_t));
+                for (j = i - 1; j >= 0; --j) if ((int32_t)a[as1 + j].x <= rs + ez->max_t) break;
+                dropped = 1;
+                if (j < 0) j = 0;
+                r->p->dp_score += (int32_t)ez->max;
+                re1 = rs + (ez->max_t + 1);
+                qe1 = qs + (ez->max_q + 1);
+                if (cnt1 - (j + 1) >= o->min_cnt) {
+                    split_reg(r, r2, as1 + j + 1 - r->as, qlen, a);
+                    if (zdrop_code == 2) r2->split_inv = 1;
+                }
+                break;
+            } else r->p->dp_score += ez->score;
+            rs = re; qs = qe;
+        }
+    }
+
+    if (!dropped && qe < qe0 && re < re0) {   /* right extension */
+        qseq = &c->qseq0[rev][qe];
+        getseq(c, rid, re, re0, tseq);
+        align_pair(o, qe0 - qe, qseq, re0 - re, tseq, mat, bw, o->end_bonus, o->zdrop, MMA_EZ_EXTZ_ONLY, ez);
+        if (ez->n_cigar > 0) { append_cigar(r, ez->n_cigar, ez->cigar); r->p->dp_score += (int32_t)ez->max; }
+        re1 = re + (ez->reach_end ? ez->mqe_t + 1 : ez->max_t + 1);
+        qe1 = qe + (ez->reach_end ? qe0 - qe : ez->max_q + 1);
+    }
+
+    r->rs = rs1; r->re = re1;
+    if (rev) { r->qs = qlen - qe1; r->qe = qlen - qs1; }
+    else { r->qs = qs1; r->qe = qe1; }
+    if (r->p) {
+        free(tseq);
+        tseq = (uint8_t *)malloc((size_t)(re1 - rs1 > 0 ? re1 - rs1 : 0) + 16);
+        getseq(c, rid, rs1, re1, tseq);
+        update_extra(r, &c->qseq0[r->rev][qs1], tseq, mat, (int8_t)o->q, (int8_t)o->e, 1);
+    }
+    free(tseq);
+}
+
+/* mm_align1_inv: between the two halves of a region split by the inversion z-drop, align the reverse complement */
+static int align1_inv(actx_t *c, const reg_t *r1, const reg_t *r2, reg_t *r_inv, mma_ez *ez)
+{
+    const mmo_opts *o = c->o;
+    const int32_t qlen = c->qlen;
+    int tl, ql, score, ret = 0, q_off, t_off;
+    uint8_t *tseq, *qseq;
+    int8_t mat[25];
+
+    memset(r_inv, 0, sizeof(*r_inv));
+    if (!(r1->split & 1) || !(r2->split & 2)) return 0;
+    if (r1->id != r1->parent && r1->parent != PARENT_TMP_PRI) return 0;
+    if (r2->id != r2->parent && r2->parent != PARENT_TMP_PRI) return 0;
+    if (r1->rid != r2->rid || r1->rev != r2->rev) return 0;
+    ql = r1->rev ? r1->qs - r2->qe : r2->qs - r1->qe;
+    tl = r2->rs - r1->re;
+    if (ql < o->min_chain_score || ql > o->max_gap) return 0;
+    if (tl < o->min_chain_score || tl > o->max_gap) return 0;
+
+    mma_gen_simple_mat(5, mat, (int8_t)o->a, (int8_t)o->b, (int8_t)o->sc_ambi);
+    tseq = (uint8_t *)malloc((size_t)tl + 16);
+    getseq(c, r1->rid, r1->re, r2->rs, tseq);
+    qseq = r1->rev ? &c->qseq0[0][r2->qe] : &c->qseq0[1][qlen - r2->qs];
+
+    seq_rev(ql, qseq);
+    seq_rev(tl, tseq);
+    score = mma_ksw_ll(ql, qseq, tl, tseq, mat, o->q, o->e, &q_off, &t_off);
+    seq_rev(ql, qseq);
+    seq_rev(tl, tseq);
+    if (score < o->min_dp_max) goto end_align1_inv;
+    q_off = ql - (q_off + 1); t_off = tl - (t_off + 1);
+    align_pair(o, ql - q_off, qseq + q_off, tl - t_off, tseq + t_off, mat, (int)(o->bw * 1.5), -1, o->zdrop, MMA_EZ_EXTZ_ONLY, ez);
+    if (ez->n_cigar == 0) goto end_align1_inv;
+    append_cigar(r_inv, ez->n_cigar, ez->cigar);
+    r_inv->p->dp_score = (int32_t)ez->max;
+    r_inv->id = -1;
+    r_inv->parent = PARENT_UNSET;
+    r_inv->inv = 1;
+    r_inv->rev = !r1->rev;
+    r_inv->rid = r1->rid;
+    r_inv->div = -1.0f;
+    if (r_inv->rev == 0) {
+        r_inv->qs = r2->qe + q_off;
+        r_inv->qe = r_inv->qs + ez->max_q + 1;
+    } else {
+        r_inv->qe = r2->qs - q_off;
+        r_inv->qs = r_inv->qe - (ez->max_q + 1);
+    }
+    r_inv->rs = r1->re + t_off;
+    r_inv->re = r_inv->rs + ez->max_t + 1;
+    update_extra(r_inv, &qseq[q_off], &tseq[t_off], mat, (int8_t)o->q, (int8_t)o->e, !o->is_sr);
+    ret = 1;
+end_align1_inv:
+    free(tseq);
+    return ret;
 }
 
 static void filter_regs(const mmo_opts *o, int qlen, int *n_regs, reg_t *regs)
@@ -814,7 +1375,8 @@ static const uint8_t nt4[256] = {
 };
 
 void mma_align_read(const mmo_opts *o, const uint8_t *ref_packed, const uint64_t *contig_start, uint32_t n_contigs,
-                    const uint8_t *seq, int32_t qlen, int32_t n_u, const uint64_t *u, mma_anchor *a, mma_result *res)
+                    const uint8_t *seq, int32_t qlen, int32_t n_u, const uint64_t *u, mma_anchor *a,
+                    int32_t n_mini_pos, const uint64_t *mini_pos, mma_result *res)
 {
     actx_t c;
     reg_t *regs;
@@ -832,10 +1394,14 @@ void mma_align_read(const mmo_opts *o, const uint8_t *ref_packed, const uint64_t
     /* chain_post */
     set_parent(o->mask_level, INT_MAX, n_regs, regs);
     select_sub(o->pri_ratio, o->k * 2, o->best_n, 1, (int)(o->max_gap * 0.8), &n_regs, regs);
+    c.o = o; c.ref = ref_packed; c.cstart = contig_start; c.n_contigs = n_contigs; c.qlen = qlen; c.a = a; c.n_a = 0;
+    if (!o->is_sr) {      /* mm_map_frag: !is_sr && !MM_F_QSTRAND */
+        est_err(&c, n_regs, regs, n_mini_pos, mini_pos);
+        n_regs = filter_strand_retained(n_regs, regs);
+    }
     res->n_aligned = n_regs;
 
     /* mm_align_skeleton */
-    c.o = o; c.ref = ref_packed; c.cstart = contig_start; c.n_contigs = n_contigs; c.qlen = qlen; c.a = a;
     c.qseq0[0] = (uint8_t *)malloc((size_t)qlen * 2 + 16);
     c.qseq0[1] = c.qseq0[0] + qlen;
     for (i = 0; i < qlen; ++i) {
@@ -843,15 +1409,25 @@ void mma_align_read(const mmo_opts *o, const uint8_t *ref_packed, const uint64_t
         c.qseq0[1][qlen - 1 - i] = c.qseq0[0][i] < 4 ? 3 - c.qseq0[0][i] : 4;
     }
     memset(&ez, 0, sizeof(ez));
-    /* mm_squeeze_a only renumbers r->as; the short-read branch of mm_align1 never looks at neighbouring regions' anchors */
+    c.n_a = squeeze_a(n_regs, regs, a);
     for (i = 0; i < n_regs; ++i) {
         reg_t r2;
-        align1_sr(&c, &regs[i], &r2, &ez);
+        if (o->is_sr) align1_sr(&c, &regs[i], &r2, &ez);
+        else align1_lr(&c, &regs[i], &r2, &ez);
         if (r2.cnt > 0) {       /* mm_insert_reg */
             regs = (reg_t *)realloc(regs, (size_t)(n_regs + 1) * sizeof(reg_t));
             if (i + 1 != n_regs) memmove(&regs[i + 2], &regs[i + 1], sizeof(reg_t) * (size_t)(n_regs - i - 1));
             regs[i + 1] = r2;
             ++n_regs;
+        }
+        if (i > 0 && regs[i].split_inv) {
+            if (align1_inv(&c, &regs[i - 1], &regs[i], &r2, &ez)) {
+                regs = (reg_t *)realloc(regs, (size_t)(n_regs + 1) * sizeof(reg_t));
+                if (i + 1 != n_regs) memmove(&regs[i + 2], &regs[i + 1], sizeof(reg_t) * (size_t)(n_regs - i - 1));
+                regs[i + 1] = r2;
+                ++n_regs;
+                ++i;
+            }
         }
     }
     free(c.qseq0[0]); free(ez.cigar);

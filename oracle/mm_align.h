@@ -12,7 +12,7 @@
 extern "C" {
 #endif
 
-typedef struct { uint64_t x, y; } mma_anchor;     /* x = strand<<63 | rid<<32 | rpos, y = q_span<<32 | qpos */
+typedef struct { uint64_t x, y; } mma_anchor;     /* x = strand<<63 | rid<<32 | rpos, y = flags (MM_SEED_TANDEM = 1<<42, ...) | q_span<<32 | qpos */
 
 typedef struct {
     uint32_t max; int zdropped;                   /* ksw_extz_t (max is a 31-bit unsigned field upstream) */
@@ -45,7 +45,15 @@ typedef struct {
 /* n_u chains: u[i] = score<<32 | cnt, anchors a[] already compacted in chain order (compact_a).  ref: 4-bit packed nt4
  * codes of all contigs, contig_start[n_contigs + 1]. */
 void mma_align_read(const mmo_opts *o, const uint8_t *ref_packed, const uint64_t *contig_start, uint32_t n_contigs,
-                    const uint8_t *seq, int32_t qlen, int32_t n_u, const uint64_t *u, mma_anchor *a, mma_result *res);
+                    const uint8_t *seq, int32_t qlen, int32_t n_u, const uint64_t *u, mma_anchor *a,
+                    int32_t n_mini_pos, const uint64_t *mini_pos /* mm_collect_matches' list, for mm_est_err */, mma_result *res);
+
+/* ksw_ll_i16 (local alignment score, end of the best hit as upstream's striped scan reports it); used by the inversion tests */
+int mma_ksw_ll(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int gapo, int gape, int *qe, int *te);
+
+/* mg_lchain_rmq's scoring pass (mm_rmq.c): a[] sorted by x; f / p out; t zeroed by the caller */
+void mmo_lchain_rmq_fill(int max_dist, int max_dist_inner, int bw, int max_chn_skip, int cap_rmq_size,
+                         float chn_pen_gap, float chn_pen_skip, int64_t n, const mma_anchor *a, int32_t *f, int64_t *p, int32_t *t);
 
 #ifdef __cplusplus
 }

@@ -38,6 +38,7 @@ static void opts_default(mmo_opts *o)
     o->zdrop = 400; o->zdrop_inv = 200; o->end_bonus = -1; o->min_dp_max = o->min_chain_score * o->a;
     o->best_n = 5; o->bw_long = 20000; o->min_ksw_len = 200;
     o->pri_ratio = 0.8f; o->mask_level = 0.5f; o->max_clip_ratio = 1.0f;
+    o->rmq_inner_dist = 1000; o->rmq_size_cap = 100000; o->rmq_rescue_size = 1000; o->rmq_rescue_ratio = 0.1f;
 }
 
 int mmo_preset(const char *name, mmo_opts *o)
@@ -377,9 +378,13 @@ void mmo_opts_update(mmo_opts *o, const mmo_index *idx)
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
     uint32_t n, q_pos, q_span;   /* q_pos = pos<<1 | strand */
-    uint32_t flt;
+    uint32_t flt, is_tandem;
     const uint64_t *cr;
 } seed_t;
+
+#define SEED_LONG_JOIN (1ULL << 40)
+#define SEED_IGNORE    (1ULL << 41)
+#define SEED_TANDEM    (1ULL << 42)
 
 typedef struct {          /* per-thread scratch, grown on demand */
     uint64_t *mx, *my; int64_t cap_m;
@@ -389,6 +394,7 @@ typedef struct {          /* per-thread scratch, grown on demand */
     m128 *srt; int64_t cap_srt;
     uint64_t *u; int32_t *v; m128 *b; int64_t cap_u, cap_v;      /* chains: u[i] = score<<32 | cnt, v = anchor indices; b = compact_a's output */
     int32_t n_u; int64_t n_v;
+    uint64_t *mini_pos; int64_t cap_mp; int32_t n_mini_pos;      /* mm_collect_matches: q_span<<32 | q_pos of the seeds that were not filtered */
 } scratch_t;
 
 static void *grow(void *p, int64_t *cap, int64_t need, size_t sz)
@@ -402,7 +408,7 @@ static void scratch_free(scratch_t *s)
 {
     free(s->mx); free(s->my); free(s->seeds); free(s->a); free(s->a2);
     free(s->f); free(s->t); free(s->p); free(s->z); free(s->srt);
-    free(s->u); free(s->v); free(s->b);
+    free(s->u); free(s->v); free(s->b); free(s->mini_pos);
 }
 
 /* stable merge sort on x (ties keep input order) — radix_sort_128x is stable for the small
@@ -502,18 +508,25 @@ static int64_t collect_anchors(const mmo_index *idx, const mmo_opts *o, scratch_
         if (t == 0) continue;
         m[n_m0].q_pos = (uint32_t)s->my[i]; m[n_m0].q_span = (uint32_t)(s->mx[i] & 0xff);
         m[n_m0].cr = cr; m[n_m0].n = (uint32_t)t; m[n_m0].flt = 0;
+        /* mm_seed_collect_all: a seed is "tandem" when a neighbour in the minimizer list has the same hash */
+        m[n_m0].is_tandem = (i > 0 && s->mx[i] >> 8 == s->mx[i - 1] >> 8) || (i < n_mv - 1 && s->mx[i] >> 8 == s->mx[i + 1] >> 8);
         ++n_m0;
     }
     *n_seed_out = n_m0;
     if (o->occ_dist > 0 && o->max_max_occ > max_occ) seed_select(n_m0, m, qlen, max_occ, o->max_max_occ, o->occ_dist);
     else for (i = 0; i < n_m0; ++i) if (m[i].n > (uint32_t)max_occ) m[i].flt = 1;
+    s->mini_pos = (uint64_t *)grow(s->mini_pos, &s->cap_mp, n_m0 + 1, 8);
+    s->n_mini_pos = 0;
     for (i = 0; i < n_m0; ++i) {
         seed_t *q = &m[i];
         if (q->flt) {
             int en = (int)(q->q_pos >> 1) + 1, st = en - (int)q->q_span;
             if (st > rep_en) { rep_len += rep_en - rep_st; rep_st = st; rep_en = en; }
             else rep_en = en;
-        } else n_a += q->n;
+        } else {
+            n_a += q->n;
+            s->mini_pos[s->n_mini_pos++] = (uint64_t)q->q_span << 32 | q->q_pos >> 1;
+        }
     }
     rep_len += rep_en - rep_st;
     *rep_len_out = rep_len;
@@ -537,6 +550,7 @@ static int64_t collect_anchors(const mmo_index *idx, const mmo_opts *o, scratch_
                 p->x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
                 p->y = (uint64_t)q->q_span << 32 | (uint32_t)(qlen - ((int32_t)(q->q_pos >> 1) + 1 - (int32_t)q->q_span) - 1);
             }
+            if (q->is_tandem) p->y |= SEED_TANDEM;
         }
     }
     sort128x(s->a, s->a2, n_a);
@@ -594,14 +608,48 @@ static int64_t chain_bk_end(int32_t max_drop, const m128 *z, const int32_t *f, c
     return max_i;
 }
 
+/* mg_chain_backtrack over s->f / s->p (n anchors): chains into s->u / s->v; returns their number */
+static int32_t chain_backtrack(const mmo_opts *o, scratch_t *s, int64_t n, int32_t max_drop, int32_t *best_score)
+{
+    int32_t *f = s->f, *t = s->t, n_u = 0, best = 0;
+    int64_t *p = s->p, i, n_z, k, n_v = 0;
+    m128 *z = s->z;
+    *best_score = 0;
+    s->n_u = 0; s->n_v = 0;
+    /* candidates with f >= min_sc in ascending (f, index) order, visited from the top */
+    for (i = 0, n_z = 0; i < n; ++i)
+        if (f[i] >= o->min_chain_score) z[n_z].x = (uint64_t)(int64_t)f[i], z[n_z].y = (uint64_t)i, ++n_z;
+    if (n_z == 0) return 0;
+    sort128x(z, z + n_z, n_z);
+    memset(t, 0, 4 * (size_t)n);
+    if (n > s->cap_v) { s->cap_v = n + (n >> 1) + 16; s->v = (int32_t *)realloc(s->v, 4 * (size_t)s->cap_v); }
+    for (k = n_z - 1; k >= 0; --k) {
+        if (t[z[k].y] == 0) {
+            int64_t n_v0 = n_v, end_i;
+            int32_t sc;
+            end_i = chain_bk_end(max_drop, z, f, p, t, k);
+            for (i = (int64_t)z[k].y; i != end_i; i = p[i]) s->v[n_v++] = (int32_t)i, t[i] = 1;
+            sc = i < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - f[i];
+            if (sc >= o->min_chain_score && n_v > n_v0 && n_v - n_v0 >= o->min_cnt) {
+                if (n_u >= s->cap_u) { s->cap_u = s->cap_u * 2 + 16; s->u = (uint64_t *)realloc(s->u, 8 * (size_t)s->cap_u); }
+                s->u[n_u++] = (uint64_t)sc << 32 | (uint64_t)(n_v - n_v0);
+                if (sc > best) best = sc;
+            } else n_v = n_v0;
+        }
+    }
+    s->n_u = n_u; s->n_v = n_v;
+    *best_score = best;
+    return n_u;
+}
+
 /* mg_lchain_dp + mg_chain_backtrack: number of chains kept and best kept score */
 static int32_t chain_dp(const mmo_opts *o, scratch_t *s, int64_t n, int k_idx, int qlen, int32_t *best_score)
 {
-    int32_t max_dist_x, max_dist_y, bw = o->bw, max_drop = o->bw, n_u = 0, best = 0;
+    int32_t max_dist_x, max_dist_y, bw = o->bw, max_drop = o->bw;
     int32_t *f, *t;
-    int64_t *p, i, j, max_ii, st = 0, n_z, k, n_v = 0;
+    int64_t *p, i, j, max_ii, st = 0;
     float chn_pen_gap, chn_pen_skip;
-    m128 *a = s->a, *z;
+    m128 *a = s->a;
 
     *best_score = 0;
     if (n == 0) return 0;
@@ -624,7 +672,7 @@ static int32_t chain_dp(const mmo_opts *o, scratch_t *s, int64_t n, int k_idx, i
         s->p = (int64_t *)realloc(s->p, 8 * (size_t)s->cap_dp);
         s->z = (m128 *)realloc(s->z, 16 * (size_t)s->cap_dp * 2);
     }
-    f = s->f; t = s->t; p = s->p; z = s->z;
+    f = s->f; t = s->t; p = s->p;
     memset(t, 0, 4 * (size_t)n);
 
     for (i = 0, max_ii = -1; i < n; ++i) {
@@ -661,30 +709,7 @@ static int32_t chain_dp(const mmo_opts *o, scratch_t *s, int64_t n, int k_idx, i
             max_ii = i;
     }
 
-    /* backtrack: candidates with f >= min_sc in ascending (f, index) order, visited from the top */
-    for (i = 0, n_z = 0; i < n; ++i)
-        if (f[i] >= o->min_chain_score) z[n_z].x = (uint64_t)(int64_t)f[i], z[n_z].y = (uint64_t)i, ++n_z;
-    if (n_z == 0) return 0;
-    sort128x(z, z + n_z, n_z);
-    memset(t, 0, 4 * (size_t)n);
-    if (n > s->cap_v) { s->cap_v = n + (n >> 1) + 16; s->v = (int32_t *)realloc(s->v, 4 * (size_t)s->cap_v); }
-    for (k = n_z - 1; k >= 0; --k) {
-        if (t[z[k].y] == 0) {
-            int64_t n_v0 = n_v, end_i;
-            int32_t sc;
-            end_i = chain_bk_end(max_drop, z, f, p, t, k);
-            for (i = (int64_t)z[k].y; i != end_i; i = p[i]) s->v[n_v++] = (int32_t)i, t[i] = 1;
-            sc = i < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - f[i];
-            if (sc >= o->min_chain_score && n_v > n_v0 && n_v - n_v0 >= o->min_cnt) {
-                if (n_u >= s->cap_u) { s->cap_u = s->cap_u * 2 + 16; s->u = (uint64_t *)realloc(s->u, 8 * (size_t)s->cap_u); }
-                s->u[n_u++] = (uint64_t)sc << 32 | (uint64_t)(n_v - n_v0);
-                if (sc > best) best = sc;
-            } else n_v = n_v0;
-        }
-    }
-    s->n_u = n_u; s->n_v = n_v;
-    *best_score = best;
-    return n_u;
+    return chain_backtrack(o, s, n, max_drop, best_score);
 }
 
 /* compact_a of mg_lchain_dp: each chain's anchors in ascending order, chains re-ordered by the target position of their
@@ -740,13 +765,32 @@ static void map_one(const mmo_index *idx, const mmo_opts *o, scratch_t *s, const
     tr->n_seed = n_seed; tr->n_anchor = (int32_t)n_a; tr->rep_len = rep_len;
     tr->n_chain = n_u; tr->best_score = best; tr->flag = n_u > 0;
     /* A.6: with MM_F_CIGAR (`.with_cigar()`, cleaner.rs:473) a chain only counts once a region of it survives the base-level
-     * alignment and mm_filter_regs.  Restated for the short-read mode; long-read presets keep the chain-level decision. */
-    if (n_u > 0 && (o->flags & MMO_F_CIGAR) && o->is_sr && idx->ref) {
+     * alignment and mm_filter_regs. */
+    if (n_u > 0 && (o->flags & MMO_F_CIGAR) && idx->ref) {
         mma_result res;
         compact_chains(s);
-        mma_align_read(o, idx->ref, idx->cstart, idx->n_contigs, seq, (int32_t)len, n_u, s->u, (mma_anchor *)s->b, &res);
-        tr->n_aligned = res.n_aligned; tr->n_regs = res.n_regs; tr->dp_max = res.dp_max; tr->sig = res.sig;
-        tr->flag = res.n_regs > 0;
+        if (!o->is_sr && o->bw_long > o->bw && n_u > 1) {      /* mm_map_frag: re-chain / long-join for long sequences */
+            const int32_t st = (int32_t)s->b[0].y, en = (int32_t)s->b[(int32_t)s->u[0] - 1].y;
+            if ((int32_t)len - (en - st) > o->rmq_rescue_size || en - st > (int32_t)len * o->rmq_rescue_ratio) {
+                int64_t i;
+                const float chn_pen_gap = (float)(o->chain_gap_scale * 0.01 * o->k), chn_pen_skip = (float)(o->chain_skip_scale * 0.01 * o->k);
+                for (i = 0, n_a = 0; i < n_u; ++i) n_a += (int32_t)s->u[i];
+                memcpy(s->a, s->b, sizeof(m128) * (size_t)n_a);      /* the chains' anchors only; n_a <= the anchors s->a was sized for */
+                sort128x(s->a, s->a2, n_a);
+                memset(s->t, 0, 4 * (size_t)n_a);
+                mmo_lchain_rmq_fill(o->max_gap, o->rmq_inner_dist, o->bw_long, o->max_chain_skip, o->rmq_size_cap, chn_pen_gap, chn_pen_skip,
+                                    n_a, (const mma_anchor *)s->a, s->f, s->p, s->t);
+                n_u = chain_backtrack(o, s, n_a, o->bw_long, &best);
+                tr->rechained |= 2; tr->n_chain = n_u; tr->best_score = best;
+                if (n_u > 0) compact_chains(s);
+            }
+        }
+        if (n_u > 0) {
+            mma_align_read(o, idx->ref, idx->cstart, idx->n_contigs, seq, (int32_t)len, n_u, s->u, (mma_anchor *)s->b,
+                           s->n_mini_pos, s->mini_pos, &res);
+            tr->n_aligned = res.n_aligned; tr->n_regs = res.n_regs; tr->dp_max = res.dp_max; tr->sig = res.sig;
+            tr->flag = res.n_regs > 0;
+        } else tr->flag = 0;
     }
 }
 

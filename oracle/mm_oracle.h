@@ -22,9 +22,9 @@
  *   A.3 index                 (mmo_index_*)
  *   A.4 seed collection, occurrence filter, sr re-chain with max_occ
  *   A.5 chaining DP + backtrack; decision = "at least one chain kept"
- *   A.6 base-level extension stage and mm_filter_regs (mm_align.c), for the short-read
- *       mode (MM_F_SR: preset sr); for long-read presets the decision stays at A.5
- *       (documented divergence)
+ *   A.6 base-level extension stage and mm_filter_regs (mm_align.c): the short-read branch
+ *       (MM_F_SR: preset sr) and the long-read branch (map-ont, lr:hq, map-hifi) with the
+ *       RMQ re-chain (mm_rmq.c), mm_est_err and the strand filter that precede it
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  The product (scrubby_amd/) never links or calls it.
@@ -60,6 +60,9 @@ typedef struct {
     int32_t zdrop, zdrop_inv, end_bonus, min_dp_max;
     int32_t best_n, bw_long, min_ksw_len;
     float   pri_ratio, mask_level, max_clip_ratio;
+    /* the long-join re-chain of mm_map_frag (bw_long > bw, more than one chain): mg_lchain_rmq, mm_rmq.c */
+    int32_t rmq_inner_dist, rmq_size_cap, rmq_rescue_size;
+    float   rmq_rescue_ratio;
 } mmo_opts;
 #define MMO_F_CIGAR 1
 
@@ -69,7 +72,7 @@ typedef struct {
     int32_t n_seed;      /* minimizers present in the index (mm_seed_collect_all) */
     int32_t n_anchor;    /* anchors entering the LAST chaining pass */
     int32_t rep_len;     /* repetitive query length of the last pass */
-    int32_t rechained;   /* 1 if the max_occ second pass ran */
+    int32_t rechained;   /* bit 0: the max_occ second pass ran (sr); bit 1: the RMQ long-join re-chain ran (long-read presets with MM_F_CIGAR) */
     int32_t n_chain;     /* chains kept by backtrack (n_regs0) */
     int32_t best_score;  /* max chain score among kept chains, 0 if none */
     int32_t flag;        /* 1 = host, 0 = retained, 2 = empty read (reference: Err).  host = n_chain > 0 without MM_F_CIGAR, n_regs > 0 with it */

@@ -30,9 +30,31 @@ struct AlignParams {
 };
 
 // a chain as the chaining kernels hand it over: anchors cx/cq[off .. off + cnt) in ascending order
-struct ChainRec { uint32_t next, cnt; int32_t score; uint32_t key_f, key_i, pad; unsigned long long off, z; };
+struct ChainRec { uint32_t next, cnt; int32_t score; uint32_t key_f, key_i, yfl /* y flags of the first anchor >> 32 */; unsigned long long off, z; };
 #define SINK_SHARDS 64
+// Which seeds of a read are "tandem" (mm_seed_collect_all): their anchors carry MM_SEED_TANDEM in y, which mm_gen_regs hashes into the
+// order of equal-score chains and which the long-read gap filling skips.  Looked up by query position in the read's seed records.
+#define SH_Y_TANDEM (1ull << 42)
+struct TandemQ { const uint4 *rec; uint32_t n, stride; int32_t qlen; uint32_t any; };
+__device__ inline uint64_t tandem_yflag(const TandemQ &t, uint64_t x0, uint32_t q0, int32_t k)
+{
+    if (!t.any) return 0;
+    const uint32_t qpos = (x0 >> 63) ? (uint32_t)(t.qlen + k - 2) - q0 : q0;      // back to the forward strand of the query
+    for (uint32_t j = 0; j < t.n; ++j) {
+        const uint4 s = t.rec[(size_t)j * t.stride];
+        if ((s.w >> 1) == qpos) {
+            bool td = (s.z & SH_REC_PREV_SAME) != 0;
+            if (!td && j + 1 < t.n) td = (t.rec[(size_t)(j + 1) * t.stride].z & SH_REC_PREV_SAME) != 0;
+            return td ? SH_Y_TANDEM : 0ull;
+        }
+    }
+    return 0;
+}
+
 struct ChainSink {
+    // seed records of the batch in K1's layout (read r: trec + r * tseed_cap, count and "has a tandem seed" in tinfo[r]): what sink_emit
+    // looks the first anchor's MM_SEED_TANDEM up in; kernels that sketch reads themselves pass their own TandemQ
+    const uint4 *trec; const uint32_t *tinfo; uint32_t tseed_cap;
     ChainRec *recs; uint32_t *n_recs; uint32_t cap_recs;                 // 64 shards of cap_recs records (one cursor each: a single address
     uint64_t *cx; uint32_t *cq; unsigned long long *n_anch; unsigned long long cap_anch;   // only sustains ~90 M atomics/s), likewise cap_anch anchors
     uint32_t *head;        // per read of the chunk: newest record, ~0u = none
@@ -67,9 +89,9 @@ __device__ inline uint32_t region_hash(int32_t qlen)
     return al_wang(h);
 }
 // mm_gen_regs' sort key of a chain whose first anchor is (x0, q0)
-__device__ inline unsigned long long chain_z(uint64_t x0, uint32_t q0, int32_t k, int32_t score, uint32_t cnt, uint32_t rhash)
+__device__ inline unsigned long long chain_z(uint64_t x0, uint32_t q0, int32_t k, int32_t score, uint32_t cnt, uint32_t rhash, uint64_t yfl)
 {
-    const uint64_t y0 = (uint64_t)(uint32_t)k << 32 | q0;
+    const uint64_t y0 = yfl | (uint64_t)(uint32_t)k << 32 | q0;
     const uint32_t h = (uint32_t)al_hash64((al_hash64(x0) + al_hash64(y0)) ^ rhash);
     return ((unsigned long long)(uint32_t)score << 32 | cnt) ^ h;
 }
@@ -84,14 +106,21 @@ __device__ inline int32_t sink_best_score(const ChainSink &sk, uint32_t read)
 // append one chain.  pred(i) -> predecessor; xq(i, x, q) reads an anchor.  Called by ONE lane.
 template <class XQ, class PRED>
 __device__ inline void sink_emit(const ChainSink &sk, uint32_t read, int32_t zi, int32_t end_i, int32_t score, uint32_t cnt,
-                                 uint32_t key_f, uint32_t key_i, int32_t k, uint32_t rhash, XQ xq, PRED pred)
+                                 uint32_t key_f, uint32_t key_i, int32_t k, uint32_t rhash, int32_t qlen, XQ xq, PRED pred, const TandemQ *tq = nullptr)
 {
     if (score < sink_best_score(sk, read)) return;
     int32_t first = zi;
     for (int32_t p = pred(first); p != end_i; p = pred(first)) first = p;
     uint64_t x0; uint32_t q0;
     xq(first, x0, q0);
-    const unsigned long long z = chain_z(x0, q0, k, score, cnt, rhash);
+    uint64_t yfl = 0;
+    if (tq) yfl = tandem_yflag(*tq, x0, q0, k);
+    else if (sk.trec) {
+        const uint32_t info = sk.tinfo[read], n = info >> 16 & 0x7fffu;
+        const TandemQ t{sk.trec + (size_t)read * sk.tseed_cap, n < sk.tseed_cap ? n : sk.tseed_cap, 1u, qlen, info >> 31};
+        yfl = tandem_yflag(t, x0, q0, k);
+    }
+    const unsigned long long z = chain_z(x0, q0, k, score, cnt, rhash, yfl);
     if (sk.best) {
         const unsigned long long old = atomicMax(&sk.best[read], z);
         if (z < old) return;
@@ -105,7 +134,7 @@ __device__ inline void sink_emit(const ChainSink &sk, uint32_t read, int32_t zi,
     const unsigned long long off = (unsigned long long)sh * sk.cap_anch + lo;
     uint32_t j = cnt;
     for (int32_t i = zi; i != end_i && j > 0; i = pred(i)) { --j; uint64_t x; uint32_t q; xq(i, x, q); sk.cx[off + j] = x; sk.cq[off + j] = q; }
-    ChainRec rc{0u, cnt, score, key_f, key_i, 0u, off, z};
+    ChainRec rc{0u, cnt, score, key_f, key_i, (uint32_t)(yfl >> 32), off, z};
     rc.next = atomicExch(&sk.head[read], idx);
     sk.recs[idx] = rc;
 }
@@ -674,7 +703,7 @@ __device__ inline bool align_read_wave(const AlignIn &in, const AlignParams &P, 
     hash = al_wang(hash);
     for (int32_t i = (int32_t)lane; i < n_u; i += 64) {
         const ChainRec rc = in.recs[kh[i]];
-        const uint64_t x0 = in.cx[rc.off], y0 = (uint64_t)(uint32_t)P.k << 32 | in.cq[rc.off];
+        const uint64_t x0 = in.cx[rc.off], y0 = (uint64_t)rc.yfl << 32 | (uint64_t)(uint32_t)P.k << 32 | in.cq[rc.off];
         const uint32_t h = (uint32_t)al_hash64((al_hash64(x0) + al_hash64(y0)) ^ hash);
         kz[i] = ((uint64_t)(uint32_t)rc.score << 32 | rc.cnt) ^ h;
         kx[i] = x0;

@@ -122,15 +122,15 @@ __device__ inline bool resolve_mid_wave(bool need, const MidReq &req, const uint
 }
 
 // ---- seeds: one 16-B record per query minimizer found in the index ---------------------------
-//   .x,.y = w1 of the slot (position word, or off<<28|n)   .z = n | flt<<31   .w = qpos<<1|strand
+//   .x,.y = w1 of the slot (position word, or off<<28|n)   .z = n | SH_REC_PREV_SAME | flt<<31   .w = qpos<<1|strand
 struct SeedView {
     uint4 *base;
     uint32_t stride;   // in records
     uint32_t n;
     __device__ inline uint4 get(uint32_t i) const { return base[(size_t)i * stride]; }
-    __device__ inline uint32_t occ(uint32_t i) const { return base[(size_t)i * stride].z & 0x7fffffffu; }
+    __device__ inline uint32_t occ(uint32_t i) const { return base[(size_t)i * stride].z & SH_REC_OCC_MASK; }
     __device__ inline uint32_t qposz(uint32_t i) const { return base[(size_t)i * stride].w; }
-    __device__ inline void set_flt(uint32_t i, uint32_t occ_, uint32_t flt) { base[(size_t)i * stride].z = occ_ | flt << 31; }
+    __device__ inline void set_flt(uint32_t i, uint32_t occ_, uint32_t flt) { uint32_t &z = base[(size_t)i * stride].z; z = (z & SH_REC_PREV_SAME) | occ_ | flt << 31; }
 };
 
 // mm_seed_select + the plain occurrence cut + the rep_len / anchor count loop of
@@ -183,7 +183,7 @@ __device__ inline void seed_filter(SeedView sv, int32_t qlen, int32_t max_occ, c
             int32_t en = (int32_t)(s.w >> 1) + 1, st = en - P.k;
             if (st > rep_en) { rep_len += rep_en - rep_st; rep_st = st; rep_en = en; }
             else rep_en = en;
-        } else n_a += s.z;
+        } else n_a += s.z & SH_REC_OCC_MASK;
     }
     rep_len += rep_en - rep_st;
     n_a_out = n_a; rep_len_out = rep_len;
@@ -318,7 +318,7 @@ __device__ inline void gen_anchors(Store &S, SeedView sv, const uint64_t *__rest
     for (uint32_t i = 0; i < sv.n; ++i) {
         uint4 s = sv.get(i);
         if (s.z >> 31) continue;
-        uint32_t occ = s.z;
+        uint32_t occ = s.z & SH_REC_OCC_MASK;
         uint64_t w1 = (uint64_t)s.y << 32 | s.x;
         if (occ == 1) {
             uint64_t x; uint32_t q;
@@ -597,14 +597,14 @@ struct SliceStore {
 // anchor array (the discovery key of mg_chain_backtrack is (f, that global index)); on = this lane does the writing.
 template <class Store>
 struct StoreEmit {
-    const ChainSink *sk; Store *S; uint32_t read, base; bool on; int32_t k; uint32_t rhash;
+    const ChainSink *sk; Store *S; uint32_t read, base; bool on; int32_t k; uint32_t rhash; int32_t qlen; const TandemQ *tq;
     __device__ inline void operator()(int64_t zi, int64_t end_i, int32_t sc, int64_t cnt, int32_t zf) const
     {
         if (!sk || !on) return;
         Store &St = *S;
-        sink_emit(*sk, read, (int32_t)zi, (int32_t)end_i, sc, (uint32_t)cnt, (uint32_t)zf, base + (uint32_t)zi, k, rhash,
+        sink_emit(*sk, read, (int32_t)zi, (int32_t)end_i, sc, (uint32_t)cnt, (uint32_t)zf, base + (uint32_t)zi, k, rhash, qlen,
                   [&](int32_t i, uint64_t &x, uint32_t &q) { x = St.X(i); q = St.qp(i); },
-                  [&](int32_t i) { return (int32_t)St.Pm(i); });
+                  [&](int32_t i) { return (int32_t)St.Pm(i); }, tq);
     }
     // a chain's score is at most the f of its last anchor: once that falls below the best score handed over, the rest is not wanted
     __device__ inline bool done(int32_t zf) const { return sk && sk->best && zf < sink_best_score(*sk, read); }
@@ -625,14 +625,14 @@ __device__ inline void best_update(BestChain &b, unsigned long long z, int32_t z
 // emitter that only remembers the top chain; hi(i) = x >> 32 of anchor i
 template <class Store, class HI>
 struct BestEmit {
-    Store *S; BestChain *b; uint32_t rhash; int32_t k; uint32_t base; HI hi; bool on;
+    Store *S; BestChain *b; uint32_t rhash; int32_t k; uint32_t base; HI hi; bool on; TandemQ tq;
     __device__ inline void operator()(int64_t zi, int64_t end_i, int32_t sc, int64_t cnt, int32_t) const
     {
         if (!on) return;
         int32_t first = (int32_t)zi;
         for (int32_t p = (int32_t)S->Pm(first); p != (int32_t)end_i; p = (int32_t)S->Pm(first)) first = p;
         const uint64_t x0 = (uint64_t)hi(first) << 32 | S->rlo(first);
-        best_update(*b, chain_z(x0, S->qp(first), k, sc, (uint32_t)cnt, rhash), (int32_t)zi, (int32_t)end_i, sc, (int32_t)cnt, base);
+        best_update(*b, chain_z(x0, S->qp(first), k, sc, (uint32_t)cnt, rhash, tandem_yflag(tq, x0, S->qp(first), k)), (int32_t)zi, (int32_t)end_i, sc, (int32_t)cnt, base);
     }
     __device__ inline bool done(int32_t zf) const { return b->n > 0 && zf < b->score; }
 };
@@ -1029,7 +1029,7 @@ __device__ inline void chain_cluster_ring(const uint64_t *gx, uint32_t *gq, int3
     if (sk) {      // hand-over mode: every chain, anchors intact (the heap lives in `heap`, not over the x slice)
         chain_dp_ring(gx, gq, gf, gpt, n, qlen, P, lane, rm, dbg_cnt);
         SliceStore S{gx, gq, gf, gpt};
-        const StoreEmit<SliceStore> em{sk, &S, read, base, lane == 0, P.k, region_hash(qlen)};
+        const StoreEmit<SliceStore> em{sk, &S, read, base, lane == 0, P.k, region_hash(qlen), qlen, nullptr};
         if (sk->best) backtrack_wave_top(S, n, P, n_u, best, em, lane);
         else backtrack_heap<SliceStore, int32_t, StoreEmit<SliceStore>>(S, n, P, heap, n_u, best, false, em);
         wave_mem_sync();
@@ -1051,7 +1051,7 @@ __device__ inline void chain_cluster_wave(SliceStore &S, int32_t n, int32_t qlen
                                           bool first_only, uint32_t lane, const ChainSink *sk = nullptr, uint32_t read = 0, uint32_t base = 0)
 {
     if (sk) {      // hand-over mode (zbuf must not alias the anchors)
-        const StoreEmit<SliceStore> em{sk, &S, read, base, lane == 0, P.k, region_hash(qlen)};
+        const StoreEmit<SliceStore> em{sk, &S, read, base, lane == 0, P.k, region_hash(qlen), qlen, nullptr};
         if (P.ext_s1 && n >= 2 && n <= 64) {
             // A cluster whose anchors all lie on ONE diagonal, d <= min(max_dist_x, max_dist_y) apart (a copy of the read up to substitutions -
             // the true locus nearly always): the outcome of mg_lchain_dp + mg_chain_backtrack is known without running them (the argument of
@@ -1102,7 +1102,7 @@ __device__ inline void chain_cluster(SliceStore &S, int32_t n, int32_t qlen, con
                                      bool first_only, const ChainSink *sk = nullptr, uint32_t read = 0, uint32_t base = 0)
 {
     if (sk) {      // hand-over mode (zbuf must not alias the anchors)
-        const StoreEmit<SliceStore> em{sk, &S, read, base, true, P.k, region_hash(qlen)};
+        const StoreEmit<SliceStore> em{sk, &S, read, base, true, P.k, region_hash(qlen), qlen, nullptr};
         if (n <= 64) { chain_dp_mask(S, n, qlen, P); backtrack_mask(S, n, P, n_u, best, false, em); }
         else { chain_dp<SliceStore, int32_t>(S, n, qlen, P); backtrack_heap<SliceStore, int32_t, StoreEmit<SliceStore>>(S, n, P, zbuf, n_u, best, false, em); }
         return;

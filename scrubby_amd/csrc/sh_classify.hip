@@ -146,21 +146,24 @@ struct K1Args {
 // Slow path of K1: this lane's minimizer queue is full in the middle of a W-step block (tie-heavy,
 // low-complexity reads).  Probe the lane's queued entries now, in order, so that seed records stay in
 // query order; rare, divergent, deliberately not inlined.
-__device__ __noinline__ uint4 k1_lane_flush(const uint64_t *list, uint32_t lane, uint32_t head, uint32_t tail, const uint4 *slots, uint32_t lg_slots,
-                                            uint4 *rec, uint32_t seed_cap, uint4 acc /* n_seed, overflow, sum_occ, n_high: by value, so the caller's stay in registers */,
+__device__ __noinline__ uint4 k1_lane_flush(const uint64_t *list, uint64_t *prevk, uint32_t lane, uint32_t head, uint32_t tail, const uint4 *slots, uint32_t lg_slots,
+                                            uint4 *rec, uint32_t seed_cap, uint4 acc /* n_seed, overflow | tandem << 1, sum_occ, n_high: by value, so the caller's stay in registers */,
                                             uint32_t mid_occ)
 {
     const uint64_t slot_mask = (1ULL << lg_slots) - 1;
     for (uint32_t e = head; e != tail; ++e) {
         uint64_t m = list[(e & (K1_LIST_CAP - 1)) * 64 + lane];
         uint64_t key = m >> 18, idx = sh_slot_home(key, lg_slots);
+        const uint32_t same = key == prevk[lane] ? SH_REC_PREV_SAME : 0u;
+        prevk[lane] = key;
         uint4 sl = slots[idx];
         uint64_t w0 = (uint64_t)sl.y << 32 | sl.x;
         while (w0 != SH_SLOT_EMPTY && (w0 & SH_SLOT_KEYMASK) != key) { idx = (idx + 1) & slot_mask; sl = slots[idx]; w0 = (uint64_t)sl.y << 32 | sl.x; }
         if (w0 != SH_SLOT_EMPTY) {
             uint32_t occ = (w0 & SH_SLOT_MULTI) ? (sl.z & (uint32_t)SH_SLOT_NMASK) : 1u;
-            if (acc.x < seed_cap) rec[acc.x] = make_uint4(sl.z, sl.w, occ, (uint32_t)m & 0x3ffffu);
-            else acc.y = 1;
+            if (acc.x < seed_cap) rec[acc.x] = make_uint4(sl.z, sl.w, occ | same, (uint32_t)m & 0x3ffffu);
+            else acc.y |= 1;
+            if (same) acc.y |= 2;
             ++acc.x;
             acc.z = acc.z + occ < acc.z ? 0xffffffffu : acc.z + occ;
             acc.w += occ > mid_occ;
@@ -176,6 +179,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     uint64_t *list = (uint64_t *)smem;
     uint32_t *pk = (uint32_t *)(smem + (size_t)K1_LIST_CAP * 64 * 8);
     uint16_t *nm = (uint16_t *)(pk + a.lds_words + 2);
+    // the hash of the minimizer each lane consumed last (mm_sketch order): a seed whose predecessor has the same hash is marked (SH_REC_PREV_SAME)
+    uint64_t *prevk = (uint64_t *)(smem + (((size_t)K1_LIST_CAP * 64 * 8 + ((size_t)a.lds_words + 2) * 6 + 7) & ~(size_t)7));
 
     const uint32_t lane = threadIdx.x;
     const uint64_t tile = blockIdx.x, r0 = tile * 64, r = r0 + lane;
@@ -243,13 +248,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // home-slot gathers in flight (sl[]).  Every W-step block starts by issuing up to 4 gathers per lane for what earlier blocks
     // queued and ends by consuming them, so a lane's HBM latency is covered by its own sketch arithmetic, not only by the
     // other waves of the SIMD.  Seed records stay in query order: the ring is FIFO.
-    uint32_t qh = 0, qt = 0, pend = 0, n_mini = 0, n_seed = 0, overflow = 0, sum_occ = 0, n_high = 0;
+    uint32_t qh = 0, qt = 0, pend = 0, n_mini = 0, n_seed = 0, overflow = 0, sum_occ = 0, n_high = 0, tand = 0;
+    prevk[lane] = ~0ull;
     const uint64_t slot_mask = (1ULL << a.lg_slots) - 1;
     uint4 *rec = a.records + (size_t)(valid ? r : 0) * a.seed_cap;      // per-read contiguous seed records
     auto emit = [&](uint64_t packed) {
         if (qt - qh >= K1_LIST_CAP) {      // tie-heavy read: the lane drains its whole ring now, in order; gathers in flight are dropped
-            const uint4 acc = k1_lane_flush(list, lane, qh, qt, a.slots, a.lg_slots, rec, a.seed_cap, make_uint4(n_seed, overflow, sum_occ, n_high), (uint32_t)a.mid_occ);
-            n_seed = acc.x; overflow = acc.y; sum_occ = acc.z; n_high = acc.w;
+            const uint4 acc = k1_lane_flush(list, prevk, lane, qh, qt, a.slots, a.lg_slots, rec, a.seed_cap, make_uint4(n_seed, overflow, sum_occ, n_high), (uint32_t)a.mid_occ);
+            n_seed = acc.x; overflow = acc.y & 1u; tand |= acc.y >> 1; sum_occ = acc.z; n_high = acc.w;
             qh = qt; pend = 0;
         }
         list[(qt & (K1_LIST_CAP - 1)) * 64 + lane] = sh_packed_entry(packed);      // hash << 18 | pos << 1 | strand
@@ -261,6 +267,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if ((uint32_t)u < pend) {
                 const uint64_t m = list[((qh + u) & (K1_LIST_CAP - 1)) * 64 + lane];
                 const uint64_t key = m >> 18;
+                const uint32_t same = key == prevk[lane] ? SH_REC_PREV_SAME : 0u;
+                prevk[lane] = key;
                 uint4 v = sl[u];
                 uint64_t w0 = (uint64_t)v.y << 32 | v.x;
                 if (w0 != SH_SLOT_EMPTY && (w0 & SH_SLOT_KEYMASK) != key) {
@@ -269,8 +277,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }
                 if (w0 != SH_SLOT_EMPTY) {
                     const uint32_t occ = (w0 & SH_SLOT_MULTI) ? (v.z & (uint32_t)SH_SLOT_NMASK) : 1u;
-                    if (n_seed < a.seed_cap) rec[n_seed] = make_uint4(v.z, v.w, occ, (uint32_t)m & 0x3ffffu);
+                    if (n_seed < a.seed_cap) rec[n_seed] = make_uint4(v.z, v.w, occ | same, (uint32_t)m & 0x3ffffu);
                     else overflow = 1;
+                    tand |= same;
                     ++n_seed;
                     sum_occ = sum_occ + occ < sum_occ ? 0xffffffffu : sum_occ + occ;
                     n_high += occ > (uint32_t)a.mid_occ;
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
 
     // ---- per-read result ------------------------------------------------------------------------
-    if (valid) a.k1info[r] = n_mini | n_seed << 16;
+    if (valid) a.k1info[r] = n_mini | (n_seed & 0x7fffu) << 16 | (tand ? 1u << 31 : 0u);      // bit 31: some seed of the read is tandem (K1 reads have < 2^15 seeds)
     // reads whose seeds need no occurrence filtering and give <= K2_CAP anchors are chained by K2 (lane per read);
     // everything else goes to the repeat path (wave per read)
     if (n_mini > a.q_occ_max) overflow = 1;
@@ -637,7 +646,9 @@ __global__ __launch_bounds__(64) void k_long_probe(LongArgs a)
                 const uint64_t hm = __ballot(hit);
                 if (hit) {
                     const uint32_t occ = (w0 & SH_SLOT_MULTI) ? (sl[u].z & (uint32_t)SH_SLOT_NMASK) : 1u;
-                    a.lrec[base + n_seed + prefix_popc(hm)] = make_uint4(sl[u].z, sl[u].w, occ, y[u]);
+                    const unsigned long long t = t0 + 64ull * u + lane;
+                    const uint32_t same = (t > 0 && a.mz_hash[base + t - 1] == key[u]) ? SH_REC_PREV_SAME : 0u;      // after mm_seed_mz_flt's compaction
+                    a.lrec[base + n_seed + prefix_popc(hm)] = make_uint4(sl[u].z, sl[u].w, occ | same, y[u]);
                 }
                 n_seed += (uint32_t)__popcll(hm);
             }
@@ -716,8 +727,9 @@ __device__ inline uint32_t small_group_hi(SeedView sv, const uint64_t *__restric
             const uint4 sd = sv.get(i);
             if (sd.z >> 31) continue;
             const uint64_t w1 = (uint64_t)sd.y << 32 | sd.x;
-            for (uint32_t t = 0; t < sd.z; ++t) {
-                const uint64_t rp = sd.z == 1 ? w1 : positions[(w1 >> SH_SLOT_NBITS) + t];
+            const uint32_t sd_n = sd.z & SH_REC_OCC_MASK;
+            for (uint32_t t = 0; t < sd_n; ++t) {
+                const uint64_t rp = sd_n == 1 ? w1 : positions[(w1 >> SH_SLOT_NBITS) + t];
                 uint64_t x; uint32_t q;
                 make_anchor(rp, sd.w, qlen, k, x, q);
                 const long long hi = (long long)(x >> 32);
@@ -759,7 +771,7 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
         if (valid) {
             const uint32_t r = a.work[wi];
             const uint32_t info = a.k1info[r];
-            const int32_t n_mini = (int32_t)(info & 0xffffu), n_seed = (int32_t)(info >> 16);
+            const int32_t n_mini = (int32_t)(info & 0xffffu), n_seed = (int32_t)(info >> 16 & 0x7fffu);
             const int32_t qlen = (int32_t)(a.offsets[r + 1] - a.offsets[r]);
             SeedView sv;
             sv.base = a.records + (size_t)r * a.seed_cap;
@@ -774,7 +786,7 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
                 chain_dp_mask(S, (int)n_a, qlen, a.P);
                 BestChain bc{};
                 auto hi = [&](int32_t i) { return small_group_hi(sv, a.positions, qlen, a.P.k, S.grp(i)); };
-                const BestEmit<SmallStore<CAP>, decltype(hi)> be{&S, &bc, region_hash(qlen), a.P.k, 0u, hi, true};
+                const BestEmit<SmallStore<CAP>, decltype(hi)> be{&S, &bc, region_hash(qlen), a.P.k, 0u, hi, true, TandemQ{sv.base, sv.n, sv.stride, qlen, info >> 31}};
                 backtrack_mask(S, (int)n_a, a.P, n_u, best, false, be);
                 tried = true;
                 if (n_u == 0) decided = true;
@@ -799,7 +811,7 @@ __global__ __launch_bounds__(64) void k_chain_small(K2Args a)
                 if (!tried) chain_dp_mask(S, (int)n_a, qlen, a.P);
                 auto emf = [&](int64_t zi, int64_t end_i, int32_t sc, int64_t cnt, int32_t zf) {
                     const uint32_t hi = small_group_hi(sv, a.positions, qlen, a.P.k, S.grp((int)zi));
-                    sink_emit(a.sink, r, (int32_t)zi, (int32_t)end_i, sc, (uint32_t)cnt, (uint32_t)zf, (uint32_t)zi, a.P.k, region_hash(qlen),
+                    sink_emit(a.sink, r, (int32_t)zi, (int32_t)end_i, sc, (uint32_t)cnt, (uint32_t)zf, (uint32_t)zi, a.P.k, region_hash(qlen), qlen,
                               [&](int32_t i, uint64_t &x, uint32_t &q) { x = (uint64_t)hi << 32 | S.rlo(i); q = S.qp(i); },
                               [&](int32_t i) { return S.Pm(i); });
                 };
@@ -860,7 +872,7 @@ __global__ __launch_bounds__(64) void k_pair_pass(K2Args a, int distinct)
             // in fill_chain_params.  Everything else goes through the full path.
             r = a.work[wi];
             info = a.k1info[r];
-            n_seed = info >> 16;
+            n_seed = info >> 16 & 0x7fffu;
             const uint4 *rec = a.records + (size_t)r * a.seed_cap;
             const int32_t qlen = (int32_t)(a.offsets[r + 1] - a.offsets[r]);
             int32_t mdy = a.P.is_sr ? (qlen > a.P.max_gap ? qlen : a.P.max_gap) : a.P.max_gap, mdx;
@@ -875,7 +887,7 @@ __global__ __launch_bounds__(64) void k_pair_pass(K2Args a, int distinct)
             for (uint32_t i = 0; ok && i < n_seed; ++i) {
                 const uint4 sd = rec[i];
                 const uint64_t w1 = (uint64_t)sd.y << 32 | sd.x;
-                if ((sd.z & 0x7fffffffu) != 1u) { ok = false; break; }
+                if ((sd.z & SH_REC_OCC_MASK) != 1u) { ok = false; break; }
                 if (i == 0) { w0 = w1; q0 = sd.w; qp = sd.w >> 1; continue; }
                 const bool fw0 = (uint32_t)(w0 & 1u) == (q0 & 1u), fwi = (uint32_t)(w1 & 1u) == (sd.w & 1u);
                 const int32_t D = (int32_t)(sd.w >> 1) - (int32_t)(q0 >> 1), d = (int32_t)(sd.w >> 1) - (int32_t)qp;
@@ -890,7 +902,7 @@ __global__ __launch_bounds__(64) void k_pair_pass(K2Args a, int distinct)
         } else if (valid) {
             r = a.work[wi];
             info = a.k1info[r];
-            n_seed = info >> 16;
+            n_seed = info >> 16 & 0x7fffu;
             const uint4 *rec = a.records + (size_t)r * a.seed_cap;
             uint64_t w_p = 0, w_pp = 0; uint32_t q_p = 0, q_pp = 0; int have = 0;
             auto codiag = [&](uint64_t wf, uint32_t qf, uint64_t wg, uint32_t qg) {
@@ -902,7 +914,7 @@ __global__ __launch_bounds__(64) void k_pair_pass(K2Args a, int distinct)
             const uint32_t lim = distinct ? (n_seed <= 32u ? n_seed : 0u) : n_seed;
             for (uint32_t i = 0; i < lim; ++i) {
                 const uint4 sd = rec[i];
-                const uint32_t occ = sd.z & 0x7fffffffu;
+                const uint32_t occ = sd.z & SH_REC_OCC_MASK;
                 if (occ <= (uint32_t)a.P.mid_occ) tot += occ;
                 if (distinct) s_key[i * 64 + lane] = sd.x ^ (sd.y * 0x9E3779B1u);
                 if (occ == 1) {
@@ -1001,13 +1013,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {
         const uint32_t r = a.work[w];
         const uint32_t info = a.k1info[r];
-        const uint32_t n_seed = info >> 16;
+        const uint32_t n_seed = info >> 16 & 0x7fffu;
         const int32_t qlen = (int32_t)(a.offsets[r + 1] - a.offsets[r]);
         bool decided = false;
         if (n_seed <= 64u && n_seed >= 2u) {
             const bool have0 = lane < n_seed;
             const uint4 rec0 = have0 ? a.records[(size_t)r * a.seed_cap + lane] : make_uint4(0, 0, 0, 0);
-            const uint32_t occ0 = rec0.z & 0x7fffffffu;
+            const uint32_t occ0 = rec0.z & SH_REC_OCC_MASK;
             const bool single = have0 && occ0 == 1u;
             const uint64_t sm = __ballot(single);
             bool ok = sm != 0 && __ballot(have0 && occ0 > (uint32_t)P.mid_occ) == 0;       // no seed is filtered: every occurrence is an anchor
@@ -1160,7 +1172,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     SliceStore S{(const uint64_t *)&e_x[cb], (const uint32_t *)&e_q[cb], e_f + cb, e_pt + 2 * (size_t)cb};
                     int32_t n_u, best;
                     auto hif = [&](int32_t j) { return (uint32_t)(S.X(j) >> 32); };
-                    const BestEmit<SliceStore, decltype(hif)> be{&S, &bc, region_hash(qlen), P.k, cb, hif, true};
+                    const BestEmit<SliceStore, decltype(hif)> be{&S, &bc, region_hash(qlen), P.k, cb, hif, true, TandemQ{a.records + (size_t)r * a.seed_cap, n_seed, 1u, qlen, info >> 31}};
                     chain_dp_wave(S, cl, qlen, P, lane);
                     backtrack_mask(S, cl, P, n_u, best, false, be);
                 }
@@ -1243,7 +1255,7 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
                                     const ChainParams &P, volatile int32_t *found, BigList bl,
                                     int32_t &n_u_thr, int32_t &best_thr, uint32_t &n_cl_thr, const GlobalQ *gq = nullptr,
                                     uint32_t *nxt = nullptr, const ChainSink *sk = nullptr, uint32_t read = 0, uint64_t *heap = nullptr,
-                                    BestChain *bc = nullptr, uint32_t rhash = 0, int phase = -1)
+                                    BestChain *bc = nullptr, uint32_t rhash = 0, int phase = -1, TandemQ tq = TandemQ{nullptr, 0u, 1u, 0, 0u})
 {   // phase (flag-only hand-over, where a cluster that cannot beat the best score found so far is skipped): the BIG clusters first -
     //   CONTIG: 0 = only clusters of more than 64 anchors (queued for k_cluster_dp), 1 = only the others, afterwards; -1 = all at once
     //   else:   the clusters a wave chains (> 6 anchors) before the ones a lane chains, inside this call
@@ -1287,7 +1299,7 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
             SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i};
             int32_t n_u, best;
             auto hi = [&](int32_t j) { return (uint32_t)(S.X(j) >> 32); };
-            const BestEmit<SliceStore, decltype(hi)> be{&S, bc, rhash, P.k, i, hi, true};
+            const BestEmit<SliceStore, decltype(hi)> be{&S, bc, rhash, P.k, i, hi, true, tq};
             chain_dp_mask(S, (int)len, qlen, P);
             backtrack_mask(S, (int)len, P, n_u, best, false, be);
             ++n_cl_thr;
@@ -1570,7 +1582,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const uint32_t w = w_next++;
         const uint32_t r = a.list[w];
         const uint32_t info = a.k1info[r];
-        const uint32_t n_seed = info >> 16;
+        const uint32_t n_seed = LONG ? info >> 16 : (info >> 16 & 0x7fffu);      // K1's records: bit 31 = the read has a tandem seed
         const int32_t qlen = (int32_t)(a.offsets[r + 1] - a.offsets[r]);
         const uint32_t n_st = (n_seed + 63) / 64;
         const bool no_keep = plain_cut || (int32_t)((double)qlen / (double)P.occ_dist + .499) <= 0;   // every streak has max_high_occ == 0
@@ -1590,7 +1602,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const uint32_t sidx = t * 64 + lane;
             have = sidx < n_seed;
             rec = have ? recb[sidx] : make_uint4(0, 0, 0, 0);
-            const uint32_t occ = rec.z & 0x7fffffffu, qposz = rec.w;
+            const uint32_t occ = rec.z & SH_REC_OCC_MASK, qposz = rec.w;
             const bool high = have && occ > (uint32_t)a.max_occ;
             flt = false;
             if (plain_cut) flt = high;
@@ -1635,7 +1647,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             for (uint32_t t = 0; t < n_st; ++t) {
                 const uint32_t sidx = t * 64 + lane;
                 const bool have = sidx < n_seed;
-                const uint32_t occ = have ? recb[sidx].z & 0x7fffffffu : 0u;
+                const uint32_t occ = have ? recb[sidx].z & SH_REC_OCC_MASK : 0u;
                 const bool high = have && occ > (uint32_t)a.max_occ;
                 const uint64_t low = __ballot(have && !high);
                 const uint64_t below = low & ((1ULL << lane) - 1);
@@ -1649,7 +1661,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 const uint32_t sidx = (uint32_t)t * 64 + lane;
                 const bool have = sidx < n_seed;
                 const uint4 rec = have ? recb[sidx] : make_uint4(0, 0, 0, 0);
-                const uint32_t occ = rec.z & 0x7fffffffu;
+                const uint32_t occ = rec.z & SH_REC_OCC_MASK;
                 const bool high = have && occ > (uint32_t)a.max_occ;
                 const uint64_t low = __ballot(have && !high);
                 const uint64_t above = lane >= 63 ? 0 : low & ~((2ULL << lane) - 1);
@@ -1665,7 +1677,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     if (mho > 0) {      // keep the mho smallest by (occ, index) of the streak (last0, nxt)
                         int32_t rank = 0;
                         for (int32_t u = last0 + 1; u < nxt && rank < mho; ++u) {
-                            const uint32_t ou = recb[u].z & 0x7fffffffu;
+                            const uint32_t ou = recb[u].z & SH_REC_OCC_MASK;
                             rank += (ou < occ) || (ou == occ && u < (int32_t)sidx);
                         }
                         if (rank < mho) flt = false;
@@ -1795,7 +1807,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 // regs[0] of mm_gen_regs - if chain_lemma vouches for it the read is mapped and nothing is handed over
                 BestChain bc{};
                 chain_sorted<false>(e_x, e_q, e_f, e_pt, n_a, lane, 64, qlen, P, nullptr, BigList{e_bstart, e_blen, &e_bcount, 8}, n_u, best, n_clusters,
-                                    nullptr, nullptr, nullptr, r, nullptr, &bc, region_hash(qlen));
+                                    nullptr, nullptr, nullptr, r, nullptr, &bc, region_hash(qlen), -1, TandemQ{recb, n_seed, 1u, qlen, LONG ? 1u : info >> 31});
                 unsigned long long zmax = bc.n ? bc.z : 0ull;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = (unsigned long long)__shfl_xor((long long)zmax, o); zmax = other > zmax ? other : zmax; }
@@ -2304,7 +2316,7 @@ __global__ void k_finalize(K3Args a)
         const uint32_t info = a.k1info[m.r];
         int32_t fl = n_u > 0;
         a.flags[m.r] = (uint8_t)fl;
-        write_trace(a.trace, m.r, (int32_t)(info & 0xffffu), (int32_t)(info >> 16), (int32_t)m.n_a, m.rep_len, a.pass, n_u, best, fl);
+        write_trace(a.trace, m.r, (int32_t)(info & 0xffffu), (int32_t)(a.seed_off ? info >> 16 : (info >> 16 & 0x7fffu)), (int32_t)m.n_a, m.rep_len, a.pass, n_u, best, fl);
         n_host_thr += (uint32_t)fl;
     }
     if (n_host_thr) atomicAdd(&a.ctr->sh_host[(blockIdx.x + threadIdx.x) & 63], n_host_thr);
@@ -2370,6 +2382,7 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
                         for (int32_t e = nm - 1; e > 0; --e) { uint64_t t0 = hs[0]; hs[0] = hs[e]; hs[e] = t0; down(0, e); }
                     }
                     const uint64_t slot_mask = (1ULL << a.lg_slots) - 1;
+                    uint64_t prev_key = ~0ull;
                     for (int32_t i = 0; i < nm; ++i) {
                         const uint64_t key = mh[i];
                         if (thin) {     // occurrences of this hash in the query, from the sorted copy
@@ -2381,6 +2394,8 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
                             if (cnt > a.P.mid_occ && (float)cnt > (float)nm * a.P.q_occ_frac) continue;
                         }
                         ++n_mini;
+                        const uint32_t same = key == prev_key ? SH_REC_PREV_SAME : 0u;
+                        prev_key = key;
                         uint64_t idx = sh_slot_home(key, a.lg_slots);
                         uint4 s = a.slots[idx];
                         uint64_t w0 = (uint64_t)s.y << 32 | s.x;
@@ -2389,7 +2404,7 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
                         }
                         if (w0 != SH_SLOT_EMPTY) {
                             uint32_t occ = (w0 & SH_SLOT_MULTI) ? (s.z & (uint32_t)SH_SLOT_NMASK) : 1u;
-                            recs[n_seed++] = make_uint4(s.z, s.w, occ, my[i]);
+                            recs[n_seed++] = make_uint4(s.z, s.w, occ | same, my[i]);
                         }
                     }
                     sv.base = recs; sv.stride = 1; sv.n = (uint32_t)n_seed;
@@ -2410,7 +2425,8 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
                     gen_anchors(S, sv, a.positions, qlen, a.P.k);
                     chain_dp<LargeStore, int64_t>(S, n_a, qlen, a.P);
                     if (a.emit) {
-                        const StoreEmit<LargeStore> em{&a.sink, &S, r, 0u, true, a.P.k, region_hash(qlen)};
+                        const TandemQ tq{sv.base, sv.n, sv.stride, qlen, 1u};
+                        const StoreEmit<LargeStore> em{&a.sink, &S, r, 0u, true, a.P.k, region_hash(qlen), qlen, &tq};
                         backtrack_heap<LargeStore, int64_t, StoreEmit<LargeStore>>(S, n_a, a.P, S.z, n_u, best, false, em);
                     } else
                     backtrack_heap<LargeStore, int64_t>(S, n_a, a.P, S.z, n_u, best);
@@ -2771,6 +2787,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         c->sink.recs = (ChainRec *)take(SINK_SHARDS * cap_recs * sizeof(ChainRec)); c->sink.cap_recs = (uint32_t)cap_recs;
         c->sink.cx = (uint64_t *)take(SINK_SHARDS * cap_anch * 8); c->sink.cq = (uint32_t *)take(SINK_SHARDS * cap_anch * 4); c->sink.cap_anch = cap_anch;
         c->sink.head = (uint32_t *)take(max_reads * 4);
+        c->sink.trec = c->use_k1 ? c->d_records : nullptr; c->sink.tinfo = c->d_k1info; c->sink.tseed_cap = c->seed_cap;
         c->d_ext_list = (uint32_t *)take(max_reads * 4);
         c->d_ext_redo = (uint32_t *)take(max_reads * 4);
         c->sink.best = (unsigned long long *)take(max_reads * 8);
@@ -2892,7 +2909,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         a.work_small = c->d_work_small; a.work_resketch = c->d_work_resketch; a.work_big = c->d_big[0][0]; a.ctr = c->d_ctr;
         a.lds_words = c->lds_words; a.mid_occ = c->P.mid_occ;
         a.q_occ_max = (c->P.q_occ_frac > 0.0f && c->P.mid_occ > 0) ? (uint32_t)c->P.mid_occ : UINT32_MAX;
-        size_t lds = (size_t)K1_LIST_CAP * 64 * 8 + ((size_t)c->lds_words + 2) * 4 + (((size_t)c->lds_words + 2) * 2 + 3) / 4 * 4;
+        size_t lds = (((size_t)K1_LIST_CAP * 64 * 8 + ((size_t)c->lds_words + 2) * 6 + 7) & ~(size_t)7) + 64 * 8;
         switch (idx->w) {
         case 5: launch_k1<5>(a, n_tiles, lds, s); break;
         case 10: launch_k1<10>(a, n_tiles, lds, s); break;

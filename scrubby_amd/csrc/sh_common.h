@@ -18,6 +18,12 @@
 #define SH_SLOT_KEYMASK ((1ULL << 56) - 1)
 #define SH_SLOT_NBITS 28
 #define SH_SLOT_NMASK ((1ULL << SH_SLOT_NBITS) - 1)
+// seed record (uint4): x,y = slot payload w1, z = occurrence count | flags, w = qpos << 1 | strand
+//   z bit 31: filtered by mm_seed_select (set by the consumers that store their verdict)
+//   z bit 30: the minimizer emitted just before this one - in mm_sketch's order, after mm_seed_mz_flt - has the same hash.  A seed is
+//             "tandem" (mm_seed_collect_all: MM_SEED_TANDEM on its anchors) when this bit is set on it or on the record behind it.
+#define SH_REC_PREV_SAME (1u << 30)
+#define SH_REC_OCC_MASK 0x3fffffffu
 
 struct sh_index {
     int32_t device = 0;
