@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SH_VERSION 100   /* 0.1.0 */
+#define SH_VERSION 101   /* 0.1.1: sh_opts grew the rmq_* fields (round 3); sh_trace has 12 words since 0.1.0's second round */
 
 typedef int32_t sh_status;
 enum {
@@ -73,6 +73,10 @@ typedef struct sh_opts {
     int32_t zdrop, zdrop_inv, end_bonus, min_dp_max;
     int32_t best_n, bw_long, min_ksw_len;
     float   pri_ratio, mask_level, max_clip_ratio;
+    /* long-read presets: minimap2 re-chains a read whose first chaining pass left more than one chain with mg_lchain_rmq
+     * (mm_map_frag: bw_long > bw), unless the first chain is small on a short read (rmq_rescue_*) */
+    int32_t rmq_inner_dist, rmq_size_cap, rmq_rescue_size;
+    float   rmq_rescue_ratio;
 } sh_opts;
 #define SH_F_CIGAR 1
 

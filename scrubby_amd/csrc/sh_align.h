@@ -19,6 +19,8 @@
 
 #define KSW_NEG_INF (-0x40000000)
 #define EZ_RIGHT 0x02
+#define EZ_APPROX_MAX 0x08
+#define EZ_APPROX_DROP 0x10
 #define EZ_EXTZ_ONLY 0x40
 #define EZ_REV_CIGAR 0x80
 
@@ -325,7 +327,7 @@ __device__ inline void ksw_extd2_core(int32_t qlen, const uint8_t *query, bool q
     for (int32_t t = (int32_t)lane; t < qr_cap; t += 64) qr[t] = t < qlen ? ld8(query + (qlen - 1 - t), qg) : 0;
     al_sync();
 
-    int32_t last_st = -1, last_en = -1, r;
+    int32_t last_st = -1, last_en = -1, r, H0 = 0, last_H0_t = 0;
     for (r = 0; r < qlen + tlen - 1; ++r) {
         int32_t st = 0, en = tlen - 1;
         if (st < r - qlen + 1) st = r - qlen + 1;
@@ -408,6 +410,28 @@ __device__ inline void ksw_extd2_core(int32_t qlen, const uint8_t *query, bool q
             }
         }
         al_sync();
+        if (flag & EZ_APPROX_MAX) {      // ksw2's approximate maximum: follow one path (the first pass of the long-read gap filling)
+            if (r > 0) {
+                if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
+                    const int32_t d0 = (int32_t)ld8s(v + last_H0_t, g), d1 = (int32_t)ld8s(u + last_H0_t + 1, g);
+                    if (d0 > d1) H0 += d0;
+                    else { H0 += d1; ++last_H0_t; }
+                } else if (last_H0_t >= st0 && last_H0_t <= en0) H0 += (int32_t)ld8s(v + last_H0_t, g);
+                else { ++last_H0_t; H0 += (int32_t)ld8s(u + last_H0_t, g); }
+            } else { H0 = (int32_t)ld8s(v, g) - qe; last_H0_t = 0; }
+            if (flag & EZ_APPROX_DROP) {
+                bool brk = false;
+                if (H0 > ez.max) { ez.max = H0; ez.max_t = last_H0_t; ez.max_q = r - last_H0_t; }
+                else if (last_H0_t >= ez.max_t && r - last_H0_t >= ez.max_q) {
+                    const int32_t tl = last_H0_t - ez.max_t, ql = (r - last_H0_t) - ez.max_q, l = tl > ql ? tl - ql : ql - tl;
+                    if (zdrop >= 0 && ez.max - H0 > zdrop + l * e2) { ez.zdropped = 1; brk = true; }
+                }
+                if (brk) break;
+            }
+            if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H0;
+            last_st = st; last_en = en;
+            continue;
+        }
         // exact maximum through the 32-bit score array; ties resolve as upstream's 4-lane scan does: the last cell first, then
         // lane class (t - st0) & 3 in rising order (smallest t inside a class), then the scalar tail in rising t
         int32_t max_H, max_t, h_st0, h_en0;
@@ -525,6 +549,17 @@ __device__ inline void seq_rev_wave(int32_t len, uint8_t *seq, bool g)
 
 struct AlignOut { int32_t n_aligned, n_regs, dp_max; uint32_t sig; };
 
+// minimap2's fast approximate log2 (mg_log2; valid for x >= 2), bit for bit the oracle's mmo_log2
+__device__ inline float al_mg_log2(float x)
+{
+    union { float f; uint32_t i; } z = { x };
+    float log_2 = (float)(int32_t)(((z.i >> 23) & 255) - 128);
+    z.i &= ~(255U << 23);
+    z.i += 127U << 23;
+    log_2 += (-0.34484843f * z.f + 2.02466578f) * z.f - 0.67487759f;
+    return log_2;
+}
+
 // lane-0 helpers over the region's cigar (plain memory: lane 0 is the only reader and writer) --------------------------
 __device__ inline void append_cigar0(uint32_t *rc, int32_t &rn, int32_t n_cigar, const uint32_t *cigar)
 {
@@ -540,8 +575,9 @@ __device__ inline void append_cigar0(uint32_t *rc, int32_t &rn, int32_t n_cigar,
 }
 
 // mm_fix_cigar + mm_update_extra (log_gap = 0) on lane 0.  qseq / tseq already offset to (qs1, rs1).
-__device__ inline void update_extra0(RegLite &r, uint32_t *c, int32_t &n_cigar, const uint8_t *qseq, bool qg, const uint8_t *tseq, bool tg,
-                                     const AlignParams &P, int32_t &mlen_o, int32_t &blen_o, int32_t &dp_max_o)
+template <class REG>
+__device__ inline void update_extra0(REG &r, uint32_t *c, int32_t &n_cigar, const uint8_t *qseq, bool qg, const uint8_t *tseq, bool tg,
+                                     const AlignParams &P, int32_t &mlen_o, int32_t &blen_o, int32_t &dp_max_o, bool log_gap = false)
 {
     int32_t qshift = 0, tshift = 0;
     if (n_cigar > 1) {
@@ -618,14 +654,16 @@ __device__ inline void update_extra0(RegLite &r, uint32_t *c, int32_t &n_cigar, 
             int32_t n_ambi = 0;
             for (uint32_t l = 0; l < len; ++l) if (ld8(qseq + qoff + (int32_t)l, qg) > 3) ++n_ambi;
             blen += (int32_t)len - n_ambi;
-            s -= P.q + P.e * (int32_t)len;
+            if (log_gap) s -= P.q + (double)P.e * al_mg_log2((float)(1.0 + len));
+            else s -= P.q + P.e * (int32_t)len;
             if (s < 0) s = 0;
             qoff += (int32_t)len;
         } else if (op == 2) {
             int32_t n_ambi = 0;
             for (uint32_t l = 0; l < len; ++l) if (ld8(tseq + toff + (int32_t)l, tg) > 3) ++n_ambi;
             blen += (int32_t)len - n_ambi;
-            s -= P.q + P.e * (int32_t)len;
+            if (log_gap) s -= P.q + (double)P.e * al_mg_log2((float)(1.0 + len));
+            else s -= P.q + P.e * (int32_t)len;
             if (s < 0) s = 0;
             toff += (int32_t)len;
         }

@@ -46,6 +46,7 @@ static void opts_default(sh_opts *o)
     o->zdrop = 400; o->zdrop_inv = 200; o->end_bonus = -1; o->min_dp_max = o->min_chain_score * o->a;
     o->best_n = 5; o->bw_long = 20000; o->min_ksw_len = 200;
     o->pri_ratio = 0.8f; o->mask_level = 0.5f; o->max_clip_ratio = 1.0f;
+    o->rmq_inner_dist = 1000; o->rmq_size_cap = 100000; o->rmq_rescue_size = 1000; o->rmq_rescue_ratio = 0.1f;
 }
 
 extern "C" sh_status sh_preset(const char *name, sh_opts *o)

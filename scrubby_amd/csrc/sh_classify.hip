@@ -43,6 +43,7 @@
 #include "sh_common.h"
 #include "sh_sketch.h"
 #include "sh_chain.h"
+#include "sh_long.h"
 #include <algorithm>
 
 #define SH_SPLIT ((sh_status)-2)      // internal: classify_chunk asks for smaller chunks
@@ -71,6 +72,7 @@ struct Counters {
     uint32_t ext_s3[8];           // SCRUBBY_HIP_DBG & 16: outcome of the local-cluster shortcut (k_expand): 0 tried, 1 no singleton / filtered seed, 2 singletons apart, 3 window grew / too many, 4 K > 64, 5 no margin over U_out, 6 lemma, 7 decided
     uint32_t ext_overflow, ext_n_list, ext_ticket, ext_regions, ext_dropped, ext_n_redo, ext_n_list2, ext_ticket2, ext_n_redo2, ext_ticket3;      // extension stage (sh_align.h)
     uint32_t ext_n_recs[SINK_SHARDS]; unsigned long long ext_n_anch[SINK_SHARDS];                 // hand-over cursors, one per shard
+    uint32_t lext_n_big, lext_ticket_big, lext_rechained, lext_rmq_tie, lext_err_read, lext_pad;  // long-read extension stage (sh_long.h): reads for the large-scratch pass, RMQ re-chains, steps with tied priorities
     uint32_t n_cl[4], cl_ticket, pad3;      // global queue of big clusters (k_cluster_dp), by size class
     uint32_t n_leg_reason[4];     // why reads left the long-read front end: 0 room/segments, 1 thinning screen, 2 anchors beyond the giant path, 3 unused
     unsigned long long arena_cursor, anchor_cursor;
@@ -616,7 +618,7 @@ __global__ __launch_bounds__(64) void k_long_probe(LongArgs a)
             __syncthreads();
         }
         if (legacy || len == 0) {
-            if (lane == 0) { uint32_t i = atomicAdd(&a.ctr->n_resketch, 1u); a.work_resketch[i] = (uint32_t)r; }
+            if (lane == 0) { uint32_t i = atomicAdd(&a.ctr->n_resketch, 1u); a.work_resketch[i] = (uint32_t)r; a.k1info[r] = 0; a.seed_off[r] = 0; }      // no seed records of this read here
             continue;
         }
         const uint64_t slot_mask = (1ULL << a.lg_slots) - 1;
@@ -2546,6 +2548,67 @@ __global__ __launch_bounds__(64) void k_regs_align(ExtArgs a)
     if (lane == 0) { if (n_regions) atomicAdd(&a.ctr->ext_regions, n_regions); if (n_dropped) atomicAdd(&a.ctr->ext_dropped, n_dropped); }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// extension stage, long-read presets (sh_long.h): one wave per read with at least one chain
+// ------------------------------------------------------------------------------------------------
+struct ExtLongArgs {
+    LongIn I; LongParams P; AlignParams AP; ChainParams CP;
+    uint8_t *scratch; unsigned long long scratch_per_wave; LongSizes sz;
+    uint32_t *list; uint32_t *n_list, *ticket; uint32_t *big_list; Counters *ctr; uint8_t *flags; sh_trace *trace; int32_t flag_only;
+};
+
+__global__ __launch_bounds__(64) void k_regs_align_long(ExtLongArgs a)
+{
+    __shared__ AlignLds Ls;
+    __shared__ RmqLds RL;
+    const uint32_t lane = threadIdx.x;
+    LongWs W;
+    long_ws_carve(&W, a.scratch + (unsigned long long)blockIdx.x * a.scratch_per_wave, a.sz);
+    const uint32_t n_list = *a.n_list;
+    uint32_t n_regions = 0, n_dropped = 0, n_rechain = 0, n_tie = 0;
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(a.ticket, 1u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= n_list) break;
+        const uint32_t r = a.list[t];
+        LongCtx C;
+        C.P = &a.P; C.AP = &a.AP; C.I = &a.I; C.W = &W; C.Ls = &Ls;
+        C.A = AlignScratch{};
+        C.A.kmem = W.kmem; C.A.kH = W.kH; C.A.koff = W.koff; C.A.kp = W.kp; C.A.tcap = W.cap_k; C.A.qcap = W.cap_k; C.A.pcap = W.cap_p;
+        C.qlen = (int32_t)(a.I.in.offsets[r + 1] - a.I.in.offsets[r]); C.read = r;
+        C.sc_mch = (int8_t)(a.P.a < 0 ? -a.P.a : a.P.a); C.sc_mis = (int8_t)(a.P.b > 0 ? -a.P.b : a.P.b);
+        C.sc_amb = (int8_t)(a.P.sc_ambi > 0 ? -a.P.sc_ambi : a.P.sc_ambi); C.sc_N = C.sc_amb == 0 ? (int8_t)(-a.P.e2) : C.sc_amb;
+        C.need_big = false; C.err = 0;
+        LongOut o;
+        const int32_t rc = lr_read_wave(C, a.CP, RL, a.flag_only != 0, o);
+        if (rc == 1) {      // an alignment larger than this pass's direction-byte buffer
+            if (lane == 0) {
+                if (a.big_list) a.big_list[atomicAdd(&a.ctr->lext_n_big, 1u)] = r;
+                else { atomicExch(&a.ctr->ext_overflow, 32u); atomicExch(&a.ctr->lext_err_read, r); }
+            }
+        } else if (rc != 0) {
+            if (lane == 0) { atomicExch(&a.ctr->ext_overflow, 16u + C.err); atomicExch(&a.ctr->lext_err_read, r); }
+        } else if (lane == 0) {
+            a.flags[r] = o.n_regs > 0 ? 1 : 0;
+            if (a.trace) {
+                int32_t *tr = (int32_t *)(a.trace + r);
+                tr[4] |= o.rechained | (o.rmq_tie ? 4 : 0); tr[5] = o.n_chain; tr[6] = o.best; tr[7] = o.n_regs > 0;
+                ((int4 *)tr)[2] = make_int4(o.n_aligned, o.n_regs, o.dp_max, (int32_t)o.sig);
+            }
+        }
+        if (rc == 0) { n_regions += (uint32_t)o.n_aligned; n_dropped += o.n_regs == 0; n_rechain += (o.rechained & 2) != 0; n_tie += o.rmq_tie != 0; }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        if (n_regions) atomicAdd(&a.ctr->ext_regions, n_regions);
+        if (n_dropped) atomicAdd(&a.ctr->ext_dropped, n_dropped);
+        if (n_rechain) atomicAdd(&a.ctr->lext_rechained, n_rechain);
+        if (n_tie) atomicAdd(&a.ctr->lext_rmq_tie, n_tie);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side: context
 // ------------------------------------------------------------------------------------------------
@@ -2579,6 +2642,11 @@ struct sh_ctx {
     uint32_t *d_ext_list = nullptr, *d_ext_redo = nullptr; uint8_t *d_ext_scratch = nullptr;
     unsigned long long ext_scratch_per_wave = 0; uint32_t ext_waves = 0, ext_reg_cap = 0;
     hipEvent_t ev_ext[2] = {};
+    // the same stage for the long-read presets (sh_long.h): per-wave working memory in two sizes
+    bool ext_long = false;
+    LongParams LP{};
+    uint8_t *d_lext[2] = {}; unsigned long long lext_per_wave[2] = {}; uint32_t lext_waves[2] = {}; LongSizes lext_sz[2] = {};
+    uint32_t *d_lext_big = nullptr;
     hipStream_t sx[4] = {};          // side streams: K2 and the sort classes run beside the main stream
     int par = 1;                     // bit 0: K2 on a side stream (SCRUBBY_HIP_STREAMS=0: on the main stream)
     hipEvent_t evx[6] = {};
@@ -2616,6 +2684,19 @@ static void fill_chain_params(const sh_opts &o, int32_t mid_occ, ChainParams &P)
         P.ext_unc_max = (s1 || lem) ? o.zdrop / o.b : 0;
         P.ext_a = o.a; P.ext_b = -o.b; P.ext_amb = o.sc_ambi > 0 ? -o.sc_ambi : o.sc_ambi; P.ext_zdrop = o.zdrop;
     }
+    // long-read presets with SH_F_CIGAR (sh_long.h): every chain of a read is handed over, the chain-level shortcuts are off
+    if ((o.flags & SH_F_CIGAR) && !o.is_sr) { P.flag_stop = INT32_MAX; P.pair_dq_min = P.pair_dq_max = 0; }
+}
+
+static void fill_long_params(const sh_opts &o, int32_t mid_occ, LongParams &L)
+{
+    L.k = o.k; L.min_cnt = o.min_cnt; L.min_sc = o.min_chain_score; L.max_gap = o.max_gap; L.bw = o.bw; L.bw_long = o.bw_long < o.bw ? o.bw : o.bw_long; L.min_ksw_len = o.min_ksw_len;
+    L.a = o.a; L.b = o.b; L.q = o.q; L.e = o.e; L.q2 = o.q2; L.e2 = o.e2; L.sc_ambi = o.sc_ambi;
+    L.zdrop = o.zdrop; L.zdrop_inv = o.zdrop_inv; L.end_bonus = o.end_bonus; L.min_dp_max = o.min_dp_max; L.best_n = o.best_n;
+    L.pri_ratio = o.pri_ratio; L.mask_level = o.mask_level; L.max_clip_ratio = o.max_clip_ratio;
+    L.max_skip = o.max_chain_skip; L.rmq_inner_dist = o.rmq_inner_dist; L.rmq_size_cap = o.rmq_size_cap; L.rmq_rescue_size = o.rmq_rescue_size; L.rmq_rescue_ratio = o.rmq_rescue_ratio;
+    L.pen_gap = (float)(o.chain_gap_scale * 0.01 * o.k); L.pen_skip = (float)(o.chain_skip_scale * 0.01 * o.k);
+    L.mid_occ = mid_occ; L.max_max_occ = o.max_max_occ; L.occ_dist = o.occ_dist;
 }
 
 static void fill_align_params(const sh_opts &o, AlignParams &A)
@@ -2644,6 +2725,7 @@ sh_status shi_ctx_rebind(sh_ctx *c, const sh_index *idx)
     const int32_t mid_occ = c->opts.mid_occ > 0 ? c->opts.mid_occ : idx->mid_occ;
     fill_chain_params(c->opts, mid_occ, c->P);
     c->AP.lemma = c->P.ext_lemma; c->AP.unc_max = c->P.ext_unc_max;
+    fill_long_params(c->opts, mid_occ, c->LP);
     return SH_OK;
 }
 uint64_t shi_ctx_max_reads(const sh_ctx *c) { return c->max_reads; }
@@ -2667,16 +2749,9 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
     fill_chain_params(*opts, mid_occ, c->P);
     fill_align_params(*opts, c->AP);
     c->AP.lemma = c->P.ext_lemma; c->AP.unc_max = c->P.ext_unc_max;
-    c->ext = (opts->flags & SH_F_CIGAR) && opts->is_sr;
-    if ((opts->flags & SH_F_CIGAR) && !opts->is_sr) {
-        static bool warned = false;
-        if (!warned) {
-            warned = true;
-            fprintf(stderr, "[scrubby-hip] WARNING: the base-level extension filter that `.with_cigar()` enables (minimap2 mm_align_skeleton / mm_filter_regs) is only "
-                            "implemented for the short-read mode (preset sr).  For this preset a read counts as mapped as soon as one chain is kept; "
-                            "reads whose chains would all fail min_dp_max / min_chain_score after alignment are depleted although the reference keeps them.\n");
-        }
-    }
+    fill_long_params(*opts, mid_occ, c->LP);
+    c->ext = (opts->flags & SH_F_CIGAR) != 0;
+    c->ext_long = c->ext && !opts->is_sr;
     if (c->ext) {
         SH_CHECK(idx->d_ref && idx->d_cstart, SH_ERR_INDEX, "sh_ctx_create: this index holds no reference bases, which the extension stage (SH_F_CIGAR) aligns against: rebuild it from FASTA");
         SH_CHECK(opts->a > 0 && opts->e > 0 && opts->q + opts->e < 100 && opts->q2 + opts->e2 < 100, SH_ERR_BAD_ARG, "sh_ctx_create: alignment scores out of the int8 range of ksw2");
@@ -2776,6 +2851,11 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         // chain hand-over: 32-B records, 12 B per chain anchor, one list head per read; sized for ~2 chains and ~32 chain anchors per
         // read of the chunk (a chunk that needs more is cut in two and re-run: classify_chunk returns SH_SPLIT)
         uint64_t cap_recs = std::max<uint64_t>(1ull << 20, 2 * max_reads), cap_anch = std::max<uint64_t>(1ull << 24, 32 * max_reads);
+        if (c->ext_long) {      // a long read's chains hold most of its minimizers (~2 / (w + 1) per base), secondary chains as many again
+            const uint64_t cb = std::min<uint64_t>(max_bases + 64, max_reads * (uint64_t)max_read_len + 64);
+            cap_anch = std::max<uint64_t>(cap_anch, cb / 2);
+            cap_recs = std::max<uint64_t>(cap_recs, std::min<uint64_t>(cb / 256, 1ull << 28) + 8 * max_reads);
+        }
         if (const char *env = getenv("SCRUBBY_HIP_EXT_MB")) { cap_anch = std::max<uint64_t>(1 << 16, ((uint64_t)atoll(env) << 20) / 16); cap_recs = std::max<uint64_t>(1 << 12, cap_anch / 16); }
         cap_recs = std::min<uint64_t>((cap_recs + SINK_SHARDS - 1) / SINK_SHARDS, 0xfffffff0ull / SINK_SHARDS);      // per shard
         cap_anch = (cap_anch + SINK_SHARDS - 1) / SINK_SHARDS;
@@ -2794,10 +2874,38 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         c->sink.tie = (uint32_t *)take(max_reads * 4);
         c->sink.n_recs = c->d_ctr->ext_n_recs; c->sink.n_anch = c->d_ctr->ext_n_anch; c->sink.overflow = &c->d_ctr->ext_overflow;
         c->ext_reg_cap = 16384;
-        c->ext_scratch_per_wave = align_scratch_layout(max_read_len, c->ext_reg_cap, nullptr, nullptr, nullptr);
-        const uint64_t budget = 4ull << 30;
-        c->ext_waves = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)256 * std::max<uint64_t>(1, (160u << 10) / sizeof(AlignLds)), budget / c->ext_scratch_per_wave, (max_reads + 3) / 4}));
-        if ((e = hipMalloc(&c->d_ext_scratch, (uint64_t)c->ext_waves * c->ext_scratch_per_wave)) != hipSuccess) return fail(e, "extension-stage scratch");
+        if (!c->ext_long) {
+            c->ext_scratch_per_wave = align_scratch_layout(max_read_len, c->ext_reg_cap, nullptr, nullptr, nullptr);
+            const uint64_t budget = 4ull << 30;
+            c->ext_waves = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)256 * std::max<uint64_t>(1, (160u << 10) / sizeof(AlignLds)), budget / c->ext_scratch_per_wave, (max_reads + 3) / 4}));
+            if ((e = hipMalloc(&c->d_ext_scratch, (uint64_t)c->ext_waves * c->ext_scratch_per_wave)) != hipSuccess) return fail(e, "extension-stage scratch");
+        } else {
+            // per-wave working memory of k_regs_align_long in two sizes: every wave slot with room for the usual alignments (a gap between
+            // two anchors ~min_ksw_len apart, end extensions inside the 1.5 * bw band), and a few waves with room for the largest
+            // alignment minimap2 attempts (max_sw_mat = 10^8 cells)
+            const uint64_t L = std::max<uint32_t>(max_read_len, 64);
+            LongSizes z{};
+            z.cap_q = (uint32_t)((L + 31) & ~15ull);
+            z.cap_k = (uint32_t)std::min<uint64_t>(32768, ((2 * L + 1024) + 15) & ~15ull);
+            z.cap_t = (uint32_t)(2 * L + 65536);
+            z.cap_a = (uint32_t)std::min<uint64_t>(1ull << 20, std::max<uint64_t>(16384, L / 2));
+            z.cap_u = z.cap_r = (uint32_t)std::min<uint64_t>(z.cap_a, 16384);
+            z.cap_m = (uint32_t)std::min<uint64_t>(65536, L / 4 + 1024);
+            z.cap_p = std::min<uint64_t>(8ull << 20, (uint64_t)(2 * z.cap_k) * (z.cap_k + 32));
+            if (const char *env = getenv("SCRUBBY_HIP_LEXT_P_KB")) z.cap_p = (uint64_t)atoll(env) << 10;
+            c->lext_sz[0] = z;
+            c->lext_per_wave[0] = long_ws_carve(nullptr, nullptr, z);
+            const uint64_t budget0 = 32ull << 30;
+            c->lext_waves[0] = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)256 * 5, budget0 / c->lext_per_wave[0], max_reads}));
+            LongSizes zb = z;
+            zb.cap_p = std::min<uint64_t>(256ull << 20, (uint64_t)(2 * z.cap_k) * (z.cap_k + 32));
+            c->lext_sz[1] = zb;
+            c->lext_per_wave[1] = long_ws_carve(nullptr, nullptr, zb);
+            c->lext_waves[1] = zb.cap_p > z.cap_p ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, (8ull << 30) / c->lext_per_wave[1])) : 0;
+            for (int t = 0; t < 2; ++t)
+                if (c->lext_waves[t] && (e = hipMalloc(&c->d_lext[t], (uint64_t)c->lext_waves[t] * c->lext_per_wave[t])) != hipSuccess) return fail(e, "long-read extension-stage scratch");
+            if ((e = hipMalloc(&c->d_lext_big, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
+        }
         for (auto &ev : c->ev_ext) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "event");
     }
     for (auto &ev : c->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "event");
@@ -2815,7 +2923,7 @@ extern "C" sh_status sh_ctx_destroy(sh_ctx *c)
     hipFree(c->d_work_defer); hipFree(c->d_work_defer2);
     for (auto &pp : c->d_big) for (auto p : pp) hipFree(p);
     hipFree(c->d_ctr); if (c->h_ctr) hipHostFree(c->h_ctr); hipFree(c->d_arena); hipFree(c->d_long);
-    hipFree(c->d_ext); hipFree(c->d_ext_scratch);
+    hipFree(c->d_ext); hipFree(c->d_ext_scratch); hipFree(c->d_lext[0]); hipFree(c->d_lext[1]); hipFree(c->d_lext_big);
     for (auto ev : c->ev_ext) if (ev) hipEventDestroy(ev);
     for (auto ev : c->ev) if (ev) hipEventDestroy(ev);
     for (auto ev : c->evx) if (ev) hipEventDestroy(ev);
@@ -2956,7 +3064,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     b.P = c->P;
     b.sink = c->sink; b.emit = c->ext ? 1 : 0;
     b.BC = BaseCtx{idx->d_ref, idx->d_cstart, d_bases};
-    if (c->ext && d_trace != nullptr) { b.sink.best = nullptr; b.sink.tie = nullptr; }      // trace mode: every chain is handed over
+    if (c->ext && (d_trace != nullptr || c->ext_long)) { b.sink.best = nullptr; b.sink.tie = nullptr; }      // trace mode / long-read presets: every chain is handed over
     const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(n_tiles, 1), 256 * 8);
     // K2 only needs K1's output and nothing waits for it before the end of the call: it runs on a side stream, beside k_local_cluster /
     // k_expand / the sort classes.  Starting it late instead, beside the giant reads' DP kernels of the second pass (SCRUBBY_HIP_K2_LATE=1),
@@ -2988,7 +3096,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     k.seed_off = c->use_long ? c->d_seed_off : nullptr; k.sel_scratch = c->use_long ? (uint32_t *)c->d_mz_hash : nullptr;
     k.k1info = c->d_k1info; k.flags = d_flags; k.trace = d_trace; k.ctr = c->d_ctr; k.B = c->B; k.P = c->P;
     k.flag_only = d_trace == nullptr && !c->ext;      // SH_F_CIGAR: every chain is needed, no early exit
-    k.sink = b.sink; k.emit = c->ext ? 1 : 0; k.BC = b.BC; k.t_mode = (c->ext && d_trace == nullptr) ? 1 : 0;
+    k.sink = b.sink; k.emit = c->ext ? 1 : 0; k.BC = b.BC; k.t_mode = (c->ext && !c->ext_long && d_trace == nullptr) ? 1 : 0;
     k.dbg = getenv("SCRUBBY_HIP_DBG") ? atoi(getenv("SCRUBBY_HIP_DBG")) : 0;
     k.resketch_list = c->d_work_resketch;
     uint32_t resk_done = 0;
@@ -3073,7 +3181,45 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     }
     uint32_t ext_list = 0, ext_regions = 0, ext_dropped = 0;
     float ms_ext = 0;
-    if (c->ext) {
+    if (c->ext_long) {
+        ExtLongArgs x{};
+        x.I.in.ref = idx->d_ref; x.I.in.cstart = idx->d_cstart; x.I.in.n_contigs = idx->n_contigs;
+        x.I.in.bases = d_bases; x.I.in.offsets = d_offsets; x.I.in.cx = c->sink.cx; x.I.in.cq = c->sink.cq; x.I.in.recs = c->sink.recs; x.I.in.head = c->sink.head;
+        x.I.rec = c->use_long ? c->d_lrec : c->d_records; x.I.k1info = c->d_k1info; x.I.seed_off = c->use_long ? c->d_seed_off : nullptr; x.I.seed_cap = c->seed_cap;
+        x.P = c->LP; x.AP = c->AP; x.CP = c->P;
+        x.scratch = c->d_lext[0]; x.scratch_per_wave = c->lext_per_wave[0]; x.sz = c->lext_sz[0];
+        x.list = c->d_ext_list; x.n_list = &c->d_ctr->ext_n_list; x.ticket = &c->d_ctr->ext_ticket; x.big_list = c->lext_waves[1] ? c->d_lext_big : nullptr;
+        x.ctr = c->d_ctr; x.flags = d_flags; x.trace = d_trace; x.flag_only = d_trace == nullptr;
+        SH_HIP(hipEventRecord(c->ev_ext[0], s));
+        {
+            ExtArgs xl{};
+            xl.in = x.I.in; xl.list = x.list; xl.n_list = x.n_list; xl.n_reads = n_reads;
+            hipLaunchKernelGGL(k_ext_list, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, s, xl);
+        }
+        hipLaunchKernelGGL(k_regs_align_long, dim3(c->lext_waves[0]), dim3(64), 0, s, x);
+        SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+        SH_HIP(hipStreamSynchronize(s));
+        SH_HIP(hipGetLastError());
+        if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;       // hand-over buffers full: the caller cuts the chunk in two
+        SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "long-read extension stage: read %u exceeds the per-wave working memory (code %u: 18 chains, 20 read length, 21 chain anchors, 22 inner RMQ window, 23 seeds, 24 regions, 27/28/29/30 alignment window, 32 direction bytes)", c->h_ctr->lext_err_read, c->h_ctr->ext_overflow);
+        ext_list = c->h_ctr->ext_n_list;
+        if (c->h_ctr->lext_n_big > 0) {      // reads with an alignment beyond the first pass's direction-byte buffer
+            ExtLongArgs x2 = x;
+            x2.scratch = c->d_lext[1]; x2.scratch_per_wave = c->lext_per_wave[1]; x2.sz = c->lext_sz[1];
+            x2.list = c->d_lext_big; x2.n_list = &c->d_ctr->lext_n_big; x2.ticket = &c->d_ctr->lext_ticket_big; x2.big_list = nullptr;
+            hipLaunchKernelGGL(k_regs_align_long, dim3(c->lext_waves[1]), dim3(64), 0, s, x2);
+            SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+            SH_HIP(hipStreamSynchronize(s));
+            SH_HIP(hipGetLastError());
+            SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "long-read extension stage: read %u exceeds the large working memory (code %u)", c->h_ctr->lext_err_read, c->h_ctr->ext_overflow);
+        }
+        if (getenv("SCRUBBY_HIP_DBG")) fprintf(stderr, "[dbg] long-read extension stage: %u reads with chains, %u re-chained (RMQ), %u with tied RMQ priorities, %u needed the large scratch, %u regions aligned, %u reads dropped\n",
+                                               ext_list, c->h_ctr->lext_rechained, c->h_ctr->lext_rmq_tie, c->h_ctr->lext_n_big, c->h_ctr->ext_regions, c->h_ctr->ext_dropped);
+        SH_HIP(hipEventRecord(c->ev_ext[1], s));
+        SH_HIP(hipEventSynchronize(c->ev_ext[1]));
+        ext_regions = c->h_ctr->ext_regions; ext_dropped = c->h_ctr->ext_dropped;
+        hipEventElapsedTime(&ms_ext, c->ev_ext[0], c->ev_ext[1]);
+    } else if (c->ext) {
         ExtArgs x{};
         x.in.ref = idx->d_ref; x.in.cstart = idx->d_cstart; x.in.n_contigs = idx->n_contigs;
         x.in.bases = d_bases; x.in.offsets = d_offsets; x.in.cx = c->sink.cx; x.in.cq = c->sink.cq; x.in.recs = c->sink.recs; x.in.head = c->sink.head;

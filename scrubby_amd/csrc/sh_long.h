@@ -1,0 +1,1335 @@
+// sh_long.h — the base-level extension stage for the long-read presets (map-ont, lr:hq, map-hifi) on the device.
+//
+// `.with_cigar()` at /root/reference/src/cleaner.rs:473 applies to every preset of :456-468, and `mappings.len() > 0` (:552-556) is
+// then "a region survives mm_filter_regs".  Without MM_F_SR minimap2 takes a longer road from the chains to that count than the
+// short-read mode restated in sh_align.h; this header restates it, statement for statement with oracle/mm_align.c and oracle/mm_rmq.c
+// (which cite the upstream functions):
+//     [mm_map_frag]  more than one chain and bw_long > bw: the chains' anchors are re-chained by mg_lchain_rmq (long join)
+//     mm_gen_regs -> mm_set_parent -> mm_select_sub -> mm_est_err -> mm_filter_strand_retained -> mm_squeeze_a
+//     per region mm_align1: mm_fix_bad_ends, mm_filter_bad_seeds(_alt), the extension windows from the neighbouring regions' anchors,
+//         left extension, ksw_extd2 between anchor mid-points every >= min_ksw_len bases (first pass with the approximate maximum,
+//         mm_test_zdrop incl. the inversion test through a local alignment, second pass, mm_split_reg), right extension,
+//         mm_update_extra with the logarithmic gap cost; mm_align1_inv behind an inversion split
+//     mm_filter_regs
+// One WAVE per read.  Data-parallel where there is width (sorting, the RMQ scan over the look-back window, sequence staging, the
+// anti-diagonals of ksw_extd2, the rows of the local alignment); the region bookkeeping is scalar work on lane 0 over the wave's HBM
+// scratch (phases are separated by lr_sync(): agent-scope fence, so what one lane stored is what the others load).
+#pragma once
+#include "sh_align.h"
+#include "sh_chain.h"
+
+struct LAnchor { uint64_t x, y; };      // minimap2's mm128_t for an anchor: y = flags | q_span << 32 | qpos
+#define LY_LONG_JOIN (1ull << 40)
+#define LY_IGNORE    (1ull << 41)
+#define LY_TANDEM    (1ull << 42)
+
+struct LReg {                           // mm_reg1_t, the fields the decision reads
+    int32_t id, cnt, rid, score, qs, qe, rs, re, parent, as, mlen, blen;
+    uint32_t hash;
+    int32_t rev, inv, split_inv, strand_retained, split;
+    float div;
+    int32_t has_p, dp_max, subsc, n_sub;
+};
+#define LR_PARENT_UNSET (-1)
+#define LR_PARENT_TMP_PRI (-2)
+
+struct SKey { uint64_t k, v; };         // sort element: ascending (k, v)
+
+struct LongParams {
+    int32_t k, min_cnt, min_sc, max_gap, bw, bw_long, min_ksw_len;
+    int32_t a, b, q, e, q2, e2, sc_ambi, zdrop, zdrop_inv, end_bonus, min_dp_max, best_n;
+    float pri_ratio, mask_level, max_clip_ratio;
+    int32_t max_skip, rmq_inner_dist, rmq_size_cap, rmq_rescue_size;
+    float rmq_rescue_ratio, pen_gap, pen_skip;
+    int32_t mid_occ, max_max_occ, occ_dist;
+};
+
+// ---- per-wave working memory (HBM) -------------------------------------------------------------------------------------
+struct LongWs {
+    LAnchor *a, *b;                 // cap_a: the read's chain anchors (compact_a order) / sort and re-chain buffer
+    int32_t *f, *p, *t, *v;         // cap_a: chaining state, backtrack output
+    double *pri;                    // cap_a
+    SKey *sk, *sk2;                 // cap_a: sort keys
+    uint64_t *u; uint32_t *uoff;    // cap_u: chains (score << 32 | cnt) and where their anchors start
+    LReg *regs; uint64_t *cov; int32_t *wpri;     // cap_r
+    uint64_t *mini_pos;             // cap_m
+    uint32_t *tbits;                // cap_q / 32 + 1: query positions of tandem seeds
+    int32_t *K;                     // cap_a: positions of long gaps (mm_filter_bad_seeds)
+    uint32_t *r_cigar, *ez_cigar;   // cap_c
+    uint8_t *qseq, *tseq;           // 2 * cap_q, cap_t
+    uint8_t *kmem; int32_t *kH, *koff; uint8_t *kp;      // ksw_extd2: state for up to cap_k x cap_k bases, cap_p direction bytes
+    int32_t *lH, *lE, *lHmax;       // local alignment rows (cap_k + 8 each)
+    uint32_t cap_a, cap_u, cap_r, cap_m, cap_c, cap_q, cap_t, cap_k; unsigned long long cap_p;
+};
+
+struct LongSizes { uint32_t cap_a, cap_u, cap_r, cap_m, cap_q, cap_t, cap_k; unsigned long long cap_p; };
+
+__host__ __device__ inline unsigned long long long_ws_carve(LongWs *W, uint8_t *base, const LongSizes &z)
+{
+    unsigned long long off = 0;
+    auto take = [&](unsigned long long bytes) { uint8_t *q = base ? base + off : nullptr; off += (bytes + 255) & ~255ull; return q; };
+    const unsigned long long ca = z.cap_a, cu = z.cap_u, cr = z.cap_r, cq = z.cap_q, ct = z.cap_t, ck = z.cap_k;
+    const unsigned long long cc = 2ull * (cq + ct) + 64;
+    LongWs w{};
+    w.a = (LAnchor *)take(ca * 16); w.b = (LAnchor *)take(ca * 16);
+    w.f = (int32_t *)take(ca * 4); w.p = (int32_t *)take(ca * 4); w.t = (int32_t *)take(ca * 4); w.v = (int32_t *)take(ca * 4);
+    w.pri = (double *)take(ca * 8); w.sk = (SKey *)take(ca * 16); w.sk2 = (SKey *)take(ca * 16);
+    w.u = (uint64_t *)take(cu * 8); w.uoff = (uint32_t *)take((cu + 1) * 4);
+    w.regs = (LReg *)take(cr * sizeof(LReg)); w.cov = (uint64_t *)take(cr * 8); w.wpri = (int32_t *)take(cr * 4);
+    w.mini_pos = (uint64_t *)take((unsigned long long)z.cap_m * 8);
+    w.tbits = (uint32_t *)take((cq / 32 + 2) * 4);
+    w.K = (int32_t *)take(ca * 4);
+    w.r_cigar = (uint32_t *)take(cc * 4); w.ez_cigar = (uint32_t *)take(cc * 4);
+    w.qseq = take(2 * cq + 32); w.tseq = take(ct + 32);
+    w.kmem = take(8 * (ck + 16) + ck + 64); w.kH = (int32_t *)take((ck + 16) * 4); w.koff = (int32_t *)take(8 * (2 * ck + 32)); w.kp = take(z.cap_p);
+    w.lH = (int32_t *)take((ck + 16) * 4 * 2); w.lE = (int32_t *)take((ck + 16) * 4); w.lHmax = (int32_t *)take((ck + 16) * 4);
+    w.cap_a = z.cap_a; w.cap_u = z.cap_u; w.cap_r = z.cap_r; w.cap_m = z.cap_m; w.cap_c = (uint32_t)cc; w.cap_q = z.cap_q; w.cap_t = z.cap_t; w.cap_k = z.cap_k; w.cap_p = z.cap_p;
+    if (W) *W = w;
+    return off;
+}
+
+// ---- small helpers ---------------------------------------------------------------------------------------------------
+__device__ inline void lr_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __builtin_amdgcn_wave_barrier(); }
+__device__ inline uint64_t lr_b0_64(uint64_t v) { return al_b0_64(v); }
+__device__ inline uint64_t lr_readlane64(uint64_t v, int l)
+{
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32;
+}
+__device__ inline bool sk_less(const SKey &a, const SKey &b) { return a.k < b.k || (a.k == b.k && a.v < b.v); }
+
+// Stable-by-construction sort of n distinct (k, v) pairs, ascending, by one wave: tiles of 64 ranked in registers, then merge
+// passes in which every lane merges one slice of the output found by a merge-path search.  Result in `a` (tmp is scratch).
+__device__ inline void lr_sort(SKey *a, SKey *tmp, int32_t n)
+{
+    const int32_t lane = (int32_t)al_lane();
+    if (n < 2) return;
+    for (int32_t t0 = 0; t0 < n; t0 += 64) {       // 64-tiles: rank = number of smaller elements of the tile
+        const int32_t i = t0 + lane, m = n - t0 < 64 ? n - t0 : 64;
+        SKey e{~0ull, ~0ull};
+        if (i < n) e = a[i];
+        int32_t rank = 0;
+        for (int32_t l = 0; l < m; ++l) {
+            SKey o; o.k = lr_readlane64(e.k, l); o.v = lr_readlane64(e.v, l);
+            rank += sk_less(o, e);
+        }
+        if (i < n) tmp[t0 + rank] = e;
+    }
+    lr_sync();
+    SKey *src = tmp, *dst = a;
+    for (int32_t width = 64; width < n; width <<= 1) {
+        for (int32_t base = 0; base < n; base += 2 * width) {
+            const int32_t l0 = base, l1 = base + width < n ? base + width : n, r1 = base + 2 * width < n ? base + 2 * width : n;
+            const int32_t la = l1 - l0, lb = r1 - l1, tot = la + lb;
+            if (lb == 0) { for (int32_t i = l0 + lane; i < l1; i += 64) dst[i] = src[i]; continue; }
+            // slices of the output: lane `lane` produces [o0, o1)
+            const int32_t per = (tot + 63) / 64, o0 = lane * per < tot ? lane * per : tot, o1 = o0 + per < tot ? o0 + per : tot;
+            if (o0 < o1) {
+                // merge path: i elements of A and o0 - i of B precede the slice; A wins ties (stability is irrelevant: pairs are distinct)
+                int32_t lo = o0 - lb > 0 ? o0 - lb : 0, hi = o0 < la ? o0 : la;
+                while (lo < hi) {
+                    const int32_t mid = (lo + hi) >> 1;       // take mid from A?
+                    if (sk_less(src[l1 + (o0 - mid - 1)], src[l0 + mid])) hi = mid; else lo = mid + 1;
+                }
+                int32_t ia = lo, ib = o0 - lo;
+                for (int32_t o = o0; o < o1; ++o) {
+                    const bool ta = ib >= lb || (ia < la && !sk_less(src[l1 + ib], src[l0 + ia]));
+                    dst[l0 + o] = ta ? src[l0 + ia] : src[l1 + ib];
+                    if (ta) ++ia; else ++ib;
+                }
+            }
+        }
+        lr_sync();
+        SKey *x = src; src = dst; dst = x;
+    }
+    if (src != a) { for (int32_t i = lane; i < n; i += 64) a[i] = src[i]; lr_sync(); }
+}
+
+// ---- hashing, coordinates (hit.c) --------------------------------------------------------------------------------------
+__device__ inline void lr_reg_set_coor(LReg &r, int32_t qlen, const LAnchor *a)
+{   // mm_reg_set_coor + mm_cal_fuzzy_len
+    const int32_t k = r.as, q_span = (int32_t)(a[k].y >> 32 & 0xff);
+    r.rev = (int32_t)(a[k].x >> 63);
+    r.rid = (int32_t)(a[k].x << 1 >> 33);
+    r.rs = (int32_t)a[k].x + 1 > q_span ? (int32_t)a[k].x + 1 - q_span : 0;
+    r.re = (int32_t)a[k + r.cnt - 1].x + 1;
+    if (!r.rev) { r.qs = (int32_t)a[k].y + 1 - q_span; r.qe = (int32_t)a[k + r.cnt - 1].y + 1; }
+    else { r.qs = qlen - ((int32_t)a[k + r.cnt - 1].y + 1); r.qe = qlen - ((int32_t)a[k].y + 1 - q_span); }
+    r.mlen = r.blen = 0;
+    if (r.cnt <= 0) return;
+    r.mlen = r.blen = q_span;
+    for (int32_t i = r.as + 1; i < r.as + r.cnt; ++i) {
+        const int32_t span = (int32_t)(a[i].y >> 32 & 0xff);
+        const int32_t tl = (int32_t)a[i].x - (int32_t)a[i - 1].x, ql = (int32_t)a[i].y - (int32_t)a[i - 1].y;
+        r.blen += tl > ql ? tl : ql;
+        r.mlen += tl > span && ql > span ? span : tl < ql ? tl : ql;
+    }
+}
+
+// ---- mg_lchain_rmq on one wave -------------------------------------------------------------------------------------------
+// Upstream keeps the look-back window in two balanced trees keyed by (y, i) (oracle/mm_rmq.c).  What the trees are asked:
+//   (1) the element of smallest priority -(f + 0.5 * pen_gap * (x + y)) among the active anchors with y in the query interval;
+//   (2) the active anchors of the inner window in descending (y, i) order from just below y_i.
+// Here (1) is a wave-wide scan over the active range [st, i0) of the x-sorted anchors with an arg-min reduction, and (2) walks a
+// y-sorted copy of the inner window kept in LDS.  With distinct priorities the answers are the trees'; when the minimum is shared by
+// two candidates the tree's choice depends on its shape, which this scan does not have: such reads are reported (*tie) and the
+// caller sends them down the exact serial path.
+#define LRQ_INNER 1024          // active anchors of the inner window kept y-sorted in LDS
+struct RmqLds { int32_t iy[LRQ_INNER]; int32_t ij[LRQ_INNER]; };
+
+__device__ inline int32_t lr_sc_simple(uint64_t xi, uint64_t yi, uint64_t xj, uint64_t yj, float pen_gap, float pen_skip, int32_t &exact, int32_t &width)
+{   // comput_sc_simple
+    const int32_t dq = (int32_t)yi - (int32_t)yj, dr = (int32_t)(xi - xj);
+    const int32_t dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq, q_span = (int32_t)(yj >> 32 & 0xff);
+    int32_t sc = q_span < dg ? q_span : dg;
+    width = dd;
+    exact = (dd == 0 && dg <= q_span);
+    if (dd || dq > q_span) {
+        const float lin_pen = pen_gap * (float)dd + pen_skip * (float)dg;
+        const float log_pen = dd >= 1 ? al_mg_log2((float)(dd + 1)) : 0.0f;
+        sc -= (int32_t)(lin_pen + .5f * log_pen);
+    }
+    return sc;
+}
+
+// a[] sorted by x.  Out: f, p (int32; -1 = none).  t: scratch marks, zeroed here.  n_tie: steps whose minimum priority was shared (the
+// smallest index was taken; upstream's tree may pick another).  Returns false when the inner window outgrows LRQ_INNER or the read has
+// more anchors than rmq_size_cap.
+__device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int32_t bw, int32_t n, const LAnchor *a, int32_t *f, int32_t *p, int32_t *t,
+                                   double *pri, RmqLds &L, int32_t &n_tie)
+{
+    n_tie = 0;
+    const int32_t lane = (int32_t)al_lane();
+    int32_t max_dist = max_dist_in, max_dist_inner = P.rmq_inner_dist;
+    if (max_dist < bw) max_dist = bw;
+    if (max_dist_inner < 0) max_dist_inner = 0;
+    if (max_dist_inner > max_dist) max_dist_inner = max_dist;
+    if (n > P.rmq_size_cap) return false;          // the size cap evicts out of order: serial path
+    for (int32_t i = lane; i < n; i += 64) t[i] = 0;
+    lr_sync();
+    int32_t i0 = 0, st = 0, st_inner = 0, n_in = 0;      // inner window: L.iy/ij[0 .. n_in) ascending (y, j)
+    bool ok = true;
+    for (int32_t i = 0; i < n && ok; ++i) {
+        const uint64_t xi = a[i].x, yi = a[i].y;
+        const int32_t qi = (int32_t)yi;
+        // add the anchors whose x is now strictly smaller
+        if (i0 < i && a[i0].x != xi) {
+            for (int32_t jb = i0; jb < i; jb += 64) {
+                const int32_t j = jb + lane;
+                if (j < i) pri[j] = -((double)f[j] + 0.5 * (double)P.pen_gap * (double)((int32_t)a[j].x + (int32_t)a[j].y));
+            }
+            if (max_dist_inner > 0) {
+                for (int32_t j = i0; j < i; ++j) {      // insert (y_j, j) into the y-sorted inner window
+                    if (n_in >= LRQ_INNER) { ok = false; break; }
+                    const int32_t yj = (int32_t)a[j].y;
+                    // position: first element greater than (yj, j); j is the largest index so far: behind every equal y
+                    int32_t pos = 0;
+                    for (int32_t c = 0; c < n_in; c += 64) { const int32_t e = c + lane; pos += (int32_t)__popcll(__ballot(e < n_in && L.iy[e] <= yj)); }
+                    for (int32_t c = ((n_in - pos + 63) / 64 - 1) * 64; c >= 0; c -= 64) {      // shift [pos, n_in) up by one, from the top
+                        const int32_t e = pos + c + lane;
+                        int32_t vy = 0, vj = 0;
+                        const bool on = e < n_in;
+                        if (on) { vy = L.iy[e]; vj = L.ij[e]; }
+                        __builtin_amdgcn_wave_barrier();
+                        if (on) { L.iy[e + 1] = vy; L.ij[e + 1] = vj; }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    if (lane == 0) { L.iy[pos] = yj; L.ij[pos] = j; }
+                    __builtin_amdgcn_wave_barrier();
+                    ++n_in;
+                }
+                if (!ok) break;
+            }
+            i0 = i;
+            lr_sync();
+        }
+        // anchors out of range leave
+        while (st < i && (xi >> 32 != a[st].x >> 32 || xi > a[st].x + (uint64_t)max_dist)) ++st;
+        if (max_dist_inner > 0) {
+            const int32_t st_old = st_inner;
+            while (st_inner < i && (xi >> 32 != a[st_inner].x >> 32 || xi > a[st_inner].x + (uint64_t)max_dist_inner)) ++st_inner;
+            if (st_inner > st_old && n_in > 0) {      // drop the elements with j < st_inner (those that were inserted: j < i0): compaction in order
+                int32_t kept = 0;
+                for (int32_t c = 0; c < n_in; c += 64) {
+                    const int32_t e = c + lane;
+                    int32_t vy = 0, vj = 0;
+                    const bool on = e < n_in;
+                    if (on) { vy = L.iy[e]; vj = L.ij[e]; }
+                    const bool keep = on && vj >= st_inner;
+                    const uint64_t km = __ballot(keep);
+                    __builtin_amdgcn_wave_barrier();
+                    if (keep) { const int32_t d = kept + (int32_t)prefix_popc64(km); L.iy[d] = vy; L.ij[d] = vj; }
+                    __builtin_amdgcn_wave_barrier();
+                    kept += (int32_t)__popcll(km);
+                }
+                n_in = kept;
+            }
+        }
+        int32_t max_f = (int32_t)(yi >> 32 & 0xff), max_j = -1;
+        // (1) range minimum of the priority over the active anchors [st, i0) with (y_j, j) in [(q_i - max_dist, INT32_MAX), (q_i, 0)]
+        double bp = 0.0; int32_t bj = -1, ties = 0;
+        {
+            double mp = 0.0; int32_t mj = -1;
+            for (int32_t jb = st; jb < i0; jb += 64) {
+                const int32_t j = jb + lane;
+                if (j < i0) {
+                    const int32_t yj = (int32_t)a[j].y;
+                    const bool in = yj > qi - max_dist && (yj < qi || (yj == qi && j == 0));
+                    if (in) { const double pj = pri[j]; if (mj < 0 || pj < mp) { mp = pj; mj = j; } }      // within a lane ties keep the first: counted below
+                }
+            }
+            // wave arg-min; equal priorities are counted over the whole window in a second sweep only when the minimum is found
+            double wm = mp; int32_t wj = mj;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double om = __shfl_xor(wm, o); const int32_t oj = __shfl_xor(wj, o);
+                if (oj >= 0 && (wj < 0 || om < wm || (om == wm && oj < wj))) { wm = om; wj = oj; }
+            }
+            bp = wm; bj = wj;
+            if (bj >= 0) {
+                for (int32_t jb = st; jb < i0; jb += 64) {
+                    const int32_t j = jb + lane;
+                    bool eq = false;
+                    if (j < i0) {
+                        const int32_t yj = (int32_t)a[j].y;
+                        const bool in = yj > qi - max_dist && (yj < qi || (yj == qi && j == 0));
+                        eq = in && pri[j] == bp;
+                    }
+                    ties += (int32_t)__popcll(__ballot(eq));
+                }
+            }
+        }
+        if (bj >= 0) {
+            if (ties > 1) ++n_tie;      // the smallest index among the equal priorities is taken; the caller reports the read
+            int32_t exact, width, n_skip = 0;
+            int32_t sc = f[bj] + lr_sc_simple(xi, yi, a[bj].x, a[bj].y, P.pen_gap, P.pen_skip, exact, width);
+            if (width <= bw && sc > max_f) { max_f = sc; max_j = bj; }
+            if (!exact && n_in > 0 && qi > 0) {
+                // (2) the inner window from the largest (y, j) <= (q_i - 1, n) downwards, while y >= q_i - max_dist_inner
+                int32_t top = 0;      // number of elements with y <= q_i - 1
+                for (int32_t c = 0; c < n_in; c += 64) { const int32_t e = c + lane; top += (int32_t)__popcll(__ballot(e < n_in && L.iy[e] <= qi - 1)); }
+                for (int32_t eb = top - 1; eb >= 0; eb -= 64) {
+                    const int32_t e = eb - lane;
+                    const bool valid = e >= 0 && L.iy[e] >= qi - max_dist_inner;
+                    const uint64_t vm = __ballot(valid);
+                    if (vm == 0) break;
+                    int32_t j = -1, scj = INT32_MIN, pj = -1;
+                    bool has = false;
+                    if (valid) {
+                        j = L.ij[e];
+                        int32_t ex2, w2;
+                        scj = f[j] + lr_sc_simple(xi, yi, a[j].x, a[j].y, P.pen_gap, P.pen_skip, ex2, w2);
+                        has = w2 <= bw;
+                        pj = p[j];
+                    }
+                    if (has && pj >= 0) t[pj] = i;
+                    lr_sync();
+                    const bool is_t = has && t[j] == i;
+                    const int32_t scv = has ? scj : INT32_MIN;
+                    const int32_t incl = wave_scan_max_incl(scv);
+                    int32_t excl = wave_shr1(incl, INT32_MIN);
+                    if (excl < max_f) excl = max_f;
+                    const bool new_max = has && scj > excl;
+                    const bool inc_ev = has && !new_max && is_t;
+                    const uint64_t inc_m = __ballot(inc_ev), nm_m = __ballot(new_max);
+                    const int32_t yl = n_skip + (int32_t)prefix_popc64(inc_m) + (inc_ev ? 1 : 0) - (int32_t)prefix_popc64(nm_m) - (new_max ? 1 : 0);
+                    const int32_t mn = wave_scan_min_incl(yl);
+                    const int32_t val = yl - (mn < 0 ? mn : 0);
+                    const uint64_t brk = __ballot(inc_ev && val > P.max_skip);
+                    // the scan also ends at the first element below the y range (valid is a prefix of the lanes: the window is sorted)
+                    const int nv = (int)__popcll(vm);
+                    int Lb = brk ? __ffsll((unsigned long long)brk) - 1 : 63;
+                    if (Lb > nv - 1) Lb = nv - 1;
+                    const int32_t mm = __builtin_amdgcn_readlane(incl, Lb);
+                    if (mm > max_f) {
+                        max_f = mm;
+                        const uint64_t eq = __ballot(lane <= Lb && scv == mm);
+                        max_j = __builtin_amdgcn_readlane(j, (int)(__ffsll((unsigned long long)eq) - 1));
+                    }
+                    n_skip = __builtin_amdgcn_readlane(val, Lb);
+                    if ((brk && (__ffsll((unsigned long long)brk) - 1) <= nv - 1) || nv < 64) break;
+                }
+            }
+        }
+        if (lane == 0) { f[i] = max_f; p[i] = max_j; }
+        lr_sync();
+    }
+    return ok;
+}
+
+// ---- mg_chain_backtrack (lane 0) -----------------------------------------------------------------------------------------
+// zc: candidates (f << 32 | index) with f >= min_sc, sorted ascending.  Chains into u (score << 32 | cnt) and v (anchor indices,
+// each chain from its end backwards).  Returns n_u; n_v through the reference.
+__device__ inline int32_t lr_backtrack0(const SKey *zc, int32_t n_z, const int32_t *f, const int32_t *p, int32_t *t, int32_t *v, uint64_t *u, uint32_t cap_u,
+                                        int32_t min_cnt, int32_t min_sc, int32_t max_drop, int32_t &n_v_out, int32_t &best_out, bool &ovf)
+{
+    int32_t n_u = 0, n_v = 0, best = 0;
+    for (int32_t k = n_z - 1; k >= 0; --k) {
+        const int32_t zi = (int32_t)zc[k].v, zf = (int32_t)zc[k].k;
+        if (t[zi] != 0) continue;
+        // mg_chain_bk_end
+        int32_t end_i;
+        {
+            int32_t i = zi, e = -1, max_i = i, max_s = 0;
+            do {
+                t[i] = 2;
+                e = i = p[i];
+                const int32_t s = i < 0 ? zf : zf - f[i];
+                if (s > max_s) { max_s = s; max_i = i; }
+                else if (max_s - s > max_drop) break;
+            } while (i >= 0 && t[i] == 0);
+            for (i = zi; i >= 0 && i != e; i = p[i]) t[i] = 0;
+            end_i = max_i;
+        }
+        const int32_t n_v0 = n_v;
+        int32_t i;
+        for (i = zi; i != end_i; i = p[i]) { v[n_v++] = i; t[i] = 1; }
+        const int32_t sc = i < 0 ? zf : zf - f[i];
+        if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt) {
+            if ((uint32_t)n_u >= cap_u) { ovf = true; break; }
+            u[n_u++] = (uint64_t)(uint32_t)sc << 32 | (uint32_t)(n_v - n_v0);
+            if (sc > best) best = sc;
+        } else n_v = n_v0;
+    }
+    n_v_out = n_v; best_out = best;
+    return n_u;
+}
+
+// ---- region bookkeeping on lane 0 (hit.c) ------------------------------------------------------------------------------------
+__device__ inline void lr_set_parent0(float mask_level, int32_t n, LReg *r, uint64_t *cov, int32_t *w)
+{
+    if (n <= 0) return;
+    for (int32_t i = 0; i < n; ++i) r[i].id = i;
+    w[0] = 0; r[0].parent = 0;
+    int32_t k = 1;
+    for (int32_t i = 1; i < n; ++i) {
+        LReg *ri = &r[i];
+        const int32_t si = ri->qs, ei = ri->qe;
+        int32_t n_cov = 0, uncov_len = 0, j;
+        for (j = 0; j < k; ++j) {
+            const LReg *rp = &r[w[j]];
+            int32_t sj = rp->qs, ej = rp->qe;
+            if (ej <= si || sj >= ei) continue;
+            if (sj < si) sj = si;
+            if (ej > ei) ej = ei;
+            cov[n_cov++] = (uint64_t)(uint32_t)sj << 32 | (uint32_t)ej;
+        }
+        if (n_cov > 0) {
+            for (int32_t a1 = 1; a1 < n_cov; ++a1) { const uint64_t tt = cov[a1]; int32_t b1 = a1; for (; b1 > 0 && cov[b1 - 1] > tt; --b1) cov[b1] = cov[b1 - 1]; cov[b1] = tt; }
+            int32_t x = si;
+            for (j = 0; j < n_cov; ++j) {
+                if ((int32_t)(cov[j] >> 32) > x) uncov_len += (int32_t)(cov[j] >> 32) - x;
+                x = (int32_t)cov[j] > x ? (int32_t)cov[j] : x;
+            }
+            if (ei > x) uncov_len += ei - x;
+            for (j = 0; j < k; ++j) {
+                LReg *rp = &r[w[j]];
+                const int32_t sj = rp->qs, ej = rp->qe;
+                if (ej <= si || sj >= ei) continue;
+                const int32_t mn = ej - sj < ei - si ? ej - sj : ei - si, mx = ej - sj > ei - si ? ej - sj : ei - si;
+                const int32_t ol = si < sj ? (ei < sj ? 0 : ei < ej ? ei - sj : ej - sj) : (ej < si ? 0 : ej < ei ? ej - si : ei - si);
+                if ((float)ol / mn - (float)uncov_len / mx > mask_level) {
+                    ri->parent = rp->parent;
+                    rp->subsc = rp->subsc > ri->score ? rp->subsc : ri->score;
+                    if (ri->cnt >= rp->cnt) ++rp->n_sub;
+                    break;
+                }
+            }
+        } else j = k;
+        if (j == k) { w[k++] = i; ri->parent = i; ri->n_sub = 0; }
+    }
+}
+
+__device__ inline void lr_sync_regs0(int32_t n_regs, LReg *regs, int32_t *tmp)
+{   // mm_sync_regs; tmp: max id + 1 ints
+    if (n_regs <= 0) return;
+    int32_t max_id = -1;
+    for (int32_t i = 0; i < n_regs; ++i) max_id = max_id > regs[i].id ? max_id : regs[i].id;
+    for (int32_t i = 0; i <= max_id; ++i) tmp[i] = -1;
+    for (int32_t i = 0; i < n_regs; ++i) if (regs[i].id >= 0) tmp[regs[i].id] = i;
+    for (int32_t i = 0; i < n_regs; ++i) {
+        LReg *r = &regs[i];
+        r->id = i;
+        if (r->parent == LR_PARENT_TMP_PRI) r->parent = i;
+        else if (r->parent >= 0 && tmp[r->parent] >= 0) r->parent = tmp[r->parent];
+        else r->parent = LR_PARENT_UNSET;
+    }
+}
+
+__device__ inline int32_t lr_select_sub0(float pri_ratio, int32_t min_diff, int32_t best_n, int32_t min_strand_sc, int32_t n, LReg *r, int32_t *tmp)
+{   // in place like upstream: r[p] is read after earlier regions moved up
+    if (!(pri_ratio > 0.0f) || n <= 0) return n;
+    int32_t k = 0, n_2nd = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        const int32_t p = r[i].parent;
+        if (p == i || r[i].inv) r[k++] = r[i];
+        else if ((r[i].score >= r[p].score * pri_ratio || r[i].score + min_diff >= r[p].score) && n_2nd < best_n) {
+            if (!(r[i].qs == r[p].qs && r[i].qe == r[p].qe && r[i].rid == r[p].rid && r[i].rs == r[p].rs && r[i].re == r[p].re)) { r[k++] = r[i]; ++n_2nd; }
+        } else if (n_2nd < best_n && r[i].score > min_strand_sc && r[p].rev != r[i].rev && r[p].rid == r[i].rid && r[i].rs < r[p].re && r[i].re > r[p].rs) {
+            r[i].strand_retained = 1;
+            r[k++] = r[i]; ++n_2nd;
+        }
+    }
+    if (k != n) lr_sync_regs0(k, r, tmp);
+    return k;
+}
+
+__device__ inline int32_t lr_get_for_qpos(int32_t qlen, const LAnchor &a)
+{
+    int32_t x = (int32_t)a.y;
+    const int32_t q_span = (int32_t)(a.y >> 32 & 0xff);
+    if (a.x >> 63) x = qlen - 1 - (x + 1 - q_span);
+    return x;
+}
+
+__device__ inline void lr_est_err0(int32_t qlen, int32_t n_regs, LReg *regs, const LAnchor *a, int32_t n, const uint64_t *mini_pos, const uint64_t *cstart)
+{
+    if (n == 0) return;
+    uint64_t sum_k = 0;
+    for (int32_t i = 0; i < n; ++i) sum_k += mini_pos[i] >> 32 & 0xff;
+    const float avg_k = (float)sum_k / n;
+    for (int32_t i = 0; i < n_regs; ++i) {
+        LReg *r = &regs[i];
+        r->div = -1.0f;
+        if (r->cnt == 0) continue;
+        int32_t st;
+        {   // get_mini_idx
+            const int32_t x = lr_get_for_qpos(qlen, r->rev ? a[r->as + r->cnt - 1] : a[r->as]);
+            int32_t L = 0, R = n - 1;
+            st = -1;
+            while (L <= R) {
+                const int32_t m = (int32_t)(((uint64_t)L + (uint64_t)R) >> 1);
+                const int32_t y = (int32_t)mini_pos[m];
+                if (y < x) L = m + 1;
+                else if (y > x) R = m - 1;
+                else { st = m; break; }
+            }
+        }
+        if (st < 0) continue;
+        int32_t en = st, k, j, n_match;
+        const int32_t l_ref = (int32_t)(cstart[r->rid + 1] - cstart[r->rid]);
+        for (k = 1, j = st + 1, n_match = 1; j < n && k < r->cnt; ++j) {
+            const int32_t q = lr_get_for_qpos(qlen, r->rev ? a[r->as + r->cnt - 1 - k] : a[r->as + k]);
+            if (q == (int32_t)mini_pos[j]) { ++k; en = j; ++n_match; }
+        }
+        int32_t n_tot = en - st + 1;
+        if (r->qs > avg_k && r->rs > avg_k) ++n_tot;
+        if (qlen - r->qe > avg_k && l_ref - r->re > avg_k) ++n_tot;
+        r->div = n_match >= n_tot ? 0.0f : (float)(1.0 - pow((double)n_match / n_tot, 1.0 / avg_k));
+    }
+}
+
+__device__ inline int32_t lr_filter_strand0(int32_t n_regs, LReg *r)
+{
+    int32_t k = 0;
+    for (int32_t i = 0; i < n_regs; ++i) {
+        const int32_t p = r[i].parent;
+        if (!r[i].strand_retained || r[i].div < r[p].div * 5.0f || r[i].div < 0.01f) {
+            if (k < i) r[k++] = r[i];
+            else ++k;
+        }
+    }
+    return k;
+}
+
+// ---- mm_align1's anchor filters (lane 0) ---------------------------------------------------------------------------------------
+__device__ inline void lr_fix_bad_ends0(const LReg &r, const LAnchor *a, int32_t bw, int32_t min_match, int32_t &as_o, int32_t &cnt_o)
+{
+    int32_t as = r.as, cnt = r.cnt;
+    if (r.cnt >= 3) {
+        int32_t i, l, m;
+        m = l = (int32_t)(a[r.as].y >> 32 & 0xff);
+        for (i = r.as + 1; i < r.as + r.cnt - 1; ++i) {
+            const int32_t q_span = (int32_t)(a[i].y >> 32 & 0xff);
+            if (a[i].y & LY_LONG_JOIN) break;
+            const int32_t lr = (int32_t)a[i].x - (int32_t)a[i - 1].x, lq = (int32_t)a[i].y - (int32_t)a[i - 1].y;
+            const int32_t mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
+            if (mx - mn > l >> 1) as = i;
+            l += mn;
+            m += mn < q_span ? mn : q_span;
+            if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r.mlen >> 1) break;
+        }
+        cnt = r.as + r.cnt - as;
+        m = l = (int32_t)(a[r.as + r.cnt - 1].y >> 32 & 0xff);
+        for (i = r.as + r.cnt - 2; i > as; --i) {
+            const int32_t q_span = (int32_t)(a[i + 1].y >> 32 & 0xff);
+            if (a[i + 1].y & LY_LONG_JOIN) break;
+            const int32_t lr = (int32_t)a[i + 1].x - (int32_t)a[i].x, lq = (int32_t)a[i + 1].y - (int32_t)a[i].y;
+            const int32_t mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
+            if (mx - mn > l >> 1) cnt = i + 1 - as;
+            l += mn;
+            m += mn < q_span ? mn : q_span;
+            if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r.mlen >> 1) break;
+        }
+    }
+    as_o = as; cnt_o = cnt;
+}
+
+__device__ inline int32_t lr_gap_at(const LAnchor *a, int32_t i)
+{
+    return (int32_t)((uint32_t)a[i].y - (uint32_t)a[i - 1].y - ((uint32_t)a[i].x - (uint32_t)a[i - 1].x));
+}
+
+__device__ inline int32_t lr_collect_long_gaps0(int32_t as1, int32_t cnt1, const LAnchor *a, int32_t min_gap, int32_t *K)
+{
+    int32_t n = 0;
+    for (int32_t i = 1; i < cnt1; ++i) {
+        const int32_t gap = lr_gap_at(a, as1 + i);
+        if (gap < -min_gap || gap > min_gap) K[n++] = i;
+    }
+    return n <= 1 ? 0 : n;
+}
+
+__device__ inline void lr_filter_bad_seeds0(int32_t as1, int32_t cnt1, LAnchor *a, int32_t min_gap, int32_t diff_thres, int32_t max_ext_len, int32_t max_ext_cnt, int32_t *K)
+{
+    const int32_t n = lr_collect_long_gaps0(as1, cnt1, a, min_gap, K);
+    if (n == 0) return;
+    int32_t max = 0, max_st = -1, max_en = -1;
+    for (int32_t k = 0;; ++k) {
+        int32_t gap, l, n_ins = 0, n_del = 0, qs, rs, max_diff = 0, max_diff_l = -1, i;
+        if (k == n || k >= max_en) {
+            if (max_en > 0) for (i = K[max_st]; i < K[max_en]; ++i) a[as1 + i].y |= LY_IGNORE;
+            max = 0; max_st = max_en = -1;
+            if (k == n) break;
+        }
+        i = K[k];
+        gap = lr_gap_at(a, as1 + i);
+        if (gap > 0) n_ins += gap; else n_del += -gap;
+        qs = (int32_t)a[as1 + i - 1].y;
+        rs = (int32_t)a[as1 + i - 1].x;
+        for (l = k + 1; l < n && l <= k + max_ext_cnt; ++l) {
+            const int32_t j = K[l];
+            if ((int32_t)a[as1 + j].y - qs > max_ext_len || (int32_t)a[as1 + j].x - rs > max_ext_len) break;
+            gap = lr_gap_at(a, as1 + j);
+            if (gap > 0) n_ins += gap; else n_del += -gap;
+            const int32_t ad = n_ins - n_del < 0 ? n_del - n_ins : n_ins - n_del;
+            const int32_t diff = n_ins + n_del - ad;
+            if (max_diff < diff) { max_diff = diff; max_diff_l = l; }
+        }
+        if (max_diff > diff_thres && max_diff > max) { max = max_diff; max_st = k; max_en = max_diff_l; }
+    }
+}
+
+__device__ inline void lr_filter_bad_seeds_alt0(int32_t as1, int32_t cnt1, LAnchor *a, int32_t min_gap, int32_t max_ext, int32_t *K)
+{
+    const int32_t n = lr_collect_long_gaps0(as1, cnt1, a, min_gap, K);
+    if (n == 0) return;
+    for (int32_t k = 0; k < n;) {
+        const int32_t i = K[k];
+        int32_t l;
+        int32_t gap1 = lr_gap_at(a, as1 + i);
+        int32_t re1 = (int32_t)a[as1 + i].x, qe1 = (int32_t)a[as1 + i].y;
+        gap1 = gap1 > 0 ? gap1 : -gap1;
+        for (l = k + 1; l < n; ++l) {
+            const int32_t j = K[l];
+            if ((int32_t)a[as1 + j].y - qe1 > max_ext || (int32_t)a[as1 + j].x - re1 > max_ext) break;
+            int32_t gap2 = lr_gap_at(a, as1 + j);
+            const int32_t q_span_pre = (int32_t)(a[as1 + j - 1].y >> 32 & 0xff);
+            const int32_t rs2 = (int32_t)a[as1 + j - 1].x + q_span_pre, qs2 = (int32_t)a[as1 + j - 1].y + q_span_pre;
+            const int32_t m = rs2 - re1 < qs2 - qe1 ? rs2 - re1 : qs2 - qe1;
+            gap2 = gap2 > 0 ? gap2 : -gap2;
+            if (m > gap1 + gap2) break;
+            re1 = (int32_t)a[as1 + j].x; qe1 = (int32_t)a[as1 + j].y;
+            gap1 = gap2;
+        }
+        if (l > k + 1) {
+            const int32_t end = K[l - 1];
+            for (int32_t j = K[k]; j < end; ++j) a[as1 + j].y |= LY_IGNORE;
+            a[as1 + end].y |= LY_LONG_JOIN;
+        }
+        k = l;
+    }
+}
+
+// ---- ksw_ll_i16 on one wave: local alignment, rows of the target one after the other, the columns across the lanes ----------------------
+// H(i,j) = max(0, H(i-1,j-1) + s, E(i,j), F(i,j)); E(i+1,j) = max(0, E(i,j) - e, H(i,j) - (o + e)); F along a row likewise.  F is the
+// only dependency inside a row: F(j) = max(0, max_{j' < j}(H'(j') - (o + e) - (j - 1 - j') * e)) with H' = max(diag, E) - a prefix
+// maximum of H'(j') + j' * e.  The query is padded to a multiple of 8 with columns scoring 0, as the striped profile pads it; te / qe
+// are the LAST row reaching the maximum and the LAST column (in striped memory order) holding it there (oracle mma_ksw_ll).
+__device__ inline int32_t lr_ksw_ll_wave(int32_t qlen, const uint8_t *query, int32_t tlen, const uint8_t *target, int8_t sc_mch, int8_t sc_mis, int8_t sc_amb,
+                                         int32_t gapo, int32_t gape, int32_t &qe, int32_t &te, int32_t *H0, int32_t *E, int32_t *Hmax)
+{
+    const int32_t lane = (int32_t)al_lane();
+    const int32_t slen = (qlen + 7) / 8, qp = slen * 8, gapoe = gapo + gape;
+    qe = te = -1;
+    if (qlen <= 0) return 0;
+    int32_t *H1 = H0 + qp + 8;
+    for (int32_t j = lane; j < qp; j += 64) { H0[j] = 0; E[j] = 0; Hmax[j] = 0; }
+    lr_sync();
+    int32_t gmax = 0;
+    for (int32_t i = 0; i < tlen; ++i) {
+        const int32_t tb = target[i];
+        int32_t imax = 0, fcarry = INT32_MIN / 2;      // max over earlier chunks of (H'(j') - gapoe + j' * gape), "minus infinity" = F of 0
+        for (int32_t jb = 0; jb < qp; jb += 64) {
+            const int32_t j = jb + lane;
+            const bool on = j < qp;
+            int32_t hp = 0, fsrc = INT32_MIN / 2;
+            if (on) {
+                const int32_t hd = j > 0 ? H0[j - 1] : 0;
+                int32_t s = 0;
+                if (j < qlen) { const int32_t qb = query[j]; s = (tb > 3 || qb > 3) ? sc_amb : (tb == qb ? sc_mch : sc_mis); }
+                const int32_t e = E[j];
+                hp = hd + s; hp = hp > e ? hp : e;      // H' >= 0 because E >= 0
+                fsrc = hp - gapoe + j * gape;
+            }
+            // exclusive prefix maximum of fsrc over the lanes, seeded with the carry
+            int32_t incl = wave_scan_max_incl(fsrc);
+            int32_t excl = wave_shr1(incl, INT32_MIN / 2);
+            if (excl < fcarry) excl = fcarry;
+            fcarry = __builtin_amdgcn_readlane(incl, 63) > fcarry ? __builtin_amdgcn_readlane(incl, 63) : fcarry;
+            if (on) {
+                int32_t fj = excl - (j - 1) * gape;      // F(j) = max_{j'<j}(H'(j') - gapoe - (j - 1 - j') * gape)
+                if (fj < 0) fj = 0;
+                const int32_t h = hp > fj ? hp : fj;
+                imax = imax > h ? imax : h;
+                H1[j] = h;
+                int32_t tt = h - gapoe; if (tt < 0) tt = 0;
+                int32_t e = E[j] - gape; if (e < 0) e = 0;
+                E[j] = e > tt ? e : tt;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int32_t ot = __shfl_xor(imax, o); imax = ot > imax ? ot : imax; }
+        lr_sync();
+        if (imax >= gmax) {
+            gmax = imax; te = i;
+            for (int32_t j = lane; j < qp; j += 64) Hmax[j] = H1[j];
+        }
+        { int32_t *S = H1; H1 = H0; H0 = S; }
+        lr_sync();
+    }
+    {   // the last hit in striped memory order: memory index m <-> position m / 8 + m % 8 * slen
+        int32_t best_m = -1;
+        for (int32_t m = lane; m < qp; m += 64) { const int32_t pos = m / 8 + m % 8 * slen; if (Hmax[pos] == gmax) best_m = m; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int32_t ot = __shfl_xor(best_m, o); best_m = ot > best_m ? ot : best_m; }
+        if (best_m >= 0) qe = best_m / 8 + best_m % 8 * slen;
+    }
+    return gmax;
+}
+
+// ---- mm_align1 without MM_F_SR (align.c), one region -------------------------------------------------------------------------------
+struct LongIn {
+    AlignIn in;                      // reference, reads, the chains handed over
+    const uint4 *rec; const uint32_t *k1info; const unsigned long long *seed_off; uint32_t seed_cap;      // the reads' seed records
+};
+
+struct LongCtx {
+    const LongParams *P; const AlignParams *AP; const LongIn *I; LongWs *W; AlignLds *Ls; AlignScratch A;
+    int32_t qlen; uint32_t read;
+    int8_t sc_mch, sc_mis, sc_amb, sc_N;
+    bool need_big;                   // an alignment does not fit this wave's direction-byte buffer: the read goes to the large-scratch pass
+    uint32_t err;                    // a capacity of the working memory was exceeded (code)
+};
+
+// mm_align_pair: false = the caller must stop (need_big / err set)
+__device__ inline bool lr_align_pair(LongCtx &C, int32_t qlen, const uint8_t *qseq, int32_t tlen, const uint8_t *tseq, int32_t w, int32_t end_bonus, int32_t zdrop, int32_t flag, Ez &ez)
+{
+    const LongParams &P = *C.P;
+    if ((long long)tlen * qlen > 100000000ll) { ez_reset(ez); ez.zdropped = 1; return true; }      // max_sw_mat
+    if (qlen <= 0 || tlen <= 0) { ez_reset(ez); return true; }
+    const int32_t ww = w < 0 ? (tlen > qlen ? tlen : qlen) : w;
+    int32_t nc = qlen < tlen ? qlen : tlen;
+    nc = (((nc < ww + 1 ? nc : ww + 1) + 15) / 16 + 1) * 16;
+    const unsigned long long p_need = (unsigned long long)(qlen + tlen - 1) * (unsigned long long)nc;
+    if ((uint32_t)tlen + 16 > C.W->cap_k || (uint32_t)qlen + 16 > C.W->cap_k) { C.err = 11; return false; }
+    if (p_need > C.W->cap_p) { C.need_big = true; return false; }
+    const int32_t T16 = (tlen + 15) / 16 * 16, Q16 = (qlen + 15) / 16 * 16;
+    const bool mem_lds = T16 <= AL_T16 && Q16 <= AL_Q16;
+    if (mem_lds) ksw_extd2_core<false, true>(qlen, qseq, false, tlen, tseq, false, C.sc_mch, C.sc_mis, C.sc_N, P.q, P.e, P.q2, P.e2, w, zdrop, end_bonus, flag, ez, C.W->ez_cigar, C.A, *C.Ls);
+    else ksw_extd2_core<true, true>(qlen, qseq, false, tlen, tseq, false, C.sc_mch, C.sc_mis, C.sc_N, P.q, P.e, P.q2, P.e2, w, zdrop, end_bonus, flag, ez, C.W->ez_cigar, C.A, *C.Ls);
+    lr_sync();
+    return true;
+}
+
+__device__ inline void lr_getseq(const LongCtx &C, int32_t rid, int32_t st, int32_t en, uint8_t *out)
+{
+    getseq_wave(C.I->in, rid, st, en, out);
+    lr_sync();
+}
+
+__device__ inline void lr_seq_rev(int32_t len, uint8_t *seq)
+{
+    lr_sync();
+    seq_rev_wave(len, seq, false);
+    lr_sync();
+}
+
+// mm_test_zdrop, long-read form (uniform): 0, 1 (z-drop), 2 (z-drop over a stretch that aligns to its own reverse complement)
+__device__ inline int32_t lr_test_zdrop(LongCtx &C, const uint8_t *qseq, const uint8_t *tseq, int32_t n_cigar, const uint32_t *cigar)
+{
+    const LongParams &P = *C.P;
+    int32_t res[6] = {0, 0, 0, 0, 0, 0};      // max_zdrop, pos[0][0], pos[0][1], pos[1][0], pos[1][1]
+    if (al_lane() == 0) {
+        int32_t score = 0, max = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
+        int32_t p00 = -1, p01 = -1, p10 = -1, p11 = -1;
+        auto upd = [&](int32_t sc, int32_t ii, int32_t jj) {
+            if (sc < max) {
+                const int32_t li = ii - max_i, lj = jj - max_j, diff = li > lj ? li - lj : lj - li, z = max - sc - diff * P.e;
+                if (z > max_zdrop) { max_zdrop = z; p00 = max_i; p01 = max_j; p10 = ii; p11 = jj; }
+            } else { max = sc; max_i = ii; max_j = jj; }
+        };
+        for (int32_t k = 0; k < n_cigar; ++k) {
+            const uint32_t op = cigar[k] & 0xf, len = cigar[k] >> 4;
+            if (op == 0) {
+                for (uint32_t l = 0; l < len; ++l) {
+                    const int32_t ct = tseq[i + (int32_t)l], cq = qseq[j + (int32_t)l];
+                    score += (ct > 3 || cq > 3) ? C.sc_amb : (ct == cq ? C.sc_mch : C.sc_mis);
+                    upd(score, i + (int32_t)l, j + (int32_t)l);
+                }
+                i += (int32_t)len; j += (int32_t)len;
+            } else if (op == 1 || op == 2) {
+                score -= P.q + P.e * (int32_t)len;
+                if (op == 1) j += (int32_t)len; else i += (int32_t)len;
+                upd(score, i, j);
+            }
+        }
+        res[0] = max_zdrop; res[1] = p00; res[2] = p01; res[3] = p10; res[4] = p11;
+    }
+    const int32_t max_zdrop = al_b0(res[0]), p00 = al_b0(res[1]), p01 = al_b0(res[2]), p10 = al_b0(res[3]), p11 = al_b0(res[4]);
+    const int32_t q_len = p11 - p01, t_len = p10 - p00;
+    if (max_zdrop > P.zdrop_inv && q_len < P.max_gap && t_len < P.max_gap) {
+        // the reverse complement of the dropped stretch of the query, against the same stretch of the target
+        if ((uint32_t)q_len + 16 > C.W->cap_k || (uint32_t)t_len + 16 > C.W->cap_k) { C.err = 12; return 0; }
+        uint8_t *q2 = C.W->kmem;      // free between alignments
+        for (int32_t i = (int32_t)al_lane(); i < q_len; i += 64) { const int32_t c = qseq[p11 - i - 1]; q2[i] = (uint8_t)(c >= 4 ? 4 : 3 - c); }
+        lr_sync();
+        int32_t qo, to;
+        const int32_t score = lr_ksw_ll_wave(q_len, q2, t_len, tseq + p00, C.sc_mch, C.sc_mis, C.sc_amb, P.q, P.e, qo, to, C.W->lH, C.W->lE, C.W->lHmax);
+        lr_sync();
+        if (score >= P.min_sc * P.a && score >= P.min_dp_max) return 2;
+    }
+    return max_zdrop > P.zdrop ? 1 : 0;
+}
+
+// One region.  r / r2 live in registers (uniform); the caller stores them.  a = the squeezed anchors, n_a their number.
+// flag_only: stop as soon as the region is known to survive mm_filter_regs is NOT done here: this is the complete procedure.
+__device__ inline bool lr_align1(LongCtx &C, LReg &r, LReg &r2, LAnchor *a, int32_t n_a)
+{
+    const LongParams &P = *C.P;
+    LongWs &W = *C.W;
+    const uint32_t lane = al_lane();
+    const int32_t qlen = C.qlen, hk = P.k >> 1;
+    r2.cnt = 0;
+    if (r.cnt == 0) return true;
+    const int32_t rid = (int32_t)(a[r.as].x << 1 >> 33), rev = (int32_t)(a[r.as].x >> 63);
+    const int32_t clen = (int32_t)(C.I->in.cstart[rid + 1] - C.I->in.cstart[rid]);
+    const int32_t bw = (int32_t)(P.bw * 1.5 + 1.);
+    int32_t bw_long = (int32_t)(P.bw_long * 1.5 + 1.);
+    if (bw_long < bw) bw_long = bw;
+    int32_t as1, cnt1;
+    lr_fix_bad_ends0(r, a, P.bw, P.min_sc * 2, as1, cnt1);
+    if (lane == 0) {
+        lr_filter_bad_seeds0(as1, cnt1, a, 10, 40, P.max_gap >> 1, 10, W.K);
+        lr_filter_bad_seeds_alt0(as1, cnt1, a, 30, P.max_gap >> 1, W.K);
+    }
+    lr_sync();
+    int32_t rs = (int32_t)a[as1].x - hk, qs = (int32_t)a[as1].y - hk;
+    int32_t re = (int32_t)a[as1 + cnt1 - 1].x - hk, qe = (int32_t)a[as1 + cnt1 - 1].y - hk;
+    int32_t rs0, qs0, re0, qe0, rs1, qs1, re1, qe1, l, i;
+    rs0 = (int32_t)a[r.as].x + 1 - (int32_t)(a[r.as].y >> 32 & 0xff);
+    qs0 = (int32_t)a[r.as].y + 1 - (int32_t)(a[r.as].y >> 32 & 0xff);
+    if (rs0 < 0) rs0 = 0;
+    rs1 = qs1 = 0;
+    for (i = r.as - 1, l = 0; i >= 0 && a[i].x >> 32 == a[r.as].x >> 32; --i) {
+        const int32_t x = (int32_t)a[i].x + 1 - (int32_t)(a[i].y >> 32 & 0xff), y = (int32_t)a[i].y + 1 - (int32_t)(a[i].y >> 32 & 0xff);
+        if (x < rs0 && y < qs0) {
+            if (++l > P.min_cnt) {
+                l = rs0 - x > qs0 - y ? rs0 - x : qs0 - y;
+                rs1 = rs0 - l; qs1 = qs0 - l;
+                if (rs1 < 0) rs1 = 0;
+                break;
+            }
+        }
+    }
+    if (qs > 0 && rs > 0) {
+        l = qs < P.max_gap ? qs : P.max_gap;
+        qs1 = qs1 > qs - l ? qs1 : qs - l;
+        qs0 = qs0 < qs1 ? qs0 : qs1;
+        l += l * P.a > P.q ? (l * P.a - P.q) / P.e : 0;
+        l = l < P.max_gap ? l : P.max_gap;
+        l = l < rs ? l : rs;
+        rs1 = rs1 > rs - l ? rs1 : rs - l;
+        rs0 = rs0 < rs1 ? rs0 : rs1;
+        rs0 = rs0 < rs ? rs0 : rs;
+    } else { rs0 = rs; qs0 = qs; }
+    re0 = (int32_t)a[r.as + r.cnt - 1].x + 1;
+    qe0 = (int32_t)a[r.as + r.cnt - 1].y + 1;
+    re1 = clen; qe1 = qlen;
+    for (i = r.as + r.cnt, l = 0; i < n_a && a[i].x >> 32 == a[r.as].x >> 32; ++i) {
+        const int32_t x = (int32_t)a[i].x + 1, y = (int32_t)a[i].y + 1;
+        if (x > re0 && y > qe0) {
+            if (++l > P.min_cnt) {
+                l = x - re0 > y - qe0 ? x - re0 : y - qe0;
+                re1 = re0 + l; qe1 = qe0 + l;
+                break;
+            }
+        }
+    }
+    if (qe < qlen && re < clen) {
+        l = qlen - qe < P.max_gap ? qlen - qe : P.max_gap;
+        qe1 = qe1 < qe + l ? qe1 : qe + l;
+        qe0 = qe0 > qe1 ? qe0 : qe1;
+        l += l * P.a > P.q ? (l * P.a - P.q) / P.e : 0;
+        l = l < P.max_gap ? l : P.max_gap;
+        l = l < clen - re ? l : clen - re;
+        re1 = re1 < re + l ? re1 : re + l;
+        re0 = re0 > re1 ? re0 : re1;
+    } else { re0 = re; qe0 = qe; }
+    if ((uint32_t)(re0 - rs0 > 0 ? re0 - rs0 : 0) + 16 > W.cap_t) { C.err = 13; return false; }
+
+    uint8_t *qrow = W.qseq + (rev ? qlen : 0), *tseq = W.tseq;
+    uint32_t *rc = W.r_cigar, *ezc = W.ez_cigar;
+    int32_t rn = 0, dropped = 0;
+    Ez ez;
+    r.has_p = 0;
+    if (qs > 0 && rs > 0) {       // left extension
+        lr_getseq(C, rid, rs0, rs, tseq);
+        lr_seq_rev(qs - qs0, qrow + qs0);
+        lr_seq_rev(rs - rs0, tseq);
+        if (!lr_align_pair(C, qs - qs0, qrow + qs0, rs - rs0, tseq, bw, P.end_bonus, r.split_inv ? P.zdrop_inv : P.zdrop, EZ_EXTZ_ONLY | EZ_RIGHT | EZ_REV_CIGAR, ez)) {
+            lr_seq_rev(qs - qs0, qrow + qs0);      // leave the query as it was for the pass that takes the read over
+            return false;
+        }
+        if (ez.n_cigar > 0) { if (lane == 0) append_cigar0(rc, rn, ez.n_cigar, ezc); r.has_p = 1; }
+        rs1 = rs - (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
+        qs1 = qs - (ez.reach_end ? qs - qs0 : ez.max_q + 1);
+        lr_seq_rev(qs - qs0, qrow + qs0);
+    } else { rs1 = rs; qs1 = qs; }
+    re1 = rs; qe1 = qs;
+
+    for (i = 1; i < cnt1; ++i) {       // gap filling
+        const uint64_t ay = a[as1 + i].y;
+        if ((ay & (LY_IGNORE | LY_TANDEM)) && i != cnt1 - 1) continue;
+        re = (int32_t)a[as1 + i].x - hk; qe = (int32_t)ay - hk;
+        re1 = re; qe1 = qe;
+        if (i == cnt1 - 1 || (ay & LY_LONG_JOIN) || (qe - qs >= P.min_ksw_len && re - rs >= P.min_ksw_len)) {
+            int32_t j, bw1 = bw_long, zdrop_code;
+            if (ay & LY_LONG_JOIN) bw1 = qe - qs > re - rs ? qe - qs : re - rs;
+            if ((uint32_t)(re - rs > 0 ? re - rs : 0) + 16 > W.cap_t) { C.err = 13; return false; }
+            lr_getseq(C, rid, rs, re, tseq);
+            if (!lr_align_pair(C, qe - qs, qrow + qs, re - rs, tseq, bw1, -1, P.zdrop, EZ_APPROX_MAX, ez)) return false;      // first pass: approximate maximum
+            zdrop_code = lr_test_zdrop(C, qrow + qs, tseq, ez.n_cigar, ezc);
+            if (C.err) return false;
+            if (zdrop_code != 0) {
+                if (!lr_align_pair(C, qe - qs, qrow + qs, re - rs, tseq, bw1, -1, zdrop_code == 2 ? P.zdrop_inv : P.zdrop, 0, ez)) return false;
+            }
+            if (ez.n_cigar > 0) { if (lane == 0) append_cigar0(rc, rn, ez.n_cigar, ezc); r.has_p = 1; }
+            if (ez.zdropped) {
+                r.has_p = 1;
+                for (j = i - 1; j >= 0; --j) if ((int32_t)a[as1 + j].x <= rs + ez.max_t) break;
+                dropped = 1;
+                if (j < 0) j = 0;
+                re1 = rs + (ez.max_t + 1);
+                qe1 = qs + (ez.max_q + 1);
+                if (cnt1 - (j + 1) >= P.min_cnt) {      // mm_split_reg(r, r2, as1 + j + 1 - r->as)
+                    const int32_t n = as1 + j + 1 - r.as;
+                    if (n > 0 && n < r.cnt) {
+                        r2 = r;
+                        r2.id = -1; r2.has_p = 0; r2.split_inv = 0;
+                        r2.cnt = r.cnt - n;
+                        r2.score = (int32_t)(r.score * ((float)r2.cnt / r.cnt) + .499);
+                        r2.as = r.as + n;
+                        if (r.parent == r.id) r2.parent = LR_PARENT_TMP_PRI;
+                        lr_reg_set_coor(r2, qlen, a);
+                        r.cnt -= r2.cnt;
+                        r.score -= r2.score;
+                        lr_reg_set_coor(r, qlen, a);
+                        r.split |= 1; r2.split |= 2;
+                        if (zdrop_code == 2) r2.split_inv = 1;
+                    }
+                }
+                break;
+            }
+            rs = re; qs = qe;
+        }
+    }
+
+    if (!dropped && qe < qe0 && re < re0) {   // right extension
+        lr_getseq(C, rid, re, re0, tseq);
+        if (!lr_align_pair(C, qe0 - qe, qrow + qe, re0 - re, tseq, bw, P.end_bonus, P.zdrop, EZ_EXTZ_ONLY, ez)) return false;
+        if (ez.n_cigar > 0) { if (lane == 0) append_cigar0(rc, rn, ez.n_cigar, ezc); r.has_p = 1; }
+        re1 = re + (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
+        qe1 = qe + (ez.reach_end ? qe0 - qe : ez.max_q + 1);
+    }
+
+    r.rs = rs1; r.re = re1;
+    if (rev) { r.qs = qlen - qe1; r.qe = qlen - qs1; } else { r.qs = qs1; r.qe = qe1; }
+    if (r.has_p) {
+        if ((uint32_t)(re1 - rs1 > 0 ? re1 - rs1 : 0) + 16 > W.cap_t) { C.err = 13; return false; }
+        lr_getseq(C, rid, rs1, re1, tseq);
+        int32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (lane == 0) {
+            int32_t mlen = 0, blen = 0, dpm = 0;
+            update_extra0<LReg>(r, rc, rn, W.qseq + (r.rev ? qlen : 0) + qs1, false, tseq, false, *C.AP, mlen, blen, dpm, true);
+            v[0] = mlen; v[1] = blen; v[2] = dpm; v[3] = r.qs; v[4] = r.qe; v[5] = r.rs;
+        }
+        r.mlen = al_b0(v[0]); r.blen = al_b0(v[1]); r.dp_max = al_b0(v[2]); r.qs = al_b0(v[3]); r.qe = al_b0(v[4]); r.rs = al_b0(v[5]);
+    }
+    return true;
+}
+
+// mm_align1_inv: between the two halves of a region split by the inversion z-drop, align the reverse complement
+__device__ inline int32_t lr_align1_inv(LongCtx &C, const LReg &r1, const LReg &r2, LReg &ri)
+{
+    const LongParams &P = *C.P;
+    LongWs &W = *C.W;
+    const uint32_t lane = al_lane();
+    const int32_t qlen = C.qlen;
+    if (!(r1.split & 1) || !(r2.split & 2)) return 0;
+    if (r1.id != r1.parent && r1.parent != LR_PARENT_TMP_PRI) return 0;
+    if (r2.id != r2.parent && r2.parent != LR_PARENT_TMP_PRI) return 0;
+    if (r1.rid != r2.rid || r1.rev != r2.rev) return 0;
+    const int32_t ql = r1.rev ? r1.qs - r2.qe : r2.qs - r1.qe, tl = r2.rs - r1.re;
+    if (ql < P.min_sc || ql > P.max_gap) return 0;
+    if (tl < P.min_sc || tl > P.max_gap) return 0;
+    if ((uint32_t)tl + 16 > W.cap_t || (uint32_t)tl + 16 > W.cap_k || (uint32_t)ql + 16 > W.cap_k) { C.err = 14; return 0; }
+    uint8_t *tseq = W.tseq;
+    lr_getseq(C, r1.rid, r1.re, r2.rs, tseq);
+    uint8_t *qseq = r1.rev ? W.qseq + r2.qe : W.qseq + qlen + (qlen - r2.qs);
+    lr_seq_rev(ql, qseq);
+    lr_seq_rev(tl, tseq);
+    int32_t q_off, t_off;
+    const int32_t score = lr_ksw_ll_wave(ql, qseq, tl, tseq, C.sc_mch, C.sc_mis, C.sc_amb, P.q, P.e, q_off, t_off, W.lH, W.lE, W.lHmax);
+    lr_seq_rev(ql, qseq);
+    lr_seq_rev(tl, tseq);
+    if (score < P.min_dp_max) return 0;
+    q_off = ql - (q_off + 1); t_off = tl - (t_off + 1);
+    Ez ez;
+    if (!lr_align_pair(C, ql - q_off, qseq + q_off, tl - t_off, tseq + t_off, (int32_t)(P.bw * 1.5), -1, P.zdrop, EZ_EXTZ_ONLY, ez)) return -1;
+    if (ez.n_cigar == 0) return 0;
+    int32_t rn = 0;
+    if (lane == 0) append_cigar0(W.r_cigar, rn, ez.n_cigar, W.ez_cigar);
+    LReg z{};
+    ri = z;
+    ri.has_p = 1;
+    ri.id = -1; ri.parent = LR_PARENT_UNSET; ri.inv = 1; ri.rev = !r1.rev; ri.rid = r1.rid; ri.div = -1.0f;
+    if (ri.rev == 0) { ri.qs = r2.qe + q_off; ri.qe = ri.qs + ez.max_q + 1; }
+    else { ri.qe = r2.qs - q_off; ri.qs = ri.qe - (ez.max_q + 1); }
+    ri.rs = r1.re + t_off;
+    ri.re = ri.rs + ez.max_t + 1;
+    int32_t v[6] = {0, 0, 0, 0, 0, 0};
+    if (lane == 0) {
+        int32_t mlen = 0, blen = 0, dpm = 0;
+        rn = ez.n_cigar;      // a single append: the region's CIGAR is the extension's
+        update_extra0<LReg>(ri, W.r_cigar, rn, qseq + q_off, false, tseq + t_off, false, *C.AP, mlen, blen, dpm, true);
+        v[0] = mlen; v[1] = blen; v[2] = dpm; v[3] = ri.qs; v[4] = ri.qe; v[5] = ri.rs;
+    }
+    ri.mlen = al_b0(v[0]); ri.blen = al_b0(v[1]); ri.dp_max = al_b0(v[2]); ri.qs = al_b0(v[3]); ri.qe = al_b0(v[4]); ri.rs = al_b0(v[5]);
+    return 1;
+}
+
+// ---- the whole stage for one read ---------------------------------------------------------------------------------------------------
+struct LongOut { int32_t n_chain, best, rechained, n_aligned, n_regs, dp_max; uint32_t sig; int32_t rmq_tie; };
+
+__device__ inline bool lr_region_kept(const LongParams &P, int32_t qlen, const LReg &r)
+{   // mm_filter_regs, one region
+    int32_t flt = 0;
+    if (!r.inv && r.cnt < P.min_cnt) flt = 1;
+    if (r.has_p) {
+        if (r.mlen < P.min_sc) flt = 1;
+        else if (r.dp_max < P.min_dp_max) flt = 1;
+        else if (r.qs > qlen * P.max_clip_ratio && qlen - r.qe > qlen * P.max_clip_ratio) flt = 1;
+    }
+    return !flt;
+}
+
+// 0: done; 1: the read needs the large-scratch pass; 3: a capacity was exceeded (C.err)
+__device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds &RL, bool flag_only, LongOut &out)
+{
+    const LongParams &P = *C.P;
+    LongWs &W = *C.W;
+    const AlignIn &in = C.I->in;
+    const int32_t lane = (int32_t)al_lane();
+    const uint32_t read = C.read;
+    const int32_t qlen = C.qlen;
+    out.n_chain = out.best = out.rechained = out.n_aligned = out.n_regs = out.dp_max = 0; out.sig = 0; out.rmq_tie = 0;
+    if ((uint32_t)qlen > W.cap_q) { C.err = 4; return 3; }
+
+    // ---- the read's chains, in compact_a's order: by the first anchor's x, ties in discovery order (larger (f, index) first)
+    int32_t n_u = 0;
+    for (uint32_t h = in.head[read]; h != ~0u; h = in.recs[h].next) {
+        if ((uint32_t)n_u < W.cap_u && (n_u & 63) == lane) W.K[n_u] = (int32_t)h;
+        ++n_u;
+    }
+    if (n_u == 0) return 0;
+    if ((uint32_t)n_u > W.cap_u || (uint32_t)n_u > W.cap_r) { C.err = 2; return 3; }
+    lr_sync();
+    for (int32_t i = lane; i < n_u; i += 64) {
+        const ChainRec rc = in.recs[W.K[i]];
+        W.sk[i].k = in.cx[rc.off]; W.sk[i].v = (uint64_t)rc.key_f << 32 | rc.key_i;
+    }
+    lr_sync();
+    for (int32_t i0 = 0; i0 < n_u; i0 += 64) {
+        const int32_t i = i0 + lane;
+        const bool on = i < n_u;
+        const uint64_t xi = on ? W.sk[i].k : 0, ki = on ? W.sk[i].v : 0;
+        int32_t rank = 0;
+        for (int32_t j0 = 0; j0 < n_u; j0 += 64) {
+            const int32_t jm = j0 + lane;
+            const uint64_t xj_ = jm < n_u ? W.sk[jm].k : 0, kj_ = jm < n_u ? W.sk[jm].v : 0;
+            const int32_t lim = n_u - j0 < 64 ? n_u - j0 : 64;
+            for (int32_t l = 0; l < lim; ++l) {
+                const uint64_t xj = lr_readlane64(xj_, l), kj = lr_readlane64(kj_, l);
+                rank += (xj < xi) || (xj == xi && kj > ki);
+            }
+        }
+        if (on) W.v[rank] = W.K[i];
+    }
+    lr_sync();
+    int32_t n_a = 0;
+    {
+        int32_t tot = 0;
+        if (lane == 0) {
+            for (int32_t i = 0; i < n_u; ++i) {
+                const ChainRec rc = in.recs[W.v[i]];
+                W.u[i] = (uint64_t)(uint32_t)rc.score << 32 | rc.cnt;
+                W.uoff[i] = (uint32_t)tot;
+                tot += (int32_t)rc.cnt;
+                if (tot < 0 || (uint32_t)tot > W.cap_a) { tot = -1; break; }
+            }
+            if (tot >= 0) W.uoff[n_u] = (uint32_t)tot;
+        }
+        n_a = al_b0(tot);
+        if (n_a < 0) { C.err = 5; return 3; }
+    }
+    lr_sync();
+    // ---- which query positions carry a tandem seed (MM_SEED_TANDEM on their anchors)
+    {
+        const uint32_t info = C.I->k1info[read];
+        const uint32_t n_seed = C.I->seed_off ? info >> 16 : (info >> 16 & 0x7fffu);
+        const uint4 *rec = C.I->rec + (C.I->seed_off ? (size_t)C.I->seed_off[read] : (size_t)read * C.I->seed_cap);
+        const uint32_t n_rec = C.I->seed_off ? n_seed : (n_seed < C.I->seed_cap ? n_seed : C.I->seed_cap);
+        for (int32_t i = lane; i < qlen / 32 + 1; i += 64) W.tbits[i] = 0;
+        lr_sync();
+        for (uint32_t j = (uint32_t)lane; j < n_rec; j += 64) {
+            bool td = (rec[j].z & SH_REC_PREV_SAME) != 0;
+            if (!td && j + 1 < n_rec) td = (rec[j + 1].z & SH_REC_PREV_SAME) != 0;
+            if (td) { const uint32_t qp = rec[j].w >> 1; if (qp < (uint32_t)qlen) atomicOr(&W.tbits[qp >> 5], 1u << (qp & 31)); }
+        }
+        lr_sync();
+    }
+    LAnchor *A0 = W.a, *B0 = W.b;
+    for (int32_t c = 0; c < n_u; ++c) {
+        const ChainRec rc = in.recs[W.v[c]];
+        const uint32_t o = W.uoff[c];
+        for (uint32_t j = (uint32_t)lane; j < rc.cnt; j += 64) {
+            const uint64_t x = in.cx[rc.off + j]; const uint32_t q = in.cq[rc.off + j];
+            const uint32_t qp = (x >> 63) ? (uint32_t)(qlen + P.k - 2) - q : q;
+            const bool td = qp < (uint32_t)qlen && (W.tbits[qp >> 5] >> (qp & 31) & 1u);
+            A0[o + j].x = x; A0[o + j].y = (td ? LY_TANDEM : 0ull) | (uint64_t)(uint32_t)P.k << 32 | q;
+        }
+    }
+    lr_sync();
+    out.n_chain = n_u;
+    {
+        int32_t best = 0;
+        for (int32_t i = lane; i < n_u; i += 64) { const int32_t s = (int32_t)(W.u[i] >> 32); best = s > best ? s : best; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int32_t ot = __shfl_xor(best, o); best = ot > best ? ot : best; }
+        out.best = best;
+    }
+
+    // ---- mm_map_frag: re-chain / long join
+    if (P.bw_long > P.bw && n_u > 1) {
+        const int32_t st = (int32_t)A0[0].y, en = (int32_t)A0[(int32_t)(uint32_t)W.u[0] - 1].y;
+        if (qlen - (en - st) > P.rmq_rescue_size || en - st > qlen * P.rmq_rescue_ratio) {
+            out.rechained |= 2;
+            for (int32_t i = lane; i < n_a; i += 64) { W.sk[i].k = A0[i].x; W.sk[i].v = (uint64_t)i; }
+            lr_sync();
+            lr_sort(W.sk, W.sk2, n_a);
+            for (int32_t i = lane; i < n_a; i += 64) B0[i] = A0[W.sk[i].v];
+            lr_sync();
+            int32_t tie = 0;
+            if (!lr_rmq_fill(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.t, W.pri, RL, tie)) { C.err = 6; return 3; }
+            out.rmq_tie = tie;
+            // mg_chain_backtrack
+            int32_t n_z = 0;
+            for (int32_t i0 = 0; i0 < n_a; i0 += 64) {
+                const int32_t i = i0 + lane;
+                const bool c = i < n_a && W.f[i] >= P.min_sc;
+                const uint64_t m = __ballot(c);
+                if (c) { const int32_t d = n_z + (int32_t)prefix_popc64(m); W.sk[d].k = (uint64_t)(uint32_t)W.f[i]; W.sk[d].v = (uint64_t)i; }
+                n_z += (int32_t)__popcll(m);
+            }
+            lr_sync();
+            lr_sort(W.sk, W.sk2, n_z);
+            for (int32_t i = lane; i < n_a; i += 64) W.t[i] = 0;
+            lr_sync();
+            int32_t res[3] = {0, 0, 0};
+            if (lane == 0) {
+                int32_t n_v = 0, best = 0; bool ovf = false;
+                res[0] = lr_backtrack0(W.sk, n_z, W.f, W.p, W.t, W.v, W.u, W.cap_u, P.min_cnt, P.min_sc, P.bw_long, n_v, best, ovf);
+                res[1] = ovf ? -1 : n_v; res[2] = best;
+                if (!ovf) {      // chain starts in v[] (discovery order)
+                    int32_t k0 = 0;
+                    for (int32_t i = 0; i < res[0]; ++i) { W.uoff[i] = (uint32_t)k0; k0 += (int32_t)(uint32_t)W.u[i]; }
+                    W.uoff[res[0]] = (uint32_t)k0;
+                }
+            }
+            n_u = al_b0(res[0]);
+            const int32_t n_v = al_b0(res[1]);
+            out.best = al_b0(res[2]); out.n_chain = n_u;
+            if (n_v < 0 || (uint32_t)n_u > W.cap_r) { C.err = 2; return 3; }
+            lr_sync();
+            if (n_u == 0) return 0;
+            // compact_a: every chain ascending, then the chains by the x of their first anchor (ties: discovery order)
+            for (int32_t c = 0; c < n_u; ++c) {
+                const int32_t k0 = (int32_t)W.uoff[c], ni = (int32_t)(uint32_t)W.u[c];
+                for (int32_t j = lane; j < ni; j += 64) A0[k0 + j] = B0[W.v[k0 + (ni - j - 1)]];
+            }
+            lr_sync();
+            for (int32_t c = lane; c < n_u; c += 64) { W.sk[c].k = A0[W.uoff[c]].x; W.sk[c].v = (uint64_t)c; }
+            lr_sync();
+            lr_sort(W.sk, W.sk2, n_u);
+            // chains in their new order: anchors to B0, u to pri (as raw bits), offsets recomputed
+            uint64_t *u2 = (uint64_t *)W.pri;
+            if (lane == 0) {
+                int32_t k0 = 0;
+                for (int32_t c = 0; c < n_u; ++c) { const int32_t s = (int32_t)W.sk[c].v; u2[c] = W.u[s]; W.K[c] = k0; k0 += (int32_t)(uint32_t)W.u[s]; }
+                W.K[n_u] = k0;
+            }
+            lr_sync();
+            for (int32_t c = 0; c < n_u; ++c) {
+                const int32_t s = (int32_t)W.sk[c].v, so = (int32_t)W.uoff[s], d = W.K[c], ni = (int32_t)(uint32_t)u2[c];
+                for (int32_t j = lane; j < ni; j += 64) B0[d + j] = A0[so + j];
+            }
+            lr_sync();
+            for (int32_t c = lane; c <= n_u; c += 64) { if (c < n_u) W.u[c] = u2[c]; W.uoff[c] = (uint32_t)W.K[c]; }
+            n_a = n_v;
+            { LAnchor *x = A0; A0 = B0; B0 = x; }
+            lr_sync();
+        }
+    }
+
+    // ---- mm_gen_regs: regions in descending z = (score << 32 | cnt) ^ h; of equal z the later chain first
+    uint32_t hash = 0;
+    hash ^= al_wang((uint32_t)qlen) + al_wang(11u);
+    hash = al_wang(hash);
+    for (int32_t i = lane; i < n_u; i += 64) {
+        const LAnchor f0 = A0[W.uoff[i]];
+        const uint32_t h = (uint32_t)al_hash64((al_hash64(f0.x) + al_hash64(f0.y)) ^ hash);
+        W.sk[i].k = W.u[i] ^ h; W.sk[i].v = (uint64_t)i;
+    }
+    lr_sync();
+    lr_sort(W.sk, W.sk2, n_u);
+    for (int32_t j = lane; j < n_u; j += 64) {
+        const SKey z = W.sk[n_u - 1 - j];
+        LReg r{};
+        r.id = j; r.parent = LR_PARENT_UNSET;
+        r.score = (int32_t)(z.k >> 32); r.hash = (uint32_t)z.k;
+        r.cnt = (int32_t)(uint32_t)W.u[z.v]; r.as = (int32_t)W.uoff[z.v];
+        r.div = -1.0f;
+        lr_reg_set_coor(r, qlen, A0);
+        W.regs[j] = r;
+    }
+    lr_sync();
+    // ---- chain_post, mm_est_err, mm_filter_strand_retained (lane 0)
+    int32_t n_regs = n_u;
+    {
+        int32_t res[2] = {0, 0};
+        if (lane == 0) {
+            lr_set_parent0(P.mask_level, n_regs, W.regs, W.cov, W.wpri);
+            n_regs = lr_select_sub0(P.pri_ratio, P.k * 2, P.best_n, (int32_t)(P.max_gap * 0.8), n_regs, W.regs, W.K);
+            bool any_sr = false;
+            for (int32_t i = 0; i < n_regs; ++i) any_sr |= W.regs[i].strand_retained != 0;
+            if (any_sr) {
+                // mm_collect_matches' mini_pos: the seeds mm_seed_select lets through, in minimizer order
+                const uint32_t info = C.I->k1info[read];
+                const uint32_t n_seed = C.I->seed_off ? info >> 16 : (info >> 16 & 0x7fffu);
+                uint4 *rec = (uint4 *)C.I->rec + (C.I->seed_off ? (size_t)C.I->seed_off[read] : (size_t)read * C.I->seed_cap);
+                SeedView sv; sv.base = rec; sv.stride = 1; sv.n = n_seed;
+                int64_t na2 = 0; int32_t rl2 = 0;
+                seed_filter(sv, qlen, CP.mid_occ, CP, na2, rl2);
+                int32_t m = 0;
+                for (uint32_t j = 0; j < n_seed; ++j) {
+                    const uint4 s = rec[j];
+                    if (s.z >> 31) continue;
+                    if ((uint32_t)m >= W.cap_m) { m = -1; break; }
+                    W.mini_pos[m++] = (uint64_t)(uint32_t)P.k << 32 | s.w >> 1;
+                }
+                if (m < 0) res[1] = 7;
+                else {
+                    lr_est_err0(qlen, n_regs, W.regs, A0, m, W.mini_pos, in.cstart);
+                    n_regs = lr_filter_strand0(n_regs, W.regs);
+                }
+            }
+            res[0] = n_regs;
+        }
+        n_regs = al_b0(res[0]);
+        if (al_b0(res[1])) { C.err = 7; return 3; }
+    }
+    lr_sync();
+    out.n_aligned = n_regs;
+
+    // ---- mm_align_skeleton: the query on both strands, mm_squeeze_a, the regions one after the other
+    {
+        const uint8_t *seq = in.bases + in.offsets[read];
+        for (int32_t i = lane; i < qlen; i += 64) {
+            const uint8_t c = (uint8_t)sh_nt4(seq[i]);
+            W.qseq[i] = c;
+            W.qseq[qlen + (qlen - 1 - i)] = c < 4 ? 3 - c : 4;
+        }
+    }
+    for (int32_t i = lane; i < n_regs; i += 64) { W.sk[i].k = (uint64_t)(uint32_t)W.regs[i].as; W.sk[i].v = (uint64_t)i; }
+    lr_sync();
+    lr_sort(W.sk, W.sk2, n_regs);
+    int32_t n_sq = 0;
+    for (int32_t c = 0; c < n_regs; ++c) {
+        const int32_t ri = (int32_t)W.sk[c].v;
+        const int32_t src = W.regs[ri].as, cnt = W.regs[ri].cnt;
+        if (src != n_sq) {
+            for (int32_t j0 = 0; j0 < cnt; j0 += 64) {
+                const int32_t j = j0 + lane;
+                LAnchor e{0, 0};
+                if (j < cnt) e = A0[src + j];
+                lr_sync();
+                if (j < cnt) A0[n_sq + j] = e;
+                lr_sync();
+            }
+            if (lane == 0) W.regs[ri].as = n_sq;
+        }
+        n_sq += cnt;
+    }
+    lr_sync();
+
+    uint32_t sig = 2166136261u;
+    int32_t n_keep = 0, dp_best = 0;
+    auto account = [&](const LReg &r) {      // a region that mm_filter_regs keeps (uniform)
+        const int32_t v[8] = { r.rs, r.re, r.qs, r.qe, r.mlen, r.blen, r.has_p ? r.dp_max : -1, r.cnt };
+        for (int32_t j = 0; j < 8; ++j) { sig ^= (uint32_t)v[j]; sig *= 16777619u; }
+        if (r.has_p && r.dp_max > dp_best) dp_best = r.dp_max;
+        ++n_keep;
+    };
+    auto insert_after = [&](int32_t i, const LReg &x) -> bool {      // mm_insert_reg
+        if ((uint32_t)(n_regs + 1) > W.cap_r) { C.err = 8; return false; }
+        if (lane == 0) {
+            for (int32_t m = n_regs - 1; m > i; --m) W.regs[m + 1] = W.regs[m];
+            W.regs[i + 1] = x;
+        }
+        ++n_regs;
+        lr_sync();
+        return true;
+    };
+    for (int32_t i = 0; i < n_regs; ++i) {
+        LReg r = W.regs[i], r2;
+        r2.cnt = 0;
+        if (!lr_align1(C, r, r2, A0, n_sq)) return C.need_big ? 1 : 3;
+        if (lane == 0) W.regs[i] = r;
+        lr_sync();
+        if (r2.cnt > 0 && !insert_after(i, r2)) return 3;
+        if (lr_region_kept(P, qlen, r)) { account(r); if (flag_only) { out.n_regs = 1; return 0; } }
+        if (i > 0 && r.split_inv) {
+            const LReg r1 = W.regs[i - 1];
+            LReg rv;
+            const int32_t ok = lr_align1_inv(C, r1, r, rv);
+            if (ok < 0 || C.err) return C.need_big ? 1 : 3;
+            if (ok > 0) {
+                if (!insert_after(i, rv)) return 3;
+                ++i;
+                if (lr_region_kept(P, qlen, rv)) { account(rv); if (flag_only) { out.n_regs = 1; return 0; } }
+            }
+        }
+    }
+    out.n_regs = n_keep; out.dp_max = dp_best; out.sig = n_keep > 0 ? sig : 0u;
+    return 0;
+}

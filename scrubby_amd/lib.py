@@ -43,6 +43,8 @@ class Opts(C.Structure):
         ("e2", C.c_int32), ("sc_ambi", C.c_int32), ("zdrop", C.c_int32), ("zdrop_inv", C.c_int32), ("end_bonus", C.c_int32),
         ("min_dp_max", C.c_int32), ("best_n", C.c_int32), ("bw_long", C.c_int32), ("min_ksw_len", C.c_int32),
         ("pri_ratio", C.c_float), ("mask_level", C.c_float), ("max_clip_ratio", C.c_float),
+        # the RMQ long-join re-chain of the long-read presets
+        ("rmq_inner_dist", C.c_int32), ("rmq_size_cap", C.c_int32), ("rmq_rescue_size", C.c_int32), ("rmq_rescue_ratio", C.c_float),
     ]
 
 
