@@ -1,0 +1,91 @@
+"""Long reads built to exercise the long-read branch of the extension stage (SURVEY.md App. A.6 without MM_F_SR: oracle/mm_align.c
+align1_lr, oracle/mm_rmq.c): plain noisy reads, chimeras, large deletions / insertions (z-drop splits, long joins), inverted segments
+(the inversion test and mm_align1_inv), reads near the identity at which min_dp_max bites, clipped ends, N runs, tandem duplications
+(overlapping chains, RMQ re-chain).  Shared by the CPU and GPU suites."""
+import numpy as np
+
+ACGT = np.frombuffer(b"ACGT", np.uint8)
+COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def _noisy(rng, src, sub, indel):
+    out = bytearray()
+    for c in bytes(src):
+        u = rng.random()
+        if u < indel:
+            continue
+        if u < 2 * indel:
+            out.append(ACGT[rng.integers(0, 4)])
+        out.append(ACGT[rng.integers(0, 4)] if u > 1.0 - sub else c)
+    return bytes(out)
+
+
+def _rc(b):
+    return bytes(b).translate(COMP)[::-1]
+
+
+def long_edge_reads(ref, n=240, seed=11, max_len=6000):
+    rng = np.random.default_rng(seed)
+    G = len(ref)
+
+    def rnd(m):
+        return bytes(ACGT[rng.integers(0, 4, m)])
+
+    def locus(L):
+        s = int(rng.integers(0, G - L - 1))
+        return s, bytes(ref[s:s + L])
+    recs = []
+    for it in range(n):
+        kind = it % 13
+        L = int(min(max(rng.lognormal(7.6, 0.5), 700), max_len))
+        if kind == 0:
+            r = _noisy(rng, locus(L)[1], 0.02, 0.015)
+        elif kind == 1:      # chimera of two loci, the second on the other strand half of the time
+            a, b = locus(L // 2)[1], locus(L // 2)[1]
+            r = _noisy(rng, a, 0.02, 0.015) + _noisy(rng, _rc(b) if rng.random() < 0.5 else b, 0.02, 0.015)
+        elif kind == 2:      # a stretch of the reference missing from the read
+            s, src = locus(L + 2500)
+            d = int(rng.integers(300, 2000)); p = int(rng.integers(300, L - 300))
+            r = _noisy(rng, src[:p] + src[p + d:p + d + (L - p)], 0.02, 0.015)
+        elif kind == 3:      # a stretch of random sequence inserted into the read
+            s, src = locus(L)
+            d = int(rng.integers(300, 1500)); p = int(rng.integers(300, L - 300))
+            r = _noisy(rng, src[:p], 0.02, 0.015) + rnd(d) + _noisy(rng, src[p:], 0.02, 0.015)
+        elif kind == 4:      # an inverted segment in the middle
+            s, src = locus(L)
+            d = int(rng.integers(250, 900)); p = int(rng.integers(300, max(301, L - 300 - d)))
+            r = _noisy(rng, src[:p] + _rc(src[p:p + d]) + src[p + d:], 0.015, 0.01)
+        elif kind == 5:      # divergent reads: chains exist, regions may fall below min_dp_max / min_chain_score
+            e = float(rng.uniform(0.10, 0.24))
+            r = _noisy(rng, locus(L)[1], e * 0.5, e * 0.25)
+        elif kind == 6:      # short and noisy
+            L2 = int(rng.integers(160, 420)); e = float(rng.uniform(0.06, 0.16))
+            r = _noisy(rng, locus(L2)[1], e * 0.5, e * 0.25)
+        elif kind == 7:      # clipped ends
+            r = rnd(int(rng.integers(100, 600))) + _noisy(rng, locus(L)[1], 0.02, 0.015) + rnd(int(rng.integers(100, 800)))
+        elif kind == 8:      # a run of Ns
+            src = bytearray(locus(L)[1]); p = int(rng.integers(200, L - 300)); m = int(rng.integers(5, 120))
+            src[p:p + m] = b"N" * m
+            r = _noisy(rng, bytes(src), 0.02, 0.015)
+        elif kind == 9:      # tandem duplication of a segment inside the read
+            s, src = locus(L)
+            d = int(rng.integers(200, 900)); p = int(rng.integers(300, max(301, L - 300 - d)))
+            r = _noisy(rng, src[:p + d] + src[p:], 0.02, 0.015)
+        elif kind == 10:     # unrelated sequence
+            r = rnd(L)
+        elif kind == 12:     # a few exact k-mers on one diagonal with unrelated sequence between them: a chain, hardly an alignment
+            m = int(rng.integers(3, 6)); s, src = locus(600)
+            parts, pos = [rnd(int(rng.integers(20, 200)))], 0
+            for _ in range(m):
+                kl = int(rng.integers(15, 20)); g = int(rng.integers(5, 45))
+                parts += [src[pos:pos + kl], rnd(g)]; pos += kl + g
+            r = b"".join(parts) + rnd(int(rng.integers(20, 200)))
+        else:                # accurate read (HiFi-like)
+            r = _noisy(rng, locus(L)[1], 0.002, 0.001)
+        if it % 3 == 1:
+            r = _rc(r)
+        recs.append(r)
+    bases = np.frombuffer(b"".join(recs), np.uint8)
+    offs = np.zeros(len(recs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(x) for x in recs])
+    return recs, bases, offs

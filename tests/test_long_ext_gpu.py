@@ -1,0 +1,93 @@
+"""GPU parity of the extension stage for the long-read presets (scrubby_amd/csrc/sh_long.h vs oracle/mm_align.c align1_lr + oracle/mm_rmq.c;
+`.map_ont() / .lrhq() / .map_hifi()` + `.with_cigar()`, /root/reference/src/cleaner.rs:457-458,465,473): the chains after the RMQ long
+join, the regions aligned, the regions mm_filter_regs keeps, their largest dp_max and the fingerprint of their coordinates / mlen /
+blen / dp_max - bit for bit, in trace mode (every region aligned) and in flag-only mode (what the boundary returns)."""
+import numpy as np
+import pytest
+
+from tests import long_cases as LC
+from tests import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    from scrubby_amd import lib
+    lib.require_gpu()
+    return lib
+
+
+@pytest.fixture(scope="module")
+def cfg1(oracle):
+    return W.cfg1(oracle, 100)
+
+
+def assert_same(S, gf, gt, of, ot):
+    assert np.array_equal(gf, of), f"{int((gf != of).sum())} flags differ, first {np.where(gf != of)[0][:5]}"
+    for name in S.TRACE_FIELDS:
+        g = gt[name] & 3 if name == "rechained" else gt[name]        # bit 2 of the GPU's word: a tied RMQ priority was met (reported, not an error)
+        bad = np.where(g != ot[name])[0]
+        assert len(bad) == 0, f"trace.{name}: {len(bad)} differ, first read {bad[0]}: gpu={gt[name][bad[0]]} cpu={ot[name][bad[0]]}"
+
+
+@pytest.mark.parametrize("preset,w,k", [("map-ont", 10, 15), ("lr:hq", 19, 19), ("map-hifi", 19, 19)])
+def test_structural_reads_all_presets(S, oracle, cfg1, preset, w, k):
+    P, R, ref, seqs, reads, off = cfg1
+    recs, bases, offs = LC.long_edge_reads(ref, 260)
+    go = S.preset(preset)
+    gidx = S.Index.build([bytes(s) for s in seqs], go)
+    cidx = oracle.Index.build(seqs, w, k)
+    oo = cidx.update_opts(oracle.preset(preset))
+    for f, _ in S.Opts._fields_:
+        assert getattr(go, f) == getattr(oracle.preset(preset), f), f
+    gf, gt, st, rc = gidx.classify(bases, offs, want_trace=True)
+    of, ot = cidx.classify(oo, bases, offs, threads=8)
+    assert rc == 0
+    assert_same(S, gf, gt, of, ot)
+    assert int(((gt["rechained"] & 4) != 0).sum()) == 0                      # no tied RMQ priority on this set: nothing rests on the tie rule
+    kinds = np.arange(len(recs)) % 13
+    if preset == "map-ont":
+        assert int((gt["n_regs"][kinds == 4] > gt["n_aligned"][kinds == 4]).sum()) >= 5      # inversions split regions on the device too
+        o0 = cidx.update_opts(oracle.preset(preset)); o0.flags = 0
+        f0, _ = cidx.classify(o0, bases, offs, threads=8)
+        assert int(((f0 == 1) & (gf == 0)).sum()) >= 2                       # the stage flips flags on this set
+    # flag-only call: the same flags, whatever it skips
+    gf2, _, st2, rc2 = gidx.classify(bases, offs, want_trace=False)
+    assert rc2 == 0 and np.array_equal(gf2, of)
+    assert st2["n_host"] == int(of.sum())
+
+
+def test_small_direction_buffer_sends_reads_to_the_large_pass(S, oracle, cfg1, monkeypatch):
+    """A first pass with 256 KB of direction bytes per wave: the end extensions of clipped reads and the long joins no longer fit, the
+    reads are finished by the large-scratch pass, the answers stay the same."""
+    P, R, ref, seqs, reads, off = cfg1
+    recs, bases, offs = LC.long_edge_reads(ref, 104, seed=23)
+    monkeypatch.setenv("SCRUBBY_HIP_LEXT_P_KB", "256")
+    go = S.preset("map-ont")
+    gidx = S.Index.build([bytes(s) for s in seqs], go)
+    cidx = oracle.Index.build(seqs, 10, 15)
+    oo = cidx.update_opts(oracle.preset("map-ont"))
+    gf, gt, st, rc = gidx.classify(bases, offs, want_trace=True)
+    of, ot = cidx.classify(oo, bases, offs, threads=8)
+    assert rc == 0
+    assert_same(S, gf, gt, of, ot)
+
+
+def test_noisy_reads_at_bench_error_rates(S, oracle, cfg1):
+    """BASELINE configs[3] in miniature with the decision the reference takes: the synthetic ONT generator's reads (2 % substitutions,
+    1.56 % insertions, 1.56 % deletions), map-ont, full trace."""
+    Po = oracle.ref_params(0x5C2B0010, [1_000_000] * 5)
+    Ro = oracle.read_params(0x5C2B0020, read_len=0, host_pct=50, sub_per_10k=200, n_read_pct=1)
+    n = 400
+    cpu, offs = oracle.synth_long_reads(Po, Ro, 7, n)
+    seqs = [oracle.synth_ref(Po, Po.contig_start[i], 1_000_000) for i in range(5)]
+    gidx = S.Index.build([bytes(s) for s in seqs], S.preset("map-ont"))
+    cidx = oracle.Index.build(seqs, 10, 15)
+    oo = cidx.update_opts(oracle.preset("map-ont"))
+    gf, gt, st, rc = gidx.classify(cpu, offs, want_trace=True)
+    of, ot = cidx.classify(oo, cpu, offs, threads=8)
+    assert rc == 0
+    assert_same(S, gf, gt, of, ot)
+    gf2, _, _, _ = gidx.classify(cpu, offs, want_trace=False)
+    assert np.array_equal(gf2, of)
