@@ -575,11 +575,11 @@ __device__ inline void append_cigar0(uint32_t *rc, int32_t &rn, int32_t n_cigar,
 }
 
 // mm_fix_cigar + mm_update_extra (log_gap = 0) on lane 0.  qseq / tseq already offset to (qs1, rs1).
+// mm_fix_cigar on lane 0: indel left-alignment, I/D run merging, removal of a leading I/D (which moves the region's start)
 template <class REG>
-__device__ inline void update_extra0(REG &r, uint32_t *c, int32_t &n_cigar, const uint8_t *qseq, bool qg, const uint8_t *tseq, bool tg,
-                                     const AlignParams &P, int32_t &mlen_o, int32_t &blen_o, int32_t &dp_max_o, bool log_gap = false)
+__device__ inline void fix_cigar0(REG &r, uint32_t *c, int32_t &n_cigar, const uint8_t *qseq, bool qg, const uint8_t *tseq, bool tg, int32_t &qshift, int32_t &tshift)
 {
-    int32_t qshift = 0, tshift = 0;
+    qshift = 0; tshift = 0;
     if (n_cigar > 1) {
         int32_t toff = 0, qoff = 0, to_shrink = 0, k;
         for (k = 0; k < n_cigar; ++k) {
@@ -633,6 +633,14 @@ __device__ inline void update_extra0(REG &r, uint32_t *c, int32_t &n_cigar, cons
             for (k = 0; k < n_cigar; ++k) c[k] = c[k + 1];
         }
     }
+}
+
+template <class REG>
+__device__ inline void update_extra0(REG &r, uint32_t *c, int32_t &n_cigar, const uint8_t *qseq, bool qg, const uint8_t *tseq, bool tg,
+                                     const AlignParams &P, int32_t &mlen_o, int32_t &blen_o, int32_t &dp_max_o, bool log_gap = false)
+{
+    int32_t qshift = 0, tshift = 0;
+    fix_cigar0(r, c, n_cigar, qseq, qg, tseq, tg, qshift, tshift);
     qseq += qshift; tseq += tshift;
     int32_t toff = 0, qoff = 0, blen = 0, mlen = 0;
     double s = 0.0, max = 0.0;

@@ -72,7 +72,8 @@ struct Counters {
     uint32_t ext_s3[8];           // SCRUBBY_HIP_DBG & 16: outcome of the local-cluster shortcut (k_expand): 0 tried, 1 no singleton / filtered seed, 2 singletons apart, 3 window grew / too many, 4 K > 64, 5 no margin over U_out, 6 lemma, 7 decided
     uint32_t ext_overflow, ext_n_list, ext_ticket, ext_regions, ext_dropped, ext_n_redo, ext_n_list2, ext_ticket2, ext_n_redo2, ext_ticket3;      // extension stage (sh_align.h)
     uint32_t ext_n_recs[SINK_SHARDS]; unsigned long long ext_n_anch[SINK_SHARDS];                 // hand-over cursors, one per shard
-    uint32_t lext_n_big, lext_ticket_big, lext_rechained, lext_rmq_tie, lext_err_read, lext_pad;  // long-read extension stage (sh_long.h): reads for the large-scratch pass, RMQ re-chains, steps with tied priorities
+    uint32_t lext_n_big, lext_ticket_big, lext_rechained, lext_rmq_tie, lext_err_read, lext_unresolved, lext_err_code, lext_pad;
+    unsigned long long lext_clk[LR_NCLK];  // long-read extension stage (sh_long.h): reads for the large-scratch pass, RMQ re-chains, steps with tied priorities
     uint32_t n_cl[4], cl_ticket, pad3;      // global queue of big clusters (k_cluster_dp), by size class
     uint32_t n_leg_reason[4];     // why reads left the long-read front end: 0 room/segments, 1 thinning screen, 2 anchors beyond the giant path, 3 unused
     unsigned long long arena_cursor, anchor_cursor;
@@ -2555,7 +2556,7 @@ __global__ __launch_bounds__(64) void k_regs_align(ExtArgs a)
 struct ExtLongArgs {
     LongIn I; LongParams P; AlignParams AP; ChainParams CP;
     uint8_t *scratch; unsigned long long scratch_per_wave; LongSizes sz;
-    uint32_t *list; uint32_t *n_list, *ticket; uint32_t *big_list; Counters *ctr; uint8_t *flags; sh_trace *trace; int32_t flag_only;
+    uint32_t *list; uint32_t *n_list, *ticket; uint32_t *big_list; Counters *ctr; uint8_t *flags; sh_trace *trace; int32_t flag_only, clk, probe;
 };
 
 __global__ __launch_bounds__(64) void k_regs_align_long(ExtLongArgs a)
@@ -2566,7 +2567,8 @@ __global__ __launch_bounds__(64) void k_regs_align_long(ExtLongArgs a)
     LongWs W;
     long_ws_carve(&W, a.scratch + (unsigned long long)blockIdx.x * a.scratch_per_wave, a.sz);
     const uint32_t n_list = *a.n_list;
-    uint32_t n_regions = 0, n_dropped = 0, n_rechain = 0, n_tie = 0;
+    uint32_t n_regions = 0, n_dropped = 0, n_rechain = 0, n_tie = 0, n_probed = 0;
+    LongClk clk{};
     for (;;) {
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(a.ticket, 1u);
@@ -2580,16 +2582,19 @@ __global__ __launch_bounds__(64) void k_regs_align_long(ExtLongArgs a)
         C.qlen = (int32_t)(a.I.in.offsets[r + 1] - a.I.in.offsets[r]); C.read = r;
         C.sc_mch = (int8_t)(a.P.a < 0 ? -a.P.a : a.P.a); C.sc_mis = (int8_t)(a.P.b > 0 ? -a.P.b : a.P.b);
         C.sc_amb = (int8_t)(a.P.sc_ambi > 0 ? -a.P.sc_ambi : a.P.sc_ambi); C.sc_N = C.sc_amb == 0 ? (int8_t)(-a.P.e2) : C.sc_amb;
-        C.need_big = false; C.err = 0;
+        C.need_big = false; C.err = 0; C.clk = a.clk ? &clk : nullptr;
         LongOut o;
-        const int32_t rc = lr_read_wave(C, a.CP, RL, a.flag_only != 0, o);
-        if (rc == 1) {      // an alignment larger than this pass's direction-byte buffer
+        const int32_t rc = lr_read_wave(C, a.CP, RL, a.flag_only != 0, a.probe != 0, o);
+        if (rc != 0) {      // the read outgrew this pass's working memory (an alignment beyond the direction-byte buffer, more chain anchors / regions than fit)
             if (lane == 0) {
                 if (a.big_list) a.big_list[atomicAdd(&a.ctr->lext_n_big, 1u)] = r;
-                else { atomicExch(&a.ctr->ext_overflow, 32u); atomicExch(&a.ctr->lext_err_read, r); }
+                else {
+                    // beyond the large pass too (minimap2 has no such limit): the read keeps its chain-level answer - it has a chain - and is counted
+                    a.flags[r] = 1;
+                    if (a.trace) ((int32_t *)(a.trace + r))[7] = 1;
+                    atomicAdd(&a.ctr->lext_unresolved, 1u); atomicExch(&a.ctr->lext_err_read, r); atomicExch(&a.ctr->lext_err_code, rc == 1 ? 32u : 16u + C.err);
+                }
             }
-        } else if (rc != 0) {
-            if (lane == 0) { atomicExch(&a.ctr->ext_overflow, 16u + C.err); atomicExch(&a.ctr->lext_err_read, r); }
         } else if (lane == 0) {
             a.flags[r] = o.n_regs > 0 ? 1 : 0;
             if (a.trace) {
@@ -2598,7 +2603,7 @@ __global__ __launch_bounds__(64) void k_regs_align_long(ExtLongArgs a)
                 ((int4 *)tr)[2] = make_int4(o.n_aligned, o.n_regs, o.dp_max, (int32_t)o.sig);
             }
         }
-        if (rc == 0) { n_regions += (uint32_t)o.n_aligned; n_dropped += o.n_regs == 0; n_rechain += (o.rechained & 2) != 0; n_tie += o.rmq_tie != 0; }
+        if (rc == 0) { n_regions += (uint32_t)o.n_aligned; n_dropped += o.n_regs == 0; n_rechain += (o.rechained & 2) != 0; n_tie += o.rmq_tie != 0; n_probed += (uint32_t)o.probed; }
         __syncthreads();
     }
     if (lane == 0) {
@@ -2606,6 +2611,8 @@ __global__ __launch_bounds__(64) void k_regs_align_long(ExtLongArgs a)
         if (n_dropped) atomicAdd(&a.ctr->ext_dropped, n_dropped);
         if (n_rechain) atomicAdd(&a.ctr->lext_rechained, n_rechain);
         if (n_tie) atomicAdd(&a.ctr->lext_rmq_tie, n_tie);
+        if (n_probed) atomicAdd(&a.ctr->sh_lemma[SHARD()], n_probed);
+        if (a.clk) for (int i = 0; i < LR_NCLK; ++i) atomicAdd(&a.ctr->lext_clk[i], clk.t[i]);
     }
 }
 
@@ -2854,7 +2861,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         if (c->ext_long) {      // a long read's chains hold most of its minimizers (~2 / (w + 1) per base), secondary chains as many again
             const uint64_t cb = std::min<uint64_t>(max_bases + 64, max_reads * (uint64_t)max_read_len + 64);
             cap_anch = std::max<uint64_t>(cap_anch, cb / 2);
-            cap_recs = std::max<uint64_t>(cap_recs, std::min<uint64_t>(cb / 256, 1ull << 28) + 8 * max_reads);
+            cap_recs = std::max<uint64_t>(cap_recs, std::min<uint64_t>(cb / 16, 1ull << 28) + 8 * max_reads);      // repeat-rich reads leave hundreds of small chains each
         }
         if (const char *env = getenv("SCRUBBY_HIP_EXT_MB")) { cap_anch = std::max<uint64_t>(1 << 16, ((uint64_t)atoll(env) << 20) / 16); cap_recs = std::max<uint64_t>(1 << 12, cap_anch / 16); }
         cap_recs = std::min<uint64_t>((cap_recs + SINK_SHARDS - 1) / SINK_SHARDS, 0xfffffff0ull / SINK_SHARDS);      // per shard
@@ -2888,7 +2895,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             z.cap_q = (uint32_t)((L + 31) & ~15ull);
             z.cap_k = (uint32_t)std::min<uint64_t>(32768, ((2 * L + 1024) + 15) & ~15ull);
             z.cap_t = (uint32_t)(2 * L + 65536);
-            z.cap_a = (uint32_t)std::min<uint64_t>(1ull << 20, std::max<uint64_t>(16384, L / 2));
+            z.cap_a = (uint32_t)std::min<uint64_t>(1ull << 17, std::max<uint64_t>(16384, 2 * L));
             z.cap_u = z.cap_r = (uint32_t)std::min<uint64_t>(z.cap_a, 16384);
             z.cap_m = (uint32_t)std::min<uint64_t>(65536, L / 4 + 1024);
             z.cap_p = std::min<uint64_t>(8ull << 20, (uint64_t)(2 * z.cap_k) * (z.cap_k + 32));
@@ -2899,9 +2906,10 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             c->lext_waves[0] = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)256 * 5, budget0 / c->lext_per_wave[0], max_reads}));
             LongSizes zb = z;
             zb.cap_p = std::min<uint64_t>(256ull << 20, (uint64_t)(2 * z.cap_k) * (z.cap_k + 32));
+            zb.cap_a = 1u << 21; zb.cap_u = zb.cap_r = 1u << 18; zb.cap_m = 65536;
             c->lext_sz[1] = zb;
             c->lext_per_wave[1] = long_ws_carve(nullptr, nullptr, zb);
-            c->lext_waves[1] = zb.cap_p > z.cap_p ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, (8ull << 30) / c->lext_per_wave[1])) : 0;
+            c->lext_waves[1] = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, (12ull << 30) / c->lext_per_wave[1]));
             for (int t = 0; t < 2; ++t)
                 if (c->lext_waves[t] && (e = hipMalloc(&c->d_lext[t], (uint64_t)c->lext_waves[t] * c->lext_per_wave[t])) != hipSuccess) return fail(e, "long-read extension-stage scratch");
             if ((e = hipMalloc(&c->d_lext_big, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
@@ -3189,7 +3197,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         x.P = c->LP; x.AP = c->AP; x.CP = c->P;
         x.scratch = c->d_lext[0]; x.scratch_per_wave = c->lext_per_wave[0]; x.sz = c->lext_sz[0];
         x.list = c->d_ext_list; x.n_list = &c->d_ctr->ext_n_list; x.ticket = &c->d_ctr->ext_ticket; x.big_list = c->lext_waves[1] ? c->d_lext_big : nullptr;
-        x.ctr = c->d_ctr; x.flags = d_flags; x.trace = d_trace; x.flag_only = d_trace == nullptr;
+        x.ctr = c->d_ctr; x.flags = d_flags; x.trace = d_trace; x.flag_only = d_trace == nullptr; x.clk = getenv("SCRUBBY_HIP_DBG") ? 1 : 0; x.probe = getenv("SCRUBBY_HIP_NO_PROBE") ? 0 : 1;
         SH_HIP(hipEventRecord(c->ev_ext[0], s));
         {
             ExtArgs xl{};
@@ -3201,7 +3209,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         SH_HIP(hipStreamSynchronize(s));
         SH_HIP(hipGetLastError());
         if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;       // hand-over buffers full: the caller cuts the chunk in two
-        SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "long-read extension stage: read %u exceeds the per-wave working memory (code %u: 18 chains, 20 read length, 21 chain anchors, 22 inner RMQ window, 23 seeds, 24 regions, 27/28/29/30 alignment window, 32 direction bytes)", c->h_ctr->lext_err_read, c->h_ctr->ext_overflow);
+        SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "long-read extension stage: internal overflow code %u", c->h_ctr->ext_overflow);
         ext_list = c->h_ctr->ext_n_list;
         if (c->h_ctr->lext_n_big > 0) {      // reads with an alignment beyond the first pass's direction-byte buffer
             ExtLongArgs x2 = x;
@@ -3211,10 +3219,22 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
             SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
             SH_HIP(hipStreamSynchronize(s));
             SH_HIP(hipGetLastError());
-            SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "long-read extension stage: read %u exceeds the large working memory (code %u)", c->h_ctr->lext_err_read, c->h_ctr->ext_overflow);
+            if (c->h_ctr->lext_unresolved) {
+                static bool warned = false;
+                if (!warned) { warned = true; fprintf(stderr, "[scrubby-hip] WARNING: %u read(s) outgrew the extension stage's largest working memory (e.g. read %u of its batch, code %u: 18 chains, 20 read length, 21 chain anchors, 22 inner RMQ window, 23 seeds, 24 regions, 27-30 alignment window, 32 direction bytes); they keep their chain-level answer (mapped)\n", c->h_ctr->lext_unresolved, c->h_ctr->lext_err_read, c->h_ctr->lext_err_code); }
+            }
         }
         if (getenv("SCRUBBY_HIP_DBG")) fprintf(stderr, "[dbg] long-read extension stage: %u reads with chains, %u re-chained (RMQ), %u with tied RMQ priorities, %u needed the large scratch, %u regions aligned, %u reads dropped\n",
                                                ext_list, c->h_ctr->lext_rechained, c->h_ctr->lext_rmq_tie, c->h_ctr->lext_n_big, c->h_ctr->ext_regions, c->h_ctr->ext_dropped);
+        if (getenv("SCRUBBY_HIP_DBG")) {
+            unsigned long long tot = 0, mr = 0, ma = 0, sr = 0, sa = 0;
+            for (int i = 0; i < LR_NCLK; ++i) tot += c->h_ctr->lext_clk[i];
+            fprintf(stderr, "[dbg] long-read extension stage, share of wave time: gather %.1f  rmq-sort %.1f  rmq-fill %.1f  backtrack+compact %.1f  gen_regs %.1f  parent/select %.1f  squeeze %.1f  region set-up %.1f  ksw %.1f  z-drop test %.1f  update_extra %.1f  staging %.1f %%  (total %.1f wave-s at 100 MHz)\n",
+                    100. * c->h_ctr->lext_clk[0] / (tot + 1), 100. * c->h_ctr->lext_clk[1] / (tot + 1), 100. * c->h_ctr->lext_clk[2] / (tot + 1), 100. * c->h_ctr->lext_clk[3] / (tot + 1), 100. * c->h_ctr->lext_clk[4] / (tot + 1), 100. * c->h_ctr->lext_clk[5] / (tot + 1),
+                    100. * c->h_ctr->lext_clk[6] / (tot + 1), 100. * c->h_ctr->lext_clk[7] / (tot + 1), 100. * c->h_ctr->lext_clk[8] / (tot + 1), 100. * c->h_ctr->lext_clk[9] / (tot + 1), 100. * c->h_ctr->lext_clk[10] / (tot + 1), 100. * c->h_ctr->lext_clk[11] / (tot + 1), tot / 1e8);
+            for (int i = 0; i < SINK_SHARDS; ++i) { sr += c->h_ctr->ext_n_recs[i]; sa += c->h_ctr->ext_n_anch[i]; mr = std::max<unsigned long long>(mr, c->h_ctr->ext_n_recs[i]); ma = std::max<unsigned long long>(ma, c->h_ctr->ext_n_anch[i]); }
+            fprintf(stderr, "[dbg] chain hand-over: %llu chains, %llu anchors; fullest shard %llu / %u chains, %llu / %llu anchors\n", sr, sa, mr, c->sink.cap_recs, ma, c->sink.cap_anch);
+        }
         SH_HIP(hipEventRecord(c->ev_ext[1], s));
         SH_HIP(hipEventSynchronize(c->ev_ext[1]));
         ext_regions = c->h_ctr->ext_regions; ext_dropped = c->h_ctr->ext_dropped;

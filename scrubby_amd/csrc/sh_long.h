@@ -33,7 +33,7 @@ struct LReg {                           // mm_reg1_t, the fields the decision re
 #define LR_PARENT_UNSET (-1)
 #define LR_PARENT_TMP_PRI (-2)
 
-struct SKey { uint64_t k, v; };         // sort element: ascending (k, v)
+struct SKey { uint64_t k, v; uint32_t i, pad; };         // sort element: ascending (k, v); i = payload
 
 struct LongParams {
     int32_t k, min_cnt, min_sc, max_gap, bw, bw_long, min_ksw_len;
@@ -73,7 +73,7 @@ __host__ __device__ inline unsigned long long long_ws_carve(LongWs *W, uint8_t *
     LongWs w{};
     w.a = (LAnchor *)take(ca * 16); w.b = (LAnchor *)take(ca * 16);
     w.f = (int32_t *)take(ca * 4); w.p = (int32_t *)take(ca * 4); w.t = (int32_t *)take(ca * 4); w.v = (int32_t *)take(ca * 4);
-    w.pri = (double *)take(ca * 8); w.sk = (SKey *)take(ca * 16); w.sk2 = (SKey *)take(ca * 16);
+    w.pri = (double *)take(ca * 8); w.sk = (SKey *)take(ca * sizeof(SKey)); w.sk2 = (SKey *)take(ca * sizeof(SKey));
     w.u = (uint64_t *)take(cu * 8); w.uoff = (uint32_t *)take((cu + 1) * 4);
     w.regs = (LReg *)take(cr * sizeof(LReg)); w.cov = (uint64_t *)take(cr * 8); w.wpri = (int32_t *)take(cr * 4);
     w.mini_pos = (uint64_t *)take((unsigned long long)z.cap_m * 8);
@@ -89,7 +89,15 @@ __host__ __device__ inline unsigned long long long_ws_carve(LongWs *W, uint8_t *
 }
 
 // ---- small helpers ---------------------------------------------------------------------------------------------------
-__device__ inline void lr_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __builtin_amdgcn_wave_barrier(); }
+// What one lane stored is what the others load: all of it is traffic of ONE wave through one L1 and one L2, so it takes the stores to
+// have reached the L2 (s_waitcnt) and the L1 to forget what it holds (buffer_inv) - not the agent-scope release of a seq_cst fence, whose
+// L2 write-back made every phase change cost microseconds.
+__device__ inline void lr_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tbuffer_inv sc1" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 __device__ inline uint64_t lr_b0_64(uint64_t v) { return al_b0_64(v); }
 __device__ inline uint64_t lr_readlane64(uint64_t v, int l)
 {
@@ -105,11 +113,11 @@ __device__ inline void lr_sort(SKey *a, SKey *tmp, int32_t n)
     if (n < 2) return;
     for (int32_t t0 = 0; t0 < n; t0 += 64) {       // 64-tiles: rank = number of smaller elements of the tile
         const int32_t i = t0 + lane, m = n - t0 < 64 ? n - t0 : 64;
-        SKey e{~0ull, ~0ull};
+        SKey e{~0ull, ~0ull, 0u, 0u};
         if (i < n) e = a[i];
         int32_t rank = 0;
         for (int32_t l = 0; l < m; ++l) {
-            SKey o; o.k = lr_readlane64(e.k, l); o.v = lr_readlane64(e.v, l);
+            SKey o; o.k = lr_readlane64(e.k, l); o.v = lr_readlane64(e.v, l); o.i = 0; o.pad = 0;
             rank += sk_less(o, e);
         }
         if (i < n) tmp[t0 + rank] = e;
@@ -173,13 +181,12 @@ __device__ inline void lr_reg_set_coor(LReg &r, int32_t qlen, const LAnchor *a)
 // y-sorted copy of the inner window kept in LDS.  With distinct priorities the answers are the trees'; when the minimum is shared by
 // two candidates the tree's choice depends on its shape, which this scan does not have: such reads are reported (*tie) and the
 // caller sends them down the exact serial path.
-#define LRQ_INNER 1024          // active anchors of the inner window kept y-sorted in LDS
-struct RmqLds { int32_t iy[LRQ_INNER]; int32_t ij[LRQ_INNER]; };
+#define LRQ_INNER 1024          // active anchors of the inner window: y-sorted list + a ring of their (x, y, f, p, t) in LDS
+struct RmqLds { int32_t iy[LRQ_INNER], ij[LRQ_INNER]; uint32_t rx[LRQ_INNER]; int32_t ry[LRQ_INNER], rf[LRQ_INNER], rp[LRQ_INNER], rt[LRQ_INNER]; };
 
-__device__ inline int32_t lr_sc_simple(uint64_t xi, uint64_t yi, uint64_t xj, uint64_t yj, float pen_gap, float pen_skip, int32_t &exact, int32_t &width)
+__device__ inline int32_t lr_sc_simple(int32_t dr, int32_t dq, int32_t q_span, float pen_gap, float pen_skip, int32_t &exact, int32_t &width)
 {   // comput_sc_simple
-    const int32_t dq = (int32_t)yi - (int32_t)yj, dr = (int32_t)(xi - xj);
-    const int32_t dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq, q_span = (int32_t)(yj >> 32 & 0xff);
+    const int32_t dd = dr > dq ? dr - dq : dq - dr, dg = dr < dq ? dr : dq;
     int32_t sc = q_span < dg ? q_span : dg;
     width = dd;
     exact = (dd == 0 && dg <= q_span);
@@ -190,38 +197,44 @@ __device__ inline int32_t lr_sc_simple(uint64_t xi, uint64_t yi, uint64_t xj, ui
     }
     return sc;
 }
+__device__ inline double lr_cc_f64(const double *p) { return __longlong_as_double((long long)cc_u64(p)); }
 
-// a[] sorted by x.  Out: f, p (int32; -1 = none).  t: scratch marks, zeroed here.  n_tie: steps whose minimum priority was shared (the
-// smallest index was taken; upstream's tree may pick another).  Returns false when the inner window outgrows LRQ_INNER or the read has
-// more anchors than rmq_size_cap.
-__device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int32_t bw, int32_t n, const LAnchor *a, int32_t *f, int32_t *p, int32_t *t,
-                                   double *pri, RmqLds &L, int32_t &n_tie)
+// a[] sorted by x (read-only here).  Out: f, p (int32; -1 = none) - visible to the other lanes after the caller's lr_sync().  n_tie: steps
+// whose minimum priority was shared (the smallest index was taken; upstream's tree may pick another).  Returns false when the inner window
+// outgrows LRQ_INNER or the read has more anchors than rmq_size_cap.
+// Memory: what a step needs of the recent anchors (f, p, the t marks, x, y) lives in the LDS ring, so no step waits for HBM; the priorities
+// and block minima are written once and read past the L1 (they share cache lines with entries read before they were written).
+__device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int32_t bw, int32_t n, const LAnchor *a, int32_t *f, int32_t *p,
+                                   double *pri, double *bmin /* n / 64 + 1 */, RmqLds &L, int32_t &n_tie)
 {
     n_tie = 0;
     const int32_t lane = (int32_t)al_lane();
+    constexpr int32_t M = LRQ_INNER - 1;
     int32_t max_dist = max_dist_in, max_dist_inner = P.rmq_inner_dist;
     if (max_dist < bw) max_dist = bw;
     if (max_dist_inner < 0) max_dist_inner = 0;
     if (max_dist_inner > max_dist) max_dist_inner = max_dist;
-    if (n > P.rmq_size_cap) return false;          // the size cap evicts out of order: serial path
-    for (int32_t i = lane; i < n; i += 64) t[i] = 0;
-    lr_sync();
-    int32_t i0 = 0, st = 0, st_inner = 0, n_in = 0;      // inner window: L.iy/ij[0 .. n_in) ascending (y, j)
+    if (n > P.rmq_size_cap) return false;          // the size cap evicts out of order: not handled here
+    for (int32_t i = lane; i < LRQ_INNER; i += 64) L.rt[i] = -1;
+    __builtin_amdgcn_wave_barrier();
+    int32_t blk_done = 0;      // blocks [0, blk_done) of 64 anchors are completely inserted; bmin[b] = their smallest priority
+    int32_t i0 = 0, st = 0, st_inner = 0, n_in = 0;      // inner window: L.iy/ij[0 .. n_in) ascending (y, j) = the anchors [st_inner, i0)
     bool ok = true;
     for (int32_t i = 0; i < n && ok; ++i) {
         const uint64_t xi = a[i].x, yi = a[i].y;
-        const int32_t qi = (int32_t)yi;
+        const int32_t qi = (int32_t)yi, q_span_i = (int32_t)(yi >> 32 & 0xff);
         // add the anchors whose x is now strictly smaller
         if (i0 < i && a[i0].x != xi) {
+            if (i - i0 > LRQ_INNER) { ok = false; break; }
             for (int32_t jb = i0; jb < i; jb += 64) {
                 const int32_t j = jb + lane;
-                if (j < i) pri[j] = -((double)f[j] + 0.5 * (double)P.pen_gap * (double)((int32_t)a[j].x + (int32_t)a[j].y));
+                if (j < i) pri[j] = -((double)L.rf[j & M] + 0.5 * (double)P.pen_gap * (double)((int32_t)L.rx[j & M] + L.ry[j & M]));
             }
             if (max_dist_inner > 0) {
                 for (int32_t j = i0; j < i; ++j) {      // insert (y_j, j) into the y-sorted inner window
                     if (n_in >= LRQ_INNER) { ok = false; break; }
-                    const int32_t yj = (int32_t)a[j].y;
-                    // position: first element greater than (yj, j); j is the largest index so far: behind every equal y
+                    const int32_t yj = L.ry[j & M];
+                    // position: behind every element with y <= yj (j is the largest index so far)
                     int32_t pos = 0;
                     for (int32_t c = 0; c < n_in; c += 64) { const int32_t e = c + lane; pos += (int32_t)__popcll(__ballot(e < n_in && L.iy[e] <= yj)); }
                     for (int32_t c = ((n_in - pos + 63) / 64 - 1) * 64; c >= 0; c -= 64) {      // shift [pos, n_in) up by one, from the top
@@ -240,7 +253,17 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 if (!ok) break;
             }
             i0 = i;
-            lr_sync();
+            if ((blk_done + 1) * 64 <= i0) {      // blocks completed by this insertion: their priorities must have reached L2 first
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                while ((blk_done + 1) * 64 <= i0) {
+                    double m = lr_cc_f64(pri + blk_done * 64 + lane);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) { const double om = __shfl_xor(m, o); m = om < m ? om : m; }
+                    if (lane == 0) bmin[blk_done] = m;
+                    ++blk_done;
+                }
+            }
         }
         // anchors out of range leave
         while (st < i && (xi >> 32 != a[st].x >> 32 || xi > a[st].x + (uint64_t)max_dist)) ++st;
@@ -264,44 +287,57 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 n_in = kept;
             }
         }
-        int32_t max_f = (int32_t)(yi >> 32 & 0xff), max_j = -1;
-        // (1) range minimum of the priority over the active anchors [st, i0) with (y_j, j) in [(q_i - max_dist, INT32_MAX), (q_i, 0)]
+        // a ring slot may only be reused once its anchor has left the inner window
+        if (i - st_inner >= LRQ_INNER) { ok = false; break; }
+        int32_t max_f = q_span_i, max_j = -1;
+        // (1) range minimum of the priority over the active anchors [st, i0) with (y_j, j) in [(q_i - max_dist, INT32_MAX), (q_i, 0)].
+        // The anchors are visited newest first in blocks of 64; a completed block whose smallest priority (bmin, whatever its y) is above the
+        // best found so far cannot hold the answer or a tie with it and is skipped - the answer is nearly always among the newest anchors.
         double bp = 0.0; int32_t bj = -1, ties = 0;
         {
-            double mp = 0.0; int32_t mj = -1;
-            for (int32_t jb = st; jb < i0; jb += 64) {
-                const int32_t j = jb + lane;
-                if (j < i0) {
+            auto eval = [&](int32_t j, bool cand) {      // one candidate per lane
+                bool in = false; double pj = 0.0;
+                if (cand) {
                     const int32_t yj = (int32_t)a[j].y;
-                    const bool in = yj > qi - max_dist && (yj < qi || (yj == qi && j == 0));
-                    if (in) { const double pj = pri[j]; if (mj < 0 || pj < mp) { mp = pj; mj = j; } }      // within a lane ties keep the first: counted below
+                    in = yj > qi - max_dist && (yj < qi || (yj == qi && j == 0));
+                    if (in) pj = lr_cc_f64(pri + j);
                 }
-            }
-            // wave arg-min; equal priorities are counted over the whole window in a second sweep only when the minimum is found
-            double wm = mp; int32_t wj = mj;
+                const uint64_t im = __ballot(in);
+                if (im == 0) return;
+                double wm = pj; int32_t wj = in ? j : -1;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double om = __shfl_xor(wm, o); const int32_t oj = __shfl_xor(wj, o);
-                if (oj >= 0 && (wj < 0 || om < wm || (om == wm && oj < wj))) { wm = om; wj = oj; }
-            }
-            bp = wm; bj = wj;
-            if (bj >= 0) {
-                for (int32_t jb = st; jb < i0; jb += 64) {
-                    const int32_t j = jb + lane;
-                    bool eq = false;
-                    if (j < i0) {
-                        const int32_t yj = (int32_t)a[j].y;
-                        const bool in = yj > qi - max_dist && (yj < qi || (yj == qi && j == 0));
-                        eq = in && pri[j] == bp;
-                    }
-                    ties += (int32_t)__popcll(__ballot(eq));
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double om = __shfl_xor(wm, o); const int32_t oj = __shfl_xor(wj, o);
+                    if (oj >= 0 && (wj < 0 || om < wm || (om == wm && oj < wj))) { wm = om; wj = oj; }
+                }
+                const int32_t c = (int32_t)__popcll(__ballot(in && pj == wm));
+                if (bj < 0 || wm < bp) { bp = wm; bj = wj; ties = c; }
+                else if (wm == bp) { ties += c; bj = wj < bj ? wj : bj; }
+            };
+            const int32_t part = blk_done * 64 > st ? blk_done * 64 : st;      // the newest, not yet completed block
+            if (part < i0) { const int32_t j = part + lane; eval(j, j < i0); }
+            const int32_t b_lo = st >> 6;
+            for (int32_t bt = blk_done - 1; bt >= b_lo; bt -= 64) {
+                const int32_t b = bt - lane;
+                bool todo = b >= b_lo;
+                const double v = todo ? lr_cc_f64(bmin + b) : 0.0;
+                for (;;) {
+                    const uint64_t m = __ballot(todo && (bj < 0 || v <= bp));
+                    if (m == 0) break;
+                    const int l = __ffsll((unsigned long long)m) - 1;      // lane l holds the newest such block
+                    const int32_t bb = bt - l, j = bb * 64 + lane;
+                    eval(j, j >= st);
+                    if (lane == l) todo = false;
                 }
             }
         }
         if (bj >= 0) {
             if (ties > 1) ++n_tie;      // the smallest index among the equal priorities is taken; the caller reports the read
             int32_t exact, width, n_skip = 0;
-            int32_t sc = f[bj] + lr_sc_simple(xi, yi, a[bj].x, a[bj].y, P.pen_gap, P.pen_skip, exact, width);
+            int32_t fb, dr, dq, span_b;
+            if (bj >= st_inner && i - bj < LRQ_INNER) { fb = L.rf[bj & M]; dr = (int32_t)((uint32_t)xi - L.rx[bj & M]); dq = qi - L.ry[bj & M]; span_b = P.k; }
+            else { fb = (int32_t)cc_u32(f + bj); dr = (int32_t)(xi - a[bj].x); dq = qi - (int32_t)a[bj].y; span_b = (int32_t)(a[bj].y >> 32 & 0xff); }
+            int32_t sc = fb + lr_sc_simple(dr, dq, span_b, P.pen_gap, P.pen_skip, exact, width);
             if (width <= bw && sc > max_f) { max_f = sc; max_j = bj; }
             if (!exact && n_in > 0 && qi > 0) {
                 // (2) the inner window from the largest (y, j) <= (q_i - 1, n) downwards, while y >= q_i - max_dist_inner
@@ -317,13 +353,13 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                     if (valid) {
                         j = L.ij[e];
                         int32_t ex2, w2;
-                        scj = f[j] + lr_sc_simple(xi, yi, a[j].x, a[j].y, P.pen_gap, P.pen_skip, ex2, w2);
+                        scj = L.rf[j & M] + lr_sc_simple((int32_t)((uint32_t)xi - L.rx[j & M]), qi - L.ry[j & M], P.k, P.pen_gap, P.pen_skip, ex2, w2);
                         has = w2 <= bw;
-                        pj = p[j];
+                        pj = L.rp[j & M];
                     }
-                    if (has && pj >= 0) t[pj] = i;
-                    lr_sync();
-                    const bool is_t = has && t[j] == i;
+                    if (has && pj >= st_inner) L.rt[pj & M] = i;      // a mark only matters on an anchor this scan can still visit
+                    __builtin_amdgcn_wave_barrier();
+                    const bool is_t = has && L.rt[j & M] == i;
                     const int32_t scv = has ? scj : INT32_MIN;
                     const int32_t incl = wave_scan_max_incl(scv);
                     int32_t excl = wave_shr1(incl, INT32_MIN);
@@ -350,8 +386,11 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 }
             }
         }
-        if (lane == 0) { f[i] = max_f; p[i] = max_j; }
-        lr_sync();
+        if (lane == 0) {
+            f[i] = max_f; p[i] = max_j;
+            L.rx[i & M] = (uint32_t)xi; L.ry[i & M] = qi; L.rf[i & M] = max_f; L.rp[i & M] = max_j;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     return ok;
 }
@@ -713,8 +752,13 @@ struct LongIn {
     const uint4 *rec; const uint32_t *k1info; const unsigned long long *seed_off; uint32_t seed_cap;      // the reads' seed records
 };
 
+// where a wave's time goes (SCRUBBY_HIP_DBG): 0 gather, 1 rmq sort, 2 rmq fill, 3 backtrack + compact, 4 gen_regs, 5 parent / select / est_err, 6 squeeze,
+// 7 region set-up (bad ends / seeds, windows), 8 ksw, 9 z-drop test, 10 update_extra, 11 sequence staging
+#define LR_NCLK 12
+struct LongClk { unsigned long long t[LR_NCLK]; unsigned long long last; };
+__device__ inline void lr_tick(LongClk *c, int ph) { if (c) { const unsigned long long now = wall_clock64(); c->t[ph] += now - c->last; c->last = now; } }
 struct LongCtx {
-    const LongParams *P; const AlignParams *AP; const LongIn *I; LongWs *W; AlignLds *Ls; AlignScratch A;
+    const LongParams *P; const AlignParams *AP; const LongIn *I; LongWs *W; AlignLds *Ls; AlignScratch A; LongClk *clk;
     int32_t qlen; uint32_t read;
     int8_t sc_mch, sc_mis, sc_amb, sc_N;
     bool need_big;                   // an alignment does not fit this wave's direction-byte buffer: the read goes to the large-scratch pass
@@ -735,9 +779,11 @@ __device__ inline bool lr_align_pair(LongCtx &C, int32_t qlen, const uint8_t *qs
     if (p_need > C.W->cap_p) { C.need_big = true; return false; }
     const int32_t T16 = (tlen + 15) / 16 * 16, Q16 = (qlen + 15) / 16 * 16;
     const bool mem_lds = T16 <= AL_T16 && Q16 <= AL_Q16;
+    lr_tick(C.clk, 11);
     if (mem_lds) ksw_extd2_core<false, true>(qlen, qseq, false, tlen, tseq, false, C.sc_mch, C.sc_mis, C.sc_N, P.q, P.e, P.q2, P.e2, w, zdrop, end_bonus, flag, ez, C.W->ez_cigar, C.A, *C.Ls);
     else ksw_extd2_core<true, true>(qlen, qseq, false, tlen, tseq, false, C.sc_mch, C.sc_mis, C.sc_N, P.q, P.e, P.q2, P.e2, w, zdrop, end_bonus, flag, ez, C.W->ez_cigar, C.A, *C.Ls);
     lr_sync();
+    lr_tick(C.clk, 8);
     return true;
 }
 
@@ -803,7 +849,7 @@ __device__ inline int32_t lr_test_zdrop(LongCtx &C, const uint8_t *qseq, const u
 
 // One region.  r / r2 live in registers (uniform); the caller stores them.  a = the squeezed anchors, n_a their number.
 // flag_only: stop as soon as the region is known to survive mm_filter_regs is NOT done here: this is the complete procedure.
-__device__ inline bool lr_align1(LongCtx &C, LReg &r, LReg &r2, LAnchor *a, int32_t n_a)
+__device__ inline bool lr_align1(LongCtx &C, LReg &r, LReg &r2, LAnchor *a, int32_t n_a, int32_t pre_as1 = -1, int32_t pre_cnt1 = 0)
 {
     const LongParams &P = *C.P;
     LongWs &W = *C.W;
@@ -817,7 +863,9 @@ __device__ inline bool lr_align1(LongCtx &C, LReg &r, LReg &r2, LAnchor *a, int3
     int32_t bw_long = (int32_t)(P.bw_long * 1.5 + 1.);
     if (bw_long < bw) bw_long = bw;
     int32_t as1, cnt1;
-    lr_fix_bad_ends0(r, a, P.bw, P.min_sc * 2, as1, cnt1);
+    lr_tick(C.clk, 6);
+    if (pre_as1 >= 0) { as1 = pre_as1; cnt1 = pre_cnt1; }      // a probe of this region ran first: mm_fix_bad_ends must not see the flags its seed filters left
+    else lr_fix_bad_ends0(r, a, P.bw, P.min_sc * 2, as1, cnt1);
     if (lane == 0) {
         lr_filter_bad_seeds0(as1, cnt1, a, 10, 40, P.max_gap >> 1, 10, W.K);
         lr_filter_bad_seeds_alt0(as1, cnt1, a, 30, P.max_gap >> 1, W.K);
@@ -877,6 +925,7 @@ __device__ inline bool lr_align1(LongCtx &C, LReg &r, LReg &r2, LAnchor *a, int3
     } else { re0 = re; qe0 = qe; }
     if ((uint32_t)(re0 - rs0 > 0 ? re0 - rs0 : 0) + 16 > W.cap_t) { C.err = 13; return false; }
 
+    lr_tick(C.clk, 7);
     uint8_t *qrow = W.qseq + (rev ? qlen : 0), *tseq = W.tseq;
     uint32_t *rc = W.r_cigar, *ezc = W.ez_cigar;
     int32_t rn = 0, dropped = 0;
@@ -909,6 +958,7 @@ __device__ inline bool lr_align1(LongCtx &C, LReg &r, LReg &r2, LAnchor *a, int3
             lr_getseq(C, rid, rs, re, tseq);
             if (!lr_align_pair(C, qe - qs, qrow + qs, re - rs, tseq, bw1, -1, P.zdrop, EZ_APPROX_MAX, ez)) return false;      // first pass: approximate maximum
             zdrop_code = lr_test_zdrop(C, qrow + qs, tseq, ez.n_cigar, ezc);
+            lr_tick(C.clk, 9);
             if (C.err) return false;
             if (zdrop_code != 0) {
                 if (!lr_align_pair(C, qe - qs, qrow + qs, re - rs, tseq, bw1, -1, zdrop_code == 2 ? P.zdrop_inv : P.zdrop, 0, ez)) return false;
@@ -954,6 +1004,7 @@ __device__ inline bool lr_align1(LongCtx &C, LReg &r, LReg &r2, LAnchor *a, int3
 
     r.rs = rs1; r.re = re1;
     if (rev) { r.qs = qlen - qe1; r.qe = qlen - qs1; } else { r.qs = qs1; r.qe = qe1; }
+    lr_tick(C.clk, 11);
     if (r.has_p) {
         if ((uint32_t)(re1 - rs1 > 0 ? re1 - rs1 : 0) + 16 > W.cap_t) { C.err = 13; return false; }
         lr_getseq(C, rid, rs1, re1, tseq);
@@ -964,6 +1015,7 @@ __device__ inline bool lr_align1(LongCtx &C, LReg &r, LReg &r2, LAnchor *a, int3
             v[0] = mlen; v[1] = blen; v[2] = dpm; v[3] = r.qs; v[4] = r.qe; v[5] = r.rs;
         }
         r.mlen = al_b0(v[0]); r.blen = al_b0(v[1]); r.dp_max = al_b0(v[2]); r.qs = al_b0(v[3]); r.qe = al_b0(v[4]); r.rs = al_b0(v[5]);
+        lr_tick(C.clk, 10);
     }
     return true;
 }
@@ -1018,8 +1070,133 @@ __device__ inline int32_t lr_align1_inv(LongCtx &C, const LReg &r1, const LReg &
     return 1;
 }
 
+
+// ---- flag-only calls: a region is known to survive mm_filter_regs long before it is completely aligned ---------------------------------
+// The boundary returns `mappings.len() > 0`; one surviving region settles a read.  mm_align1 assembles a region's CIGAR as
+// left extension + gap fillings + right extension and mm_update_extra reads mlen and dp_max off it; dp_max is the maximum of a running
+// score that is clamped at zero.  Take the gap fillings of the first anchors alone, C = seg_1 + ... + seg_i (no z-drop among them), and
+// let M_1 .. M_g be the match runs of mm_fix_cigar(C).  Whatever the rest of the region turns out to be, the final CIGAR F = left + C + rest:
+//   * mm_fix_cigar(F) equals mm_fix_cigar(C) on every operation from M_1 to M_{g-1}: left-alignment moves an indel into the match run in
+//     front of it only, the I/D merging stops at a non-empty match run, so what lies outside C can lengthen M_1 at its front, shorten or
+//     swallow M_g and re-pair the gaps next to it, nothing more;
+//   * left-alignment re-pairs equal bases only, so the matching columns of C are matching columns of F: mlen(F) >= mlen(C);
+//   * a clamped running score started at zero at M_1 never exceeds the true one (which is >= 0 there and sees the same columns): the largest
+//     value it takes up to the end of M_{g-1} is a lower bound of dp_max(F);
+//   * a z-drop in a later gap filling cuts the region behind C and leaves it as many anchors as lie `k/2 + 1` before C's last one
+//     (mm_align1's split rule), which is checked; max_clip_ratio >= 1 disables the clip test (checked on the host).
+// So mlen(C) >= min_chain_score, that bound >= min_dp_max and enough anchors prove the region is kept - typically after one gap filling
+// of ~200 bases instead of the whole read.  A region the probe cannot vouch for takes the complete procedure.
+__device__ inline int32_t lr_probe_eval0(const LongCtx &C, uint32_t *pc, int32_t n_pc, uint32_t *tmp, const uint8_t *qseq, const uint8_t *tseq)
+{   // lane 0.  1: proven
+    const LongParams &P = *C.P;
+    int32_t mlen = 0;
+    {
+        int32_t toff = 0, qoff = 0;
+        for (int32_t k = 0; k < n_pc; ++k) {
+            const uint32_t op = pc[k] & 0xf, len = pc[k] >> 4;
+            if (op == 0) {
+                for (uint32_t l = 0; l < len; ++l) { const int32_t cq = qseq[qoff + (int32_t)l], ct = tseq[toff + (int32_t)l]; mlen += (ct <= 3 && cq <= 3 && ct == cq); }
+                toff += (int32_t)len; qoff += (int32_t)len;
+            } else if (op == 1) qoff += (int32_t)len;
+            else toff += (int32_t)len;
+        }
+    }
+    if (mlen < P.min_sc) return 0;
+    for (int32_t k = 0; k < n_pc; ++k) tmp[k] = pc[k];
+    int32_t n = n_pc, qshift = 0, tshift = 0;
+    LReg dummy{};
+    fix_cigar0(dummy, tmp, n, qseq, false, tseq, false, qshift, tshift);
+    qseq += qshift; tseq += tshift;
+    int32_t first_m = -1, last_m = -1;
+    for (int32_t k = 0; k < n; ++k) if ((tmp[k] & 0xf) == 0 && (tmp[k] >> 4) != 0) { if (first_m < 0) first_m = k; last_m = k; }
+    if (first_m < 0 || last_m == first_m) return 0;
+    int32_t toff = 0, qoff = 0;
+    double sc = 0.0, mx = 0.0;
+    for (int32_t k = 0; k < last_m; ++k) {
+        const uint32_t op = tmp[k] & 0xf, len = tmp[k] >> 4;
+        if (op == 0) {
+            if (k >= first_m) {
+                for (uint32_t l = 0; l < len; ++l) {
+                    const int32_t cq = qseq[qoff + (int32_t)l], ct = tseq[toff + (int32_t)l];
+                    sc += (ct > 3 || cq > 3) ? C.sc_amb : (ct == cq ? C.sc_mch : C.sc_mis);
+                    if (sc < 0) sc = 0; else mx = mx > sc ? mx : sc;
+                }
+            }
+            toff += (int32_t)len; qoff += (int32_t)len;
+        } else {
+            if (k > first_m) { sc -= P.q + (double)P.e * al_mg_log2((float)(1.0 + len)); if (sc < 0) sc = 0; }
+            if (op == 1) qoff += (int32_t)len; else toff += (int32_t)len;
+        }
+    }
+    return (int32_t)(mx + .499) >= P.min_dp_max ? 1 : 0;
+}
+
+// 1: the region survives; 0: unknown (take the complete procedure); -1: stop (C.need_big / C.err)
+__device__ inline int32_t lr_probe_region(LongCtx &C, const LReg &r, LAnchor *a, int32_t &as1, int32_t &cnt1)
+{
+    const LongParams &P = *C.P;
+    LongWs &W = *C.W;
+    const uint32_t lane = al_lane();
+    const int32_t hk = P.k >> 1;
+    as1 = -1; cnt1 = 0;
+    if (r.cnt == 0 || r.inv || !(P.max_clip_ratio >= 1.0f)) return 0;
+    const int32_t rid = (int32_t)(a[r.as].x << 1 >> 33), rev = (int32_t)(a[r.as].x >> 63);
+    int32_t bw_long = (int32_t)(P.bw_long * 1.5 + 1.);
+    { const int32_t bw = (int32_t)(P.bw * 1.5 + 1.); if (bw_long < bw) bw_long = bw; }
+    lr_fix_bad_ends0(r, a, P.bw, P.min_sc * 2, as1, cnt1);
+    if (lane == 0) {
+        lr_filter_bad_seeds0(as1, cnt1, a, 10, 40, P.max_gap >> 1, 10, W.K);
+        lr_filter_bad_seeds_alt0(as1, cnt1, a, 30, P.max_gap >> 1, W.K);
+    }
+    lr_sync();
+    const int32_t rs_first = (int32_t)a[as1].x - hk, qs_first = (int32_t)a[as1].y - hk;
+    int32_t rs = rs_first, qs = qs_first, n_pc = 0, n_seg = 0;
+    uint8_t *qrow = W.qseq + (rev ? C.qlen : 0), *tseq = W.tseq;
+    uint32_t *pc = W.r_cigar, *ezc = W.ez_cigar, *tmp = (uint32_t *)W.K;
+    Ez ez;
+    for (int32_t i = 1; i < cnt1 && n_seg < 6; ++i) {
+        const uint64_t ay = a[as1 + i].y;
+        if ((ay & (LY_IGNORE | LY_TANDEM)) && i != cnt1 - 1) continue;
+        const int32_t re = (int32_t)a[as1 + i].x - hk, qe = (int32_t)ay - hk;
+        if (!(i == cnt1 - 1 || (ay & LY_LONG_JOIN) || (qe - qs >= P.min_ksw_len && re - rs >= P.min_ksw_len))) continue;
+        int32_t bw1 = bw_long;
+        if (ay & LY_LONG_JOIN) bw1 = qe - qs > re - rs ? qe - qs : re - rs;
+        if ((uint32_t)(re - rs_first > 0 ? re - rs_first : 0) + 16 > W.cap_t) return 0;
+        // an alignment the first pass's buffers do not hold is not worth probing: the complete procedure deals with it
+        {
+            const int32_t ql = qe - qs, tl = re - rs;
+            if (ql <= 0 || tl <= 0 || (long long)ql * tl > 4000000ll) return 0;
+        }
+        lr_getseq(C, rid, rs, re, tseq);
+        if (!lr_align_pair(C, qe - qs, qrow + qs, re - rs, tseq, bw1, -1, P.zdrop, EZ_APPROX_MAX, ez)) { if (C.need_big) { C.need_big = false; return 0; } return -1; }
+        const int32_t zdrop_code = lr_test_zdrop(C, qrow + qs, tseq, ez.n_cigar, ezc);
+        if (C.err) return -1;
+        if (zdrop_code != 0) {
+            if (!lr_align_pair(C, qe - qs, qrow + qs, re - rs, tseq, bw1, -1, zdrop_code == 2 ? P.zdrop_inv : P.zdrop, 0, ez)) { if (C.need_big) { C.need_big = false; return 0; } return -1; }
+        }
+        if (ez.zdropped || ez.n_cigar == 0) return 0;
+        if ((uint32_t)(n_pc + ez.n_cigar + 8) > W.cap_a || (uint32_t)(n_pc + ez.n_cigar + 8) > W.cap_c) return 0;
+        if (lane == 0) append_cigar0(pc, n_pc, ez.n_cigar, ezc);
+        n_pc = al_b0(n_pc);
+        ++n_seg;
+        rs = re; qs = qe;
+        // anchors the region keeps if a later gap filling drops right behind this one
+        int32_t jstar = i;
+        while (jstar >= 0 && (int32_t)a[as1 + jstar].x > (int32_t)a[as1 + i].x - hk - 1) --jstar;
+        if ((as1 - r.as) + jstar + 1 < P.min_cnt) continue;
+        lr_getseq(C, rid, rs_first, re, tseq);
+        int32_t ok = 0;
+        if (lane == 0) ok = lr_probe_eval0(C, pc, n_pc, tmp, qrow + qs_first, tseq);
+        ok = al_b0(ok);
+        lr_tick(C.clk, 10);
+        if (ok) return 1;
+    }
+    return 0;
+}
+
 // ---- the whole stage for one read ---------------------------------------------------------------------------------------------------
-struct LongOut { int32_t n_chain, best, rechained, n_aligned, n_regs, dp_max; uint32_t sig; int32_t rmq_tie; };
+struct LongOut { int32_t n_chain, best, rechained, n_aligned, n_regs, dp_max; uint32_t sig; int32_t rmq_tie, probed; };
+
 
 __device__ inline bool lr_region_kept(const LongParams &P, int32_t qlen, const LReg &r)
 {   // mm_filter_regs, one region
@@ -1033,8 +1210,9 @@ __device__ inline bool lr_region_kept(const LongParams &P, int32_t qlen, const L
     return !flt;
 }
 
-// 0: done; 1: the read needs the large-scratch pass; 3: a capacity was exceeded (C.err)
-__device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds &RL, bool flag_only, LongOut &out)
+// 0: done; 1: an alignment needs a larger direction-byte buffer; 3: another capacity of the working memory was exceeded (C.err).
+// Either way the caller hands the read to the pass with the large working memory.
+__device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds &RL, bool flag_only, bool probe, LongOut &out)
 {
     const LongParams &P = *C.P;
     LongWs &W = *C.W;
@@ -1042,7 +1220,7 @@ __device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds
     const int32_t lane = (int32_t)al_lane();
     const uint32_t read = C.read;
     const int32_t qlen = C.qlen;
-    out.n_chain = out.best = out.rechained = out.n_aligned = out.n_regs = out.dp_max = 0; out.sig = 0; out.rmq_tie = 0;
+    out.n_chain = out.best = out.rechained = out.n_aligned = out.n_regs = out.dp_max = 0; out.sig = 0; out.rmq_tie = 0; out.probed = 0;
     if ((uint32_t)qlen > W.cap_q) { C.err = 4; return 3; }
 
     // ---- the read's chains, in compact_a's order: by the first anchor's x, ties in discovery order (larger (f, index) first)
@@ -1056,25 +1234,11 @@ __device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds
     lr_sync();
     for (int32_t i = lane; i < n_u; i += 64) {
         const ChainRec rc = in.recs[W.K[i]];
-        W.sk[i].k = in.cx[rc.off]; W.sk[i].v = (uint64_t)rc.key_f << 32 | rc.key_i;
+        W.sk[i].k = in.cx[rc.off]; W.sk[i].v = ~((uint64_t)rc.key_f << 32 | rc.key_i); W.sk[i].i = (uint32_t)W.K[i];      // of equal x the earlier discovery first
     }
     lr_sync();
-    for (int32_t i0 = 0; i0 < n_u; i0 += 64) {
-        const int32_t i = i0 + lane;
-        const bool on = i < n_u;
-        const uint64_t xi = on ? W.sk[i].k : 0, ki = on ? W.sk[i].v : 0;
-        int32_t rank = 0;
-        for (int32_t j0 = 0; j0 < n_u; j0 += 64) {
-            const int32_t jm = j0 + lane;
-            const uint64_t xj_ = jm < n_u ? W.sk[jm].k : 0, kj_ = jm < n_u ? W.sk[jm].v : 0;
-            const int32_t lim = n_u - j0 < 64 ? n_u - j0 : 64;
-            for (int32_t l = 0; l < lim; ++l) {
-                const uint64_t xj = lr_readlane64(xj_, l), kj = lr_readlane64(kj_, l);
-                rank += (xj < xi) || (xj == xi && kj > ki);
-            }
-        }
-        if (on) W.v[rank] = W.K[i];
-    }
+    lr_sort(W.sk, W.sk2, n_u);
+    for (int32_t i = lane; i < n_u; i += 64) W.v[i] = (int32_t)W.sk[i].i;
     lr_sync();
     int32_t n_a = 0;
     {
@@ -1109,6 +1273,7 @@ __device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds
         lr_sync();
     }
     LAnchor *A0 = W.a, *B0 = W.b;
+    if (C.clk) C.clk->last = wall_clock64();
     for (int32_t c = 0; c < n_u; ++c) {
         const ChainRec rc = in.recs[W.v[c]];
         const uint32_t o = W.uoff[c];
@@ -1129,6 +1294,7 @@ __device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds
         out.best = best;
     }
 
+    lr_tick(C.clk, 0);
     // ---- mm_map_frag: re-chain / long join
     if (P.bw_long > P.bw && n_u > 1) {
         const int32_t st = (int32_t)A0[0].y, en = (int32_t)A0[(int32_t)(uint32_t)W.u[0] - 1].y;
@@ -1140,7 +1306,10 @@ __device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds
             for (int32_t i = lane; i < n_a; i += 64) B0[i] = A0[W.sk[i].v];
             lr_sync();
             int32_t tie = 0;
-            if (!lr_rmq_fill(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.t, W.pri, RL, tie)) { C.err = 6; return 3; }
+            lr_tick(C.clk, 1);
+            if (!lr_rmq_fill(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie)) { C.err = 6; return 3; }
+            lr_sync();
+            lr_tick(C.clk, 2);
             out.rmq_tie = tie;
             // mg_chain_backtrack
             int32_t n_z = 0;
@@ -1201,6 +1370,7 @@ __device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds
         }
     }
 
+    lr_tick(C.clk, 3);
     // ---- mm_gen_regs: regions in descending z = (score << 32 | cnt) ^ h; of equal z the later chain first
     uint32_t hash = 0;
     hash ^= al_wang((uint32_t)qlen) + al_wang(11u);
@@ -1223,6 +1393,7 @@ __device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds
         W.regs[j] = r;
     }
     lr_sync();
+    lr_tick(C.clk, 4);
     // ---- chain_post, mm_est_err, mm_filter_strand_retained (lane 0)
     int32_t n_regs = n_u;
     {
@@ -1259,6 +1430,7 @@ __device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds
         if (al_b0(res[1])) { C.err = 7; return 3; }
     }
     lr_sync();
+    lr_tick(C.clk, 5);
     out.n_aligned = n_regs;
 
     // ---- mm_align_skeleton: the query on both strands, mm_squeeze_a, the regions one after the other
@@ -1292,6 +1464,7 @@ __device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds
     }
     lr_sync();
 
+    lr_tick(C.clk, 6);
     uint32_t sig = 2166136261u;
     int32_t n_keep = 0, dp_best = 0;
     auto account = [&](const LReg &r) {      // a region that mm_filter_regs keeps (uniform)
@@ -1313,7 +1486,13 @@ __device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds
     for (int32_t i = 0; i < n_regs; ++i) {
         LReg r = W.regs[i], r2;
         r2.cnt = 0;
-        if (!lr_align1(C, r, r2, A0, n_sq)) return C.need_big ? 1 : 3;
+        int32_t pre_as1 = -1, pre_cnt1 = 0;
+        if (flag_only && probe) {
+            const int32_t pr = lr_probe_region(C, r, A0, pre_as1, pre_cnt1);
+            if (pr < 0) return C.need_big ? 1 : 3;
+            if (pr > 0) { out.n_regs = 1; out.probed = 1; return 0; }
+        }
+        if (!lr_align1(C, r, r2, A0, n_sq, pre_as1, pre_cnt1)) return C.need_big ? 1 : 3;
         if (lane == 0) W.regs[i] = r;
         lr_sync();
         if (r2.cnt > 0 && !insert_after(i, r2)) return 3;
