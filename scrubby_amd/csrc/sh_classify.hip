@@ -72,8 +72,8 @@ struct Counters {
     uint32_t ext_s3[8];           // SCRUBBY_HIP_DBG & 16: outcome of the local-cluster shortcut (k_expand): 0 tried, 1 no singleton / filtered seed, 2 singletons apart, 3 window grew / too many, 4 K > 64, 5 no margin over U_out, 6 lemma, 7 decided
     uint32_t ext_overflow, ext_n_list, ext_ticket, ext_regions, ext_dropped, ext_n_redo, ext_n_list2, ext_ticket2, ext_n_redo2, ext_ticket3;      // extension stage (sh_align.h)
     uint32_t ext_n_recs[SINK_SHARDS]; unsigned long long ext_n_anch[SINK_SHARDS];                 // hand-over cursors, one per shard
-    uint32_t lext_n_big, lext_ticket_big, lext_rechained, lext_rmq_tie, lext_err_read, lext_unresolved, lext_err_code, lext_pad;
-    unsigned long long lext_clk[LR_NCLK];  // long-read extension stage (sh_long.h): reads for the large-scratch pass, RMQ re-chains, steps with tied priorities
+    uint32_t lext_n_big, lext_ticket_big, lext_n_big2, lext_ticket_big2, lext_ticket_b, lext_pad2, lext_rechained, lext_rmq_tie, lext_err_read, lext_unresolved, lext_err_code, lext_pad;
+    unsigned long long lext_clk[LR_NCLK], lext_d[8];  // long-read extension stage (sh_long.h): reads for the large-scratch pass, RMQ re-chains, steps with tied priorities
     uint32_t n_cl[4], cl_ticket, pad3;      // global queue of big clusters (k_cluster_dp), by size class
     uint32_t n_leg_reason[4];     // why reads left the long-read front end: 0 room/segments, 1 thinning screen, 2 anchors beyond the giant path, 3 unused
     unsigned long long arena_cursor, anchor_cursor;
@@ -2551,23 +2551,34 @@ __global__ __launch_bounds__(64) void k_regs_align(ExtArgs a)
 
 
 // ------------------------------------------------------------------------------------------------
-// extension stage, long-read presets (sh_long.h): one wave per read with at least one chain
+// extension stage, long-read presets (sh_long.h): one wave per read with at least one chain, two kernels
 // ------------------------------------------------------------------------------------------------
 struct ExtLongArgs {
     LongIn I; LongParams P; AlignParams AP; ChainParams CP;
-    uint8_t *scratch; unsigned long long scratch_per_wave; LongSizes sz;
-    uint32_t *list; uint32_t *n_list, *ticket; uint32_t *big_list; Counters *ctr; uint8_t *flags; sh_trace *trace; int32_t flag_only, clk, probe;
+    uint8_t *scratch; unsigned long long scratch_per_wave; LongSizes sz; LongArena AR;
+    uint32_t *list; uint32_t *n_list, *ticket; uint32_t *big_list; uint32_t *n_big; Counters *ctr; uint8_t *flags; sh_trace *trace; int32_t flag_only, clk, probe;
 };
 
-__global__ __launch_bounds__(64) void k_regs_align_long(ExtLongArgs a)
+// a read that outgrew the pass: to the pass with the large working memory, or - beyond that too - it keeps its chain-level answer and is counted
+__device__ inline void lext_defer(const ExtLongArgs &a, uint32_t r, uint32_t code, bool has_hdr)
 {
-    __shared__ AlignLds Ls;
-    __shared__ RmqLds RL;
+    if (a.big_list) { a.big_list[atomicAdd(a.n_big, 1u)] = r; return; }
+    a.flags[r] = 1;
+    if (a.trace) ((int32_t *)(a.trace + r))[7] = 1;
+    if (!has_hdr) { LongHdr h{0ull, -1, 0, 0, 0}; a.AR.hdr[r] = h; }
+    atomicAdd(&a.ctr->lext_unresolved, 1u); atomicExch(&a.ctr->lext_err_read, r); atomicExch(&a.ctr->lext_err_code, code);
+}
+
+template <int NR>
+__global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
+{
+    __shared__ RmqLdsT<NR> RL;
     const uint32_t lane = threadIdx.x;
+    const LongParams P_l = a.P; const LongIn I_l = a.I; const LongArena AR_l = a.AR;      // no pointers into the kernel-argument struct
     LongWs W;
     long_ws_carve(&W, a.scratch + (unsigned long long)blockIdx.x * a.scratch_per_wave, a.sz);
     const uint32_t n_list = *a.n_list;
-    uint32_t n_regions = 0, n_dropped = 0, n_rechain = 0, n_tie = 0, n_probed = 0;
+    uint32_t n_rechain = 0, n_tie = 0;
     LongClk clk{};
     for (;;) {
         uint32_t t = 0;
@@ -2576,26 +2587,52 @@ __global__ __launch_bounds__(64) void k_regs_align_long(ExtLongArgs a)
         if (t >= n_list) break;
         const uint32_t r = a.list[t];
         LongCtx C;
-        C.P = &a.P; C.AP = &a.AP; C.I = &a.I; C.W = &W; C.Ls = &Ls;
+        C.P = &P_l; C.AP = nullptr; C.I = &I_l; C.W = &W; C.Ls = nullptr; C.A = AlignScratch{};
+        C.qlen = (int32_t)(I_l.in.offsets[r + 1] - I_l.in.offsets[r]); C.read = r;
+        C.sc_mch = C.sc_mis = C.sc_amb = C.sc_N = 0; C.need_big = false; C.err = 0; C.clk = a.clk ? &clk : nullptr;
+        LongOut o;
+        const int32_t rc = lr_chains_wave<NR>(C, RL, AR_l, o);
+        if (rc == 4) { if (lane == 0) atomicExch(&a.ctr->ext_overflow, 1u); }      // arena full: the host cuts the chunk in two
+        else if (rc != 0) { if (lane == 0) lext_defer(a, r, 16u + C.err, false); }
+        else { n_rechain += (o.rechained & 2) != 0; n_tie += o.rmq_tie != 0; }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        if (n_rechain) atomicAdd(&a.ctr->lext_rechained, n_rechain);
+        if (n_tie) atomicAdd(&a.ctr->lext_rmq_tie, n_tie);
+        if (a.clk) { for (int i = 0; i < LR_NCLK; ++i) atomicAdd(&a.ctr->lext_clk[i], clk.t[i]); for (int i = 0; i < 7; ++i) atomicAdd(&a.ctr->lext_d[i], clk.d[i]); atomicMax(&a.ctr->lext_d[7], clk.d[7]); }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_regs_align_long(ExtLongArgs a)
+{
+    __shared__ AlignLds Ls;
+    const uint32_t lane = threadIdx.x;
+    const LongParams P_l = a.P; const AlignParams AP_l = a.AP; const ChainParams CP_l = a.CP; const LongIn I_l = a.I; const LongArena AR_l = a.AR;
+    LongWs W;
+    long_ws_carve(&W, a.scratch + (unsigned long long)blockIdx.x * a.scratch_per_wave, a.sz);
+    const uint32_t n_list = *a.n_list;
+    uint32_t n_regions = 0, n_dropped = 0, n_probed = 0;
+    LongClk clk{};
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(a.ticket, 1u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= n_list) break;
+        const uint32_t r = a.list[t];
+        if (AR_l.hdr[r].n_u < 0) { __syncthreads(); continue; }      // given up by the chains kernel
+        LongCtx C;
+        C.P = &P_l; C.AP = &AP_l; C.I = &I_l; C.W = &W; C.Ls = &Ls;
         C.A = AlignScratch{};
         C.A.kmem = W.kmem; C.A.kH = W.kH; C.A.koff = W.koff; C.A.kp = W.kp; C.A.tcap = W.cap_k; C.A.qcap = W.cap_k; C.A.pcap = W.cap_p;
-        C.qlen = (int32_t)(a.I.in.offsets[r + 1] - a.I.in.offsets[r]); C.read = r;
-        C.sc_mch = (int8_t)(a.P.a < 0 ? -a.P.a : a.P.a); C.sc_mis = (int8_t)(a.P.b > 0 ? -a.P.b : a.P.b);
-        C.sc_amb = (int8_t)(a.P.sc_ambi > 0 ? -a.P.sc_ambi : a.P.sc_ambi); C.sc_N = C.sc_amb == 0 ? (int8_t)(-a.P.e2) : C.sc_amb;
+        C.qlen = (int32_t)(I_l.in.offsets[r + 1] - I_l.in.offsets[r]); C.read = r;
+        C.sc_mch = (int8_t)(P_l.a < 0 ? -P_l.a : P_l.a); C.sc_mis = (int8_t)(P_l.b > 0 ? -P_l.b : P_l.b);
+        C.sc_amb = (int8_t)(P_l.sc_ambi > 0 ? -P_l.sc_ambi : P_l.sc_ambi); C.sc_N = C.sc_amb == 0 ? (int8_t)(-P_l.e2) : C.sc_amb;
         C.need_big = false; C.err = 0; C.clk = a.clk ? &clk : nullptr;
         LongOut o;
-        const int32_t rc = lr_read_wave(C, a.CP, RL, a.flag_only != 0, a.probe != 0, o);
-        if (rc != 0) {      // the read outgrew this pass's working memory (an alignment beyond the direction-byte buffer, more chain anchors / regions than fit)
-            if (lane == 0) {
-                if (a.big_list) a.big_list[atomicAdd(&a.ctr->lext_n_big, 1u)] = r;
-                else {
-                    // beyond the large pass too (minimap2 has no such limit): the read keeps its chain-level answer - it has a chain - and is counted
-                    a.flags[r] = 1;
-                    if (a.trace) ((int32_t *)(a.trace + r))[7] = 1;
-                    atomicAdd(&a.ctr->lext_unresolved, 1u); atomicExch(&a.ctr->lext_err_read, r); atomicExch(&a.ctr->lext_err_code, rc == 1 ? 32u : 16u + C.err);
-                }
-            }
-        } else if (lane == 0) {
+        const int32_t rc = lr_regs_wave(C, CP_l, AR_l, a.flag_only != 0, a.probe != 0, o);
+        if (rc != 0) { if (lane == 0) lext_defer(a, r, rc == 1 ? 32u : 16u + C.err, true); }
+        else if (lane == 0) {
             a.flags[r] = o.n_regs > 0 ? 1 : 0;
             if (a.trace) {
                 int32_t *tr = (int32_t *)(a.trace + r);
@@ -2603,14 +2640,12 @@ __global__ __launch_bounds__(64) void k_regs_align_long(ExtLongArgs a)
                 ((int4 *)tr)[2] = make_int4(o.n_aligned, o.n_regs, o.dp_max, (int32_t)o.sig);
             }
         }
-        if (rc == 0) { n_regions += (uint32_t)o.n_aligned; n_dropped += o.n_regs == 0; n_rechain += (o.rechained & 2) != 0; n_tie += o.rmq_tie != 0; n_probed += (uint32_t)o.probed; }
+        if (rc == 0) { n_regions += (uint32_t)o.n_aligned; n_dropped += o.n_regs == 0 && o.n_chain > 0; n_probed += (uint32_t)o.probed; }
         __syncthreads();
     }
     if (lane == 0) {
         if (n_regions) atomicAdd(&a.ctr->ext_regions, n_regions);
         if (n_dropped) atomicAdd(&a.ctr->ext_dropped, n_dropped);
-        if (n_rechain) atomicAdd(&a.ctr->lext_rechained, n_rechain);
-        if (n_tie) atomicAdd(&a.ctr->lext_rmq_tie, n_tie);
         if (n_probed) atomicAdd(&a.ctr->sh_lemma[SHARD()], n_probed);
         if (a.clk) for (int i = 0; i < LR_NCLK; ++i) atomicAdd(&a.ctr->lext_clk[i], clk.t[i]);
     }
@@ -2652,8 +2687,9 @@ struct sh_ctx {
     // the same stage for the long-read presets (sh_long.h): per-wave working memory in two sizes
     bool ext_long = false;
     LongParams LP{};
-    uint8_t *d_lext[2] = {}; unsigned long long lext_per_wave[2] = {}; uint32_t lext_waves[2] = {}; LongSizes lext_sz[2] = {};
-    uint32_t *d_lext_big = nullptr;
+    uint8_t *d_lext[4] = {}; unsigned long long lext_per_wave[4] = {}; uint32_t lext_waves[4] = {}; LongSizes lext_sz[4] = {};      // [phase * 2 + tier]
+    uint32_t *d_lext_big = nullptr, *d_lext_big2 = nullptr;
+    uint8_t *d_larena = nullptr; unsigned long long larena_bytes = 0; LongHdr *d_lhdr = nullptr;
     hipStream_t sx[4] = {};          // side streams: K2 and the sort classes run beside the main stream
     int par = 1;                     // bit 0: K2 on a side stream (SCRUBBY_HIP_STREAMS=0: on the main stream)
     hipEvent_t evx[6] = {};
@@ -2887,9 +2923,9 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             c->ext_waves = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)256 * std::max<uint64_t>(1, (160u << 10) / sizeof(AlignLds)), budget / c->ext_scratch_per_wave, (max_reads + 3) / 4}));
             if ((e = hipMalloc(&c->d_ext_scratch, (uint64_t)c->ext_waves * c->ext_scratch_per_wave)) != hipSuccess) return fail(e, "extension-stage scratch");
         } else {
-            // per-wave working memory of k_regs_align_long in two sizes: every wave slot with room for the usual alignments (a gap between
-            // two anchors ~min_ksw_len apart, end extensions inside the 1.5 * bw band), and a few waves with room for the largest
-            // alignment minimap2 attempts (max_sw_mat = 10^8 cells)
+            // per-wave working memory of the two kernels (k_long_chains, k_regs_align_long), each in two sizes: every wave slot with room for
+            // the usual read, and a few waves with room for the largest alignment minimap2 attempts (max_sw_mat = 10^8 cells) / for reads
+            // with millions of chain anchors
             const uint64_t L = std::max<uint32_t>(max_read_len, 64);
             LongSizes z{};
             z.cap_q = (uint32_t)((L + 31) & ~15ull);
@@ -2900,19 +2936,26 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             z.cap_m = (uint32_t)std::min<uint64_t>(65536, L / 4 + 1024);
             z.cap_p = std::min<uint64_t>(8ull << 20, (uint64_t)(2 * z.cap_k) * (z.cap_k + 32));
             if (const char *env = getenv("SCRUBBY_HIP_LEXT_P_KB")) z.cap_p = (uint64_t)atoll(env) << 10;
-            c->lext_sz[0] = z;
-            c->lext_per_wave[0] = long_ws_carve(nullptr, nullptr, z);
-            const uint64_t budget0 = 32ull << 30;
-            c->lext_waves[0] = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)256 * 5, budget0 / c->lext_per_wave[0], max_reads}));
             LongSizes zb = z;
             zb.cap_p = std::min<uint64_t>(256ull << 20, (uint64_t)(2 * z.cap_k) * (z.cap_k + 32));
             zb.cap_a = 1u << 21; zb.cap_u = zb.cap_r = 1u << 18; zb.cap_m = 65536;
-            c->lext_sz[1] = zb;
-            c->lext_per_wave[1] = long_ws_carve(nullptr, nullptr, zb);
-            c->lext_waves[1] = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, (12ull << 30) / c->lext_per_wave[1]));
-            for (int t = 0; t < 2; ++t)
-                if (c->lext_waves[t] && (e = hipMalloc(&c->d_lext[t], (uint64_t)c->lext_waves[t] * c->lext_per_wave[t])) != hipSuccess) return fail(e, "long-read extension-stage scratch");
+            const uint64_t budget[4] = {24ull << 30, 8ull << 30, 24ull << 30, 12ull << 30};
+            const uint64_t wave_max[4] = {256 * 8, 32, 256 * 8, 32};      // LDS: 19 KB per wave in both kernels
+            for (int ph = 0; ph < 2; ++ph) for (int t = 0; t < 2; ++t) {
+                LongSizes q = t ? zb : z;
+                q.phase = ph;
+                const int i = ph * 2 + t;
+                c->lext_sz[i] = q;
+                c->lext_per_wave[i] = long_ws_carve(nullptr, nullptr, q);
+                c->lext_waves[i] = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({wave_max[i], budget[i] / c->lext_per_wave[i], t ? wave_max[i] : max_reads}));
+                if ((e = hipMalloc(&c->d_lext[i], (uint64_t)c->lext_waves[i] * c->lext_per_wave[i])) != hipSuccess) return fail(e, "long-read extension-stage scratch");
+            }
             if ((e = hipMalloc(&c->d_lext_big, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
+            if ((e = hipMalloc(&c->d_lext_big2, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
+            // the chains between the two kernels: what the hand-over buffers can hold, once more (the long join re-orders, it adds nothing)
+            c->larena_bytes = SINK_SHARDS * cap_anch * 16 + SINK_SHARDS * cap_recs * 12 + max_reads * 32 + (1ull << 20);
+            if ((e = hipMalloc(&c->d_larena, c->larena_bytes)) != hipSuccess) return fail(e, "long-read extension-stage arena");
+            if ((e = hipMalloc(&c->d_lhdr, max_reads * sizeof(LongHdr))) != hipSuccess) return fail(e, "long-read extension-stage headers");
         }
         for (auto &ev : c->ev_ext) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "event");
     }
@@ -2931,7 +2974,7 @@ extern "C" sh_status sh_ctx_destroy(sh_ctx *c)
     hipFree(c->d_work_defer); hipFree(c->d_work_defer2);
     for (auto &pp : c->d_big) for (auto p : pp) hipFree(p);
     hipFree(c->d_ctr); if (c->h_ctr) hipHostFree(c->h_ctr); hipFree(c->d_arena); hipFree(c->d_long);
-    hipFree(c->d_ext); hipFree(c->d_ext_scratch); hipFree(c->d_lext[0]); hipFree(c->d_lext[1]); hipFree(c->d_lext_big);
+    hipFree(c->d_ext); hipFree(c->d_ext_scratch); for (auto q : c->d_lext) hipFree(q); hipFree(c->d_lext_big); hipFree(c->d_lext_big2); hipFree(c->d_larena); hipFree(c->d_lhdr);
     for (auto ev : c->ev_ext) if (ev) hipEventDestroy(ev);
     for (auto ev : c->ev) if (ev) hipEventDestroy(ev);
     for (auto ev : c->evx) if (ev) hipEventDestroy(ev);
@@ -3195,43 +3238,70 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         x.I.in.bases = d_bases; x.I.in.offsets = d_offsets; x.I.in.cx = c->sink.cx; x.I.in.cq = c->sink.cq; x.I.in.recs = c->sink.recs; x.I.in.head = c->sink.head;
         x.I.rec = c->use_long ? c->d_lrec : c->d_records; x.I.k1info = c->d_k1info; x.I.seed_off = c->use_long ? c->d_seed_off : nullptr; x.I.seed_cap = c->seed_cap;
         x.P = c->LP; x.AP = c->AP; x.CP = c->P;
-        x.scratch = c->d_lext[0]; x.scratch_per_wave = c->lext_per_wave[0]; x.sz = c->lext_sz[0];
-        x.list = c->d_ext_list; x.n_list = &c->d_ctr->ext_n_list; x.ticket = &c->d_ctr->ext_ticket; x.big_list = c->lext_waves[1] ? c->d_lext_big : nullptr;
-        x.ctr = c->d_ctr; x.flags = d_flags; x.trace = d_trace; x.flag_only = d_trace == nullptr; x.clk = getenv("SCRUBBY_HIP_DBG") ? 1 : 0; x.probe = getenv("SCRUBBY_HIP_NO_PROBE") ? 0 : 1;
+        x.AR.base = c->d_larena; x.AR.cap = c->larena_bytes; x.AR.cursor = &c->d_ctr->arena_cursor; x.AR.hdr = c->d_lhdr;
+        x.list = c->d_ext_list; x.n_list = &c->d_ctr->ext_n_list; x.ctr = c->d_ctr; x.flags = d_flags; x.trace = d_trace; x.flag_only = d_trace == nullptr;
+        x.clk = getenv("SCRUBBY_HIP_DBG") ? 1 : 0; x.probe = getenv("SCRUBBY_HIP_NO_PROBE") ? 0 : 1;
         SH_HIP(hipEventRecord(c->ev_ext[0], s));
+        SH_HIP(hipMemsetAsync(&c->d_ctr->arena_cursor, 0, 8, s));
         {
             ExtArgs xl{};
             xl.in = x.I.in; xl.list = x.list; xl.n_list = x.n_list; xl.n_reads = n_reads;
             hipLaunchKernelGGL(k_ext_list, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, s, xl);
         }
-        hipLaunchKernelGGL(k_regs_align_long, dim3(c->lext_waves[0]), dim3(64), 0, s, x);
-        SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
-        SH_HIP(hipStreamSynchronize(s));
-        SH_HIP(hipGetLastError());
-        if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;       // hand-over buffers full: the caller cuts the chunk in two
-        SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "long-read extension stage: internal overflow code %u", c->h_ctr->ext_overflow);
-        ext_list = c->h_ctr->ext_n_list;
-        if (c->h_ctr->lext_n_big > 0) {      // reads with an alignment beyond the first pass's direction-byte buffer
-            ExtLongArgs x2 = x;
-            x2.scratch = c->d_lext[1]; x2.scratch_per_wave = c->lext_per_wave[1]; x2.sz = c->lext_sz[1];
-            x2.list = c->d_lext_big; x2.n_list = &c->d_ctr->lext_n_big; x2.ticket = &c->d_ctr->lext_ticket_big; x2.big_list = nullptr;
-            hipLaunchKernelGGL(k_regs_align_long, dim3(c->lext_waves[1]), dim3(64), 0, s, x2);
+        auto sync_ctr = [&]() -> sh_status {
             SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
             SH_HIP(hipStreamSynchronize(s));
             SH_HIP(hipGetLastError());
-            if (c->h_ctr->lext_unresolved) {
-                static bool warned = false;
-                if (!warned) { warned = true; fprintf(stderr, "[scrubby-hip] WARNING: %u read(s) outgrew the extension stage's largest working memory (e.g. read %u of its batch, code %u: 18 chains, 20 read length, 21 chain anchors, 22 inner RMQ window, 23 seeds, 24 regions, 27-30 alignment window, 32 direction bytes); they keep their chain-level answer (mapped)\n", c->h_ctr->lext_unresolved, c->h_ctr->lext_err_read, c->h_ctr->lext_err_code); }
+            return SH_OK;
+        };
+        // first kernel: final chains (tier 0, then the reads that outgrew it with the large working memory)
+        {
+            ExtLongArgs xa = x;
+            xa.scratch = c->d_lext[0]; xa.scratch_per_wave = c->lext_per_wave[0]; xa.sz = c->lext_sz[0];
+            xa.ticket = &c->d_ctr->ext_ticket; xa.big_list = c->d_lext_big; xa.n_big = &c->d_ctr->lext_n_big;
+            hipLaunchKernelGGL(k_long_chains<512>, dim3(c->lext_waves[0]), dim3(64), 0, s, xa);
+            sh_status st = sync_ctr(); if (st != SH_OK) return st;
+            if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;       // hand-over buffers or arena full: the caller cuts the chunk in two
+            if (c->h_ctr->lext_n_big > 0) {
+                xa.scratch = c->d_lext[1]; xa.scratch_per_wave = c->lext_per_wave[1]; xa.sz = c->lext_sz[1];
+                xa.list = c->d_lext_big; xa.n_list = &c->d_ctr->lext_n_big; xa.ticket = &c->d_ctr->lext_ticket_big; xa.big_list = nullptr; xa.n_big = nullptr;
+                hipLaunchKernelGGL(k_long_chains<4096>, dim3(c->lext_waves[1]), dim3(64), 0, s, xa);
+                st = sync_ctr(); if (st != SH_OK) return st;
+                if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
             }
         }
+        SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "long-read extension stage: internal overflow code %u", c->h_ctr->ext_overflow);
+        ext_list = c->h_ctr->ext_n_list;
+        const uint32_t n_big_a = c->h_ctr->lext_n_big;
+        // second kernel: regions and alignment
+        {
+            ExtLongArgs xb = x;
+            xb.scratch = c->d_lext[2]; xb.scratch_per_wave = c->lext_per_wave[2]; xb.sz = c->lext_sz[2];
+            xb.ticket = &c->d_ctr->lext_ticket_b; xb.big_list = c->d_lext_big2; xb.n_big = &c->d_ctr->lext_n_big2;
+            hipLaunchKernelGGL(k_regs_align_long, dim3(c->lext_waves[2]), dim3(64), 0, s, xb);
+            sh_status st = sync_ctr(); if (st != SH_OK) return st;
+            if (c->h_ctr->lext_n_big2 > 0) {
+                xb.scratch = c->d_lext[3]; xb.scratch_per_wave = c->lext_per_wave[3]; xb.sz = c->lext_sz[3];
+                xb.list = c->d_lext_big2; xb.n_list = &c->d_ctr->lext_n_big2; xb.ticket = &c->d_ctr->lext_ticket_big2; xb.big_list = nullptr; xb.n_big = nullptr;
+                hipLaunchKernelGGL(k_regs_align_long, dim3(c->lext_waves[3]), dim3(64), 0, s, xb);
+                st = sync_ctr(); if (st != SH_OK) return st;
+            }
+        }
+        if (c->h_ctr->lext_unresolved) {
+            static bool warned = false;
+            if (!warned) { warned = true; fprintf(stderr, "[scrubby-hip] WARNING: %u read(s) outgrew the extension stage's largest working memory (e.g. read %u of its batch, code %u: 18 chains, 20 read length, 21 chain anchors, 22 RMQ window, 23 seeds, 24 regions, 27-30 alignment window, 32 direction bytes); they keep their chain-level answer (mapped)\n", c->h_ctr->lext_unresolved, c->h_ctr->lext_err_read, c->h_ctr->lext_err_code); }
+        }
         if (getenv("SCRUBBY_HIP_DBG")) fprintf(stderr, "[dbg] long-read extension stage: %u reads with chains, %u re-chained (RMQ), %u with tied RMQ priorities, %u needed the large scratch, %u regions aligned, %u reads dropped\n",
-                                               ext_list, c->h_ctr->lext_rechained, c->h_ctr->lext_rmq_tie, c->h_ctr->lext_n_big, c->h_ctr->ext_regions, c->h_ctr->ext_dropped);
+                                               ext_list, c->h_ctr->lext_rechained, c->h_ctr->lext_rmq_tie, n_big_a + c->h_ctr->lext_n_big2, c->h_ctr->ext_regions, c->h_ctr->ext_dropped);
         if (getenv("SCRUBBY_HIP_DBG")) {
             unsigned long long tot = 0, mr = 0, ma = 0, sr = 0, sa = 0;
             for (int i = 0; i < LR_NCLK; ++i) tot += c->h_ctr->lext_clk[i];
             fprintf(stderr, "[dbg] long-read extension stage, share of wave time: gather %.1f  rmq-sort %.1f  rmq-fill %.1f  backtrack+compact %.1f  gen_regs %.1f  parent/select %.1f  squeeze %.1f  region set-up %.1f  ksw %.1f  z-drop test %.1f  update_extra %.1f  staging %.1f %%  (total %.1f wave-s at 100 MHz)\n",
                     100. * c->h_ctr->lext_clk[0] / (tot + 1), 100. * c->h_ctr->lext_clk[1] / (tot + 1), 100. * c->h_ctr->lext_clk[2] / (tot + 1), 100. * c->h_ctr->lext_clk[3] / (tot + 1), 100. * c->h_ctr->lext_clk[4] / (tot + 1), 100. * c->h_ctr->lext_clk[5] / (tot + 1),
                     100. * c->h_ctr->lext_clk[6] / (tot + 1), 100. * c->h_ctr->lext_clk[7] / (tot + 1), 100. * c->h_ctr->lext_clk[8] / (tot + 1), 100. * c->h_ctr->lext_clk[9] / (tot + 1), 100. * c->h_ctr->lext_clk[10] / (tot + 1), 100. * c->h_ctr->lext_clk[11] / (tot + 1), tot / 1e8);
+            fprintf(stderr, "[dbg] RMQ: %llu reads, %llu anchors (largest read %llu), 10 ns ticks per anchor: insert/evict %.2f, range minimum %.3f, inner scan %.2f, store %.1f; %.2f inner chunks\n",
+                    c->h_ctr->lext_d[6], c->h_ctr->lext_d[0], c->h_ctr->lext_d[7], (double)c->h_ctr->lext_d[1] / (c->h_ctr->lext_d[0] + 1), (double)c->h_ctr->lext_d[2] / (c->h_ctr->lext_d[0] + 1),
+                    (double)c->h_ctr->lext_d[3] / (c->h_ctr->lext_d[0] + 1), (double)c->h_ctr->lext_d[4] / (c->h_ctr->lext_d[0] + 1), (double)c->h_ctr->lext_d[5] / (c->h_ctr->lext_d[0] + 1));
             for (int i = 0; i < SINK_SHARDS; ++i) { sr += c->h_ctr->ext_n_recs[i]; sa += c->h_ctr->ext_n_anch[i]; mr = std::max<unsigned long long>(mr, c->h_ctr->ext_n_recs[i]); ma = std::max<unsigned long long>(ma, c->h_ctr->ext_n_anch[i]); }
             fprintf(stderr, "[dbg] chain hand-over: %llu chains, %llu anchors; fullest shard %llu / %u chains, %llu / %llu anchors\n", sr, sa, mr, c->sink.cap_recs, ma, c->sink.cap_anch);
         }

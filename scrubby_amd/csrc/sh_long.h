@@ -62,7 +62,7 @@ struct LongWs {
     uint32_t cap_a, cap_u, cap_r, cap_m, cap_c, cap_q, cap_t, cap_k; unsigned long long cap_p;
 };
 
-struct LongSizes { uint32_t cap_a, cap_u, cap_r, cap_m, cap_q, cap_t, cap_k; unsigned long long cap_p; };
+struct LongSizes { uint32_t cap_a, cap_u, cap_r, cap_m, cap_q, cap_t, cap_k; unsigned long long cap_p; int32_t phase; };      // phase 0: the chains kernel, 1: the regions / alignment kernel
 
 __host__ __device__ inline unsigned long long long_ws_carve(LongWs *W, uint8_t *base, const LongSizes &z)
 {
@@ -71,18 +71,24 @@ __host__ __device__ inline unsigned long long long_ws_carve(LongWs *W, uint8_t *
     const unsigned long long ca = z.cap_a, cu = z.cap_u, cr = z.cap_r, cq = z.cap_q, ct = z.cap_t, ck = z.cap_k;
     const unsigned long long cc = 2ull * (cq + ct) + 64;
     LongWs w{};
-    w.a = (LAnchor *)take(ca * 16); w.b = (LAnchor *)take(ca * 16);
-    w.f = (int32_t *)take(ca * 4); w.p = (int32_t *)take(ca * 4); w.t = (int32_t *)take(ca * 4); w.v = (int32_t *)take(ca * 4);
-    w.pri = (double *)take(ca * 8); w.sk = (SKey *)take(ca * sizeof(SKey)); w.sk2 = (SKey *)take(ca * sizeof(SKey));
-    w.u = (uint64_t *)take(cu * 8); w.uoff = (uint32_t *)take((cu + 1) * 4);
-    w.regs = (LReg *)take(cr * sizeof(LReg)); w.cov = (uint64_t *)take(cr * 8); w.wpri = (int32_t *)take(cr * 4);
-    w.mini_pos = (uint64_t *)take((unsigned long long)z.cap_m * 8);
-    w.tbits = (uint32_t *)take((cq / 32 + 2) * 4);
-    w.K = (int32_t *)take(ca * 4);
-    w.r_cigar = (uint32_t *)take(cc * 4); w.ez_cigar = (uint32_t *)take(cc * 4);
-    w.qseq = take(2 * cq + 32); w.tseq = take(ct + 32);
-    w.kmem = take(8 * (ck + 16) + ck + 64); w.kH = (int32_t *)take((ck + 16) * 4); w.koff = (int32_t *)take(8 * (2 * ck + 32)); w.kp = take(z.cap_p);
-    w.lH = (int32_t *)take((ck + 16) * 4 * 2); w.lE = (int32_t *)take((ck + 16) * 4); w.lHmax = (int32_t *)take((ck + 16) * 4);
+    if (z.phase == 0) {
+        w.a = (LAnchor *)take(ca * 16); w.b = (LAnchor *)take(ca * 16);
+        w.f = (int32_t *)take(ca * 4); w.p = (int32_t *)take(ca * 4); w.t = (int32_t *)take(ca * 4); w.v = (int32_t *)take(ca * 4);
+        w.pri = (double *)take(ca * 8); w.sk = (SKey *)take(ca * sizeof(SKey)); w.sk2 = (SKey *)take(ca * sizeof(SKey));
+        w.u = (uint64_t *)take(cu * 8); w.uoff = (uint32_t *)take((cu + 1) * 4);
+        w.tbits = (uint32_t *)take((cq / 32 + 2) * 4);
+        w.K = (int32_t *)take(ca * 4);
+    } else {
+        w.a = (LAnchor *)take(ca * 16);
+        w.sk = (SKey *)take(cr * sizeof(SKey)); w.sk2 = (SKey *)take(cr * sizeof(SKey));
+        w.regs = (LReg *)take(cr * sizeof(LReg)); w.cov = (uint64_t *)take(cr * 8); w.wpri = (int32_t *)take(cr * 4);
+        w.mini_pos = (uint64_t *)take((unsigned long long)z.cap_m * 8);
+        w.K = (int32_t *)take(ca * 4);
+        w.r_cigar = (uint32_t *)take(cc * 4); w.ez_cigar = (uint32_t *)take(cc * 4);
+        w.qseq = take(2 * cq + 32); w.tseq = take(ct + 32);
+        w.kmem = take(8 * (ck + 16) + ck + 64); w.kH = (int32_t *)take((ck + 16) * 4); w.koff = (int32_t *)take(8 * (2 * ck + 32)); w.kp = take(z.cap_p);
+        w.lH = (int32_t *)take((ck + 16) * 4 * 2); w.lE = (int32_t *)take((ck + 16) * 4); w.lHmax = (int32_t *)take((ck + 16) * 4);
+    }
     w.cap_a = z.cap_a; w.cap_u = z.cap_u; w.cap_r = z.cap_r; w.cap_m = z.cap_m; w.cap_c = (uint32_t)cc; w.cap_q = z.cap_q; w.cap_t = z.cap_t; w.cap_k = z.cap_k; w.cap_p = z.cap_p;
     if (W) *W = w;
     return off;
@@ -107,7 +113,7 @@ __device__ inline bool sk_less(const SKey &a, const SKey &b) { return a.k < b.k 
 
 // Stable-by-construction sort of n distinct (k, v) pairs, ascending, by one wave: tiles of 64 ranked in registers, then merge
 // passes in which every lane merges one slice of the output found by a merge-path search.  Result in `a` (tmp is scratch).
-__device__ inline void lr_sort(SKey *a, SKey *tmp, int32_t n)
+__device__ __noinline__ void lr_sort(SKey *a, SKey *tmp, int32_t n)
 {
     const int32_t lane = (int32_t)al_lane();
     if (n < 2) return;
@@ -173,6 +179,12 @@ __device__ inline void lr_reg_set_coor(LReg &r, int32_t qlen, const LAnchor *a)
     }
 }
 
+// where a wave's time goes (SCRUBBY_HIP_DBG): 0 gather, 1 rmq sort, 2 rmq fill, 3 backtrack + compact, 4 gen_regs, 5 parent / select / est_err, 6 squeeze,
+// 7 region set-up (bad ends / seeds, windows), 8 ksw, 9 z-drop test, 10 update_extra, 11 sequence staging
+#define LR_NCLK 12
+struct LongClk { unsigned long long t[LR_NCLK]; unsigned long long last; unsigned long long d[8]; };      // d: RMQ statistics (steps, ring blocks evaluated, steps that went behind the ring, old blocks evaluated, sum of the list length, inner chunks, anchors)
+__device__ inline void lr_tick(LongClk *c, int ph) { if (c) { const unsigned long long now = wall_clock64(); c->t[ph] += now - c->last; c->last = now; } }
+
 // ---- mg_lchain_rmq on one wave -------------------------------------------------------------------------------------------
 // Upstream keeps the look-back window in two balanced trees keyed by (y, i) (oracle/mm_rmq.c).  What the trees are asked:
 //   (1) the element of smallest priority -(f + 0.5 * pen_gap * (x + y)) among the active anchors with y in the query interval;
@@ -181,8 +193,17 @@ __device__ inline void lr_reg_set_coor(LReg &r, int32_t qlen, const LAnchor *a)
 // y-sorted copy of the inner window kept in LDS.  With distinct priorities the answers are the trees'; when the minimum is shared by
 // two candidates the tree's choice depends on its shape, which this scan does not have: such reads are reported (*tie) and the
 // caller sends them down the exact serial path.
-#define LRQ_INNER 1024          // active anchors of the inner window: y-sorted list + a ring of their (x, y, f, p, t) in LDS
-struct RmqLds { int32_t iy[LRQ_INNER], ij[LRQ_INNER]; uint32_t rx[LRQ_INNER]; int32_t ry[LRQ_INNER], rf[LRQ_INNER], rp[LRQ_INNER], rt[LRQ_INNER]; };
+// NR = the newest anchors kept in LDS: a ring of their (x, y, f, p, t, priority) and the y-sorted list of the inner window.  The kernel runs
+// with NR = 512 (19 KB: eight waves per CU); a read whose inner window or same-x group outgrows it is redone with NR = 4096.
+#define LRQ_RBLK(NR) ((NR) / 64 - 4)            // completed blocks of 64 anchors that are always inside the ring ...
+#define LRQ_SAMEX(NR) ((NR) - 1 - (LRQ_RBLK(NR) + 1) * 64)      // ... with up to this many anchors waiting on one x
+template <int LRQ_INNER>
+struct RmqLdsT {
+    int32_t iy[LRQ_INNER], ij[LRQ_INNER];
+    uint32_t rx[LRQ_INNER]; int32_t ry[LRQ_INNER], rf[LRQ_INNER], rp[LRQ_INNER], rt[LRQ_INNER];
+    double rpri[LRQ_INNER];
+    double pml[64], bml[64];    // pml[b & 63] = smallest priority of the blocks 0 .. b, bml[b & 63] = of block b alone
+};
 
 __device__ inline int32_t lr_sc_simple(int32_t dr, int32_t dq, int32_t q_span, float pen_gap, float pen_skip, int32_t &exact, int32_t &width)
 {   // comput_sc_simple
@@ -202,12 +223,14 @@ __device__ inline double lr_cc_f64(const double *p) { return __longlong_as_doubl
 // a[] sorted by x (read-only here).  Out: f, p (int32; -1 = none) - visible to the other lanes after the caller's lr_sync().  n_tie: steps
 // whose minimum priority was shared (the smallest index was taken; upstream's tree may pick another).  Returns false when the inner window
 // outgrows LRQ_INNER or the read has more anchors than rmq_size_cap.
-// Memory: what a step needs of the recent anchors (f, p, the t marks, x, y) lives in the LDS ring, so no step waits for HBM; the priorities
-// and block minima are written once and read past the L1 (they share cache lines with entries read before they were written).
-__device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int32_t bw, int32_t n, const LAnchor *a, int32_t *f, int32_t *p,
-                                   double *pri, double *bmin /* n / 64 + 1 */, RmqLds &L, int32_t &n_tie)
+// Memory: what a step needs of the newest ~1000 anchors (f, p, the t marks, x, y, the priority) lives in the LDS ring, and the smallest
+// priority of everything older is one number (pml): a step only goes to HBM when the answer may lie further back than the ring.
+template <int LRQ_INNER>
+__device__ __noinline__ bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int32_t bw, int32_t n, const LAnchor *a, int32_t *f, int32_t *p,
+                                   double *pri, double *bmin /* n / 64 + 1 */, RmqLdsT<LRQ_INNER> &L, int32_t &n_tie, LongClk *dbg = nullptr)
 {
     n_tie = 0;
+    unsigned long long d_ring = 0, d_oldsteps = 0, d_old = 0, d_nin = 0, d_chunks = 0, tc0 = 0, tA = 0, tB = 0, tC = 0, tD = 0;
     const int32_t lane = (int32_t)al_lane();
     constexpr int32_t M = LRQ_INNER - 1;
     int32_t max_dist = max_dist_in, max_dist_inner = P.rmq_inner_dist;
@@ -218,90 +241,108 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
     for (int32_t i = lane; i < LRQ_INNER; i += 64) L.rt[i] = -1;
     __builtin_amdgcn_wave_barrier();
     int32_t blk_done = 0;      // blocks [0, blk_done) of 64 anchors are completely inserted; bmin[b] = their smallest priority
-    int32_t i0 = 0, st = 0, st_inner = 0, n_in = 0;      // inner window: L.iy/ij[0 .. n_in) ascending (y, j) = the anchors [st_inner, i0)
+    int32_t i0 = 0, st = 0, st_inner = 0, n_in = 0, seg0 = 0, head = 0;      // the list is circular: entry e lives at (head + e) & M
+#define LIY(e) L.iy[(head + (e)) & M]
+#define LIJ(e) L.ij[(head + (e)) & M]      // inner window: the live entries (j >= st_inner) of L.iy/ij[0 .. n_in), ascending (y, j)
     bool ok = true;
+    uint32_t hi_prev = 0;
+    LAnchor cur = a[0];
     for (int32_t i = 0; i < n && ok; ++i) {
-        const uint64_t xi = a[i].x, yi = a[i].y;
+        if (dbg) tc0 = wall_clock64();
+        const uint64_t xi = cur.x, yi = cur.y;
+        if (i + 1 < n) cur = a[i + 1];      // the next anchor travels while this one is worked on
         const int32_t qi = (int32_t)yi, q_span_i = (int32_t)(yi >> 32 & 0xff);
+        if (i > 0 && (uint32_t)(xi >> 32) != hi_prev) seg0 = i;      // another strand / contig: nothing before i is in range
         // add the anchors whose x is now strictly smaller
-        if (i0 < i && a[i0].x != xi) {
-            if (i - i0 > LRQ_INNER) { ok = false; break; }
+        if (i - i0 > LRQ_SAMEX(LRQ_INNER)) { ok = false; break; }      // more anchors on one reference position than the ring can hold back
+        if (i0 < i && (seg0 == i || L.rx[i0 & M] != (uint32_t)xi)) {
             for (int32_t jb = i0; jb < i; jb += 64) {
                 const int32_t j = jb + lane;
-                if (j < i) pri[j] = -((double)L.rf[j & M] + 0.5 * (double)P.pen_gap * (double)((int32_t)L.rx[j & M] + L.ry[j & M]));
+                if (j < i) { const double pj = -((double)L.rf[j & M] + 0.5 * (double)P.pen_gap * (double)((int32_t)L.rx[j & M] + L.ry[j & M])); L.rpri[j & M] = pj; pri[j] = pj; }
             }
+            __builtin_amdgcn_wave_barrier();
             if (max_dist_inner > 0) {
                 for (int32_t j = i0; j < i; ++j) {      // insert (y_j, j) into the y-sorted inner window
                     if (n_in >= LRQ_INNER) { ok = false; break; }
                     const int32_t yj = L.ry[j & M];
-                    // position: behind every element with y <= yj (j is the largest index so far)
-                    int32_t pos = 0;
-                    for (int32_t c = 0; c < n_in; c += 64) { const int32_t e = c + lane; pos += (int32_t)__popcll(__ballot(e < n_in && L.iy[e] <= yj)); }
+                    // position: behind every element with y <= yj (j is the largest index so far); searched from the top, where a collinear
+                    // anchor belongs
+                    int32_t pos = n_in;
+                    for (int32_t c = n_in; c > 0; c -= 64) {
+                        const int32_t e = c - 1 - lane;      // lane 0 = the topmost entry of the chunk
+                        const uint64_t gt = __ballot(e >= 0 && LIY(e) > yj);      // a prefix of the lanes
+                        pos -= (int32_t)__popcll(gt);
+                        if (__popcll(gt) < 64) break;
+                    }
                     for (int32_t c = ((n_in - pos + 63) / 64 - 1) * 64; c >= 0; c -= 64) {      // shift [pos, n_in) up by one, from the top
                         const int32_t e = pos + c + lane;
                         int32_t vy = 0, vj = 0;
                         const bool on = e < n_in;
-                        if (on) { vy = L.iy[e]; vj = L.ij[e]; }
+                        if (on) { vy = LIY(e); vj = LIJ(e); }
                         __builtin_amdgcn_wave_barrier();
-                        if (on) { L.iy[e + 1] = vy; L.ij[e + 1] = vj; }
+                        if (on) { LIY(e + 1) = vy; LIJ(e + 1) = vj; }
                         __builtin_amdgcn_wave_barrier();
                     }
-                    if (lane == 0) { L.iy[pos] = yj; L.ij[pos] = j; }
+                    if (lane == 0) { LIY(pos) = yj; LIJ(pos) = j; }
                     __builtin_amdgcn_wave_barrier();
                     ++n_in;
                 }
                 if (!ok) break;
             }
             i0 = i;
-            if ((blk_done + 1) * 64 <= i0) {      // blocks completed by this insertion: their priorities must have reached L2 first
-                __builtin_amdgcn_s_waitcnt(0);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                while ((blk_done + 1) * 64 <= i0) {
-                    double m = lr_cc_f64(pri + blk_done * 64 + lane);
+            while ((blk_done + 1) * 64 <= i0) {      // blocks completed by this insertion (their anchors are all in the ring)
+                double m = L.rpri[(blk_done * 64 + lane) & M];
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) { const double om = __shfl_xor(m, o); m = om < m ? om : m; }
-                    if (lane == 0) bmin[blk_done] = m;
-                    ++blk_done;
-                }
+                for (int o = 32; o > 0; o >>= 1) { const double om = __shfl_xor(m, o); m = om < m ? om : m; }
+                const double pm = blk_done > 0 && L.pml[(blk_done - 1) & 63] < m ? L.pml[(blk_done - 1) & 63] : m;
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) { bmin[blk_done] = m; L.pml[blk_done & 63] = pm; L.bml[blk_done & 63] = m; }
+                __builtin_amdgcn_wave_barrier();
+                ++blk_done;
             }
         }
         // anchors out of range leave
-        while (st < i && (xi >> 32 != a[st].x >> 32 || xi > a[st].x + (uint64_t)max_dist)) ++st;
+        if (st < seg0) st = seg0;
+        while (st < i && xi > a[st].x + (uint64_t)max_dist) ++st;
         if (max_dist_inner > 0) {
             const int32_t st_old = st_inner;
-            while (st_inner < i && (xi >> 32 != a[st_inner].x >> 32 || xi > a[st_inner].x + (uint64_t)max_dist_inner)) ++st_inner;
-            if (st_inner > st_old && n_in > 0) {      // drop the elements with j < st_inner (those that were inserted: j < i0): compaction in order
-                int32_t kept = 0;
-                for (int32_t c = 0; c < n_in; c += 64) {
-                    const int32_t e = c + lane;
-                    int32_t vy = 0, vj = 0;
-                    const bool on = e < n_in;
-                    if (on) { vy = L.iy[e]; vj = L.ij[e]; }
-                    const bool keep = on && vj >= st_inner;
-                    const uint64_t km = __ballot(keep);
-                    __builtin_amdgcn_wave_barrier();
-                    if (keep) { const int32_t d = kept + (int32_t)prefix_popc64(km); L.iy[d] = vy; L.ij[d] = vj; }
-                    __builtin_amdgcn_wave_barrier();
-                    kept += (int32_t)__popcll(km);
+            if (st_inner < seg0) st_inner = seg0;
+            if (i - st_inner >= LRQ_INNER) { ok = false; break; }      // the inner window must fit the ring
+            while (st_inner < i && (uint32_t)xi - L.rx[st_inner & M] > (uint32_t)max_dist_inner) ++st_inner;
+            if (st_inner > st_old && n_in > 0) {      // drop the entries that left the window
+                // the anchors that leave are the oldest; on a collinear chain they are also the lowest in y, i.e. the head of the list
+                int32_t d = st_inner - st_old;
+                if (d > n_in) d = n_in;
+                bool prefix = d <= 64;
+                if (prefix) { const uint64_t dm = __ballot(lane < d && LIJ(lane) < st_inner); prefix = (int32_t)__popcll(dm) == d; }
+                if (prefix) { head = (head + d) & M; n_in -= d; }
+                else {
+                    int32_t kept = 0;
+                    for (int32_t c = 0; c < n_in; c += 64) {
+                        const int32_t e = c + lane;
+                        int32_t vy = 0, vj = 0;
+                        const bool on = e < n_in;
+                        if (on) { vy = LIY(e); vj = LIJ(e); }
+                        const bool keep = on && vj >= st_inner;
+                        const uint64_t km = __ballot(keep);
+                        __builtin_amdgcn_wave_barrier();
+                        if (keep) { const int32_t dd = kept + (int32_t)prefix_popc64(km); LIY(dd) = vy; LIJ(dd) = vj; }
+                        __builtin_amdgcn_wave_barrier();
+                        kept += (int32_t)__popcll(km);
+                    }
+                    n_in = kept;
                 }
-                n_in = kept;
             }
         }
-        // a ring slot may only be reused once its anchor has left the inner window
-        if (i - st_inner >= LRQ_INNER) { ok = false; break; }
+        d_nin += (unsigned long long)n_in;
+        if (dbg) { const unsigned long long t1 = wall_clock64(); tA += t1 - tc0; tc0 = t1; }
         int32_t max_f = q_span_i, max_j = -1;
         // (1) range minimum of the priority over the active anchors [st, i0) with (y_j, j) in [(q_i - max_dist, INT32_MAX), (q_i, 0)].
-        // The anchors are visited newest first in blocks of 64; a completed block whose smallest priority (bmin, whatever its y) is above the
-        // best found so far cannot hold the answer or a tie with it and is skipped - the answer is nearly always among the newest anchors.
+        // Newest first in blocks of 64: the blocks inside the ring out of LDS; everything older only if its smallest priority (pml, whatever
+        // the y) is not above the best found so far - then block by block, skipping those whose own minimum (bmin) is above it.
         double bp = 0.0; int32_t bj = -1, ties = 0;
         {
-            auto eval = [&](int32_t j, bool cand) {      // one candidate per lane
-                bool in = false; double pj = 0.0;
-                if (cand) {
-                    const int32_t yj = (int32_t)a[j].y;
-                    in = yj > qi - max_dist && (yj < qi || (yj == qi && j == 0));
-                    if (in) pj = lr_cc_f64(pri + j);
-                }
+            auto reduce = [&](bool in, double pj, int32_t j) {
                 const uint64_t im = __ballot(in);
                 if (im == 0) return;
                 double wm = pj; int32_t wj = in ? j : -1;
@@ -314,48 +355,95 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 if (bj < 0 || wm < bp) { bp = wm; bj = wj; ties = c; }
                 else if (wm == bp) { ties += c; bj = wj < bj ? wj : bj; }
             };
-            const int32_t part = blk_done * 64 > st ? blk_done * 64 : st;      // the newest, not yet completed block
-            if (part < i0) { const int32_t j = part + lane; eval(j, j < i0); }
-            const int32_t b_lo = st >> 6;
-            for (int32_t bt = blk_done - 1; bt >= b_lo; bt -= 64) {
-                const int32_t b = bt - lane;
-                bool todo = b >= b_lo;
-                const double v = todo ? lr_cc_f64(bmin + b) : 0.0;
+            const int32_t ring_lo = blk_done > LRQ_RBLK(LRQ_INNER) ? (blk_done - LRQ_RBLK(LRQ_INNER)) * 64 : 0;      // anchors [ring_lo, i0) are in the ring
+            auto ring_eval = [&](int32_t j, bool cand) {
+                bool in = false; double pj = 0.0;
+                if (cand) {
+                    const int32_t yj = L.ry[j & M];
+                    in = yj > qi - max_dist && (yj < qi || (yj == qi && j == 0));
+                    if (in) pj = L.rpri[j & M];
+                }
+                reduce(in, pj, j);
+            };
+            {   // the newest, not yet completed block
+                const int32_t part = blk_done * 64 > st ? blk_done * 64 : st;
+                if (part < i0) { const int32_t j = part + lane; ring_eval(j, j < i0); }
+            }
+            {   // the completed blocks inside the ring, newest first, those whose own minimum can still matter
+                const int32_t rb_lo = (ring_lo >> 6) > (st >> 6) ? (ring_lo >> 6) : (st >> 6);
+                const int32_t b = blk_done - 1 - lane;
+                bool todo = b >= rb_lo;
+                const double v = todo ? L.bml[b & 63] : 0.0;
                 for (;;) {
                     const uint64_t m = __ballot(todo && (bj < 0 || v <= bp));
                     if (m == 0) break;
-                    const int l = __ffsll((unsigned long long)m) - 1;      // lane l holds the newest such block
-                    const int32_t bb = bt - l, j = bb * 64 + lane;
-                    eval(j, j >= st);
+                    const int l = __ffsll((unsigned long long)m) - 1;
+                    const int32_t j = (blk_done - 1 - l) * 64 + lane;
+                    ring_eval(j, j >= st);
+                    ++d_ring;
                     if (lane == l) todo = false;
                 }
             }
+            const int32_t b_lo = st >> 6, b_hi = ring_lo / 64 - 1;      // completed blocks older than the ring: [b_lo, b_hi]
+            if (b_hi >= b_lo && (bj < 0 || L.pml[b_hi & 63] <= bp)) {
+                ++d_oldsteps;
+                for (int32_t bt = b_hi; bt >= b_lo; bt -= 64) {
+                    const int32_t b = bt - lane;
+                    bool todo = b >= b_lo;
+                    const double v = todo ? lr_cc_f64(bmin + b) : 0.0;
+                    for (;;) {
+                        const uint64_t m = __ballot(todo && (bj < 0 || v <= bp));
+                        if (m == 0) break;
+                        const int l = __ffsll((unsigned long long)m) - 1;      // lane l holds the newest such block
+                        const int32_t bb = bt - l, j = bb * 64 + lane;
+                        bool in = false; double pj = 0.0;
+                        if (j >= st) {
+                            const int32_t yj = (int32_t)a[j].y;
+                            in = yj > qi - max_dist && (yj < qi || (yj == qi && j == 0));
+                            if (in) pj = lr_cc_f64(pri + j);
+                        }
+                        reduce(in, pj, j);
+                        ++d_old;
+                        if (lane == l) todo = false;
+                    }
+                }
+            }
         }
+        if (dbg) { const unsigned long long t1 = wall_clock64(); tB += t1 - tc0; tc0 = t1; }
         if (bj >= 0) {
             if (ties > 1) ++n_tie;      // the smallest index among the equal priorities is taken; the caller reports the read
             int32_t exact, width, n_skip = 0;
             int32_t fb, dr, dq, span_b;
-            if (bj >= st_inner && i - bj < LRQ_INNER) { fb = L.rf[bj & M]; dr = (int32_t)((uint32_t)xi - L.rx[bj & M]); dq = qi - L.ry[bj & M]; span_b = P.k; }
+            if (i - bj < LRQ_INNER - 64) { fb = L.rf[bj & M]; dr = (int32_t)((uint32_t)xi - L.rx[bj & M]); dq = qi - L.ry[bj & M]; span_b = P.k; }
             else { fb = (int32_t)cc_u32(f + bj); dr = (int32_t)(xi - a[bj].x); dq = qi - (int32_t)a[bj].y; span_b = (int32_t)(a[bj].y >> 32 & 0xff); }
             int32_t sc = fb + lr_sc_simple(dr, dq, span_b, P.pen_gap, P.pen_skip, exact, width);
             if (width <= bw && sc > max_f) { max_f = sc; max_j = bj; }
             if (!exact && n_in > 0 && qi > 0) {
-                // (2) the inner window from the largest (y, j) <= (q_i - 1, n) downwards, while y >= q_i - max_dist_inner
-                int32_t top = 0;      // number of elements with y <= q_i - 1
-                for (int32_t c = 0; c < n_in; c += 64) { const int32_t e = c + lane; top += (int32_t)__popcll(__ballot(e < n_in && L.iy[e] <= qi - 1)); }
+                // (2) the inner window from the largest (y, j) <= (q_i - 1, n) downwards, while y >= q_i - max_dist_inner; entries that have left
+                // the window (j < st_inner) are still in the list until it is compacted: they are passed over
+                int32_t top = n_in;      // number of elements with y <= q_i - 1, counted down from the top
+                for (int32_t c = n_in; c > 0; c -= 64) {
+                    const int32_t e = c - 1 - lane;
+                    const uint64_t gt = __ballot(e >= 0 && LIY(e) > qi - 1);
+                    top -= (int32_t)__popcll(gt);
+                    if (__popcll(gt) < 64) break;
+                }
                 for (int32_t eb = top - 1; eb >= 0; eb -= 64) {
                     const int32_t e = eb - lane;
-                    const bool valid = e >= 0 && L.iy[e] >= qi - max_dist_inner;
-                    const uint64_t vm = __ballot(valid);
+                    ++d_chunks;
+                    const bool inr = e >= 0 && LIY(e) >= qi - max_dist_inner;      // a prefix of the lanes: the list is sorted
+                    const uint64_t vm = __ballot(inr);
                     if (vm == 0) break;
                     int32_t j = -1, scj = INT32_MIN, pj = -1;
                     bool has = false;
-                    if (valid) {
-                        j = L.ij[e];
-                        int32_t ex2, w2;
-                        scj = L.rf[j & M] + lr_sc_simple((int32_t)((uint32_t)xi - L.rx[j & M]), qi - L.ry[j & M], P.k, P.pen_gap, P.pen_skip, ex2, w2);
-                        has = w2 <= bw;
-                        pj = L.rp[j & M];
+                    if (inr) {
+                        j = LIJ(e);
+                        if (j >= st_inner) {
+                            int32_t ex2, w2;
+                            scj = L.rf[j & M] + lr_sc_simple((int32_t)((uint32_t)xi - L.rx[j & M]), qi - L.ry[j & M], P.k, P.pen_gap, P.pen_skip, ex2, w2);
+                            has = w2 <= bw;
+                            pj = L.rp[j & M];
+                        }
                     }
                     if (has && pj >= st_inner) L.rt[pj & M] = i;      // a mark only matters on an anchor this scan can still visit
                     __builtin_amdgcn_wave_barrier();
@@ -371,7 +459,6 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                     const int32_t mn = wave_scan_min_incl(yl);
                     const int32_t val = yl - (mn < 0 ? mn : 0);
                     const uint64_t brk = __ballot(inc_ev && val > P.max_skip);
-                    // the scan also ends at the first element below the y range (valid is a prefix of the lanes: the window is sorted)
                     const int nv = (int)__popcll(vm);
                     int Lb = brk ? __ffsll((unsigned long long)brk) - 1 : 63;
                     if (Lb > nv - 1) Lb = nv - 1;
@@ -386,19 +473,25 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 }
             }
         }
+        if (dbg) { const unsigned long long t1 = wall_clock64(); tC += t1 - tc0; tc0 = t1; }
         if (lane == 0) {
             f[i] = max_f; p[i] = max_j;
             L.rx[i & M] = (uint32_t)xi; L.ry[i & M] = qi; L.rf[i & M] = max_f; L.rp[i & M] = max_j;
         }
+        hi_prev = (uint32_t)(xi >> 32);
         __builtin_amdgcn_wave_barrier();
+        if (dbg) { const unsigned long long t1 = wall_clock64(); tD += t1 - tc0; tc0 = t1; }
     }
+#undef LIY
+#undef LIJ
+    if (dbg) { dbg->d[0] += (unsigned long long)n; dbg->d[1] += tA; dbg->d[2] += tB; dbg->d[3] += tC; dbg->d[4] += tD; dbg->d[5] += d_chunks; dbg->d[6] += 1; if ((unsigned long long)n > dbg->d[7]) dbg->d[7] = (unsigned long long)n; }
     return ok;
 }
 
 // ---- mg_chain_backtrack (lane 0) -----------------------------------------------------------------------------------------
 // zc: candidates (f << 32 | index) with f >= min_sc, sorted ascending.  Chains into u (score << 32 | cnt) and v (anchor indices,
 // each chain from its end backwards).  Returns n_u; n_v through the reference.
-__device__ inline int32_t lr_backtrack0(const SKey *zc, int32_t n_z, const int32_t *f, const int32_t *p, int32_t *t, int32_t *v, uint64_t *u, uint32_t cap_u,
+__device__ __noinline__ int32_t lr_backtrack0(const SKey *zc, int32_t n_z, const int32_t *f, const int32_t *p, int32_t *t, int32_t *v, uint64_t *u, uint32_t cap_u,
                                         int32_t min_cnt, int32_t min_sc, int32_t max_drop, int32_t &n_v_out, int32_t &best_out, bool &ovf)
 {
     int32_t n_u = 0, n_v = 0, best = 0;
@@ -684,7 +777,7 @@ __device__ inline void lr_filter_bad_seeds_alt0(int32_t as1, int32_t cnt1, LAnch
 // only dependency inside a row: F(j) = max(0, max_{j' < j}(H'(j') - (o + e) - (j - 1 - j') * e)) with H' = max(diag, E) - a prefix
 // maximum of H'(j') + j' * e.  The query is padded to a multiple of 8 with columns scoring 0, as the striped profile pads it; te / qe
 // are the LAST row reaching the maximum and the LAST column (in striped memory order) holding it there (oracle mma_ksw_ll).
-__device__ inline int32_t lr_ksw_ll_wave(int32_t qlen, const uint8_t *query, int32_t tlen, const uint8_t *target, int8_t sc_mch, int8_t sc_mis, int8_t sc_amb,
+__device__ __noinline__ int32_t lr_ksw_ll_wave(int32_t qlen, const uint8_t *query, int32_t tlen, const uint8_t *target, int8_t sc_mch, int8_t sc_mis, int8_t sc_amb,
                                          int32_t gapo, int32_t gape, int32_t &qe, int32_t &te, int32_t *H0, int32_t *E, int32_t *Hmax)
 {
     const int32_t lane = (int32_t)al_lane();
@@ -752,11 +845,6 @@ struct LongIn {
     const uint4 *rec; const uint32_t *k1info; const unsigned long long *seed_off; uint32_t seed_cap;      // the reads' seed records
 };
 
-// where a wave's time goes (SCRUBBY_HIP_DBG): 0 gather, 1 rmq sort, 2 rmq fill, 3 backtrack + compact, 4 gen_regs, 5 parent / select / est_err, 6 squeeze,
-// 7 region set-up (bad ends / seeds, windows), 8 ksw, 9 z-drop test, 10 update_extra, 11 sequence staging
-#define LR_NCLK 12
-struct LongClk { unsigned long long t[LR_NCLK]; unsigned long long last; };
-__device__ inline void lr_tick(LongClk *c, int ph) { if (c) { const unsigned long long now = wall_clock64(); c->t[ph] += now - c->last; c->last = now; } }
 struct LongCtx {
     const LongParams *P; const AlignParams *AP; const LongIn *I; LongWs *W; AlignLds *Ls; AlignScratch A; LongClk *clk;
     int32_t qlen; uint32_t read;
@@ -766,7 +854,7 @@ struct LongCtx {
 };
 
 // mm_align_pair: false = the caller must stop (need_big / err set)
-__device__ inline bool lr_align_pair(LongCtx &C, int32_t qlen, const uint8_t *qseq, int32_t tlen, const uint8_t *tseq, int32_t w, int32_t end_bonus, int32_t zdrop, int32_t flag, Ez &ez)
+__device__ __noinline__ bool lr_align_pair(LongCtx &C, int32_t qlen, const uint8_t *qseq, int32_t tlen, const uint8_t *tseq, int32_t w, int32_t end_bonus, int32_t zdrop, int32_t flag, Ez &ez)
 {
     const LongParams &P = *C.P;
     if ((long long)tlen * qlen > 100000000ll) { ez_reset(ez); ez.zdropped = 1; return true; }      // max_sw_mat
@@ -849,7 +937,7 @@ __device__ inline int32_t lr_test_zdrop(LongCtx &C, const uint8_t *qseq, const u
 
 // One region.  r / r2 live in registers (uniform); the caller stores them.  a = the squeezed anchors, n_a their number.
 // flag_only: stop as soon as the region is known to survive mm_filter_regs is NOT done here: this is the complete procedure.
-__device__ inline bool lr_align1(LongCtx &C, LReg &r, LReg &r2, LAnchor *a, int32_t n_a, int32_t pre_as1 = -1, int32_t pre_cnt1 = 0)
+__device__ __noinline__ bool lr_align1(LongCtx &C, LReg &r, LReg &r2, LAnchor *a, int32_t n_a, int32_t pre_as1 = -1, int32_t pre_cnt1 = 0)
 {
     const LongParams &P = *C.P;
     LongWs &W = *C.W;
@@ -1021,7 +1109,7 @@ __device__ inline bool lr_align1(LongCtx &C, LReg &r, LReg &r2, LAnchor *a, int3
 }
 
 // mm_align1_inv: between the two halves of a region split by the inversion z-drop, align the reverse complement
-__device__ inline int32_t lr_align1_inv(LongCtx &C, const LReg &r1, const LReg &r2, LReg &ri)
+__device__ __noinline__ int32_t lr_align1_inv(LongCtx &C, const LReg &r1, const LReg &r2, LReg &ri)
 {
     const LongParams &P = *C.P;
     LongWs &W = *C.W;
@@ -1132,7 +1220,7 @@ __device__ inline int32_t lr_probe_eval0(const LongCtx &C, uint32_t *pc, int32_t
 }
 
 // 1: the region survives; 0: unknown (take the complete procedure); -1: stop (C.need_big / C.err)
-__device__ inline int32_t lr_probe_region(LongCtx &C, const LReg &r, LAnchor *a, int32_t &as1, int32_t &cnt1)
+__device__ __noinline__ int32_t lr_probe_region(LongCtx &C, const LReg &r, LAnchor *a, int32_t &as1, int32_t &cnt1)
 {
     const LongParams &P = *C.P;
     LongWs &W = *C.W;
@@ -1196,6 +1284,14 @@ __device__ inline int32_t lr_probe_region(LongCtx &C, const LReg &r, LAnchor *a,
 
 // ---- the whole stage for one read ---------------------------------------------------------------------------------------------------
 struct LongOut { int32_t n_chain, best, rechained, n_aligned, n_regs, dp_max; uint32_t sig; int32_t rmq_tie, probed; };
+// The stage runs as two kernels, so that neither carries the other's registers and LDS: the first leaves a read's final chains (after the
+// long join, in compact_a's order, MM_SEED_TANDEM set) in an arena; the second turns them into regions and aligns.
+struct LongHdr { unsigned long long off; int32_t n_u, n_a, best, rechained; };      // per read: u[n_u] (8 B), uoff[n_u + 1] (4 B), a[n_a] (16 B) at arena + off
+struct LongArena { uint8_t *base; unsigned long long cap; unsigned long long *cursor; LongHdr *hdr; };
+__host__ __device__ inline unsigned long long long_arena_bytes(int32_t n_u, int32_t n_a)
+{
+    return (((unsigned long long)n_u * 8 + ((unsigned long long)n_u + 1) * 4 + 15) & ~15ull) + (unsigned long long)n_a * 16;
+}
 
 
 __device__ inline bool lr_region_kept(const LongParams &P, int32_t qlen, const LReg &r)
@@ -1212,7 +1308,10 @@ __device__ inline bool lr_region_kept(const LongParams &P, int32_t qlen, const L
 
 // 0: done; 1: an alignment needs a larger direction-byte buffer; 3: another capacity of the working memory was exceeded (C.err).
 // Either way the caller hands the read to the pass with the large working memory.
-__device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds &RL, bool flag_only, bool probe, LongOut &out)
+// ---- first kernel: the read's final chains ----
+// 0: done (header written; n_u may be 0); 3: a capacity of the working memory was exceeded (C.err); 4: the arena is full
+template <int NR>
+__device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const LongArena &AR, LongOut &out)
 {
     const LongParams &P = *C.P;
     LongWs &W = *C.W;
@@ -1229,8 +1328,8 @@ __device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds
         if ((uint32_t)n_u < W.cap_u && (n_u & 63) == lane) W.K[n_u] = (int32_t)h;
         ++n_u;
     }
-    if (n_u == 0) return 0;
-    if ((uint32_t)n_u > W.cap_u || (uint32_t)n_u > W.cap_r) { C.err = 2; return 3; }
+    if (n_u == 0) { if (lane == 0) { LongHdr h{0ull, 0, 0, 0, 0}; AR.hdr[read] = h; } return 0; }
+    if ((uint32_t)n_u > W.cap_u) { C.err = 2; return 3; }
     lr_sync();
     for (int32_t i = lane; i < n_u; i += 64) {
         const ChainRec rc = in.recs[W.K[i]];
@@ -1307,7 +1406,7 @@ __device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds
             lr_sync();
             int32_t tie = 0;
             lr_tick(C.clk, 1);
-            if (!lr_rmq_fill(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie)) { C.err = 6; return 3; }
+            if (!lr_rmq_fill<NR>(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie, C.clk)) { C.err = 6; return 3; }
             lr_sync();
             lr_tick(C.clk, 2);
             out.rmq_tie = tie;
@@ -1338,9 +1437,9 @@ __device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds
             n_u = al_b0(res[0]);
             const int32_t n_v = al_b0(res[1]);
             out.best = al_b0(res[2]); out.n_chain = n_u;
-            if (n_v < 0 || (uint32_t)n_u > W.cap_r) { C.err = 2; return 3; }
+            if (n_v < 0) { C.err = 2; return 3; }
             lr_sync();
-            if (n_u == 0) return 0;
+            if (n_u == 0) { if (lane == 0) { LongHdr h{0ull, 0, 0, 0, out.rechained | (out.rmq_tie ? 4 : 0)}; AR.hdr[read] = h; } return 0; }
             // compact_a: every chain ascending, then the chains by the x of their first anchor (ties: discovery order)
             for (int32_t c = 0; c < n_u; ++c) {
                 const int32_t k0 = (int32_t)W.uoff[c], ni = (int32_t)(uint32_t)W.u[c];
@@ -1371,14 +1470,60 @@ __device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds
     }
 
     lr_tick(C.clk, 3);
+    // ---- hand the chains to the second kernel
+    {
+        const unsigned long long bytes = long_arena_bytes(n_u, n_a);
+        unsigned long long off = 0;
+        if (lane == 0) off = atomicAdd(AR.cursor, bytes);
+        off = lr_b0_64(off);
+        if (off + bytes > AR.cap) return 4;
+        uint64_t *U = (uint64_t *)(AR.base + off);
+        uint32_t *UO = (uint32_t *)(U + n_u);
+        LAnchor *AO = (LAnchor *)(AR.base + off + (((unsigned long long)n_u * 8 + ((unsigned long long)n_u + 1) * 4 + 15) & ~15ull));
+        for (int32_t i = lane; i <= n_u; i += 64) { if (i < n_u) U[i] = W.u[i]; UO[i] = W.uoff[i]; }
+        for (int32_t i = lane; i < n_a; i += 64) AO[i] = A0[i];
+        if (lane == 0) { LongHdr h; h.off = off; h.n_u = n_u; h.n_a = n_a; h.best = out.best; h.rechained = out.rechained | (out.rmq_tie ? 4 : 0); AR.hdr[read] = h; }
+    }
+    return 0;
+}
+
+// ---- second kernel: regions, alignment, mm_filter_regs ----
+// 0: done; 1: an alignment needs a larger direction-byte buffer; 3: another capacity of the working memory was exceeded (C.err).
+__device__ inline int32_t lr_regs_wave(LongCtx &C, const ChainParams &CP, const LongArena &AR, bool flag_only, bool probe, LongOut &out)
+{
+    const LongParams &P = *C.P;
+    LongWs &W = *C.W;
+    const AlignIn &in = C.I->in;
+    const int32_t lane = (int32_t)al_lane();
+    const uint32_t read = C.read;
+    const int32_t qlen = C.qlen;
+    const LongHdr hd = AR.hdr[read];
+    out.n_chain = hd.n_u; out.best = hd.best; out.rechained = hd.rechained & 3; out.rmq_tie = (hd.rechained & 4) != 0;
+    out.n_aligned = out.n_regs = out.dp_max = 0; out.sig = 0; out.probed = 0;
+    if ((uint32_t)qlen > W.cap_q) { C.err = 4; return 3; }
+    const int32_t n_u = hd.n_u;
+    if (n_u == 0) return 0;
+    if ((uint32_t)n_u > W.cap_r || (uint32_t)n_u > W.cap_a) { C.err = 2; return 3; }
+    const uint64_t *Uh = (const uint64_t *)(AR.base + hd.off);
+    const uint32_t *UOh = (const uint32_t *)(Uh + n_u);
+    // the anchors are worked on in place (mm_squeeze_a moves them, the seed filters flag them): on a copy, so that a read this pass has to
+    // give up half-way starts from the same chains in the next one
+    if ((uint32_t)hd.n_a > W.cap_a) { C.err = 5; return 3; }
+    LAnchor *A0 = W.a;
+    {
+        const LAnchor *src = (const LAnchor *)(AR.base + hd.off + (((unsigned long long)n_u * 8 + ((unsigned long long)n_u + 1) * 4 + 15) & ~15ull));
+        for (int32_t i = lane; i < hd.n_a; i += 64) A0[i] = src[i];
+        lr_sync();
+    }
+    if (C.clk) C.clk->last = wall_clock64();
     // ---- mm_gen_regs: regions in descending z = (score << 32 | cnt) ^ h; of equal z the later chain first
     uint32_t hash = 0;
     hash ^= al_wang((uint32_t)qlen) + al_wang(11u);
     hash = al_wang(hash);
     for (int32_t i = lane; i < n_u; i += 64) {
-        const LAnchor f0 = A0[W.uoff[i]];
+        const LAnchor f0 = A0[UOh[i]];
         const uint32_t h = (uint32_t)al_hash64((al_hash64(f0.x) + al_hash64(f0.y)) ^ hash);
-        W.sk[i].k = W.u[i] ^ h; W.sk[i].v = (uint64_t)i;
+        W.sk[i].k = Uh[i] ^ h; W.sk[i].v = (uint64_t)i;
     }
     lr_sync();
     lr_sort(W.sk, W.sk2, n_u);
@@ -1387,7 +1532,7 @@ __device__ inline int32_t lr_read_wave(LongCtx &C, const ChainParams &CP, RmqLds
         LReg r{};
         r.id = j; r.parent = LR_PARENT_UNSET;
         r.score = (int32_t)(z.k >> 32); r.hash = (uint32_t)z.k;
-        r.cnt = (int32_t)(uint32_t)W.u[z.v]; r.as = (int32_t)W.uoff[z.v];
+        r.cnt = (int32_t)(uint32_t)Uh[z.v]; r.as = (int32_t)UOh[z.v];
         r.div = -1.0f;
         lr_reg_set_coor(r, qlen, A0);
         W.regs[j] = r;
