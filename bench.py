@@ -21,7 +21,8 @@ RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher instead.  Ranks that
 CPU copies of the bitmap, since RCCL refuses two ranks on one device.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel (k_sketch_probe): algorithmic bytes / HIP-event kernel time vs 8 TB/s
+  roofline      the stage that takes longest (`kernel` lists the kernels it sums; --chain-only: k_sketch_probe alone): algorithmic
+                bytes / HIP-event time vs 8 TB/s, the other stages in stage_ms_per_step, K1's own figure in streaming_kernel
   cpu_baseline  the CPU oracle (oracle/, "port": restated minimap2 decision path, NOT minimap2-rs)
                 on the host cores, on a bounded sample of the same records and the same index
 """
@@ -279,7 +280,7 @@ def main_reads(a, rank, world, local, dev, backend):
     }
     ext_ms = float(np.mean([s.get("ms_ext", 0.0) for s in stats]))
     if ext_ms > 0:      # SH_F_CIGAR: list building + base-level alignment of the reads no shortcut settles (reads + their reference windows + 40-B chain records)
-        stages["extension stage (k_ext_* + k_regs_align)"] = (ext_ms, 40 * s0.get("n_ext_regions", 0) + 2 * s0["n_bases"] // max(s0["n_reads"], 1) * s0.get("n_ext_reads", 0))
+        stages["extension stage (k_long_chains + k_regs_align_long)" if ont else "extension stage (k_ext_* + k_regs_align)"] = (ext_ms, 40 * s0.get("n_ext_regions", 0) + 2 * s0["n_bases"] // max(s0["n_reads"], 1) * s0.get("n_ext_reads", 0))
     # the roofline object describes the stage that takes LONGEST.  Round 1 (chain-level decision, --chain-only): k_sketch_probe, one streaming
     # kernel.  With the extension stage (SH_F_CIGAR, the default, what .with_cigar() makes the reference compute) the repeat path leads:
     # a few thousand satellite reads re-chained with max_occ hold most of the anchors, and their sort + sequential DP is latency-bound,
@@ -345,7 +346,7 @@ def main_reads(a, rank, world, local, dev, backend):
                              "configs[1]: 10M synthetic 2x150bp PE (20M records) vs CHM13v2-sized synthetic reference, sr preset, k-mer/minimizer classifier path"),
                 "records_total": n_total, "records_rank0": n_rec, "read_len": (round(n_bases / n_rec, 1) if ont else L), "host_pct": R.host_pct, "reference_bp": int(G),
                 "preset": "map-ont" if ont else "sr", "decision": ("chain level (--chain-only: no extension stage)" if a.chain_only else
-                                                                      "chain level: the extension filter is implemented for the short-read branch only (the library warns)" if ont else
+                                                                      "mappings.len() > 0 after the long-read branch of the extension filter (with_cigar): RMQ long join, mm_est_err, gap-filling alignment, mm_filter_regs" if ont else
                                                                       "mappings.len() > 0 after the extension filter (with_cigar)"), "k": info["k"], "w": info["w"], "records_per_launch": ctx_chunk(a, n_rec),
                 "parallelism": f"read-sharded x{world} (contiguous pair-aligned ranges of the same records), index replicated",
                 "ref_seed": hex(REF_SEED), "read_seed": hex(R.seed),
@@ -871,7 +872,7 @@ def cpu_baseline(index, info, d_reads, n_rec, L, seconds, d_flags, d_off=None, p
         dt = time.perf_counter() - t0
         return dt, int((fl != d_flags[first:first + count].cpu().numpy()).sum())
 
-    n_cal = min(n_rec, 200_000 if off_all is None else 4_000)
+    n_cal = min(n_rec, 200_000 if off_all is None else (4_000 if chain_only else 600))      # long reads with the extension stage: ~20 reads/s per core
     dt_cal, _ = run(0, n_cal, cores)                                    # calibration (also warms the index pages)
     n_s = int(min(n_rec, max(n_cal, n_cal / max(dt_cal, 1e-6) * seconds)))
     dt, mism = run(0, n_s, cores)

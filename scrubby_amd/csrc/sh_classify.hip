@@ -72,8 +72,8 @@ struct Counters {
     uint32_t ext_s3[8];           // SCRUBBY_HIP_DBG & 16: outcome of the local-cluster shortcut (k_expand): 0 tried, 1 no singleton / filtered seed, 2 singletons apart, 3 window grew / too many, 4 K > 64, 5 no margin over U_out, 6 lemma, 7 decided
     uint32_t ext_overflow, ext_n_list, ext_ticket, ext_regions, ext_dropped, ext_n_redo, ext_n_list2, ext_ticket2, ext_n_redo2, ext_ticket3;      // extension stage (sh_align.h)
     uint32_t ext_n_recs[SINK_SHARDS]; unsigned long long ext_n_anch[SINK_SHARDS];                 // hand-over cursors, one per shard
-    uint32_t lext_n_big, lext_ticket_big, lext_n_big2, lext_ticket_big2, lext_ticket_b, lext_pad2, lext_rechained, lext_rmq_tie, lext_err_read, lext_unresolved, lext_err_code, lext_pad;
-    unsigned long long lext_clk[LR_NCLK], lext_d[8];  // long-read extension stage (sh_long.h): reads for the large-scratch pass, RMQ re-chains, steps with tied priorities
+    uint32_t lext_hist[64]; uint32_t lext_n_big, lext_ticket_big, lext_n_big2, lext_ticket_big2, lext_ticket_b, lext_pad2, lext_rechained, lext_rmq_tie, lext_err_read, lext_unresolved, lext_err_code, lext_pad;
+    unsigned long long lext_clk[LR_NCLK], lext_d[8], lext_slow, lext_kernel_sum;  // long-read extension stage (sh_long.h): reads for the large-scratch pass, RMQ re-chains, steps with tied priorities
     uint32_t n_cl[4], cl_ticket, pad3;      // global queue of big clusters (k_cluster_dp), by size class
     uint32_t n_leg_reason[4];     // why reads left the long-read front end: 0 room/segments, 1 thinning screen, 2 anchors beyond the giant path, 3 unused
     unsigned long long arena_cursor, anchor_cursor;
@@ -2559,6 +2559,31 @@ struct ExtLongArgs {
     uint32_t *list; uint32_t *n_list, *ticket; uint32_t *big_list; uint32_t *n_big; Counters *ctr; uint8_t *flags; sh_trace *trace; int32_t flag_only, clk, probe;
 };
 
+// Largest reads first: a read's cost grows with its chain anchors (one with 70 k of them keeps a wave busy for a third of a second), and a
+// kernel ends with its slowest wave.  Reads are binned by log2 of their chain-anchor count and listed from the top bin down.
+__global__ void k_lext_bins(const ChainRec *recs, const uint32_t *head, const uint32_t *list, const uint32_t *n_list, uint32_t *size_of, uint32_t *hist)
+{
+    const uint32_t n = *n_list;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t r = list[i];
+        unsigned long long tot = 0;
+        for (uint32_t h = head[r]; h != ~0u; h = recs[h].next) tot += recs[h].cnt;
+        const uint32_t b = tot ? 63u - (uint32_t)__clzll(tot) : 0u;
+        size_of[i] = b < 31u ? b : 31u;
+        atomicAdd(&hist[size_of[i]], 1u);
+    }
+}
+__global__ void k_lext_scan(uint32_t *hist)      // hist[32] -> start of each bin, largest bin first; hist[32 + b] = running cursor
+{
+    uint32_t acc = 0;
+    for (int b = 31; b >= 0; --b) { const uint32_t c = hist[b]; hist[32 + b] = acc; acc += c; }
+}
+__global__ void k_lext_scatter(const uint32_t *list, const uint32_t *n_list, const uint32_t *size_of, uint32_t *hist, uint32_t *out)
+{
+    const uint32_t n = *n_list;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[atomicAdd(&hist[32 + size_of[i]], 1u)] = list[i];
+}
+
 // a read that outgrew the pass: to the pass with the large working memory, or - beyond that too - it keeps its chain-level answer and is counted
 __device__ inline void lext_defer(const ExtLongArgs &a, uint32_t r, uint32_t code, bool has_hdr)
 {
@@ -2591,7 +2616,9 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
         C.qlen = (int32_t)(I_l.in.offsets[r + 1] - I_l.in.offsets[r]); C.read = r;
         C.sc_mch = C.sc_mis = C.sc_amb = C.sc_N = 0; C.need_big = false; C.err = 0; C.clk = a.clk ? &clk : nullptr;
         LongOut o;
+        const unsigned long long t_r0 = a.clk ? wall_clock64() : 0ull;
         const int32_t rc = lr_chains_wave<NR>(C, RL, AR_l, o);
+        if (a.clk && lane == 0) { const unsigned long long dt = wall_clock64() - t_r0; atomicMax(&a.ctr->lext_slow, dt << 24 | (unsigned long long)(o.n_chain > 0xffffff ? 0xffffff : o.n_chain)); atomicAdd(&a.ctr->lext_kernel_sum, dt); }
         if (rc == 4) { if (lane == 0) atomicExch(&a.ctr->ext_overflow, 1u); }      // arena full: the host cuts the chunk in two
         else if (rc != 0) { if (lane == 0) lext_defer(a, r, 16u + C.err, false); }
         else { n_rechain += (o.rechained & 2) != 0; n_tie += o.rmq_tie != 0; }
@@ -2688,7 +2715,7 @@ struct sh_ctx {
     bool ext_long = false;
     LongParams LP{};
     uint8_t *d_lext[4] = {}; unsigned long long lext_per_wave[4] = {}; uint32_t lext_waves[4] = {}; LongSizes lext_sz[4] = {};      // [phase * 2 + tier]
-    uint32_t *d_lext_big = nullptr, *d_lext_big2 = nullptr;
+    uint32_t *d_lext_big = nullptr, *d_lext_big2 = nullptr, *d_lext_sorted = nullptr;
     uint8_t *d_larena = nullptr; unsigned long long larena_bytes = 0; LongHdr *d_lhdr = nullptr;
     hipStream_t sx[4] = {};          // side streams: K2 and the sort classes run beside the main stream
     int par = 1;                     // bit 0: K2 on a side stream (SCRUBBY_HIP_STREAMS=0: on the main stream)
@@ -2952,6 +2979,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             }
             if ((e = hipMalloc(&c->d_lext_big, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
             if ((e = hipMalloc(&c->d_lext_big2, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
+            if ((e = hipMalloc(&c->d_lext_sorted, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
             // the chains between the two kernels: what the hand-over buffers can hold, once more (the long join re-orders, it adds nothing)
             c->larena_bytes = SINK_SHARDS * cap_anch * 16 + SINK_SHARDS * cap_recs * 12 + max_reads * 32 + (1ull << 20);
             if ((e = hipMalloc(&c->d_larena, c->larena_bytes)) != hipSuccess) return fail(e, "long-read extension-stage arena");
@@ -2974,7 +3002,7 @@ extern "C" sh_status sh_ctx_destroy(sh_ctx *c)
     hipFree(c->d_work_defer); hipFree(c->d_work_defer2);
     for (auto &pp : c->d_big) for (auto p : pp) hipFree(p);
     hipFree(c->d_ctr); if (c->h_ctr) hipHostFree(c->h_ctr); hipFree(c->d_arena); hipFree(c->d_long);
-    hipFree(c->d_ext); hipFree(c->d_ext_scratch); for (auto q : c->d_lext) hipFree(q); hipFree(c->d_lext_big); hipFree(c->d_lext_big2); hipFree(c->d_larena); hipFree(c->d_lhdr);
+    hipFree(c->d_ext); hipFree(c->d_ext_scratch); for (auto q : c->d_lext) hipFree(q); hipFree(c->d_lext_big); hipFree(c->d_lext_big2); hipFree(c->d_lext_sorted); hipFree(c->d_larena); hipFree(c->d_lhdr);
     for (auto ev : c->ev_ext) if (ev) hipEventDestroy(ev);
     for (auto ev : c->ev) if (ev) hipEventDestroy(ev);
     for (auto ev : c->evx) if (ev) hipEventDestroy(ev);
@@ -3247,6 +3275,11 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
             ExtArgs xl{};
             xl.in = x.I.in; xl.list = x.list; xl.n_list = x.n_list; xl.n_reads = n_reads;
             hipLaunchKernelGGL(k_ext_list, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, s, xl);
+            // largest reads first (d_ext_redo: bin of each list entry; d_lext_big2: the ordered list, free until the second kernel's first pass ends)
+            hipLaunchKernelGGL(k_lext_bins, dim3(256), dim3(256), 0, s, c->sink.recs, c->sink.head, c->d_ext_list, &c->d_ctr->ext_n_list, c->d_ext_redo, c->d_ctr->lext_hist);
+            hipLaunchKernelGGL(k_lext_scan, dim3(1), dim3(1), 0, s, c->d_ctr->lext_hist);
+            hipLaunchKernelGGL(k_lext_scatter, dim3(256), dim3(256), 0, s, c->d_ext_list, &c->d_ctr->ext_n_list, c->d_ext_redo, c->d_ctr->lext_hist, c->d_lext_sorted);
+            x.list = c->d_lext_sorted;
         }
         auto sync_ctr = [&]() -> sh_status {
             SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -3299,9 +3332,10 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
             fprintf(stderr, "[dbg] long-read extension stage, share of wave time: gather %.1f  rmq-sort %.1f  rmq-fill %.1f  backtrack+compact %.1f  gen_regs %.1f  parent/select %.1f  squeeze %.1f  region set-up %.1f  ksw %.1f  z-drop test %.1f  update_extra %.1f  staging %.1f %%  (total %.1f wave-s at 100 MHz)\n",
                     100. * c->h_ctr->lext_clk[0] / (tot + 1), 100. * c->h_ctr->lext_clk[1] / (tot + 1), 100. * c->h_ctr->lext_clk[2] / (tot + 1), 100. * c->h_ctr->lext_clk[3] / (tot + 1), 100. * c->h_ctr->lext_clk[4] / (tot + 1), 100. * c->h_ctr->lext_clk[5] / (tot + 1),
                     100. * c->h_ctr->lext_clk[6] / (tot + 1), 100. * c->h_ctr->lext_clk[7] / (tot + 1), 100. * c->h_ctr->lext_clk[8] / (tot + 1), 100. * c->h_ctr->lext_clk[9] / (tot + 1), 100. * c->h_ctr->lext_clk[10] / (tot + 1), 100. * c->h_ctr->lext_clk[11] / (tot + 1), tot / 1e8);
-            fprintf(stderr, "[dbg] RMQ: %llu reads, %llu anchors (largest read %llu), 10 ns ticks per anchor: insert/evict %.2f, range minimum %.3f, inner scan %.2f, store %.1f; %.2f inner chunks\n",
+            fprintf(stderr, "[dbg] RMQ: %llu reads, %llu anchors (largest read %llu), per anchor: %.2f ring blocks, %.3f trips behind the ring with %.2f old blocks, list length %.1f, %.2f inner chunks\n",
                     c->h_ctr->lext_d[6], c->h_ctr->lext_d[0], c->h_ctr->lext_d[7], (double)c->h_ctr->lext_d[1] / (c->h_ctr->lext_d[0] + 1), (double)c->h_ctr->lext_d[2] / (c->h_ctr->lext_d[0] + 1),
                     (double)c->h_ctr->lext_d[3] / (c->h_ctr->lext_d[0] + 1), (double)c->h_ctr->lext_d[4] / (c->h_ctr->lext_d[0] + 1), (double)c->h_ctr->lext_d[5] / (c->h_ctr->lext_d[0] + 1));
+            fprintf(stderr, "[dbg] chains kernel: slowest read %.1f ms (%llu chains after the long join), all reads %.1f wave-ms\n", (c->h_ctr->lext_slow >> 24) / 1e5, c->h_ctr->lext_slow & 0xffffff, c->h_ctr->lext_kernel_sum / 1e5);
             for (int i = 0; i < SINK_SHARDS; ++i) { sr += c->h_ctr->ext_n_recs[i]; sa += c->h_ctr->ext_n_anch[i]; mr = std::max<unsigned long long>(mr, c->h_ctr->ext_n_recs[i]); ma = std::max<unsigned long long>(ma, c->h_ctr->ext_n_anch[i]); }
             fprintf(stderr, "[dbg] chain hand-over: %llu chains, %llu anchors; fullest shard %llu / %u chains, %llu / %llu anchors\n", sr, sa, mr, c->sink.cap_recs, ma, c->sink.cap_anch);
         }

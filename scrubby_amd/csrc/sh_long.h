@@ -226,18 +226,22 @@ __device__ inline double lr_cc_f64(const double *p) { return __longlong_as_doubl
 // Memory: what a step needs of the newest ~1000 anchors (f, p, the t marks, x, y, the priority) lives in the LDS ring, and the smallest
 // priority of everything older is one number (pml): a step only goes to HBM when the answer may lie further back than the ring.
 template <int LRQ_INNER>
-__device__ __noinline__ bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int32_t bw, int32_t n, const LAnchor *a, int32_t *f, int32_t *p,
+__device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int32_t bw, int32_t n, const LAnchor *a, int32_t *f, int32_t *p,
                                    double *pri, double *bmin /* n / 64 + 1 */, RmqLdsT<LRQ_INNER> &L, int32_t &n_tie, LongClk *dbg = nullptr)
 {
     n_tie = 0;
-    unsigned long long d_ring = 0, d_oldsteps = 0, d_old = 0, d_nin = 0, d_chunks = 0, tc0 = 0, tA = 0, tB = 0, tC = 0, tD = 0;
+    // the parameters in registers: P lives in the caller's scratch, and a load from it inside the loop costs more than the step's arithmetic
+    const float pen_gap = P.pen_gap, pen_skip = P.pen_skip;
+    const int32_t kk = P.k, max_skip = P.max_skip, rmq_inner_dist = P.rmq_inner_dist, rmq_size_cap = P.rmq_size_cap;
+    int32_t tie_cnt = 0;
+    unsigned long long d_ring = 0, d_oldsteps = 0, d_old = 0, d_nin = 0, d_chunks = 0;
     const int32_t lane = (int32_t)al_lane();
     constexpr int32_t M = LRQ_INNER - 1;
-    int32_t max_dist = max_dist_in, max_dist_inner = P.rmq_inner_dist;
+    int32_t max_dist = max_dist_in, max_dist_inner = rmq_inner_dist;
     if (max_dist < bw) max_dist = bw;
     if (max_dist_inner < 0) max_dist_inner = 0;
     if (max_dist_inner > max_dist) max_dist_inner = max_dist;
-    if (n > P.rmq_size_cap) return false;          // the size cap evicts out of order: not handled here
+    if (n > rmq_size_cap) return false;          // the size cap evicts out of order: not handled here
     for (int32_t i = lane; i < LRQ_INNER; i += 64) L.rt[i] = -1;
     __builtin_amdgcn_wave_barrier();
     int32_t blk_done = 0;      // blocks [0, blk_done) of 64 anchors are completely inserted; bmin[b] = their smallest priority
@@ -248,7 +252,6 @@ __device__ __noinline__ bool lr_rmq_fill(const LongParams &P, int32_t max_dist_i
     uint32_t hi_prev = 0;
     LAnchor cur = a[0];
     for (int32_t i = 0; i < n && ok; ++i) {
-        if (dbg) tc0 = wall_clock64();
         const uint64_t xi = cur.x, yi = cur.y;
         if (i + 1 < n) cur = a[i + 1];      // the next anchor travels while this one is worked on
         const int32_t qi = (int32_t)yi, q_span_i = (int32_t)(yi >> 32 & 0xff);
@@ -258,7 +261,7 @@ __device__ __noinline__ bool lr_rmq_fill(const LongParams &P, int32_t max_dist_i
         if (i0 < i && (seg0 == i || L.rx[i0 & M] != (uint32_t)xi)) {
             for (int32_t jb = i0; jb < i; jb += 64) {
                 const int32_t j = jb + lane;
-                if (j < i) { const double pj = -((double)L.rf[j & M] + 0.5 * (double)P.pen_gap * (double)((int32_t)L.rx[j & M] + L.ry[j & M])); L.rpri[j & M] = pj; pri[j] = pj; }
+                if (j < i) { const double pj = -((double)L.rf[j & M] + 0.5 * (double)pen_gap * (double)((int32_t)L.rx[j & M] + L.ry[j & M])); L.rpri[j & M] = pj; }
             }
             __builtin_amdgcn_wave_barrier();
             if (max_dist_inner > 0) {
@@ -297,6 +300,10 @@ __device__ __noinline__ bool lr_rmq_fill(const LongParams &P, int32_t max_dist_i
                 const double pm = blk_done > 0 && L.pml[(blk_done - 1) & 63] < m ? L.pml[(blk_done - 1) & 63] : m;
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 0) { bmin[blk_done] = m; L.pml[blk_done & 63] = pm; L.bml[blk_done & 63] = m; }
+                {   // the block leaves for HBM in one piece (a store inside the loop would make every later wait of the step wait for it too)
+                    const int32_t j = blk_done * 64 + lane;
+                    f[j] = L.rf[j & M]; p[j] = L.rp[j & M]; pri[j] = L.rpri[j & M];
+                }
                 __builtin_amdgcn_wave_barrier();
                 ++blk_done;
             }
@@ -335,7 +342,6 @@ __device__ __noinline__ bool lr_rmq_fill(const LongParams &P, int32_t max_dist_i
             }
         }
         d_nin += (unsigned long long)n_in;
-        if (dbg) { const unsigned long long t1 = wall_clock64(); tA += t1 - tc0; tc0 = t1; }
         int32_t max_f = q_span_i, max_j = -1;
         // (1) range minimum of the priority over the active anchors [st, i0) with (y_j, j) in [(q_i - max_dist, INT32_MAX), (q_i, 0)].
         // Newest first in blocks of 64: the blocks inside the ring out of LDS; everything older only if its smallest priority (pml, whatever
@@ -409,14 +415,13 @@ __device__ __noinline__ bool lr_rmq_fill(const LongParams &P, int32_t max_dist_i
                 }
             }
         }
-        if (dbg) { const unsigned long long t1 = wall_clock64(); tB += t1 - tc0; tc0 = t1; }
         if (bj >= 0) {
-            if (ties > 1) ++n_tie;      // the smallest index among the equal priorities is taken; the caller reports the read
+            if (ties > 1) ++tie_cnt;      // the smallest index among the equal priorities is taken; the caller reports the read
             int32_t exact, width, n_skip = 0;
             int32_t fb, dr, dq, span_b;
-            if (i - bj < LRQ_INNER - 64) { fb = L.rf[bj & M]; dr = (int32_t)((uint32_t)xi - L.rx[bj & M]); dq = qi - L.ry[bj & M]; span_b = P.k; }
+            if (i - bj < LRQ_INNER - 64) { fb = L.rf[bj & M]; dr = (int32_t)((uint32_t)xi - L.rx[bj & M]); dq = qi - L.ry[bj & M]; span_b = kk; }
             else { fb = (int32_t)cc_u32(f + bj); dr = (int32_t)(xi - a[bj].x); dq = qi - (int32_t)a[bj].y; span_b = (int32_t)(a[bj].y >> 32 & 0xff); }
-            int32_t sc = fb + lr_sc_simple(dr, dq, span_b, P.pen_gap, P.pen_skip, exact, width);
+            int32_t sc = fb + lr_sc_simple(dr, dq, span_b, pen_gap, pen_skip, exact, width);
             if (width <= bw && sc > max_f) { max_f = sc; max_j = bj; }
             if (!exact && n_in > 0 && qi > 0) {
                 // (2) the inner window from the largest (y, j) <= (q_i - 1, n) downwards, while y >= q_i - max_dist_inner; entries that have left
@@ -440,7 +445,7 @@ __device__ __noinline__ bool lr_rmq_fill(const LongParams &P, int32_t max_dist_i
                         j = LIJ(e);
                         if (j >= st_inner) {
                             int32_t ex2, w2;
-                            scj = L.rf[j & M] + lr_sc_simple((int32_t)((uint32_t)xi - L.rx[j & M]), qi - L.ry[j & M], P.k, P.pen_gap, P.pen_skip, ex2, w2);
+                            scj = L.rf[j & M] + lr_sc_simple((int32_t)((uint32_t)xi - L.rx[j & M]), qi - L.ry[j & M], kk, pen_gap, pen_skip, ex2, w2);
                             has = w2 <= bw;
                             pj = L.rp[j & M];
                         }
@@ -458,7 +463,7 @@ __device__ __noinline__ bool lr_rmq_fill(const LongParams &P, int32_t max_dist_i
                     const int32_t yl = n_skip + (int32_t)prefix_popc64(inc_m) + (inc_ev ? 1 : 0) - (int32_t)prefix_popc64(nm_m) - (new_max ? 1 : 0);
                     const int32_t mn = wave_scan_min_incl(yl);
                     const int32_t val = yl - (mn < 0 ? mn : 0);
-                    const uint64_t brk = __ballot(inc_ev && val > P.max_skip);
+                    const uint64_t brk = __ballot(inc_ev && val > max_skip);
                     const int nv = (int)__popcll(vm);
                     int Lb = brk ? __ffsll((unsigned long long)brk) - 1 : 63;
                     if (Lb > nv - 1) Lb = nv - 1;
@@ -473,18 +478,15 @@ __device__ __noinline__ bool lr_rmq_fill(const LongParams &P, int32_t max_dist_i
                 }
             }
         }
-        if (dbg) { const unsigned long long t1 = wall_clock64(); tC += t1 - tc0; tc0 = t1; }
-        if (lane == 0) {
-            f[i] = max_f; p[i] = max_j;
-            L.rx[i & M] = (uint32_t)xi; L.ry[i & M] = qi; L.rf[i & M] = max_f; L.rp[i & M] = max_j;
-        }
+        if (lane == 0) { L.rx[i & M] = (uint32_t)xi; L.ry[i & M] = qi; L.rf[i & M] = max_f; L.rp[i & M] = max_j; }
         hi_prev = (uint32_t)(xi >> 32);
         __builtin_amdgcn_wave_barrier();
-        if (dbg) { const unsigned long long t1 = wall_clock64(); tD += t1 - tc0; tc0 = t1; }
     }
 #undef LIY
 #undef LIJ
-    if (dbg) { dbg->d[0] += (unsigned long long)n; dbg->d[1] += tA; dbg->d[2] += tB; dbg->d[3] += tC; dbg->d[4] += tD; dbg->d[5] += d_chunks; dbg->d[6] += 1; if ((unsigned long long)n > dbg->d[7]) dbg->d[7] = (unsigned long long)n; }
+    n_tie = tie_cnt;
+    if (ok) for (int32_t j = blk_done * 64 + lane; j < n; j += 64) { f[j] = L.rf[j & M]; p[j] = L.rp[j & M]; }      // the last, incomplete block(s)
+    if (dbg) { dbg->d[0] += (unsigned long long)n; dbg->d[1] += d_ring; dbg->d[2] += d_oldsteps; dbg->d[3] += d_old; dbg->d[4] += d_nin; dbg->d[5] += d_chunks; dbg->d[6] += 1; if ((unsigned long long)n > dbg->d[7]) dbg->d[7] = (unsigned long long)n; }
     return ok;
 }
 
