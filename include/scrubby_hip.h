@@ -206,6 +206,10 @@ typedef struct sh_reads_result {
 } sh_reads_result;
 
 sh_status sh_reads_run(const sh_reads_config *cfg, sh_reads_result *out);
+/* sh_reads_run / sh_kraken_run keep the classification context of the last run (tens of GB of HBM scratch) for the next run of the
+ * process, because handing such memory back and asking for it again costs seconds (the driver wipes it).  A long-lived embedding
+ * process gets that memory back with this call; SCRUBBY_HIP_CTX_CACHE=0 in the environment switches the caching off.  Returns SH_OK. */
+sh_status sh_release_cached_ctx(void);
 
 /* ---- `scrubby classifier`: cleaning from precomputed Kraken2 / Metabuli outputs ------------------------------------
  * Cleaner::run_classifier_output (cleaner.rs:177-194) with the taxid decision rule of src/classifier.rs:

@@ -2833,7 +2833,9 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
     c->lds_words = (uint32_t)((tile_bytes + 15) / 16);
     const uint64_t n_tiles = (max_reads + 63) / 64;
     auto fail = [&](hipError_t e, const char *what) {
-        sh_set_error("sh_ctx_create: %s: %s", what, hipGetErrorString(e));
+        size_t mf = 0, mt = 0;
+        (void)hipMemGetInfo(&mf, &mt);
+        sh_set_error("sh_ctx_create: %s: %s (device memory: %.1f of %.1f GB free)", what, hipGetErrorString(e), mf / 1e9, mt / 1e9);
         sh_ctx_destroy(c);
         return e == hipErrorOutOfMemory ? SH_ERR_OOM : SH_ERR_HIP;
     };
@@ -2922,7 +2924,9 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         // read of the chunk (a chunk that needs more is cut in two and re-run: classify_chunk returns SH_SPLIT)
         uint64_t cap_recs = std::max<uint64_t>(1ull << 20, 2 * max_reads), cap_anch = std::max<uint64_t>(1ull << 24, 32 * max_reads);
         if (c->ext_long) {      // a long read's chains hold most of its minimizers (~2 / (w + 1) per base), secondary chains as many again
-            const uint64_t cb = std::min<uint64_t>(max_bases + 64, max_reads * (uint64_t)max_read_len + 64);
+            // bases of one chunk: max_bases may describe a whole batch of many chunks; ~8 kb per read is what long-read sets average - a
+            // chunk that holds more is cut in two when its chains do not fit (SH_SPLIT)
+            const uint64_t cb = std::min<uint64_t>({max_bases + 64, max_reads * (uint64_t)max_read_len + 64, max_reads * 8192ull + (64ull << 20)});
             cap_anch = std::max<uint64_t>(cap_anch, cb / 2);
             cap_recs = std::max<uint64_t>(cap_recs, std::min<uint64_t>(cb / 16, 1ull << 28) + 8 * max_reads);      // repeat-rich reads leave hundreds of small chains each
         }
@@ -2958,15 +2962,15 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             z.cap_q = (uint32_t)((L + 31) & ~15ull);
             z.cap_k = (uint32_t)std::min<uint64_t>(32768, ((2 * L + 1024) + 15) & ~15ull);
             z.cap_t = (uint32_t)(2 * L + 65536);
-            z.cap_a = (uint32_t)std::min<uint64_t>(1ull << 17, std::max<uint64_t>(16384, 2 * L));
+            z.cap_a = (uint32_t)std::min<uint64_t>(1ull << 16, std::max<uint64_t>(16384, 2 * L));
             z.cap_u = z.cap_r = (uint32_t)std::min<uint64_t>(z.cap_a, 16384);
             z.cap_m = (uint32_t)std::min<uint64_t>(65536, L / 4 + 1024);
-            z.cap_p = std::min<uint64_t>(8ull << 20, (uint64_t)(2 * z.cap_k) * (z.cap_k + 32));
+            z.cap_p = std::min<uint64_t>(4ull << 20, (uint64_t)(2 * z.cap_k) * (z.cap_k + 32));
             if (const char *env = getenv("SCRUBBY_HIP_LEXT_P_KB")) z.cap_p = (uint64_t)atoll(env) << 10;
             LongSizes zb = z;
             zb.cap_p = std::min<uint64_t>(256ull << 20, (uint64_t)(2 * z.cap_k) * (z.cap_k + 32));
             zb.cap_a = 1u << 21; zb.cap_u = zb.cap_r = 1u << 18; zb.cap_m = 65536;
-            const uint64_t budget[4] = {24ull << 30, 8ull << 30, 24ull << 30, 12ull << 30};
+            const uint64_t budget[4] = {12ull << 30, 7ull << 30, 14ull << 30, 11ull << 30};
             const uint64_t wave_max[4] = {256 * 8, 32, 256 * 8, 32};      // LDS: 19 KB per wave in both kernels
             for (int ph = 0; ph < 2; ++ph) for (int t = 0; t < 2; ++t) {
                 LongSizes q = t ? zb : z;

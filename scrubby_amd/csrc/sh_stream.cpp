@@ -737,7 +737,7 @@ __global__ void k_rebase_offsets(const uint64_t *__restrict__ src, uint64_t *__r
 }
 
 // The context the last run left behind (one per process): taken by the next run if it was built with the same options and is large
-// enough, re-pointed at that run's index (shi_ctx_rebind).  Freed only at process exit, by the driver.
+// enough, re-pointed at that run's index (shi_ctx_rebind).  Freed by sh_release_cached_ctx(), never kept with SCRUBBY_HIP_CTX_CACHE=0.
 struct CtxCache {
     std::mutex mu;
     sh_ctx *ctx = nullptr;
@@ -746,7 +746,7 @@ struct CtxCache {
     static std::string env_sig()
     {
         std::string e;
-        for (const char *v : {"SCRUBBY_HIP_ARENA_MB", "SCRUBBY_HIP_NO_FLAG_STOP", "SCRUBBY_HIP_NO_PAIR", "SCRUBBY_HIP_PAIR_MIN", "SCRUBBY_HIP_NO_S1", "SCRUBBY_HIP_NO_LEMMA", "SCRUBBY_HIP_EXT_MB", "SCRUBBY_HIP_DBG"}) {
+        for (const char *v : {"SCRUBBY_HIP_ARENA_MB", "SCRUBBY_HIP_NO_FLAG_STOP", "SCRUBBY_HIP_NO_PAIR", "SCRUBBY_HIP_PAIR_MIN", "SCRUBBY_HIP_NO_S1", "SCRUBBY_HIP_NO_LEMMA", "SCRUBBY_HIP_EXT_MB", "SCRUBBY_HIP_DBG", "SCRUBBY_HIP_LEXT_P_KB"}) {
             const char *x = getenv(v); e += x ? x : "-"; e += '|';
         }
         return e;
@@ -764,10 +764,20 @@ struct CtxCache {
     {
         std::lock_guard<std::mutex> lk(mu);
         if (ctx) sh_ctx_destroy(ctx);
+        ctx = nullptr;
+        const char *off = getenv("SCRUBBY_HIP_CTX_CACHE");
+        if (off && atoi(off) == 0) { sh_ctx_destroy(c); return; }
         ctx = c; opts = o; env = env_sig();
+    }
+    void release()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (ctx) sh_ctx_destroy(ctx);
+        ctx = nullptr;
     }
 };
 CtxCache g_ctx_cache;
+extern "C" sh_status sh_release_cached_ctx(void) { g_ctx_cache.release(); return SH_OK; }
 
 // the device thread's side of pass 1: one context (minimap2's thread buffer), one stream; kernels and the flags' way back
 struct DeviceSide {

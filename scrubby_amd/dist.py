@@ -69,6 +69,34 @@ def gathered_to_flags(gathered, slice_bytes, n_records, world):
     return torch.cat(parts)
 
 
+def gather_calls(calls, slice_len=None, group=None, via_host=False):
+    """The Kraken2-style arm (run_kraken, /root/reference/src/cleaner.rs:288-330): every rank classified a contiguous range of the pairs;
+    the per-pair taxid calls (uint32, one per pair - what kraken.reads lists and what the report counts) are all-gathered, so that
+    every rank holds the calls of the whole job.  calls: this rank's int32/uint32 vector.  Returns (gathered [world * slice_len], slice_len)."""
+    c = calls.contiguous().view(-1)
+    if via_host:
+        c = c.cpu()
+    world = dist.get_world_size(group)
+    if slice_len is None:
+        m = torch.tensor([c.numel()], dtype=torch.int64, device=c.device)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+        slice_len = int(m.item())
+    if c.numel() < slice_len:
+        c = torch.cat([c, torch.zeros(slice_len - c.numel(), dtype=c.dtype, device=c.device)])
+    out = [torch.empty(slice_len, dtype=c.dtype, device=c.device) for _ in range(world)]
+    dist.all_gather(out, c, group=group)
+    return torch.cat(out), slice_len
+
+
+def gathered_to_calls(gathered, slice_len, n_records, world):
+    """The all-gathered call slices back to one vector over the job's pairs (records 2p, 2p + 1 = pair p)."""
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(n_records, r, world)
+        parts.append(gathered[r * slice_len:r * slice_len + (hi - lo) // 2])
+    return torch.cat(parts)
+
+
 def sum_counters(values, device, group=None):
     """all_reduce(sum) of a few int64 counters ({records, depleted, ...})."""
     t = torch.tensor(list(values), dtype=torch.int64, device=device)

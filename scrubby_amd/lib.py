@@ -124,7 +124,7 @@ EXPORTS = [
     "sh_index_info_get", "sh_index_export", "sh_index_export_ref", "sh_index_free",
     "sh_ctx_create", "sh_ctx_destroy", "sh_classify_device", "sh_classify_batch",
     "sh_synth_ref_device", "sh_synth_reads_device", "sh_synth_long_reads_device", "sh_bench_gather", "sh_pack_flags_device",
-    "sh_reads_run", "sh_host_get_id", "sh_host_filter_fastx", "sh_host_filter_fastx_stream", "sh_host_read_difference",
+    "sh_reads_run", "sh_release_cached_ctx", "sh_host_get_id", "sh_host_filter_fastx", "sh_host_filter_fastx_stream", "sh_host_read_difference",
     "sh_classifier_run", "sh_classifier_taxids", "sh_alignment_run",
     "sh_k2_default_opts", "sh_k2_open", "sh_k2_create", "sh_k2_insert_device", "sh_k2_insert_sequence_device",
     "sh_k2_insert_random", "sh_k2_save", "sh_k2_info_get", "sh_k2_db_opts", "sh_k2_export", "sh_k2_free",
@@ -315,8 +315,13 @@ class Context:
         self.h = h
 
     def classify(self, d_bases, d_offsets, d_flags, d_trace=None, want_stats=True):
-        """All arguments are torch CUDA tensors (uint8 / int64-as-uint64 / uint8 / int32[n,8])."""
+        """All arguments are torch CUDA tensors: bases uint8, offsets int64 (read as uint64) [n + 1], flags uint8 [n], and optionally
+        the trace, int32 [n, 12] = one sh_trace (48 bytes) per read, contiguous - the kernels write all twelve words."""
         n = d_offsets.numel() - 1
+        if d_trace is not None:
+            assert d_trace.is_contiguous() and d_trace.element_size() == 4 and d_trace.numel() >= n * len(TRACE_FIELDS), \
+                f"trace buffer must hold {len(TRACE_FIELDS)} int32 words per read ({n} reads)"
+        assert d_flags.numel() >= n and d_offsets.is_contiguous() and d_bases.is_contiguous()
         st = Stats()
         check(load().sh_classify_device(self.h, C.c_void_p(d_bases.data_ptr()), C.c_void_p(d_offsets.data_ptr()), n,
                                         d_bases.numel(), C.c_void_p(d_flags.data_ptr()),
@@ -411,6 +416,11 @@ def read_difference(inputs, outputs):
     r = [C.c_uint64(), C.c_uint64(), C.c_uint64()]
     check(load().sh_host_read_difference(a, b, n, C.byref(r[0]), C.byref(r[1]), C.byref(r[2])))
     return tuple(x.value for x in r)
+
+
+def release_cached_context():
+    """Give back the HBM scratch that reads_run / kraken_run keep between runs of this process (sh_release_cached_ctx)."""
+    check(load().sh_release_cached_ctx())
 
 
 def reads_run(inputs, outputs, index, preset=None, extract=False, json=None, read_ids=None, command="", threads=4, device=0):

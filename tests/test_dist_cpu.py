@@ -56,3 +56,30 @@ def test_pack_unpack_roundtrip():
     b = D.pack_flags(f)
     assert b.tolist() == [0b10011001, 0b101]
     assert D.unpack_flags(b, 11).tolist() == [1, 0, 0, 1, 1, 0, 0, 1, 1, 0, 1]
+
+
+def _calls_worker(rank, world, port, n_records, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scrubby_amd import dist as D
+    rng = np.random.default_rng(99)
+    n_pairs = n_records // 2
+    all_calls = rng.integers(0, 50_000, n_pairs).astype(np.int32)
+    lo, hi = D.shard_range(n_records, rank, world)
+    res = np.zeros(((hi - lo) // 2, 4), np.int32)              # the classifier's result rows: column 0 = the call
+    res[:, 0] = all_calls[lo // 2:hi // 2]
+    res[:, 1:] = 7
+    gathered, sl = D.gather_calls(torch.from_numpy(res)[:, 0], D.shard_range(n_records, 0, world)[1] // 2)
+    back = D.gathered_to_calls(gathered, sl, n_records, world).numpy()
+    ret[rank] = bool(np.array_equal(back, all_calls)) and sl * world >= n_pairs
+    dist.destroy_process_group()
+
+
+def test_taxid_calls_gathered_world2():
+    """The exchange of the Kraken2-style arm at N > 1 (bench.py --workload k2 --gpus N): contiguous pair shards, calls all-gathered."""
+    world, n = 2, 100_006
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_calls_worker, args=(world, 29519, n, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: True, 1: True}

@@ -74,3 +74,23 @@ def test_bench_spawns_its_ranks(tmp_path):
                          env=env, capture_output=True, text=True, timeout=280)
     j1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     assert j1["n_gpus"] == 1 and j1["result"]["reads_removed"] == j["result"]["reads_removed"]
+
+
+def test_k2_bench_is_strong_scaled_over_its_ranks(tmp_path):
+    """BASELINE configs[4] in miniature: `bench.py --workload k2 --gpus 2` cuts the SAME pairs in two (the ranks share device 0 here, so
+    gloo carries the calls), gathers every pair's call inside the timed region and finds the human pairs the one-rank run finds."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    runs = {}
+    for n in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "k2", "--gpus", str(n), "--small", "--steps", "2", "--warmup", "1", "--no-cpu"],
+                           env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs[n] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    j1, j2 = runs[1], runs[2]
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "strong" and j2["config"]["records_total"] == 200_000 and j2["config"]["records_rank0"] == 100_000
+    assert j2["calls_gathered_bytes"] == 2 * 50_000 * 4
+    assert j1["result"]["pairs_human_total"] == j2["result"]["pairs_human_total"] > 10_000
