@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--records", type=int, default=20_000_000, help="records per GPU (2 per pair)")
     ap.add_argument("--chunk", type=int, default=1 << 25, help="records per kernel launch (default: the whole batch in one launch)")
     ap.add_argument("--small", action="store_true", help="5 Mb reference / 200k records (plumbing check)")
-    ap.add_argument("--workload", choices=["sr", "ont", "k2", "e2e", "e2e-k2"], default="sr",
+    ap.add_argument("--workload", choices=["sr", "sr-div", "ont", "k2", "e2e", "e2e-k2"], default="sr",
                     help="sr = BASELINE configs[1] (headline); ont = configs[3] stand-in: long noisy reads, map-ont preset; "
                          "k2 = configs[4] stand-in: Kraken2-style taxid classification of 2x150 bp pairs against an 8 GB table (not the headline metric)")
     ap.add_argument("--k2-cells", type=int, default=2_000_000_000, help="cells of the compact hash table (4 B each)")
@@ -195,6 +195,8 @@ def main_reads(a, rank, world, local, dev, backend):
                 reads_from_packed(d_packed, G, r_lo, n, L, R.host_pct, R.sub_per_10k, READ_SEED, b["d_reads"], b["d_off"])
             else:
                 S.synth_reads_device(P, R, r_lo, n, b["d_reads"], b["d_off"])
+            if a.workload == "sr-div":
+                diverge_reads(b["d_reads"], n, L, r_lo, dev)
             b["ctx"] = S.Context(index, max(min(a.chunk, n), 1), b["n_bases"], L)
         b["d_flags"] = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)[:n]
         torch.cuda.synchronize()
@@ -311,6 +313,9 @@ def main_reads(a, rank, world, local, dev, backend):
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
         cpu = cpu_baseline(index, info, d_reads, n_rec, L, a.cpu_seconds, d_flags, d_off if ont else None, "map-ont" if ont else "sr", a.chain_only)
+    strat = None
+    if rank == 0 and world == 1 and not a.no_cpu and not ont and not a.chain_only and ctx_chunk(a, n_rec) >= n_rec:
+        strat = stratified_parity(index, ctx, info, d_reads, d_flags, n_rec, L)
     ext_oracle = None
     if rank == 0 and world == 1 and not a.no_cpu and not ont:
         ext_oracle = external_oracle(index, d_reads, n_rec, L, d_flags, contigs, P, dev, real_ref)
@@ -333,6 +338,7 @@ def main_reads(a, rank, world, local, dev, backend):
     if rank == 0:
         out = {
             "metric": ("reads/s depleted (long reads, map-ont, vs CHM13v2-sized reference) - NOT the headline metric" if ont else
+                       "reads/s depleted (2x150bp PE diverged / chimeric, vs CHM13v2-sized reference) - NOT the headline metric" if a.workload == "sr-div" else
                        "reads/s depleted (2x150bp PE vs CHM13v2-sized reference), records classified per second"),
             "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -341,6 +347,7 @@ def main_reads(a, rank, world, local, dev, backend):
             "config": {
                 "workload": ("configs[3] stand-in: %d long reads (log-normal-like lengths, median 5.4 kb; 2 %% substitutions, 1.56 %% insertions, 1.56 %% deletions), map-ont preset; "
                              "segment-parallel long-read front end + repeat path" % n_rec if ont else
+                             "sr-div (NOT the headline): the records of configs[1] diverged in place - a third each with 5 / 10 / 15 %% substitutions, 2 %% chimeras, 5 %% with a 15 %%-diverged 70-base stretch of another record spliced in - vs the same reference, sr preset" if a.workload == "sr-div" else
                              "cfg1-small: 200k records vs 5 Mb" if a.small else
                              ("configs[2]: the 10M synthetic 2x150bp PE (20M records) of configs[1], read-sharded over %d GPUs, vs CHM13v2-sized synthetic reference, sr preset" % world) if world > 1 else
                              "configs[1]: 10M synthetic 2x150bp PE (20M records) vs CHM13v2-sized synthetic reference, sr preset, k-mer/minimizer classifier path"),
@@ -357,11 +364,15 @@ def main_reads(a, rank, world, local, dev, backend):
                        "pair_decided": s0["n_pair_decided"],
                        # the extension stage `.with_cigar()` enables: reads it had to align, regions, and the flags it flips
                        "ext_shortcut_reads": s0["n_ext_shortcut"], "ext_reads": s0["n_ext_reads"], "ext_regions": s0["n_ext_regions"],
-                       "ext_flags_flipped": s0["n_ext_dropped"], "ext_ms_per_step": round(float(np.mean([x["ms_ext"] for x in stats])), 3)},
+                       "ext_flags_flipped": s0["n_ext_dropped"], "ext_ms_per_step": round(float(np.mean([x["ms_ext"] for x in stats])), 3),
+                       # reads whose regs[0] did not survive and that were re-chained with every chain kept (sr), and what that costs per step
+                       "ext_fallback_reads": s0.get("n_ext_fallback", 0), "ext_fallback_ms_per_step": round(float(np.mean([x.get("ms_ext_fallback", 0.0) for x in stats])), 3),
+                       "ext_fallback_share_of_step": round(float(np.mean([x.get("ms_ext_fallback", 0.0) for x in stats])) / max(ms_step, 1e-9), 4),
+                       "rmq_rechained": s0.get("n_rmq_rechained", 0), "rmq_tied": s0.get("n_rmq_tied", 0), "ext_unresolved": s0.get("n_ext_unresolved", 0)},
             "index": {"n_keys": info["n_keys"], "n_minimizers": info["n_minimizers"], "n_slots": info["n_slots"],
                       "n_positions": info["n_positions"], "hbm_GB": round(info["hbm_bytes"] / 1e9, 2),
                       "build_s": round(t_idx, 2), "ref_synth_s": round(t_ref, 2)},
-            "roofline": roofline, "cpu_baseline": cpu, "host_buffer_path": host_path,
+            "roofline": roofline, "cpu_baseline": cpu, "stratified_parity": strat, "host_buffer_path": host_path,
             # the real tools, if this box has them (it has no network, so normally it does not); a real CHM13v2 FASTA
             # given through $SCRUBBY_CHM13 replaces the synthetic reference of the same size
             "external_oracle": ext_oracle, "reference_source": ref_source,
@@ -772,6 +783,43 @@ def reads_from_packed(d_packed, G, r_lo, n, L, host_pct, sub_per_10k, seed, d_ou
     d_off.copy_(torch.arange(n + 1, dtype=torch.int64, device=dev) * L)
 
 
+SR_DIV_SEED = 0x5C2B0040
+
+
+def diverge_reads(d_reads, n, L, r_lo, dev, slab=2_000_000):
+    """--workload sr-div: the headline's records made hard for the extension filter, in place on the device (seeded; same reads every run on
+    the same hardware).  A third of the records each get 5 / 10 / 15 % of their bases replaced by a random base (on top of the generator's
+    0.5 %), 2 % become chimeras (second half taken from another record), and 5 % get a 70-base stretch of another record, itself 15 %
+    diverged, spliced into their middle (microbial reads sharing a diverged repeat family with the host, host reads with a foreign insert):
+    chains that die in mm_filter_regs, regs[0] that does not survive, reads that need every chain."""
+    reads = d_reads[:n * L].view(n, L)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(SR_DIV_SEED + r_lo)
+    rates = torch.tensor([0.05, 0.10, 0.15], device=dev)
+    src = reads.clone()
+    for s0 in range(0, n, slab):
+        s1 = min(n, s0 + slab)
+        m = s1 - s0
+        idx = torch.arange(s0, s1, device=dev)
+        blk = reads[s0:s1]
+        u = torch.rand((m, L), device=dev, generator=g)
+        rnd = acgt[torch.randint(0, 4, (m, L), device=dev, generator=g)]
+        sub = u < rates[(idx % 3)].unsqueeze(1)
+        blk[sub] = rnd[sub]
+        sel = torch.rand(m, device=dev, generator=g)
+        chim = sel < 0.02
+        other = (idx + 2 * 100_003) % n
+        blk[chim, L // 2:] = src[other[chim], L // 2:]
+        ins = (sel >= 0.02) & (sel < 0.07)
+        seg = src[(idx + 2 * 7919 + 1) % n][:, 40:110].clone()
+        segsub = torch.rand((m, 70), device=dev, generator=g) < 0.15
+        seg[segsub] = acgt[torch.randint(0, 4, (m, 70), device=dev, generator=g)][segsub]
+        blk[ins, 40:110] = seg[ins]
+    del src
+    torch.cuda.synchronize()
+
+
 def ctx_chunk(a, n_rec):
     return min(a.chunk, n_rec)
 
@@ -902,6 +950,39 @@ def cpu_baseline(index, info, d_reads, n_rec, L, seconds, d_flags, d_off=None, p
             "reads_per_s_per_thread": round(n_s / dt / cores, 1), "logical_cpus": logical, "physical_cores": physical_cores(), "cgroup_cpu_quota": cpu_quota(),
             "sample": f"first {n_s} records of the same batch in ONE call, same index and reference (copied from HBM), {cores} threads (one per usable core: physical cores capped by the cgroup CPU quota), {dt:.1f} s; "
                       f"restatement baseline - not minimap2-rs; flags differing from the GPU on the sample: {mism}"}
+
+
+def stratified_parity(index, ctx, info, d_reads, d_flags, n_rec, L, n_random=300_000, seed=20261004):
+    """Flags of the GPU against the oracle where a bug would live: EVERY read of the batch that was re-chained with max_occ, every read whose
+    regs[0] had to be aligned base by base, every read that fell back to the complete procedure (sh_ctx_debug_list), plus a random sample
+    of the rest.  The batch must have been classified by ONE launch of `ctx` (the lists describe its last chunk)."""
+    from oracle import oracle as O
+    strata = {}
+    names = ("rechained_max_occ", "regs0_aligned", "full_fallback")
+    for which, nm in enumerate(names):
+        strata[nm] = np.unique(ctx.debug_list(which).astype(np.int64))
+        strata[nm] = strata[nm][strata[nm] < n_rec]
+    special = np.unique(np.concatenate(list(strata.values()))) if strata else np.zeros(0, np.int64)
+    rng = np.random.default_rng(seed)
+    rest = rng.choice(n_rec, size=min(n_random, n_rec), replace=False).astype(np.int64)
+    rest = np.setdiff1d(rest, special)
+    pick = np.concatenate([special, rest])
+    if len(pick) == 0:
+        return None
+    idx = torch.from_numpy(pick).to(d_reads.device)
+    rows = d_reads[:n_rec * L].view(n_rec, L)[idx].cpu().numpy().reshape(-1)
+    gflags = d_flags[idx].cpu().numpy()
+    slots, pos = index.export()
+    oidx = O.Index.wrap(slots, pos, info["w"], info["k"], ref=index.export_ref())
+    oo = oidx.update_opts(O.preset("sr"))
+    t0 = time.perf_counter()
+    of, _ = oidx.classify(oo, rows, np.arange(len(pick) + 1, dtype=np.uint64) * L, threads=usable_cores(), want_trace=False)
+    dt = time.perf_counter() - t0
+    bad = of != gflags
+    out = {"reads_checked": int(len(pick)), "flags_differing": int(bad.sum()), "oracle_s": round(dt, 1),
+           "strata": {nm: {"reads": int(len(v)), "flags_differing": int(bad[np.isin(pick, v)].sum())} for nm, v in strata.items()},
+           "random_rest": {"reads": int(len(rest)), "flags_differing": int(bad[len(special):].sum())}}
+    return out
 
 
 def external_oracle(index, d_reads, n_rec, L, d_flags, contigs, P, dev, real_ref=None, max_reads=400_000):

@@ -122,6 +122,11 @@ typedef struct sh_stats {
     uint64_t n_ext_dropped;    /* reads with a chain but no surviving region: the flags this stage flips */
     double   ms_ext;           /* HIP-event time of the extension stage */
     uint64_t n_ext_shortcut;   /* SH_F_CIGAR flag-only: reads decided inside a chaining kernel - their top chain's max stretch alone passes mm_filter_regs */
+    uint64_t n_ext_fallback;   /* SH_F_CIGAR flag-only, sr: reads whose regs[0] did not survive and that were re-chained with every chain kept */
+    double   ms_ext_fallback;  /* wall time of that fallback (re-chaining + the complete procedure) */
+    uint64_t n_ext_unresolved; /* long-read presets: reads beyond the stage's largest working memory, left at their chain-level answer (see the warning) */
+    uint64_t n_rmq_rechained;  /* long-read presets: reads re-chained by the RMQ long join */
+    uint64_t n_rmq_tied;       /* ... of which met two candidates of equal priority in the join (the smaller index was taken) */
 } sh_stats;
 
 typedef struct sh_index sh_index;
@@ -166,6 +171,10 @@ sh_status sh_index_free(sh_index *idx);
 sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uint64_t max_reads, uint64_t max_bases,
                         uint32_t max_read_len, sh_ctx **out);
 sh_status sh_ctx_destroy(sh_ctx *ctx);
+/* Measurement aid (bench.py's stratified parity sample): which reads of the LAST chunk the context classified took the rare paths of
+ * the short-read extension stage.  which = 0: re-chained with max_occ (mm_map_frag's second pass), 1: regs[0] aligned base by base,
+ * 2: the complete procedure over every chain.  Read ordinals within that chunk; *n_out = their number (out may be NULL). */
+sh_status sh_ctx_debug_list(const sh_ctx *ctx, int32_t which, uint32_t *out, uint64_t cap, uint64_t *n_out);
 
 /* Inputs and outputs in HBM.  d_flags[r] = 1 host (>=1 mapping), 0 retained, 2 empty read.
  * d_trace may be NULL.  Asynchronous on `stream`; stats (nullable) forces a stream sync. */

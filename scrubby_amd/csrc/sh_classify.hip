@@ -45,6 +45,7 @@
 #include "sh_chain.h"
 #include "sh_long.h"
 #include <algorithm>
+#include <chrono>
 
 #define SH_SPLIT ((sh_status)-2)      // internal: classify_chunk asks for smaller chunks
 #define K1_LIST_CAP 8           // ring of queued minimizers per lane (power of two; 4 KiB of LDS per wave); 4 are drained per W-step block
@@ -1469,6 +1470,7 @@ struct K3Args {
     ChainSink sink; int32_t emit;      // SH_F_CIGAR: chains are handed to the extension stage (flag_only is 0 then: no early exit)
     BaseCtx BC;
     int32_t t_mode;                    // SH_F_CIGAR and no trace wanted: only regs[0] matters, shortcuts allowed
+    int32_t quiet;                     // a second visit of reads that were counted already: no statistics
 };
 
 
@@ -2322,7 +2324,7 @@ __global__ void k_finalize(K3Args a)
         write_trace(a.trace, m.r, (int32_t)(info & 0xffffu), (int32_t)(a.seed_off ? info >> 16 : (info >> 16 & 0x7fffu)), (int32_t)m.n_a, m.rep_len, a.pass, n_u, best, fl);
         n_host_thr += (uint32_t)fl;
     }
-    if (n_host_thr) atomicAdd(&a.ctr->sh_host[(blockIdx.x + threadIdx.x) & 63], n_host_thr);
+    if (n_host_thr && !a.quiet) atomicAdd(&a.ctr->sh_host[(blockIdx.x + threadIdx.x) & 63], n_host_thr);
 }
 
 __device__ inline uint8_t *arena_alloc(const K2Args &a, size_t bytes)
@@ -2711,6 +2713,9 @@ struct sh_ctx {
     uint32_t *d_ext_list = nullptr, *d_ext_redo = nullptr; uint8_t *d_ext_scratch = nullptr;
     unsigned long long ext_scratch_per_wave = 0; uint32_t ext_waves = 0, ext_reg_cap = 0;
     hipEvent_t ev_ext[2] = {};
+    // which reads of the LAST chunk took the rare paths (sh_ctx_debug_list: the bench's stratified oracle sample): 0 re-chained with max_occ,
+    // 1 regs[0] aligned base by base, 2 the full fallback with every chain
+    const uint32_t *dbg_ptr[3] = {}; uint32_t dbg_n[3] = {};
     // the same stage for the long-read presets (sh_long.h): per-wave working memory in two sizes
     bool ext_long = false;
     LongParams LP{};
@@ -2999,6 +3004,17 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
     return SH_OK;
 }
 
+extern "C" sh_status sh_ctx_debug_list(const sh_ctx *c, int32_t which, uint32_t *out, uint64_t cap, uint64_t *n_out)
+{
+    SH_CHECK(c && n_out && which >= 0 && which < 3, SH_ERR_BAD_ARG, "sh_ctx_debug_list: bad argument");
+    *n_out = c->dbg_ptr[which] ? c->dbg_n[which] : 0;
+    if (!out || !c->dbg_ptr[which]) return SH_OK;
+    const uint64_t n = std::min<uint64_t>(cap, c->dbg_n[which]);
+    SH_HIP(hipSetDevice(c->idx_device));
+    if (n) SH_HIP(hipMemcpy(out, c->dbg_ptr[which], n * 4, hipMemcpyDeviceToHost));
+    return SH_OK;
+}
+
 extern "C" sh_status sh_ctx_destroy(sh_ctx *c)
 {
     if (!c) return SH_OK;
@@ -3204,45 +3220,50 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     }
     bool first = true;
     Counters snap{};
-    for (int iter = 0;; ++iter) {
-        SH_CHECK(iter < 256, SH_ERR_OOM, "chain arena (%llu MiB) too small; set SCRUBBY_HIP_ARENA_MB", (unsigned long long)(c->arena_bytes >> 20));
-        k.pass = 0; k.max_occ = c->P.mid_occ;
-        k.list = c->d_big[0][cur0]; k.list_count = &c->d_ctr->n_big[0];
-        k.defer_list = c->d_big[0][cur0 ^ 1]; k.defer_count = &c->d_ctr->n_big_defer[0];
-        k.next_list = c->d_big[1][cur1]; k.next_count = &c->d_ctr->n_big[1];
-        sh_status st = big_pass(c, k, grid, s);
-        if (st != SH_OK) return st;
-        if (first && k2_late) { st = launch_k2(); if (st != SH_OK) return st; }
-        k.pass = 1; k.max_occ = c->P.max_occ;
-        k.list = c->d_big[1][cur1]; k.list_count = &c->d_ctr->n_big[1];
-        k.defer_list = c->d_big[1][cur1 ^ 1]; k.defer_count = &c->d_ctr->n_big_defer[1];
-        k.next_list = nullptr; k.next_count = nullptr;
-        st = big_pass(c, k, grid, s);
-        if (st != SH_OK) return st;
-        // the rare reads K1 or k_expand could not take
-        b.work = c->d_work_resketch; b.work_count = &c->d_ctr->n_resketch; b.work_begin = resk_done;
-        hipLaunchKernelGGL(k_chain_large, dim3(grid), dim3(64), 0, s, b);
-        if (first && c->use_k1) SH_HIP(hipStreamWaitEvent(s, c->evx[5], 0));
-        SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
-        SH_HIP(hipStreamSynchronize(s));
-        SH_HIP(hipGetLastError());
-        if (first) { snap = *c->h_ctr; first = false; }
-        if (k.dbg & 16) fprintf(stderr, "[dbg] iter %d resketch %u reasons %u %u %u pair tests between two singletons (dbg) %u segs %u big %u/%u defer %u/%u\n", iter, c->h_ctr->n_resketch, c->h_ctr->n_leg_reason[0], c->h_ctr->n_leg_reason[1], c->h_ctr->n_leg_reason[2], c->h_ctr->n_leg_reason[3], c->h_ctr->n_long_segs, c->h_ctr->n_big[0], c->h_ctr->n_big[1], c->h_ctr->n_big_defer[0], c->h_ctr->n_big_defer[1]);
-        if (k.dbg & 16) fprintf(stderr, "[dbg] clusters chained by k_cluster_dp by class: %llu %llu %llu %llu, their anchors %llu %llu %llu %llu\n", c->h_ctr->cl_tot[0], c->h_ctr->cl_tot[1], c->h_ctr->cl_tot[2], c->h_ctr->cl_tot[3], c->h_ctr->cl_anchor_tot[0], c->h_ctr->cl_anchor_tot[1], c->h_ctr->cl_anchor_tot[2], c->h_ctr->cl_anchor_tot[3]);
-        if (k.dbg & 16) fprintf(stderr, "[dbg] reads (anchors) by sort class: <=64 %llu (%llu), <=256 %llu (%llu), <=512 %llu (%llu), <=1024 %llu (%llu), <=2048 %llu (%llu), <=4096 %llu (%llu), giant %llu (%llu)\n", c->h_ctr->sort_tot[6], c->h_ctr->sort_anchor_tot[6], c->h_ctr->sort_tot[0], c->h_ctr->sort_anchor_tot[0], c->h_ctr->sort_tot[1], c->h_ctr->sort_anchor_tot[1], c->h_ctr->sort_tot[2], c->h_ctr->sort_anchor_tot[2], c->h_ctr->sort_tot[3], c->h_ctr->sort_anchor_tot[3], c->h_ctr->sort_tot[4], c->h_ctr->sort_anchor_tot[4], c->h_ctr->sort_tot[5], c->h_ctr->sort_anchor_tot[5]);
-        if (k.dbg & 16) fprintf(stderr, "[dbg] local-cluster shortcut: tried %u, no singleton / filtered %u, singletons apart %u, window %u, K size %u, no margin %u, decided %u\n", c->h_ctr->ext_s3[0], c->h_ctr->ext_s3[1], c->h_ctr->ext_s3[2], c->h_ctr->ext_s3[3], c->h_ctr->ext_s3[4], c->h_ctr->ext_s3[5], c->h_ctr->ext_s3[7]);
-        if (k.dbg & 16) fprintf(stderr, "[dbg] ring DP: chunks in window %llu, beyond %llu, far rescans %llu\n", c->h_ctr->cl_dbg[0], c->h_ctr->cl_dbg[1], c->h_ctr->cl_dbg[2]);
-        resk_done = c->h_ctr->n_resketch;
-        const uint32_t d0 = c->h_ctr->n_big_defer[0], d1 = c->h_ctr->n_big_defer[1];
-        if (d0 == 0 && d1 == 0) break;
-        // a read deferred when it was alone in the arena can never fit
-        SH_CHECK(!(d0 == c->h_ctr->n_big[0] && c->h_ctr->n_big[0] == 1 && d1 == 0) && !(d1 == c->h_ctr->n_big[1] && c->h_ctr->n_big[1] == 1 && d0 == 0),
-                 SH_ERR_OOM, "chain arena (%llu MiB) too small for one read; set SCRUBBY_HIP_ARENA_MB", (unsigned long long)(c->arena_bytes >> 20));
-        Counters z = *c->h_ctr;
-        z.n_big[0] = d0; z.n_big[1] = d1; z.n_big_defer[0] = z.n_big_defer[1] = 0;
-        SH_HIP(hipMemcpyAsync(c->d_ctr, &z, sizeof(Counters), hipMemcpyHostToDevice, s));
-        cur0 ^= 1; cur1 ^= 1;
-    }
+    // the repeat path over the lists d_big[0][cur0] (pass 0, mid_occ) -> d_big[1][cur1] (pass 1, max_occ), until no read is deferred any more
+    auto run_repeat_path = [&](K3Args &k, K2Args &b, int &cur0, int &cur1, uint32_t &resk_done) -> sh_status {
+        for (int iter = 0;; ++iter) {
+            SH_CHECK(iter < 256, SH_ERR_OOM, "chain arena (%llu MiB) too small; set SCRUBBY_HIP_ARENA_MB", (unsigned long long)(c->arena_bytes >> 20));
+            k.pass = 0; k.max_occ = c->P.mid_occ;
+            k.list = c->d_big[0][cur0]; k.list_count = &c->d_ctr->n_big[0];
+            k.defer_list = c->d_big[0][cur0 ^ 1]; k.defer_count = &c->d_ctr->n_big_defer[0];
+            k.next_list = c->d_big[1][cur1]; k.next_count = &c->d_ctr->n_big[1];
+            sh_status st = big_pass(c, k, grid, s);
+            if (st != SH_OK) return st;
+            if (first && k2_late) { st = launch_k2(); if (st != SH_OK) return st; }
+            k.pass = 1; k.max_occ = c->P.max_occ;
+            k.list = c->d_big[1][cur1]; k.list_count = &c->d_ctr->n_big[1];
+            k.defer_list = c->d_big[1][cur1 ^ 1]; k.defer_count = &c->d_ctr->n_big_defer[1];
+            k.next_list = nullptr; k.next_count = nullptr;
+            st = big_pass(c, k, grid, s);
+            if (st != SH_OK) return st;
+            // the rare reads K1 or k_expand could not take
+            b.work = c->d_work_resketch; b.work_count = &c->d_ctr->n_resketch; b.work_begin = resk_done;
+            hipLaunchKernelGGL(k_chain_large, dim3(grid), dim3(64), 0, s, b);
+            if (first && c->use_k1) SH_HIP(hipStreamWaitEvent(s, c->evx[5], 0));
+            SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+            SH_HIP(hipStreamSynchronize(s));
+            SH_HIP(hipGetLastError());
+            if (first) { snap = *c->h_ctr; first = false; c->dbg_ptr[0] = c->d_big[1][cur1]; c->dbg_n[0] = snap.n_big[1]; c->dbg_ptr[1] = c->dbg_ptr[2] = nullptr; c->dbg_n[1] = c->dbg_n[2] = 0; }
+            if (k.dbg & 16) fprintf(stderr, "[dbg] iter %d resketch %u reasons %u %u %u pair tests between two singletons (dbg) %u segs %u big %u/%u defer %u/%u\n", iter, c->h_ctr->n_resketch, c->h_ctr->n_leg_reason[0], c->h_ctr->n_leg_reason[1], c->h_ctr->n_leg_reason[2], c->h_ctr->n_leg_reason[3], c->h_ctr->n_long_segs, c->h_ctr->n_big[0], c->h_ctr->n_big[1], c->h_ctr->n_big_defer[0], c->h_ctr->n_big_defer[1]);
+            if (k.dbg & 16) fprintf(stderr, "[dbg] clusters chained by k_cluster_dp by class: %llu %llu %llu %llu, their anchors %llu %llu %llu %llu\n", c->h_ctr->cl_tot[0], c->h_ctr->cl_tot[1], c->h_ctr->cl_tot[2], c->h_ctr->cl_tot[3], c->h_ctr->cl_anchor_tot[0], c->h_ctr->cl_anchor_tot[1], c->h_ctr->cl_anchor_tot[2], c->h_ctr->cl_anchor_tot[3]);
+            if (k.dbg & 16) fprintf(stderr, "[dbg] reads (anchors) by sort class: <=64 %llu (%llu), <=256 %llu (%llu), <=512 %llu (%llu), <=1024 %llu (%llu), <=2048 %llu (%llu), <=4096 %llu (%llu), giant %llu (%llu)\n", c->h_ctr->sort_tot[6], c->h_ctr->sort_anchor_tot[6], c->h_ctr->sort_tot[0], c->h_ctr->sort_anchor_tot[0], c->h_ctr->sort_tot[1], c->h_ctr->sort_anchor_tot[1], c->h_ctr->sort_tot[2], c->h_ctr->sort_anchor_tot[2], c->h_ctr->sort_tot[3], c->h_ctr->sort_anchor_tot[3], c->h_ctr->sort_tot[4], c->h_ctr->sort_anchor_tot[4], c->h_ctr->sort_tot[5], c->h_ctr->sort_anchor_tot[5]);
+            if (k.dbg & 16) fprintf(stderr, "[dbg] local-cluster shortcut: tried %u, no singleton / filtered %u, singletons apart %u, window %u, K size %u, no margin %u, decided %u\n", c->h_ctr->ext_s3[0], c->h_ctr->ext_s3[1], c->h_ctr->ext_s3[2], c->h_ctr->ext_s3[3], c->h_ctr->ext_s3[4], c->h_ctr->ext_s3[5], c->h_ctr->ext_s3[7]);
+            if (k.dbg & 16) fprintf(stderr, "[dbg] ring DP: chunks in window %llu, beyond %llu, far rescans %llu\n", c->h_ctr->cl_dbg[0], c->h_ctr->cl_dbg[1], c->h_ctr->cl_dbg[2]);
+            resk_done = c->h_ctr->n_resketch;
+            const uint32_t d0 = c->h_ctr->n_big_defer[0], d1 = c->h_ctr->n_big_defer[1];
+            if (d0 == 0 && d1 == 0) break;
+            // a read deferred when it was alone in the arena can never fit
+            SH_CHECK(!(d0 == c->h_ctr->n_big[0] && c->h_ctr->n_big[0] == 1 && d1 == 0) && !(d1 == c->h_ctr->n_big[1] && c->h_ctr->n_big[1] == 1 && d0 == 0),
+                     SH_ERR_OOM, "chain arena (%llu MiB) too small for one read; set SCRUBBY_HIP_ARENA_MB", (unsigned long long)(c->arena_bytes >> 20));
+            Counters z = *c->h_ctr;
+            z.n_big[0] = d0; z.n_big[1] = d1; z.n_big_defer[0] = z.n_big_defer[1] = 0;
+            SH_HIP(hipMemcpyAsync(c->d_ctr, &z, sizeof(Counters), hipMemcpyHostToDevice, s));
+            cur0 ^= 1; cur1 ^= 1;
+        }
+        return SH_OK;
+    };
+    { sh_status st = run_repeat_path(k, b, cur0, cur1, resk_done); if (st != SH_OK) return st; }
     SH_HIP(hipEventRecord(c->ev[3], s));
 
     // legacy path deferrals
@@ -3346,6 +3367,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         SH_HIP(hipEventRecord(c->ev_ext[1], s));
         SH_HIP(hipEventSynchronize(c->ev_ext[1]));
         ext_regions = c->h_ctr->ext_regions; ext_dropped = c->h_ctr->ext_dropped;
+        if (stats) { stats->n_ext_unresolved += c->h_ctr->lext_unresolved; stats->n_rmq_rechained += c->h_ctr->lext_rechained; stats->n_rmq_tied += c->h_ctr->lext_rmq_tie; }
         hipEventElapsedTime(&ms_ext, c->ev_ext[0], c->ev_ext[1]);
     } else if (c->ext) {
         ExtArgs x{};
@@ -3371,6 +3393,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "extension stage: a read exceeds the per-wave working memory (code %u: 2 chains, 3 primaries, 4 read length, 5 window, 6 regions)", c->h_ctr->ext_overflow);
         ext_list = c->h_ctr->ext_n_list;
         const uint32_t n_redo = c->h_ctr->ext_n_redo;
+        if (d_trace == nullptr) { c->dbg_ptr[1] = c->d_ext_redo; c->dbg_n[1] = n_redo; }
         if (getenv("SCRUBBY_HIP_DBG")) fprintf(stderr, "[dbg] extension stage: %u reads handed over chains, %u not settled by their top chain (tie %u, missing %u, short stretch %u, z-drop %u)\n", ext_list, n_redo, c->h_ctr->ext_reason[1], c->h_ctr->ext_reason[2], c->h_ctr->ext_reason[3], c->h_ctr->ext_reason[4]);
         uint32_t n_redo2 = 0;
         if (d_trace == nullptr && n_redo > 0) {
@@ -3383,35 +3406,47 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
             SH_HIP(hipGetLastError());
             SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "extension stage: a read exceeds the per-wave working memory (code %u)", c->h_ctr->ext_overflow);
             n_redo2 = c->h_ctr->ext_n_redo2;
+            c->dbg_ptr[2] = c->d_ext_list; c->dbg_n[2] = n_redo2;
         }
+        uint32_t n_fallback = 0; double ms_fallback = 0;
         if (n_redo2 > 0) {
-            // third pass, reads whose top chain does not survive: all their chains (legacy lane-per-read chaining, nothing filtered), then the
-            // full procedure.  The hand-over buffers start over.
+            n_fallback = n_redo2;
+            const auto t_fb = std::chrono::steady_clock::now();
+            // third pass, reads whose top chain does not survive: all their chains, then the complete procedure.  They take the repeat path
+            // again (wave-parallel expansion, sort classes, cluster DP) with nothing filtered; the legacy lane-per-read kernel that used to
+            // carry this pass spent 130 ms on 507 reads of the sr-div workload.  The hand-over buffers start over.
             Counters z = *c->h_ctr;
             memset(z.ext_n_recs, 0, sizeof(z.ext_n_recs)); memset(z.ext_n_anch, 0, sizeof(z.ext_n_anch));
-            z.n_defer = 0; z.arena_cursor = 0; z.n_resketch = n_redo2; z.ext_n_list2 = n_redo2; z.ext_ticket3 = 0;
+            z.n_defer = 0; z.arena_cursor = 0; z.ext_n_list2 = n_redo2; z.ext_ticket3 = 0;
+            z.n_big[0] = n_redo2; z.n_big[1] = 0; z.n_big_defer[0] = z.n_big_defer[1] = 0;
             SH_HIP(hipMemcpyAsync(c->d_ctr, &z, sizeof(Counters), hipMemcpyHostToDevice, s));
             ExtArgs x2 = x;
             x2.list = c->d_ext_list; x2.n_list = &c->d_ctr->ext_n_list2; x2.ticket = &c->d_ctr->ext_ticket3;
             hipLaunchKernelGGL(k_ext_reset, dim3(64), dim3(256), 0, s, x2);
+            SH_HIP(hipMemcpyAsync(c->d_big[0][0], c->d_ext_list, (size_t)n_redo2 * 4, hipMemcpyDeviceToDevice, s));
+            K3Args kf = k;
+            kf.sink.best = nullptr; kf.sink.tie = nullptr; kf.t_mode = 0; kf.flag_only = 0; kf.quiet = 1;
             K2Args rb = b;
             rb.sink.best = nullptr; rb.sink.tie = nullptr; rb.quiet = 1;
-            rb.work = c->d_ext_list; rb.work_count = &c->d_ctr->n_resketch; rb.work_begin = 0; rb.work_defer = c->d_work_defer;
-            uint32_t left = n_redo2;
+            int f0 = 0, f1 = c->dbg_ptr[0] == c->d_big[1][0] ? 1 : 0;      // not over the first pass's list of re-chained reads (sh_ctx_debug_list)
+            { sh_status st = run_repeat_path(kf, rb, f0, f1, resk_done); if (st != SH_OK) return st; }
+            // reads the repeat path handed to the legacy kernel and that found no room there
+            rb.work_defer = c->d_work_defer;
+            uint32_t left = c->h_ctr->n_defer;
             int rounds2 = 0;
-            for (;;) {
+            while (left > 0) {
+                SH_CHECK(++rounds2 < 64, SH_ERR_OOM, "re-sketch arena too small for the extension stage's last pass; set SCRUBBY_HIP_ARENA_MB");
+                std::swap(c->d_work_defer, c->d_work_defer2);
+                Counters z2 = *c->h_ctr;
+                z2.n_defer = 0; z2.arena_cursor = 0; z2.n_resketch = left;
+                SH_HIP(hipMemcpyAsync(c->d_ctr, &z2, sizeof(Counters), hipMemcpyHostToDevice, s));
+                rb.work = c->d_work_defer2; rb.work_count = &c->d_ctr->n_resketch; rb.work_begin = 0; rb.work_defer = c->d_work_defer;
                 hipLaunchKernelGGL(k_chain_large, dim3(grid), dim3(64), 0, s, rb);
                 SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
                 SH_HIP(hipStreamSynchronize(s));
                 const uint32_t nd = c->h_ctr->n_defer;
-                if (nd == 0) break;
-                SH_CHECK(nd < left && ++rounds2 < 64, SH_ERR_OOM, "re-sketch arena too small for the extension stage's last pass; set SCRUBBY_HIP_ARENA_MB");
+                SH_CHECK(nd < left, SH_ERR_OOM, "re-sketch arena too small for the extension stage's last pass; set SCRUBBY_HIP_ARENA_MB");
                 left = nd;
-                std::swap(c->d_work_defer, c->d_work_defer2);
-                Counters z2 = *c->h_ctr;
-                z2.n_defer = 0; z2.arena_cursor = 0; z2.n_resketch = nd;
-                SH_HIP(hipMemcpyAsync(c->d_ctr, &z2, sizeof(Counters), hipMemcpyHostToDevice, s));
-                rb.work = c->d_work_defer2; rb.work_defer = c->d_work_defer;
             }
             if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
             hipLaunchKernelGGL(k_regs_align, dim3(c->ext_waves), dim3(64), 0, s, x2);
@@ -3420,7 +3455,9 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
             SH_HIP(hipGetLastError());
             if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
             SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "extension stage: a read exceeds the per-wave working memory (code %u)", c->h_ctr->ext_overflow);
+            ms_fallback = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fb).count();
         }
+        if (stats) { stats->n_ext_fallback += n_fallback; stats->ms_ext_fallback += ms_fallback; }
         SH_HIP(hipEventRecord(c->ev_ext[1], s));
         SH_HIP(hipEventSynchronize(c->ev_ext[1]));
         ext_regions = c->h_ctr->ext_regions; ext_dropped = c->h_ctr->ext_dropped;

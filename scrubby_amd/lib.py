@@ -71,7 +71,8 @@ class Stats(C.Structure):
         ("ms_chain_large", C.c_double), ("ms_total", C.c_double),
         ("n_anchors", C.c_uint64), ("n_clusters", C.c_uint64), ("n_resketch", C.c_uint64), ("n_pair_decided", C.c_uint64),
         ("n_ext_reads", C.c_uint64), ("n_ext_regions", C.c_uint64), ("n_ext_dropped", C.c_uint64), ("ms_ext", C.c_double),
-        ("n_ext_shortcut", C.c_uint64),
+        ("n_ext_shortcut", C.c_uint64), ("n_ext_fallback", C.c_uint64), ("ms_ext_fallback", C.c_double),
+        ("n_ext_unresolved", C.c_uint64), ("n_rmq_rechained", C.c_uint64), ("n_rmq_tied", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -122,7 +123,7 @@ EXPORTS = [
     "sh_version", "sh_device_count", "sh_last_error", "sh_preset",
     "sh_index_build", "sh_index_build_device", "sh_index_build_fasta", "sh_index_save", "sh_index_load",
     "sh_index_info_get", "sh_index_export", "sh_index_export_ref", "sh_index_free",
-    "sh_ctx_create", "sh_ctx_destroy", "sh_classify_device", "sh_classify_batch",
+    "sh_ctx_create", "sh_ctx_destroy", "sh_ctx_debug_list", "sh_classify_device", "sh_classify_batch",
     "sh_synth_ref_device", "sh_synth_reads_device", "sh_synth_long_reads_device", "sh_bench_gather", "sh_pack_flags_device",
     "sh_reads_run", "sh_release_cached_ctx", "sh_host_get_id", "sh_host_filter_fastx", "sh_host_filter_fastx_stream", "sh_host_read_difference",
     "sh_classifier_run", "sh_classifier_taxids", "sh_alignment_run",
@@ -328,6 +329,15 @@ class Context:
                                         C.c_void_p(d_trace.data_ptr()) if d_trace is not None else None,
                                         _stream_ptr(), C.byref(st) if want_stats else None))
         return st.as_dict() if want_stats else None
+
+    def debug_list(self, which):
+        """Ordinals (within the last chunk classified) of the reads that took a rare path: 0 re-chained with max_occ, 1 regs[0] aligned
+        base by base, 2 the complete procedure over every chain (sh_ctx_debug_list)."""
+        n = C.c_uint64()
+        check(load().sh_ctx_debug_list(self.h, which, None, C.c_uint64(0), C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.uint32)
+        check(load().sh_ctx_debug_list(self.h, which, C.c_void_p(out.ctypes.data), C.c_uint64(n.value), C.byref(n)))
+        return out[:n.value]
 
     def close(self):
         if getattr(self, "h", None):
