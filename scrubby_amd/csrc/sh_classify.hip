@@ -73,7 +73,7 @@ struct Counters {
     uint32_t ext_s3[8];           // SCRUBBY_HIP_DBG & 16: outcome of the local-cluster shortcut (k_expand): 0 tried, 1 no singleton / filtered seed, 2 singletons apart, 3 window grew / too many, 4 K > 64, 5 no margin over U_out, 6 lemma, 7 decided
     uint32_t ext_overflow, ext_n_list, ext_ticket, ext_regions, ext_dropped, ext_n_redo, ext_n_list2, ext_ticket2, ext_n_redo2, ext_ticket3;      // extension stage (sh_align.h)
     uint32_t ext_n_recs[SINK_SHARDS]; unsigned long long ext_n_anch[SINK_SHARDS];                 // hand-over cursors, one per shard
-    uint32_t lext_hist[64]; uint32_t lext_n_big, lext_ticket_big, lext_n_big2, lext_ticket_big2, lext_ticket_b, lext_pad2, lext_rechained, lext_rmq_tie, lext_err_read, lext_unresolved, lext_err_code, lext_pad;
+    uint32_t lext_hist[64]; uint32_t lext_ticket_g, lext_pad3; uint32_t lext_n_big, lext_ticket_big, lext_n_big2, lext_ticket_big2, lext_ticket_b, lext_pad2, lext_rechained, lext_rmq_tie, lext_err_read, lext_unresolved, lext_err_code, lext_pad;
     unsigned long long lext_clk[LR_NCLK], lext_d[8], lext_slow, lext_kernel_sum;  // long-read extension stage (sh_long.h): reads for the large-scratch pass, RMQ re-chains, steps with tied priorities
     uint32_t n_cl[4], cl_ticket, pad3;      // global queue of big clusters (k_cluster_dp), by size class
     uint32_t n_leg_reason[4];     // why reads left the long-read front end: 0 room/segments, 1 thinning screen, 2 anchors beyond the giant path, 3 unused
@@ -2559,6 +2559,7 @@ struct ExtLongArgs {
     LongIn I; LongParams P; AlignParams AP; ChainParams CP;
     uint8_t *scratch; unsigned long long scratch_per_wave; LongSizes sz; LongArena AR;
     uint32_t *list; uint32_t *n_list, *ticket; uint32_t *big_list; uint32_t *n_big; Counters *ctr; uint8_t *flags; sh_trace *trace; int32_t flag_only, clk, probe;
+    const uint32_t *hist; int32_t bin_cut, part;      // the size-ordered list's giants (bins >= bin_cut) come first: part 1 = all but them, 2 = only them, 0 = the whole list
 };
 
 // Largest reads first: a read's cost grows with its chain anchors (one with 70 k of them keeps a wave busy for a third of a second), and a
@@ -2604,13 +2605,18 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
     const LongParams P_l = a.P; const LongIn I_l = a.I; const LongArena AR_l = a.AR;      // no pointers into the kernel-argument struct
     LongWs W;
     long_ws_carve(&W, a.scratch + (unsigned long long)blockIdx.x * a.scratch_per_wave, a.sz);
-    const uint32_t n_list = *a.n_list;
+    uint32_t n_list = *a.n_list, t_first = 0;
+    if (a.part) {
+        uint32_t n_giant = 0;
+        for (int b2 = a.bin_cut; b2 < 32; ++b2) n_giant += a.hist[b2];
+        if (a.part == 1) t_first = n_giant; else n_list = n_giant;
+    }
     uint32_t n_rechain = 0, n_tie = 0;
     LongClk clk{};
     for (;;) {
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(a.ticket, 1u);
-        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) + t_first;
         if (t >= n_list) break;
         const uint32_t r = a.list[t];
         LongCtx C;
@@ -2633,7 +2639,7 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
     }
 }
 
-__global__ __launch_bounds__(64) void k_regs_align_long(ExtLongArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_regs_align_long(ExtLongArgs a)
 {
     __shared__ AlignLds Ls;
     const uint32_t lane = threadIdx.x;
@@ -3317,12 +3323,24 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
             ExtLongArgs xa = x;
             xa.scratch = c->d_lext[0]; xa.scratch_per_wave = c->lext_per_wave[0]; xa.sz = c->lext_sz[0];
             xa.ticket = &c->d_ctr->ext_ticket; xa.big_list = c->d_lext_big; xa.n_big = &c->d_ctr->lext_n_big;
+            // reads whose chain anchors outgrow the first size go straight to the large working memory, on a side stream beside the rest
+            int bin_cut = 0;
+            while (bin_cut < 31 && (2ull << bin_cut) <= c->lext_sz[0].cap_a) ++bin_cut;      // bin b holds totals in [2^b, 2^(b+1))
+            xa.hist = c->d_ctr->lext_hist; xa.bin_cut = bin_cut; xa.part = 1;
+            ExtLongArgs xg = xa;
+            xg.scratch = c->d_lext[1]; xg.scratch_per_wave = c->lext_per_wave[1]; xg.sz = c->lext_sz[1];
+            xg.ticket = &c->d_ctr->lext_ticket_g; xg.part = 2;      // same ring as the others (19 KB of LDS: they share CUs); what outgrows the ring joins the big list
+            SH_HIP(hipEventRecord(c->evx[0], s));
+            SH_HIP(hipStreamWaitEvent(c->sx[0], c->evx[0], 0));
+            hipLaunchKernelGGL(k_long_chains<512>, dim3(c->lext_waves[1]), dim3(64), 0, c->sx[0], xg);
+            SH_HIP(hipEventRecord(c->evx[1], c->sx[0]));
             hipLaunchKernelGGL(k_long_chains<512>, dim3(c->lext_waves[0]), dim3(64), 0, s, xa);
+            SH_HIP(hipStreamWaitEvent(s, c->evx[1], 0));
             sh_status st = sync_ctr(); if (st != SH_OK) return st;
             if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;       // hand-over buffers or arena full: the caller cuts the chunk in two
             if (c->h_ctr->lext_n_big > 0) {
                 xa.scratch = c->d_lext[1]; xa.scratch_per_wave = c->lext_per_wave[1]; xa.sz = c->lext_sz[1];
-                xa.list = c->d_lext_big; xa.n_list = &c->d_ctr->lext_n_big; xa.ticket = &c->d_ctr->lext_ticket_big; xa.big_list = nullptr; xa.n_big = nullptr;
+                xa.list = c->d_lext_big; xa.n_list = &c->d_ctr->lext_n_big; xa.ticket = &c->d_ctr->lext_ticket_big; xa.big_list = nullptr; xa.n_big = nullptr; xa.part = 0;
                 hipLaunchKernelGGL(k_long_chains<4096>, dim3(c->lext_waves[1]), dim3(64), 0, s, xa);
                 st = sync_ctr(); if (st != SH_OK) return st;
                 if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;

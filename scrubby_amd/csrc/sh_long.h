@@ -528,6 +528,70 @@ __device__ __noinline__ int32_t lr_backtrack0(const SKey *zc, int32_t n_z, const
     return n_u;
 }
 
+// mg_chain_backtrack, the whole wave on one control flow: the walks go down the index space a few anchors at a time, so the 64 anchors
+// below the current one (f, p, t) sit in registers - one lane each, loaded past the L1 in one go - and a step is a readlane, not a trip
+// to memory.  Marks are stored by lane 0 and mirrored in the register block; the block is refetched when a walk leaves it.
+struct BtBlock { int32_t lo, f, p, t; };      // lane l holds anchor lo + l
+__device__ inline void bt_load(BtBlock &B, int32_t i, int32_t n, const int32_t *f, const int32_t *p, const int32_t *t)
+{
+    int32_t lo = i - 63; if (lo < 0) lo = 0;
+    B.lo = lo;
+    const int32_t a = lo + (int32_t)al_lane();
+    const bool on = a < n;
+    B.f = on ? (int32_t)cc_u32(f + a) : 0; B.p = on ? (int32_t)cc_u32(p + a) : -1; B.t = on ? (int32_t)cc_u32(t + a) : 0;
+}
+#define BT_IN(B, i) ((i) >= (B).lo && (i) < (B).lo + 64)
+#define BT_GET(B, fld, i) __builtin_amdgcn_readlane((B).fld, (i) - (B).lo)
+__device__ inline int32_t lr_backtrack_wave(const SKey *zc, int32_t n_z, int32_t n, const int32_t *f, const int32_t *p, int32_t *t, int32_t *v, uint64_t *u, uint32_t cap_u,
+                                            int32_t min_cnt, int32_t min_sc, int32_t max_drop, int32_t &n_v_out, int32_t &best_out, bool &ovf)
+{
+    const int32_t lane = (int32_t)al_lane();
+    int32_t n_u = 0, n_v = 0, best = 0;
+    BtBlock B; B.lo = -1000; B.f = B.p = B.t = 0;
+    auto need = [&](int32_t i) { if (!BT_IN(B, i)) { __builtin_amdgcn_s_waitcnt(0); bt_load(B, i, n, f, p, t); } };
+    auto set_t = [&](int32_t i, int32_t val) {      // i is inside the block
+        if (lane == 0) t[i] = val;
+        if (lane == i - B.lo) B.t = val;
+    };
+    for (int32_t k = n_z - 1; k >= 0; --k) {
+        const int32_t zi = (int32_t)zc[k].v, zf = (int32_t)zc[k].k;
+        need(zi);
+        if (BT_GET(B, t, zi) != 0) continue;
+        // mg_chain_bk_end
+        int32_t end_i;
+        {
+            int32_t i = zi, e = -1, max_i = i, max_s = 0;
+            for (;;) {
+                need(i);
+                set_t(i, 2);
+                e = i = BT_GET(B, p, i);
+                int32_t s2 = zf;
+                if (i >= 0) { need(i); s2 = zf - BT_GET(B, f, i); }
+                if (s2 > max_s) { max_s = s2; max_i = i; }
+                else if (max_s - s2 > max_drop) break;
+                if (!(i >= 0 && BT_GET(B, t, i) == 0)) break;
+            }
+            for (i = zi; i >= 0 && i != e; ) { need(i); set_t(i, 0); i = BT_GET(B, p, i); }
+            end_i = max_i;
+        }
+        const int32_t n_v0 = n_v;
+        int32_t i;
+        for (i = zi; i != end_i; ) { need(i); if (lane == 0) v[n_v] = i; ++n_v; set_t(i, 1); i = BT_GET(B, p, i); }
+        int32_t sc = zf;
+        if (i >= 0) { need(i); sc = zf - BT_GET(B, f, i); }
+        if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt) {
+            if ((uint32_t)n_u >= cap_u) { ovf = true; break; }
+            if (lane == 0) u[n_u] = (uint64_t)(uint32_t)sc << 32 | (uint32_t)(n_v - n_v0);
+            ++n_u;
+            if (sc > best) best = sc;
+        } else n_v = n_v0;
+    }
+    n_v_out = n_v; best_out = best;
+    return n_u;
+}
+#undef BT_IN
+#undef BT_GET
+
 // ---- region bookkeeping on lane 0 (hit.c) ------------------------------------------------------------------------------------
 __device__ inline void lr_set_parent0(float mask_level, int32_t n, LReg *r, uint64_t *cov, int32_t *w)
 {
@@ -1284,6 +1348,15 @@ __device__ __noinline__ int32_t lr_probe_region(LongCtx &C, const LReg &r, LAnch
     return 0;
 }
 
+// the chain that holds flat anchor index i: largest c with off[c] <= i (off ascending, off[n] = total)
+template <class OFF>
+__device__ inline int32_t lr_chain_of(OFF off, int32_t n, int32_t i)
+{
+    int32_t lo = 0, hi = n - 1;
+    while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if ((int32_t)off[mid] <= i) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
 // ---- the whole stage for one read ---------------------------------------------------------------------------------------------------
 struct LongOut { int32_t n_chain, best, rechained, n_aligned, n_regs, dp_max; uint32_t sig; int32_t rmq_tie, probed; };
 // The stage runs as two kernels, so that neither carries the other's registers and LDS: the first leaves a read's final chains (after the
@@ -1375,15 +1448,16 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const Long
     }
     LAnchor *A0 = W.a, *B0 = W.b;
     if (C.clk) C.clk->last = wall_clock64();
-    for (int32_t c = 0; c < n_u; ++c) {
+    // every lane takes anchors of the flat index space and finds their chain itself: a read with thousands of small chains must not pay a
+    // memory round trip per chain
+    for (int32_t i = lane; i < n_a; i += 64) {
+        const int32_t c = lr_chain_of(W.uoff, n_u, i);
         const ChainRec rc = in.recs[W.v[c]];
-        const uint32_t o = W.uoff[c];
-        for (uint32_t j = (uint32_t)lane; j < rc.cnt; j += 64) {
-            const uint64_t x = in.cx[rc.off + j]; const uint32_t q = in.cq[rc.off + j];
-            const uint32_t qp = (x >> 63) ? (uint32_t)(qlen + P.k - 2) - q : q;
-            const bool td = qp < (uint32_t)qlen && (W.tbits[qp >> 5] >> (qp & 31) & 1u);
-            A0[o + j].x = x; A0[o + j].y = (td ? LY_TANDEM : 0ull) | (uint64_t)(uint32_t)P.k << 32 | q;
-        }
+        const uint32_t j = (uint32_t)i - W.uoff[c];
+        const uint64_t x = in.cx[rc.off + j]; const uint32_t q = in.cq[rc.off + j];
+        const uint32_t qp = (x >> 63) ? (uint32_t)(qlen + P.k - 2) - q : q;
+        const bool td = qp < (uint32_t)qlen && (W.tbits[qp >> 5] >> (qp & 31) & 1u);
+        A0[i].x = x; A0[i].y = (td ? LY_TANDEM : 0ull) | (uint64_t)(uint32_t)P.k << 32 | q;
     }
     lr_sync();
     out.n_chain = n_u;
@@ -1426,11 +1500,12 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const Long
             for (int32_t i = lane; i < n_a; i += 64) W.t[i] = 0;
             lr_sync();
             int32_t res[3] = {0, 0, 0};
-            if (lane == 0) {
+            {
                 int32_t n_v = 0, best = 0; bool ovf = false;
-                res[0] = lr_backtrack0(W.sk, n_z, W.f, W.p, W.t, W.v, W.u, W.cap_u, P.min_cnt, P.min_sc, P.bw_long, n_v, best, ovf);
+                res[0] = lr_backtrack_wave(W.sk, n_z, n_a, W.f, W.p, W.t, W.v, W.u, W.cap_u, P.min_cnt, P.min_sc, P.bw_long, n_v, best, ovf);
                 res[1] = ovf ? -1 : n_v; res[2] = best;
-                if (!ovf) {      // chain starts in v[] (discovery order)
+                lr_sync();
+                if (!ovf && lane == 0) {      // chain starts in v[] (discovery order)
                     int32_t k0 = 0;
                     for (int32_t i = 0; i < res[0]; ++i) { W.uoff[i] = (uint32_t)k0; k0 += (int32_t)(uint32_t)W.u[i]; }
                     W.uoff[res[0]] = (uint32_t)k0;
@@ -1443,9 +1518,10 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const Long
             lr_sync();
             if (n_u == 0) { if (lane == 0) { LongHdr h{0ull, 0, 0, 0, out.rechained | (out.rmq_tie ? 4 : 0)}; AR.hdr[read] = h; } return 0; }
             // compact_a: every chain ascending, then the chains by the x of their first anchor (ties: discovery order)
-            for (int32_t c = 0; c < n_u; ++c) {
-                const int32_t k0 = (int32_t)W.uoff[c], ni = (int32_t)(uint32_t)W.u[c];
-                for (int32_t j = lane; j < ni; j += 64) A0[k0 + j] = B0[W.v[k0 + (ni - j - 1)]];
+            for (int32_t i = lane; i < n_v; i += 64) {
+                const int32_t c = lr_chain_of(W.uoff, n_u, i);
+                const int32_t k0 = (int32_t)W.uoff[c], ni = (int32_t)(uint32_t)W.u[c], j = i - k0;
+                A0[i] = B0[W.v[k0 + (ni - j - 1)]];
             }
             lr_sync();
             for (int32_t c = lane; c < n_u; c += 64) { W.sk[c].k = A0[W.uoff[c]].x; W.sk[c].v = (uint64_t)c; }
@@ -1459,9 +1535,10 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const Long
                 W.K[n_u] = k0;
             }
             lr_sync();
-            for (int32_t c = 0; c < n_u; ++c) {
-                const int32_t s = (int32_t)W.sk[c].v, so = (int32_t)W.uoff[s], d = W.K[c], ni = (int32_t)(uint32_t)u2[c];
-                for (int32_t j = lane; j < ni; j += 64) B0[d + j] = A0[so + j];
+            for (int32_t i = lane; i < n_v; i += 64) {      // flat over the new order
+                const int32_t c = lr_chain_of(W.K, n_u, i);
+                const int32_t s = (int32_t)W.sk[c].v, so = (int32_t)W.uoff[s], d = W.K[c];
+                B0[i] = A0[so + (i - d)];
             }
             lr_sync();
             for (int32_t c = lane; c <= n_u; c += 64) { if (c < n_u) W.u[c] = u2[c]; W.uoff[c] = (uint32_t)W.K[c]; }
