@@ -506,6 +506,106 @@ __device__ inline bool chain_dp_mask(Store &S, int n, int32_t qlen, const ChainP
     return false;
 }
 
+__device__ inline uint32_t chain_max_dist_x(const ChainParams &P, int32_t qlen)
+{
+    int32_t m;
+    if (P.max_gap_ref > 0) m = P.max_gap_ref;
+    else if (P.max_frag_len > 0) { m = P.max_frag_len - qlen; if (m < P.max_gap) m = P.max_gap; }
+    else m = P.max_gap;
+    if (m < P.bw) m = P.bw;
+    return (uint32_t)m;
+}
+__device__ inline int32_t chain_max_dist_y(const ChainParams &P, int32_t qlen)
+{
+    int32_t m = P.is_sr ? (qlen > P.max_gap ? qlen : P.max_gap) : P.max_gap;
+    return m < P.bw ? P.bw : m;
+}
+
+// ---- mg_lchain_dp without its sequential state: all anchors of a read at once ---------------------------------------------------------
+// mg_lchain_dp carries three pieces of state from anchor to anchor: the t[] marks with the n_skip counter (they END a look-back scan early,
+// after max_skip marked non-maxima), the max_iter cut of the window, and max_ii (a shortcut that is only consulted when the scan ended
+// early or was cut: `max_ii < end_j`).  n_skip only moves on predecessors j whose comput_sc is valid, so an anchor with at most max_skip
+// valid predecessors inside an uncut window scans all of it, never consults max_ii, and
+//     f[i] = max(k, max over the valid j in [st, i) of f[j] + sc(i, j)),     p[i] = the largest such j attaining it (strictly above k), else -1
+// - a recurrence without hidden state.  A valid link needs dq > 0, so the anchors of one query position are independent of each other and
+// depend on smaller query positions only: the read's anchors are ordered by the rank of their query position (counting sort, the
+// permutation in the t slots) and each rank is one parallel round over ALL clusters of the read, one thread per anchor.  An anchor that
+// breaks the premise (more than max_skip valid predecessors, or a window beyond max_iter) makes its CLUSTER dirty: clusters are
+// independent DP problems, a dirty one is chained by the sequential code as before, the others keep what was computed here.  On the bench
+// workload 472 of 1.6 M clusters of more than 64 anchors are dirty.
+// Predecessors are stored as indices into the read's array (SliceStore::pbase turns them into the slice-relative ones the backtrack uses).
+#define PF_MAX_Q 1024
+#define PF_MAX_RANK 128
+#define PF_DIRTY_CAP 64
+#define PF_DIRTY 0x7ffffff1
+#define PF_DEAD 0x7ffffff2
+struct ParFillLds { unsigned long long qmask[PF_MAX_Q / 64]; uint32_t qpre[PF_MAX_Q / 64 + 1]; uint32_t start[PF_MAX_RANK + 1], cur[PF_MAX_RANK]; int32_t n_dirty; uint32_t dirty[PF_DIRTY_CAP]; };
+
+// x, q: the read's sorted anchors with the cluster starts marked in bit 31 of q; f, pt: DP state (pt = p, t interleaved).  All threads of the
+// block call it.  false: not applicable (query positions beyond PF_MAX_Q, more than PF_MAX_RANK of them, too many dirty anchors) - nothing usable
+// was written.  true: f and p hold mg_lchain_dp's values for every clean cluster, t = 0 except PF_DIRTY at the first anchor of a dirty one.
+template <class PX, class PQ>
+__device__ inline bool par_fill_block(PX x, PQ q, int32_t *f, int32_t *pt, uint32_t n, int32_t qlen, const ChainParams &P, uint32_t tid, uint32_t nthr, ParFillLds &L)
+{
+    if (qlen > PF_MAX_Q || n >= 0x7ffffff0u) return false;
+    const int32_t mdy = chain_max_dist_y(P, qlen), mdx = (int32_t)chain_max_dist_x(P, qlen);
+    for (uint32_t t = tid; t < PF_MAX_Q / 64; t += nthr) L.qmask[t] = 0;
+    if (tid == 0) L.n_dirty = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += nthr) {
+        const uint32_t qq = (uint32_t)q[i] & 0x7fffffffu;
+        if (!((L.qmask[qq >> 6] >> (qq & 63)) & 1ull)) atomicOr(&L.qmask[qq >> 6], 1ull << (qq & 63));
+    }
+    __syncthreads();
+    if (tid == 0) { uint32_t acc = 0; for (int w = 0; w < PF_MAX_Q / 64; ++w) { L.qpre[w] = acc; acc += (uint32_t)__popcll(L.qmask[w]); } L.qpre[PF_MAX_Q / 64] = acc; }
+    __syncthreads();
+    const uint32_t R = L.qpre[PF_MAX_Q / 64];
+    if (R > PF_MAX_RANK) return false;
+    for (uint32_t t = tid; t <= R; t += nthr) L.start[t] = 0;
+    __syncthreads();
+    auto rank_of = [&](uint32_t qq) { return L.qpre[qq >> 6] + (uint32_t)__popcll(L.qmask[qq >> 6] & ((1ull << (qq & 63)) - 1ull)); };
+    for (uint32_t i = tid; i < n; i += nthr) atomicAdd(&L.start[rank_of((uint32_t)q[i] & 0x7fffffffu) + 1], 1u);
+    __syncthreads();
+    if (tid == 0) { uint32_t acc = 0; for (uint32_t r = 0; r < R; ++r) { acc += L.start[r + 1]; L.start[r + 1] = acc; } }
+    __syncthreads();
+    for (uint32_t t = tid; t < R; t += nthr) L.cur[t] = L.start[t];
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += nthr) { const uint32_t slot = atomicAdd(&L.cur[rank_of((uint32_t)q[i] & 0x7fffffffu)], 1u); pt[2 * (size_t)slot + 1] = (int32_t)i; }
+    __syncthreads();
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t e = L.start[r + 1];
+        for (uint32_t idx = L.start[r] + tid; idx < e; idx += nthr) {
+            const uint32_t i = (uint32_t)pt[2 * (size_t)idx + 1];
+            const uint32_t qraw = (uint32_t)q[i], qi = qraw & 0x7fffffffu, xi = (uint32_t)x[i];
+            int32_t max_f = P.k, max_j = -1, nv = 0;
+            bool bad = false;
+            if (r > 0 && !(qraw >> 31)) {
+                // a valid predecessor has 0 < dq <= q_i and |dr - dq| <= bw, so it lies within q_i + bw of x_i: the scan stops there (what lies
+                // between that and max_dist_x only matters for the max_iter cut, tested on its own)
+                const uint32_t lim = min((uint32_t)mdx, qi + (uint32_t)P.bw);
+                if (i > (uint32_t)P.max_iter) { const uint64_t xo = x[i - (uint32_t)P.max_iter - 1u], xf = x[i]; bad = (xo >> 32) == (xf >> 32) && (uint32_t)xf - (uint32_t)xo <= (uint32_t)mdx; }
+                for (uint32_t j = i - 1;; --j) {
+                    const uint32_t qj = (uint32_t)q[j], xj = (uint32_t)x[j];
+                    if (xi - xj > lim) break;
+                    const int32_t sc = comput_sc(xi, qi, xj, qj & 0x7fffffffu, mdx, mdy, P);
+                    if (sc != SH_SC_NONE) { ++nv; const int32_t c = sc + f[j]; if (c > max_f) { max_f = c; max_j = (int32_t)j; } }
+                    if (qj >> 31) break;
+                }
+            }
+            f[i] = max_f; pt[2 * (size_t)i] = max_j;
+            if (bad || nv > P.max_skip) { const int32_t d = atomicAdd(&L.n_dirty, 1); if (d < PF_DIRTY_CAP) L.dirty[d] = i; }
+        }
+        __syncthreads();
+    }
+    const int32_t nd = L.n_dirty;
+    if (nd > PF_DIRTY_CAP) return false;
+    for (uint32_t i = tid; i < n; i += nthr) pt[2 * (size_t)i + 1] = 0;
+    __syncthreads();
+    for (int32_t d = (int32_t)tid; d < nd; d += (int32_t)nthr) { uint32_t c = L.dirty[d]; while (!((uint32_t)q[c] >> 31)) --c; pt[2 * (size_t)c + 1] = PF_DIRTY; }
+    __syncthreads();
+    return true;
+}
+
 template <class Store, class EM = NoEmit>
 __device__ inline void backtrack_mask(Store &S, int n, const ChainParams &P, int32_t &n_u, int32_t &best, bool first_only, const EM &em = EM())
 {
@@ -580,12 +680,13 @@ __device__ inline void backtrack_heap(Store &S, Idx n, const ChainParams &P, uin
 // x/q are the sorted anchors, f and pt (p,t interleaved) the DP state; LDS or arena pointers alike.
 struct SliceStore {
     const uint64_t *x; const uint32_t *q; int32_t *f; int32_t *pt;
+    int32_t pbase = 0;      // predecessors as par_fill_block leaves them (indices into the read's array): the slice's first anchor there; 0 = slice-relative
     __device__ inline uint32_t grp(int32_t) const { return 0; }
     __device__ inline uint32_t rlo(int32_t i) const { return (uint32_t)x[i]; }
     __device__ inline uint32_t qp(int32_t i) const { return q[i] & 0x7fffffffu; }     // bit 31 = cluster-start mark
     __device__ inline uint64_t X(int32_t i) const { return x[i]; }
     __device__ inline int32_t F(int32_t i) const { return f[i]; }
-    __device__ inline int32_t Pm(int32_t i) const { return pt[2 * i]; }
+    __device__ inline int32_t Pm(int32_t i) const { const int32_t v = pt[2 * i]; return v < 0 ? v : v - pbase; }
     __device__ inline int32_t T(int32_t i) const { return pt[2 * i + 1]; }
     __device__ inline void setFP(int32_t i, int32_t fv, int32_t pv) { f[i] = fv; pt[2 * i] = pv; }
     __device__ inline void setT(int32_t i, int32_t tv) { pt[2 * i + 1] = tv; }
@@ -831,7 +932,7 @@ __device__ inline bool chain_dp_ring(const uint64_t *gx, const uint32_t *gq, int
     // the parameters by value: through the reference they live in the kernel's private copy of its argument struct, and every use inside the
     // loops below was a scratch load (five per chunk of predecessors in the ISA)
     const ChainParams P = P_in;
-    unsigned long long n_ch_in = 0, n_ch_out = 0, n_far = 0;
+    unsigned long long n_ch_in = 0, n_ch_out = 0, n_far = 0; int n_evt = 0, max_win = 0;
     int32_t max_dist_y = P.is_sr ? (qlen > P.max_gap ? qlen : P.max_gap) : P.max_gap;
     int32_t max_dist_x;
     if (P.max_gap_ref > 0) max_dist_x = P.max_gap_ref;
@@ -913,8 +1014,9 @@ __device__ inline bool chain_dp_ring(const uint64_t *gx, const uint32_t *gq, int
                 max_j = jb - (__ffsll((unsigned long long)eq) - 1);
             }
             n_skip = __builtin_amdgcn_readlane(val, L);
-            if (brk) { end_j = jb - L; break; }
+            if (brk) { end_j = jb - L; ++n_evt; break; }
         }
+        if (i - st > max_win) max_win = i - st;
         if (marked) {       // clear the marks of this step: they all lie in [st, i)
             const int d1 = (i - 1) >> 5;
             for (int d = (st >> 5) + (int)lane; d <= d1; d += 64) rm.tb[d & (TW - 1)] = 0;
@@ -956,7 +1058,14 @@ __device__ inline bool chain_dp_ring(const uint64_t *gx, const uint32_t *gq, int
         if (max_ii < 0 || (near && mi_f < max_f)) { max_ii = i; mi_x = li; mi_q = qi; mi_f = max_f; }
     }
     wave_mem_sync();
-    if (dbg_cnt && lane == 0) { atomicAdd(&dbg_cnt[0], n_ch_in); atomicAdd(&dbg_cnt[1], n_ch_out); atomicAdd(&dbg_cnt[2], n_far); }
+    if (dbg_cnt && lane == 0) {
+        atomicAdd(&dbg_cnt[0], n_ch_in); atomicAdd(&dbg_cnt[1], n_ch_out); atomicAdd(&dbg_cnt[2], n_far);
+        atomicAdd(&dbg_cnt[3], 1ull); atomicAdd(&dbg_cnt[6], (unsigned long long)n);
+        if (n_evt) { atomicAdd(&dbg_cnt[4], 1ull); atomicAdd(&dbg_cnt[5], (unsigned long long)n); }
+        atomicMax(&dbg_cnt[7], (unsigned long long)max_win);
+        if (max_win > 64) atomicAdd(&dbg_cnt[8], (unsigned long long)n);
+        if (max_win > 128) atomicAdd(&dbg_cnt[9], (unsigned long long)n);
+    }
     return false;
 }
 
@@ -1023,36 +1132,36 @@ __device__ inline void backtrack_wave_top(SliceStore &S, int32_t n, const ChainP
 // one big cluster, one wave, DP state through the LDS ring
 __device__ inline void chain_cluster_ring(const uint64_t *gx, uint32_t *gq, int32_t *gf, int32_t *gpt, int32_t n, int32_t qlen, const ChainParams &P,
                                           int32_t &n_u, int32_t &best, bool first_only, uint32_t lane, RingMem &rm, unsigned long long *dbg_cnt = nullptr,
-                                          const ChainSink *sk = nullptr, uint32_t read = 0, uint32_t base = 0, uint64_t *heap = nullptr)
-{
+                                          const ChainSink *sk = nullptr, uint32_t read = 0, uint32_t base = 0, uint64_t *heap = nullptr, bool pre = false)
+{   // pre: f and p are there already (par_fill_block; p as indices into the read's array, this cluster starting at `base`)
     n_u = 0; best = 0;
     if (sk) {      // hand-over mode: every chain, anchors intact (the heap lives in `heap`, not over the x slice)
-        chain_dp_ring(gx, gq, gf, gpt, n, qlen, P, lane, rm, dbg_cnt);
-        SliceStore S{gx, gq, gf, gpt};
+        if (!pre) chain_dp_ring(gx, gq, gf, gpt, n, qlen, P, lane, rm, dbg_cnt);
+        SliceStore S{gx, gq, gf, gpt, pre ? (int32_t)base : 0};
         const StoreEmit<SliceStore> em{sk, &S, read, base, lane == 0, P.k, region_hash(qlen), qlen, nullptr};
         if (sk->best) backtrack_wave_top(S, n, P, n_u, best, em, lane);
         else backtrack_heap<SliceStore, int32_t, StoreEmit<SliceStore>>(S, n, P, heap, n_u, best, false, em);
         wave_mem_sync();
         return;
     }
-    if (first_only && P.flag_stop != INT32_MAX) { n_u = chain_dp_ring(gx, gq, gf, gpt, n, qlen, P, lane, rm, dbg_cnt, P.flag_stop) ? 1 : 0; return; }
-    chain_dp_ring(gx, gq, gf, gpt, n, qlen, P, lane, rm, dbg_cnt);
-    if (first_only) {
+    if (first_only && P.flag_stop != INT32_MAX && !pre) { n_u = chain_dp_ring(gx, gq, gf, gpt, n, qlen, P, lane, rm, dbg_cnt, P.flag_stop) ? 1 : 0; return; }
+    if (!pre) chain_dp_ring(gx, gq, gf, gpt, n, qlen, P, lane, rm, dbg_cnt);
+    if (first_only && !pre) {
         const int rc = first_chain_quick(gf, gpt, n, P, lane);
         if (rc >= 0) { n_u = rc; return; }
     }
-    SliceStore S{gx, gq, gf, gpt};
+    SliceStore S{gx, gq, gf, gpt, pre ? (int32_t)base : 0};
     backtrack_heap<SliceStore, int32_t>(S, n, P, (uint64_t *)gx, n_u, best, first_only);
     wave_mem_sync();
 }
 
 // one cluster, the whole wave: DP in parallel, backtrack executed uniformly by every lane
 __device__ inline void chain_cluster_wave(SliceStore &S, int32_t n, int32_t qlen, const ChainParams &P, uint64_t *zbuf, int32_t &n_u, int32_t &best,
-                                          bool first_only, uint32_t lane, const ChainSink *sk = nullptr, uint32_t read = 0, uint32_t base = 0)
-{
+                                          bool first_only, uint32_t lane, const ChainSink *sk = nullptr, uint32_t read = 0, uint32_t base = 0, bool pre = false)
+{   // pre: f and p are there already (par_fill_block; S.pbase set by the caller)
     if (sk) {      // hand-over mode (zbuf must not alias the anchors)
         const StoreEmit<SliceStore> em{sk, &S, read, base, lane == 0, P.k, region_hash(qlen), qlen, nullptr};
-        if (P.ext_s1 && n >= 2 && n <= 64) {
+        if (P.ext_s1 && n >= 2 && n <= 64 && !pre) {
             // A cluster whose anchors all lie on ONE diagonal, d <= min(max_dist_x, max_dist_y) apart (a copy of the read up to substitutions -
             // the true locus nearly always): the outcome of mg_lchain_dp + mg_chain_backtrack is known without running them (the argument of
             // k_pair_pass mode 2; no skip penalty: ext_s1) - every anchor links to its predecessor (it is scanned first and no earlier one can
@@ -1084,14 +1193,14 @@ __device__ inline void chain_cluster_wave(SliceStore &S, int32_t n, int32_t qlen
                 return;
             }
         }
-        chain_dp_wave(S, n, qlen, P, lane);
+        if (!pre) chain_dp_wave(S, n, qlen, P, lane);
         if (n <= 64) backtrack_mask(S, n, P, n_u, best, false, em);
         else if (sk->best) backtrack_wave_top(S, n, P, n_u, best, em, lane);
         else { backtrack_heap<SliceStore, int32_t, StoreEmit<SliceStore>>(S, n, P, zbuf, n_u, best, false, em); wave_mem_sync(); }
         return;
     }
-    if (first_only && P.flag_stop != INT32_MAX) { n_u = chain_dp_wave(S, n, qlen, P, lane, P.flag_stop) ? 1 : 0; best = 0; return; }
-    chain_dp_wave(S, n, qlen, P, lane);
+    if (first_only && P.flag_stop != INT32_MAX && !pre) { n_u = chain_dp_wave(S, n, qlen, P, lane, P.flag_stop) ? 1 : 0; best = 0; return; }
+    if (!pre) chain_dp_wave(S, n, qlen, P, lane);
     if (n <= 64) backtrack_mask(S, n, P, n_u, best, first_only);
     else { backtrack_heap<SliceStore, int32_t>(S, n, P, zbuf, n_u, best, first_only); wave_mem_sync(); }
 }
@@ -1099,24 +1208,24 @@ __device__ inline void chain_cluster_wave(SliceStore &S, int32_t n, int32_t qlen
 // DP + backtrack of one cluster.  zbuf: n 8-B words for the heap when n > 32 (may alias the x slice: the
 // anchors are dead once the DP is done).
 __device__ inline void chain_cluster(SliceStore &S, int32_t n, int32_t qlen, const ChainParams &P, uint64_t *zbuf, int32_t &n_u, int32_t &best,
-                                     bool first_only, const ChainSink *sk = nullptr, uint32_t read = 0, uint32_t base = 0)
-{
+                                     bool first_only, const ChainSink *sk = nullptr, uint32_t read = 0, uint32_t base = 0, bool pre = false)
+{   // pre: f and p are there already (par_fill_block; S.pbase set by the caller)
     if (sk) {      // hand-over mode (zbuf must not alias the anchors)
         const StoreEmit<SliceStore> em{sk, &S, read, base, true, P.k, region_hash(qlen), qlen, nullptr};
-        if (n <= 64) { chain_dp_mask(S, n, qlen, P); backtrack_mask(S, n, P, n_u, best, false, em); }
-        else { chain_dp<SliceStore, int32_t>(S, n, qlen, P); backtrack_heap<SliceStore, int32_t, StoreEmit<SliceStore>>(S, n, P, zbuf, n_u, best, false, em); }
+        if (n <= 64) { if (!pre) chain_dp_mask(S, n, qlen, P); backtrack_mask(S, n, P, n_u, best, false, em); }
+        else { if (!pre) chain_dp<SliceStore, int32_t>(S, n, qlen, P); backtrack_heap<SliceStore, int32_t, StoreEmit<SliceStore>>(S, n, P, zbuf, n_u, best, false, em); }
         return;
     }
-    if (first_only && P.flag_stop != INT32_MAX) {
+    if (first_only && P.flag_stop != INT32_MAX && !pre) {
         n_u = (n <= 64 ? chain_dp_mask(S, n, qlen, P, P.flag_stop) : chain_dp<SliceStore, int32_t>(S, n, qlen, P, P.flag_stop)) ? 1 : 0;
         best = 0;
         return;
     }
     if (n <= 64) {
-        chain_dp_mask(S, n, qlen, P);
+        if (!pre) chain_dp_mask(S, n, qlen, P);
         backtrack_mask(S, n, P, n_u, best, first_only);
     } else {
-        chain_dp<SliceStore, int32_t>(S, n, qlen, P);
+        if (!pre) chain_dp<SliceStore, int32_t>(S, n, qlen, P);
         backtrack_heap<SliceStore, int32_t>(S, n, P, zbuf, n_u, best, first_only);
     }
 }

@@ -75,10 +75,10 @@ struct Counters {
     uint32_t ext_n_recs[SINK_SHARDS]; unsigned long long ext_n_anch[SINK_SHARDS];                 // hand-over cursors, one per shard
     uint32_t lext_hist[64]; uint32_t lext_ticket_g, lext_pad3; uint32_t lext_n_big, lext_ticket_big, lext_n_big2, lext_ticket_big2, lext_ticket_b, lext_pad2, lext_rechained, lext_rmq_tie, lext_err_read, lext_unresolved, lext_err_code, lext_pad;
     unsigned long long lext_clk[LR_NCLK], lext_d[8], lext_slow, lext_kernel_sum;  // long-read extension stage (sh_long.h): reads for the large-scratch pass, RMQ re-chains, steps with tied priorities
-    uint32_t n_cl[4], cl_ticket, pad3;      // global queue of big clusters (k_cluster_dp), by size class
+    uint32_t n_cl[4], cl_ticket, cl_ticket3;      // global queue of big clusters (k_cluster_dp), by size class; tickets: classes 0-2 one by one, class 3 eight at a time
     uint32_t n_leg_reason[4];     // why reads left the long-read front end: 0 room/segments, 1 thinning screen, 2 anchors beyond the giant path, 3 unused
     unsigned long long arena_cursor, anchor_cursor;
-    unsigned long long cl_tot[4], cl_anchor_tot[4], cl_dbg[4];
+    unsigned long long cl_tot[4], cl_anchor_tot[4], cl_dbg[10], pf_dbg[8];
     unsigned long long sort_tot[N_SORT_CLS + 1], sort_anchor_tot[N_SORT_CLS + 1];    // SCRUBBY_HIP_DBG & 16: reads / anchors per sort class (4 = chained inside k_expand)     // statistics of k_cluster_dp by size class (whole chunk)
     unsigned long long sh_mini[64], sh_anchors[64];     // sharded sums
     uint32_t sh_host[64], sh_clusters[64], sh_pair[64];      // sh_pair: reads decided by the pair test
@@ -982,16 +982,6 @@ __device__ inline void wave_rank_sort(uint64_t &x, uint32_t &q, uint32_t n, uint
     x = (uint64_t)xh << 32 | xl;
 }
 
-__device__ inline uint32_t chain_max_dist_x(const ChainParams &P, int32_t qlen)
-{
-    int32_t m;
-    if (P.max_gap_ref > 0) m = P.max_gap_ref;
-    else if (P.max_frag_len > 0) { m = P.max_frag_len - qlen; if (m < P.max_gap) m = P.max_gap; }
-    else m = P.max_gap;
-    if (m < P.bw) m = P.bw;
-    return (uint32_t)m;
-}
-
 // SH_F_CIGAR, flag-only (ChainParams::ext_*): the cluster(s) around a read's singleton seeds, alone.
 // One wave per read of the repeat path's list, one lane per seed.  A read with unique seeds has its true locus there; the other
 // occurrences of its repeated seeds - hundreds of loci - need not be expanded, sorted and chained if they cannot matter:
@@ -1259,8 +1249,10 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
                                     const ChainParams &P, volatile int32_t *found, BigList bl,
                                     int32_t &n_u_thr, int32_t &best_thr, uint32_t &n_cl_thr, const GlobalQ *gq = nullptr,
                                     uint32_t *nxt = nullptr, const ChainSink *sk = nullptr, uint32_t read = 0, uint64_t *heap = nullptr,
-                                    BestChain *bc = nullptr, uint32_t rhash = 0, int phase = -1, TandemQ tq = TandemQ{nullptr, 0u, 1u, 0, 0u})
-{   // phase (flag-only hand-over, where a cluster that cannot beat the best score found so far is skipped): the BIG clusters first -
+                                    BestChain *bc = nullptr, uint32_t rhash = 0, int phase = -1, TandemQ tq = TandemQ{nullptr, 0u, 1u, 0, 0u},
+                                    ParFillLds *pf = nullptr, bool *pre_io = nullptr, unsigned long long *pf_dbg = nullptr)
+{   // pf: the DP of all clusters at once (par_fill_block) before any cluster is visited; *pre_io: whether it applied (out; in for CONTIG phase 1,
+    // whose f / p / dirty marks are phase 0's)   // phase (flag-only hand-over, where a cluster that cannot beat the best score found so far is skipped): the BIG clusters first -
     //   CONTIG: 0 = only clusters of more than 64 anchors (queued for k_cluster_dp), 1 = only the others, afterwards; -1 = all at once
     //   else:   the clusters a wave chains (> 6 anchors) before the ones a lane chains, inside this call
     // bc: SH_F_CIGAR flag-only, n <= 64: every lane chains its clusters itself and remembers its top chain (BestChain), nothing is emitted
@@ -1278,11 +1270,21 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
         if (start) q[i] |= 0x80000000u;
     }
     __syncthreads();
+    bool pre = false;
+    if (pf) {
+        if (CONTIG && phase == 1) pre = pre_io && *pre_io;
+        else {
+            pre = par_fill_block(x, q, f, pt, n, qlen, P, tid, nthr, *pf); if (pre_io) *pre_io = pre;
+            if (pf_dbg && tid == 0) { atomicAdd(&pf_dbg[pre ? 0 : 1], 1ull); atomicAdd(&pf_dbg[2], (unsigned long long)pf->n_dirty); atomicAdd(&pf_dbg[pre ? 3 : 4], (unsigned long long)n); }
+        }
+    }
     // one cluster [i, i + len): chained by this lane if small, else queued for a whole wave
-    auto handle = [&](uint32_t i, uint32_t len) {
+    auto handle = [&](uint32_t i, uint32_t len, uint32_t known_dirty = 2u) {
         if (len < 2 && !keep_single) return;
+        const int32_t tflag = pre && known_dirty == 2u ? pt[2 * (size_t)i + 1] : 0;
+        const bool pre_c = pre && (known_dirty == 2u ? tflag != PF_DIRTY : known_dirty == 0u);
         // flag-only hand-over: a cluster of len anchors cannot chain to more than k * len; below the best score already handed over it is moot
-        if (CONTIG && phase == 1 && sk && sk->best && P.is_sr && P.ext_lemma && len <= 64u && f[i] == INT32_MIN) return;      // ruled out by its wave (prefilter below)
+        if (CONTIG && phase == 1 && sk && sk->best && P.is_sr && P.ext_lemma && len <= 64u && (pre ? tflag == PF_DEAD : f[i] == INT32_MIN)) return;      // ruled out by its wave (prefilter below)
         if (sk && sk->best) {
             const int32_t bs = sink_best_score(*sk, read);
             if ((int64_t)P.k * (int64_t)len < (int64_t)bs) return;
@@ -1315,14 +1317,14 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
             if (gq) {
                 const int cc = cl_class(len);
                 const uint32_t gs = atomicAdd(&gq->count[cc], 1u);
-                if (gs < gq->cap[cc]) { SortItem ci{gq->w, len, (uint32_t)qlen, gq->in_b | i << 1, gq->off + i}; gq->items[cc][gs] = ci; return; }     // pad = buffer | cluster start << 1
+                if (gs < gq->cap[cc]) { SortItem ci{gq->w, len, (uint32_t)qlen | (pre_c ? 0x80000000u : 0u), gq->in_b | i << 1, gq->off + i}; gq->items[cc][gs] = ci; return; }     // pad = buffer | cluster start << 1; qlen bit 31: DP done
             }
             const int32_t slot = atomicAdd(bl.count, 1);
             if ((uint32_t)slot < bl.cap) { bl.start[slot] = i; bl.len[slot] = len; return; }
         }
-        SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i};
+        SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i, pre_c ? (int32_t)i : 0};
         int32_t n_u, best;
-        chain_cluster(S, (int32_t)len, qlen, P, heap ? heap + i : (uint64_t *)&x[i], n_u, best, found != nullptr, sk, read, i);
+        chain_cluster(S, (int32_t)len, qlen, P, heap ? heap + i : (uint64_t *)&x[i], n_u, best, found != nullptr, sk, read, i, pre_c);
         ++n_cl_thr;
         if (n_u > 0) { n_u_thr += n_u; if (best > best_thr) best_thr = best; if (found) *found = 1; }
     };
@@ -1372,22 +1374,25 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
                         // survivors are packed into the block's LDS list, so that every thread gets one instead of the few threads whose ranges
                         // hold them chaining two or three in a row while the rest of their waves idle; a full list leaves them to the sweeps
                         bool listed = false;
+                        const bool dirty = pre && pt[2 * (size_t)st + 1] == PF_DIRTY;
                         if (!dead) {
                             const int32_t slot = atomicAdd(bl.count, 1);
-                            if ((uint32_t)slot < bl.cap) { bl.start[slot] = st; bl.len[slot] = len; listed = true; }
+                            if ((uint32_t)slot < bl.cap) { bl.start[slot] = st; bl.len[slot] = len | (dirty ? 0x80000000u : 0u); listed = true; }
                         }
-                        f[st] = dead || listed ? INT32_MIN : 0;
+                        if (pre) { if (dead || listed) pt[2 * (size_t)st + 1] = PF_DEAD; }      // f[st] is the DP's
+                        else f[st] = dead || listed ? INT32_MIN : 0;
                     }
                 }
             }
             __syncthreads();
             const uint32_t n_list = (uint32_t)*bl.count < bl.cap ? (uint32_t)*bl.count : bl.cap;
             for (uint32_t b = tid; b < n_list; b += nthr) {
-                const uint32_t ci = bl.start[b], cl = bl.len[b];
+                const uint32_t ci = bl.start[b], cl = bl.len[b] & 0x7fffffffu;
+                const bool pre_c = pre && !(bl.len[b] >> 31);
                 if ((int64_t)P.k * (int64_t)cl < (int64_t)sink_best_score(*sk, read)) continue;      // the score to beat has risen since
-                SliceStore S{(const uint64_t *)&x[ci], (const uint32_t *)&q[ci], f + ci, pt + 2 * (size_t)ci};
+                SliceStore S{(const uint64_t *)&x[ci], (const uint32_t *)&q[ci], f + ci, pt + 2 * (size_t)ci, pre_c ? (int32_t)ci : 0};
                 int32_t n_u, best;
-                chain_cluster(S, (int32_t)cl, qlen, P, heap ? heap + ci : (uint64_t *)&x[ci], n_u, best, false, sk, read, ci);
+                chain_cluster(S, (int32_t)cl, qlen, P, heap ? heap + ci : (uint64_t *)&x[ci], n_u, best, false, sk, read, ci, pre_c);
                 ++n_cl_thr;
                 if (n_u > 0) { n_u_thr += n_u; if (best > best_thr) best_thr = best; }
             }
@@ -1435,9 +1440,10 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
             const int32_t bs = sink_best_score(*sk, read);
             if (bs > P.k && cluster_cannot_reach((const uint64_t *)&x[0], (const uint32_t *)&q[0], i, len, bs, P, lane)) continue;
         }
-        SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i};
+        const bool pre_c = pre && pt[2 * (size_t)i + 1] != PF_DIRTY;
+        SliceStore S{(const uint64_t *)&x[i], (const uint32_t *)&q[i], f + i, pt + 2 * (size_t)i, pre_c ? (int32_t)i : 0};
         int32_t n_u, best;
-        chain_cluster_wave(S, (int32_t)len, qlen, P, heap ? heap + i : (uint64_t *)&x[i], n_u, best, found != nullptr, lane, sk, read, i);
+        chain_cluster_wave(S, (int32_t)len, qlen, P, heap ? heap + i : (uint64_t *)&x[i], n_u, best, found != nullptr, lane, sk, read, i, pre_c);
         if (lane == 0) {
             ++n_cl_thr;
             if (n_u > 0) { n_u_thr += n_u; if (best > best_thr) best_thr = best; if (found) *found = 1; }
@@ -2030,7 +2036,11 @@ __global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
     __shared__ uint64_t s_x[2][NMAX];
     __shared__ uint32_t s_q[2][NMAX];
     __shared__ int32_t s_found, s_red[2], s_bcount, s_gover;
-    __shared__ uint32_t s_bstart[NMAX / 7 + 1], s_blen[NMAX / 7 + 1], s_gkey[GP_SLOTS], s_gcnt[GP_SLOTS], s_gw[16], s_gsel[2];
+    __shared__ uint32_t s_bstart[NMAX / 7 + 1], s_blen[NMAX / 7 + 1], s_gw[16], s_gsel[2];
+    __shared__ union GpPf { struct { uint32_t key[GP_SLOTS], cnt[GP_SLOTS]; } g; ParFillLds pf; } s_u;      // group_probe's table (before the sort, flag-only) / par_fill_block's (after it)
+    uint32_t *const s_gkey = s_u.g.key, *const s_gcnt = s_u.g.cnt;
+    ParFillLds &s_pf = s_u.pf;
+    const bool use_pf = (a.emit || !a.flag_only) && !(a.dbg & 128);
     const uint32_t tid = threadIdx.x;
     const uint32_t n_items = a.ctr->n_sort[CLS];
     __shared__ uint32_t s_it;
@@ -2067,7 +2077,8 @@ __global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
         if (!(a.dbg & 1))
         chain_sorted<false>(rx, rq, f, pt, n, tid, NTHR, (int32_t)si.qlen, a.P, a.flag_only ? &s_found : nullptr,
                             BigList{s_bstart, s_blen, &s_bcount, NMAX / 7 + 1}, n_u, best, n_cl, nullptr, nullptr,
-                            a.emit ? &a.sink : nullptr, a.B.meta[si.w].r, a.emit ? a.B.hz + si.off : nullptr);
+                            a.emit ? &a.sink : nullptr, a.B.meta[si.w].r, a.emit ? a.B.hz + si.off : nullptr,
+                            nullptr, 0u, -1, TandemQ{nullptr, 0u, 1u, 0, 0u}, use_pf ? &s_pf : nullptr, nullptr, (a.dbg & 16) ? a.ctr->pf_dbg : nullptr);
         store_read_result(a, si.w, n_u, best, n_cl, s_red);
         __syncthreads();
     }
@@ -2228,6 +2239,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 {
     __shared__ int32_t s_found, s_red[2], s_bcount;
     __shared__ uint32_t s_bstart[2048], s_blen[2048], s_nxt[1024];
+    __shared__ ParFillLds s_pf;
+    const bool use_pf = (a.emit || !a.flag_only) && !(a.dbg & 128);
     // local copies: a pointer or reference INTO the argument struct makes the compiler copy all ~640 B of it to scratch at entry and read
     // every a.X from there afterwards
     const ChainSink sink_l = a.sink; const ChainParams P_l = a.P;
@@ -2240,9 +2253,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const uint32_t it = s_it;
         __syncthreads();
         if (it >= n_items) break;
-        const SortItem si = a.B.sort_items[SORT_CLS_GIANT][a.B.giant_order[it]];
+        SortItem si = a.B.sort_items[SORT_CLS_GIANT][a.B.giant_order[it]];
         const uint32_t n = si.n;
         if (n == 0) continue;                 // decided by k_group_probe
+        bool pre = (si.qlen >> 31) != 0;      // phase 1: what phase 0's par_fill_block said
+        si.qlen &= 0x7fffffffu;
         const bool in_b = giant_rounds(n) & 1;
         uint64_t *sx = (in_b ? a.B.bx : a.B.ax) + si.off; uint32_t *sq = (in_b ? a.B.bq : a.B.aq) + si.off;
         if (tid == 0) s_found = 0;
@@ -2253,7 +2268,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         chain_sorted<true>(sx, sq, a.B.af + si.off, (int32_t *)(a.B.az + si.off), n, tid, nthr, (int32_t)si.qlen, P_l,
                      a.flag_only ? &s_found : nullptr, BigList{s_bstart, s_blen, &s_bcount, 2048}, n_u, best, n_cl, &gq, s_nxt,
                      a.emit ? &sink_l : nullptr, a.B.meta[si.w].r, a.emit ? (in_b ? a.B.ax : a.B.bx) + si.off : nullptr,      // heap: the sort's other buffer
-                     nullptr, 0u, phase);
+                     nullptr, 0u, phase, TandemQ{nullptr, 0u, 1u, 0, 0u}, use_pf ? &s_pf : nullptr, &pre, (a.dbg & 16) ? a.ctr->pf_dbg : nullptr);
+        if (phase == 0 && pre && tid == 0) a.B.sort_items[SORT_CLS_GIANT][a.B.giant_order[it]].qlen = si.qlen | 0x80000000u;
         store_read_result(a, si.w, n_u, best, n_cl, s_red, phase == 1);
         __syncthreads();
     }
@@ -2270,17 +2286,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     const uint32_t cnt2 = min(a.ctr->n_cl[2], a.B.cl_cap[2]), cnt3 = min(a.ctr->n_cl[3], a.B.cl_cap[3]);
     const uint32_t total = cnt0 + cnt1 + cnt2 + cnt3;
     uint32_t n_cl = 0;
+    // One address takes ~90 M atomics/s: a ticket per cluster (1.6 M of them per step of the bench workload, most of 65..256 anchors) plus two
+    // statistics counters per cluster kept every wave queueing at the L2 - the kernel took 40 ms with the DP itself switched off.  Classes 0-2
+    // (few, large) are drawn one by one, class 3 eight at a time; the per-class statistics are debug output only.
+    const uint32_t big = cnt0 + cnt1 + cnt2;
+    uint32_t t3 = 0, t3_end = 0;
+    bool big_done = big == 0;
     for (;;) {
         uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(&a.ctr->cl_ticket, 1u);
-        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        if (t >= total) break;
         int c;
         const SortItem *items;
-        if (t < cnt0) { c = 0; items = a.B.cl_items[0]; }
-        else if (t < cnt0 + cnt1) { c = 1; t -= cnt0; items = a.B.cl_items[1]; }
-        else if (t < cnt0 + cnt1 + cnt2) { c = 2; t -= cnt0 + cnt1; items = a.B.cl_items[2]; }
-        else { c = 3; t -= cnt0 + cnt1 + cnt2; items = a.B.cl_items[3]; }
+        if (!big_done) {
+            if (lane == 0) t = atomicAdd(&a.ctr->cl_ticket, 1u);
+            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            if (t >= big) { big_done = true; continue; }
+            if (t < cnt0) { c = 0; items = a.B.cl_items[0]; }
+            else if (t < cnt0 + cnt1) { c = 1; t -= cnt0; items = a.B.cl_items[1]; }
+            else { c = 2; t -= cnt0 + cnt1; items = a.B.cl_items[2]; }
+        } else {
+            if (t3 >= t3_end) {
+                if (lane == 0) t3 = atomicAdd(&a.ctr->cl_ticket3, 8u);
+                t3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t3);
+                if (t3 >= cnt3) break;
+                t3_end = min(t3 + 8u, cnt3);
+            }
+            t = t3++; c = 3; items = a.B.cl_items[3];
+        }
         const SortItem ci = items[t];
         if (a.flag_only && __atomic_load_n(&a.B.acc_nu[ci.w], __ATOMIC_RELAXED) > 0) continue;      // the read is decided
         const bool in_b = (ci.pad & 1u) != 0;
@@ -2289,15 +2320,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
         const ChainSink *sk = a.emit ? &a.sink : nullptr;
         const uint32_t rd = a.emit ? a.B.meta[ci.w].r : 0u, cbase = ci.pad >> 1;
         int32_t n_u, best;
+        const bool pre = (ci.qlen >> 31) != 0;      // f and p are par_fill_block's
+        if ((a.dbg & 16) && lane == 0) { atomicAdd(&a.ctr->pf_dbg[pre ? 5 : 6], 1ull); if (!pre) atomicAdd(&a.ctr->pf_dbg[7], (unsigned long long)ci.n); }
+        const int32_t cqlen = (int32_t)(ci.qlen & 0x7fffffffu);
         if (a.P.max_iter <= RING_TMAX_ITER)
-            chain_cluster_ring(gx, gq, a.B.af + ci.off, (int32_t *)(a.B.az + ci.off), (int32_t)ci.n, (int32_t)ci.qlen, a.P, n_u, best,
-                               a.flag_only != 0, lane, s_ring[wv], (a.dbg & 16) ? a.ctr->cl_dbg : nullptr, sk, rd, cbase, heap);
+            chain_cluster_ring(gx, gq, a.B.af + ci.off, (int32_t *)(a.B.az + ci.off), (int32_t)ci.n, cqlen, a.P, n_u, best,
+                               a.flag_only != 0, lane, s_ring[wv], (a.dbg & 16) ? a.ctr->cl_dbg : nullptr, sk, a.emit ? rd : 0u, cbase, heap, pre);
         else {      // look-back windows beyond the LDS mark bitmap: DP state in the arena throughout
-            SliceStore S{gx, gq, a.B.af + ci.off, (int32_t *)(a.B.az + ci.off)};
-            chain_cluster_wave(S, (int32_t)ci.n, (int32_t)ci.qlen, a.P, heap, n_u, best, a.flag_only != 0, lane, sk, rd, cbase);
+            SliceStore S{gx, gq, a.B.af + ci.off, (int32_t *)(a.B.az + ci.off), pre ? (int32_t)cbase : 0};
+            chain_cluster_wave(S, (int32_t)ci.n, cqlen, a.P, heap, n_u, best, a.flag_only != 0, lane, sk, rd, cbase, pre);
         }
         ++n_cl;
-        if (lane == 0) { atomicAdd(&a.ctr->cl_tot[c], 1ull); atomicAdd(&a.ctr->cl_anchor_tot[c], (unsigned long long)ci.n); }
+        if ((a.dbg & 16) && lane == 0) { atomicAdd(&a.ctr->cl_tot[c], 1ull); atomicAdd(&a.ctr->cl_anchor_tot[c], (unsigned long long)ci.n); }
         if (lane == 0 && n_u > 0) { atomicAdd(&a.B.acc_nu[ci.w], n_u); atomicMax(&a.B.acc_best[ci.w], best); }
     }
     if (lane == 0 && n_cl) atomicAdd(&a.ctr->sh_clusters[(blockIdx.x * 4 + wv) & 63], n_cl);
@@ -3203,6 +3237,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     k.flag_only = d_trace == nullptr && !c->ext;      // SH_F_CIGAR: every chain is needed, no early exit
     k.sink = b.sink; k.emit = c->ext ? 1 : 0; k.BC = b.BC; k.t_mode = (c->ext && !c->ext_long && d_trace == nullptr) ? 1 : 0;
     k.dbg = getenv("SCRUBBY_HIP_DBG") ? atoi(getenv("SCRUBBY_HIP_DBG")) : 0;
+    if (getenv("SCRUBBY_HIP_NO_PARFILL")) k.dbg |= 128;      // A/B: every cluster chained by the sequential DP
     k.resketch_list = c->d_work_resketch;
     uint32_t resk_done = 0;
     // pass 0 (mid_occ) over the reads K2 routed, pass 1 (max_occ) over the reads pass 0 could not chain;
@@ -3255,7 +3290,8 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
             if (k.dbg & 16) fprintf(stderr, "[dbg] clusters chained by k_cluster_dp by class: %llu %llu %llu %llu, their anchors %llu %llu %llu %llu\n", c->h_ctr->cl_tot[0], c->h_ctr->cl_tot[1], c->h_ctr->cl_tot[2], c->h_ctr->cl_tot[3], c->h_ctr->cl_anchor_tot[0], c->h_ctr->cl_anchor_tot[1], c->h_ctr->cl_anchor_tot[2], c->h_ctr->cl_anchor_tot[3]);
             if (k.dbg & 16) fprintf(stderr, "[dbg] reads (anchors) by sort class: <=64 %llu (%llu), <=256 %llu (%llu), <=512 %llu (%llu), <=1024 %llu (%llu), <=2048 %llu (%llu), <=4096 %llu (%llu), giant %llu (%llu)\n", c->h_ctr->sort_tot[6], c->h_ctr->sort_anchor_tot[6], c->h_ctr->sort_tot[0], c->h_ctr->sort_anchor_tot[0], c->h_ctr->sort_tot[1], c->h_ctr->sort_anchor_tot[1], c->h_ctr->sort_tot[2], c->h_ctr->sort_anchor_tot[2], c->h_ctr->sort_tot[3], c->h_ctr->sort_anchor_tot[3], c->h_ctr->sort_tot[4], c->h_ctr->sort_anchor_tot[4], c->h_ctr->sort_tot[5], c->h_ctr->sort_anchor_tot[5]);
             if (k.dbg & 16) fprintf(stderr, "[dbg] local-cluster shortcut: tried %u, no singleton / filtered %u, singletons apart %u, window %u, K size %u, no margin %u, decided %u\n", c->h_ctr->ext_s3[0], c->h_ctr->ext_s3[1], c->h_ctr->ext_s3[2], c->h_ctr->ext_s3[3], c->h_ctr->ext_s3[4], c->h_ctr->ext_s3[5], c->h_ctr->ext_s3[7]);
-            if (k.dbg & 16) fprintf(stderr, "[dbg] ring DP: chunks in window %llu, beyond %llu, far rescans %llu\n", c->h_ctr->cl_dbg[0], c->h_ctr->cl_dbg[1], c->h_ctr->cl_dbg[2]);
+            if (k.dbg & 16) fprintf(stderr, "[dbg] ring DP: chunks in window %llu, beyond %llu, far rescans %llu; clusters %llu (anchors %llu), with a max_skip break %llu (anchors %llu), widest window %llu, anchors of clusters with a window > 64: %llu, > 128: %llu\n", c->h_ctr->cl_dbg[0], c->h_ctr->cl_dbg[1], c->h_ctr->cl_dbg[2], c->h_ctr->cl_dbg[3], c->h_ctr->cl_dbg[6], c->h_ctr->cl_dbg[4], c->h_ctr->cl_dbg[5], c->h_ctr->cl_dbg[7], c->h_ctr->cl_dbg[8], c->h_ctr->cl_dbg[9]);
+            if (k.dbg & 16) fprintf(stderr, "[dbg] parallel fill: reads done %llu (anchors %llu), not applicable %llu (anchors %llu), dirty anchors %llu; k_cluster_dp clusters prefilled %llu, sequential %llu (anchors %llu)\n", c->h_ctr->pf_dbg[0], c->h_ctr->pf_dbg[3], c->h_ctr->pf_dbg[1], c->h_ctr->pf_dbg[4], c->h_ctr->pf_dbg[2], c->h_ctr->pf_dbg[5], c->h_ctr->pf_dbg[6], c->h_ctr->pf_dbg[7]);
             resk_done = c->h_ctr->n_resketch;
             const uint32_t d0 = c->h_ctr->n_big_defer[0], d1 = c->h_ctr->n_big_defer[1];
             if (d0 == 0 && d1 == 0) break;
