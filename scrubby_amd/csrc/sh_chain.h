@@ -606,6 +606,95 @@ __device__ inline bool par_fill_block(PX x, PQ q, int32_t *f, int32_t *pt, uint3
     return true;
 }
 
+// par_fill_block for reads whose anchors live in HBM (tens of thousands per read): the rounds sweep a read's data once per rank, and with
+// hundreds of reads in flight that data does not stay in the L2 between sweeps - measured, the kernel moved ~20 x its input.  The DP only
+// looks back a few dozen anchors, so the read is cut into tiles of PFT_T consecutive anchors that are chained one after the other, each
+// completely in LDS (its own rank table, all rounds), with the last PFT_H anchors of the tile before it as a halo; f and (p, t = 0) go
+// out once, coalesced.  An anchor whose window is not inside tile + halo is dirty (so is one with PFT_H anchors within max_dist_x behind
+// it: the max_iter cut is not looked at any closer than that; needs max_iter >= PFT_H).  Same contract as par_fill_block.
+#define PFT_T 4096
+#define PFT_H 256
+struct PfTile { uint32_t x[PFT_H + PFT_T], q[PFT_H + PFT_T]; int32_t f[PFT_H + PFT_T]; uint16_t p[PFT_T], perm[PFT_T]; };
+
+__device__ inline bool par_fill_tiled(const uint64_t *x, const uint32_t *q, int32_t *f, int32_t *pt, uint32_t n, int32_t qlen, const ChainParams &P, uint32_t tid, uint32_t nthr,
+                                      ParFillLds &L, PfTile &T)
+{
+    if (qlen > PF_MAX_Q || n >= 0x7ffffff0u || P.max_iter < PFT_H || nthr < PFT_H) return false;
+    const int32_t mdy = chain_max_dist_y(P, qlen), mdx = (int32_t)chain_max_dist_x(P, qlen);
+    if (tid == 0) L.n_dirty = 0;
+    uint32_t h = 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += PFT_T) {
+        const uint32_t tn = n - t0 < PFT_T ? n - t0 : PFT_T;
+        for (uint32_t t = tid; t < PF_MAX_Q / 64; t += nthr) L.qmask[t] = 0;
+        __syncthreads();
+        for (uint32_t k = tid; k < tn; k += nthr) {
+            const uint32_t qr = q[t0 + k], qq = qr & 0x7fffffffu;
+            T.x[h + k] = (uint32_t)x[t0 + k]; T.q[h + k] = qr;
+            if (!((L.qmask[qq >> 6] >> (qq & 63)) & 1ull)) atomicOr(&L.qmask[qq >> 6], 1ull << (qq & 63));
+        }
+        __syncthreads();
+        if (tid == 0) { uint32_t acc = 0; for (int w = 0; w < PF_MAX_Q / 64; ++w) { L.qpre[w] = acc; acc += (uint32_t)__popcll(L.qmask[w]); } L.qpre[PF_MAX_Q / 64] = acc; }
+        __syncthreads();
+        const uint32_t R = L.qpre[PF_MAX_Q / 64];
+        if (R > PF_MAX_RANK) return false;
+        for (uint32_t t = tid; t <= R; t += nthr) L.start[t] = 0;
+        __syncthreads();
+        auto rank_of = [&](uint32_t qq) { return L.qpre[qq >> 6] + (uint32_t)__popcll(L.qmask[qq >> 6] & ((1ull << (qq & 63)) - 1ull)); };
+        for (uint32_t k = tid; k < tn; k += nthr) atomicAdd(&L.start[rank_of(T.q[h + k] & 0x7fffffffu) + 1], 1u);
+        __syncthreads();
+        if (tid == 0) { uint32_t acc = 0; for (uint32_t r = 0; r < R; ++r) { acc += L.start[r + 1]; L.start[r + 1] = acc; } }
+        __syncthreads();
+        for (uint32_t t = tid; t < R; t += nthr) L.cur[t] = L.start[t];
+        __syncthreads();
+        for (uint32_t k = tid; k < tn; k += nthr) T.perm[atomicAdd(&L.cur[rank_of(T.q[h + k] & 0x7fffffffu)], 1u)] = (uint16_t)k;
+        __syncthreads();
+        for (uint32_t r = 0; r < R; ++r) {
+            const uint32_t e = L.start[r + 1];
+            for (uint32_t idx = L.start[r] + tid; idx < e; idx += nthr) {
+                const uint32_t kt = T.perm[idx], k = h + kt;
+                const uint32_t qraw = T.q[k], qi = qraw & 0x7fffffffu, xi = T.x[k];
+                int32_t max_f = P.k, nv = 0;
+                uint32_t max_d = 0;
+                bool bad = false;
+                if (!(qraw >> 31)) {
+                    const uint32_t lim = min((uint32_t)mdx, qi + (uint32_t)P.bw);
+                    if (k >= PFT_H && xi - T.x[k - PFT_H] <= (uint32_t)mdx) bad = true;      // a window of PFT_H anchors or more: left to the sequential code
+                    bool stop = false;
+                    for (int32_t j = (int32_t)k - 1; j >= 0; --j) {
+                        const uint32_t qj = T.q[j], xj = T.x[j];
+                        if (xi - xj > lim) { stop = true; break; }
+                        const int32_t sc = comput_sc(xi, qi, xj, qj & 0x7fffffffu, mdx, mdy, P);
+                        if (sc != SH_SC_NONE) { ++nv; const int32_t c = sc + T.f[j]; if (c > max_f) { max_f = c; max_d = k - (uint32_t)j; } }
+                        if (qj >> 31) { stop = true; break; }
+                    }
+                    if (!stop && t0 > h) bad = true;      // ran out of halo
+                }
+                T.f[k] = max_f; T.p[kt] = (uint16_t)max_d;
+                if (bad || nv > P.max_skip) { const int32_t d = atomicAdd(&L.n_dirty, 1); if (d < PF_DIRTY_CAP) L.dirty[d] = t0 + kt; }
+            }
+            __syncthreads();
+        }
+        for (uint32_t k = tid; k < tn; k += nthr) {
+            const uint32_t g = t0 + k, d = T.p[k];
+            f[g] = T.f[h + k];
+            *(int2 *)(pt + 2 * (size_t)g) = make_int2(d ? (int32_t)(g - d) : -1, 0);
+        }
+        // the halo of the next tile: the last anchors of this one
+        const uint32_t tot = h + tn, nh = tot < PFT_H ? tot : PFT_H;
+        uint32_t hx = 0, hq = 0; int32_t hf = 0;
+        if (tid < nh) { hx = T.x[tot - nh + tid]; hq = T.q[tot - nh + tid]; hf = T.f[tot - nh + tid]; }
+        __syncthreads();
+        if (tid < nh) { T.x[tid] = hx; T.q[tid] = hq; T.f[tid] = hf; }
+        h = nh;
+        __syncthreads();
+    }
+    const int32_t nd = L.n_dirty;
+    if (nd > PF_DIRTY_CAP) return false;
+    for (int32_t d = (int32_t)tid; d < nd; d += (int32_t)nthr) { uint32_t c = L.dirty[d]; while (!(q[c] >> 31)) --c; pt[2 * (size_t)c + 1] = PF_DIRTY; }
+    __syncthreads();
+    return true;
+}
+
 template <class Store, class EM = NoEmit>
 __device__ inline void backtrack_mask(Store &S, int n, const ChainParams &P, int32_t &n_u, int32_t &best, bool first_only, const EM &em = EM())
 {
@@ -1127,6 +1216,83 @@ __device__ inline void backtrack_wave_top(SliceStore &S, int32_t n, const ChainP
         backtrack_visit<SliceStore, int32_t, EM>(S, P, zf, zi, n_v, n_u, best, em);       // uniform: every lane walks, lane 0's emitter writes
         wave_mem_sync();
     }
+}
+
+// mg_chain_backtrack over ALL anchors of a read whose DP par_fill_block has done, for hand-overs that only want candidates for regs[0]
+// (ChainSink::best): mg_chain_backtrack knows no clusters - it visits the read's candidates in descending (f, index) order - and the
+// emitter's done(zf) ends the visit once f falls below the best score handed over.  The maximum (f, index) comes from a block-wide argmax;
+// its chain's score S is found by a dry walk (mg_chain_bk_end leaves no marks); ONE pass then lists every candidate with f >= S - the only
+// ones that can still matter, the top one included - and wave 0 visits them in order.  That settles a typical read with three sweeps over f
+// and a handful of walks, without looking at a single cluster.  Reads with many candidates at the top score (tandem arrays: every copy
+// chains alike) are better served cluster by cluster, in parallel: false is returned before anything is marked or emitted, and the caller
+// carries on as if this had not run.  S spans the read (p = indices into it); t must be 0 everywhere.  Results in thread 0.
+// s_red: 18 long longs of LDS; cand_f / cand_i / cand_n: an LDS list of `cap` entries.
+#define TOPBT_MAX 64
+template <class EM>
+__device__ inline bool backtrack_block_top(SliceStore &S, int32_t n, const ChainParams &P, int32_t &n_u, int32_t &best, const EM &em, const ChainSink &sk, uint32_t read,
+                                           uint32_t tid, uint32_t nthr, long long *s_red, uint32_t *cand_f, uint32_t *cand_i, int32_t *cand_n, uint32_t cap, unsigned long long *dbg = nullptr)
+{
+    n_u = 0; best = 0;
+    const uint32_t lane = tid & 63, wave = tid >> 6, n_wave = nthr >> 6;
+    long long key = -1;
+    for (int32_t i = (int32_t)tid; i < n; i += (int32_t)nthr) {
+        const int32_t f = S.f[i];
+        if (f < P.min_sc) continue;
+        const long long kk = (long long)f << 32 | (uint32_t)i;
+        if (kk > key) key = kk;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const long long t = __shfl_xor(key, o); key = t > key ? t : key; }
+    if (lane == 0) s_red[wave] = key;
+    if (tid == 0) *cand_n = 0;
+    __syncthreads();
+    key = s_red[0];
+    for (uint32_t w = 1; w < n_wave; ++w) key = s_red[w] > key ? s_red[w] : key;
+    if (key < 0) return true;                 // no candidate at all
+    const int32_t zf = (int32_t)(key >> 32), zi = (int32_t)(key & 0xffffffff);
+    if (em.done(zf)) return true;
+    if (wave == 0) {      // the top chain's score, nothing marked
+        const int32_t end_i = chain_bk_end<SliceStore, int32_t>(S, P.bw, zf, zi);
+        int32_t cnt = 0;
+        for (int32_t i = zi; i != end_i; i = S.Pm(i)) ++cnt;
+        const int32_t sc = end_i < 0 ? zf : zf - S.F(end_i);
+        if (lane == 0) s_red[16] = sc >= P.min_sc && cnt >= 1 && cnt >= P.min_cnt ? sc : -1;
+    }
+    __syncthreads();
+    const int32_t s1 = (int32_t)s_red[16];
+    if (s1 < 0) return false;
+    int32_t thr = sink_best_score(sk, read);
+    if (thr < s1) thr = s1;
+    for (int32_t i = (int32_t)tid; i < n; i += (int32_t)nthr) {
+        const int32_t f = S.f[i];
+        if (f < thr) continue;
+        const int32_t slot = atomicAdd(cand_n, 1);
+        if ((uint32_t)slot < cap && slot < TOPBT_MAX) { cand_f[slot] = (uint32_t)f; cand_i[slot] = (uint32_t)i; }
+    }
+    __syncthreads();
+    const int32_t nc = *cand_n;
+    if (dbg && tid == 0) { atomicAdd(&dbg[8], 1ull); atomicAdd(&dbg[11], (unsigned long long)nc); if ((uint32_t)nc > cap || nc > TOPBT_MAX) atomicAdd(&dbg[12], 1ull); }
+    if ((uint32_t)nc > cap || nc > TOPBT_MAX) return false;
+    if (wave == 0) {
+        long long bound = 1ll << 62;
+        int64_t n_v = 0;
+        unsigned long long d_visit = 0;
+        for (;;) {
+            long long k2 = -1;
+            if ((int32_t)lane < nc) { const long long kk = (long long)cand_f[lane] << 32 | cand_i[lane]; if (kk < bound) k2 = kk; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const long long t = __shfl_xor(k2, o); k2 = t > k2 ? t : k2; }
+            if (k2 < 0) break;
+            bound = k2;
+            const int32_t f2 = (int32_t)(k2 >> 32), i2 = (int32_t)(k2 & 0xffffffff);
+            if (em.done(f2)) break;
+            ++d_visit;
+            backtrack_visit<SliceStore, int32_t, EM>(S, P, f2, i2, n_v, n_u, best, em);
+        }
+        if (dbg && lane == 0) atomicAdd(&dbg[10], d_visit);
+    }
+    __syncthreads();
+    return true;
 }
 
 // one big cluster, one wave, DP state through the LDS ring

@@ -67,6 +67,7 @@ struct Counters {
     uint32_t n_big_total, pad1;   // repeat-path reads before the pair pass took its share (0: no pair pass)
     uint32_t n_sort[N_SORT_CLS], n_giant_tiles, n_giant_rounds;
     uint32_t expand_ticket, pad_t;         // k_expand: next read of the pass's list
+    uint32_t top_ticket[N_SORT_CLS];       // k_sort_top / k_giant_top: likewise
     uint32_t sort_ticket[N_SORT_CLS];      // k_sort_lds: next item of the class (blocks draw reads one by one: their costs differ a hundredfold)
     uint32_t n_long_segs, pad2;
     uint32_t ext_reason[8];       // why the top chain did not settle a read (k_ext_top)
@@ -78,7 +79,7 @@ struct Counters {
     uint32_t n_cl[4], cl_ticket, cl_ticket3;      // global queue of big clusters (k_cluster_dp), by size class; tickets: classes 0-2 one by one, class 3 eight at a time
     uint32_t n_leg_reason[4];     // why reads left the long-read front end: 0 room/segments, 1 thinning screen, 2 anchors beyond the giant path, 3 unused
     unsigned long long arena_cursor, anchor_cursor;
-    unsigned long long cl_tot[4], cl_anchor_tot[4], cl_dbg[10], pf_dbg[8];
+    unsigned long long cl_tot[4], cl_anchor_tot[4], cl_dbg[10], pf_dbg[16];
     unsigned long long sort_tot[N_SORT_CLS + 1], sort_anchor_tot[N_SORT_CLS + 1];    // SCRUBBY_HIP_DBG & 16: reads / anchors per sort class (4 = chained inside k_expand)     // statistics of k_cluster_dp by size class (whole chunk)
     unsigned long long sh_mini[64], sh_anchors[64];     // sharded sums
     uint32_t sh_host[64], sh_clusters[64], sh_pair[64];      // sh_pair: reads decided by the pair test
@@ -1271,6 +1272,7 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
     }
     __syncthreads();
     bool pre = false;
+    if (!pf && pre_io) pre = *pre_io;      // the caller knows (k_giant_top ran par_fill_block)
     if (pf) {
         if (CONTIG && phase == 1) pre = pre_io && *pre_io;
         else {
@@ -2102,6 +2104,142 @@ __device__ inline uint32_t giant_rounds(uint32_t n)
     return r;
 }
 
+// The dirty clusters par_fill_block left (PF_DIRTY at their first anchor): the sequential DP, p turned into indices into the read's array,
+// marks cleared.  One wave per cluster; every thread of the block calls.
+template <class PX, class PQ>
+__device__ inline void fix_dirty_clusters(PX x, PQ q, int32_t *f, int32_t *pt, uint32_t n, int32_t qlen, const ChainParams &P, uint32_t tid, uint32_t nthr, const ParFillLds &L)
+{
+    const uint32_t wave = tid >> 6, n_wave = nthr >> 6, lane = tid & 63;
+    const int32_t nd = L.n_dirty;
+    for (int32_t d = (int32_t)wave; d < nd; d += (int32_t)n_wave) {
+        uint32_t c = L.dirty[d];
+        while (!((uint32_t)q[c] >> 31)) --c;
+        int32_t mine = 0;
+        if (lane == 0) mine = atomicCAS(&pt[2 * (size_t)c + 1], (int32_t)PF_DIRTY, (int32_t)PF_DEAD) == (int32_t)PF_DIRTY ? 1 : 0;
+        mine = __builtin_amdgcn_readfirstlane(mine);
+        if (!mine) continue;      // another anchor of the same cluster got there first
+        uint32_t e = c + 1;
+        while (e < n && !((uint32_t)q[e] >> 31)) ++e;
+        SliceStore S{(const uint64_t *)&x[c], (const uint32_t *)&q[c], f + c, pt + 2 * (size_t)c};
+        chain_dp_wave(S, (int)(e - c), qlen, P, lane);
+        for (uint32_t i = c + lane; i < e; i += 64) { const int32_t pv = pt[2 * (size_t)i]; if (pv >= 0) pt[2 * (size_t)i] = pv + (int32_t)c; pt[2 * (size_t)i + 1] = 0; }
+    }
+    __syncthreads();
+}
+
+// Flag-only hand-over (ChainSink::best), ahead of k_sort_lds: sort in LDS, the DP of all clusters at once (par_fill_block), then
+// mg_chain_backtrack's first candidates over the whole read (backtrack_block_top) - no cluster is visited.  A read it settles is emptied in
+// its class table, so k_sort_lds skips it; the others (many candidates at the top score; par_fill_block not applicable) are left untouched.
+// Its own kernel: inside k_sort_lds the extra code cost 80 VGPRs and half the occupancy.
+template <int NMAX, int CLS, int NTHR>
+__global__ __launch_bounds__(NTHR) void k_sort_top(K3Args a)
+{
+    __shared__ uint64_t s_x[2][NMAX];
+    __shared__ uint32_t s_q[2][NMAX];
+    __shared__ ParFillLds s_pf;
+    __shared__ long long s_top[18];
+    __shared__ uint32_t s_cf[TOPBT_MAX], s_ci[TOPBT_MAX], s_it;
+    __shared__ int32_t s_cn, s_red[2];
+    const ChainSink sink_l = a.sink; const ChainParams P_l = a.P;      // local copies: see k_giant_chain
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_items = a.ctr->n_sort[CLS];
+    unsigned long long *const dbg = (a.dbg & 16) ? a.ctr->pf_dbg : nullptr;
+    for (;;) {
+        if (tid == 0) s_it = atomicAdd(&a.ctr->top_ticket[CLS], 1u);
+        __syncthreads();
+        const uint32_t it = s_it;
+        __syncthreads();
+        if (it >= n_items) break;
+        const SortItem si = a.B.sort_items[CLS][it];
+        const uint32_t n = si.n;
+        if (n == 0) continue;
+        const int32_t qlen = (int32_t)si.qlen;
+        const uint64_t *gx = a.B.ax + si.off; const uint32_t *gq = a.B.aq + si.off;
+        for (uint32_t i = tid; i < n; i += NTHR) { s_x[0][i] = gx[i]; s_q[0][i] = gq[i]; }
+        __syncthreads();
+        const bool fl = block_merge_sort(&s_x[0][0], &s_q[0][0], &s_x[1][0], &s_q[1][0], n);
+        uint64_t *rx = fl ? s_x[1] : s_x[0]; uint32_t *rq = fl ? s_q[1] : s_q[0];
+        int32_t *f = (int32_t *)(fl ? s_q[0] : s_q[1]), *pt = (int32_t *)(fl ? s_x[0] : s_x[1]);
+        const uint32_t mdx = chain_max_dist_x(P_l, qlen);
+        uint32_t starts = 0;
+        for (uint32_t i = tid; i < n; i += NTHR) {
+            bool start = i == 0;
+            if (!start) { const uint64_t xi = rx[i], xp = rx[i - 1]; start = (uint32_t)(xi >> 32) != (uint32_t)(xp >> 32) || (uint32_t)xi - (uint32_t)xp > mdx; }
+            if (start) { rq[i] |= 0x80000000u; ++starts; }
+        }
+        __syncthreads();
+        if (!par_fill_block(rx, rq, f, pt, n, qlen, P_l, tid, NTHR, s_pf)) { if (dbg && tid == 0) atomicAdd(&dbg[1], 1ull); continue; }
+        fix_dirty_clusters(rx, rq, f, pt, n, qlen, P_l, tid, NTHR, s_pf);
+        SliceStore S{(const uint64_t *)rx, (const uint32_t *)rq, f, pt};
+        const uint32_t read = a.B.meta[si.w].r;
+        const StoreEmit<SliceStore> em{&sink_l, &S, read, 0u, tid == 0, P_l.k, region_hash(qlen), qlen, nullptr};
+        int32_t n_u = 0, best = 0;
+        const bool settled = backtrack_block_top(S, (int32_t)n, P_l, n_u, best, em, sink_l, read, tid, NTHR, s_top, s_cf, s_ci, &s_cn, (uint32_t)TOPBT_MAX, dbg);
+        if (!settled) continue;      // uniform; nothing was marked or handed over
+        store_read_result(a, si.w, tid == 0 ? n_u : 0, best, starts, s_red);
+        if (tid == 0) a.B.sort_items[CLS][it].n = 0;
+        __syncthreads();
+    }
+}
+
+// The same for the giant reads, after their sort and ahead of k_giant_chain (anchors and DP state in the arena).  Also without
+// ChainSink::best (trace mode) it runs par_fill_block, so that k_giant_chain and k_cluster_dp only have the backtracks left: the read's
+// table entry then carries the mark (qlen bit 31).
+__global__ __launch_bounds__(512) void k_giant_top(K3Args a)
+{
+    __shared__ ParFillLds s_pf;
+    __shared__ PfTile s_tile;
+    __shared__ long long s_top[18];
+    __shared__ uint32_t s_cf[TOPBT_MAX], s_ci[TOPBT_MAX], s_it;
+    __shared__ int32_t s_cn, s_red[2];
+    const ChainSink sink_l = a.sink; const ChainParams P_l = a.P;
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    const uint32_t n_items = a.ctr->n_sort[SORT_CLS_GIANT];
+    unsigned long long *const dbg = (a.dbg & 16) ? a.ctr->pf_dbg : nullptr;
+    const bool top = a.emit && sink_l.best != nullptr && !(a.dbg & 512);
+    for (;;) {
+        if (tid == 0) s_it = atomicAdd(&a.ctr->top_ticket[SORT_CLS_GIANT], 1u);
+        __syncthreads();
+        const uint32_t it = s_it;
+        __syncthreads();
+        if (it >= n_items) break;
+        const uint32_t slot = a.B.giant_order[it];
+        const SortItem si = a.B.sort_items[SORT_CLS_GIANT][slot];
+        const uint32_t n = si.n;
+        if (n == 0) continue;
+        const int32_t qlen = (int32_t)si.qlen;
+        const bool in_b = giant_rounds(n) & 1;
+        uint64_t *x = (in_b ? a.B.bx : a.B.ax) + si.off; uint32_t *q = (in_b ? a.B.bq : a.B.aq) + si.off;
+        int32_t *f = a.B.af + si.off, *pt = (int32_t *)(a.B.az + si.off);
+        const uint32_t mdx = chain_max_dist_x(P_l, qlen);
+        uint32_t starts = 0;
+        for (uint32_t i = tid; i < n; i += nthr) {
+            bool start = i == 0;
+            if (!start) { const uint64_t xi = x[i], xp = x[i - 1]; start = (uint32_t)(xi >> 32) != (uint32_t)(xp >> 32) || (uint32_t)xi - (uint32_t)xp > mdx; }
+            if (start) { q[i] |= 0x80000000u; ++starts; }
+        }
+        __syncthreads();
+        const bool pre = par_fill_tiled(x, q, f, pt, n, qlen, P_l, tid, nthr, s_pf, s_tile);
+        if (dbg && tid == 0) { atomicAdd(&dbg[pre ? 0 : 1], 1ull); atomicAdd(&dbg[2], (unsigned long long)s_pf.n_dirty); atomicAdd(&dbg[pre ? 3 : 4], (unsigned long long)n); }
+        if (!pre) continue;
+        bool settled = false;
+        if (top) {
+            fix_dirty_clusters(x, q, f, pt, n, qlen, P_l, tid, nthr, s_pf);
+            SliceStore S{(const uint64_t *)x, (const uint32_t *)q, f, pt};
+            const uint32_t read = a.B.meta[si.w].r;
+            const StoreEmit<SliceStore> em{&sink_l, &S, read, 0u, tid == 0, P_l.k, region_hash(qlen), qlen, nullptr};
+            int32_t n_u = 0, best = 0;
+            settled = backtrack_block_top(S, (int32_t)n, P_l, n_u, best, em, sink_l, read, tid, nthr, s_top, s_cf, s_ci, &s_cn, (uint32_t)TOPBT_MAX, dbg);
+            if (settled) store_read_result(a, si.w, tid == 0 ? n_u : 0, best, starts, s_red);
+        }
+        if (tid == 0) {
+            if (settled) a.B.sort_items[SORT_CLS_GIANT][slot].n = 0;                        // nothing left for k_giant_chain or k_cluster_dp
+            else a.B.sort_items[SORT_CLS_GIANT][slot].qlen = si.qlen | 0x80000000u;         // DP done: backtracks only
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_giant_scan(K3Args a)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63, n_items = a.ctr->n_sort[SORT_CLS_GIANT];
@@ -2239,8 +2377,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 {
     __shared__ int32_t s_found, s_red[2], s_bcount;
     __shared__ uint32_t s_bstart[2048], s_blen[2048], s_nxt[1024];
-    __shared__ ParFillLds s_pf;
-    const bool use_pf = (a.emit || !a.flag_only) && !(a.dbg & 128);
     // local copies: a pointer or reference INTO the argument struct makes the compiler copy all ~640 B of it to scratch at entry and read
     // every a.X from there afterwards
     const ChainSink sink_l = a.sink; const ChainParams P_l = a.P;
@@ -2256,7 +2392,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         SortItem si = a.B.sort_items[SORT_CLS_GIANT][a.B.giant_order[it]];
         const uint32_t n = si.n;
         if (n == 0) continue;                 // decided by k_group_probe
-        bool pre = (si.qlen >> 31) != 0;      // phase 1: what phase 0's par_fill_block said
+        bool pre = (si.qlen >> 31) != 0;      // k_giant_top's par_fill_block applied: f, p and the dirty marks are there
         si.qlen &= 0x7fffffffu;
         const bool in_b = giant_rounds(n) & 1;
         uint64_t *sx = (in_b ? a.B.bx : a.B.ax) + si.off; uint32_t *sq = (in_b ? a.B.bq : a.B.aq) + si.off;
@@ -2268,8 +2404,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         chain_sorted<true>(sx, sq, a.B.af + si.off, (int32_t *)(a.B.az + si.off), n, tid, nthr, (int32_t)si.qlen, P_l,
                      a.flag_only ? &s_found : nullptr, BigList{s_bstart, s_blen, &s_bcount, 2048}, n_u, best, n_cl, &gq, s_nxt,
                      a.emit ? &sink_l : nullptr, a.B.meta[si.w].r, a.emit ? (in_b ? a.B.ax : a.B.bx) + si.off : nullptr,      // heap: the sort's other buffer
-                     nullptr, 0u, phase, TandemQ{nullptr, 0u, 1u, 0, 0u}, use_pf ? &s_pf : nullptr, &pre, (a.dbg & 16) ? a.ctr->pf_dbg : nullptr);
-        if (phase == 0 && pre && tid == 0) a.B.sort_items[SORT_CLS_GIANT][a.B.giant_order[it]].qlen = si.qlen | 0x80000000u;
+                     nullptr, 0u, phase, TandemQ{nullptr, 0u, 1u, 0, 0u}, nullptr, &pre);
         store_read_result(a, si.w, n_u, best, n_cl, s_red, phase == 1);
         __syncthreads();
     }
@@ -3115,6 +3250,16 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
         hipLaunchKernelGGL(k_group_probe, dim3(256 * 3), dim3(256), 0, s, k, 4);
         hipLaunchKernelGGL(k_group_probe, dim3(256 * 3), dim3(256), 0, s, k, (int)SORT_CLS_GIANT);
     }
+    const bool use_pf = (k.emit || !k.flag_only) && !(k.dbg & 128);
+    const bool use_top = use_pf && k.emit && k.sink.best != nullptr && !(k.dbg & 512);
+    if (use_pf) SH_HIP(hipMemsetAsync(&ctr->top_ticket[0], 0, 4 * N_SORT_CLS, s));
+    if (use_top) {
+        hipLaunchKernelGGL((k_sort_top<256, 0, 64>), dim3(grid * 2), dim3(64), 0, s, k);
+        hipLaunchKernelGGL((k_sort_top<SORT_LDS_A, 1, 128>), dim3(grid * 2), dim3(128), 0, s, k);
+        hipLaunchKernelGGL((k_sort_top<1024, 2, 256>), dim3(256 * 6), dim3(256), 0, s, k);
+        hipLaunchKernelGGL((k_sort_top<SORT_LDS_B, 3, 256>), dim3(256 * 3), dim3(256), 0, s, k);
+        hipLaunchKernelGGL((k_sort_top<SORT_LDS_C, 4, 512>), dim3(256), dim3(512), 0, s, k);
+    }
     hipLaunchKernelGGL((k_sort_lds<256, 0, 64>), dim3(grid * 2), dim3(64), 0, s, k);
     hipLaunchKernelGGL((k_sort_lds<SORT_LDS_A, 1, 128>), dim3(grid * 2), dim3(128), 0, s, k);
     hipLaunchKernelGGL((k_sort_lds<1024, 2, 256>), dim3(256 * 6), dim3(256), 0, s0, k);
@@ -3128,6 +3273,7 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     }
     // flag-only hand-over (t_mode): the big clusters first (k_cluster_dp), then the small ones against the best score those gave
     const bool two_phase = k.t_mode && k.sink.best != nullptr;
+    if (use_pf) hipLaunchKernelGGL(k_giant_top, dim3(1024), dim3(512), 0, g, k);
     hipLaunchKernelGGL(k_giant_chain, dim3(1024), dim3(512), 0, g, k, two_phase ? 0 : -1);
     if (!(k.dbg & 32)) hipLaunchKernelGGL(k_cluster_dp, dim3(256 * 7), dim3(256), 0, g, k);      // 72 VGPRs: 7 waves per SIMD (4: 74 ms, 6: 60, 8 with spills: 57)
     if (two_phase) {
@@ -3238,6 +3384,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     k.sink = b.sink; k.emit = c->ext ? 1 : 0; k.BC = b.BC; k.t_mode = (c->ext && !c->ext_long && d_trace == nullptr) ? 1 : 0;
     k.dbg = getenv("SCRUBBY_HIP_DBG") ? atoi(getenv("SCRUBBY_HIP_DBG")) : 0;
     if (getenv("SCRUBBY_HIP_NO_PARFILL")) k.dbg |= 128;      // A/B: every cluster chained by the sequential DP
+    if (getenv("SCRUBBY_HIP_NO_TOPBT")) k.dbg |= 512;        // A/B: clusters visited one by one even when the read's DP is done
     k.resketch_list = c->d_work_resketch;
     uint32_t resk_done = 0;
     // pass 0 (mid_occ) over the reads K2 routed, pass 1 (max_occ) over the reads pass 0 could not chain;
@@ -3291,7 +3438,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
             if (k.dbg & 16) fprintf(stderr, "[dbg] reads (anchors) by sort class: <=64 %llu (%llu), <=256 %llu (%llu), <=512 %llu (%llu), <=1024 %llu (%llu), <=2048 %llu (%llu), <=4096 %llu (%llu), giant %llu (%llu)\n", c->h_ctr->sort_tot[6], c->h_ctr->sort_anchor_tot[6], c->h_ctr->sort_tot[0], c->h_ctr->sort_anchor_tot[0], c->h_ctr->sort_tot[1], c->h_ctr->sort_anchor_tot[1], c->h_ctr->sort_tot[2], c->h_ctr->sort_anchor_tot[2], c->h_ctr->sort_tot[3], c->h_ctr->sort_anchor_tot[3], c->h_ctr->sort_tot[4], c->h_ctr->sort_anchor_tot[4], c->h_ctr->sort_tot[5], c->h_ctr->sort_anchor_tot[5]);
             if (k.dbg & 16) fprintf(stderr, "[dbg] local-cluster shortcut: tried %u, no singleton / filtered %u, singletons apart %u, window %u, K size %u, no margin %u, decided %u\n", c->h_ctr->ext_s3[0], c->h_ctr->ext_s3[1], c->h_ctr->ext_s3[2], c->h_ctr->ext_s3[3], c->h_ctr->ext_s3[4], c->h_ctr->ext_s3[5], c->h_ctr->ext_s3[7]);
             if (k.dbg & 16) fprintf(stderr, "[dbg] ring DP: chunks in window %llu, beyond %llu, far rescans %llu; clusters %llu (anchors %llu), with a max_skip break %llu (anchors %llu), widest window %llu, anchors of clusters with a window > 64: %llu, > 128: %llu\n", c->h_ctr->cl_dbg[0], c->h_ctr->cl_dbg[1], c->h_ctr->cl_dbg[2], c->h_ctr->cl_dbg[3], c->h_ctr->cl_dbg[6], c->h_ctr->cl_dbg[4], c->h_ctr->cl_dbg[5], c->h_ctr->cl_dbg[7], c->h_ctr->cl_dbg[8], c->h_ctr->cl_dbg[9]);
-            if (k.dbg & 16) fprintf(stderr, "[dbg] parallel fill: reads done %llu (anchors %llu), not applicable %llu (anchors %llu), dirty anchors %llu; k_cluster_dp clusters prefilled %llu, sequential %llu (anchors %llu)\n", c->h_ctr->pf_dbg[0], c->h_ctr->pf_dbg[3], c->h_ctr->pf_dbg[1], c->h_ctr->pf_dbg[4], c->h_ctr->pf_dbg[2], c->h_ctr->pf_dbg[5], c->h_ctr->pf_dbg[6], c->h_ctr->pf_dbg[7]);
+            if (k.dbg & 16) fprintf(stderr, "[dbg] parallel fill: reads done %llu (anchors %llu), not applicable %llu (anchors %llu), dirty anchors %llu; k_cluster_dp clusters prefilled %llu, sequential %llu (anchors %llu); read-level backtracks tried %llu, candidates listed %llu, given up (too many) %llu, chains visited %llu\n", c->h_ctr->pf_dbg[0], c->h_ctr->pf_dbg[3], c->h_ctr->pf_dbg[1], c->h_ctr->pf_dbg[4], c->h_ctr->pf_dbg[2], c->h_ctr->pf_dbg[5], c->h_ctr->pf_dbg[6], c->h_ctr->pf_dbg[7], c->h_ctr->pf_dbg[8], c->h_ctr->pf_dbg[11], c->h_ctr->pf_dbg[12], c->h_ctr->pf_dbg[10]);
             resk_done = c->h_ctr->n_resketch;
             const uint32_t d0 = c->h_ctr->n_big_defer[0], d1 = c->h_ctr->n_big_defer[1];
             if (d0 == 0 && d1 == 0) break;
