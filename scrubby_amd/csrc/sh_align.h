@@ -685,7 +685,7 @@ __device__ inline void update_extra0(REG &r, uint32_t *c, int32_t &n_cigar, cons
 // settled here (a tie in z, a stretch the test cannot vouch for): the read goes through the full procedure with all its chains.
 struct MidReq;
 template <class MID>
-__device__ inline int32_t top_chain_settles(const AlignIn &in, const AlignParams &P, uint32_t read, unsigned long long best, uint32_t tie, MID &mid)
+__device__ inline int32_t top_chain_settles(const AlignIn &in, const AlignParams &P, uint32_t read, unsigned long long best, uint32_t tie, MID &mid, uint32_t *h_out = nullptr)
 {
     // returns 1 settled, 2 settled if the stretch described in `mid` shows no z-drop on the bases (the caller's wave checks:
     // middle_no_zdrop_wave), or minus the reason it is not: -1 tie / off, -2 record missing, -3 stretch too short, -4 z-drop in the stretch
@@ -693,6 +693,7 @@ __device__ inline int32_t top_chain_settles(const AlignIn &in, const AlignParams
     uint32_t h = in.head[read];
     while (h != ~0u && in.recs[h].z != best) h = in.recs[h].next;
     if (h == ~0u) return -2;
+    if (h_out) *h_out = h;
     const ChainRec rc = in.recs[h];
     int32_t run_score = P.k, run_unc = 0, best_score = -1, best_unc = 0;
     uint32_t xp = (uint32_t)in.cx[rc.off], qp = in.cq[rc.off], run_first = 0, run_last = 0, b_first = 0, b_last = 0;
@@ -728,7 +729,7 @@ __device__ inline bool align_read_wave(const AlignIn &in, const AlignParams &P, 
     // ---- the read's chains (a linked list, newest first; every lane walks it)
     int32_t n_u = 0;
     uint32_t h_top = ~0u;
-    for (uint32_t h = in.head[read]; h != ~0u; h = in.recs[h].next) { ++n_u; if (top_z != 0 && in.recs[h].z == top_z) h_top = h; }
+    for (uint32_t h = in.head[read]; h != ~0u; h = in.recs[h].next) { ++n_u; if (top_z != 0 && in.recs[h].z == top_z) { h_top = h; break; } }      // (a tandem-array read has hundreds of records: each step is a round trip to HBM)
     if (n_u == 0) return true;
     if (top_z != 0) { if (h_top == ~0u) return true; n_u = 1; }
     if ((uint32_t)n_u > A.reg_cap) { if (lane == 0) atomicExch(overflow, 2u); return false; }

@@ -2168,7 +2168,9 @@ __global__ __launch_bounds__(NTHR) void k_sort_top(K3Args a)
             if (start) { rq[i] |= 0x80000000u; ++starts; }
         }
         __syncthreads();
+        if (a.dbg & 1024) continue;
         if (!par_fill_block(rx, rq, f, pt, n, qlen, P_l, tid, NTHR, s_pf)) { if (dbg && tid == 0) atomicAdd(&dbg[1], 1ull); continue; }
+        if (a.dbg & 2048) continue;
         fix_dirty_clusters(rx, rq, f, pt, n, qlen, P_l, tid, NTHR, s_pf);
         SliceStore S{(const uint64_t *)rx, (const uint32_t *)rq, f, pt};
         const uint32_t read = a.B.meta[si.w].r;
@@ -2652,9 +2654,10 @@ __global__ __launch_bounds__(64) void k_ext_top(ExtArgs a)
         uint32_t r = 0;
         int32_t rc = 0;
         MidReq mid{0, 0, 0, 0, 0};
+        uint32_t h_top = ~0u;
         if (t < n_list) {
             r = a.list[t];
-            rc = top_chain_settles(a.in, a.P, r, a.best[r], a.tie[r], mid);
+            rc = top_chain_settles(a.in, a.P, r, a.best[r], a.tie[r], mid, &h_top);
         }
         {   // rc == 2: the stretch's k-mers leave too many bases uncovered - mm_test_zdrop on the bases, the wave on one lane's request at a time
             ChainParams cp{}; cp.ext_a = a.P.a < 0 ? -a.P.a : a.P.a; cp.ext_b = a.P.b > 0 ? -a.P.b : a.P.b; cp.ext_amb = a.P.sc_ambi > 0 ? -a.P.sc_ambi : a.P.sc_ambi; cp.ext_zdrop = a.P.zdrop;
@@ -2665,7 +2668,11 @@ __global__ __launch_bounds__(64) void k_ext_top(ExtArgs a)
         }
         if (t < n_list) {
             if (rc > 0) a.flags[r] = 1;
-            else { redo = true; atomicAdd(&a.ctr->ext_reason[-rc & 7], 1u); }
+            else {
+                redo = true; atomicAdd(&a.ctr->ext_reason[-rc & 7], 1u);
+                // k_regs_align (top_only) wants this record alone: the list now starts there (a read it does not settle starts over with an empty list)
+                if (h_top != ~0u) const_cast<uint32_t *>(a.in.head)[r] = h_top;
+            }
         }
         const uint32_t li = wave_append(&a.ctr->ext_n_redo, redo);
         if (redo) a.redo[li] = r;
