@@ -2168,9 +2168,7 @@ __global__ __launch_bounds__(NTHR) void k_sort_top(K3Args a)
             if (start) { rq[i] |= 0x80000000u; ++starts; }
         }
         __syncthreads();
-        if (a.dbg & 1024) continue;
         if (!par_fill_block(rx, rq, f, pt, n, qlen, P_l, tid, NTHR, s_pf)) { if (dbg && tid == 0) atomicAdd(&dbg[1], 1ull); continue; }
-        if (a.dbg & 2048) continue;
         fix_dirty_clusters(rx, rq, f, pt, n, qlen, P_l, tid, NTHR, s_pf);
         SliceStore S{(const uint64_t *)rx, (const uint32_t *)rq, f, pt};
         const uint32_t read = a.B.meta[si.w].r;
