@@ -43,6 +43,7 @@ CHM13_CONTIGS = [248387328, 242696752, 201105948, 193574945, 182045439, 17212662
                  150617247, 134758134, 135127769, 133324548, 113566686, 101161492, 99753195, 96330374,
                  84276897, 80542538, 61707364, 66210255, 45090682, 51324926, 154259566, 62460029, 16569]
 REF_SEED, READ_SEED = 0x5C2B0010, 0x5C2B0011
+REPEAT_STAGE = "repeat path (k_local_cluster, k_expand, k_sort_top / k_sort_lds classes, k_giant_*, k_cluster_dp, k_finalize)"
 HBM_PEAK_GBS = 8000.0
 
 
@@ -278,7 +279,7 @@ def main_reads(a, rank, world, local, dev, backend):
     k3_bytes = 16 * 20 * s0["n_chain_large"] + 8 * s0["n_anchors"]
     stages = {
         "k_sketch_probe": (k1_ms, k1_bytes), "k_chain_small": (k2_ms, k2_bytes),
-        "repeat path (k_expand + k_sort_lds* + k_sort + k_finalize)": (k3_ms, k3_bytes),
+        REPEAT_STAGE: (k3_ms, k3_bytes),
     }
     ext_ms = float(np.mean([s.get("ms_ext", 0.0) for s in stats]))
     if ext_ms > 0:      # SH_F_CIGAR: list building + base-level alignment of the reads no shortcut settles (reads + their reference windows + 40-B chain records)

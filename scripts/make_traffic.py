@@ -24,10 +24,11 @@ def source_hash(workload="sr"):
     return h.hexdigest()
 
 
-STAGES = {      # bench.py's stage names -> kernel name prefixes
+STAGES = {      # bench.py's stage names -> kernel name prefixes; a kernel belongs to the FIRST stage one of whose prefixes it carries
+    "extension stage (k_long_chains + k_regs_align_long)": ("k_lext_", "k_long_chains", "k_regs_align_long"),
     "k_sketch_probe": ("k_sketch_probe", "k_long_"),      # long reads: the segment-parallel front end stands where K1 does
     "k_chain_small": ("k_chain_small", "k_pair_pass"),
-    "repeat path (k_expand + k_sort_lds* + k_sort + k_finalize)": ("k_local_cluster", "k_expand", "k_group_probe", "k_sort_lds", "k_giant", "k_cluster_dp", "k_finalize", "k_chain_large"),
+    "repeat path (k_local_cluster, k_expand, k_sort_top / k_sort_lds classes, k_giant_*, k_cluster_dp, k_finalize)": ("k_local_cluster", "k_expand", "k_group_probe", "k_sort_", "k_giant", "k_cluster_dp", "k_finalize", "k_chain_large"),
     "extension stage (k_ext_* + k_regs_align)": ("k_ext_", "k_regs_align"),
     "k_k2_classify": ("k_k2_classify",),
 }
@@ -45,6 +46,7 @@ def collect(d, counter):
             if any(p in name for p in pats):
                 acc[st] += float(r["Counter_Value"]) * 1024.0
                 kern[name.split("(")[0].replace("void ", "")[:40]] += float(r["Counter_Value"]) * 1024.0
+                break
     return acc, kern
 
 

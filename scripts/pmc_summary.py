@@ -1,6 +1,7 @@
 """Sum rocprofv3 --pmc counter_collection.csv rows per kernel (classification kernels only)."""
 import csv, glob, sys, collections
-keep = ("k_sketch_probe", "k_chain_small", "k_expand", "k_sort", "k_finalize", "k_giant", "k_chain_large")
+keep = ("k_sketch_probe", "k_chain_small", "k_pair_pass", "k_local_cluster", "k_expand", "k_sort", "k_finalize", "k_giant", "k_cluster_dp", "k_chain_large",
+        "k_ext_", "k_regs_align", "k_long_", "k_lext_", "k_k2_")
 for d in sys.argv[1:]:
     fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
     if not fs:
