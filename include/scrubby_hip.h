@@ -127,6 +127,9 @@ typedef struct sh_stats {
     uint64_t n_ext_unresolved; /* long-read presets: reads beyond the stage's largest working memory, left at their chain-level answer (see the warning) */
     uint64_t n_rmq_rechained;  /* long-read presets: reads re-chained by the RMQ long join */
     uint64_t n_rmq_tied;       /* ... of which met two candidates of equal priority in the join (the smaller index was taken) */
+    uint64_t n_dp_parallel;    /* repeat-path reads whose mg_lchain_dp ran as the parallel recurrence */
+    uint64_t n_dp_dirty;       /* ... their anchors that broke its premise (their clusters were chained by the sequential code) */
+    uint64_t n_top_settled;    /* ... reads whose candidates for regs[0] were read off the whole read, no cluster visited */
 } sh_stats;
 
 typedef struct sh_index sh_index;

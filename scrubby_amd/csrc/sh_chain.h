@@ -1231,7 +1231,7 @@ __device__ inline void backtrack_wave_top(SliceStore &S, int32_t n, const ChainP
 template <class EM>
 __device__ inline bool backtrack_block_top(SliceStore &S, int32_t n, const ChainParams &P, int32_t &n_u, int32_t &best, const EM &em, const ChainSink &sk, uint32_t read,
                                            uint32_t tid, uint32_t nthr, long long *s_red, uint32_t *cand_f, uint32_t *cand_i, int32_t *cand_n, uint32_t cap, unsigned long long *dbg = nullptr)
-{
+{   // cap <= TOPBT_MAX <= 64: the list is one entry per lane of wave 0
     n_u = 0; best = 0;
     const uint32_t lane = tid & 63, wave = tid >> 6, n_wave = nthr >> 6;
     long long key = -1;
@@ -1267,12 +1267,12 @@ __device__ inline bool backtrack_block_top(SliceStore &S, int32_t n, const Chain
         const int32_t f = S.f[i];
         if (f < thr) continue;
         const int32_t slot = atomicAdd(cand_n, 1);
-        if ((uint32_t)slot < cap && slot < TOPBT_MAX) { cand_f[slot] = (uint32_t)f; cand_i[slot] = (uint32_t)i; }
+        if ((uint32_t)slot < cap) { cand_f[slot] = (uint32_t)f; cand_i[slot] = (uint32_t)i; }
     }
     __syncthreads();
     const int32_t nc = *cand_n;
-    if (dbg && tid == 0) { atomicAdd(&dbg[8], 1ull); atomicAdd(&dbg[11], (unsigned long long)nc); if ((uint32_t)nc > cap || nc > TOPBT_MAX) atomicAdd(&dbg[12], 1ull); }
-    if ((uint32_t)nc > cap || nc > TOPBT_MAX) return false;
+    if (dbg && tid == 0) { atomicAdd(&dbg[8], 1ull); atomicAdd(&dbg[11], (unsigned long long)nc); if ((uint32_t)nc > cap) atomicAdd(&dbg[12], 1ull); }
+    if ((uint32_t)nc > cap) return false;
     if (wave == 0) {
         long long bound = 1ll << 62;
         int64_t n_v = 0;

@@ -83,6 +83,7 @@ struct Counters {
     unsigned long long sort_tot[N_SORT_CLS + 1], sort_anchor_tot[N_SORT_CLS + 1];    // SCRUBBY_HIP_DBG & 16: reads / anchors per sort class (4 = chained inside k_expand)     // statistics of k_cluster_dp by size class (whole chunk)
     unsigned long long sh_mini[64], sh_anchors[64];     // sharded sums
     uint32_t sh_host[64], sh_clusters[64], sh_pair[64];      // sh_pair: reads decided by the pair test
+    uint32_t sh_pf_reads[64], sh_pf_dirty[64], sh_top[64];   // reads chained by par_fill_block / _tiled, their dirty anchors, reads settled by backtrack_block_top
     uint32_t sh_lemma[64];       // SH_F_CIGAR flag-only: reads decided inside a chaining kernel (top chain + chain_lemma)
 };
 #define SHARD() ((blockIdx.x + (blockIdx.x >> 6)) & 63)
@@ -1251,7 +1252,7 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
                                     int32_t &n_u_thr, int32_t &best_thr, uint32_t &n_cl_thr, const GlobalQ *gq = nullptr,
                                     uint32_t *nxt = nullptr, const ChainSink *sk = nullptr, uint32_t read = 0, uint64_t *heap = nullptr,
                                     BestChain *bc = nullptr, uint32_t rhash = 0, int phase = -1, TandemQ tq = TandemQ{nullptr, 0u, 1u, 0, 0u},
-                                    ParFillLds *pf = nullptr, bool *pre_io = nullptr, unsigned long long *pf_dbg = nullptr)
+                                    ParFillLds *pf = nullptr, bool *pre_io = nullptr, unsigned long long *pf_dbg = nullptr, uint32_t *pf_cnt = nullptr)
 {   // pf: the DP of all clusters at once (par_fill_block) before any cluster is visited; *pre_io: whether it applied (out; in for CONTIG phase 1,
     // whose f / p / dirty marks are phase 0's)   // phase (flag-only hand-over, where a cluster that cannot beat the best score found so far is skipped): the BIG clusters first -
     //   CONTIG: 0 = only clusters of more than 64 anchors (queued for k_cluster_dp), 1 = only the others, afterwards; -1 = all at once
@@ -1277,6 +1278,7 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
         if (CONTIG && phase == 1) pre = pre_io && *pre_io;
         else {
             pre = par_fill_block(x, q, f, pt, n, qlen, P, tid, nthr, *pf); if (pre_io) *pre_io = pre;
+            if (pf_cnt && pre && tid == 0) { atomicAdd(&pf_cnt[SHARD()], 1u); if (pf->n_dirty) atomicAdd(&pf_cnt[64 + SHARD()], (uint32_t)pf->n_dirty); }
             if (pf_dbg && tid == 0) { atomicAdd(&pf_dbg[pre ? 0 : 1], 1ull); atomicAdd(&pf_dbg[2], (unsigned long long)pf->n_dirty); atomicAdd(&pf_dbg[pre ? 3 : 4], (unsigned long long)n); }
         }
     }
@@ -1479,6 +1481,7 @@ struct K3Args {
     BaseCtx BC;
     int32_t t_mode;                    // SH_F_CIGAR and no trace wanted: only regs[0] matters, shortcuts allowed
     int32_t quiet;                     // a second visit of reads that were counted already: no statistics
+    int32_t top_max;                   // backtrack_block_top: candidates a read may have at its top score (<= TOPBT_MAX; SCRUBBY_HIP_TOPBT_MAX, tests)
 };
 
 
@@ -2080,7 +2083,8 @@ __global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
         chain_sorted<false>(rx, rq, f, pt, n, tid, NTHR, (int32_t)si.qlen, a.P, a.flag_only ? &s_found : nullptr,
                             BigList{s_bstart, s_blen, &s_bcount, NMAX / 7 + 1}, n_u, best, n_cl, nullptr, nullptr,
                             a.emit ? &a.sink : nullptr, a.B.meta[si.w].r, a.emit ? a.B.hz + si.off : nullptr,
-                            nullptr, 0u, -1, TandemQ{nullptr, 0u, 1u, 0, 0u}, use_pf ? &s_pf : nullptr, nullptr, (a.dbg & 16) ? a.ctr->pf_dbg : nullptr);
+                            nullptr, 0u, -1, TandemQ{nullptr, 0u, 1u, 0, 0u}, use_pf ? &s_pf : nullptr, nullptr, (a.dbg & 16) ? a.ctr->pf_dbg : nullptr,
+                            (a.quiet || (a.emit && a.sink.best && !(a.dbg & 512))) ? nullptr : a.ctr->sh_pf_reads);      // with ChainSink::best k_sort_top counted the read
         store_read_result(a, si.w, n_u, best, n_cl, s_red);
         __syncthreads();
     }
@@ -2169,15 +2173,16 @@ __global__ __launch_bounds__(NTHR) void k_sort_top(K3Args a)
         }
         __syncthreads();
         if (!par_fill_block(rx, rq, f, pt, n, qlen, P_l, tid, NTHR, s_pf)) { if (dbg && tid == 0) atomicAdd(&dbg[1], 1ull); continue; }
+        if (tid == 0 && !a.quiet) { atomicAdd(&a.ctr->sh_pf_reads[SHARD()], 1u); if (s_pf.n_dirty) atomicAdd(&a.ctr->sh_pf_dirty[SHARD()], (uint32_t)s_pf.n_dirty); }
         fix_dirty_clusters(rx, rq, f, pt, n, qlen, P_l, tid, NTHR, s_pf);
         SliceStore S{(const uint64_t *)rx, (const uint32_t *)rq, f, pt};
         const uint32_t read = a.B.meta[si.w].r;
         const StoreEmit<SliceStore> em{&sink_l, &S, read, 0u, tid == 0, P_l.k, region_hash(qlen), qlen, nullptr};
         int32_t n_u = 0, best = 0;
-        const bool settled = backtrack_block_top(S, (int32_t)n, P_l, n_u, best, em, sink_l, read, tid, NTHR, s_top, s_cf, s_ci, &s_cn, (uint32_t)TOPBT_MAX, dbg);
+        const bool settled = backtrack_block_top(S, (int32_t)n, P_l, n_u, best, em, sink_l, read, tid, NTHR, s_top, s_cf, s_ci, &s_cn, (uint32_t)a.top_max, dbg);
         if (!settled) continue;      // uniform; nothing was marked or handed over
         store_read_result(a, si.w, tid == 0 ? n_u : 0, best, starts, s_red);
-        if (tid == 0) a.B.sort_items[CLS][it].n = 0;
+        if (tid == 0) { a.B.sort_items[CLS][it].n = 0; if (!a.quiet) atomicAdd(&a.ctr->sh_top[SHARD()], 1u); }
         __syncthreads();
     }
 }
@@ -2222,6 +2227,7 @@ __global__ __launch_bounds__(512) void k_giant_top(K3Args a)
         const bool pre = par_fill_tiled(x, q, f, pt, n, qlen, P_l, tid, nthr, s_pf, s_tile);
         if (dbg && tid == 0) { atomicAdd(&dbg[pre ? 0 : 1], 1ull); atomicAdd(&dbg[2], (unsigned long long)s_pf.n_dirty); atomicAdd(&dbg[pre ? 3 : 4], (unsigned long long)n); }
         if (!pre) continue;
+        if (tid == 0 && !a.quiet) { atomicAdd(&a.ctr->sh_pf_reads[SHARD()], 1u); if (s_pf.n_dirty) atomicAdd(&a.ctr->sh_pf_dirty[SHARD()], (uint32_t)s_pf.n_dirty); }
         bool settled = false;
         if (top) {
             fix_dirty_clusters(x, q, f, pt, n, qlen, P_l, tid, nthr, s_pf);
@@ -2229,11 +2235,11 @@ __global__ __launch_bounds__(512) void k_giant_top(K3Args a)
             const uint32_t read = a.B.meta[si.w].r;
             const StoreEmit<SliceStore> em{&sink_l, &S, read, 0u, tid == 0, P_l.k, region_hash(qlen), qlen, nullptr};
             int32_t n_u = 0, best = 0;
-            settled = backtrack_block_top(S, (int32_t)n, P_l, n_u, best, em, sink_l, read, tid, nthr, s_top, s_cf, s_ci, &s_cn, (uint32_t)TOPBT_MAX, dbg);
+            settled = backtrack_block_top(S, (int32_t)n, P_l, n_u, best, em, sink_l, read, tid, nthr, s_top, s_cf, s_ci, &s_cn, (uint32_t)a.top_max, dbg);
             if (settled) store_read_result(a, si.w, tid == 0 ? n_u : 0, best, starts, s_red);
         }
         if (tid == 0) {
-            if (settled) a.B.sort_items[SORT_CLS_GIANT][slot].n = 0;                        // nothing left for k_giant_chain or k_cluster_dp
+            if (settled) { a.B.sort_items[SORT_CLS_GIANT][slot].n = 0; if (!a.quiet) atomicAdd(&a.ctr->sh_top[SHARD()], 1u); }      // nothing left for k_giant_chain or k_cluster_dp
             else a.B.sort_items[SORT_CLS_GIANT][slot].qlen = si.qlen | 0x80000000u;         // DP done: backtracks only
         }
         __syncthreads();
@@ -3389,6 +3395,8 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     k.sink = b.sink; k.emit = c->ext ? 1 : 0; k.BC = b.BC; k.t_mode = (c->ext && !c->ext_long && d_trace == nullptr) ? 1 : 0;
     k.dbg = getenv("SCRUBBY_HIP_DBG") ? atoi(getenv("SCRUBBY_HIP_DBG")) : 0;
     if (getenv("SCRUBBY_HIP_NO_PARFILL")) k.dbg |= 128;      // A/B: every cluster chained by the sequential DP
+    k.top_max = TOPBT_MAX;
+    if (const char *env = getenv("SCRUBBY_HIP_TOPBT_MAX")) k.top_max = std::max(1, std::min(TOPBT_MAX, atoi(env)));
     if (getenv("SCRUBBY_HIP_NO_TOPBT")) k.dbg |= 512;        // A/B: clusters visited one by one even when the read's DP is done
     k.resketch_list = c->d_work_resketch;
     uint32_t resk_done = 0;
@@ -3676,10 +3684,10 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         float t01 = 0, t12 = 0, t23 = 0, t04 = 0;
         hipEventElapsedTime(&t01, c->ev[0], c->ev[1]); hipEventElapsedTime(&t12, c->ev[1], c->ev[2]);
         hipEventElapsedTime(&t23, c->ev[1], c->ev[3]); hipEventElapsedTime(&t04, c->ev[0], c->ev[4]);
-        uint64_t sum_host = 0, sum_mini = 0, sum_anchors = 0, sum_clusters = 0, sum_pair = 0, sum_lemma = 0;
+        uint64_t sum_host = 0, sum_mini = 0, sum_anchors = 0, sum_clusters = 0, sum_pair = 0, sum_lemma = 0, sum_pf = 0, sum_pfd = 0, sum_top = 0;
         for (int i = 0; i < 64; ++i) sum_lemma += c->h_ctr->sh_lemma[i];
         stats->n_ext_shortcut += sum_lemma;
-        for (int i = 0; i < 64; ++i) { sum_host += c->h_ctr->sh_host[i]; sum_mini += c->h_ctr->sh_mini[i]; sum_anchors += c->h_ctr->sh_anchors[i]; sum_clusters += c->h_ctr->sh_clusters[i]; sum_pair += c->h_ctr->sh_pair[i]; }
+        for (int i = 0; i < 64; ++i) { sum_host += c->h_ctr->sh_host[i]; sum_mini += c->h_ctr->sh_mini[i]; sum_anchors += c->h_ctr->sh_anchors[i]; sum_clusters += c->h_ctr->sh_clusters[i]; sum_pair += c->h_ctr->sh_pair[i]; sum_pf += c->h_ctr->sh_pf_reads[i]; sum_pfd += c->h_ctr->sh_pf_dirty[i]; sum_top += c->h_ctr->sh_top[i]; }
         stats->n_reads += n_reads; stats->n_bases += n_bases;
         stats->n_host += sum_host - ext_dropped;
         stats->n_ext_reads += ext_list; stats->n_ext_regions += ext_regions; stats->n_ext_dropped += ext_dropped; stats->ms_ext += ms_ext; const uint32_t n_big0 = snap.n_big_total ? snap.n_big_total : snap.n_big[0];
@@ -3688,6 +3696,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         stats->n_chain_large += nl; stats->n_chain_small += snap.n_small;
         stats->n_minimizers += sum_mini;
         stats->n_anchors += sum_anchors; stats->n_clusters += sum_clusters; stats->n_resketch += resk_done; stats->n_pair_decided += sum_pair;
+        stats->n_dp_parallel += sum_pf; stats->n_dp_dirty += sum_pfd; stats->n_top_settled += sum_top;
         stats->ms_sketch_probe += t01; stats->ms_chain_small += t12; stats->ms_chain_large += t23; stats->ms_total += t04;
     }
     return SH_OK;

@@ -600,3 +600,42 @@ def test_pair_test_on_satellite_heavy_reference(S, oracle, monkeypatch):
     assert rc == 0 and np.array_equal(f1, of1)
     gf1, gt1, _, rc = gidx1.classify(bases, offs, want_trace=True)
     assert_trace_equal(S, gf1, gt1, of1, ot1)
+
+
+def test_parallel_chaining_recurrence_and_read_level_backtrack(S, oracle, monkeypatch):
+    """DESIGN.md 3.3 on a reference where it can fail: tandem arrays (171 / 68 / 5 bp monomers) whose windows hold dozens to hundreds of valid
+    predecessors, so that anchors break the premise of the parallel recurrence (dirty clusters: sequential DP) next to clusters that keep it.
+    Flags of the flag-only call (par_fill_block + backtrack_block_top), of the same call with the read-level backtrack off (cluster path over
+    the prefilled DP), with the recurrence off (the sequential DP everywhere), and the full trace must all equal the oracle's."""
+    contigs = [700_000, 500_000]
+    Po = oracle.ref_params(0x5C2B0C01, contigs, sat_pct=45, rep_pct=30, n_sat_fam=3, n_rep_fam=20)
+    ref = oracle.synth_ref(Po, 0, Po.genome_len)
+    seqs = [ref[Po.contig_start[i]:Po.contig_start[i + 1]] for i in range(len(contigs))]
+    Ro = oracle.read_params(0x5C2B0C02)
+    n = 8000
+    bases = oracle.synth_reads(Po, Ro, 0, n)
+    offs = np.arange(n + 1, dtype=np.uint64) * 150
+    cidx = oracle.Index.build(seqs, 11, 21)
+    gidx = S.Index.build([bytes(s) for s in seqs], S.preset("sr"))
+    of, ot = cidx.classify(oracle.preset("sr"), bases, offs, threads=8)
+    f1, _, st1, rc = gidx.classify(bases, offs, want_trace=False)
+    assert rc == 0 and np.array_equal(f1, of), f"{int((f1 != of).sum())} flags differ"
+    print({k: st1[k] for k in ("n_chain_large", "n_anchors", "n_dp_parallel", "n_dp_dirty", "n_top_settled", "n_ext_reads")})
+    assert st1["n_dp_parallel"] > 300 and st1["n_top_settled"] > 100 and st1["n_dp_dirty"] > 0, st1
+    monkeypatch.setenv("SCRUBBY_HIP_TOPBT_MAX", "2")                         # reads with more than two candidates at the top score: cluster by cluster
+    f4, _, st4, rc = gidx.classify(bases, offs, want_trace=False)
+    assert rc == 0 and np.array_equal(f4, of) and 0 < st4["n_top_settled"] < st1["n_top_settled"], st4
+    monkeypatch.delenv("SCRUBBY_HIP_TOPBT_MAX")
+    monkeypatch.setenv("SCRUBBY_HIP_NO_TOPBT", "1")
+    f2, _, st2, rc = gidx.classify(bases, offs, want_trace=False)
+    assert rc == 0 and np.array_equal(f2, of) and st2["n_top_settled"] == 0 and st2["n_dp_parallel"] > 300
+    monkeypatch.delenv("SCRUBBY_HIP_NO_TOPBT")
+    monkeypatch.setenv("SCRUBBY_HIP_NO_PARFILL", "1")
+    f3, _, st3, rc = gidx.classify(bases, offs, want_trace=False)
+    assert rc == 0 and np.array_equal(f3, of) and st3["n_dp_parallel"] == 0 and st3["n_top_settled"] == 0
+    gf0, gt0, _, rc = gidx.classify(bases, offs, want_trace=True)            # the sequential DP's trace ...
+    assert_trace_equal(S, gf0, gt0, of, ot)
+    monkeypatch.delenv("SCRUBBY_HIP_NO_PARFILL")
+    gf, gt, st, rc = gidx.classify(bases, offs, want_trace=True)             # ... and the recurrence's, cluster by cluster
+    assert_trace_equal(S, gf, gt, of, ot)
+    assert st["n_dp_parallel"] > 300 and st["n_top_settled"] == 0
