@@ -176,18 +176,25 @@ struct RegLite {            // mm_reg1_t, the fields the decision reads
 #define AL_R 64             // chains of a read kept in LDS
 #define AL_PRI 256          // primaries mm_set_parent may find (a 150-bp read has a handful)
 
-struct AlignLds {
+// NR chains of a read and NPRI primaries fit the LDS copy (more chains: the region arrays move to the wave's HBM scratch).  The kernel that
+// aligns regs[0] alone (k_regs_align_top) holds one chain and the few regions z-drops split off it: 12 KB instead of 19, 12 waves per CU
+// instead of 8 - the stage is bound by the latency of one wave's anti-diagonals, so residency is throughput.
+template <int NR_, int NPRI_>
+struct AlignLdsT {
+    static constexpr int NR = NR_, NPRI = NPRI_;
     __attribute__((aligned(16))) uint8_t kmem[8 * AL_T16 + AL_Q16 + 32];
     int32_t kH[AL_T16];
     __attribute__((aligned(16))) uint8_t kp[AL_P];
     uint8_t qseq[2 * AL_Q];
     uint8_t tseq[AL_T];
-    RegLite regs[AL_R];
-    uint64_t kz[AL_R], kx[AL_R], kk[AL_R];
-    uint32_t kh[AL_R], ord[AL_R];
-    int32_t pri[AL_PRI];
-    uint64_t cov[AL_PRI];
+    RegLite regs[NR_];
+    uint64_t kz[NR_], kx[NR_], kk[NR_];
+    uint32_t kh[NR_], ord[NR_];
+    int32_t pri[NPRI_];
+    uint64_t cov[NPRI_];
 };
+typedef AlignLdsT<AL_R, AL_PRI> AlignLds;
+typedef AlignLdsT<16, 16> AlignLdsTop;
 
 struct AlignScratch {       // one per wave, in HBM; sized by the host from max_read_len (align_scratch_bytes)
     uint8_t *qseq, *tseq, *kmem, *kp;
@@ -284,10 +291,10 @@ __device__ inline void ksw_backtrack_dev(bool is_rev, RD rd, const int32_t *off,
 // G = the buffers are the wave's HBM scratch; false = LDS (every pointer then derives from Ls alone, so the accesses compile to ds_*)
 // G: the DP state (u v x y x2 y2 s | sf | qr, H) in the wave's HBM scratch instead of LDS; GP: the direction bytes there.  Three forms: all in
 // LDS (short extensions), state in LDS + directions in HBM (written once, read by the backtrack only), all in HBM (beyond AL_T16 / AL_Q16).
-template <bool G, bool GP>
+template <bool G, bool GP, class LDS>
 __device__ inline void ksw_extd2_core(int32_t qlen, const uint8_t *query, bool qg, int32_t tlen, const uint8_t *target, bool tg,
                                       int8_t sc_mch, int8_t sc_mis, int8_t sc_N, int32_t q, int32_t e, int32_t q2, int32_t e2, int32_t w,
-                                      int32_t zdrop, int32_t end_bonus, int32_t flag, Ez &ez, uint32_t *cigar, AlignScratch &A, AlignLds &Ls)
+                                      int32_t zdrop, int32_t end_bonus, int32_t flag, Ez &ez, uint32_t *cigar, AlignScratch &A, LDS &Ls)
 {
     const uint32_t lane = al_lane();
     ez_reset(ez);
@@ -490,9 +497,10 @@ __device__ inline void ksw_extd2_core(int32_t qlen, const uint8_t *query, bool q
     al_sync();
 }
 
+template <class LDS>
 __device__ inline void ksw_extd2_wave(int32_t qlen, const uint8_t *query, bool qg, int32_t tlen, const uint8_t *target, bool tg,
                                       int8_t sc_mch, int8_t sc_mis, int8_t sc_N, int32_t q, int32_t e, int32_t q2, int32_t e2, int32_t w,
-                                      int32_t zdrop, int32_t end_bonus, int32_t flag, Ez &ez, uint32_t *cigar, AlignScratch &A, AlignLds &Ls)
+                                      int32_t zdrop, int32_t end_bonus, int32_t flag, Ez &ez, uint32_t *cigar, AlignScratch &A, LDS &Ls)
 {
     const int32_t T16 = (tlen + 15) / 16 * 16, Q16 = (qlen + 15) / 16 * 16;
     int32_t ww = w < 0 ? (tlen > qlen ? tlen : qlen) : w, nc = qlen < tlen ? qlen : tlen;
@@ -720,7 +728,8 @@ __device__ inline int32_t top_chain_settles(const AlignIn &in, const AlignParams
 // `mappings.len() > 0`); else every region is aligned and the counts / fingerprint are those of the oracle's trace.
 // top_z != 0: only the chain with that z - regs[0] of mm_gen_regs, which is aligned whatever the other chains are - goes through
 // mm_align1; a surviving region settles the read (n_regs > 0), none means the caller must run the full procedure on all chains.
-__device__ inline bool align_read_wave(const AlignIn &in, const AlignParams &P, uint32_t read, bool flag_only, AlignScratch &A, AlignLds &Ls,
+template <class LDS>
+__device__ inline bool align_read_wave(const AlignIn &in, const AlignParams &P, uint32_t read, bool flag_only, AlignScratch &A, LDS &Ls,
                                        AlignOut &out, uint32_t *overflow, unsigned long long top_z = 0)
 {
     const uint32_t lane = al_lane();
@@ -733,7 +742,7 @@ __device__ inline bool align_read_wave(const AlignIn &in, const AlignParams &P, 
     if (n_u == 0) return true;
     if (top_z != 0) { if (h_top == ~0u) return true; n_u = 1; }
     if ((uint32_t)n_u > A.reg_cap) { if (lane == 0) atomicExch(overflow, 2u); return false; }
-    const bool rg = n_u > AL_R;                 // region arrays in HBM scratch
+    const bool rg = n_u > LDS::NR;                 // region arrays in HBM scratch
     RegLite *regs = rg ? A.regs : Ls.regs;
     uint64_t *kz = rg ? A.kz : Ls.kz, *kx = rg ? A.kx : Ls.kx, *kk = rg ? A.kk : Ls.kk;
     uint32_t *kh = rg ? A.kh : Ls.kh, *ord = rg ? A.ord : Ls.ord;
@@ -823,7 +832,7 @@ __device__ inline bool align_read_wave(const AlignIn &in, const AlignParams &P, 
                 }
             } else j = k;
             if (j == k) {
-                if (k >= AL_PRI) { too_many = true; break; }
+                if (k >= LDS::NPRI) { too_many = true; break; }
                 w[k++] = i; regs[i].parent = i;
             }
         }
@@ -987,7 +996,7 @@ __device__ inline bool align_read_wave(const AlignIn &in, const AlignParams &P, 
         // a split leaves r with its first split_n anchors and queues r2 = the rest right behind it
         int32_t r_cnt = r.cnt;
         if (r2_cnt > 0) {
-            if ((uint32_t)(n_regs + 1) > (rg ? A.reg_cap : (uint32_t)AL_R)) { if (lane == 0) atomicExch(overflow, 6u); return false; }
+            if ((uint32_t)(n_regs + 1) > (rg ? A.reg_cap : (uint32_t)LDS::NR)) { if (lane == 0) atomicExch(overflow, 6u); return false; }
             if (lane == 0) {
                 RegLite r2; r2.cnt = r2_cnt; r2.as = r.as + (unsigned long long)split_n; r2.score = (int32_t)(r.score * ((float)r2_cnt / r.cnt) + .499);
                 r2.qs = r2.qe = r2.rs = r2.re = 0; r2.parent = -2; r2.rid = rid; r2.rev = rev; r2.pad = 0;

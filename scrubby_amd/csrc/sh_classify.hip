@@ -2731,6 +2731,37 @@ __global__ __launch_bounds__(64) void k_regs_align(ExtArgs a)
     if (lane == 0) { if (n_regions) atomicAdd(&a.ctr->ext_regions, n_regions); if (n_dropped) atomicAdd(&a.ctr->ext_dropped, n_dropped); }
 }
 
+// regs[0] alone (flag-only second pass): one chain, a handful of regions - a third less LDS per wave than k_regs_align, half as many waves
+// again per CU.  A read that outgrows the small arrays is not an error here: it joins the reads regs[0] did not settle (redo2) and
+// meets the full-size kernel there.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_regs_align_top(ExtArgs a)
+{
+    __shared__ AlignLdsTop Ls;
+    __shared__ uint32_t s_ovf;
+    const uint32_t lane = threadIdx.x;
+    AlignScratch A;
+    align_scratch_carve(A, a.scratch + (unsigned long long)blockIdx.x * a.scratch_per_wave, a.max_read_len, a.reg_cap);
+    const uint32_t n_list = *a.n_list;
+    uint32_t n_regions = 0;
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) { t = atomicAdd(a.ticket, 1u); s_ovf = 0; }
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= n_list) break;
+        __syncthreads();
+        const uint32_t r = a.list[t];
+        AlignOut o;
+        const bool done = align_read_wave(a.in, a.P, r, true, A, Ls, o, &s_ovf, a.best[r]);
+        if (lane == 0) {
+            if (done && o.n_regs > 0) a.flags[r] = 1;
+            else a.redo2[atomicAdd(&a.ctr->ext_n_redo2, 1u)] = r;
+        }
+        if (done) n_regions += (uint32_t)o.n_aligned;
+        __syncthreads();
+    }
+    if (lane == 0 && n_regions) atomicAdd(&a.ctr->ext_regions, n_regions);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // extension stage, long-read presets (sh_long.h): one wave per read with at least one chain, two kernels
@@ -2897,7 +2928,7 @@ struct sh_ctx {
     ChainSink sink{};
     uint8_t *d_ext = nullptr; uint64_t ext_bytes = 0;
     uint32_t *d_ext_list = nullptr, *d_ext_redo = nullptr; uint8_t *d_ext_scratch = nullptr;
-    unsigned long long ext_scratch_per_wave = 0; uint32_t ext_waves = 0, ext_reg_cap = 0;
+    unsigned long long ext_scratch_per_wave = 0; uint32_t ext_waves_top = 0; uint32_t ext_waves = 0, ext_reg_cap = 0;
     hipEvent_t ev_ext[2] = {};
     // which reads of the LAST chunk took the rare paths (sh_ctx_debug_list: the bench's stratified oracle sample): 0 re-chained with max_occ,
     // 1 regs[0] aligned base by base, 2 the full fallback with every chain
@@ -3143,7 +3174,8 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             c->ext_scratch_per_wave = align_scratch_layout(max_read_len, c->ext_reg_cap, nullptr, nullptr, nullptr);
             const uint64_t budget = 4ull << 30;
             c->ext_waves = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)256 * std::max<uint64_t>(1, (160u << 10) / sizeof(AlignLds)), budget / c->ext_scratch_per_wave, (max_reads + 3) / 4}));
-            if ((e = hipMalloc(&c->d_ext_scratch, (uint64_t)c->ext_waves * c->ext_scratch_per_wave)) != hipSuccess) return fail(e, "extension-stage scratch");
+            c->ext_waves_top = (uint32_t)std::max<uint64_t>(c->ext_waves, std::min<uint64_t>({(uint64_t)256 * std::max<uint64_t>(1, (160u << 10) / (sizeof(AlignLdsTop) + 16)), budget / c->ext_scratch_per_wave, (max_reads + 3) / 4}));
+            if ((e = hipMalloc(&c->d_ext_scratch, (uint64_t)c->ext_waves_top * c->ext_scratch_per_wave)) != hipSuccess) return fail(e, "extension-stage scratch");
         } else {
             // per-wave working memory of the two kernels (k_long_chains, k_regs_align_long), each in two sizes: every wave slot with room for
             // the usual read, and a few waves with room for the largest alignment minimap2 attempts (max_sw_mat = 10^8 cells) / for reads
@@ -3614,7 +3646,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
             // second pass: regs[0] of the reads its max stretch could not vouch for goes through mm_align1 (one wave per read)
             ExtArgs x1 = x;
             x1.list = c->d_ext_redo; x1.n_list = &c->d_ctr->ext_n_redo; x1.ticket = &c->d_ctr->ext_ticket2; x1.top_only = 1; x1.redo2 = c->d_ext_list;     // the first list is spent
-            hipLaunchKernelGGL(k_regs_align, dim3(c->ext_waves), dim3(64), 0, s, x1);
+            hipLaunchKernelGGL(k_regs_align_top, dim3(c->ext_waves_top), dim3(64), 0, s, x1);
             SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
             SH_HIP(hipStreamSynchronize(s));
             SH_HIP(hipGetLastError());
