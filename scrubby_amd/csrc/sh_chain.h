@@ -588,7 +588,7 @@ __device__ inline bool par_fill_block(PX x, PQ q, int32_t *f, int32_t *pt, uint3
                     const uint32_t qj = (uint32_t)q[j], xj = (uint32_t)x[j];
                     if (xi - xj > lim) break;
                     const int32_t sc = comput_sc(xi, qi, xj, qj & 0x7fffffffu, mdx, mdy, P);
-                    if (sc != SH_SC_NONE) { ++nv; const int32_t c = sc + f[j]; if (c > max_f) { max_f = c; max_j = (int32_t)j; } }
+                    if (sc != SH_SC_NONE) { if (++nv > P.max_skip) break; const int32_t c = sc + f[j]; if (c > max_f) { max_f = c; max_j = (int32_t)j; } }      // dirty: no need to see the rest
                     if (qj >> 31) break;
                 }
             }
@@ -596,9 +596,9 @@ __device__ inline bool par_fill_block(PX x, PQ q, int32_t *f, int32_t *pt, uint3
             if (bad || nv > P.max_skip) { const int32_t d = atomicAdd(&L.n_dirty, 1); if (d < PF_DIRTY_CAP) L.dirty[d] = i; }
         }
         __syncthreads();
+        if (L.n_dirty > PF_DIRTY_CAP) return false;      // uniform (read after the barrier): a read of dense tandem arrays - every window overflows
     }
     const int32_t nd = L.n_dirty;
-    if (nd > PF_DIRTY_CAP) return false;
     for (uint32_t i = tid; i < n; i += nthr) pt[2 * (size_t)i + 1] = 0;
     __syncthreads();
     for (int32_t d = (int32_t)tid; d < nd; d += (int32_t)nthr) { uint32_t c = L.dirty[d]; while (!((uint32_t)q[c] >> 31)) --c; pt[2 * (size_t)c + 1] = PF_DIRTY; }
@@ -612,20 +612,28 @@ __device__ inline bool par_fill_block(PX x, PQ q, int32_t *f, int32_t *pt, uint3
 // completely in LDS (its own rank table, all rounds), with the last PFT_H anchors of the tile before it as a halo; f and (p, t = 0) go
 // out once, coalesced.  An anchor whose window is not inside tile + halo is dirty (so is one with PFT_H anchors within max_dist_x behind
 // it: the max_iter cut is not looked at any closer than that; needs max_iter >= PFT_H).  Same contract as par_fill_block.
+__device__ inline int32_t wave_scan_max_incl(int32_t v);      // below, with the other DPP scans
 #define PFT_T 4096
 #define PFT_H 256
-struct PfTile { uint32_t x[PFT_H + PFT_T], q[PFT_H + PFT_T]; int32_t f[PFT_H + PFT_T]; uint16_t p[PFT_T], perm[PFT_T]; };
+struct PfTile { uint32_t x[PFT_H + PFT_T], q[PFT_H + PFT_T]; int32_t f[PFT_H + PFT_T]; uint16_t p[PFT_T], perm[PFT_T], dcs[PFT_H + PFT_T]; int32_t wtot[16], carry; };
 
 __device__ inline bool par_fill_tiled(const uint64_t *x, const uint32_t *q, int32_t *f, int32_t *pt, uint32_t n, int32_t qlen, const ChainParams &P, uint32_t tid, uint32_t nthr,
-                                      ParFillLds &L, PfTile &T)
+                                      ParFillLds &L, PfTile &T, uint32_t g_min = 32768u)
 {
-    if (qlen > PF_MAX_Q || n >= 0x7ffffff0u || P.max_iter < PFT_H || nthr < PFT_H) return false;
+    if (qlen > PF_MAX_Q || n >= 0x7ffffff0u || P.max_iter < PFT_H || nthr < PFT_H || nthr > 1024) return false;
     const int32_t mdy = chain_max_dist_y(P, qlen), mdx = (int32_t)chain_max_dist_x(P, qlen);
+    // The largest reads of a batch (10^5 anchors of a dense tandem array, hundreds of them inside every window) set the kernel's time however
+    // small the batch: for those G = 8 lanes share an anchor, each taking every eighth predecessor (combined as the sequential scan would
+    // have decided: largest sum, of equal sums the largest index).  Every lane must then know where its anchor's cluster starts without
+    // walking there: dcs = distance to the cluster start, from a block-wide scan of the marks.
+    const uint32_t G = n >= g_min ? 8u : 1u, sub = tid & (G - 1u), grp = tid / G, n_grp = nthr / G;
+    const uint32_t lane = tid & 63u, wave = tid >> 6, n_wave = nthr >> 6;
     if (tid == 0) L.n_dirty = 0;
     uint32_t h = 0;
     for (uint32_t t0 = 0; t0 < n; t0 += PFT_T) {
         const uint32_t tn = n - t0 < PFT_T ? n - t0 : PFT_T;
         for (uint32_t t = tid; t < PF_MAX_Q / 64; t += nthr) L.qmask[t] = 0;
+        if (tid == 0) T.carry = -1;
         __syncthreads();
         for (uint32_t k = tid; k < tn; k += nthr) {
             const uint32_t qr = q[t0 + k], qq = qr & 0x7fffffffu;
@@ -634,6 +642,21 @@ __device__ inline bool par_fill_tiled(const uint64_t *x, const uint32_t *q, int3
         }
         __syncthreads();
         if (tid == 0) { uint32_t acc = 0; for (int w = 0; w < PF_MAX_Q / 64; ++w) { L.qpre[w] = acc; acc += (uint32_t)__popcll(L.qmask[w]); } L.qpre[PF_MAX_Q / 64] = acc; }
+        if (G > 1) {      // dcs over halo + tile (an anchor whose cluster starts before the halo counts from index 0: the scan then runs out of halo)
+            for (uint32_t c0 = 0; c0 < h + tn; c0 += nthr) {
+                const uint32_t k = c0 + tid;
+                const int32_t v = k < h + tn && (T.q[k] >> 31) ? (int32_t)k : -1;
+                int32_t inc = wave_scan_max_incl(v);
+                if (lane == 63) T.wtot[wave] = inc;
+                __syncthreads();
+                int32_t before = T.carry;
+                for (uint32_t w = 0; w < wave; ++w) before = T.wtot[w] > before ? T.wtot[w] : before;
+                inc = inc > before ? inc : before;
+                if (k < h + tn) T.dcs[k] = (uint16_t)(inc < 0 ? k : k - (uint32_t)inc);
+                __syncthreads();
+                if (tid == nthr - 1) T.carry = inc;
+            }
+        }
         __syncthreads();
         const uint32_t R = L.qpre[PF_MAX_Q / 64];
         if (R > PF_MAX_RANK) return false;
@@ -650,29 +673,52 @@ __device__ inline bool par_fill_tiled(const uint64_t *x, const uint32_t *q, int3
         __syncthreads();
         for (uint32_t r = 0; r < R; ++r) {
             const uint32_t e = L.start[r + 1];
-            for (uint32_t idx = L.start[r] + tid; idx < e; idx += nthr) {
-                const uint32_t kt = T.perm[idx], k = h + kt;
+            for (uint32_t base = L.start[r]; base < e; base += n_grp) {
+                const uint32_t idx = base + grp;
+                const bool on = idx < e;
+                const uint32_t kt = on ? T.perm[idx] : 0u, k = h + kt;
                 const uint32_t qraw = T.q[k], qi = qraw & 0x7fffffffu, xi = T.x[k];
-                int32_t max_f = P.k, nv = 0;
-                uint32_t max_d = 0;
+                int32_t max_f = P.k, max_j = -1, nv = 0;
                 bool bad = false;
-                if (!(qraw >> 31)) {
+                if (on && !(qraw >> 31)) {
                     const uint32_t lim = min((uint32_t)mdx, qi + (uint32_t)P.bw);
-                    if (k >= PFT_H && xi - T.x[k - PFT_H] <= (uint32_t)mdx) bad = true;      // a window of PFT_H anchors or more: left to the sequential code
-                    bool stop = false;
-                    for (int32_t j = (int32_t)k - 1; j >= 0; --j) {
-                        const uint32_t qj = T.q[j], xj = T.x[j];
-                        if (xi - xj > lim) { stop = true; break; }
-                        const int32_t sc = comput_sc(xi, qi, xj, qj & 0x7fffffffu, mdx, mdy, P);
-                        if (sc != SH_SC_NONE) { ++nv; const int32_t c = sc + T.f[j]; if (c > max_f) { max_f = c; max_d = k - (uint32_t)j; } }
-                        if (qj >> 31) { stop = true; break; }
+                    if (sub == 0 && k >= PFT_H && xi - T.x[k - PFT_H] <= (uint32_t)mdx) bad = true;      // a window of PFT_H anchors or more: left to the sequential code
+                    if (G == 1) {
+                        bool stop = false;
+                        for (int32_t j = (int32_t)k - 1; j >= 0; --j) {
+                            const uint32_t qj = T.q[j], xj = T.x[j];
+                            if (xi - xj > lim) { stop = true; break; }
+                            const int32_t sc = comput_sc(xi, qi, xj, qj & 0x7fffffffu, mdx, mdy, P);
+                            if (sc != SH_SC_NONE) { if (++nv > P.max_skip) { stop = true; break; } const int32_t c = sc + T.f[j]; if (c > max_f) { max_f = c; max_j = j; } }
+                            if (qj >> 31) { stop = true; break; }
+                        }
+                        if (!stop && t0 > h) bad = true;      // ran out of halo
+                    } else {
+                        const int32_t jmin = (int32_t)k - (int32_t)T.dcs[k];
+                        bool stop = false;
+                        for (int32_t j = (int32_t)k - 1 - (int32_t)sub; j >= jmin; j -= (int32_t)G) {
+                            const uint32_t xj = T.x[j];
+                            if (xi - xj > lim) { stop = true; break; }
+                            const int32_t sc = comput_sc(xi, qi, xj, T.q[j] & 0x7fffffffu, mdx, mdy, P);
+                            if (sc != SH_SC_NONE) { if (++nv > P.max_skip) { stop = true; break; } const int32_t c = sc + T.f[j]; if (c > max_f) { max_f = c; max_j = j; } }
+                        }
+                        // the cluster starts before the halo and this lane never met the distance limit
+                        if (!stop && jmin == 0 && t0 > h && !(T.q[0] >> 31)) bad = true;
                     }
-                    if (!stop && t0 > h) bad = true;      // ran out of halo
                 }
-                T.f[k] = max_f; T.p[kt] = (uint16_t)max_d;
-                if (bad || nv > P.max_skip) { const int32_t d = atomicAdd(&L.n_dirty, 1); if (d < PF_DIRTY_CAP) L.dirty[d] = t0 + kt; }
+                for (uint32_t o = 1; o < G; o <<= 1) {      // uniform: G is
+                    const int32_t of = __shfl_xor(max_f, (int)o), oj = __shfl_xor(max_j, (int)o);
+                    nv += __shfl_xor(nv, (int)o);
+                    bad |= __shfl_xor((int)bad, (int)o) != 0;
+                    if (of > max_f || (of == max_f && oj > max_j)) { max_f = of; max_j = oj; }
+                }
+                if (on && sub == 0) {
+                    T.f[k] = max_f; T.p[kt] = (uint16_t)(max_j < 0 ? 0 : (int32_t)k - max_j);
+                    if (bad || nv > P.max_skip) { const int32_t d = atomicAdd(&L.n_dirty, 1); if (d < PF_DIRTY_CAP) L.dirty[d] = t0 + kt; }
+                }
             }
             __syncthreads();
+            if (L.n_dirty > PF_DIRTY_CAP) return false;      // uniform: see par_fill_block
         }
         for (uint32_t k = tid; k < tn; k += nthr) {
             const uint32_t g = t0 + k, d = T.p[k];

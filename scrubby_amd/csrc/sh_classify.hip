@@ -1481,6 +1481,7 @@ struct K3Args {
     BaseCtx BC;
     int32_t t_mode;                    // SH_F_CIGAR and no trace wanted: only regs[0] matters, shortcuts allowed
     int32_t quiet;                     // a second visit of reads that were counted already: no statistics
+    uint32_t pft_gmin;                 // par_fill_tiled: reads of this many anchors get eight lanes per anchor (SCRUBBY_HIP_PFT_GMIN, tests)
     int32_t top_max;                   // backtrack_block_top: candidates a read may have at its top score (<= TOPBT_MAX; SCRUBBY_HIP_TOPBT_MAX, tests)
 };
 
@@ -2109,26 +2110,33 @@ __device__ inline uint32_t giant_rounds(uint32_t n)
 }
 
 // The dirty clusters par_fill_block left (PF_DIRTY at their first anchor): the sequential DP, p turned into indices into the read's array,
-// marks cleared.  One wave per cluster; every thread of the block calls.
+// marks cleared.  One wave per cluster; every thread of the block calls.  A dirty cluster of more than max_len anchors is left as it is and
+// false is returned: one wave stepping through 20 k anchors in HBM would hold the whole block (and, for the largest read of a batch, the
+// kernel) for milliseconds - k_cluster_dp chains such a cluster through its LDS ring while other waves do the read's other clusters.
 template <class PX, class PQ>
-__device__ inline void fix_dirty_clusters(PX x, PQ q, int32_t *f, int32_t *pt, uint32_t n, int32_t qlen, const ChainParams &P, uint32_t tid, uint32_t nthr, const ParFillLds &L)
+__device__ inline bool fix_dirty_clusters(PX x, PQ q, int32_t *f, int32_t *pt, uint32_t n, int32_t qlen, const ChainParams &P, uint32_t tid, uint32_t nthr, const ParFillLds &L,
+                                          uint32_t max_len, int32_t *s_left)
 {
     const uint32_t wave = tid >> 6, n_wave = nthr >> 6, lane = tid & 63;
     const int32_t nd = L.n_dirty;
+    if (tid == 0) *s_left = 0;
+    __syncthreads();
     for (int32_t d = (int32_t)wave; d < nd; d += (int32_t)n_wave) {
         uint32_t c = L.dirty[d];
         while (!((uint32_t)q[c] >> 31)) --c;
+        uint32_t e = c + 1;
+        while (e < n && !((uint32_t)q[e] >> 31)) ++e;
+        if (e - c > max_len) { if (lane == 0) *s_left = 1; continue; }
         int32_t mine = 0;
         if (lane == 0) mine = atomicCAS(&pt[2 * (size_t)c + 1], (int32_t)PF_DIRTY, (int32_t)PF_DEAD) == (int32_t)PF_DIRTY ? 1 : 0;
         mine = __builtin_amdgcn_readfirstlane(mine);
         if (!mine) continue;      // another anchor of the same cluster got there first
-        uint32_t e = c + 1;
-        while (e < n && !((uint32_t)q[e] >> 31)) ++e;
         SliceStore S{(const uint64_t *)&x[c], (const uint32_t *)&q[c], f + c, pt + 2 * (size_t)c};
         chain_dp_wave(S, (int)(e - c), qlen, P, lane);
         for (uint32_t i = c + lane; i < e; i += 64) { const int32_t pv = pt[2 * (size_t)i]; if (pv >= 0) pt[2 * (size_t)i] = pv + (int32_t)c; pt[2 * (size_t)i + 1] = 0; }
     }
     __syncthreads();
+    return *s_left == 0;
 }
 
 // Flag-only hand-over (ChainSink::best), ahead of k_sort_lds: sort in LDS, the DP of all clusters at once (par_fill_block), then
@@ -2174,7 +2182,7 @@ __global__ __launch_bounds__(NTHR) void k_sort_top(K3Args a)
         __syncthreads();
         if (!par_fill_block(rx, rq, f, pt, n, qlen, P_l, tid, NTHR, s_pf)) { if (dbg && tid == 0) atomicAdd(&dbg[1], 1ull); continue; }
         if (tid == 0 && !a.quiet) { atomicAdd(&a.ctr->sh_pf_reads[SHARD()], 1u); if (s_pf.n_dirty) atomicAdd(&a.ctr->sh_pf_dirty[SHARD()], (uint32_t)s_pf.n_dirty); }
-        fix_dirty_clusters(rx, rq, f, pt, n, qlen, P_l, tid, NTHR, s_pf);
+        fix_dirty_clusters(rx, rq, f, pt, n, qlen, P_l, tid, NTHR, s_pf, 0xffffffffu, &s_cn);
         SliceStore S{(const uint64_t *)rx, (const uint32_t *)rq, f, pt};
         const uint32_t read = a.B.meta[si.w].r;
         const StoreEmit<SliceStore> em{&sink_l, &S, read, 0u, tid == 0, P_l.k, region_hash(qlen), qlen, nullptr};
@@ -2224,13 +2232,12 @@ __global__ __launch_bounds__(512) void k_giant_top(K3Args a)
             if (start) { q[i] |= 0x80000000u; ++starts; }
         }
         __syncthreads();
-        const bool pre = par_fill_tiled(x, q, f, pt, n, qlen, P_l, tid, nthr, s_pf, s_tile);
+        const bool pre = par_fill_tiled(x, q, f, pt, n, qlen, P_l, tid, nthr, s_pf, s_tile, a.pft_gmin);
         if (dbg && tid == 0) { atomicAdd(&dbg[pre ? 0 : 1], 1ull); atomicAdd(&dbg[2], (unsigned long long)s_pf.n_dirty); atomicAdd(&dbg[pre ? 3 : 4], (unsigned long long)n); }
         if (!pre) continue;
         if (tid == 0 && !a.quiet) { atomicAdd(&a.ctr->sh_pf_reads[SHARD()], 1u); if (s_pf.n_dirty) atomicAdd(&a.ctr->sh_pf_dirty[SHARD()], (uint32_t)s_pf.n_dirty); }
         bool settled = false;
-        if (top) {
-            fix_dirty_clusters(x, q, f, pt, n, qlen, P_l, tid, nthr, s_pf);
+        if (top && fix_dirty_clusters(x, q, f, pt, n, qlen, P_l, tid, nthr, s_pf, 512u, &s_cn)) {
             SliceStore S{(const uint64_t *)x, (const uint32_t *)q, f, pt};
             const uint32_t read = a.B.meta[si.w].r;
             const StoreEmit<SliceStore> em{&sink_l, &S, read, 0u, tid == 0, P_l.k, region_hash(qlen), qlen, nullptr};
@@ -3427,7 +3434,8 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     k.sink = b.sink; k.emit = c->ext ? 1 : 0; k.BC = b.BC; k.t_mode = (c->ext && !c->ext_long && d_trace == nullptr) ? 1 : 0;
     k.dbg = getenv("SCRUBBY_HIP_DBG") ? atoi(getenv("SCRUBBY_HIP_DBG")) : 0;
     if (getenv("SCRUBBY_HIP_NO_PARFILL")) k.dbg |= 128;      // A/B: every cluster chained by the sequential DP
-    k.top_max = TOPBT_MAX;
+    k.top_max = TOPBT_MAX; k.pft_gmin = 32768u;
+    if (const char *env = getenv("SCRUBBY_HIP_PFT_GMIN")) k.pft_gmin = (uint32_t)std::max(1, atoi(env));
     if (const char *env = getenv("SCRUBBY_HIP_TOPBT_MAX")) k.top_max = std::max(1, std::min(TOPBT_MAX, atoi(env)));
     if (getenv("SCRUBBY_HIP_NO_TOPBT")) k.dbg |= 512;        // A/B: clusters visited one by one even when the read's DP is done
     k.resketch_list = c->d_work_resketch;

@@ -622,6 +622,12 @@ def test_parallel_chaining_recurrence_and_read_level_backtrack(S, oracle, monkey
     assert rc == 0 and np.array_equal(f1, of), f"{int((f1 != of).sum())} flags differ"
     print({k: st1[k] for k in ("n_chain_large", "n_anchors", "n_dp_parallel", "n_dp_dirty", "n_top_settled", "n_ext_reads")})
     assert st1["n_dp_parallel"] > 300 and st1["n_top_settled"] > 100 and st1["n_dp_dirty"] > 0, st1
+    monkeypatch.setenv("SCRUBBY_HIP_PFT_GMIN", "1")                          # giant reads: eight lanes per anchor in the tiled recurrence (the bench's largest reads)
+    f5, _, st5, rc = gidx.classify(bases, offs, want_trace=False)
+    assert rc == 0 and np.array_equal(f5, of) and st5["n_dp_parallel"] == st1["n_dp_parallel"]
+    gf5, gt5, _, rc = gidx.classify(bases, offs, want_trace=True)
+    assert_trace_equal(S, gf5, gt5, of, ot)
+    monkeypatch.delenv("SCRUBBY_HIP_PFT_GMIN")
     monkeypatch.setenv("SCRUBBY_HIP_TOPBT_MAX", "2")                         # reads with more than two candidates at the top score: cluster by cluster
     f4, _, st4, rc = gidx.classify(bases, offs, want_trace=False)
     assert rc == 0 and np.array_equal(f4, of) and 0 < st4["n_top_settled"] < st1["n_top_settled"], st4
