@@ -2935,6 +2935,7 @@ struct sh_ctx {
     ChainSink sink{};
     uint8_t *d_ext = nullptr; uint64_t ext_bytes = 0;
     uint32_t *d_ext_list = nullptr, *d_ext_redo = nullptr; uint8_t *d_ext_scratch = nullptr;
+    unsigned long long cur_reads = 0;      // records of the chunk being classified
     unsigned long long ext_scratch_per_wave = 0; uint32_t ext_waves_top = 0; uint32_t ext_waves = 0, ext_reg_cap = 0;
     hipEvent_t ev_ext[2] = {};
     // which reads of the LAST chunk took the rare paths (sh_ctx_debug_list: the bench's stratified oracle sample): 0 re-chained with max_occ,
@@ -3290,30 +3291,32 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     // the sort classes run one after the other.  Side by side (streams sx[0..2]) measured 9 % slower when they carried the whole repeat
     // path (they fight for LDS); that mode predates k_group_probe, which the class-4 and giant kernels must follow: it stays off.
     static const int side_env = getenv("SCRUBBY_HIP_SIDE") ? atoi(getenv("SCRUBBY_HIP_SIDE")) : -1;
-    const bool side = side_env > 0;      // round 2, extension filter on (no k_group_probe, so race-free): still 2-3 % slower at 2.5 M and at 20 M records
+    // small batches (an eighth of the bench's records on each of 8 GPUs): every class kernel is mostly tail, side by side they overlap:
+    // 39.3 -> 36.6 ms at 2.5 M records; at 20 M it costs 2 % (SCRUBBY_HIP_SIDE=0 / 1 forces either)
+    const bool gp = k.flag_only && k.P.flag_stop != INT32_MAX && !(k.dbg & 64);      // k_group_probe runs (chain-level decision): the class-4 and giant kernels must follow it
+    const bool side = side_env > 0 || (side_env < 0 && !gp && c->cur_reads <= 3000000ull);
     hipStream_t s0 = side ? c->sx[0] : s, s1 = side ? c->sx[1] : s, g = side ? c->sx[2] : s;
+    const bool use_pf = (k.emit || !k.flag_only) && !(k.dbg & 128);
+    const bool use_top = use_pf && k.emit && k.sink.best != nullptr && !(k.dbg & 512);
+    if (use_pf) SH_HIP(hipMemsetAsync(&ctr->top_ticket[0], 0, 4 * N_SORT_CLS, s));
     if (side) {
         SH_HIP(hipEventRecord(c->evx[0], s));
         for (int i = 0; i < 3; ++i) SH_HIP(hipStreamWaitEvent(c->sx[i], c->evx[0], 0));
     }
-    if (k.flag_only && k.P.flag_stop != INT32_MAX && !(k.dbg & 64)) {      // reads with thousands of anchors: try one (strand, contig) group first
+    if (gp) {      // reads with thousands of anchors: try one (strand, contig) group first
         hipLaunchKernelGGL(k_group_probe, dim3(256 * 3), dim3(256), 0, s, k, 4);
         hipLaunchKernelGGL(k_group_probe, dim3(256 * 3), dim3(256), 0, s, k, (int)SORT_CLS_GIANT);
     }
-    const bool use_pf = (k.emit || !k.flag_only) && !(k.dbg & 128);
-    const bool use_top = use_pf && k.emit && k.sink.best != nullptr && !(k.dbg & 512);
-    if (use_pf) SH_HIP(hipMemsetAsync(&ctr->top_ticket[0], 0, 4 * N_SORT_CLS, s));
-    if (use_top) {
-        hipLaunchKernelGGL((k_sort_top<256, 0, 64>), dim3(grid * 2), dim3(64), 0, s, k);
-        hipLaunchKernelGGL((k_sort_top<SORT_LDS_A, 1, 128>), dim3(grid * 2), dim3(128), 0, s, k);
-        hipLaunchKernelGGL((k_sort_top<1024, 2, 256>), dim3(256 * 6), dim3(256), 0, s, k);
-        hipLaunchKernelGGL((k_sort_top<SORT_LDS_B, 3, 256>), dim3(256 * 3), dim3(256), 0, s, k);
-        hipLaunchKernelGGL((k_sort_top<SORT_LDS_C, 4, 512>), dim3(256), dim3(512), 0, s, k);
-    }
+    // each class: the read-level pass (k_sort_top), then the cluster path for what it left (k_sort_lds), on the class's stream
+    if (use_top) hipLaunchKernelGGL((k_sort_top<256, 0, 64>), dim3(grid * 2), dim3(64), 0, s, k);
     hipLaunchKernelGGL((k_sort_lds<256, 0, 64>), dim3(grid * 2), dim3(64), 0, s, k);
+    if (use_top) hipLaunchKernelGGL((k_sort_top<SORT_LDS_A, 1, 128>), dim3(grid * 2), dim3(128), 0, s, k);
     hipLaunchKernelGGL((k_sort_lds<SORT_LDS_A, 1, 128>), dim3(grid * 2), dim3(128), 0, s, k);
+    if (use_top) hipLaunchKernelGGL((k_sort_top<1024, 2, 256>), dim3(256 * 6), dim3(256), 0, s0, k);
     hipLaunchKernelGGL((k_sort_lds<1024, 2, 256>), dim3(256 * 6), dim3(256), 0, s0, k);
+    if (use_top) hipLaunchKernelGGL((k_sort_top<SORT_LDS_B, 3, 256>), dim3(256 * 3), dim3(256), 0, s0, k);
     hipLaunchKernelGGL((k_sort_lds<SORT_LDS_B, 3, 256>), dim3(256 * 3), dim3(256), 0, s0, k);
+    if (use_top) hipLaunchKernelGGL((k_sort_top<SORT_LDS_C, 4, 512>), dim3(256), dim3(512), 0, s1, k);
     hipLaunchKernelGGL((k_sort_lds<SORT_LDS_C, 4, 512>), dim3(256), dim3(512), 0, s1, k);
     hipLaunchKernelGGL(k_giant_scan, dim3(1), dim3(1024), 0, g, k);
     hipLaunchKernelGGL(k_giant_chunksort, dim3(256 * 3), dim3(256), 0, g, k);
@@ -3339,6 +3342,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                                 uint8_t *d_flags, sh_trace *d_trace, hipStream_t s, sh_stats *stats)
 {
     const sh_index *idx = c->idx;
+    c->cur_reads = n_reads;
     SH_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), s));
     if (c->ext) { SH_HIP(hipMemsetAsync(c->sink.head, 0xff, n_reads * 4, s)); SH_HIP(hipMemsetAsync(c->sink.best, 0, n_reads * 8, s)); SH_HIP(hipMemsetAsync(c->sink.tie, 0, n_reads * 4, s)); }
     SH_HIP(hipEventRecord(c->ev[0], s));
