@@ -2364,10 +2364,13 @@ __global__ __launch_bounds__(256) void k_giant_merge(K3Args a, uint32_t round)
         for (uint32_t i = tid; i < la; i += 256) { s_x[i] = g.sx[g.L0 + a0 + i]; s_q[i] = g.sq[g.L0 + a0 + i]; }
         for (uint32_t i = tid; i < lb; i += 256) { s_x[la + i] = g.sx[g.L1 + b0 + i]; s_q[la + i] = g.sq[g.L1 + b0 + i]; }
         __syncthreads();
-        // merge in LDS: 8 outputs per thread
-        const uint32_t m = la + lb, C = 8;
-        for (uint32_t c = tid; c * C < m; c += 256) {
-            const uint32_t e0 = c * C, e1 = e0 + C < m ? e0 + C : m;
+        // merge in LDS: 8 outputs per thread, kept in registers until every thread has read its inputs, then through LDS again so that the
+        // stores are coalesced (a thread storing its own 8 outputs touched 64 sectors per instruction: a quarter of the kernel's time)
+        const uint32_t m = la + lb;
+        constexpr uint32_t C = 8;
+        uint64_t ox[C]; uint32_t oq[C];
+        const uint32_t e0 = tid * C, e1 = e0 + C < m ? e0 + C : m;      // GT = 256 * C outputs at most
+        if (e0 < m) {
             uint32_t lo = e0 > lb ? e0 - lb : 0, hi = e0 < la ? e0 : la;
             while (lo < hi) {
                 uint32_t mid = (lo + hi) >> 1;
@@ -2375,12 +2378,20 @@ __global__ __launch_bounds__(256) void k_giant_merge(K3Args a, uint32_t round)
             }
             uint32_t ia = lo, ib = e0 - lo;
             uint64_t va = ia < la ? s_x[ia] : ~0ull, vb = ib < lb ? s_x[la + ib] : ~0ull;
-            for (uint32_t e = e0; e < e1; ++e) {
-                const bool takeL = ia < la && (ib >= lb || va <= vb);
-                if (takeL) { g.dx[g.o0 + e] = va; g.dq[g.o0 + e] = s_q[ia]; ++ia; va = ia < la ? s_x[ia] : ~0ull; }
-                else { g.dx[g.o0 + e] = vb; g.dq[g.o0 + e] = s_q[la + ib]; ++ib; vb = ib < lb ? s_x[la + ib] : ~0ull; }
+#pragma unroll
+            for (uint32_t u = 0; u < C; ++u) {
+                if (e0 + u < e1) {
+                    const bool takeL = ia < la && (ib >= lb || va <= vb);
+                    if (takeL) { ox[u] = va; oq[u] = s_q[ia]; ++ia; va = ia < la ? s_x[ia] : ~0ull; }
+                    else { ox[u] = vb; oq[u] = s_q[la + ib]; ++ib; vb = ib < lb ? s_x[la + ib] : ~0ull; }
+                }
             }
         }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < C; ++u) if (e0 + u < e1) { s_x[e0 + u] = ox[u]; s_q[e0 + u] = oq[u]; }
+        __syncthreads();
+        for (uint32_t i = tid; i < m; i += 256) { g.dx[g.o0 + i] = s_x[i]; g.dq[g.o0 + i] = s_q[i]; }
         __syncthreads();
     }
 }
