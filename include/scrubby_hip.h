@@ -124,7 +124,7 @@ typedef struct sh_stats {
     uint64_t n_ext_shortcut;   /* SH_F_CIGAR flag-only: reads decided inside a chaining kernel - their top chain's max stretch alone passes mm_filter_regs */
     uint64_t n_ext_fallback;   /* SH_F_CIGAR flag-only, sr: reads whose regs[0] did not survive and that were re-chained with every chain kept */
     double   ms_ext_fallback;  /* wall time of that fallback (re-chaining + the complete procedure) */
-    uint64_t n_ext_unresolved; /* long-read presets: reads beyond the stage's largest working memory, left at their chain-level answer (see the warning) */
+    uint64_t n_ext_unresolved; /* reads beyond the extension stage's working memory (long reads: its largest; sr: 16 384 chains), left at their chain-level answer (see the warning) */
     uint64_t n_rmq_rechained;  /* long-read presets: reads re-chained by the RMQ long join */
     uint64_t n_rmq_tied;       /* ... of which met two candidates of equal priority in the join (the smaller index was taken) */
     uint64_t n_dp_parallel;    /* repeat-path reads whose mg_lchain_dp ran as the parallel recurrence */

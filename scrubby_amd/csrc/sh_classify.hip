@@ -2713,6 +2713,7 @@ __global__ void k_ext_reset(ExtArgs a)
 __global__ __launch_bounds__(64) void k_regs_align(ExtArgs a)
 {
     __shared__ AlignLds Ls;
+    __shared__ uint32_t s_ovf;
     const uint32_t lane = threadIdx.x;
     AlignScratch A;
     align_scratch_carve(A, a.scratch + (unsigned long long)blockIdx.x * a.scratch_per_wave, a.max_read_len, a.reg_cap);
@@ -2720,12 +2721,26 @@ __global__ __launch_bounds__(64) void k_regs_align(ExtArgs a)
     uint32_t n_regions = 0, n_dropped = 0;
     for (;;) {
         uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(a.ticket, 1u);
+        if (lane == 0) { t = atomicAdd(a.ticket, 1u); s_ovf = 0; }
         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
         if (t >= n_list) break;
+        __syncthreads();
         const uint32_t r = a.list[t];
         AlignOut o;
-        if (!align_read_wave(a.in, a.P, r, a.flag_only != 0, A, Ls, o, &a.ctr->ext_overflow, a.top_only ? a.best[r] : 0ull)) continue;
+        if (!align_read_wave(a.in, a.P, r, a.flag_only != 0, A, Ls, o, &s_ovf, a.top_only ? a.best[r] : 0ull)) {
+            // minimap2 has no such limits.  A read with more chains / primaries / regions than the working memory holds (codes 2, 3, 6) keeps
+            // its chain-level answer and is counted (sh_stats.n_ext_unresolved; the host warns); anything else is a sizing error of the call
+            if (lane == 0) {
+                const uint32_t code = s_ovf;
+                if (code == 2u || code == 3u || code == 6u) {
+                    a.flags[r] = 1;
+                    if (a.trace) ((int32_t *)(a.trace + r))[7] = 1;
+                    atomicAdd(&a.ctr->lext_unresolved, 1u); atomicExch(&a.ctr->lext_err_read, r); atomicExch(&a.ctr->lext_err_code, code);
+                } else atomicExch(&a.ctr->ext_overflow, code ? code : 7u);
+            }
+            __syncthreads();
+            continue;
+        }
         if (a.top_only) {      // regs[0] alone: a survivor settles the read, otherwise every chain is needed
             if (lane == 0) {
                 if (o.n_regs > 0) a.flags[r] = 1;
@@ -3189,6 +3204,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         c->sink.tie = (uint32_t *)take(max_reads * 4);
         c->sink.n_recs = c->d_ctr->ext_n_recs; c->sink.n_anch = c->d_ctr->ext_n_anch; c->sink.overflow = &c->d_ctr->ext_overflow;
         c->ext_reg_cap = 16384;
+        if (const char *env = getenv("SCRUBBY_HIP_EXT_REGCAP")) c->ext_reg_cap = (uint32_t)std::max(65, atoi(env));      // tests: chains of a read the full procedure takes
         if (!c->ext_long) {
             c->ext_scratch_per_wave = align_scratch_layout(max_read_len, c->ext_reg_cap, nullptr, nullptr, nullptr);
             const uint64_t budget = 4ull << 30;
@@ -3726,7 +3742,11 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
             SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "extension stage: a read exceeds the per-wave working memory (code %u)", c->h_ctr->ext_overflow);
             ms_fallback = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fb).count();
         }
-        if (stats) { stats->n_ext_fallback += n_fallback; stats->ms_ext_fallback += ms_fallback; }
+        if (stats) { stats->n_ext_fallback += n_fallback; stats->ms_ext_fallback += ms_fallback; stats->n_ext_unresolved += c->h_ctr->lext_unresolved; }
+        if (c->h_ctr->lext_unresolved) {
+            static bool warned_sr = false;
+            if (!warned_sr) { warned_sr = true; fprintf(stderr, "[scrubby-hip] WARNING: %u read(s) outgrew the extension stage's working memory (e.g. read %u of its batch, code %u: 2 chains, 3 primaries, 6 regions); they keep their chain-level answer (mapped)\n", c->h_ctr->lext_unresolved, c->h_ctr->lext_err_read, c->h_ctr->lext_err_code); }
+        }
         SH_HIP(hipEventRecord(c->ev_ext[1], s));
         SH_HIP(hipEventSynchronize(c->ev_ext[1]));
         ext_regions = c->h_ctr->ext_regions; ext_dropped = c->h_ctr->ext_dropped;

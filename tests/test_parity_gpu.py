@@ -645,3 +645,29 @@ def test_parallel_chaining_recurrence_and_read_level_backtrack(S, oracle, monkey
     gf, gt, st, rc = gidx.classify(bases, offs, want_trace=True)             # ... and the recurrence's, cluster by cluster
     assert_trace_equal(S, gf, gt, of, ot)
     assert st["n_dp_parallel"] > 300 and st["n_top_settled"] == 0
+
+
+def test_reads_beyond_the_extension_stages_working_memory_are_counted_not_fatal(S, oracle, monkeypatch):
+    """minimap2 has no limit on the chains of a read; the extension stage's per-wave working memory has (16 384; 70 here, through
+    SCRUBBY_HIP_EXT_REGCAP).  A read beyond it keeps its chain-level answer (mapped), is counted in sh_stats.n_ext_unresolved and named in
+    a warning; every other read of the call is answered as always."""
+    contigs = [700_000, 500_000]
+    Po = oracle.ref_params(0x5C2B0B01, contigs, sat_pct=45, rep_pct=30, n_sat_fam=3, n_rep_fam=20)
+    ref = oracle.synth_ref(Po, 0, Po.genome_len)
+    seqs = [ref[Po.contig_start[i]:Po.contig_start[i + 1]] for i in range(len(contigs))]
+    Ro = oracle.read_params(0x5C2B0B02)
+    n = 3000
+    bases = oracle.synth_reads(Po, Ro, 0, n)
+    offs = np.arange(n + 1, dtype=np.uint64) * 150
+    cidx = oracle.Index.build(seqs, 11, 21)
+    of, ot = cidx.classify(oracle.preset("sr"), bases, offs, threads=8)
+    big = ot["n_chain"] > 70
+    assert 0 < int(big.sum()) < n // 2
+    monkeypatch.setenv("SCRUBBY_HIP_EXT_REGCAP", "70")
+    gidx = S.Index.build([bytes(s) for s in seqs], S.preset("sr"))
+    gf, gt, st, rc = gidx.classify(bases, offs, want_trace=True)
+    assert rc == 0
+    assert st["n_ext_unresolved"] == int(big.sum())
+    assert np.all(gf[big] == 1) and np.array_equal(gf[~big], of[~big])
+    for name in ("n_regs", "n_aligned", "dp_max"):
+        assert np.array_equal(gt[name][~big], ot[name][~big]), name
