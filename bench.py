@@ -283,7 +283,7 @@ def main_reads(a, rank, world, local, dev, backend):
     }
     ext_ms = float(np.mean([s.get("ms_ext", 0.0) for s in stats]))
     if ext_ms > 0:      # SH_F_CIGAR: list building + base-level alignment of the reads no shortcut settles (reads + their reference windows + 40-B chain records)
-        stages["extension stage (k_long_chains + k_regs_align_long)" if ont else "extension stage (k_ext_* + k_regs_align)"] = (ext_ms, 40 * s0.get("n_ext_regions", 0) + 2 * s0["n_bases"] // max(s0["n_reads"], 1) * s0.get("n_ext_reads", 0))
+        stages["extension stage (k_long_chains + k_regs_align_long)" if ont else "extension stage (k_ext_* + k_regs_align)"] = (ext_ms, 40 * s0.get("n_ext_regions", 0) + 2 * (n_bases // max(n_rec, 1)) * s0.get("n_ext_reads", 0))      # mean read length of the batch (a launch's n_bases / n_reads is not it when a step is several launches)
     # the roofline object describes the stage that takes LONGEST.  Round 1 (chain-level decision, --chain-only): k_sketch_probe, one streaming
     # kernel.  With the extension stage (SH_F_CIGAR, the default, what .with_cigar() makes the reference compute) the repeat path leads:
     # a few thousand satellite reads re-chained with max_occ hold most of the anchors, and their sort + sequential DP is latency-bound,
