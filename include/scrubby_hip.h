@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SH_VERSION 101   /* 0.1.1: sh_opts grew the rmq_* fields (round 3); sh_trace has 12 words since 0.1.0's second round */
+#define SH_VERSION 102   /* 0.1.2: sh_stats grew n_locus_* / n_rmq_exact (round 4); 0.1.1: sh_opts grew the rmq_* fields (round 3); sh_trace has 12 words since 0.1.0's second round */
 
 typedef int32_t sh_status;
 enum {
@@ -130,6 +130,9 @@ typedef struct sh_stats {
     uint64_t n_dp_parallel;    /* repeat-path reads whose mg_lchain_dp ran as the parallel recurrence */
     uint64_t n_dp_dirty;       /* ... their anchors that broke its premise (their clusters were chained by the sequential code) */
     uint64_t n_top_settled;    /* ... reads whose candidates for regs[0] were read off the whole read, no cluster visited */
+    uint64_t n_locus_reads;    /* long-read presets, flag-only: reads chained over the reference windows that can hold regs[0] only */
+    uint64_t n_locus_redone;   /* ... of which the answer could depend on what was left out: redone with every anchor */
+    uint64_t n_rmq_exact;      /* long-read presets: reads whose RMQ join was redone on the literal krmq tree (tied priorities, windows beyond the LDS ring, rmq_size_cap) */
 } sh_stats;
 
 typedef struct sh_index sh_index;

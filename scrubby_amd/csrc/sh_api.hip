@@ -209,6 +209,7 @@ extern "C" sh_status sh_classify_batch(const sh_index *idx, const sh_opts *opts,
                 stats->n_ext_reads += ps.n_ext_reads; stats->n_ext_regions += ps.n_ext_regions; stats->n_ext_dropped += ps.n_ext_dropped; stats->ms_ext += ps.ms_ext; stats->n_ext_shortcut += ps.n_ext_shortcut;
                 stats->n_ext_fallback += ps.n_ext_fallback; stats->ms_ext_fallback += ps.ms_ext_fallback; stats->n_ext_unresolved += ps.n_ext_unresolved; stats->n_rmq_rechained += ps.n_rmq_rechained; stats->n_rmq_tied += ps.n_rmq_tied;
                 stats->n_dp_parallel += ps.n_dp_parallel; stats->n_dp_dirty += ps.n_dp_dirty; stats->n_top_settled += ps.n_top_settled;
+                stats->n_locus_reads += ps.n_locus_reads; stats->n_locus_redone += ps.n_locus_redone; stats->n_rmq_exact += ps.n_rmq_exact;
             }
         }
     });

@@ -57,6 +57,12 @@
 #define N_SORT_CLS 6             // LDS classes <= 256, 512, 1024, 2048, 4096 anchors (block LDS sized to the class: occupancy), then giant
 #define SORT_CLS_GIANT 5
 #define GT 2048u                 // tile of the giant-read merge sort
+// k_lr_locus (long-read presets, flag-only): reads of up to LOCUS_N0 / LOCUS_N1 / LOCUS_MAX_N anchors count their anchors per reference
+// window in 2^12 / 2^14 / 2^15 sixteen-bit counters of LDS; a run of more than LOCUS_RUN_MAX occupied windows is kept whatever it holds
+#define LOCUS_N0 1024u
+#define LOCUS_N1 4096u
+#define LOCUS_MAX_N 65535u
+#define LOCUS_RUN_MAX 16
 
 __device__ inline uint32_t lane_id() { return threadIdx.x & 63; }
 
@@ -85,6 +91,10 @@ struct Counters {
     uint32_t sh_host[64], sh_clusters[64], sh_pair[64];      // sh_pair: reads decided by the pair test
     uint32_t sh_pf_reads[64], sh_pf_dirty[64], sh_top[64];   // reads chained by par_fill_block / _tiled, their dirty anchors, reads settled by backtrack_block_top
     uint32_t sh_lemma[64];       // SH_F_CIGAR flag-only: reads decided inside a chaining kernel (top chain + chain_lemma)
+    // long-read presets, flag-only: anchors pre-selected by locus (k_lr_locus) - reads listed per table size, reads with anchors dropped,
+    // anchors kept, reads that must be redone with every anchor (lr_fb list)
+    uint32_t n_locus[3], locus_ticket[3], lr_n_fb, lr_locus_reads; unsigned long long lr_locus_in, lr_locus_kept;
+    uint32_t lr_fb_why[8], lr_fb_had, lr_pad;
 };
 #define SHARD() ((blockIdx.x + (blockIdx.x >> 6)) & 63)
 
@@ -1483,6 +1493,9 @@ struct K3Args {
     int32_t quiet;                     // a second visit of reads that were counted already: no statistics
     uint32_t pft_gmin;                 // par_fill_tiled: reads of this many anchors get eight lanes per anchor (SCRUBBY_HIP_PFT_GMIN, tests)
     int32_t top_max;                   // backtrack_block_top: candidates a read may have at its top score (<= TOPBT_MAX; SCRUBBY_HIP_TOPBT_MAX, tests)
+    // long-read presets, flag-only with the extension filter: k_expand lists reads of more than 64 anchors here instead of in the sort
+    // classes, k_lr_locus keeps the anchors of the reference windows that can hold regs[0] and passes the read on
+    SortItem *locus_items[3]; uint32_t *lr_drop; int32_t locus, locus_shift;
 };
 
 
@@ -1854,6 +1867,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (lane == 0) { a.B.acc_nu[w] = n_u; a.B.acc_best[w] = best; }
             if ((a.dbg & 16) && lane == 0) { atomicAdd(&a.ctr->sort_tot[N_SORT_CLS], 1ull); atomicAdd(&a.ctr->sort_anchor_tot[N_SORT_CLS], (unsigned long long)n_a); }
             __syncthreads();
+        } else if (LONG && a.locus && n_a <= LOCUS_MAX_N) {
+            // the anchors are in the arena; k_lr_locus decides which of them can matter and lists the read in a sort class
+            const int lc = n_a <= LOCUS_N0 ? 0 : (n_a <= LOCUS_N1 ? 1 : 2);
+            if (lane == 0) { const uint32_t li = atomicAdd(&a.ctr->n_locus[lc], 1u); SortItem it{w, n_a, (uint32_t)qlen, 0, off}; a.locus_items[lc][li] = it; }
         } else {
             const int cls = n_a <= 256 ? 0 : (n_a <= SORT_LDS_A ? 1 : (n_a <= 1024 ? 2 : (n_a <= SORT_LDS_B ? 3 : (n_a <= SORT_LDS_C ? 4 : SORT_CLS_GIANT))));
             uint32_t lo, hi;
@@ -1871,6 +1888,100 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if (lane == 0 && n_clusters) atomicAdd(&a.ctr->sh_clusters[SHARD()], n_clusters);
     if (lane == 0 && n_pair) atomicAdd(&a.ctr->sh_pair[SHARD()], n_pair);
     if (lane == 0 && n_lemma) atomicAdd(&a.ctr->sh_lemma[SHARD()], n_lemma);
+}
+
+// ---- long-read presets, flag-only with the extension filter: which anchors can matter --------------------------------------
+// The boundary returns mappings.len() > 0 (cleaner.rs:552-556), and the extension stage proves "mapped" from regs[0] - the chain of largest
+// score after mm_map_frag's two chaining passes - alone (lr_probe_region).  Both passes work inside CLUSTERS: anchors of one strand and contig
+// whose reference positions lie no further apart than D = max(mg_lchain_dp's max_dist_x, mg_lchain_rmq's max_dist); neither links two anchors
+// across a wider gap, their windows, marks and backtracks never reach across it, and a chain gains at most k per anchor.  So a cluster of c
+// anchors holds no chain scoring more than k * c, in either pass, and leaving WHOLE clusters out changes nothing about the chains of the
+// others.  One block per read counts the anchors per reference window of 2^shift >= D bases (sixteen-bit counters in LDS, addressed by a hash
+// of the window: a collision only makes a count too large), takes for every anchor the total of the run of occupied windows around its own -
+// an upper bound of its cluster's size, the same for every anchor of a cluster - and keeps the anchors whose bound reaches T: the three largest
+// bounds of the read, and everything within an eighth of the largest.  What is dropped is remembered per read as the largest bound dropped
+// (lr_drop); the chains kernel of the extension stage checks afterwards that the answer cannot depend on it (lr_chains_wave) and sends the
+// read through the complete path otherwise.  The survivors keep their generation order, so equal reference positions sort as before.
+template <int LG>
+__global__ __launch_bounds__(256) void k_lr_locus(K3Args a, int lc)
+{
+    __shared__ uint32_t s_tab[1u << (LG - 1)];
+    __shared__ uint32_t s_it, s_w[4][4], s_wcnt[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n_items = a.ctr->n_locus[lc];
+    const int sh = a.locus_shift;
+    const uint32_t min_cnt = (uint32_t)(a.P.min_cnt > 1 ? a.P.min_cnt : 1);
+    auto bin_of = [&](uint64_t x) -> uint64_t { return (x >> 32) << 24 | (uint64_t)((uint32_t)x >> sh); };      // window id; id +- 1 = the neighbouring window (never another contig's: shift >= 9)
+    auto slot = [&](uint64_t id) -> uint32_t { return (uint32_t)((id * 0x9E3779B97F4A7C15ull) >> (64 - LG)); };
+    auto cnt_of = [&](uint64_t id) -> uint32_t { const uint32_t h = slot(id); return (s_tab[h >> 1] >> ((h & 1u) << 4)) & 0xffffu; };
+    auto block_max = [&](uint32_t v, int k) -> uint32_t {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, o); v = t > v ? t : v; }
+        if (lane == 0) s_w[k][wave] = v;
+        __syncthreads();
+        return max(max(s_w[k][0], s_w[k][1]), max(s_w[k][2], s_w[k][3]));
+    };
+    unsigned long long st_in = 0, st_kept = 0; uint32_t st_reads = 0;
+    for (;;) {
+        if (tid == 0) s_it = atomicAdd(&a.ctr->locus_ticket[lc], 1u);
+        __syncthreads();
+        const uint32_t it = s_it;
+        __syncthreads();
+        if (it >= n_items) break;
+        const SortItem si = a.locus_items[lc][it];
+        const uint32_t n = si.n;
+        uint64_t *gx = a.B.ax + si.off; uint32_t *gq = a.B.aq + si.off; int32_t *gv = a.B.af + si.off;
+        for (uint32_t i = tid; i < (1u << (LG - 1)); i += 256) s_tab[i] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += 256) { const uint32_t h = slot(bin_of(gx[i])); atomicAdd(&s_tab[h >> 1], 1u << ((h & 1u) << 4)); }      // n <= 65535: no carry
+        __syncthreads();
+        uint32_t t1 = 0, t2 = 0, t3 = 0;      // this thread's three largest distinct bounds
+        for (uint32_t i = tid; i < n; i += 256) {
+            const uint64_t id = bin_of(gx[i]);
+            uint32_t vr = cnt_of(id);
+            int len = 1; bool inf = false;
+            for (int d = 1;; ++d) { if (d > LOCUS_RUN_MAX) { inf = true; break; } const uint32_t c = cnt_of(id - (uint64_t)d); if (!c) break; vr += c; ++len; }
+            if (!inf) for (int d = 1;; ++d) { if (d > LOCUS_RUN_MAX) { inf = true; break; } const uint32_t c = cnt_of(id + (uint64_t)d); if (!c) break; vr += c; ++len; }
+            if (inf || len > LOCUS_RUN_MAX) vr = 0x7fffffffu;      // a run of more than LOCUS_RUN_MAX windows (the same verdict from each of them): kept
+            gv[i] = (int32_t)vr;
+            if (vr > t1) { t3 = t2; t2 = t1; t1 = vr; } else if (vr < t1 && vr > t2) { t3 = t2; t2 = vr; } else if (vr < t2 && vr > t3) t3 = vr;
+        }
+        const uint32_t V1 = block_max(t1, 0);
+        const uint32_t V2 = block_max(t1 < V1 ? t1 : t2, 1);
+        const uint32_t V3 = block_max(t1 < V2 ? t1 : (t2 < V2 ? t2 : t3), 2);
+        uint32_t T = V3 < (V1 >> 3) ? V3 : (V1 >> 3);
+        if (a.dbg & 1024) T = V1;      // tests (SCRUBBY_HIP_LOCUS_TOP1): the largest run only - reads with a second locus must be caught and redone
+        if (T < min_cnt) T = min_cnt;
+        uint32_t base = 0, dmax = 0;
+        for (uint32_t c0 = 0; c0 < n; c0 += 256) {      // stable compaction in place: a chunk is read, then written at or before where it was
+            const uint32_t i = c0 + tid;
+            uint64_t x = 0; uint32_t q = 0; bool keep = false;
+            if (i < n) { const uint32_t vr = (uint32_t)gv[i]; keep = vr >= T; if (keep) { x = gx[i]; q = gq[i]; } else if (vr > dmax) dmax = vr; }
+            const uint64_t km = __ballot(keep);
+            if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(km);
+            __syncthreads();
+            uint32_t woff = 0, tot = 0;
+#pragma unroll
+            for (uint32_t w2 = 0; w2 < 4; ++w2) { const uint32_t c = s_wcnt[w2]; if (w2 < wave) woff += c; tot += c; }
+            if (keep) { const uint32_t d = base + woff + prefix_popc(km); gx[d] = x; gq[d] = q; }
+            base += tot;
+            __syncthreads();
+        }
+        dmax = block_max(dmax, 3);
+        if (tid == 0) {
+            a.lr_drop[a.B.meta[si.w].r] = dmax;      // 0: every anchor kept
+            if (base > 0) {
+                const int cls = base <= 256 ? 0 : (base <= SORT_LDS_A ? 1 : (base <= 1024 ? 2 : (base <= SORT_LDS_B ? 3 : (base <= SORT_LDS_C ? 4 : SORT_CLS_GIANT))));
+                const uint32_t oi = atomicAdd(&a.ctr->n_sort[cls], 1u);
+                SortItem o{si.w, base, si.qlen, 0, si.off};
+                a.B.tabs->sort_items[cls][oi] = o;
+                if (a.dbg & 16) { atomicAdd(&a.ctr->sort_tot[cls], 1ull); atomicAdd(&a.ctr->sort_anchor_tot[cls], (unsigned long long)base); }
+            }
+            st_in += n; st_kept += base; st_reads += dmax != 0;
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && st_in) { atomicAdd(&a.ctr->lr_locus_in, st_in); atomicAdd(&a.ctr->lr_locus_kept, st_kept); if (st_reads) atomicAdd(&a.ctr->lr_locus_reads, st_reads); }
 }
 
 // stable block merge sort: 64-element tiles ranked in registers (one tile per wave at a time), then merge-path
@@ -2517,7 +2628,7 @@ __global__ void k_finalize(K3Args a)
         write_trace(a.trace, m.r, (int32_t)(info & 0xffffu), (int32_t)(a.seed_off ? info >> 16 : (info >> 16 & 0x7fffu)), (int32_t)m.n_a, m.rep_len, a.pass, n_u, best, fl);
         n_host_thr += (uint32_t)fl;
     }
-    if (n_host_thr && !a.quiet) atomicAdd(&a.ctr->sh_host[(blockIdx.x + threadIdx.x) & 63], n_host_thr);
+    if (n_host_thr && a.quiet != 1) atomicAdd(&a.ctr->sh_host[(blockIdx.x + threadIdx.x) & 63], n_host_thr);      // quiet == 2: reads whose earlier visit was taken back (k_lext_forget)
 }
 
 __device__ inline uint8_t *arena_alloc(const K2Args &a, size_t bytes)
@@ -2642,7 +2753,7 @@ __global__ __launch_bounds__(64) void k_chain_large(K2Args a)
             }
         }
         uint64_t mh = __ballot(host);
-        if (lane == 0 && mh && !a.quiet) atomicAdd(&a.ctr->sh_host[SHARD()], (uint32_t)__popcll(mh));
+        if (lane == 0 && mh && a.quiet != 1) atomicAdd(&a.ctr->sh_host[SHARD()], (uint32_t)__popcll(mh));
     }
 }
 
@@ -2804,6 +2915,7 @@ struct ExtLongArgs {
     uint8_t *scratch; unsigned long long scratch_per_wave; LongSizes sz; LongArena AR;
     uint32_t *list; uint32_t *n_list, *ticket; uint32_t *big_list; uint32_t *n_big; Counters *ctr; uint8_t *flags; sh_trace *trace; int32_t flag_only, clk, probe;
     const uint32_t *hist; int32_t bin_cut, part;      // the size-ordered list's giants (bins >= bin_cut) come first: part 1 = all but them, 2 = only them, 0 = the whole list
+    const uint32_t *drop; uint32_t *fb_list, *n_fb;   // k_lr_locus: what was left out of a read's anchors; reads that must be redone with every anchor
 };
 
 // Largest reads first: a read's cost grows with its chain anchors (one with 70 k of them keeps a wave busy for a third of a second), and a
@@ -2831,6 +2943,38 @@ __global__ void k_lext_scatter(const uint32_t *list, const uint32_t *n_list, con
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[atomicAdd(&hist[32 + size_of[i]], 1u)] = list[i];
 }
 
+// the stage's list: every read with a chain; a read without one among the anchors k_lr_locus kept, but with a cluster left out that could
+// hold one (drop >= min_cnt), is redone with every anchor
+__global__ void k_lext_list(ExtArgs a, const uint32_t *drop, uint32_t min_cnt, uint32_t *fb_list, uint32_t *n_fb)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool has = r < a.n_reads && a.in.head[r] != ~0u;
+    const uint32_t li = wave_append(a.n_list, has);
+    if (has) a.list[li] = (uint32_t)r;
+    const bool redo = r < a.n_reads && !has && drop != nullptr && drop[r] >= min_cnt;
+    const uint32_t fi = wave_append(n_fb, redo);
+    if (redo) { fb_list[fi] = (uint32_t)r; atomicAdd(&a.ctr->lr_fb_why[6], 1u); }
+}
+// second round: the reads of `from` that have a chain now
+__global__ void k_lext_list_from(ExtArgs a, const uint32_t *from, const uint32_t *n_from)
+{
+    const uint32_t n = *n_from;
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint32_t r = i < n ? from[i] : 0u;
+        const bool has = i < n && a.in.head[r] != ~0u;
+        const uint32_t li = wave_append(a.n_list, has);
+        if (has) a.list[li] = r;
+    }
+}
+// reads about to be chained again: no chains, nothing left out
+__global__ void k_lext_forget(const uint32_t *list, uint32_t n, uint32_t *head, uint32_t *drop, uint32_t *n_had_chain)
+{
+    uint32_t had = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const uint32_t r = list[i]; had += head[r] != ~0u; head[r] = ~0u; drop[r] = 0u; }
+    if (had) atomicAdd(n_had_chain, had);      // k_finalize counted them as mapped at chain level; it will count them again
+}
+
 // a read that outgrew the pass: to the pass with the large working memory, or - beyond that too - it keeps its chain-level answer and is counted
 __device__ inline void lext_defer(const ExtLongArgs &a, uint32_t r, uint32_t code, bool has_hdr)
 {
@@ -2839,6 +2983,14 @@ __device__ inline void lext_defer(const ExtLongArgs &a, uint32_t r, uint32_t cod
     if (a.trace) ((int32_t *)(a.trace + r))[7] = 1;
     if (!has_hdr) { LongHdr h{0ull, -1, 0, 0, 0}; a.AR.hdr[r] = h; }
     atomicAdd(&a.ctr->lext_unresolved, 1u); atomicExch(&a.ctr->lext_err_read, r); atomicExch(&a.ctr->lext_err_code, code);
+}
+
+// a read k_lr_locus thinned out and whose answer may depend on what was left out: to the list of reads that take the complete path
+__device__ inline void lext_redo(const ExtLongArgs &a, uint32_t r, uint32_t why)
+{
+    a.fb_list[atomicAdd(a.n_fb, 1u)] = r;
+    LongHdr h{0ull, -1, 0, 0, 0}; a.AR.hdr[r] = h;
+    atomicAdd(&a.ctr->lr_fb_why[why >= 40u && why < 48u ? why - 40u : 7u], 1u);
 }
 
 template <int NR>
@@ -2869,9 +3021,10 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
         C.sc_mch = C.sc_mis = C.sc_amb = C.sc_N = 0; C.need_big = false; C.err = 0; C.clk = a.clk ? &clk : nullptr;
         LongOut o;
         const unsigned long long t_r0 = a.clk ? wall_clock64() : 0ull;
-        const int32_t rc = lr_chains_wave<NR>(C, RL, AR_l, o);
+        const int32_t rc = lr_chains_wave<NR>(C, RL, AR_l, o, a.drop ? a.drop[r] : 0u);
         if (a.clk && lane == 0) { const unsigned long long dt = wall_clock64() - t_r0; atomicMax(&a.ctr->lext_slow, dt << 24 | (unsigned long long)(o.n_chain > 0xffffff ? 0xffffff : o.n_chain)); atomicAdd(&a.ctr->lext_kernel_sum, dt); }
         if (rc == 4) { if (lane == 0) atomicExch(&a.ctr->ext_overflow, 1u); }      // arena full: the host cuts the chunk in two
+        else if (rc == 5) { if (lane == 0) lext_redo(a, r, C.err); }
         else if (rc != 0) { if (lane == 0) lext_defer(a, r, 16u + C.err, false); }
         else { n_rechain += (o.rechained & 2) != 0; n_tie += o.rmq_tie != 0; }
         __syncthreads();
@@ -2910,7 +3063,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         C.need_big = false; C.err = 0; C.clk = a.clk ? &clk : nullptr;
         LongOut o;
         const int32_t rc = lr_regs_wave(C, CP_l, AR_l, a.flag_only != 0, a.probe != 0, o);
-        if (rc != 0) { if (lane == 0) lext_defer(a, r, rc == 1 ? 32u : 16u + C.err, true); }
+        if (rc == 5) {
+            if (lane == 0) {      // counted again when the read comes back with all its anchors
+                const int32_t rch = AR_l.hdr[r].rechained;
+                if (rch & 2) atomicSub(&a.ctr->lext_rechained, 1u);
+                if (rch & 4) atomicSub(&a.ctr->lext_rmq_tie, 1u);
+                lext_redo(a, r, C.err);
+            }
+        }
+        else if (rc != 0) { if (lane == 0) lext_defer(a, r, rc == 1 ? 32u : 16u + C.err, true); }
         else if (lane == 0) {
             a.flags[r] = o.n_regs > 0 ? 1 : 0;
             if (a.trace) {
@@ -2919,7 +3080,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 ((int4 *)tr)[2] = make_int4(o.n_aligned, o.n_regs, o.dp_max, (int32_t)o.sig);
             }
         }
-        if (rc == 0) { n_regions += (uint32_t)o.n_aligned; n_dropped += o.n_regs == 0 && o.n_chain > 0; n_probed += (uint32_t)o.probed; }
+        if (rc == 0) { n_regions += (uint32_t)o.n_aligned; n_dropped += o.n_regs == 0; n_probed += (uint32_t)o.probed; }      // every read of the list had a chain: also one the long join left without
         __syncthreads();
     }
     if (lane == 0) {
@@ -2973,6 +3134,8 @@ struct sh_ctx {
     uint8_t *d_lext[4] = {}; unsigned long long lext_per_wave[4] = {}; uint32_t lext_waves[4] = {}; LongSizes lext_sz[4] = {};      // [phase * 2 + tier]
     uint32_t *d_lext_big = nullptr, *d_lext_big2 = nullptr, *d_lext_sorted = nullptr;
     uint8_t *d_larena = nullptr; unsigned long long larena_bytes = 0; LongHdr *d_lhdr = nullptr;
+    // flag-only calls: anchors pre-selected by locus (k_lr_locus) - its read lists, what it left out per read, the reads to redo in full
+    SortItem *d_locus[3] = {}; uint32_t *d_lr_drop = nullptr, *d_lr_fb = nullptr; int locus_shift = 0;
     hipStream_t sx[4] = {};          // side streams: K2 and the sort classes run beside the main stream
     int par = 1;                     // bit 0: K2 on a side stream (SCRUBBY_HIP_STREAMS=0: on the main stream)
     hipEvent_t evx[6] = {};
@@ -3246,6 +3409,15 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             c->larena_bytes = SINK_SHARDS * cap_anch * 16 + SINK_SHARDS * cap_recs * 12 + max_reads * 32 + (1ull << 20);
             if ((e = hipMalloc(&c->d_larena, c->larena_bytes)) != hipSuccess) return fail(e, "long-read extension-stage arena");
             if ((e = hipMalloc(&c->d_lhdr, max_reads * sizeof(LongHdr))) != hipSuccess) return fail(e, "long-read extension-stage headers");
+            for (auto &q : c->d_locus) if ((e = hipMalloc(&q, max_reads * sizeof(SortItem))) != hipSuccess) return fail(e, "long-read locus lists");
+            if ((e = hipMalloc(&c->d_lr_drop, max_reads * 4)) != hipSuccess) return fail(e, "long-read locus table");
+            if ((e = hipMalloc(&c->d_lr_fb, max_reads * 4)) != hipSuccess) return fail(e, "long-read locus list");
+            {   // reference windows of 2^shift bases, at least as wide as the widest gap either chaining pass links across
+                const int32_t D = std::max({opts->max_gap, opts->max_gap_ref, opts->bw, opts->bw_long, 1});
+                int sh = 9;
+                while (sh < 31 && (1ll << sh) < (long long)D) ++sh;
+                c->locus_shift = sh;
+            }
         }
         for (auto &ev : c->ev_ext) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "event");
     }
@@ -3275,7 +3447,7 @@ extern "C" sh_status sh_ctx_destroy(sh_ctx *c)
     hipFree(c->d_work_defer); hipFree(c->d_work_defer2);
     for (auto &pp : c->d_big) for (auto p : pp) hipFree(p);
     hipFree(c->d_ctr); if (c->h_ctr) hipHostFree(c->h_ctr); hipFree(c->d_arena); hipFree(c->d_long);
-    hipFree(c->d_ext); hipFree(c->d_ext_scratch); for (auto q : c->d_lext) hipFree(q); hipFree(c->d_lext_big); hipFree(c->d_lext_big2); hipFree(c->d_lext_sorted); hipFree(c->d_larena); hipFree(c->d_lhdr);
+    hipFree(c->d_ext); hipFree(c->d_ext_scratch); for (auto q : c->d_lext) hipFree(q); hipFree(c->d_lext_big); hipFree(c->d_lext_big2); hipFree(c->d_lext_sorted); hipFree(c->d_larena); hipFree(c->d_lhdr); for (auto q : c->d_locus) hipFree(q); hipFree(c->d_lr_drop); hipFree(c->d_lr_fb);
     for (auto ev : c->ev_ext) if (ev) hipEventDestroy(ev);
     for (auto ev : c->ev) if (ev) hipEventDestroy(ev);
     for (auto ev : c->evx) if (ev) hipEventDestroy(ev);
@@ -3313,8 +3485,14 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     SH_HIP(hipMemsetAsync(&ctr->expand_ticket, 0, 4, s));
     SH_HIP(hipMemsetAsync(&ctr->n_cl[0], 0, 4 * 6, s));
     // 6144 waves for 4096 resident (103 VGPRs: 4 per SIMD): measured best; 4096 or 5120 waves, or 5 waves per SIMD at 96 VGPRs, are 0-3 % slower
+    if (k.locus) SH_HIP(hipMemsetAsync(&ctr->n_locus[0], 0, 4 * 6, s));
     if (k.seed_off) hipLaunchKernelGGL(k_expand<true>, dim3(grid * 3), dim3(64), 0, s, k);
     else hipLaunchKernelGGL(k_expand<false>, dim3(grid * 3), dim3(64), 0, s, k);
+    if (k.locus && k.seed_off) {      // long-read presets, flag-only: only the anchors that can hold regs[0] reach the sort classes
+        hipLaunchKernelGGL(k_lr_locus<12>, dim3(256 * 8), dim3(256), 0, s, k, 0);
+        hipLaunchKernelGGL(k_lr_locus<14>, dim3(256 * 5), dim3(256), 0, s, k, 1);
+        hipLaunchKernelGGL(k_lr_locus<15>, dim3(256 * 2), dim3(256), 0, s, k, 2);
+    }
     // the sort classes run one after the other.  Side by side (streams sx[0..2]) measured 9 % slower when they carried the whole repeat
     // path (they fight for LDS); that mode predates k_group_probe, which the class-4 and giant kernels must follow: it stays off.
     static const int side_env = getenv("SCRUBBY_HIP_SIDE") ? atoi(getenv("SCRUBBY_HIP_SIDE")) : -1;
@@ -3469,7 +3647,16 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     if (const char *env = getenv("SCRUBBY_HIP_PFT_GMIN")) k.pft_gmin = (uint32_t)std::max(1, atoi(env));
     if (const char *env = getenv("SCRUBBY_HIP_TOPBT_MAX")) k.top_max = std::max(1, std::min(TOPBT_MAX, atoi(env)));
     if (getenv("SCRUBBY_HIP_NO_TOPBT")) k.dbg |= 512;        // A/B: clusters visited one by one even when the read's DP is done
+    if (getenv("SCRUBBY_HIP_LOCUS_TOP1")) k.dbg |= 1024;     // tests: k_lr_locus keeps the largest run of windows only
     k.resketch_list = c->d_work_resketch;
+    // long-read presets, flag-only: the anchors that cannot hold regs[0] never reach the sort classes (k_lr_locus).  Needs the probe (a read
+    // with anchors left out is only ever proven mapped by it), a single chaining pass (max_occ <= mid_occ: whether mm_map_frag chains again
+    // must not hinge on chains left out) and windows narrow enough to tell loci apart
+    k.locus = c->ext_long && c->use_long && d_trace == nullptr && !getenv("SCRUBBY_HIP_NO_LOCUS") && !getenv("SCRUBBY_HIP_NO_PROBE") &&
+              c->opts.max_clip_ratio >= 1.0f && c->P.max_occ <= c->P.mid_occ && c->locus_shift <= 20 && c->opts.min_cnt >= 1;
+    k.locus_shift = c->locus_shift; k.lr_drop = c->d_lr_drop;
+    for (int i = 0; i < 3; ++i) k.locus_items[i] = c->d_locus[i];
+    if (c->ext_long) SH_HIP(hipMemsetAsync(c->d_lr_drop, 0, n_reads * 4, s));
     uint32_t resk_done = 0;
     // pass 0 (mid_occ) over the reads K2 routed, pass 1 (max_occ) over the reads pass 0 could not chain;
     // reads that found no arena room come back in the next iteration
@@ -3539,23 +3726,27 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     { sh_status st = run_repeat_path(k, b, cur0, cur1, resk_done); if (st != SH_OK) return st; }
     SH_HIP(hipEventRecord(c->ev[3], s));
 
-    // legacy path deferrals
-    uint32_t n_defer = c->h_ctr->n_defer;
-    int rounds = 0;
-    while (n_defer > 0) {
-        SH_CHECK(++rounds < 64, SH_ERR_OOM, "re-sketch arena too small; set SCRUBBY_HIP_ARENA_MB");
-        std::swap(c->d_work_defer, c->d_work_defer2);
-        Counters z = *c->h_ctr;
-        z.n_defer = 0; z.arena_cursor = 0; z.n_resketch = n_defer;
-        SH_HIP(hipMemcpyAsync(c->d_ctr, &z, sizeof(Counters), hipMemcpyHostToDevice, s));
-        b.work = c->d_work_defer2; b.work_count = &c->d_ctr->n_resketch; b.work_begin = 0; b.work_defer = c->d_work_defer;
-        hipLaunchKernelGGL(k_chain_large, dim3(grid), dim3(64), 0, s, b);
-        SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
-        SH_HIP(hipStreamSynchronize(s));
-        uint32_t nd = c->h_ctr->n_defer;
-        SH_CHECK(nd < n_defer, SH_ERR_OOM, "re-sketch arena too small; set SCRUBBY_HIP_ARENA_MB");
-        n_defer = nd;
-    }
+    // legacy path deferrals: reads of k_chain_large that found no room in its arena slice come back alone
+    auto legacy_defers = [&](K2Args &bb) -> sh_status {
+        uint32_t n_defer = c->h_ctr->n_defer;
+        int rounds = 0;
+        while (n_defer > 0) {
+            SH_CHECK(++rounds < 64, SH_ERR_OOM, "re-sketch arena too small; set SCRUBBY_HIP_ARENA_MB");
+            std::swap(c->d_work_defer, c->d_work_defer2);
+            Counters z = *c->h_ctr;
+            z.n_defer = 0; z.arena_cursor = 0; z.n_resketch = n_defer;
+            SH_HIP(hipMemcpyAsync(c->d_ctr, &z, sizeof(Counters), hipMemcpyHostToDevice, s));
+            bb.work = c->d_work_defer2; bb.work_count = &c->d_ctr->n_resketch; bb.work_begin = 0; bb.work_defer = c->d_work_defer;
+            hipLaunchKernelGGL(k_chain_large, dim3(grid), dim3(64), 0, s, bb);
+            SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+            SH_HIP(hipStreamSynchronize(s));
+            uint32_t nd = c->h_ctr->n_defer;
+            SH_CHECK(nd < n_defer, SH_ERR_OOM, "re-sketch arena too small; set SCRUBBY_HIP_ARENA_MB");
+            n_defer = nd;
+        }
+        return SH_OK;
+    };
+    { sh_status st = legacy_defers(b); if (st != SH_OK) return st; }
     uint32_t ext_list = 0, ext_regions = 0, ext_dropped = 0;
     float ms_ext = 0;
     if (c->ext_long) {
@@ -3567,75 +3758,109 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         x.AR.base = c->d_larena; x.AR.cap = c->larena_bytes; x.AR.cursor = &c->d_ctr->arena_cursor; x.AR.hdr = c->d_lhdr;
         x.list = c->d_ext_list; x.n_list = &c->d_ctr->ext_n_list; x.ctr = c->d_ctr; x.flags = d_flags; x.trace = d_trace; x.flag_only = d_trace == nullptr;
         x.clk = getenv("SCRUBBY_HIP_DBG") ? 1 : 0; x.probe = getenv("SCRUBBY_HIP_NO_PROBE") ? 0 : 1;
+        x.drop = k.locus ? c->d_lr_drop : nullptr; x.fb_list = c->d_lr_fb; x.n_fb = &c->d_ctr->lr_n_fb;
         SH_HIP(hipEventRecord(c->ev_ext[0], s));
-        SH_HIP(hipMemsetAsync(&c->d_ctr->arena_cursor, 0, 8, s));
-        {
-            ExtArgs xl{};
-            xl.in = x.I.in; xl.list = x.list; xl.n_list = x.n_list; xl.n_reads = n_reads;
-            hipLaunchKernelGGL(k_ext_list, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, s, xl);
-            // largest reads first (d_ext_redo: bin of each list entry; d_lext_big2: the ordered list, free until the second kernel's first pass ends)
-            hipLaunchKernelGGL(k_lext_bins, dim3(256), dim3(256), 0, s, c->sink.recs, c->sink.head, c->d_ext_list, &c->d_ctr->ext_n_list, c->d_ext_redo, c->d_ctr->lext_hist);
-            hipLaunchKernelGGL(k_lext_scan, dim3(1), dim3(1), 0, s, c->d_ctr->lext_hist);
-            hipLaunchKernelGGL(k_lext_scatter, dim3(256), dim3(256), 0, s, c->d_ext_list, &c->d_ctr->ext_n_list, c->d_ext_redo, c->d_ctr->lext_hist, c->d_lext_sorted);
-            x.list = c->d_lext_sorted;
-        }
         auto sync_ctr = [&]() -> sh_status {
             SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
             SH_HIP(hipStreamSynchronize(s));
             SH_HIP(hipGetLastError());
             return SH_OK;
         };
-        // first kernel: final chains (tier 0, then the reads that outgrew it with the large working memory)
-        {
-            ExtLongArgs xa = x;
-            xa.scratch = c->d_lext[0]; xa.scratch_per_wave = c->lext_per_wave[0]; xa.sz = c->lext_sz[0];
-            xa.ticket = &c->d_ctr->ext_ticket; xa.big_list = c->d_lext_big; xa.n_big = &c->d_ctr->lext_n_big;
-            // reads whose chain anchors outgrow the first size go straight to the large working memory, on a side stream beside the rest
-            int bin_cut = 0;
-            while (bin_cut < 31 && (2ull << bin_cut) <= c->lext_sz[0].cap_a) ++bin_cut;      // bin b holds totals in [2^b, 2^(b+1))
-            xa.hist = c->d_ctr->lext_hist; xa.bin_cut = bin_cut; xa.part = 1;
-            ExtLongArgs xg = xa;
-            xg.scratch = c->d_lext[1]; xg.scratch_per_wave = c->lext_per_wave[1]; xg.sz = c->lext_sz[1];
-            xg.ticket = &c->d_ctr->lext_ticket_g; xg.part = 2;      // same ring as the others (19 KB of LDS: they share CUs); what outgrows the ring joins the big list
-            SH_HIP(hipEventRecord(c->evx[0], s));
-            SH_HIP(hipStreamWaitEvent(c->sx[0], c->evx[0], 0));
-            hipLaunchKernelGGL(k_long_chains<512>, dim3(c->lext_waves[1]), dim3(64), 0, c->sx[0], xg);
-            SH_HIP(hipEventRecord(c->evx[1], c->sx[0]));
-            hipLaunchKernelGGL(k_long_chains<512>, dim3(c->lext_waves[0]), dim3(64), 0, s, xa);
-            SH_HIP(hipStreamWaitEvent(s, c->evx[1], 0));
-            sh_status st = sync_ctr(); if (st != SH_OK) return st;
-            if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;       // hand-over buffers or arena full: the caller cuts the chunk in two
-            if (c->h_ctr->lext_n_big > 0) {
-                xa.scratch = c->d_lext[1]; xa.scratch_per_wave = c->lext_per_wave[1]; xa.sz = c->lext_sz[1];
-                xa.list = c->d_lext_big; xa.n_list = &c->d_ctr->lext_n_big; xa.ticket = &c->d_ctr->lext_ticket_big; xa.big_list = nullptr; xa.n_big = nullptr; xa.part = 0;
-                hipLaunchKernelGGL(k_long_chains<4096>, dim3(c->lext_waves[1]), dim3(64), 0, s, xa);
-                st = sync_ctr(); if (st != SH_OK) return st;
-                if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
+        uint32_t n_big_a = 0;
+        // One round of the stage: round 0 over every read with a chain; round 1 - flag-only calls whose anchors k_lr_locus thinned out - over the
+        // reads whose answer could depend on what was left out, after the repeat path has chained them again with every anchor
+        auto ext_round = [&](int round) -> sh_status {
+            SH_HIP(hipMemsetAsync(&c->d_ctr->arena_cursor, 0, 8, s));
+            {
+                ExtArgs xl{};
+                xl.in = x.I.in; xl.list = c->d_ext_list; xl.n_list = x.n_list; xl.n_reads = n_reads; xl.ctr = c->d_ctr;
+                if (round == 0) hipLaunchKernelGGL(k_lext_list, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, s, xl, x.drop, (uint32_t)std::max(1, c->LP.min_cnt), x.fb_list, x.n_fb);
+                else hipLaunchKernelGGL(k_lext_list_from, dim3(256), dim3(256), 0, s, xl, (const uint32_t *)c->d_lr_fb, (const uint32_t *)&c->d_ctr->lr_n_fb);
+                // largest reads first (d_ext_redo: bin of each list entry; d_lext_big2: the ordered list, free until the second kernel's first pass ends)
+                hipLaunchKernelGGL(k_lext_bins, dim3(256), dim3(256), 0, s, c->sink.recs, c->sink.head, c->d_ext_list, &c->d_ctr->ext_n_list, c->d_ext_redo, c->d_ctr->lext_hist);
+                hipLaunchKernelGGL(k_lext_scan, dim3(1), dim3(1), 0, s, c->d_ctr->lext_hist);
+                hipLaunchKernelGGL(k_lext_scatter, dim3(256), dim3(256), 0, s, c->d_ext_list, &c->d_ctr->ext_n_list, c->d_ext_redo, c->d_ctr->lext_hist, c->d_lext_sorted);
+                x.list = c->d_lext_sorted;
             }
-        }
-        SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "long-read extension stage: internal overflow code %u", c->h_ctr->ext_overflow);
-        ext_list = c->h_ctr->ext_n_list;
-        const uint32_t n_big_a = c->h_ctr->lext_n_big;
-        // second kernel: regions and alignment
-        {
-            ExtLongArgs xb = x;
-            xb.scratch = c->d_lext[2]; xb.scratch_per_wave = c->lext_per_wave[2]; xb.sz = c->lext_sz[2];
-            xb.ticket = &c->d_ctr->lext_ticket_b; xb.big_list = c->d_lext_big2; xb.n_big = &c->d_ctr->lext_n_big2;
-            hipLaunchKernelGGL(k_regs_align_long, dim3(c->lext_waves[2]), dim3(64), 0, s, xb);
-            sh_status st = sync_ctr(); if (st != SH_OK) return st;
-            if (c->h_ctr->lext_n_big2 > 0) {
-                xb.scratch = c->d_lext[3]; xb.scratch_per_wave = c->lext_per_wave[3]; xb.sz = c->lext_sz[3];
-                xb.list = c->d_lext_big2; xb.n_list = &c->d_ctr->lext_n_big2; xb.ticket = &c->d_ctr->lext_ticket_big2; xb.big_list = nullptr; xb.n_big = nullptr;
-                hipLaunchKernelGGL(k_regs_align_long, dim3(c->lext_waves[3]), dim3(64), 0, s, xb);
-                st = sync_ctr(); if (st != SH_OK) return st;
+            // first kernel: final chains (tier 0, then the reads that outgrew it with the large working memory)
+            {
+                ExtLongArgs xa = x;
+                xa.scratch = c->d_lext[0]; xa.scratch_per_wave = c->lext_per_wave[0]; xa.sz = c->lext_sz[0];
+                xa.ticket = &c->d_ctr->ext_ticket; xa.big_list = c->d_lext_big; xa.n_big = &c->d_ctr->lext_n_big;
+                // reads whose chain anchors outgrow the first size go straight to the large working memory, on a side stream beside the rest
+                int bin_cut = 0;
+                while (bin_cut < 31 && (2ull << bin_cut) <= c->lext_sz[0].cap_a) ++bin_cut;      // bin b holds totals in [2^b, 2^(b+1))
+                xa.hist = c->d_ctr->lext_hist; xa.bin_cut = bin_cut; xa.part = 1;
+                ExtLongArgs xg = xa;
+                xg.scratch = c->d_lext[1]; xg.scratch_per_wave = c->lext_per_wave[1]; xg.sz = c->lext_sz[1];
+                xg.ticket = &c->d_ctr->lext_ticket_g; xg.part = 2;      // same ring as the others (19 KB of LDS: they share CUs); what outgrows the ring joins the big list
+                SH_HIP(hipEventRecord(c->evx[0], s));
+                SH_HIP(hipStreamWaitEvent(c->sx[0], c->evx[0], 0));
+                hipLaunchKernelGGL(k_long_chains<512>, dim3(c->lext_waves[1]), dim3(64), 0, c->sx[0], xg);
+                SH_HIP(hipEventRecord(c->evx[1], c->sx[0]));
+                hipLaunchKernelGGL(k_long_chains<512>, dim3(c->lext_waves[0]), dim3(64), 0, s, xa);
+                SH_HIP(hipStreamWaitEvent(s, c->evx[1], 0));
+                sh_status st = sync_ctr(); if (st != SH_OK) return st;
+                if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;       // hand-over buffers or arena full: the caller cuts the chunk in two
+                if (c->h_ctr->lext_n_big > 0) {
+                    xa.scratch = c->d_lext[1]; xa.scratch_per_wave = c->lext_per_wave[1]; xa.sz = c->lext_sz[1];
+                    xa.list = c->d_lext_big; xa.n_list = &c->d_ctr->lext_n_big; xa.ticket = &c->d_ctr->lext_ticket_big; xa.big_list = nullptr; xa.n_big = nullptr; xa.part = 0;
+                    hipLaunchKernelGGL(k_long_chains<4096>, dim3(c->lext_waves[1]), dim3(64), 0, s, xa);
+                    st = sync_ctr(); if (st != SH_OK) return st;
+                    if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
+                }
             }
+            SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "long-read extension stage: internal overflow code %u", c->h_ctr->ext_overflow);
+            ext_list += c->h_ctr->ext_n_list;
+            n_big_a += c->h_ctr->lext_n_big;
+            // second kernel: regions and alignment
+            {
+                ExtLongArgs xb = x;
+                xb.scratch = c->d_lext[2]; xb.scratch_per_wave = c->lext_per_wave[2]; xb.sz = c->lext_sz[2];
+                xb.ticket = &c->d_ctr->lext_ticket_b; xb.big_list = c->d_lext_big2; xb.n_big = &c->d_ctr->lext_n_big2;
+                hipLaunchKernelGGL(k_regs_align_long, dim3(c->lext_waves[2]), dim3(64), 0, s, xb);
+                sh_status st = sync_ctr(); if (st != SH_OK) return st;
+                if (c->h_ctr->lext_n_big2 > 0) {
+                    xb.scratch = c->d_lext[3]; xb.scratch_per_wave = c->lext_per_wave[3]; xb.sz = c->lext_sz[3];
+                    xb.list = c->d_lext_big2; xb.n_list = &c->d_ctr->lext_n_big2; xb.ticket = &c->d_ctr->lext_ticket_big2; xb.big_list = nullptr; xb.n_big = nullptr;
+                    hipLaunchKernelGGL(k_regs_align_long, dim3(c->lext_waves[3]), dim3(64), 0, s, xb);
+                    st = sync_ctr(); if (st != SH_OK) return st;
+                }
+                n_big_a += c->h_ctr->lext_n_big2;
+            }
+            return SH_OK;
+        };
+        { sh_status st = ext_round(0); if (st != SH_OK) return st; }
+        const uint32_t n_fb = c->h_ctr->lr_n_fb;
+        if (k.locus && getenv("SCRUBBY_HIP_DBG")) fprintf(stderr, "[dbg] anchors by locus: %u reads thinned out (%llu of %llu anchors kept); %u reads redone with every anchor (one chain and more possible %u, short read %u, top score within reach of what was left out %u, no chain after the join %u, probe undecided %u, no probe %u, no chain among the anchors kept %u)\n",
+                                                        c->h_ctr->lr_locus_reads, c->h_ctr->lr_locus_kept, c->h_ctr->lr_locus_in, n_fb, c->h_ctr->lr_fb_why[0], c->h_ctr->lr_fb_why[1], c->h_ctr->lr_fb_why[2], c->h_ctr->lr_fb_why[3], c->h_ctr->lr_fb_why[4], c->h_ctr->lr_fb_why[5], c->h_ctr->lr_fb_why[6]);
+        if (stats && k.locus) { stats->n_locus_reads += c->h_ctr->lr_locus_reads; stats->n_locus_redone += n_fb; }
+        if (n_fb > 0) {
+            // the reads whose answer could depend on the anchors left out: the repeat path once more with every anchor, then the stage again.
+            // Hand-over buffers, arena and lists start over; their first visit is forgotten (chain lists emptied, lr_drop cleared).
+            Counters z = *c->h_ctr;
+            memset(z.ext_n_recs, 0, sizeof(z.ext_n_recs)); memset(z.ext_n_anch, 0, sizeof(z.ext_n_anch)); memset(z.lext_hist, 0, sizeof(z.lext_hist));
+            z.n_defer = 0; z.arena_cursor = 0;
+            z.n_big[0] = n_fb; z.n_big[1] = 0; z.n_big_defer[0] = z.n_big_defer[1] = 0;
+            z.ext_n_list = 0; z.ext_ticket = 0; z.lext_ticket_g = 0; z.lext_n_big = 0; z.lext_ticket_big = 0; z.lext_n_big2 = 0; z.lext_ticket_big2 = 0; z.lext_ticket_b = 0;
+            SH_HIP(hipMemcpyAsync(c->d_ctr, &z, sizeof(Counters), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_lext_forget, dim3(64), dim3(256), 0, s, (const uint32_t *)c->d_lr_fb, n_fb, c->sink.head, c->d_lr_drop, &c->d_ctr->lr_fb_had);
+            SH_HIP(hipMemcpyAsync(c->d_big[0][0], c->d_lr_fb, (size_t)n_fb * 4, hipMemcpyDeviceToDevice, s));
+            K3Args kf = k; kf.locus = 0; kf.quiet = 2;      // their chain-level count was taken back (k_lext_forget); the other statistics stay as they are
+            K2Args rb = b; rb.quiet = 2;
+            int f0 = 0, f1 = 0;
+            { sh_status st = run_repeat_path(kf, rb, f0, f1, resk_done); if (st != SH_OK) return st; }
+            rb.work_defer = c->d_work_defer;
+            { sh_status st = legacy_defers(rb); if (st != SH_OK) return st; }
+            x.drop = nullptr;
+            { sh_status st = ext_round(1); if (st != SH_OK) return st; }
         }
         if (c->h_ctr->lext_unresolved) {
             static bool warned = false;
             if (!warned) { warned = true; fprintf(stderr, "[scrubby-hip] WARNING: %u read(s) outgrew the extension stage's largest working memory (e.g. read %u of its batch, code %u: 18 chains, 20 read length, 21 chain anchors, 22 RMQ window, 23 seeds, 24 regions, 27-30 alignment window, 32 direction bytes); they keep their chain-level answer (mapped)\n", c->h_ctr->lext_unresolved, c->h_ctr->lext_err_read, c->h_ctr->lext_err_code); }
         }
         if (getenv("SCRUBBY_HIP_DBG")) fprintf(stderr, "[dbg] long-read extension stage: %u reads with chains, %u re-chained (RMQ), %u with tied RMQ priorities, %u needed the large scratch, %u regions aligned, %u reads dropped\n",
-                                               ext_list, c->h_ctr->lext_rechained, c->h_ctr->lext_rmq_tie, n_big_a + c->h_ctr->lext_n_big2, c->h_ctr->ext_regions, c->h_ctr->ext_dropped);
+                                               ext_list, c->h_ctr->lext_rechained, c->h_ctr->lext_rmq_tie, n_big_a, c->h_ctr->ext_regions, c->h_ctr->ext_dropped);
         if (getenv("SCRUBBY_HIP_DBG")) {
             unsigned long long tot = 0, mr = 0, ma = 0, sr = 0, sa = 0;
             for (int i = 0; i < LR_NCLK; ++i) tot += c->h_ctr->lext_clk[i];
@@ -3764,7 +3989,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         stats->n_ext_shortcut += sum_lemma;
         for (int i = 0; i < 64; ++i) { sum_host += c->h_ctr->sh_host[i]; sum_mini += c->h_ctr->sh_mini[i]; sum_anchors += c->h_ctr->sh_anchors[i]; sum_clusters += c->h_ctr->sh_clusters[i]; sum_pair += c->h_ctr->sh_pair[i]; sum_pf += c->h_ctr->sh_pf_reads[i]; sum_pfd += c->h_ctr->sh_pf_dirty[i]; sum_top += c->h_ctr->sh_top[i]; }
         stats->n_reads += n_reads; stats->n_bases += n_bases;
-        stats->n_host += sum_host - ext_dropped;
+        stats->n_host += sum_host - ext_dropped - c->h_ctr->lr_fb_had;
         stats->n_ext_reads += ext_list; stats->n_ext_regions += ext_regions; stats->n_ext_dropped += ext_dropped; stats->ms_ext += ms_ext; const uint32_t n_big0 = snap.n_big_total ? snap.n_big_total : snap.n_big[0];
         stats->n_no_seed += n_reads - snap.n_small - n_big0 - snap.n_resketch;
         uint64_t nl = (uint64_t)snap.n_resketch + n_big0;

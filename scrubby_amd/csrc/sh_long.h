@@ -1361,7 +1361,7 @@ __device__ inline int32_t lr_chain_of(OFF off, int32_t n, int32_t i)
 struct LongOut { int32_t n_chain, best, rechained, n_aligned, n_regs, dp_max; uint32_t sig; int32_t rmq_tie, probed; };
 // The stage runs as two kernels, so that neither carries the other's registers and LDS: the first leaves a read's final chains (after the
 // long join, in compact_a's order, MM_SEED_TANDEM set) in an arena; the second turns them into regions and aligns.
-struct LongHdr { unsigned long long off; int32_t n_u, n_a, best, rechained; };      // per read: u[n_u] (8 B), uoff[n_u + 1] (4 B), a[n_a] (16 B) at arena + off
+struct LongHdr { unsigned long long off; int32_t n_u, n_a, best, rechained; unsigned long long alt; };      // per read: u[n_u] (8 B), uoff[n_u + 1] (4 B), a[n_a] (16 B) at arena + off; alt - 1: a second outcome to prove (lr_chains_wave), {n_a, score, 0, 0} + a[n_a]
 struct LongArena { uint8_t *base; unsigned long long cap; unsigned long long *cursor; LongHdr *hdr; };
 __host__ __device__ inline unsigned long long long_arena_bytes(int32_t n_u, int32_t n_a)
 {
@@ -1385,8 +1385,13 @@ __device__ inline bool lr_region_kept(const LongParams &P, int32_t qlen, const L
 // Either way the caller hands the read to the pass with the large working memory.
 // ---- first kernel: the read's final chains ----
 // 0: done (header written; n_u may be 0); 3: a capacity of the working memory was exceeded (C.err); 4: the arena is full
+// drop: the largest cluster bound k_lr_locus left out of this read's anchors (0: the read has all of them).  With anchors left out the read's
+// chains are those of the clusters kept - exactly, clusters are independent in both chaining passes - and a chain of a cluster left out would
+// score at most k * drop (none at all when drop < min_cnt: such a read is complete for every purpose).  What the answer needs beyond that, and what is checked here (5 = the read must be redone with every anchor, C.err
+// says why): whether mm_map_frag re-chains at all (more than one chain in the first pass; for a short read also which chain comes first),
+// and that regs[0] - the only region a flag-only call asks about - is among the chains kept: top score > k * drop.
 template <int NR>
-__device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const LongArena &AR, LongOut &out)
+__device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const LongArena &AR, LongOut &out, uint32_t drop = 0)
 {
     const LongParams &P = *C.P;
     LongWs &W = *C.W;
@@ -1470,11 +1475,27 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const Long
     }
 
     lr_tick(C.clk, 0);
+    const bool chainable_out = drop >= (uint32_t)(P.min_cnt > 1 ? P.min_cnt : 1);      // a cluster left out may hold a chain of its own
+    // `both`: one chain among the anchors kept, more possible among those left out - whether mm_map_frag runs the long join (n_regs0 > 1) is
+    // not known.  Either way regs[0] comes from this cluster (the check on the top score below), so both outcomes are prepared: the chains
+    // the join leaves (the read's arena block) and the chain as it stands (`alt`); the regions kernel wants a proof from each.  Most of the
+    // time the join returns the one chain with all its anchors and the two coincide.
+    bool both = false;
+    int32_t s1 = 0;                            // the first pass's top score (`both`)
+    unsigned long long alt_off = 0;            // arena offset + 1 of the alternative
+    if (chainable_out && P.bw_long > P.bw) {
+        // the rescue test on the first chain in x order must not depend on a chain left out: it holds for every span when the read is long
+        // enough (qlen - span > rescue_size or span > qlen * rescue_ratio)
+        const bool always = (float)(qlen - P.rmq_rescue_size) > (float)qlen * P.rmq_rescue_ratio;
+        if (!always) { C.err = 41; return 5; }
+        if (n_u < 2) { both = true; s1 = out.best; }
+    }
     // ---- mm_map_frag: re-chain / long join
-    if (P.bw_long > P.bw && n_u > 1) {
+    if (P.bw_long > P.bw && (n_u > 1 || both)) {
         const int32_t st = (int32_t)A0[0].y, en = (int32_t)A0[(int32_t)(uint32_t)W.u[0] - 1].y;
-        if (qlen - (en - st) > P.rmq_rescue_size || en - st > qlen * P.rmq_rescue_ratio) {
-            out.rechained |= 2;
+        if (both || qlen - (en - st) > P.rmq_rescue_size || en - st > qlen * P.rmq_rescue_ratio) {
+            if (!both) out.rechained |= 2;
+            const int32_t n_a_first = n_a;
             for (int32_t i = lane; i < n_a; i += 64) { W.sk[i].k = A0[i].x; W.sk[i].v = (uint64_t)i; }
             lr_sync();
             lr_sort(W.sk, W.sk2, n_a);
@@ -1516,7 +1537,23 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const Long
             out.best = al_b0(res[2]); out.n_chain = n_u;
             if (n_v < 0) { C.err = 2; return 3; }
             lr_sync();
-            if (n_u == 0) { if (lane == 0) { LongHdr h{0ull, 0, 0, 0, out.rechained | (out.rmq_tie ? 4 : 0)}; AR.hdr[read] = h; } return 0; }
+            if (both && !(n_u == 1 && n_v == n_a_first)) {
+                // the join changes the chain: keep it as it stood (B0 holds its anchors, sorted by x - the order of a chain) for the second proof
+                const unsigned long long bytes = 16ull + (unsigned long long)n_a_first * 16ull;
+                unsigned long long off = 0;
+                if (lane == 0) off = atomicAdd(AR.cursor, bytes);
+                off = lr_b0_64(off);
+                if (off + bytes > AR.cap) return 4;
+                if (lane == 0) { int32_t *hh = (int32_t *)(AR.base + off); hh[0] = n_a_first; hh[1] = s1; hh[2] = hh[3] = 0; }
+                LAnchor *AO = (LAnchor *)(AR.base + off + 16);
+                for (int32_t i = lane; i < n_a_first; i += 64) AO[i] = B0[i];
+                alt_off = off + 1;
+            }
+            if (n_u == 0) {
+                if (chainable_out) { C.err = 43; return 5; }      // the clusters kept hold no chain after the join: the answer lies with the rest
+                if (lane == 0) { LongHdr h{0ull, 0, 0, 0, out.rechained | (out.rmq_tie ? 4 : 0)}; AR.hdr[read] = h; }
+                return 0;
+            }
             // compact_a: every chain ascending, then the chains by the x of their first anchor (ties: discovery order)
             for (int32_t i = lane; i < n_v; i += 64) {
                 const int32_t c = lr_chain_of(W.uoff, n_u, i);
@@ -1549,6 +1586,7 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const Long
     }
 
     lr_tick(C.clk, 3);
+    if (chainable_out && ((long long)out.best <= (long long)P.k * (long long)drop || (both && (long long)s1 <= (long long)P.k * (long long)drop))) { C.err = 42; return 5; }      // a chain left out could be regs[0]
     // ---- hand the chains to the second kernel
     {
         const unsigned long long bytes = long_arena_bytes(n_u, n_a);
@@ -1561,13 +1599,14 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const Long
         LAnchor *AO = (LAnchor *)(AR.base + off + (((unsigned long long)n_u * 8 + ((unsigned long long)n_u + 1) * 4 + 15) & ~15ull));
         for (int32_t i = lane; i <= n_u; i += 64) { if (i < n_u) U[i] = W.u[i]; UO[i] = W.uoff[i]; }
         for (int32_t i = lane; i < n_a; i += 64) AO[i] = A0[i];
-        if (lane == 0) { LongHdr h; h.off = off; h.n_u = n_u; h.n_a = n_a; h.best = out.best; h.rechained = out.rechained | (out.rmq_tie ? 4 : 0); AR.hdr[read] = h; }
+        if (lane == 0) { LongHdr h; h.off = off; h.n_u = n_u; h.n_a = n_a; h.best = out.best; h.rechained = out.rechained | (out.rmq_tie ? 4 : 0) | (chainable_out ? 8 : 0); h.alt = alt_off; AR.hdr[read] = h; }
     }
     return 0;
 }
 
 // ---- second kernel: regions, alignment, mm_filter_regs ----
-// 0: done; 1: an alignment needs a larger direction-byte buffer; 3: another capacity of the working memory was exceeded (C.err).
+// 0: done; 1: an alignment needs a larger direction-byte buffer; 3: another capacity of the working memory was exceeded (C.err);
+// 5: anchors were left out of this read (k_lr_locus) and regs[0] alone does not prove it mapped: it must be redone with every anchor.
 __device__ inline int32_t lr_regs_wave(LongCtx &C, const ChainParams &CP, const LongArena &AR, bool flag_only, bool probe, LongOut &out)
 {
     const LongParams &P = *C.P;
@@ -1595,10 +1634,71 @@ __device__ inline int32_t lr_regs_wave(LongCtx &C, const ChainParams &CP, const 
         lr_sync();
     }
     if (C.clk) C.clk->last = wall_clock64();
+    const bool partial = (hd.rechained & 8) != 0;      // k_lr_locus left clusters out that may hold chains: only a proof from regs[0] alone counts
+    // ---- mm_align_skeleton's query on both strands (staged early: the probe below reads it)
+    {
+        const uint8_t *seq = in.bases + in.offsets[read];
+        for (int32_t i = lane; i < qlen; i += 64) {
+            const uint8_t c = (uint8_t)sh_nt4(seq[i]);
+            W.qseq[i] = c;
+            W.qseq[qlen + (qlen - 1 - i)] = c < 4 ? 3 - c : 4;
+        }
+    }
     // ---- mm_gen_regs: regions in descending z = (score << 32 | cnt) ^ h; of equal z the later chain first
     uint32_t hash = 0;
     hash ^= al_wang((uint32_t)qlen) + al_wang(11u);
     hash = al_wang(hash);
+    bool skip_probe0 = false;
+    if (flag_only && probe) {
+        // Probe before bookkeeping.  regs[0] is the chain of largest (z, index); it is its own parent whatever mm_set_parent makes of the
+        // others, mm_select_sub keeps every primary, mm_filter_strand_retained only drops strand_retained regions, and its gap fillings
+        // read its own anchors only - so the proof lr_probe_region gives does not need the ranking of the other ~400 chains, their
+        // parents, mm_est_err or mm_squeeze_a.  A probe that cannot conclude starts the read over with the complete procedure.
+        unsigned long long bz = 0; int32_t bi = -1;
+        for (int32_t i = lane; i < n_u; i += 64) {
+            const LAnchor f0 = A0[UOh[i]];
+            const uint32_t h = (uint32_t)al_hash64((al_hash64(f0.x) + al_hash64(f0.y)) ^ hash);
+            const unsigned long long z = Uh[i] ^ h;
+            if (bi < 0 || z > bz || (z == bz && i > bi)) { bz = z; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long oz = (unsigned long long)__shfl_xor((long long)bz, o); const int32_t oi = __shfl_xor(bi, o);
+            if (oi >= 0 && (bi < 0 || oz > bz || (oz == bz && oi > bi))) { bz = oz; bi = oi; }
+        }
+        LReg r{};
+        r.id = 0; r.parent = 0;
+        r.score = (int32_t)(bz >> 32); r.hash = (uint32_t)bz;
+        r.cnt = (int32_t)(uint32_t)Uh[bi]; r.as = (int32_t)UOh[bi];
+        r.div = -1.0f;
+        lr_sync();
+        lr_reg_set_coor(r, qlen, A0);
+        int32_t as1, cnt1;
+        const int32_t pr = lr_probe_region(C, r, A0, as1, cnt1);
+        if (pr < 0) return C.need_big ? 1 : 3;
+        if (pr > 0 && hd.alt != 0) {
+            // mm_map_frag may not have run the long join at all (lr_chains_wave, `both`): then regs[0] is the first pass's one chain
+            const int32_t *hh = (const int32_t *)(AR.base + (hd.alt - 1));
+            const int32_t n_alt = hh[0];
+            if ((uint32_t)n_alt > W.cap_a) { C.err = 5; return 3; }
+            const LAnchor *src = (const LAnchor *)(AR.base + (hd.alt - 1) + 16);
+            for (int32_t i = lane; i < n_alt; i += 64) A0[i] = src[i];
+            lr_sync();
+            LReg r1{};
+            r1.id = 0; r1.parent = 0; r1.score = hh[1]; r1.cnt = n_alt; r1.as = 0; r1.div = -1.0f;
+            lr_reg_set_coor(r1, qlen, A0);
+            const int32_t pr2 = lr_probe_region(C, r1, A0, as1, cnt1);
+            if (pr2 < 0) return C.need_big ? 1 : 3;
+            if (pr2 == 0) { C.err = 46; return 5; }
+        }
+        if (pr > 0) { out.n_regs = 1; out.probed = 1; return 0; }
+        if (partial) { C.err = 44; return 5; }
+        // the seed filters flagged anchors of the region: start from the arena's copy again
+        const LAnchor *src = (const LAnchor *)(AR.base + hd.off + (((unsigned long long)n_u * 8 + ((unsigned long long)n_u + 1) * 4 + 15) & ~15ull));
+        for (int32_t i = lane; i < hd.n_a; i += 64) A0[i] = src[i];
+        lr_sync();
+        skip_probe0 = true;
+    } else if (partial) { C.err = 45; return 5; }
     for (int32_t i = lane; i < n_u; i += 64) {
         const LAnchor f0 = A0[UOh[i]];
         const uint32_t h = (uint32_t)al_hash64((al_hash64(f0.x) + al_hash64(f0.y)) ^ hash);
@@ -1657,15 +1757,7 @@ __device__ inline int32_t lr_regs_wave(LongCtx &C, const ChainParams &CP, const 
     lr_tick(C.clk, 5);
     out.n_aligned = n_regs;
 
-    // ---- mm_align_skeleton: the query on both strands, mm_squeeze_a, the regions one after the other
-    {
-        const uint8_t *seq = in.bases + in.offsets[read];
-        for (int32_t i = lane; i < qlen; i += 64) {
-            const uint8_t c = (uint8_t)sh_nt4(seq[i]);
-            W.qseq[i] = c;
-            W.qseq[qlen + (qlen - 1 - i)] = c < 4 ? 3 - c : 4;
-        }
-    }
+    // ---- mm_align_skeleton: mm_squeeze_a, the regions one after the other (the query was staged above)
     for (int32_t i = lane; i < n_regs; i += 64) { W.sk[i].k = (uint64_t)(uint32_t)W.regs[i].as; W.sk[i].v = (uint64_t)i; }
     lr_sync();
     lr_sort(W.sk, W.sk2, n_regs);
@@ -1711,7 +1803,7 @@ __device__ inline int32_t lr_regs_wave(LongCtx &C, const ChainParams &CP, const 
         LReg r = W.regs[i], r2;
         r2.cnt = 0;
         int32_t pre_as1 = -1, pre_cnt1 = 0;
-        if (flag_only && probe) {
+        if (flag_only && probe && !(i == 0 && skip_probe0)) {
             const int32_t pr = lr_probe_region(C, r, A0, pre_as1, pre_cnt1);
             if (pr < 0) return C.need_big ? 1 : 3;
             if (pr > 0) { out.n_regs = 1; out.probed = 1; return 0; }

@@ -91,3 +91,32 @@ def test_noisy_reads_at_bench_error_rates(S, oracle, cfg1):
     assert_same(S, gf, gt, of, ot)
     gf2, _, _, _ = gidx.classify(cpu, offs, want_trace=False)
     assert np.array_equal(gf2, of)
+
+
+def test_anchors_by_locus_flag_only(S, oracle, monkeypatch):
+    """Flag-only calls chain a long read over the reference windows that can hold regs[0] only (k_lr_locus) and redo the
+    reads whose answer could depend on the rest with every anchor.  Repeat-rich reference (the bench generator's satellites and
+    interspersed repeats): the flags must equal the oracle's with the selection on and off, reads must have been thinned out, and some
+    must have taken the second round."""
+    Po = oracle.ref_params(0x5C2B0010, [1_000_000] * 5)
+    Ro = oracle.read_params(0x5C2B0020, read_len=0, host_pct=60, sub_per_10k=200, n_read_pct=1)
+    n = 3000
+    cpu, offs = oracle.synth_long_reads(Po, Ro, 11, n)
+    seqs = [oracle.synth_ref(Po, Po.contig_start[i], 1_000_000) for i in range(5)]
+    gidx = S.Index.build([bytes(s) for s in seqs], S.preset("map-ont"))
+    cidx = oracle.Index.build(seqs, 10, 15)
+    oo = cidx.update_opts(oracle.preset("map-ont"))
+    of, _ = cidx.classify(oo, cpu, offs, threads=8)
+    gf, _, st, rc = gidx.classify(cpu, offs, want_trace=False)
+    assert rc == 0 and np.array_equal(gf, of), f"{int((gf != of).sum())} flags differ, first {np.where(gf != of)[0][:5]}"
+    assert st["n_locus_reads"] > 0 and st["n_host"] == int(of.sum())
+    monkeypatch.setenv("SCRUBBY_HIP_NO_LOCUS", "1")
+    gf0, _, st0, rc0 = gidx.classify(cpu, offs, want_trace=False)
+    assert rc0 == 0 and np.array_equal(gf0, of) and st0["n_locus_reads"] == 0
+    monkeypatch.delenv("SCRUBBY_HIP_NO_LOCUS")
+    # only the largest run of windows kept: reads with chains elsewhere must be caught by the checks and redone with every anchor
+    monkeypatch.setenv("SCRUBBY_HIP_LOCUS_TOP1", "1")
+    gf1, _, st1, rc1 = gidx.classify(cpu, offs, want_trace=False)
+    assert rc1 == 0 and np.array_equal(gf1, of), f"{int((gf1 != of).sum())} flags differ, first {np.where(gf1 != of)[0][:5]}"
+    assert st1["n_locus_redone"] > 0 and st1["n_host"] == int(of.sum())
+    print("locus:", st["n_locus_reads"], "redone:", st["n_locus_redone"], "top-1 only: redone", st1["n_locus_redone"])
