@@ -133,6 +133,7 @@ typedef struct sh_stats {
     uint64_t n_locus_reads;    /* long-read presets, flag-only: reads chained over the reference windows that can hold regs[0] only */
     uint64_t n_locus_redone;   /* ... of which the answer could depend on what was left out: redone with every anchor */
     uint64_t n_rmq_exact;      /* long-read presets: reads whose RMQ join was redone on the literal krmq tree (tied priorities, windows beyond the LDS ring, rmq_size_cap) */
+    uint64_t n_ext_ondemand;   /* reads beyond the extension stage's prepared working-memory sizes, redone with memory allocated for them (visits, both kernels) */
 } sh_stats;
 
 typedef struct sh_index sh_index;

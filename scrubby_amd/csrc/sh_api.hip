@@ -136,7 +136,8 @@ extern "C" sh_status sh_classify_batch(const sh_index *idx, const sh_opts *opts,
     for (uint64_t r0 = 0; r0 < n_reads; r0 += CH) piece_bases = std::max(piece_bases, offsets[std::min(n_reads, r0 + CH)] - offsets[r0]);
     const uint64_t need_reads = std::min(CH, n_reads);
     std::string env_sig;
-    for (const char *v : {"SCRUBBY_HIP_ARENA_MB", "SCRUBBY_HIP_NO_FLAG_STOP", "SCRUBBY_HIP_NO_PAIR", "SCRUBBY_HIP_PAIR_MIN", "SCRUBBY_HIP_NO_S1", "SCRUBBY_HIP_EXT_MB"}) { const char *e = getenv(v); env_sig += e ? e : "-"; env_sig += '|'; }
+    for (const char *v : {"SCRUBBY_HIP_ARENA_MB", "SCRUBBY_HIP_NO_FLAG_STOP", "SCRUBBY_HIP_NO_PAIR", "SCRUBBY_HIP_PAIR_MIN", "SCRUBBY_HIP_NO_S1", "SCRUBBY_HIP_EXT_MB", "SCRUBBY_HIP_EXT_REGCAP", "SCRUBBY_HIP_NO_LEMMA",
+                          "SCRUBBY_HIP_LEXT_A", "SCRUBBY_HIP_LEXT_BIG_A", "SCRUBBY_HIP_LEXT_P_KB", "SCRUBBY_HIP_LEXT_BIG_P_KB", "SCRUBBY_HIP_STAGE_MB", "SCRUBBY_HIP_STREAMS"}) { const char *e = getenv(v); env_sig += e ? e : "-"; env_sig += '|'; }
     const bool no_pool = false;
 
     BatchScratch *B = nullptr;
@@ -209,7 +210,7 @@ extern "C" sh_status sh_classify_batch(const sh_index *idx, const sh_opts *opts,
                 stats->n_ext_reads += ps.n_ext_reads; stats->n_ext_regions += ps.n_ext_regions; stats->n_ext_dropped += ps.n_ext_dropped; stats->ms_ext += ps.ms_ext; stats->n_ext_shortcut += ps.n_ext_shortcut;
                 stats->n_ext_fallback += ps.n_ext_fallback; stats->ms_ext_fallback += ps.ms_ext_fallback; stats->n_ext_unresolved += ps.n_ext_unresolved; stats->n_rmq_rechained += ps.n_rmq_rechained; stats->n_rmq_tied += ps.n_rmq_tied;
                 stats->n_dp_parallel += ps.n_dp_parallel; stats->n_dp_dirty += ps.n_dp_dirty; stats->n_top_settled += ps.n_top_settled;
-                stats->n_locus_reads += ps.n_locus_reads; stats->n_locus_redone += ps.n_locus_redone; stats->n_rmq_exact += ps.n_rmq_exact;
+                stats->n_locus_reads += ps.n_locus_reads; stats->n_locus_redone += ps.n_locus_redone; stats->n_rmq_exact += ps.n_rmq_exact; stats->n_ext_ondemand += ps.n_ext_ondemand;
             }
         }
     });

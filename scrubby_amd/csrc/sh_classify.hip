@@ -95,6 +95,8 @@ struct Counters {
     // anchors kept, reads that must be redone with every anchor (lr_fb list)
     uint32_t n_locus[3], locus_ticket[3], lr_n_fb, lr_locus_reads; unsigned long long lr_locus_in, lr_locus_kept;
     uint32_t lr_fb_why[8], lr_fb_had, lr_pad;
+    uint32_t lext_n_unres, lext_ticket_unres, lext_n_unres_in, lext_pad4, lext_n_exact, lext_ticket_exact;      // reads beyond the stage's second working-memory size: redone with memory allocated for them
+    unsigned long long stage_cursor;      // k_expand's raw anchors of the reads k_lr_locus will thin out (their own buffer: 12 B per anchor)
 };
 #define SHARD() ((blockIdx.x + (blockIdx.x >> 6)) & 63)
 
@@ -1496,6 +1498,7 @@ struct K3Args {
     // long-read presets, flag-only with the extension filter: k_expand lists reads of more than 64 anchors here instead of in the sort
     // classes, k_lr_locus keeps the anchors of the reference windows that can hold regs[0] and passes the read on
     SortItem *locus_items[3]; uint32_t *lr_drop; int32_t locus, locus_shift;
+    uint64_t *stage_x; uint32_t *stage_q; unsigned long long stage_cap;      // where k_expand leaves those reads' anchors (generation order)
 };
 
 
@@ -1593,7 +1596,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const bool plain_cut = !(P.occ_dist > 0 && P.max_max_occ > a.max_occ);
     WaveAlloc al_sort[N_SORT_CLS];
     uint32_t n_clusters = 0, n_pair = 0, n_lemma = 0;
-    unsigned long long anchors_wave = 0, a_cur = 0, a_end = 0;      // wave-local slice of the anchor arena
+    unsigned long long anchors_wave = 0, a_cur = 0, a_end = 0, s_cur = 0, s_end = 0;      // wave-local slices of the anchor arena / the staging buffer
     __shared__ uint64_t e_x[64];
     __shared__ uint32_t e_q[64];
     __shared__ int32_t e_f[64], e_pt[128], e_bcount;
@@ -1760,27 +1763,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             continue;
         }
         const bool in_lds = n_a <= 64;     // short anchor lists never leave the CU
-        // anchor slots: the wave advances the arena cursor by 16 Ki slots at a time
-        if (!in_lds && a_cur + n_a > a_end) {
+        const bool to_stage = LONG && a.locus && !in_lds && n_a <= LOCUS_MAX_N;      // k_lr_locus takes the arena slots, for what it keeps
+        // anchor slots: the wave advances the arena (or staging) cursor by 16 Ki slots at a time
+        if (to_stage) {
+            if (s_cur + n_a > s_end) {
+                const unsigned long long want = n_a > 16384u ? n_a : 16384u;
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(&a.ctr->stage_cursor, want);
+                base = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32;
+                s_cur = base; s_end = base + want;
+            }
+        } else if (!in_lds && a_cur + n_a > a_end) {
             const unsigned long long want = n_a > 16384u ? n_a : 16384u;
             unsigned long long base = 0;
             if (lane == 0) base = atomicAdd(&a.ctr->anchor_cursor, want);
             base = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32;
             a_cur = base; a_end = base + want;
         }
-        const unsigned long long off = a_cur;
-        const bool defer = !in_lds && off + n_a > a.B.anchor_cap;
+        const unsigned long long off = to_stage ? s_cur : a_cur;
+        const bool defer = !in_lds && off + n_a > (to_stage ? a.stage_cap : a.B.anchor_cap);
         if (lane == 0) {
             BigMeta m{r, n_a, rep_len, defer ? 1u : 0u};
             a.B.meta[w] = m; a.B.acc_nu[w] = 0; a.B.acc_best[w] = 0;
             if (defer) { uint32_t di = atomicAdd(a.defer_count, 1u); a.defer_list[di] = r; }
         }
-        if (defer) { a_cur = a_end = 0; continue; }
+        if (defer) { if (to_stage) s_cur = s_end = 0; else a_cur = a_end = 0; continue; }
         if (n_a == 0) continue;
-        if (!in_lds) a_cur += n_a;
+        if (to_stage) s_cur += n_a; else if (!in_lds) a_cur += n_a;
         anchors_wave += n_a;
-        uint64_t *const gx = in_lds ? e_x : a.B.ax + off;
-        uint32_t *const gq = in_lds ? e_q : a.B.aq + off;
+        uint64_t *const gx = in_lds ? e_x : (to_stage ? a.stage_x + off : a.B.ax + off);
+        uint32_t *const gq = in_lds ? e_q : (to_stage ? a.stage_q + off : a.B.aq + off);
 
         // ---- pass 2: anchors in generation order (seed order, then occurrence order) ----
         uint32_t run = 0;
@@ -1867,8 +1879,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (lane == 0) { a.B.acc_nu[w] = n_u; a.B.acc_best[w] = best; }
             if ((a.dbg & 16) && lane == 0) { atomicAdd(&a.ctr->sort_tot[N_SORT_CLS], 1ull); atomicAdd(&a.ctr->sort_anchor_tot[N_SORT_CLS], (unsigned long long)n_a); }
             __syncthreads();
-        } else if (LONG && a.locus && n_a <= LOCUS_MAX_N) {
-            // the anchors are in the arena; k_lr_locus decides which of them can matter and lists the read in a sort class
+        } else if (to_stage) {
+            // the anchors are in the staging buffer; k_lr_locus decides which of them can matter, moves those to the arena and lists the read in a sort class
             const int lc = n_a <= LOCUS_N0 ? 0 : (n_a <= LOCUS_N1 ? 1 : 2);
             if (lane == 0) { const uint32_t li = atomicAdd(&a.ctr->n_locus[lc], 1u); SortItem it{w, n_a, (uint32_t)qlen, 0, off}; a.locus_items[lc][li] = it; }
         } else {
@@ -1906,7 +1918,8 @@ template <int LG>
 __global__ __launch_bounds__(256) void k_lr_locus(K3Args a, int lc)
 {
     __shared__ uint32_t s_tab[1u << (LG - 1)];
-    __shared__ uint32_t s_it, s_w[4][4], s_wcnt[4];
+    __shared__ uint32_t s_it, s_w[4][4], s_wcnt[4], s_off[3];
+    __shared__ uint32_t s_keep[(LOCUS_MAX_N + 1) / 32 + 8];      // one bit per anchor: it stays
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n_items = a.ctr->n_locus[lc];
     const int sh = a.locus_shift;
@@ -1930,20 +1943,24 @@ __global__ __launch_bounds__(256) void k_lr_locus(K3Args a, int lc)
         if (it >= n_items) break;
         const SortItem si = a.locus_items[lc][it];
         const uint32_t n = si.n;
-        uint64_t *gx = a.B.ax + si.off; uint32_t *gq = a.B.aq + si.off; int32_t *gv = a.B.af + si.off;
+        const uint64_t *gx = a.stage_x + si.off; const uint32_t *gq = a.stage_q + si.off;
         for (uint32_t i = tid; i < (1u << (LG - 1)); i += 256) s_tab[i] = 0;
         __syncthreads();
         for (uint32_t i = tid; i < n; i += 256) { const uint32_t h = slot(bin_of(gx[i])); atomicAdd(&s_tab[h >> 1], 1u << ((h & 1u) << 4)); }      // n <= 65535: no carry
         __syncthreads();
-        uint32_t t1 = 0, t2 = 0, t3 = 0;      // this thread's three largest distinct bounds
-        for (uint32_t i = tid; i < n; i += 256) {
-            const uint64_t id = bin_of(gx[i]);
+        // the bound of anchor i: the anchors in the run of occupied windows around its own (0x7fffffff: a run of more than LOCUS_RUN_MAX
+        // windows - the same verdict from each of them)
+        auto bound_of = [&](uint64_t x) -> uint32_t {
+            const uint64_t id = bin_of(x);
             uint32_t vr = cnt_of(id);
             int len = 1; bool inf = false;
             for (int d = 1;; ++d) { if (d > LOCUS_RUN_MAX) { inf = true; break; } const uint32_t c = cnt_of(id - (uint64_t)d); if (!c) break; vr += c; ++len; }
             if (!inf) for (int d = 1;; ++d) { if (d > LOCUS_RUN_MAX) { inf = true; break; } const uint32_t c = cnt_of(id + (uint64_t)d); if (!c) break; vr += c; ++len; }
-            if (inf || len > LOCUS_RUN_MAX) vr = 0x7fffffffu;      // a run of more than LOCUS_RUN_MAX windows (the same verdict from each of them): kept
-            gv[i] = (int32_t)vr;
+            return (inf || len > LOCUS_RUN_MAX) ? 0x7fffffffu : vr;
+        };
+        uint32_t t1 = 0, t2 = 0, t3 = 0;      // this thread's three largest distinct bounds
+        for (uint32_t i = tid; i < n; i += 256) {
+            const uint32_t vr = bound_of(gx[i]);
             if (vr > t1) { t3 = t2; t2 = t1; t1 = vr; } else if (vr < t1 && vr > t2) { t3 = t2; t2 = vr; } else if (vr < t2 && vr > t3) t3 = vr;
         }
         const uint32_t V1 = block_max(t1, 0);
@@ -1952,32 +1969,55 @@ __global__ __launch_bounds__(256) void k_lr_locus(K3Args a, int lc)
         uint32_t T = V3 < (V1 >> 3) ? V3 : (V1 >> 3);
         if (a.dbg & 1024) T = V1;      // tests (SCRUBBY_HIP_LOCUS_TOP1): the largest run only - reads with a second locus must be caught and redone
         if (T < min_cnt) T = min_cnt;
-        uint32_t base = 0, dmax = 0;
-        for (uint32_t c0 = 0; c0 < n; c0 += 256) {      // stable compaction in place: a chunk is read, then written at or before where it was
+        // which anchors stay (one bit each), how many, the largest bound left out
+        uint32_t kept_thr = 0, dmax = 0;
+        for (uint32_t c0 = 0; c0 < n; c0 += 256) {
             const uint32_t i = c0 + tid;
-            uint64_t x = 0; uint32_t q = 0; bool keep = false;
-            if (i < n) { const uint32_t vr = (uint32_t)gv[i]; keep = vr >= T; if (keep) { x = gx[i]; q = gq[i]; } else if (vr > dmax) dmax = vr; }
+            bool keep = false;
+            if (i < n) { const uint32_t vr = bound_of(gx[i]); keep = vr >= T; if (!keep && vr > dmax) dmax = vr; }
             const uint64_t km = __ballot(keep);
-            if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(km);
+            if (lane == 0) { s_keep[(c0 >> 5) + 2 * wave] = (uint32_t)km; s_keep[(c0 >> 5) + 2 * wave + 1] = (uint32_t)(km >> 32); }
+            kept_thr += keep;
+        }
+        kept_thr = wave_sum_u32(kept_thr);
+        if (lane == 0) s_wcnt[wave] = kept_thr;
+        dmax = block_max(dmax, 3);      // (the barrier inside also publishes s_wcnt and s_keep)
+        const uint32_t n_keep = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        // arena slots for the survivors; a read that finds none comes back in the next iteration of the pass, like k_expand's
+        if (tid == 0) {
+            unsigned long long o = 0; uint32_t ok = 1;
+            if (n_keep) { o = atomicAdd(&a.ctr->anchor_cursor, (unsigned long long)n_keep); ok = o + n_keep <= a.B.anchor_cap; }
+            s_off[0] = (uint32_t)o; s_off[1] = (uint32_t)(o >> 32); s_off[2] = ok;
+        }
+        __syncthreads();
+        const unsigned long long doff = (unsigned long long)s_off[0] | (unsigned long long)s_off[1] << 32;
+        const uint32_t r = a.B.meta[si.w].r;
+        if (!s_off[2]) {
+            if (tid == 0) { a.B.meta[si.w].state = 1u; const uint32_t di = atomicAdd(a.defer_count, 1u); a.defer_list[di] = r; }
             __syncthreads();
+            continue;
+        }
+        uint64_t *dx = a.B.ax + doff; uint32_t *dq = a.B.aq + doff;
+        uint32_t base = 0;
+        for (uint32_t c0 = 0; c0 < n; c0 += 256) {      // stable: the survivors keep their generation order
+            const uint32_t i = c0 + tid;
+            const uint64_t km = (uint64_t)s_keep[(c0 >> 5) + 2 * wave] | (uint64_t)s_keep[(c0 >> 5) + 2 * wave + 1] << 32;
             uint32_t woff = 0, tot = 0;
 #pragma unroll
-            for (uint32_t w2 = 0; w2 < 4; ++w2) { const uint32_t c = s_wcnt[w2]; if (w2 < wave) woff += c; tot += c; }
-            if (keep) { const uint32_t d = base + woff + prefix_popc(km); gx[d] = x; gq[d] = q; }
+            for (uint32_t w2 = 0; w2 < 4; ++w2) { const uint32_t c = (uint32_t)__popc(s_keep[(c0 >> 5) + 2 * w2]) + (uint32_t)__popc(s_keep[(c0 >> 5) + 2 * w2 + 1]); if (w2 < wave) woff += c; tot += c; }
+            if (i < n && (km >> lane & 1ull)) { const uint32_t d = base + woff + prefix_popc(km); dx[d] = gx[i]; dq[d] = gq[i]; }
             base += tot;
-            __syncthreads();
         }
-        dmax = block_max(dmax, 3);
         if (tid == 0) {
-            a.lr_drop[a.B.meta[si.w].r] = dmax;      // 0: every anchor kept
-            if (base > 0) {
-                const int cls = base <= 256 ? 0 : (base <= SORT_LDS_A ? 1 : (base <= 1024 ? 2 : (base <= SORT_LDS_B ? 3 : (base <= SORT_LDS_C ? 4 : SORT_CLS_GIANT))));
+            a.lr_drop[r] = dmax;      // 0: every anchor kept
+            if (n_keep > 0) {
+                const int cls = n_keep <= 256 ? 0 : (n_keep <= SORT_LDS_A ? 1 : (n_keep <= 1024 ? 2 : (n_keep <= SORT_LDS_B ? 3 : (n_keep <= SORT_LDS_C ? 4 : SORT_CLS_GIANT))));
                 const uint32_t oi = atomicAdd(&a.ctr->n_sort[cls], 1u);
-                SortItem o{si.w, base, si.qlen, 0, si.off};
+                SortItem o{si.w, n_keep, si.qlen, 0, doff};
                 a.B.tabs->sort_items[cls][oi] = o;
-                if (a.dbg & 16) { atomicAdd(&a.ctr->sort_tot[cls], 1ull); atomicAdd(&a.ctr->sort_anchor_tot[cls], (unsigned long long)base); }
+                if (a.dbg & 16) { atomicAdd(&a.ctr->sort_tot[cls], 1ull); atomicAdd(&a.ctr->sort_anchor_tot[cls], (unsigned long long)n_keep); }
             }
-            st_in += n; st_kept += base; st_reads += dmax != 0;
+            st_in += n; st_kept += n_keep; st_reads += dmax != 0;
         }
         __syncthreads();
     }
@@ -2915,6 +2955,8 @@ struct ExtLongArgs {
     uint8_t *scratch; unsigned long long scratch_per_wave; LongSizes sz; LongArena AR;
     uint32_t *list; uint32_t *n_list, *ticket; uint32_t *big_list; uint32_t *n_big; Counters *ctr; uint8_t *flags; sh_trace *trace; int32_t flag_only, clk, probe;
     const uint32_t *hist; int32_t bin_cut, part;      // the size-ordered list's giants (bins >= bin_cut) come first: part 1 = all but them, 2 = only them, 0 = the whole list
+    uint32_t *exact_list, *n_exact;                   // reads whose long join must run on the literal trees (lr_chains_wave returns 6)
+    uint32_t *unres_list, *n_unres;                   // reads that outgrew the large working memory too (with big_list == nullptr): redone with memory sized for them
     const uint32_t *drop; uint32_t *fb_list, *n_fb;   // k_lr_locus: what was left out of a read's anchors; reads that must be redone with every anchor
 };
 
@@ -2975,10 +3017,28 @@ __global__ void k_lext_forget(const uint32_t *list, uint32_t n, uint32_t *head, 
     if (had) atomicAdd(n_had_chain, had);      // k_finalize counted them as mapped at chain level; it will count them again
 }
 
+// no memory could be had for these reads: they keep their chain-level answer (mapped) and are counted (sh_stats.n_ext_unresolved; the host warns)
+__global__ void k_lext_giveup(const uint32_t *list, uint32_t n, uint8_t *flags, sh_trace *trace, LongHdr *hdr, Counters *ctr)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t r = list[i];
+        flags[r] = 1;
+        if (trace) ((int32_t *)(trace + r))[7] = 1;
+        LongHdr h{0ull, -1, 0, 0, 0}; hdr[r] = h;
+        atomicAdd(&ctr->lext_unresolved, 1u);
+    }
+}
+
 // a read that outgrew the pass: to the pass with the large working memory, or - beyond that too - it keeps its chain-level answer and is counted
 __device__ inline void lext_defer(const ExtLongArgs &a, uint32_t r, uint32_t code, bool has_hdr)
 {
     if (a.big_list) { a.big_list[atomicAdd(a.n_big, 1u)] = r; return; }
+    if (a.unres_list) {
+        a.unres_list[atomicAdd(a.n_unres, 1u)] = r;
+        if (!has_hdr) { LongHdr h{0ull, -1, 0, 0, 0}; a.AR.hdr[r] = h; }      // the regions kernel must not take it before the chains kernel has
+        atomicExch(&a.ctr->lext_err_read, r); atomicExch(&a.ctr->lext_err_code, code);
+        return;
+    }
     a.flags[r] = 1;
     if (a.trace) ((int32_t *)(a.trace + r))[7] = 1;
     if (!has_hdr) { LongHdr h{0ull, -1, 0, 0, 0}; a.AR.hdr[r] = h; }
@@ -2993,7 +3053,7 @@ __device__ inline void lext_redo(const ExtLongArgs &a, uint32_t r, uint32_t why)
     atomicAdd(&a.ctr->lr_fb_why[why >= 40u && why < 48u ? why - 40u : 7u], 1u);
 }
 
-template <int NR>
+template <int NR, bool EXACT>
 __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
 {
     __shared__ RmqLdsT<NR> RL;
@@ -3007,7 +3067,7 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
         for (int b2 = a.bin_cut; b2 < 32; ++b2) n_giant += a.hist[b2];
         if (a.part == 1) t_first = n_giant; else n_list = n_giant;
     }
-    uint32_t n_rechain = 0, n_tie = 0;
+    uint32_t n_rechain = 0;
     LongClk clk{};
     for (;;) {
         uint32_t t = 0;
@@ -3021,17 +3081,23 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
         C.sc_mch = C.sc_mis = C.sc_amb = C.sc_N = 0; C.need_big = false; C.err = 0; C.clk = a.clk ? &clk : nullptr;
         LongOut o;
         const unsigned long long t_r0 = a.clk ? wall_clock64() : 0ull;
-        const int32_t rc = lr_chains_wave<NR>(C, RL, AR_l, o, a.drop ? a.drop[r] : 0u);
+        const int32_t rc = lr_chains_wave<NR, EXACT>(C, RL, AR_l, o, a.drop ? a.drop[r] : 0u);
         if (a.clk && lane == 0) { const unsigned long long dt = wall_clock64() - t_r0; atomicMax(&a.ctr->lext_slow, dt << 24 | (unsigned long long)(o.n_chain > 0xffffff ? 0xffffff : o.n_chain)); atomicAdd(&a.ctr->lext_kernel_sum, dt); }
         if (rc == 4) { if (lane == 0) atomicExch(&a.ctr->ext_overflow, 1u); }      // arena full: the host cuts the chunk in two
         else if (rc == 5) { if (lane == 0) lext_redo(a, r, C.err); }
+        else if (rc == 6) {      // tied priorities / beyond the ring: the EXACT instance of this kernel takes the read
+            if (lane == 0) {
+                a.exact_list[atomicAdd(a.n_exact, 1u)] = r;
+                LongHdr h{0ull, -1, 0, 0, 0}; AR_l.hdr[r] = h;
+                if (C.err == 50u) atomicAdd(&a.ctr->lext_rmq_tie, 1u);
+            }
+        }
         else if (rc != 0) { if (lane == 0) lext_defer(a, r, 16u + C.err, false); }
-        else { n_rechain += (o.rechained & 2) != 0; n_tie += o.rmq_tie != 0; }
+        else { n_rechain += (o.rechained & 2) != 0; }
         __syncthreads();
     }
     if (lane == 0) {
         if (n_rechain) atomicAdd(&a.ctr->lext_rechained, n_rechain);
-        if (n_tie) atomicAdd(&a.ctr->lext_rmq_tie, n_tie);
         if (a.clk) { for (int i = 0; i < LR_NCLK; ++i) atomicAdd(&a.ctr->lext_clk[i], clk.t[i]); for (int i = 0; i < 7; ++i) atomicAdd(&a.ctr->lext_d[i], clk.d[i]); atomicMax(&a.ctr->lext_d[7], clk.d[7]); }
     }
 }
@@ -3132,10 +3198,12 @@ struct sh_ctx {
     bool ext_long = false;
     LongParams LP{};
     uint8_t *d_lext[4] = {}; unsigned long long lext_per_wave[4] = {}; uint32_t lext_waves[4] = {}; LongSizes lext_sz[4] = {};      // [phase * 2 + tier]
-    uint32_t *d_lext_big = nullptr, *d_lext_big2 = nullptr, *d_lext_sorted = nullptr;
+    uint32_t *d_lext_big = nullptr, *d_lext_big2 = nullptr, *d_lext_sorted = nullptr, *d_lext_unres[2] = {}, *d_lext_exact_list = nullptr;
+    uint8_t *d_lext_exact = nullptr; unsigned long long lext_exact_per_wave = 0; uint32_t lext_exact_waves = 0; LongSizes lext_exact_sz{};      // the chains kernel with the long join on the literal trees
     uint8_t *d_larena = nullptr; unsigned long long larena_bytes = 0; LongHdr *d_lhdr = nullptr;
     // flag-only calls: anchors pre-selected by locus (k_lr_locus) - its read lists, what it left out per read, the reads to redo in full
     SortItem *d_locus[3] = {}; uint32_t *d_lr_drop = nullptr, *d_lr_fb = nullptr; int locus_shift = 0;
+    uint64_t *d_stage_x = nullptr; uint32_t *d_stage_q = nullptr; uint64_t stage_cap = 0;      // raw anchors of the reads k_lr_locus thins out
     hipStream_t sx[4] = {};          // side streams: K2 and the sort classes run beside the main stream
     int par = 1;                     // bit 0: K2 on a side stream (SCRUBBY_HIP_STREAMS=0: on the main stream)
     hipEvent_t evx[6] = {};
@@ -3275,7 +3343,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
     // workload averages 72), at least 4 GiB; reads that find no room are deferred and re-run.
     c->arena_bytes = std::max<uint64_t>(4ull << 30, max_reads * 4096ull);      // floor: a small batch still meets reads with 10^5 anchors (4 MB each); a starved arena means deferral rounds of ~1.5 ms
     // without K1 every read takes the legacy path, whose sketch buffers and anchors live in the arena: ~48 B per base
-    if (!c->use_k1) c->arena_bytes = std::max<uint64_t>(c->arena_bytes, std::min<uint64_t>(max_reads * (uint64_t)max_read_len * 48ull, 64ull << 30));
+    if (!c->use_k1) c->arena_bytes = std::max<uint64_t>(c->arena_bytes, std::min<uint64_t>(max_reads * (uint64_t)max_read_len * 48ull, (c->ext_long ? 32ull : 64ull) << 30));      // long-read presets with the extension filter: the raw anchors have their own buffer (d_stage_*)
     if (const char *env = getenv("SCRUBBY_HIP_ARENA_MB")) c->arena_bytes = (uint64_t)atoll(env) << 20;
     if ((e = hipMalloc(&c->d_arena, c->arena_bytes)) != hipSuccess) return fail(e, "arena");
     {
@@ -3346,8 +3414,11 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             // bases of one chunk: max_bases may describe a whole batch of many chunks; ~8 kb per read is what long-read sets average - a
             // chunk that holds more is cut in two when its chains do not fit (SH_SPLIT)
             const uint64_t cb = std::min<uint64_t>({max_bases + 64, max_reads * (uint64_t)max_read_len + 64, max_reads * 8192ull + (64ull << 20)});
-            cap_anch = std::max<uint64_t>(cap_anch, cb / 2);
-            cap_recs = std::max<uint64_t>(cap_recs, std::min<uint64_t>(cb / 16, 1ull << 28) + 8 * max_reads);      // repeat-rich reads leave hundreds of small chains each
+            // flag-only calls hand over the chains of the loci that can hold regs[0] (k_lr_locus: ~100 chain anchors and a dozen chains per read
+            // of the bench workload); a call with a trace hands over every chain (thousands of anchors, hundreds of chains per read) and is
+            // cut into smaller chunks when they do not fit
+            cap_anch = std::max<uint64_t>(cap_anch, cb / 8);
+            cap_recs = std::max<uint64_t>(cap_recs, std::min<uint64_t>(cb / 64, 1ull << 28) + 8 * max_reads);
         }
         if (const char *env = getenv("SCRUBBY_HIP_EXT_MB")) { cap_anch = std::max<uint64_t>(1 << 16, ((uint64_t)atoll(env) << 20) / 16); cap_recs = std::max<uint64_t>(1 << 12, cap_anch / 16); }
         cap_recs = std::min<uint64_t>((cap_recs + SINK_SHARDS - 1) / SINK_SHARDS, 0xfffffff0ull / SINK_SHARDS);      // per shard
@@ -3379,32 +3450,54 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             // the usual read, and a few waves with room for the largest alignment minimap2 attempts (max_sw_mat = 10^8 cells) / for reads
             // with millions of chain anchors
             const uint64_t L = std::max<uint32_t>(max_read_len, 64);
+            // Sizes: every wave slot takes the usual read (16 Ki chain anchors - with the anchors pre-selected by locus a read brings ~1000 -,
+            // 8 MB of direction bytes: an end extension of max_gap bases at the band of the long-read presets); a few hundred slots take a
+            // read of 256 Ki chain anchors or an alignment of 128 MB; beyond that memory is allocated for the reads that need it (ext_round)
             LongSizes z{};
             z.cap_q = (uint32_t)((L + 31) & ~15ull);
             z.cap_k = (uint32_t)std::min<uint64_t>(32768, ((2 * L + 1024) + 15) & ~15ull);
             z.cap_t = (uint32_t)(2 * L + 65536);
-            z.cap_a = (uint32_t)std::min<uint64_t>(1ull << 16, std::max<uint64_t>(16384, 2 * L));
-            z.cap_u = z.cap_r = (uint32_t)std::min<uint64_t>(z.cap_a, 16384);
+            z.cap_a = 16384;
+            z.cap_u = z.cap_r = 4096;
             z.cap_m = (uint32_t)std::min<uint64_t>(65536, L / 4 + 1024);
-            z.cap_p = std::min<uint64_t>(4ull << 20, (uint64_t)(2 * z.cap_k) * (z.cap_k + 32));
+            z.cap_p = std::min<uint64_t>(8ull << 20, (uint64_t)(2 * z.cap_k) * (z.cap_k + 32));
             if (const char *env = getenv("SCRUBBY_HIP_LEXT_P_KB")) z.cap_p = (uint64_t)atoll(env) << 10;
+            if (const char *env = getenv("SCRUBBY_HIP_LEXT_A")) { z.cap_a = (uint32_t)std::max(64, atoi(env)); z.cap_u = z.cap_r = std::max(16u, z.cap_a / 4); }      // tests
             LongSizes zb = z;
-            zb.cap_p = std::min<uint64_t>(256ull << 20, (uint64_t)(2 * z.cap_k) * (z.cap_k + 32));
-            zb.cap_a = 1u << 21; zb.cap_u = zb.cap_r = 1u << 18; zb.cap_m = 65536;
-            const uint64_t budget[4] = {12ull << 30, 7ull << 30, 14ull << 30, 11ull << 30};
-            const uint64_t wave_max[4] = {256 * 8, 32, 256 * 8, 32};      // LDS: 19 KB per wave in both kernels
+            zb.cap_p = std::min<uint64_t>(128ull << 20, (uint64_t)(2 * z.cap_k) * (z.cap_k + 32));
+            zb.cap_a = 1u << 18; zb.cap_u = zb.cap_r = 1u << 16; zb.cap_m = 65536;
+            if (const char *env = getenv("SCRUBBY_HIP_LEXT_BIG_P_KB")) zb.cap_p = (uint64_t)atoll(env) << 10;      // tests: alignments beyond the second size
+            if (const char *env = getenv("SCRUBBY_HIP_LEXT_BIG_A")) { zb.cap_a = (uint32_t)std::max(1024, atoi(env)); zb.cap_u = zb.cap_r = std::max(64u, zb.cap_a / 4); }      // tests: reads beyond the second size
+            uint64_t budget[4] = {6ull << 30, 8ull << 30, 26ull << 30, 10ull << 30};
+            const uint64_t wave_max[4] = {256 * 8, 256, 256 * 8, 64};      // LDS: 19 KB per wave in both kernels
+            {   // no more than a third of what the device has left (several contexts, ranks sharing a device, smaller GPUs)
+                size_t mf = 0, mt = 0;
+                if (hipMemGetInfo(&mf, &mt) == hipSuccess && mf > 0) {
+                    const double scale = std::min(1.0, (double)mf / 3.0 / (double)(budget[0] + budget[1] + budget[2] + budget[3]));
+                    for (auto &b : budget) b = (uint64_t)((double)b * scale);
+                }
+            }
             for (int ph = 0; ph < 2; ++ph) for (int t = 0; t < 2; ++t) {
                 LongSizes q = t ? zb : z;
                 q.phase = ph;
                 const int i = ph * 2 + t;
                 c->lext_sz[i] = q;
                 c->lext_per_wave[i] = long_ws_carve(nullptr, nullptr, q);
-                c->lext_waves[i] = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({wave_max[i], budget[i] / c->lext_per_wave[i], t ? wave_max[i] : max_reads}));
+                c->lext_waves[i] = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({wave_max[i], budget[i] / c->lext_per_wave[i], t ? std::max<uint64_t>(4, max_reads / 16) : max_reads}));
                 if ((e = hipMalloc(&c->d_lext[i], (uint64_t)c->lext_waves[i] * c->lext_per_wave[i])) != hipSuccess) return fail(e, "long-read extension-stage scratch");
             }
             if ((e = hipMalloc(&c->d_lext_big, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
             if ((e = hipMalloc(&c->d_lext_big2, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
             if ((e = hipMalloc(&c->d_lext_sorted, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
+            for (auto &q : c->d_lext_unres) if ((e = hipMalloc(&q, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
+            if ((e = hipMalloc(&c->d_lext_exact_list, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
+            {   // the exact long join: the first size of the chains kernel plus the node pools of the two trees, for a few hundred waves
+                LongSizes q = z; q.phase = 2;
+                c->lext_exact_sz = q;
+                c->lext_exact_per_wave = long_ws_carve(nullptr, nullptr, q);
+                c->lext_exact_waves = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({256, (1ull << 30) / c->lext_exact_per_wave, std::max<uint64_t>(4, max_reads / 16)}));
+                if ((e = hipMalloc(&c->d_lext_exact, (uint64_t)c->lext_exact_waves * c->lext_exact_per_wave)) != hipSuccess) return fail(e, "long-read extension-stage scratch");
+            }
             // the chains between the two kernels: what the hand-over buffers can hold, once more (the long join re-orders, it adds nothing)
             c->larena_bytes = SINK_SHARDS * cap_anch * 16 + SINK_SHARDS * cap_recs * 12 + max_reads * 32 + (1ull << 20);
             if ((e = hipMalloc(&c->d_larena, c->larena_bytes)) != hipSuccess) return fail(e, "long-read extension-stage arena");
@@ -3412,6 +3505,14 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             for (auto &q : c->d_locus) if ((e = hipMalloc(&q, max_reads * sizeof(SortItem))) != hipSuccess) return fail(e, "long-read locus lists");
             if ((e = hipMalloc(&c->d_lr_drop, max_reads * 4)) != hipSuccess) return fail(e, "long-read locus table");
             if ((e = hipMalloc(&c->d_lr_fb, max_reads * 4)) != hipSuccess) return fail(e, "long-read locus list");
+            {   // k_expand's raw anchors wait here for k_lr_locus (12 B each; ~1.1 anchors per base on a repeat-rich reference); reads that
+                // find no room come back in the pass's next iteration
+                const uint64_t cb = std::min<uint64_t>({max_bases + 64, max_reads * (uint64_t)max_read_len + 64, max_reads * 8192ull + (64ull << 20)});
+                c->stage_cap = std::min<uint64_t>(cb + cb / 4 + (1ull << 20), (64ull << 30) / 12);
+                if (const char *env = getenv("SCRUBBY_HIP_STAGE_MB")) c->stage_cap = std::max<uint64_t>(1ull << 16, ((uint64_t)atoll(env) << 20) / 12);
+                if ((e = hipMalloc(&c->d_stage_x, c->stage_cap * 8)) != hipSuccess) return fail(e, "long-read anchor staging");
+                if ((e = hipMalloc(&c->d_stage_q, c->stage_cap * 4)) != hipSuccess) return fail(e, "long-read anchor staging");
+            }
             {   // reference windows of 2^shift bases, at least as wide as the widest gap either chaining pass links across
                 const int32_t D = std::max({opts->max_gap, opts->max_gap_ref, opts->bw, opts->bw_long, 1});
                 int sh = 9;
@@ -3447,7 +3548,7 @@ extern "C" sh_status sh_ctx_destroy(sh_ctx *c)
     hipFree(c->d_work_defer); hipFree(c->d_work_defer2);
     for (auto &pp : c->d_big) for (auto p : pp) hipFree(p);
     hipFree(c->d_ctr); if (c->h_ctr) hipHostFree(c->h_ctr); hipFree(c->d_arena); hipFree(c->d_long);
-    hipFree(c->d_ext); hipFree(c->d_ext_scratch); for (auto q : c->d_lext) hipFree(q); hipFree(c->d_lext_big); hipFree(c->d_lext_big2); hipFree(c->d_lext_sorted); hipFree(c->d_larena); hipFree(c->d_lhdr); for (auto q : c->d_locus) hipFree(q); hipFree(c->d_lr_drop); hipFree(c->d_lr_fb);
+    hipFree(c->d_ext); hipFree(c->d_ext_scratch); for (auto q : c->d_lext) hipFree(q); hipFree(c->d_lext_big); hipFree(c->d_lext_big2); hipFree(c->d_lext_sorted); for (auto q : c->d_lext_unres) hipFree(q); hipFree(c->d_lext_exact_list); hipFree(c->d_lext_exact); hipFree(c->d_larena); hipFree(c->d_lhdr); for (auto q : c->d_locus) hipFree(q); hipFree(c->d_lr_drop); hipFree(c->d_lr_fb); hipFree(c->d_stage_x); hipFree(c->d_stage_q);
     for (auto ev : c->ev_ext) if (ev) hipEventDestroy(ev);
     for (auto ev : c->ev) if (ev) hipEventDestroy(ev);
     for (auto ev : c->evx) if (ev) hipEventDestroy(ev);
@@ -3485,7 +3586,7 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     SH_HIP(hipMemsetAsync(&ctr->expand_ticket, 0, 4, s));
     SH_HIP(hipMemsetAsync(&ctr->n_cl[0], 0, 4 * 6, s));
     // 6144 waves for 4096 resident (103 VGPRs: 4 per SIMD): measured best; 4096 or 5120 waves, or 5 waves per SIMD at 96 VGPRs, are 0-3 % slower
-    if (k.locus) SH_HIP(hipMemsetAsync(&ctr->n_locus[0], 0, 4 * 6, s));
+    if (k.locus) { SH_HIP(hipMemsetAsync(&ctr->n_locus[0], 0, 4 * 6, s)); SH_HIP(hipMemsetAsync(&ctr->stage_cursor, 0, 8, s)); }
     if (k.seed_off) hipLaunchKernelGGL(k_expand<true>, dim3(grid * 3), dim3(64), 0, s, k);
     else hipLaunchKernelGGL(k_expand<false>, dim3(grid * 3), dim3(64), 0, s, k);
     if (k.locus && k.seed_off) {      // long-read presets, flag-only: only the anchors that can hold regs[0] reach the sort classes
@@ -3654,7 +3755,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     // must not hinge on chains left out) and windows narrow enough to tell loci apart
     k.locus = c->ext_long && c->use_long && d_trace == nullptr && !getenv("SCRUBBY_HIP_NO_LOCUS") && !getenv("SCRUBBY_HIP_NO_PROBE") &&
               c->opts.max_clip_ratio >= 1.0f && c->P.max_occ <= c->P.mid_occ && c->locus_shift <= 20 && c->opts.min_cnt >= 1;
-    k.locus_shift = c->locus_shift; k.lr_drop = c->d_lr_drop;
+    k.locus_shift = c->locus_shift; k.lr_drop = c->d_lr_drop; k.stage_x = c->d_stage_x; k.stage_q = c->d_stage_q; k.stage_cap = c->stage_cap;
     for (int i = 0; i < 3; ++i) k.locus_items[i] = c->d_locus[i];
     if (c->ext_long) SH_HIP(hipMemsetAsync(c->d_lr_drop, 0, n_reads * 4, s));
     uint32_t resk_done = 0;
@@ -3759,6 +3860,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         x.list = c->d_ext_list; x.n_list = &c->d_ctr->ext_n_list; x.ctr = c->d_ctr; x.flags = d_flags; x.trace = d_trace; x.flag_only = d_trace == nullptr;
         x.clk = getenv("SCRUBBY_HIP_DBG") ? 1 : 0; x.probe = getenv("SCRUBBY_HIP_NO_PROBE") ? 0 : 1;
         x.drop = k.locus ? c->d_lr_drop : nullptr; x.fb_list = c->d_lr_fb; x.n_fb = &c->d_ctr->lr_n_fb;
+        x.exact_list = c->d_lext_exact_list; x.n_exact = &c->d_ctr->lext_n_exact;
         SH_HIP(hipEventRecord(c->ev_ext[0], s));
         auto sync_ctr = [&]() -> sh_status {
             SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -3766,7 +3868,47 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
             SH_HIP(hipGetLastError());
             return SH_OK;
         };
-        uint32_t n_big_a = 0;
+        uint32_t n_big_a = 0, n_exact_reads = 0, n_ondemand = 0;
+        // Reads that outgrew the second size of a kernel's working memory too (minimap2 has no such limits): memory is allocated for them,
+        // four times the size before, until they fit (a chain-anchor count in the millions, an alignment of max_sw_mat cells); only when
+        // the device cannot give it do they keep their chain-level answer, counted and named in a warning.  xa: the arguments of the
+        // second-size pass; h_ctr holds its counters.
+        auto on_demand = [&](int phase, ExtLongArgs xa) -> sh_status {      // phase: 0 chains, 1 regions / alignment, 2 chains with the exact long join
+            uint32_t n_un = c->h_ctr->lext_n_unres;
+            n_ondemand += n_un;
+            LongSizes q = phase == 2 ? c->lext_exact_sz : c->lext_sz[phase * 2 + 1];
+            int cur = 0;
+            for (int round = 0; n_un > 0; ++round) {
+                uint8_t *buf = nullptr;
+                unsigned long long per = 0; uint32_t waves = 0;
+                if (round < 5) {
+                    q.cap_a = (uint32_t)std::min<uint64_t>((uint64_t)q.cap_a * 4, 1u << 28); q.cap_u = (uint32_t)std::min<uint64_t>((uint64_t)q.cap_u * 4, 1u << 26); q.cap_r = q.cap_u;
+                    q.cap_m = (uint32_t)std::min<uint64_t>((uint64_t)q.cap_m * 4, 1u << 26); q.cap_k = (uint32_t)std::min<uint64_t>((uint64_t)q.cap_k * 4, 1u << 22);
+                    q.cap_t = (uint32_t)std::min<uint64_t>((uint64_t)q.cap_t * 4, 1u << 28); q.cap_p = std::min<uint64_t>(q.cap_p * 4, 4ull << 30);
+                    per = long_ws_carve(nullptr, nullptr, q);
+                    for (waves = std::min<uint32_t>(n_un, 4); waves > 0 && hipMalloc(&buf, per * waves) != hipSuccess; waves >>= 1) { buf = nullptr; (void)hipGetLastError(); }
+                }
+                if (!buf) {      // no memory to be had: counted, warned about, chain-level answer
+                    hipLaunchKernelGGL(k_lext_giveup, dim3(16), dim3(256), 0, s, (const uint32_t *)c->d_lext_unres[cur], n_un, d_flags, d_trace, c->d_lhdr, c->d_ctr);
+                    SH_HIP(hipMemsetAsync(&c->d_ctr->lext_n_unres, 0, 4, s));
+                    return sync_ctr();
+                }
+                const uint32_t zero2[4] = {0, 0, n_un, 0};
+                SH_HIP(hipMemcpyAsync(&c->d_ctr->lext_n_unres, zero2, 16, hipMemcpyHostToDevice, s));      // lext_n_unres, lext_ticket_unres, lext_n_unres_in
+                xa.scratch = buf; xa.scratch_per_wave = per; xa.sz = q;
+                xa.list = c->d_lext_unres[cur]; xa.n_list = &c->d_ctr->lext_n_unres_in; xa.ticket = &c->d_ctr->lext_ticket_unres;
+                xa.big_list = nullptr; xa.n_big = nullptr; xa.part = 0; xa.unres_list = c->d_lext_unres[cur ^ 1]; xa.n_unres = &c->d_ctr->lext_n_unres;
+                if (phase == 0) hipLaunchKernelGGL((k_long_chains<4096, false>), dim3(waves), dim3(64), 0, s, xa);
+                else if (phase == 2) hipLaunchKernelGGL((k_long_chains<64, true>), dim3(waves), dim3(64), 0, s, xa);
+                else hipLaunchKernelGGL(k_regs_align_long, dim3(waves), dim3(64), 0, s, xa);
+                sh_status st = sync_ctr();
+                hipFree(buf);
+                if (st != SH_OK) return st;
+                if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
+                n_un = c->h_ctr->lext_n_unres; cur ^= 1;
+            }
+            return SH_OK;
+        };
         // One round of the stage: round 0 over every read with a chain; round 1 - flag-only calls whose anchors k_lr_locus thinned out - over the
         // reads whose answer could depend on what was left out, after the repeat path has chained them again with every anchor
         auto ext_round = [&](int round) -> sh_status {
@@ -3796,19 +3938,35 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 xg.ticket = &c->d_ctr->lext_ticket_g; xg.part = 2;      // same ring as the others (19 KB of LDS: they share CUs); what outgrows the ring joins the big list
                 SH_HIP(hipEventRecord(c->evx[0], s));
                 SH_HIP(hipStreamWaitEvent(c->sx[0], c->evx[0], 0));
-                hipLaunchKernelGGL(k_long_chains<512>, dim3(c->lext_waves[1]), dim3(64), 0, c->sx[0], xg);
+                hipLaunchKernelGGL((k_long_chains<512, false>), dim3(c->lext_waves[1]), dim3(64), 0, c->sx[0], xg);
                 SH_HIP(hipEventRecord(c->evx[1], c->sx[0]));
-                hipLaunchKernelGGL(k_long_chains<512>, dim3(c->lext_waves[0]), dim3(64), 0, s, xa);
+                hipLaunchKernelGGL((k_long_chains<512, false>), dim3(c->lext_waves[0]), dim3(64), 0, s, xa);
                 SH_HIP(hipStreamWaitEvent(s, c->evx[1], 0));
                 sh_status st = sync_ctr(); if (st != SH_OK) return st;
                 if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;       // hand-over buffers or arena full: the caller cuts the chunk in two
                 if (c->h_ctr->lext_n_big > 0) {
                     xa.scratch = c->d_lext[1]; xa.scratch_per_wave = c->lext_per_wave[1]; xa.sz = c->lext_sz[1];
                     xa.list = c->d_lext_big; xa.n_list = &c->d_ctr->lext_n_big; xa.ticket = &c->d_ctr->lext_ticket_big; xa.big_list = nullptr; xa.n_big = nullptr; xa.part = 0;
-                    hipLaunchKernelGGL(k_long_chains<4096>, dim3(c->lext_waves[1]), dim3(64), 0, s, xa);
+                    xa.unres_list = c->d_lext_unres[0]; xa.n_unres = &c->d_ctr->lext_n_unres;
+                    hipLaunchKernelGGL((k_long_chains<4096, false>), dim3(c->lext_waves[1]), dim3(64), 0, s, xa);
                     st = sync_ctr(); if (st != SH_OK) return st;
                     if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
+                    st = on_demand(0, xa); if (st != SH_OK) return st;
                 }
+            }
+            if (c->h_ctr->lext_n_exact > 0) {
+                // the long join of these reads met two candidates of equal priority (or outgrew the LDS ring, or rmq_size_cap): once more, on
+                // the literal trees (sh_rmq_tree.h)
+                n_exact_reads += c->h_ctr->lext_n_exact;
+                ExtLongArgs xe = x;
+                xe.scratch = c->d_lext_exact; xe.scratch_per_wave = c->lext_exact_per_wave; xe.sz = c->lext_exact_sz;
+                xe.list = c->d_lext_exact_list; xe.n_list = &c->d_ctr->lext_n_exact; xe.ticket = &c->d_ctr->lext_ticket_exact;
+                xe.big_list = nullptr; xe.n_big = nullptr; xe.part = 0; xe.exact_list = nullptr; xe.n_exact = nullptr;
+                xe.unres_list = c->d_lext_unres[0]; xe.n_unres = &c->d_ctr->lext_n_unres;
+                hipLaunchKernelGGL((k_long_chains<64, true>), dim3(c->lext_exact_waves), dim3(64), 0, s, xe);
+                sh_status st = sync_ctr(); if (st != SH_OK) return st;
+                if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
+                st = on_demand(2, xe); if (st != SH_OK) return st;
             }
             SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "long-read extension stage: internal overflow code %u", c->h_ctr->ext_overflow);
             ext_list += c->h_ctr->ext_n_list;
@@ -3823,8 +3981,10 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 if (c->h_ctr->lext_n_big2 > 0) {
                     xb.scratch = c->d_lext[3]; xb.scratch_per_wave = c->lext_per_wave[3]; xb.sz = c->lext_sz[3];
                     xb.list = c->d_lext_big2; xb.n_list = &c->d_ctr->lext_n_big2; xb.ticket = &c->d_ctr->lext_ticket_big2; xb.big_list = nullptr; xb.n_big = nullptr;
+                    xb.unres_list = c->d_lext_unres[0]; xb.n_unres = &c->d_ctr->lext_n_unres;
                     hipLaunchKernelGGL(k_regs_align_long, dim3(c->lext_waves[3]), dim3(64), 0, s, xb);
                     st = sync_ctr(); if (st != SH_OK) return st;
+                    st = on_demand(1, xb); if (st != SH_OK) return st;
                 }
                 n_big_a += c->h_ctr->lext_n_big2;
             }
@@ -3842,7 +4002,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
             memset(z.ext_n_recs, 0, sizeof(z.ext_n_recs)); memset(z.ext_n_anch, 0, sizeof(z.ext_n_anch)); memset(z.lext_hist, 0, sizeof(z.lext_hist));
             z.n_defer = 0; z.arena_cursor = 0;
             z.n_big[0] = n_fb; z.n_big[1] = 0; z.n_big_defer[0] = z.n_big_defer[1] = 0;
-            z.ext_n_list = 0; z.ext_ticket = 0; z.lext_ticket_g = 0; z.lext_n_big = 0; z.lext_ticket_big = 0; z.lext_n_big2 = 0; z.lext_ticket_big2 = 0; z.lext_ticket_b = 0;
+            z.ext_n_list = 0; z.ext_ticket = 0; z.lext_ticket_g = 0; z.lext_n_big = 0; z.lext_ticket_big = 0; z.lext_n_big2 = 0; z.lext_ticket_big2 = 0; z.lext_ticket_b = 0; z.lext_n_unres = 0; z.lext_ticket_unres = 0; z.lext_n_exact = 0; z.lext_ticket_exact = 0;
             SH_HIP(hipMemcpyAsync(c->d_ctr, &z, sizeof(Counters), hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_lext_forget, dim3(64), dim3(256), 0, s, (const uint32_t *)c->d_lr_fb, n_fb, c->sink.head, c->d_lr_drop, &c->d_ctr->lr_fb_had);
             SH_HIP(hipMemcpyAsync(c->d_big[0][0], c->d_lr_fb, (size_t)n_fb * 4, hipMemcpyDeviceToDevice, s));
@@ -3877,7 +4037,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         SH_HIP(hipEventRecord(c->ev_ext[1], s));
         SH_HIP(hipEventSynchronize(c->ev_ext[1]));
         ext_regions = c->h_ctr->ext_regions; ext_dropped = c->h_ctr->ext_dropped;
-        if (stats) { stats->n_ext_unresolved += c->h_ctr->lext_unresolved; stats->n_rmq_rechained += c->h_ctr->lext_rechained; stats->n_rmq_tied += c->h_ctr->lext_rmq_tie; }
+        if (stats) { stats->n_ext_unresolved += c->h_ctr->lext_unresolved; stats->n_rmq_rechained += c->h_ctr->lext_rechained; stats->n_rmq_tied += c->h_ctr->lext_rmq_tie; stats->n_rmq_exact += n_exact_reads; stats->n_ext_ondemand += n_ondemand; }
         hipEventElapsedTime(&ms_ext, c->ev_ext[0], c->ev_ext[1]);
     } else if (c->ext) {
         ExtArgs x{};

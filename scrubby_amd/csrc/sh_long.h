@@ -17,6 +17,7 @@
 #pragma once
 #include "sh_align.h"
 #include "sh_chain.h"
+#include "sh_rmq_tree.h"
 
 struct LAnchor { uint64_t x, y; };      // minimap2's mm128_t for an anchor: y = flags | q_span << 32 | qpos
 #define LY_LONG_JOIN (1ull << 40)
@@ -59,10 +60,11 @@ struct LongWs {
     uint8_t *qseq, *tseq;           // 2 * cap_q, cap_t
     uint8_t *kmem; int32_t *kH, *koff; uint8_t *kp;      // ksw_extd2: state for up to cap_k x cap_k bases, cap_p direction bytes
     int32_t *lH, *lE, *lHmax;       // local alignment rows (cap_k + 8 each)
+    RqNode *rq0, *rq1;              // phase 2 (the exact long join, sh_rmq_tree.h): node pools of the two trees, cap_a + 2 each
     uint32_t cap_a, cap_u, cap_r, cap_m, cap_c, cap_q, cap_t, cap_k; unsigned long long cap_p;
 };
 
-struct LongSizes { uint32_t cap_a, cap_u, cap_r, cap_m, cap_q, cap_t, cap_k; unsigned long long cap_p; int32_t phase; };      // phase 0: the chains kernel, 1: the regions / alignment kernel
+struct LongSizes { uint32_t cap_a, cap_u, cap_r, cap_m, cap_q, cap_t, cap_k; unsigned long long cap_p; int32_t phase; };      // phase 0: the chains kernel, 1: the regions / alignment kernel, 2: the chains kernel with the long join on the literal trees
 
 __host__ __device__ inline unsigned long long long_ws_carve(LongWs *W, uint8_t *base, const LongSizes &z)
 {
@@ -71,7 +73,8 @@ __host__ __device__ inline unsigned long long long_ws_carve(LongWs *W, uint8_t *
     const unsigned long long ca = z.cap_a, cu = z.cap_u, cr = z.cap_r, cq = z.cap_q, ct = z.cap_t, ck = z.cap_k;
     const unsigned long long cc = 2ull * (cq + ct) + 64;
     LongWs w{};
-    if (z.phase == 0) {
+    if (z.phase == 0 || z.phase == 2) {
+        if (z.phase == 2) { w.rq0 = (RqNode *)take((ca + 2) * sizeof(RqNode)); w.rq1 = (RqNode *)take((ca + 2) * sizeof(RqNode)); }
         w.a = (LAnchor *)take(ca * 16); w.b = (LAnchor *)take(ca * 16);
         w.f = (int32_t *)take(ca * 4); w.p = (int32_t *)take(ca * 4); w.t = (int32_t *)take(ca * 4); w.v = (int32_t *)take(ca * 4);
         w.pri = (double *)take(ca * 8); w.sk = (SKey *)take(ca * sizeof(SKey)); w.sk2 = (SKey *)take(ca * sizeof(SKey));
@@ -488,6 +491,87 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
     if (ok) for (int32_t j = blk_done * 64 + lane; j < n; j += 64) { f[j] = L.rf[j & M]; p[j] = L.rp[j & M]; }      // the last, incomplete block(s)
     if (dbg) { dbg->d[0] += (unsigned long long)n; dbg->d[1] += d_ring; dbg->d[2] += d_oldsteps; dbg->d[3] += d_old; dbg->d[4] += d_nin; dbg->d[5] += d_chunks; dbg->d[6] += 1; if ((unsigned long long)n > dbg->d[7]) dbg->d[7] = (unsigned long long)n; }
     return ok;
+}
+
+// ---- mg_lchain_rmq's scoring pass on the literal trees (sh_rmq_tree.h): one lane, statement for statement ---------------------------------
+// a[] sorted by x; t[] zeroed by the caller (the skip marks; the backtrack clears them again).  f, p as lr_rmq_fill leaves them.
+__device__ __noinline__ bool lr_rmq_fill_tree(const LongParams &P, int32_t max_dist, int32_t bw, int32_t n, const LAnchor *a, int32_t *f, int32_t *p, int32_t *t,
+                                              RqNode *pool0, RqNode *pool1, int32_t pool_cap)
+{
+    int32_t okv = 1;
+    if (al_lane() == 0) {
+        RqTree T0, T1;
+        rq_init(T0, pool0, pool_cap); rq_init(T1, pool1, pool_cap);
+        const float chn_pen_gap = P.pen_gap, chn_pen_skip = P.pen_skip;
+        const int32_t max_chn_skip = P.max_skip, cap_rmq_size = P.rmq_size_cap;
+        int32_t max_dist_inner = P.rmq_inner_dist;
+        if (max_dist < bw) max_dist = bw;
+        if (max_dist_inner < 0) max_dist_inner = 0;
+        if (max_dist_inner > max_dist) max_dist_inner = max_dist;
+        int32_t i, i0, st = 0, st_inner = 0;
+        auto root_size = [](const RqTree &tr) -> int32_t { return tr.root != RQ_NIL ? (int32_t)tr.n[tr.root].size : 0; };
+        for (i = i0 = 0; i < n && okv; ++i) {
+            int32_t max_j = -1;
+            const uint64_t xi = a[i].x; const int32_t yi = (int32_t)a[i].y;
+            const int32_t q_span = (int32_t)(a[i].y >> 32 & 0xff);
+            int32_t max_f = q_span;
+            if (i0 < i && a[i0].x != xi) {      // add in-range anchors
+                for (int32_t j = i0; j < i; ++j) {
+                    const double pri = -((double)f[j] + 0.5 * (double)chn_pen_gap * (double)((int32_t)a[j].x + (int32_t)a[j].y));
+                    for (int k = 0; k < (max_dist_inner > 0 ? 2 : 1); ++k) {
+                        RqTree &T = k ? T1 : T0;
+                        const int32_t x = rq_alloc(T);
+                        if (x == RQ_NIL) { okv = 0; break; }
+                        T.n[x].y = (int32_t)a[j].y; T.n[x].i = j; T.n[x].pri = pri;
+                        rq_insert(T, x);
+                    }
+                }
+                i0 = i;
+            }
+            while (st < i && (xi >> 32 != a[st].x >> 32 || xi > a[st].x + (uint64_t)max_dist || root_size(T0) > cap_rmq_size)) {
+                const int32_t e = rq_erase(T0, (int32_t)a[st].y, st);
+                if (e != RQ_NIL) rq_free(T0, e);
+                ++st;
+            }
+            if (max_dist_inner > 0) {
+                while (st_inner < i && (xi >> 32 != a[st_inner].x >> 32 || xi > a[st_inner].x + (uint64_t)max_dist_inner || root_size(T1) > cap_rmq_size)) {
+                    const int32_t e = rq_erase(T1, (int32_t)a[st_inner].y, st_inner);
+                    if (e != RQ_NIL) rq_free(T1, e);
+                    ++st_inner;
+                }
+            }
+            const int32_t q = rq_rmq(T0, yi - max_dist, INT32_MAX, yi, 0);
+            if (q != RQ_NIL) {
+                int32_t sc, exact, width, n_skip = 0;
+                int32_t j = T0.n[q].i;
+                sc = f[j] + lr_sc_simple((int32_t)(xi - a[j].x), yi - (int32_t)a[j].y, (int32_t)(a[j].y >> 32 & 0xff), chn_pen_gap, chn_pen_skip, exact, width);
+                if (width <= bw && sc > max_f) { max_f = sc; max_j = j; }
+                if (!exact && T1.root != RQ_NIL && yi > 0) {
+                    RqItr it;
+                    if (rq_itr_find_le(T1, yi - 1, n, it)) {
+                        do {
+                            const RqNode &e = T1.n[it.stack[it.top]];
+                            if (e.y < yi - max_dist_inner) break;
+                            j = e.i;
+                            int32_t ex2;
+                            sc = f[j] + lr_sc_simple((int32_t)(xi - a[j].x), yi - (int32_t)a[j].y, (int32_t)(a[j].y >> 32 & 0xff), chn_pen_gap, chn_pen_skip, ex2, width);
+                            if (width <= bw) {
+                                if (sc > max_f) {
+                                    max_f = sc; max_j = j;
+                                    if (n_skip > 0) --n_skip;
+                                } else if (t[j] == i) {
+                                    if (++n_skip > max_chn_skip) break;
+                                }
+                                if (p[j] >= 0) t[p[j]] = i;
+                            }
+                        } while (rq_itr_prev(T1, it));
+                    }
+                }
+            }
+            f[i] = max_f; p[i] = max_j;
+        }
+    }
+    return al_b0(okv) != 0;
 }
 
 // ---- mg_chain_backtrack (lane 0) -----------------------------------------------------------------------------------------
@@ -1390,7 +1474,9 @@ __device__ inline bool lr_region_kept(const LongParams &P, int32_t qlen, const L
 // score at most k * drop (none at all when drop < min_cnt: such a read is complete for every purpose).  What the answer needs beyond that, and what is checked here (5 = the read must be redone with every anchor, C.err
 // says why): whether mm_map_frag re-chains at all (more than one chain in the first pass; for a short read also which chain comes first),
 // and that regs[0] - the only region a flag-only call asks about - is among the chains kept: top score > k * drop.
-template <int NR>
+// EXACT: the long join on the literal trees (lr_rmq_fill_tree).  Without it a join that meets two candidates of equal priority, or that the
+// LDS ring cannot hold, returns 6: the read is redone by the EXACT instance of the kernel.
+template <int NR, bool EXACT>
 __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const LongArena &AR, LongOut &out, uint32_t drop = 0)
 {
     const LongParams &P = *C.P;
@@ -1503,10 +1589,20 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const Long
             lr_sync();
             int32_t tie = 0;
             lr_tick(C.clk, 1);
-            if (!lr_rmq_fill<NR>(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie, C.clk)) { C.err = 6; return 3; }
+            if constexpr (EXACT) {
+                for (int32_t i = lane; i < n_a; i += 64) W.t[i] = 0;
+                lr_sync();
+                if (!lr_rmq_fill_tree(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.t, W.rq0, W.rq1, (int32_t)W.cap_a + 2)) { C.err = 6; return 3; }
+            } else {
+                if (!lr_rmq_fill<NR>(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie, C.clk)) {
+                    if (NR < 4096 && n_a <= P.rmq_size_cap) { C.err = 6; return 3; }      // beyond this ring: the pass with the large one
+                    C.err = 51; return 6;                                                   // beyond that too (or rmq_size_cap): the trees
+                }
+                if (tie) { C.err = 50; return 6; }      // the scan's choice among equal priorities is not the tree's
+            }
             lr_sync();
             lr_tick(C.clk, 2);
-            out.rmq_tie = tie;
+            out.rmq_tie = 0;
             // mg_chain_backtrack
             int32_t n_z = 0;
             for (int32_t i0 = 0; i0 < n_a; i0 += 64) {

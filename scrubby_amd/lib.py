@@ -74,7 +74,7 @@ class Stats(C.Structure):
         ("n_ext_shortcut", C.c_uint64), ("n_ext_fallback", C.c_uint64), ("ms_ext_fallback", C.c_double),
         ("n_ext_unresolved", C.c_uint64), ("n_rmq_rechained", C.c_uint64), ("n_rmq_tied", C.c_uint64),
         ("n_dp_parallel", C.c_uint64), ("n_dp_dirty", C.c_uint64), ("n_top_settled", C.c_uint64),
-        ("n_locus_reads", C.c_uint64), ("n_locus_redone", C.c_uint64), ("n_rmq_exact", C.c_uint64),
+        ("n_locus_reads", C.c_uint64), ("n_locus_redone", C.c_uint64), ("n_rmq_exact", C.c_uint64), ("n_ext_ondemand", C.c_uint64),
     ]
 
     def as_dict(self):

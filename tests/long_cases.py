@@ -89,3 +89,40 @@ def long_edge_reads(ref, n=240, seed=11, max_len=6000):
     offs = np.zeros(len(recs) + 1, np.uint64)
     offs[1:] = np.cumsum([len(x) for x in recs])
     return recs, bases, offs
+
+
+def tandem_case(seed=5, n_arrays=24, n_reads=240):
+    """A reference with short PERFECT tandem arrays (4-8 copies of a 40-180 bp monomer, below any occurrence cut-off) in unique sequence,
+    and reads across them with a different copy number than the reference.  The anchors of such a read form a lattice - (x + m P, y + n P)
+    for every pair of copies - and two lattice points on one anti-diagonal reached by mirror-image gaps carry the same chaining score: the
+    long join's range-minimum query meets candidates of EQUAL priority, which krmq_rmq resolves by the shape of its tree
+    (oracle/mm_rmq.c; scrubby_amd/csrc/sh_rmq_tree.h).  Returns (contigs, bases, offsets)."""
+    rng = np.random.default_rng(seed)
+
+    def rnd(m):
+        return bytes(ACGT[rng.integers(0, 4, m)])
+    parts, arrays, pos = [], [], 0
+    for _ in range(n_arrays):
+        flank = rnd(int(rng.integers(6000, 9000)))
+        mono = rnd(int(rng.integers(40, 180)))
+        copies = int(rng.integers(4, 9))
+        parts += [flank, mono * copies]
+        arrays.append((pos + len(flank), mono, copies))
+        pos += len(flank) + len(mono) * copies
+    parts.append(rnd(8000))
+    ref = b"".join(parts)
+    recs = []
+    for it in range(n_reads):
+        st, mono, copies = arrays[it % n_arrays]
+        left = int(rng.integers(600, 2500)); right = int(rng.integers(600, 2500))
+        c2 = max(2, copies + int(rng.integers(-2, 3)))                       # the read's copy number
+        src = ref[st - left:st] + mono * c2 + ref[st + len(mono) * copies:st + len(mono) * copies + right]
+        e = (0.0, 0.004, 0.02)[it % 3]                                       # exact, HiFi-like, ONT-like
+        r = _noisy(rng, src, e, e * 0.75) if e > 0 else src
+        if it % 4 == 1:
+            r = _rc(r)
+        recs.append(r)
+    bases = np.frombuffer(b"".join(recs), np.uint8)
+    offs = np.zeros(len(recs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(x) for x in recs])
+    return [ref], bases, offs
