@@ -3958,6 +3958,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 // the long join of these reads met two candidates of equal priority (or outgrew the LDS ring, or rmq_size_cap): once more, on
                 // the literal trees (sh_rmq_tree.h)
                 n_exact_reads += c->h_ctr->lext_n_exact;
+                const auto t_ex = std::chrono::steady_clock::now();
                 ExtLongArgs xe = x;
                 xe.scratch = c->d_lext_exact; xe.scratch_per_wave = c->lext_exact_per_wave; xe.sz = c->lext_exact_sz;
                 xe.list = c->d_lext_exact_list; xe.n_list = &c->d_ctr->lext_n_exact; xe.ticket = &c->d_ctr->lext_ticket_exact;
@@ -3966,7 +3967,10 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 hipLaunchKernelGGL((k_long_chains<64, true>), dim3(c->lext_exact_waves), dim3(64), 0, s, xe);
                 sh_status st = sync_ctr(); if (st != SH_OK) return st;
                 if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
+                const uint32_t n_ex_big = c->h_ctr->lext_n_unres;
                 st = on_demand(2, xe); if (st != SH_OK) return st;
+                if (getenv("SCRUBBY_HIP_DBG")) fprintf(stderr, "[dbg] exact long join: %u reads (%u with tied priorities so far), %u beyond the first size, %.1f ms\n", c->h_ctr->lext_n_exact, c->h_ctr->lext_rmq_tie, n_ex_big,
+                                                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ex).count());
             }
             SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "long-read extension stage: internal overflow code %u", c->h_ctr->ext_overflow);
             ext_list += c->h_ctr->ext_n_list;

@@ -418,8 +418,45 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 }
             }
         }
+        bool tie_pending = false; int32_t tie_sc = 0;
+        if (bj >= 0 && ties > 1) {
+            // Several candidates share the smallest priority; the tree returns ONE of them, which one depends on its shape.  The state after
+            // this step is the same whichever it is when (a) none of them is accepted (band, score) and they agree on `exact` - the step
+            // keeps max_f = q_span, max_j = -1 and runs the inner scan or not - or (b) all are accepted with one score, none exact, and the
+            // inner scan then finds a strictly better predecessor: max_f and the skip counter evolve alike and max_j is the scan's.
+            // Anything else makes the read one for the literal trees (sh_rmq_tree.h).
+            const int32_t ring_lo2 = blk_done > LRQ_RBLK(LRQ_INNER) ? (blk_done - LRQ_RBLK(LRQ_INNER)) * 64 : 0;
+            uint32_t n_tied = 0, n_acc = 0, n_ex = 0;
+            int32_t sc_lo = INT32_MAX, sc_hi = INT32_MIN;
+            for (int32_t b = (i0 - 1) >> 6; b >= (st >> 6) && i0 > 0; --b) {
+                const bool in_ring = b * 64 >= ring_lo2;
+                if (b < blk_done) { const double bm = in_ring ? L.bml[b & 63] : lr_cc_f64(bmin + b); if (bm > bp) continue; }
+                const int32_t j = b * 64 + lane;
+                bool tied = false; int32_t fb = 0, dr = 0, dq = 0, span_b = kk;
+                if (j >= st && j < i0) {
+                    const bool near = i - j < LRQ_INNER - 64;
+                    const int32_t yj = near ? L.ry[j & M] : (int32_t)a[j].y;
+                    if (yj > qi - max_dist && (yj < qi || (yj == qi && j == 0))) {
+                        const double pj = near ? L.rpri[j & M] : lr_cc_f64(pri + j);
+                        if (pj == bp) {
+                            tied = true;
+                            if (near) { fb = L.rf[j & M]; dr = (int32_t)((uint32_t)xi - L.rx[j & M]); dq = qi - yj; }
+                            else { fb = (int32_t)cc_u32(f + j); dr = (int32_t)(xi - a[j].x); dq = qi - yj; span_b = (int32_t)(a[j].y >> 32 & 0xff); }
+                        }
+                    }
+                }
+                int32_t ex = 0, wd = 0, sc = 0; bool acc = false;
+                if (tied) { sc = fb + lr_sc_simple(dr, dq, span_b, pen_gap, pen_skip, ex, wd); acc = wd <= bw && sc > q_span_i; }
+                n_tied += (uint32_t)__popcll(__ballot(tied)); n_acc += (uint32_t)__popcll(__ballot(acc)); n_ex += (uint32_t)__popcll(__ballot(tied && ex));
+                if (acc) { sc_lo = sc < sc_lo ? sc : sc_lo; sc_hi = sc > sc_hi ? sc : sc_hi; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int32_t a1 = __shfl_xor(sc_lo, o), a2 = __shfl_xor(sc_hi, o); sc_lo = a1 < sc_lo ? a1 : sc_lo; sc_hi = a2 > sc_hi ? a2 : sc_hi; }
+            if (n_acc == 0 && (n_ex == 0 || n_ex == n_tied)) { /* (a) */ }
+            else if (n_acc == n_tied && sc_lo == sc_hi && n_ex == 0) { tie_pending = true; tie_sc = sc_lo; }      // (b), if the inner scan improves on it
+            else ++tie_cnt;
+        }
         if (bj >= 0) {
-            if (ties > 1) ++tie_cnt;      // the smallest index among the equal priorities is taken; the caller reports the read
             int32_t exact, width, n_skip = 0;
             int32_t fb, dr, dq, span_b;
             if (i - bj < LRQ_INNER - 64) { fb = L.rf[bj & M]; dr = (int32_t)((uint32_t)xi - L.rx[bj & M]); dq = qi - L.ry[bj & M]; span_b = kk; }
@@ -481,6 +518,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 }
             }
         }
+        if (tie_pending && max_f <= tie_sc) ++tie_cnt;      // no better predecessor turned up: max_j is the tree's choice among the tied
         if (lane == 0) { L.rx[i & M] = (uint32_t)xi; L.ry[i & M] = qi; L.rf[i & M] = max_f; L.rp[i & M] = max_j; }
         hi_prev = (uint32_t)(xi >> 32);
         __builtin_amdgcn_wave_barrier();
