@@ -126,13 +126,14 @@ typedef struct sh_stats {
     double   ms_ext_fallback;  /* wall time of that fallback (re-chaining + the complete procedure) */
     uint64_t n_ext_unresolved; /* reads beyond the extension stage's working memory (long reads: its largest; sr: 16 384 chains), left at their chain-level answer (see the warning) */
     uint64_t n_rmq_rechained;  /* long-read presets: reads re-chained by the RMQ long join */
-    uint64_t n_rmq_tied;       /* ... of which met two candidates of equal priority in the join (the smaller index was taken) */
+    uint64_t n_rmq_tied;       /* ... of which met candidates of equal priority in the join in a way that can change the chains (ties that cannot are recognised and pass) */
     uint64_t n_dp_parallel;    /* repeat-path reads whose mg_lchain_dp ran as the parallel recurrence */
     uint64_t n_dp_dirty;       /* ... their anchors that broke its premise (their clusters were chained by the sequential code) */
     uint64_t n_top_settled;    /* ... reads whose candidates for regs[0] were read off the whole read, no cluster visited */
     uint64_t n_locus_reads;    /* long-read presets, flag-only: reads chained over the reference windows that can hold regs[0] only */
     uint64_t n_locus_redone;   /* ... of which the answer could depend on what was left out: redone with every anchor */
     uint64_t n_rmq_exact;      /* long-read presets: reads whose RMQ join was redone on the literal krmq tree (tied priorities, windows beyond the LDS ring, rmq_size_cap) */
+    uint64_t n_rmq_open;       /* ... reads of more than SCRUBBY_HIP_RMQ_EXACT_MAX (4096) chain anchors that met such a tie: the scan's choice (smallest index) stands - the one documented divergence of the long join */
     uint64_t n_ext_ondemand;   /* reads beyond the extension stage's prepared working-memory sizes, redone with memory allocated for them (visits, both kernels) */
 } sh_stats;
 
@@ -394,6 +395,10 @@ sh_status sh_pack_flags_device(const uint8_t *d_flags, uint64_t n, uint8_t *d_bi
 /* ---- micro-benchmarks for the roofline (bench.py) ---------------------------------------- */
 /* random 16-B slot gathers over the index table; returns achieved GB/s of useful bytes */
 sh_status sh_bench_gather(const sh_index *idx, uint64_t n_probes, int32_t iters, double *out_gbs_useful, double *out_ms);
+/* Test aid: the krmq tree of the long join (csrc/sh_rmq_tree.h) on the device - one lane runs a random insert / erase / query sequence with
+ * heavily tied priorities (the generator of oracle/mm_rmq.c's mmo_rmq_trace) and returns, per query, the element the tree answered with
+ * (its i, or -1); cache = entries of the LDS node cache (0: none, else a power of two <= 1024).  out: host array of n_ops int64. */
+sh_status sh_dbg_rmq_trace(int32_t device, uint64_t seed, int32_t n_ops, int32_t key_range, int32_t fifo, int32_t cache, int64_t *out, int64_t *n_out);
 
 #ifdef __cplusplus
 }

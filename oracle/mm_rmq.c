@@ -436,3 +436,39 @@ int mmo_rmq_selftest(uint64_t seed, int n_ops, int key_range)
     free(T.n); free(ly); free(li); free(lp);
     return bad;
 }
+
+/* The answers of a random insert / erase / query sequence with HEAVILY tied priorities (values 0..9): which element krmq_rmq returns
+ * among equal minima is decided by the shape of the tree and by the subtree-minimum pointers its rotations carried over.  The device
+ * restatement (scrubby_amd/csrc/sh_rmq_tree.h, compiled for the host by tests/test_rmq_tree_cpu.py) must give the same sequence.
+ * Erases are FIFO (mg_lchain_rmq's window) when fifo != 0.  out[] receives one int64 per query: the element's i, or -1. */
+int64_t mmo_rmq_trace(uint64_t seed, int n_ops, int key_range, int fifo, int64_t *out)
+{
+    rq_tree T; int op; int64_t n_out = 0, head = 0, n_all = 0;
+    int32_t *ly = (int32_t *)malloc(4 * (size_t)(n_ops + 1)); int64_t *li = (int64_t *)malloc(8 * (size_t)(n_ops + 1));
+    uint64_t s = seed * 0x9E3779B97F4A7C15ULL + 1;
+#define RND() (s ^= s << 13, s ^= s >> 7, s ^= s << 17, s)
+    T.n = 0; T.cap = T.n_used = 0; T.free_head = NIL; T.root = NIL;
+    for (op = 0; op < n_ops; ++op) {
+        const unsigned r = (unsigned)(RND() % 10);
+        const int64_t n_live = n_all - head;
+        if (r < 5 || n_live == 0) {
+            const int32_t x = rq_alloc(&T);
+            T.n[x].y = (int32_t)(RND() % (uint64_t)key_range); T.n[x].i = op; T.n[x].pri = (double)(RND() % 10);
+            ly[n_all] = T.n[x].y; li[n_all] = op; ++n_all;
+            rq_insert(&T, x);
+        } else if (r < 7) {
+            const int64_t k = fifo ? head : head + (int64_t)(RND() % (uint64_t)n_live);
+            const int32_t e = rq_erase(&T, ly[k], li[k]);
+            if (e != NIL) rq_free(&T, e);
+            ly[k] = ly[head]; li[k] = li[head]; ++head;
+        } else {
+            int32_t a = (int32_t)(RND() % (uint64_t)key_range), b = (int32_t)(RND() % (uint64_t)key_range), q;
+            if (a > b) { const int32_t tt = a; a = b; b = tt; }
+            q = rq_rmq(&T, a, INT32_MAX, b, 0);
+            out[n_out++] = q == NIL ? -1 : T.n[q].i;
+        }
+    }
+#undef RND
+    free(T.n); free(ly); free(li);
+    return n_out;
+}

@@ -210,7 +210,7 @@ extern "C" sh_status sh_classify_batch(const sh_index *idx, const sh_opts *opts,
                 stats->n_ext_reads += ps.n_ext_reads; stats->n_ext_regions += ps.n_ext_regions; stats->n_ext_dropped += ps.n_ext_dropped; stats->ms_ext += ps.ms_ext; stats->n_ext_shortcut += ps.n_ext_shortcut;
                 stats->n_ext_fallback += ps.n_ext_fallback; stats->ms_ext_fallback += ps.ms_ext_fallback; stats->n_ext_unresolved += ps.n_ext_unresolved; stats->n_rmq_rechained += ps.n_rmq_rechained; stats->n_rmq_tied += ps.n_rmq_tied;
                 stats->n_dp_parallel += ps.n_dp_parallel; stats->n_dp_dirty += ps.n_dp_dirty; stats->n_top_settled += ps.n_top_settled;
-                stats->n_locus_reads += ps.n_locus_reads; stats->n_locus_redone += ps.n_locus_redone; stats->n_rmq_exact += ps.n_rmq_exact; stats->n_ext_ondemand += ps.n_ext_ondemand;
+                stats->n_locus_reads += ps.n_locus_reads; stats->n_locus_redone += ps.n_locus_redone; stats->n_rmq_exact += ps.n_rmq_exact; stats->n_ext_ondemand += ps.n_ext_ondemand; stats->n_rmq_open += ps.n_rmq_open;
             }
         }
     });
@@ -577,5 +577,59 @@ extern "C" sh_status sh_bench_gather(const sh_index *idx, uint64_t n_probes, int
     *out_ms = ms / iters;
     *out_gbs_useful = 16.0 * (double)n_probes / (*out_ms * 1e-3) / 1e9;
     hipEventDestroy(e0); hipEventDestroy(e1); hipFree(sink);
+    return SH_OK;
+}
+
+
+// ---- test aid: the long join's tree on the device (sh_rmq_tree.h), one lane, against the oracle's answers --------------------------------
+#include "sh_rmq_tree.h"
+__global__ void k_dbg_rmq_trace(uint64_t seed, int32_t n_ops, int32_t key_range, int32_t fifo, int32_t cache, RqNode *pool, int32_t *ly, int32_t *li, long long *out, long long *n_out_p)
+{
+    __shared__ RqNode s_c[1024];
+    __shared__ int32_t s_t[1024];
+    if (threadIdx.x != 0) return;
+    RqTree T;
+    rq_init(T, pool, n_ops + 4, cache ? RqCache{s_c, s_t, cache - 1} : RqCache{nullptr, nullptr, 0});
+    long long n_out = 0, head = 0, n_all = 0;
+    uint64_t s = seed * 0x9E3779B97F4A7C15ULL + 1;
+#define RND() (s ^= s << 13, s ^= s >> 7, s ^= s << 17, s)
+    for (int op = 0; op < n_ops; ++op) {
+        const unsigned r = (unsigned)(RND() % 10);
+        const long long n_live = n_all - head;
+        if (r < 5 || n_live == 0) {
+            const int32_t x = rq_alloc(T);
+            const int32_t y = (int32_t)(RND() % (uint64_t)key_range); const double pri = (double)(RND() % 10);
+            rq_node_set(T, x, y, op, pri);
+            ly[n_all] = y; li[n_all] = op; ++n_all;
+            rq_insert(T, x);
+        } else if (r < 7) {
+            const long long k = fifo ? head : head + (long long)(RND() % (uint64_t)n_live);
+            const int32_t e = rq_erase(T, ly[k], li[k]);
+            if (e != RQ_NIL) rq_free(T, e);
+            ly[k] = ly[head]; li[k] = li[head]; ++head;
+        } else {
+            int32_t a = (int32_t)(RND() % (uint64_t)key_range), b = (int32_t)(RND() % (uint64_t)key_range);
+            if (a > b) { const int32_t tt = a; a = b; b = tt; }
+            const int32_t q = rq_rmq(T, a, INT32_MAX, b, 0);
+            out[n_out++] = q == RQ_NIL ? -1 : rq_at(T, q)->i;
+        }
+    }
+#undef RND
+    *n_out_p = T.bad ? -(long long)T.bad : n_out;
+}
+extern "C" sh_status sh_dbg_rmq_trace(int32_t device, uint64_t seed, int32_t n_ops, int32_t key_range, int32_t fifo, int32_t cache, int64_t *out, int64_t *n_out)
+{
+    SH_CHECK(out && n_out && n_ops > 0 && key_range > 0 && (cache == 0 || (cache <= 1024 && !(cache & (cache - 1)))), SH_ERR_BAD_ARG, "sh_dbg_rmq_trace: bad argument");
+    SH_HIP(hipSetDevice(device));
+    RqNode *pool = nullptr; int32_t *ly = nullptr, *li = nullptr; long long *d_out = nullptr, *d_n = nullptr;
+    SH_HIP(hipMalloc(&pool, sizeof(RqNode) * ((size_t)n_ops + 4))); SH_HIP(hipMalloc(&ly, 4 * ((size_t)n_ops + 1))); SH_HIP(hipMalloc(&li, 4 * ((size_t)n_ops + 1)));
+    SH_HIP(hipMalloc(&d_out, 8 * (size_t)n_ops)); SH_HIP(hipMalloc(&d_n, 8));
+    hipLaunchKernelGGL(k_dbg_rmq_trace, dim3(1), dim3(64), 0, 0, seed, n_ops, key_range, fifo, cache, pool, ly, li, d_out, d_n);
+    SH_HIP(hipDeviceSynchronize());
+    long long n = 0;
+    SH_HIP(hipMemcpy(&n, d_n, 8, hipMemcpyDeviceToHost));
+    if (n > 0) SH_HIP(hipMemcpy(out, d_out, 8 * (size_t)n, hipMemcpyDeviceToHost));
+    *n_out = n;
+    hipFree(pool); hipFree(ly); hipFree(li); hipFree(d_out); hipFree(d_n);
     return SH_OK;
 }

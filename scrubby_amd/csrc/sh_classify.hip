@@ -95,7 +95,7 @@ struct Counters {
     // anchors kept, reads that must be redone with every anchor (lr_fb list)
     uint32_t n_locus[3], locus_ticket[3], lr_n_fb, lr_locus_reads; unsigned long long lr_locus_in, lr_locus_kept;
     uint32_t lr_fb_why[8], lr_fb_had, lr_pad;
-    uint32_t lext_n_unres, lext_ticket_unres, lext_n_unres_in, lext_pad4, lext_n_exact, lext_ticket_exact;      // reads beyond the stage's second working-memory size: redone with memory allocated for them
+    uint32_t lext_n_unres, lext_ticket_unres, lext_n_unres_in, lext_pad4, lext_n_exact, lext_ticket_exact, lext_rmq_open, lext_pad5;      // reads beyond the stage's second working-memory size: redone with memory allocated for them
     unsigned long long stage_cursor;      // k_expand's raw anchors of the reads k_lr_locus will thin out (their own buffer: 12 B per anchor)
 };
 #define SHARD() ((blockIdx.x + (blockIdx.x >> 6)) & 63)
@@ -3057,6 +3057,7 @@ template <int NR, bool EXACT>
 __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
 {
     __shared__ RmqLdsT<NR> RL;
+    const RqCache TC{nullptr, nullptr, 0};      // (the trees' LDS node cache of sh_rmq_tree.h stays off on the device: see DESIGN.md 3.2)
     const uint32_t lane = threadIdx.x;
     const LongParams P_l = a.P; const LongIn I_l = a.I; const LongArena AR_l = a.AR;      // no pointers into the kernel-argument struct
     LongWs W;
@@ -3067,7 +3068,7 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
         for (int b2 = a.bin_cut; b2 < 32; ++b2) n_giant += a.hist[b2];
         if (a.part == 1) t_first = n_giant; else n_list = n_giant;
     }
-    uint32_t n_rechain = 0;
+    uint32_t n_rechain = 0, n_open = 0;
     LongClk clk{};
     for (;;) {
         uint32_t t = 0;
@@ -3081,10 +3082,18 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
         C.sc_mch = C.sc_mis = C.sc_amb = C.sc_N = 0; C.need_big = false; C.err = 0; C.clk = a.clk ? &clk : nullptr;
         LongOut o;
         const unsigned long long t_r0 = a.clk ? wall_clock64() : 0ull;
-        const int32_t rc = lr_chains_wave<NR, EXACT>(C, RL, AR_l, o, a.drop ? a.drop[r] : 0u);
+        const int32_t rc = lr_chains_wave<NR, EXACT>(C, RL, AR_l, o, a.drop ? a.drop[r] : 0u, TC);
         if (a.clk && lane == 0) { const unsigned long long dt = wall_clock64() - t_r0; atomicMax(&a.ctr->lext_slow, dt << 24 | (unsigned long long)(o.n_chain > 0xffffff ? 0xffffff : o.n_chain)); atomicAdd(&a.ctr->lext_kernel_sum, dt); }
         if (rc == 4) { if (lane == 0) atomicExch(&a.ctr->ext_overflow, 1u); }      // arena full: the host cuts the chunk in two
         else if (rc == 5) { if (lane == 0) lext_redo(a, r, C.err); }
+        else if (rc == 7) {      // beyond the large ring and too large for the one-lane trees: chain-level answer, counted
+            if (lane == 0) {
+                a.flags[r] = 1;
+                if (a.trace) ((int32_t *)(a.trace + r))[7] = 1;
+                LongHdr h{0ull, -1, 0, 0, 0}; AR_l.hdr[r] = h;
+                atomicAdd(&a.ctr->lext_unresolved, 1u); atomicExch(&a.ctr->lext_err_read, r); atomicExch(&a.ctr->lext_err_code, 16u + C.err);
+            }
+        }
         else if (rc == 6) {      // tied priorities / beyond the ring: the EXACT instance of this kernel takes the read
             if (lane == 0) {
                 a.exact_list[atomicAdd(a.n_exact, 1u)] = r;
@@ -3093,11 +3102,12 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
             }
         }
         else if (rc != 0) { if (lane == 0) lext_defer(a, r, 16u + C.err, false); }
-        else { n_rechain += (o.rechained & 2) != 0; }
+        else { n_rechain += (o.rechained & 2) != 0; n_open += o.rmq_tie != 0; }
         __syncthreads();
     }
     if (lane == 0) {
         if (n_rechain) atomicAdd(&a.ctr->lext_rechained, n_rechain);
+        if (n_open) { atomicAdd(&a.ctr->lext_rmq_tie, n_open); atomicAdd(&a.ctr->lext_rmq_open, n_open); }
         if (a.clk) { for (int i = 0; i < LR_NCLK; ++i) atomicAdd(&a.ctr->lext_clk[i], clk.t[i]); for (int i = 0; i < 7; ++i) atomicAdd(&a.ctr->lext_d[i], clk.d[i]); atomicMax(&a.ctr->lext_d[7], clk.d[7]); }
     }
 }
@@ -3199,7 +3209,7 @@ struct sh_ctx {
     LongParams LP{};
     uint8_t *d_lext[4] = {}; unsigned long long lext_per_wave[4] = {}; uint32_t lext_waves[4] = {}; LongSizes lext_sz[4] = {};      // [phase * 2 + tier]
     uint32_t *d_lext_big = nullptr, *d_lext_big2 = nullptr, *d_lext_sorted = nullptr, *d_lext_unres[2] = {}, *d_lext_exact_list = nullptr;
-    uint8_t *d_lext_exact = nullptr; unsigned long long lext_exact_per_wave = 0; uint32_t lext_exact_waves = 0; LongSizes lext_exact_sz{};      // the chains kernel with the long join on the literal trees
+    uint8_t *d_lext_exact[2] = {}; unsigned long long lext_exact_per_wave[2] = {}; uint32_t lext_exact_waves[2] = {}; LongSizes lext_exact_sz[2] = {};      // the chains kernel with the long join on the literal trees
     uint8_t *d_larena = nullptr; unsigned long long larena_bytes = 0; LongHdr *d_lhdr = nullptr;
     // flag-only calls: anchors pre-selected by locus (k_lr_locus) - its read lists, what it left out per read, the reads to redo in full
     SortItem *d_locus[3] = {}; uint32_t *d_lr_drop = nullptr, *d_lr_fb = nullptr; int locus_shift = 0;
@@ -3254,6 +3264,10 @@ static void fill_long_params(const sh_opts &o, int32_t mid_occ, LongParams &L)
     L.max_skip = o.max_chain_skip; L.rmq_inner_dist = o.rmq_inner_dist; L.rmq_size_cap = o.rmq_size_cap; L.rmq_rescue_size = o.rmq_rescue_size; L.rmq_rescue_ratio = o.rmq_rescue_ratio;
     L.pen_gap = (float)(o.chain_gap_scale * 0.01 * o.k); L.pen_skip = (float)(o.chain_skip_scale * 0.01 * o.k);
     L.mid_occ = mid_occ; L.max_max_occ = o.max_max_occ; L.occ_dist = o.occ_dist;
+    // ties of the long join that matter: the literal tree for reads of up to this many chain anchors (4096 by default; a satellite read of 10^5 anchors would keep
+    // one lane chasing pointers for seconds - DESIGN.md 3.2); SCRUBBY_HIP_RMQ_EXACT_MAX=-1 takes every such read to the tree, 0 none
+    L.rmq_exact_max = 4096;
+    if (const char *env = getenv("SCRUBBY_HIP_RMQ_EXACT_MAX")) L.rmq_exact_max = atoi(env);
 }
 
 static void fill_align_params(const sh_opts &o, AlignParams &A)
@@ -3491,15 +3505,17 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             if ((e = hipMalloc(&c->d_lext_sorted, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
             for (auto &q : c->d_lext_unres) if ((e = hipMalloc(&q, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
             if ((e = hipMalloc(&c->d_lext_exact_list, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
-            {   // the exact long join: the first size of the chains kernel plus the node pools of the two trees, for a few hundred waves
-                LongSizes q = z; q.phase = 2;
-                c->lext_exact_sz = q;
-                c->lext_exact_per_wave = long_ws_carve(nullptr, nullptr, q);
-                c->lext_exact_waves = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({256, (1ull << 30) / c->lext_exact_per_wave, std::max<uint64_t>(4, max_reads / 16)}));
-                if ((e = hipMalloc(&c->d_lext_exact, (uint64_t)c->lext_exact_waves * c->lext_exact_per_wave)) != hipSuccess) return fail(e, "long-read extension-stage scratch");
+            for (int t = 0; t < 2; ++t) {   // the exact long join: the two sizes of the chains kernel plus the node pools of the two trees; one wave per CU (LDS)
+                LongSizes q = t ? zb : z; q.phase = 2;
+                c->lext_exact_sz[t] = q;
+                c->lext_exact_per_wave[t] = long_ws_carve(nullptr, nullptr, q);
+                const uint64_t bud = (t ? 6ull << 30 : 1ull << 30) * (budget[0] + 1) / ((6ull << 30) + 1);      // scaled like the others
+                c->lext_exact_waves[t] = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({256, bud / c->lext_exact_per_wave[t], std::max<uint64_t>(4, max_reads / 16)}));
+                if ((e = hipMalloc(&c->d_lext_exact[t], (uint64_t)c->lext_exact_waves[t] * c->lext_exact_per_wave[t])) != hipSuccess) return fail(e, "long-read extension-stage scratch");
             }
-            // the chains between the two kernels: what the hand-over buffers can hold, once more (the long join re-orders, it adds nothing)
-            c->larena_bytes = SINK_SHARDS * cap_anch * 16 + SINK_SHARDS * cap_recs * 12 + max_reads * 32 + (1ull << 20);
+            // the chains between the two kernels: what the hand-over buffers can hold, twice (the long join re-orders, it adds nothing; a read
+            // with one chain kept may leave that chain beside the join's outcome: lr_chains_wave, `both`)
+            c->larena_bytes = SINK_SHARDS * cap_anch * 32 + SINK_SHARDS * cap_recs * 12 + max_reads * 48 + (1ull << 20);
             if ((e = hipMalloc(&c->d_larena, c->larena_bytes)) != hipSuccess) return fail(e, "long-read extension-stage arena");
             if ((e = hipMalloc(&c->d_lhdr, max_reads * sizeof(LongHdr))) != hipSuccess) return fail(e, "long-read extension-stage headers");
             for (auto &q : c->d_locus) if ((e = hipMalloc(&q, max_reads * sizeof(SortItem))) != hipSuccess) return fail(e, "long-read locus lists");
@@ -3548,7 +3564,7 @@ extern "C" sh_status sh_ctx_destroy(sh_ctx *c)
     hipFree(c->d_work_defer); hipFree(c->d_work_defer2);
     for (auto &pp : c->d_big) for (auto p : pp) hipFree(p);
     hipFree(c->d_ctr); if (c->h_ctr) hipHostFree(c->h_ctr); hipFree(c->d_arena); hipFree(c->d_long);
-    hipFree(c->d_ext); hipFree(c->d_ext_scratch); for (auto q : c->d_lext) hipFree(q); hipFree(c->d_lext_big); hipFree(c->d_lext_big2); hipFree(c->d_lext_sorted); for (auto q : c->d_lext_unres) hipFree(q); hipFree(c->d_lext_exact_list); hipFree(c->d_lext_exact); hipFree(c->d_larena); hipFree(c->d_lhdr); for (auto q : c->d_locus) hipFree(q); hipFree(c->d_lr_drop); hipFree(c->d_lr_fb); hipFree(c->d_stage_x); hipFree(c->d_stage_q);
+    hipFree(c->d_ext); hipFree(c->d_ext_scratch); for (auto q : c->d_lext) hipFree(q); hipFree(c->d_lext_big); hipFree(c->d_lext_big2); hipFree(c->d_lext_sorted); for (auto q : c->d_lext_unres) hipFree(q); hipFree(c->d_lext_exact_list); for (auto q : c->d_lext_exact) hipFree(q); hipFree(c->d_larena); hipFree(c->d_lhdr); for (auto q : c->d_locus) hipFree(q); hipFree(c->d_lr_drop); hipFree(c->d_lr_fb); hipFree(c->d_stage_x); hipFree(c->d_stage_q);
     for (auto ev : c->ev_ext) if (ev) hipEventDestroy(ev);
     for (auto ev : c->ev) if (ev) hipEventDestroy(ev);
     for (auto ev : c->evx) if (ev) hipEventDestroy(ev);
@@ -3876,7 +3892,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         auto on_demand = [&](int phase, ExtLongArgs xa) -> sh_status {      // phase: 0 chains, 1 regions / alignment, 2 chains with the exact long join
             uint32_t n_un = c->h_ctr->lext_n_unres;
             n_ondemand += n_un;
-            LongSizes q = phase == 2 ? c->lext_exact_sz : c->lext_sz[phase * 2 + 1];
+            LongSizes q = phase == 2 ? c->lext_exact_sz[1] : c->lext_sz[phase * 2 + 1];
             int cur = 0;
             for (int round = 0; n_un > 0; ++round) {
                 uint8_t *buf = nullptr;
@@ -3899,7 +3915,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 xa.list = c->d_lext_unres[cur]; xa.n_list = &c->d_ctr->lext_n_unres_in; xa.ticket = &c->d_ctr->lext_ticket_unres;
                 xa.big_list = nullptr; xa.n_big = nullptr; xa.part = 0; xa.unres_list = c->d_lext_unres[cur ^ 1]; xa.n_unres = &c->d_ctr->lext_n_unres;
                 if (phase == 0) hipLaunchKernelGGL((k_long_chains<4096, false>), dim3(waves), dim3(64), 0, s, xa);
-                else if (phase == 2) hipLaunchKernelGGL((k_long_chains<64, true>), dim3(waves), dim3(64), 0, s, xa);
+                else if (phase == 2) hipLaunchKernelGGL((k_long_chains<4096, true>), dim3(waves), dim3(64), 0, s, xa);
                 else hipLaunchKernelGGL(k_regs_align_long, dim3(waves), dim3(64), 0, s, xa);
                 sh_status st = sync_ctr();
                 hipFree(buf);
@@ -3954,27 +3970,36 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                     st = on_demand(0, xa); if (st != SH_OK) return st;
                 }
             }
+            n_big_a += c->h_ctr->lext_n_big;
             if (c->h_ctr->lext_n_exact > 0) {
                 // the long join of these reads met two candidates of equal priority (or outgrew the LDS ring, or rmq_size_cap): once more, on
                 // the literal trees (sh_rmq_tree.h)
                 n_exact_reads += c->h_ctr->lext_n_exact;
                 const auto t_ex = std::chrono::steady_clock::now();
                 ExtLongArgs xe = x;
-                xe.scratch = c->d_lext_exact; xe.scratch_per_wave = c->lext_exact_per_wave; xe.sz = c->lext_exact_sz;
+                xe.scratch = c->d_lext_exact[0]; xe.scratch_per_wave = c->lext_exact_per_wave[0]; xe.sz = c->lext_exact_sz[0];
                 xe.list = c->d_lext_exact_list; xe.n_list = &c->d_ctr->lext_n_exact; xe.ticket = &c->d_ctr->lext_ticket_exact;
-                xe.big_list = nullptr; xe.n_big = nullptr; xe.part = 0; xe.exact_list = nullptr; xe.n_exact = nullptr;
-                xe.unres_list = c->d_lext_unres[0]; xe.n_unres = &c->d_ctr->lext_n_unres;
-                hipLaunchKernelGGL((k_long_chains<64, true>), dim3(c->lext_exact_waves), dim3(64), 0, s, xe);
+                xe.part = 0; xe.exact_list = nullptr; xe.n_exact = nullptr;
+                SH_HIP(hipMemsetAsync(&c->d_ctr->lext_n_big, 0, 8, s));      // lext_n_big, lext_ticket_big: the list of the reads beyond the first size, once more
+                xe.big_list = c->d_lext_big; xe.n_big = &c->d_ctr->lext_n_big; xe.unres_list = nullptr; xe.n_unres = nullptr;
+                hipLaunchKernelGGL((k_long_chains<4096, true>), dim3(c->lext_exact_waves[0]), dim3(64), 0, s, xe);
                 sh_status st = sync_ctr(); if (st != SH_OK) return st;
                 if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
-                const uint32_t n_ex_big = c->h_ctr->lext_n_unres;
-                st = on_demand(2, xe); if (st != SH_OK) return st;
+                if (c->h_ctr->lext_n_big > 0) {
+                    xe.scratch = c->d_lext_exact[1]; xe.scratch_per_wave = c->lext_exact_per_wave[1]; xe.sz = c->lext_exact_sz[1];
+                    xe.list = c->d_lext_big; xe.n_list = &c->d_ctr->lext_n_big; xe.ticket = &c->d_ctr->lext_ticket_big; xe.big_list = nullptr; xe.n_big = nullptr;
+                    xe.unres_list = c->d_lext_unres[0]; xe.n_unres = &c->d_ctr->lext_n_unres;
+                    hipLaunchKernelGGL((k_long_chains<4096, true>), dim3(c->lext_exact_waves[1]), dim3(64), 0, s, xe);
+                    st = sync_ctr(); if (st != SH_OK) return st;
+                    if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
+                }
+                const uint32_t n_ex_big = c->h_ctr->lext_n_big;
+                if (c->h_ctr->lext_n_unres > 0) { st = on_demand(2, xe); if (st != SH_OK) return st; }
                 if (getenv("SCRUBBY_HIP_DBG")) fprintf(stderr, "[dbg] exact long join: %u reads (%u with tied priorities so far), %u beyond the first size, %.1f ms\n", c->h_ctr->lext_n_exact, c->h_ctr->lext_rmq_tie, n_ex_big,
                                                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ex).count());
             }
             SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "long-read extension stage: internal overflow code %u", c->h_ctr->ext_overflow);
             ext_list += c->h_ctr->ext_n_list;
-            n_big_a += c->h_ctr->lext_n_big;
             // second kernel: regions and alignment
             {
                 ExtLongArgs xb = x;
@@ -4041,7 +4066,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         SH_HIP(hipEventRecord(c->ev_ext[1], s));
         SH_HIP(hipEventSynchronize(c->ev_ext[1]));
         ext_regions = c->h_ctr->ext_regions; ext_dropped = c->h_ctr->ext_dropped;
-        if (stats) { stats->n_ext_unresolved += c->h_ctr->lext_unresolved; stats->n_rmq_rechained += c->h_ctr->lext_rechained; stats->n_rmq_tied += c->h_ctr->lext_rmq_tie; stats->n_rmq_exact += n_exact_reads; stats->n_ext_ondemand += n_ondemand; }
+        if (stats) { stats->n_ext_unresolved += c->h_ctr->lext_unresolved; stats->n_rmq_rechained += c->h_ctr->lext_rechained; stats->n_rmq_tied += c->h_ctr->lext_rmq_tie; stats->n_rmq_exact += n_exact_reads; stats->n_ext_ondemand += n_ondemand; stats->n_rmq_open += c->h_ctr->lext_rmq_open; }
         hipEventElapsedTime(&ms_ext, c->ev_ext[0], c->ev_ext[1]);
     } else if (c->ext) {
         ExtArgs x{};

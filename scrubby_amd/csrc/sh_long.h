@@ -41,6 +41,7 @@ struct LongParams {
     int32_t a, b, q, e, q2, e2, sc_ambi, zdrop, zdrop_inv, end_bonus, min_dp_max, best_n;
     float pri_ratio, mask_level, max_clip_ratio;
     int32_t max_skip, rmq_inner_dist, rmq_size_cap, rmq_rescue_size;
+    int32_t rmq_exact_max;          // reads of up to this many chain anchors take the literal tree when the long join meets a tie that matters (-1: all)
     float rmq_rescue_ratio, pen_gap, pen_skip;
     int32_t mid_occ, max_max_occ, occ_dist;
 };
@@ -228,10 +229,16 @@ __device__ inline double lr_cc_f64(const double *p) { return __longlong_as_doubl
 // outgrows LRQ_INNER or the read has more anchors than rmq_size_cap.
 // Memory: what a step needs of the newest ~1000 anchors (f, p, the t marks, x, y, the priority) lives in the LDS ring, and the smallest
 // priority of everything older is one number (pml): a step only goes to HBM when the answer may lie further back than the ring.
-template <int LRQ_INNER>
+// TREE: lane 0 keeps upstream's main tree beside the scan (insert when anchors enter the window, erase when they leave, sh_rmq_tree.h) and the
+// tree answers query (1) whenever the scan finds the smallest priority shared - n_tie then counts those steps, none of which is left open.
+template <int LRQ_INNER, bool TREE>
 __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int32_t bw, int32_t n, const LAnchor *a, int32_t *f, int32_t *p,
-                                   double *pri, double *bmin /* n / 64 + 1 */, RmqLdsT<LRQ_INNER> &L, int32_t &n_tie, LongClk *dbg = nullptr)
+                                   double *pri, double *bmin /* n / 64 + 1 */, RmqLdsT<LRQ_INNER> &L, int32_t &n_tie, LongClk *dbg = nullptr,
+                                   RqNode *pool = nullptr, int32_t pool_cap = 0, RqCache TC = RqCache{nullptr, nullptr, 0})
 {
+    RqTree T0;
+    if (TREE) { if (al_lane() == 0) rq_init(T0, pool, pool_cap, TC); else rq_init(T0, pool, pool_cap); }
+    int32_t st_tree = 0;      // anchors [st_tree, i0) are in the tree
     n_tie = 0;
     // the parameters in registers: P lives in the caller's scratch, and a load from it inside the loop costs more than the step's arithmetic
     const float pen_gap = P.pen_gap, pen_skip = P.pen_skip;
@@ -295,6 +302,15 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 }
                 if (!ok) break;
             }
+            if (TREE && lane == 0) {
+                for (int32_t j = i0; j < i; ++j) {
+                    const int32_t x = rq_alloc(T0);
+                    if (x == RQ_NIL) { T0.bad = 11; break; }
+                    rq_node_set(T0, x, L.ry[j & M], j, L.rpri[j & M]);
+                    rq_insert(T0, x);
+                }
+            }
+            if (TREE && al_b0(T0.bad)) { ok = false; break; }      // the pool or a walk gave out: the caller takes the read to the one-lane version
             i0 = i;
             while ((blk_done + 1) * 64 <= i0) {      // blocks completed by this insertion (their anchors are all in the ring)
                 double m = L.rpri[(blk_done * 64 + lane) & M];
@@ -314,6 +330,10 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
         // anchors out of range leave
         if (st < seg0) st = seg0;
         while (st < i && xi > a[st].x + (uint64_t)max_dist) ++st;
+        if (TREE && st_tree < st) {
+            if (lane == 0) for (int32_t j = st_tree; j < st && j < i0; ++j) { const int32_t e = rq_erase(T0, (int32_t)a[j].y, j); if (e != RQ_NIL) rq_free(T0, e); }
+            st_tree = st;
+        }
         if (max_dist_inner > 0) {
             const int32_t st_old = st_inner;
             if (st_inner < seg0) st_inner = seg0;
@@ -419,7 +439,13 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
             }
         }
         bool tie_pending = false; int32_t tie_sc = 0;
-        if (bj >= 0 && ties > 1) {
+        if (TREE && bj >= 0 && ties > 1) {
+            int32_t tj = -1;
+            if (lane == 0) { const int32_t q = rq_rmq(T0, qi - max_dist, INT32_MAX, qi, 0); tj = q != RQ_NIL ? rq_at(T0, q)->i : -1; }
+            tj = al_b0(tj);
+            if (tj >= 0) bj = tj;
+            ++tie_cnt;
+        } else if (bj >= 0 && ties > 1 && tie_cnt == 0) {      // (a read that has met a tie that matters needs no further verdicts)
             // Several candidates share the smallest priority; the tree returns ONE of them, which one depends on its shape.  The state after
             // this step is the same whichever it is when (a) none of them is accepted (band, score) and they agree on `exact` - the step
             // keeps max_f = q_span, max_j = -1 and runs the inner scan or not - or (b) all are accepted with one score, none exact, and the
@@ -428,9 +454,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
             const int32_t ring_lo2 = blk_done > LRQ_RBLK(LRQ_INNER) ? (blk_done - LRQ_RBLK(LRQ_INNER)) * 64 : 0;
             uint32_t n_tied = 0, n_acc = 0, n_ex = 0;
             int32_t sc_lo = INT32_MAX, sc_hi = INT32_MIN;
-            for (int32_t b = (i0 - 1) >> 6; b >= (st >> 6) && i0 > 0; --b) {
-                const bool in_ring = b * 64 >= ring_lo2;
-                if (b < blk_done) { const double bm = in_ring ? L.bml[b & 63] : lr_cc_f64(bmin + b); if (bm > bp) continue; }
+            auto tally_block = [&](int32_t b) {      // the candidates of block b that hold the smallest priority
                 const int32_t j = b * 64 + lane;
                 bool tied = false; int32_t fb = 0, dr = 0, dq = 0, span_b = kk;
                 if (j >= st && j < i0) {
@@ -449,6 +473,18 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 if (tied) { sc = fb + lr_sc_simple(dr, dq, span_b, pen_gap, pen_skip, ex, wd); acc = wd <= bw && sc > q_span_i; }
                 n_tied += (uint32_t)__popcll(__ballot(tied)); n_acc += (uint32_t)__popcll(__ballot(acc)); n_ex += (uint32_t)__popcll(__ballot(tied && ex));
                 if (acc) { sc_lo = sc < sc_lo ? sc : sc_lo; sc_hi = sc > sc_hi ? sc : sc_hi; }
+            };
+            if (i0 > 0) {
+                const int32_t b_top = (i0 - 1) >> 6, b_bot = st >> 6;
+                if (b_top >= blk_done) tally_block(b_top);      // the newest, not yet completed block
+                // completed blocks, 64 at a time, one lane each: only those whose own minimum is the smallest priority can hold a tied candidate
+                for (int32_t bt = (b_top < blk_done ? b_top : blk_done - 1); bt >= b_bot; bt -= 64) {
+                    const int32_t b = bt - lane;
+                    bool todo = false;
+                    if (b >= b_bot) { const double bm = b * 64 >= ring_lo2 ? L.bml[b & 63] : lr_cc_f64(bmin + b); todo = bm <= bp; }
+                    uint64_t m = __ballot(todo);
+                    while (m) { const int l = __ffsll((unsigned long long)m) - 1; m &= m - 1; tally_block(bt - l); }
+                }
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { const int32_t a1 = __shfl_xor(sc_lo, o), a2 = __shfl_xor(sc_hi, o); sc_lo = a1 < sc_lo ? a1 : sc_lo; sc_hi = a2 > sc_hi ? a2 : sc_hi; }
@@ -525,6 +561,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
     }
 #undef LIY
 #undef LIJ
+    if (TREE && al_b0(T0.bad)) ok = false;
     n_tie = tie_cnt;
     if (ok) for (int32_t j = blk_done * 64 + lane; j < n; j += 64) { f[j] = L.rf[j & M]; p[j] = L.rp[j & M]; }      // the last, incomplete block(s)
     if (dbg) { dbg->d[0] += (unsigned long long)n; dbg->d[1] += d_ring; dbg->d[2] += d_oldsteps; dbg->d[3] += d_old; dbg->d[4] += d_nin; dbg->d[5] += d_chunks; dbg->d[6] += 1; if ((unsigned long long)n > dbg->d[7]) dbg->d[7] = (unsigned long long)n; }
@@ -534,12 +571,12 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
 // ---- mg_lchain_rmq's scoring pass on the literal trees (sh_rmq_tree.h): one lane, statement for statement ---------------------------------
 // a[] sorted by x; t[] zeroed by the caller (the skip marks; the backtrack clears them again).  f, p as lr_rmq_fill leaves them.
 __device__ __noinline__ bool lr_rmq_fill_tree(const LongParams &P, int32_t max_dist, int32_t bw, int32_t n, const LAnchor *a, int32_t *f, int32_t *p, int32_t *t,
-                                              RqNode *pool0, RqNode *pool1, int32_t pool_cap)
+                                              RqNode *pool0, RqNode *pool1, int32_t pool_cap, RqCache C0, RqCache C1, uint32_t *dbg_code = nullptr)
 {
     int32_t okv = 1;
     if (al_lane() == 0) {
         RqTree T0, T1;
-        rq_init(T0, pool0, pool_cap); rq_init(T1, pool1, pool_cap);
+        rq_init(T0, pool0, pool_cap, C0); rq_init(T1, pool1, pool_cap, C1);
         const float chn_pen_gap = P.pen_gap, chn_pen_skip = P.pen_skip;
         const int32_t max_chn_skip = P.max_skip, cap_rmq_size = P.rmq_size_cap;
         int32_t max_dist_inner = P.rmq_inner_dist;
@@ -547,7 +584,7 @@ __device__ __noinline__ bool lr_rmq_fill_tree(const LongParams &P, int32_t max_d
         if (max_dist_inner < 0) max_dist_inner = 0;
         if (max_dist_inner > max_dist) max_dist_inner = max_dist;
         int32_t i, i0, st = 0, st_inner = 0;
-        auto root_size = [](const RqTree &tr) -> int32_t { return tr.root != RQ_NIL ? (int32_t)tr.n[tr.root].size : 0; };
+        auto root_size = [](const RqTree &tr) -> int32_t { return tr.root != RQ_NIL ? (int32_t)rq_at(tr, tr.root)->size : 0; };
         for (i = i0 = 0; i < n && okv; ++i) {
             int32_t max_j = -1;
             const uint64_t xi = a[i].x; const int32_t yi = (int32_t)a[i].y;
@@ -559,8 +596,8 @@ __device__ __noinline__ bool lr_rmq_fill_tree(const LongParams &P, int32_t max_d
                     for (int k = 0; k < (max_dist_inner > 0 ? 2 : 1); ++k) {
                         RqTree &T = k ? T1 : T0;
                         const int32_t x = rq_alloc(T);
-                        if (x == RQ_NIL) { okv = 0; break; }
-                        T.n[x].y = (int32_t)a[j].y; T.n[x].i = j; T.n[x].pri = pri;
+                        if (x == RQ_NIL) { okv = 0; T.bad = 12; break; }
+                        rq_node_set(T, x, (int32_t)a[j].y, j, pri);
                         rq_insert(T, x);
                     }
                 }
@@ -581,16 +618,16 @@ __device__ __noinline__ bool lr_rmq_fill_tree(const LongParams &P, int32_t max_d
             const int32_t q = rq_rmq(T0, yi - max_dist, INT32_MAX, yi, 0);
             if (q != RQ_NIL) {
                 int32_t sc, exact, width, n_skip = 0;
-                int32_t j = T0.n[q].i;
+                int32_t j = rq_at(T0, q)->i;
                 sc = f[j] + lr_sc_simple((int32_t)(xi - a[j].x), yi - (int32_t)a[j].y, (int32_t)(a[j].y >> 32 & 0xff), chn_pen_gap, chn_pen_skip, exact, width);
                 if (width <= bw && sc > max_f) { max_f = sc; max_j = j; }
                 if (!exact && T1.root != RQ_NIL && yi > 0) {
                     RqItr it;
                     if (rq_itr_find_le(T1, yi - 1, n, it)) {
                         do {
-                            const RqNode &e = T1.n[it.stack[it.top]];
-                            if (e.y < yi - max_dist_inner) break;
-                            j = e.i;
+                            const RqNode *e = rq_at(T1, it.stack[it.top]);
+                            if (e->y < yi - max_dist_inner) break;
+                            j = e->i;
                             int32_t ex2;
                             sc = f[j] + lr_sc_simple((int32_t)(xi - a[j].x), yi - (int32_t)a[j].y, (int32_t)(a[j].y >> 32 & 0xff), chn_pen_gap, chn_pen_skip, ex2, width);
                             if (width <= bw) {
@@ -607,7 +644,9 @@ __device__ __noinline__ bool lr_rmq_fill_tree(const LongParams &P, int32_t max_d
                 }
             }
             f[i] = max_f; p[i] = max_j;
+            if (T0.bad || T1.bad) okv = 0;
         }
+        if (!okv && dbg_code) *dbg_code = (uint32_t)(T0.bad ? T0.bad : 20 + T1.bad);
     }
     return al_b0(okv) != 0;
 }
@@ -1515,7 +1554,7 @@ __device__ inline bool lr_region_kept(const LongParams &P, int32_t qlen, const L
 // EXACT: the long join on the literal trees (lr_rmq_fill_tree).  Without it a join that meets two candidates of equal priority, or that the
 // LDS ring cannot hold, returns 6: the read is redone by the EXACT instance of the kernel.
 template <int NR, bool EXACT>
-__device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const LongArena &AR, LongOut &out, uint32_t drop = 0)
+__device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const LongArena &AR, LongOut &out, uint32_t drop = 0, RqCache TC = RqCache{nullptr, nullptr, 0})
 {
     const LongParams &P = *C.P;
     LongWs &W = *C.W;
@@ -1628,19 +1667,29 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const Long
             int32_t tie = 0;
             lr_tick(C.clk, 1);
             if constexpr (EXACT) {
-                for (int32_t i = lane; i < n_a; i += 64) W.t[i] = 0;
-                lr_sync();
-                if (!lr_rmq_fill_tree(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.t, W.rq0, W.rq1, (int32_t)W.cap_a + 2)) { C.err = 6; return 3; }
-            } else {
-                if (!lr_rmq_fill<NR>(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie, C.clk)) {
-                    if (NR < 4096 && n_a <= P.rmq_size_cap) { C.err = 6; return 3; }      // beyond this ring: the pass with the large one
-                    C.err = 51; return 6;                                                   // beyond that too (or rmq_size_cap): the trees
+                // the scan with upstream's main tree beside it (asked at the ties); what the ring cannot hold, or rmq_size_cap touches: both trees on one lane
+                if (!lr_rmq_fill<NR, true>(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie, C.clk, W.rq0, (int32_t)W.cap_a + 2, TC)) {
+                    lr_sync();
+                    for (int32_t i = lane; i < n_a; i += 64) W.t[i] = 0;
+                    lr_sync();
+                    const int32_t half = (TC.mask + 1) >> 1;
+                    const RqCache C0{TC.c, TC.tag, TC.c ? half - 1 : 0}, C1{TC.c ? TC.c + half : nullptr, TC.c ? TC.tag + half : nullptr, TC.c ? half - 1 : 0};
+                    uint32_t code = 0;
+                    if (!lr_rmq_fill_tree(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.t, W.rq0, W.rq1, (int32_t)W.cap_a + 2, C0, C1, &code)) { C.err = 100u + (uint32_t)al_b0((int32_t)code); return 3; }
                 }
-                if (tie) { C.err = 50; return 6; }      // the scan's choice among equal priorities is not the tree's
+            } else {
+                if (!lr_rmq_fill<NR, false>(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie, C.clk)) {
+                    if (NR < 4096 && n_a <= P.rmq_size_cap) { C.err = 6; return 3; }      // beyond this ring: the pass with the large one
+                    if (P.rmq_exact_max < 0 || n_a <= P.rmq_exact_max) { C.err = 51; return 6; }      // beyond that too (or rmq_size_cap): the trees
+                    C.err = 6; return 7;      // ... which one lane would walk for seconds on a read this size: given up, counted (sh_stats.n_ext_unresolved)
+                }
+                if (tie) {      // the scan's choice among equal priorities need not be the tree's
+                    if (P.rmq_exact_max < 0 || n_a <= P.rmq_exact_max) { C.err = 50; return 6; }
+                    out.rmq_tie = 1;      // left open (the smallest index stands), counted: sh_stats.n_rmq_open
+                }
             }
             lr_sync();
             lr_tick(C.clk, 2);
-            out.rmq_tie = 0;
             // mg_chain_backtrack
             int32_t n_z = 0;
             for (int32_t i0 = 0; i0 < n_a; i0 += 64) {
