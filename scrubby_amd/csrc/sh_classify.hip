@@ -94,7 +94,7 @@ struct Counters {
     // long-read presets, flag-only: anchors pre-selected by locus (k_lr_locus) - reads listed per table size, reads with anchors dropped,
     // anchors kept, reads that must be redone with every anchor (lr_fb list)
     uint32_t n_locus[3], locus_ticket[3], lr_n_fb, lr_locus_reads; unsigned long long lr_locus_in, lr_locus_kept;
-    uint32_t lr_fb_why[8], lr_fb_had, lr_pad;
+    uint32_t lr_fb_why[8], lr_fb_had, lr_pad, lr_probe_why[8];
     uint32_t lext_n_unres, lext_ticket_unres, lext_n_unres_in, lext_pad4, lext_n_exact, lext_ticket_exact, lext_rmq_open, lext_pad5;      // reads beyond the stage's second working-memory size: redone with memory allocated for them
     unsigned long long stage_cursor;      // k_expand's raw anchors of the reads k_lr_locus will thin out (their own buffer: 12 B per anchor)
 };
@@ -1264,8 +1264,10 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
                                     int32_t &n_u_thr, int32_t &best_thr, uint32_t &n_cl_thr, const GlobalQ *gq = nullptr,
                                     uint32_t *nxt = nullptr, const ChainSink *sk = nullptr, uint32_t read = 0, uint64_t *heap = nullptr,
                                     BestChain *bc = nullptr, uint32_t rhash = 0, int phase = -1, TandemQ tq = TandemQ{nullptr, 0u, 1u, 0, 0u},
-                                    ParFillLds *pf = nullptr, bool *pre_io = nullptr, unsigned long long *pf_dbg = nullptr, uint32_t *pf_cnt = nullptr)
-{   // pf: the DP of all clusters at once (par_fill_block) before any cluster is visited; *pre_io: whether it applied (out; in for CONTIG phase 1,
+                                    ParFillLds *pf = nullptr, bool *pre_io = nullptr, unsigned long long *pf_dbg = nullptr, uint32_t *pf_cnt = nullptr,
+                                    uint64_t *ax_out = nullptr, uint32_t *aq_out = nullptr, uint32_t gq_min = 0)
+{   // ax_out / aq_out (!CONTIG, with gq): the sorted, marked anchors are copied to the arena and clusters of more than gq_min anchors are queued
+    // for k_cluster_dp instead of being chained by one wave of this block while the others wait.   pf: the DP of all clusters at once (par_fill_block) before any cluster is visited; *pre_io: whether it applied (out; in for CONTIG phase 1,
     // whose f / p / dirty marks are phase 0's)   // phase (flag-only hand-over, where a cluster that cannot beat the best score found so far is skipped): the BIG clusters first -
     //   CONTIG: 0 = only clusters of more than 64 anchors (queued for k_cluster_dp), 1 = only the others, afterwards; -1 = all at once
     //   else:   the clusters a wave chains (> 6 anchors) before the ones a lane chains, inside this call
@@ -1284,6 +1286,7 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
         if (start) q[i] |= 0x80000000u;
     }
     __syncthreads();
+    if (!CONTIG && gq && ax_out) { for (uint32_t i = tid; i < n; i += nthr) { ax_out[i] = x[i]; aq_out[i] = q[i]; } }
     bool pre = false;
     if (!pf && pre_io) pre = *pre_io;      // the caller knows (k_giant_top ran par_fill_block)
     if (pf) {
@@ -1330,7 +1333,7 @@ __device__ inline void chain_sorted(PX x, PQ q, int32_t *f, int32_t *pt, uint32_
         }
         if (len > (CONTIG ? 64u : 6u)) {      // arena path: only clusters beyond the register-mask DP go wave-wide (flag-only hand-over: beyond 8 -
                                                                        // a lane chaining 64 anchors out of HBM holds its whole block up, and most small ones are ruled out anyway)
-            if (gq) {
+            if (gq && (CONTIG || len > gq_min)) {
                 const int cc = cl_class(len);
                 const uint32_t gs = atomicAdd(&gq->count[cc], 1u);
                 if (gs < gq->cap[cc]) { SortItem ci{gq->w, len, (uint32_t)qlen | (pre_c ? 0x80000000u : 0u), gq->in_b | i << 1, gq->off + i}; gq->items[cc][gs] = ci; return; }     // pad = buffer | cluster start << 1; qlen bit 31: DP done
@@ -1499,6 +1502,8 @@ struct K3Args {
     // classes, k_lr_locus keeps the anchors of the reference windows that can hold regs[0] and passes the read on
     SortItem *locus_items[3]; uint32_t *lr_drop; int32_t locus, locus_shift;
     uint64_t *stage_x; uint32_t *stage_q; unsigned long long stage_cap;      // where k_expand leaves those reads' anchors (generation order)
+    int32_t locus_min_qlen;            // reads shorter than this are not thinned out (mm_map_frag's rescue test could depend on what is left out)
+    int32_t cl_lds;                    // k_sort_lds queues its big clusters for k_cluster_dp (long-read presets handing over every chain)
 };
 
 
@@ -1911,7 +1916,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // others.  One block per read counts the anchors per reference window of 2^shift >= D bases (sixteen-bit counters in LDS, addressed by a hash
 // of the window: a collision only makes a count too large), takes for every anchor the total of the run of occupied windows around its own -
 // an upper bound of its cluster's size, the same for every anchor of a cluster - and keeps the anchors whose bound reaches T: the three largest
-// bounds of the read, and everything within an eighth of the largest.  What is dropped is remembered per read as the largest bound dropped
+// bounds of the read, and everything within a sixteenth of the largest.  What is dropped is remembered per read as the largest bound dropped
 // (lr_drop); the chains kernel of the extension stage checks afterwards that the answer cannot depend on it (lr_chains_wave) and sends the
 // read through the complete path otherwise.  The survivors keep their generation order, so equal reference positions sort as before.
 template <int LG>
@@ -1966,7 +1971,8 @@ __global__ __launch_bounds__(256) void k_lr_locus(K3Args a, int lc)
         const uint32_t V1 = block_max(t1, 0);
         const uint32_t V2 = block_max(t1 < V1 ? t1 : t2, 1);
         const uint32_t V3 = block_max(t1 < V2 ? t1 : (t2 < V2 ? t2 : t3), 2);
-        uint32_t T = V3 < (V1 >> 3) ? V3 : (V1 >> 3);
+        uint32_t T = V3 < (V1 >> 4) ? V3 : (V1 >> 4);
+        if ((int32_t)si.qlen < a.locus_min_qlen) T = 0;      // a short read: whether the long join runs can hinge on a chain left out (lr_chains_wave) - it keeps everything
         if (a.dbg & 1024) T = V1;      // tests (SCRUBBY_HIP_LOCUS_TOP1): the largest run only - reads with a second locus must be caught and redone
         if (T < min_cnt) T = min_cnt;
         // which anchors stay (one bit each), how many, the largest bound left out
@@ -2231,12 +2237,17 @@ __global__ __launch_bounds__(NTHR) void k_sort_lds(K3Args a)
         uint64_t *rx = fl ? s_x[1] : s_x[0]; uint32_t *rq = fl ? s_q[1] : s_q[0];
         int32_t *f = (int32_t *)(fl ? s_q[0] : s_q[1]), *pt = (int32_t *)(fl ? s_x[0] : s_x[1]);
         int32_t n_u = 0, best = 0; uint32_t n_cl = 0;
+        // long-read presets: a read is mostly ONE cluster (its locus), which a single wave of this block would chain while the others wait -
+        // clusters of more than 256 anchors go to k_cluster_dp's queue instead (their sorted anchors to the arena's second buffer)
+        const bool to_q = CLS >= 1 && a.cl_lds && n > 256u;
+        const GlobalQ clq{a.B.tabs->cl_items, a.B.tabs->cl_cap, a.ctr->n_cl, si.w, 1u, si.off};
         if (!(a.dbg & 1))
         chain_sorted<false>(rx, rq, f, pt, n, tid, NTHR, (int32_t)si.qlen, a.P, a.flag_only ? &s_found : nullptr,
-                            BigList{s_bstart, s_blen, &s_bcount, NMAX / 7 + 1}, n_u, best, n_cl, nullptr, nullptr,
+                            BigList{s_bstart, s_blen, &s_bcount, NMAX / 7 + 1}, n_u, best, n_cl, to_q ? &clq : nullptr, nullptr,
                             a.emit ? &a.sink : nullptr, a.B.meta[si.w].r, a.emit ? a.B.hz + si.off : nullptr,
                             nullptr, 0u, -1, TandemQ{nullptr, 0u, 1u, 0, 0u}, use_pf ? &s_pf : nullptr, nullptr, (a.dbg & 16) ? a.ctr->pf_dbg : nullptr,
-                            (a.quiet || (a.emit && a.sink.best && !(a.dbg & 512))) ? nullptr : a.ctr->sh_pf_reads);      // with ChainSink::best k_sort_top counted the read
+                            (a.quiet || (a.emit && a.sink.best && !(a.dbg & 512))) ? nullptr : a.ctr->sh_pf_reads,      // with ChainSink::best k_sort_top counted the read
+                            to_q ? a.B.bx + si.off : nullptr, to_q ? a.B.bq + si.off : nullptr, 256u);
         store_read_result(a, si.w, n_u, best, n_cl, s_red);
         __syncthreads();
     }
@@ -3136,7 +3147,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         C.qlen = (int32_t)(I_l.in.offsets[r + 1] - I_l.in.offsets[r]); C.read = r;
         C.sc_mch = (int8_t)(P_l.a < 0 ? -P_l.a : P_l.a); C.sc_mis = (int8_t)(P_l.b > 0 ? -P_l.b : P_l.b);
         C.sc_amb = (int8_t)(P_l.sc_ambi > 0 ? -P_l.sc_ambi : P_l.sc_ambi); C.sc_N = C.sc_amb == 0 ? (int8_t)(-P_l.e2) : C.sc_amb;
-        C.need_big = false; C.err = 0; C.clk = a.clk ? &clk : nullptr;
+        C.need_big = false; C.err = 0; C.clk = a.clk ? &clk : nullptr; C.probe_why = 0;
         LongOut o;
         const int32_t rc = lr_regs_wave(C, CP_l, AR_l, a.flag_only != 0, a.probe != 0, o);
         if (rc == 5) {
@@ -3156,6 +3167,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 ((int4 *)tr)[2] = make_int4(o.n_aligned, o.n_regs, o.dp_max, (int32_t)o.sig);
             }
         }
+        if (a.clk && lane == 0 && !o.probed && C.probe_why) atomicAdd(&a.ctr->lr_probe_why[C.probe_why & 7], 1u);
         if (rc == 0) { n_regions += (uint32_t)o.n_aligned; n_dropped += o.n_regs == 0; n_probed += (uint32_t)o.probed; }      // every read of the list had a chain: also one the long join left without
         __syncthreads();
     }
@@ -3466,7 +3478,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             const uint64_t L = std::max<uint32_t>(max_read_len, 64);
             // Sizes: every wave slot takes the usual read (16 Ki chain anchors - with the anchors pre-selected by locus a read brings ~1000 -,
             // 8 MB of direction bytes: an end extension of max_gap bases at the band of the long-read presets); a few hundred slots take a
-            // read of 256 Ki chain anchors or an alignment of 128 MB; beyond that memory is allocated for the reads that need it (ext_round)
+            // read of 256 Ki chain anchors or an alignment of 32 MB; beyond that memory is allocated for the reads that need it (ext_round)
             LongSizes z{};
             z.cap_q = (uint32_t)((L + 31) & ~15ull);
             z.cap_k = (uint32_t)std::min<uint64_t>(32768, ((2 * L + 1024) + 15) & ~15ull);
@@ -3478,12 +3490,12 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             if (const char *env = getenv("SCRUBBY_HIP_LEXT_P_KB")) z.cap_p = (uint64_t)atoll(env) << 10;
             if (const char *env = getenv("SCRUBBY_HIP_LEXT_A")) { z.cap_a = (uint32_t)std::max(64, atoi(env)); z.cap_u = z.cap_r = std::max(16u, z.cap_a / 4); }      // tests
             LongSizes zb = z;
-            zb.cap_p = std::min<uint64_t>(128ull << 20, (uint64_t)(2 * z.cap_k) * (z.cap_k + 32));
+            zb.cap_p = std::min<uint64_t>(32ull << 20, (uint64_t)(2 * z.cap_k) * (z.cap_k + 32));
             zb.cap_a = 1u << 18; zb.cap_u = zb.cap_r = 1u << 16; zb.cap_m = 65536;
             if (const char *env = getenv("SCRUBBY_HIP_LEXT_BIG_P_KB")) zb.cap_p = (uint64_t)atoll(env) << 10;      // tests: alignments beyond the second size
             if (const char *env = getenv("SCRUBBY_HIP_LEXT_BIG_A")) { zb.cap_a = (uint32_t)std::max(1024, atoi(env)); zb.cap_u = zb.cap_r = std::max(64u, zb.cap_a / 4); }      // tests: reads beyond the second size
             uint64_t budget[4] = {6ull << 30, 8ull << 30, 26ull << 30, 10ull << 30};
-            const uint64_t wave_max[4] = {256 * 8, 256, 256 * 8, 64};      // LDS: 19 KB per wave in both kernels
+            const uint64_t wave_max[4] = {256 * 8, 256, 256 * 8, 256};      // LDS: 19 KB per wave in both kernels
             {   // no more than a third of what the device has left (several contexts, ranks sharing a device, smaller GPUs)
                 size_t mf = 0, mt = 0;
                 if (hipMemGetInfo(&mf, &mt) == hipSuccess && mf > 0) {
@@ -3650,6 +3662,10 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     const bool two_phase = k.t_mode && k.sink.best != nullptr;
     if (use_pf) hipLaunchKernelGGL(k_giant_top, dim3(1024), dim3(512), 0, g, k);
     hipLaunchKernelGGL(k_giant_chain, dim3(1024), dim3(512), 0, g, k, two_phase ? 0 : -1);
+    if (side && k.cl_lds) {      // the LDS classes feed k_cluster_dp's queue too
+        SH_HIP(hipEventRecord(c->evx[1], c->sx[0])); SH_HIP(hipStreamWaitEvent(g, c->evx[1], 0));
+        SH_HIP(hipEventRecord(c->evx[2], c->sx[1])); SH_HIP(hipStreamWaitEvent(g, c->evx[2], 0));
+    }
     if (!(k.dbg & 32)) hipLaunchKernelGGL(k_cluster_dp, dim3(256 * 7), dim3(256), 0, g, k);      // 72 VGPRs: 7 waves per SIMD (4: 74 ms, 6: 60, 8 with spills: 57)
     if (two_phase) {
         SH_HIP(hipMemsetAsync(&ctr->sort_ticket[SORT_CLS_GIANT], 0, 4, g));
@@ -3771,6 +3787,12 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     // must not hinge on chains left out) and windows narrow enough to tell loci apart
     k.locus = c->ext_long && c->use_long && d_trace == nullptr && !getenv("SCRUBBY_HIP_NO_LOCUS") && !getenv("SCRUBBY_HIP_NO_PROBE") &&
               c->opts.max_clip_ratio >= 1.0f && c->P.max_occ <= c->P.mid_occ && c->locus_shift <= 20 && c->opts.min_cnt >= 1;
+    {   // the shortest read for which `qlen - span > rmq_rescue_size || span > qlen * rmq_rescue_ratio` holds whatever the span (lr_chains_wave)
+        int32_t q = 1;
+        while (q < (1 << 30) && !((float)(q - c->LP.rmq_rescue_size) > (float)q * c->LP.rmq_rescue_ratio)) q = q < 64 ? q + 1 : q + q / 64;
+        k.locus_min_qlen = c->LP.bw_long > c->LP.bw ? q : 0;
+    }
+    k.cl_lds = c->ext_long && c->P.max_iter <= RING_TMAX_ITER && !getenv("SCRUBBY_HIP_NO_CL_LDS");
     k.locus_shift = c->locus_shift; k.lr_drop = c->d_lr_drop; k.stage_x = c->d_stage_x; k.stage_q = c->d_stage_q; k.stage_cap = c->stage_cap;
     for (int i = 0; i < 3; ++i) k.locus_items[i] = c->d_locus[i];
     if (c->ext_long) SH_HIP(hipMemsetAsync(c->d_lr_drop, 0, n_reads * 4, s));
@@ -4023,6 +4045,8 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         const uint32_t n_fb = c->h_ctr->lr_n_fb;
         if (k.locus && getenv("SCRUBBY_HIP_DBG")) fprintf(stderr, "[dbg] anchors by locus: %u reads thinned out (%llu of %llu anchors kept); %u reads redone with every anchor (one chain and more possible %u, short read %u, top score within reach of what was left out %u, no chain after the join %u, probe undecided %u, no probe %u, no chain among the anchors kept %u)\n",
                                                         c->h_ctr->lr_locus_reads, c->h_ctr->lr_locus_kept, c->h_ctr->lr_locus_in, n_fb, c->h_ctr->lr_fb_why[0], c->h_ctr->lr_fb_why[1], c->h_ctr->lr_fb_why[2], c->h_ctr->lr_fb_why[3], c->h_ctr->lr_fb_why[4], c->h_ctr->lr_fb_why[5], c->h_ctr->lr_fb_why[6]);
+        if (getenv("SCRUBBY_HIP_DBG")) fprintf(stderr, "[dbg] probes that gave up (first round): region %u, window %u, filling over 4 M cells %u, direction bytes %u, z-drop / empty %u, CIGAR room %u, no proof within six fillings %u\n",
+                                               c->h_ctr->lr_probe_why[1], c->h_ctr->lr_probe_why[2], c->h_ctr->lr_probe_why[3], c->h_ctr->lr_probe_why[4], c->h_ctr->lr_probe_why[5], c->h_ctr->lr_probe_why[6], c->h_ctr->lr_probe_why[7]);
         if (stats && k.locus) { stats->n_locus_reads += c->h_ctr->lr_locus_reads; stats->n_locus_redone += n_fb; }
         if (n_fb > 0) {
             // the reads whose answer could depend on the anchors left out: the repeat path once more with every anchor, then the stage again.

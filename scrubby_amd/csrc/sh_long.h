@@ -261,6 +261,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
     bool ok = true;
     uint32_t hi_prev = 0;
     LAnchor cur = a[0];
+    uint64_t x_st = cur.x;
     for (int32_t i = 0; i < n && ok; ++i) {
         const uint64_t xi = cur.x, yi = cur.y;
         if (i + 1 < n) cur = a[i + 1];      // the next anchor travels while this one is worked on
@@ -328,8 +329,8 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
             }
         }
         // anchors out of range leave
-        if (st < seg0) st = seg0;
-        while (st < i && xi > a[st].x + (uint64_t)max_dist) ++st;
+        if (st < seg0) { st = seg0; x_st = a[st < n ? st : n - 1].x; }
+        while (st < i && xi > x_st + (uint64_t)max_dist) { ++st; x_st = a[st].x; }      // a[st].x in a register: a trip to HBM per anchor otherwise
         if (TREE && st_tree < st) {
             if (lane == 0) for (int32_t j = st_tree; j < st && j < i0; ++j) { const int32_t e = rq_erase(T0, (int32_t)a[j].y, j); if (e != RQ_NIL) rq_free(T0, e); }
             st_tree = st;
@@ -1076,6 +1077,7 @@ struct LongCtx {
     const LongParams *P; const AlignParams *AP; const LongIn *I; LongWs *W; AlignLds *Ls; AlignScratch A; LongClk *clk;
     int32_t qlen; uint32_t read;
     int8_t sc_mch, sc_mis, sc_amb, sc_N;
+    int32_t probe_why;               // why lr_probe_region last gave up (statistics)
     bool need_big;                   // an alignment does not fit this wave's direction-byte buffer: the read goes to the large-scratch pass
     uint32_t err;                    // a capacity of the working memory was exceeded (code)
 };
@@ -1447,65 +1449,92 @@ __device__ inline int32_t lr_probe_eval0(const LongCtx &C, uint32_t *pc, int32_t
 }
 
 // 1: the region survives; 0: unknown (take the complete procedure); -1: stop (C.need_big / C.err)
-__device__ __noinline__ int32_t lr_probe_region(LongCtx &C, const LReg &r, LAnchor *a, int32_t &as1, int32_t &cnt1)
+// follow_splits: a z-drop in one of the fillings does not end the probe - mm_align1 cuts the region there (mm_split_reg) and the anchors behind
+// the drop become a region of their own, inserted behind this one and aligned in its turn whatever the other regions do; the probe moves on
+// to that region (mm_fix_bad_ends and the seed filters on its anchors, then its fillings).  Only where the caller starts the read over
+// after an undecided probe (the flags those filters leave on the anchors are upstream's only in upstream's order).
+__device__ __noinline__ int32_t lr_probe_region(LongCtx &C, const LReg &r, LAnchor *a, int32_t &as1, int32_t &cnt1, bool follow_splits = false)
 {
     const LongParams &P = *C.P;
     LongWs &W = *C.W;
     const uint32_t lane = al_lane();
     const int32_t hk = P.k >> 1;
     as1 = -1; cnt1 = 0;
-    if (r.cnt == 0 || r.inv || !(P.max_clip_ratio >= 1.0f)) return 0;
+    if (r.cnt == 0 || r.inv || !(P.max_clip_ratio >= 1.0f)) { C.probe_why = 1; return 0; }
     const int32_t rid = (int32_t)(a[r.as].x << 1 >> 33), rev = (int32_t)(a[r.as].x >> 63);
     int32_t bw_long = (int32_t)(P.bw_long * 1.5 + 1.);
     { const int32_t bw = (int32_t)(P.bw * 1.5 + 1.); if (bw_long < bw) bw_long = bw; }
-    lr_fix_bad_ends0(r, a, P.bw, P.min_sc * 2, as1, cnt1);
-    if (lane == 0) {
-        lr_filter_bad_seeds0(as1, cnt1, a, 10, 40, P.max_gap >> 1, 10, W.K);
-        lr_filter_bad_seeds_alt0(as1, cnt1, a, 30, P.max_gap >> 1, W.K);
-    }
-    lr_sync();
-    const int32_t rs_first = (int32_t)a[as1].x - hk, qs_first = (int32_t)a[as1].y - hk;
-    int32_t rs = rs_first, qs = qs_first, n_pc = 0, n_seg = 0;
     uint8_t *qrow = W.qseq + (rev ? C.qlen : 0), *tseq = W.tseq;
     uint32_t *pc = W.r_cigar, *ezc = W.ez_cigar, *tmp = (uint32_t *)W.K;
-    Ez ez;
-    for (int32_t i = 1; i < cnt1 && n_seg < 6; ++i) {
-        const uint64_t ay = a[as1 + i].y;
-        if ((ay & (LY_IGNORE | LY_TANDEM)) && i != cnt1 - 1) continue;
-        const int32_t re = (int32_t)a[as1 + i].x - hk, qe = (int32_t)ay - hk;
-        if (!(i == cnt1 - 1 || (ay & LY_LONG_JOIN) || (qe - qs >= P.min_ksw_len && re - rs >= P.min_ksw_len))) continue;
-        int32_t bw1 = bw_long;
-        if (ay & LY_LONG_JOIN) bw1 = qe - qs > re - rs ? qe - qs : re - rs;
-        if ((uint32_t)(re - rs_first > 0 ? re - rs_first : 0) + 16 > W.cap_t) return 0;
-        // an alignment the first pass's buffers do not hold is not worth probing: the complete procedure deals with it
-        {
-            const int32_t ql = qe - qs, tl = re - rs;
-            if (ql <= 0 || tl <= 0 || (long long)ql * tl > 4000000ll) return 0;
+    LReg rr = r;      // the region under the probe: r, then what a z-drop splits off it
+    for (int depth = 0; depth < 4; ++depth) {
+        int32_t as_c, cnt_c;
+        lr_fix_bad_ends0(rr, a, P.bw, P.min_sc * 2, as_c, cnt_c);
+        if (depth == 0) { as1 = as_c; cnt1 = cnt_c; }
+        if (lane == 0) {
+            lr_filter_bad_seeds0(as_c, cnt_c, a, 10, 40, P.max_gap >> 1, 10, W.K);
+            lr_filter_bad_seeds_alt0(as_c, cnt_c, a, 30, P.max_gap >> 1, W.K);
         }
-        lr_getseq(C, rid, rs, re, tseq);
-        if (!lr_align_pair(C, qe - qs, qrow + qs, re - rs, tseq, bw1, -1, P.zdrop, EZ_APPROX_MAX, ez)) { if (C.need_big) { C.need_big = false; return 0; } return -1; }
-        const int32_t zdrop_code = lr_test_zdrop(C, qrow + qs, tseq, ez.n_cigar, ezc);
-        if (C.err) return -1;
-        if (zdrop_code != 0) {
-            if (!lr_align_pair(C, qe - qs, qrow + qs, re - rs, tseq, bw1, -1, zdrop_code == 2 ? P.zdrop_inv : P.zdrop, 0, ez)) { if (C.need_big) { C.need_big = false; return 0; } return -1; }
+        lr_sync();
+        const int32_t rs_first = (int32_t)a[as_c].x - hk, qs_first = (int32_t)a[as_c].y - hk;
+        int32_t rs = rs_first, qs = qs_first, n_pc = 0, n_seg = 0;
+        Ez ez;
+        bool split = false;
+        for (int32_t i = 1; i < cnt_c && n_seg < 6; ++i) {
+            const uint64_t ay = a[as_c + i].y;
+            if ((ay & (LY_IGNORE | LY_TANDEM)) && i != cnt_c - 1) continue;
+            const int32_t re = (int32_t)a[as_c + i].x - hk, qe = (int32_t)ay - hk;
+            if (!(i == cnt_c - 1 || (ay & LY_LONG_JOIN) || (qe - qs >= P.min_ksw_len && re - rs >= P.min_ksw_len))) continue;
+            int32_t bw1 = bw_long;
+            if (ay & LY_LONG_JOIN) bw1 = qe - qs > re - rs ? qe - qs : re - rs;
+            if ((uint32_t)(re - rs_first > 0 ? re - rs_first : 0) + 16 > W.cap_t) { C.probe_why = 2; return 0; }
+            // an alignment the first pass's buffers do not hold is not worth probing: the complete procedure deals with it
+            {
+                const int32_t ql = qe - qs, tl = re - rs;
+                if (ql <= 0 || tl <= 0 || (long long)ql * tl > 4000000ll) { C.probe_why = 3; return 0; }
+            }
+            lr_getseq(C, rid, rs, re, tseq);
+            if (!lr_align_pair(C, qe - qs, qrow + qs, re - rs, tseq, bw1, -1, P.zdrop, EZ_APPROX_MAX, ez)) { if (C.need_big) { C.need_big = false; C.probe_why = 4; return 0; } return -1; }
+            const int32_t zdrop_code = lr_test_zdrop(C, qrow + qs, tseq, ez.n_cigar, ezc);
+            if (C.err) return -1;
+            if (zdrop_code != 0) {
+                if (!lr_align_pair(C, qe - qs, qrow + qs, re - rs, tseq, bw1, -1, zdrop_code == 2 ? P.zdrop_inv : P.zdrop, 0, ez)) { if (C.need_big) { C.need_big = false; C.probe_why = 4; return 0; } return -1; }
+            }
+            if (ez.zdropped) {
+                if (!follow_splits) { C.probe_why = 5; return 0; }
+                // mm_align1: the anchors behind the drop (beyond rs + max_t) leave for a region of their own if enough of them are left
+                int32_t j;
+                for (j = i - 1; j >= 0; --j) if ((int32_t)a[as_c + j].x <= rs + ez.max_t) break;
+                if (j < 0) j = 0;
+                const int32_t n = as_c + j + 1 - rr.as;
+                if (cnt_c - (j + 1) < P.min_cnt || !(n > 0 && n < rr.cnt)) { C.probe_why = 5; return 0; }
+                LReg r2 = rr;
+                r2.cnt = rr.cnt - n; r2.as = rr.as + n;
+                lr_reg_set_coor(r2, C.qlen, a);
+                rr = r2;
+                split = true;
+                break;
+            }
+            if (ez.n_cigar == 0) { C.probe_why = 5; return 0; }
+            if ((uint32_t)(n_pc + ez.n_cigar + 8) > W.cap_a || (uint32_t)(n_pc + ez.n_cigar + 8) > W.cap_c) { C.probe_why = 6; return 0; }
+            if (lane == 0) append_cigar0(pc, n_pc, ez.n_cigar, ezc);
+            n_pc = al_b0(n_pc);
+            ++n_seg;
+            rs = re; qs = qe;
+            // anchors the region keeps if a later gap filling drops right behind this one
+            int32_t jstar = i;
+            while (jstar >= 0 && (int32_t)a[as_c + jstar].x > (int32_t)a[as_c + i].x - hk - 1) --jstar;
+            if ((as_c - rr.as) + jstar + 1 < P.min_cnt) continue;
+            lr_getseq(C, rid, rs_first, re, tseq);
+            int32_t ok = 0;
+            if (lane == 0) ok = lr_probe_eval0(C, pc, n_pc, tmp, qrow + qs_first, tseq);
+            ok = al_b0(ok);
+            lr_tick(C.clk, 10);
+            if (ok) return 1;
         }
-        if (ez.zdropped || ez.n_cigar == 0) return 0;
-        if ((uint32_t)(n_pc + ez.n_cigar + 8) > W.cap_a || (uint32_t)(n_pc + ez.n_cigar + 8) > W.cap_c) return 0;
-        if (lane == 0) append_cigar0(pc, n_pc, ez.n_cigar, ezc);
-        n_pc = al_b0(n_pc);
-        ++n_seg;
-        rs = re; qs = qe;
-        // anchors the region keeps if a later gap filling drops right behind this one
-        int32_t jstar = i;
-        while (jstar >= 0 && (int32_t)a[as1 + jstar].x > (int32_t)a[as1 + i].x - hk - 1) --jstar;
-        if ((as1 - r.as) + jstar + 1 < P.min_cnt) continue;
-        lr_getseq(C, rid, rs_first, re, tseq);
-        int32_t ok = 0;
-        if (lane == 0) ok = lr_probe_eval0(C, pc, n_pc, tmp, qrow + qs_first, tseq);
-        ok = al_b0(ok);
-        lr_tick(C.clk, 10);
-        if (ok) return 1;
+        if (!split) { C.probe_why = 7; return 0; }
     }
+    C.probe_why = 7;
     return 0;
 }
 
@@ -1857,7 +1886,7 @@ __device__ inline int32_t lr_regs_wave(LongCtx &C, const ChainParams &CP, const 
         lr_sync();
         lr_reg_set_coor(r, qlen, A0);
         int32_t as1, cnt1;
-        const int32_t pr = lr_probe_region(C, r, A0, as1, cnt1);
+        const int32_t pr = lr_probe_region(C, r, A0, as1, cnt1, true);
         if (pr < 0) return C.need_big ? 1 : 3;
         if (pr > 0 && hd.alt != 0) {
             // mm_map_frag may not have run the long join at all (lr_chains_wave, `both`): then regs[0] is the first pass's one chain
@@ -1870,7 +1899,7 @@ __device__ inline int32_t lr_regs_wave(LongCtx &C, const ChainParams &CP, const 
             LReg r1{};
             r1.id = 0; r1.parent = 0; r1.score = hh[1]; r1.cnt = n_alt; r1.as = 0; r1.div = -1.0f;
             lr_reg_set_coor(r1, qlen, A0);
-            const int32_t pr2 = lr_probe_region(C, r1, A0, as1, cnt1);
+            const int32_t pr2 = lr_probe_region(C, r1, A0, as1, cnt1, true);
             if (pr2 < 0) return C.need_big ? 1 : 3;
             if (pr2 == 0) { C.err = 46; return 5; }
         }
