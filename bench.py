@@ -318,8 +318,8 @@ def main_reads(a, rank, world, local, dev, backend):
     if rank == 0 and world == 1 and not a.no_cpu and not ont and not a.chain_only and ctx_chunk(a, n_rec) >= n_rec:
         strat = stratified_parity(index, ctx, info, d_reads, d_flags, n_rec, L)
     ext_oracle = None
-    if rank == 0 and world == 1 and not a.no_cpu and not ont:
-        ext_oracle = external_oracle(index, d_reads, n_rec, L, d_flags, contigs, P, dev, real_ref)
+    if rank == 0 and world == 1 and not a.no_cpu:      # the real tool, when the box has it: `-c -x sr` / `-c -x map-ont`
+        ext_oracle = external_oracle(index, d_reads, n_rec, L, d_flags, contigs, P, dev, real_ref, preset="map-ont" if ont else "sr", d_off=d_off if ont else None)
 
     # ---- the host-buffer entry point (sh_classify_batch: what a Rust caller binds), PCIe included; never `value` -----------
     host_path = None
@@ -564,7 +564,8 @@ def main_k2(a, rank, world, local, dev, backend=None):
                           "probes": int(st["n_probes"]), "kmers": int(st["n_kmers"]), "overflow_units": int(st["n_overflow"])},
                "database": {"cells": info["capacity"], "occupied": info["size"], "reference_minimizer_runs": int(n_runs), "nodes": info["n_nodes"],
                             "build_s": round(t_db, 2)},
-               "roofline": roof, "cpu_baseline": cpu}
+               "roofline": roof, "cpu_baseline": cpu,
+               "external_oracle": (external_oracle_k2(db, d_reads, n_rec // 2, L, res["taxid"]) if world == 1 and not a.no_cpu else None)}
         print(json.dumps(out))
     db.close()
     if world > 1:
@@ -998,10 +999,11 @@ def stratified_parity(index, ctx, info, d_reads, d_flags, n_rec, L, n_random=300
     return out
 
 
-def external_oracle(index, d_reads, n_rec, L, d_flags, contigs, P, dev, real_ref=None, max_reads=400_000):
-    """if a `minimap2` binary exists on this box, map a bounded sample single-end (`-c -x sr`, as the reference maps
-    each mate on its own with CIGAR on: cleaner.rs:473,499-501,527-529,552) and diff the mapped-read set with the GPU flags - the only
-    route by which parity can become pinned.  Absent: says so."""
+def external_oracle(index, d_reads, n_rec, L, d_flags, contigs, P, dev, real_ref=None, max_reads=400_000, preset="sr", d_off=None):
+    """if a `minimap2` binary exists on this box, map a bounded sample single-end with CIGAR on (`-c -x sr`, or
+    `-c -x map-ont` for the long reads: the reference maps every record on its own with `.with_cigar()`, cleaner.rs:457,473,499-501,
+    527-529,552) and diff the mapped-read set with the GPU flags - the only route by which parity can become pinned.  Absent: says so.
+    d_off (long reads): the records' offsets; the sample is then bounded by bases as well."""
     import shutil
     import subprocess
     import tempfile
@@ -1024,19 +1026,65 @@ def external_oracle(index, d_reads, n_rec, L, d_flags, contigs, P, dev, real_ref
                     f.write(b">ctg%d\n" % i)
                     h_ref[P.contig_start[i]:P.contig_start[i + 1]].tofile(f)
                     f.write(b"\n")
-        reads = d_reads[:n * L].cpu().numpy().reshape(n, L)
         fq = os.path.join(work, "reads.fq")
-        fastq_file(fq, reads, 1, 0)
+        if d_off is None:
+            reads = d_reads[:n * L].cpu().numpy().reshape(n, L)
+            fastq_file(fq, reads, 1, 0)
+        else:
+            off = d_off[:n + 1].cpu().numpy().astype(np.int64)
+            n = int(min(n, max(1, np.searchsorted(off, 400_000_000) - 1)))       # at most 0.4 Gbases of long reads
+            h = d_reads[:int(off[n])].cpu().numpy()
+            with open(fq, "wb") as f:
+                for i in range(n):
+                    f.write(b"@syn.%09d 1:N:0:0\n" % i)
+                    h[off[i]:off[i + 1]].tofile(f)
+                    f.write(b"\n+\n" + b"I" * int(off[i + 1] - off[i]) + b"\n")
         t0 = time.perf_counter()
-        out = subprocess.run([exe, "-c", "-x", "sr", "-t", str(usable_cores()), fa, fq], capture_output=True, check=True).stdout
+        out = subprocess.run([exe, "-c", "-x", preset, "-t", str(usable_cores()), fa, fq], capture_output=True, check=True).stdout
         dt = time.perf_counter() - t0
         mapped = np.zeros(n, dtype=np.uint8)
         for ln in out.splitlines():
             mapped[int(ln.split(b"\t", 1)[0][4:])] = 1
         gpu = (d_flags[:n].cpu().numpy() == 1).astype(np.uint8)
-        return {"minimap2": "present", "version": subprocess.run([exe, "--version"], capture_output=True).stdout.decode().strip(),
+        return {"minimap2": "present", "version": subprocess.run([exe, "--version"], capture_output=True).stdout.decode().strip(), "preset": preset,
                 "sample_reads": n, "mapped_by_minimap2": int(mapped.sum()), "mapped_by_gpu": int(gpu.sum()), "differ": int((mapped != gpu).sum()),
                 "reads_per_s_incl_index": round(n / dt, 1), "threads": usable_cores()}
+    except Exception as e:      # the real tool is an extra: its failure must not fail the bench
+        return {"minimap2": "present", "error": repr(e)[:300]}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def external_oracle_k2(db, d_reads, n_pairs, L, gpu_calls, max_pairs=400_000):
+    """The Kraken2 arm's real-tool hook: if a `kraken2` binary exists, write the synthetic database out in Kraken 2's own files (hash.k2d,
+    opts.k2d, taxo.k2d: sh_k2_save), classify a bounded sample of the pairs with `kraken2 --paired` (the command of cleaner.rs:300-323) and
+    diff the per-pair taxid calls with the GPU's.  Absent: says so."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("kraken2")
+    if exe is None:
+        return {"kraken2": "absent"}
+    n = int(min(n_pairs, max_pairs))
+    work = tempfile.mkdtemp(prefix="scrubby_k2_")
+    try:
+        db.save(work)
+        reads = d_reads[:2 * n * L].cpu().numpy().reshape(2 * n, L)
+        f1, f2 = os.path.join(work, "r1.fq"), os.path.join(work, "r2.fq")
+        fastq_file(f1, reads[0::2], 1, 0)
+        fastq_file(f2, reads[1::2], 2, 0)
+        t0 = time.perf_counter()
+        out = subprocess.run([exe, "--threads", str(usable_cores()), "--db", work, "--paired", f1, f2, "--output", "-"], capture_output=True, check=True).stdout
+        dt = time.perf_counter() - t0
+        calls = np.zeros(n, dtype=np.int64)
+        for ln in out.splitlines():
+            c = ln.split(b"\t")
+            calls[int(c[1][4:13])] = int(c[2])
+        g = np.asarray(gpu_calls[:n]).astype(np.int64)
+        return {"kraken2": "present", "sample_pairs": n, "classified_by_kraken2": int((calls != 0).sum()), "classified_by_gpu": int((g != 0).sum()),
+                "differ": int((calls != g).sum()), "pairs_per_s_incl_db_load": round(n / dt, 1), "threads": usable_cores()}
+    except Exception as e:
+        return {"kraken2": "present", "error": repr(e)[:300]}
     finally:
         shutil.rmtree(work, ignore_errors=True)
 

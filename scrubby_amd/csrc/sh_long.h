@@ -873,7 +873,7 @@ __device__ inline void lr_est_err0(int32_t qlen, int32_t n_regs, LReg *regs, con
         }
         int32_t n_tot = en - st + 1;
         if (r->qs > avg_k && r->rs > avg_k) ++n_tot;
-        if (qlen - r->qe > avg_k && l_ref - r->re > avg_k) ++n_tot;
+        if (qlen - r->qs > avg_k && l_ref - r->re > avg_k) ++n_tot;      /* qs, not qe: upstream's mm_est_err reads `qlen - r->qs` here (hit.c, v2.28 as recalled by builder and reviewer alike) */
         r->div = n_match >= n_tot ? 0.0f : (float)(1.0 - pow((double)n_match / n_tot, 1.0 / avg_k));
     }
 }

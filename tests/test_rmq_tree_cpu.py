@@ -70,7 +70,7 @@ def test_scoring_pass_on_the_device_trees_equals_the_oracles(oracle, host_tree, 
     Lo.mmo_lchain_rmq_fill.argtypes = [C.c_int] * 5 + [C.c_float, C.c_float, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     host_tree.rqh_lchain_fill.argtypes = [C.c_int] * 5 + [C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     rng = np.random.default_rng(7)
-    for period, cr, cq in ((171, 40, 30), (68, 120, 90), (5, 400, 300), (300, 12, 9)):
+    for period, cr, cq in ((171, 14, 10), (68, 30, 22), (5, 70, 50), (300, 6, 5)):
         a = _lattice(rng, 0, period, cr, cq)
         n = len(a)
         f0 = np.zeros(n, np.int32); p0 = np.zeros(n, np.int64); t0 = np.zeros(n, np.int32)
