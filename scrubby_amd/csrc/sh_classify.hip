@@ -96,6 +96,7 @@ struct Counters {
     uint32_t n_locus[3], locus_ticket[3], lr_n_fb, lr_locus_reads; unsigned long long lr_locus_in, lr_locus_kept;
     uint32_t lr_fb_why[8], lr_fb_had, lr_pad, lr_probe_why[8];
     uint32_t lext_n_unres, lext_ticket_unres, lext_n_unres_in, lext_pad4, lext_n_exact, lext_ticket_exact, lext_rmq_open, lext_pad5;      // reads beyond the stage's second working-memory size: redone with memory allocated for them
+    unsigned long long lext_slow2, lext_slow3, lext_slow_part[4], lext_sum_part[4], lext_clk_big[LR_NCLK];      // SCRUBBY_HIP_DBG: the slowest read of the chains kernel (time << 32 | read length / read)
     unsigned long long stage_cursor;      // k_expand's raw anchors of the reads k_lr_locus will thin out (their own buffer: 12 B per anchor)
 };
 #define SHARD() ((blockIdx.x + (blockIdx.x >> 6)) & 63)
@@ -2973,13 +2974,17 @@ struct ExtLongArgs {
 
 // Largest reads first: a read's cost grows with its chain anchors (one with 70 k of them keeps a wave busy for a third of a second), and a
 // kernel ends with its slowest wave.  Reads are binned by log2 of their chain-anchor count and listed from the top bin down.
-__global__ void k_lext_bins(const ChainRec *recs, const uint32_t *head, const uint32_t *list, const uint32_t *n_list, uint32_t *size_of, uint32_t *hist)
+__global__ void k_lext_bins(const ChainRec *recs, const uint32_t *head, const uint32_t *list, const uint32_t *n_list, uint32_t *size_of, uint32_t *hist, const uint64_t *offsets)
 {
     const uint32_t n = *n_list;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t r = list[i];
         unsigned long long tot = 0;
         for (uint32_t h = head[r]; h != ~0u; h = recs[h].next) tot += recs[h].cnt;
+        // a long read's join looks back over a window of bw_long reference bases: beyond the LDS ring every anchor scans blocks in HBM, and the
+        // cost per anchor grows with the read - half its length stands in when that is more than its anchors
+        const unsigned long long ql = (offsets[r + 1] - offsets[r]) >> 1;
+        if (ql > tot) tot = ql;
         const uint32_t b = tot ? 63u - (uint32_t)__clzll(tot) : 0u;
         size_of[i] = b < 31u ? b : 31u;
         atomicAdd(&hist[size_of[i]], 1u);
@@ -3094,7 +3099,14 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
         LongOut o;
         const unsigned long long t_r0 = a.clk ? wall_clock64() : 0ull;
         const int32_t rc = lr_chains_wave<NR, EXACT>(C, RL, AR_l, o, a.drop ? a.drop[r] : 0u, TC);
-        if (a.clk && lane == 0) { const unsigned long long dt = wall_clock64() - t_r0; atomicMax(&a.ctr->lext_slow, dt << 24 | (unsigned long long)(o.n_chain > 0xffffff ? 0xffffff : o.n_chain)); atomicAdd(&a.ctr->lext_kernel_sum, dt); }
+        if (a.clk && lane == 0) {
+            const unsigned long long dt = wall_clock64() - t_r0;
+            atomicMax(&a.ctr->lext_slow, dt << 24 | (unsigned long long)(o.n_chain > 0xffffff ? 0xffffff : o.n_chain)); atomicAdd(&a.ctr->lext_kernel_sum, dt);
+            atomicMax(&a.ctr->lext_slow2, dt << 32 | (unsigned long long)(uint32_t)C.qlen);
+            atomicMax(&a.ctr->lext_slow3, dt << 32 | (unsigned long long)r);
+            atomicMax(&a.ctr->lext_slow_part[a.part & 3], dt << 32 | (unsigned long long)(uint32_t)o.n_chain);
+            atomicAdd(&a.ctr->lext_sum_part[a.part & 3], dt);
+        }
         if (rc == 4) { if (lane == 0) atomicExch(&a.ctr->ext_overflow, 1u); }      // arena full: the host cuts the chunk in two
         else if (rc == 5) { if (lane == 0) lext_redo(a, r, C.err); }
         else if (rc == 7) {      // beyond the large ring and too large for the one-lane trees: chain-level answer, counted
@@ -3175,7 +3187,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (n_regions) atomicAdd(&a.ctr->ext_regions, n_regions);
         if (n_dropped) atomicAdd(&a.ctr->ext_dropped, n_dropped);
         if (n_probed) atomicAdd(&a.ctr->sh_lemma[SHARD()], n_probed);
-        if (a.clk) for (int i = 0; i < LR_NCLK; ++i) atomicAdd(&a.ctr->lext_clk[i], clk.t[i]);
+        if (a.clk) for (int i = 0; i < LR_NCLK; ++i) atomicAdd(a.big_list ? &a.ctr->lext_clk[i] : &a.ctr->lext_clk_big[i], clk.t[i]);
     }
 }
 
@@ -3494,7 +3506,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             zb.cap_a = 1u << 18; zb.cap_u = zb.cap_r = 1u << 16; zb.cap_m = 65536;
             if (const char *env = getenv("SCRUBBY_HIP_LEXT_BIG_P_KB")) zb.cap_p = (uint64_t)atoll(env) << 10;      // tests: alignments beyond the second size
             if (const char *env = getenv("SCRUBBY_HIP_LEXT_BIG_A")) { zb.cap_a = (uint32_t)std::max(1024, atoi(env)); zb.cap_u = zb.cap_r = std::max(64u, zb.cap_a / 4); }      // tests: reads beyond the second size
-            uint64_t budget[4] = {6ull << 30, 8ull << 30, 26ull << 30, 10ull << 30};
+            uint64_t budget[4] = {15ull << 30, 8ull << 30, 26ull << 30, 10ull << 30};
             const uint64_t wave_max[4] = {256 * 8, 256, 256 * 8, 256};      // LDS: 19 KB per wave in both kernels
             {   // no more than a third of what the device has left (several contexts, ranks sharing a device, smaller GPUs)
                 size_t mf = 0, mt = 0;
@@ -3506,6 +3518,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             for (int ph = 0; ph < 2; ++ph) for (int t = 0; t < 2; ++t) {
                 LongSizes q = t ? zb : z;
                 q.phase = ph;
+                if (ph == 0 && !t && !getenv("SCRUBBY_HIP_LEXT_A")) { q.cap_a = 65536; q.cap_u = 16384; }      // the chains kernel: 64 Ki anchors in every slot (the second size has 256 slots only, and a 40-kb read's join takes a second)
                 const int i = ph * 2 + t;
                 c->lext_sz[i] = q;
                 c->lext_per_wave[i] = long_ws_carve(nullptr, nullptr, q);
@@ -3957,7 +3970,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 if (round == 0) hipLaunchKernelGGL(k_lext_list, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, s, xl, x.drop, (uint32_t)std::max(1, c->LP.min_cnt), x.fb_list, x.n_fb);
                 else hipLaunchKernelGGL(k_lext_list_from, dim3(256), dim3(256), 0, s, xl, (const uint32_t *)c->d_lr_fb, (const uint32_t *)&c->d_ctr->lr_n_fb);
                 // largest reads first (d_ext_redo: bin of each list entry; d_lext_big2: the ordered list, free until the second kernel's first pass ends)
-                hipLaunchKernelGGL(k_lext_bins, dim3(256), dim3(256), 0, s, c->sink.recs, c->sink.head, c->d_ext_list, &c->d_ctr->ext_n_list, c->d_ext_redo, c->d_ctr->lext_hist);
+                hipLaunchKernelGGL(k_lext_bins, dim3(256), dim3(256), 0, s, c->sink.recs, c->sink.head, c->d_ext_list, &c->d_ctr->ext_n_list, c->d_ext_redo, c->d_ctr->lext_hist, d_offsets);
                 hipLaunchKernelGGL(k_lext_scan, dim3(1), dim3(1), 0, s, c->d_ctr->lext_hist);
                 hipLaunchKernelGGL(k_lext_scatter, dim3(256), dim3(256), 0, s, c->d_ext_list, &c->d_ctr->ext_n_list, c->d_ext_redo, c->d_ctr->lext_hist, c->d_lext_sorted);
                 x.list = c->d_lext_sorted;
@@ -4083,7 +4096,11 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
             fprintf(stderr, "[dbg] RMQ: %llu reads, %llu anchors (largest read %llu), per anchor: %.2f ring blocks, %.3f trips behind the ring with %.2f old blocks, list length %.1f, %.2f inner chunks\n",
                     c->h_ctr->lext_d[6], c->h_ctr->lext_d[0], c->h_ctr->lext_d[7], (double)c->h_ctr->lext_d[1] / (c->h_ctr->lext_d[0] + 1), (double)c->h_ctr->lext_d[2] / (c->h_ctr->lext_d[0] + 1),
                     (double)c->h_ctr->lext_d[3] / (c->h_ctr->lext_d[0] + 1), (double)c->h_ctr->lext_d[4] / (c->h_ctr->lext_d[0] + 1), (double)c->h_ctr->lext_d[5] / (c->h_ctr->lext_d[0] + 1));
-            fprintf(stderr, "[dbg] chains kernel: slowest read %.1f ms (%llu chains after the long join), all reads %.1f wave-ms\n", (c->h_ctr->lext_slow >> 24) / 1e5, c->h_ctr->lext_slow & 0xffffff, c->h_ctr->lext_kernel_sum / 1e5);
+            fprintf(stderr, "[dbg] chains kernel: slowest read %.1f ms (%llu chains after the long join; read %llu of the chunk, %llu bases), all reads %.1f wave-ms\n", (c->h_ctr->lext_slow >> 24) / 1e5, c->h_ctr->lext_slow & 0xffffff,
+                    c->h_ctr->lext_slow3 & 0xffffffffull, c->h_ctr->lext_slow2 & 0xffffffffull, c->h_ctr->lext_kernel_sum / 1e5);
+            { unsigned long long tb = 0; for (int i = 0; i < LR_NCLK; ++i) tb += c->h_ctr->lext_clk_big[i];
+              fprintf(stderr, "[dbg] regions kernel, second size: gen_regs %.1f  parent/select %.1f  squeeze %.1f  set-up %.1f  ksw %.1f  z-drop %.1f  update_extra %.1f  staging %.1f %% of %.1f wave-s\n", 100. * c->h_ctr->lext_clk_big[4] / (tb + 1), 100. * c->h_ctr->lext_clk_big[5] / (tb + 1), 100. * c->h_ctr->lext_clk_big[6] / (tb + 1), 100. * c->h_ctr->lext_clk_big[7] / (tb + 1), 100. * c->h_ctr->lext_clk_big[8] / (tb + 1), 100. * c->h_ctr->lext_clk_big[9] / (tb + 1), 100. * c->h_ctr->lext_clk_big[10] / (tb + 1), 100. * c->h_ctr->lext_clk_big[11] / (tb + 1), tb / 1e8); }
+            for (int pp = 0; pp < 3; ++pp) fprintf(stderr, "[dbg] chains kernel, part %d (0 lists of later passes, 1 all but the giants, 2 the giants): slowest read %.1f ms, all reads %.1f wave-ms\n", pp, (c->h_ctr->lext_slow_part[pp] >> 32) / 1e5, c->h_ctr->lext_sum_part[pp] / 1e5);
             for (int i = 0; i < SINK_SHARDS; ++i) { sr += c->h_ctr->ext_n_recs[i]; sa += c->h_ctr->ext_n_anch[i]; mr = std::max<unsigned long long>(mr, c->h_ctr->ext_n_recs[i]); ma = std::max<unsigned long long>(ma, c->h_ctr->ext_n_anch[i]); }
             fprintf(stderr, "[dbg] chain hand-over: %llu chains, %llu anchors; fullest shard %llu / %u chains, %llu / %llu anchors\n", sr, sa, mr, c->sink.cap_recs, ma, c->sink.cap_anch);
         }
