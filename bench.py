@@ -379,7 +379,8 @@ def main_reads(a, rank, world, local, dev, backend):
                        # reads whose regs[0] did not survive and that were re-chained with every chain kept (sr), and what that costs per step
                        "ext_fallback_reads": s0.get("n_ext_fallback", 0), "ext_fallback_ms_per_step": round(float(np.mean([x.get("ms_ext_fallback", 0.0) for x in stats])), 3),
                        "ext_fallback_share_of_step": round(float(np.mean([x.get("ms_ext_fallback", 0.0) for x in stats])) / max(ms_step, 1e-9), 4),
-                       "rmq_rechained": s0.get("n_rmq_rechained", 0), "rmq_tied": s0.get("n_rmq_tied", 0), "ext_unresolved": s0.get("n_ext_unresolved", 0),
+                       "rmq_rechained": s0.get("n_rmq_rechained", 0), "rmq_tied": s0.get("n_rmq_tied", 0), "rmq_exact": s0.get("n_rmq_exact", 0), "rmq_open": s0.get("n_rmq_open", 0),
+                       "ext_unresolved": s0.get("n_ext_unresolved", 0), "ext_ondemand": s0.get("n_ext_ondemand", 0), "locus_reads": s0.get("n_locus_reads", 0), "locus_redone": s0.get("n_locus_redone", 0),
                        "dp_parallel_reads": s0.get("n_dp_parallel", 0), "dp_dirty_anchors": s0.get("n_dp_dirty", 0), "top_settled_reads": s0.get("n_top_settled", 0)},
             "index": {"n_keys": info["n_keys"], "n_minimizers": info["n_minimizers"], "n_slots": info["n_slots"],
                       "n_positions": info["n_positions"], "hbm_GB": round(info["hbm_bytes"] / 1e9, 2),
