@@ -159,6 +159,11 @@ __device__ inline int32_t ld32(const int32_t *p, bool g) { return g ? (int32_t)c
 __device__ inline uint64_t ld64(const uint64_t *p, bool g) { return g ? cc_u64(p) : *p; }
 
 __device__ inline void al_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+// the same for data the wave shares through LDS only: outstanding LDS operations are waited for, stores on their way to HBM (direction bytes,
+// which nothing reads before the backtrack) are not - the full fence made every anti-diagonal wait for them
+#define AL_WIDE_MIN 128     // anti-diagonals wider than this take four cells per lane; narrower ones are bound by the arithmetic, not by LDS issue, and keep one
+__device__ inline int32_t al_wave_shr1(int32_t v, int32_t fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }   // lane i takes lane i-1's value
+__device__ inline void al_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 __device__ inline uint32_t al_lane() { return threadIdx.x & 63; }
 __device__ inline int32_t al_b0(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ inline uint64_t al_b0_64(uint64_t v) { return (uint64_t)(uint32_t)al_b0((int32_t)(uint32_t)v) | (uint64_t)(uint32_t)al_b0((int32_t)(uint32_t)(v >> 32)) << 32; }
@@ -297,6 +302,7 @@ __device__ inline void ksw_extd2_core(int32_t qlen, const uint8_t *query, bool q
                                       int32_t zdrop, int32_t end_bonus, int32_t flag, Ez &ez, uint32_t *cigar, AlignScratch &A, LDS &Ls)
 {
     const uint32_t lane = al_lane();
+    auto dsync = [&]() { if constexpr (G) al_sync(); else al_sync_lds(); };      // the DP state lives in LDS (!G): no anti-diagonal waits for HBM
     ez_reset(ez);
     if (qlen <= 0 || tlen <= 0) return;
     if (q2 + e2 < q + e) { int32_t t = q; q = q2; q2 = t; t = e; e = e2; e2 = t; }
@@ -332,7 +338,7 @@ __device__ inline void ksw_extd2_core(int32_t qlen, const uint8_t *query, bool q
         H[t] = KSW_NEG_INF;
     }
     for (int32_t t = (int32_t)lane; t < qr_cap; t += 64) qr[t] = t < qlen ? ld8(query + (qlen - 1 - t), qg) : 0;
-    al_sync();
+    dsync();
 
     int32_t last_st = -1, last_en = -1, r, H0 = 0, last_H0_t = 0;
     for (r = 0; r < qlen + tlen - 1; ++r) {
@@ -352,7 +358,7 @@ __device__ inline void ksw_extd2_core(int32_t qlen, const uint8_t *query, bool q
             x1 = (int8_t)(-q - e); x21 = (int8_t)(-q2 - e2);
             v1 = r == 0 ? (int8_t)(-q - e) : r < long_thres ? (int8_t)(-e) : r == long_thres ? (int8_t)long_diff : (int8_t)(-e2);
         }
-        al_sync();      // the boundary reads above come before this diagonal's stores
+        dsync();      // the boundary reads above come before this diagonal's stores
         if (en >= r && lane == 0) {
             y[r] = (int8_t)(-q - e); y2[r] = (int8_t)(-q2 - e2);
             u[r] = r == 0 ? (int8_t)(-q - e) : r < long_thres ? (int8_t)(-e) : r == long_thres ? (int8_t)long_diff : (int8_t)(-e2);
@@ -371,52 +377,115 @@ __device__ inline void ksw_extd2_core(int32_t qlen, const uint8_t *query, bool q
             }
         }
         if (lane == 0) { off[r] = st; off_end[r] = en; }
-        al_sync();
-        // core loop over the rounded range, 64 cells at a time; every cell reads the previous anti-diagonal only
-        int8_t cx1 = x1, cx21 = x21, cv1 = v1;
-        for (int32_t tb = st; tb <= en; tb += 64) {
-            const int32_t t = tb + (int32_t)lane;
-            const bool on = t <= en;
-            const int8_t ox = on ? ld8s(x + t, g) : (int8_t)0, ov = on ? ld8s(v + t, g) : (int8_t)0, ox2 = on ? ld8s(x2 + t, g) : (int8_t)0;
-            int8_t xt1 = (int8_t)__shfl_up((int)ox, 1), vt1 = (int8_t)__shfl_up((int)ov, 1), x2t1 = (int8_t)__shfl_up((int)ox2, 1);
-            if (lane == 0) { xt1 = cx1; vt1 = cv1; x2t1 = cx21; }
-            cx1 = (int8_t)__builtin_amdgcn_readlane((int)ox, 63); cv1 = (int8_t)__builtin_amdgcn_readlane((int)ov, 63); cx21 = (int8_t)__builtin_amdgcn_readlane((int)ox2, 63);
-            if (on) {
-                int8_t z = ld8s(s + t, g);
-                const int8_t ut = ld8s(u + t, g);
-                int8_t a = (int8_t)(xt1 + vt1), b = (int8_t)(ld8s(y + t, g) + ut), a2 = (int8_t)(x2t1 + vt1), b2 = (int8_t)(ld8s(y2 + t, g) + ut), tmp;
-                uint8_t d;
-                if (!(flag & EZ_RIGHT)) {
-                    d = a > z ? 1 : 0;  z = z > a ? z : a;
-                    d = b > z ? 2 : d;  z = z > b ? z : b;
-                    d = a2 > z ? 3 : d; z = z > a2 ? z : a2;
-                    d = b2 > z ? 4 : d; z = z > b2 ? z : b2;
-                    z = z < sc_mch ? z : sc_mch;
-                    u[t] = (int8_t)(z - vt1); v[t] = (int8_t)(z - ut);
-                    tmp = (int8_t)(z - q);  a = (int8_t)(a - tmp);  b = (int8_t)(b - tmp);
-                    tmp = (int8_t)(z - q2); a2 = (int8_t)(a2 - tmp); b2 = (int8_t)(b2 - tmp);
-                    x[t] = (int8_t)((a > 0 ? a : 0) - qe);    d |= a > 0 ? 0x08 : 0;
-                    y[t] = (int8_t)((b > 0 ? b : 0) - qe);    d |= b > 0 ? 0x10 : 0;
-                    x2[t] = (int8_t)((a2 > 0 ? a2 : 0) - qe2); d |= a2 > 0 ? 0x20 : 0;
-                    y2[t] = (int8_t)((b2 > 0 ? b2 : 0) - qe2); d |= b2 > 0 ? 0x40 : 0;
-                } else {
-                    d = z > a ? 0 : 1;  z = z > a ? z : a;
-                    d = z > b ? d : 2;  z = z > b ? z : b;
-                    d = z > a2 ? d : 3; z = z > a2 ? z : a2;
-                    d = z > b2 ? d : 4; z = z > b2 ? z : b2;
-                    z = z < sc_mch ? z : sc_mch;
-                    u[t] = (int8_t)(z - vt1); v[t] = (int8_t)(z - ut);
-                    tmp = (int8_t)(z - q);  a = (int8_t)(a - tmp);  b = (int8_t)(b - tmp);
-                    tmp = (int8_t)(z - q2); a2 = (int8_t)(a2 - tmp); b2 = (int8_t)(b2 - tmp);
-                    x[t] = (int8_t)((0 > a ? 0 : a) - qe);    d |= 0 > a ? 0 : 0x08;
-                    y[t] = (int8_t)((0 > b ? 0 : b) - qe);    d |= 0 > b ? 0 : 0x10;
-                    x2[t] = (int8_t)((0 > a2 ? 0 : a2) - qe2); d |= 0 > a2 ? 0 : 0x20;
-                    y2[t] = (int8_t)((0 > b2 ? 0 : b2) - qe2); d |= 0 > b2 ? 0 : 0x40;
+        dsync();
+        if (en - st + 1 > AL_WIDE_MIN) {
+            // core loop over the rounded range, FOUR cells per lane (256 a step: the state arrays move as dwords - the byte-wide form issued
+            // thirteen LDS operations per 64 cells and was bound by them); every cell reads the previous anti-diagonal only.  [st, en] starts on a
+            // multiple of 16 and holds a multiple of 16 cells, so a lane's four cells are all inside or all outside.
+            uint32_t cwx = (uint32_t)(uint8_t)x1 << 24, cwv = (uint32_t)(uint8_t)v1 << 24, cwx2 = (uint32_t)(uint8_t)x21 << 24;      // byte 3 = the cell before the range
+            for (int32_t tb = st; tb <= en; tb += 256) {
+                const int32_t t = tb + 4 * (int32_t)lane;
+                const bool on = t <= en;
+                auto LDW = [&](const int8_t *a) -> uint32_t { if constexpr (G) return cc_u32((const uint32_t *)(a + t)); else return *(const uint32_t *)(a + t); };
+                const uint32_t wx = on ? LDW(x) : 0u, wv = on ? LDW(v) : 0u, wx2 = on ? LDW(x2) : 0u;
+                uint32_t px = (uint32_t)al_wave_shr1((int32_t)wx, 0), pv = (uint32_t)al_wave_shr1((int32_t)wv, 0), px2 = (uint32_t)al_wave_shr1((int32_t)wx2, 0);
+                if (lane == 0) { px = cwx; pv = cwv; px2 = cwx2; }
+                cwx = (uint32_t)__builtin_amdgcn_readlane((int)wx, 63); cwv = (uint32_t)__builtin_amdgcn_readlane((int)wv, 63); cwx2 = (uint32_t)__builtin_amdgcn_readlane((int)wx2, 63);
+                if (on) {
+                    const uint32_t ws = LDW(s), wu = LDW(u), wy = LDW(y), wy2 = LDW(y2);
+                    // the cells' left neighbours: bytes (prev.3, own.0, own.1, own.2)
+                    const uint32_t nx = wx << 8 | px >> 24, nv = wv << 8 | pv >> 24, nx2 = wx2 << 8 | px2 >> 24;
+                    uint32_t ou = 0, ov = 0, ox = 0, oy = 0, ox2 = 0, oy2 = 0, od = 0;
+    #pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int sh = 8 * c;
+                        const int8_t xt1 = (int8_t)(nx >> sh), vt1 = (int8_t)(nv >> sh), x2t1 = (int8_t)(nx2 >> sh);
+                        int8_t z = (int8_t)(ws >> sh);
+                        const int8_t ut = (int8_t)(wu >> sh);
+                        int8_t a = (int8_t)(xt1 + vt1), b = (int8_t)((int8_t)(wy >> sh) + ut), a2 = (int8_t)(x2t1 + vt1), b2 = (int8_t)((int8_t)(wy2 >> sh) + ut), tmp;
+                        uint8_t d;
+                        int8_t nxv, nyv, nx2v, ny2v;
+                        if (!(flag & EZ_RIGHT)) {
+                            d = a > z ? 1 : 0;  z = z > a ? z : a;
+                            d = b > z ? 2 : d;  z = z > b ? z : b;
+                            d = a2 > z ? 3 : d; z = z > a2 ? z : a2;
+                            d = b2 > z ? 4 : d; z = z > b2 ? z : b2;
+                            z = z < sc_mch ? z : sc_mch;
+                            tmp = (int8_t)(z - q);  a = (int8_t)(a - tmp);  b = (int8_t)(b - tmp);
+                            tmp = (int8_t)(z - q2); a2 = (int8_t)(a2 - tmp); b2 = (int8_t)(b2 - tmp);
+                            nxv = (int8_t)((a > 0 ? a : 0) - qe);    d |= a > 0 ? 0x08 : 0;
+                            nyv = (int8_t)((b > 0 ? b : 0) - qe);    d |= b > 0 ? 0x10 : 0;
+                            nx2v = (int8_t)((a2 > 0 ? a2 : 0) - qe2); d |= a2 > 0 ? 0x20 : 0;
+                            ny2v = (int8_t)((b2 > 0 ? b2 : 0) - qe2); d |= b2 > 0 ? 0x40 : 0;
+                        } else {
+                            d = z > a ? 0 : 1;  z = z > a ? z : a;
+                            d = z > b ? d : 2;  z = z > b ? z : b;
+                            d = z > a2 ? d : 3; z = z > a2 ? z : a2;
+                            d = z > b2 ? d : 4; z = z > b2 ? z : b2;
+                            z = z < sc_mch ? z : sc_mch;
+                            tmp = (int8_t)(z - q);  a = (int8_t)(a - tmp);  b = (int8_t)(b - tmp);
+                            tmp = (int8_t)(z - q2); a2 = (int8_t)(a2 - tmp); b2 = (int8_t)(b2 - tmp);
+                            nxv = (int8_t)((0 > a ? 0 : a) - qe);    d |= 0 > a ? 0 : 0x08;
+                            nyv = (int8_t)((0 > b ? 0 : b) - qe);    d |= 0 > b ? 0 : 0x10;
+                            nx2v = (int8_t)((0 > a2 ? 0 : a2) - qe2); d |= 0 > a2 ? 0 : 0x20;
+                            ny2v = (int8_t)((0 > b2 ? 0 : b2) - qe2); d |= 0 > b2 ? 0 : 0x40;
+                        }
+                        ou |= (uint32_t)(uint8_t)(int8_t)(z - vt1) << sh; ov |= (uint32_t)(uint8_t)(int8_t)(z - ut) << sh;
+                        ox |= (uint32_t)(uint8_t)nxv << sh; oy |= (uint32_t)(uint8_t)nyv << sh; ox2 |= (uint32_t)(uint8_t)nx2v << sh; oy2 |= (uint32_t)(uint8_t)ny2v << sh;
+                        od |= (uint32_t)d << sh;
+                    }
+                    *(uint32_t *)(u + t) = ou; *(uint32_t *)(v + t) = ov; *(uint32_t *)(x + t) = ox; *(uint32_t *)(y + t) = oy;
+                    *(uint32_t *)(x2 + t) = ox2; *(uint32_t *)(y2 + t) = oy2;
+                    *(uint32_t *)(p + ((unsigned long long)r * (unsigned long long)n_col + (unsigned long long)(t - st))) = od;
                 }
-                p[(unsigned long long)r * (unsigned long long)n_col + (unsigned long long)(t - st)] = d;
+            }
+        } else {
+            // core loop over the rounded range, 64 cells at a time; every cell reads the previous anti-diagonal only
+            int8_t cx1 = x1, cx21 = x21, cv1 = v1;
+            for (int32_t tb = st; tb <= en; tb += 64) {
+                const int32_t t = tb + (int32_t)lane;
+                const bool on = t <= en;
+                const int8_t ox = on ? ld8s(x + t, g) : (int8_t)0, ov = on ? ld8s(v + t, g) : (int8_t)0, ox2 = on ? ld8s(x2 + t, g) : (int8_t)0;
+                int8_t xt1 = (int8_t)al_wave_shr1((int)ox, 0), vt1 = (int8_t)al_wave_shr1((int)ov, 0), x2t1 = (int8_t)al_wave_shr1((int)ox2, 0);
+                if (lane == 0) { xt1 = cx1; vt1 = cv1; x2t1 = cx21; }
+                cx1 = (int8_t)__builtin_amdgcn_readlane((int)ox, 63); cv1 = (int8_t)__builtin_amdgcn_readlane((int)ov, 63); cx21 = (int8_t)__builtin_amdgcn_readlane((int)ox2, 63);
+                if (on) {
+                    int8_t z = ld8s(s + t, g);
+                    const int8_t ut = ld8s(u + t, g);
+                    int8_t a = (int8_t)(xt1 + vt1), b = (int8_t)(ld8s(y + t, g) + ut), a2 = (int8_t)(x2t1 + vt1), b2 = (int8_t)(ld8s(y2 + t, g) + ut), tmp;
+                    uint8_t d;
+                    if (!(flag & EZ_RIGHT)) {
+                        d = a > z ? 1 : 0;  z = z > a ? z : a;
+                        d = b > z ? 2 : d;  z = z > b ? z : b;
+                        d = a2 > z ? 3 : d; z = z > a2 ? z : a2;
+                        d = b2 > z ? 4 : d; z = z > b2 ? z : b2;
+                        z = z < sc_mch ? z : sc_mch;
+                        u[t] = (int8_t)(z - vt1); v[t] = (int8_t)(z - ut);
+                        tmp = (int8_t)(z - q);  a = (int8_t)(a - tmp);  b = (int8_t)(b - tmp);
+                        tmp = (int8_t)(z - q2); a2 = (int8_t)(a2 - tmp); b2 = (int8_t)(b2 - tmp);
+                        x[t] = (int8_t)((a > 0 ? a : 0) - qe);    d |= a > 0 ? 0x08 : 0;
+                        y[t] = (int8_t)((b > 0 ? b : 0) - qe);    d |= b > 0 ? 0x10 : 0;
+                        x2[t] = (int8_t)((a2 > 0 ? a2 : 0) - qe2); d |= a2 > 0 ? 0x20 : 0;
+                        y2[t] = (int8_t)((b2 > 0 ? b2 : 0) - qe2); d |= b2 > 0 ? 0x40 : 0;
+                    } else {
+                        d = z > a ? 0 : 1;  z = z > a ? z : a;
+                        d = z > b ? d : 2;  z = z > b ? z : b;
+                        d = z > a2 ? d : 3; z = z > a2 ? z : a2;
+                        d = z > b2 ? d : 4; z = z > b2 ? z : b2;
+                        z = z < sc_mch ? z : sc_mch;
+                        u[t] = (int8_t)(z - vt1); v[t] = (int8_t)(z - ut);
+                        tmp = (int8_t)(z - q);  a = (int8_t)(a - tmp);  b = (int8_t)(b - tmp);
+                        tmp = (int8_t)(z - q2); a2 = (int8_t)(a2 - tmp); b2 = (int8_t)(b2 - tmp);
+                        x[t] = (int8_t)((0 > a ? 0 : a) - qe);    d |= 0 > a ? 0 : 0x08;
+                        y[t] = (int8_t)((0 > b ? 0 : b) - qe);    d |= 0 > b ? 0 : 0x10;
+                        x2[t] = (int8_t)((0 > a2 ? 0 : a2) - qe2); d |= 0 > a2 ? 0 : 0x20;
+                        y2[t] = (int8_t)((0 > b2 ? 0 : b2) - qe2); d |= 0 > b2 ? 0 : 0x40;
+                    }
+                    p[(unsigned long long)r * (unsigned long long)n_col + (unsigned long long)(t - st)] = d;
+                }
             }
         }
-        al_sync();
+        dsync();
         if (flag & EZ_APPROX_MAX) {      // ksw2's approximate maximum: follow one path (the first pass of the long-read gap filling)
             if (r > 0) {
                 if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
@@ -445,7 +514,7 @@ __device__ inline void ksw_extd2_core(int32_t qlen, const uint8_t *query, bool q
         if (r > 0) {
             const int32_t en1 = st0 + (en0 - st0) / 4 * 4;
             const int32_t h_last = en0 > 0 ? ld32(H + en0 - 1, g) + (int32_t)ld8s(u + en0, g) : ld32(H + en0, g) + (int32_t)ld8s(v + en0, g);
-            al_sync();
+            dsync();
             long long best = ((long long)h_last << 32) | 0x7fffffffll;
             int32_t mine_st0 = KSW_NEG_INF;
             for (int32_t tb = st0; tb < en0; tb += 64) {

@@ -183,6 +183,30 @@ __device__ inline void lr_reg_set_coor(LReg &r, int32_t qlen, const LAnchor *a)
     }
 }
 
+// the same with the whole wave on one region (uniform result): the fuzzy lengths are sums over the region's ~1000 anchor pairs
+__device__ inline void lr_reg_set_coor_wave(LReg &r, int32_t qlen, const LAnchor *a)
+{
+    const int32_t k = r.as, q_span = (int32_t)(a[k].y >> 32 & 0xff), lane = (int32_t)al_lane();
+    r.rev = (int32_t)(a[k].x >> 63);
+    r.rid = (int32_t)(a[k].x << 1 >> 33);
+    r.rs = (int32_t)a[k].x + 1 > q_span ? (int32_t)a[k].x + 1 - q_span : 0;
+    r.re = (int32_t)a[k + r.cnt - 1].x + 1;
+    if (!r.rev) { r.qs = (int32_t)a[k].y + 1 - q_span; r.qe = (int32_t)a[k + r.cnt - 1].y + 1; }
+    else { r.qs = qlen - ((int32_t)a[k + r.cnt - 1].y + 1); r.qe = qlen - ((int32_t)a[k].y + 1 - q_span); }
+    r.mlen = r.blen = 0;
+    if (r.cnt <= 0) return;
+    int32_t ml = 0, bl = 0;
+    for (int32_t i = r.as + 1 + lane; i < r.as + r.cnt; i += 64) {
+        const int32_t span = (int32_t)(a[i].y >> 32 & 0xff);
+        const int32_t tl = (int32_t)a[i].x - (int32_t)a[i - 1].x, ql = (int32_t)a[i].y - (int32_t)a[i - 1].y;
+        bl += tl > ql ? tl : ql;
+        ml += tl > span && ql > span ? span : tl < ql ? tl : ql;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ml += __shfl_xor(ml, o); bl += __shfl_xor(bl, o); }
+    r.mlen = q_span + ml; r.blen = q_span + bl;
+}
+
 // where a wave's time goes (SCRUBBY_HIP_DBG): 0 gather, 1 rmq sort, 2 rmq fill, 3 backtrack + compact, 4 gen_regs, 5 parent / select / est_err, 6 squeeze,
 // 7 region set-up (bad ends / seeds, windows), 8 ksw, 9 z-drop test, 10 update_extra, 11 sequence staging
 #define LR_NCLK 12
@@ -939,9 +963,28 @@ __device__ inline int32_t lr_collect_long_gaps0(int32_t as1, int32_t cnt1, const
     return n <= 1 ? 0 : n;
 }
 
-__device__ inline void lr_filter_bad_seeds0(int32_t as1, int32_t cnt1, LAnchor *a, int32_t min_gap, int32_t diff_thres, int32_t max_ext_len, int32_t max_ext_cnt, int32_t *K)
+// collect_long_gaps by the whole wave: a region of a long read has ~1000 anchors, and one lane walking them through HBM scratch (twice per
+// region: two thresholds) was most of a probe's time.  K receives the indices in rising order; returns their number (0 when it is 1: upstream).
+__device__ inline int32_t lr_collect_long_gaps_wave(int32_t as1, int32_t cnt1, const LAnchor *a, int32_t min_gap, int32_t *K)
 {
-    const int32_t n = lr_collect_long_gaps0(as1, cnt1, a, min_gap, K);
+    const int32_t lane = (int32_t)al_lane();
+    int32_t n = 0;
+    for (int32_t i0 = 1; i0 < cnt1; i0 += 64) {
+        const int32_t i = i0 + lane;
+        bool g = false;
+        if (i < cnt1) { const int32_t gap = lr_gap_at(a, as1 + i); g = gap < -min_gap || gap > min_gap; }
+        const uint64_t m = __ballot(g);
+        if (g) K[n + (int32_t)prefix_popc64(m)] = i;
+        n += (int32_t)__popcll(m);
+    }
+    lr_sync();
+    return n <= 1 ? 0 : n;
+}
+
+// n: what lr_collect_long_gaps_wave returned for (as1, cnt1, min_gap) - or -1: collect here, on this lane
+__device__ inline void lr_filter_bad_seeds0(int32_t as1, int32_t cnt1, LAnchor *a, int32_t min_gap, int32_t diff_thres, int32_t max_ext_len, int32_t max_ext_cnt, int32_t *K, int32_t n_pre = -1)
+{
+    const int32_t n = n_pre >= 0 ? n_pre : lr_collect_long_gaps0(as1, cnt1, a, min_gap, K);
     if (n == 0) return;
     int32_t max = 0, max_st = -1, max_en = -1;
     for (int32_t k = 0;; ++k) {
@@ -969,9 +1012,9 @@ __device__ inline void lr_filter_bad_seeds0(int32_t as1, int32_t cnt1, LAnchor *
     }
 }
 
-__device__ inline void lr_filter_bad_seeds_alt0(int32_t as1, int32_t cnt1, LAnchor *a, int32_t min_gap, int32_t max_ext, int32_t *K)
+__device__ inline void lr_filter_bad_seeds_alt0(int32_t as1, int32_t cnt1, LAnchor *a, int32_t min_gap, int32_t max_ext, int32_t *K, int32_t n_pre = -1)
 {
-    const int32_t n = lr_collect_long_gaps0(as1, cnt1, a, min_gap, K);
+    const int32_t n = n_pre >= 0 ? n_pre : lr_collect_long_gaps0(as1, cnt1, a, min_gap, K);
     if (n == 0) return;
     for (int32_t k = 0; k < n;) {
         const int32_t i = K[k];
@@ -1183,9 +1226,12 @@ __device__ __noinline__ bool lr_align1(LongCtx &C, LReg &r, LReg &r2, LAnchor *a
     lr_tick(C.clk, 6);
     if (pre_as1 >= 0) { as1 = pre_as1; cnt1 = pre_cnt1; }      // a probe of this region ran first: mm_fix_bad_ends must not see the flags its seed filters left
     else lr_fix_bad_ends0(r, a, P.bw, P.min_sc * 2, as1, cnt1);
-    if (lane == 0) {
-        lr_filter_bad_seeds0(as1, cnt1, a, 10, 40, P.max_gap >> 1, 10, W.K);
-        lr_filter_bad_seeds_alt0(as1, cnt1, a, 30, P.max_gap >> 1, W.K);
+    {
+        const int32_t n1 = lr_collect_long_gaps_wave(as1, cnt1, a, 10, W.K);
+        if (lane == 0) lr_filter_bad_seeds0(as1, cnt1, a, 10, 40, P.max_gap >> 1, 10, W.K, n1);
+        lr_sync();
+        const int32_t n2 = lr_collect_long_gaps_wave(as1, cnt1, a, 30, W.K);
+        if (lane == 0) lr_filter_bad_seeds_alt0(as1, cnt1, a, 30, P.max_gap >> 1, W.K, n2);
     }
     lr_sync();
     int32_t rs = (int32_t)a[as1].x - hk, qs = (int32_t)a[as1].y - hk;
@@ -1471,9 +1517,12 @@ __device__ __noinline__ int32_t lr_probe_region(LongCtx &C, const LReg &r, LAnch
         int32_t as_c, cnt_c;
         lr_fix_bad_ends0(rr, a, P.bw, P.min_sc * 2, as_c, cnt_c);
         if (depth == 0) { as1 = as_c; cnt1 = cnt_c; }
-        if (lane == 0) {
-            lr_filter_bad_seeds0(as_c, cnt_c, a, 10, 40, P.max_gap >> 1, 10, W.K);
-            lr_filter_bad_seeds_alt0(as_c, cnt_c, a, 30, P.max_gap >> 1, W.K);
+        {
+            const int32_t n1 = lr_collect_long_gaps_wave(as_c, cnt_c, a, 10, W.K);
+            if (lane == 0) lr_filter_bad_seeds0(as_c, cnt_c, a, 10, 40, P.max_gap >> 1, 10, W.K, n1);
+            lr_sync();
+            const int32_t n2 = lr_collect_long_gaps_wave(as_c, cnt_c, a, 30, W.K);
+            if (lane == 0) lr_filter_bad_seeds_alt0(as_c, cnt_c, a, 30, P.max_gap >> 1, W.K, n2);
         }
         lr_sync();
         const int32_t rs_first = (int32_t)a[as_c].x - hk, qs_first = (int32_t)a[as_c].y - hk;
@@ -1510,7 +1559,7 @@ __device__ __noinline__ int32_t lr_probe_region(LongCtx &C, const LReg &r, LAnch
                 if (cnt_c - (j + 1) < P.min_cnt || !(n > 0 && n < rr.cnt)) { C.probe_why = 5; return 0; }
                 LReg r2 = rr;
                 r2.cnt = rr.cnt - n; r2.as = rr.as + n;
-                lr_reg_set_coor(r2, C.qlen, a);
+                lr_reg_set_coor_wave(r2, C.qlen, a);
                 rr = r2;
                 split = true;
                 break;
@@ -1884,7 +1933,7 @@ __device__ inline int32_t lr_regs_wave(LongCtx &C, const ChainParams &CP, const 
         r.cnt = (int32_t)(uint32_t)Uh[bi]; r.as = (int32_t)UOh[bi];
         r.div = -1.0f;
         lr_sync();
-        lr_reg_set_coor(r, qlen, A0);
+        lr_reg_set_coor_wave(r, qlen, A0);
         int32_t as1, cnt1;
         const int32_t pr = lr_probe_region(C, r, A0, as1, cnt1, true);
         if (pr < 0) return C.need_big ? 1 : 3;
@@ -1898,7 +1947,7 @@ __device__ inline int32_t lr_regs_wave(LongCtx &C, const ChainParams &CP, const 
             lr_sync();
             LReg r1{};
             r1.id = 0; r1.parent = 0; r1.score = hh[1]; r1.cnt = n_alt; r1.as = 0; r1.div = -1.0f;
-            lr_reg_set_coor(r1, qlen, A0);
+            lr_reg_set_coor_wave(r1, qlen, A0);
             const int32_t pr2 = lr_probe_region(C, r1, A0, as1, cnt1, true);
             if (pr2 < 0) return C.need_big ? 1 : 3;
             if (pr2 == 0) { C.err = 46; return 5; }
