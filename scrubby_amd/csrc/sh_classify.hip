@@ -96,7 +96,7 @@ struct Counters {
     uint32_t n_locus[3], locus_ticket[3], lr_n_fb, lr_locus_reads; unsigned long long lr_locus_in, lr_locus_kept;
     uint32_t lr_fb_why[8], lr_fb_had, lr_pad, lr_probe_why[8];
     uint32_t lext_n_unres, lext_ticket_unres, lext_n_unres_in, lext_pad4, lext_n_exact, lext_ticket_exact, lext_rmq_open, lext_pad5;      // reads beyond the stage's second working-memory size: redone with memory allocated for them
-    unsigned long long lext_slow2, lext_slow3, lext_slow_part[4], lext_sum_part[4], lext_clk_big[LR_NCLK];      // SCRUBBY_HIP_DBG: the slowest read of the chains kernel (time << 32 | read length / read)
+    unsigned long long lext_slow2, lext_slow3, lext_slow_part[4], lext_sum_part[4], lext_clk_big[LR_NCLK], lext_d_big[8], lext_phase_max[LR_NCLK];      // SCRUBBY_HIP_DBG: the slowest read of the chains kernel (time << 32 | read length / read)
     unsigned long long stage_cursor;      // k_expand's raw anchors of the reads k_lr_locus will thin out (their own buffer: 12 B per anchor)
 };
 #define SHARD() ((blockIdx.x + (blockIdx.x >> 6)) & 63)
@@ -3131,7 +3131,7 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
     if (lane == 0) {
         if (n_rechain) atomicAdd(&a.ctr->lext_rechained, n_rechain);
         if (n_open) { atomicAdd(&a.ctr->lext_rmq_tie, n_open); atomicAdd(&a.ctr->lext_rmq_open, n_open); }
-        if (a.clk) { for (int i = 0; i < LR_NCLK; ++i) atomicAdd(&a.ctr->lext_clk[i], clk.t[i]); for (int i = 0; i < 7; ++i) atomicAdd(&a.ctr->lext_d[i], clk.d[i]); atomicMax(&a.ctr->lext_d[7], clk.d[7]); }
+        if (a.clk) { for (int i = 0; i < LR_NCLK; ++i) atomicAdd(a.part == 2 ? &a.ctr->lext_clk_big[i] : &a.ctr->lext_clk[i], clk.t[i]); unsigned long long *dd = a.part == 2 ? a.ctr->lext_d_big : a.ctr->lext_d; for (int i = 0; i < 7; ++i) atomicAdd(&dd[i], clk.d[i]); atomicMax(&dd[7], clk.d[7]); }
     }
 }
 
@@ -3161,7 +3161,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         C.sc_amb = (int8_t)(P_l.sc_ambi > 0 ? -P_l.sc_ambi : P_l.sc_ambi); C.sc_N = C.sc_amb == 0 ? (int8_t)(-P_l.e2) : C.sc_amb;
         C.need_big = false; C.err = 0; C.clk = a.clk ? &clk : nullptr; C.probe_why = 0;
         LongOut o;
+        const unsigned long long t_r0 = a.clk ? wall_clock64() : 0ull;
+        LongClk clk0 = clk;
         const int32_t rc = lr_regs_wave(C, CP_l, AR_l, a.flag_only != 0, a.probe != 0, o);
+        if (a.clk && lane == 0 && !a.big_list) { const unsigned long long dt = wall_clock64() - t_r0; atomicMax(&a.ctr->lext_slow_part[3], dt << 32 | (unsigned long long)(uint32_t)C.qlen); atomicAdd(&a.ctr->lext_sum_part[3], dt); for (int i = 0; i < LR_NCLK; ++i) atomicMax(&a.ctr->lext_phase_max[i], clk.t[i] - clk0.t[i]); }
         if (rc == 5) {
             if (lane == 0) {      // counted again when the read comes back with all its anchors
                 const int32_t rch = AR_l.hdr[r].rechained;
@@ -3231,7 +3234,7 @@ struct sh_ctx {
     // the same stage for the long-read presets (sh_long.h): per-wave working memory in two sizes
     bool ext_long = false;
     LongParams LP{};
-    uint8_t *d_lext[4] = {}; unsigned long long lext_per_wave[4] = {}; uint32_t lext_waves[4] = {}; LongSizes lext_sz[4] = {};      // [phase * 2 + tier]
+    uint8_t *d_lext[4] = {}; unsigned long long lext_per_wave[4] = {}; uint32_t lext_waves[4] = {}; LongSizes lext_sz[4] = {}; int n_cu = 256;      // [phase * 2 + tier]
     uint32_t *d_lext_big = nullptr, *d_lext_big2 = nullptr, *d_lext_sorted = nullptr, *d_lext_unres[2] = {}, *d_lext_exact_list = nullptr;
     uint8_t *d_lext_exact[2] = {}; unsigned long long lext_exact_per_wave[2] = {}; uint32_t lext_exact_waves[2] = {}; LongSizes lext_exact_sz[2] = {};      // the chains kernel with the long join on the literal trees
     uint8_t *d_larena = nullptr; unsigned long long larena_bytes = 0; LongHdr *d_lhdr = nullptr;
@@ -3522,6 +3525,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
                 const int i = ph * 2 + t;
                 c->lext_sz[i] = q;
                 c->lext_per_wave[i] = long_ws_carve(nullptr, nullptr, q);
+                if (i == 0) { int dev = 0, ncu = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) c->n_cu = ncu; }
                 c->lext_waves[i] = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({wave_max[i], budget[i] / c->lext_per_wave[i], t ? std::max<uint64_t>(4, max_reads / 16) : max_reads}));
                 if ((e = hipMalloc(&c->d_lext[i], (uint64_t)c->lext_waves[i] * c->lext_per_wave[i])) != hipSuccess) return fail(e, "long-read extension-stage scratch");
             }
@@ -3989,9 +3993,15 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 xg.ticket = &c->d_ctr->lext_ticket_g; xg.part = 2;      // same ring as the others (19 KB of LDS: they share CUs); what outgrows the ring joins the big list
                 SH_HIP(hipEventRecord(c->evx[0], s));
                 SH_HIP(hipStreamWaitEvent(c->sx[0], c->evx[0], 0));
-                hipLaunchKernelGGL((k_long_chains<512, false>), dim3(c->lext_waves[1]), dim3(64), 0, c->sx[0], xg);
+                // Both kernels are persistent and hold 19 KB of LDS a wave - eight to a CU.  Launched with every slot taken, the main kernel kept the
+                // giants' waves waiting until it had ended (their second-long reads then ran alone: the stage's longest stretch); so the two
+                // grids together stay within the slots the device has.
+                const uint32_t slots = 8u * (uint32_t)c->n_cu;
+                const uint32_t g_waves = std::min<uint32_t>(c->lext_waves[1], 128u);
+                const uint32_t m_waves = c->lext_waves[0] + g_waves > slots && slots > 2 * g_waves ? std::min<uint32_t>(c->lext_waves[0], slots - g_waves) : c->lext_waves[0];
+                hipLaunchKernelGGL((k_long_chains<512, false>), dim3(g_waves), dim3(64), 0, c->sx[0], xg);
                 SH_HIP(hipEventRecord(c->evx[1], c->sx[0]));
-                hipLaunchKernelGGL((k_long_chains<512, false>), dim3(c->lext_waves[0]), dim3(64), 0, s, xa);
+                hipLaunchKernelGGL((k_long_chains<512, false>), dim3(m_waves), dim3(64), 0, s, xa);
                 SH_HIP(hipStreamWaitEvent(s, c->evx[1], 0));
                 sh_status st = sync_ctr(); if (st != SH_OK) return st;
                 if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;       // hand-over buffers or arena full: the caller cuts the chunk in two
@@ -4100,6 +4110,15 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                     c->h_ctr->lext_slow3 & 0xffffffffull, c->h_ctr->lext_slow2 & 0xffffffffull, c->h_ctr->lext_kernel_sum / 1e5);
             { unsigned long long tb = 0; for (int i = 0; i < LR_NCLK; ++i) tb += c->h_ctr->lext_clk_big[i];
               fprintf(stderr, "[dbg] regions kernel, second size: gen_regs %.1f  parent/select %.1f  squeeze %.1f  set-up %.1f  ksw %.1f  z-drop %.1f  update_extra %.1f  staging %.1f %% of %.1f wave-s\n", 100. * c->h_ctr->lext_clk_big[4] / (tb + 1), 100. * c->h_ctr->lext_clk_big[5] / (tb + 1), 100. * c->h_ctr->lext_clk_big[6] / (tb + 1), 100. * c->h_ctr->lext_clk_big[7] / (tb + 1), 100. * c->h_ctr->lext_clk_big[8] / (tb + 1), 100. * c->h_ctr->lext_clk_big[9] / (tb + 1), 100. * c->h_ctr->lext_clk_big[10] / (tb + 1), 100. * c->h_ctr->lext_clk_big[11] / (tb + 1), tb / 1e8); }
+            { unsigned long long tg = c->h_ctr->lext_clk_big[0] + c->h_ctr->lext_clk_big[1] + c->h_ctr->lext_clk_big[2] + c->h_ctr->lext_clk_big[3];
+              fprintf(stderr, "[dbg] giants rmq-fill sections (wave-s): insert %.2f  trim %.2f  query %.2f  tally %.2f  score+inner %.2f\n", c->h_ctr->lext_clk_big[4] / 1e8, c->h_ctr->lext_clk_big[5] / 1e8, c->h_ctr->lext_clk_big[6] / 1e8, c->h_ctr->lext_clk_big[7] / 1e8, c->h_ctr->lext_clk_big[8] / 1e8);
+              fprintf(stderr, "[dbg] all rmq-fill sections (wave-s): insert %.2f  trim %.2f  query %.2f  tally %.2f  score+inner %.2f\n", c->h_ctr->lext_clk[4] / 1e8, c->h_ctr->lext_clk[5] / 1e8, c->h_ctr->lext_clk[6] / 1e8, c->h_ctr->lext_clk[7] / 1e8, c->h_ctr->lext_clk[8] / 1e8);
+              fprintf(stderr, "[dbg] chains kernel, the giants: gather %.1f  rmq-sort %.1f  rmq-fill %.1f  backtrack+compact %.1f %% of %.2f wave-s\n", 100. * c->h_ctr->lext_clk_big[0] / (tg + 1), 100. * c->h_ctr->lext_clk_big[1] / (tg + 1), 100. * c->h_ctr->lext_clk_big[2] / (tg + 1), 100. * c->h_ctr->lext_clk_big[3] / (tg + 1), tg / 1e8); }
+            { const unsigned long long *dd = c->h_ctr->lext_d_big;
+              fprintf(stderr, "[dbg] RMQ, the giants: %llu reads, %llu anchors (largest read %llu), per anchor: %.2f ring blocks, %.3f trips behind the ring with %.2f old blocks, list length %.1f, %.2f inner chunks\n",
+                      dd[6], dd[0], dd[7], (double)dd[1] / (dd[0] + 1), (double)dd[2] / (dd[0] + 1), (double)dd[3] / (dd[0] + 1), (double)dd[4] / (dd[0] + 1), (double)dd[5] / (dd[0] + 1)); }
+            fprintf(stderr, "[dbg] regions kernel, second size: slowest read %.1f ms (%llu bases), all reads %.1f wave-ms\n", (c->h_ctr->lext_slow_part[3] >> 32) / 1e5, c->h_ctr->lext_slow_part[3] & 0xffffffffull, c->h_ctr->lext_sum_part[3] / 1e5);
+            fprintf(stderr, "[dbg] regions kernel, second size, largest per-read time of each step (ms): gen_regs %.1f  parent/select %.1f  squeeze %.1f  set-up %.1f  ksw %.1f  z-drop %.1f  update_extra %.1f  staging %.1f\n", c->h_ctr->lext_phase_max[4] / 1e5, c->h_ctr->lext_phase_max[5] / 1e5, c->h_ctr->lext_phase_max[6] / 1e5, c->h_ctr->lext_phase_max[7] / 1e5, c->h_ctr->lext_phase_max[8] / 1e5, c->h_ctr->lext_phase_max[9] / 1e5, c->h_ctr->lext_phase_max[10] / 1e5, c->h_ctr->lext_phase_max[11] / 1e5);
             for (int pp = 0; pp < 3; ++pp) fprintf(stderr, "[dbg] chains kernel, part %d (0 lists of later passes, 1 all but the giants, 2 the giants): slowest read %.1f ms, all reads %.1f wave-ms\n", pp, (c->h_ctr->lext_slow_part[pp] >> 32) / 1e5, c->h_ctr->lext_sum_part[pp] / 1e5);
             for (int i = 0; i < SINK_SHARDS; ++i) { sr += c->h_ctr->ext_n_recs[i]; sa += c->h_ctr->ext_n_anch[i]; mr = std::max<unsigned long long>(mr, c->h_ctr->ext_n_recs[i]); ma = std::max<unsigned long long>(ma, c->h_ctr->ext_n_anch[i]); }
             fprintf(stderr, "[dbg] chain hand-over: %llu chains, %llu anchors; fullest shard %llu / %u chains, %llu / %llu anchors\n", sr, sa, mr, c->sink.cap_recs, ma, c->sink.cap_anch);

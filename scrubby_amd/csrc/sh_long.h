@@ -246,6 +246,30 @@ __device__ inline int32_t lr_sc_simple(int32_t dr, int32_t dq, int32_t q_span, f
     }
     return sc;
 }
+// the smallest of a wave's doubles, on every lane: four DPP stages inside the rows of 16 and the four row results through scalar registers (a
+// butterfly of __shfl_xor is eighteen ds_bpermute round trips in a row - it was most of a long-join step)
+template <int CTRL>
+__device__ inline double lr_dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double lr_readlane_f64(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ inline double lr_wave_min_f64(double v)
+{
+    double t;
+    t = lr_dpp_f64<0xB1>(v); v = t < v ? t : v;       // quad_perm [1,0,3,2]
+    t = lr_dpp_f64<0x4E>(v); v = t < v ? t : v;       // quad_perm [2,3,0,1]
+    t = lr_dpp_f64<0x141>(v); v = t < v ? t : v;      // row_half_mirror
+    t = lr_dpp_f64<0x140>(v); v = t < v ? t : v;      // row_mirror
+    const double r0 = lr_readlane_f64(v, 0), r1 = lr_readlane_f64(v, 16), r2 = lr_readlane_f64(v, 32), r3 = lr_readlane_f64(v, 48);
+    const double m01 = r1 < r0 ? r1 : r0, m23 = r3 < r2 ? r3 : r2;
+    return m23 < m01 ? m23 : m01;
+}
 __device__ inline double lr_cc_f64(const double *p) { return __longlong_as_double((long long)cc_u64(p)); }
 
 // a[] sorted by x (read-only here).  Out: f, p (int32; -1 = none) - visible to the other lanes after the caller's lr_sync().  n_tie: steps
@@ -285,7 +309,10 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
     bool ok = true;
     uint32_t hi_prev = 0;
     LAnchor cur = a[0];
-    uint64_t x_st = cur.x;
+    int32_t xw_base = 0;
+    uint64_t xw = a[lane < n ? lane : n - 1].x;
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pl = dbg ? wall_clock64() : 0ull;
+#define LRQ_T(k) do { if (dbg) { const unsigned long long nw = wall_clock64(); pt[k] += nw - pl; pl = nw; } } while (0)
     for (int32_t i = 0; i < n && ok; ++i) {
         const uint64_t xi = cur.x, yi = cur.y;
         if (i + 1 < n) cur = a[i + 1];      // the next anchor travels while this one is worked on
@@ -338,9 +365,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
             if (TREE && al_b0(T0.bad)) { ok = false; break; }      // the pool or a walk gave out: the caller takes the read to the one-lane version
             i0 = i;
             while ((blk_done + 1) * 64 <= i0) {      // blocks completed by this insertion (their anchors are all in the ring)
-                double m = L.rpri[(blk_done * 64 + lane) & M];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { const double om = __shfl_xor(m, o); m = om < m ? om : m; }
+                const double m = lr_wave_min_f64(L.rpri[(blk_done * 64 + lane) & M]);
                 const double pm = blk_done > 0 && L.pml[(blk_done - 1) & 63] < m ? L.pml[(blk_done - 1) & 63] : m;
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 0) { bmin[blk_done] = m; L.pml[blk_done & 63] = pm; L.bml[blk_done & 63] = m; }
@@ -352,9 +377,19 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 ++blk_done;
             }
         }
+        LRQ_T(0);
         // anchors out of range leave
-        if (st < seg0) { st = seg0; x_st = a[st < n ? st : n - 1].x; }
-        while (st < i && xi > x_st + (uint64_t)max_dist) { ++st; x_st = a[st].x; }      // a[st].x in a register: a trip to HBM per anchor otherwise
+        // (the x of a[xw_base + lane] waits in a register: the window's tail moves by about one anchor a step, and a load per move would be a
+        // trip to memory per anchor - the step's longest wait; this way there is one per 64 moves)
+        if (st < seg0) st = seg0;
+        while (st < i) {
+            if (st < xw_base || st >= xw_base + 64) { xw_base = st; xw = a[st + lane < n ? st + lane : n - 1].x; }
+            const int32_t j = xw_base + lane;
+            const uint64_t stay = __ballot(j >= st && !(j < i && xi > xw + (uint64_t)max_dist));      // a[] is sorted: the anchors that leave are a prefix
+            const int32_t first = stay ? (int32_t)__ffsll((unsigned long long)stay) - 1 : 64;
+            st = xw_base + first;
+            if (first < 64) break;
+        }
         if (TREE && st_tree < st) {
             if (lane == 0) for (int32_t j = st_tree; j < st && j < i0; ++j) { const int32_t e = rq_erase(T0, (int32_t)a[j].y, j); if (e != RQ_NIL) rq_free(T0, e); }
             st_tree = st;
@@ -390,22 +425,20 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
             }
         }
         d_nin += (unsigned long long)n_in;
+        LRQ_T(1);
         int32_t max_f = q_span_i, max_j = -1;
         // (1) range minimum of the priority over the active anchors [st, i0) with (y_j, j) in [(q_i - max_dist, INT32_MAX), (q_i, 0)].
         // Newest first in blocks of 64: the blocks inside the ring out of LDS; everything older only if its smallest priority (pml, whatever
         // the y) is not above the best found so far - then block by block, skipping those whose own minimum (bmin) is above it.
         double bp = 0.0; int32_t bj = -1, ties = 0;
         {
-            auto reduce = [&](bool in, double pj, int32_t j) {
+            auto reduce = [&](bool in, double pj, int32_t j) {      // j = a block's base + lane at every call: among equals the lowest lane has the smallest index
                 const uint64_t im = __ballot(in);
                 if (im == 0) return;
-                double wm = pj; int32_t wj = in ? j : -1;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const double om = __shfl_xor(wm, o); const int32_t oj = __shfl_xor(wj, o);
-                    if (oj >= 0 && (wj < 0 || om < wm || (om == wm && oj < wj))) { wm = om; wj = oj; }
-                }
-                const int32_t c = (int32_t)__popcll(__ballot(in && pj == wm));
+                const double wm = lr_wave_min_f64(in ? pj : __longlong_as_double(0x7ff0000000000000ll));
+                const uint64_t em = __ballot(in && pj == wm);
+                const int32_t wj = __builtin_amdgcn_readlane(j, (int)(__ffsll((unsigned long long)em) - 1));
+                const int32_t c = (int32_t)__popcll(em);
                 if (bj < 0 || wm < bp) { bp = wm; bj = wj; ties = c; }
                 else if (wm == bp) { ties += c; bj = wj < bj ? wj : bj; }
             };
@@ -446,23 +479,34 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                     bool todo = b >= b_lo;
                     const double v = todo ? lr_cc_f64(bmin + b) : 0.0;
                     for (;;) {
-                        const uint64_t m = __ballot(todo && (bj < 0 || v <= bp));
+                        uint64_t m = __ballot(todo && (bj < 0 || v <= bp));
                         if (m == 0) break;
-                        const int l = __ffsll((unsigned long long)m) - 1;      // lane l holds the newest such block
-                        const int32_t bb = bt - l, j = bb * 64 + lane;
-                        bool in = false; double pj = 0.0;
-                        if (j >= st) {
-                            const int32_t yj = (int32_t)a[j].y;
-                            in = yj > qi - max_dist && (yj < qi || (yj == qi && j == 0));
-                            if (in) pj = lr_cc_f64(pri + j);
+                        // up to four such blocks a trip, newest first: their loads leave together (one memory latency instead of eight - a block
+                        // evaluated although an earlier one of the trip would have ruled it out only adds candidates of the window to the minimum)
+                        int32_t jv[4]; int32_t yv[4]; double pv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            jv[q] = -1; yv[q] = 0; pv[q] = 0.0;
+                            if (m) {
+                                const int l = __ffsll((unsigned long long)m) - 1; m &= m - 1;
+                                if (lane == l) todo = false;
+                                const int32_t j = (bt - l) * 64 + lane;
+                                jv[q] = j;
+                                if (j >= st) { yv[q] = (int32_t)a[j].y; pv[q] = lr_cc_f64(pri + j); }
+                            }
                         }
-                        reduce(in, pj, j);
-                        ++d_old;
-                        if (lane == l) todo = false;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (jv[q] < 0) continue;      // (uniform: jv is -1 on every lane or on none)
+                            const bool in = jv[q] >= st && yv[q] > qi - max_dist && (yv[q] < qi || (yv[q] == qi && jv[q] == 0));
+                            reduce(in, pv[q], jv[q]);
+                            ++d_old;
+                        }
                     }
                 }
             }
         }
+        LRQ_T(2);
         bool tie_pending = false; int32_t tie_sc = 0;
         if (TREE && bj >= 0 && ties > 1) {
             int32_t tj = -1;
@@ -517,6 +561,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
             else if (n_acc == n_tied && sc_lo == sc_hi && n_ex == 0) { tie_pending = true; tie_sc = sc_lo; }      // (b), if the inner scan improves on it
             else ++tie_cnt;
         }
+        LRQ_T(3);
         if (bj >= 0) {
             int32_t exact, width, n_skip = 0;
             int32_t fb, dr, dq, span_b;
@@ -579,6 +624,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 }
             }
         }
+        LRQ_T(4);
         if (tie_pending && max_f <= tie_sc) ++tie_cnt;      // no better predecessor turned up: max_j is the tree's choice among the tied
         if (lane == 0) { L.rx[i & M] = (uint32_t)xi; L.ry[i & M] = qi; L.rf[i & M] = max_f; L.rp[i & M] = max_j; }
         hi_prev = (uint32_t)(xi >> 32);
@@ -589,6 +635,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
     if (TREE && al_b0(T0.bad)) ok = false;
     n_tie = tie_cnt;
     if (ok) for (int32_t j = blk_done * 64 + lane; j < n; j += 64) { f[j] = L.rf[j & M]; p[j] = L.rp[j & M]; }      // the last, incomplete block(s)
+    if (dbg) for (int k2 = 0; k2 < 5; ++k2) dbg->t[4 + k2] += pt[k2];
     if (dbg) { dbg->d[0] += (unsigned long long)n; dbg->d[1] += d_ring; dbg->d[2] += d_oldsteps; dbg->d[3] += d_old; dbg->d[4] += d_nin; dbg->d[5] += d_chunks; dbg->d[6] += 1; if ((unsigned long long)n > dbg->d[7]) dbg->d[7] = (unsigned long long)n; }
     return ok;
 }
