@@ -16,6 +16,7 @@
 // there is no contraction dimension to feed a matrix core.
 #pragma once
 #include "sh_common.h"
+#include "sh_wave.h"
 
 #define KSW_NEG_INF (-0x40000000)
 #define EZ_RIGHT 0x02
@@ -529,8 +530,7 @@ __device__ inline void ksw_extd2_core(int32_t qlen, const uint8_t *query, bool q
                 }
             }
             if (lane == 0) H[en0] = h_last;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const long long other = __shfl_xor(best, o); best = other > best ? other : best; }
+            best = wave_all_max_i64(best);
             max_H = (int32_t)(best >> 32);
             const uint32_t lo = (uint32_t)best;
             max_t = lo == 0x7fffffffu ? en0 : (int32_t)(0x3ffffffu - (lo & 0x3ffffffu));

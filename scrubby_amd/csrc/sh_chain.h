@@ -13,6 +13,7 @@
 // of an HBM arena.
 #pragma once
 #include "sh_common.h"
+#include "sh_wave.h"
 #include "sh_align.h"
 
 // Chain hand-over to the extension stage (sh_align.h): every backtrack below takes an emitter that is called once per ACCEPTED
@@ -83,20 +84,13 @@ __device__ inline bool middle_no_zdrop_wave(const BaseCtx &B, const uint8_t *seq
             const uint32_t ct = (B.ref[g >> 1] >> ((g & 1) * 4)) & 15u;
             sc = (cq > 3 || ct > 3) ? P.ext_amb : (cq == ct ? P.ext_a : P.ext_b);
         }
-        int32_t ps = sc;                                  // inclusive prefix sum over the lanes
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int32_t t = __shfl_up(ps, o); if ((int)lane >= o) ps += t; }
-        ps += carry_s;
-        int32_t pm = on ? ps : INT32_MIN;                 // inclusive prefix maximum, seeded with the chunks before
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int32_t t = __shfl_up(pm, o); if ((int)lane >= o) pm = t > pm ? t : pm; }
+        int32_t ps = wave_scan_add_incl(sc) + carry_s;    // inclusive prefix sum over the lanes
+        int32_t pm = wave_scan_max_incl(on ? ps : INT32_MIN);      // inclusive prefix maximum, seeded with the chunks before
         pm = pm > carry_mx ? pm : carry_mx;
-        int32_t d = on ? pm - ps : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const int32_t t = __shfl_xor(d, o); d = t > d ? t : d; }
+        const int32_t d = wave_all_max(on ? pm - ps : 0);
         zd = d > zd ? d : zd;
         const int32_t last = (m.qe - m.qs - j0) < 64 ? (m.qe - m.qs - j0) - 1 : 63;
-        carry_s = __shfl(ps, last); carry_mx = __shfl(pm, last);
+        carry_s = wave_bcast(ps, last); carry_mx = wave_bcast(pm, last);
     }
     return zd <= P.ext_zdrop;
 }
@@ -112,10 +106,10 @@ __device__ inline bool resolve_mid_wave(bool need, const MidReq &req, const uint
         const int l = __ffsll((unsigned long long)todo) - 1;
         todo &= todo - 1;
         MidReq m;
-        m.rid = __shfl(req.rid, l); m.rev = __shfl(req.rev, l); m.qs = __shfl(req.qs, l); m.qe = __shfl(req.qe, l); m.rs = __shfl(req.rs, l);
+        m.rid = wave_bcast(req.rid, l); m.rev = wave_bcast(req.rev, l); m.qs = wave_bcast(req.qs, l); m.qe = wave_bcast(req.qe, l); m.rs = wave_bcast(req.rs, l);
         const uint64_t sp = (uint64_t)(uintptr_t)seq;
-        const uint64_t p = (uint64_t)(uint32_t)__shfl((int)(uint32_t)sp, l) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(sp >> 32), l) << 32;
-        const bool ok = middle_no_zdrop_wave(B, (const uint8_t *)(uintptr_t)p, __shfl(qlen, l), m, P);
+        const uint64_t p = wave_bcast_u64(sp, l);
+        const bool ok = middle_no_zdrop_wave(B, (const uint8_t *)(uintptr_t)p, wave_bcast(qlen, l), m, P);
         if ((int)lane == l) res = ok;
     }
     return res;
@@ -706,11 +700,12 @@ __device__ inline bool par_fill_tiled(const uint64_t *x, const uint32_t *q, int3
                         if (!stop && jmin == 0 && t0 > h && !(T.q[0] >> 31)) bad = true;
                     }
                 }
-                for (uint32_t o = 1; o < G; o <<= 1) {      // uniform: G is
-                    const int32_t of = __shfl_xor(max_f, (int)o), oj = __shfl_xor(max_j, (int)o);
-                    nv += __shfl_xor(nv, (int)o);
-                    bad |= __shfl_xor((int)bad, (int)o) != 0;
-                    if (of > max_f || (of == max_f && oj > max_j)) { max_f = of; max_j = oj; }
+                if (G == 8u) {      // uniform: G is.  The eight lanes of an anchor combine over DPP (neighbour, other pair, other quad)
+#define PF_COMBINE(CTRL) { const int32_t of = dpp_mov<CTRL, 0xf>(max_f, max_f), oj = dpp_mov<CTRL, 0xf>(max_j, max_j); \
+                           nv += dpp_mov<CTRL, 0xf>(nv, nv); int32_t bi = (int32_t)bad; bi |= dpp_mov<CTRL, 0xf>(bi, bi); bad = bi != 0; \
+                           if (of > max_f || (of == max_f && oj > max_j)) { max_f = of; max_j = oj; } }
+                    PF_COMBINE(0xB1) PF_COMBINE(0x4E) PF_COMBINE(0x141)
+#undef PF_COMBINE
                 }
                 if (on && sub == 0) {
                     T.f[k] = max_f; T.p[kt] = (uint16_t)(max_j < 0 ? 0 : (int32_t)k - max_j);
@@ -904,24 +899,6 @@ __device__ inline uint32_t prefix_popc64(uint64_t mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// ---- wave scans on the DPP network (gfx9: row_shr within rows of 16, row_bcast:15 / :31 across rows, wave_shr:1) ----
-template <int CTRL, int ROWS>
-__device__ inline int32_t dpp_mov(int32_t old, int32_t v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROWS, 0xf, false); }
-
-__device__ inline int32_t wave_scan_max_incl(int32_t v)
-{
-    int32_t t;
-    t = dpp_mov<0x111, 0xf>(INT32_MIN, v); v = t > v ? t : v;
-    t = dpp_mov<0x112, 0xf>(INT32_MIN, v); v = t > v ? t : v;
-    t = dpp_mov<0x114, 0xf>(INT32_MIN, v); v = t > v ? t : v;
-    t = dpp_mov<0x118, 0xf>(INT32_MIN, v); v = t > v ? t : v;
-    t = dpp_mov<0x142, 0xa>(INT32_MIN, v); v = t > v ? t : v;
-    t = dpp_mov<0x143, 0xc>(INT32_MIN, v); v = t > v ? t : v;
-    return v;
-}
-// lane l receives lane l-1's value, lane 0 receives `fill`
-__device__ inline int32_t wave_shr1(int32_t v, int32_t fill) { return dpp_mov<0x138, 0xf>(fill, v); }
-
 // inclusive prefix composition (lane order) of the functions x -> max(x + a, b)
 #define SH_COMP_STEP(CTRL, ROWS) { const int32_t pa = dpp_mov<CTRL, ROWS>(0, a), pb = dpp_mov<CTRL, ROWS>(-(1 << 29), b); \
                                    const int32_t nb = pb + a > b ? pb + a : b; a = pa + a; b = nb; }
@@ -929,18 +906,6 @@ __device__ inline void wave_scan_compose(int32_t &a, int32_t &b)
 {
     SH_COMP_STEP(0x111, 0xf) SH_COMP_STEP(0x112, 0xf) SH_COMP_STEP(0x114, 0xf) SH_COMP_STEP(0x118, 0xf)
     SH_COMP_STEP(0x142, 0xa) SH_COMP_STEP(0x143, 0xc)
-}
-
-__device__ inline int32_t wave_scan_min_incl(int32_t v)
-{
-    int32_t t;
-    t = dpp_mov<0x111, 0xf>(INT32_MAX, v); v = t < v ? t : v;
-    t = dpp_mov<0x112, 0xf>(INT32_MAX, v); v = t < v ? t : v;
-    t = dpp_mov<0x114, 0xf>(INT32_MAX, v); v = t < v ? t : v;
-    t = dpp_mov<0x118, 0xf>(INT32_MAX, v); v = t < v ? t : v;
-    t = dpp_mov<0x142, 0xa>(INT32_MAX, v); v = t < v ? t : v;
-    t = dpp_mov<0x143, 0xc>(INT32_MAX, v); v = t < v ? t : v;
-    return v;
 }
 
 // ---- wave-cooperative DP: all 64 lanes work on ONE cluster ---------------------------------------------------------
@@ -1020,9 +985,7 @@ __device__ inline bool chain_dp_wave(const SliceStore &S, int n, int32_t qlen, c
             for (int jb = i - 1; jb >= st; jb -= 64) {
                 const int j = jb - (int)lane;
                 int32_t fj = j >= st ? f[j] : INT32_MIN;
-                int32_t cm = fj;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { int32_t t = __shfl_xor(cm, o); cm = t > cm ? t : cm; }
+                const int32_t cm = wave_all_max(fj);
                 if (cm > bf) { bf = cm; bj = jb - (__ffsll((unsigned long long)__ballot(j >= st && fj == cm)) - 1); }
             }
             max_ii = bj;
@@ -1170,9 +1133,7 @@ __device__ inline bool chain_dp_ring(const uint64_t *gx, const uint32_t *gq, int
                     if (!synced) { wave_mem_sync(); synced = true; }
                     if (j >= st) fj = ld_agent(gf + j);
                 }
-                int32_t cm = fj;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { int32_t t = __shfl_xor(cm, o); cm = t > cm ? t : cm; }
+                const int32_t cm = wave_all_max(fj);
                 if (cm > bf) { bf = cm; bj = jb - (__ffsll((unsigned long long)__ballot(j >= st && fj == cm)) - 1); }
             }
             max_ii = bj;
@@ -1215,8 +1176,7 @@ __device__ inline int first_chain_quick(const int32_t *gf, const int32_t *gpt, i
         const int32_t f = vf[i];
         if (f >= P.min_sc) { const long long kk = (long long)f << 32 | (uint32_t)i; key = kk > key ? kk : key; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const long long t = __shfl_xor(key, o); key = t > key ? t : key; }
+    key = wave_all_max_i64(key);
     if (key < 0) return 0;
     const int32_t zf = (int32_t)(key >> 32);
     int i = (int)(key & 0xffffffff), steps = 0, cnt = 0;
@@ -1253,8 +1213,7 @@ __device__ inline void backtrack_wave_top(SliceStore &S, int32_t n, const ChainP
             const long long kk = (long long)f << 32 | (uint32_t)i;
             if (kk < bound && kk > key) key = kk;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const long long t = __shfl_xor(key, o); key = t > key ? t : key; }
+        key = wave_all_max_i64(key);
         if (key < 0) break;
         bound = key;
         const int32_t zf = (int32_t)(key >> 32), zi = (int32_t)(key & 0xffffffff);
@@ -1287,8 +1246,7 @@ __device__ inline bool backtrack_block_top(SliceStore &S, int32_t n, const Chain
         const long long kk = (long long)f << 32 | (uint32_t)i;
         if (kk > key) key = kk;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const long long t = __shfl_xor(key, o); key = t > key ? t : key; }
+    key = wave_all_max_i64(key);
     if (lane == 0) s_red[wave] = key;
     if (tid == 0) *cand_n = 0;
     __syncthreads();
@@ -1326,8 +1284,7 @@ __device__ inline bool backtrack_block_top(SliceStore &S, int32_t n, const Chain
         for (;;) {
             long long k2 = -1;
             if ((int32_t)lane < nc) { const long long kk = (long long)cand_f[lane] << 32 | cand_i[lane]; if (kk < bound) k2 = kk; }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const long long t = __shfl_xor(k2, o); k2 = t > k2 ? t : k2; }
+            k2 = wave_all_max_i64(k2);
             if (k2 < 0) break;
             bound = k2;
             const int32_t f2 = (int32_t)(k2 >> 32), i2 = (int32_t)(k2 & 0xffffffff);
@@ -1388,17 +1345,15 @@ __device__ inline void chain_cluster_wave(SliceStore &S, int32_t n, int32_t qlen
             const int32_t dmax = mdx < mdy ? mdx : mdy;
             const bool in = (int32_t)lane < n;
             const uint32_t lo = in ? S.rlo((int32_t)lane) : 0u, qv = in ? S.qp((int32_t)lane) : 0u;
-            const uint32_t dg = lo - qv, dg0 = (uint32_t)__shfl((int)dg, 0);
-            const int32_t dq = (int32_t)qv - (int32_t)(uint32_t)__shfl_up((int)qv, 1);
+            const uint32_t dg = lo - qv, dg0 = (uint32_t)__builtin_amdgcn_readlane((int)dg, 0);
+            const int32_t dq = (int32_t)qv - wave_shr1((int32_t)qv, 0);
             const bool good = !in || (dg == dg0 && (lane == 0 || (dq > 0 && dq <= dmax)));
             if (__ballot(!good) == 0) {
                 int32_t v = !in ? 0 : (lane == 0 ? P.k : (dq < P.k ? dq : P.k));
-                int32_t fl = v;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const int32_t t = __shfl_up(fl, o); if ((int)lane >= o) fl += t; }
+                const int32_t fl = wave_scan_add_incl(v);
                 if (in) { S.setFP((int32_t)lane, fl, (int32_t)lane - 1); S.setT((int32_t)lane, 0); }
                 wave_mem_sync();
-                const int32_t sc = __shfl(fl, n - 1);
+                const int32_t sc = wave_bcast(fl, n - 1);
                 n_u = 0; best = 0;
                 if (sc >= P.min_sc && n >= P.min_cnt) { n_u = 1; best = sc; em((int64_t)(n - 1), (int64_t)-1, sc, (int64_t)n, sc); }
                 wave_mem_sync();

@@ -41,6 +41,7 @@
 //
 // Results are bit-identical to oracle/mm_oracle.c (tests/test_parity_gpu.py).
 #include "sh_common.h"
+#include "sh_wave.h"
 #include "sh_sketch.h"
 #include "sh_chain.h"
 #include "sh_long.h"
@@ -135,7 +136,7 @@ __device__ inline uint32_t wave_append(uint32_t *counter, bool pred)
     uint32_t base = 0;
     uint32_t leader = __ffsll((unsigned long long)mask) - 1;
     if (lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader);
+    base = (uint32_t)wave_bcast((int32_t)base, (int)leader);
     return pred ? base + prefix_popc(mask) : ~0u;
 }
 
@@ -260,8 +261,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     st.init(a.k);
     const uint32_t b0 = (uint32_t)((base_addr + o_beg) - a0);    // tile-relative index of this read's first base
     uint32_t maxlen = len;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, o));
+    maxlen = wave_all_max_u32(maxlen);
 
     // The minimizer queue is a ring of K1_LIST_CAP entries per lane in LDS: [qh, qt), of which the first `pend` have their
     // home-slot gathers in flight (sl[]).  Every W-step block starts by issuing up to 4 gathers per lane for what earlier blocks
@@ -385,9 +385,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     wi = wave_append(&a.ctr->n_resketch, to_k3);
     if (to_k3) a.work_resketch[wi] = (uint32_t)r;
     // statistics (sharded)
-    uint32_t msum = n_mini;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) msum += (uint32_t)__shfl_xor((int)msum, o);
+    const uint32_t msum = (uint32_t)wave_all_add((int32_t)n_mini);
     if (lane == 0) atomicAdd(&a.ctr->sh_mini[SHARD()], (unsigned long long)msum);
 }
 
@@ -395,16 +393,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 __device__ inline uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ inline uint32_t wave_sum_u32(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
-    return v;
+    return (uint32_t)wave_all_add((int32_t)v);
 }
 __device__ inline uint32_t wave_excl_scan_u32(uint32_t v, uint32_t lane)
 {
-    uint32_t s = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)s, o); if (lane >= (uint32_t)o) s += t; }
-    return s - v;
+    return (uint32_t)wave_scan_add_incl((int32_t)v) - v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -525,9 +518,7 @@ __global__ __launch_bounds__(1024) void k_long_scan(LongArgs a, int mode)
         for (uint32_t base = 0; base < n_blocks; base += 1024) {
             const uint32_t i = base + tid;
             const unsigned long long v = i < n_blocks ? a.scan_tot[i] : 0ull;
-            unsigned long long inc = v;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = (unsigned long long)__shfl_up((long long)inc, o); if ((int)lane >= o) inc += t; }
+            unsigned long long inc = wave_scan_add_incl_u64(v);
             if (lane == 63) s_wave[wv] = inc;
             __syncthreads();
             unsigned long long pre = run;
@@ -589,8 +580,7 @@ __global__ __launch_bounds__(64) void k_long_probe(LongArgs a)
             __syncthreads();
             uint32_t mx = 0;
             for (uint32_t i = lane; i < 4096; i += 64) mx = s_cnt[i] > mx ? s_cnt[i] : mx;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { uint32_t v = (uint32_t)__shfl_xor((int)mx, o); mx = v > mx ? v : mx; }
+            mx = wave_all_max_u32(mx);
             if (mx > (uint32_t)a.mid_occ) {
                 for (uint32_t i = lane; i < LT_CAP; i += 64) { s_tkey[i] = ~0ull; s_tcnt[i] = 0; }
                 if (lane == 0) s_tover = 0;
@@ -947,8 +937,7 @@ __global__ __launch_bounds__(64) void k_pair_pass(K2Args a, int distinct)
         }
         if (distinct == 1 && __ballot(found) != 0) {
             uint32_t mx = found ? n_seed : 0u;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+            mx = wave_all_max_u32(mx);
             bool dup = false;
             for (uint32_t i = 1; i < mx; ++i) {
                 const uint32_t ki = s_key[i * 64 + lane];
@@ -967,8 +956,7 @@ __global__ __launch_bounds__(64) void k_pair_pass(K2Args a, int distinct)
         if (undecided) a.leftover[li] = r;
     }
     if (lane == 0 && n_host_wave) { atomicAdd(&a.ctr->sh_host[SHARD()], n_host_wave); atomicAdd(&a.ctr->sh_pair[SHARD()], n_host_wave); }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) anchors_wave += (unsigned long long)__shfl_xor((long long)anchors_wave, o);
+    anchors_wave = wave_all_add_u64(anchors_wave);
     if (lane == 0 && anchors_wave) atomicAdd(&a.ctr->sh_anchors[SHARD()], anchors_wave);
 }
 
@@ -1035,12 +1023,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             uint64_t xs = 0; uint32_t qs_ = 0;
             if (single) make_anchor((uint64_t)rec0.y << 32 | rec0.x, rec0.w, qlen, P.k, xs, qs_);
             const int fl = sm ? __ffsll((unsigned long long)sm) - 1 : 0;
-            const uint32_t hiw = (uint32_t)__shfl((int)(uint32_t)(xs >> 32), fl);
+            const uint32_t hiw = (uint32_t)wave_bcast((int32_t)(uint32_t)(xs >> 32), fl);
             // singletons elsewhere (another contig / strand) count as seeds with occurrences outside K
             const bool s_in = single && (uint32_t)(xs >> 32) == hiw;
             uint32_t lo = s_in ? (uint32_t)xs : 0xffffffffu, hi = s_in ? (uint32_t)xs : 0u;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o)); }
+            lo = wave_all_min_u32(lo); hi = wave_all_max_u32(hi);
             const uint32_t mdx = chain_max_dist_x(P, qlen);
             ok = ok && hi - lo <= 4u * mdx;                       // singletons of one locus; far-apart ones on one contig: full path
             const uint32_t rel = hiw >> 31;                      // strand relation of K's anchors
@@ -1091,8 +1078,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                             }
                         }
                     }
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) { nlo = min(nlo, (uint32_t)__shfl_xor((int)nlo, o)); nhi = max(nhi, (uint32_t)__shfl_xor((int)nhi, o)); }
+                    nlo = wave_all_min_u32(nlo); nhi = wave_all_max_u32(nhi);
                     if (__ballot(c_l > 16u) != 0) { ok = false; break; }
                     if (nlo == lo && nhi == hi) break;
                     if (round == 3) { ok = false; break; }
@@ -1119,12 +1105,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 __syncthreads();
                 uint64_t x = lane < n_k ? e_x[lane] : ~0ull;
                 uint32_t q = lane < n_k ? e_q[lane] : 0u;
-                const uint64_t xp = (uint64_t)__shfl_up((long long)x, 1);
+                const uint64_t xp = wave_shr1_u64(x, 0ull);
                 if (__ballot(lane > 0 && lane < n_k && x < xp) != 0) wave_rank_sort(x, q, n_k, lane);
                 __syncthreads();
                 if (lane < n_k) { e_x[lane] = x; e_q[lane] = q; }
                 // clusters: lane i owns the cluster that starts at anchor i
-                const uint64_t xq = (uint64_t)__shfl_up((long long)x, 1);
+                const uint64_t xq = wave_shr1_u64(x, 0ull);
                 const bool start = lane < n_k && (lane == 0 || (uint32_t)(x >> 32) != (uint32_t)(xq >> 32) || (uint32_t)x - (uint32_t)xq > mdx);
                 const uint64_t stm = __ballot(start);
                 const uint64_t above = lane >= 63 ? 0ull : stm & ~((2ULL << lane) - 1);
@@ -1149,8 +1135,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     if (mdy < P.bw) mdy = P.bw;
                     const int32_t dmax = (int32_t)mdx < mdy ? (int32_t)mdx : mdy;
                     const bool in = lane < n_k;
-                    const uint32_t dg = (uint32_t)x - q, dg0 = (uint32_t)__shfl((int)dg, 0);
-                    const uint32_t qpv = (uint32_t)__shfl_up((int)q, 1);
+                    const uint32_t dg = (uint32_t)x - q, dg0 = (uint32_t)__builtin_amdgcn_readlane((int)dg, 0);
+                    const uint32_t qpv = (uint32_t)wave_shr1((int32_t)q, 0);
                     const int32_t dq = (int32_t)q - (int32_t)qpv;
                     const bool good = !in || (dg == dg0 && (lane == 0 || (dq > 0 && dq <= dmax)));
                     fast = P.ext_s1 != 0 && __popcll(stm) == 1 && (int32_t)n_k >= P.min_cnt && __ballot(!good) == 0;
@@ -1158,8 +1144,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                         const bool link = in && lane > 0;
                         const int32_t covered = P.k + (int32_t)wave_sum_u32(link ? (uint32_t)(dq < P.k ? dq : P.k) : 0u);
                         const int32_t unc = (int32_t)wave_sum_u32(link && dq > P.k ? (uint32_t)(dq - P.k) : 0u);
-                        const uint32_t q_first = (uint32_t)__shfl((int)q, 0), q_last = (uint32_t)__shfl((int)q, (int)n_k - 1);
-                        const uint32_t lo_first = (uint32_t)__shfl((int)(uint32_t)x, 0), hi_w = (uint32_t)__shfl((int)(uint32_t)(x >> 32), 0);
+                        const uint32_t q_first = (uint32_t)__builtin_amdgcn_readlane((int)q, 0), q_last = (uint32_t)wave_bcast((int32_t)q, (int)n_k - 1);
+                        const uint32_t lo_first = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 0), hi_w = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), 0);
                         if (covered > u_out && (int32_t)(q_last - q_first) >= P.k && covered >= P.min_sc) {
                             if (unc <= P.ext_unc_max) code = 1;
                             else {
@@ -1177,7 +1163,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 while (todo) {
                     const uint32_t cb = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
                     todo &= todo - 1;
-                    const int32_t cl = __shfl((int)clen, (int)cb);
+                    const int32_t cl = wave_bcast((int32_t)clen, (int)cb);
                     SliceStore S{(const uint64_t *)&e_x[cb], (const uint32_t *)&e_q[cb], e_f + cb, e_pt + 2 * (size_t)cb};
                     int32_t n_u, best;
                     auto hif = [&](int32_t j) { return (uint32_t)(S.X(j) >> 32); };
@@ -1215,20 +1201,17 @@ __device__ inline bool cluster_cannot_reach(const uint64_t *__restrict__ x, cons
     const bool on = lane < len;
     const uint32_t lo = on ? (uint32_t)x[s + lane] : 0u, qv = on ? q[s + lane] & 0x7fffffffu : 0u;
     const int32_t dg = (int32_t)(lo - qv);
-    int32_t mn = on ? dg : INT32_MAX;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int32_t t = __shfl_xor(mn, o); mn = t < mn ? t : mn; }
+    const int32_t mn = wave_all_min(on ? dg : INT32_MAX);
     const uint32_t bin = on ? (uint32_t)(dg - mn) / (uint32_t)(P.bw + 1) : 0u;
     if (__ballot(on && bin >= 64u) != 0) return false;
     uint32_t ol = on && bin < 32u ? 1u << bin : 0u, oh = on && bin >= 32u ? 1u << (bin - 32u) : 0u;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { ol |= (uint32_t)__shfl_xor((int)ol, o); oh |= (uint32_t)__shfl_xor((int)oh, o); }
+    ol = wave_all_or(ol); oh = wave_all_or(oh);
     const uint64_t occ = (uint64_t)oh << 32 | ol, starts = occ & ~(occ << 1);
     const uint32_t comp = (uint32_t)__popcll(starts & (bin == 63u ? ~0ull : (2ull << bin) - 1ull));
     uint64_t key = on ? (uint64_t)comp << 32 | qv : ~0ull;
     uint32_t dummy = 0;
     wave_rank_sort(key, dummy, len, lane);
-    const uint64_t prev = (uint64_t)__shfl_up((long long)key, 1);
+    const uint64_t prev = wave_shr1_u64(key, 0ull);
     const uint32_t kc = (uint32_t)(key >> 32);
     const bool first = lane == 0 || kc != (uint32_t)(prev >> 32);
     int32_t c = !on ? 0 : (first ? P.k : min(P.k, (int32_t)((uint32_t)key - (uint32_t)prev)));
@@ -1238,9 +1221,7 @@ __device__ inline bool cluster_cannot_reach(const uint64_t *__restrict__ x, cons
         const uint32_t tk = (uint32_t)__shfl_up((int)kc, o);
         if ((int)lane >= o && tk == kc) c += t;
     }
-    int32_t mx = on ? c : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int32_t t = __shfl_xor(mx, o); mx = t > mx ? t : mx; }
+    const int32_t mx = wave_all_max(on ? c : 0);
     return mx < bs;
 }
 
@@ -1536,8 +1517,7 @@ __device__ inline bool pair_decides(const uint4 rec, uint32_t my_n, uint32_t n_s
     };
     sweep(P.pair_dq_max, true);
     uint32_t M = sel ? mult : 0u;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) M = max(M, (uint32_t)__shfl_xor((int)M, o));
+    M = wave_all_max_u32(M);
     if (M > 1) {
         const int32_t dmax = min((int32_t)(((uint32_t)P.max_skip + 1u) / M) - 1, P.pair_dq_max);
         if (dmax < P.pair_dq_min) { if (dbg_cost0 && lane == 0) atomicAdd(dbg_cost0 - 3, 1u); return false; }       // dbg: n_leg_reason[0] = keys repeat too often
@@ -1551,8 +1531,7 @@ __device__ inline bool pair_decides(const uint4 rec, uint32_t my_n, uint32_t n_s
     }
   for (int attempt = 0; attempt < PAIR_ATTEMPTS; ++attempt) {      // the cheapest pair first; a pair that finds nothing retires its earlier seed
     unsigned long long key = (unsigned long long)cost << 32 | lane;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = (unsigned long long)__shfl_xor((long long)key, o); key = other < key ? other : key; }
+    key = wave_all_min_u64(key);
     if ((uint32_t)(key >> 32) > PAIR_MAX_COST) { if (dbg_cost0 && lane == 0 && attempt == 0) atomicAdd(dbg_cost0 - 2, 1u); break; }   // dbg: [1] = no pair in range / too costly
     if (dbg_cost0 && (uint32_t)(key >> 32) == 0 && lane == 0 && attempt == 0) atomicAdd(dbg_cost0, 1u);
     const uint32_t lf = (uint32_t)key & 63u, lg = rdlane(p_u, lf);          // F: earlier in the query, G: later
@@ -1747,8 +1726,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (fm) carry_en = (int32_t)(rdlane(rec.w, 63 - __clzll((unsigned long long)fm)) >> 1) + 1;
         }
         const int32_t rep_len = (int32_t)wave_sum_u32((uint32_t)contrib);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) n_part += (unsigned long long)__shfl_xor((long long)n_part, o);
+        n_part = wave_all_add_u64(n_part);
         // the count can exceed 31 bits only for absurd inputs; saturate (such a read never gets arena space)
         const uint32_t n_a = n_part > 0x7fffffffull ? 0x7fffffffu : (uint32_t)n_part;
 
@@ -1841,7 +1819,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (in_lds) {
             uint64_t x = lane < n_a ? e_x[lane] : ~0ull;
             uint32_t q = lane < n_a ? e_q[lane] : 0u;
-            uint64_t xp = (uint64_t)__shfl_up((long long)x, 1);
+            uint64_t xp = wave_shr1_u64(x, 0ull);
             if (__ballot(lane > 0 && lane < n_a && x < xp) != 0) {
                 wave_rank_sort(x, q, n_a, lane);
                 __syncthreads();
@@ -1857,8 +1835,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 chain_sorted<false>(e_x, e_q, e_f, e_pt, n_a, lane, 64, qlen, P, nullptr, BigList{e_bstart, e_blen, &e_bcount, 8}, n_u, best, n_clusters,
                                     nullptr, nullptr, nullptr, r, nullptr, &bc, region_hash(qlen), -1, TandemQ{recb, n_seed, 1u, qlen, LONG ? 1u : info >> 31});
                 unsigned long long zmax = bc.n ? bc.z : 0ull;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = (unsigned long long)__shfl_xor((long long)zmax, o); zmax = other > zmax ? other : zmax; }
+                zmax = wave_all_max_u64(zmax);
                 const uint64_t holders = __ballot(bc.n > 0 && bc.z == zmax);
                 const uint64_t any = __ballot(bc.n > 0);
                 bool ok = false;
@@ -1880,8 +1857,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (!lemma_done)
             chain_sorted<false>(e_x, e_q, e_f, e_pt, n_a, lane, 64, qlen, P, nullptr, BigList{e_bstart, e_blen, &e_bcount, 8}, n_u, best, n_clusters,
                                 nullptr, nullptr, a.emit ? &sink_l : nullptr, r, nullptr);      // <= 64 anchors: no cluster needs a heap
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { n_u += __shfl_xor(n_u, o); int32_t b = __shfl_xor(best, o); best = b > best ? b : best; }
+            n_u = wave_all_add(n_u); best = wave_all_max(best);
             if (lane == 0) { a.B.acc_nu[w] = n_u; a.B.acc_best[w] = best; }
             if ((a.dbg & 16) && lane == 0) { atomicAdd(&a.ctr->sort_tot[N_SORT_CLS], 1ull); atomicAdd(&a.ctr->sort_anchor_tot[N_SORT_CLS], (unsigned long long)n_a); }
             __syncthreads();
@@ -1934,8 +1910,7 @@ __global__ __launch_bounds__(256) void k_lr_locus(K3Args a, int lc)
     auto slot = [&](uint64_t id) -> uint32_t { return (uint32_t)((id * 0x9E3779B97F4A7C15ull) >> (64 - LG)); };
     auto cnt_of = [&](uint64_t id) -> uint32_t { const uint32_t h = slot(id); return (s_tab[h >> 1] >> ((h & 1u) << 4)) & 0xffffu; };
     auto block_max = [&](uint32_t v, int k) -> uint32_t {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, o); v = t > v ? t : v; }
+        v = wave_all_max_u32(v);
         if (lane == 0) s_w[k][wave] = v;
         __syncthreads();
         return max(max(s_w[k][0], s_w[k][1]), max(s_w[k][2], s_w[k][3]));
@@ -2042,7 +2017,7 @@ __device__ inline bool block_merge_sort(PX sx, PQ sq, PX dx, PQ dq, uint32_t n)
         const uint32_t cnt = n - base < 64 ? n - base : 64;
         uint64_t x = lane < cnt ? sx[base + lane] : ~0ull;
         uint32_t q = lane < cnt ? sq[base + lane] : 0u;
-        uint64_t xp = (uint64_t)__shfl_up((long long)x, 1);
+        uint64_t xp = wave_shr1_u64(x, 0ull);
         if (__ballot(lane > 0 && lane < cnt && x < xp) != 0) {
             wave_rank_sort(x, q, cnt, lane);
             if (lane < cnt) { sx[base + lane] = x; sq[base + lane] = q; }
@@ -2433,8 +2408,7 @@ __global__ __launch_bounds__(1024) void k_giant_scan(K3Args a)
             if (i < n_items) a.B.tile_base[i] = run + ex;
             run += wave_sum_u32(t);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { uint32_t v = (uint32_t)__shfl_xor((int)max_n, o); max_n = v > max_n ? v : max_n; }
+        max_n = wave_all_max_u32(max_n);
         if (lane == 0) { a.B.tile_base[n_items] = run; a.ctr->n_giant_tiles = run; a.ctr->n_giant_rounds = giant_rounds(max_n); }
     }
     // largest first: a read of 500 k anchors drawn last would run on alone after every other block has finished.  Counting sort by

@@ -202,8 +202,7 @@ __device__ inline void lr_reg_set_coor_wave(LReg &r, int32_t qlen, const LAnchor
         bl += tl > ql ? tl : ql;
         ml += tl > span && ql > span ? span : tl < ql ? tl : ql;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { ml += __shfl_xor(ml, o); bl += __shfl_xor(bl, o); }
+    ml = wave_all_add(ml); bl = wave_all_add(bl);
     r.mlen = q_span + ml; r.blen = q_span + bl;
 }
 
@@ -1137,8 +1136,7 @@ __device__ __noinline__ int32_t lr_ksw_ll_wave(int32_t qlen, const uint8_t *quer
                 E[j] = e > tt ? e : tt;
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const int32_t ot = __shfl_xor(imax, o); imax = ot > imax ? ot : imax; }
+        imax = wave_all_max(imax);
         lr_sync();
         if (imax >= gmax) {
             gmax = imax; te = i;
@@ -1150,8 +1148,7 @@ __device__ __noinline__ int32_t lr_ksw_ll_wave(int32_t qlen, const uint8_t *quer
     {   // the last hit in striped memory order: memory index m <-> position m / 8 + m % 8 * slen
         int32_t best_m = -1;
         for (int32_t m = lane; m < qp; m += 64) { const int32_t pos = m / 8 + m % 8 * slen; if (Hmax[pos] == gmax) best_m = m; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const int32_t ot = __shfl_xor(best_m, o); best_m = ot > best_m ? ot : best_m; }
+        best_m = wave_all_max(best_m);
         if (best_m >= 0) qe = best_m / 8 + best_m % 8 * slen;
     }
     return gmax;
@@ -1757,8 +1754,7 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const Long
     {
         int32_t best = 0;
         for (int32_t i = lane; i < n_u; i += 64) { const int32_t s = (int32_t)(W.u[i] >> 32); best = s > best ? s : best; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const int32_t ot = __shfl_xor(best, o); best = ot > best ? ot : best; }
+        best = wave_all_max(best);
         out.best = best;
     }
 
