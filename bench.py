@@ -60,7 +60,7 @@ def parse():
                          "k2 = configs[4] stand-in: Kraken2-style taxid classification of 2x150 bp pairs against an 8 GB table (not the headline metric)")
     ap.add_argument("--k2-cells", type=int, default=2_000_000_000, help="cells of the compact hash table (4 B each)")
     ap.add_argument("--k2-nodes", type=int, default=50_000, help="taxonomy nodes of the synthetic database")
-    ap.add_argument("--ont-chunk", type=int, default=500_000, help="long reads per launch (--workload ont)")
+    ap.add_argument("--ont-chunk", type=int, default=1_000_000, help="long reads per launch (--workload ont): a launch pays the extension stage's longest single reads once, so fewer, larger launches are faster; 1 M reads (6.3 Gbases) is what a 288 GB device holds")
     ap.add_argument("--e2e-threads", type=int, default=0, help="-t of `scrubby reads` for --workload e2e (0: the usable cores - physical, capped by the cgroup quota)")
     ap.add_argument("--e2e-gz", action="store_true", help="--workload e2e: write .fastq.gz outputs")
     ap.add_argument("--e2e-legacy", action="store_true", help="--workload e2e: also time the collect-then-map host path")

@@ -3528,6 +3528,11 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
                 // find no room come back in the pass's next iteration
                 const uint64_t cb = std::min<uint64_t>({max_bases + 64, max_reads * (uint64_t)max_read_len + 64, max_reads * 8192ull + (64ull << 20)});
                 c->stage_cap = std::min<uint64_t>(cb + cb / 4 + (1ull << 20), (64ull << 30) / 12);
+                {   // last of the context's allocations: at most 45 % of what the device still has (a million-read context fits that way - its
+                    // launches pay the stage's longest reads once where two half-size ones pay them twice; what finds no room is deferred)
+                    size_t fr = 0, tot = 0;
+                    if (hipMemGetInfo(&fr, &tot) == hipSuccess) c->stage_cap = std::min<uint64_t>(c->stage_cap, std::max<uint64_t>(1ull << 20, (uint64_t)((double)fr * 0.45) / 12));
+                }
                 if (const char *env = getenv("SCRUBBY_HIP_STAGE_MB")) c->stage_cap = std::max<uint64_t>(1ull << 16, ((uint64_t)atoll(env) << 20) / 12);
                 if ((e = hipMalloc(&c->d_stage_x, c->stage_cap * 8)) != hipSuccess) return fail(e, "long-read anchor staging");
                 if ((e = hipMalloc(&c->d_stage_q, c->stage_cap * 4)) != hipSuccess) return fail(e, "long-read anchor staging");
