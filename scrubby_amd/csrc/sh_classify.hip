@@ -3483,8 +3483,8 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             zb.cap_a = 1u << 18; zb.cap_u = zb.cap_r = 1u << 16; zb.cap_m = 65536;
             if (const char *env = getenv("SCRUBBY_HIP_LEXT_BIG_P_KB")) zb.cap_p = (uint64_t)atoll(env) << 10;      // tests: alignments beyond the second size
             if (const char *env = getenv("SCRUBBY_HIP_LEXT_BIG_A")) { zb.cap_a = (uint32_t)std::max(1024, atoi(env)); zb.cap_u = zb.cap_r = std::max(64u, zb.cap_a / 4); }      // tests: reads beyond the second size
-            uint64_t budget[4] = {15ull << 30, 8ull << 30, 26ull << 30, 10ull << 30};
-            const uint64_t wave_max[4] = {256 * 8, 256, 256 * 8, 256};      // LDS: 19 KB per wave in both kernels
+            uint64_t budget[4] = {22ull << 30, 8ull << 30, 26ull << 30, 10ull << 30};
+            const uint64_t wave_max[4] = {256 * 12, 256, 256 * 8, 256};      // LDS: 13 KB per wave in the chains kernel (twelve to a CU), 19 KB in the regions kernel
             {   // no more than a third of what the device has left (several contexts, ranks sharing a device, smaller GPUs)
                 size_t mf = 0, mt = 0;
                 if (hipMemGetInfo(&mf, &mt) == hipSuccess && mf > 0) {
@@ -3501,6 +3501,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
                 c->lext_per_wave[i] = long_ws_carve(nullptr, nullptr, q);
                 if (i == 0) { int dev = 0, ncu = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) c->n_cu = ncu; }
                 c->lext_waves[i] = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({wave_max[i], budget[i] / c->lext_per_wave[i], t ? std::max<uint64_t>(4, max_reads / 16) : max_reads}));
+                if (getenv("SCRUBBY_HIP_DBG")) fprintf(stderr, "[dbg] long-read stage working memory %d: %u waves x %.2f MB\n", i, c->lext_waves[i], c->lext_per_wave[i] / 1048576.0);
                 if ((e = hipMalloc(&c->d_lext[i], (uint64_t)c->lext_waves[i] * c->lext_per_wave[i])) != hipSuccess) return fail(e, "long-read extension-stage scratch");
             }
             if ((e = hipMalloc(&c->d_lext_big, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
@@ -3972,10 +3973,10 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 xg.ticket = &c->d_ctr->lext_ticket_g; xg.part = 2;      // same ring as the others (19 KB of LDS: they share CUs); what outgrows the ring joins the big list
                 SH_HIP(hipEventRecord(c->evx[0], s));
                 SH_HIP(hipStreamWaitEvent(c->sx[0], c->evx[0], 0));
-                // Both kernels are persistent and hold 19 KB of LDS a wave - eight to a CU.  Launched with every slot taken, the main kernel kept the
+                // Both kernels are persistent and hold 13 KB of LDS a wave - twelve to a CU.  Launched with every slot taken, the main kernel kept the
                 // giants' waves waiting until it had ended (their second-long reads then ran alone: the stage's longest stretch); so the two
                 // grids together stay within the slots the device has.
-                const uint32_t slots = 8u * (uint32_t)c->n_cu;
+                const uint32_t slots = 12u * (uint32_t)c->n_cu;
                 const uint32_t g_waves = std::min<uint32_t>(c->lext_waves[1], 128u);
                 const uint32_t m_waves = c->lext_waves[0] + g_waves > slots && slots > 2 * g_waves ? std::min<uint32_t>(c->lext_waves[0], slots - g_waves) : c->lext_waves[0];
                 hipLaunchKernelGGL((k_long_chains<512, false>), dim3(g_waves), dim3(64), 0, c->sx[0], xg);

@@ -226,9 +226,8 @@ __device__ inline void lr_tick(LongClk *c, int ph) { if (c) { const unsigned lon
 #define LRQ_SAMEX(NR) ((NR) - 1 - (LRQ_RBLK(NR) + 1) * 64)      // ... with up to this many anchors waiting on one x
 template <int LRQ_INNER>
 struct RmqLdsT {
-    int32_t iy[LRQ_INNER], ij[LRQ_INNER];
-    uint32_t rx[LRQ_INNER]; int32_t ry[LRQ_INNER], rf[LRQ_INNER], rp[LRQ_INNER], rt[LRQ_INNER];
-    double rpri[LRQ_INNER];
+    int32_t ij[LRQ_INNER];      // the inner window's list: indices only - an entry's y is the ring's (ry); the priority is recomputed from rf, rx, ry
+    uint32_t rx[LRQ_INNER]; int32_t ry[LRQ_INNER], rf[LRQ_INNER], rp[LRQ_INNER], rt[LRQ_INNER];      // 24 B a slot: 13 KB at 512 slots, twelve waves to a CU (36 B: eight)
     double pml[64], bml[64];    // pml[b & 63] = smallest priority of the blocks 0 .. b, bml[b & 63] = of block b alone
 };
 
@@ -294,6 +293,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
     unsigned long long d_ring = 0, d_oldsteps = 0, d_old = 0, d_nin = 0, d_chunks = 0;
     const int32_t lane = (int32_t)al_lane();
     constexpr int32_t M = LRQ_INNER - 1;
+    auto rpri_of = [&](int32_t j) -> double { return -((double)L.rf[j & M] + 0.5 * (double)pen_gap * (double)((int32_t)L.rx[j & M] + L.ry[j & M])); };      // of a ring anchor whose f is final
     int32_t max_dist = max_dist_in, max_dist_inner = rmq_inner_dist;
     if (max_dist < bw) max_dist = bw;
     if (max_dist_inner < 0) max_dist_inner = 0;
@@ -303,8 +303,8 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
     __builtin_amdgcn_wave_barrier();
     int32_t blk_done = 0;      // blocks [0, blk_done) of 64 anchors are completely inserted; bmin[b] = their smallest priority
     int32_t i0 = 0, st = 0, st_inner = 0, n_in = 0, seg0 = 0, head = 0;      // the list is circular: entry e lives at (head + e) & M
-#define LIY(e) L.iy[(head + (e)) & M]
-#define LIJ(e) L.ij[(head + (e)) & M]      // inner window: the live entries (j >= st_inner) of L.iy/ij[0 .. n_in), ascending (y, j)
+#define LIJ(e) L.ij[(head + (e)) & M]
+#define LIY(e) L.ry[LIJ(e) & M]      // inner window: the live entries (j >= st_inner) of L.iy/ij[0 .. n_in), ascending (y, j)
     bool ok = true;
     uint32_t hi_prev = 0;
     LAnchor cur = a[0];
@@ -320,11 +320,6 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
         // add the anchors whose x is now strictly smaller
         if (i - i0 > LRQ_SAMEX(LRQ_INNER)) { ok = false; break; }      // more anchors on one reference position than the ring can hold back
         if (i0 < i && (seg0 == i || L.rx[i0 & M] != (uint32_t)xi)) {
-            for (int32_t jb = i0; jb < i; jb += 64) {
-                const int32_t j = jb + lane;
-                if (j < i) { const double pj = -((double)L.rf[j & M] + 0.5 * (double)pen_gap * (double)((int32_t)L.rx[j & M] + L.ry[j & M])); L.rpri[j & M] = pj; }
-            }
-            __builtin_amdgcn_wave_barrier();
             if (max_dist_inner > 0) {
                 for (int32_t j = i0; j < i; ++j) {      // insert (y_j, j) into the y-sorted inner window
                     if (n_in >= LRQ_INNER) { ok = false; break; }
@@ -340,14 +335,14 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                     }
                     for (int32_t c = ((n_in - pos + 63) / 64 - 1) * 64; c >= 0; c -= 64) {      // shift [pos, n_in) up by one, from the top
                         const int32_t e = pos + c + lane;
-                        int32_t vy = 0, vj = 0;
+                        int32_t vj = 0;
                         const bool on = e < n_in;
-                        if (on) { vy = LIY(e); vj = LIJ(e); }
+                        if (on) vj = LIJ(e);
                         __builtin_amdgcn_wave_barrier();
-                        if (on) { LIY(e + 1) = vy; LIJ(e + 1) = vj; }
+                        if (on) LIJ(e + 1) = vj;
                         __builtin_amdgcn_wave_barrier();
                     }
-                    if (lane == 0) { LIY(pos) = yj; LIJ(pos) = j; }
+                    if (lane == 0) LIJ(pos) = j;
                     __builtin_amdgcn_wave_barrier();
                     ++n_in;
                 }
@@ -357,20 +352,20 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 for (int32_t j = i0; j < i; ++j) {
                     const int32_t x = rq_alloc(T0);
                     if (x == RQ_NIL) { T0.bad = 11; break; }
-                    rq_node_set(T0, x, L.ry[j & M], j, L.rpri[j & M]);
+                    rq_node_set(T0, x, L.ry[j & M], j, rpri_of(j));
                     rq_insert(T0, x);
                 }
             }
             if (TREE && al_b0(T0.bad)) { ok = false; break; }      // the pool or a walk gave out: the caller takes the read to the one-lane version
             i0 = i;
             while ((blk_done + 1) * 64 <= i0) {      // blocks completed by this insertion (their anchors are all in the ring)
-                const double m = lr_wave_min_f64(L.rpri[(blk_done * 64 + lane) & M]);
+                const double m = lr_wave_min_f64(rpri_of(blk_done * 64 + lane));
                 const double pm = blk_done > 0 && L.pml[(blk_done - 1) & 63] < m ? L.pml[(blk_done - 1) & 63] : m;
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 0) { bmin[blk_done] = m; L.pml[blk_done & 63] = pm; L.bml[blk_done & 63] = m; }
                 {   // the block leaves for HBM in one piece (a store inside the loop would make every later wait of the step wait for it too)
                     const int32_t j = blk_done * 64 + lane;
-                    f[j] = L.rf[j & M]; p[j] = L.rp[j & M]; pri[j] = L.rpri[j & M];
+                    f[j] = L.rf[j & M]; p[j] = L.rp[j & M]; pri[j] = rpri_of(j);
                 }
                 __builtin_amdgcn_wave_barrier();
                 ++blk_done;
@@ -409,13 +404,13 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                     int32_t kept = 0;
                     for (int32_t c = 0; c < n_in; c += 64) {
                         const int32_t e = c + lane;
-                        int32_t vy = 0, vj = 0;
+                        int32_t vj = 0;
                         const bool on = e < n_in;
-                        if (on) { vy = LIY(e); vj = LIJ(e); }
+                        if (on) vj = LIJ(e);
                         const bool keep = on && vj >= st_inner;
                         const uint64_t km = __ballot(keep);
                         __builtin_amdgcn_wave_barrier();
-                        if (keep) { const int32_t dd = kept + (int32_t)prefix_popc64(km); LIY(dd) = vy; LIJ(dd) = vj; }
+                        if (keep) { const int32_t dd = kept + (int32_t)prefix_popc64(km); LIJ(dd) = vj; }
                         __builtin_amdgcn_wave_barrier();
                         kept += (int32_t)__popcll(km);
                     }
@@ -447,7 +442,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 if (cand) {
                     const int32_t yj = L.ry[j & M];
                     in = yj > qi - max_dist && (yj < qi || (yj == qi && j == 0));
-                    if (in) pj = L.rpri[j & M];
+                    if (in) pj = rpri_of(j);
                 }
                 reduce(in, pj, j);
             };
@@ -529,7 +524,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                     const bool near = i - j < LRQ_INNER - 64;
                     const int32_t yj = near ? L.ry[j & M] : (int32_t)a[j].y;
                     if (yj > qi - max_dist && (yj < qi || (yj == qi && j == 0))) {
-                        const double pj = near ? L.rpri[j & M] : lr_cc_f64(pri + j);
+                        const double pj = near ? rpri_of(j) : lr_cc_f64(pri + j);
                         if (pj == bp) {
                             tied = true;
                             if (near) { fb = L.rf[j & M]; dr = (int32_t)((uint32_t)xi - L.rx[j & M]); dq = qi - yj; }
