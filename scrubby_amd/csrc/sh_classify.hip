@@ -97,7 +97,8 @@ struct Counters {
     uint32_t n_locus[3], locus_ticket[3], lr_n_fb, lr_locus_reads; unsigned long long lr_locus_in, lr_locus_kept;
     uint32_t lr_fb_why[8], lr_fb_had, lr_pad, lr_probe_why[8];
     uint32_t lext_n_unres, lext_ticket_unres, lext_n_unres_in, lext_pad4, lext_n_exact, lext_ticket_exact, lext_rmq_open, lext_pad5;      // reads beyond the stage's second working-memory size: redone with memory allocated for them
-    unsigned long long lext_slow2, lext_slow3, lext_slow_part[4], lext_sum_part[4], lext_clk_big[LR_NCLK], lext_d_big[8], lext_phase_max[LR_NCLK];      // SCRUBBY_HIP_DBG: the slowest read of the chains kernel (time << 32 | read length / read)
+    unsigned long long lext_slow2, lext_slow3, lext_slow_part[4], lext_sum_part[4], lext_clk_big[LR_NCLK], lext_d_big[8], lext_phase_max[LR_NCLK];
+    uint32_t lext_started, lext_pad7;      // SCRUBBY_HIP_DBG: the slowest read of the chains kernel (time << 32 | read length / read)
     unsigned long long stage_cursor;      // k_expand's raw anchors of the reads k_lr_locus will thin out (their own buffer: 12 B per anchor)
 };
 #define SHARD() ((blockIdx.x + (blockIdx.x >> 6)) & 63)
@@ -2944,6 +2945,7 @@ struct ExtLongArgs {
     uint32_t *exact_list, *n_exact;                   // reads whose long join must run on the literal trees (lr_chains_wave returns 6)
     uint32_t *unres_list, *n_unres;                   // reads that outgrew the large working memory too (with big_list == nullptr): redone with memory sized for them
     const uint32_t *drop; uint32_t *fb_list, *n_fb;   // k_lr_locus: what was left out of a read's anchors; reads that must be redone with every anchor
+    uint32_t *started;                                // counts the blocks that have begun (the giants' grid: the main grid is launched once they hold their LDS)
 };
 
 // Largest reads first: a read's cost grows with its chain anchors (one with 70 k of them keeps a wave busy for a third of a second), and a
@@ -3043,16 +3045,30 @@ __device__ inline void lext_redo(const ExtLongArgs &a, uint32_t r, uint32_t why)
     atomicAdd(&a.ctr->lr_fb_why[why >= 40u && why < 48u ? why - 40u : 7u], 1u);
 }
 
-template <int NR, bool EXACT>
+// holds a stream until `want` blocks of a kernel on another stream have begun, or ~2 ms have passed (one lane, sleeping between looks)
+__global__ void k_wait_started(const uint32_t *cnt, uint32_t want, uint32_t max_looks)
+{
+    if (threadIdx.x == 0)
+        for (uint32_t i = 0; i < max_looks; ++i) {
+            if (__atomic_load_n(cnt, __ATOMIC_RELAXED) >= want) break;
+            __builtin_amdgcn_s_sleep(64);
+        }
+}
+
+template <int NR, bool EXACT, bool FAT>
 __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
 {
-    __shared__ RmqLdsT<NR> RL;
+    __shared__ RmqLdsT<NR, FAT> RL;
     const RqCache TC{nullptr, nullptr, 0};      // (the trees' LDS node cache of sh_rmq_tree.h stays off on the device: see DESIGN.md 3.2)
     const uint32_t lane = threadIdx.x;
     const LongParams P_l = a.P; const LongIn I_l = a.I; const LongArena AR_l = a.AR;      // no pointers into the kernel-argument struct
     LongWs W;
     long_ws_carve(&W, a.scratch + (unsigned long long)blockIdx.x * a.scratch_per_wave, a.sz);
     uint32_t n_list = *a.n_list, t_first = 0;
+    // the giants' waves share their SIMDs with the main grid's: a dozen reads that each keep one wave busy for half a second and more are
+    // the kernel pair's critical path, so they issue first (s_setprio)
+    if (a.part == 2) __builtin_amdgcn_s_setprio(3);
+    if (a.started && lane == 0) atomicAdd(a.started, 1u);
     if (a.part) {
         uint32_t n_giant = 0;
         for (int b2 = a.bin_cut; b2 < 32; ++b2) n_giant += a.hist[b2];
@@ -3072,7 +3088,7 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
         C.sc_mch = C.sc_mis = C.sc_amb = C.sc_N = 0; C.need_big = false; C.err = 0; C.clk = a.clk ? &clk : nullptr;
         LongOut o;
         const unsigned long long t_r0 = a.clk ? wall_clock64() : 0ull;
-        const int32_t rc = lr_chains_wave<NR, EXACT>(C, RL, AR_l, o, a.drop ? a.drop[r] : 0u, TC);
+        const int32_t rc = lr_chains_wave<NR, EXACT, FAT>(C, RL, AR_l, o, a.drop ? a.drop[r] : 0u, TC);
         if (a.clk && lane == 0) {
             const unsigned long long dt = wall_clock64() - t_r0;
             atomicMax(&a.ctr->lext_slow, dt << 24 | (unsigned long long)(o.n_chain > 0xffffff ? 0xffffff : o.n_chain)); atomicAdd(&a.ctr->lext_kernel_sum, dt);
@@ -3933,8 +3949,8 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 xa.scratch = buf; xa.scratch_per_wave = per; xa.sz = q;
                 xa.list = c->d_lext_unres[cur]; xa.n_list = &c->d_ctr->lext_n_unres_in; xa.ticket = &c->d_ctr->lext_ticket_unres;
                 xa.big_list = nullptr; xa.n_big = nullptr; xa.part = 0; xa.unres_list = c->d_lext_unres[cur ^ 1]; xa.n_unres = &c->d_ctr->lext_n_unres;
-                if (phase == 0) hipLaunchKernelGGL((k_long_chains<4096, false>), dim3(waves), dim3(64), 0, s, xa);
-                else if (phase == 2) hipLaunchKernelGGL((k_long_chains<4096, true>), dim3(waves), dim3(64), 0, s, xa);
+                if (phase == 0) hipLaunchKernelGGL((k_long_chains<4096, false, true>), dim3(waves), dim3(64), 0, s, xa);
+                else if (phase == 2) hipLaunchKernelGGL((k_long_chains<4096, true, true>), dim3(waves), dim3(64), 0, s, xa);
                 else hipLaunchKernelGGL(k_regs_align_long, dim3(waves), dim3(64), 0, s, xa);
                 sh_status st = sync_ctr();
                 hipFree(buf);
@@ -3970,18 +3986,22 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 xa.hist = c->d_ctr->lext_hist; xa.bin_cut = bin_cut; xa.part = 1;
                 ExtLongArgs xg = xa;
                 xg.scratch = c->d_lext[1]; xg.scratch_per_wave = c->lext_per_wave[1]; xg.sz = c->lext_sz[1];
-                xg.ticket = &c->d_ctr->lext_ticket_g; xg.part = 2;      // same ring as the others (19 KB of LDS: they share CUs); what outgrows the ring joins the big list
+                xg.ticket = &c->d_ctr->lext_ticket_g; xg.part = 2;
+                // The giants - a dozen reads per half million, 10^5 chain anchors each, half a second and more of one wave apiece - are the pair's
+                // critical path.  With the 512-anchor ring their window reaches back into HBM at nearly every step, and those trips take several
+                // times longer while the main grid loads the memory system; so they get the 4096-anchor ring (99 KB of LDS a wave, no trip
+                // behind it), and because a CU the main grid has filled has no such room left, the main grid is held back until the giants'
+                // blocks have begun (k_wait_started: bounded, ~2 ms at most).  The main grid's blocks (13 KB) fit beside them.
+                const uint32_t g_waves = std::min<uint32_t>(c->lext_waves[1], 64u);
+                xg.started = &c->d_ctr->lext_started;
+                SH_HIP(hipMemsetAsync(&c->d_ctr->lext_started, 0, 4, s));
                 SH_HIP(hipEventRecord(c->evx[0], s));
                 SH_HIP(hipStreamWaitEvent(c->sx[0], c->evx[0], 0));
-                // Both kernels are persistent and hold 13 KB of LDS a wave - twelve to a CU.  Launched with every slot taken, the main kernel kept the
-                // giants' waves waiting until it had ended (their second-long reads then ran alone: the stage's longest stretch); so the two
-                // grids together stay within the slots the device has.
-                const uint32_t slots = 12u * (uint32_t)c->n_cu;
-                const uint32_t g_waves = std::min<uint32_t>(c->lext_waves[1], 128u);
-                const uint32_t m_waves = c->lext_waves[0] + g_waves > slots && slots > 2 * g_waves ? std::min<uint32_t>(c->lext_waves[0], slots - g_waves) : c->lext_waves[0];
-                hipLaunchKernelGGL((k_long_chains<512, false>), dim3(g_waves), dim3(64), 0, c->sx[0], xg);
+                const uint32_t m_waves = c->lext_waves[0];
+                hipLaunchKernelGGL((k_long_chains<4096, false, false>), dim3(g_waves), dim3(64), 0, c->sx[0], xg);
                 SH_HIP(hipEventRecord(c->evx[1], c->sx[0]));
-                hipLaunchKernelGGL((k_long_chains<512, false>), dim3(m_waves), dim3(64), 0, s, xa);
+                hipLaunchKernelGGL(k_wait_started, dim3(1), dim3(64), 0, s, (const uint32_t *)&c->d_ctr->lext_started, g_waves, 2000u);
+                hipLaunchKernelGGL((k_long_chains<512, false, false>), dim3(m_waves), dim3(64), 0, s, xa);
                 SH_HIP(hipStreamWaitEvent(s, c->evx[1], 0));
                 sh_status st = sync_ctr(); if (st != SH_OK) return st;
                 if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;       // hand-over buffers or arena full: the caller cuts the chunk in two
@@ -3989,7 +4009,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                     xa.scratch = c->d_lext[1]; xa.scratch_per_wave = c->lext_per_wave[1]; xa.sz = c->lext_sz[1];
                     xa.list = c->d_lext_big; xa.n_list = &c->d_ctr->lext_n_big; xa.ticket = &c->d_ctr->lext_ticket_big; xa.big_list = nullptr; xa.n_big = nullptr; xa.part = 0;
                     xa.unres_list = c->d_lext_unres[0]; xa.n_unres = &c->d_ctr->lext_n_unres;
-                    hipLaunchKernelGGL((k_long_chains<4096, false>), dim3(c->lext_waves[1]), dim3(64), 0, s, xa);
+                    hipLaunchKernelGGL((k_long_chains<4096, false, true>), dim3(c->lext_waves[1]), dim3(64), 0, s, xa);
                     st = sync_ctr(); if (st != SH_OK) return st;
                     if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
                     st = on_demand(0, xa); if (st != SH_OK) return st;
@@ -4007,14 +4027,14 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 xe.part = 0; xe.exact_list = nullptr; xe.n_exact = nullptr;
                 SH_HIP(hipMemsetAsync(&c->d_ctr->lext_n_big, 0, 8, s));      // lext_n_big, lext_ticket_big: the list of the reads beyond the first size, once more
                 xe.big_list = c->d_lext_big; xe.n_big = &c->d_ctr->lext_n_big; xe.unres_list = nullptr; xe.n_unres = nullptr;
-                hipLaunchKernelGGL((k_long_chains<4096, true>), dim3(c->lext_exact_waves[0]), dim3(64), 0, s, xe);
+                hipLaunchKernelGGL((k_long_chains<4096, true, true>), dim3(c->lext_exact_waves[0]), dim3(64), 0, s, xe);
                 sh_status st = sync_ctr(); if (st != SH_OK) return st;
                 if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
                 if (c->h_ctr->lext_n_big > 0) {
                     xe.scratch = c->d_lext_exact[1]; xe.scratch_per_wave = c->lext_exact_per_wave[1]; xe.sz = c->lext_exact_sz[1];
                     xe.list = c->d_lext_big; xe.n_list = &c->d_ctr->lext_n_big; xe.ticket = &c->d_ctr->lext_ticket_big; xe.big_list = nullptr; xe.n_big = nullptr;
                     xe.unres_list = c->d_lext_unres[0]; xe.n_unres = &c->d_ctr->lext_n_unres;
-                    hipLaunchKernelGGL((k_long_chains<4096, true>), dim3(c->lext_exact_waves[1]), dim3(64), 0, s, xe);
+                    hipLaunchKernelGGL((k_long_chains<4096, true, true>), dim3(c->lext_exact_waves[1]), dim3(64), 0, s, xe);
                     st = sync_ctr(); if (st != SH_OK) return st;
                     if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
                 }

@@ -224,10 +224,14 @@ __device__ inline void lr_tick(LongClk *c, int ph) { if (c) { const unsigned lon
 // with NR = 512 (19 KB: eight waves per CU); a read whose inner window or same-x group outgrows it is redone with NR = 4096.
 #define LRQ_RBLK(NR) ((NR) / 64 - 4)            // completed blocks of 64 anchors that are always inside the ring ...
 #define LRQ_SAMEX(NR) ((NR) - 1 - (LRQ_RBLK(NR) + 1) * 64)      // ... with up to this many anchors waiting on one x
-template <int LRQ_INNER>
+// FAT: the list also holds each entry's y and the ring each anchor's priority (36 B a slot).  Without them (24 B a slot: 13 KB at 512 slots,
+// twelve waves to a CU instead of eight) an entry's y is read through its index and the priority is recomputed from rf, rx, ry: more waves
+// per CU for the many ordinary reads, a longer dependent chain per step for a wave that has a CU's issue slots to itself (the giants).
+template <int LRQ_INNER, bool FAT = false>
 struct RmqLdsT {
-    int32_t ij[LRQ_INNER];      // the inner window's list: indices only - an entry's y is the ring's (ry); the priority is recomputed from rf, rx, ry
-    uint32_t rx[LRQ_INNER]; int32_t ry[LRQ_INNER], rf[LRQ_INNER], rp[LRQ_INNER], rt[LRQ_INNER];      // 24 B a slot: 13 KB at 512 slots, twelve waves to a CU (36 B: eight)
+    int32_t ij[LRQ_INNER];      // the inner window's list, ascending (y, j)
+    uint32_t rx[LRQ_INNER]; int32_t ry[LRQ_INNER], rf[LRQ_INNER], rp[LRQ_INNER], rt[LRQ_INNER];
+    int32_t iy[FAT ? LRQ_INNER : 1]; double rpri[FAT ? LRQ_INNER : 1];
     double pml[64], bml[64];    // pml[b & 63] = smallest priority of the blocks 0 .. b, bml[b & 63] = of block b alone
 };
 
@@ -277,9 +281,9 @@ __device__ inline double lr_cc_f64(const double *p) { return __longlong_as_doubl
 // priority of everything older is one number (pml): a step only goes to HBM when the answer may lie further back than the ring.
 // TREE: lane 0 keeps upstream's main tree beside the scan (insert when anchors enter the window, erase when they leave, sh_rmq_tree.h) and the
 // tree answers query (1) whenever the scan finds the smallest priority shared - n_tie then counts those steps, none of which is left open.
-template <int LRQ_INNER, bool TREE>
+template <int LRQ_INNER, bool TREE, bool FAT = false>
 __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int32_t bw, int32_t n, const LAnchor *a, int32_t *f, int32_t *p,
-                                   double *pri, double *bmin /* n / 64 + 1 */, RmqLdsT<LRQ_INNER> &L, int32_t &n_tie, LongClk *dbg = nullptr,
+                                   double *pri, double *bmin /* n / 64 + 1 */, RmqLdsT<LRQ_INNER, FAT> &L, int32_t &n_tie, LongClk *dbg = nullptr,
                                    RqNode *pool = nullptr, int32_t pool_cap = 0, RqCache TC = RqCache{nullptr, nullptr, 0})
 {
     RqTree T0;
@@ -293,7 +297,8 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
     unsigned long long d_ring = 0, d_oldsteps = 0, d_old = 0, d_nin = 0, d_chunks = 0;
     const int32_t lane = (int32_t)al_lane();
     constexpr int32_t M = LRQ_INNER - 1;
-    auto rpri_of = [&](int32_t j) -> double { return -((double)L.rf[j & M] + 0.5 * (double)pen_gap * (double)((int32_t)L.rx[j & M] + L.ry[j & M])); };      // of a ring anchor whose f is final
+    auto rpri_calc = [&](int32_t j) -> double { return -((double)L.rf[j & M] + 0.5 * (double)pen_gap * (double)((int32_t)L.rx[j & M] + L.ry[j & M])); };      // of a ring anchor whose f is final
+    auto rpri_of = [&](int32_t j) -> double { if constexpr (FAT) return L.rpri[j & M]; else return rpri_calc(j); };
     int32_t max_dist = max_dist_in, max_dist_inner = rmq_inner_dist;
     if (max_dist < bw) max_dist = bw;
     if (max_dist_inner < 0) max_dist_inner = 0;
@@ -304,7 +309,8 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
     int32_t blk_done = 0;      // blocks [0, blk_done) of 64 anchors are completely inserted; bmin[b] = their smallest priority
     int32_t i0 = 0, st = 0, st_inner = 0, n_in = 0, seg0 = 0, head = 0;      // the list is circular: entry e lives at (head + e) & M
 #define LIJ(e) L.ij[(head + (e)) & M]
-#define LIY(e) L.ry[LIJ(e) & M]      // inner window: the live entries (j >= st_inner) of L.iy/ij[0 .. n_in), ascending (y, j)
+#define LIY(e) (FAT ? L.iy[FAT ? (head + (e)) & M : 0] : L.ry[LIJ(e) & M])
+#define LIY_SET(e, v) do { if constexpr (FAT) L.iy[(head + (e)) & M] = (v); } while (0)      // inner window: the live entries (j >= st_inner) of L.iy/ij[0 .. n_in), ascending (y, j)
     bool ok = true;
     uint32_t hi_prev = 0;
     LAnchor cur = a[0];
@@ -320,6 +326,10 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
         // add the anchors whose x is now strictly smaller
         if (i - i0 > LRQ_SAMEX(LRQ_INNER)) { ok = false; break; }      // more anchors on one reference position than the ring can hold back
         if (i0 < i && (seg0 == i || L.rx[i0 & M] != (uint32_t)xi)) {
+            if constexpr (FAT) {
+                for (int32_t jb = i0; jb < i; jb += 64) { const int32_t j = jb + lane; if (j < i) L.rpri[j & M] = rpri_calc(j); }
+                __builtin_amdgcn_wave_barrier();
+            }
             if (max_dist_inner > 0) {
                 for (int32_t j = i0; j < i; ++j) {      // insert (y_j, j) into the y-sorted inner window
                     if (n_in >= LRQ_INNER) { ok = false; break; }
@@ -335,14 +345,14 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                     }
                     for (int32_t c = ((n_in - pos + 63) / 64 - 1) * 64; c >= 0; c -= 64) {      // shift [pos, n_in) up by one, from the top
                         const int32_t e = pos + c + lane;
-                        int32_t vj = 0;
+                        int32_t vj = 0, vy = 0;
                         const bool on = e < n_in;
-                        if (on) vj = LIJ(e);
+                        if (on) { vj = LIJ(e); if constexpr (FAT) vy = LIY(e); }
                         __builtin_amdgcn_wave_barrier();
-                        if (on) LIJ(e + 1) = vj;
+                        if (on) { LIJ(e + 1) = vj; LIY_SET(e + 1, vy); }
                         __builtin_amdgcn_wave_barrier();
                     }
-                    if (lane == 0) LIJ(pos) = j;
+                    if (lane == 0) { LIJ(pos) = j; LIY_SET(pos, yj); }
                     __builtin_amdgcn_wave_barrier();
                     ++n_in;
                 }
@@ -404,13 +414,13 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                     int32_t kept = 0;
                     for (int32_t c = 0; c < n_in; c += 64) {
                         const int32_t e = c + lane;
-                        int32_t vj = 0;
+                        int32_t vj = 0, vy = 0;
                         const bool on = e < n_in;
-                        if (on) vj = LIJ(e);
+                        if (on) { vj = LIJ(e); if constexpr (FAT) vy = LIY(e); }
                         const bool keep = on && vj >= st_inner;
                         const uint64_t km = __ballot(keep);
                         __builtin_amdgcn_wave_barrier();
-                        if (keep) { const int32_t dd = kept + (int32_t)prefix_popc64(km); LIJ(dd) = vj; }
+                        if (keep) { const int32_t dd = kept + (int32_t)prefix_popc64(km); LIJ(dd) = vj; LIY_SET(dd, vy); }
                         __builtin_amdgcn_wave_barrier();
                         kept += (int32_t)__popcll(km);
                     }
@@ -625,6 +635,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
         __builtin_amdgcn_wave_barrier();
     }
 #undef LIY
+#undef LIY_SET
 #undef LIJ
     if (TREE && al_b0(T0.bad)) ok = false;
     n_tie = tie_cnt;
@@ -1670,8 +1681,8 @@ __device__ inline bool lr_region_kept(const LongParams &P, int32_t qlen, const L
 // and that regs[0] - the only region a flag-only call asks about - is among the chains kept: top score > k * drop.
 // EXACT: the long join on the literal trees (lr_rmq_fill_tree).  Without it a join that meets two candidates of equal priority, or that the
 // LDS ring cannot hold, returns 6: the read is redone by the EXACT instance of the kernel.
-template <int NR, bool EXACT>
-__device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const LongArena &AR, LongOut &out, uint32_t drop = 0, RqCache TC = RqCache{nullptr, nullptr, 0})
+template <int NR, bool EXACT, bool FAT = false>
+__device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR, FAT> &RL, const LongArena &AR, LongOut &out, uint32_t drop = 0, RqCache TC = RqCache{nullptr, nullptr, 0})
 {
     const LongParams &P = *C.P;
     LongWs &W = *C.W;
@@ -1784,7 +1795,7 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const Long
             lr_tick(C.clk, 1);
             if constexpr (EXACT) {
                 // the scan with upstream's main tree beside it (asked at the ties); what the ring cannot hold, or rmq_size_cap touches: both trees on one lane
-                if (!lr_rmq_fill<NR, true>(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie, C.clk, W.rq0, (int32_t)W.cap_a + 2, TC)) {
+                if (!lr_rmq_fill<NR, true, FAT>(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie, C.clk, W.rq0, (int32_t)W.cap_a + 2, TC)) {
                     lr_sync();
                     for (int32_t i = lane; i < n_a; i += 64) W.t[i] = 0;
                     lr_sync();
@@ -1794,7 +1805,7 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR> &RL, const Long
                     if (!lr_rmq_fill_tree(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.t, W.rq0, W.rq1, (int32_t)W.cap_a + 2, C0, C1, &code)) { C.err = 100u + (uint32_t)al_b0((int32_t)code); return 3; }
                 }
             } else {
-                if (!lr_rmq_fill<NR, false>(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie, C.clk)) {
+                if (!lr_rmq_fill<NR, false, FAT>(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie, C.clk)) {
                     if (NR < 4096 && n_a <= P.rmq_size_cap) { C.err = 6; return 3; }      // beyond this ring: the pass with the large one
                     if (P.rmq_exact_max < 0 || n_a <= P.rmq_exact_max) { C.err = 51; return 6; }      // beyond that too (or rmq_size_cap): the trees
                     C.err = 6; return 7;      // ... which one lane would walk for seconds on a read this size: given up, counted (sh_stats.n_ext_unresolved)
