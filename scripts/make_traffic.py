@@ -11,7 +11,7 @@ applies only to the coalesced 16-B/lane streams (K1's 3 GB of bases: FETCH_SIZE 
 for the gathers and a lower bound by at most that amount overall."""
 import csv, glob, hashlib, json, os, sys, collections
 
-KERNEL_SOURCES = ("sh_classify.hip", "sh_sketch.h", "sh_chain.h", "sh_align.h", "sh_long.h", "sh_rmq_tree.h")
+KERNEL_SOURCES = ("sh_classify.hip", "sh_sketch.h", "sh_chain.h", "sh_align.h", "sh_long.h", "sh_rmq_tree.h", "sh_wave.h")
 K2_SOURCES = ("sh_k2.hip",)
 
 
@@ -25,7 +25,7 @@ def source_hash(workload="sr"):
 
 
 STAGES = {      # bench.py's stage names -> kernel name prefixes; a kernel belongs to the FIRST stage one of whose prefixes it carries
-    "extension stage (k_long_chains + k_regs_align_long)": ("k_lext_", "k_long_chains", "k_regs_align_long"),
+    "extension stage (k_long_chains + k_regs_align_long)": ("k_lext_", "k_long_chains", "k_regs_align_long", "k_wait_started"),
     "k_sketch_probe": ("k_sketch_probe", "k_long_"),      # long reads: the segment-parallel front end stands where K1 does
     "k_chain_small": ("k_chain_small", "k_pair_pass"),
     "repeat path (k_local_cluster, k_expand, k_sort_top / k_sort_lds classes, k_giant_*, k_cluster_dp, k_finalize)": ("k_local_cluster", "k_expand", "k_lr_locus", "k_group_probe", "k_sort_", "k_giant", "k_cluster_dp", "k_finalize", "k_chain_large"),

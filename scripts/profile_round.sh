@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for W in $WHAT; do
   case $W in
     sr)  ARGS=""; TAG=""; NREC=20000000; LAUNCHES=1; TOP=28 ;;
-    ont) ARGS="--workload ont"; TAG="_ont"; NREC=500000; LAUNCHES=4; TOP=20 ;;
+    ont) ARGS="--workload ont"; TAG="_ont"; NREC=1000000; LAUNCHES=2; TOP=20 ;;
     k2)  ARGS="--workload k2"; TAG="_k2"; NREC=40000000; LAUNCHES=1; TOP=12 ;;
   esac
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}${TAG}_stats -- python3 bench.py $ARGS --steps 3 --warmup 1 --no-cpu > gpurun_out/${R}${TAG}_bench_under_rocprof.log 2>&1 || exit 1
