@@ -209,6 +209,7 @@ struct AlignScratch {       // one per wave, in HBM; sized by the host from max_
     RegLite *regs;
     uint64_t *kz, *kx, *kk;
     uint32_t *kh, *ord;
+    int32_t *pri; uint64_t *cov;      // mm_set_parent's primaries and coverage intervals when the regions live here (more than AL_R chains)
     uint32_t qcap, tcap, reg_cap; unsigned long long pcap;
 };
 
@@ -224,6 +225,7 @@ __host__ __device__ inline unsigned long long align_scratch_layout(uint32_t max_
     unsigned long long b = 0;
     auto add = [&](unsigned long long bytes) { b += (bytes + 15) & ~15ull; };
     add((unsigned long long)reg_cap * sizeof(RegLite)); add(8ull * reg_cap); add(8ull * reg_cap); add(8ull * reg_cap); add(4ull * reg_cap); add(4ull * reg_cap);
+    add(4ull * reg_cap); add(8ull * reg_cap);
     add(4 * tcap); add(8 * (qcap + tcap)); add(4 * (qcap + tcap + 8)); add(4 * (2 * (qcap + tcap) + 16));
     add(2 * qcap); add(tcap); add(8 * tcap + qcap + 32); add(pcap);
     return (b + 255) & ~255ull;
@@ -238,6 +240,7 @@ __device__ inline void align_scratch_carve(AlignScratch &A, uint8_t *p, uint32_t
     A.regs = (RegLite *)take((unsigned long long)reg_cap * sizeof(RegLite));
     A.kz = (uint64_t *)take(8ull * reg_cap); A.kx = (uint64_t *)take(8ull * reg_cap); A.kk = (uint64_t *)take(8ull * reg_cap);
     A.kh = (uint32_t *)take(4ull * reg_cap); A.ord = (uint32_t *)take(4ull * reg_cap);
+    A.pri = (int32_t *)take(4ull * reg_cap); A.cov = (uint64_t *)take(8ull * reg_cap);
     A.kH = (int32_t *)take(4ull * A.tcap);
     A.koff = (int32_t *)take(8ull * (A.qcap + A.tcap));
     A.ez_cigar = (uint32_t *)take(4ull * (A.qcap + A.tcap + 8));
@@ -870,10 +873,12 @@ __device__ inline bool align_read_wave(const AlignIn &in, const AlignParams &P, 
     if (lane == 0) {
         auto R_qs = [&](int32_t i) { return ld32(&regs[i].qs, rg); };
         auto R_qe = [&](int32_t i) { return ld32(&regs[i].qe, rg); };
-        int32_t *w = Ls.pri; uint64_t *cov = Ls.cov;
+        bool too_many = false;
+        // the primaries' list and the coverage intervals: in LDS with the regions (AL_R chains: never more primaries than that), in the wave's
+        // scratch with them otherwise - one instance of the loop each, so that the LDS one keeps its ds_ accesses
+        auto set_parent = [&](int32_t *w, uint64_t *cov, const int32_t pri_cap) {
         int32_t k = 1;
         w[0] = 0; regs[0].parent = 0;
-        bool too_many = false;
         for (int32_t i = 1; i < n_u; ++i) {
             const int32_t si = R_qs(i), ei = R_qe(i);
             int32_t n_cov = 0, uncov_len = 0, j;
@@ -901,10 +906,12 @@ __device__ inline bool align_read_wave(const AlignIn &in, const AlignParams &P, 
                 }
             } else j = k;
             if (j == k) {
-                if (k >= LDS::NPRI) { too_many = true; break; }
+                if (k >= pri_cap) { too_many = true; break; }
                 w[k++] = i; regs[i].parent = i;
             }
         }
+        };
+        if (rg) set_parent(A.pri, A.cov, (int32_t)A.reg_cap); else set_parent(Ls.pri, Ls.cov, (int32_t)LDS::NPRI);
         if (too_many) atomicExch(overflow, 3u);
         // mm_select_sub (check_strand = 1, min_strand_sc = max_gap * 0.8), in place like upstream: r[p] is read AFTER earlier
         // regions moved up, so a parent index can alias a later region - kept literally

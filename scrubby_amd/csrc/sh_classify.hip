@@ -79,7 +79,7 @@ struct Counters {
     uint32_t n_long_segs, pad2;
     uint32_t ext_reason[8];       // why the top chain did not settle a read (k_ext_top)
     uint32_t ext_s3[8];           // SCRUBBY_HIP_DBG & 16: outcome of the local-cluster shortcut (k_expand): 0 tried, 1 no singleton / filtered seed, 2 singletons apart, 3 window grew / too many, 4 K > 64, 5 no margin over U_out, 6 lemma, 7 decided
-    uint32_t ext_overflow, ext_n_list, ext_ticket, ext_regions, ext_dropped, ext_n_redo, ext_n_list2, ext_ticket2, ext_n_redo2, ext_ticket3;      // extension stage (sh_align.h)
+    uint32_t ext_overflow, ext_n_list, ext_ticket, ext_regions, ext_dropped, ext_n_redo, ext_n_list2, ext_ticket2, ext_n_redo2, ext_ticket3, ext_n_unres, ext_ticket_unres, ext_n_unres_in, ext_pad8;      // extension stage (sh_align.h)
     uint32_t ext_n_recs[SINK_SHARDS]; unsigned long long ext_n_anch[SINK_SHARDS];                 // hand-over cursors, one per shard
     uint32_t lext_hist[64]; uint32_t lext_ticket_g, lext_pad3; uint32_t lext_n_big, lext_ticket_big, lext_n_big2, lext_ticket_big2, lext_ticket_b, lext_pad2, lext_rechained, lext_rmq_tie, lext_err_read, lext_unresolved, lext_err_code, lext_pad;
     unsigned long long lext_clk[LR_NCLK], lext_d[8], lext_slow, lext_kernel_sum;  // long-read extension stage (sh_long.h): reads for the large-scratch pass, RMQ re-chains, steps with tied priorities
@@ -2793,6 +2793,7 @@ struct ExtArgs {
     uint32_t *list; uint32_t *n_list, *ticket; Counters *ctr; uint8_t *flags; sh_trace *trace; int32_t flag_only; uint64_t n_reads;
     const unsigned long long *best; const uint32_t *tie;      // first pass of a flag-only call: decide from the top chain, or queue for the full pass
     uint32_t *redo, *redo2; int32_t top_only;                 // k_regs_align, top_only: align regs[0] alone; reads it does not settle go to redo2
+    uint32_t *unres_list, *n_unres;                           // k_regs_align: reads with more chains / regions than this launch's working memory holds (redone with more)
 };
 
 __global__ void k_ext_list(ExtArgs a)
@@ -2870,7 +2871,8 @@ __global__ __launch_bounds__(64) void k_regs_align(ExtArgs a)
             // its chain-level answer and is counted (sh_stats.n_ext_unresolved; the host warns); anything else is a sizing error of the call
             if (lane == 0) {
                 const uint32_t code = s_ovf;
-                if (code == 2u || code == 3u || code == 6u) {
+                if ((code == 2u || code == 3u || code == 6u) && a.unres_list) a.unres_list[atomicAdd(a.n_unres, 1u)] = r;      // once more, with memory sized for it
+                else if (code == 2u || code == 3u || code == 6u) {
                     a.flags[r] = 1;
                     if (a.trace) ((int32_t *)(a.trace + r))[7] = 1;
                     atomicAdd(&a.ctr->lext_unresolved, 1u); atomicExch(&a.ctr->lext_err_read, r); atomicExch(&a.ctr->lext_err_code, code);
@@ -3214,9 +3216,9 @@ struct sh_ctx {
     AlignParams AP{};
     ChainSink sink{};
     uint8_t *d_ext = nullptr; uint64_t ext_bytes = 0;
-    uint32_t *d_ext_list = nullptr, *d_ext_redo = nullptr; uint8_t *d_ext_scratch = nullptr;
+    uint32_t *d_ext_list = nullptr, *d_ext_redo = nullptr; uint8_t *d_ext_scratch = nullptr; uint32_t *d_ext_unres[2] = {};
     unsigned long long cur_reads = 0;      // records of the chunk being classified
-    unsigned long long ext_scratch_per_wave = 0; uint32_t ext_waves_top = 0; uint32_t ext_waves = 0, ext_reg_cap = 0;
+    unsigned long long ext_scratch_per_wave = 0, ext_scratch_per_wave_top = 0; uint32_t ext_waves_top = 0; uint32_t ext_waves = 0, ext_reg_cap = 0;
     hipEvent_t ev_ext[2] = {};
     // which reads of the LAST chunk took the rare paths (sh_ctx_debug_list: the bench's stratified oracle sample): 0 re-chained with max_occ,
     // 1 regs[0] aligned base by base, 2 the full fallback with every chain
@@ -3455,7 +3457,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         cap_recs = std::min<uint64_t>((cap_recs + SINK_SHARDS - 1) / SINK_SHARDS, 0xfffffff0ull / SINK_SHARDS);      // per shard
         cap_anch = (cap_anch + SINK_SHARDS - 1) / SINK_SHARDS;
         auto al = [](uint64_t b) { return (b + 255) & ~255ull; };
-        c->ext_bytes = al(SINK_SHARDS * cap_recs * sizeof(ChainRec)) + al(SINK_SHARDS * cap_anch * 8) + al(SINK_SHARDS * cap_anch * 4) + 3 * al(max_reads * 4) + al(max_reads * 8) + al(max_reads * 4);
+        c->ext_bytes = al(SINK_SHARDS * cap_recs * sizeof(ChainRec)) + al(SINK_SHARDS * cap_anch * 8) + al(SINK_SHARDS * cap_anch * 4) + 3 * al(max_reads * 4) + al(max_reads * 8) + al(max_reads * 4) + (c->ext_long ? 0 : 2 * al(max_reads * 4));
         if ((e = hipMalloc(&c->d_ext, c->ext_bytes)) != hipSuccess) return fail(e, "extension-stage buffers");
         uint8_t *p = c->d_ext;
         auto take = [&](uint64_t b) { uint8_t *q = p; p += al(b); return q; };
@@ -3465,6 +3467,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
         c->sink.trec = c->use_k1 ? c->d_records : nullptr; c->sink.tinfo = c->d_k1info; c->sink.tseed_cap = c->seed_cap;
         c->d_ext_list = (uint32_t *)take(max_reads * 4);
         c->d_ext_redo = (uint32_t *)take(max_reads * 4);
+        if (!c->ext_long) { c->d_ext_unres[0] = (uint32_t *)take(max_reads * 4); c->d_ext_unres[1] = (uint32_t *)take(max_reads * 4); }
         c->sink.best = (unsigned long long *)take(max_reads * 8);
         c->sink.tie = (uint32_t *)take(max_reads * 4);
         c->sink.n_recs = c->d_ctr->ext_n_recs; c->sink.n_anch = c->d_ctr->ext_n_anch; c->sink.overflow = &c->d_ctr->ext_overflow;
@@ -3474,8 +3477,10 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             c->ext_scratch_per_wave = align_scratch_layout(max_read_len, c->ext_reg_cap, nullptr, nullptr, nullptr);
             const uint64_t budget = 4ull << 30;
             c->ext_waves = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)256 * std::max<uint64_t>(1, (160u << 10) / sizeof(AlignLds)), budget / c->ext_scratch_per_wave, (max_reads + 3) / 4}));
-            c->ext_waves_top = (uint32_t)std::max<uint64_t>(c->ext_waves, std::min<uint64_t>({(uint64_t)256 * std::max<uint64_t>(1, (160u << 10) / (sizeof(AlignLdsTop) + 16)), budget / c->ext_scratch_per_wave, (max_reads + 3) / 4}));
-            if ((e = hipMalloc(&c->d_ext_scratch, (uint64_t)c->ext_waves_top * c->ext_scratch_per_wave)) != hipSuccess) return fail(e, "extension-stage scratch");
+            // k_regs_align_top holds one chain and the few regions z-drops split off it in LDS: its share of the scratch needs no region arrays
+            c->ext_scratch_per_wave_top = align_scratch_layout(max_read_len, 64, nullptr, nullptr, nullptr);
+            c->ext_waves_top = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)256 * std::max<uint64_t>(1, (160u << 10) / (sizeof(AlignLdsTop) + 16)), budget / c->ext_scratch_per_wave_top, (max_reads + 3) / 4}));
+            if ((e = hipMalloc(&c->d_ext_scratch, std::max<uint64_t>((uint64_t)c->ext_waves * c->ext_scratch_per_wave, (uint64_t)c->ext_waves_top * c->ext_scratch_per_wave_top))) != hipSuccess) return fail(e, "extension-stage scratch");
         } else {
             // per-wave working memory of the two kernels (k_long_chains, k_regs_align_long), each in two sizes: every wave slot with room for
             // the usual read, and a few waves with room for the largest alignment minimap2 attempts (max_sw_mat = 10^8 cells) / for reads
@@ -4136,6 +4141,39 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         x.list = c->d_ext_list; x.n_list = &c->d_ctr->ext_n_list; x.ticket = &c->d_ctr->ext_ticket;
         x.ctr = c->d_ctr; x.flags = d_flags; x.trace = d_trace; x.flag_only = d_trace == nullptr; x.n_reads = n_reads;
         x.best = c->sink.best; x.tie = c->sink.tie; x.redo = c->d_ext_redo;
+        x.unres_list = c->d_ext_unres[0]; x.n_unres = &c->d_ctr->ext_n_unres;
+        uint32_t n_sr_ondemand = 0;
+        // minimap2 has no limit on a read's chains or regions; k_regs_align's per-wave working memory has (ext_reg_cap).  Reads beyond it are
+        // listed and redone with memory allocated for them, four times the last size per round, until none is left; only when the device
+        // cannot give it do they keep their chain-level answer (counted: sh_stats.n_ext_unresolved).  h_ctr holds the last launch's counters.
+        auto sr_on_demand = [&](ExtArgs xa) -> sh_status {
+            uint32_t n_un = c->h_ctr->ext_n_unres, cap = c->ext_reg_cap;
+            n_sr_ondemand += n_un;
+            int cur = 0;
+            while (n_un > 0) {
+                uint8_t *buf = nullptr; unsigned long long per = 0; uint32_t waves = 0;
+                if (cap < (1u << 24)) {
+                    cap = (uint32_t)std::min<uint64_t>((uint64_t)cap * 4, 1u << 24);
+                    per = align_scratch_layout(c->max_read_len, cap, nullptr, nullptr, nullptr);
+                    for (waves = std::min<uint32_t>(n_un, 8); waves > 0 && hipMalloc(&buf, per * waves) != hipSuccess; waves >>= 1) { buf = nullptr; (void)hipGetLastError(); }
+                }
+                const uint32_t z4[4] = {0, 0, n_un, 0};      // ext_n_unres, ext_ticket_unres, ext_n_unres_in
+                SH_HIP(hipMemcpyAsync(&c->d_ctr->ext_n_unres, z4, 16, hipMemcpyHostToDevice, s));
+                xa.list = c->d_ext_unres[cur]; xa.n_list = &c->d_ctr->ext_n_unres_in; xa.ticket = &c->d_ctr->ext_ticket_unres;
+                if (buf) { xa.scratch = buf; xa.scratch_per_wave = per; xa.reg_cap = cap; xa.unres_list = c->d_ext_unres[cur ^ 1]; xa.n_unres = &c->d_ctr->ext_n_unres; }
+                else { xa.unres_list = nullptr; xa.n_unres = nullptr; waves = std::min<uint32_t>(c->ext_waves, n_un); }      // no memory to be had: counted, chain-level answer
+                hipLaunchKernelGGL(k_regs_align, dim3(waves), dim3(64), 0, s, xa);
+                SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+                SH_HIP(hipStreamSynchronize(s));
+                if (buf) hipFree(buf);
+                SH_HIP(hipGetLastError());
+                if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
+                SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "extension stage: a read exceeds the per-wave working memory (code %u)", c->h_ctr->ext_overflow);
+                if (!buf) break;
+                n_un = c->h_ctr->ext_n_unres; cur ^= 1;
+            }
+            return SH_OK;
+        };
         SH_HIP(hipEventRecord(c->ev_ext[0], s));
         hipLaunchKernelGGL(k_ext_list, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, s, x);
         if (d_trace != nullptr) {
@@ -4151,6 +4189,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;       // hand-over buffers full: the caller cuts the chunk in two
         SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "extension stage: a read exceeds the per-wave working memory (code %u: 2 chains, 3 primaries, 4 read length, 5 window, 6 regions)", c->h_ctr->ext_overflow);
         ext_list = c->h_ctr->ext_n_list;
+        if (d_trace != nullptr && c->h_ctr->ext_n_unres > 0) { const uint32_t keep = ext_list; sh_status st = sr_on_demand(x); if (st != SH_OK) return st; ext_list = keep; }
         const uint32_t n_redo = c->h_ctr->ext_n_redo;
         if (d_trace == nullptr) { c->dbg_ptr[1] = c->d_ext_redo; c->dbg_n[1] = n_redo; }
         if (getenv("SCRUBBY_HIP_DBG")) fprintf(stderr, "[dbg] extension stage: %u reads handed over chains, %u not settled by their top chain (tie %u, missing %u, short stretch %u, z-drop %u)\n", ext_list, n_redo, c->h_ctr->ext_reason[1], c->h_ctr->ext_reason[2], c->h_ctr->ext_reason[3], c->h_ctr->ext_reason[4]);
@@ -4159,6 +4198,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
             // second pass: regs[0] of the reads its max stretch could not vouch for goes through mm_align1 (one wave per read)
             ExtArgs x1 = x;
             x1.list = c->d_ext_redo; x1.n_list = &c->d_ctr->ext_n_redo; x1.ticket = &c->d_ctr->ext_ticket2; x1.top_only = 1; x1.redo2 = c->d_ext_list;     // the first list is spent
+            x1.scratch_per_wave = c->ext_scratch_per_wave_top; x1.reg_cap = 64;
             hipLaunchKernelGGL(k_regs_align_top, dim3(c->ext_waves_top), dim3(64), 0, s, x1);
             SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
             SH_HIP(hipStreamSynchronize(s));
@@ -4214,9 +4254,10 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
             SH_HIP(hipGetLastError());
             if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
             SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "extension stage: a read exceeds the per-wave working memory (code %u)", c->h_ctr->ext_overflow);
+            if (c->h_ctr->ext_n_unres > 0) { sh_status st = sr_on_demand(x2); if (st != SH_OK) return st; }
             ms_fallback = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fb).count();
         }
-        if (stats) { stats->n_ext_fallback += n_fallback; stats->ms_ext_fallback += ms_fallback; stats->n_ext_unresolved += c->h_ctr->lext_unresolved; }
+        if (stats) { stats->n_ext_fallback += n_fallback; stats->ms_ext_fallback += ms_fallback; stats->n_ext_unresolved += c->h_ctr->lext_unresolved; stats->n_ext_ondemand += n_sr_ondemand; }
         if (c->h_ctr->lext_unresolved) {
             static bool warned_sr = false;
             if (!warned_sr) { warned_sr = true; fprintf(stderr, "[scrubby-hip] WARNING: %u read(s) outgrew the extension stage's working memory (e.g. read %u of its batch, code %u: 2 chains, 3 primaries, 6 regions); they keep their chain-level answer (mapped)\n", c->h_ctr->lext_unresolved, c->h_ctr->lext_err_read, c->h_ctr->lext_err_code); }

@@ -647,10 +647,10 @@ def test_parallel_chaining_recurrence_and_read_level_backtrack(S, oracle, monkey
     assert st["n_dp_parallel"] > 300 and st["n_top_settled"] == 0
 
 
-def test_reads_beyond_the_extension_stages_working_memory_are_counted_not_fatal(S, oracle, monkeypatch):
+def test_reads_beyond_the_extension_stages_working_memory_get_memory_of_their_own(S, oracle, monkeypatch):
     """minimap2 has no limit on the chains of a read; the extension stage's per-wave working memory has (16 384; 70 here, through
-    SCRUBBY_HIP_EXT_REGCAP).  A read beyond it keeps its chain-level answer (mapped), is counted in sh_stats.n_ext_unresolved and named in
-    a warning; every other read of the call is answered as always."""
+    SCRUBBY_HIP_EXT_REGCAP).  A read beyond it is redone with working memory allocated for it (sh_stats.n_ext_ondemand) and answered like
+    every other read: flags and traces equal the oracle's, nothing is left at a chain-level answer."""
     contigs = [700_000, 500_000]
     Po = oracle.ref_params(0x5C2B0B01, contigs, sat_pct=45, rep_pct=30, n_sat_fam=3, n_rep_fam=20)
     ref = oracle.synth_ref(Po, 0, Po.genome_len)
@@ -667,7 +667,8 @@ def test_reads_beyond_the_extension_stages_working_memory_are_counted_not_fatal(
     gidx = S.Index.build([bytes(s) for s in seqs], S.preset("sr"))
     gf, gt, st, rc = gidx.classify(bases, offs, want_trace=True)
     assert rc == 0
-    assert st["n_ext_unresolved"] == int(big.sum())
-    assert np.all(gf[big] == 1) and np.array_equal(gf[~big], of[~big])
+    assert st["n_ext_unresolved"] == 0 and st["n_ext_ondemand"] >= int(big.sum())      # (a read may need two rounds: 70 -> 280 -> 1120)
+    assert np.array_equal(gf, of)
     for name in ("n_regs", "n_aligned", "dp_max"):
-        assert np.array_equal(gt[name][~big], ot[name][~big]), name
+        assert np.array_equal(gt[name], ot[name]), name
+    assert int(ot["n_chain"].max()) > 280          # the case does hold reads that need the second round
