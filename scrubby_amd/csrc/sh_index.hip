@@ -569,9 +569,72 @@ static sh_status fasta_to_device(const char *path, int32_t device, DevBuf &d_bas
     return SH_OK;
 }
 
+// ---- minimap2 index files (.mmi) ------------------------------------------------------------------------------------------
+// `cleaner.rs:475-479` hands minimap2 whatever path the user gave; minimap2 recognises its own index dump by the magic "MMI\2"
+// (mm_idx_reader_open / mm_idx_load, index.c of v2.28 - restated from the writer, mm_idx_dump: magic; uint32 w, k, b, n_seq, flag; per
+// sequence uint8 name length, name, uint32 length; per bucket (2^b of them) int32 n + n 8-byte positions, uint32 size + size 16-byte
+// (key, value) pairs; then, unless MM_I_NO_SEQ, the sequences as 4-bit codes, eight to a uint32, concatenated).  The minimizer tables are
+// skipped: the index is rebuilt on the device from the sequences with the file's k and w (0.2 s for a human genome), which prevail over
+// the preset's as they do upstream.  Only the first part of a multi-part file is read (as minimap2-rs does).  PARITY UNPINNED: no
+// minimap2 is on this box to write such a file; tests/test_index_mmi.py writes one from the statement above.
+static sh_status mmi_read(const char *path, std::vector<std::vector<uint8_t>> &seqs, int32_t *k_o, int32_t *w_o)
+{
+    FILE *f = fopen(path, "rb");
+    SH_CHECK(f, SH_ERR_IO, "cannot open %s", path);
+    struct Closer { FILE *f; ~Closer() { fclose(f); } } closer{f};
+    char mg[4];
+    uint32_t x[5];
+    SH_CHECK(fread(mg, 1, 4, f) == 4 && memcmp(mg, "MMI\2", 4) == 0, SH_ERR_INDEX, "%s: not a minimap2 index (magic)", path);
+    SH_CHECK(fread(x, 4, 5, f) == 5, SH_ERR_IO, "%s: truncated minimap2 index header", path);
+    const uint32_t w = x[0], k = x[1], b = x[2], n_seq = x[3], flag = x[4];
+    SH_CHECK(k >= 1 && k <= 28 && w >= 1 && w < 256 && b <= 28 && n_seq > 0, SH_ERR_INDEX, "%s: implausible minimap2 index header (k=%u w=%u b=%u n_seq=%u)", path, k, w, b, n_seq);
+    SH_CHECK(!(flag & 1u), SH_ERR_PRESET_UNSUPPORTED, "%s: homopolymer-compressed index (MM_I_HPC) - not implemented on the HIP path", path);
+    SH_CHECK(!(flag & 2u), SH_ERR_INDEX, "%s: index written without sequences (MM_I_NO_SEQ): the extension filter needs the reference bases", path);
+    std::vector<uint32_t> lens(n_seq);
+    uint64_t sum_len = 0;
+    for (uint32_t i = 0; i < n_seq; ++i) {
+        uint8_t l = 0;
+        char name[256];
+        SH_CHECK(fread(&l, 1, 1, f) == 1 && (l == 0 || fread(name, 1, l, f) == l) && fread(&lens[i], 4, 1, f) == 1, SH_ERR_IO, "%s: truncated minimap2 index (sequence table)", path);
+        sum_len += lens[i];
+    }
+    for (uint64_t i = 0; i < (1ull << b); ++i) {      // the minimizer tables: skipped by their counts
+        int32_t n = 0; uint32_t size = 0;
+        SH_CHECK(fread(&n, 4, 1, f) == 1 && n >= 0 && fseeko(f, (off_t)n * 8, SEEK_CUR) == 0 && fread(&size, 4, 1, f) == 1 && fseeko(f, (off_t)size * 16, SEEK_CUR) == 0,
+                 SH_ERR_IO, "%s: truncated minimap2 index (bucket %llu)", path, (unsigned long long)i);
+    }
+    std::vector<uint32_t> S((sum_len + 7) / 8);
+    SH_CHECK(fread(S.data(), 4, S.size(), f) == S.size(), SH_ERR_IO, "%s: truncated minimap2 index (sequences)", path);
+    seqs.assign(n_seq, {});
+    uint64_t o = 0;
+    for (uint32_t i = 0; i < n_seq; ++i) {
+        seqs[i].resize(lens[i]);
+        for (uint32_t j = 0; j < lens[i]; ++j, ++o) { const uint32_t c = S[o >> 3] >> ((o & 7) << 2) & 0xfu; seqs[i][j] = (uint8_t)"ACGTN"[c < 4 ? c : 4]; }
+    }
+    *k_o = (int32_t)k; *w_o = (int32_t)w;
+    return SH_OK;
+}
+
 extern "C" sh_status sh_index_build_fasta(const char *path, const sh_opts *opts, int32_t device, sh_index **out)
 {
     SH_CHECK(path && opts && out, SH_ERR_BAD_ARG, "sh_index_build_fasta: null argument");
+    {
+        FILE *f = fopen(path, "rb");
+        SH_CHECK(f, SH_ERR_IO, "cannot open %s", path);
+        char mg[4] = {0, 0, 0, 0};
+        const size_t got = fread(mg, 1, 4, f);
+        fclose(f);
+        if (got == 4 && memcmp(mg, "MMI\2", 4) == 0) {
+            std::vector<std::vector<uint8_t>> seqs;
+            sh_opts o2 = *opts;
+            sh_status st = mmi_read(path, seqs, &o2.k, &o2.w);
+            if (st != SH_OK) return st;
+            std::vector<const uint8_t *> ptr(seqs.size());
+            std::vector<uint64_t> lens(seqs.size());
+            for (size_t i = 0; i < seqs.size(); ++i) { ptr[i] = seqs[i].data(); lens[i] = seqs[i].size(); }
+            return sh_index_build(ptr.data(), lens.data(), (uint32_t)seqs.size(), &o2, device, out);
+        }
+    }
     if (const char *e = getenv("SCRUBBY_HIP_FASTA_HOST")) if (*e == '1') return shi_index_build_fasta_host(path, opts, device, out);
     DevBuf d_bases;
     std::vector<uint64_t> cs;

@@ -1213,6 +1213,8 @@ extern "C" sh_status sh_reads_run(const sh_reads_config *c, sh_reads_result *res
         const std::string ip = c->index;
         st = ends_with(ip, ".shidx") ? sh_index_load(c->index, c->device, &idx) : sh_index_build_fasta(c->index, &opts, c->device, &idx);
         if (st != SH_OK) return st == SH_ERR_IO ? st : SH_ERR_INDEX;
+        // a prebuilt index (.mmi, .shidx) brings its own k and w; they prevail over the preset's, as with minimap2
+        { sh_index_info ii; if (sh_index_info_get(idx, &ii) == SH_OK) { opts.k = ii.k; opts.w = ii.w; } }
     }
     const auto t1 = now();
 

@@ -243,7 +243,14 @@ class Index:
         L = require_gpu()
         h = C.c_void_p()
         check(L.sh_index_build_fasta(os.fsencode(path), C.byref(opts), device, C.byref(h)))
-        return cls(h, opts)
+        idx = cls(h, opts)
+        info = idx.info()      # a minimap2 index file (.mmi) brings its own k and w: they prevail over the preset's
+        if (info["k"], info["w"]) != (opts.k, opts.w):
+            o2 = Opts()
+            C.memmove(C.byref(o2), C.byref(opts), C.sizeof(Opts))
+            o2.k, o2.w = info["k"], info["w"]
+            idx.opts = o2
+        return idx
 
     @classmethod
     def load(cls, path, opts, device=0):
