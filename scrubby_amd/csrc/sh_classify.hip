@@ -4161,7 +4161,10 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 SH_HIP(hipMemcpyAsync(&c->d_ctr->ext_n_unres, z4, 16, hipMemcpyHostToDevice, s));
                 xa.list = c->d_ext_unres[cur]; xa.n_list = &c->d_ctr->ext_n_unres_in; xa.ticket = &c->d_ctr->ext_ticket_unres;
                 if (buf) { xa.scratch = buf; xa.scratch_per_wave = per; xa.reg_cap = cap; xa.unres_list = c->d_ext_unres[cur ^ 1]; xa.n_unres = &c->d_ctr->ext_n_unres; }
-                else { xa.unres_list = nullptr; xa.n_unres = nullptr; waves = std::min<uint32_t>(c->ext_waves, n_un); }      // no memory to be had: counted, chain-level answer
+                else {      // no memory to be had: counted, chain-level answer (on the context's own working memory: the last round's is freed)
+                    xa.unres_list = nullptr; xa.n_unres = nullptr; waves = std::min<uint32_t>(c->ext_waves, n_un);
+                    xa.scratch = c->d_ext_scratch; xa.scratch_per_wave = c->ext_scratch_per_wave; xa.reg_cap = c->ext_reg_cap;
+                }
                 hipLaunchKernelGGL(k_regs_align, dim3(waves), dim3(64), 0, s, xa);
                 SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
                 SH_HIP(hipStreamSynchronize(s));
