@@ -98,7 +98,7 @@ struct Counters {
     uint32_t lr_fb_why[8], lr_fb_had, lr_pad, lr_probe_why[8];
     uint32_t lext_n_unres, lext_ticket_unres, lext_n_unres_in, lext_pad4, lext_n_exact, lext_ticket_exact, lext_rmq_open, lext_pad5;      // reads beyond the stage's second working-memory size: redone with memory allocated for them
     unsigned long long lext_slow2, lext_slow3, lext_slow_part[4], lext_sum_part[4], lext_clk_big[LR_NCLK], lext_d_big[8], lext_phase_max[LR_NCLK];
-    uint32_t lext_started, lext_pad7;      // SCRUBBY_HIP_DBG: the slowest read of the chains kernel (time << 32 | read length / read)
+    uint32_t lext_started, lext_t0_done;      // SCRUBBY_HIP_DBG: the slowest read of the chains kernel (time << 32 | read length / read)
     unsigned long long stage_cursor;      // k_expand's raw anchors of the reads k_lr_locus will thin out (their own buffer: 12 B per anchor)
 };
 #define SHARD() ((blockIdx.x + (blockIdx.x >> 6)) & 63)
@@ -2948,6 +2948,7 @@ struct ExtLongArgs {
     uint32_t *unres_list, *n_unres;                   // reads that outgrew the large working memory too (with big_list == nullptr): redone with memory sized for them
     const uint32_t *drop; uint32_t *fb_list, *n_fb;   // k_lr_locus: what was left out of a read's anchors; reads that must be redone with every anchor
     uint32_t *started;                                // counts the blocks that have begun (the giants' grid: the main grid is launched once they hold their LDS)
+    const uint32_t *follow_done;                      // k_regs_align_long beside the launch that fills its list: set when that launch has ended
 };
 
 // Largest reads first: a read's cost grows with its chain anchors (one with 70 k of them keeps a wave busy for a third of a second), and a
@@ -3026,7 +3027,11 @@ __global__ void k_lext_giveup(const uint32_t *list, uint32_t n, uint8_t *flags, 
 // a read that outgrew the pass: to the pass with the large working memory, or - beyond that too - it keeps its chain-level answer and is counted
 __device__ inline void lext_defer(const ExtLongArgs &a, uint32_t r, uint32_t code, bool has_hdr)
 {
-    if (a.big_list) { a.big_list[atomicAdd(a.n_big, 1u)] = r; return; }
+    if (a.big_list) {      // (a launch of the second size may be reading the list while it grows: what this wave wrote for the read first, then the entry)
+        __threadfence();
+        __atomic_store_n(&a.big_list[atomicAdd(a.n_big, 1u)], r, __ATOMIC_RELAXED);
+        return;
+    }
     if (a.unres_list) {
         a.unres_list[atomicAdd(a.n_unres, 1u)] = r;
         if (!has_hdr) { LongHdr h{0ull, -1, 0, 0, 0}; a.AR.hdr[r] = h; }      // the regions kernel must not take it before the chains kernel has
@@ -3046,6 +3051,8 @@ __device__ inline void lext_redo(const ExtLongArgs &a, uint32_t r, uint32_t why)
     LongHdr h{0ull, -1, 0, 0, 0}; a.AR.hdr[r] = h;
     atomicAdd(&a.ctr->lr_fb_why[why >= 40u && why < 48u ? why - 40u : 7u], 1u);
 }
+
+__global__ void k_set_word(uint32_t *p, uint32_t v) { if (threadIdx.x == 0 && blockIdx.x == 0) __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 
 // holds a stream until `want` blocks of a kernel on another stream have begun, or ~2 ms have passed (one lane, sleeping between looks)
 __global__ void k_wait_started(const uint32_t *cnt, uint32_t want, uint32_t max_looks)
@@ -3138,11 +3145,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     uint32_t n_regions = 0, n_dropped = 0, n_probed = 0;
     LongClk clk{};
     for (;;) {
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(a.ticket, 1u);
-        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        if (t >= n_list) break;
-        const uint32_t r = a.list[t];
+        uint32_t t = 0, r = 0;
+        if (a.follow_done) {
+            // The list is being filled by the launch of the first size, running beside this one: an entry is taken only when there is one
+            // (compare-and-swap on the ticket, so none is lost when this block gives up), the block sleeps between looks and leaves when the
+            // other launch has ended and the list is empty - or after ~10 s of looks, whatever is left going to the launch that follows.
+            uint32_t got = ~0u, rr = ~0u;
+            if (lane == 0) {
+                for (uint32_t looks = 0; looks < 2000000u; ++looks) {
+                    const uint32_t cur = __atomic_load_n(a.ticket, __ATOMIC_RELAXED), n = __atomic_load_n(a.n_list, __ATOMIC_RELAXED);
+                    if (cur < n) { if (atomicCAS(a.ticket, cur, cur + 1u) == cur) { got = cur; break; } continue; }
+                    if (__atomic_load_n(a.follow_done, __ATOMIC_RELAXED) && __atomic_load_n(a.n_list, __ATOMIC_RELAXED) <= __atomic_load_n(a.ticket, __ATOMIC_RELAXED)) break;
+                    __builtin_amdgcn_s_sleep(127);
+                }
+                if (got != ~0u)
+                    for (uint32_t looks = 0; looks < 2000000u; ++looks) {      // the entry is written right after its index was drawn
+                        rr = __atomic_load_n(&a.list[got], __ATOMIC_RELAXED);
+                        if (rr != ~0u) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                __threadfence();
+            }
+            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)got); r = (uint32_t)__builtin_amdgcn_readfirstlane((int)rr);
+            if (t == ~0u || r == ~0u) break;
+        } else {
+            if (lane == 0) t = atomicAdd(a.ticket, 1u);
+            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            if (t >= n_list) break;
+            r = a.list[t];
+        }
         if (AR_l.hdr[r].n_u < 0) { __syncthreads(); continue; }      // given up by the chains kernel
         LongCtx C;
         C.P = &P_l; C.AP = &AP_l; C.I = &I_l; C.W = &W; C.Ls = &Ls;
@@ -4055,7 +4086,31 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 ExtLongArgs xb = x;
                 xb.scratch = c->d_lext[2]; xb.scratch_per_wave = c->lext_per_wave[2]; xb.sz = c->lext_sz[2];
                 xb.ticket = &c->d_ctr->lext_ticket_b; xb.big_list = c->d_lext_big2; xb.n_big = &c->d_ctr->lext_n_big2;
+                // The launch of the second size runs BESIDE the first (side stream), taking reads off the list as the first launch puts them
+                // there: the pass used to begin when the first had ended, and it is one alignment of ~4 * 10^8 cells on one wave - a third of a
+                // second during which nothing else ran.  Both grids are resident together (two waves per SIMD each: 8 per CU); what the
+                // follower leaves (it gives up after a bounded number of looks) the launch after the first one takes, as before.
+                static const bool no_follow = getenv("SCRUBBY_HIP_NO_FOLLOW") != nullptr;
+                const bool follow = !no_follow && c->lext_waves[2] + c->lext_waves[3] <= 8u * (uint32_t)c->n_cu;
+                if (follow) {
+                    SH_HIP(hipMemsetAsync(c->d_lext_big2, 0xff, (size_t)n_reads * 4, s));
+                    SH_HIP(hipMemsetAsync(&c->d_ctr->lext_t0_done, 0, 4, s));
+                    SH_HIP(hipEventRecord(c->evx[2], s));
+                }
                 hipLaunchKernelGGL(k_regs_align_long, dim3(c->lext_waves[2]), dim3(64), 0, s, xb);
+                if (follow) {
+                    // submitted in this order - first launch, its end mark, then the follower: two streams may share a hardware queue, and
+                    // a follower submitted ahead of the launch it follows would then sit in front of it until its looks ran out
+                    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(64), 0, s, &c->d_ctr->lext_t0_done, 1u);
+                    ExtLongArgs xf = xb;
+                    xf.scratch = c->d_lext[3]; xf.scratch_per_wave = c->lext_per_wave[3]; xf.sz = c->lext_sz[3];
+                    xf.list = c->d_lext_big2; xf.n_list = &c->d_ctr->lext_n_big2; xf.ticket = &c->d_ctr->lext_ticket_big2; xf.big_list = nullptr; xf.n_big = nullptr;
+                    xf.unres_list = c->d_lext_unres[0]; xf.n_unres = &c->d_ctr->lext_n_unres; xf.follow_done = &c->d_ctr->lext_t0_done;
+                    SH_HIP(hipStreamWaitEvent(c->sx[1], c->evx[2], 0));
+                    hipLaunchKernelGGL(k_regs_align_long, dim3(c->lext_waves[3]), dim3(64), 0, c->sx[1], xf);
+                    SH_HIP(hipEventRecord(c->evx[3], c->sx[1]));
+                    SH_HIP(hipStreamWaitEvent(s, c->evx[3], 0));
+                }
                 sh_status st = sync_ctr(); if (st != SH_OK) return st;
                 if (c->h_ctr->lext_n_big2 > 0) {
                     xb.scratch = c->d_lext[3]; xb.scratch_per_wave = c->lext_per_wave[3]; xb.sz = c->lext_sz[3];
