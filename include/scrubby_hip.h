@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SH_VERSION 102   /* 0.1.2: sh_stats grew n_locus_* / n_rmq_exact (round 4); 0.1.1: sh_opts grew the rmq_* fields (round 3); sh_trace has 12 words since 0.1.0's second round */
+#define SH_VERSION 103   /* 0.1.2: sh_stats grew n_locus_* / n_rmq_exact (round 4); 0.1.1: sh_opts grew the rmq_* fields (round 3); sh_trace has 12 words since 0.1.0's second round */
 
 typedef int32_t sh_status;
 enum {
@@ -124,7 +124,7 @@ typedef struct sh_stats {
     uint64_t n_ext_shortcut;   /* SH_F_CIGAR flag-only: reads decided inside a chaining kernel - their top chain's max stretch alone passes mm_filter_regs */
     uint64_t n_ext_fallback;   /* SH_F_CIGAR flag-only, sr: reads whose regs[0] did not survive and that were re-chained with every chain kept */
     double   ms_ext_fallback;  /* wall time of that fallback (re-chaining + the complete procedure) */
-    uint64_t n_ext_unresolved; /* reads beyond the extension stage's working memory (long reads: its largest; sr: 16 384 chains), left at their chain-level answer (see the warning) */
+    uint64_t n_ext_unresolved; /* reads the extension stage left at their chain-level answer, mapped (see the warning): the device had no memory left for them, or - long reads - the long join's window outgrew the 4096-anchor ring on a read of more than SCRUBBY_HIP_RMQ_EXACT_MAX anchors */
     uint64_t n_rmq_rechained;  /* long-read presets: reads re-chained by the RMQ long join */
     uint64_t n_rmq_tied;       /* ... of which met candidates of equal priority in the join in a way that can change the chains (ties that cannot are recognised and pass) */
     uint64_t n_dp_parallel;    /* repeat-path reads whose mg_lchain_dp ran as the parallel recurrence */
@@ -220,6 +220,8 @@ typedef struct sh_reads_result {
     uint64_t reads_in, reads_out, reads_removed, reads_extracted;   /* as in the JSON report (records over both files) */
     uint64_t n_depleted_ids;                                        /* size of the HashSet<String> of cleaner.rs:564-570 */
     double   ms_index, ms_ingest, ms_classify, ms_write;
+    uint64_t n_ext_unresolved;   /* reads the extension stage left at their chain-level answer (mapped); sh_stats of the same name, summed over the run's calls */
+    uint64_t n_rmq_open;         /* long reads whose long join met a tie that matters beyond SCRUBBY_HIP_RMQ_EXACT_MAX anchors (sh_stats.n_rmq_open) */
 } sh_reads_result;
 
 sh_status sh_reads_run(const sh_reads_config *cfg, sh_reads_result *out);

@@ -557,9 +557,12 @@ sh_status shi_reads_run_legacy(const sh_reads_config *c, sh_reads_result *res)
     // classify: aligner.map(..).len() > 0 per record (cleaner.rs:550-558); any per-read error aborts (:566)
     std::vector<uint8_t> flags(ids.size() ? ids.size() : 1, 0);
     bases.resize(bases.size() + 32, 'N');
-    st = sh_classify_batch(idx, &opts, bases.data(), offsets.data(), ids.size(), flags.data(), nullptr, nullptr);
+    sh_stats cs;
+    memset(&cs, 0, sizeof cs);
+    st = sh_classify_batch(idx, &opts, bases.data(), offsets.data(), ids.size(), flags.data(), nullptr, &cs);
     sh_index_free(idx);
     if (st != SH_OK) return st;
+    res->n_ext_unresolved = cs.n_ext_unresolved; res->n_rmq_open = cs.n_rmq_open;
     auto t3 = now();
 
     // id set (cleaner.rs:564-570), then the filter/writer over each input file (clean_reads, :236-254)

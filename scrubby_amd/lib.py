@@ -90,7 +90,8 @@ class ReadsConfig(C.Structure):
 class ReadsResult(C.Structure):
     _fields_ = [("reads_in", C.c_uint64), ("reads_out", C.c_uint64), ("reads_removed", C.c_uint64),
                 ("reads_extracted", C.c_uint64), ("n_depleted_ids", C.c_uint64), ("ms_index", C.c_double),
-                ("ms_ingest", C.c_double), ("ms_classify", C.c_double), ("ms_write", C.c_double)]
+                ("ms_ingest", C.c_double), ("ms_classify", C.c_double), ("ms_write", C.c_double),
+                ("n_ext_unresolved", C.c_uint64), ("n_rmq_open", C.c_uint64)]
 
 
 class ClassifierConfig(C.Structure):
