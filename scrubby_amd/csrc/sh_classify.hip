@@ -3527,7 +3527,9 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             z.cap_a = 16384;
             z.cap_u = z.cap_r = 4096;
             z.cap_m = (uint32_t)std::min<uint64_t>(65536, L / 4 + 1024);
-            z.cap_p = std::min<uint64_t>(8ull << 20, (uint64_t)(2 * z.cap_k) * (z.cap_k + 32));
+            // 2 MB of direction bytes in the first size (8 until the second size's launch ran beside the first: a read that needs more costs
+            // nothing extra now, and the smaller slots are 1700 waves instead of 1100 within the same budget)
+            z.cap_p = std::min<uint64_t>(2ull << 20, (uint64_t)(2 * z.cap_k) * (z.cap_k + 32));
             if (const char *env = getenv("SCRUBBY_HIP_LEXT_P_KB")) z.cap_p = (uint64_t)atoll(env) << 10;
             if (const char *env = getenv("SCRUBBY_HIP_LEXT_A")) { z.cap_a = (uint32_t)std::max(64, atoi(env)); z.cap_u = z.cap_r = std::max(16u, z.cap_a / 4); }      // tests
             LongSizes zb = z;
@@ -3824,6 +3826,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     k.flag_only = d_trace == nullptr && !c->ext;      // SH_F_CIGAR: every chain is needed, no early exit
     k.sink = b.sink; k.emit = c->ext ? 1 : 0; k.BC = b.BC; k.t_mode = (c->ext && !c->ext_long && d_trace == nullptr) ? 1 : 0;
     k.dbg = getenv("SCRUBBY_HIP_DBG") ? atoi(getenv("SCRUBBY_HIP_DBG")) : 0;
+    if (!getenv("SCRUBBY_HIP_AB_NOCHAIN")) k.dbg &= ~3;      // bits 0 / 1 switch the class kernels' chaining OFF (timing A/Bs: the answers are then wrong) - only with this second switch
     if (getenv("SCRUBBY_HIP_NO_PARFILL")) k.dbg |= 128;      // A/B: every cluster chained by the sequential DP
     k.top_max = TOPBT_MAX; k.pft_gmin = 32768u;
     if (const char *env = getenv("SCRUBBY_HIP_PFT_GMIN")) k.pft_gmin = (uint32_t)std::max(1, atoi(env));
