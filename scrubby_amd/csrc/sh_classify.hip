@@ -3265,8 +3265,10 @@ struct sh_ctx {
     SortItem *d_locus[3] = {}; uint32_t *d_lr_drop = nullptr, *d_lr_fb = nullptr; int locus_shift = 0;
     uint64_t *d_stage_x = nullptr; uint32_t *d_stage_q = nullptr; uint64_t stage_cap = 0;      // raw anchors of the reads k_lr_locus thins out
     hipStream_t sx[4] = {};          // side streams: K2 and the sort classes run beside the main stream
+    int side_pick[2] = {0, 1};       // long reads: the side streams of the giants' launch and of the follower (pick_side_streams)
+    hipStream_t side_probed = nullptr; bool side_probed_done = false;
     int par = 1;                     // bit 0: K2 on a side stream (SCRUBBY_HIP_STREAMS=0: on the main stream)
-    hipEvent_t evx[6] = {};
+    hipEvent_t evx[8] = {};
 };
 
 static void fill_chain_params(const sh_opts &o, int32_t mid_occ, ChainParams &P)
@@ -3603,7 +3605,8 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
     }
     for (auto &ev : c->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "event");
     for (auto &ev : c->evx) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail(e, "event");
-    for (auto &st : c->sx) if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return fail(e, "stream");
+    // (the side streams are created when a call first needs one: HIP deals its hardware queues - four by default - out to the streams that
+    // exist, and a side stream that shares the caller's queue runs after it, not beside it)
     if (const char *env = getenv("SCRUBBY_HIP_STREAMS")) c->par = atoi(env);
     *out = c;
     return SH_OK;
@@ -3654,6 +3657,53 @@ static void launch_long(const LongArgs &a, hipStream_t s)
     hipLaunchKernelGGL(k_long_probe, dim3(256 * 16), dim3(64), 0, s, a);
 }
 
+static sh_status ensure_side_streams(sh_ctx *c, int first, int last)
+{
+    for (int i = first; i <= last; ++i)
+        if (!c->sx[i]) SH_HIP(hipStreamCreateWithFlags(&c->sx[i], hipStreamNonBlocking));
+    return SH_OK;
+}
+
+// one wave busy for `ticks` of the 100 MHz clock (bounded)
+__global__ void k_spin(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+// Which side streams run BESIDE the caller's stream?  HIP deals a few hardware queues out to the streams of a process, and two streams on
+// one queue take turns.  Measured once per (context, caller's stream): a 200-us kernel on each side stream beside one on the caller's - both
+// done after ~200 us (side by side) or ~400 (one after the other).  The giants' launch gets the first stream found to run beside, the
+// follower the second; when none does the launches run in turn, which is merely slower.
+static sh_status pick_side_streams(sh_ctx *c, hipStream_t s)
+{
+    if (c->side_probed_done && c->side_probed == s) return SH_OK;
+    sh_status es = ensure_side_streams(c, 0, 2);
+    if (es != SH_OK) return es;
+    hipEvent_t t0 = nullptr, t1 = nullptr, e = nullptr;
+    SH_HIP(hipEventCreate(&t0)); SH_HIP(hipEventCreate(&t1)); SH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    float ms[3] = {1e9f, 1e9f, 1e9f};
+    for (int i = 0; i < 3; ++i) {
+        SH_HIP(hipStreamSynchronize(s));
+        SH_HIP(hipEventRecord(t0, s));
+        SH_HIP(hipStreamWaitEvent(c->sx[i], t0, 0));
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, 20000ull);
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->sx[i], 20000ull);
+        SH_HIP(hipEventRecord(e, c->sx[i]));
+        SH_HIP(hipStreamWaitEvent(s, e, 0));
+        SH_HIP(hipEventRecord(t1, s));
+        SH_HIP(hipEventSynchronize(t1));
+        SH_HIP(hipEventElapsedTime(&ms[i], t0, t1));
+    }
+    hipEventDestroy(t0); hipEventDestroy(t1); hipEventDestroy(e);
+    int ord[3] = {0, 1, 2};
+    std::sort(ord, ord + 3, [&](int a, int b) { return ms[a] < ms[b]; });
+    c->side_pick[0] = ord[0]; c->side_pick[1] = ord[1];
+    c->side_probed = s; c->side_probed_done = true;
+    if (getenv("SCRUBBY_HIP_DBG")) fprintf(stderr, "[dbg] side streams beside the caller's: %.2f %.2f %.2f ms for two 0.2-ms kernels; giants on %d, follower on %d\n", ms[0], ms[1], ms[2], c->side_pick[0], c->side_pick[1]);
+    return SH_OK;
+}
+
 // one pass of the repeat path over list[*count]: expand -> sort -> DP -> finalize
 static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
 {
@@ -3680,6 +3730,7 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     // 39.3 -> 36.6 ms at 2.5 M records; at 20 M it costs 2 % (SCRUBBY_HIP_SIDE=0 / 1 forces either)
     const bool gp = k.flag_only && k.P.flag_stop != INT32_MAX && !(k.dbg & 64);      // k_group_probe runs (chain-level decision): the class-4 and giant kernels must follow it
     const bool side = side_env > 0 || (side_env < 0 && !gp && c->cur_reads <= 3000000ull);
+    if (side) { sh_status es = ensure_side_streams(c, 0, 2); if (es != SH_OK) return es; }
     hipStream_t s0 = side ? c->sx[0] : s, s1 = side ? c->sx[1] : s, g = side ? c->sx[2] : s;
     const bool use_pf = (k.emit || !k.flag_only) && !(k.dbg & 128);
     const bool use_top = use_pf && k.emit && k.sink.best != nullptr && !(k.dbg & 512);
@@ -3713,9 +3764,10 @@ static sh_status big_pass(sh_ctx *c, K3Args k, uint32_t grid, hipStream_t s)
     const bool two_phase = k.t_mode && k.sink.best != nullptr;
     if (use_pf) hipLaunchKernelGGL(k_giant_top, dim3(1024), dim3(512), 0, g, k);
     hipLaunchKernelGGL(k_giant_chain, dim3(1024), dim3(512), 0, g, k, two_phase ? 0 : -1);
-    if (side && k.cl_lds) {      // the LDS classes feed k_cluster_dp's queue too
+    if (side && k.cl_lds) {      // the LDS classes feed k_cluster_dp's queue too - all of them: the 512 class runs on the main stream
         SH_HIP(hipEventRecord(c->evx[1], c->sx[0])); SH_HIP(hipStreamWaitEvent(g, c->evx[1], 0));
         SH_HIP(hipEventRecord(c->evx[2], c->sx[1])); SH_HIP(hipStreamWaitEvent(g, c->evx[2], 0));
+        SH_HIP(hipEventRecord(c->evx[6], s)); SH_HIP(hipStreamWaitEvent(g, c->evx[6], 0));
     }
     if (!(k.dbg & 32)) hipLaunchKernelGGL(k_cluster_dp, dim3(256 * 7), dim3(256), 0, g, k);      // 72 VGPRs: 7 waves per SIMD (4: 74 ms, 6: 60, 8 with spills: 57)
     if (two_phase) {
@@ -3802,6 +3854,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
     const bool k2_late = c->use_k1 && (c->par & 1) && k2_late_env > 0;
     K2Args kb = b;
     auto launch_k2 = [&]() -> sh_status {
+        if (c->par & 1) { sh_status es = ensure_side_streams(c, 3, 3); if (es != SH_OK) return es; }
         hipStream_t sk = (c->par & 1) ? c->sx[3] : s;
         SH_HIP(hipEventRecord(c->evx[4], s));
         SH_HIP(hipStreamWaitEvent(sk, c->evx[4], 0));
@@ -3951,6 +4004,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         x.clk = getenv("SCRUBBY_HIP_DBG") ? 1 : 0; x.probe = getenv("SCRUBBY_HIP_NO_PROBE") ? 0 : 1;
         x.drop = k.locus ? c->d_lr_drop : nullptr; x.fb_list = c->d_lr_fb; x.n_fb = &c->d_ctr->lr_n_fb;
         x.exact_list = c->d_lext_exact_list; x.n_exact = &c->d_ctr->lext_n_exact;
+        { sh_status ps = pick_side_streams(c, s); if (ps != SH_OK) return ps; }
         SH_HIP(hipEventRecord(c->ev_ext[0], s));
         auto sync_ctr = [&]() -> sh_status {
             SH_HIP(hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -4035,10 +4089,11 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 xg.started = &c->d_ctr->lext_started;
                 SH_HIP(hipMemsetAsync(&c->d_ctr->lext_started, 0, 4, s));
                 SH_HIP(hipEventRecord(c->evx[0], s));
-                SH_HIP(hipStreamWaitEvent(c->sx[0], c->evx[0], 0));
+                hipStream_t sg = c->sx[c->side_pick[0]];
+                SH_HIP(hipStreamWaitEvent(sg, c->evx[0], 0));
                 const uint32_t m_waves = c->lext_waves[0];
-                hipLaunchKernelGGL((k_long_chains<4096, false, false>), dim3(g_waves), dim3(64), 0, c->sx[0], xg);
-                SH_HIP(hipEventRecord(c->evx[1], c->sx[0]));
+                hipLaunchKernelGGL((k_long_chains<4096, false, false>), dim3(g_waves), dim3(64), 0, sg, xg);
+                SH_HIP(hipEventRecord(c->evx[1], sg));
                 hipLaunchKernelGGL(k_wait_started, dim3(1), dim3(64), 0, s, (const uint32_t *)&c->d_ctr->lext_started, g_waves, 2000u);
                 hipLaunchKernelGGL((k_long_chains<512, false, false>), dim3(m_waves), dim3(64), 0, s, xa);
                 SH_HIP(hipStreamWaitEvent(s, c->evx[1], 0));
@@ -4109,9 +4164,10 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                     xf.scratch = c->d_lext[3]; xf.scratch_per_wave = c->lext_per_wave[3]; xf.sz = c->lext_sz[3];
                     xf.list = c->d_lext_big2; xf.n_list = &c->d_ctr->lext_n_big2; xf.ticket = &c->d_ctr->lext_ticket_big2; xf.big_list = nullptr; xf.n_big = nullptr;
                     xf.unres_list = c->d_lext_unres[0]; xf.n_unres = &c->d_ctr->lext_n_unres; xf.follow_done = &c->d_ctr->lext_t0_done;
-                    SH_HIP(hipStreamWaitEvent(c->sx[1], c->evx[2], 0));
-                    hipLaunchKernelGGL(k_regs_align_long, dim3(c->lext_waves[3]), dim3(64), 0, c->sx[1], xf);
-                    SH_HIP(hipEventRecord(c->evx[3], c->sx[1]));
+                    hipStream_t sf = c->sx[c->side_pick[1]];
+                    SH_HIP(hipStreamWaitEvent(sf, c->evx[2], 0));
+                    hipLaunchKernelGGL(k_regs_align_long, dim3(c->lext_waves[3]), dim3(64), 0, sf, xf);
+                    SH_HIP(hipEventRecord(c->evx[3], sf));
                     SH_HIP(hipStreamWaitEvent(s, c->evx[3], 0));
                 }
                 sh_status st = sync_ctr(); if (st != SH_OK) return st;
