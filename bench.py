@@ -60,6 +60,7 @@ def parse():
                          "k2 = configs[4] stand-in: Kraken2-style taxid classification of 2x150 bp pairs against an 8 GB table (not the headline metric)")
     ap.add_argument("--k2-cells", type=int, default=2_000_000_000, help="cells of the compact hash table (4 B each)")
     ap.add_argument("--k2-nodes", type=int, default=50_000, help="taxonomy nodes of the synthetic database")
+    ap.add_argument("--ont-preset", default="map-ont", choices=["map-ont", "lr:hq", "map-hifi"], help="preset of --workload ont (the bench line is map-ont; the others are parity checks at scale)")
     ap.add_argument("--ont-chunk", type=int, default=1_000_000, help="long reads per launch (--workload ont): a launch pays the extension stage's longest single reads once, so fewer, larger launches are faster; 1 M reads (6.3 Gbases) is what a 288 GB device holds")
     ap.add_argument("--e2e-threads", type=int, default=0, help="-t of `scrubby reads` for --workload e2e (0: the usable cores - physical, capped by the cgroup quota)")
     ap.add_argument("--e2e-gz", action="store_true", help="--workload e2e: write .fastq.gz outputs")
@@ -139,7 +140,7 @@ def main_reads(a, rank, world, local, dev, backend):
     # long reads: 2 % substitutions + 1.56 % insertions + 1.56 % deletions (n_read_pct = 1 switches the generator's indels on)
     R = S.read_params(0x5C2B0020, host_pct=50, sub_per_10k=200, n_read_pct=1) if ont else S.read_params(READ_SEED)
     G = P.genome_len
-    opts = S.preset("map-ont" if ont else "sr")
+    opts = S.preset(a.ont_preset if ont else "sr")
     if a.chain_only:
         opts.flags &= ~S.SH_F_CIGAR
 
@@ -313,13 +314,13 @@ def main_reads(a, rank, world, local, dev, backend):
     # ---- CPU baseline: the oracle on the host cores, same index, bounded sample -------------------------
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
-        cpu = cpu_baseline(index, info, d_reads, n_rec, L, a.cpu_seconds, d_flags, d_off if ont else None, "map-ont" if ont else "sr", a.chain_only)
+        cpu = cpu_baseline(index, info, d_reads, n_rec, L, a.cpu_seconds, d_flags, d_off if ont else None, a.ont_preset if ont else "sr", a.chain_only)
     strat = None
     if rank == 0 and world == 1 and not a.no_cpu and not ont and not a.chain_only and ctx_chunk(a, n_rec) >= n_rec:
         strat = stratified_parity(index, ctx, info, d_reads, d_flags, n_rec, L)
     ext_oracle = None
     if rank == 0 and world == 1 and not a.no_cpu:      # the real tool, when the box has it: `-c -x sr` / `-c -x map-ont`
-        ext_oracle = external_oracle(index, d_reads, n_rec, L, d_flags, contigs, P, dev, real_ref, preset="map-ont" if ont else "sr", d_off=d_off if ont else None)
+        ext_oracle = external_oracle(index, d_reads, n_rec, L, d_flags, contigs, P, dev, real_ref, preset=a.ont_preset if ont else "sr", d_off=d_off if ont else None)
 
     # ---- the host-buffer entry point (sh_classify_batch: what a Rust caller binds), PCIe included; never `value` -----------
     host_path = None
@@ -363,7 +364,7 @@ def main_reads(a, rank, world, local, dev, backend):
                              ("configs[2]: the 10M synthetic 2x150bp PE (20M records) of configs[1], read-sharded over %d GPUs, vs CHM13v2-sized synthetic reference, sr preset" % world) if world > 1 else
                              "configs[1]: 10M synthetic 2x150bp PE (20M records) vs CHM13v2-sized synthetic reference, sr preset, k-mer/minimizer classifier path"),
                 "records_total": n_total, "records_rank0": n_rec, "read_len": (round(n_bases / n_rec, 1) if ont else L), "host_pct": R.host_pct, "reference_bp": int(G),
-                "preset": "map-ont" if ont else "sr", "decision": ("chain level (--chain-only: no extension stage)" if a.chain_only else
+                "preset": a.ont_preset if ont else "sr", "decision": ("chain level (--chain-only: no extension stage)" if a.chain_only else
                                                                       "mappings.len() > 0 after the long-read branch of the extension filter (with_cigar): RMQ long join, mm_est_err, gap-filling alignment, mm_filter_regs" if ont else
                                                                       "mappings.len() > 0 after the extension filter (with_cigar)"), "k": info["k"], "w": info["w"], "records_per_launch": ctx_chunk(a, n_rec),
                 "parallelism": f"read-sharded x{world} (contiguous pair-aligned ranges of the same records), index replicated",
