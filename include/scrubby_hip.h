@@ -401,6 +401,9 @@ sh_status sh_bench_gather(const sh_index *idx, uint64_t n_probes, int32_t iters,
  * heavily tied priorities (the generator of oracle/mm_rmq.c's mmo_rmq_trace) and returns, per query, the element the tree answered with
  * (its i, or -1); cache = entries of the LDS node cache (0: none, else a power of two <= 1024).  out: host array of n_ops int64. */
 sh_status sh_dbg_rmq_trace(int32_t device, uint64_t seed, int32_t n_ops, int32_t key_range, int32_t fifo, int32_t cache, int64_t *out, int64_t *n_out);
+/* test aid: the wave primitives of csrc/sh_wave.h (DPP scans / reductions / broadcasts) on one wave of inputs: 12 x 64 int32 and 9 x 64 uint64
+ * results in the order of k_dbg_wave_ops (tests/test_wave_ops_gpu.py compares them with numpy) */
+sh_status sh_dbg_wave_ops(int32_t device, const int32_t *in32, const uint64_t *in64, int32_t bcast_lane, int32_t *out32, uint64_t *out64);
 
 #ifdef __cplusplus
 }

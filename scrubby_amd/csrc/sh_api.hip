@@ -633,3 +633,36 @@ extern "C" sh_status sh_dbg_rmq_trace(int32_t device, uint64_t seed, int32_t n_o
     hipFree(pool); hipFree(ly); hipFree(li); hipFree(d_out); hipFree(d_n);
     return SH_OK;
 }
+
+// ---- test aid: the wave primitives of sh_wave.h against plain arithmetic (tests/test_wave_ops_gpu.py) -----------------------------------
+#include "sh_wave.h"
+__global__ void k_dbg_wave_ops(const int32_t *in32, const unsigned long long *in64, int32_t bl, int32_t *o32, unsigned long long *o64)
+{
+    const int lane = threadIdx.x;
+    const int32_t v = in32[lane];
+    const unsigned long long w = in64[lane];
+    int32_t r32[12];
+    r32[0] = wave_scan_max_incl(v); r32[1] = wave_scan_min_incl(v); r32[2] = wave_scan_add_incl(v); r32[3] = wave_scan_or_incl(v);
+    r32[4] = wave_shr1(v, -7); r32[5] = wave_all_max(v); r32[6] = wave_all_min(v); r32[7] = wave_all_add(v);
+    r32[8] = (int32_t)wave_all_or((uint32_t)v); r32[9] = (int32_t)wave_all_max_u32((uint32_t)v); r32[10] = (int32_t)wave_all_min_u32((uint32_t)v);
+    r32[11] = wave_bcast(v, bl);
+    for (int i = 0; i < 12; ++i) o32[i * 64 + lane] = r32[i];
+    unsigned long long r64[9];
+    r64[0] = (unsigned long long)wave_scan_max_incl_i64((long long)w); r64[1] = wave_scan_max_incl_u64(w); r64[2] = wave_scan_min_incl_u64(w);
+    r64[3] = wave_scan_add_incl_u64(w); r64[4] = (unsigned long long)wave_all_max_i64((long long)w); r64[5] = wave_all_max_u64(w);
+    r64[6] = wave_all_min_u64(w); r64[7] = wave_bcast_u64(w, bl); r64[8] = wave_shr1_u64(w, 99ull);
+    for (int i = 0; i < 9; ++i) o64[i * 64 + lane] = r64[i];
+}
+extern "C" sh_status sh_dbg_wave_ops(int32_t device, const int32_t *in32, const uint64_t *in64, int32_t bcast_lane, int32_t *out32, uint64_t *out64)
+{
+    SH_CHECK(in32 && in64 && out32 && out64 && bcast_lane >= 0 && bcast_lane < 64, SH_ERR_BAD_ARG, "sh_dbg_wave_ops: bad argument");
+    SH_HIP(hipSetDevice(device));
+    int32_t *d_i = nullptr, *d_o = nullptr; unsigned long long *d_i64 = nullptr, *d_o64 = nullptr;
+    SH_HIP(hipMalloc(&d_i, 256)); SH_HIP(hipMalloc(&d_i64, 512)); SH_HIP(hipMalloc(&d_o, 12 * 256)); SH_HIP(hipMalloc(&d_o64, 9 * 512));
+    SH_HIP(hipMemcpy(d_i, in32, 256, hipMemcpyHostToDevice)); SH_HIP(hipMemcpy(d_i64, in64, 512, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_dbg_wave_ops, dim3(1), dim3(64), 0, 0, d_i, d_i64, bcast_lane, d_o, d_o64);
+    SH_HIP(hipDeviceSynchronize());
+    SH_HIP(hipMemcpy(out32, d_o, 12 * 256, hipMemcpyDeviceToHost)); SH_HIP(hipMemcpy(out64, d_o64, 9 * 512, hipMemcpyDeviceToHost));
+    hipFree(d_i); hipFree(d_i64); hipFree(d_o); hipFree(d_o64);
+    return SH_OK;
+}

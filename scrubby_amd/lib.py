@@ -127,7 +127,7 @@ EXPORTS = [
     "sh_index_build", "sh_index_build_device", "sh_index_build_fasta", "sh_index_save", "sh_index_load",
     "sh_index_info_get", "sh_index_export", "sh_index_export_ref", "sh_index_free",
     "sh_ctx_create", "sh_ctx_destroy", "sh_ctx_debug_list", "sh_classify_device", "sh_classify_batch",
-    "sh_synth_ref_device", "sh_synth_reads_device", "sh_synth_long_reads_device", "sh_bench_gather", "sh_dbg_rmq_trace", "sh_pack_flags_device",
+    "sh_synth_ref_device", "sh_synth_reads_device", "sh_synth_long_reads_device", "sh_bench_gather", "sh_dbg_rmq_trace", "sh_dbg_wave_ops", "sh_pack_flags_device",
     "sh_reads_run", "sh_release_cached_ctx", "sh_host_get_id", "sh_host_filter_fastx", "sh_host_filter_fastx_stream", "sh_host_read_difference",
     "sh_classifier_run", "sh_classifier_taxids", "sh_alignment_run",
     "sh_k2_default_opts", "sh_k2_open", "sh_k2_create", "sh_k2_insert_device", "sh_k2_insert_sequence_device",
@@ -172,6 +172,7 @@ def load():
     L.sh_synth_long_reads_device.argtypes = [C.POINTER(RefParams), C.POINTER(ReadParams), u64, u64, vp, u64, vp, vp]
     L.sh_bench_gather.argtypes = [vp, u64, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.sh_dbg_rmq_trace.argtypes = [i32, u64, i32, i32, i32, i32, vp, vp]
+    L.sh_dbg_wave_ops.argtypes = [i32, vp, vp, i32, vp, vp]
     L.sh_pack_flags_device.argtypes = [vp, u64, vp, vp]
     L.sh_reads_run.argtypes = [C.POINTER(ReadsConfig), C.POINTER(ReadsResult)]
     L.sh_classifier_run.argtypes = [C.POINTER(ClassifierConfig), C.POINTER(ReadsResult)]
