@@ -73,6 +73,10 @@ def parse():
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the secondary weak-scaling measurement (20 M records per GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather-bench", action="store_true", help="also time raw 16-B random gathers over the table")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="headline run (--workload sr, one GPU): skip the `secondary` object - configs[3] (long reads, map-ont) and configs[4] (Kraken2-style) "
+                         "measured in the same process AFTER the headline's timed region")
+    ap.add_argument("--secondary-cpu-seconds", type=float, default=8.0, help="CPU-oracle sample of each secondary line")
     return ap.parse_args()
 
 
@@ -119,13 +123,48 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     S.require_gpu()
-    if a.workload == "k2":
-        return main_k2(a, rank, world, local, dev, backend)
     if a.workload == "e2e":
         return main_e2e(a, rank, world, local, dev)
     if a.workload == "e2e-k2":
         return main_e2e_k2(a, rank, world, local, dev)
-    return main_reads(a, rank, world, local, dev, backend)
+    out = main_k2(a, rank, world, local, dev, backend) if a.workload == "k2" else main_reads(a, rank, world, local, dev, backend)
+    if out is not None and a.workload == "sr" and world == 1 and not a.chain_only and not a.no_secondary:
+        out["secondary"] = secondary_lines(a, rank, local, dev)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def secondary_lines(a, rank, local, dev):
+    """configs[3] and configs[4] in the headline's own run, so that the driver's clock witnesses them too: measured after the headline's timed
+    region has ended and its buffers are freed (nothing here touches `value` / `ms_per_step` / `roofline` of the headline).  Each entry is the
+    line `--workload ont` / `--workload k2` prints, cut to what a reader checks: value, ms_per_step, roofline (with PMC traffic), the
+    long-read stage's exactness counters, a small CPU-oracle sample (and, for long reads, the stratified check over every read whose answer
+    took a path with a documented limit)."""
+    import copy
+    import gc
+    sec = {"note": "measured in this process after the headline's timed region; not part of value / ms_per_step / roofline above"}
+    for name, steps, warm in (("ont", 1, 1), ("k2", 3, 1)):
+        gc.collect()
+        S.release_cached_context()
+        torch.cuda.empty_cache()
+        b = copy.copy(a)
+        b.workload, b.steps, b.warmup, b.cpu_seconds, b.gather_bench = name, steps, warm, a.secondary_cpu_seconds, False
+        b.records = 20_000_000      # the sentinel both workloads read as "BASELINE's own size"
+        t0 = time.time()
+        try:
+            o = main_k2(b, rank, 1, local, dev, None) if name == "k2" else main_reads(b, rank, 1, local, dev, None)
+        except Exception as e:      # a secondary line must never take the headline with it
+            sec[name] = {"error": f"{type(e).__name__}: {e}"}
+            continue
+        keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "data", "roofline", "cpu_baseline", "stratified_parity", "result", "database")
+        e = {k: o[k] for k in keep if k in o}
+        e["workload"] = o["config"]["workload"]
+        e["wall_s_incl_setup"] = round(time.time() - t0, 1)
+        sec[name] = e
+    return sec
 
 
 def main_reads(a, rank, world, local, dev, backend):
@@ -318,6 +357,9 @@ def main_reads(a, rank, world, local, dev, backend):
     strat = None
     if rank == 0 and world == 1 and not a.no_cpu and not ont and not a.chain_only and ctx_chunk(a, n_rec) >= n_rec:
         strat = stratified_parity(index, ctx, info, d_reads, d_flags, n_rec, L)
+    if rank == 0 and world == 1 and not a.no_cpu and ont and not a.chain_only:
+        # every read whose answer took one of the long-read stage's rarer paths (of the whole batch: the lists describe the last CALL), plus a random rest
+        strat = stratified_parity_long(index, ctx, info, d_reads, d_off, d_flags, n_rec, a.ont_preset, a.cpu_seconds)
     ext_oracle = None
     if rank == 0 and world == 1 and not a.no_cpu:      # the real tool, when the box has it: `-c -x sr` / `-c -x map-ont`
         ext_oracle = external_oracle(index, d_reads, n_rec, L, d_flags, contigs, P, dev, real_ref, preset=a.ont_preset if ont else "sr", d_off=d_off if ont else None)
@@ -394,9 +436,8 @@ def main_reads(a, rank, world, local, dev, backend):
         }
         if gather:
             out["gather_ceiling"] = gather
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 def k2_taxonomy(n_nodes, seed):
@@ -568,11 +609,8 @@ def main_k2(a, rank, world, local, dev, backend=None):
                             "build_s": round(t_db, 2)},
                "roofline": roof, "cpu_baseline": cpu,
                "external_oracle": (external_oracle_k2(db, d_reads, n_rec // 2, L, res["taxid"]) if world == 1 and not a.no_cpu else None)}
-        print(json.dumps(out))
     db.close()
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    return out if rank == 0 else None
 
 
 def fastq_file(path, reads, mate, first_ordinal):
@@ -998,6 +1036,66 @@ def stratified_parity(index, ctx, info, d_reads, d_flags, n_rec, L, n_random=300
     out = {"reads_checked": int(len(pick)), "flags_differing": int(bad.sum()), "oracle_s": round(dt, 1),
            "strata": {nm: {"reads": int(len(v)), "flags_differing": int(bad[np.isin(pick, v)].sum())} for nm, v in strata.items()},
            "random_rest": {"reads": int(len(rest)), "flags_differing": int(bad[len(special):].sum())}}
+    return out
+
+
+LONG_STRATA = ((3, "rmq_exact_tree"), (4, "rmq_tie_left_open"), (5, "ext_unresolved"), (6, "locus_redone"), (7, "memory_on_demand"),
+               (8, "probe_undecided_full_procedure"), (9, "second_working_memory_size"), (10, "one_lane_trees"))
+
+
+def stratified_parity_long(index, ctx, info, d_reads, d_off, d_flags, n_rec, preset, seconds, seed=20261005, cap_per_stratum=4000):
+    """The long-read form of stratified_parity: the oracle over EVERY read of the batch (the last call of `ctx`: sh_ctx_debug_list 3..10) whose
+    answer came by one of the extension stage's rarer paths - long join redone on the literal tree, a tie left open, left at the chain-level
+    answer, redone with every anchor, memory on demand, probe undecided, second working-memory size, one-lane trees - plus a random rest that
+    fills `seconds` of CPU time.  A stratum larger than cap_per_stratum is sampled (and says so)."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    strata, sampled = {}, {}
+    for which, nm in LONG_STRATA:
+        v = np.unique(ctx.debug_list(which).astype(np.int64))
+        v = v[v < n_rec]
+        sampled[nm] = int(len(v))
+        if len(v) > cap_per_stratum:
+            v = np.sort(rng.choice(v, size=cap_per_stratum, replace=False))
+        strata[nm] = v
+    special = np.unique(np.concatenate(list(strata.values()))) if strata else np.zeros(0, np.int64)
+    off_all = d_off.cpu().numpy().astype(np.int64)
+    slots, pos = index.export()
+    oidx = O.Index.wrap(slots, pos, info["w"], info["k"], ref=index.export_ref())
+    oo = oidx.update_opts(O.preset(preset))
+    cores = usable_cores()
+
+    def run(pick):
+        lens = off_all[pick + 1] - off_all[pick]
+        o = np.zeros(len(pick) + 1, dtype=np.uint64)
+        o[1:] = np.cumsum(lens)
+        rows = torch.cat([d_reads[off_all[r]:off_all[r + 1]] for r in pick]).cpu().numpy() if len(pick) else np.zeros(0, np.uint8)
+        t0 = time.perf_counter()
+        of, _ = oidx.classify(oo, rows, o, threads=cores, want_trace=False)
+        return of, time.perf_counter() - t0
+
+    out = {"strata": {}, "flags_differing": 0, "reads_checked": 0}
+    gflags = d_flags.cpu().numpy()
+    t_special = 0.0
+    if len(special):
+        of, t_special = run(special)
+        bad = of != gflags[special]
+        out["flags_differing"] += int(bad.sum()); out["reads_checked"] += int(len(special))
+        for nm, v in strata.items():
+            out["strata"][nm] = {"reads_in_batch": sampled[nm], "reads_checked": int(len(v)), "flags_differing": int(bad[np.isin(special, v)].sum())}
+    else:
+        for nm in strata:
+            out["strata"][nm] = {"reads_in_batch": 0, "reads_checked": 0, "flags_differing": 0}
+    # the random rest: sized by what the special reads cost per read (they are the expensive ones: an upper bound), at least 2000 reads
+    left = max(seconds - t_special, 3.0)
+    per = (t_special / len(special)) if len(special) else 0.01
+    n_rest = int(min(n_rec, max(2000, left / max(per, 1e-4) * 4)))
+    rest = np.setdiff1d(np.sort(rng.choice(n_rec, size=min(n_rest, n_rec), replace=False)).astype(np.int64), special)
+    of, t_rest = run(rest)
+    bad = of != gflags[rest]
+    out["flags_differing"] += int(bad.sum()); out["reads_checked"] += int(len(rest))
+    out["random_rest"] = {"reads": int(len(rest)), "flags_differing": int(bad.sum())}
+    out["oracle_s"] = round(t_special + t_rest, 1)
     return out
 
 

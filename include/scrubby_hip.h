@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SH_VERSION 103   /* 0.1.2: sh_stats grew n_locus_* / n_rmq_exact (round 4); 0.1.1: sh_opts grew the rmq_* fields (round 3); sh_trace has 12 words since 0.1.0's second round */
+#define SH_VERSION 104   /* 0.1.3: sh_index_replicate / sh_classify_sharded, sh_ctx_debug_list 3..10, the long join's tree in LDS (round 5); 0.1.2: sh_stats grew n_locus_* / n_rmq_exact (round 4); 0.1.1: sh_opts grew the rmq_* fields (round 3); sh_trace has 12 words since 0.1.0's second round */
 
 typedef int32_t sh_status;
 enum {
@@ -179,9 +179,14 @@ sh_status sh_index_free(sh_index *idx);
 sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uint64_t max_reads, uint64_t max_bases,
                         uint32_t max_read_len, sh_ctx **out);
 sh_status sh_ctx_destroy(sh_ctx *ctx);
-/* Measurement aid (bench.py's stratified parity sample): which reads of the LAST chunk the context classified took the rare paths of
- * the short-read extension stage.  which = 0: re-chained with max_occ (mm_map_frag's second pass), 1: regs[0] aligned base by base,
- * 2: the complete procedure over every chain.  Read ordinals within that chunk; *n_out = their number (out may be NULL). */
+/* Measurement aid (bench.py's stratified parity sample): which reads the context classified took the rarer paths.
+ * Short-read extension stage, reads of the LAST CHUNK (ordinals within it): which = 0: re-chained with max_occ (mm_map_frag's second
+ * pass), 1: regs[0] aligned base by base, 2: the complete procedure over every chain.
+ * Long-read extension stage, reads of the LAST CALL (ordinals within it): which = 3: long join redone with the literal krmq tree beside the
+ * scan (a tie that matters, or a window beyond the first ring), 4: tie left open (only with SCRUBBY_HIP_RMQ_EXACT_MAX >= 0), 5: left at the
+ * chain-level answer (sh_stats.n_ext_unresolved), 6: redone with every anchor after the locus selection, 7: working memory allocated on
+ * demand, 8: probe undecided - the complete procedure answered, 9: second working-memory size, 10: long join on the one-lane trees.
+ * *n_out = their number (out may be NULL). */
 sh_status sh_ctx_debug_list(const sh_ctx *ctx, int32_t which, uint32_t *out, uint64_t cap, uint64_t *n_out);
 
 /* Inputs and outputs in HBM.  d_flags[r] = 1 host (>=1 mapping), 0 retained, 2 empty read.
@@ -197,6 +202,23 @@ sh_status sh_classify_device(sh_ctx *ctx, const uint8_t *d_bases, const uint64_t
  * per-read Err aborts the run. */
 sh_status sh_classify_batch(const sh_index *idx, const sh_opts *opts, const uint8_t *bases, const uint64_t *offsets,
                             uint64_t n_reads, uint8_t *out_flags, sh_trace *out_trace, sh_stats *stats);
+
+/* ---- in-process multi-GPU (SURVEY.md 8(b) "Threading", 8(e)) -------------------------------------------------------
+ * The reference shares ONE &Aligner among all rayon workers (cleaner.rs:546-559).  A set holds one replica of the index per
+ * shard: devices[i] is shard i's device (NULL / 0: every visible device, one shard each; a device may be listed more than
+ * once - logical shards); the source index is borrowed for its own device (free the set first), the other devices get
+ * copies (device to device where the devices are peers), freed with the set. */
+typedef struct sh_index_set sh_index_set;
+sh_status sh_index_replicate(const sh_index *idx, const int32_t *devices, uint32_t n_devices, sh_index_set **out);
+uint32_t  sh_index_set_size(const sh_index_set *set);
+sh_status sh_index_set_free(sh_index_set *set);
+/* sh_classify_batch over all replicas at once: the batch is cut into contiguous shards at even record ordinals (mates stay
+ * together), balanced by bases (= by count for fixed-length records); each shard is classified on its device by a host thread
+ * of its own; the flags land in the caller's array - disjoint ranges, so the union of cleaner.rs:564-570 is a concatenation
+ * and needs no collective.  shard_first (nullable, n_shards + 1 entries) receives the first record of each shard.  stats:
+ * counters summed, stage times the largest over the devices.  Errors as sh_classify_batch; the message names the shard. */
+sh_status sh_classify_sharded(const sh_index_set *set, const sh_opts *opts, const uint8_t *bases, const uint64_t *offsets,
+                              uint64_t n_reads, uint8_t *out_flags, sh_trace *out_trace, sh_stats *stats, uint64_t *shard_first);
 
 /* ---- the whole replaced path:  Cleaner::run_minimap2_rs + clean_reads + ScrubbyReport  ------------------------
  * (/root/reference/src/cleaner.rs:443-575, :236-254, :731-760; src/report.rs:24-57; src/utils.rs:250-285)
@@ -399,8 +421,9 @@ sh_status sh_pack_flags_device(const uint8_t *d_flags, uint64_t n, uint8_t *d_bi
 sh_status sh_bench_gather(const sh_index *idx, uint64_t n_probes, int32_t iters, double *out_gbs_useful, double *out_ms);
 /* Test aid: the krmq tree of the long join (csrc/sh_rmq_tree.h) on the device - one lane runs a random insert / erase / query sequence with
  * heavily tied priorities (the generator of oracle/mm_rmq.c's mmo_rmq_trace) and returns, per query, the element the tree answered with
- * (its i, or -1); cache = entries of the LDS node cache (0: none, else a power of two <= 1024).  out: host array of n_ops int64. */
-sh_status sh_dbg_rmq_trace(int32_t device, uint64_t seed, int32_t n_ops, int32_t key_range, int32_t fifo, int32_t cache, int64_t *out, int64_t *n_out);
+ * (its i, or -1).  lds = 0: nodes in a pool in HBM (RqPool); lds != 0: the tree in LDS (RqLds, 4096 nodes: *n_out = -100 when the sequence
+ * holds more at once).  out: host array of n_ops int64; *n_out < 0: a guard of the tree code tripped. */
+sh_status sh_dbg_rmq_trace(int32_t device, uint64_t seed, int32_t n_ops, int32_t key_range, int32_t fifo, int32_t lds, int64_t *out, int64_t *n_out);
 /* test aid: the wave primitives of csrc/sh_wave.h (DPP scans / reductions / broadcasts) on one wave of inputs: 12 x 64 int32 and 9 x 64 uint64
  * results in the order of k_dbg_wave_ops (tests/test_wave_ops_gpu.py compares them with numpy) */
 sh_status sh_dbg_wave_ops(int32_t device, const int32_t *in32, const uint64_t *in64, int32_t bcast_lane, int32_t *out32, uint64_t *out64);

@@ -238,6 +238,148 @@ extern "C" sh_status sh_classify_batch(const sh_index *idx, const sh_opts *opts,
     return SH_OK;
 }
 
+// ---- in-process multi-GPU: replicas of the index and one call that fans a batch out over them ----------------------------
+// The reference shares ONE &Aligner among all rayon workers (cleaner.rs:546-559); a Rust caller of this library cannot use
+// torch.distributed, so the fan-out SURVEY.md 8(b) "Threading" / 8(e) asks for lives behind the C ABI: the index is replicated per device
+// (<= 20 GB of 288), the batch is cut into contiguous shards - at even record ordinals, so that mates stay together, and balanced by BASES,
+// which for fixed-length records is by count - each shard goes through sh_classify_batch on its own host thread (its own context, streams and
+// device buffers, kept with that replica), and the union of cleaner.rs:564-570 is the concatenation of the shards' flags in the caller's
+// array: one process, no collective.
+static uint64_t ref_words(uint64_t n_bases) { return ((n_bases + 31) / 32) * 2; }      // the packed reference is written in 16-B units
+
+struct sh_index_set {
+    std::vector<const sh_index *> rep;      // one per shard (a device may appear more than once: logical shards on one device)
+    std::vector<sh_index *> owned;          // the copies this set made (freed with it); the source index is borrowed
+};
+
+static sh_status index_copy_to(const sh_index *src, int device, sh_index **out)
+{
+    sh_index *r = new sh_index();
+    r->device = device; r->k = src->k; r->w = src->w; r->mid_occ = src->mid_occ; r->n_contigs = src->n_contigs; r->n_bases = src->n_bases;
+    r->n_minimizers = src->n_minimizers; r->n_keys = src->n_keys; r->n_slots = src->n_slots; r->n_positions = src->n_positions; r->lg_slots = src->lg_slots;
+    r->contig_len = src->contig_len; r->o_mid_occ = src->o_mid_occ; r->o_min_mid_occ = src->o_min_mid_occ; r->o_max_mid_occ = src->o_max_mid_occ;
+    r->o_mid_occ_frac = src->o_mid_occ_frac; r->ref_checksum = src->ref_checksum; r->build_ms = src->build_ms;
+    const size_t b_slots = (size_t)src->n_slots * 16, b_pos = ((size_t)src->n_positions + 2) * 8, b_ref = src->d_ref ? (size_t)ref_words(src->n_bases) * 8 + 16 : 0,
+                 b_cs = src->d_cstart ? ((size_t)src->n_contigs + 1) * 8 : 0;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc(&r->d_slots, b_slots);
+    if (e == hipSuccess) e = hipMalloc(&r->d_positions, b_pos);
+    if (e == hipSuccess && b_ref) e = hipMalloc(&r->d_ref, b_ref);
+    if (e == hipSuccess && b_cs) e = hipMalloc(&r->d_cstart, b_cs);
+    // device to device over xGMI where the two devices are peers; the runtime stages through the host otherwise
+    if (e == hipSuccess) e = hipMemcpyPeer(r->d_slots, device, src->d_slots, src->device, b_slots);
+    if (e == hipSuccess && src->n_positions) e = hipMemcpyPeer(r->d_positions, device, src->d_positions, src->device, (size_t)src->n_positions * 8);
+    if (e == hipSuccess && b_ref) e = hipMemcpyPeer(r->d_ref, device, src->d_ref, src->device, b_ref);
+    if (e == hipSuccess && b_cs) e = hipMemcpyPeer(r->d_cstart, device, src->d_cstart, src->device, b_cs);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        sh_set_error("sh_index_replicate: device %d: %s", device, hipGetErrorString(e));
+        sh_index_free(r);
+        return e == hipErrorOutOfMemory ? SH_ERR_OOM : SH_ERR_HIP;
+    }
+    *out = r;
+    return SH_OK;
+}
+
+extern "C" sh_status sh_index_set_free(sh_index_set *set)
+{
+    if (!set) return SH_OK;
+    for (sh_index *r : set->owned) sh_index_free(r);
+    delete set;
+    return SH_OK;
+}
+
+extern "C" sh_status sh_index_replicate(const sh_index *idx, const int32_t *devices, uint32_t n_devices, sh_index_set **out)
+{
+    SH_CHECK(idx && out, SH_ERR_BAD_ARG, "sh_index_replicate: null argument");
+    const int n_vis = sh_device_count();
+    SH_CHECK(n_vis > 0, SH_ERR_NO_DEVICE, "sh_index_replicate: no HIP device");
+    std::vector<int> devs;
+    if (!devices || n_devices == 0) for (int d = 0; d < n_vis; ++d) devs.push_back(d);
+    else devs.assign(devices, devices + n_devices);
+    for (int d : devs) SH_CHECK(d >= 0 && d < n_vis, SH_ERR_BAD_ARG, "sh_index_replicate: device %d of %d", d, n_vis);
+    sh_index_set *S = new sh_index_set;
+    for (int d : devs) {
+        const sh_index *have = d == idx->device ? idx : nullptr;
+        for (sh_index *o : S->owned) if (o->device == d) have = o;
+        if (!have) {
+            sh_index *r = nullptr;
+            const sh_status st = index_copy_to(idx, d, &r);
+            if (st != SH_OK) { sh_index_set_free(S); return st; }
+            S->owned.push_back(r);
+            have = r;
+        }
+        S->rep.push_back(have);
+    }
+    hipSetDevice(idx->device);
+    *out = S;
+    return SH_OK;
+}
+
+extern "C" uint32_t sh_index_set_size(const sh_index_set *set) { return set ? (uint32_t)set->rep.size() : 0u; }
+
+// first record of each shard: shard_first[n_shards + 1], even ordinals (mates of a pair are records 2i, 2i + 1), equal shares of the bases
+static void shard_cuts(const uint64_t *offsets, uint64_t n_reads, uint32_t n_shards, std::vector<uint64_t> &cut)
+{
+    cut.assign(n_shards + 1, 0);
+    cut[n_shards] = n_reads;
+    const uint64_t b0 = offsets[0], tot = offsets[n_reads] - b0;
+    for (uint32_t i = 1; i < n_shards; ++i) {
+        const uint64_t want = b0 + (uint64_t)((unsigned __int128)tot * i / n_shards);
+        uint64_t r = (uint64_t)(std::lower_bound(offsets, offsets + n_reads + 1, want) - offsets);      // first record starting at or behind the share's end
+        r &= ~1ull;
+        cut[i] = std::min<uint64_t>(std::max<uint64_t>(r, cut[i - 1]), n_reads & ~1ull);
+    }
+}
+
+extern "C" sh_status sh_classify_sharded(const sh_index_set *set, const sh_opts *opts, const uint8_t *bases, const uint64_t *offsets,
+                                         uint64_t n_reads, uint8_t *out_flags, sh_trace *out_trace, sh_stats *stats, uint64_t *shard_first)
+{
+    SH_CHECK(set && !set->rep.empty() && opts && offsets && out_flags, SH_ERR_BAD_ARG, "sh_classify_sharded: null argument");
+    const uint32_t n_sh = (uint32_t)set->rep.size();
+    if (stats) memset(stats, 0, sizeof(*stats));
+    std::vector<uint64_t> cut;
+    shard_cuts(offsets, n_reads, n_sh, cut);
+    if (shard_first) for (uint32_t i = 0; i <= n_sh; ++i) shard_first[i] = cut[i];
+    if (n_reads == 0) return SH_OK;
+    std::vector<sh_status> rc(n_sh, SH_OK);
+    std::vector<std::string> msg(n_sh);
+    std::vector<sh_stats> ss(n_sh);
+    std::vector<std::thread> th;
+    for (uint32_t i = 0; i < n_sh; ++i)
+        th.emplace_back([&, i]() {
+            const uint64_t r0 = cut[i], r1 = cut[i + 1];
+            memset(&ss[i], 0, sizeof(sh_stats));
+            if (r1 <= r0) return;
+            // `bases` stays the caller's pointer: sh_classify_batch reads bases + offsets[r], whatever offsets[r0] is
+            rc[i] = sh_classify_batch(set->rep[i], opts, bases, offsets + r0, r1 - r0, out_flags + r0, out_trace ? out_trace + r0 : nullptr, stats ? &ss[i] : nullptr);
+            if (rc[i] != SH_OK) msg[i] = sh_last_error();      // (thread-local: carried over to the caller's thread below)
+        });
+    for (auto &t : th) t.join();
+    sh_status st = SH_OK;
+    for (uint32_t i = 0; i < n_sh; ++i)
+        if (rc[i] != SH_OK && (st == SH_OK || st == SH_ERR_EMPTY_READ)) {      // an empty read is reported only when nothing worse happened
+            if (rc[i] == SH_ERR_EMPTY_READ && st == SH_ERR_EMPTY_READ) continue;
+            st = rc[i];
+            sh_set_error("shard %u (records %llu..%llu, device %d): %s", i, (unsigned long long)cut[i], (unsigned long long)cut[i + 1], set->rep[i]->device, msg[i].c_str());
+        }
+    if (stats)
+        for (uint32_t i = 0; i < n_sh; ++i) {
+            // counters add up; the stage times are per-device clocks of launches that ran side by side: the largest is the job's
+            const uint64_t *a = (const uint64_t *)&ss[i]; uint64_t *d = (uint64_t *)stats;
+            static_assert(sizeof(sh_stats) % 8 == 0, "sh_stats is made of 8-byte fields");
+            const size_t dbl[] = {offsetof(sh_stats, ms_sketch_probe) / 8, offsetof(sh_stats, ms_chain_small) / 8, offsetof(sh_stats, ms_chain_large) / 8, offsetof(sh_stats, ms_total) / 8,
+                                  offsetof(sh_stats, ms_ext) / 8, offsetof(sh_stats, ms_ext_fallback) / 8};
+            for (size_t w = 0; w < sizeof(sh_stats) / 8; ++w) {
+                bool is_d = false;
+                for (size_t q : dbl) is_d |= q == w;
+                if (is_d) { double &x = ((double *)stats)[w]; x = std::max(x, ((const double *)&ss[i])[w]); }
+                else d[w] += a[w];
+            }
+        }
+    return st;
+}
+
 // ---- index cache -----------------------------------------------------------------
 // The reference rebuilds the index on every run (`.with_index(path, None)`, cleaner.rs:475-479: no output file).  The cache is
 // one file: header, contig lengths, the 16-B slots, the position array, the 4-bit reference (what the extension stage aligns
@@ -275,7 +417,6 @@ static sh_status device_checksum(const void *d, uint64_t n_words, uint64_t *out)
     return SH_OK;
 }
 
-static uint64_t ref_words(uint64_t n_bases) { return ((n_bases + 31) / 32) * 2; }      // the packed reference is written in 16-B units
 
 extern "C" sh_status sh_index_save(const sh_index *idx, const char *path)
 {
@@ -583,13 +724,9 @@ extern "C" sh_status sh_bench_gather(const sh_index *idx, uint64_t n_probes, int
 
 // ---- test aid: the long join's tree on the device (sh_rmq_tree.h), one lane, against the oracle's answers --------------------------------
 #include "sh_rmq_tree.h"
-__global__ void k_dbg_rmq_trace(uint64_t seed, int32_t n_ops, int32_t key_range, int32_t fifo, int32_t cache, RqNode *pool, int32_t *ly, int32_t *li, long long *out, long long *n_out_p)
+template <class TT>
+__device__ inline long long dbg_rmq_trace_on(TT &T, uint64_t seed, int32_t n_ops, int32_t key_range, int32_t fifo, int32_t *ly, int32_t *li, long long *out)
 {
-    __shared__ RqNode s_c[1024];
-    __shared__ int32_t s_t[1024];
-    if (threadIdx.x != 0) return;
-    RqTree T;
-    rq_init(T, pool, n_ops + 4, cache ? RqCache{s_c, s_t, cache - 1} : RqCache{nullptr, nullptr, 0});
     long long n_out = 0, head = 0, n_all = 0;
     uint64_t s = seed * 0x9E3779B97F4A7C15ULL + 1;
 #define RND() (s ^= s << 13, s ^= s >> 7, s ^= s << 17, s)
@@ -598,6 +735,7 @@ __global__ void k_dbg_rmq_trace(uint64_t seed, int32_t n_ops, int32_t key_range,
         const long long n_live = n_all - head;
         if (r < 5 || n_live == 0) {
             const int32_t x = rq_alloc(T);
+            if (x == RQ_NIL) return -100;
             const int32_t y = (int32_t)(RND() % (uint64_t)key_range); const double pri = (double)(RND() % 10);
             rq_node_set(T, x, y, op, pri);
             ly[n_all] = y; li[n_all] = op; ++n_all;
@@ -611,15 +749,33 @@ __global__ void k_dbg_rmq_trace(uint64_t seed, int32_t n_ops, int32_t key_range,
             int32_t a = (int32_t)(RND() % (uint64_t)key_range), b = (int32_t)(RND() % (uint64_t)key_range);
             if (a > b) { const int32_t tt = a; a = b; b = tt; }
             const int32_t q = rq_rmq(T, a, INT32_MAX, b, 0);
-            out[n_out++] = q == RQ_NIL ? -1 : rq_at(T, q)->i;
+            out[n_out++] = q == RQ_NIL ? -1 : rq_i(T, q);
         }
     }
 #undef RND
-    *n_out_p = T.bad ? -(long long)T.bad : n_out;
+    return T.bad ? -(long long)T.bad : n_out;
+}
+__global__ void k_dbg_rmq_trace(uint64_t seed, int32_t n_ops, int32_t key_range, int32_t fifo, int32_t lds, RqNode *pool, int32_t *ly, int32_t *li, long long *out, long long *n_out_p)
+{
+    __shared__ RqLdsMem<4096> s_m;
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    long long n = 0;
+    if (lds) {
+        RqTreeT<RqLds> T;
+        T.st.init(s_m); rq_reset(T);
+        n = dbg_rmq_trace_on(T, seed, n_ops, key_range, fifo, ly, li, out);
+    } else {
+        RqTree T;
+        rq_init(T, pool, n_ops + 4);
+        n = dbg_rmq_trace_on(T, seed, n_ops, key_range, fifo, ly, li, out);
+    }
+    if (n >= 0 && n < n_ops - 1) out[n_ops - 1] = (long long)(wall_clock64() - t0);      // (behind the answers: the sequence's time in 100-MHz ticks, for whoever wants it)
+    *n_out_p = n;
 }
 extern "C" sh_status sh_dbg_rmq_trace(int32_t device, uint64_t seed, int32_t n_ops, int32_t key_range, int32_t fifo, int32_t cache, int64_t *out, int64_t *n_out)
 {
-    SH_CHECK(out && n_out && n_ops > 0 && key_range > 0 && (cache == 0 || (cache <= 1024 && !(cache & (cache - 1)))), SH_ERR_BAD_ARG, "sh_dbg_rmq_trace: bad argument");
+    SH_CHECK(out && n_out && n_ops > 0 && key_range > 0 && cache >= 0, SH_ERR_BAD_ARG, "sh_dbg_rmq_trace: bad argument");
     SH_HIP(hipSetDevice(device));
     RqNode *pool = nullptr; int32_t *ly = nullptr, *li = nullptr; long long *d_out = nullptr, *d_n = nullptr;
     SH_HIP(hipMalloc(&pool, sizeof(RqNode) * ((size_t)n_ops + 4))); SH_HIP(hipMalloc(&ly, 4 * ((size_t)n_ops + 1))); SH_HIP(hipMalloc(&li, 4 * ((size_t)n_ops + 1)));
@@ -628,7 +784,7 @@ extern "C" sh_status sh_dbg_rmq_trace(int32_t device, uint64_t seed, int32_t n_o
     SH_HIP(hipDeviceSynchronize());
     long long n = 0;
     SH_HIP(hipMemcpy(&n, d_n, 8, hipMemcpyDeviceToHost));
-    if (n > 0) SH_HIP(hipMemcpy(out, d_out, 8 * (size_t)n, hipMemcpyDeviceToHost));
+    if (n > 0) SH_HIP(hipMemcpy(out, d_out, 8 * (size_t)n_ops, hipMemcpyDeviceToHost));
     *n_out = n;
     hipFree(pool); hipFree(ly); hipFree(li); hipFree(d_out); hipFree(d_n);
     return SH_OK;

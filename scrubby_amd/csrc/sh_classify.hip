@@ -2949,7 +2949,11 @@ struct ExtLongArgs {
     const uint32_t *drop; uint32_t *fb_list, *n_fb;   // k_lr_locus: what was left out of a read's anchors; reads that must be redone with every anchor
     uint32_t *started;                                // counts the blocks that have begun (the giants' grid: the main grid is launched once they hold their LDS)
     const uint32_t *follow_done;                      // k_regs_align_long beside the launch that fills its list: set when that launch has ended
+    uint8_t *kind;                                    // per read of the call: which of the stage's rarer paths it took (LK_*; sh_ctx_debug_list, the bench's stratified oracle check)
 };
+// bits of ExtLongArgs::kind
+enum { LK_EXACT = 1, LK_RMQ_OPEN = 2, LK_UNRESOLVED = 4, LK_LOCUS_REDONE = 8, LK_ONDEMAND = 16, LK_FULL = 32, LK_SECOND_SIZE = 64, LK_ONE_LANE_TREES = 128 };
+__device__ inline void lk_mark(const ExtLongArgs &a, uint32_t r, uint8_t bit) { if (a.kind) a.kind[r] |= bit; }      // (one wave owns a read at a time)
 
 // Largest reads first: a read's cost grows with its chain anchors (one with 70 k of them keeps a wave busy for a third of a second), and a
 // kernel ends with its slowest wave.  Reads are binned by log2 of their chain-anchor count and listed from the top bin down.
@@ -3013,11 +3017,12 @@ __global__ void k_lext_forget(const uint32_t *list, uint32_t n, uint32_t *head, 
 }
 
 // no memory could be had for these reads: they keep their chain-level answer (mapped) and are counted (sh_stats.n_ext_unresolved; the host warns)
-__global__ void k_lext_giveup(const uint32_t *list, uint32_t n, uint8_t *flags, sh_trace *trace, LongHdr *hdr, Counters *ctr)
+__global__ void k_lext_giveup(const uint32_t *list, uint32_t n, uint8_t *flags, sh_trace *trace, LongHdr *hdr, Counters *ctr, uint8_t *kind)
 {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t r = list[i];
         flags[r] = 1;
+        if (kind) kind[r] |= 4;      // LK_UNRESOLVED
         if (trace) ((int32_t *)(trace + r))[7] = 1;
         LongHdr h{0ull, -1, 0, 0, 0}; hdr[r] = h;
         atomicAdd(&ctr->lext_unresolved, 1u);
@@ -3028,17 +3033,20 @@ __global__ void k_lext_giveup(const uint32_t *list, uint32_t n, uint8_t *flags, 
 __device__ inline void lext_defer(const ExtLongArgs &a, uint32_t r, uint32_t code, bool has_hdr)
 {
     if (a.big_list) {      // (a launch of the second size may be reading the list while it grows: what this wave wrote for the read first, then the entry)
+        lk_mark(a, r, code == 16u + 7u ? (LK_SECOND_SIZE | LK_ONE_LANE_TREES) : LK_SECOND_SIZE);
         __threadfence();
         __atomic_store_n(&a.big_list[atomicAdd(a.n_big, 1u)], r, __ATOMIC_RELAXED);
         return;
     }
     if (a.unres_list) {
+        lk_mark(a, r, LK_ONDEMAND);
         a.unres_list[atomicAdd(a.n_unres, 1u)] = r;
         if (!has_hdr) { LongHdr h{0ull, -1, 0, 0, 0}; a.AR.hdr[r] = h; }      // the regions kernel must not take it before the chains kernel has
         atomicExch(&a.ctr->lext_err_read, r); atomicExch(&a.ctr->lext_err_code, code);
         return;
     }
     a.flags[r] = 1;
+    lk_mark(a, r, LK_UNRESOLVED);
     if (a.trace) ((int32_t *)(a.trace + r))[7] = 1;
     if (!has_hdr) { LongHdr h{0ull, -1, 0, 0, 0}; a.AR.hdr[r] = h; }
     atomicAdd(&a.ctr->lext_unresolved, 1u); atomicExch(&a.ctr->lext_err_read, r); atomicExch(&a.ctr->lext_err_code, code);
@@ -3048,6 +3056,7 @@ __device__ inline void lext_defer(const ExtLongArgs &a, uint32_t r, uint32_t cod
 __device__ inline void lext_redo(const ExtLongArgs &a, uint32_t r, uint32_t why)
 {
     a.fb_list[atomicAdd(a.n_fb, 1u)] = r;
+    lk_mark(a, r, LK_LOCUS_REDONE);
     LongHdr h{0ull, -1, 0, 0, 0}; a.AR.hdr[r] = h;
     atomicAdd(&a.ctr->lr_fb_why[why >= 40u && why < 48u ? why - 40u : 7u], 1u);
 }
@@ -3068,7 +3077,13 @@ template <int NR, bool EXACT, bool FAT>
 __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
 {
     __shared__ RmqLdsT<NR, FAT> RL;
-    const RqCache TC{nullptr, nullptr, 0};      // (the trees' LDS node cache of sh_rmq_tree.h stays off on the device: see DESIGN.md 3.2)
+    // EXACT: the long join's main tree in LDS beside the ring (sh_rmq_tree.h).  It holds the look-back window only (max_gap reference bases:
+    // at most ~1 500 anchors on the bench's satellite reads); a window beyond it sends the read to the instance with the larger ring and tree,
+    // and from there to the one-lane version over node pools in HBM.
+    constexpr int TCAP = EXACT ? (NR >= 4096 ? 1792 : 1264) : 1;      // 32 B a node: 54 KB of LDS with the 512-anchor ring (three waves to a CU), 156 KB with the 4096-anchor ring
+    __shared__ RqLdsMem<TCAP> TM;
+    RqLds TL{};
+    if (EXACT) TL.init(TM);
     const uint32_t lane = threadIdx.x;
     const LongParams P_l = a.P; const LongIn I_l = a.I; const LongArena AR_l = a.AR;      // no pointers into the kernel-argument struct
     LongWs W;
@@ -3097,9 +3112,12 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
         C.sc_mch = C.sc_mis = C.sc_amb = C.sc_N = 0; C.need_big = false; C.err = 0; C.clk = a.clk ? &clk : nullptr;
         LongOut o;
         const unsigned long long t_r0 = a.clk ? wall_clock64() : 0ull;
-        const int32_t rc = lr_chains_wave<NR, EXACT, FAT>(C, RL, AR_l, o, a.drop ? a.drop[r] : 0u, TC);
+        const unsigned long long d0_before = clk.d[0];
+        if (a.clk) { clk.w_max = 0; clk.n_q = 0; }
+        const int32_t rc = lr_chains_wave<NR, EXACT, FAT>(C, RL, AR_l, o, a.drop ? a.drop[r] : 0u, TL);
         if (a.clk && lane == 0) {
             const unsigned long long dt = wall_clock64() - t_r0;
+            if (EXACT && (a.clk & 2)) printf("[exact] read %u qlen %d chains %d anchors %llu window %llu queries %llu ms %.1f rc %d\n", r, C.qlen, o.n_chain, clk.d[0] - d0_before, clk.w_max, clk.n_q, dt / 1e5, rc);
             atomicMax(&a.ctr->lext_slow, dt << 24 | (unsigned long long)(o.n_chain > 0xffffff ? 0xffffff : o.n_chain)); atomicAdd(&a.ctr->lext_kernel_sum, dt);
             atomicMax(&a.ctr->lext_slow2, dt << 32 | (unsigned long long)(uint32_t)C.qlen);
             atomicMax(&a.ctr->lext_slow3, dt << 32 | (unsigned long long)r);
@@ -3111,6 +3129,7 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
         else if (rc == 7) {      // beyond the large ring and too large for the one-lane trees: chain-level answer, counted
             if (lane == 0) {
                 a.flags[r] = 1;
+                lk_mark(a, r, LK_UNRESOLVED);
                 if (a.trace) ((int32_t *)(a.trace + r))[7] = 1;
                 LongHdr h{0ull, -1, 0, 0, 0}; AR_l.hdr[r] = h;
                 atomicAdd(&a.ctr->lext_unresolved, 1u); atomicExch(&a.ctr->lext_err_read, r); atomicExch(&a.ctr->lext_err_code, 16u + C.err);
@@ -3119,12 +3138,13 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
         else if (rc == 6) {      // tied priorities / beyond the ring: the EXACT instance of this kernel takes the read
             if (lane == 0) {
                 a.exact_list[atomicAdd(a.n_exact, 1u)] = r;
+                lk_mark(a, r, LK_EXACT);
                 LongHdr h{0ull, -1, 0, 0, 0}; AR_l.hdr[r] = h;
                 if (C.err == 50u) atomicAdd(&a.ctr->lext_rmq_tie, 1u);
             }
         }
         else if (rc != 0) { if (lane == 0) lext_defer(a, r, 16u + C.err, false); }
-        else { n_rechain += (o.rechained & 2) != 0; n_open += o.rmq_tie != 0; }
+        else { n_rechain += (o.rechained & 2) != 0; n_open += o.rmq_tie != 0; if (o.rmq_tie && lane == 0) lk_mark(a, r, LK_RMQ_OPEN); }
         __syncthreads();
     }
     if (lane == 0) {
@@ -3205,6 +3225,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 ((int4 *)tr)[2] = make_int4(o.n_aligned, o.n_regs, o.dp_max, (int32_t)o.sig);
             }
         }
+        if (rc == 0 && lane == 0 && a.flag_only && a.probe && !o.probed) lk_mark(a, r, LK_FULL);      // the probe did not decide: the complete procedure did
         if (a.clk && lane == 0 && !o.probed && C.probe_why) atomicAdd(&a.ctr->lr_probe_why[C.probe_why & 7], 1u);
         if (rc == 0) { n_regions += (uint32_t)o.n_aligned; n_dropped += o.n_regs == 0; n_probed += (uint32_t)o.probed; }      // every read of the list had a chain: also one the long join left without
         __syncthreads();
@@ -3254,6 +3275,8 @@ struct sh_ctx {
     // which reads of the LAST chunk took the rare paths (sh_ctx_debug_list: the bench's stratified oracle sample): 0 re-chained with max_occ,
     // 1 regs[0] aligned base by base, 2 the full fallback with every chain
     const uint32_t *dbg_ptr[3] = {}; uint32_t dbg_n[3] = {};
+    // long-read presets: per read of the LAST CALL, the rarer paths of the extension stage it took (LK_* bits; sh_ctx_debug_list 3 .. 10)
+    uint8_t *d_lkind = nullptr; uint64_t lkind_cap = 0, lkind_n = 0, lkind_r0 = 0;
     // the same stage for the long-read presets (sh_long.h): per-wave working memory in two sizes
     bool ext_long = false;
     LongParams LP{};
@@ -3318,7 +3341,7 @@ static void fill_long_params(const sh_opts &o, int32_t mid_occ, LongParams &L)
     L.mid_occ = mid_occ; L.max_max_occ = o.max_max_occ; L.occ_dist = o.occ_dist;
     // ties of the long join that matter: the literal tree for reads of up to this many chain anchors (4096 by default; a satellite read of 10^5 anchors would keep
     // one lane chasing pointers for seconds - DESIGN.md 3.2); SCRUBBY_HIP_RMQ_EXACT_MAX=-1 takes every such read to the tree, 0 none
-    L.rmq_exact_max = 4096;
+    L.rmq_exact_max = -1;      // every read that meets a tie that matters, or outgrows the rings, takes the literal tree (round 5: the tree lives in LDS)
     if (const char *env = getenv("SCRUBBY_HIP_RMQ_EXACT_MAX")) L.rmq_exact_max = atoi(env);
 }
 
@@ -3565,7 +3588,7 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             if ((e = hipMalloc(&c->d_lext_sorted, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
             for (auto &q : c->d_lext_unres) if ((e = hipMalloc(&q, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
             if ((e = hipMalloc(&c->d_lext_exact_list, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
-            for (int t = 0; t < 2; ++t) {   // the exact long join: the two sizes of the chains kernel plus the node pools of the two trees; one wave per CU (LDS)
+            for (int t = 1; t < 2; ++t) {   // the exact long join on the one-lane trees (E3): the second size of the chains kernel plus the node pools of the two trees; one wave per CU (LDS)
                 LongSizes q = t ? zb : z; q.phase = 2;
                 c->lext_exact_sz[t] = q;
                 c->lext_exact_per_wave[t] = long_ws_carve(nullptr, nullptr, q);
@@ -3614,7 +3637,18 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
 
 extern "C" sh_status sh_ctx_debug_list(const sh_ctx *c, int32_t which, uint32_t *out, uint64_t cap, uint64_t *n_out)
 {
-    SH_CHECK(c && n_out && which >= 0 && which < 3, SH_ERR_BAD_ARG, "sh_ctx_debug_list: bad argument");
+    SH_CHECK(c && n_out && which >= 0 && which < 11, SH_ERR_BAD_ARG, "sh_ctx_debug_list: bad argument");
+    if (which >= 3) {      // long reads: the reads of the last call with bit (which - 3) of their kind byte set
+        *n_out = 0;
+        if (!c->d_lkind || c->lkind_n == 0) return SH_OK;
+        std::vector<uint8_t> h(c->lkind_n);
+        SH_HIP(hipSetDevice(c->idx_device));
+        SH_HIP(hipMemcpy(h.data(), c->d_lkind, c->lkind_n, hipMemcpyDeviceToHost));
+        uint64_t n = 0;
+        for (uint64_t r = 0; r < c->lkind_n; ++r) if (h[r] >> (which - 3) & 1) { if (out && n < cap) out[n] = (uint32_t)r; ++n; }
+        *n_out = n;
+        return SH_OK;
+    }
     *n_out = c->dbg_ptr[which] ? c->dbg_n[which] : 0;
     if (!out || !c->dbg_ptr[which]) return SH_OK;
     const uint64_t n = std::min<uint64_t>(cap, c->dbg_n[which]);
@@ -3630,7 +3664,7 @@ extern "C" sh_status sh_ctx_destroy(sh_ctx *c)
     hipFree(c->d_work_defer); hipFree(c->d_work_defer2);
     for (auto &pp : c->d_big) for (auto p : pp) hipFree(p);
     hipFree(c->d_ctr); if (c->h_ctr) hipHostFree(c->h_ctr); hipFree(c->d_arena); hipFree(c->d_long);
-    hipFree(c->d_ext); hipFree(c->d_ext_scratch); for (auto q : c->d_lext) hipFree(q); hipFree(c->d_lext_big); hipFree(c->d_lext_big2); hipFree(c->d_lext_sorted); for (auto q : c->d_lext_unres) hipFree(q); hipFree(c->d_lext_exact_list); for (auto q : c->d_lext_exact) hipFree(q); hipFree(c->d_larena); hipFree(c->d_lhdr); for (auto q : c->d_locus) hipFree(q); hipFree(c->d_lr_drop); hipFree(c->d_lr_fb); hipFree(c->d_stage_x); hipFree(c->d_stage_q);
+    hipFree(c->d_ext); hipFree(c->d_ext_scratch); for (auto q : c->d_lext) hipFree(q); hipFree(c->d_lext_big); hipFree(c->d_lext_big2); hipFree(c->d_lext_sorted); for (auto q : c->d_lext_unres) hipFree(q); hipFree(c->d_lext_exact_list); for (auto q : c->d_lext_exact) hipFree(q); hipFree(c->d_larena); hipFree(c->d_lhdr); for (auto q : c->d_locus) hipFree(q); hipFree(c->d_lr_drop); hipFree(c->d_lr_fb); hipFree(c->d_stage_x); hipFree(c->d_stage_q); hipFree(c->d_lkind);
     for (auto ev : c->ev_ext) if (ev) hipEventDestroy(ev);
     for (auto ev : c->ev) if (ev) hipEventDestroy(ev);
     for (auto ev : c->evx) if (ev) hipEventDestroy(ev);
@@ -4001,9 +4035,10 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         x.P = c->LP; x.AP = c->AP; x.CP = c->P;
         x.AR.base = c->d_larena; x.AR.cap = c->larena_bytes; x.AR.cursor = &c->d_ctr->arena_cursor; x.AR.hdr = c->d_lhdr;
         x.list = c->d_ext_list; x.n_list = &c->d_ctr->ext_n_list; x.ctr = c->d_ctr; x.flags = d_flags; x.trace = d_trace; x.flag_only = d_trace == nullptr;
-        x.clk = getenv("SCRUBBY_HIP_DBG") ? 1 : 0; x.probe = getenv("SCRUBBY_HIP_NO_PROBE") ? 0 : 1;
+        x.clk = getenv("SCRUBBY_HIP_DBG") ? (getenv("SCRUBBY_HIP_DBG_EXACT") ? 3 : 1) : 0; x.probe = getenv("SCRUBBY_HIP_NO_PROBE") ? 0 : 1;
         x.drop = k.locus ? c->d_lr_drop : nullptr; x.fb_list = c->d_lr_fb; x.n_fb = &c->d_ctr->lr_n_fb;
         x.exact_list = c->d_lext_exact_list; x.n_exact = &c->d_ctr->lext_n_exact;
+        x.kind = c->d_lkind ? c->d_lkind + c->lkind_r0 : nullptr;
         { sh_status ps = pick_side_streams(c, s); if (ps != SH_OK) return ps; }
         SH_HIP(hipEventRecord(c->ev_ext[0], s));
         auto sync_ctr = [&]() -> sh_status {
@@ -4033,7 +4068,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                     for (waves = std::min<uint32_t>(n_un, 4); waves > 0 && hipMalloc(&buf, per * waves) != hipSuccess; waves >>= 1) { buf = nullptr; (void)hipGetLastError(); }
                 }
                 if (!buf) {      // no memory to be had: counted, warned about, chain-level answer
-                    hipLaunchKernelGGL(k_lext_giveup, dim3(16), dim3(256), 0, s, (const uint32_t *)c->d_lext_unres[cur], n_un, d_flags, d_trace, c->d_lhdr, c->d_ctr);
+                    hipLaunchKernelGGL(k_lext_giveup, dim3(16), dim3(256), 0, s, (const uint32_t *)c->d_lext_unres[cur], n_un, d_flags, d_trace, c->d_lhdr, c->d_ctr, x.kind);
                     SH_HIP(hipMemsetAsync(&c->d_ctr->lext_n_unres, 0, 4, s));
                     return sync_ctr();
                 }
@@ -4043,7 +4078,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 xa.list = c->d_lext_unres[cur]; xa.n_list = &c->d_ctr->lext_n_unres_in; xa.ticket = &c->d_ctr->lext_ticket_unres;
                 xa.big_list = nullptr; xa.n_big = nullptr; xa.part = 0; xa.unres_list = c->d_lext_unres[cur ^ 1]; xa.n_unres = &c->d_ctr->lext_n_unres;
                 if (phase == 0) hipLaunchKernelGGL((k_long_chains<4096, false, true>), dim3(waves), dim3(64), 0, s, xa);
-                else if (phase == 2) hipLaunchKernelGGL((k_long_chains<4096, true, true>), dim3(waves), dim3(64), 0, s, xa);
+                else if (phase == 2) hipLaunchKernelGGL((k_long_chains<4096, true, false>), dim3(waves), dim3(64), 0, s, xa);
                 else hipLaunchKernelGGL(k_regs_align_long, dim3(waves), dim3(64), 0, s, xa);
                 sh_status st = sync_ctr();
                 hipFree(buf);
@@ -4111,30 +4146,47 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
             }
             n_big_a += c->h_ctr->lext_n_big;
             if (c->h_ctr->lext_n_exact > 0) {
-                // the long join of these reads met two candidates of equal priority (or outgrew the LDS ring, or rmq_size_cap): once more, on
-                // the literal trees (sh_rmq_tree.h)
+                // The long join of these reads met two candidates of equal priority in a way that can change the chains (or outgrew the rings):
+                // once more with upstream's main tree beside the scan (sh_rmq_tree.h), asked at the ties.  The tree holds the look-back window
+                // only and lives in LDS, so the passes run on the ordinary working memory of the chains kernel:
+                //   E1  the 512-anchor ring + a 1264-node tree (54 KB of LDS a wave, three waves to a CU), first size;
+                //   E2  what outgrew E1's ring, tree or working memory: 4096-anchor ring + 1792-node tree (156 KB, one wave to a CU), second size;
+                //   E3  what outgrew E2's ring or tree: both trees on one lane over node pools in the wave's scratch (lr_rmq_fill_tree) - the
+                //       literal mg_lchain_rmq, for windows no LDS holds; then memory on demand for what outgrew the sizes.
                 n_exact_reads += c->h_ctr->lext_n_exact;
                 const auto t_ex = std::chrono::steady_clock::now();
                 ExtLongArgs xe = x;
-                xe.scratch = c->d_lext_exact[0]; xe.scratch_per_wave = c->lext_exact_per_wave[0]; xe.sz = c->lext_exact_sz[0];
+                xe.scratch = c->d_lext[0]; xe.scratch_per_wave = c->lext_per_wave[0]; xe.sz = c->lext_sz[0];
                 xe.list = c->d_lext_exact_list; xe.n_list = &c->d_ctr->lext_n_exact; xe.ticket = &c->d_ctr->lext_ticket_exact;
                 xe.part = 0; xe.exact_list = nullptr; xe.n_exact = nullptr;
                 SH_HIP(hipMemsetAsync(&c->d_ctr->lext_n_big, 0, 8, s));      // lext_n_big, lext_ticket_big: the list of the reads beyond the first size, once more
                 xe.big_list = c->d_lext_big; xe.n_big = &c->d_ctr->lext_n_big; xe.unres_list = nullptr; xe.n_unres = nullptr;
-                hipLaunchKernelGGL((k_long_chains<4096, true, true>), dim3(c->lext_exact_waves[0]), dim3(64), 0, s, xe);
+                hipLaunchKernelGGL((k_long_chains<512, true, false>), dim3(std::min<uint32_t>(c->lext_waves[0], 3u * (uint32_t)c->n_cu)), dim3(64), 0, s, xe);
                 sh_status st = sync_ctr(); if (st != SH_OK) return st;
                 if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
-                if (c->h_ctr->lext_n_big > 0) {
-                    xe.scratch = c->d_lext_exact[1]; xe.scratch_per_wave = c->lext_exact_per_wave[1]; xe.sz = c->lext_exact_sz[1];
-                    xe.list = c->d_lext_big; xe.n_list = &c->d_ctr->lext_n_big; xe.ticket = &c->d_ctr->lext_ticket_big; xe.big_list = nullptr; xe.n_big = nullptr;
-                    xe.unres_list = c->d_lext_unres[0]; xe.n_unres = &c->d_ctr->lext_n_unres;
-                    hipLaunchKernelGGL((k_long_chains<4096, true, true>), dim3(c->lext_exact_waves[1]), dim3(64), 0, s, xe);
+                const uint32_t n_e2 = c->h_ctr->lext_n_big;
+                uint32_t n_e3 = 0;
+                if (n_e2 > 0) {
+                    xe.scratch = c->d_lext[1]; xe.scratch_per_wave = c->lext_per_wave[1]; xe.sz = c->lext_sz[1];
+                    xe.list = c->d_lext_big; xe.n_list = &c->d_ctr->lext_n_big; xe.ticket = &c->d_ctr->lext_ticket_big;
+                    SH_HIP(hipMemsetAsync(&c->d_ctr->lext_n_big2, 0, 8, s));      // lext_n_big2, lext_ticket_big2 (the regions kernel's list: free until it starts)
+                    xe.big_list = c->d_lext_big2; xe.n_big = &c->d_ctr->lext_n_big2;
+                    hipLaunchKernelGGL((k_long_chains<4096, true, false>), dim3(std::min<uint32_t>(c->lext_waves[1], (uint32_t)c->n_cu)), dim3(64), 0, s, xe);
                     st = sync_ctr(); if (st != SH_OK) return st;
                     if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
+                    n_e3 = c->h_ctr->lext_n_big2;
                 }
-                const uint32_t n_ex_big = c->h_ctr->lext_n_big;
-                if (c->h_ctr->lext_n_unres > 0) { st = on_demand(2, xe); if (st != SH_OK) return st; }
-                if (getenv("SCRUBBY_HIP_DBG")) fprintf(stderr, "[dbg] exact long join: %u reads (%u with tied priorities so far), %u beyond the first size, %.1f ms\n", c->h_ctr->lext_n_exact, c->h_ctr->lext_rmq_tie, n_ex_big,
+                if (n_e3 > 0) {
+                    xe.scratch = c->d_lext_exact[1]; xe.scratch_per_wave = c->lext_exact_per_wave[1]; xe.sz = c->lext_exact_sz[1];
+                    xe.list = c->d_lext_big2; xe.n_list = &c->d_ctr->lext_n_big2; xe.ticket = &c->d_ctr->lext_ticket_big2; xe.big_list = nullptr; xe.n_big = nullptr;
+                    xe.unres_list = c->d_lext_unres[0]; xe.n_unres = &c->d_ctr->lext_n_unres;
+                    hipLaunchKernelGGL((k_long_chains<4096, true, false>), dim3(std::min<uint32_t>(c->lext_exact_waves[1], (uint32_t)c->n_cu)), dim3(64), 0, s, xe);
+                    st = sync_ctr(); if (st != SH_OK) return st;
+                    if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
+                    if (c->h_ctr->lext_n_unres > 0) { st = on_demand(2, xe); if (st != SH_OK) return st; }
+                    SH_HIP(hipMemsetAsync(&c->d_ctr->lext_n_big2, 0, 8, s));
+                }
+                if (getenv("SCRUBBY_HIP_DBG")) fprintf(stderr, "[dbg] exact long join: %u reads (%u with tied priorities so far), %u beyond the 512-anchor ring / 1264-node tree / first size, %u on the one-lane trees, %.1f ms\n", c->h_ctr->lext_n_exact, c->h_ctr->lext_rmq_tie, n_e2, n_e3,
                                                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ex).count());
             }
             SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "long-read extension stage: internal overflow code %u", c->h_ctr->ext_overflow);
@@ -4416,11 +4468,22 @@ extern "C" sh_status sh_classify_device(sh_ctx *c, const uint8_t *d_bases, const
     SH_HIP(hipSetDevice(c->idx->device));
     hipStream_t s = (hipStream_t)stream;
     if (stats) memset(stats, 0, sizeof(*stats));
+    if (c->ext_long) {      // the stage's per-read path record of this call
+        if (n_reads > c->lkind_cap) {
+            if (c->d_lkind) hipFree(c->d_lkind);
+            c->d_lkind = nullptr; c->lkind_cap = 0;
+            SH_HIP(hipMalloc(&c->d_lkind, n_reads + n_reads / 8 + 64));
+            c->lkind_cap = n_reads + n_reads / 8 + 64;
+        }
+        c->lkind_n = n_reads;
+        if (n_reads) SH_HIP(hipMemsetAsync(c->d_lkind, 0, n_reads, s));
+    }
     std::vector<std::pair<uint64_t, uint64_t>> todo;      // (first read, count), processed back to front
     for (uint64_t r0 = n_reads; r0 > 0;) { const uint64_t n = (r0 - 1) % c->max_reads + 1; r0 -= n; todo.push_back({r0, n}); }
     while (!todo.empty()) {
         const auto [r0, n] = todo.back();
         todo.pop_back();
+        c->lkind_r0 = r0;
         sh_status st = classify_chunk(c, d_bases, d_offsets + r0, n, n_bases, d_flags + r0, d_trace ? d_trace + r0 : nullptr, s, stats);
         if (st == SH_SPLIT) {      // the chains of this chunk did not fit the hand-over buffers of the extension stage
             SH_CHECK(n > 1, SH_ERR_OOM, "extension stage: the chains of a single read exceed the hand-over buffers; raise SCRUBBY_HIP_EXT_MB");

@@ -209,7 +209,7 @@ __device__ inline void lr_reg_set_coor_wave(LReg &r, int32_t qlen, const LAnchor
 // where a wave's time goes (SCRUBBY_HIP_DBG): 0 gather, 1 rmq sort, 2 rmq fill, 3 backtrack + compact, 4 gen_regs, 5 parent / select / est_err, 6 squeeze,
 // 7 region set-up (bad ends / seeds, windows), 8 ksw, 9 z-drop test, 10 update_extra, 11 sequence staging
 #define LR_NCLK 12
-struct LongClk { unsigned long long t[LR_NCLK]; unsigned long long last; unsigned long long d[8]; };      // d: RMQ statistics (steps, ring blocks evaluated, steps that went behind the ring, old blocks evaluated, sum of the list length, inner chunks, anchors)
+struct LongClk { unsigned long long t[LR_NCLK]; unsigned long long last; unsigned long long d[8]; unsigned long long w_max, n_q; };      // d: RMQ statistics (steps, ring blocks evaluated, steps that went behind the ring, old blocks evaluated, sum of the list length, inner chunks, anchors)
 __device__ inline void lr_tick(LongClk *c, int ph) { if (c) { const unsigned long long now = wall_clock64(); c->t[ph] += now - c->last; c->last = now; } }
 
 // ---- mg_lchain_rmq on one wave -------------------------------------------------------------------------------------------
@@ -276,7 +276,7 @@ __device__ inline double lr_cc_f64(const double *p) { return __longlong_as_doubl
 
 // a[] sorted by x (read-only here).  Out: f, p (int32; -1 = none) - visible to the other lanes after the caller's lr_sync().  n_tie: steps
 // whose minimum priority was shared (the smallest index was taken; upstream's tree may pick another).  Returns false when the inner window
-// outgrows LRQ_INNER or the read has more anchors than rmq_size_cap.
+// outgrows LRQ_INNER (or, TREE, the look-back window outgrows the LDS tree).
 // Memory: what a step needs of the newest ~1000 anchors (f, p, the t marks, x, y, the priority) lives in the LDS ring, and the smallest
 // priority of everything older is one number (pml): a step only goes to HBM when the answer may lie further back than the ring.
 // TREE: lane 0 keeps upstream's main tree beside the scan (insert when anchors enter the window, erase when they leave, sh_rmq_tree.h) and the
@@ -284,10 +284,12 @@ __device__ inline double lr_cc_f64(const double *p) { return __longlong_as_doubl
 template <int LRQ_INNER, bool TREE, bool FAT = false>
 __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int32_t bw, int32_t n, const LAnchor *a, int32_t *f, int32_t *p,
                                    double *pri, double *bmin /* n / 64 + 1 */, RmqLdsT<LRQ_INNER, FAT> &L, int32_t &n_tie, LongClk *dbg = nullptr,
-                                   RqNode *pool = nullptr, int32_t pool_cap = 0, RqCache TC = RqCache{nullptr, nullptr, 0})
+                                   RqLds TL = RqLds{})
 {
-    RqTree T0;
-    if (TREE) { if (al_lane() == 0) rq_init(T0, pool, pool_cap, TC); else rq_init(T0, pool, pool_cap); }
+    // TREE: the main tree in LDS (sh_rmq_tree.h, RqLds): it holds the anchors of the look-back window only - max_dist reference bases - and is
+    // walked by lane 0; a window that outgrows its nodes ends the call (ok = false), like a window that outgrows the ring
+    RqTreeT<RqLds> T0;
+    T0.st = TL; T0.st.n_used = 0; T0.st.free_head = RQ_NIL; rq_reset(T0);
     int32_t st_tree = 0;      // anchors [st_tree, i0) are in the tree
     n_tie = 0;
     // the parameters in registers: P lives in the caller's scratch, and a load from it inside the loop costs more than the step's arithmetic
@@ -303,7 +305,10 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
     if (max_dist < bw) max_dist = bw;
     if (max_dist_inner < 0) max_dist_inner = 0;
     if (max_dist_inner > max_dist) max_dist_inner = max_dist;
-    if (n > rmq_size_cap) return false;          // the size cap evicts out of order: not handled here
+    // (rmq_size_cap: upstream's trim loop also runs while the tree holds more than rmq_size_cap nodes; the tree holds the anchors
+    // [st, i0), so that is st = max(st, i0 - rmq_size_cap) - first in, first out like every other exit: handled where st moves.  The inner
+    // window's tree has the same rule; its window must fit the ring, so a cap below the ring's size is left to the one-lane version)
+    if (rmq_size_cap < LRQ_INNER) return false;
     for (int32_t i = lane; i < LRQ_INNER; i += 64) L.rt[i] = -1;
     __builtin_amdgcn_wave_barrier();
     int32_t blk_done = 0;      // blocks [0, blk_done) of 64 anchors are completely inserted; bmin[b] = their smallest priority
@@ -394,10 +399,12 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
             st = xw_base + first;
             if (first < 64) break;
         }
+        if (i0 - st > rmq_size_cap) st = i0 - rmq_size_cap;
         if (TREE && st_tree < st) {
             if (lane == 0) for (int32_t j = st_tree; j < st && j < i0; ++j) { const int32_t e = rq_erase(T0, (int32_t)a[j].y, j); if (e != RQ_NIL) rq_free(T0, e); }
             st_tree = st;
         }
+        if (TREE && dbg && (unsigned long long)(i0 - st) > dbg->w_max) dbg->w_max = (unsigned long long)(i0 - st);
         if (max_dist_inner > 0) {
             const int32_t st_old = st_inner;
             if (st_inner < seg0) st_inner = seg0;
@@ -514,10 +521,11 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
         bool tie_pending = false; int32_t tie_sc = 0;
         if (TREE && bj >= 0 && ties > 1) {
             int32_t tj = -1;
-            if (lane == 0) { const int32_t q = rq_rmq(T0, qi - max_dist, INT32_MAX, qi, 0); tj = q != RQ_NIL ? rq_at(T0, q)->i : -1; }
+            if (lane == 0) { const int32_t q = rq_rmq(T0, qi - max_dist, INT32_MAX, qi, 0); tj = q != RQ_NIL ? rq_i(T0, q) : -1; }
             tj = al_b0(tj);
             if (tj >= 0) bj = tj;
             ++tie_cnt;
+            if (dbg) ++dbg->n_q;
         } else if (bj >= 0 && ties > 1 && tie_cnt == 0) {      // (a read that has met a tie that matters needs no further verdicts)
             // Several candidates share the smallest priority; the tree returns ONE of them, which one depends on its shape.  The state after
             // this step is the same whichever it is when (a) none of them is accepted (band, score) and they agree on `exact` - the step
@@ -648,12 +656,12 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
 // ---- mg_lchain_rmq's scoring pass on the literal trees (sh_rmq_tree.h): one lane, statement for statement ---------------------------------
 // a[] sorted by x; t[] zeroed by the caller (the skip marks; the backtrack clears them again).  f, p as lr_rmq_fill leaves them.
 __device__ __noinline__ bool lr_rmq_fill_tree(const LongParams &P, int32_t max_dist, int32_t bw, int32_t n, const LAnchor *a, int32_t *f, int32_t *p, int32_t *t,
-                                              RqNode *pool0, RqNode *pool1, int32_t pool_cap, RqCache C0, RqCache C1, uint32_t *dbg_code = nullptr)
+                                              RqNode *pool0, RqNode *pool1, int32_t pool_cap, uint32_t *dbg_code = nullptr)
 {
     int32_t okv = 1;
     if (al_lane() == 0) {
         RqTree T0, T1;
-        rq_init(T0, pool0, pool_cap, C0); rq_init(T1, pool1, pool_cap, C1);
+        rq_init(T0, pool0, pool_cap); rq_init(T1, pool1, pool_cap);
         const float chn_pen_gap = P.pen_gap, chn_pen_skip = P.pen_skip;
         const int32_t max_chn_skip = P.max_skip, cap_rmq_size = P.rmq_size_cap;
         int32_t max_dist_inner = P.rmq_inner_dist;
@@ -661,7 +669,7 @@ __device__ __noinline__ bool lr_rmq_fill_tree(const LongParams &P, int32_t max_d
         if (max_dist_inner < 0) max_dist_inner = 0;
         if (max_dist_inner > max_dist) max_dist_inner = max_dist;
         int32_t i, i0, st = 0, st_inner = 0;
-        auto root_size = [](const RqTree &tr) -> int32_t { return tr.root != RQ_NIL ? (int32_t)rq_at(tr, tr.root)->size : 0; };
+        auto root_size = [](const RqTree &tr) -> int32_t { return rq_size(tr); };
         for (i = i0 = 0; i < n && okv; ++i) {
             int32_t max_j = -1;
             const uint64_t xi = a[i].x; const int32_t yi = (int32_t)a[i].y;
@@ -695,16 +703,16 @@ __device__ __noinline__ bool lr_rmq_fill_tree(const LongParams &P, int32_t max_d
             const int32_t q = rq_rmq(T0, yi - max_dist, INT32_MAX, yi, 0);
             if (q != RQ_NIL) {
                 int32_t sc, exact, width, n_skip = 0;
-                int32_t j = rq_at(T0, q)->i;
+                int32_t j = rq_i(T0, q);
                 sc = f[j] + lr_sc_simple((int32_t)(xi - a[j].x), yi - (int32_t)a[j].y, (int32_t)(a[j].y >> 32 & 0xff), chn_pen_gap, chn_pen_skip, exact, width);
                 if (width <= bw && sc > max_f) { max_f = sc; max_j = j; }
                 if (!exact && T1.root != RQ_NIL && yi > 0) {
                     RqItr it;
                     if (rq_itr_find_le(T1, yi - 1, n, it)) {
                         do {
-                            const RqNode *e = rq_at(T1, it.stack[it.top]);
-                            if (e->y < yi - max_dist_inner) break;
-                            j = e->i;
+                            const int32_t e = it.stack[it.top];
+                            if (rq_y(T1, e) < yi - max_dist_inner) break;
+                            j = rq_i(T1, e);
                             int32_t ex2;
                             sc = f[j] + lr_sc_simple((int32_t)(xi - a[j].x), yi - (int32_t)a[j].y, (int32_t)(a[j].y >> 32 & 0xff), chn_pen_gap, chn_pen_skip, ex2, width);
                             if (width <= bw) {
@@ -1682,7 +1690,7 @@ __device__ inline bool lr_region_kept(const LongParams &P, int32_t qlen, const L
 // EXACT: the long join on the literal trees (lr_rmq_fill_tree).  Without it a join that meets two candidates of equal priority, or that the
 // LDS ring cannot hold, returns 6: the read is redone by the EXACT instance of the kernel.
 template <int NR, bool EXACT, bool FAT = false>
-__device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR, FAT> &RL, const LongArena &AR, LongOut &out, uint32_t drop = 0, RqCache TC = RqCache{nullptr, nullptr, 0})
+__device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR, FAT> &RL, const LongArena &AR, LongOut &out, uint32_t drop = 0, RqLds TL = RqLds{})
 {
     const LongParams &P = *C.P;
     LongWs &W = *C.W;
@@ -1794,20 +1802,22 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR, FAT> &RL, const
             int32_t tie = 0;
             lr_tick(C.clk, 1);
             if constexpr (EXACT) {
-                // the scan with upstream's main tree beside it (asked at the ties); what the ring cannot hold, or rmq_size_cap touches: both trees on one lane
-                if (!lr_rmq_fill<NR, true, FAT>(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie, C.clk, W.rq0, (int32_t)W.cap_a + 2, TC)) {
+                // the scan with upstream's main tree beside it (in LDS, asked at the ties).  What this instance's ring or tree cannot hold goes to
+                // the instance with the larger ones; beyond those, both trees on one lane over node pools in the wave's scratch (the launch that
+                // brings them: W.rq0)
+                if (!lr_rmq_fill<NR, true, FAT>(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie, C.clk, TL)) {
+                    if (NR < 4096) { C.err = 6; return 3; }
+                    if (!W.rq0) { C.err = 7; return 3; }
                     lr_sync();
                     for (int32_t i = lane; i < n_a; i += 64) W.t[i] = 0;
                     lr_sync();
-                    const int32_t half = (TC.mask + 1) >> 1;
-                    const RqCache C0{TC.c, TC.tag, TC.c ? half - 1 : 0}, C1{TC.c ? TC.c + half : nullptr, TC.c ? TC.tag + half : nullptr, TC.c ? half - 1 : 0};
                     uint32_t code = 0;
-                    if (!lr_rmq_fill_tree(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.t, W.rq0, W.rq1, (int32_t)W.cap_a + 2, C0, C1, &code)) { C.err = 100u + (uint32_t)al_b0((int32_t)code); return 3; }
+                    if (!lr_rmq_fill_tree(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.t, W.rq0, W.rq1, (int32_t)W.cap_a + 2, &code)) { C.err = 100u + (uint32_t)al_b0((int32_t)code); return 3; }
                 }
             } else {
                 if (!lr_rmq_fill<NR, false, FAT>(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie, C.clk)) {
-                    if (NR < 4096 && n_a <= P.rmq_size_cap) { C.err = 6; return 3; }      // beyond this ring: the pass with the large one
-                    if (P.rmq_exact_max < 0 || n_a <= P.rmq_exact_max) { C.err = 51; return 6; }      // beyond that too (or rmq_size_cap): the trees
+                    if (NR < 4096) { C.err = 6; return 3; }      // beyond this ring: the pass with the large one
+                    if (P.rmq_exact_max < 0 || n_a <= P.rmq_exact_max) { C.err = 51; return 6; }      // beyond that too: the trees
                     C.err = 6; return 7;      // ... which one lane would walk for seconds on a read this size: given up, counted (sh_stats.n_ext_unresolved)
                 }
                 if (tie) {      // the scan's choice among equal priorities need not be the tree's

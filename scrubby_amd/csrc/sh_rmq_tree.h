@@ -6,290 +6,383 @@
 // two candidates tie, krmq_rmq returns the one the shape of the tree and the history of its rotations favour (krmq_rotate1/2 hand the old
 // root's subtree-minimum pointer to the new root instead of recomputing it), and the predecessor an anchor gets decides the chains.  Reads
 // that meet such a tie keep the scan for everything that has width and ask a literal tree - insert / erase / rotate / rmq as upstream states
-// them, on an index-based node pool, maintained by ONE lane - at the ties only (lr_rmq_fill<NR, true>); reads the LDS ring cannot hold, or
-// with more anchors than rmq_size_cap (the cap evicts out of order), run both trees on one lane (lr_rmq_fill_tree).
-// The pool lives in the wave's HBM scratch; the nodes every walk passes - the top of the tree - are mirrored in a direct-mapped LDS cache
-// (write-through), which is what makes a read of 10^5 anchors a matter of tenths of a second instead of seconds.
+// them, on an index-based node pool, maintained by ONE lane - at the ties only (lr_rmq_fill<NR, true>); reads the LDS ring cannot hold run
+// both trees on one lane (lr_rmq_fill_tree).
+//
+// Where the nodes live is a storage policy (round 5).  The tree of a read holds the anchors of its look-back window - max_gap reference
+// bases: at most ~1 400 anchors on the bench's satellite reads, whatever the read's size (measured) - so the scan's tree
+// lives entirely in LDS (RqLds: 32 B a node - a 16-byte piece with the key, the 16-bit links and the balance, which one ds_read_b128 brings to a
+// descent step, the priority, and the priority of the subtree minimum kept beside its pointer - every access a ds_read / ds_write through
+// address-space-3 pointers: no generic pointer into LDS is ever formed; the walks' path arrays are in LDS too).  RqPool keeps 32-B nodes in the wave's HBM scratch, for windows LDS cannot hold
+// and for the one-lane version with both trees.  Upstream's per-node subtree SIZE is not kept: nothing but krmq_size(root) reads it, and
+// that is the number of live nodes (n_live); the shape, the subtree-minimum pointers and the answers do not depend on it.
 // The CPU oracle holds the same restatement (oracle/mm_rmq.c, checked there against a brute-force scan); the two share no code.
 #pragma once
 #include <stdint.h>
 
 #define RQ_MAX_DEPTH 64
 #define RQ_NIL (-1)
-// The node cache is written for LDS and checked on the host (tests/test_rmq_tree_cpu.py); the device build leaves it out until its generic
-// pointers into LDS are sorted out: with RQ_CACHE_ON 0 every access goes to the pool and the cache code folds away.
-#ifndef RQ_CACHE_ON
-#define RQ_CACHE_ON 0
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RQ_LDS __attribute__((address_space(3)))
+#else
+#define RQ_LDS
 #endif
 
-struct alignas(16) RqNode {      // 48 bytes, 16-byte aligned: a node moves between pool and cache in 128-bit pieces, which LDS only takes aligned
+// ---- storage: a pool of 32-byte nodes in global memory ---------------------------------------------------------------------
+struct alignas(16) RqNode {      // 32 bytes: two 128-bit pieces
     int32_t y, i; double pri;
     int32_t p[2], s;           // children, subtree minimum (node indices)
-    int32_t balance; uint32_t size;
+    int32_t balance;
 };
-struct RqCache { RqNode *c; int32_t *tag; int32_t mask; };      // LDS: mask + 1 entries (a power of two); c == nullptr: no cache
-struct RqTree { RqNode *n; RqCache C; int32_t cap, n_used, free_head, root, bad; };      // bad: an index outside the pool was asked for (the caller gives the read up instead of touching memory it does not own)
+struct RqPool {
+    RqNode *n; int32_t cap, n_used, free_head;
+    // the walks' path arrays (upstream's on-stack arrays): private memory here
+    static constexpr int max_depth = RQ_MAX_DEPTH;
+    int32_t sp_[2][RQ_MAX_DEPTH]; int8_t sd_[2][RQ_MAX_DEPTH];
+    __device__ inline int32_t sp(int w, int i) const { return sp_[w][i]; }
+    __device__ inline void set_sp(int w, int i, int32_t v) { sp_[w][i] = v; }
+    __device__ inline int sd(int w, int i) const { return sd_[w][i]; }
+    __device__ inline void set_sd(int w, int i, int v) { sd_[w][i] = (int8_t)v; }
+    __device__ inline void init(RqNode *pool, int32_t c) { n = pool; cap = c; n_used = 0; free_head = RQ_NIL; }
+    __device__ inline bool valid(int32_t k) const { return (uint32_t)k < (uint32_t)cap; }
+    __device__ inline int32_t alloc()
+    {
+        if (free_head != RQ_NIL) { const int32_t k = free_head; free_head = n[k].p[0]; return k; }
+        if (n_used >= cap) return RQ_NIL;
+        return n_used++;
+    }
+    __device__ inline void release(int32_t k) { n[k].p[0] = free_head; free_head = k; }
+    __device__ inline int32_t y(int32_t k) const { return n[k].y; }
+    __device__ inline int32_t i(int32_t k) const { return n[k].i; }
+    __device__ inline double pri(int32_t k) const { return n[k].pri; }
+    __device__ inline int32_t ch(int32_t k, int d) const { return n[k].p[d]; }
+    __device__ inline int32_t s(int32_t k) const { return n[k].s; }
+    __device__ inline int32_t bal(int32_t k) const { return n[k].balance; }
+    __device__ inline void set_ch(int32_t k, int d, int32_t v) { n[k].p[d] = v; }
+    __device__ inline void set_s(int32_t k, int32_t v, double) { n[k].s = v; }
+    __device__ inline double spri(int32_t k) const { return n[n[k].s].pri; }      // priority of the subtree minimum
+    __device__ inline void hot(int32_t k, int32_t &yy, int32_t &ii, int32_t &l, int32_t &r, int32_t &b) const { const RqNode z = n[k]; yy = z.y; ii = z.i; l = z.p[0]; r = z.p[1]; b = z.balance; }
+    __device__ inline void set_bal(int32_t k, int32_t v) { n[k].balance = v; }
+    __device__ inline void fresh(int32_t k, int32_t yy, int32_t ii, double pp) { RqNode z; z.y = yy; z.i = ii; z.pri = pp; z.p[0] = z.p[1] = RQ_NIL; z.s = k; z.balance = 0; n[k] = z; }
+    __device__ inline void fake(int32_t k, int32_t root) { RqNode z = n[root]; z.p[0] = root; z.p[1] = RQ_NIL; n[k] = z; }      // krmq_erase's `fake = **root_` with the tree below its left link
+};
 
-__device__ inline void rq_init(RqTree &t, RqNode *pool, int32_t cap, RqCache C = RqCache{nullptr, nullptr, 0})
-{
-    t.n = pool; t.C = C; t.cap = cap; t.n_used = 0; t.free_head = RQ_NIL; t.root = RQ_NIL; t.bad = 0;
-    if (RQ_CACHE_ON && C.c) for (int32_t k = 0; k <= C.mask; ++k) C.tag[k] = RQ_NIL;
-}
-// the copy of node k to read from (and to write to, together with the pool: RQ_SET); good until the next rq_at
-__device__ inline RqNode *rq_at(const RqTree &t, int32_t k)
-{
-    if ((uint32_t)k >= (uint32_t)t.cap) { if (!t.bad) const_cast<RqTree &>(t).bad = 1; k = 0; }
-    if (!RQ_CACHE_ON || !t.C.c) return t.n + k;
-    const int32_t sl = k & t.C.mask;
-    if (t.C.tag[sl] != k) { t.C.c[sl] = t.n[k]; t.C.tag[sl] = k; }
-    return t.C.c + sl;
-}
-#define RQ_GET(k, fld) (rq_at(t, (k))->fld)
-#define RQ_SET(k, fld, v) do { const int32_t k__ = (k); const auto v__ = (v); rq_at(t, k__)->fld = v__; if (RQ_CACHE_ON && t.C.c && (uint32_t)k__ < (uint32_t)t.cap) t.n[k__].fld = v__; } while (0)
+// ---- storage: the whole tree in LDS -------------------------------------------------------------------------------------------
+// The memory (a __shared__ object of the kernel; CAP <= 65535 nodes, 32 B each) and the handle the tree code works through.
+#define RQ_LDS_DEPTH 40      // an AVL tree that deep holds more than 10^8 nodes
+struct alignas(16) RqHot { int32_t y, i; uint16_t l, r, s; int8_t bal, pad; };      // what a descent step reads, in one 128-bit piece
+template <int CAP>
+struct RqLdsMem { RqHot hot[CAP]; double pri[CAP], spri[CAP]; int32_t sp[2][RQ_LDS_DEPTH]; int8_t sd[2][RQ_LDS_DEPTH]; };
+struct RqLds {
+    RQ_LDS RqHot *h_; RQ_LDS double *pri_, *spri_;
+    RQ_LDS int32_t *sp_; RQ_LDS int8_t *sd_;      // the walks' path arrays: in LDS too (in private memory every access is a trip to the L1 / L2: it was most of an operation)
+    int32_t cap, n_used, free_head;
+    static constexpr int max_depth = RQ_LDS_DEPTH;
+    __device__ inline int32_t sp(int w, int i) const { return sp_[w * RQ_LDS_DEPTH + i]; }
+    __device__ inline void set_sp(int w, int i, int32_t v) { sp_[w * RQ_LDS_DEPTH + i] = v; }
+    __device__ inline int sd(int w, int i) const { return (int)sd_[w * RQ_LDS_DEPTH + i]; }
+    __device__ inline void set_sd(int w, int i, int v) { sd_[w * RQ_LDS_DEPTH + i] = (int8_t)v; }
+    template <int CAP>
+    __device__ inline void init(RqLdsMem<CAP> &m)
+    {
+        // (an LDS address is the low half of the generic one: the casts below go through the integer, as the compiler asks)
+        h_ = (RQ_LDS RqHot *)(uintptr_t)m.hot; pri_ = (RQ_LDS double *)(uintptr_t)m.pri; spri_ = (RQ_LDS double *)(uintptr_t)m.spri;
+        sp_ = (RQ_LDS int32_t *)(uintptr_t)&m.sp[0][0]; sd_ = (RQ_LDS int8_t *)(uintptr_t)&m.sd[0][0];
+        cap = CAP; n_used = 0; free_head = RQ_NIL;
+    }
+    __device__ static inline int32_t up(uint16_t v) { return v == 0xffffu ? RQ_NIL : (int32_t)v; }
+    __device__ inline bool valid(int32_t k) const { return (uint32_t)k < (uint32_t)cap; }
+    __device__ inline int32_t alloc()
+    {
+        if (free_head != RQ_NIL) { const int32_t k = free_head; free_head = up(h_[k].l); return k; }
+        if (n_used >= cap) return RQ_NIL;
+        return n_used++;
+    }
+    __device__ inline void release(int32_t k) { h_[k].l = (uint16_t)free_head; free_head = k; }
+    __device__ inline int32_t y(int32_t k) const { return h_[k].y; }
+    __device__ inline int32_t i(int32_t k) const { return h_[k].i; }
+    __device__ inline double pri(int32_t k) const { return pri_[k]; }
+    __device__ inline double spri(int32_t k) const { return spri_[k]; }
+    __device__ inline int32_t ch(int32_t k, int d) const { return up(d ? h_[k].r : h_[k].l); }
+    __device__ inline int32_t s(int32_t k) const { return up(h_[k].s); }
+    __device__ inline int32_t bal(int32_t k) const { return (int32_t)h_[k].bal; }
+    __device__ inline void hot(int32_t k, int32_t &yy, int32_t &ii, int32_t &l, int32_t &r, int32_t &b) const
+    {
+        const RqHot z = h_[k];      // one ds_read_b128
+        yy = z.y; ii = z.i; l = up(z.l); r = up(z.r); b = (int32_t)z.bal;
+    }
+    __device__ inline void set_ch(int32_t k, int d, int32_t v) { if (d) h_[k].r = (uint16_t)v; else h_[k].l = (uint16_t)v; }
+    __device__ inline void set_s(int32_t k, int32_t v, double pv) { h_[k].s = (uint16_t)v; spri_[k] = pv; }
+    __device__ inline void set_bal(int32_t k, int32_t v) { h_[k].bal = (int8_t)v; }
+    __device__ inline void fresh(int32_t k, int32_t yy, int32_t ii, double pp) { RqHot z; z.y = yy; z.i = ii; z.l = 0xffffu; z.r = 0xffffu; z.s = (uint16_t)k; z.bal = 0; z.pad = 0; h_[k] = z; pri_[k] = pp; spri_[k] = pp; }
+    __device__ inline void fake(int32_t k, int32_t root) { RqHot z = h_[root]; z.l = (uint16_t)root; z.r = 0xffffu; h_[k] = z; pri_[k] = pri_[root]; spri_[k] = spri_[root]; }
+};
 
-__device__ inline int32_t rq_alloc(RqTree &t)
+// ---- the tree ------------------------------------------------------------------------------------------------------------------------
+// bad: a walk left the pool or grew deeper than RQ_MAX_DEPTH (the caller gives the read up instead of touching memory it does not own)
+template <class ST>
+struct RqTreeT { ST st; int32_t root, bad, n_live; };
+typedef RqTreeT<RqPool> RqTree;
+
+template <class ST> __device__ inline void rq_reset(RqTreeT<ST> &t) { t.root = RQ_NIL; t.bad = 0; t.n_live = 0; }
+__device__ inline void rq_init(RqTree &t, RqNode *pool, int32_t cap) { t.st.init(pool, cap); rq_reset(t); }
+// every index a walk follows goes through here: one outside the pool marks the tree bad and reads node 0 instead
+template <class ST> __device__ inline int32_t rq_ok(const RqTreeT<ST> &t, int32_t k)
 {
-    if (t.free_head != RQ_NIL) { const int32_t k = t.free_head; t.free_head = RQ_GET(k, p[0]); return k; }
-    if (t.n_used >= t.cap) return RQ_NIL;      // cannot happen: cap = window + 2
-    return t.n_used++;
+    if (!t.st.valid(k)) { if (!t.bad) const_cast<RqTreeT<ST> &>(t).bad = 1; return 0; }
+    return k;
 }
-__device__ inline void rq_free(RqTree &t, int32_t k) { RQ_SET(k, p[0], t.free_head); t.free_head = k; }
+template <class ST> __device__ inline int32_t rq_alloc(RqTreeT<ST> &t) { return t.st.alloc(); }
+template <class ST> __device__ inline void rq_free(RqTreeT<ST> &t, int32_t k) { if (t.st.valid(k)) t.st.release(k); }
 // a fresh node, not yet in the tree
-__device__ inline void rq_node_set(RqTree &t, int32_t k, int32_t y, int32_t i, double pri)
+template <class ST> __device__ inline void rq_node_set(RqTreeT<ST> &t, int32_t k, int32_t y, int32_t i, double pri)
 {
-    RqNode z; z.y = y; z.i = i; z.pri = pri; z.p[0] = z.p[1] = RQ_NIL; z.s = k; z.balance = 0; z.size = 1;
-    if ((uint32_t)k >= (uint32_t)t.cap) { if (!t.bad) t.bad = 2; return; }
-    t.n[k] = z;
-    if (RQ_CACHE_ON && t.C.c) { const int32_t sl = k & t.C.mask; t.C.c[sl] = z; t.C.tag[sl] = k; }
+    if (!t.st.valid(k)) { if (!t.bad) t.bad = 2; return; }
+    t.st.fresh(k, y, i, pri);
 }
+template <class ST> __device__ inline int32_t rq_i(const RqTreeT<ST> &t, int32_t k) { return t.st.i(rq_ok(t, k)); }
+template <class ST> __device__ inline int32_t rq_y(const RqTreeT<ST> &t, int32_t k) { return t.st.y(rq_ok(t, k)); }
+template <class ST> __device__ inline int32_t rq_size(const RqTreeT<ST> &t) { return t.n_live; }      // krmq_size(root)
 
 __device__ inline int rq_cmp_key(int32_t ay, int32_t ai, int32_t by, int32_t bi)
 {   // lc_elem_cmp
     return ay < by ? -1 : ay > by ? 1 : (ai > bi) - (ai < bi);
 }
-__device__ inline int rq_cmp_node(const RqTree &t, int32_t ay, int32_t ai, int32_t k) { const RqNode *b = rq_at(t, k); return rq_cmp_key(ay, ai, b->y, b->i); }
-__device__ inline bool rq_lt2(const RqTree &t, int32_t a, int32_t b) { const double pa = RQ_GET(a, pri); return pa < RQ_GET(b, pri); }
-__device__ inline uint32_t rq_size_child(const RqTree &t, int32_t q, int i) { const int32_t c = RQ_GET(q, p[i]); return c != RQ_NIL ? RQ_GET(c, size) : 0u; }
+#define RQ_Y(k) t.st.y(rq_ok(t, (k)))
+#define RQ_I(k) t.st.i(rq_ok(t, (k)))
+#define RQ_PRI(k) t.st.pri(rq_ok(t, (k)))
+#define RQ_CH(k, d) t.st.ch(rq_ok(t, (k)), (d))
+#define RQ_S(k) t.st.s(rq_ok(t, (k)))
+#define RQ_BAL(k) t.st.bal(rq_ok(t, (k)))
+#define RQ_SET_CH(k, d, v) t.st.set_ch(rq_ok(t, (k)), (d), (v))
+#define RQ_SET_S(k, v, pv) t.st.set_s(rq_ok(t, (k)), (v), (pv))
+#define RQ_SPRI(k) t.st.spri(rq_ok(t, (k)))
+#define RQ_SET_BAL(k, v) t.st.set_bal(rq_ok(t, (k)), (v))
+template <class ST> __device__ inline int rq_cmp_node(const RqTreeT<ST> &t, int32_t ay, int32_t ai, int32_t k) { const int32_t kk = rq_ok(t, k); return rq_cmp_key(ay, ai, t.st.y(kk), t.st.i(kk)); }
+template <class ST> __device__ inline bool rq_lt2(const RqTreeT<ST> &t, int32_t a, int32_t b) { const double pa = RQ_PRI(a); return pa < RQ_PRI(b); }
 
 // krmq_update_min(p, q, r): p's subtree minimum from p itself and the minima of the two given subtrees, in that order
-__device__ inline void rq_update_min(RqTree &t, int32_t p, int32_t q, int32_t r)
+template <class ST> __device__ inline void rq_update_min(RqTreeT<ST> &t, int32_t p, int32_t q, int32_t r)
 {
-    int32_t s = p;
-    if (q != RQ_NIL) { const int32_t qs = RQ_GET(q, s); if (!rq_lt2(t, p, qs)) s = qs; }
-    if (r != RQ_NIL) { const int32_t rs = RQ_GET(r, s); if (!rq_lt2(t, s, rs)) s = rs; }
-    RQ_SET(p, s, s);
+    // (the subtrees' minima come with their priorities: the loads below do not depend on one another)
+    const double pp = RQ_PRI(p);
+    const int32_t qs = q != RQ_NIL ? RQ_S(q) : RQ_NIL, rs = r != RQ_NIL ? RQ_S(r) : RQ_NIL;
+    const double qp = q != RQ_NIL ? RQ_SPRI(q) : 0.0, rp = r != RQ_NIL ? RQ_SPRI(r) : 0.0;
+    int32_t s = p; double sp = pp;
+    if (q != RQ_NIL && !(pp < qp)) { s = qs; sp = qp; }
+    if (r != RQ_NIL && !(sp < rp)) { s = rs; sp = rp; }
+    RQ_SET_S(p, s, sp);
 }
 
 // one rotation: (a,(b,c)q)p => ((a,b)p,c)q
-__device__ inline int32_t rq_rotate1(RqTree &t, int32_t p, int dir)
+template <class ST> __device__ inline int32_t rq_rotate1(RqTreeT<ST> &t, int32_t p, int dir)
 {
     const int opp = 1 - dir;
-    const int32_t q = RQ_GET(p, p[opp]), s = RQ_GET(p, s);
-    const uint32_t size_p = RQ_GET(p, size);
-    RQ_SET(p, size, size_p - (RQ_GET(q, size) - rq_size_child(t, q, dir)));
-    RQ_SET(q, size, size_p);
-    rq_update_min(t, p, RQ_GET(p, p[dir]), RQ_GET(q, p[dir]));
-    RQ_SET(q, s, s);
-    RQ_SET(p, p[opp], RQ_GET(q, p[dir]));
-    RQ_SET(q, p[dir], p);
+    const int32_t q = RQ_CH(p, opp), s = RQ_S(p);
+    const double s_pri = RQ_SPRI(p);
+    rq_update_min(t, p, RQ_CH(p, dir), RQ_CH(q, dir));
+    RQ_SET_S(q, s, s_pri);
+    RQ_SET_CH(p, opp, RQ_CH(q, dir));
+    RQ_SET_CH(q, dir, p);
     return q;
 }
 
 // two consecutive rotations: (a,((b,c)r,d)q)p => ((a,b)p,(c,d)q)r
-__device__ inline int32_t rq_rotate2(RqTree &t, int32_t p, int dir)
+template <class ST> __device__ inline int32_t rq_rotate2(RqTreeT<ST> &t, int32_t p, int dir)
 {
     const int opp = 1 - dir;
-    const int32_t q = RQ_GET(p, p[opp]), r = RQ_GET(q, p[dir]), s = RQ_GET(p, s);
-    const uint32_t size_x_dir = rq_size_child(t, r, dir);
-    const uint32_t size_p = RQ_GET(p, size), size_q = RQ_GET(q, size);
-    RQ_SET(r, size, size_p);
-    RQ_SET(p, size, size_p - (size_q - size_x_dir));
-    RQ_SET(q, size, size_q - (size_x_dir + 1));
-    rq_update_min(t, p, RQ_GET(p, p[dir]), RQ_GET(r, p[dir]));
-    rq_update_min(t, q, RQ_GET(q, p[opp]), RQ_GET(r, p[opp]));
-    RQ_SET(r, s, s);
-    RQ_SET(p, p[opp], RQ_GET(r, p[dir]));
-    RQ_SET(r, p[dir], p);
-    RQ_SET(q, p[dir], RQ_GET(r, p[opp]));
-    RQ_SET(r, p[opp], q);
+    const int32_t q = RQ_CH(p, opp), r = RQ_CH(q, dir), s = RQ_S(p);
+    const double s_pri = RQ_SPRI(p);
+    rq_update_min(t, p, RQ_CH(p, dir), RQ_CH(r, dir));
+    rq_update_min(t, q, RQ_CH(q, opp), RQ_CH(r, opp));
+    RQ_SET_S(r, s, s_pri);
+    RQ_SET_CH(p, opp, RQ_CH(r, dir));
+    RQ_SET_CH(r, dir, p);
+    RQ_SET_CH(q, dir, RQ_CH(r, opp));
+    RQ_SET_CH(r, opp, q);
     const int b1 = dir == 0 ? +1 : -1;
-    const int32_t rb = RQ_GET(r, balance);
-    if (rb == b1) { RQ_SET(q, balance, 0); RQ_SET(p, balance, -b1); }
-    else if (rb == 0) { RQ_SET(q, balance, 0); RQ_SET(p, balance, 0); }
-    else { RQ_SET(q, balance, b1); RQ_SET(p, balance, 0); }
-    RQ_SET(r, balance, 0);
+    const int32_t rb = RQ_BAL(r);
+    if (rb == b1) { RQ_SET_BAL(q, 0); RQ_SET_BAL(p, -b1); }
+    else if (rb == 0) { RQ_SET_BAL(q, 0); RQ_SET_BAL(p, 0); }
+    else { RQ_SET_BAL(q, b1); RQ_SET_BAL(p, 0); }
+    RQ_SET_BAL(r, 0);
     return r;
 }
 
 // x: a node prepared by rq_node_set
-__device__ inline void rq_insert(RqTree &t, int32_t x)
+template <class ST> __device__ inline void rq_insert(RqTreeT<ST> &t, int32_t x)
 {
-    unsigned char stack[RQ_MAX_DEPTH];
-    int32_t path[RQ_MAX_DEPTH];
+    // stack[] = t.st.sd(0, .), path[] = t.st.sp(0, .)
     int32_t bp, bq, p, q, r;
     int i, which = 0, top, path_len;
-    const int32_t xy = RQ_GET(x, y), xi = RQ_GET(x, i);
+    const int32_t xy = RQ_Y(x), xi = RQ_I(x);
     bp = t.root; bq = RQ_NIL;
-    for (p = bp, q = bq, top = path_len = 0; p != RQ_NIL; q = p, p = RQ_GET(p, p[which])) {
-        const int cmp = rq_cmp_node(t, xy, xi, p);
+    for (p = bp, q = bq, top = path_len = 0; p != RQ_NIL;) {
+        int32_t ny, ni, nl, nr, nb;
+        t.st.hot(rq_ok(t, p), ny, ni, nl, nr, nb);      // key, children and balance of p in one piece
+        const int cmp = rq_cmp_key(xy, xi, ny, ni);
         if (cmp == 0) return;     // (y, i) is unique: never taken
-        if (RQ_GET(p, balance) != 0) { bq = q; bp = p; top = 0; }
-        stack[top++] = (unsigned char)(which = (cmp > 0));
-        path[path_len++] = p;
-        if (path_len >= RQ_MAX_DEPTH - 1) { if (!t.bad) t.bad = 4; return; }
+        if (nb != 0) { bq = q; bp = p; top = 0; }
+        which = (cmp > 0);
+        t.st.set_sd(0, top++, which);
+        t.st.set_sp(0, path_len++, p);
+        if (path_len >= ST::max_depth - 1) { if (!t.bad) t.bad = 4; return; }
+        q = p; p = which ? nr : nl;
     }
+    ++t.n_live;
     if (q == RQ_NIL) t.root = x;
-    else RQ_SET(q, p[which], x);
+    else RQ_SET_CH(q, which, x);
     if (bp == RQ_NIL) return;
-    for (i = 0; i < path_len; ++i) RQ_SET(path[i], size, RQ_GET(path[i], size) + 1u);
     for (i = path_len - 1; i >= 0; --i) {
-        rq_update_min(t, path[i], RQ_GET(path[i], p[0]), RQ_GET(path[i], p[1]));
-        if (RQ_GET(path[i], s) != x) break;
+        const int32_t pi = t.st.sp(0, i);
+        rq_update_min(t, pi, RQ_CH(pi, 0), RQ_CH(pi, 1));
+        if (RQ_S(pi) != x) break;
     }
-    for (p = bp, top = 0; p != x; p = RQ_GET(p, p[stack[top]]), ++top) {
-        if (stack[top] == 0) RQ_SET(p, balance, RQ_GET(p, balance) - 1);
-        else RQ_SET(p, balance, RQ_GET(p, balance) + 1);
+    for (p = bp, top = 0; p != x; ++top) {
+        const int dd = t.st.sd(0, top);
+        if (dd == 0) RQ_SET_BAL(p, RQ_BAL(p) - 1);
+        else RQ_SET_BAL(p, RQ_BAL(p) + 1);
+        p = RQ_CH(p, dd);
     }
-    const int32_t bb = RQ_GET(bp, balance);
+    const int32_t bb = RQ_BAL(bp);
     if (bb > -2 && bb < 2) return;
     which = (bb < 0);
     const int b1 = which == 0 ? +1 : -1;
-    q = RQ_GET(bp, p[1 - which]);
-    if (RQ_GET(q, balance) == b1) {
+    q = RQ_CH(bp, 1 - which);
+    if (RQ_BAL(q) == b1) {
         r = rq_rotate1(t, bp, which);
-        RQ_SET(q, balance, 0); RQ_SET(bp, balance, 0);
+        RQ_SET_BAL(q, 0); RQ_SET_BAL(bp, 0);
     } else r = rq_rotate2(t, bp, which);
     if (bq == RQ_NIL) t.root = r;
-    else { const int wi = bp != RQ_GET(bq, p[0]); RQ_SET(bq, p[wi], r); }      // (the index first: the macro evaluates its field expression twice)
+    else { const int wi = bp != RQ_CH(bq, 0); RQ_SET_CH(bq, wi, r); }
 }
 
 // krmq_erase of the node with key (y, i); returns its index or RQ_NIL.  path[0] stands for upstream's `fake` node.
-__device__ inline int32_t rq_erase(RqTree &t, int32_t ky, int32_t ki)
+template <class ST> __device__ inline int32_t rq_erase(RqTreeT<ST> &t, int32_t ky, int32_t ki)
 {
-    int32_t p, path[RQ_MAX_DEPTH], fake;
-    unsigned char dir[RQ_MAX_DEPTH];
+    // path[] = t.st.sp(0, .), dir[] = t.st.sd(0, .)
+#define PATH(i) t.st.sp(0, (i))
+#define DIR(i) t.st.sd(0, (i))
+    int32_t p, fake;
     int i, d = 0, cmp;
     if (t.root == RQ_NIL) return RQ_NIL;
     fake = rq_alloc(t);
     if (fake == RQ_NIL) { if (!t.bad) t.bad = 3; return RQ_NIL; }
-    {   // fake = **root_, with the tree below its left link
-        RqNode z = *rq_at(t, t.root);
-        z.p[0] = t.root; z.p[1] = RQ_NIL;
-        t.n[fake] = z;
-        if (RQ_CACHE_ON && t.C.c) { const int32_t sl = fake & t.C.mask; t.C.c[sl] = z; t.C.tag[sl] = fake; }
-    }
-    for (cmp = -1, p = fake; cmp; cmp = rq_cmp_node(t, ky, ki, p)) {
+    t.st.fake(fake, rq_ok(t, t.root));
+    int32_t p_l = t.root, p_r = RQ_NIL, p_bal = 0;      // (children and balance of the node the walk stands on; fake's left link is the root)
+    for (cmp = -1, p = fake; cmp;) {
         const int which = (cmp > 0);
-        dir[d] = (unsigned char)which;
-        path[d++] = p;
-        if (d >= RQ_MAX_DEPTH - 2) { if (!t.bad) t.bad = 5; rq_free(t, fake); return RQ_NIL; }
-        p = RQ_GET(p, p[which]);
+        t.st.set_sd(0, d, which);
+        t.st.set_sp(0, d++, p);
+        if (d >= ST::max_depth - 2) { if (!t.bad) t.bad = 5; rq_free(t, fake); return RQ_NIL; }
+        p = which ? p_r : p_l;
         if (p == RQ_NIL) { rq_free(t, fake); return RQ_NIL; }
+        int32_t ny, ni;
+        t.st.hot(rq_ok(t, p), ny, ni, p_l, p_r, p_bal);
+        cmp = rq_cmp_key(ky, ki, ny, ni);
     }
-    for (i = 1; i < d; ++i) RQ_SET(path[i], size, RQ_GET(path[i], size) - 1u);
-    const int32_t p_l = RQ_GET(p, p[0]), p_r = RQ_GET(p, p[1]), p_bal = RQ_GET(p, balance);
-    const uint32_t p_size = RQ_GET(p, size);
+    --t.n_live;
     if (p_r == RQ_NIL) {
-        RQ_SET(path[d - 1], p[dir[d - 1]], p_l);
+        RQ_SET_CH(PATH(d - 1), DIR(d - 1), p_l);
     } else {
         int32_t q = p_r;
-        if (RQ_GET(q, p[0]) == RQ_NIL) {
-            RQ_SET(q, p[0], p_l);
-            RQ_SET(q, balance, p_bal);
-            RQ_SET(path[d - 1], p[dir[d - 1]], q);
-            path[d] = q; dir[d++] = 1;
-            RQ_SET(q, size, p_size - 1u);
+        if (RQ_CH(q, 0) == RQ_NIL) {
+            RQ_SET_CH(q, 0, p_l);
+            RQ_SET_BAL(q, p_bal);
+            RQ_SET_CH(PATH(d - 1), DIR(d - 1), q);
+            t.st.set_sp(0, d, q); t.st.set_sd(0, d++, 1);
         } else {
             int32_t r;
             const int e = d++;
             for (;;) {
-                dir[d] = 0;
-                path[d++] = q;
-                if (d >= RQ_MAX_DEPTH - 1) { if (!t.bad) t.bad = 6; rq_free(t, fake); return RQ_NIL; }
-                r = RQ_GET(q, p[0]);
-                if (RQ_GET(r, p[0]) == RQ_NIL) break;
+                t.st.set_sd(0, d, 0);
+                t.st.set_sp(0, d++, q);
+                if (d >= ST::max_depth - 1) { if (!t.bad) t.bad = 6; rq_free(t, fake); return RQ_NIL; }
+                r = RQ_CH(q, 0);
+                if (RQ_CH(r, 0) == RQ_NIL) break;
                 q = r;
             }
-            RQ_SET(r, p[0], p_l);
-            RQ_SET(q, p[0], RQ_GET(r, p[1]));
-            RQ_SET(r, p[1], p_r);
-            RQ_SET(r, balance, p_bal);
-            RQ_SET(path[e - 1], p[dir[e - 1]], r);
-            path[e] = r; dir[e] = 1;
-            for (i = e + 1; i < d; ++i) RQ_SET(path[i], size, RQ_GET(path[i], size) - 1u);
-            RQ_SET(r, size, p_size - 1u);
+            RQ_SET_CH(r, 0, p_l);
+            RQ_SET_CH(q, 0, RQ_CH(r, 1));
+            RQ_SET_CH(r, 1, p_r);
+            RQ_SET_BAL(r, p_bal);
+            RQ_SET_CH(PATH(e - 1), DIR(e - 1), r);
+            t.st.set_sp(0, e, r); t.st.set_sd(0, e, 1);
         }
     }
-    for (i = d - 1; i >= 0; --i) rq_update_min(t, path[i], RQ_GET(path[i], p[0]), RQ_GET(path[i], p[1]));
+    for (i = d - 1; i >= 0; --i) { const int32_t pi = PATH(i); rq_update_min(t, pi, RQ_CH(pi, 0), RQ_CH(pi, 1)); }
     while (--d > 0) {
-        const int32_t q = path[d];
+        const int32_t q = PATH(d);
         int which, other, b1 = 1, b2 = 2;
-        which = dir[d]; other = 1 - which;
+        which = DIR(d); other = 1 - which;
         if (which) { b1 = -b1; b2 = -b2; }
-        const int32_t qb = RQ_GET(q, balance) + b1;
-        RQ_SET(q, balance, qb);
+        const int32_t qb = RQ_BAL(q) + b1;
+        RQ_SET_BAL(q, qb);
         if (qb == b1) break;
         else if (qb == b2) {
-            const int32_t r = RQ_GET(q, p[other]);
-            const int32_t rbal = RQ_GET(r, balance);
+            const int32_t r = RQ_CH(q, other);
+            const int32_t rbal = RQ_BAL(r);
             if (rbal == -b1) {
                 const int32_t nr = rq_rotate2(t, q, which);
-                RQ_SET(path[d - 1], p[dir[d - 1]], nr);
+                RQ_SET_CH(PATH(d - 1), DIR(d - 1), nr);
             } else {
                 const int32_t nr = rq_rotate1(t, q, which);
-                RQ_SET(path[d - 1], p[dir[d - 1]], nr);
+                RQ_SET_CH(PATH(d - 1), DIR(d - 1), nr);
                 if (rbal == 0) {
-                    RQ_SET(r, balance, -b1);
-                    RQ_SET(q, balance, b1);
+                    RQ_SET_BAL(r, -b1);
+                    RQ_SET_BAL(q, b1);
                     break;
-                } else { RQ_SET(r, balance, 0); RQ_SET(q, balance, 0); }
+                } else { RQ_SET_BAL(r, 0); RQ_SET_BAL(q, 0); }
             }
         }
     }
-    t.root = RQ_GET(fake, p[0]);
+    t.root = RQ_CH(fake, 0);
     rq_free(t, fake);
     return p;
+#undef PATH
+#undef DIR
 }
 
 // krmq_rmq over the CLOSED key interval [(lo_y, lo_i), (hi_y, hi_i)]
-__device__ inline int32_t rq_rmq(const RqTree &t, int32_t lo_y, int32_t lo_i, int32_t hi_y, int32_t hi_i)
+template <class ST> __device__ inline int32_t rq_rmq(const RqTreeT<ST> &tc, int32_t lo_y, int32_t lo_i, int32_t hi_y, int32_t hi_i)
 {
-    int32_t p = t.root, path[2][RQ_MAX_DEPTH], min;
-    int plen[2] = {0, 0}, pcmp[2][RQ_MAX_DEPTH], i, cmp, lca;
+    RqTreeT<ST> &t = const_cast<RqTreeT<ST> &>(tc);      // (the walks' path arrays belong to the storage)
+    // path[w][] = t.st.sp(w, .), pcmp[w][] = t.st.sd(w, .)
+    int32_t p = t.root, min;
+    int plen[2] = {0, 0}, i, cmp, lca;
     if (t.root == RQ_NIL) return RQ_NIL;
-    while (p != RQ_NIL) {
-        cmp = rq_cmp_node(t, lo_y, lo_i, p);
-        if (plen[0] >= RQ_MAX_DEPTH - 1) { if (!t.bad) const_cast<RqTree &>(t).bad = 7; return RQ_NIL; }
-        path[0][plen[0]] = p; pcmp[0][plen[0]++] = cmp;
-        if (cmp < 0) p = RQ_GET(p, p[0]);
-        else if (cmp > 0) p = RQ_GET(p, p[1]);
-        else break;
-    }
-    p = t.root;
-    while (p != RQ_NIL) {
-        cmp = rq_cmp_node(t, hi_y, hi_i, p);
-        if (plen[1] >= RQ_MAX_DEPTH - 1) { if (!t.bad) const_cast<RqTree &>(t).bad = 8; return RQ_NIL; }
-        path[1][plen[1]] = p; pcmp[1][plen[1]++] = cmp;
-        if (cmp < 0) p = RQ_GET(p, p[0]);
-        else if (cmp > 0) p = RQ_GET(p, p[1]);
-        else break;
+    for (int w = 0; w < 2; ++w) {
+        const int32_t key_y = w ? hi_y : lo_y, key_i = w ? hi_i : lo_i;
+        p = t.root;
+        while (p != RQ_NIL) {
+            int32_t ny, ni, nl, nr, nb;
+            t.st.hot(rq_ok(t, p), ny, ni, nl, nr, nb);
+            cmp = rq_cmp_key(key_y, key_i, ny, ni);
+            if (plen[w] >= ST::max_depth - 1) { if (!t.bad) t.bad = 7 + w; return RQ_NIL; }
+            t.st.set_sp(w, plen[w], p); t.st.set_sd(w, plen[w]++, cmp);
+            if (cmp < 0) p = nl;
+            else if (cmp > 0) p = nr;
+            else break;
+        }
     }
     for (i = 0; i < plen[0] && i < plen[1]; ++i)
-        if (path[0][i] == path[1][i] && pcmp[0][i] <= 0 && pcmp[1][i] >= 0) break;
+        if (t.st.sp(0, i) == t.st.sp(1, i) && t.st.sd(0, i) <= 0 && t.st.sd(1, i) >= 0) break;
     if (i == plen[0] || i == plen[1]) return RQ_NIL;
-    lca = i; min = path[0][lca];
+    lca = i; min = t.st.sp(0, lca);
     for (i = lca + 1; i < plen[0]; ++i) {
-        if (pcmp[0][i] <= 0) {
-            if (rq_lt2(t, path[0][i], min)) min = path[0][i];
-            const int32_t c = RQ_GET(path[0][i], p[1]);
-            if (c != RQ_NIL) { const int32_t cs = RQ_GET(c, s); if (rq_lt2(t, cs, min)) min = cs; }
+        if (t.st.sd(0, i) <= 0) {
+            const int32_t pi = t.st.sp(0, i);
+            if (rq_lt2(t, pi, min)) min = pi;
+            const int32_t c = RQ_CH(pi, 1);
+            if (c != RQ_NIL) { const int32_t cs = RQ_S(c); if (rq_lt2(t, cs, min)) min = cs; }
         }
     }
     for (i = lca + 1; i < plen[1]; ++i) {
-        if (pcmp[1][i] >= 0) {
-            if (rq_lt2(t, path[1][i], min)) min = path[1][i];
-            const int32_t c = RQ_GET(path[1][i], p[0]);
-            if (c != RQ_NIL) { const int32_t cs = RQ_GET(c, s); if (rq_lt2(t, cs, min)) min = cs; }
+        if (t.st.sd(1, i) >= 0) {
+            const int32_t pi = t.st.sp(1, i);
+            if (rq_lt2(t, pi, min)) min = pi;
+            const int32_t c = RQ_CH(pi, 0);
+            if (c != RQ_NIL) { const int32_t cs = RQ_S(c); if (rq_lt2(t, cs, min)) min = cs; }
         }
     }
     return min;
@@ -297,31 +390,31 @@ __device__ inline int32_t rq_rmq(const RqTree &t, int32_t lo_y, int32_t lo_i, in
 
 // krmq_interval's lower bound and krmq_itr_prev: the largest element <= (y, i), then its in-order predecessors
 struct RqItr { int32_t stack[RQ_MAX_DEPTH]; int top; };      // top < 0: exhausted
-__device__ inline bool rq_itr_find_le(const RqTree &t, int32_t ky, int32_t ki, RqItr &it)
+template <class ST> __device__ inline bool rq_itr_find_le(const RqTreeT<ST> &t, int32_t ky, int32_t ki, RqItr &it)
 {
     int32_t p = t.root;
     int d = 0, best = -1;
     while (p != RQ_NIL) {
         const int cmp = rq_cmp_node(t, ky, ki, p);
-        if (d >= RQ_MAX_DEPTH - 1) { if (!t.bad) const_cast<RqTree &>(t).bad = 9; it.top = -1; return false; }
+        if (d >= RQ_MAX_DEPTH - 1) { if (!t.bad) const_cast<RqTreeT<ST> &>(t).bad = 9; it.top = -1; return false; }
         it.stack[d++] = p;
-        if (cmp < 0) p = RQ_GET(p, p[0]);
-        else if (cmp > 0) { best = d; p = RQ_GET(p, p[1]); }
+        if (cmp < 0) p = RQ_CH(p, 0);
+        else if (cmp > 0) { best = d; p = RQ_CH(p, 1); }
         else { best = d; break; }
     }
     if (best < 0) { it.top = -1; return false; }
     it.top = best - 1;
     return true;
 }
-__device__ inline bool rq_itr_prev(const RqTree &t, RqItr &it)
+template <class ST> __device__ inline bool rq_itr_prev(const RqTreeT<ST> &t, RqItr &it)
 {
     int32_t p;
     if (it.top < 0) return false;
-    p = RQ_GET(it.stack[it.top], p[0]);
+    p = RQ_CH(it.stack[it.top], 0);
     if (p != RQ_NIL) {
-        for (; p != RQ_NIL; p = RQ_GET(p, p[1])) { if (it.top >= RQ_MAX_DEPTH - 2) { if (!t.bad) const_cast<RqTree &>(t).bad = 10; it.top = -1; return false; } it.stack[++it.top] = p; }
+        for (; p != RQ_NIL; p = RQ_CH(p, 1)) { if (it.top >= RQ_MAX_DEPTH - 2) { if (!t.bad) const_cast<RqTreeT<ST> &>(t).bad = 10; it.top = -1; return false; } it.stack[++it.top] = p; }
         return true;
     }
-    do { p = it.stack[it.top--]; } while (it.top >= 0 && p == RQ_GET(it.stack[it.top], p[0]));
+    do { p = it.stack[it.top--]; } while (it.top >= 0 && p == RQ_CH(it.stack[it.top], 0));
     return it.top >= 0;
 }

@@ -127,6 +127,7 @@ EXPORTS = [
     "sh_index_build", "sh_index_build_device", "sh_index_build_fasta", "sh_index_save", "sh_index_load",
     "sh_index_info_get", "sh_index_export", "sh_index_export_ref", "sh_index_free",
     "sh_ctx_create", "sh_ctx_destroy", "sh_ctx_debug_list", "sh_classify_device", "sh_classify_batch",
+    "sh_index_replicate", "sh_index_set_size", "sh_index_set_free", "sh_classify_sharded",
     "sh_synth_ref_device", "sh_synth_reads_device", "sh_synth_long_reads_device", "sh_bench_gather", "sh_dbg_rmq_trace", "sh_dbg_wave_ops", "sh_pack_flags_device",
     "sh_reads_run", "sh_release_cached_ctx", "sh_host_get_id", "sh_host_filter_fastx", "sh_host_filter_fastx_stream", "sh_host_read_difference",
     "sh_classifier_run", "sh_classifier_taxids", "sh_alignment_run",
@@ -167,6 +168,10 @@ def load():
     L.sh_ctx_destroy.argtypes = [vp]
     L.sh_classify_device.argtypes = [vp, vp, vp, u64, u64, vp, vp, vp, C.POINTER(Stats)]
     L.sh_classify_batch.argtypes = [vp, C.POINTER(Opts), vp, vp, u64, vp, vp, C.POINTER(Stats)]
+    L.sh_index_replicate.argtypes = [vp, C.POINTER(i32), u32, C.POINTER(vp)]
+    L.sh_index_set_size.argtypes = [vp]
+    L.sh_index_set_free.argtypes = [vp]
+    L.sh_classify_sharded.argtypes = [vp, C.POINTER(Opts), vp, vp, u64, vp, vp, C.POINTER(Stats), vp]
     L.sh_synth_ref_device.argtypes = [C.POINTER(RefParams), u64, u64, vp, vp]
     L.sh_synth_reads_device.argtypes = [C.POINTER(RefParams), C.POINTER(ReadParams), u64, u64, vp, vp, vp]
     L.sh_synth_long_reads_device.argtypes = [C.POINTER(RefParams), C.POINTER(ReadParams), u64, u64, vp, u64, vp, vp]
@@ -183,8 +188,9 @@ def load():
     L.sh_host_filter_fastx_stream.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u64, i32, u64, i32, i32, C.POINTER(u64), C.POINTER(u64)]
     L.sh_host_read_difference.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     for name in EXPORTS:
-        if name not in ("sh_version", "sh_device_count", "sh_last_error"):
+        if name not in ("sh_version", "sh_device_count", "sh_last_error", "sh_index_set_size"):
             getattr(L, name).restype = i32
+    L.sh_index_set_size.restype = u32
     _LIB = L
     return L
 
@@ -300,6 +306,10 @@ class Index:
             check(rc)
         return flags[:n], (tr[:n] if want_trace else None), st.as_dict(), rc
 
+    def replicate(self, devices=None):
+        """One replica of the index per shard (sh_index_replicate): devices = list of device ordinals (None: every visible device)."""
+        return IndexSet(self, devices)
+
     def gather_bench(self, n_probes=1 << 28, iters=3):
         gbs, ms = C.c_double(), C.c_double()
         check(load().sh_bench_gather(self.h, n_probes, iters, C.byref(gbs), C.byref(ms)))
@@ -308,6 +318,49 @@ class Index:
     def close(self):
         if getattr(self, "h", None):
             load().sh_index_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class IndexSet:
+    """sh_index_set: replicas of one index, one per shard; classify() is sh_classify_sharded (the in-process multi-GPU fan-out a Rust
+    caller binds instead of the rayon loop of cleaner.rs:546-559).  Marshalling only."""
+
+    def __init__(self, index, devices=None):
+        L = require_gpu()
+        self.index = index      # borrowed for its own device: keep it alive
+        h = C.c_void_p()
+        if devices is None:
+            check(L.sh_index_replicate(index.h, None, 0, C.byref(h)))
+        else:
+            arr = (C.c_int32 * len(devices))(*devices)
+            check(L.sh_index_replicate(index.h, arr, len(devices), C.byref(h)))
+        self.h = h
+        self.n_shards = int(L.sh_index_set_size(h))
+
+    def classify(self, bases, offsets, want_trace=False):
+        L = require_gpu()
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        flags = np.zeros(max(n, 1), dtype=np.uint8)
+        tr = np.zeros(max(n, 1), dtype=TRACE_DTYPE) if want_trace else None
+        first = np.zeros(self.n_shards + 1, dtype=np.uint64)
+        st = Stats()
+        rc = L.sh_classify_sharded(self.h, C.byref(self.index.opts), bases.ctypes.data, offsets.ctypes.data, n, flags.ctypes.data,
+                                   tr.ctypes.data if want_trace else None, C.byref(st), first.ctypes.data)
+        if rc not in (SH_OK, SH_ERR_EMPTY_READ):
+            check(rc)
+        return flags[:n], (tr[:n] if want_trace else None), st.as_dict(), rc, first
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().sh_index_set_free(self.h)
             self.h = None
 
     def __del__(self):
@@ -343,8 +396,10 @@ class Context:
         return st.as_dict() if want_stats else None
 
     def debug_list(self, which):
-        """Ordinals (within the last chunk classified) of the reads that took a rare path: 0 re-chained with max_occ, 1 regs[0] aligned
-        base by base, 2 the complete procedure over every chain (sh_ctx_debug_list)."""
+        """Ordinals of the reads that took a rare path (sh_ctx_debug_list).  Short reads, within the last chunk classified: 0 re-chained with
+        max_occ, 1 regs[0] aligned base by base, 2 the complete procedure over every chain.  Long reads, within the last call: 3 long join on
+        the literal tree, 4 tie left open, 5 unresolved, 6 redone with every anchor, 7 memory on demand, 8 probe undecided, 9 second
+        working-memory size, 10 one-lane trees."""
         n = C.c_uint64()
         check(load().sh_ctx_debug_list(self.h, which, None, C.c_uint64(0), C.byref(n)))
         out = np.zeros(max(n.value, 1), dtype=np.uint32)

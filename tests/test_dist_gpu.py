@@ -70,7 +70,7 @@ def test_bench_spawns_its_ranks(tmp_path):
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["records_total"] == 200_000 and j["config"]["records_rank0"] == 100_000
     assert j["weak_scaling"]["records_per_gpu"] == 200_000 and j["union_bytes_gathered"] == 2 * 12500
-    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--small", "--steps", "2", "--warmup", "1", "--no-cpu"],
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--small", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-secondary"],
                          env=env, capture_output=True, text=True, timeout=280)
     j1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     assert j1["n_gpus"] == 1 and j1["result"]["reads_removed"] == j["result"]["reads_removed"]

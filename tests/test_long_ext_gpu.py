@@ -179,21 +179,22 @@ def test_reads_beyond_every_prepared_size_get_memory_of_their_own(S, oracle, cfg
     print("on demand:", st["n_ext_ondemand"], st2["n_ext_ondemand"])
 
 
-@pytest.mark.parametrize("cache", [0])
-def test_the_long_joins_tree_on_the_device_answers_like_the_oracles(S, oracle, cache):
-    """sh_rmq_tree.h executed by the GPU (one lane, nodes in HBM, hot nodes in the LDS cache): the random insert / erase / query sequence
+@pytest.mark.parametrize("lds", [0, 1])
+def test_the_long_joins_tree_on_the_device_answers_like_the_oracles(S, oracle, lds):
+    """sh_rmq_tree.h executed by the GPU, one lane, on both storages - nodes in an HBM pool (lds = 0), the whole tree in LDS through
+    address-space-3 pointers with 16-bit links (lds = 1, what lr_rmq_fill<NR, true> runs on): the random insert / erase / query sequence
     with heavily tied priorities of oracle/mm_rmq.c's mmo_rmq_trace must be answered element for element like the oracle's tree."""
     import ctypes as C
     Lo = oracle.lib()
     Lo.mmo_rmq_trace.restype = C.c_int64
     Lo.mmo_rmq_trace.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L = S.load()
-    n_ops = 30000
-    for seed, key_range, fifo in ((1, 40, 1), (2, 5000, 0), (3, 300, 1)):
+    n_ops = 9000 if lds else 30000      # (the LDS tree of the test kernel holds 4096 nodes; ~0.3 n_ops are alive at the end)
+    for seed, key_range, fifo in ((1, 40, 1), (2, 5000, 0), (3, 300, 1), (4, 100000, 1)):
         a = np.full(n_ops, -7, np.int64)
         na = Lo.mmo_rmq_trace(seed, n_ops, key_range, fifo, a.ctypes.data)
         b = np.full(n_ops, -9, np.int64)
         nb = C.c_int64(0)
-        S.check(L.sh_dbg_rmq_trace(0, seed, n_ops, key_range, fifo, cache, b.ctypes.data, C.byref(nb)))
+        S.check(L.sh_dbg_rmq_trace(0, seed, n_ops, key_range, fifo, lds, b.ctypes.data, C.byref(nb)))
         assert nb.value == na, f"device guard / count: {nb.value} vs {na}"
-        assert np.array_equal(a[:na], b[:na]), f"seed {seed} cache {cache}: first difference at query {int(np.where(a[:na] != b[:na])[0][0])}"
+        assert np.array_equal(a[:na], b[:na]), f"seed {seed} lds {lds}: first difference at query {int(np.where(a[:na] != b[:na])[0][0])}"

@@ -228,7 +228,7 @@ def test_c_abi_exports_every_declared_symbol():
 def test_c_abi_presets_and_errors_without_gpu():
     from scrubby_amd import lib
     L = lib.load()
-    assert L.sh_version() == 103
+    assert L.sh_version() == 104
     o = lib.preset("sr")
     assert (o.k, o.w, o.mid_occ, o.max_occ) == (21, 11, 1000, 5000)
     with pytest.raises(lib.ScrubbyHipError) as e:

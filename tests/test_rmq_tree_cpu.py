@@ -2,7 +2,8 @@
 long join, /root/reference/src/cleaner.rs:552 with the long-read presets) against the oracle's (oracle/mm_rmq.c), both compiled for the
 host: the same random insert / erase / query sequences with HEAVILY tied priorities must return the same elements - which of several equal
 minima comes back is decided by the tree's shape and the subtree-minimum pointers its rotations carried over, the very thing the device
-code exists to reproduce.  With and without the LDS node cache (a write-through mirror: the pool must equal it at the end)."""
+code exists to reproduce.  On both storages: the 32-byte node pool (HBM on the device) and the structure-of-arrays form with 16-bit links
+(LDS on the device)."""
 import ctypes as C
 import os
 import subprocess
@@ -34,11 +35,11 @@ def test_device_tree_returns_the_oracles_element_among_equal_minima(oracle, host
         a = np.full(n_ops, -7, np.int64)
         na = Lo.mmo_rmq_trace(seed, n_ops, key_range, fifo, a.ctypes.data)
         assert na > n_ops // 5
-        for cache in (0, 16, 1024):
+        for cache in (0, 1):
             b = np.full(n_ops, -9, np.int64)
             nb = host_tree.rqh_trace(seed, n_ops, key_range, fifo, cache, b.ctypes.data)
-            assert nb == na, "cache and pool disagree" if nb < 0 else "different number of queries"
-            assert np.array_equal(a[:na], b[:nb]), f"seed {seed} cache {cache}: first difference at query {int(np.where(a[:na] != b[:nb])[0][0])}"
+            assert nb == na, f"guard {nb}" if nb < 0 else "different number of queries"
+            assert np.array_equal(a[:na], b[:nb]), f"seed {seed} lds {cache}: first difference at query {int(np.where(a[:na] != b[:nb])[0][0])}"
         assert int((a[:na] >= 0).sum()) > na // 2
 
 
@@ -61,7 +62,7 @@ def _lattice(rng, n_per, period, copies_ref, copies_read, flank=60):
     return np.ascontiguousarray(a)
 
 
-@pytest.mark.parametrize("cache", [0, 64, 512])
+@pytest.mark.parametrize("cache", [0, 1])
 def test_scoring_pass_on_the_device_trees_equals_the_oracles(oracle, host_tree, cache):
     """mg_lchain_rmq's scoring pass over lattices of anchors (perfect tandem arrays: many anchors per reference position and per query
     position, ties everywhere) on the product's trees, against the oracle's mmo_lchain_rmq_fill: f and p equal, no guard of the device
