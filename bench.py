@@ -1043,12 +1043,14 @@ LONG_STRATA = ((3, "rmq_exact_tree"), (4, "rmq_tie_left_open"), (5, "ext_unresol
                (8, "probe_undecided_full_procedure"), (9, "second_working_memory_size"), (10, "one_lane_trees"))
 
 
-def stratified_parity_long(index, ctx, info, d_reads, d_off, d_flags, n_rec, preset, seconds, seed=20261005, cap_per_stratum=4000):
+def stratified_parity_long(index, ctx, info, d_reads, d_off, d_flags, n_rec, preset, seconds, seed=20261005, cap_per_stratum=None):
     """The long-read form of stratified_parity: the oracle over EVERY read of the batch (the last call of `ctx`: sh_ctx_debug_list 3..10) whose
     answer came by one of the extension stage's rarer paths - long join redone on the literal tree, a tie left open, left at the chain-level
     answer, redone with every anchor, memory on demand, probe undecided, second working-memory size, one-lane trees - plus a random rest that
     fills `seconds` of CPU time.  A stratum larger than cap_per_stratum is sampled (and says so)."""
     from oracle import oracle as O
+    if cap_per_stratum is None:      # the dedicated run (--cpu-seconds >= 15) takes every read of a stratum up to 4000; the headline's secondary line a sample of 150
+        cap_per_stratum = 4000 if seconds >= 15 else 150
     rng = np.random.default_rng(seed)
     strata, sampled = {}, {}
     for which, nm in LONG_STRATA:

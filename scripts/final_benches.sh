@@ -5,7 +5,7 @@ run() { tag=$1; shift; timeout -k 10 $TMO python bench.py "$@" > gpurun_out/${R}
 import json; d=json.load(open("gpurun_out/${R}_${tag}.json")); print("${tag}", d.get("value"), d.get("unit"), d.get("ms_per_step"))
 PY
 }
-TMO=300 run bench --steps 5 --warmup 1 &&
+TMO=300 run bench --steps 5 --warmup 1 --no-secondary &&
 TMO=200 run chain_only_bench --chain-only --steps 5 --warmup 1 &&
 TMO=300 run srdiv_bench --workload sr-div --steps 3 --warmup 1 &&
 TMO=200 run k2_bench --workload k2 &&

@@ -6,7 +6,7 @@ WHAT=${*:-sr ont k2}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for W in $WHAT; do
   case $W in
-    sr)  ARGS=""; TAG=""; NREC=20000000; LAUNCHES=1; TOP=28 ;;
+    sr)  ARGS="--no-secondary"; TAG=""; NREC=20000000; LAUNCHES=1; TOP=28 ;;
     ont) ARGS="--workload ont"; TAG="_ont"; NREC=1000000; LAUNCHES=2; TOP=20 ;;
     k2)  ARGS="--workload k2"; TAG="_k2"; NREC=40000000; LAUNCHES=1; TOP=12 ;;
   esac

@@ -137,7 +137,7 @@ extern "C" sh_status sh_classify_batch(const sh_index *idx, const sh_opts *opts,
     const uint64_t need_reads = std::min(CH, n_reads);
     std::string env_sig;
     for (const char *v : {"SCRUBBY_HIP_ARENA_MB", "SCRUBBY_HIP_NO_FLAG_STOP", "SCRUBBY_HIP_NO_PAIR", "SCRUBBY_HIP_PAIR_MIN", "SCRUBBY_HIP_NO_S1", "SCRUBBY_HIP_EXT_MB", "SCRUBBY_HIP_EXT_REGCAP", "SCRUBBY_HIP_NO_LEMMA",
-                          "SCRUBBY_HIP_LEXT_A", "SCRUBBY_HIP_LEXT_BIG_A", "SCRUBBY_HIP_LEXT_P_KB", "SCRUBBY_HIP_LEXT_BIG_P_KB", "SCRUBBY_HIP_STAGE_MB", "SCRUBBY_HIP_STREAMS"}) { const char *e = getenv(v); env_sig += e ? e : "-"; env_sig += '|'; }
+                          "SCRUBBY_HIP_LEXT_A", "SCRUBBY_HIP_LEXT_BIG_A", "SCRUBBY_HIP_LEXT_P_KB", "SCRUBBY_HIP_RMQ_EXACT_MAX", "SCRUBBY_HIP_RMQ_ONE_LANE", "SCRUBBY_HIP_LEXT_BIG_P_KB", "SCRUBBY_HIP_STAGE_MB", "SCRUBBY_HIP_STREAMS"}) { const char *e = getenv(v); env_sig += e ? e : "-"; env_sig += '|'; }
     const bool no_pool = false;
 
     BatchScratch *B = nullptr;
@@ -755,9 +755,52 @@ __device__ inline long long dbg_rmq_trace_on(TT &T, uint64_t seed, int32_t n_ops
 #undef RND
     return T.bad ? -(long long)T.bad : n_out;
 }
+// the same sequence with the insertions and erasures done by the whole wave (rq_insert_w / rq_erase_w); queries on lane 0
+__device__ inline long long dbg_rmq_trace_wave(RqTreeT<RqLds> &T, uint64_t seed, int32_t n_ops, int32_t key_range, int32_t fifo, int32_t *ly, int32_t *li, long long *out)
+{
+    const int lane = rqw_lane();
+    long long n_out = 0, head = 0, n_all = 0;
+    uint64_t s = seed * 0x9E3779B97F4A7C15ULL + 1;
+#define RND() (s ^= s << 13, s ^= s >> 7, s ^= s << 17, s)
+    for (int op = 0; op < n_ops; ++op) {
+        const unsigned r = (unsigned)(RND() % 10);
+        const long long n_live = n_all - head;
+        if (r < 5 || n_live == 0) {
+            const int32_t y = (int32_t)(RND() % (uint64_t)key_range); const double pri = (double)(RND() % 10);
+            if (rq_insert_w(T, y, op, pri) == RQ_NIL) return -100;
+            if (lane == 0) { ly[n_all] = y; li[n_all] = op; }
+            ++n_all;
+        } else if (r < 7) {
+            const long long k = fifo ? head : head + (long long)(RND() % (uint64_t)n_live);
+            // (lane 0's global stores of ly / li are read back by every lane: stores drained, L1 invalidated)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tbuffer_inv sc1" ::: "memory");
+            const int32_t ky = __atomic_load_n(ly + k, __ATOMIC_RELAXED), ki = __atomic_load_n(li + k, __ATOMIC_RELAXED);
+            const int32_t e = rq_erase_w(T, ky, ki);
+            if (e != RQ_NIL) rqw_free(T, e);
+            if (lane == 0) { ly[k] = ly[head]; li[k] = li[head]; }
+            ++head;
+        } else {
+            int32_t a = (int32_t)(RND() % (uint64_t)key_range), b = (int32_t)(RND() % (uint64_t)key_range);
+            if (a > b) { const int32_t tt = a; a = b; b = tt; }
+            int32_t ans = 0;
+            if (lane == 0) { const int32_t q = rq_rmq(T, a, INT32_MAX, b, 0); ans = q == RQ_NIL ? -1 : rq_i(T, q); out[n_out] = ans; }
+            ++n_out;
+        }
+    }
+#undef RND
+    return T.bad ? -(long long)T.bad : n_out;
+}
 __global__ void k_dbg_rmq_trace(uint64_t seed, int32_t n_ops, int32_t key_range, int32_t fifo, int32_t lds, RqNode *pool, int32_t *ly, int32_t *li, long long *out, long long *n_out_p)
 {
     __shared__ RqLdsMem<4096> s_m;
+    if (lds == 2) {      // every lane takes part
+        const unsigned long long t0 = wall_clock64();
+        RqTreeT<RqLds> T;
+        T.st.init(s_m); rq_reset(T);
+        const long long n = dbg_rmq_trace_wave(T, seed, n_ops, key_range, fifo, ly, li, out);
+        if (threadIdx.x == 0) { if (n >= 0 && n < n_ops - 1) out[n_ops - 1] = (long long)(wall_clock64() - t0); *n_out_p = n; }
+        return;
+    }
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();
     long long n = 0;

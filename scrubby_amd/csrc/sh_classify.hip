@@ -81,6 +81,7 @@ struct Counters {
     uint32_t ext_s3[8];           // SCRUBBY_HIP_DBG & 16: outcome of the local-cluster shortcut (k_expand): 0 tried, 1 no singleton / filtered seed, 2 singletons apart, 3 window grew / too many, 4 K > 64, 5 no margin over U_out, 6 lemma, 7 decided
     uint32_t ext_overflow, ext_n_list, ext_ticket, ext_regions, ext_dropped, ext_n_redo, ext_n_list2, ext_ticket2, ext_n_redo2, ext_ticket3, ext_n_unres, ext_ticket_unres, ext_n_unres_in, ext_pad8;      // extension stage (sh_align.h)
     uint32_t ext_n_recs[SINK_SHARDS]; unsigned long long ext_n_anch[SINK_SHARDS];                 // hand-over cursors, one per shard
+    uint32_t lext_n_exact2, lext_ticket_exact2;      // the exact pass's second list (reads of the 4096-anchor ring)
     uint32_t lext_hist[64]; uint32_t lext_ticket_g, lext_pad3; uint32_t lext_n_big, lext_ticket_big, lext_n_big2, lext_ticket_big2, lext_ticket_b, lext_pad2, lext_rechained, lext_rmq_tie, lext_err_read, lext_unresolved, lext_err_code, lext_pad;
     unsigned long long lext_clk[LR_NCLK], lext_d[8], lext_slow, lext_kernel_sum;  // long-read extension stage (sh_long.h): reads for the large-scratch pass, RMQ re-chains, steps with tied priorities
     uint32_t n_cl[4], cl_ticket, cl_ticket3;      // global queue of big clusters (k_cluster_dp), by size class; tickets: classes 0-2 one by one, class 3 eight at a time
@@ -2945,6 +2946,7 @@ struct ExtLongArgs {
     uint32_t *list; uint32_t *n_list, *ticket; uint32_t *big_list; uint32_t *n_big; Counters *ctr; uint8_t *flags; sh_trace *trace; int32_t flag_only, clk, probe;
     const uint32_t *hist; int32_t bin_cut, part;      // the size-ordered list's giants (bins >= bin_cut) come first: part 1 = all but them, 2 = only them, 0 = the whole list
     uint32_t *exact_list, *n_exact;                   // reads whose long join must run on the literal trees (lr_chains_wave returns 6)
+    uint32_t *exact_list2, *n_exact2;                 // ... those of them that needed the 4096-anchor ring already: straight to the exact pass with that ring
     uint32_t *unres_list, *n_unres;                   // reads that outgrew the large working memory too (with big_list == nullptr): redone with memory sized for them
     const uint32_t *drop; uint32_t *fb_list, *n_fb;   // k_lr_locus: what was left out of a read's anchors; reads that must be redone with every anchor
     uint32_t *started;                                // counts the blocks that have begun (the giants' grid: the main grid is launched once they hold their LDS)
@@ -3080,7 +3082,7 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
     // EXACT: the long join's main tree in LDS beside the ring (sh_rmq_tree.h).  It holds the look-back window only (max_gap reference bases:
     // at most ~1 500 anchors on the bench's satellite reads); a window beyond it sends the read to the instance with the larger ring and tree,
     // and from there to the one-lane version over node pools in HBM.
-    constexpr int TCAP = EXACT ? (NR >= 4096 ? 1792 : 1264) : 1;      // 32 B a node: 54 KB of LDS with the 512-anchor ring (three waves to a CU), 156 KB with the 4096-anchor ring
+    constexpr int TCAP = EXACT ? (NR >= 4096 ? 1792 : 1664) : 1;      // 32 B a node: 79 KB of LDS with the 1024-anchor ring (two waves to a CU), 156 KB with the 4096-anchor ring
     __shared__ RqLdsMem<TCAP> TM;
     RqLds TL{};
     if (EXACT) TL.init(TM);
@@ -3113,11 +3115,13 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
         LongOut o;
         const unsigned long long t_r0 = a.clk ? wall_clock64() : 0ull;
         const unsigned long long d0_before = clk.d[0];
+        LongClk clk_b = clk;
         if (a.clk) { clk.w_max = 0; clk.n_q = 0; }
         const int32_t rc = lr_chains_wave<NR, EXACT, FAT>(C, RL, AR_l, o, a.drop ? a.drop[r] : 0u, TL);
         if (a.clk && lane == 0) {
             const unsigned long long dt = wall_clock64() - t_r0;
-            if (EXACT && (a.clk & 2)) printf("[exact] read %u qlen %d chains %d anchors %llu window %llu queries %llu ms %.1f rc %d\n", r, C.qlen, o.n_chain, clk.d[0] - d0_before, clk.w_max, clk.n_q, dt / 1e5, rc);
+            if ((a.clk & 2) && (EXACT || a.part == 1) && dt > 20000000ull) printf("[%s] read %u qlen %d chains %d anchors %llu window %llu queries %llu ms %.1f rc %d | gather %.1f sort %.1f fill %.1f bt %.1f | ins %.1f trim %.1f query %.1f tally %.1f inner %.1f\n", EXACT ? "exact" : "main", r, C.qlen, o.n_chain, clk.d[0] - d0_before, clk.w_max, clk.n_q, dt / 1e5, rc,
+                                                           (clk.t[0] - clk_b.t[0]) / 1e5, (clk.t[1] - clk_b.t[1]) / 1e5, (clk.t[2] - clk_b.t[2]) / 1e5, (clk.t[3] - clk_b.t[3]) / 1e5, (clk.t[4] - clk_b.t[4]) / 1e5, (clk.t[5] - clk_b.t[5]) / 1e5, (clk.t[6] - clk_b.t[6]) / 1e5, (clk.t[7] - clk_b.t[7]) / 1e5, (clk.t[8] - clk_b.t[8]) / 1e5);
             atomicMax(&a.ctr->lext_slow, dt << 24 | (unsigned long long)(o.n_chain > 0xffffff ? 0xffffff : o.n_chain)); atomicAdd(&a.ctr->lext_kernel_sum, dt);
             atomicMax(&a.ctr->lext_slow2, dt << 32 | (unsigned long long)(uint32_t)C.qlen);
             atomicMax(&a.ctr->lext_slow3, dt << 32 | (unsigned long long)r);
@@ -3137,7 +3141,9 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
         }
         else if (rc == 6) {      // tied priorities / beyond the ring: the EXACT instance of this kernel takes the read
             if (lane == 0) {
-                a.exact_list[atomicAdd(a.n_exact, 1u)] = r;
+                // (a join of tens of thousands of anchors looks back over more of them than the small ring holds: every step would go to HBM)
+                if ((NR >= 4096 || o.n_join > 60000) && a.exact_list2) a.exact_list2[atomicAdd(a.n_exact2, 1u)] = r;
+                else a.exact_list[atomicAdd(a.n_exact, 1u)] = r;
                 lk_mark(a, r, LK_EXACT);
                 LongHdr h{0ull, -1, 0, 0, 0}; AR_l.hdr[r] = h;
                 if (C.err == 50u) atomicAdd(&a.ctr->lext_rmq_tie, 1u);
@@ -3170,20 +3176,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             // The list is being filled by the launch of the first size, running beside this one: an entry is taken only when there is one
             // (compare-and-swap on the ticket, so none is lost when this block gives up), the block sleeps between looks and leaves when the
             // other launch has ended and the list is empty - or after ~10 s of looks, whatever is left going to the launch that follows.
+            // A ticket is only drawn for an entry that is already THERE (the list is preset to ~0 and an entry is written once, right after
+            // its index was drawn by the producer): nothing is consumed and then given up on.
             uint32_t got = ~0u, rr = ~0u;
             if (lane == 0) {
                 for (uint32_t looks = 0; looks < 2000000u; ++looks) {
                     const uint32_t cur = __atomic_load_n(a.ticket, __ATOMIC_RELAXED), n = __atomic_load_n(a.n_list, __ATOMIC_RELAXED);
-                    if (cur < n) { if (atomicCAS(a.ticket, cur, cur + 1u) == cur) { got = cur; break; } continue; }
+                    if (cur < n) {
+                        const uint32_t e = __atomic_load_n(&a.list[cur], __ATOMIC_RELAXED);
+                        if (e != ~0u) { if (atomicCAS(a.ticket, cur, cur + 1u) == cur) { got = cur; rr = e; break; } continue; }
+                        __builtin_amdgcn_s_sleep(8);
+                        continue;
+                    }
                     if (__atomic_load_n(a.follow_done, __ATOMIC_RELAXED) && __atomic_load_n(a.n_list, __ATOMIC_RELAXED) <= __atomic_load_n(a.ticket, __ATOMIC_RELAXED)) break;
                     __builtin_amdgcn_s_sleep(127);
                 }
-                if (got != ~0u)
-                    for (uint32_t looks = 0; looks < 2000000u; ++looks) {      // the entry is written right after its index was drawn
-                        rr = __atomic_load_n(&a.list[got], __ATOMIC_RELAXED);
-                        if (rr != ~0u) break;
-                        __builtin_amdgcn_s_sleep(8);
-                    }
                 __threadfence();
             }
             t = (uint32_t)__builtin_amdgcn_readfirstlane((int)got); r = (uint32_t)__builtin_amdgcn_readfirstlane((int)rr);
@@ -3281,7 +3288,7 @@ struct sh_ctx {
     bool ext_long = false;
     LongParams LP{};
     uint8_t *d_lext[4] = {}; unsigned long long lext_per_wave[4] = {}; uint32_t lext_waves[4] = {}; LongSizes lext_sz[4] = {}; int n_cu = 256;      // [phase * 2 + tier]
-    uint32_t *d_lext_big = nullptr, *d_lext_big2 = nullptr, *d_lext_sorted = nullptr, *d_lext_unres[2] = {}, *d_lext_exact_list = nullptr;
+    uint32_t *d_lext_big = nullptr, *d_lext_big2 = nullptr, *d_lext_sorted = nullptr, *d_lext_unres[2] = {}, *d_lext_exact_list = nullptr, *d_lext_exact_list2 = nullptr, *d_lext_esorted = nullptr;
     uint8_t *d_lext_exact[2] = {}; unsigned long long lext_exact_per_wave[2] = {}; uint32_t lext_exact_waves[2] = {}; LongSizes lext_exact_sz[2] = {};      // the chains kernel with the long join on the literal trees
     uint8_t *d_larena = nullptr; unsigned long long larena_bytes = 0; LongHdr *d_lhdr = nullptr;
     // flag-only calls: anchors pre-selected by locus (k_lr_locus) - its read lists, what it left out per read, the reads to redo in full
@@ -3343,6 +3350,11 @@ static void fill_long_params(const sh_opts &o, int32_t mid_occ, LongParams &L)
     // one lane chasing pointers for seconds - DESIGN.md 3.2); SCRUBBY_HIP_RMQ_EXACT_MAX=-1 takes every such read to the tree, 0 none
     L.rmq_exact_max = -1;      // every read that meets a tie that matters, or outgrows the rings, takes the literal tree (round 5: the tree lives in LDS)
     if (const char *env = getenv("SCRUBBY_HIP_RMQ_EXACT_MAX")) L.rmq_exact_max = atoi(env);
+    // A read whose inner RMQ window (1000 reference bases) holds more than the 4096-anchor ring (5-bp satellite lattices: 23 of the bench's 2 M
+    // reads) can only be chained by the literal one-lane trees over node pools in HBM - 10 to 25 s of one wave per read, measured.  Off by
+    // default: such reads are counted (sh_stats.n_ext_unresolved) and keep their chain-level answer; SCRUBBY_HIP_RMQ_ONE_LANE=1 chains them.
+    L.rmq_one_lane = 0;
+    if (const char *env = getenv("SCRUBBY_HIP_RMQ_ONE_LANE")) L.rmq_one_lane = atoi(env) != 0;
 }
 
 static void fill_align_params(const sh_opts &o, AlignParams &A)
@@ -3588,6 +3600,8 @@ extern "C" sh_status sh_ctx_create(const sh_index *idx, const sh_opts *opts, uin
             if ((e = hipMalloc(&c->d_lext_sorted, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
             for (auto &q : c->d_lext_unres) if ((e = hipMalloc(&q, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
             if ((e = hipMalloc(&c->d_lext_exact_list, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
+            if ((e = hipMalloc(&c->d_lext_exact_list2, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
+            if ((e = hipMalloc(&c->d_lext_esorted, max_reads * 4)) != hipSuccess) return fail(e, "long-read extension-stage list");
             for (int t = 1; t < 2; ++t) {   // the exact long join on the one-lane trees (E3): the second size of the chains kernel plus the node pools of the two trees; one wave per CU (LDS)
                 LongSizes q = t ? zb : z; q.phase = 2;
                 c->lext_exact_sz[t] = q;
@@ -3664,7 +3678,7 @@ extern "C" sh_status sh_ctx_destroy(sh_ctx *c)
     hipFree(c->d_work_defer); hipFree(c->d_work_defer2);
     for (auto &pp : c->d_big) for (auto p : pp) hipFree(p);
     hipFree(c->d_ctr); if (c->h_ctr) hipHostFree(c->h_ctr); hipFree(c->d_arena); hipFree(c->d_long);
-    hipFree(c->d_ext); hipFree(c->d_ext_scratch); for (auto q : c->d_lext) hipFree(q); hipFree(c->d_lext_big); hipFree(c->d_lext_big2); hipFree(c->d_lext_sorted); for (auto q : c->d_lext_unres) hipFree(q); hipFree(c->d_lext_exact_list); for (auto q : c->d_lext_exact) hipFree(q); hipFree(c->d_larena); hipFree(c->d_lhdr); for (auto q : c->d_locus) hipFree(q); hipFree(c->d_lr_drop); hipFree(c->d_lr_fb); hipFree(c->d_stage_x); hipFree(c->d_stage_q); hipFree(c->d_lkind);
+    hipFree(c->d_ext); hipFree(c->d_ext_scratch); for (auto q : c->d_lext) hipFree(q); hipFree(c->d_lext_big); hipFree(c->d_lext_big2); hipFree(c->d_lext_sorted); for (auto q : c->d_lext_unres) hipFree(q); hipFree(c->d_lext_exact_list); hipFree(c->d_lext_exact_list2); hipFree(c->d_lext_esorted); for (auto q : c->d_lext_exact) hipFree(q); hipFree(c->d_larena); hipFree(c->d_lhdr); for (auto q : c->d_locus) hipFree(q); hipFree(c->d_lr_drop); hipFree(c->d_lr_fb); hipFree(c->d_stage_x); hipFree(c->d_stage_q); hipFree(c->d_lkind);
     for (auto ev : c->ev_ext) if (ev) hipEventDestroy(ev);
     for (auto ev : c->ev) if (ev) hipEventDestroy(ev);
     for (auto ev : c->evx) if (ev) hipEventDestroy(ev);
@@ -3714,22 +3728,34 @@ static sh_status pick_side_streams(sh_ctx *c, hipStream_t s)
     if (c->side_probed_done && c->side_probed == s) return SH_OK;
     sh_status es = ensure_side_streams(c, 0, 2);
     if (es != SH_OK) return es;
-    hipEvent_t t0 = nullptr, t1 = nullptr, e = nullptr;
-    SH_HIP(hipEventCreate(&t0)); SH_HIP(hipEventCreate(&t1)); SH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // SCRUBBY_HIP_SIDE_PICK=g,f pins the two streams (giants' launch, follower) and skips the probe
+    if (const char *pin = getenv("SCRUBBY_HIP_SIDE_PICK")) {
+        int g = 0, f = 1;
+        if (sscanf(pin, "%d,%d", &g, &f) == 2 && g >= 0 && g < 3 && f >= 0 && f < 3) { c->side_pick[0] = g; c->side_pick[1] = f; c->side_probed = s; c->side_probed_done = true; return SH_OK; }
+    }
+    struct Events {      // destroyed on every way out
+        hipEvent_t t0 = nullptr, t1 = nullptr, e = nullptr;
+        ~Events() { if (t0) hipEventDestroy(t0); if (t1) hipEventDestroy(t1); if (e) hipEventDestroy(e); }
+    } ev;
+    SH_HIP(hipEventCreate(&ev.t0)); SH_HIP(hipEventCreate(&ev.t1)); SH_HIP(hipEventCreateWithFlags(&ev.e, hipEventDisableTiming));
     float ms[3] = {1e9f, 1e9f, 1e9f};
     for (int i = 0; i < 3; ++i) {
-        SH_HIP(hipStreamSynchronize(s));
-        SH_HIP(hipEventRecord(t0, s));
-        SH_HIP(hipStreamWaitEvent(c->sx[i], t0, 0));
-        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, 20000ull);
-        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->sx[i], 20000ull);
-        SH_HIP(hipEventRecord(e, c->sx[i]));
-        SH_HIP(hipStreamWaitEvent(s, e, 0));
-        SH_HIP(hipEventRecord(t1, s));
-        SH_HIP(hipEventSynchronize(t1));
-        SH_HIP(hipEventElapsedTime(&ms[i], t0, t1));
+        float rep[3] = {0, 0, 0};      // the median of three tries: one 0.2-ms timing is at the mercy of whatever else the device is doing
+        for (int k = 0; k < 3; ++k) {
+            SH_HIP(hipStreamSynchronize(s));
+            SH_HIP(hipEventRecord(ev.t0, s));
+            SH_HIP(hipStreamWaitEvent(c->sx[i], ev.t0, 0));
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, 20000ull);
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->sx[i], 20000ull);
+            SH_HIP(hipEventRecord(ev.e, c->sx[i]));
+            SH_HIP(hipStreamWaitEvent(s, ev.e, 0));
+            SH_HIP(hipEventRecord(ev.t1, s));
+            SH_HIP(hipEventSynchronize(ev.t1));
+            SH_HIP(hipEventElapsedTime(&rep[k], ev.t0, ev.t1));
+        }
+        std::sort(rep, rep + 3);
+        ms[i] = rep[1];
     }
-    hipEventDestroy(t0); hipEventDestroy(t1); hipEventDestroy(e);
     int ord[3] = {0, 1, 2};
     std::sort(ord, ord + 3, [&](int a, int b) { return ms[a] < ms[b]; });
     c->side_pick[0] = ord[0]; c->side_pick[1] = ord[1];
@@ -4038,6 +4064,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         x.clk = getenv("SCRUBBY_HIP_DBG") ? (getenv("SCRUBBY_HIP_DBG_EXACT") ? 3 : 1) : 0; x.probe = getenv("SCRUBBY_HIP_NO_PROBE") ? 0 : 1;
         x.drop = k.locus ? c->d_lr_drop : nullptr; x.fb_list = c->d_lr_fb; x.n_fb = &c->d_ctr->lr_n_fb;
         x.exact_list = c->d_lext_exact_list; x.n_exact = &c->d_ctr->lext_n_exact;
+        x.exact_list2 = c->d_lext_exact_list2; x.n_exact2 = &c->d_ctr->lext_n_exact2;
         x.kind = c->d_lkind ? c->d_lkind + c->lkind_r0 : nullptr;
         { sh_status ps = pick_side_streams(c, s); if (ps != SH_OK) return ps; }
         SH_HIP(hipEventRecord(c->ev_ext[0], s));
@@ -4145,48 +4172,73 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 }
             }
             n_big_a += c->h_ctr->lext_n_big;
-            if (c->h_ctr->lext_n_exact > 0) {
-                // The long join of these reads met two candidates of equal priority in a way that can change the chains (or outgrew the rings):
-                // once more with upstream's main tree beside the scan (sh_rmq_tree.h), asked at the ties.  The tree holds the look-back window
-                // only and lives in LDS, so the passes run on the ordinary working memory of the chains kernel:
-                //   E1  the 512-anchor ring + a 1264-node tree (54 KB of LDS a wave, three waves to a CU), first size;
-                //   E2  what outgrew E1's ring, tree or working memory: 4096-anchor ring + 1792-node tree (156 KB, one wave to a CU), second size;
-                //   E3  what outgrew E2's ring or tree: both trees on one lane over node pools in the wave's scratch (lr_rmq_fill_tree) - the
-                //       literal mg_lchain_rmq, for windows no LDS holds; then memory on demand for what outgrew the sizes.
-                n_exact_reads += c->h_ctr->lext_n_exact;
+            if (c->h_ctr->lext_n_exact + c->h_ctr->lext_n_exact2 > 0) {
+                // The long join of these reads met two candidates of equal priority in a way that can change the chains: once more with
+                // upstream's main tree beside the scan (sh_rmq_tree.h), maintained by the whole wave and asked at the ties.  The tree holds the
+                // look-back window only and lives in LDS, so the passes run on the ordinary working memory of the chains kernel:
+                //   E1   the 1024-anchor ring + a 1664-node tree (79 KB of LDS a wave, two waves to a CU), first size, largest reads first;
+                //   E2a  the reads that needed the 4096-anchor ring in the first pass already, and those whose join holds more than 60 000 anchors: that ring + a 1792-node tree (156 KB, one wave to a
+                //        CU), second size - on a side stream BESIDE E1 (launched first, so that its few blocks find their LDS);
+                //   E2b  what outgrew E1's ring or working memory after all: the same instance, after E1;
+                //   E3   (SCRUBBY_HIP_RMQ_ONE_LANE=1) what outgrew E2's ring or tree: both trees on one lane over node pools in the wave's scratch
+                //        (lr_rmq_fill_tree) - the literal mg_lchain_rmq, for windows no LDS holds; then memory on demand for what outgrew the sizes.
+                const uint32_t n_e1 = c->h_ctr->lext_n_exact, n_e2a = c->h_ctr->lext_n_exact2;
+                n_exact_reads += n_e1 + n_e2a;
                 const auto t_ex = std::chrono::steady_clock::now();
                 ExtLongArgs xe = x;
-                xe.scratch = c->d_lext[0]; xe.scratch_per_wave = c->lext_per_wave[0]; xe.sz = c->lext_sz[0];
-                xe.list = c->d_lext_exact_list; xe.n_list = &c->d_ctr->lext_n_exact; xe.ticket = &c->d_ctr->lext_ticket_exact;
-                xe.part = 0; xe.exact_list = nullptr; xe.n_exact = nullptr;
-                SH_HIP(hipMemsetAsync(&c->d_ctr->lext_n_big, 0, 8, s));      // lext_n_big, lext_ticket_big: the list of the reads beyond the first size, once more
-                xe.big_list = c->d_lext_big; xe.n_big = &c->d_ctr->lext_n_big; xe.unres_list = nullptr; xe.n_unres = nullptr;
-                hipLaunchKernelGGL((k_long_chains<512, true, false>), dim3(std::min<uint32_t>(c->lext_waves[0], 3u * (uint32_t)c->n_cu)), dim3(64), 0, s, xe);
+                xe.part = 0; xe.exact_list = nullptr; xe.n_exact = nullptr; xe.exact_list2 = nullptr; xe.n_exact2 = nullptr;
+                SH_HIP(hipMemsetAsync(&c->d_ctr->lext_n_big, 0, 8, s));       // lext_n_big, lext_ticket_big: E1's list of deferred reads
+                SH_HIP(hipMemsetAsync(&c->d_ctr->lext_n_big2, 0, 8, s));      // lext_n_big2, lext_ticket_big2 (the regions kernel's list: free until it starts): E2's
+                hipStream_t se = c->sx[c->side_pick[0]];
+                if (n_e2a > 0) {
+                    ExtLongArgs x2 = xe;
+                    x2.scratch = c->d_lext[1]; x2.scratch_per_wave = c->lext_per_wave[1]; x2.sz = c->lext_sz[1];
+                    x2.list = c->d_lext_exact_list2; x2.n_list = &c->d_ctr->lext_n_exact2; x2.ticket = &c->d_ctr->lext_ticket_exact2;
+                    x2.big_list = c->d_lext_big2; x2.n_big = &c->d_ctr->lext_n_big2; x2.unres_list = nullptr; x2.n_unres = nullptr;
+                    x2.started = &c->d_ctr->lext_started;
+                    const uint32_t w2 = std::min<uint32_t>({c->lext_waves[1], (uint32_t)c->n_cu / 2u, n_e2a});      // half of the CUs at most: E1's blocks need the others
+                    SH_HIP(hipMemsetAsync(&c->d_ctr->lext_started, 0, 4, s));
+                    SH_HIP(hipEventRecord(c->evx[0], s));
+                    SH_HIP(hipStreamWaitEvent(se, c->evx[0], 0));
+                    hipLaunchKernelGGL((k_long_chains<4096, true, false>), dim3(w2), dim3(64), 0, se, x2);
+                    SH_HIP(hipEventRecord(c->evx[1], se));
+                    hipLaunchKernelGGL(k_wait_started, dim3(1), dim3(64), 0, s, (const uint32_t *)&c->d_ctr->lext_started, w2, 2000u);
+                }
+                if (n_e1 > 0) {
+                    xe.scratch = c->d_lext[0]; xe.scratch_per_wave = c->lext_per_wave[0]; xe.sz = c->lext_sz[0];
+                    // largest first, like every list of the stage: the pass ends with its slowest read (a read of 10^5 chain anchors is more than a second of one wave)
+                    SH_HIP(hipMemsetAsync(c->d_ctr->lext_hist, 0, sizeof(c->d_ctr->lext_hist), s));
+                    hipLaunchKernelGGL(k_lext_bins, dim3(64), dim3(256), 0, s, c->sink.recs, c->sink.head, c->d_lext_exact_list, &c->d_ctr->lext_n_exact, c->d_ext_redo, c->d_ctr->lext_hist, d_offsets);
+                    hipLaunchKernelGGL(k_lext_scan, dim3(1), dim3(1), 0, s, c->d_ctr->lext_hist);
+                    hipLaunchKernelGGL(k_lext_scatter, dim3(64), dim3(256), 0, s, c->d_lext_exact_list, &c->d_ctr->lext_n_exact, c->d_ext_redo, c->d_ctr->lext_hist, c->d_lext_esorted);
+                    xe.list = c->d_lext_esorted; xe.n_list = &c->d_ctr->lext_n_exact; xe.ticket = &c->d_ctr->lext_ticket_exact;
+                    xe.big_list = c->d_lext_big; xe.n_big = &c->d_ctr->lext_n_big; xe.unres_list = nullptr; xe.n_unres = nullptr;
+                    hipLaunchKernelGGL((k_long_chains<1024, true, false>), dim3(std::min<uint32_t>({c->lext_waves[0], 2u * (uint32_t)c->n_cu, n_e1})), dim3(64), 0, s, xe);
+                }
+                if (n_e2a > 0) SH_HIP(hipStreamWaitEvent(s, c->evx[1], 0));
                 sh_status st = sync_ctr(); if (st != SH_OK) return st;
                 if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
-                const uint32_t n_e2 = c->h_ctr->lext_n_big;
-                uint32_t n_e3 = 0;
-                if (n_e2 > 0) {
+                const uint32_t n_e2b = c->h_ctr->lext_n_big;
+                if (n_e2b > 0) {
                     xe.scratch = c->d_lext[1]; xe.scratch_per_wave = c->lext_per_wave[1]; xe.sz = c->lext_sz[1];
                     xe.list = c->d_lext_big; xe.n_list = &c->d_ctr->lext_n_big; xe.ticket = &c->d_ctr->lext_ticket_big;
-                    SH_HIP(hipMemsetAsync(&c->d_ctr->lext_n_big2, 0, 8, s));      // lext_n_big2, lext_ticket_big2 (the regions kernel's list: free until it starts)
-                    xe.big_list = c->d_lext_big2; xe.n_big = &c->d_ctr->lext_n_big2;
-                    hipLaunchKernelGGL((k_long_chains<4096, true, false>), dim3(std::min<uint32_t>(c->lext_waves[1], (uint32_t)c->n_cu)), dim3(64), 0, s, xe);
+                    xe.big_list = c->d_lext_big2; xe.n_big = &c->d_ctr->lext_n_big2; xe.unres_list = nullptr; xe.n_unres = nullptr; xe.started = nullptr;
+                    hipLaunchKernelGGL((k_long_chains<4096, true, false>), dim3(std::min<uint32_t>({c->lext_waves[1], (uint32_t)c->n_cu, n_e2b})), dim3(64), 0, s, xe);
                     st = sync_ctr(); if (st != SH_OK) return st;
                     if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
-                    n_e3 = c->h_ctr->lext_n_big2;
                 }
-                if (n_e3 > 0) {
+                const uint32_t n_e3 = c->h_ctr->lext_n_big2;
+                if (n_e3 > 0) {      // (only with SCRUBBY_HIP_RMQ_ONE_LANE, or reads beyond the second working-memory size)
                     xe.scratch = c->d_lext_exact[1]; xe.scratch_per_wave = c->lext_exact_per_wave[1]; xe.sz = c->lext_exact_sz[1];
-                    xe.list = c->d_lext_big2; xe.n_list = &c->d_ctr->lext_n_big2; xe.ticket = &c->d_ctr->lext_ticket_big2; xe.big_list = nullptr; xe.n_big = nullptr;
+                    xe.list = c->d_lext_big2; xe.n_list = &c->d_ctr->lext_n_big2; xe.ticket = &c->d_ctr->lext_ticket_big2; xe.big_list = nullptr; xe.n_big = nullptr; xe.started = nullptr;
                     xe.unres_list = c->d_lext_unres[0]; xe.n_unres = &c->d_ctr->lext_n_unres;
                     hipLaunchKernelGGL((k_long_chains<4096, true, false>), dim3(std::min<uint32_t>(c->lext_exact_waves[1], (uint32_t)c->n_cu)), dim3(64), 0, s, xe);
                     st = sync_ctr(); if (st != SH_OK) return st;
                     if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;
                     if (c->h_ctr->lext_n_unres > 0) { st = on_demand(2, xe); if (st != SH_OK) return st; }
-                    SH_HIP(hipMemsetAsync(&c->d_ctr->lext_n_big2, 0, 8, s));
                 }
-                if (getenv("SCRUBBY_HIP_DBG")) fprintf(stderr, "[dbg] exact long join: %u reads (%u with tied priorities so far), %u beyond the 512-anchor ring / 1264-node tree / first size, %u on the one-lane trees, %.1f ms\n", c->h_ctr->lext_n_exact, c->h_ctr->lext_rmq_tie, n_e2, n_e3,
+                SH_HIP(hipMemsetAsync(&c->d_ctr->lext_n_big2, 0, 8, s));
+                if (getenv("SCRUBBY_HIP_DBG")) fprintf(stderr, "[dbg] exact long join: %u reads on the 1024-anchor ring beside %u on the 4096-anchor ring (%u with tied priorities so far), %u more on the large ring afterwards, %u beyond it, %.1f ms\n", n_e1, n_e2a, c->h_ctr->lext_rmq_tie, n_e2b, n_e3,
                                                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ex).count());
             }
             SH_CHECK(c->h_ctr->ext_overflow == 0, SH_ERR_OOM, "long-read extension stage: internal overflow code %u", c->h_ctr->ext_overflow);
@@ -4249,7 +4301,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
             memset(z.ext_n_recs, 0, sizeof(z.ext_n_recs)); memset(z.ext_n_anch, 0, sizeof(z.ext_n_anch)); memset(z.lext_hist, 0, sizeof(z.lext_hist));
             z.n_defer = 0; z.arena_cursor = 0;
             z.n_big[0] = n_fb; z.n_big[1] = 0; z.n_big_defer[0] = z.n_big_defer[1] = 0;
-            z.ext_n_list = 0; z.ext_ticket = 0; z.lext_ticket_g = 0; z.lext_n_big = 0; z.lext_ticket_big = 0; z.lext_n_big2 = 0; z.lext_ticket_big2 = 0; z.lext_ticket_b = 0; z.lext_n_unres = 0; z.lext_ticket_unres = 0; z.lext_n_exact = 0; z.lext_ticket_exact = 0;
+            z.ext_n_list = 0; z.ext_ticket = 0; z.lext_ticket_g = 0; z.lext_n_big = 0; z.lext_ticket_big = 0; z.lext_n_big2 = 0; z.lext_ticket_big2 = 0; z.lext_ticket_b = 0; z.lext_n_unres = 0; z.lext_ticket_unres = 0; z.lext_n_exact = 0; z.lext_ticket_exact = 0; z.lext_n_exact2 = 0; z.lext_ticket_exact2 = 0;
             SH_HIP(hipMemcpyAsync(c->d_ctr, &z, sizeof(Counters), hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_lext_forget, dim3(64), dim3(256), 0, s, (const uint32_t *)c->d_lr_fb, n_fb, c->sink.head, c->d_lr_drop, &c->d_ctr->lr_fb_had);
             SH_HIP(hipMemcpyAsync(c->d_big[0][0], c->d_lr_fb, (size_t)n_fb * 4, hipMemcpyDeviceToDevice, s));

@@ -588,6 +588,7 @@ static sh_status mmi_read(const char *path, std::vector<std::vector<uint8_t>> &s
     SH_CHECK(fread(x, 4, 5, f) == 5, SH_ERR_IO, "%s: truncated minimap2 index header", path);
     const uint32_t w = x[0], k = x[1], b = x[2], n_seq = x[3], flag = x[4];
     SH_CHECK(k >= 1 && k <= 28 && w >= 1 && w < 256 && b <= 28 && n_seq > 0, SH_ERR_INDEX, "%s: implausible minimap2 index header (k=%u w=%u b=%u n_seq=%u)", path, k, w, b, n_seq);
+    SH_CHECK(k & 1u, SH_ERR_INDEX, "%s: minimap2 index built with an even k (%u): this path needs an odd k (every preset's is)", path, k);
     SH_CHECK(!(flag & 1u), SH_ERR_PRESET_UNSUPPORTED, "%s: homopolymer-compressed index (MM_I_HPC) - not implemented on the HIP path", path);
     SH_CHECK(!(flag & 2u), SH_ERR_INDEX, "%s: index written without sequences (MM_I_NO_SEQ): the extension filter needs the reference bases", path);
     std::vector<uint32_t> lens(n_seq);
@@ -611,6 +612,9 @@ static sh_status mmi_read(const char *path, std::vector<std::vector<uint8_t>> &s
         seqs[i].resize(lens[i]);
         for (uint32_t j = 0; j < lens[i]; ++j, ++o) { const uint32_t c = S[o >> 3] >> ((o & 7) << 2) & 0xfu; seqs[i][j] = (uint8_t)"ACGTN"[c < 4 ? c : 4]; }
     }
+    // what minimap2 says on stderr in the same situations: the file's k / w replace the preset's; only the first part of a multi-part index is used
+    if ((int32_t)k != *k_o || (int32_t)w != *w_o) fprintf(stderr, "[scrubby-hip] note: %s was built with k=%u w=%u; they replace the preset's k=%d w=%d\n", path, k, w, *k_o, *w_o);
+    { char probe; if (fread(&probe, 1, 1, f) == 1) fprintf(stderr, "[scrubby-hip] note: %s holds more than one index part; only the first is used (as minimap2-rs does)\n", path); }
     *k_o = (int32_t)k; *w_o = (int32_t)w;
     return SH_OK;
 }

@@ -42,6 +42,7 @@ struct LongParams {
     float pri_ratio, mask_level, max_clip_ratio;
     int32_t max_skip, rmq_inner_dist, rmq_size_cap, rmq_rescue_size;
     int32_t rmq_exact_max;          // reads of up to this many chain anchors take the literal tree when the long join meets a tie that matters (-1: all)
+    int32_t rmq_one_lane;           // reads whose windows outgrow the 4096-anchor ring / the LDS tree take the one-lane trees (seconds per read) instead of being counted unresolved
     float rmq_rescue_ratio, pen_gap, pen_skip;
     int32_t mid_occ, max_max_occ, occ_dist;
 };
@@ -363,15 +364,11 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 }
                 if (!ok) break;
             }
-            if (TREE && lane == 0) {
-                for (int32_t j = i0; j < i; ++j) {
-                    const int32_t x = rq_alloc(T0);
-                    if (x == RQ_NIL) { T0.bad = 11; break; }
-                    rq_node_set(T0, x, L.ry[j & M], j, rpri_of(j));
-                    rq_insert(T0, x);
-                }
+            if (TREE) {      // (the whole wave: rq_insert_w)
+                for (int32_t j = i0; j < i; ++j)
+                    if (rq_insert_w(T0, L.ry[j & M], j, rpri_of(j)) == RQ_NIL) { T0.bad = 11; break; }
             }
-            if (TREE && al_b0(T0.bad)) { ok = false; break; }      // the pool or a walk gave out: the caller takes the read to the one-lane version
+            if (TREE && T0.bad) { ok = false; break; }      // the tree's nodes or a walk gave out: the caller takes the read to the instance with the larger tree
             i0 = i;
             while ((blk_done + 1) * 64 <= i0) {      // blocks completed by this insertion (their anchors are all in the ring)
                 const double m = lr_wave_min_f64(rpri_of(blk_done * 64 + lane));
@@ -401,7 +398,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
         }
         if (i0 - st > rmq_size_cap) st = i0 - rmq_size_cap;
         if (TREE && st_tree < st) {
-            if (lane == 0) for (int32_t j = st_tree; j < st && j < i0; ++j) { const int32_t e = rq_erase(T0, (int32_t)a[j].y, j); if (e != RQ_NIL) rq_free(T0, e); }
+            for (int32_t j = st_tree; j < st && j < i0; ++j) { const int32_t e = rq_erase_w(T0, (int32_t)a[j].y, j); if (e != RQ_NIL) rqw_free(T0, e); }
             st_tree = st;
         }
         if (TREE && dbg && (unsigned long long)(i0 - st) > dbg->w_max) dbg->w_max = (unsigned long long)(i0 - st);
@@ -645,7 +642,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
 #undef LIY
 #undef LIY_SET
 #undef LIJ
-    if (TREE && al_b0(T0.bad)) ok = false;
+    if (TREE && T0.bad) ok = false;
     n_tie = tie_cnt;
     if (ok) for (int32_t j = blk_done * 64 + lane; j < n; j += 64) { f[j] = L.rf[j & M]; p[j] = L.rp[j & M]; }      // the last, incomplete block(s)
     if (dbg) for (int k2 = 0; k2 < 5; ++k2) dbg->t[4 + k2] += pt[k2];
@@ -1655,7 +1652,7 @@ __device__ inline int32_t lr_chain_of(OFF off, int32_t n, int32_t i)
 }
 
 // ---- the whole stage for one read ---------------------------------------------------------------------------------------------------
-struct LongOut { int32_t n_chain, best, rechained, n_aligned, n_regs, dp_max; uint32_t sig; int32_t rmq_tie, probed; };
+struct LongOut { int32_t n_chain, best, rechained, n_aligned, n_regs, dp_max; uint32_t sig; int32_t rmq_tie, probed; int32_t n_join; };      // n_join: anchors that entered the long join
 // The stage runs as two kernels, so that neither carries the other's registers and LDS: the first leaves a read's final chains (after the
 // long join, in compact_a's order, MM_SEED_TANDEM set) in an arena; the second turns them into regions and aligns.
 struct LongHdr { unsigned long long off; int32_t n_u, n_a, best, rechained; unsigned long long alt; };      // per read: u[n_u] (8 B), uoff[n_u + 1] (4 B), a[n_a] (16 B) at arena + off; alt - 1: a second outcome to prove (lr_chains_wave), {n_a, score, 0, 0} + a[n_a]
@@ -1698,7 +1695,7 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR, FAT> &RL, const
     const int32_t lane = (int32_t)al_lane();
     const uint32_t read = C.read;
     const int32_t qlen = C.qlen;
-    out.n_chain = out.best = out.rechained = out.n_aligned = out.n_regs = out.dp_max = 0; out.sig = 0; out.rmq_tie = 0; out.probed = 0;
+    out.n_chain = out.best = out.rechained = out.n_aligned = out.n_regs = out.dp_max = 0; out.sig = 0; out.rmq_tie = 0; out.probed = 0; out.n_join = 0;
     if ((uint32_t)qlen > W.cap_q) { C.err = 4; return 3; }
 
     // ---- the read's chains, in compact_a's order: by the first anchor's x, ties in discovery order (larger (f, index) first)
@@ -1794,6 +1791,7 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR, FAT> &RL, const
         if (both || qlen - (en - st) > P.rmq_rescue_size || en - st > qlen * P.rmq_rescue_ratio) {
             if (!both) out.rechained |= 2;
             const int32_t n_a_first = n_a;
+            out.n_join = n_a;
             for (int32_t i = lane; i < n_a; i += 64) { W.sk[i].k = A0[i].x; W.sk[i].v = (uint64_t)i; }
             lr_sync();
             lr_sort(W.sk, W.sk2, n_a);
@@ -1807,6 +1805,7 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR, FAT> &RL, const
                 // brings them: W.rq0)
                 if (!lr_rmq_fill<NR, true, FAT>(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie, C.clk, TL)) {
                     if (NR < 4096) { C.err = 6; return 3; }
+                    if (!P.rmq_one_lane) { C.err = 6; return 7; }      // beyond the large ring / the LDS tree: counted (sh_stats.n_ext_unresolved) unless the one-lane trees are asked for
                     if (!W.rq0) { C.err = 7; return 3; }
                     lr_sync();
                     for (int32_t i = lane; i < n_a; i += 64) W.t[i] = 0;
@@ -1817,7 +1816,7 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR, FAT> &RL, const
             } else {
                 if (!lr_rmq_fill<NR, false, FAT>(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie, C.clk)) {
                     if (NR < 4096) { C.err = 6; return 3; }      // beyond this ring: the pass with the large one
-                    if (P.rmq_exact_max < 0 || n_a <= P.rmq_exact_max) { C.err = 51; return 6; }      // beyond that too: the trees
+                    if (P.rmq_one_lane) { C.err = 51; return 6; }      // beyond that too: the one-lane trees, by way of the exact passes
                     C.err = 6; return 7;      // ... which one lane would walk for seconds on a read this size: given up, counted (sh_stats.n_ext_unresolved)
                 }
                 if (tie) {      // the scan's choice among equal priorities need not be the tree's

@@ -111,6 +111,21 @@ struct RqLds {
         const RqHot z = h_[k];      // one ds_read_b128
         yy = z.y; ii = z.i; l = up(z.l); r = up(z.r); b = (int32_t)z.bal;
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the same for a node EVERY lane asks for (the wave forms below): one broadcast ds_read_b128, and the fields made scalar, so that the
+    // walk's control flow stays on the scalar unit (values that come out of a VGPR make every branch an exec-mask affair)
+    __device__ inline void hot_u(int32_t k, int32_t &yy, int32_t &ii, int32_t &l, int32_t &r, int32_t &b) const
+    {
+        const uint4 z = *(RQ_LDS const uint4 *)(h_ + k);
+        const uint32_t w2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)z.z), w3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)z.w);
+        yy = __builtin_amdgcn_readfirstlane((int)z.x); ii = __builtin_amdgcn_readfirstlane((int)z.y);
+        l = up((uint16_t)(w2 & 0xffffu)); r = up((uint16_t)(w2 >> 16)); b = (int32_t)(int8_t)(w3 >> 16 & 0xffu);
+    }
+    __device__ inline int32_t ch_u(int32_t k, int d) const { return __builtin_amdgcn_readfirstlane(ch(k, d)); }
+#else      // (the host pass only parses the wave forms)
+    __device__ inline void hot_u(int32_t k, int32_t &yy, int32_t &ii, int32_t &l, int32_t &r, int32_t &b) const { hot(k, yy, ii, l, r, b); }
+    __device__ inline int32_t ch_u(int32_t k, int d) const { return ch(k, d); }
+#endif
     __device__ inline void set_ch(int32_t k, int d, int32_t v) { if (d) h_[k].r = (uint16_t)v; else h_[k].l = (uint16_t)v; }
     __device__ inline void set_s(int32_t k, int32_t v, double pv) { h_[k].s = (uint16_t)v; spri_[k] = pv; }
     __device__ inline void set_bal(int32_t k, int32_t v) { h_[k].bal = (int8_t)v; }
@@ -257,6 +272,40 @@ template <class ST> __device__ inline void rq_insert(RqTreeT<ST> &t, int32_t x)
     else { const int wi = bp != RQ_CH(bq, 0); RQ_SET_CH(bq, wi, r); }
 }
 
+// krmq_erase's way back up: path / dir in the storage's walk arrays (entries 0 .. d - 1, entry 0 = the fake node)
+template <class ST> __device__ inline void rq_erase_rebalance(RqTreeT<ST> &t, int d)
+{
+#define PATH(i) t.st.sp(0, (i))
+#define DIR(i) t.st.sd(0, (i))
+    while (--d > 0) {
+        const int32_t q = PATH(d);
+        int which, other, b1 = 1, b2 = 2;
+        which = DIR(d); other = 1 - which;
+        if (which) { b1 = -b1; b2 = -b2; }
+        const int32_t qb = RQ_BAL(q) + b1;
+        RQ_SET_BAL(q, qb);
+        if (qb == b1) break;
+        else if (qb == b2) {
+            const int32_t r = RQ_CH(q, other);
+            const int32_t rbal = RQ_BAL(r);
+            if (rbal == -b1) {
+                const int32_t nr = rq_rotate2(t, q, which);
+                RQ_SET_CH(PATH(d - 1), DIR(d - 1), nr);
+            } else {
+                const int32_t nr = rq_rotate1(t, q, which);
+                RQ_SET_CH(PATH(d - 1), DIR(d - 1), nr);
+                if (rbal == 0) {
+                    RQ_SET_BAL(r, -b1);
+                    RQ_SET_BAL(q, b1);
+                    break;
+                } else { RQ_SET_BAL(r, 0); RQ_SET_BAL(q, 0); }
+            }
+        }
+    }
+#undef PATH
+#undef DIR
+}
+
 // krmq_erase of the node with key (y, i); returns its index or RQ_NIL.  path[0] stands for upstream's `fake` node.
 template <class ST> __device__ inline int32_t rq_erase(RqTreeT<ST> &t, int32_t ky, int32_t ki)
 {
@@ -311,31 +360,7 @@ template <class ST> __device__ inline int32_t rq_erase(RqTreeT<ST> &t, int32_t k
         }
     }
     for (i = d - 1; i >= 0; --i) { const int32_t pi = PATH(i); rq_update_min(t, pi, RQ_CH(pi, 0), RQ_CH(pi, 1)); }
-    while (--d > 0) {
-        const int32_t q = PATH(d);
-        int which, other, b1 = 1, b2 = 2;
-        which = DIR(d); other = 1 - which;
-        if (which) { b1 = -b1; b2 = -b2; }
-        const int32_t qb = RQ_BAL(q) + b1;
-        RQ_SET_BAL(q, qb);
-        if (qb == b1) break;
-        else if (qb == b2) {
-            const int32_t r = RQ_CH(q, other);
-            const int32_t rbal = RQ_BAL(r);
-            if (rbal == -b1) {
-                const int32_t nr = rq_rotate2(t, q, which);
-                RQ_SET_CH(PATH(d - 1), DIR(d - 1), nr);
-            } else {
-                const int32_t nr = rq_rotate1(t, q, which);
-                RQ_SET_CH(PATH(d - 1), DIR(d - 1), nr);
-                if (rbal == 0) {
-                    RQ_SET_BAL(r, -b1);
-                    RQ_SET_BAL(q, b1);
-                    break;
-                } else { RQ_SET_BAL(r, 0); RQ_SET_BAL(q, 0); }
-            }
-        }
-    }
+    rq_erase_rebalance(t, d);
     t.root = RQ_CH(fake, 0);
     rq_free(t, fake);
     return p;
@@ -418,3 +443,180 @@ template <class ST> __device__ inline bool rq_itr_prev(const RqTreeT<ST> &t, RqI
     do { p = it.stack[it.top--]; } while (it.top >= 0 && p == RQ_CH(it.stack[it.top], 0));
     return it.top >= 0;
 }
+
+#if defined(__HIPCC__)
+// ---- the same two operations by the whole wave (LDS tree only) ---------------------------------------------------------------------------
+// One lane walking the tree spends an operation's time on ~90 dependent LDS round trips (measured: 5 - 6 us an operation), most of them in
+// the loops that visit the nodes of the root-to-leaf path one after the other - krmq_update_min over the path, the balance updates.  Here
+// all 64 lanes call with the same arguments; the descent is shared (every lane reads the same node: one broadcast ds_read_b128 a level),
+// lane d keeps level d of the path in registers, the per-level loads of the path loops leave together (one round trip), the chain that
+// carries a subtree minimum from a level to the one above runs on readlane'd registers, and the stores leave together.  What has no width -
+// rotations, the walk back up after an erase - is the generic code above on lane 0.  Same tree, bit for bit: the statements are upstream's,
+// only their loads are hoisted (tests: sh_dbg_rmq_trace lds = 2 against the oracle's tree).
+__device__ inline int rqw_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ inline int32_t rqw_rl(int32_t v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ inline double rqw_rl(double v, int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); }
+__device__ inline int32_t rqw_alloc(RqTreeT<RqLds> &t)      // (uniform: every lane keeps the same cursor and free-list head)
+{
+    if (t.st.free_head != RQ_NIL) { const int32_t k = t.st.free_head; t.st.free_head = __builtin_amdgcn_readfirstlane(RqLds::up(t.st.h_[k].l)); return k; }
+    if (t.st.n_used >= t.st.cap) return RQ_NIL;
+    return t.st.n_used++;
+}
+__device__ inline void rqw_free(RqTreeT<RqLds> &t, int32_t k)
+{
+    if (!t.st.valid(k)) return;
+    if (rqw_lane() == 0) t.st.h_[k].l = (uint16_t)t.st.free_head;
+    t.st.free_head = k;
+}
+// the chain of krmq_update_min over path levels [lo, hi): level i's on-path child is level i + 1 (its minimum is what the level below
+// just computed; for i == hi - 1 it is (cs0, csp0) when bottom_on, else both children come from memory).  Per lane (level): node, dir,
+// own priority, the minima of its left / right child as loaded (ls, lp, rs, rp; xx_ex = the child exists).  stop_at: upstream's insert
+// stops behind the first level whose minimum is not `stop_at` (RQ_NIL: never).  Returns the lowest level computed; news / newsp = the
+// level's new minimum on its lane.
+__device__ inline int rqw_min_chain(int lo, int hi, int32_t pnode, int pdir, double mypri, bool l_ex, int32_t ls, double lp, bool r_ex, int32_t rs, double rp,
+                                    bool bottom_on, int32_t cs, double csp, int32_t stop_at, int32_t &news, double &newsp)
+{
+    const int lane = rqw_lane();
+    int dstar = hi;
+    for (int d = hi - 1; d >= lo; --d) {
+        const int32_t nd = rqw_rl(pnode, d); const double pd = rqw_rl(mypri, d); const int dd = rqw_rl(pdir, d);
+        bool lex = rqw_rl((int32_t)l_ex, d) != 0, rex = rqw_rl((int32_t)r_ex, d) != 0;
+        int32_t lsd = rqw_rl(ls, d), rsd = rqw_rl(rs, d); double lpd = rqw_rl(lp, d), rpd = rqw_rl(rp, d);
+        if (d < hi - 1 || bottom_on) { if (dd == 0) { lex = true; lsd = cs; lpd = csp; } else { rex = true; rsd = cs; rpd = csp; } }
+        int32_t sv = nd; double sp = pd;
+        if (lex && !(pd < lpd)) { sv = lsd; sp = lpd; }
+        if (rex && !(sp < rpd)) { sv = rsd; sp = rpd; }
+        if (lane == d) { news = sv; newsp = sp; }
+        cs = sv; csp = sp; dstar = d;
+        if (stop_at != RQ_NIL && sv != stop_at) break;
+    }
+    return dstar;
+}
+
+// krmq_insert of a new node (y, i, pri); returns its index (RQ_NIL: pool full - the caller gives the read up)
+__device__ inline int32_t rq_insert_w(RqTreeT<RqLds> &t, int32_t xy, int32_t xi, double xp)
+{
+    const int lane = rqw_lane();
+    xy = __builtin_amdgcn_readfirstlane(xy); xi = __builtin_amdgcn_readfirstlane(xi); xp = rqw_rl(xp, 0);      // (uniform by contract: scalar from here on)
+    const int32_t x = __builtin_amdgcn_readfirstlane(rqw_alloc(t));
+    if (x == RQ_NIL) return RQ_NIL;
+    if (lane == 0) t.st.fresh(x, xy, xi, xp);
+    int32_t pnode = 0, pl = RQ_NIL, pr = RQ_NIL; int pdir = 0, pbal = 0;
+    int32_t p = __builtin_amdgcn_readfirstlane(t.root), q = RQ_NIL;
+    int depth = 0, which = 0, bp_idx = 0;      // bp = the root until a node with a balance shows up
+    while (p != RQ_NIL) {
+        int32_t ny, ni, nl, nr, nb;
+        t.st.hot_u(rq_ok(t, p), ny, ni, nl, nr, nb);
+        const int cmp = rq_cmp_key(xy, xi, ny, ni);
+        if (cmp == 0) { rqw_free(t, x); return x; }     // (y, i) is unique: never taken
+        if (nb != 0) bp_idx = depth;
+        which = (cmp > 0);
+        if (lane == depth) { pnode = p; pl = nl; pr = nr; pdir = which; pbal = nb; }
+        if (++depth >= RQ_LDS_DEPTH - 1) { if (!t.bad) t.bad = 4; return x; }
+        q = p; p = __builtin_amdgcn_readfirstlane(which ? nr : nl);
+    }
+    ++t.n_live;
+    if (q == RQ_NIL) { t.root = x; return x; }      // the tree was empty
+    if (lane == 0) t.st.set_ch(q, which, x);
+    const int L = depth;
+    const bool on = lane < L;
+    // krmq_update_min up the path while x is the minimum: the other child's minimum and the node's own priority, all levels at once
+    const int32_t off = on ? (pdir ? pl : pr) : RQ_NIL;
+    const bool off_ex = off != RQ_NIL;
+    const double mypri = on ? t.st.pri(pnode) : 0.0;
+    const int32_t os = off_ex ? t.st.s(rq_ok(t, off)) : RQ_NIL;
+    const double osp = off_ex ? t.st.spri(rq_ok(t, off)) : 0.0;
+    int32_t news = RQ_NIL; double newsp = 0.0;
+    const int dstar = rqw_min_chain(0, L, pnode, pdir, mypri, pdir != 0 && off_ex, os, osp, pdir == 0 && off_ex, os, osp, true, x, xp, x, news, newsp);
+    if (on && lane >= dstar) t.st.set_s(pnode, news, newsp);
+    // balances from bp down to x
+    if (on && lane >= bp_idx) { pbal += pdir ? 1 : -1; t.st.set_bal(pnode, pbal); }
+    const int bb = rqw_rl(pbal, bp_idx);
+    if (bb > -2 && bb < 2) return x;
+    const int32_t bp = rqw_rl(pnode, bp_idx), bq = bp_idx > 0 ? rqw_rl(pnode, bp_idx - 1) : RQ_NIL;
+    int32_t r = RQ_NIL;
+    if (lane == 0) {
+        const int wh = (bb < 0);
+        const int b1 = wh == 0 ? +1 : -1;
+        const int32_t qq = RQ_CH(bp, 1 - wh);
+        if (RQ_BAL(qq) == b1) { r = rq_rotate1(t, bp, wh); RQ_SET_BAL(qq, 0); RQ_SET_BAL(bp, 0); }
+        else r = rq_rotate2(t, bp, wh);
+        if (bq != RQ_NIL) { const int wi = bp != RQ_CH(bq, 0); RQ_SET_CH(bq, wi, r); }
+    }
+    r = rqw_rl(r, 0); t.bad = rqw_rl(t.bad, 0);
+    if (bq == RQ_NIL) t.root = r;
+    return x;
+}
+
+// krmq_erase of the node with key (y, i); returns its index (freed) or RQ_NIL
+__device__ inline int32_t rq_erase_w(RqTreeT<RqLds> &t, int32_t ky, int32_t ki)
+{
+    const int lane = rqw_lane();
+    ky = __builtin_amdgcn_readfirstlane(ky); ki = __builtin_amdgcn_readfirstlane(ki);
+    if (t.root == RQ_NIL) return RQ_NIL;
+    const int32_t fake = __builtin_amdgcn_readfirstlane(rqw_alloc(t));
+    if (fake == RQ_NIL) { if (!t.bad) t.bad = 3; return RQ_NIL; }
+    if (lane == 0) t.st.fake(fake, rq_ok(t, t.root));
+    int32_t pnode = 0; int pdir = 0;
+    int32_t p = fake, p_l = __builtin_amdgcn_readfirstlane(t.root), p_r = RQ_NIL, p_bal = 0;
+    int d = 0, cmp = -1;
+    while (cmp) {
+        const int which = (cmp > 0);
+        if (lane == d) { pnode = p; pdir = which; }
+        if (++d >= RQ_LDS_DEPTH - 2) { if (!t.bad) t.bad = 5; rqw_free(t, fake); return RQ_NIL; }
+        p = __builtin_amdgcn_readfirstlane(which ? p_r : p_l);
+        if (p == RQ_NIL) { rqw_free(t, fake); return RQ_NIL; }
+        int32_t ny, ni;
+        t.st.hot_u(rq_ok(t, p), ny, ni, p_l, p_r, p_bal);
+        cmp = rq_cmp_key(ky, ki, ny, ni);
+    }
+    --t.n_live;
+#define WPATH(i) rqw_rl(pnode, (i))
+#define WDIR(i) rqw_rl(pdir, (i))
+#define WSET(i, nn, dd) do { if (lane == (i)) { pnode = (nn); pdir = (dd); } } while (0)
+    const int32_t par = WPATH(d - 1); const int par_dir = WDIR(d - 1);      // the erased node's parent (the fake node stands above the root)
+    if (p_r == RQ_NIL) {
+        if (lane == 0) RQ_SET_CH(par, par_dir, p_l);
+    } else {
+        int32_t q = p_r;
+        if (t.st.ch_u(rq_ok(t, q), 0) == RQ_NIL) {
+            if (lane == 0) { RQ_SET_CH(q, 0, p_l); RQ_SET_BAL(q, p_bal); RQ_SET_CH(par, par_dir, q); }
+            WSET(d, q, 1); ++d;
+        } else {
+            int32_t r;
+            const int e = d++;
+            for (;;) {
+                WSET(d, q, 0); ++d;
+                if (d >= RQ_LDS_DEPTH - 1) { if (!t.bad) t.bad = 6; rqw_free(t, fake); return RQ_NIL; }
+                r = t.st.ch_u(rq_ok(t, q), 0);
+                if (t.st.ch_u(rq_ok(t, r), 0) == RQ_NIL) break;
+                q = r;
+            }
+            const int32_t r_r = t.st.ch_u(rq_ok(t, r), 1);
+            if (lane == 0) { RQ_SET_CH(r, 0, p_l); RQ_SET_CH(q, 0, r_r); RQ_SET_CH(r, 1, p_r); RQ_SET_BAL(r, p_bal); RQ_SET_CH(par, par_dir, r); }      // (path[e - 1] is the parent: e = d before the walk)
+            WSET(e, r, 1);
+        }
+    }
+    // krmq_update_min over the whole path, bottom up: every level's node and both children's minima at once (the on-path child's minimum is
+    // replaced by what the level below computes)
+    const int D = d;
+    const bool on = lane < D;
+    int32_t ny, ni, cl = RQ_NIL, cr = RQ_NIL, cb = 0;
+    if (on) t.st.hot(rq_ok(t, pnode), ny, ni, cl, cr, cb);
+    const double mypri = on ? t.st.pri(rq_ok(t, pnode)) : 0.0;
+    const bool l_ex = on && cl != RQ_NIL, r_ex = on && cr != RQ_NIL;
+    const int32_t ls = l_ex ? t.st.s(rq_ok(t, cl)) : RQ_NIL, rs = r_ex ? t.st.s(rq_ok(t, cr)) : RQ_NIL;
+    const double lp = l_ex ? t.st.spri(rq_ok(t, cl)) : 0.0, rp = r_ex ? t.st.spri(rq_ok(t, cr)) : 0.0;
+    int32_t news = RQ_NIL; double newsp = 0.0;
+    rqw_min_chain(0, D, pnode, pdir, mypri, l_ex, ls, lp, r_ex, rs, rp, false, RQ_NIL, 0.0, RQ_NIL, news, newsp);
+    if (on) { t.st.set_s(rq_ok(t, pnode), news, newsp); t.st.set_sp(0, lane, pnode); t.st.set_sd(0, lane, pdir); }
+    if (lane == 0) rq_erase_rebalance(t, D);
+    t.bad = rqw_rl(t.bad, 0);
+    t.root = t.st.ch_u(rq_ok(t, fake), 0);
+    rqw_free(t, fake);
+    return p;
+#undef WPATH
+#undef WDIR
+#undef WSET
+}
+#endif

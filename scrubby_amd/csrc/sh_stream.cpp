@@ -746,7 +746,7 @@ struct CtxCache {
     static std::string env_sig()
     {
         std::string e;
-        for (const char *v : {"SCRUBBY_HIP_ARENA_MB", "SCRUBBY_HIP_NO_FLAG_STOP", "SCRUBBY_HIP_NO_PAIR", "SCRUBBY_HIP_PAIR_MIN", "SCRUBBY_HIP_NO_S1", "SCRUBBY_HIP_NO_LEMMA", "SCRUBBY_HIP_EXT_MB", "SCRUBBY_HIP_DBG", "SCRUBBY_HIP_LEXT_P_KB"}) {
+        for (const char *v : {"SCRUBBY_HIP_ARENA_MB", "SCRUBBY_HIP_NO_FLAG_STOP", "SCRUBBY_HIP_NO_PAIR", "SCRUBBY_HIP_PAIR_MIN", "SCRUBBY_HIP_NO_S1", "SCRUBBY_HIP_NO_LEMMA", "SCRUBBY_HIP_EXT_MB", "SCRUBBY_HIP_DBG", "SCRUBBY_HIP_LEXT_P_KB", "SCRUBBY_HIP_RMQ_EXACT_MAX", "SCRUBBY_HIP_RMQ_ONE_LANE"}) {
             const char *x = getenv(v); e += x ? x : "-"; e += '|';
         }
         return e;

@@ -179,10 +179,11 @@ def test_reads_beyond_every_prepared_size_get_memory_of_their_own(S, oracle, cfg
     print("on demand:", st["n_ext_ondemand"], st2["n_ext_ondemand"])
 
 
-@pytest.mark.parametrize("lds", [0, 1])
+@pytest.mark.parametrize("lds", [0, 1, 2])
 def test_the_long_joins_tree_on_the_device_answers_like_the_oracles(S, oracle, lds):
     """sh_rmq_tree.h executed by the GPU, one lane, on both storages - nodes in an HBM pool (lds = 0), the whole tree in LDS through
-    address-space-3 pointers with 16-bit links (lds = 1, what lr_rmq_fill<NR, true> runs on): the random insert / erase / query sequence
+    address-space-3 pointers with 16-bit links (lds = 1), and that tree with the insertions and erasures done by the whole wave (lds = 2:
+    rq_insert_w / rq_erase_w, what lr_rmq_fill<NR, true> runs): the random insert / erase / query sequence
     with heavily tied priorities of oracle/mm_rmq.c's mmo_rmq_trace must be answered element for element like the oracle's tree."""
     import ctypes as C
     Lo = oracle.lib()
