@@ -124,7 +124,7 @@ typedef struct sh_stats {
     uint64_t n_ext_shortcut;   /* SH_F_CIGAR flag-only: reads decided inside a chaining kernel - their top chain's max stretch alone passes mm_filter_regs */
     uint64_t n_ext_fallback;   /* SH_F_CIGAR flag-only, sr: reads whose regs[0] did not survive and that were re-chained with every chain kept */
     double   ms_ext_fallback;  /* wall time of that fallback (re-chaining + the complete procedure) */
-    uint64_t n_ext_unresolved; /* reads the extension stage left at their chain-level answer, mapped (see the warning): the device had no memory left for them, or - long reads - the long join's window outgrew the 4096-anchor ring on a read of more than SCRUBBY_HIP_RMQ_EXACT_MAX anchors */
+    uint64_t n_ext_unresolved; /* reads the extension stage left at their chain-level answer, mapped (see the warning): the device had no memory left for them, or - long reads - the long join's inner window (1000 reference bases) outgrew the 4096-anchor LDS ring (chained exactly, at seconds per read, with SCRUBBY_HIP_RMQ_ONE_LANE=1) */
     uint64_t n_rmq_rechained;  /* long-read presets: reads re-chained by the RMQ long join */
     uint64_t n_rmq_tied;       /* ... of which met candidates of equal priority in the join in a way that can change the chains (ties that cannot are recognised and pass) */
     uint64_t n_dp_parallel;    /* repeat-path reads whose mg_lchain_dp ran as the parallel recurrence */
@@ -133,7 +133,7 @@ typedef struct sh_stats {
     uint64_t n_locus_reads;    /* long-read presets, flag-only: reads chained over the reference windows that can hold regs[0] only */
     uint64_t n_locus_redone;   /* ... of which the answer could depend on what was left out: redone with every anchor */
     uint64_t n_rmq_exact;      /* long-read presets: reads whose RMQ join was redone on the literal krmq tree (tied priorities, windows beyond the LDS ring, rmq_size_cap) */
-    uint64_t n_rmq_open;       /* ... reads of more than SCRUBBY_HIP_RMQ_EXACT_MAX (4096) chain anchors that met such a tie: the scan's choice (smallest index) stands - the one documented divergence of the long join */
+    uint64_t n_rmq_open;       /* ... reads that met such a tie and kept the scan's choice (smallest index): 0 by default since round 5 (every tied read takes the tree); only with SCRUBBY_HIP_RMQ_EXACT_MAX = N >= 0, for reads of more than N chain anchors */
     uint64_t n_ext_ondemand;   /* reads beyond the extension stage's prepared working-memory sizes, redone with memory allocated for them (visits, both kernels) */
 } sh_stats;
 
@@ -421,8 +421,8 @@ sh_status sh_pack_flags_device(const uint8_t *d_flags, uint64_t n, uint8_t *d_bi
 sh_status sh_bench_gather(const sh_index *idx, uint64_t n_probes, int32_t iters, double *out_gbs_useful, double *out_ms);
 /* Test aid: the krmq tree of the long join (csrc/sh_rmq_tree.h) on the device - one lane runs a random insert / erase / query sequence with
  * heavily tied priorities (the generator of oracle/mm_rmq.c's mmo_rmq_trace) and returns, per query, the element the tree answered with
- * (its i, or -1).  lds = 0: nodes in a pool in HBM (RqPool); lds != 0: the tree in LDS (RqLds, 4096 nodes: *n_out = -100 when the sequence
- * holds more at once).  out: host array of n_ops int64; *n_out < 0: a guard of the tree code tripped. */
+ * (its i, or -1).  lds = 0: nodes in a pool in HBM (RqPool); lds = 1: the whole tree in LDS (RqLds, 4096 nodes: *n_out = -100 when the sequence
+ * holds more at once), one lane; lds = 2: that tree with the insertions and erasures done by the whole wave (rq_insert_w / rq_erase_w).  out: host array of n_ops int64; *n_out < 0: a guard of the tree code tripped. */
 sh_status sh_dbg_rmq_trace(int32_t device, uint64_t seed, int32_t n_ops, int32_t key_range, int32_t fifo, int32_t lds, int64_t *out, int64_t *n_out);
 /* test aid: the wave primitives of csrc/sh_wave.h (DPP scans / reductions / broadcasts) on one wave of inputs: 12 x 64 int32 and 9 x 64 uint64
  * results in the order of k_dbg_wave_ops (tests/test_wave_ops_gpu.py compares them with numpy) */

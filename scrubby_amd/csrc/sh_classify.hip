@@ -3115,13 +3115,12 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
         LongOut o;
         const unsigned long long t_r0 = a.clk ? wall_clock64() : 0ull;
         const unsigned long long d0_before = clk.d[0];
-        LongClk clk_b = clk;
         if (a.clk) { clk.w_max = 0; clk.n_q = 0; }
         const int32_t rc = lr_chains_wave<NR, EXACT, FAT>(C, RL, AR_l, o, a.drop ? a.drop[r] : 0u, TL);
         if (a.clk && lane == 0) {
             const unsigned long long dt = wall_clock64() - t_r0;
-            if ((a.clk & 2) && (EXACT || a.part == 1) && dt > 20000000ull) printf("[%s] read %u qlen %d chains %d anchors %llu window %llu queries %llu ms %.1f rc %d | gather %.1f sort %.1f fill %.1f bt %.1f | ins %.1f trim %.1f query %.1f tally %.1f inner %.1f\n", EXACT ? "exact" : "main", r, C.qlen, o.n_chain, clk.d[0] - d0_before, clk.w_max, clk.n_q, dt / 1e5, rc,
-                                                           (clk.t[0] - clk_b.t[0]) / 1e5, (clk.t[1] - clk_b.t[1]) / 1e5, (clk.t[2] - clk_b.t[2]) / 1e5, (clk.t[3] - clk_b.t[3]) / 1e5, (clk.t[4] - clk_b.t[4]) / 1e5, (clk.t[5] - clk_b.t[5]) / 1e5, (clk.t[6] - clk_b.t[6]) / 1e5, (clk.t[7] - clk_b.t[7]) / 1e5, (clk.t[8] - clk_b.t[8]) / 1e5);
+            // SCRUBBY_HIP_DBG_EXACT: one line per read of the exact passes (what profiles/r05_exact_reads.txt was made with)
+            if (EXACT && (a.clk & 2)) printf("[exact] read %u qlen %d chains %d anchors %llu window %llu queries %llu ms %.1f rc %d\n", r, C.qlen, o.n_chain, clk.d[0] - d0_before, clk.w_max, clk.n_q, dt / 1e5, rc);
             atomicMax(&a.ctr->lext_slow, dt << 24 | (unsigned long long)(o.n_chain > 0xffffff ? 0xffffff : o.n_chain)); atomicAdd(&a.ctr->lext_kernel_sum, dt);
             atomicMax(&a.ctr->lext_slow2, dt << 32 | (unsigned long long)(uint32_t)C.qlen);
             atomicMax(&a.ctr->lext_slow3, dt << 32 | (unsigned long long)r);

@@ -126,3 +126,31 @@ def tandem_case(seed=5, n_arrays=24, n_reads=240):
     offs = np.zeros(len(recs) + 1, np.uint64)
     offs[1:] = np.cumsum([len(x) for x in recs])
     return [ref], bases, offs
+
+
+def dense_lattice_case(seed=11, n_reads=6, ref_copies=10, read_copies=(30, 38)):
+    """Reads whose long join holds more anchors inside rmq_inner_dist (1000 reference bases) than the 4096-anchor LDS ring takes: a perfect
+    tandem array of ref_copies copies of a ~100-bp monomer (every k-mer at most ref_copies times in the reference: below map-ont's
+    min_mid_occ, nothing is filtered) read by a molecule with 30 - 38 copies between long unique flanks (so that a k-mer's copies stay below
+    q_occ_frac of the read's minimizers and mm_seed_mz_flt keeps them) - ref_copies x read_copies lattice points per minimizer of the
+    monomer, ~5 000 - 7 000 anchors over one kilobase of reference.  Returns (contigs, bases, offsets)."""
+    rng = np.random.default_rng(seed)
+
+    def rnd(m):
+        return bytes(ACGT[rng.integers(0, 4, m)])
+    left, right = rnd(9000), rnd(9000)
+    mono = rnd(int(rng.integers(96, 110)))
+    ref = left + mono * ref_copies + right
+    recs = []
+    for it in range(n_reads):
+        c2 = int(rng.integers(read_copies[0], read_copies[1] + 1))
+        src = left[-int(rng.integers(8000, 9000)):] + mono * c2 + right[:int(rng.integers(8000, 9000))]
+        e = (0.0, 0.004)[it % 2]
+        r = _noisy(rng, src, e, e * 0.75) if e > 0 else src
+        if it % 3 == 2:
+            r = _rc(r)
+        recs.append(r)
+    bases = np.frombuffer(b"".join(recs), np.uint8)
+    offs = np.zeros(len(recs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(x) for x in recs])
+    return [ref], bases, offs

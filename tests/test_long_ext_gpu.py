@@ -159,6 +159,30 @@ def test_lattices_of_anchors_across_perfect_tandem_arrays(S, oracle):
     assert rc2 == 0 and np.array_equal(gf2, of) and st2["n_ext_unresolved"] == 0
 
 
+def test_windows_beyond_the_large_ring_are_counted_or_take_the_one_lane_trees(S, oracle, monkeypatch):
+    """A read whose long join holds more anchors within rmq_inner_dist than the 4096-anchor ring (LC.dense_lattice_case: ~10^4 lattice anchors
+    over one kilobase) cannot be chained by the wave scan.  By default it keeps its chain-level answer and is COUNTED (n_ext_unresolved, and
+    listed by sh_ctx_debug_list(5) for the bench's strata); with SCRUBBY_HIP_RMQ_ONE_LANE=1 the literal one-lane trees over node pools in HBM
+    chain it (E3 of the exact passes): full trace and flags equal the oracle's, nothing unresolved."""
+    seqs, bases, offs = LC.dense_lattice_case()
+    monkeypatch.setenv("SCRUBBY_HIP_CTX_CACHE", "0")
+    cidx = oracle.Index.build([np.frombuffer(s, np.uint8) for s in seqs], 10, 15)
+    oo = cidx.update_opts(oracle.preset("map-ont"))
+    of, ot = cidx.classify(oo, bases, offs, threads=8)
+    gidx = S.Index.build([bytes(s) for s in seqs], S.preset("map-ont"))
+    gf0, _, st0, rc0 = gidx.classify(bases, offs, want_trace=False)
+    assert rc0 == 0 and st0["n_ext_unresolved"] > 0, st0
+    assert np.array_equal(gf0, of)      # (the chain-level answer happens to be the oracle's on these reads: they are host reads)
+    monkeypatch.setenv("SCRUBBY_HIP_RMQ_ONE_LANE", "1")
+    gidx1 = S.Index.build([bytes(s) for s in seqs], S.preset("map-ont"))
+    gf, gt, st, rc = gidx1.classify(bases, offs, want_trace=True)
+    assert rc == 0 and st["n_ext_unresolved"] == 0 and st["n_rmq_exact"] > 0, st
+    assert_same(S, gf, gt, of, ot)
+    gf2, _, st2, rc2 = gidx1.classify(bases, offs, want_trace=False)
+    assert rc2 == 0 and np.array_equal(gf2, of) and st2["n_ext_unresolved"] == 0
+    print("unresolved by default:", st0["n_ext_unresolved"], "one-lane trees:", st["n_rmq_exact"])
+
+
 def test_reads_beyond_every_prepared_size_get_memory_of_their_own(S, oracle, cfg1, monkeypatch):
     """minimap2 has no capacities.  With both prepared sizes of the stage's working memory made tiny (64 / 128 chain anchors, 64 / 128 KB of
     direction bytes) most reads outgrow them in both kernels; memory is then allocated for them, four times the last size per round, until
