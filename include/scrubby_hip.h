@@ -222,7 +222,8 @@ sh_status sh_classify_sharded(const sh_index_set *set, const sh_opts *opts, cons
 
 /* ---- the whole replaced path:  Cleaner::run_minimap2_rs + clean_reads + ScrubbyReport  ------------------------
  * (/root/reference/src/cleaner.rs:443-575, :236-254, :731-760; src/report.rs:24-57; src/utils.rs:250-285)
- * FASTA/FASTQ (plain or gzip) in, filtered files out, optional JSON report and TSV of removed ids.
+ * FASTA/FASTQ (plain, gzip, bzip2 or xz: sniffed by magic bytes like needletail / niffler do) in, filtered files out (the container by the
+ * output's extension: utils.rs:28-36), optional JSON report and TSV of removed ids.
  * This is what `scrubby reads -i R1 [R2] -o O1 [O2] -I ref.fa [-p sr] [-e] [-j report.json] [-r ids.tsv]` runs. */
 typedef struct sh_reads_config {
     const char *input[2];

@@ -8,7 +8,7 @@
 //   ReadDifference::get_difference /root/reference/src/utils.rs:250-285    reads_in / reads_out / difference over both files
 //   ScrubbyReport                  /root/reference/src/report.rs:10-88     JSON schema (key order = struct order), TSV of ids
 //
-// Divergences, all deliberate and documented in DESIGN.md: bz2/xz inputs or outputs are rejected (zlib only);
+// Containers: plain, gzip, bzip2 and xz in and out (sh_codec.h: niffler's set); legacy .lzma streams are refused by name;
 // a corrupt FASTQ is an error instead of a logged partial id set.
 #include "sh_common.h"
 #include "sh_host.h"
@@ -19,37 +19,47 @@
 #include <ctime>
 #include <unordered_set>
 #include <algorithm>
+#include "sh_codec.h"
 
 namespace {
 
 struct FastxRecord { std::string header, seq, qual; bool fastq = false; };
 
-// FASTA / FASTQ, plain or gzip (gzopen reads both); multi-line FASTA, 4-line FASTQ
+// FASTA / FASTQ in any of the containers sh_codec.h reads (plain, gzip, bzip2, xz: sniffed by magic bytes like needletail does); multi-line
+// FASTA, 4-line FASTQ
 class FastxReader {
-    gzFile f_ = nullptr;
+    shc::In f_;
     std::string line_, pending_;
     bool have_pending_ = false, eof_ = false;
     std::vector<char> buf_;
+    size_t bpos_ = 0, blen_ = 0;
     bool getline(std::string &out)
     {
         out.clear();
         for (;;) {
-            if (!gzgets(f_, buf_.data(), (int)buf_.size())) {
-                int e = Z_OK;
-                const char *msg = gzerror(f_, &e);       // a truncated .gz ends with Z_BUF_ERROR, not with a clean end of stream
-                if (e != Z_OK && e != Z_STREAM_END) error = std::string("read error: ") + (msg && *msg ? msg : "truncated gzip stream");
-                eof_ = true; return !out.empty();
+            if (bpos_ == blen_) {
+                if (eof_) return !out.empty();
+                const long got = f_.read(buf_.data(), buf_.size());
+                if (got < 0) { error = f_.error; eof_ = true; return !out.empty(); }      // a truncated stream is an error, not a short input
+                if (got == 0) { eof_ = true; return !out.empty(); }
+                bpos_ = 0; blen_ = (size_t)got;
             }
-            size_t n = strlen(buf_.data());
-            out.append(buf_.data(), n);
-            if (n && out.back() == '\n') { out.pop_back(); if (!out.empty() && out.back() == '\r') out.pop_back(); return true; }
+            const char *b = buf_.data() + bpos_;
+            const char *nl = (const char *)memchr(b, '\n', blen_ - bpos_);
+            if (nl) {
+                out.append(b, (size_t)(nl - b));
+                bpos_ += (size_t)(nl - b) + 1;
+                if (!out.empty() && out.back() == '\r') out.pop_back();
+                return true;
+            }
+            out.append(b, blen_ - bpos_);
+            bpos_ = blen_;
         }
     }
 public:
     std::string error;
-    explicit FastxReader(const char *path) : buf_(1 << 16) { f_ = gzopen(path, "rb"); if (f_) gzbuffer(f_, 1 << 20); }
-    ~FastxReader() { if (f_) gzclose(f_); }
-    bool ok() const { return f_ != nullptr; }
+    explicit FastxReader(const char *path) : buf_(1 << 18) { if (!f_.open(path)) error = f_.error; }
+    bool ok() const { return f_.is_open(); }
     // 1 = record, 0 = end, -1 = malformed
     int next(FastxRecord &r)
     {
@@ -60,7 +70,9 @@ public:
         if (l[0] == '@') {
             r.fastq = true; r.header = l.substr(1);
             std::string plus;
-            if (!getline(r.seq) || !getline(plus) || plus.empty() || plus[0] != '+' || !getline(r.qual)) { error = "truncated FASTQ record: " + r.header; return -1; }
+            const bool got_all = getline(r.seq) && getline(plus) && !plus.empty() && plus[0] == '+' && getline(r.qual);
+            if (!error.empty()) return -1;      // the stream itself failed (truncated / corrupt container): that, not what the partial record looks like
+            if (!got_all) { error = "truncated FASTQ record: " + r.header; return -1; }
             if (r.qual.size() != r.seq.size()) { error = "sequence/quality length mismatch: " + r.header; return -1; }
             return 1;
         }
@@ -78,14 +90,12 @@ public:
 };
 
 bool file_is_empty(const char *path, bool &exists)
-{   // is_file_empty + compression sniffing: an empty gzip stream counts as empty
-    gzFile f = gzopen(path, "rb");
-    exists = f != nullptr;
-    if (!f) return true;
+{   // is_file_empty + compression sniffing: an empty compressed stream counts as empty
+    shc::In f;
+    exists = f.open(path);
+    if (!exists) return true;
     char c;
-    int n = gzread(f, &c, 1);
-    gzclose(f);
-    return n <= 0;
+    return f.read(&c, 1) == 0;      // (a stream that errors before its first byte is not empty: the reader reports it)
 }
 
 // get_id: first whitespace-delimited token of the header; a header without one is an error
@@ -102,19 +112,14 @@ bool get_id(const std::string &header, std::string &id)
 
 // output compression chosen by extension (CompressionExt::from_path, utils.rs:28-36), level 6
 class FastxWriter {
-    gzFile gz_ = nullptr; FILE *fp_ = nullptr;
+    shc::Out o_;
 public:
     std::string error;
-    explicit FastxWriter(const std::string &path, int level = 6)
-    {
-        auto ends = [&](const char *s) { size_t k = strlen(s); return path.size() >= k && path.compare(path.size() - k, k, s) == 0; };
-        if (ends(".gz")) { std::string mode = "wb" + std::to_string(level); gz_ = gzopen(path.c_str(), mode.c_str()); if (!gz_) error = "cannot open " + path; }
-        else if (ends(".bz") || ends(".bz2") || ends(".lzma") || ends(".xz")) error = "bzip2/xz output not supported by the HIP backend: " + path;
-        else { fp_ = fopen(path.c_str(), "wb"); if (!fp_) error = "cannot open " + path; }
-    }
-    ~FastxWriter() { if (gz_) gzclose(gz_); if (fp_) fclose(fp_); }
+    explicit FastxWriter(const std::string &path, int level = 6) { if (!o_.open(path, level)) error = o_.error; }
+    ~FastxWriter() { o_.close(); }
     bool ok() const { return error.empty(); }
-    void put(const std::string &s) { if (gz_) gzwrite(gz_, s.data(), (unsigned)s.size()); else fwrite(s.data(), 1, s.size(), fp_); }
+    void put(const std::string &s) { if (!o_.write(s.data(), s.size()) && error.empty()) error = o_.error; }
+    bool finish() { if (!o_.close() && error.empty()) error = o_.error; return error.empty(); }
     void write(const FastxRecord &r)
     {   // needletail record.write(writer, None): '\n' line endings, bare '+', full original header
         std::string o;
@@ -164,24 +169,21 @@ sh_status filter_fastx(const char *in, const char *out, const std::unordered_set
         if (hit == extract) { wr.write(r); if (n_out) ++*n_out; }        // deplete: keep misses; extract: keep hits
     }
     SH_CHECK(st == 0, SH_ERR_IO, "%s: %s", in, rd.error.c_str());
+    SH_CHECK(wr.finish(), SH_ERR_IO, "%s: %s", out, wr.error.c_str());
     return SH_OK;
 }
 
 }  // namespace
 
 bool shi_unsupported_compression(const char *path)
-{
+{   // bzip2 and xz are read (sh_codec.h); what is left to refuse by name is the legacy LZMA_alone stream, which niffler does not sniff either
     FILE *f = fopen(path, "rb");
     if (!f) return false;
     unsigned char m[6] = {0, 0, 0, 0, 0, 0};
     const size_t n = fread(m, 1, 6, f);
     fclose(f);
-    const char *what = nullptr;
-    if (n >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') what = "bzip2";
-    else if (n >= 6 && m[0] == 0xFD && m[1] == '7' && m[2] == 'z' && m[3] == 'X' && m[4] == 'Z' && m[5] == 0x00) what = "xz";
-    else if (n >= 3 && m[0] == 0x5D && m[1] == 0x00 && m[2] == 0x00) what = "lzma";
-    if (!what) return false;
-    sh_set_error("%s-compressed input is not supported by the HIP backend (plain or gzip only): %s", what, path);
+    if (!(n >= 3 && m[0] == 0x5D && m[1] == 0x00 && m[2] == 0x00)) return false;
+    sh_set_error("lzma-alone compressed input is not supported (plain, gzip, bzip2 or xz): %s", path);
     return true;
 }
 
@@ -341,6 +343,7 @@ static sh_status finish_report(const char *const *input, const char *const *outp
         SH_CHECK(w.ok(), SH_ERR_IO, "%s", w.error.c_str());
         w.put("id\n");
         for (auto &id : diff_ids) w.put(id + "\n");
+        SH_CHECK(w.finish(), SH_ERR_IO, "%s: %s", read_ids, w.error.c_str());
     }
     if (json) return shi_write_report_json(input, output, n_files, command, st, res, json);
     return SH_OK;
@@ -700,20 +703,22 @@ sh_status shi_kraken_run_legacy(const sh_kraken_config *c, sh_reads_result *res)
 
 // ---- `scrubby alignment`: Cleaner::run_aligner_output (cleaner.rs:206-219) with ReadAlignment (src/alignment.rs:33-114,242-276) ----
 static bool gz_lines(const char *path, std::vector<std::string> &lines)
-{
-    gzFile f = gzopen(path, "rb");
-    if (!f) return false;
+{   // (any container sh_codec.h reads)
+    shc::In f;
+    if (!f.open(path)) return false;
     std::vector<char> buf(1 << 16);
     std::string cur;
-    while (gzgets(f, buf.data(), (int)buf.size())) {
-        cur += buf.data();
-        if (!cur.empty() && cur.back() == '\n') { cur.pop_back(); if (!cur.empty() && cur.back() == '\r') cur.pop_back(); lines.push_back(cur); cur.clear(); }
+    for (;;) {
+        const long got = f.read(buf.data(), buf.size());
+        if (got < 0) return false;      // a stream that stops in the middle
+        if (got == 0) break;
+        for (long i = 0; i < got; ++i) {
+            if (buf[i] == '\n') { if (!cur.empty() && cur.back() == '\r') cur.pop_back(); lines.push_back(cur); cur.clear(); }
+            else cur += buf[i];
+        }
     }
     if (!cur.empty()) lines.push_back(cur);
-    int e = Z_OK;
-    gzerror(f, &e);
-    const bool clean = e == Z_OK || e == Z_STREAM_END;      // Z_BUF_ERROR: the .gz stops in the middle of its stream
-    return gzclose(f) == Z_OK && clean;
+    return true;
 }
 
 static sh_status alignment_ids(const char *path, const char *format, uint64_t min_len, double min_cov, uint32_t min_mapq, std::unordered_set<std::string> &ids)

@@ -21,6 +21,7 @@
 // case handed to the collect-then-map form in sh_host.cpp.
 #include "sh_host.h"
 #include <zlib.h>
+#include "sh_codec.h"
 #include <fcntl.h>
 #include <unistd.h>
 #include <sys/mman.h>
@@ -261,12 +262,13 @@ FilePlan plan_ranges(const char *path, int max_ranges, uint64_t min_range_bytes)
     return p;
 }
 
-// Cuts a FASTA / FASTQ byte stream (plain or gzip: gzread passes plain bytes through) into chunks that end on record
+// Cuts a FASTA / FASTQ byte stream (plain, gzip, bzip2 or xz: sh_codec.h sniffs the container) into chunks that end on record
 // boundaries.  Accepts what the legacy line reader accepts: 4-line FASTQ, multi-line FASTA, CRLF, blank lines between
 // records, a last line without '\n'.  Sequential mode parses as it cuts; split-only mode cuts at find_split() and leaves
 // the parsing (and its verification) to whoever takes the chunk.
 class ChunkReader {
-    gzFile f_ = nullptr;
+    shc::In in_;
+    bool have_in_ = false;
     int fd_ = -1;                     // byte-range source (plain files): pread from pos_ up to end_
     uint64_t pos_ = 0, end_ = 0;
     size_t target_;
@@ -279,15 +281,14 @@ public:
     std::string error;
     ChunkReader(const char *path, size_t target, bool batch, bool split_only = false) : target_(std::max<size_t>(target, 64)), batch_(batch), split_only_(split_only)
     {
-        f_ = gzopen(path, "rb");
-        if (f_) gzbuffer(f_, 1 << 20);
+        have_in_ = in_.open(path);
+        if (!have_in_) error = in_.error;
     }
     // one byte range [begin, end) of a plain file; `fasta` as the whole file's first record says (the range may start anywhere in it)
     ChunkReader(int fd, uint64_t begin, uint64_t end, bool fasta, size_t target, bool batch) : fd_(fd), pos_(begin), end_(end), target_(std::max<size_t>(target, 64)),
                                                                                             batch_(batch), split_only_(true), fasta_(fasta ? 1 : 0) {}
-    ~ChunkReader() { if (f_) gzclose(f_); }
     ChunkReader(const ChunkReader &) = delete;
-    bool ok() const { return f_ != nullptr || fd_ >= 0; }
+    bool ok() const { return have_in_ || fd_ >= 0; }
 
     // 1 = a chunk with at least one record, 0 = end of input, -1 = malformed input (error set)
     int next(Chunk &c)
@@ -308,17 +309,11 @@ public:
                 if (pos_ >= end_) eof_ = true;
             }
             while (!eof_ && c.len < cap) {
-                const unsigned want = (unsigned)std::min<size_t>(cap - c.len, 1u << 30);
-                const int got = gzread(f_, c.data + c.len, want);
-                if (got < 0) { int e; error = std::string("read error: ") + gzerror(f_, &e); return -1; }
-                if ((unsigned)got < want) {
-                    // a short read is the end of the stream only if zlib says so: a truncated .gz stops short with Z_BUF_ERROR
-                    // ("unexpected end of file") and would otherwise give a silently partial output (the reference's reader errors)
-                    int e = Z_OK;
-                    const char *msg = gzerror(f_, &e);
-                    if (e != Z_OK && e != Z_STREAM_END) { error = std::string("read error: ") + (msg && *msg ? msg : "truncated gzip stream"); return -1; }
-                    eof_ = true;
-                }
+                // a short read is the end of the stream; a truncated or corrupt stream is an error (-1), never a silently partial input
+                const size_t want = cap - c.len;
+                const long got = in_.read(c.data + c.len, want);
+                if (got < 0) { error = in_.error; return -1; }
+                if ((size_t)got < want) eof_ = true;
                 c.len += (size_t)got;
             }
             size_t consumed = 0;
@@ -354,13 +349,11 @@ public:
 
 bool file_is_empty(const char *path, bool &exists)
 {
-    gzFile f = gzopen(path, "rb");
-    exists = f != nullptr;
-    if (!f) return true;
+    shc::In f;
+    exists = f.open(path);
+    if (!exists) return true;
     char ch;
-    const int n = gzread(f, &ch, 1);
-    gzclose(f);
-    return n <= 0;
+    return f.read(&ch, 1) == 0;      // (a stream that errors before its first byte is not empty: the reader reports it)
 }
 
 // get_id (utils.rs:91-103): first whitespace-delimited token of the header
@@ -544,17 +537,19 @@ struct FileFilter {
     {
         const std::string op = out_path;
         const bool gz = ends_with(op, ".gz");
-        if (ends_with(op, ".bz") || ends_with(op, ".bz2") || ends_with(op, ".lzma") || ends_with(op, ".xz")) {
-            sh_set_error("bzip2/xz output not supported by the HIP backend: %s", out_path);
-            return SH_ERR_IO;
-        }
+        // bzip2 / xz outputs (CompressionExt::from_path, utils.rs:28-36): ONE stream, fed in chunk order by whichever worker holds the turn
+        // (the gzip form is multi-member and deflated by the workers side by side; these two stay single-stream for every reader's sake)
+        const shc::Kind okind = shc::kind_by_extension(op);
+        const bool seq = okind == shc::Kind::Bzip2 || okind == shc::Kind::Xz;
+        shc::Out enc;
         std::unique_ptr<ChunkReader> rd;
         if (!retained) {
             rd.reset(new ChunkReader(in_path, chunk_bytes, false));
             SH_CHECK(rd->ok(), SH_ERR_IO, "cannot open %s", in_path);
         }
-        const int fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
-        SH_CHECK(fd >= 0, SH_ERR_IO, "cannot open %s", out_path);
+        int fd = -1;
+        if (seq) { SH_CHECK(enc.open(op, 6), SH_ERR_IO, "%s", enc.error.c_str()); }
+        else { fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0666); SH_CHECK(fd >= 0, SH_ERR_IO, "cannot open %s", out_path); }
 
         // Chunks are taken in file order; a worker filters (and deflates) its chunk, then publishes the size of its output
         // in chunk order - which fixes its offset in the file - and writes with pwrite beside the other workers.  Only the
@@ -606,13 +601,14 @@ struct FileFilter {
                         my_off = cur_off; cur_off += o.bytes.size();
                         n_in += o.n_in; n_out += o.n_out;
                         for (auto &s : o.dropped) dropped.push_back(std::move(s));
+                        if (seq && !enc.write(o.bytes.data(), o.bytes.size())) { io_ok = false; failed = true; }
                     }
                     published = i + 1;          // also on failure: nobody may wait for this chunk for ever
                     cv.notify_all();
                     if (failed) break;
                 }
                 const auto t2 = tick();
-                size_t done = 0;
+                size_t done = seq ? o.bytes.size() : 0;
                 while (done < o.bytes.size()) {
                     const ssize_t w = pwrite(fd, o.bytes.data() + done, o.bytes.size() - done, (off_t)(my_off + done));
                     if (w <= 0) { std::lock_guard<std::mutex> lk(out_mu); io_ok = false; failed = true; cv.notify_all(); break; }
@@ -633,7 +629,8 @@ struct FileFilter {
             gz_member("", 0, 6, m);
             io_ok = pwrite(fd, m.data(), m.size(), 0) == (ssize_t)m.size();
         }
-        io_ok = (close(fd) == 0) && io_ok;
+        if (seq) io_ok = enc.close() && io_ok;
+        else io_ok = (close(fd) == 0) && io_ok;
         SH_CHECK(error.empty(), SH_ERR_IO, "%s", error.c_str());
         SH_CHECK(io_ok, SH_ERR_IO, "short write to %s", out_path);
         return SH_OK;
@@ -659,15 +656,20 @@ size_t retain_budget()
 }
 
 bool write_id_table(const char *path, const std::string &body)
-{   // ReadDifference::write_read_ids (utils.rs:207-214): header `id`, one id per line; compression by extension (level 9, legacy writer)
-    std::string out;
+{   // ReadDifference::write_read_ids (utils.rs:207-214): header `id`, one id per line; container by extension (level 9, legacy writer)
     const std::string p = path;
-    const std::string *src = &body;
-    if (ends_with(p, ".gz")) { if (!gz_member(body.data(), body.size(), 9, out)) return false; src = &out; }
-    FILE *f = fopen(path, "wb");
-    if (!f) return false;
-    const bool ok = fwrite(src->data(), 1, src->size(), f) == src->size();
-    return (fclose(f) == 0) && ok;
+    if (ends_with(p, ".gz")) {
+        std::string out;
+        if (!gz_member(body.data(), body.size(), 9, out)) return false;
+        FILE *f = fopen(path, "wb");
+        if (!f) return false;
+        const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+        return (fclose(f) == 0) && ok;
+    }
+    shc::Out o;      // plain, bzip2, xz
+    if (!o.open(p, 9)) return false;
+    const bool ok = o.write(body.data(), body.size());
+    return o.close() && ok;
 }
 
 // a batch's place in HBM; filled by a parse worker (its own stream), consumed by the device thread
@@ -1283,8 +1285,6 @@ extern "C" sh_status sh_reads_run(const sh_reads_config *c, sh_reads_result *res
                     if (uniq.insert(s.data(), (uint32_t)s.size())) { body += s; body += '\n'; }
         }
         const std::string p = c->read_ids;
-        SH_CHECK(!(ends_with(p, ".bz") || ends_with(p, ".bz2") || ends_with(p, ".lzma") || ends_with(p, ".xz")), SH_ERR_IO,
-                 "bzip2/xz output not supported by the HIP backend: %s", c->read_ids);
         SH_CHECK(write_id_table(c->read_ids, body), SH_ERR_IO, "cannot write %s", c->read_ids);
     }
     if (c->json) {
@@ -1503,8 +1503,6 @@ extern "C" sh_status sh_kraken_run(const sh_kraken_config *c, sh_reads_result *r
     // ---- clean_reads over the retained chunks ----
     if (c->read_ids) {
         const std::string p = c->read_ids;
-        SH_CHECK(!(ends_with(p, ".bz") || ends_with(p, ".bz2") || ends_with(p, ".lzma") || ends_with(p, ".xz")), SH_ERR_IO,
-                 "bzip2/xz output not supported by the HIP backend: %s", c->read_ids);
     }
     // the id table lists the input records MISSING from the outputs (ReadDifference, utils.rs:265-279), not the depletion set: a pair id
     // with its "/1" stripped may match no record at all

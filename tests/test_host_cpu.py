@@ -19,7 +19,10 @@ def py_get_id(header):                       # header.split_whitespace()[0]
 def py_records(path):
     if not os.path.exists(path):
         return []
-    op = gzip.open if open(path, "rb").read(2) == b"\x1f\x8b" else open
+    import bz2
+    import lzma
+    magic = open(path, "rb").read(6)
+    op = gzip.open if magic[:2] == b"\x1f\x8b" else bz2.open if magic[:3] == b"BZh" else lzma.open if magic == b"\xfd7zXZ\x00" else open
     txt = op(path, "rt").read()
     if not txt:
         return []
@@ -106,7 +109,7 @@ def test_truncated_fastq_is_an_error(tmp_path):
     with pytest.raises(S.ScrubbyHipError):
         S.filter_fastx(str(a), str(tmp_path / "o.fastq"), [], False)
     with pytest.raises(S.ScrubbyHipError):
-        S.filter_fastx(str(a), str(tmp_path / "o.fastq.xz"), [], False)     # only gzip / plain outputs
+        S.filter_fastx(str(a), str(tmp_path / "o.fastq.xz"), [], False)     # (whatever the output's container)
 
 
 def test_read_difference_counts_records_over_both_files(tmp_path):

@@ -315,10 +315,13 @@ def test_kraken_run_end_to_end(K, oracle, db, table, cfg1, tax, tmp_path):
     got = open(tmp_path / "ids.tsv").read().split()
     assert got[0] == "id" and set(got[1:]) == hit and len(got) == 1 + len(hit)
     assert json.load(open(tmp_path / "report2.json"))["settings"]["classifier_args"] is None
-    from scrubby_amd.lib import ScrubbyHipError
-    with pytest.raises(ScrubbyHipError, match="bzip2/xz"):
-        K.kraken_run([tmp_path / "p_1.fastq", tmp_path / "p_2.fastq"], [tmp_path / "z_1.fastq", tmp_path / "z_2.fastq"], dbdir,
-                     taxa=["Chordata"], workdir=tmp_path / "work4", read_ids=tmp_path / "ids.tsv.xz")
+    # an id table with niffler's xz extension (utils.rs:28-36): the same ids (taxa_direct as above)
+    import lzma
+    K.kraken_run([tmp_path / "p_1.fastq", tmp_path / "p_2.fastq"], [tmp_path / "z_1.fastq.bz2", tmp_path / "z_2.fastq.xz"], dbdir,
+                 taxa=["Chordata"], taxa_direct=["9606"], workdir=tmp_path / "work4", read_ids=tmp_path / "ids.tsv.xz")
+    gotx = lzma.open(tmp_path / "ids.tsv.xz", "rt").read().split()
+    assert gotx[0] == "id" and set(gotx[1:]) == hit
+    assert open(tmp_path / "z_1.fastq.bz2", "rb").read(3) == b"BZh" and open(tmp_path / "z_2.fastq.xz", "rb").read(6) == b"\xfd7zXZ\x00"
     for name in ("q_1.fastq", "q_2.fastq"):
         kept = {l[1:].split()[0] for l in open(tmp_path / name) if l.startswith("@syn.")}
         assert kept == set(ids) - hit

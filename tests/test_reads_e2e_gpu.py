@@ -65,6 +65,26 @@ def test_reads_run_deplete_with_report(dataset):
     assert got_ids[0] == "id" and set(x for x in got_ids[1:] if x) == ids
 
 
+def test_reads_run_with_bzip2_and_xz_files(dataset, tmp_path):
+    """niffler's other containers end to end (utils.rs:28-36, 56-74, 377-383): R1 as bzip2, R2 as xz, outputs .bz2 / .xz, the id table
+    as .tsv.xz - same records, counts and ids as the plain / gzip run."""
+    import bz2
+    import lzma
+    from scrubby_amd import lib as S
+    d, fa, r1, r2, ids, n_pairs = dataset
+    b1, x2 = str(tmp_path / "R1.fastq.bz2"), str(tmp_path / "R2.fastq.xz")
+    open(b1, "wb").write(bz2.compress(open(r1, "rb").read()))
+    open(x2, "wb").write(lzma.compress(gzip.open(r2, "rb").read()))
+    o1, o2, js, tsv = str(tmp_path / "c1.fastq.xz"), str(tmp_path / "c2.fastq.bz2"), str(tmp_path / "report.json"), str(tmp_path / "ids.tsv.xz")
+    res = S.reads_run([b1, x2], [o1, o2], fa, json=js, read_ids=tsv, command="scrubby reads")
+    check_outputs(r1, r2, o1, o2, ids, False)
+    assert open(o1, "rb").read(6) == b"\xfd7zXZ\x00" and open(o2, "rb").read(3) == b"BZh"
+    assert res["reads_in"] == 2 * n_pairs and res["reads_removed"] == 2 * len(ids) and res["n_depleted_ids"] == len(ids)
+    got_ids = lzma.open(tsv, "rt").read().split("\n")
+    assert got_ids[0] == "id" and set(x for x in got_ids[1:] if x) == ids
+    assert json.load(open(js))["reads_removed"] == 2 * len(ids)
+
+
 def test_reads_run_extract_and_single_end(dataset):
     from scrubby_amd import lib as S
     d, fa, r1, r2, ids, n_pairs = dataset
