@@ -11,7 +11,7 @@ from scrubby_amd import lib as S
 dev = torch.device("cuda", 0)
 S.require_gpu()
 P = S.ref_params(B.REF_SEED, B.CHM13_CONTIGS); R = S.read_params(B.READ_SEED)
-G = P.genome_len; L = R.read_len; n = 20_000_000
+G = P.genome_len; L = R.read_len; n = int(os.environ.get("OVERLAP_N", "20000000"))
 opts = S.preset("sr")
 d_ref = torch.empty(G + 64, dtype=torch.uint8, device=dev); S.synth_ref_device(P, 0, G, d_ref)
 index = S.Index.build_device(d_ref, [P.contig_start[i] for i in range(len(B.CHM13_CONTIGS) + 1)], opts, device=0); del d_ref
