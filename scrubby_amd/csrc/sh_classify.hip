@@ -78,6 +78,7 @@ struct Counters {
     uint32_t sort_ticket[N_SORT_CLS];      // k_sort_lds: next item of the class (blocks draw reads one by one: their costs differ a hundredfold)
     uint32_t n_long_segs, pad2;
     uint32_t ext_reason[8];       // why the top chain did not settle a read (k_ext_top)
+    uint32_t lext_exact_direct, lext_pad_d;      // giants whose first pass ran on the EXACT instance and asked the tree
     uint32_t ext_s3[8];           // SCRUBBY_HIP_DBG & 16: outcome of the local-cluster shortcut (k_expand): 0 tried, 1 no singleton / filtered seed, 2 singletons apart, 3 window grew / too many, 4 K > 64, 5 no margin over U_out, 6 lemma, 7 decided
     uint32_t ext_overflow, ext_n_list, ext_ticket, ext_regions, ext_dropped, ext_n_redo, ext_n_list2, ext_ticket2, ext_n_redo2, ext_ticket3, ext_n_unres, ext_ticket_unres, ext_n_unres_in, ext_pad8;      // extension stage (sh_align.h)
     uint32_t ext_n_recs[SINK_SHARDS]; unsigned long long ext_n_anch[SINK_SHARDS];                 // hand-over cursors, one per shard
@@ -3115,12 +3116,12 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
         LongOut o;
         const unsigned long long t_r0 = a.clk ? wall_clock64() : 0ull;
         const unsigned long long d0_before = clk.d[0];
-        if (a.clk) { clk.w_max = 0; clk.n_q = 0; }
+        if (a.clk) { clk.w_max = 0; clk.n_q = 0; clk.n_seg = 0; clk.tie_seg_a = 0; }
         const int32_t rc = lr_chains_wave<NR, EXACT, FAT>(C, RL, AR_l, o, a.drop ? a.drop[r] : 0u, TL);
         if (a.clk && lane == 0) {
             const unsigned long long dt = wall_clock64() - t_r0;
             // SCRUBBY_HIP_DBG_EXACT: one line per read of the exact passes (what profiles/r05_exact_reads.txt was made with)
-            if (EXACT && (a.clk & 2)) printf("[exact] read %u qlen %d chains %d anchors %llu window %llu queries %llu ms %.1f rc %d\n", r, C.qlen, o.n_chain, clk.d[0] - d0_before, clk.w_max, clk.n_q, dt / 1e5, rc);
+            if (EXACT && (a.clk & 2)) printf("[exact] read %u qlen %d chains %d anchors %llu window %llu queries %llu segs %llu tie_seg_anchors %llu ms %.1f rc %d\n", r, C.qlen, o.n_chain, clk.d[0] - d0_before, clk.w_max, clk.n_q, clk.n_seg, clk.tie_seg_a, dt / 1e5, rc);
             atomicMax(&a.ctr->lext_slow, dt << 24 | (unsigned long long)(o.n_chain > 0xffffff ? 0xffffff : o.n_chain)); atomicAdd(&a.ctr->lext_kernel_sum, dt);
             atomicMax(&a.ctr->lext_slow2, dt << 32 | (unsigned long long)(uint32_t)C.qlen);
             atomicMax(&a.ctr->lext_slow3, dt << 32 | (unsigned long long)r);
@@ -3149,7 +3150,11 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
             }
         }
         else if (rc != 0) { if (lane == 0) lext_defer(a, r, 16u + C.err, false); }
-        else { n_rechain += (o.rechained & 2) != 0; n_open += o.rmq_tie != 0; if (o.rmq_tie && lane == 0) lk_mark(a, r, LK_RMQ_OPEN); }
+        else {
+            n_rechain += (o.rechained & 2) != 0; n_open += o.rmq_tie != 0; if (o.rmq_tie && lane == 0) lk_mark(a, r, LK_RMQ_OPEN);
+            // a first-pass launch of the EXACT instance (the giants): the read's join asked the tree - the same stratum and count as a read of the exact passes
+            if (EXACT && a.part && o.rmq_asked && lane == 0) { lk_mark(a, r, LK_EXACT); atomicAdd(&a.ctr->lext_rmq_tie, 1u); atomicAdd(&a.ctr->lext_exact_direct, 1u); }
+        }
         __syncthreads();
     }
     if (lane == 0) {
@@ -4137,6 +4142,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 // reads whose chain anchors outgrow the first size go straight to the large working memory, on a side stream beside the rest
                 int bin_cut = 0;
                 while (bin_cut < 31 && (2ull << bin_cut) <= c->lext_sz[0].cap_a) ++bin_cut;      // bin b holds totals in [2^b, 2^(b+1))
+                if (const char *env = getenv("SCRUBBY_HIP_GIANT_BINS_DOWN")) bin_cut = std::max(1, bin_cut - atoi(env));
                 xa.hist = c->d_ctr->lext_hist; xa.bin_cut = bin_cut; xa.part = 1;
                 ExtLongArgs xg = xa;
                 xg.scratch = c->d_lext[1]; xg.scratch_per_wave = c->lext_per_wave[1]; xg.sz = c->lext_sz[1];
@@ -4146,14 +4152,19 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 // times longer while the main grid loads the memory system; so they get the 4096-anchor ring (99 KB of LDS a wave, no trip
                 // behind it), and because a CU the main grid has filled has no such room left, the main grid is held back until the giants'
                 // blocks have begun (k_wait_started: bounded, ~2 ms at most).  The main grid's blocks (13 KB) fit beside them.
-                const uint32_t g_waves = std::min<uint32_t>(c->lext_waves[1], 64u);
+                uint32_t g_waves = std::min<uint32_t>(c->lext_waves[1], 64u);
+                if (const char *env = getenv("SCRUBBY_HIP_GIANT_WAVES")) g_waves = std::min<uint32_t>(c->lext_waves[1], (uint32_t)std::max(1, atoi(env)));
                 xg.started = &c->d_ctr->lext_started;
                 SH_HIP(hipMemsetAsync(&c->d_ctr->lext_started, 0, 4, s));
                 SH_HIP(hipEventRecord(c->evx[0], s));
                 hipStream_t sg = c->sx[c->side_pick[0]];
                 SH_HIP(hipStreamWaitEvent(sg, c->evx[0], 0));
                 const uint32_t m_waves = c->lext_waves[0];
-                hipLaunchKernelGGL((k_long_chains<4096, false, false>), dim3(g_waves), dim3(64), 0, sg, xg);
+                // (the giants on the EXACT instance at once: the tree is only kept over the stretches that ask it, lr_rmq_fill - a giant with a tie
+                // is not chained twice, and the exact passes lose their longest reads)
+                static const bool giants_exact = !getenv("SCRUBBY_HIP_GIANTS_PLAIN");
+                if (giants_exact) hipLaunchKernelGGL((k_long_chains<4096, true, false>), dim3(g_waves), dim3(64), 0, sg, xg);
+                else hipLaunchKernelGGL((k_long_chains<4096, false, false>), dim3(g_waves), dim3(64), 0, sg, xg);
                 SH_HIP(hipEventRecord(c->evx[1], sg));
                 hipLaunchKernelGGL(k_wait_started, dim3(1), dim3(64), 0, s, (const uint32_t *)&c->d_ctr->lext_started, g_waves, 2000u);
                 hipLaunchKernelGGL((k_long_chains<512, false, false>), dim3(m_waves), dim3(64), 0, s, xa);
@@ -4252,13 +4263,17 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 // second during which nothing else ran.  Both grids are resident together (two waves per SIMD each: 8 per CU); what the
                 // follower leaves (it gives up after a bounded number of looks) the launch after the first one takes, as before.
                 static const bool no_follow = getenv("SCRUBBY_HIP_NO_FOLLOW") != nullptr;
-                const bool follow = !no_follow && c->lext_waves[2] + c->lext_waves[3] <= 8u * (uint32_t)c->n_cu;
+                // (both grids must be RESIDENT together - a follower that holds the slot a block of the first launch waits for would wait for that
+                // launch to end: the first launch gives up the slots the follower needs; its reads are drawn by ticket, so fewer blocks lose nothing)
+                const uint32_t slots = 8u * (uint32_t)c->n_cu;
+                const bool follow = !no_follow && c->lext_waves[3] <= slots / 4;
+                const uint32_t w_first = follow ? std::min<uint32_t>(c->lext_waves[2], slots - c->lext_waves[3]) : c->lext_waves[2];
                 if (follow) {
                     SH_HIP(hipMemsetAsync(c->d_lext_big2, 0xff, (size_t)n_reads * 4, s));
                     SH_HIP(hipMemsetAsync(&c->d_ctr->lext_t0_done, 0, 4, s));
                     SH_HIP(hipEventRecord(c->evx[2], s));
                 }
-                hipLaunchKernelGGL(k_regs_align_long, dim3(c->lext_waves[2]), dim3(64), 0, s, xb);
+                hipLaunchKernelGGL(k_regs_align_long, dim3(w_first), dim3(64), 0, s, xb);
                 if (follow) {
                     // submitted in this order - first launch, its end mark, then the follower: two streams may share a hardware queue, and
                     // a follower submitted ahead of the launch it follows would then sit in front of it until its looks ran out
@@ -4348,7 +4363,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         SH_HIP(hipEventRecord(c->ev_ext[1], s));
         SH_HIP(hipEventSynchronize(c->ev_ext[1]));
         ext_regions = c->h_ctr->ext_regions; ext_dropped = c->h_ctr->ext_dropped;
-        if (stats) { stats->n_ext_unresolved += c->h_ctr->lext_unresolved; stats->n_rmq_rechained += c->h_ctr->lext_rechained; stats->n_rmq_tied += c->h_ctr->lext_rmq_tie; stats->n_rmq_exact += n_exact_reads; stats->n_ext_ondemand += n_ondemand; stats->n_rmq_open += c->h_ctr->lext_rmq_open; }
+        if (stats) { stats->n_ext_unresolved += c->h_ctr->lext_unresolved; stats->n_rmq_rechained += c->h_ctr->lext_rechained; stats->n_rmq_tied += c->h_ctr->lext_rmq_tie; stats->n_rmq_exact += n_exact_reads + c->h_ctr->lext_exact_direct; stats->n_ext_ondemand += n_ondemand; stats->n_rmq_open += c->h_ctr->lext_rmq_open; }
         hipEventElapsedTime(&ms_ext, c->ev_ext[0], c->ev_ext[1]);
     } else if (c->ext) {
         ExtArgs x{};

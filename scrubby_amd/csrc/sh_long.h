@@ -210,7 +210,7 @@ __device__ inline void lr_reg_set_coor_wave(LReg &r, int32_t qlen, const LAnchor
 // where a wave's time goes (SCRUBBY_HIP_DBG): 0 gather, 1 rmq sort, 2 rmq fill, 3 backtrack + compact, 4 gen_regs, 5 parent / select / est_err, 6 squeeze,
 // 7 region set-up (bad ends / seeds, windows), 8 ksw, 9 z-drop test, 10 update_extra, 11 sequence staging
 #define LR_NCLK 12
-struct LongClk { unsigned long long t[LR_NCLK]; unsigned long long last; unsigned long long d[8]; unsigned long long w_max, n_q; };      // d: RMQ statistics (steps, ring blocks evaluated, steps that went behind the ring, old blocks evaluated, sum of the list length, inner chunks, anchors)
+struct LongClk { unsigned long long t[LR_NCLK]; unsigned long long last; unsigned long long d[8]; unsigned long long w_max, n_q, n_seg, tie_seg_a; };      // d: RMQ statistics (steps, ring blocks evaluated, steps that went behind the ring, old blocks evaluated, sum of the list length, inner chunks, anchors)
 __device__ inline void lr_tick(LongClk *c, int ph) { if (c) { const unsigned long long now = wall_clock64(); c->t[ph] += now - c->last; c->last = now; } }
 
 // ---- mg_lchain_rmq on one wave -------------------------------------------------------------------------------------------
@@ -291,12 +291,20 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
     // walked by lane 0; a window that outgrows its nodes ends the call (ok = false), like a window that outgrows the ring
     RqTreeT<RqLds> T0;
     T0.st = TL; T0.st.n_used = 0; T0.st.free_head = RQ_NIL; rq_reset(T0);
-    int32_t st_tree = 0;      // anchors [st_tree, i0) are in the tree
+    int32_t st_tree = 0;      // anchors [st_tree, i0) are in the tree (while tree_on)
+    // The tree is only ever ASKED at a step whose smallest priority is shared, and what it answers depends on its shape - on every insertion
+    // and removal since it was last EMPTY, and on nothing before that.  The look-back window empties whenever the reference position jumps by
+    // more than max_dist (another contig, strand or locus: some twenty times in a read of 70 k anchors), so the tree is kept only from the
+    // start of the stretch that holds such a step: built there by replaying the stretch's insertions and removals (they depend on x and on
+    // priorities that are final by then), kept up to date until the window empties again, and dropped.  9 % of the anchors of the bench's
+    // exact reads lie in such stretches.
+    bool tree_on = false;
+    int32_t seg_i = -1, seg_i0 = 0;      // the window was last found empty after step seg_i's trim, with i0 = st = seg_i0
     n_tie = 0;
     // the parameters in registers: P lives in the caller's scratch, and a load from it inside the loop costs more than the step's arithmetic
     const float pen_gap = P.pen_gap, pen_skip = P.pen_skip;
     const int32_t kk = P.k, max_skip = P.max_skip, rmq_inner_dist = P.rmq_inner_dist, rmq_size_cap = P.rmq_size_cap;
-    int32_t tie_cnt = 0;
+    int32_t tie_cnt = 0, dbg_seg0 = 0;
     unsigned long long d_ring = 0, d_oldsteps = 0, d_old = 0, d_nin = 0, d_chunks = 0;
     const int32_t lane = (int32_t)al_lane();
     constexpr int32_t M = LRQ_INNER - 1;
@@ -364,7 +372,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 }
                 if (!ok) break;
             }
-            if (TREE) {      // (the whole wave: rq_insert_w)
+            if (TREE && tree_on) {      // (the whole wave: rq_insert_w)
                 for (int32_t j = i0; j < i; ++j)
                     if (rq_insert_w(T0, L.ry[j & M], j, rpri_of(j)) == RQ_NIL) { T0.bad = 11; break; }
             }
@@ -397,11 +405,17 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
             if (first < 64) break;
         }
         if (i0 - st > rmq_size_cap) st = i0 - rmq_size_cap;
-        if (TREE && st_tree < st) {
+        if (TREE && tree_on && st_tree < st) {
             for (int32_t j = st_tree; j < st && j < i0; ++j) { const int32_t e = rq_erase_w(T0, (int32_t)a[j].y, j); if (e != RQ_NIL) rqw_free(T0, e); }
             st_tree = st;
         }
+        if (TREE && st >= i0) {      // the window is empty, and so is upstream's tree: what follows does not depend on anything before
+            if (tree_on) { tree_on = false; T0.st.n_used = 0; T0.st.free_head = RQ_NIL; rq_reset(T0); }
+            seg_i = i; seg_i0 = i0;
+        }
         if (TREE && dbg && (unsigned long long)(i0 - st) > dbg->w_max) dbg->w_max = (unsigned long long)(i0 - st);
+        if (TREE && dbg && st >= i0 && i0 > dbg_seg0) { ++dbg->n_seg; dbg_seg0 = i0; }
+        if (TREE && dbg && tree_on) ++dbg->tie_seg_a;      // steps with the tree kept
         if (max_dist_inner > 0) {
             const int32_t st_old = st_inner;
             if (st_inner < seg0) st_inner = seg0;
@@ -517,6 +531,33 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
         LRQ_T(2);
         bool tie_pending = false; int32_t tie_sc = 0;
         if (TREE && bj >= 0 && ties > 1) {
+            if (!tree_on) {
+                // upstream's tree as it stands after this step's insertions and removals: the steps seg_i + 1 .. i once more, tree operations only
+                int32_t i0r = seg_i0, str = seg_i0;
+                uint64_t x_i0r = a[seg_i0 < n ? seg_i0 : n - 1].x;
+                st_tree = seg_i0;
+                for (int32_t ii = seg_i + 1; ii <= i && !T0.bad; ++ii) {
+                    const uint64_t xr = a[ii].x;
+                    if (i0r < ii && x_i0r != xr) {
+                        for (int32_t j = i0r; j < ii; ++j) {
+                            const double pj = j < blk_done * 64 ? lr_cc_f64(pri + j) : rpri_of(j);
+                            const int32_t yj = j < blk_done * 64 ? (int32_t)a[j].y : L.ry[j & M];
+                            if (rq_insert_w(T0, yj, j, pj) == RQ_NIL) { T0.bad = 11; break; }
+                        }
+                        i0r = ii; x_i0r = xr;
+                    }
+                    while (str < ii && xr > a[str].x + (uint64_t)max_dist) ++str;
+                    if (i0r - str > rmq_size_cap) str = i0r - rmq_size_cap;
+                    if (st_tree < str && !T0.bad) {
+                        for (int32_t j = st_tree; j < str && j < i0r; ++j) { const int32_t e = rq_erase_w(T0, (int32_t)a[j].y, j); if (e != RQ_NIL) rqw_free(T0, e); }
+                        st_tree = str;
+                    }
+                }
+                if (!T0.bad && (i0r != i0 || str != st)) T0.bad = 12;      // (the replay and the scan must agree on the window)
+                if (T0.bad) { ok = false; break; }
+                tree_on = true;
+                if (dbg) dbg->tie_seg_a += (unsigned long long)(i - seg_i);      // anchors replayed
+            }
             int32_t tj = -1;
             if (lane == 0) { const int32_t q = rq_rmq(T0, qi - max_dist, INT32_MAX, qi, 0); tj = q != RQ_NIL ? rq_i(T0, q) : -1; }
             tj = al_b0(tj);
@@ -642,6 +683,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
 #undef LIY
 #undef LIY_SET
 #undef LIJ
+    if (TREE && dbg) ++dbg->n_seg;
     if (TREE && T0.bad) ok = false;
     n_tie = tie_cnt;
     if (ok) for (int32_t j = blk_done * 64 + lane; j < n; j += 64) { f[j] = L.rf[j & M]; p[j] = L.rp[j & M]; }      // the last, incomplete block(s)
@@ -1652,7 +1694,7 @@ __device__ inline int32_t lr_chain_of(OFF off, int32_t n, int32_t i)
 }
 
 // ---- the whole stage for one read ---------------------------------------------------------------------------------------------------
-struct LongOut { int32_t n_chain, best, rechained, n_aligned, n_regs, dp_max; uint32_t sig; int32_t rmq_tie, probed; int32_t n_join; };      // n_join: anchors that entered the long join
+struct LongOut { int32_t n_chain, best, rechained, n_aligned, n_regs, dp_max; uint32_t sig; int32_t rmq_tie, probed; int32_t n_join, rmq_asked; };      // n_join: anchors that entered the long join; rmq_asked (EXACT): steps of the join that asked the tree
 // The stage runs as two kernels, so that neither carries the other's registers and LDS: the first leaves a read's final chains (after the
 // long join, in compact_a's order, MM_SEED_TANDEM set) in an arena; the second turns them into regions and aligns.
 struct LongHdr { unsigned long long off; int32_t n_u, n_a, best, rechained; unsigned long long alt; };      // per read: u[n_u] (8 B), uoff[n_u + 1] (4 B), a[n_a] (16 B) at arena + off; alt - 1: a second outcome to prove (lr_chains_wave), {n_a, score, 0, 0} + a[n_a]
@@ -1695,7 +1737,7 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR, FAT> &RL, const
     const int32_t lane = (int32_t)al_lane();
     const uint32_t read = C.read;
     const int32_t qlen = C.qlen;
-    out.n_chain = out.best = out.rechained = out.n_aligned = out.n_regs = out.dp_max = 0; out.sig = 0; out.rmq_tie = 0; out.probed = 0; out.n_join = 0;
+    out.n_chain = out.best = out.rechained = out.n_aligned = out.n_regs = out.dp_max = 0; out.sig = 0; out.rmq_tie = 0; out.probed = 0; out.n_join = 0; out.rmq_asked = 0;
     if ((uint32_t)qlen > W.cap_q) { C.err = 4; return 3; }
 
     // ---- the read's chains, in compact_a's order: by the first anchor's x, ties in discovery order (larger (f, index) first)
@@ -1813,6 +1855,7 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR, FAT> &RL, const
                     uint32_t code = 0;
                     if (!lr_rmq_fill_tree(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.t, W.rq0, W.rq1, (int32_t)W.cap_a + 2, &code)) { C.err = 100u + (uint32_t)al_b0((int32_t)code); return 3; }
                 }
+                out.rmq_asked = tie;
             } else {
                 if (!lr_rmq_fill<NR, false, FAT>(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie, C.clk)) {
                     if (NR < 4096) { C.err = 6; return 3; }      // beyond this ring: the pass with the large one

@@ -159,6 +159,24 @@ def test_lattices_of_anchors_across_perfect_tandem_arrays(S, oracle):
     assert rc2 == 0 and np.array_equal(gf2, of) and st2["n_ext_unresolved"] == 0
 
 
+def test_ties_after_the_look_back_window_has_emptied(S, oracle):
+    """Reads over two or three tandem arrays tens of kilobases apart: between the loci the long join's window - and upstream's tree - is
+    empty, so a tie in a later locus is answered by a tree built from that locus alone.  lr_rmq_fill keeps the tree only over the stretches
+    that ask it (replayed from the stretch's start); full trace and flags against the oracle, whose tree lives through the whole read."""
+    seqs, bases, offs = LC.tandem_chimera_case()
+    gidx = S.Index.build([bytes(s) for s in seqs], S.preset("map-ont"))
+    cidx = oracle.Index.build([np.frombuffer(s, np.uint8) for s in seqs], 10, 15)
+    oo = cidx.update_opts(oracle.preset("map-ont"))
+    gf, gt, st, rc = gidx.classify(bases, offs, want_trace=True)
+    of, ot = cidx.classify(oo, bases, offs, threads=8)
+    assert rc == 0 and st["n_ext_unresolved"] == 0
+    assert_same(S, gf, gt, of, ot)
+    print("tied:", st["n_rmq_tied"], "exact:", st["n_rmq_exact"], "rechained:", st["n_rmq_rechained"])
+    assert st["n_rmq_exact"] >= st["n_rmq_tied"] > 0 and st["n_rmq_rechained"] > 0
+    gf2, _, st2, rc2 = gidx.classify(bases, offs, want_trace=False)
+    assert rc2 == 0 and np.array_equal(gf2, of) and st2["n_ext_unresolved"] == 0
+
+
 def test_windows_beyond_the_large_ring_are_counted_or_take_the_one_lane_trees(S, oracle, monkeypatch):
     """A read whose long join holds more anchors within rmq_inner_dist than the 4096-anchor ring (LC.dense_lattice_case: ~10^4 lattice anchors
     over one kilobase) cannot be chained by the wave scan.  By default it keeps its chain-level answer and is COUNTED (n_ext_unresolved, and
