@@ -128,48 +128,6 @@ def tandem_case(seed=5, n_arrays=24, n_reads=240):
     return [ref], bases, offs
 
 
-def tandem_chimera_case(seed=9, n_arrays=24, n_reads=160):
-    """tandem_case's reference, and reads that cross TWO (every fourth: three) of its arrays, tens of kilobases apart, one after the other: the
-    long join's look-back window empties between the loci, upstream's tree is empty there, and a tie in the second or third locus is
-    answered by a tree that only knows that locus (lr_rmq_fill keeps the tree from the start of the stretch that asks it, rebuilt by
-    replaying the stretch).  Returns (contigs, bases, offsets)."""
-    rng = np.random.default_rng(seed)
-
-    def rnd(m):
-        return bytes(ACGT[rng.integers(0, 4, m)])
-    parts, arrays, pos = [], [], 0
-    for _ in range(n_arrays):
-        flank = rnd(int(rng.integers(6000, 9000)))
-        mono = rnd(int(rng.integers(40, 180)))
-        copies = int(rng.integers(4, 9))
-        parts += [flank, mono * copies]
-        arrays.append((pos + len(flank), mono, copies))
-        pos += len(flank) + len(mono) * copies
-    parts.append(rnd(8000))
-    ref = b"".join(parts)
-    recs = []
-    for it in range(n_reads):
-        pick = rng.choice(n_arrays, 3 if it % 4 == 3 else 2, replace=False)
-        if it % 2:
-            pick = np.sort(pick)                                             # every other read visits its loci in reference order
-        src = b""
-        for a in pick:
-            st, mono, copies = arrays[int(a)]
-            left = int(rng.integers(600, 2500)); right = int(rng.integers(600, 2500))
-            c2 = max(2, copies + int(rng.integers(-2, 3)))
-            piece = ref[st - left:st] + mono * c2 + ref[st + len(mono) * copies:st + len(mono) * copies + right]
-            src += _rc(piece) if rng.integers(0, 5) == 0 else piece
-        e = (0.0, 0.004, 0.02)[it % 3]
-        r = _noisy(rng, src, e, e * 0.75) if e > 0 else src
-        if it % 4 == 1:
-            r = _rc(r)
-        recs.append(r)
-    bases = np.frombuffer(b"".join(recs), np.uint8)
-    offs = np.zeros(len(recs) + 1, np.uint64)
-    offs[1:] = np.cumsum([len(x) for x in recs])
-    return [ref], bases, offs
-
-
 def dense_lattice_case(seed=11, n_reads=6, ref_copies=10, read_copies=(30, 38)):
     """Reads whose long join holds more anchors inside rmq_inner_dist (1000 reference bases) than the 4096-anchor LDS ring takes: a perfect
     tandem array of ref_copies copies of a ~100-bp monomer (every k-mer at most ref_copies times in the reference: below map-ont's

@@ -160,21 +160,51 @@ def test_lattices_of_anchors_across_perfect_tandem_arrays(S, oracle):
 
 
 def test_ties_after_the_look_back_window_has_emptied(S, oracle):
-    """Reads over two or three tandem arrays tens of kilobases apart: between the loci the long join's window - and upstream's tree - is
-    empty, so a tie in a later locus is answered by a tree built from that locus alone.  lr_rmq_fill keeps the tree only over the stretches
-    that ask it (replayed from the stretch's start); full trace and flags against the oracle, whose tree lives through the whole read."""
-    seqs, bases, offs = LC.tandem_chimera_case()
+    """Chimeras of the reads whose long join meets tied priorities (found among 20 000 reads of the bench's generator: sh_ctx_debug_list 3),
+    two or three of them end to end, some reverse-complemented: the loci lie megabases apart or on other contigs, so between them the
+    join's look-back window - and upstream's tree - is empty, and a tie in a later locus is answered by a tree that only knows that locus.
+    lr_rmq_fill keeps the tree only over the stretches that ask it, rebuilt by replay from where the window was last empty; the oracle's
+    tree lives through the whole read.  Full trace and flags; and ties must have been met again."""
+    import torch
+    Po = oracle.ref_params(0x5C2B0010, [1_000_000] * 5)
+    Ro = oracle.read_params(0x5C2B0020, read_len=0, host_pct=100, sub_per_10k=200, n_read_pct=1)
+    cpu, offs = oracle.synth_long_reads(Po, Ro, 3, 20000)
+    seqs = [oracle.synth_ref(Po, Po.contig_start[i], 1_000_000) for i in range(5)]
     gidx = S.Index.build([bytes(s) for s in seqs], S.preset("map-ont"))
-    cidx = oracle.Index.build([np.frombuffer(s, np.uint8) for s in seqs], 10, 15)
+    ctx = S.Context(gidx, len(offs) - 1, int(offs[-1]), int(np.diff(offs.astype(np.int64)).max()))
+    d_b = torch.from_numpy(np.ascontiguousarray(cpu)).cuda(); d_o = torch.from_numpy(offs.astype(np.int64)).cuda()
+    d_f = torch.zeros(len(offs) - 1, dtype=torch.uint8, device="cuda")
+    ctx.classify(d_b, d_o, d_f)
+    torch.cuda.synchronize()
+    tied = np.unique(ctx.debug_list(3).astype(np.int64))
+    assert len(tied) >= 2, "the generator's satellite reads no longer meet tied priorities"
+    tied = tied[:6]
+    rng = np.random.default_rng(3)
+    comp = np.zeros(256, np.uint8); comp[:] = np.arange(256); comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    rd = lambda r: np.asarray(cpu[int(offs[r]):int(offs[r + 1])])
+    rcm = lambda x: comp[x][::-1]
+    recs = []
+    for a in tied:
+        for b in tied:
+            if a == b:
+                continue
+            recs.append(np.concatenate([rd(a), rd(b)]))
+            recs.append(np.concatenate([rcm(rd(b)), rd(a)]))
+    for _ in range(6):
+        t3 = rng.choice(tied, min(3, len(tied)), replace=False)
+        recs.append(np.concatenate([rd(t) if rng.integers(0, 2) else rcm(rd(t)) for t in t3]))
+    bases = np.concatenate(recs).astype(np.uint8)
+    co = np.zeros(len(recs) + 1, np.uint64); co[1:] = np.cumsum([len(x) for x in recs])
+    cidx = oracle.Index.build(seqs, 10, 15)
     oo = cidx.update_opts(oracle.preset("map-ont"))
-    gf, gt, st, rc = gidx.classify(bases, offs, want_trace=True)
-    of, ot = cidx.classify(oo, bases, offs, threads=8)
+    gf, gt, st, rc = gidx.classify(bases, co, want_trace=True)
+    of, ot = cidx.classify(oo, bases, co, threads=16)
     assert rc == 0 and st["n_ext_unresolved"] == 0
     assert_same(S, gf, gt, of, ot)
-    print("tied:", st["n_rmq_tied"], "exact:", st["n_rmq_exact"], "rechained:", st["n_rmq_rechained"])
-    assert st["n_rmq_exact"] >= st["n_rmq_tied"] > 0 and st["n_rmq_rechained"] > 0
-    gf2, _, st2, rc2 = gidx.classify(bases, offs, want_trace=False)
-    assert rc2 == 0 and np.array_equal(gf2, of) and st2["n_ext_unresolved"] == 0
+    print("chimeras:", len(recs), "tied:", st["n_rmq_tied"], "exact:", st["n_rmq_exact"], "rechained:", st["n_rmq_rechained"])
+    assert st["n_rmq_exact"] >= st["n_rmq_tied"] > 0
+    gf2, _, st2, rc2 = gidx.classify(bases, co, want_trace=False)
+    assert rc2 == 0 and np.array_equal(gf2, of) and st2["n_ext_unresolved"] == 0 and st2["n_rmq_tied"] > 0
 
 
 def test_windows_beyond_the_large_ring_are_counted_or_take_the_one_lane_trees(S, oracle, monkeypatch):
