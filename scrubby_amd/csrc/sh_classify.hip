@@ -2952,6 +2952,7 @@ struct ExtLongArgs {
     const uint32_t *drop; uint32_t *fb_list, *n_fb;   // k_lr_locus: what was left out of a read's anchors; reads that must be redone with every anchor
     uint32_t *started;                                // counts the blocks that have begun (the giants' grid: the main grid is launched once they hold their LDS)
     const uint32_t *follow_done;                      // k_regs_align_long beside the launch that fills its list: set when that launch has ended
+    LongCoop coop; int32_t coop_on;                   // k_long_chains, EXACT instance: the launch's waves share the long join of its largest reads (lr_coop_fill)
     uint8_t *kind;                                    // per read of the call: which of the stage's rarer paths it took (LK_*; sh_ctx_debug_list, the bench's stratified oracle check)
 };
 // bits of ExtLongArgs::kind
@@ -3088,7 +3089,7 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
     RqLds TL{};
     if (EXACT) TL.init(TM);
     const uint32_t lane = threadIdx.x;
-    const LongParams P_l = a.P; const LongIn I_l = a.I; const LongArena AR_l = a.AR;      // no pointers into the kernel-argument struct
+    const LongParams P_l = a.P; const LongIn I_l = a.I; const LongArena AR_l = a.AR; const LongCoop coop_l = a.coop;      // no pointers into the kernel-argument struct
     LongWs W;
     long_ws_carve(&W, a.scratch + (unsigned long long)blockIdx.x * a.scratch_per_wave, a.sz);
     uint32_t n_list = *a.n_list, t_first = 0;
@@ -3113,6 +3114,7 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
         C.P = &P_l; C.AP = nullptr; C.I = &I_l; C.W = &W; C.Ls = nullptr; C.A = AlignScratch{};
         C.qlen = (int32_t)(I_l.in.offsets[r + 1] - I_l.in.offsets[r]); C.read = r;
         C.sc_mch = C.sc_mis = C.sc_amb = C.sc_N = 0; C.need_big = false; C.err = 0; C.clk = a.clk ? &clk : nullptr;
+        C.coop = (EXACT && a.coop_on) ? &coop_l : nullptr; C.coop_me = blockIdx.x;
         LongOut o;
         const unsigned long long t_r0 = a.clk ? wall_clock64() : 0ull;
         const unsigned long long d0_before = clk.d[0];
@@ -3157,6 +3159,15 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
         }
         __syncthreads();
     }
+    if constexpr (EXACT) {
+        if (a.coop_on) {      // no read left for this wave: runs of the reads the others still join (lr_coop_fill), while there are any
+            for (;;) {
+                if (lr_coop_take<NR, FAT>(P_l, coop_l, RL, TL)) continue;
+                if (al_b0((int32_t)cc_u32(coop_l.active)) == 0) break;
+                __builtin_amdgcn_s_sleep(64);
+            }
+        }
+    }
     if (lane == 0) {
         if (n_rechain) atomicAdd(&a.ctr->lext_rechained, n_rechain);
         if (n_open) { atomicAdd(&a.ctr->lext_rmq_tie, n_open); atomicAdd(&a.ctr->lext_rmq_open, n_open); }
@@ -3182,21 +3193,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             // other launch has ended and the list is empty - or after ~10 s of looks, whatever is left going to the launch that follows.
             // A ticket is only drawn for an entry that is already THERE (the list is preset to ~0 and an entry is written once, right after
             // its index was drawn by the producer): nothing is consumed and then given up on.
+            // (every branch on a value all lanes hold: the lanes load the same words, one lane swaps - see lr_coop_take)
             uint32_t got = ~0u, rr = ~0u;
-            if (lane == 0) {
-                for (uint32_t looks = 0; looks < 2000000u; ++looks) {
-                    const uint32_t cur = __atomic_load_n(a.ticket, __ATOMIC_RELAXED), n = __atomic_load_n(a.n_list, __ATOMIC_RELAXED);
-                    if (cur < n) {
-                        const uint32_t e = __atomic_load_n(&a.list[cur], __ATOMIC_RELAXED);
-                        if (e != ~0u) { if (atomicCAS(a.ticket, cur, cur + 1u) == cur) { got = cur; rr = e; break; } continue; }
-                        __builtin_amdgcn_s_sleep(8);
+            auto ld = [](const uint32_t *p) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)__atomic_load_n(p, __ATOMIC_RELAXED)); };
+            for (uint32_t looks = 0; looks < 2000000u; ++looks) {
+                const uint32_t cur = ld(a.ticket), n = ld(a.n_list);
+                if (cur < n) {
+                    const uint32_t e = ld(&a.list[cur]);
+                    if (e != ~0u) {
+                        uint32_t old = ~0u;
+                        if (lane == 0) old = atomicCAS(a.ticket, cur, cur + 1u);
+                        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)old) == cur) { got = cur; rr = e; break; }
                         continue;
                     }
-                    if (__atomic_load_n(a.follow_done, __ATOMIC_RELAXED) && __atomic_load_n(a.n_list, __ATOMIC_RELAXED) <= __atomic_load_n(a.ticket, __ATOMIC_RELAXED)) break;
-                    __builtin_amdgcn_s_sleep(127);
+                    __builtin_amdgcn_s_sleep(8);
+                    continue;
                 }
-                __threadfence();
+                if (ld(a.follow_done) && ld(a.n_list) <= ld(a.ticket)) break;
+                __builtin_amdgcn_s_sleep(127);
             }
+            __threadfence();
             t = (uint32_t)__builtin_amdgcn_readfirstlane((int)got); r = (uint32_t)__builtin_amdgcn_readfirstlane((int)rr);
             if (t == ~0u || r == ~0u) break;
         } else {
@@ -3288,6 +3304,7 @@ struct sh_ctx {
     const uint32_t *dbg_ptr[3] = {}; uint32_t dbg_n[3] = {};
     // long-read presets: per read of the LAST CALL, the rarer paths of the extension stage it took (LK_* bits; sh_ctx_debug_list 3 .. 10)
     uint8_t *d_lkind = nullptr; uint64_t lkind_cap = 0, lkind_n = 0, lkind_r0 = 0;
+    uint8_t *d_coop = nullptr;      // queue, counters and descriptors of lr_coop_fill (long-read presets, allocated on first use)
     // the same stage for the long-read presets (sh_long.h): per-wave working memory in two sizes
     bool ext_long = false;
     LongParams LP{};
@@ -3357,6 +3374,9 @@ static void fill_long_params(const sh_opts &o, int32_t mid_occ, LongParams &L)
     // A read whose inner RMQ window (1000 reference bases) holds more than the 4096-anchor ring (5-bp satellite lattices: 23 of the bench's 2 M
     // reads) can only be chained by the literal one-lane trees over node pools in HBM - 10 to 25 s of one wave per read, measured.  Off by
     // default: such reads are counted (sh_stats.n_ext_unresolved) and keep their chain-level answer; SCRUBBY_HIP_RMQ_ONE_LANE=1 chains them.
+    L.coop_min = LR_COOP_MIN; L.coop_run = LR_COOP_RUN; L.coop_check = getenv("SCRUBBY_HIP_COOP_CHECK") ? 1 : 0;
+    if (const char *env = getenv("SCRUBBY_HIP_COOP_MIN")) L.coop_min = std::max(1, atoi(env));
+    if (const char *env = getenv("SCRUBBY_HIP_COOP_RUN")) L.coop_run = std::max(2, atoi(env));
     L.rmq_one_lane = 0;
     if (const char *env = getenv("SCRUBBY_HIP_RMQ_ONE_LANE")) L.rmq_one_lane = atoi(env) != 0;
 }
@@ -3682,7 +3702,7 @@ extern "C" sh_status sh_ctx_destroy(sh_ctx *c)
     hipFree(c->d_work_defer); hipFree(c->d_work_defer2);
     for (auto &pp : c->d_big) for (auto p : pp) hipFree(p);
     hipFree(c->d_ctr); if (c->h_ctr) hipHostFree(c->h_ctr); hipFree(c->d_arena); hipFree(c->d_long);
-    hipFree(c->d_ext); hipFree(c->d_ext_scratch); for (auto q : c->d_lext) hipFree(q); hipFree(c->d_lext_big); hipFree(c->d_lext_big2); hipFree(c->d_lext_sorted); for (auto q : c->d_lext_unres) hipFree(q); hipFree(c->d_lext_exact_list); hipFree(c->d_lext_exact_list2); hipFree(c->d_lext_esorted); for (auto q : c->d_lext_exact) hipFree(q); hipFree(c->d_larena); hipFree(c->d_lhdr); for (auto q : c->d_locus) hipFree(q); hipFree(c->d_lr_drop); hipFree(c->d_lr_fb); hipFree(c->d_stage_x); hipFree(c->d_stage_q); hipFree(c->d_lkind);
+    hipFree(c->d_ext); hipFree(c->d_ext_scratch); for (auto q : c->d_lext) hipFree(q); hipFree(c->d_lext_big); hipFree(c->d_lext_big2); hipFree(c->d_lext_sorted); for (auto q : c->d_lext_unres) hipFree(q); hipFree(c->d_lext_exact_list); hipFree(c->d_lext_exact_list2); hipFree(c->d_lext_esorted); for (auto q : c->d_lext_exact) hipFree(q); hipFree(c->d_larena); hipFree(c->d_lhdr); for (auto q : c->d_locus) hipFree(q); hipFree(c->d_lr_drop); hipFree(c->d_lr_fb); hipFree(c->d_stage_x); hipFree(c->d_stage_q); hipFree(c->d_lkind); hipFree(c->d_coop);
     for (auto ev : c->ev_ext) if (ev) hipEventDestroy(ev);
     for (auto ev : c->ev) if (ev) hipEventDestroy(ev);
     for (auto ev : c->evx) if (ev) hipEventDestroy(ev);
@@ -4121,6 +4141,21 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
         };
         // One round of the stage: round 0 over every read with a chain; round 1 - flag-only calls whose anchors k_lr_locus thinned out - over the
         // reads whose answer could depend on what was left out, after the repeat path has chained them again with every anchor
+        // lr_coop_fill's queue, counters and descriptors for one launch of an EXACT instance (three regions: the giants, E2a, E1 - launches that
+        // may run side by side); zeroed on the launch's stream
+        static const bool coop = !getenv("SCRUBBY_HIP_GIANTS_PLAIN") && !getenv("SCRUBBY_HIP_NO_COOP");
+        auto coop_setup = [&](ExtLongArgs &xx, int which, hipStream_t st, uint32_t n_blocks) -> sh_status {
+            constexpr uint32_t QCAP = 65536, NDESC = 512;
+            constexpr size_t off_desc = 256, off_ready = off_desc + NDESC * sizeof(LongCoopDesc), off_items = off_ready + QCAP * 4, region = off_items + QCAP * 16;
+            static_assert(sizeof(LongCoopDesc) % 8 == 0 && off_items % 16 == 0 && region % 256 == 0, "coop layout");
+            if (!c->d_coop) SH_HIP(hipMalloc(&c->d_coop, 3 * region));
+            uint8_t *base = c->d_coop + (size_t)which * region;
+            SH_HIP(hipMemsetAsync(base, 0, off_items, st));
+            xx.coop.q_res = (uint32_t *)base; xx.coop.q_head = (uint32_t *)(base + 64); xx.coop.active = (uint32_t *)(base + 128); xx.coop.n_reads = (uint32_t *)(base + 192);
+            xx.coop.desc = (LongCoopDesc *)(base + off_desc); xx.coop.ready = (uint32_t *)(base + off_ready); xx.coop.items = (uint4 *)(base + off_items);
+            xx.coop.cap = QCAP; xx.coop_on = n_blocks <= NDESC;
+            return SH_OK;
+        };
         auto ext_round = [&](int round) -> sh_status {
             SH_HIP(hipMemsetAsync(&c->d_ctr->arena_cursor, 0, 8, s));
             {
@@ -4163,6 +4198,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 // (the giants on the EXACT instance at once: the tree is only kept over the stretches that ask it, lr_rmq_fill - a giant with a tie
                 // is not chained twice, and the exact passes lose their longest reads)
                 static const bool giants_exact = !getenv("SCRUBBY_HIP_GIANTS_PLAIN");
+                if (coop) { sh_status cs = coop_setup(xg, 0, sg, g_waves); if (cs != SH_OK) return cs; }      // the giants' waves share the long join of the launch's largest reads (lr_coop_fill, sh_long.h)
                 if (giants_exact) hipLaunchKernelGGL((k_long_chains<4096, true, false>), dim3(g_waves), dim3(64), 0, sg, xg);
                 else hipLaunchKernelGGL((k_long_chains<4096, false, false>), dim3(g_waves), dim3(64), 0, sg, xg);
                 SH_HIP(hipEventRecord(c->evx[1], sg));
@@ -4170,6 +4206,11 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                 hipLaunchKernelGGL((k_long_chains<512, false, false>), dim3(m_waves), dim3(64), 0, s, xa);
                 SH_HIP(hipStreamWaitEvent(s, c->evx[1], 0));
                 sh_status st = sync_ctr(); if (st != SH_OK) return st;
+                if (coop && getenv("SCRUBBY_HIP_DBG")) {
+                    uint32_t h[64] = {};
+                    SH_HIP(hipMemcpy(h, c->d_coop, sizeof(h), hipMemcpyDeviceToHost));
+                    fprintf(stderr, "[dbg] long join shared among the giants' waves: %u reads in %u runs (%u taken off the queue)\n", h[48], h[0], h[16]);
+                }
                 if (c->h_ctr->ext_overflow == 1) return SH_SPLIT;       // hand-over buffers or arena full: the caller cuts the chunk in two
                 if (c->h_ctr->lext_n_big > 0) {
                     xa.scratch = c->d_lext[1]; xa.scratch_per_wave = c->lext_per_wave[1]; xa.sz = c->lext_sz[1];
@@ -4210,6 +4251,7 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                     SH_HIP(hipMemsetAsync(&c->d_ctr->lext_started, 0, 4, s));
                     SH_HIP(hipEventRecord(c->evx[0], s));
                     SH_HIP(hipStreamWaitEvent(se, c->evx[0], 0));
+                    if (coop) { sh_status cs = coop_setup(x2, 1, se, w2); if (cs != SH_OK) return cs; }
                     hipLaunchKernelGGL((k_long_chains<4096, true, false>), dim3(w2), dim3(64), 0, se, x2);
                     SH_HIP(hipEventRecord(c->evx[1], se));
                     hipLaunchKernelGGL(k_wait_started, dim3(1), dim3(64), 0, s, (const uint32_t *)&c->d_ctr->lext_started, w2, 2000u);
@@ -4223,7 +4265,10 @@ static sh_status classify_chunk(sh_ctx *c, const uint8_t *d_bases, const uint64_
                     hipLaunchKernelGGL(k_lext_scatter, dim3(64), dim3(256), 0, s, c->d_lext_exact_list, &c->d_ctr->lext_n_exact, c->d_ext_redo, c->d_ctr->lext_hist, c->d_lext_esorted);
                     xe.list = c->d_lext_esorted; xe.n_list = &c->d_ctr->lext_n_exact; xe.ticket = &c->d_ctr->lext_ticket_exact;
                     xe.big_list = c->d_lext_big; xe.n_big = &c->d_ctr->lext_n_big; xe.unres_list = nullptr; xe.n_unres = nullptr;
-                    hipLaunchKernelGGL((k_long_chains<1024, true, false>), dim3(std::min<uint32_t>({c->lext_waves[0], 2u * (uint32_t)c->n_cu, n_e1})), dim3(64), 0, s, xe);
+                    const uint32_t w1 = std::min<uint32_t>({c->lext_waves[0], 2u * (uint32_t)c->n_cu, n_e1});
+                    ExtLongArgs x1 = xe;
+                    if (coop) { sh_status cs = coop_setup(x1, 2, s, w1); if (cs != SH_OK) return cs; }
+                    hipLaunchKernelGGL((k_long_chains<1024, true, false>), dim3(w1), dim3(64), 0, s, x1);
                 }
                 if (n_e2a > 0) SH_HIP(hipStreamWaitEvent(s, c->evx[1], 0));
                 sh_status st = sync_ctr(); if (st != SH_OK) return st;

@@ -42,6 +42,8 @@ struct LongParams {
     float pri_ratio, mask_level, max_clip_ratio;
     int32_t max_skip, rmq_inner_dist, rmq_size_cap, rmq_rescue_size;
     int32_t rmq_exact_max;          // reads of up to this many chain anchors take the literal tree when the long join meets a tie that matters (-1: all)
+    int32_t coop_check;             // (debugging, SCRUBBY_HIP_COOP_CHECK) lr_coop_fill joins the read once more in one piece and reports the first anchor that differs
+    int32_t coop_min, coop_run;     // lr_coop_fill: joins of coop_min anchors and more are shared among the launch's waves in runs of coop_run anchors and more
     int32_t rmq_one_lane;           // reads whose windows outgrow the 4096-anchor ring / the LDS tree take the one-lane trees (seconds per read) instead of being counted unresolved
     float rmq_rescue_ratio, pen_gap, pen_skip;
     int32_t mid_occ, max_max_occ, occ_dist;
@@ -285,8 +287,10 @@ __device__ inline double lr_cc_f64(const double *p) { return __longlong_as_doubl
 template <int LRQ_INNER, bool TREE, bool FAT = false>
 __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int32_t bw, int32_t n, const LAnchor *a, int32_t *f, int32_t *p,
                                    double *pri, double *bmin /* n / 64 + 1 */, RmqLdsT<LRQ_INNER, FAT> &L, int32_t &n_tie, LongClk *dbg = nullptr,
-                                   RqLds TL = RqLds{})
+                                   RqLds TL = RqLds{}, int32_t p_base = 0)
 {
+    // (p_base: a[] is a stretch of a longer array that starts where the look-back window is empty - lr_coop - and p is stored as an index
+    // into that array)
     // TREE: the main tree in LDS (sh_rmq_tree.h, RqLds): it holds the anchors of the look-back window only - max_dist reference bases - and is
     // walked by lane 0; a window that outgrows its nodes ends the call (ok = false), like a window that outgrows the ring
     RqTreeT<RqLds> T0;
@@ -385,7 +389,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 if (lane == 0) { bmin[blk_done] = m; L.pml[blk_done & 63] = pm; L.bml[blk_done & 63] = m; }
                 {   // the block leaves for HBM in one piece (a store inside the loop would make every later wait of the step wait for it too)
                     const int32_t j = blk_done * 64 + lane;
-                    f[j] = L.rf[j & M]; p[j] = L.rp[j & M]; pri[j] = rpri_of(j);
+                    f[j] = L.rf[j & M]; p[j] = L.rp[j & M] < 0 ? -1 : L.rp[j & M] + p_base; pri[j] = rpri_of(j);
                 }
                 __builtin_amdgcn_wave_barrier();
                 ++blk_done;
@@ -469,7 +473,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 bool in = false; double pj = 0.0;
                 if (cand) {
                     const int32_t yj = L.ry[j & M];
-                    in = yj > qi - max_dist && (yj < qi || (yj == qi && j == 0));
+                    in = yj > qi - max_dist && (yj < qi || (yj == qi && j + p_base == 0));      // (upstream's bound is the key (q_i, 0): index 0 of the WHOLE array)
                     if (in) pj = rpri_of(j);
                 }
                 reduce(in, pj, j);
@@ -520,7 +524,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             if (jv[q] < 0) continue;      // (uniform: jv is -1 on every lane or on none)
-                            const bool in = jv[q] >= st && yv[q] > qi - max_dist && (yv[q] < qi || (yv[q] == qi && jv[q] == 0));
+                            const bool in = jv[q] >= st && yv[q] > qi - max_dist && (yv[q] < qi || (yv[q] == qi && jv[q] + p_base == 0));
                             reduce(in, pv[q], jv[q]);
                             ++d_old;
                         }
@@ -559,7 +563,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 if (dbg) dbg->tie_seg_a += (unsigned long long)(i - seg_i);      // anchors replayed
             }
             int32_t tj = -1;
-            if (lane == 0) { const int32_t q = rq_rmq(T0, qi - max_dist, INT32_MAX, qi, 0); tj = q != RQ_NIL ? rq_i(T0, q) : -1; }
+            if (lane == 0) { const int32_t q = rq_rmq(T0, qi - max_dist, INT32_MAX, qi, -p_base); tj = q != RQ_NIL ? rq_i(T0, q) : -1; }
             tj = al_b0(tj);
             if (tj >= 0) bj = tj;
             ++tie_cnt;
@@ -579,7 +583,7 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
                 if (j >= st && j < i0) {
                     const bool near = i - j < LRQ_INNER - 64;
                     const int32_t yj = near ? L.ry[j & M] : (int32_t)a[j].y;
-                    if (yj > qi - max_dist && (yj < qi || (yj == qi && j == 0))) {
+                    if (yj > qi - max_dist && (yj < qi || (yj == qi && j + p_base == 0))) {
                         const double pj = near ? rpri_of(j) : lr_cc_f64(pri + j);
                         if (pj == bp) {
                             tied = true;
@@ -686,9 +690,146 @@ __device__ inline bool lr_rmq_fill(const LongParams &P, int32_t max_dist_in, int
     if (TREE && dbg) ++dbg->n_seg;
     if (TREE && T0.bad) ok = false;
     n_tie = tie_cnt;
-    if (ok) for (int32_t j = blk_done * 64 + lane; j < n; j += 64) { f[j] = L.rf[j & M]; p[j] = L.rp[j & M]; }      // the last, incomplete block(s)
+    if (ok) for (int32_t j = blk_done * 64 + lane; j < n; j += 64) { f[j] = L.rf[j & M]; p[j] = L.rp[j & M] < 0 ? -1 : L.rp[j & M] + p_base; }      // the last, incomplete block(s)
     if (dbg) for (int k2 = 0; k2 < 5; ++k2) dbg->t[4 + k2] += pt[k2];
     if (dbg) { dbg->d[0] += (unsigned long long)n; dbg->d[1] += d_ring; dbg->d[2] += d_oldsteps; dbg->d[3] += d_old; dbg->d[4] += d_nin; dbg->d[5] += d_chunks; dbg->d[6] += 1; if ((unsigned long long)n > dbg->d[7]) dbg->d[7] = (unsigned long long)n; }
+    return ok;
+}
+
+// ---- the long join of one read by several waves ----------------------------------------------------------------------------------------------
+// Where the look-back window is empty - the reference position jumps by more than max_dist, or to another strand / contig - nothing before
+// that anchor can be a predecessor and upstream's tree is empty: the stretches between such anchors are independent problems (f, p and the
+// tree's answers of one do not depend on another).  A read of 10^5 anchors has some twenty of them, and it is one wave's work for a second
+// and more while the launch's other waves have long finished: the wave that owns the read cuts the x-sorted anchors into runs of whole
+// stretches (LR_COOP_RUN anchors and more), puts them on a queue of the launch, and every wave of the launch that has nothing else to do
+// takes runs off it - its own LDS ring and tree, the owner's arrays in HBM.  The owner works the queue too (whoever's run is at its head), so
+// nothing ever waits for another wave to turn up; it goes on to the backtrack when its count of open runs is zero.
+#define LR_COOP_RUN 3072       // (defaults of LongParams::coop_run / coop_min; SCRUBBY_HIP_COOP_RUN / _MIN: the tests share joins of a few hundred anchors)
+#define LR_COOP_MIN 12288      // reads with fewer anchors in the join stay with their wave
+struct LongCoopDesc { const LAnchor *a; int32_t *f, *p; double *pri, *bmin; int32_t remaining, n_tie, fail, pad; };      // one per block of the launch: the read it owns
+struct LongCoop {
+    uint4 *items;                   // {owner block, first anchor, end, offset into bmin}
+    uint32_t *ready;                // per slot: 1 once the item is written (preset to 0)
+    uint32_t *q_res, *q_head;       // slots handed out to producers / taken by consumers
+    uint32_t *active;               // owners with runs open
+    uint32_t *n_reads;              // reads whose join was shared (statistics)
+    LongCoopDesc *desc;
+    uint32_t cap;
+};
+// one run off the queue, if its item is there: true = a run was worked on
+template <int NR, bool FAT>
+__device__ inline bool lr_coop_take(const LongParams &P, const LongCoop &Q, RmqLdsT<NR, FAT> &RL, RqLds TL)
+{
+    const int32_t lane = (int32_t)al_lane();
+    // (every branch on a value all lanes hold - the lanes load the same words, one lane swaps.  A loop with breaks inside `if (lane == 0)` left the
+    // code behind it running on that one lane in some of its inlined copies: measured, __ballot(1) == 1 in 3 of 15 calls)
+    uint32_t got = ~0u;
+    for (int looks = 0; looks < 64; ++looks) {
+        const uint32_t cur = (uint32_t)al_b0((int32_t)cc_u32(Q.q_head));
+        if (cur >= Q.cap || cur >= (uint32_t)al_b0((int32_t)cc_u32(Q.q_res))) break;
+        if (al_b0((int32_t)cc_u32(Q.ready + cur)) == 0) { __builtin_amdgcn_s_sleep(4); continue; }      // handed out, not yet written
+        uint32_t old = ~0u;
+        if (lane == 0) old = atomicCAS(Q.q_head, cur, cur + 1u);
+        if ((uint32_t)al_b0((int32_t)old) == cur) { got = cur; break; }
+    }
+    if (got == ~0u) return false;
+    __threadfence();      // (acquire: the item, the owner's descriptor and anchors)
+    const uint64_t i01 = cc_u64(Q.items + got), i23 = cc_u64((const uint64_t *)(Q.items + got) + 1);
+    const uint32_t owner = (uint32_t)i01; const int32_t j0 = (int32_t)(i01 >> 32), j1 = (int32_t)(uint32_t)i23; const uint32_t boff = (uint32_t)(i23 >> 32);
+    LongCoopDesc *D = Q.desc + owner;
+    const LAnchor *a = (const LAnchor *)cc_u64(&D->a);
+    int32_t *f = (int32_t *)cc_u64(&D->f), *pp = (int32_t *)cc_u64(&D->p);
+    double *pri = (double *)cc_u64(&D->pri), *bmin = (double *)cc_u64(&D->bmin);
+    int32_t tie = 0;
+    const bool ok = lr_rmq_fill<NR, true, FAT>(P, P.max_gap, P.bw_long, j1 - j0, a + j0, f + j0, pp + j0, pri + j0, bmin + boff, RL, tie, nullptr, TL, j0);
+    __threadfence();      // (release: f, p)
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        if (!ok) atomicExch(&D->fail, 1);
+        if (tie) atomicAdd(&D->n_tie, tie);
+        __threadfence();
+        atomicSub(&D->remaining, 1);
+    }
+    return true;
+}
+// the owner's side: the join of a[0 .. n) by whoever is free.  tmp: n int32 (the cuts).  false = a run failed (ring / tree outgrown)
+template <int NR, bool FAT>
+__device__ inline bool lr_coop_fill(const LongParams &P, const LongCoop &Q, uint32_t me, int32_t n, const LAnchor *a, int32_t *f, int32_t *p, double *pri, double *bmin,
+                                    int32_t *tmp, RmqLdsT<NR, FAT> &RL, RqLds TL, int32_t &n_tie, int32_t *chk_f = nullptr, int32_t *chk_p = nullptr, double *chk_pri = nullptr, double *chk_bmin = nullptr)
+{
+    const int32_t lane = (int32_t)al_lane();
+    int32_t max_dist = P.max_gap; if (max_dist < P.bw_long) max_dist = P.bw_long;
+    // cuts: anchors that start a stretch (the window is empty when the scan reaches them), thinned to runs of LR_COOP_RUN anchors and more
+    int32_t n_cut = 0;
+    for (int32_t b = 0; b < n; b += 64) {
+        const int32_t j = b + lane;
+        bool c = false;
+        if (j > 0 && j < n) { const uint64_t x1 = a[j].x, x0 = a[j - 1].x; c = (uint32_t)(x1 >> 32) != (uint32_t)(x0 >> 32) || x1 > x0 + (uint64_t)max_dist; }
+        const uint64_t m = __ballot(c);
+        if (c) tmp[n_cut + (int32_t)prefix_popc64(m)] = j;
+        n_cut += (int32_t)__popcll(m);
+    }
+    lr_sync();
+    LongCoopDesc *D = Q.desc + me;
+    int32_t n_items = 0;
+    uint32_t slot0 = 0;
+    if (lane == 0) {
+        int32_t k = 0, last = 0;
+        for (int32_t c = 0; c < n_cut; ++c) { const int32_t j = (int32_t)cc_u32(tmp + c); if (j - last >= P.coop_run && n - j >= P.coop_run / 2) { tmp[k++] = j; last = j; } }
+        n_items = k + 1;
+        D->a = a; D->f = f; D->p = p; D->pri = pri; D->bmin = bmin; D->n_tie = 0; D->fail = 0;
+        __hip_atomic_store(&D->remaining, n_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();      // (release: the descriptor and the anchors, before any slot is handed out)
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { slot0 = atomicAdd(Q.q_res, (uint32_t)n_items); atomicAdd(Q.active, 1u); atomicAdd(Q.n_reads, 1u); }
+    n_items = al_b0(n_items); slot0 = (uint32_t)al_b0((int32_t)slot0);
+    lr_sync();
+    // the items: run i = [cut[i-1], cut[i]) with cut[-1] = 0 and cut[n_items-1] = n.  What finds no slot stays with this wave
+    bool ok = true;
+    int32_t tie_own = 0, n_local = 0;
+    for (int32_t i = 0; i < n_items; ++i) {
+        const int32_t j0 = i == 0 ? 0 : (int32_t)cc_u32(tmp + i - 1), j1 = i == n_items - 1 ? n : (int32_t)cc_u32(tmp + i);
+        const uint32_t slot = slot0 + (uint32_t)i, boff = (uint32_t)(j0 / 64 + i);
+        if (slot < Q.cap) {
+            if (lane == 0) {
+                uint64_t *it = (uint64_t *)(Q.items + slot);
+                it[0] = (uint64_t)me | (uint64_t)(uint32_t)j0 << 32; it[1] = (uint64_t)(uint32_t)j1 | (uint64_t)boff << 32;
+                __threadfence();
+                __hip_atomic_store(Q.ready + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            int32_t tie = 0;
+            if (ok && !lr_rmq_fill<NR, true, FAT>(P, P.max_gap, P.bw_long, j1 - j0, a + j0, f + j0, p + j0, pri + j0, bmin + boff, RL, tie, nullptr, TL, j0)) ok = false;
+            tie_own += tie; ++n_local;
+        }
+    }
+    if (n_local && lane == 0) atomicSub(&D->remaining, n_local);
+    // work the queue until every run of this read is done
+    for (unsigned long long looks = 0;; ++looks) {
+        if (al_b0((int32_t)cc_u32(&D->remaining)) <= 0) break;
+        if (!lr_coop_take<NR, FAT>(P, Q, RL, TL)) __builtin_amdgcn_s_sleep(32);
+    }
+    __threadfence();      // (acquire: what the other waves wrote)
+    if (lane == 0) atomicSub(Q.active, 1u);
+    n_tie = tie_own + (int32_t)cc_u32(&D->n_tie);
+    if (cc_u32(&D->fail)) ok = false;
+    lr_sync();
+    if (P.coop_check && ok && chk_f) {
+        int32_t tie2 = 0;
+        const bool ok2 = lr_rmq_fill<NR, true, FAT>(P, P.max_gap, P.bw_long, n, a, chk_f, chk_p, chk_pri, chk_bmin, RL, tie2, nullptr, TL);
+        lr_sync();
+        int32_t first = n;
+        for (int32_t b = 0; b < n; b += 64) { const int32_t j = b + lane; const bool d = j < n && (f[j] != chk_f[j] || p[j] != chk_p[j]); const uint64_t m = __ballot(d); if (m) { first = b + (int32_t)__ffsll((unsigned long long)m) - 1; break; } }
+        if (lane == 0 && (first < n || !ok2)) {
+            int32_t run0 = 0, k = 0;
+            for (int32_t i = 0; i + 1 < n_items; ++i) { const int32_t c = (int32_t)cc_u32(tmp + i); if (c <= first) { run0 = c; k = i + 1; } }
+            printf("[coop-check] n %d items %d ok2 %d first diff at %d (run %d starts %d, offset %d): f %d vs %d, p %d vs %d; x %llx y %llx prev x %llx\n", n, n_items, (int)ok2, first, k, run0, first - run0,
+                   first < n ? f[first] : 0, first < n ? chk_f[first] : 0, first < n ? p[first] : 0, first < n ? chk_p[first] : 0,
+                   first < n ? (unsigned long long)a[first].x : 0ull, first < n ? (unsigned long long)a[first].y : 0ull, first > 0 && first < n ? (unsigned long long)a[first - 1].x : 0ull);
+        }
+        lr_sync();
+    }
     return ok;
 }
 
@@ -1220,6 +1361,7 @@ struct LongCtx {
     int32_t probe_why;               // why lr_probe_region last gave up (statistics)
     bool need_big;                   // an alignment does not fit this wave's direction-byte buffer: the read goes to the large-scratch pass
     uint32_t err;                    // a capacity of the working memory was exceeded (code)
+    const LongCoop *coop = nullptr; uint32_t coop_me = 0;      // the launch shares the long join of its largest reads among its waves (lr_coop_fill)
 };
 
 // mm_align_pair: false = the caller must stop (need_big / err set)
@@ -1845,7 +1987,10 @@ __device__ inline int32_t lr_chains_wave(LongCtx &C, RmqLdsT<NR, FAT> &RL, const
                 // the scan with upstream's main tree beside it (in LDS, asked at the ties).  What this instance's ring or tree cannot hold goes to
                 // the instance with the larger ones; beyond those, both trees on one lane over node pools in the wave's scratch (the launch that
                 // brings them: W.rq0)
-                if (!lr_rmq_fill<NR, true, FAT>(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie, C.clk, TL)) {
+                bool filled;
+                if (C.coop && n_a >= P.coop_min) filled = lr_coop_fill<NR, FAT>(P, *C.coop, C.coop_me, n_a, B0, W.f, W.p, W.pri, (double *)W.K, W.t, RL, TL, tie, W.v, (int32_t *)W.sk, (double *)W.sk2, (double *)W.sk + W.cap_a);
+                else filled = lr_rmq_fill<NR, true, FAT>(P, P.max_gap, P.bw_long, n_a, B0, W.f, W.p, W.pri, (double *)W.K, RL, tie, C.clk, TL);
+                if (!filled) {
                     if (NR < 4096) { C.err = 6; return 3; }
                     if (!P.rmq_one_lane) { C.err = 6; return 7; }      // beyond the large ring / the LDS tree: counted (sh_stats.n_ext_unresolved) unless the one-lane trees are asked for
                     if (!W.rq0) { C.err = 7; return 3; }

@@ -207,6 +207,44 @@ def test_ties_after_the_look_back_window_has_emptied(S, oracle):
     assert rc2 == 0 and np.array_equal(gf2, of) and st2["n_ext_unresolved"] == 0 and st2["n_rmq_tied"] > 0
 
 
+def test_the_long_join_of_one_read_shared_among_waves(S, oracle, monkeypatch, capfd):
+    """lr_coop_fill: the x-sorted anchors of a long join fall into stretches between which the look-back window is empty - independent
+    problems - and the waves of the giants' launch take runs of them off a queue.  With the first working-memory size made tiny nearly every
+    read is a giant, and with the thresholds at 256 / 64 anchors (the defaults: 12 288 / 3 072) every join of a few hundred anchors is cut
+    up: the 40 longest of 6 000 reads of the bench's generator and 20 chimeras of pairs of them (loci megabases apart), full trace and flags
+    against the oracle, which joins each read in one piece; the stage's debug line must say that joins were shared, in more runs than reads."""
+    for k, v in (("SCRUBBY_HIP_LEXT_A", "512"), ("SCRUBBY_HIP_COOP_MIN", "256"), ("SCRUBBY_HIP_COOP_RUN", "64"), ("SCRUBBY_HIP_CTX_CACHE", "0"), ("SCRUBBY_HIP_DBG", "16")):
+        monkeypatch.setenv(k, v)
+    Po = oracle.ref_params(0x5C2B0010, [1_000_000] * 5)
+    Ro = oracle.read_params(0x5C2B0020, read_len=0, host_pct=100, sub_per_10k=200, n_read_pct=1)
+    cpu, offs = oracle.synth_long_reads(Po, Ro, 3, 6000)
+    seqs = [oracle.synth_ref(Po, Po.contig_start[i], 1_000_000) for i in range(5)]
+    gidx = S.Index.build([bytes(s) for s in seqs], S.preset("map-ont"))
+    ln = np.diff(offs.astype(np.int64))
+    big = np.argsort(-ln)[:40]                                               # the longest reads, and chimeras of pairs of them
+    rd = lambda r: np.asarray(cpu[int(offs[r]):int(offs[r + 1])])
+    comp = np.zeros(256, np.uint8); comp[:] = np.arange(256); comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    recs = [rd(r) for r in big]
+    for a, b in zip(big[:20], big[20:]):
+        recs.append(np.concatenate([rd(a), comp[rd(b)][::-1]]))
+    bases = np.concatenate(recs).astype(np.uint8)
+    co = np.zeros(len(recs) + 1, np.uint64); co[1:] = np.cumsum([len(x) for x in recs])
+    cidx = oracle.Index.build(seqs, 10, 15)
+    oo = cidx.update_opts(oracle.preset("map-ont"))
+    capfd.readouterr()
+    gf, gt, st, rc = gidx.classify(bases, co, want_trace=True)
+    err = capfd.readouterr().err
+    of, ot = cidx.classify(oo, bases, co, threads=16)
+    assert rc == 0 and st["n_ext_unresolved"] == 0
+    assert_same(S, gf, gt, of, ot)
+    shared = [ln_ for ln_ in err.splitlines() if "long join shared" in ln_]
+    print(shared[-1] if shared else "no line")
+    n_reads, n_runs = (int(x) for x in __import__("re").search(r"(\d+) reads in (\d+) runs", shared[0]).groups())
+    assert n_reads > 10 and n_runs > n_reads, shared
+    gf2, _, st2, rc2 = gidx.classify(bases, co, want_trace=False)
+    assert rc2 == 0 and np.array_equal(gf2, of)
+
+
 def test_windows_beyond_the_large_ring_are_counted_or_take_the_one_lane_trees(S, oracle, monkeypatch):
     """A read whose long join holds more anchors within rmq_inner_dist than the 4096-anchor ring (LC.dense_lattice_case: ~10^4 lattice anchors
     over one kilobase) cannot be chained by the wave scan.  By default it keeps its chain-level answer and is COUNTED (n_ext_unresolved, and
