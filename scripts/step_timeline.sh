@@ -11,10 +11,12 @@ for once in 1; do
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-ks = [i for i, r in enumerate(rows) if "k_sketch_probe" in r["Kernel_Name"]]
+ks = [i for i, r in enumerate(rows) if "k_sketch_probe" in r["Kernel_Name"] or "k_long_sketch" in r["Kernel_Name"]]
 dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-big = [i for i in ks if dur(rows[i]) > 1000000]      # the timed steps' sketches
-i0 = big[-1]; i1 = min([i for i in ks if i > i0] + [len(rows)])
+big = [i for i in ks if dur(rows[i]) > 1000000]      # the timed launches' sketches (long reads: two kernels a launch, milliseconds apart)
+i0 = big[-1]
+while i0 - 1 in big or (big.index(i0) > 0 and int(rows[i0]["Start_Timestamp"]) - int(rows[big[big.index(i0) - 1]]["End_Timestamp"]) < 5000000): i0 = big[big.index(i0) - 1]
+i1 = min([i for i in ks if i > i0 and int(rows[i]["Start_Timestamp"]) - int(rows[i0]["End_Timestamp"]) > 50000000] + [len(rows)])
 t0 = int(rows[i0]["Start_Timestamp"])
 with open(sys.argv[2], "w") as f:
     for r in rows[i0:i1]:
