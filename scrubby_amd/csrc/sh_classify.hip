@@ -3161,9 +3161,9 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
     }
     if constexpr (EXACT) {
         if (a.coop_on) {      // no read left for this wave: runs of the reads the others still join (lr_coop_fill), while there are any
-            for (;;) {
-                if (lr_coop_take<NR, FAT>(P_l, coop_l, RL, TL)) continue;
-                if (al_b0((int32_t)cc_u32(coop_l.active)) == 0) break;
+            for (unsigned long long idle = 0;;) {
+                if (lr_coop_take<NR, FAT>(P_l, coop_l, RL, TL)) { idle = 0; continue; }
+                if (al_b0((int32_t)cc_u32(coop_l.active)) == 0 || ++idle > 20000000ull) break;      // (bounded: about a minute of idle looks)
                 __builtin_amdgcn_s_sleep(64);
             }
         }

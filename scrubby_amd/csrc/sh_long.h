@@ -806,9 +806,12 @@ __device__ inline bool lr_coop_fill(const LongParams &P, const LongCoop &Q, uint
     }
     if (n_local && lane == 0) atomicSub(&D->remaining, n_local);
     // work the queue until every run of this read is done
-    for (unsigned long long looks = 0;; ++looks) {
+    // (idle looks are bounded - about a minute - like every wait of the stage: a kernel must end whatever happens; a read given up this way is counted unresolved)
+    for (unsigned long long idle = 0;;) {
         if (al_b0((int32_t)cc_u32(&D->remaining)) <= 0) break;
-        if (!lr_coop_take<NR, FAT>(P, Q, RL, TL)) __builtin_amdgcn_s_sleep(32);
+        if (lr_coop_take<NR, FAT>(P, Q, RL, TL)) { idle = 0; continue; }
+        if (++idle > 30000000ull) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(32);
     }
     __threadfence();      // (acquire: what the other waves wrote)
     if (lane == 0) atomicSub(Q.active, 1u);
