@@ -137,7 +137,7 @@ extern "C" sh_status sh_classify_batch(const sh_index *idx, const sh_opts *opts,
     const uint64_t need_reads = std::min(CH, n_reads);
     std::string env_sig;
     for (const char *v : {"SCRUBBY_HIP_ARENA_MB", "SCRUBBY_HIP_NO_FLAG_STOP", "SCRUBBY_HIP_NO_PAIR", "SCRUBBY_HIP_PAIR_MIN", "SCRUBBY_HIP_NO_S1", "SCRUBBY_HIP_EXT_MB", "SCRUBBY_HIP_EXT_REGCAP", "SCRUBBY_HIP_NO_LEMMA",
-                          "SCRUBBY_HIP_LEXT_A", "SCRUBBY_HIP_LEXT_BIG_A", "SCRUBBY_HIP_LEXT_P_KB", "SCRUBBY_HIP_RMQ_EXACT_MAX", "SCRUBBY_HIP_RMQ_ONE_LANE", "SCRUBBY_HIP_COOP_MIN", "SCRUBBY_HIP_COOP_RUN", "SCRUBBY_HIP_LEXT_BIG_P_KB", "SCRUBBY_HIP_STAGE_MB", "SCRUBBY_HIP_STREAMS"}) { const char *e = getenv(v); env_sig += e ? e : "-"; env_sig += '|'; }
+                          "SCRUBBY_HIP_LEXT_A", "SCRUBBY_HIP_LEXT_BIG_A", "SCRUBBY_HIP_LEXT_P_KB", "SCRUBBY_HIP_RMQ_EXACT_MAX", "SCRUBBY_HIP_RMQ_ONE_LANE", "SCRUBBY_HIP_COOP_MIN", "SCRUBBY_HIP_COOP_RUN", "SCRUBBY_HIP_E2_JOIN_MIN", "SCRUBBY_HIP_LEXT_BIG_P_KB", "SCRUBBY_HIP_STAGE_MB", "SCRUBBY_HIP_STREAMS"}) { const char *e = getenv(v); env_sig += e ? e : "-"; env_sig += '|'; }
     const bool no_pool = false;
 
     BatchScratch *B = nullptr;

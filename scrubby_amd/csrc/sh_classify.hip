@@ -3143,8 +3143,8 @@ __global__ __launch_bounds__(64) void k_long_chains(ExtLongArgs a)
         }
         else if (rc == 6) {      // tied priorities / beyond the ring: the EXACT instance of this kernel takes the read
             if (lane == 0) {
-                // (a join of tens of thousands of anchors looks back over more of them than the small ring holds: every step would go to HBM)
-                if ((NR >= 4096 || o.n_join > 60000) && a.exact_list2) a.exact_list2[atomicAdd(a.n_exact2, 1u)] = r;
+                // (LongParams::e2_join_min: off by default)
+                if ((NR >= 4096 || o.n_join > P_l.e2_join_min) && a.exact_list2) a.exact_list2[atomicAdd(a.n_exact2, 1u)] = r;
                 else a.exact_list[atomicAdd(a.n_exact, 1u)] = r;
                 lk_mark(a, r, LK_EXACT);
                 LongHdr h{0ull, -1, 0, 0, 0}; AR_l.hdr[r] = h;
@@ -3374,6 +3374,8 @@ static void fill_long_params(const sh_opts &o, int32_t mid_occ, LongParams &L)
     // A read whose inner RMQ window (1000 reference bases) holds more than the 4096-anchor ring (5-bp satellite lattices: 23 of the bench's 2 M
     // reads) can only be chained by the literal one-lane trees over node pools in HBM - 10 to 25 s of one wave per read, measured.  Off by
     // default: such reads are counted (sh_stats.n_ext_unresolved) and keep their chain-level answer; SCRUBBY_HIP_RMQ_ONE_LANE=1 chains them.
+    L.e2_join_min = INT32_MAX;      // (was 60 000 while the tree was kept for the whole read; with the join shared among waves the 1024-anchor ring's pass is the faster place: 8.35 -> 8.24 s per 2 M reads)
+    if (const char *env = getenv("SCRUBBY_HIP_E2_JOIN_MIN")) L.e2_join_min = atoi(env);
     L.coop_min = LR_COOP_MIN; L.coop_run = LR_COOP_RUN; L.coop_check = getenv("SCRUBBY_HIP_COOP_CHECK") ? 1 : 0;
     if (const char *env = getenv("SCRUBBY_HIP_COOP_MIN")) L.coop_min = std::max(1, atoi(env));
     if (const char *env = getenv("SCRUBBY_HIP_COOP_RUN")) L.coop_run = std::max(2, atoi(env));

@@ -42,6 +42,7 @@ struct LongParams {
     float pri_ratio, mask_level, max_clip_ratio;
     int32_t max_skip, rmq_inner_dist, rmq_size_cap, rmq_rescue_size;
     int32_t rmq_exact_max;          // reads of up to this many chain anchors take the literal tree when the long join meets a tie that matters (-1: all)
+    int32_t e2_join_min;            // exact passes: a read of the main grid whose join holds more anchors than this goes to the pass with the 4096-anchor ring (SCRUBBY_HIP_E2_JOIN_MIN; default: never)
     int32_t coop_check;             // (debugging, SCRUBBY_HIP_COOP_CHECK) lr_coop_fill joins the read once more in one piece and reports the first anchor that differs
     int32_t coop_min, coop_run;     // lr_coop_fill: joins of coop_min anchors and more are shared among the launch's waves in runs of coop_run anchors and more
     int32_t rmq_one_lane;           // reads whose windows outgrow the 4096-anchor ring / the LDS tree take the one-lane trees (seconds per read) instead of being counted unresolved
